@@ -1,0 +1,275 @@
+#!/usr/bin/env python3
+"""bench.py -- matvecs/s of y <- H x on the reference's Heisenberg chain (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--model heisenberg_chain_32] [--dtype f64|c128]
+
+One "step" = one full matrix-vector product (diagonal + off-diagonal, exchange included when N > 1)
+with sigma, x, y resident in HBM.  N == 1: the fused single-partition kernel on heisenberg_chain_32
+(601 080 390 states).  N > 1 (launched by torch.distributed.run, one rank per GPU): the same vector,
+hash-partitioned over the ranks (strong scaling), all-to-all-v over RCCL/xGMI.
+
+Prints ONE JSON line on rank 0 (contract in the task description) with two extra objects:
+  roofline      algorithmic HBM bytes per matvec / HIP-event time of the dominant kernel
+  cpu_baseline  oracle (C/OpenMP restatement of the reference's numLocales=1 algorithm) on the host
+                cores, bounded sample; N == 1 only.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def parse_model(name):
+    # heisenberg_chain_<L>[_symm]
+    parts = name.split("_")
+    assert parts[0] == "heisenberg" and parts[1] == "chain", "bench workloads are the reference's chain configs"
+    return int(parts[2]), len(parts) > 3 and parts[3] == "symm"
+
+
+def chain_nnz(L, n_states):
+    """exact number of off-diagonal non-zeros of the periodic chain in the half-filling sector:
+    each of the L bonds is anti-aligned in a fraction L / (2 (L - 1)) of the states."""
+    return n_states * L * L // (2 * (L - 1))
+
+
+def cpu_baseline(sample_L, threads=0, repeats=3):
+    """oracle ("port") timed on the host cores: heisenberg_chain_<sample_L>, full matvec."""
+    import numpy as np
+
+    from oracle import c_oracle as CO
+    from oracle import model as M
+
+    cfg = M.heisenberg_chain_config(sample_L)
+    o = CO.COracle(M.model_from_config(cfg))
+    reps = o.enumerate()
+    n = len(reps)
+    x = np.random.RandomState(42).rand(n) - 0.5
+    y = np.zeros(n)
+    cores = CO.lib().lso_num_threads() if threads <= 0 else threads
+    o.local_matvec(reps, x, y, num_threads=cores)  # warm-up
+    times = []
+    for _ in range(repeats):
+        t = time.perf_counter()
+        o.local_matvec(reps, x, y, num_threads=cores)
+        times.append(time.perf_counter() - t)
+    best = min(times)
+    return {"seconds_per_matvec": best, "n": n, "nnz": chain_nnz(sample_L, n), "cores": int(cores), "L": sample_L}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--model", default="heisenberg_chain_32")
+    ap.add_argument("--dtype", default="f64", choices=["f64", "c128"])
+    ap.add_argument("--mode", default=os.environ.get("LS_AMD_MODE", "auto"), choices=["auto", "push", "pull"])
+    ap.add_argument("--cpu-sample", type=int, default=28, help="chain length of the CPU-baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary (other dtype / other mode) measurements")
+    args = ap.parse_args()
+
+    import torch
+
+    import distributed_matvec_amd as D
+    from distributed_matvec_amd import config
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    L, symm = parse_model(args.model)
+    cfg = config.heisenberg_chain_config(L, symm=symm, spin_inversion=-1 if (L == 10 and not symm) else None)
+    basis, h = D.loadConfigFromDict(cfg, hamiltonian=True)
+    tdtype = torch.float64 if args.dtype == "f64" else torch.complex128
+    w = 8 if args.dtype == "f64" else 16
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    t_setup = time.perf_counter()
+    reps_parts, masks = D.enumerateStates(basis, world)
+    n_total = int(masks.numel())
+    my_reps = reps_parts[rank].clone() if world > 1 else reps_parts[0]
+    del reps_parts, masks
+    torch.cuda.empty_cache()
+    x = D.fillRandom(my_reps, 42, tdtype)
+    y = torch.zeros_like(x)
+
+    results = {}
+
+    def time_steps(run, steps, warmup):
+        for _ in range(warmup):
+            run()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            run()
+        barrier()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    nnz = chain_nnz(L, n_total) if not symm else None
+    kernel_ms = None
+    if world == 1:
+        plan = D.MatvecPlan(h, [my_reps], tdtype, mode=args.mode)
+        plan.enable_timing(4096)
+        setup_s = time.perf_counter() - t_setup
+
+        def run():
+            plan.matvec([x], [y], check=False)
+
+        for _ in range(args.warmup):
+            run()
+        plan.check()
+        plan.kernel_times_ms()  # drop warm-up samples
+        dt = time_steps(run, args.steps, 0)
+        plan.check()
+        samples = plan.kernel_times_ms()
+        launches_per_step = max(1, len(samples) // max(1, args.steps))
+        kernel_ms = sum(samples) / max(1, len(samples))  # average duration of ONE launch
+        kernel_name = plan.kernel
+        if symm:
+            nnz = plan.nnz
+        exchange_bytes = 0
+    else:
+        from distributed_matvec_amd.distributed import DistributedOperator
+
+        op = DistributedOperator(h, my_reps, tdtype)
+        op.engine.plan.enable_timing(4096)
+        setup_s = time.perf_counter() - t_setup
+
+        def run():
+            op.matvec(x, y, check=False)
+
+        for _ in range(args.warmup):
+            run()
+        op.engine.check()
+        op.engine.plan.kernel_times_ms()
+        dt = time_steps(run, args.steps, 0)
+        op.engine.check()
+        samples = op.engine.plan.kernel_times_ms()
+        launches_per_step = max(1, len(samples) // max(1, args.steps))
+        kernel_ms = sum(samples) / max(1, len(samples))
+        kernel_name = "tile"
+        t = torch.tensor([op.exchange_bytes_per_matvec], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t)
+        exchange_bytes = float(t.item())
+        if symm:
+            t = torch.tensor([op.engine.plan.nnz], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t)
+            nnz = int(t.item())
+
+    ms_per_step = 1e3 * dt / args.steps
+    value = args.steps / dt
+
+    # ALGORITHMIC bytes per matvec: N (8 + 2w) + nnz 2w  (compulsory traffic of the
+    # push formulation: read sigma_i, x_i, write y_i; read-modify-write y_j per non-zero)
+    b_alg = n_total * (8 + 2 * w) + nnz * 2 * w
+    # the dominant kernel does the per-nnz part and (pull / tile) the per-row part of this rank
+    rows_here = int(my_reps.numel())
+    nnz_here = nnz * rows_here // max(1, n_total)
+    if kernel_name == "direct-push":
+        bytes_per_launch = rows_here * (8 + w) + nnz_here * 2 * w  # diagonal pass (y write) is a separate kernel
+    else:
+        bytes_per_launch = (rows_here * (8 + 2 * w) + nnz_here * 2 * w) / launches_per_step
+    achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms else None
+    roofline = {
+        "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+        "frac": achieved / HBM_PEAK_GBPS if achieved else None, "traffic": None,
+        "kernel": kernel_name, "kernel_ms_avg": kernel_ms, "launches_per_step": launches_per_step,
+        "algorithmic_bytes_per_launch": bytes_per_launch,
+        "whole_matvec_GBps": b_alg / (dt / args.steps) / 1e9,
+        "whole_matvec_frac_of_Nx_peak": b_alg / (dt / args.steps) / 1e9 / (HBM_PEAK_GBPS * world),
+    }
+
+    extra = {}
+    if world == 1 and not args.no_extra:
+        # secondary numbers in the same run: the other scatter/gather mode and the other dtype
+        for label, dt2, mode2 in (("f64" if args.dtype == "c128" else "c128", None, args.mode),
+                                  (args.dtype, None, "pull" if kernel_name == "direct-push" else "push")):
+            try:
+                td = torch.float64 if label == "f64" else torch.complex128
+                x2 = D.fillRandom(my_reps, 42, td)
+                y2 = torch.zeros_like(x2)
+                p2 = D.MatvecPlan(h, [my_reps], td, mode=mode2)
+                t2 = time_steps(lambda: p2.matvec([x2], [y2], check=False), max(3, args.steps // 2), 2)
+                p2.check()
+                steps2 = max(3, args.steps // 2)
+                w2 = 8 if label == "f64" else 16
+                extra[f"{label}/{p2.kernel}"] = {
+                    "matvecs_per_s": steps2 / t2,
+                    "whole_matvec_GBps": (n_total * (8 + 2 * w2) + nnz * 2 * w2) / (t2 / steps2) / 1e9,
+                }
+                p2.destroy()
+                del x2, y2
+            except D.LsAmdError as e:  # e.g. pull on a non-Hermitian operator
+                extra[f"{label}/{mode2}"] = {"error": str(e)}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        s = cpu_baseline(min(args.cpu_sample, L))
+        # scale the measured per-non-zero cost of the sample to the benchmark workload
+        per_nnz = s["seconds_per_matvec"] / s["nnz"]
+        est = per_nnz * nnz
+        cpu = {
+            "value": 1.0 / est, "unit": "matvecs/s", "cores": s["cores"], "kind": "port",
+            "sample": f"heisenberg_chain_{s['L']} full matvec (f64, {s['n']} states, {s['nnz']} nnz) "
+                      f"{s['seconds_per_matvec']:.3f} s on {s['cores']} threads; per-nnz cost scaled to "
+                      f"{args.model} ({nnz} nnz)" if s["L"] != L else
+                      f"{args.model} full matvec, {s['seconds_per_matvec']:.3f} s on {s['cores']} threads",
+            "sample_seconds_per_matvec": s["seconds_per_matvec"],
+        }
+
+    if rank == 0:
+        out = {
+            "metric": "matvecs/sec", "value": value, "unit": "matvecs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {
+                "workload": f"{args.model}: y <- H x, {n_total} basis states, {nnz} off-diagonal non-zeros, "
+                            f"{args.dtype} vectors, sigma/x/y resident in HBM",
+                "model_yaml": f"data/{args.model}.yaml (regenerated: periodic ring, sigma.sigma per bond)",
+                "partitions": world, "partitioning": "hash64_01(sigma) % n_gpus" if world > 1 else "single",
+                "kernel": kernel_name, "x": "u(hash(sigma, 42)) - 0.5",
+                "exchange_bytes_per_matvec": exchange_bytes,
+            },
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "setup_seconds": setup_s,
+            "extra": extra,
+        }
+        if cpu:
+            out["gpu_over_cpu"] = value / cpu["value"]
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

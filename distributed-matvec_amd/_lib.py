@@ -1,0 +1,198 @@
+"""ctypes binding of libls_amd.so (C host side + HIP kernels).
+
+The library is the product: there is NO Python/NumPy/torch fallback for any compute entry point.
+If the shared object is missing, or no HIP device is visible when a device function is called,
+this module raises -- loudly -- instead of computing anything on the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libls_amd.so")
+
+c_u64p = C.POINTER(C.c_uint64)
+c_i64p = C.POINTER(C.c_int64)
+c_f64p = C.POINTER(C.c_double)
+c_intp = C.POINTER(C.c_int)
+
+
+class ChplExternalArray(C.Structure):
+    """chpl_external_array (/root/reference/src/FFI.chpl:36-55)."""
+
+    _fields_ = [("elts", C.c_void_p), ("num_elts", C.c_uint64), ("freer", C.c_void_p)]
+
+
+class LsHsBasis(C.Structure):
+    """Prefix of ls_hs_basis (/root/reference/src/FFI.chpl:94-105)."""
+
+    _fields_ = [
+        ("number_sites", C.c_int),
+        ("number_particles", C.c_int),
+        ("number_up", C.c_int),
+        ("particle_type", C.c_int),
+        ("spin_inversion", C.c_int),
+        ("state_index_is_identity", C.c_bool),
+        ("requires_projection", C.c_bool),
+        ("kernels", C.c_void_p),
+        ("representatives", ChplExternalArray),
+        ("ext", C.c_void_p),
+    ]
+
+
+class LsHsNonbranchingTerms(C.Structure):
+    _fields_ = [
+        ("number_terms", C.c_int),
+        ("number_bits", C.c_int),
+        ("v", C.c_void_p),
+        ("m", C.c_void_p),
+        ("l", C.c_void_p),
+        ("r", C.c_void_p),
+        ("x", C.c_void_p),
+        ("s", C.c_void_p),
+    ]
+
+
+class LsHsOperator(C.Structure):
+    """Prefix of ls_hs_operator (/root/reference/src/FFI.chpl:114-119)."""
+
+    _fields_ = [
+        ("basis", C.POINTER(LsHsBasis)),
+        ("off_diag_terms", C.POINTER(LsHsNonbranchingTerms)),
+        ("diag_terms", C.POINTER(LsHsNonbranchingTerms)),
+        ("ext", C.c_void_p),
+    ]
+
+
+class LsAmdError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LsAmdError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback."
+        )
+    L = C.CDLL(LIB_PATH)
+    bp, op = C.POINTER(LsHsBasis), C.POINTER(LsHsOperator)
+    vp = C.c_void_p
+    sigs = {
+        "ls_amd_last_error": (C.c_char_p, []),
+        "ls_amd_set_error_handler": (None, [vp]),
+        "ls_amd_device_count": (C.c_int, []),
+        "ls_amd_set_device": (C.c_int, [C.c_int]),
+        "ls_amd_malloc": (C.c_int, [C.POINTER(vp), C.c_size_t]),
+        "ls_amd_free": (C.c_int, [vp]),
+        "ls_amd_memcpy_h2d": (C.c_int, [vp, vp, C.c_size_t]),
+        "ls_amd_memcpy_d2h": (C.c_int, [vp, vp, C.c_size_t]),
+        "ls_amd_memcpy_d2d": (C.c_int, [vp, vp, C.c_size_t, vp]),
+        "ls_amd_memset": (C.c_int, [vp, C.c_int, C.c_size_t, vp]),
+        "ls_amd_synchronize": (C.c_int, [vp]),
+        "ls_amd_hash64_01": (C.c_uint64, [C.c_uint64]),
+        "ls_amd_locale_idx_of": (C.c_int, [C.c_uint64, C.c_int]),
+        "ls_amd_plan_create": (C.c_int, [C.POINTER(vp), op, C.c_int, C.c_int, C.c_int, C.POINTER(vp), c_i64p, C.c_int, C.c_int, vp]),
+        "ls_amd_plan_destroy": (None, [vp]),
+        "ls_amd_plan_num_rounds": (C.c_int, [vp]),
+        "ls_amd_plan_kernel_name": (C.c_char_p, [vp]),
+        "ls_amd_plan_send_counts": (C.c_int, [vp, C.c_int, c_i64p]),
+        "ls_amd_plan_packet_bytes": (C.c_int, [vp]),
+        "ls_amd_plan_nnz": (C.c_int64, [vp]),
+        "ls_amd_matvec": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), vp]),
+        "ls_amd_plan_check": (C.c_int, [vp, vp]),
+        "ls_amd_plan_enable_timing": (C.c_int, [vp, C.c_int]),
+        "ls_amd_plan_kernel_times": (C.c_int, [vp, C.POINTER(C.c_float), C.c_int, c_intp]),
+        "ls_amd_fill_random": (C.c_int, [C.c_int64, vp, C.c_uint64, C.c_int, vp, vp]),
+        "ls_amd_diag": (C.c_int, [vp, vp, vp, vp]),
+        "ls_amd_generate": (C.c_int, [vp, C.c_int, vp, vp, vp, vp]),
+        "ls_amd_scatter": (C.c_int, [vp, C.c_int64, vp, vp, vp, vp]),
+        "ls_amd_enumerate_states": (C.c_int, [bp, C.c_int, C.POINTER(vp), C.POINTER(vp), c_i64p, vp]),
+        "ls_amd_mask_counts": (C.c_int, [C.c_int64, vp, C.c_int, c_i64p, vp]),
+        "ls_amd_block_to_hashed": (C.c_int, [C.c_int64, vp, C.c_int, C.c_int, vp, C.POINTER(vp), vp]),
+        "ls_amd_hashed_to_block": (C.c_int, [C.c_int64, vp, C.c_int, C.c_int, C.POINTER(vp), vp, vp]),
+        "ls_amd_basis_group_order": (C.c_int, [bp]),
+        "ls_amd_basis_apply_group_element": (C.c_uint64, [bp, C.c_int, C.c_uint64]),
+        "ls_amd_basis_group_character": (C.c_int, [bp, C.c_int, c_f64p, c_f64p]),
+        "ls_hs_init": (None, []),
+        "ls_hs_exit": (None, []),
+        "ls_hs_create_spin_basis": (bp, [C.c_int, C.c_int, C.c_int, C.c_int, c_intp, c_intp]),
+        "ls_hs_clone_basis": (bp, [bp]),
+        "ls_hs_destroy_basis": (None, [bp]),
+        "ls_hs_create_operator_from_terms": (op, [bp, C.c_int, c_f64p, c_u64p, c_u64p, c_u64p, c_u64p]),
+        "ls_hs_clone_operator": (op, [op]),
+        "ls_hs_destroy_operator": (None, [op]),
+        "ls_hs_min_state_estimate": (C.c_uint64, [bp]),
+        "ls_hs_max_state_estimate": (C.c_uint64, [bp]),
+        "ls_hs_basis_number_bits": (C.c_int, [bp]),
+        "ls_hs_basis_number_words": (C.c_int, [bp]),
+        "ls_hs_basis_has_fixed_hamming_weight": (C.c_bool, [bp]),
+        "ls_hs_basis_has_spin_inversion_symmetry": (C.c_bool, [bp]),
+        "ls_hs_basis_has_permutation_symmetries": (C.c_bool, [bp]),
+        "ls_hs_basis_requires_projection": (C.c_bool, [bp]),
+        "ls_hs_fixed_hamming_state_to_index": (C.c_ssize_t, [C.c_uint64]),
+        "ls_hs_fixed_hamming_index_to_state": (C.c_uint64, [C.c_ssize_t, C.c_int]),
+        "ls_hs_basis_build": (None, [bp]),
+        "ls_hs_unchecked_set_representatives": (None, [bp, C.POINTER(ChplExternalArray)]),
+        "ls_hs_operator_max_number_off_diag": (C.c_int, [op]),
+        "ls_hs_operator_is_hermitian": (C.c_bool, [op]),
+        "ls_hs_operator_is_real": (C.c_bool, [op]),
+        "ls_hs_internal_set_chpl_kernels": (None, [vp]),
+        "ls_hs_internal_get_chpl_kernels": (vp, []),
+        "ls_chpl_init": (None, []),
+        "ls_chpl_finalize": (None, []),
+        "ls_chpl_init_kernels": (None, []),
+        "ls_chpl_matrix_vector_product": (None, [op, C.c_int, c_f64p, c_f64p]),
+        "ls_chpl_operator_apply_diag": (None, [op, C.c_int64, c_u64p, C.POINTER(ChplExternalArray), C.c_int64]),
+        "ls_chpl_operator_apply_off_diag": (None, [op, C.c_int64, c_u64p, C.POINTER(ChplExternalArray), C.POINTER(ChplExternalArray), C.POINTER(ChplExternalArray), C.c_int64]),
+        "ls_chpl_enumerate_representatives": (None, [bp, C.c_uint64, C.c_uint64, C.POINTER(ChplExternalArray)]),
+        "ls_chpl_primme_matvec": (None, [vp, c_i64p, vp, c_i64p, c_intp, vp, c_intp]),
+        "primmeGlobalSumReal": (None, [vp, vp, c_intp, vp, c_intp]),
+        "primmeBroadcastReal": (None, [vp, c_intp, vp, c_intp]),
+    }
+    for name, (res, args) in sigs.items():
+        fn = getattr(L, name)  # AttributeError == a declared symbol is not exported: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    _install_python_error_handler(L)
+    _lib = L
+    return L
+
+
+_HANDLER_TYPE = C.CFUNCTYPE(None, C.c_char_p)
+_pending_halt = []
+
+
+@_HANDLER_TYPE
+def _on_halt(msg):
+    # the reference aborts the process (`halt`); from Python we surface it as an exception raised by
+    # the wrapper right after the C call returns
+    _pending_halt.append(msg.decode("utf-8", "replace"))
+
+
+def _install_python_error_handler(L):
+    L.ls_amd_set_error_handler(C.cast(_on_halt, C.c_void_p))
+
+
+def raise_pending_halt():
+    if _pending_halt:
+        msg = _pending_halt.pop()
+        _pending_halt.clear()
+        raise LsAmdError("halt: " + msg)
+
+
+def check(rc):
+    if rc != 0:
+        raise LsAmdError(load().ls_amd_last_error().decode("utf-8", "replace"))
+    raise_pending_halt()
+
+
+def require_device():
+    if load().ls_amd_device_count() < 1:
+        raise LsAmdError("no HIP device visible: the matvec path is HIP-only and has no CPU fallback")

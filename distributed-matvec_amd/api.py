@@ -1,0 +1,449 @@
+"""Host-side mirror of the reference's operator interface for the matvec path.
+
+Names, argument meaning and error behaviour follow the Chapel modules they stand in for:
+    Basis, Operator, loadConfigFromYaml     /root/reference/src/ForeignTypes.chpl:8-288
+    enumerateStates                          /root/reference/src/StatesEnumeration.chpl:516-585
+    arrFromBlockToHashed / arrFromHashedToBlock   /root/reference/src/BlockToHashed.chpl:87,
+                                             /root/reference/src/HashedToBlock.chpl:67
+    matrixVectorProduct / localMatrixVector  /root/reference/src/DistributedMatrixVector.chpl:1055-1093
+so that the parity tests read like test/TestMatrixVectorProduct.chpl.  Everything that computes
+calls the C ABI of libls_amd.so (include/*.h); torch only provides device memory and streams.
+A "BlockVector" here is simply a list with one device tensor per locale (hash partition).
+uint64 arrays are held as torch.int64 tensors (bit-identical).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from . import config as _config
+from ._lib import LsAmdError
+
+__all__ = [
+    "Basis", "Operator", "LsAmdError", "loadConfigFromYaml", "loadConfigFromDict", "enumerateStates",
+    "arrFromBlockToHashed", "arrFromHashedToBlock", "matrixVectorProduct", "localMatrixVector",
+    "localeIdxOf", "hash64_01", "MatvecPlan", "build_library", "fillRandom",
+]
+
+
+def build_library(verbose: bool = False):
+    """hipcc --offload-arch=gfx950 build of libls_amd.so in-tree (cross-compiles without a GPU)."""
+    import os
+    import subprocess
+
+    csrc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+    subprocess.check_call(["make", "-C", csrc] + ([] if verbose else ["-s"]))
+    return _lib.LIB_PATH
+
+
+def _torch():
+    import torch
+
+    return torch
+
+
+def _stream_ptr():
+    torch = _torch()
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def hash64_01(x: int) -> int:
+    """/root/reference/src/StatesEnumeration.chpl:122-127"""
+    return int(_lib.load().ls_amd_hash64_01(C.c_uint64(x)))
+
+
+def localeIdxOf(basisState: int, numLocales: int) -> int:
+    """/root/reference/src/StatesEnumeration.chpl:133-136"""
+    return int(_lib.load().ls_amd_locale_idx_of(C.c_uint64(basisState), numLocales))
+
+
+class Basis:
+    """RAII wrapper of ls_hs_basis (ForeignTypes.chpl:8-117)."""
+
+    def __init__(self, payload, owning=True, spec=None):
+        self.payload = payload
+        self.owning = owning
+        self.spec = spec
+        self._host_reps = None  # keeps a numpy array alive for uncheckedSetRepresentatives
+
+    @staticmethod
+    def fromSpec(spec: _config.BasisSpec) -> "Basis":
+        L = _lib.load()
+        ng = len(spec.permutations)
+        perms = (C.c_int * max(1, ng * spec.number_sites))(*[v for p in spec.permutations for v in p])
+        sectors = (C.c_int * max(1, ng))(*spec.sectors)
+        p = L.ls_hs_create_spin_basis(spec.number_sites, spec.hamming_weight, spec.spin_inversion, ng, perms, sectors)
+        if not p:
+            raise LsAmdError(L.ls_amd_last_error().decode())
+        return Basis(p, True, spec)
+
+    def __del__(self):
+        try:
+            if self.owning and self.payload:
+                _lib.load().ls_hs_destroy_basis(self.payload)
+                self.payload = None
+        except Exception:
+            pass
+
+    # accessors, same names as the Chapel record ------------------------------------------------
+    def numberSites(self): return int(self.payload.contents.number_sites)
+    def numberBits(self): return int(_lib.load().ls_hs_basis_number_bits(self.payload))
+    def numberWords(self): return int(_lib.load().ls_hs_basis_number_words(self.payload))
+    def spinInversion(self): return int(self.payload.contents.spin_inversion)
+    def isStateIndexIdentity(self): return bool(self.payload.contents.state_index_is_identity)
+    def requiresProjection(self): return bool(self.payload.contents.requires_projection)
+    def isHammingWeightFixed(self): return bool(_lib.load().ls_hs_basis_has_fixed_hamming_weight(self.payload))
+    def hasSpinInversionSymmetry(self): return bool(_lib.load().ls_hs_basis_has_spin_inversion_symmetry(self.payload))
+    def hasPermutationSymmetries(self): return bool(_lib.load().ls_hs_basis_has_permutation_symmetries(self.payload))
+    def minStateEstimate(self): return int(_lib.load().ls_hs_min_state_estimate(self.payload))
+    def maxStateEstimate(self): return int(_lib.load().ls_hs_max_state_estimate(self.payload))
+    def groupOrder(self): return int(_lib.load().ls_amd_basis_group_order(self.payload))
+
+    def build(self):
+        """ls_hs_basis_build (ForeignTypes.chpl:72): dispatches to the registered enumerate_states
+        kernel, i.e. ls_chpl_enumerate_representatives -> the HIP enumeration."""
+        _lib.require_device()
+        _lib.load().ls_hs_basis_build(self.payload)
+        _lib.raise_pending_halt()
+
+    def uncheckedSetRepresentatives(self, representatives: np.ndarray):
+        """ForeignTypes.chpl:74-77 (borrows host memory)."""
+        arr = np.ascontiguousarray(representatives, dtype=np.uint64)
+        self._host_reps = arr
+        ext = _lib.ChplExternalArray(arr.ctypes.data, arr.size, None)
+        _lib.load().ls_hs_unchecked_set_representatives(self.payload, C.byref(ext))
+
+    def representatives(self) -> np.ndarray:
+        """ForeignTypes.chpl:111-116; halts with "basis is not built"."""
+        rs = self.payload.contents.representatives
+        if not rs.elts:
+            raise LsAmdError("halt: basis is not built")
+        buf = (C.c_uint64 * rs.num_elts).from_address(rs.elts)
+        return np.frombuffer(buf, dtype=np.uint64)
+
+
+class Operator:
+    """RAII wrapper of ls_hs_operator (ForeignTypes.chpl:154-259)."""
+
+    def __init__(self, payload, owning=True):
+        self.payload = payload
+        self.owning = owning
+        self.basis = Basis(payload.contents.basis, owning=False)
+        self._plans = {}
+
+    @staticmethod
+    def fromSpec(basis: Basis, spec: _config.OperatorSpec) -> "Operator":
+        L = _lib.load()
+        n = len(spec.terms)
+        v = np.zeros(2 * max(n, 1), dtype=np.float64)
+        m = np.zeros(max(n, 1), dtype=np.uint64)
+        r = np.zeros(max(n, 1), dtype=np.uint64)
+        x = np.zeros(max(n, 1), dtype=np.uint64)
+        s = np.zeros(max(n, 1), dtype=np.uint64)
+        for i, (vv, mm, rr, xx, ss) in enumerate(spec.terms):
+            v[2 * i], v[2 * i + 1] = vv.real, vv.imag
+            m[i], r[i], x[i], s[i] = mm, rr, xx, ss
+        p = L.ls_hs_create_operator_from_terms(
+            basis.payload, n, v.ctypes.data_as(_lib.c_f64p), m.ctypes.data_as(_lib.c_u64p),
+            r.ctypes.data_as(_lib.c_u64p), x.ctypes.data_as(_lib.c_u64p), s.ctypes.data_as(_lib.c_u64p))
+        if not p:
+            raise LsAmdError(L.ls_amd_last_error().decode())
+        op = Operator(p, True)
+        op.basis.spec = basis.spec
+        return op
+
+    def __del__(self):
+        try:
+            for pl in list(self._plans.values()):
+                pl.destroy()
+            self._plans.clear()
+            if self.owning and self.payload:
+                _lib.load().ls_hs_destroy_operator(self.payload)
+                self.payload = None
+        except Exception:
+            pass
+
+    def numberDiagTerms(self):
+        p = self.payload.contents.diag_terms
+        return int(p.contents.number_terms) if p else 0
+
+    def numberOffDiagTerms(self):
+        return int(_lib.load().ls_hs_operator_max_number_off_diag(self.payload))
+
+    @property
+    def isHermitian(self): return bool(_lib.load().ls_hs_operator_is_hermitian(self.payload))
+
+    @property
+    def isReal(self): return bool(_lib.load().ls_hs_operator_is_real(self.payload))
+
+    # host-pointer entry points of the kernel table ----------------------------------------------
+    def __matmul__(self, x: np.ndarray) -> np.ndarray:
+        """kernels->matrix_vector_product (ls_chpl_matrix_vector_product, DMV:1095-1110) on host
+        f64 arrays; y starts zeroed."""
+        _lib.require_device()
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.zeros_like(x)
+        _lib.load().ls_chpl_matrix_vector_product(self.payload, 1, x.ctypes.data_as(_lib.c_f64p), y.ctypes.data_as(_lib.c_f64p))
+        _lib.raise_pending_halt()
+        return y
+
+    def applyDiag(self, alphas: np.ndarray) -> np.ndarray:
+        """ls_chpl_operator_apply_diag (BatchedOperator.chpl:217-234)."""
+        _lib.require_device()
+        alphas = np.ascontiguousarray(alphas, dtype=np.uint64)
+        out = _lib.ChplExternalArray()
+        _lib.load().ls_chpl_operator_apply_diag(self.payload, alphas.size, alphas.ctypes.data_as(_lib.c_u64p), C.byref(out), 1)
+        _lib.raise_pending_halt()
+        return _take_external(out, np.float64, 1)
+
+    def applyOffDiag(self, alphas: np.ndarray):
+        """ls_chpl_operator_apply_off_diag (BatchedOperator.chpl:236-275) -> (betas, coeffs, offsets)."""
+        _lib.require_device()
+        alphas = np.ascontiguousarray(alphas, dtype=np.uint64)
+        b, c, o = _lib.ChplExternalArray(), _lib.ChplExternalArray(), _lib.ChplExternalArray()
+        _lib.load().ls_chpl_operator_apply_off_diag(self.payload, alphas.size, alphas.ctypes.data_as(_lib.c_u64p),
+                                                    C.byref(b), C.byref(c), C.byref(o), 1)
+        _lib.raise_pending_halt()
+        offsets = _take_external(o, np.int64, 1)
+        betas = _take_external(b, np.uint64, 1)
+        coeffs = _take_external(c, np.complex128, 1)
+        return betas, coeffs, offsets
+
+
+_libc_free = None
+
+
+def _take_external(arr: "_lib.ChplExternalArray", dtype, _unused):
+    """copies a callee-allocated chpl_external_array into numpy and frees it through `freer`."""
+    n = int(arr.num_elts)
+    if not arr.elts or n == 0:
+        return np.zeros(0, dtype=dtype)
+    itemsize = np.dtype(dtype).itemsize
+    buf = (C.c_char * (n * itemsize)).from_address(arr.elts)
+    out = np.frombuffer(buf, dtype=dtype).copy()
+    if arr.freer:
+        C.CFUNCTYPE(None, C.c_void_p)(arr.freer)(arr.elts)
+    return out
+
+
+def loadConfigFromDict(cfg: dict, hamiltonian: bool = False, observables: bool = False):
+    bspec = _config.parse_basis(cfg)
+    basis = Basis.fromSpec(bspec)
+    h = None
+    if hamiltonian:
+        if cfg.get("hamiltonian") is None:
+            raise LsAmdError("halt: config does not contain a Hamiltonian")  # ForeignTypes.chpl:273-274
+        h = Operator.fromSpec(basis, _config.parse_operator(cfg["hamiltonian"]))
+    obs = [Operator.fromSpec(basis, _config.parse_operator(o)) for o in (cfg.get("observables") or [])] if observables else []
+    if not hamiltonian and not observables:
+        return basis
+    if hamiltonian and not observables:
+        return basis, h
+    if not hamiltonian and observables:
+        return basis, obs
+    return basis, h, obs
+
+
+def loadConfigFromYaml(filename: str, hamiltonian: bool = False, observables: bool = False):
+    """ForeignTypes.chpl:261-288."""
+    import yaml
+
+    try:
+        with open(filename, "r", encoding="utf-8") as f:
+            cfg = yaml.safe_load(f)
+    except OSError as e:
+        raise LsAmdError(f"halt: failed to load Config from '{filename}'") from e
+    return loadConfigFromDict(cfg, hamiltonian, observables)
+
+
+# ------------------------------------------------------------------------------------------------
+# device-side pieces
+# ------------------------------------------------------------------------------------------------
+
+def _adopt(ptr: int, count: int, torch_dtype):
+    """copies a library-owned device array into a torch tensor and frees the original."""
+    torch = _torch()
+    L = _lib.load()
+    t = torch.empty(count, dtype=torch_dtype, device="cuda")
+    try:
+        if count > 0:
+            _lib.check(L.ls_amd_memcpy_d2d(C.c_void_p(t.data_ptr()), C.c_void_p(ptr), count * t.element_size(), _stream_ptr()))
+            _lib.check(L.ls_amd_synchronize(_stream_ptr()))
+    finally:
+        if ptr:
+            L.ls_amd_free(C.c_void_p(ptr))
+    return t
+
+
+def enumerateStates(basis: Basis, numLocales: int = 1):
+    """enumerateStates(basis, masks) (StatesEnumeration.chpl:580-585): returns
+    (basisStates, masks) -- basisStates[p] = ascending representatives owned by locale p
+    (hash64_01 % numLocales), masks = owner of every state in global ascending order."""
+    _lib.require_device()
+    torch = _torch()
+    L = _lib.load()
+    d_states, d_masks, count = C.c_void_p(), C.c_void_p(), C.c_int64()
+    _lib.check(L.ls_amd_enumerate_states(basis.payload, numLocales, C.byref(d_states), C.byref(d_masks), C.byref(count), _stream_ptr()))
+    states = _adopt(d_states.value, count.value, torch.int64)
+    masks = _adopt(d_masks.value, count.value, torch.uint8)
+    parts = [states] if numLocales == 1 else arrFromBlockToHashed(states, masks, numLocales)
+    return parts, masks
+
+
+def _mask_counts(masks, numLocales):
+    counts = (C.c_int64 * numLocales)()
+    _lib.check(_lib.load().ls_amd_mask_counts(masks.numel(), C.c_void_p(masks.data_ptr()), numLocales, counts, _stream_ptr()))
+    return [int(c) for c in counts]
+
+
+def arrFromBlockToHashed(arr, masks, numLocales: int):
+    """BlockToHashed.chpl:87-208: stable partition of a block-order device tensor (8- or 16-byte
+    elements) into one tensor per locale."""
+    torch = _torch()
+    _lib.require_device()
+    assert arr.is_cuda and masks.is_cuda and arr.is_contiguous()
+    n = arr.numel()
+    assert masks.numel() == n
+    counts = _mask_counts(masks, numLocales)
+    parts = [torch.empty(c, dtype=arr.dtype, device=arr.device) for c in counts]
+    dest = (C.c_void_p * numLocales)(*[p.data_ptr() for p in parts])
+    _lib.check(_lib.load().ls_amd_block_to_hashed(n, C.c_void_p(masks.data_ptr()), numLocales, arr.element_size(),
+                                                  C.c_void_p(arr.data_ptr()), dest, _stream_ptr()))
+    return parts
+
+
+def arrFromHashedToBlock(parts, masks):
+    """HashedToBlock.chpl:67-153: inverse of arrFromBlockToHashed."""
+    torch = _torch()
+    _lib.require_device()
+    numLocales = len(parts)
+    n = masks.numel()
+    out = torch.empty(n, dtype=parts[0].dtype, device=parts[0].device)
+    src = (C.c_void_p * numLocales)(*[p.data_ptr() for p in parts])
+    _lib.check(_lib.load().ls_amd_hashed_to_block(n, C.c_void_p(masks.data_ptr()), numLocales, parts[0].element_size(),
+                                                  src, C.c_void_p(out.data_ptr()), _stream_ptr()))
+    return out
+
+
+class MatvecPlan:
+    """ls_amd_plan: binds an Operator to a partition layout (include/ls_amd.h)."""
+
+    MODES = {"auto": 0, "push": 1, "pull": 2}
+
+    def __init__(self, matrix: Operator, representatives, dtype, my_partition: int = -1,
+                 num_partitions: int | None = None, num_rounds: int = 0, mode: str = "auto"):
+        torch = _torch()
+        _lib.require_device()
+        L = _lib.load()
+        self.matrix = matrix
+        reps = list(representatives) if my_partition < 0 else [representatives]
+        self.reps = reps  # borrowed by the plan: keep alive
+        self.P = num_partitions if num_partitions is not None else len(reps)
+        self.me = my_partition
+        self.cplx = dtype in (torch.complex128, "c128")
+        n = len(reps)
+        ptrs = (C.c_void_p * n)(*[r.data_ptr() for r in reps])
+        counts = (C.c_int64 * n)(*[r.numel() for r in reps])
+        h = C.c_void_p()
+        _lib.check(L.ls_amd_plan_create(C.byref(h), matrix.payload, 1 if self.cplx else 0, self.P, my_partition,
+                                        ptrs, counts, num_rounds, self.MODES[mode], _stream_ptr()))
+        self.h = h
+
+    def destroy(self):
+        if getattr(self, "h", None):
+            _lib.load().ls_amd_plan_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+    @property
+    def kernel(self): return _lib.load().ls_amd_plan_kernel_name(self.h).decode()
+    @property
+    def num_rounds(self): return int(_lib.load().ls_amd_plan_num_rounds(self.h))
+    @property
+    def nnz(self): return int(_lib.load().ls_amd_plan_nnz(self.h))
+    @property
+    def packet_bytes(self): return int(_lib.load().ls_amd_plan_packet_bytes(self.h))
+
+    def send_counts(self, rnd: int):
+        c = (C.c_int64 * self.P)()
+        _lib.check(_lib.load().ls_amd_plan_send_counts(self.h, rnd, c))
+        return [int(v) for v in c]
+
+    def matvec(self, x, y, check: bool = True):
+        xs = (C.c_void_p * len(x))(*[t.data_ptr() for t in x])
+        ys = (C.c_void_p * len(y))(*[t.data_ptr() for t in y])
+        _lib.check(_lib.load().ls_amd_matvec(self.h, xs, ys, _stream_ptr()))
+        if check:
+            self.check()
+
+    def check(self):
+        _lib.check(_lib.load().ls_amd_plan_check(self.h, _stream_ptr()))
+
+    def enable_timing(self, max_samples: int):
+        _lib.check(_lib.load().ls_amd_plan_enable_timing(self.h, max_samples))
+
+    def kernel_times_ms(self, capacity: int = 4096):
+        buf = (C.c_float * capacity)()
+        n = C.c_int()
+        _lib.check(_lib.load().ls_amd_plan_kernel_times(self.h, buf, capacity, C.byref(n)))
+        return [float(buf[i]) for i in range(n.value)]
+
+    def diag(self, x, y):
+        _lib.check(_lib.load().ls_amd_diag(self.h, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), _stream_ptr()))
+
+    def generate(self, rnd, x, y, send):
+        _lib.check(_lib.load().ls_amd_generate(self.h, rnd, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()),
+                                               C.c_void_p(send.data_ptr() if send is not None else 0), _stream_ptr()))
+
+    def scatter(self, n, betas_ptr: int, vals_ptr: int, y):
+        _lib.check(_lib.load().ls_amd_scatter(self.h, n, C.c_void_p(betas_ptr), C.c_void_p(vals_ptr),
+                                              C.c_void_p(y.data_ptr()), _stream_ptr()))
+
+
+def fillRandom(states, seed: int, dtype):
+    """deterministic vector keyed by the basis states (same logical vector for every partitioning)."""
+    torch = _torch()
+    _lib.require_device()
+    out = torch.empty(states.numel(), dtype=dtype, device=states.device)
+    _lib.check(_lib.load().ls_amd_fill_random(states.numel(), C.c_void_p(states.data_ptr()), C.c_uint64(seed),
+                                              1 if dtype == torch.complex128 else 0, C.c_void_p(out.data_ptr()), _stream_ptr()))
+    return out
+
+
+def _plan_for(matrix: Operator, representatives, dtype, mode="auto"):
+    key = (tuple(int(r.data_ptr()) for r in representatives), tuple(int(r.numel()) for r in representatives), str(dtype), mode)
+    pl = matrix._plans.get(key)
+    if pl is None:
+        pl = MatvecPlan(matrix, representatives, dtype, mode=mode)
+        matrix._plans[key] = pl
+    return pl
+
+
+def matrixVectorProduct(matrix: Operator, x, y, representatives, mode: str = "auto", check: bool = True):
+    """matrixVectorProduct(matrix, x, y, representatives) (DMV:1072-1093) with all locales as logical
+    partitions on the current device.  x, y, representatives: lists with one device tensor per
+    locale (f64 or c128; representatives int64-viewed uint64).  y is overwritten by the diagonal
+    pass when the operator has diagonal terms, then accumulated into."""
+    torch = _torch()
+    if isinstance(x, torch.Tensor):
+        x, y, representatives = [x], [y], [representatives]
+    if len(x) != len(representatives) or len(y) != len(representatives):
+        raise LsAmdError("x, y and representatives must have one block per locale")
+    for a, b, r in zip(x, y, representatives):
+        if a.dtype != b.dtype or a.numel() != r.numel() or b.numel() != r.numel():
+            raise LsAmdError("block shapes / dtypes do not match")
+    pl = _plan_for(matrix, representatives, x[0].dtype, mode)
+    pl.matvec(x, y, check=check)
+    return pl
+
+
+def localMatrixVector(matrix: Operator, x, y, representatives, mode: str = "auto"):
+    """localMatrixVector (DMV:1055-1070): the single-locale case."""
+    return matrixVectorProduct(matrix, [x], [y], [representatives], mode=mode)

@@ -1,0 +1,1314 @@
+/* host.c -- C host side of the MI355X-native matvec: the ls_hs_* ABI subset, plans, and the
+ * ls_chpl_* exports of the reference's shared library.  Plain C11; every device action goes through
+ * the extern-"C" shim in kernels.hip (lsk.h).  No compute on the CPU: the functions here build
+ * tables (symmetry-group closure, Benes networks, term grouping), size buffers and launch kernels.
+ *
+ * Reference behaviour mirrored (see include/ls_chpl.h, include/ls_amd.h for per-symbol citations):
+ *   localMatrixVector / matrixVectorProduct   /root/reference/src/DistributedMatrixVector.chpl:1055-1110
+ *   localOffDiagonalNoQueue (sizing, rounds)  /root/reference/src/DistributedMatrixVector.chpl:856-1053
+ *   enumerateStates                           /root/reference/src/StatesEnumeration.chpl:516-603
+ *   Diagonalize's PRIMME callback             /root/reference/src/Diagonalize.chpl:134-162
+ */
+#define _GNU_SOURCE
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/ls_amd.h"
+#include "../../include/ls_chpl.h"
+#include "../../include/ls_hs.h"
+#include "lsk.h"
+
+/* ============================================================================================ */
+/* errors                                                                                       */
+/* ============================================================================================ */
+static __thread char g_last_error[1024] = "";
+static ls_amd_error_handler g_handler = NULL;
+
+static int set_error(char const *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_last_error, sizeof(g_last_error), fmt, ap);
+    va_end(ap);
+    return -1;
+}
+static int dev_error(void) { return set_error("%s", lsk_last_error()); }
+#define DEV(expr) do { if ((expr) != 0) return dev_error(); } while (0)
+
+char const *ls_amd_last_error(void) { return g_last_error; }
+void ls_amd_set_error_handler(ls_amd_error_handler handler) { g_handler = handler; }
+
+/* the reference's `halt(...)` */
+static void halt_with(char const *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    snprintf(g_last_error, sizeof(g_last_error), "%s", buf);
+    if (g_handler) { g_handler(buf); return; }
+    fprintf(stderr, "[Error]   halt: %s\n", buf);
+    abort();
+}
+
+/* ============================================================================================ */
+/* device helpers re-exported                                                                   */
+/* ============================================================================================ */
+int ls_amd_device_count(void) { return lsk_device_count(); }
+int ls_amd_set_device(int device) { DEV(lsk_set_device(device)); return 0; }
+int ls_amd_malloc(void **d_ptr, size_t bytes) { DEV(lsk_malloc(d_ptr, bytes)); return 0; }
+int ls_amd_free(void *d_ptr) { DEV(lsk_free(d_ptr)); return 0; }
+int ls_amd_memcpy_h2d(void *d, void const *h, size_t bytes) { DEV(lsk_h2d(d, h, bytes)); return 0; }
+int ls_amd_memcpy_d2h(void *h, void const *d, size_t bytes) { DEV(lsk_d2h(h, d, bytes)); return 0; }
+int ls_amd_memcpy_d2d(void *d, void const *s, size_t bytes, void *stream) { DEV(lsk_d2d_async(d, s, bytes, stream)); return 0; }
+int ls_amd_memset(void *d, int value, size_t bytes, void *stream) { DEV(lsk_memset_async(d, value, bytes, stream)); return 0; }
+int ls_amd_synchronize(void *stream) { DEV(lsk_sync(stream)); return 0; }
+
+uint64_t ls_amd_hash64_01(uint64_t x) {
+    x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ULL;
+    x = (x ^ (x >> 27)) * 0x94d049bb133111ebULL;
+    x = x ^ (x >> 31);
+    return x;
+}
+int ls_amd_locale_idx_of(uint64_t basis_state, int num_locales) {
+    return (int)(ls_amd_hash64_01(basis_state) % (uint64_t)num_locales);
+}
+
+/* ============================================================================================ */
+/* binomials                                                                                    */
+/* ============================================================================================ */
+static uint64_t g_binom[64 * LSK_BINOM_K];
+static int g_binom_ready = 0;
+static uint64_t *g_d_binom = NULL;
+
+static void binom_init(void) {
+    if (g_binom_ready) return;
+    for (int n = 0; n < 64; ++n)
+        for (int k = 0; k < LSK_BINOM_K; ++k) {
+            uint64_t v;
+            if (k == 0) v = 1;
+            else if (n == 0) v = 0;
+            else v = g_binom[(n - 1) * LSK_BINOM_K + (k - 1)] + g_binom[(n - 1) * LSK_BINOM_K + k];
+            g_binom[n * LSK_BINOM_K + k] = v;
+        }
+    g_binom_ready = 1;
+}
+static uint64_t binom(int n, int k) {
+    binom_init();
+    if (k < 0 || n < 0 || k > n) return 0;
+    if (n - k < k) k = n - k;
+    if (n < 64 && k < LSK_BINOM_K) return g_binom[n * LSK_BINOM_K + k];
+    /* n == 64 or beyond table: compute directly (only used for sizes) */
+    long double r = 1;
+    for (int i = 1; i <= k; ++i) r = r * (n - k + i) / i;
+    return (uint64_t)(r + 0.5L);
+}
+static int device_binom(uint64_t const **out) {
+    binom_init();
+    if (!g_d_binom) {
+        void *p;
+        DEV(lsk_malloc(&p, sizeof(g_binom)));
+        DEV(lsk_h2d(p, g_binom, sizeof(g_binom)));
+        g_d_binom = (uint64_t *)p;
+    }
+    *out = g_d_binom;
+    return 0;
+}
+
+ptrdiff_t ls_hs_fixed_hamming_state_to_index(uint64_t s) {
+    binom_init();
+    ptrdiff_t idx = 0;
+    int k = 1;
+    while (s) {
+        int p = __builtin_ctzll(s);
+        idx += (ptrdiff_t)binom(p, k);
+        ++k;
+        s &= s - 1;
+    }
+    return idx;
+}
+uint64_t ls_hs_fixed_hamming_index_to_state(ptrdiff_t idx, int hamming_weight) {
+    uint64_t s = 0;
+    int p = 63;
+    for (int k = hamming_weight; k >= 1; --k) {
+        while (p > k - 1 && (ptrdiff_t)binom(p, k) > idx) --p;
+        s |= 1ULL << p;
+        idx -= (ptrdiff_t)binom(p, k);
+        --p;
+    }
+    return s;
+}
+
+/* ============================================================================================ */
+/* basis                                                                                        */
+/* ============================================================================================ */
+struct ls_amd_basis_ext {
+    int hamming_weight; /* -1 unrestricted */
+    int n_generators;
+    int *gen_perms;     /* [n_generators][L] */
+    int *gen_sectors;
+    int order;          /* permutation group order (>= 1, identity first) */
+    int *perms;         /* [order][L] */
+    lsk_group_elem *elems; /* [order] host copy (characters, networks) */
+    lsk_group_elem *d_elems;
+    int owns_representatives;
+    uint64_t *d_reps_cache; /* device copy of `representatives` for the host-pointer entry points */
+    uint64_t d_reps_count;
+    void *host_plan_f64;    /* ls_amd_plan* cached by the host-pointer entry points */
+};
+
+void ls_hs_init(void) {}
+void ls_hs_exit(void) {}
+
+static int perm_order(int const *p, int L) {
+    int *q = (int *)malloc(sizeof(int) * L), *t = (int *)malloc(sizeof(int) * L);
+    memcpy(q, p, sizeof(int) * L);
+    int n = 1;
+    for (;;) {
+        int ident = 1;
+        for (int i = 0; i < L; ++i) if (q[i] != i) { ident = 0; break; }
+        if (ident) break;
+        for (int i = 0; i < L; ++i) t[i] = q[p[i]]; /* compose(p, q)[i] = q[p[i]] */
+        memcpy(q, t, sizeof(int) * L);
+        ++n;
+    }
+    free(q); free(t);
+    return n;
+}
+
+/* Benes network for y[i] = x[src[i]], i < 64.  masks[level] = input stage of recursion level
+ * `level` (distance 32 >> level), masks[10 - level] = its output stage, masks[5] = the middle. */
+static void benes_route(int base, int n, int const *src, int level, uint64_t *masks) {
+    if (n == 2) {
+        if (src[0] == 1) masks[5] |= 1ULL << base;
+        return;
+    }
+    int const h = n / 2;
+    int inv[64], incolor[64], outcolor[64], lower[32], upper[32];
+    for (int i = 0; i < n; ++i) { inv[src[i]] = i; incolor[i] = -1; outcolor[i] = -1; }
+    for (int o = 0; o < n; ++o) {
+        if (outcolor[o] != -1) continue;
+        int cur = o, c = 0;
+        while (outcolor[cur] == -1) {
+            outcolor[cur] = c;
+            int s = src[cur];
+            incolor[s] = c;
+            int sp = s ^ h;
+            incolor[sp] = 1 - c;
+            int o2 = inv[sp];
+            outcolor[o2] = 1 - c;
+            cur = o2 ^ h;
+        }
+    }
+    for (int j = 0; j < h; ++j) {
+        if (incolor[j] == 1) masks[level] |= 1ULL << (base + j);
+        if (outcolor[j] == 1) masks[10 - level] |= 1ULL << (base + j);
+    }
+    for (int i = 0; i < h; ++i) {
+        int fo_l = (outcolor[i] == 0) ? i : i + h;
+        int fo_u = (outcolor[i] == 1) ? i : i + h;
+        lower[i] = src[fo_l] & (h - 1);
+        upper[i] = src[fo_u] & (h - 1);
+    }
+    benes_route(base, h, lower, level + 1, masks);
+    benes_route(base + h, h, upper, level + 1, masks);
+}
+
+static void compile_elem(int const *perm, int L, double ch_re, double ch_im, lsk_group_elem *e) {
+    memset(e, 0, sizeof(*e));
+    e->ch_re = ch_re;
+    e->ch_im = ch_im;
+    /* rotation: perm[i] = (i + k) mod L  -> y = rotr_L(x, k) */
+    int k = perm[0];
+    int is_rot = 1;
+    for (int i = 0; i < L; ++i) if (perm[i] != (i + k) % L) { is_rot = 0; break; }
+    if (is_rot) { e->kind = LSK_ELEM_ROT; e->k = k; return; }
+    /* reflection + rotation: perm[i] = (k' - i) mod L -> y = rotr_L(rev_L(x), (L - 1 - k') mod L) */
+    int kp = perm[0];
+    int is_rev = 1;
+    for (int i = 0; i < L; ++i) if (perm[i] != ((kp - i) % L + L) % L) { is_rev = 0; break; }
+    if (is_rev) { e->kind = LSK_ELEM_REVROT; e->k = ((L - 1 - kp) % L + L) % L; return; }
+    int src[64];
+    for (int i = 0; i < 64; ++i) src[i] = i < L ? perm[i] : i;
+    e->kind = LSK_ELEM_BENES;
+    benes_route(0, 64, src, 0, e->masks);
+}
+
+static uint64_t host_delta_swap(uint64_t x, uint64_t m, int d) {
+    uint64_t t = ((x >> d) ^ x) & m;
+    return x ^ t ^ (t << d);
+}
+/* CPU mirror of apply_elem in kernels.hip -- used by the test hooks and table checks only */
+static uint64_t host_apply_elem(lsk_group_elem const *e, uint64_t x, int L) {
+    static int const dist[LSK_BENES_STAGES] = {32, 16, 8, 4, 2, 1, 2, 4, 8, 16, 32};
+    uint64_t const mask = L >= 64 ? ~0ULL : ((1ULL << L) - 1);
+    if (e->kind == LSK_ELEM_BENES) {
+        for (int s = 0; s < LSK_BENES_STAGES; ++s)
+            if (e->masks[s]) x = host_delta_swap(x, e->masks[s], dist[s]);
+        return x;
+    }
+    if (e->kind == LSK_ELEM_REVROT) {
+        uint64_t r = 0;
+        for (int i = 0; i < L; ++i) r |= ((x >> i) & 1ULL) << (L - 1 - i);
+        x = r;
+    }
+    if (e->k == 0) return x;
+    return ((x >> e->k) | (x << (L - e->k))) & mask;
+}
+
+static int close_group(struct ls_amd_basis_ext *ext, int L) {
+    int const ng = ext->n_generators;
+    int cap = 64, order = 1;
+    int *perms = (int *)malloc(sizeof(int) * cap * L);
+    double *chars = (double *)malloc(sizeof(double) * 2 * cap);
+    double *gch = (double *)malloc(sizeof(double) * 2 * (ng > 0 ? ng : 1));
+    for (int i = 0; i < L; ++i) perms[i] = i;
+    chars[0] = 1.0; chars[1] = 0.0;
+    for (int g = 0; g < ng; ++g) {
+        int const *p = ext->gen_perms + g * L;
+        int n = perm_order(p, L);
+        int k = ((ext->gen_sectors[g] % n) + n) % n;
+        double ang = -2.0 * M_PI * (double)k / (double)n;
+        double re = cos(ang), im = sin(ang);
+        /* snap the exact values so real sectors stay exactly real */
+        if (fabs(re) < 1e-15) re = 0.0;
+        if (fabs(im) < 1e-15) im = 0.0;
+        if (fabs(fabs(re) - 1.0) < 1e-15) re = re > 0 ? 1.0 : -1.0;
+        if (fabs(fabs(im) - 1.0) < 1e-15) im = im > 0 ? 1.0 : -1.0;
+        gch[2 * g] = re; gch[2 * g + 1] = im;
+    }
+    int *cand = (int *)malloc(sizeof(int) * L);
+    for (int head = 0; head < order; ++head) { /* BFS: `order` grows while we scan */
+        for (int g = 0; g < ng; ++g) {
+            int const *p = ext->gen_perms + g * L;
+            int const *e = perms + (size_t)head * L;
+            for (int i = 0; i < L; ++i) cand[i] = e[p[i]]; /* compose(g, e) */
+            double cre = chars[2 * head] * gch[2 * g] - chars[2 * head + 1] * gch[2 * g + 1];
+            double cim = chars[2 * head] * gch[2 * g + 1] + chars[2 * head + 1] * gch[2 * g];
+            int found = -1;
+            for (int j = 0; j < order; ++j)
+                if (memcmp(perms + (size_t)j * L, cand, sizeof(int) * L) == 0) { found = j; break; }
+            if (found >= 0) {
+                if (fabs(chars[2 * found] - cre) > 1e-9 || fabs(chars[2 * found + 1] - cim) > 1e-9) {
+                    free(perms); free(chars); free(gch); free(cand);
+                    return set_error("symmetry sectors are incompatible with the group structure");
+                }
+                continue;
+            }
+            if (order == cap) {
+                cap *= 2;
+                perms = (int *)realloc(perms, sizeof(int) * cap * L);
+                chars = (double *)realloc(chars, sizeof(double) * 2 * cap);
+            }
+            memcpy(perms + (size_t)order * L, cand, sizeof(int) * L);
+            chars[2 * order] = cre; chars[2 * order + 1] = cim;
+            ++order;
+            if (order > (1 << 20)) {
+                free(perms); free(chars); free(gch); free(cand);
+                return set_error("symmetry group too large");
+            }
+        }
+    }
+    ext->order = order;
+    ext->perms = perms;
+    ext->elems = (lsk_group_elem *)malloc(sizeof(lsk_group_elem) * order);
+    for (int j = 0; j < order; ++j) {
+        double re = chars[2 * j], im = chars[2 * j + 1];
+        if (fabs(im) < 1e-14) im = 0.0;
+        if (fabs(re) < 1e-14) re = 0.0;
+        compile_elem(perms + (size_t)j * L, L, re, im, ext->elems + j);
+    }
+    free(chars); free(gch); free(cand);
+    return 0;
+}
+
+ls_hs_basis *ls_hs_create_spin_basis(int number_sites, int hamming_weight, int spin_inversion,
+                                     int number_generators, int const *permutations,
+                                     int const *sectors) {
+    if (number_sites < 1 || number_sites > 64) { set_error("number_sites must be in [1, 64] (number_words == 1)"); return NULL; }
+    if (hamming_weight > number_sites) { set_error("hamming_weight > number_sites"); return NULL; }
+    if (hamming_weight >= LSK_BINOM_K) { set_error("hamming_weight too large for the binomial table"); return NULL; }
+    if (spin_inversion != 0 && spin_inversion != 1 && spin_inversion != -1) { set_error("spin_inversion must be 0, 1 or -1"); return NULL; }
+    if (spin_inversion != 0 && hamming_weight >= 0 && 2 * hamming_weight != number_sites) {
+        set_error("spin inversion requires hamming_weight == number_sites / 2"); return NULL;
+    }
+    for (int g = 0; g < number_generators; ++g) {
+        uint64_t seen = 0;
+        for (int i = 0; i < number_sites; ++i) {
+            int v = permutations[g * number_sites + i];
+            if (v < 0 || v >= number_sites || ((seen >> v) & 1)) { set_error("generator %d is not a permutation", g); return NULL; }
+            seen |= 1ULL << v;
+        }
+    }
+    ls_hs_basis *b = (ls_hs_basis *)calloc(1, sizeof(ls_hs_basis));
+    struct ls_amd_basis_ext *ext = (struct ls_amd_basis_ext *)calloc(1, sizeof(*ext));
+    b->ext = ext;
+    b->number_sites = number_sites;
+    b->number_particles = -1;
+    b->number_up = hamming_weight >= 0 ? hamming_weight : -1;
+    b->particle_type = LS_HS_SPIN;
+    b->spin_inversion = spin_inversion;
+    b->kernels = NULL;
+    ext->hamming_weight = hamming_weight < 0 ? -1 : hamming_weight;
+    ext->n_generators = number_generators;
+    ext->gen_perms = (int *)malloc(sizeof(int) * (size_t)(number_generators > 0 ? number_generators : 1) * number_sites);
+    ext->gen_sectors = (int *)malloc(sizeof(int) * (size_t)(number_generators > 0 ? number_generators : 1));
+    if (number_generators > 0) {
+        memcpy(ext->gen_perms, permutations, sizeof(int) * (size_t)number_generators * number_sites);
+        memcpy(ext->gen_sectors, sectors, sizeof(int) * (size_t)number_generators);
+    }
+    if (close_group(ext, number_sites) != 0) { ls_hs_destroy_basis(b); return NULL; }
+    b->requires_projection = ext->order > 1 || spin_inversion != 0;
+    b->state_index_is_identity = ext->hamming_weight < 0 && !b->requires_projection;
+    return b;
+}
+
+ls_hs_basis *ls_hs_clone_basis(ls_hs_basis const *basis) {
+    struct ls_amd_basis_ext const *e = basis->ext;
+    ls_hs_basis *b = ls_hs_create_spin_basis(basis->number_sites, e->hamming_weight, basis->spin_inversion,
+                                             e->n_generators, e->gen_perms, e->gen_sectors);
+    if (!b) return NULL;
+    if (basis->representatives.elts) { /* deep copy, like upstream's clone keeps the built states */
+        size_t bytes = 8 * basis->representatives.num_elts;
+        b->representatives.elts = malloc(bytes ? bytes : 8);
+        memcpy(b->representatives.elts, basis->representatives.elts, bytes);
+        b->representatives.num_elts = basis->representatives.num_elts;
+        b->representatives.freer = (void *)free;
+        b->ext->owns_representatives = 1;
+    }
+    return b;
+}
+
+static void basis_drop_device_caches(ls_hs_basis *b) {
+    struct ls_amd_basis_ext *e = b->ext;
+    if (e->host_plan_f64) { ls_amd_plan_destroy((ls_amd_plan *)e->host_plan_f64); e->host_plan_f64 = NULL; }
+    if (e->d_reps_cache) { lsk_free(e->d_reps_cache); e->d_reps_cache = NULL; e->d_reps_count = 0; }
+}
+
+void ls_hs_destroy_basis(ls_hs_basis *b) {
+    if (!b) return;
+    struct ls_amd_basis_ext *e = b->ext;
+    if (e) {
+        basis_drop_device_caches(b);
+        if (e->d_elems) lsk_free(e->d_elems);
+        if (e->owns_representatives && b->representatives.elts) free(b->representatives.elts);
+        free(e->gen_perms); free(e->gen_sectors); free(e->perms); free(e->elems);
+        free(e);
+    }
+    free(b);
+}
+
+uint64_t ls_hs_min_state_estimate(ls_hs_basis const *b) {
+    int h = b->ext->hamming_weight;
+    return h > 0 ? ((1ULL << h) - 1) : 0;
+}
+/* with spin inversion the highest admissible state has the top site bit clear (see oracle notes) */
+uint64_t ls_hs_max_state_estimate(ls_hs_basis const *b) {
+    int const L = b->number_sites - (b->spin_inversion != 0 ? 1 : 0);
+    int h = b->ext->hamming_weight;
+    if (h >= 0) return h == 0 ? 0 : ((1ULL << h) - 1) << (L - h);
+    return L >= 64 ? ~0ULL : ((1ULL << L) - 1);
+}
+int ls_hs_basis_number_bits(ls_hs_basis const *b) { return b->number_sites; }
+int ls_hs_basis_number_words(ls_hs_basis const *b) { return (b->number_sites + 63) / 64; }
+bool ls_hs_basis_has_fixed_hamming_weight(ls_hs_basis const *b) { return b->ext->hamming_weight >= 0; }
+bool ls_hs_basis_has_spin_inversion_symmetry(ls_hs_basis const *b) { return b->spin_inversion != 0; }
+bool ls_hs_basis_has_permutation_symmetries(ls_hs_basis const *b) { return b->ext->order > 1; }
+bool ls_hs_basis_requires_projection(ls_hs_basis const *b) { return b->requires_projection; }
+
+void ls_hs_unchecked_set_representatives(ls_hs_basis *b, chpl_external_array const *states) {
+    basis_drop_device_caches(b);
+    if (b->ext->owns_representatives && b->representatives.elts) free(b->representatives.elts);
+    b->representatives = *states;
+    b->ext->owns_representatives = 0;
+}
+
+int ls_amd_basis_group_order(ls_hs_basis const *b) { return b->ext->order; }
+uint64_t ls_amd_basis_apply_group_element(ls_hs_basis const *b, int element, uint64_t state) {
+    return host_apply_elem(b->ext->elems + element, state, b->number_sites);
+}
+int ls_amd_basis_group_character(ls_hs_basis const *b, int element, double *re, double *im) {
+    if (element < 0 || element >= b->ext->order) return set_error("element out of range");
+    *re = b->ext->elems[element].ch_re;
+    *im = b->ext->elems[element].ch_im;
+    return 0;
+}
+
+static int basis_device(ls_hs_basis const *b, lsk_basis *out) {
+    struct ls_amd_basis_ext *e = b->ext;
+    if (!e->d_elems) {
+        void *p;
+        DEV(lsk_malloc(&p, sizeof(lsk_group_elem) * e->order));
+        DEV(lsk_h2d(p, e->elems, sizeof(lsk_group_elem) * e->order));
+        e->d_elems = (lsk_group_elem *)p;
+    }
+    out->number_sites = b->number_sites;
+    out->hamming_weight = e->hamming_weight;
+    out->spin_inversion = b->spin_inversion;
+    out->n_elems = e->order;
+    out->proj = e->order > 1 ? LSK_PROJ_FULL : (b->spin_inversion != 0 ? LSK_PROJ_INVERSION : LSK_PROJ_NONE);
+    out->site_mask = b->number_sites >= 64 ? ~0ULL : ((1ULL << b->number_sites) - 1);
+    out->inv_order = 1.0 / ((double)e->order * (b->spin_inversion != 0 ? 2.0 : 1.0));
+    out->elems = e->d_elems;
+    return 0;
+}
+
+/* ============================================================================================ */
+/* operator                                                                                     */
+/* ============================================================================================ */
+struct ls_amd_operator_ext {
+    int n_groups;
+    lsk_group *groups; /* host */
+    lsk_term *off;     /* host, grouped */
+    lsk_term *diag;    /* host */
+    int n_off, n_diag;
+    int is_real, is_hermitian;
+    /* device mirrors */
+    lsk_group *d_groups;
+    lsk_term *d_off, *d_diag;
+    int owns_basis;
+};
+
+typedef struct { double re, im; uint64_t m, r, x, s; } raw_term;
+
+static int raw_cmp(void const *pa, void const *pb) {
+    raw_term const *a = (raw_term const *)pa, *b = (raw_term const *)pb;
+    if (a->x != b->x) return a->x < b->x ? -1 : 1;
+    if (a->m != b->m) return a->m < b->m ? -1 : 1;
+    if (a->r != b->r) return a->r < b->r ? -1 : 1;
+    if (a->s != b->s) return a->s < b->s ? -1 : 1;
+    return 0;
+}
+
+static void eval_terms(lsk_term const *t, int b, int e, uint64_t a, double *re, double *im) {
+    double cr = 0, ci = 0;
+    for (int k = b; k < e; ++k)
+        if ((a & t[k].m) == t[k].r) {
+            int neg = __builtin_popcountll(a & t[k].s) & 1;
+            cr += neg ? -t[k].v_re : t[k].v_re;
+            ci += neg ? -t[k].v_im : t[k].v_im;
+        }
+    *re = cr; *im = ci;
+}
+
+static uint64_t deposit_bits(uint64_t pattern, uint64_t support) { /* software pdep */
+    uint64_t out = 0;
+    for (int i = 0; support; ++i) {
+        uint64_t low = support & -support;
+        if ((pattern >> i) & 1) out |= low;
+        support ^= low;
+    }
+    return out;
+}
+
+static void classify_groups(struct ls_amd_operator_ext *ext) {
+    ext->is_hermitian = 1;
+    /* diagonal must be real for a Hermitian operator */
+    for (int k = 0; k < ext->n_diag; ++k) if (ext->diag[k].v_im != 0.0) ext->is_hermitian = 0;
+    for (int g = 0; g < ext->n_groups; ++g) {
+        lsk_group *G = &ext->groups[g];
+        uint64_t support = G->x;
+        for (int k = G->begin; k < G->end; ++k) support |= ext->off[k].m | ext->off[k].s;
+        int nb = __builtin_popcountll(support);
+        G->adj = -1;
+        if (__builtin_popcountll(G->x) == 2) {
+            int lo = __builtin_ctzll(G->x);
+            if (G->x == (3ULL << lo)) G->adj = lo;
+        }
+        G->fast = LSK_GROUP_GENERIC;
+        G->v_re = G->v_im = 0.0;
+        if (nb <= 16) {
+            /* exact truth table over the support */
+            int herm = 1;
+            for (uint64_t pat = 0; pat < (1ULL << nb); ++pat) {
+                uint64_t a = deposit_bits(pat, support);
+                double fr, fi, gr, gi;
+                eval_terms(ext->off, G->begin, G->end, a, &fr, &fi);
+                eval_terms(ext->off, G->begin, G->end, a ^ G->x, &gr, &gi);
+                if (fabs(gr - fr) > 1e-12 * (1 + fabs(fr)) || fabs(gi + fi) > 1e-12 * (1 + fabs(fi))) herm = 0;
+            }
+            if (!herm) ext->is_hermitian = 0;
+            if (nb == 2 && support == G->x) {
+                uint64_t b0 = G->x & -G->x, b1 = G->x ^ b0;
+                double f00r, f00i, f01r, f01i, f10r, f10i, f11r, f11i;
+                eval_terms(ext->off, G->begin, G->end, 0, &f00r, &f00i);
+                eval_terms(ext->off, G->begin, G->end, b0, &f01r, &f01i);
+                eval_terms(ext->off, G->begin, G->end, b1, &f10r, &f10i);
+                eval_terms(ext->off, G->begin, G->end, b0 | b1, &f11r, &f11i);
+                if (f00r == 0 && f00i == 0 && f11r == 0 && f11i == 0 && f01r == f10r && f01i == f10i) {
+                    G->fast = LSK_GROUP_EXCHANGE;
+                    G->v_re = f01r;
+                    G->v_im = f01i;
+                }
+            }
+        } else {
+            /* sampled check (fixed seed) */
+            uint64_t z = 0x9e3779b97f4a7c15ULL;
+            for (int it = 0; it < 4096; ++it) {
+                z = ls_amd_hash64_01(z + 0x9e3779b97f4a7c15ULL * (uint64_t)(it + 1));
+                double fr, fi, gr, gi;
+                eval_terms(ext->off, G->begin, G->end, z, &fr, &fi);
+                eval_terms(ext->off, G->begin, G->end, z ^ G->x, &gr, &gi);
+                if (fabs(gr - fr) > 1e-12 * (1 + fabs(fr)) || fabs(gi + fi) > 1e-12 * (1 + fabs(fi))) { ext->is_hermitian = 0; break; }
+            }
+        }
+    }
+}
+
+static ls_hs_nonbranching_terms *make_nbt(lsk_term const *t, uint64_t const *xs, int n, int nbits) {
+    if (n == 0) return NULL; /* the reference tests `p == nil` (ForeignTypes.chpl:219-222) */
+    ls_hs_nonbranching_terms *nb = (ls_hs_nonbranching_terms *)calloc(1, sizeof(*nb));
+    ls_hs_scalar *v = (ls_hs_scalar *)malloc(sizeof(ls_hs_scalar) * n);
+    uint64_t *m = (uint64_t *)malloc(8 * n), *l = (uint64_t *)malloc(8 * n), *r = (uint64_t *)malloc(8 * n),
+             *x = (uint64_t *)malloc(8 * n), *s = (uint64_t *)malloc(8 * n);
+    for (int i = 0; i < n; ++i) {
+        v[i].re = t[i].v_re; v[i].im = t[i].v_im;
+        m[i] = t[i].m; r[i] = t[i].r; x[i] = xs ? xs[i] : 0; s[i] = t[i].s;
+        l[i] = t[i].r ^ (x[i] & t[i].m);
+    }
+    nb->number_terms = n; nb->number_bits = nbits;
+    nb->v = v; nb->m = m; nb->l = l; nb->r = r; nb->x = x; nb->s = s;
+    return nb;
+}
+static void free_nbt(ls_hs_nonbranching_terms *nb) {
+    if (!nb) return;
+    free((void *)nb->v); free((void *)nb->m); free((void *)nb->l); free((void *)nb->r);
+    free((void *)nb->x); free((void *)nb->s); free(nb);
+}
+
+ls_hs_operator *ls_hs_create_operator_from_terms(ls_hs_basis const *basis, int number_terms,
+                                                 double const *v, uint64_t const *m, uint64_t const *r,
+                                                 uint64_t const *x, uint64_t const *s) {
+    uint64_t const site_mask = basis->number_sites >= 64 ? ~0ULL : ((1ULL << basis->number_sites) - 1);
+    raw_term *raw = (raw_term *)malloc(sizeof(raw_term) * (number_terms > 0 ? number_terms : 1));
+    int n = 0;
+    double vmax = 0;
+    for (int i = 0; i < number_terms; ++i) {
+        if ((m[i] | r[i] | x[i] | s[i]) & ~site_mask) { free(raw); set_error("term %d touches sites outside the basis", i); return NULL; }
+        if (r[i] & ~m[i]) continue; /* can never be active */
+        raw_term t = {v[2 * i], v[2 * i + 1], m[i], r[i], x[i], s[i]};
+        /* sign bits inside the projector have a fixed value when the term is active */
+        if (__builtin_popcountll(t.r & t.s) & 1) { t.re = -t.re; t.im = -t.im; }
+        t.s &= ~t.m;
+        raw[n++] = t;
+        double a = fabs(t.re) + fabs(t.im);
+        if (a > vmax) vmax = a;
+    }
+    qsort(raw, n, sizeof(raw_term), raw_cmp);
+    /* merge equal keys */
+    int w = 0;
+    for (int i = 0; i < n;) {
+        raw_term acc = raw[i];
+        int j = i + 1;
+        while (j < n && raw_cmp(&raw[i], &raw[j]) == 0) { acc.re += raw[j].re; acc.im += raw[j].im; ++j; }
+        if (fabs(acc.re) + fabs(acc.im) > 1e-15 * vmax) raw[w++] = acc;
+        i = j;
+    }
+    n = w;
+    ls_hs_operator *op = (ls_hs_operator *)calloc(1, sizeof(*op));
+    struct ls_amd_operator_ext *ext = (struct ls_amd_operator_ext *)calloc(1, sizeof(*ext));
+    op->ext = ext;
+    op->basis = ls_hs_clone_basis(basis);
+    ext->owns_basis = 1;
+    if (!op->basis) { free(raw); free(ext); free(op); return NULL; }
+    int nd = 0;
+    while (nd < n && raw[nd].x == 0) ++nd; /* sorted by x: the diagonal terms come first */
+    ext->n_diag = nd;
+    ext->n_off = n - nd;
+    ext->diag = (lsk_term *)malloc(sizeof(lsk_term) * (nd > 0 ? nd : 1));
+    ext->off = (lsk_term *)malloc(sizeof(lsk_term) * (ext->n_off > 0 ? ext->n_off : 1));
+    uint64_t *offx = (uint64_t *)malloc(8 * (ext->n_off > 0 ? ext->n_off : 1));
+    ext->is_real = 1;
+    for (int i = 0; i < n; ++i) {
+        lsk_term t = {raw[i].re, raw[i].im, raw[i].m, raw[i].r, raw[i].s};
+        if (raw[i].im != 0.0) ext->is_real = 0;
+        if (i < nd) ext->diag[i] = t; else { ext->off[i - nd] = t; offx[i - nd] = raw[i].x; }
+    }
+    ext->groups = (lsk_group *)malloc(sizeof(lsk_group) * (ext->n_off > 0 ? ext->n_off : 1));
+    ext->n_groups = 0;
+    for (int i = 0; i < ext->n_off; ++i) {
+        if (i == 0 || offx[i] != offx[i - 1]) {
+            lsk_group G;
+            memset(&G, 0, sizeof(G));
+            G.x = offx[i];
+            G.begin = i;
+            ext->groups[ext->n_groups++] = G;
+        }
+        ext->groups[ext->n_groups - 1].end = i + 1;
+    }
+    classify_groups(ext);
+    op->diag_terms = make_nbt(ext->diag, NULL, ext->n_diag, basis->number_sites);
+    op->off_diag_terms = make_nbt(ext->off, offx, ext->n_off, basis->number_sites);
+    free(offx);
+    free(raw);
+    return op;
+}
+
+ls_hs_operator *ls_hs_clone_operator(ls_hs_operator const *op) {
+    struct ls_amd_operator_ext const *e = op->ext;
+    int n = e->n_diag + e->n_off;
+    double *v = (double *)malloc(16 * (n > 0 ? n : 1));
+    uint64_t *m = (uint64_t *)malloc(8 * (n > 0 ? n : 1)), *r = (uint64_t *)malloc(8 * (n > 0 ? n : 1)),
+             *x = (uint64_t *)malloc(8 * (n > 0 ? n : 1)), *s = (uint64_t *)malloc(8 * (n > 0 ? n : 1));
+    int k = 0;
+    for (int i = 0; i < e->n_diag; ++i, ++k) {
+        v[2 * k] = e->diag[i].v_re; v[2 * k + 1] = e->diag[i].v_im;
+        m[k] = e->diag[i].m; r[k] = e->diag[i].r; x[k] = 0; s[k] = e->diag[i].s;
+    }
+    for (int g = 0; g < e->n_groups; ++g)
+        for (int i = e->groups[g].begin; i < e->groups[g].end; ++i, ++k) {
+            v[2 * k] = e->off[i].v_re; v[2 * k + 1] = e->off[i].v_im;
+            m[k] = e->off[i].m; r[k] = e->off[i].r; x[k] = e->groups[g].x; s[k] = e->off[i].s;
+        }
+    ls_hs_operator *c = ls_hs_create_operator_from_terms(op->basis, n, v, m, r, x, s);
+    free(v); free(m); free(r); free(x); free(s);
+    return c;
+}
+
+void ls_hs_destroy_operator(ls_hs_operator *op) {
+    if (!op) return;
+    struct ls_amd_operator_ext *e = op->ext;
+    if (e) {
+        if (e->d_groups) lsk_free(e->d_groups);
+        if (e->d_off) lsk_free(e->d_off);
+        if (e->d_diag) lsk_free(e->d_diag);
+        free(e->groups); free(e->off); free(e->diag);
+        if (e->owns_basis) ls_hs_destroy_basis(op->basis);
+        free(e);
+    }
+    free_nbt(op->diag_terms);
+    free_nbt(op->off_diag_terms);
+    free(op);
+}
+
+int ls_hs_operator_max_number_off_diag(ls_hs_operator const *op) { return op->ext->n_groups; }
+bool ls_hs_operator_is_hermitian(ls_hs_operator const *op) { return op->ext->is_hermitian != 0; }
+bool ls_hs_operator_is_real(ls_hs_operator const *op) { return op->ext->is_real != 0; }
+
+static int operator_device(ls_hs_operator const *op, lsk_operator *out) {
+    struct ls_amd_operator_ext *e = op->ext;
+    if (!e->d_groups) {
+        void *p;
+        DEV(lsk_malloc(&p, sizeof(lsk_group) * (e->n_groups > 0 ? e->n_groups : 1)));
+        DEV(lsk_h2d(p, e->groups, sizeof(lsk_group) * e->n_groups));
+        e->d_groups = (lsk_group *)p;
+        DEV(lsk_malloc(&p, sizeof(lsk_term) * (e->n_off > 0 ? e->n_off : 1)));
+        DEV(lsk_h2d(p, e->off, sizeof(lsk_term) * e->n_off));
+        e->d_off = (lsk_term *)p;
+        DEV(lsk_malloc(&p, sizeof(lsk_term) * (e->n_diag > 0 ? e->n_diag : 1)));
+        DEV(lsk_h2d(p, e->diag, sizeof(lsk_term) * e->n_diag));
+        e->d_diag = (lsk_term *)p;
+    }
+    out->n_diag = e->n_diag;
+    out->n_off = e->n_off;
+    out->n_groups = e->n_groups;
+    out->is_real = e->is_real;
+    out->diag = e->d_diag;
+    out->off = e->d_off;
+    out->groups = e->d_groups;
+    return 0;
+}
+
+/* ============================================================================================ */
+/* kernel table                                                                                 */
+/* ============================================================================================ */
+static ls_chpl_kernels g_kernels;
+void ls_hs_internal_set_chpl_kernels(ls_chpl_kernels const *kernels) { g_kernels = *kernels; }
+ls_chpl_kernels const *ls_hs_internal_get_chpl_kernels(void) { return &g_kernels; }
+
+void ls_chpl_init_kernels(void) {
+    ls_chpl_kernels k;
+    k.enumerate_states = (void *)ls_chpl_enumerate_representatives;
+    k.operator_apply_off_diag = (void *)ls_chpl_operator_apply_off_diag;
+    k.operator_apply_diag = (void *)ls_chpl_operator_apply_diag;
+    k.matrix_vector_product = (void *)ls_chpl_matrix_vector_product;
+    ls_hs_internal_set_chpl_kernels(&k);
+}
+
+static int g_initialised = 0;
+void ls_chpl_init(void) {
+    if (g_initialised) return;
+    if (lsk_device_count() < 1) { halt_with("ls_chpl_init: no HIP device available"); return; }
+    char const *dev = getenv("LS_AMD_DEVICE");
+    if (dev && lsk_set_device(atoi(dev)) != 0) { halt_with("ls_chpl_init: %s", lsk_last_error()); return; }
+    ls_chpl_init_kernels();
+    g_initialised = 1;
+}
+void ls_chpl_finalize(void) {
+    if (g_d_binom) { lsk_free(g_d_binom); g_d_binom = NULL; }
+    g_initialised = 0;
+}
+
+void ls_hs_basis_build(ls_hs_basis *basis) {
+    if (basis->representatives.elts) return;
+    typedef void (*enum_fn)(ls_hs_basis *, uint64_t, uint64_t, chpl_external_array *);
+    enum_fn f = (enum_fn)g_kernels.enumerate_states;
+    if (!f) { ls_chpl_init_kernels(); f = (enum_fn)g_kernels.enumerate_states; }
+    chpl_external_array arr = {NULL, 0, NULL};
+    f(basis, ls_hs_min_state_estimate(basis), ls_hs_max_state_estimate(basis), &arr);
+    if (!arr.elts) return;
+    basis_drop_device_caches(basis);
+    basis->representatives = arr;
+    basis->ext->owns_representatives = 1;
+}
+
+/* ============================================================================================ */
+/* plans                                                                                        */
+/* ============================================================================================ */
+typedef struct part_state {
+    int64_t count;
+    uint64_t const *d_reps; /* borrowed */
+    lsk_index index;
+    uint32_t *d_table;      /* owned */
+    double *d_norms;        /* owned (FULL projection) */
+    int rounds;
+    int64_t *send_counts;   /* [rounds][P] host */
+    lsk_round_layout *d_layouts; /* [rounds] device */
+    int64_t max_send_bytes;
+    int64_t *h_beta_off, *h_val_off; /* [rounds][P] host copies of the layout */
+} part_state;
+
+enum { FAMILY_DIRECT_PUSH = 0, FAMILY_DIRECT_PULL = 1, FAMILY_TILE = 2 };
+
+struct ls_amd_plan {
+    ls_hs_operator const *op;
+    lsk_operator dop;
+    lsk_basis dbs;
+    int cplx, P, me, n_local;
+    int family;
+    part_state *parts; /* [n_local] */
+    void *d_send;      /* local mode: staging for one round */
+    int64_t send_capacity;
+    unsigned long long *d_cursors; /* [P] */
+    unsigned long long *d_counts;  /* [P] */
+    int *d_err;
+    int64_t nnz;
+    /* kernel timing ring */
+    int t_capacity, t_count;
+    void **t_start, **t_stop;
+};
+
+static int timing_begin(ls_amd_plan *pl, void *stream) {
+    if (pl->t_count >= pl->t_capacity) return -1;
+    if (lsk_event_record(pl->t_start[pl->t_count], stream) != 0) return -1;
+    return pl->t_count;
+}
+static void timing_end(ls_amd_plan *pl, int slot, void *stream) {
+    if (slot < 0) return;
+    if (lsk_event_record(pl->t_stop[slot], stream) == 0) pl->t_count = slot + 1;
+}
+
+int ls_amd_plan_enable_timing(ls_amd_plan *pl, int max_samples) {
+    for (int i = 0; i < pl->t_capacity; ++i) { lsk_event_destroy(pl->t_start[i]); lsk_event_destroy(pl->t_stop[i]); }
+    free(pl->t_start); free(pl->t_stop);
+    pl->t_start = pl->t_stop = NULL;
+    pl->t_capacity = pl->t_count = 0;
+    if (max_samples <= 0) return 0;
+    pl->t_start = (void **)calloc(max_samples, sizeof(void *));
+    pl->t_stop = (void **)calloc(max_samples, sizeof(void *));
+    for (int i = 0; i < max_samples; ++i) {
+        DEV(lsk_event_create(&pl->t_start[i]));
+        DEV(lsk_event_create(&pl->t_stop[i]));
+        pl->t_capacity = i + 1;
+    }
+    return 0;
+}
+int ls_amd_plan_kernel_times(ls_amd_plan *pl, float *ms, int capacity, int *count) {
+    int n = pl->t_count < capacity ? pl->t_count : capacity;
+    for (int i = 0; i < n; ++i) DEV(lsk_event_elapsed_ms(pl->t_start[i], pl->t_stop[i], &ms[i]));
+    *count = n;
+    pl->t_count = 0;
+    return 0;
+}
+int ls_amd_fill_random(int64_t n, uint64_t const *d_states, uint64_t seed, ls_amd_dtype dtype, void *d_out,
+                       void *stream) {
+    DEV(lsk_fill_random(n, d_states, seed, dtype == LS_AMD_C128, d_out, stream));
+    return 0;
+}
+
+static int64_t rows_per_round_default(void) {
+    char const *e = getenv("LS_AMD_ROWS_PER_ROUND");
+    if (e) { long long v = atoll(e); if (v > 0) return (int64_t)v; }
+    return (int64_t)1 << 24;
+}
+
+static int build_search_index(part_state *ps, int number_sites, void *stream) {
+    if (ps->count >= 0xffffffffLL) return set_error("partitions with >= 2^32 states are not supported");
+    int bits = 0;
+    while ((1LL << (bits + 1)) <= ps->count) ++bits; /* floor(log2(count)) */
+    bits -= 3;
+    if (bits < 1) bits = 1;
+    if (bits > 26) bits = 26;
+    if (bits > number_sites) bits = number_sites;
+    int shift = number_sites - bits;
+    int64_t nbuckets = (int64_t)1 << bits;
+    void *p;
+    DEV(lsk_malloc(&p, 4 * (size_t)(nbuckets + 2)));
+    ps->d_table = (uint32_t *)p;
+    DEV(lsk_build_table(ps->count, ps->d_reps, shift, nbuckets, ps->d_table, stream));
+    ps->index.kind = LSK_INDEX_SEARCH;
+    ps->index.shift = shift;
+    ps->index.table = ps->d_table;
+    return 0;
+}
+
+static int plan_setup_part(ls_amd_plan *pl, part_state *ps, int part_id, int num_rounds, void *stream) {
+    ls_hs_basis const *b = pl->op->basis;
+    int const L = b->number_sites;
+    int const h = b->ext->hamming_weight;
+    uint64_t const *d_binom;
+    if (device_binom(&d_binom) != 0) return -1;
+    ps->index.count = ps->count;
+    ps->index.reps = ps->d_reps;
+    ps->index.binom = d_binom;
+    ps->index.table = NULL;
+    ps->index.shift = 0;
+    ps->index.kind = LSK_INDEX_SEARCH;
+    int closed_form = 0;
+    if (pl->P == 1 && pl->dbs.proj != LSK_PROJ_FULL) {
+        int const Leff = L - (b->spin_inversion != 0 ? 1 : 0);
+        if (h < 0) {
+            if (Leff < 63 && ps->count == ((int64_t)1 << Leff)) { ps->index.kind = LSK_INDEX_IDENTITY; closed_form = 1; }
+        } else if ((uint64_t)ps->count == binom(Leff, h) && ps->count > 0) {
+            /* the basis should be the full fixed-Hamming prefix: verify on the device */
+            int zero = 0, flag = 0;
+            DEV(lsk_h2d(pl->d_err, &zero, sizeof(int)));
+            DEV(lsk_check_combinadic(ps->index, h, ps->count, ps->d_reps, pl->d_err, stream));
+            DEV(lsk_sync(stream));
+            DEV(lsk_d2h(&flag, pl->d_err, sizeof(int)));
+            DEV(lsk_h2d(pl->d_err, &zero, sizeof(int)));
+            if (!flag) { ps->index.kind = LSK_INDEX_COMBINADIC; closed_form = 1; }
+        }
+    }
+    if (!closed_form && ps->count > 0) {
+        if (build_search_index(ps, L, stream) != 0) return -1;
+    }
+    if (pl->family != FAMILY_TILE) return 0;
+
+    if (pl->dbs.proj == LSK_PROJ_FULL) {
+        void *p;
+        DEV(lsk_malloc(&p, 8 * (size_t)(ps->count > 0 ? ps->count : 1)));
+        ps->d_norms = (double *)p;
+        DEV(lsk_norms(pl->dbs, ps->count, ps->d_reps, ps->d_norms, stream));
+    }
+    int rounds = num_rounds;
+    if (rounds <= 0) {
+        int64_t rpr = rows_per_round_default();
+        rounds = (int)((ps->count + rpr - 1) / rpr);
+        if (rounds < 1) rounds = 1;
+    }
+    ps->rounds = rounds;
+    int const P = pl->P;
+    ps->send_counts = (int64_t *)calloc((size_t)rounds * P, sizeof(int64_t));
+    ps->h_beta_off = (int64_t *)calloc((size_t)rounds * P, sizeof(int64_t));
+    ps->h_val_off = (int64_t *)calloc((size_t)rounds * P, sizeof(int64_t));
+    lsk_round_layout *layouts = (lsk_round_layout *)calloc(rounds, sizeof(lsk_round_layout));
+    int const w = pl->cplx ? 16 : 8;
+    unsigned long long hc[LSK_MAX_PARTS];
+    for (int r = 0; r < rounds; ++r) {
+        int64_t row0 = ps->count * r / rounds, row1 = ps->count * (r + 1) / rounds;
+        DEV(lsk_memset_async(pl->d_counts, 0, 8 * LSK_MAX_PARTS, stream));
+        DEV(lsk_tile(pl->dop, pl->dbs, ps->index, pl->cplx, 1, P, part_id, row0, row1, ps->d_reps, ps->d_norms,
+                     NULL, NULL, pl->d_cursors, NULL, NULL, pl->d_counts, pl->d_err, stream));
+        DEV(lsk_sync(stream));
+        DEV(lsk_d2h(hc, pl->d_counts, 8 * (size_t)P));
+        int64_t off = 0;
+        for (int d = 0; d < P; ++d) {
+            pl->nnz += (int64_t)hc[d];
+            int64_t c = (d == part_id) ? 0 : (int64_t)hc[d];
+            ps->send_counts[(size_t)r * P + d] = c;
+            layouts[r].beta_off[d] = off;
+            layouts[r].val_off[d] = off + 8 * c;
+            ps->h_beta_off[(size_t)r * P + d] = off;
+            ps->h_val_off[(size_t)r * P + d] = off + 8 * c;
+            off += (8 + w) * c;
+        }
+        if (off > ps->max_send_bytes) ps->max_send_bytes = off;
+    }
+    void *p;
+    DEV(lsk_malloc(&p, sizeof(lsk_round_layout) * (size_t)rounds));
+    DEV(lsk_h2d(p, layouts, sizeof(lsk_round_layout) * (size_t)rounds));
+    ps->d_layouts = (lsk_round_layout *)p;
+    free(layouts);
+    return 0;
+}
+
+int ls_amd_plan_create(ls_amd_plan **out, ls_hs_operator const *op, ls_amd_dtype dtype,
+                       int num_partitions, int my_partition, uint64_t const *const *d_reps,
+                       int64_t const *counts, int num_rounds, ls_amd_mode mode, void *stream) {
+    *out = NULL;
+    if (!op || !op->basis) return set_error("null operator");
+    if (ls_hs_basis_number_words(op->basis) != 1) return set_error("bases with more than 64 bits are not yet implemented"); /* DMV:1099 */
+    if (num_partitions < 1 || num_partitions > LSK_MAX_PARTS) return set_error("num_partitions must be in [1, %d]", LSK_MAX_PARTS);
+    if (my_partition >= num_partitions) return set_error("my_partition out of range");
+    if (dtype == LS_AMD_F64 && !op->ext->is_real) return set_error("an operator with complex coefficients needs dtype c128");
+    ls_amd_plan *pl = (ls_amd_plan *)calloc(1, sizeof(*pl));
+    pl->op = op;
+    pl->cplx = dtype == LS_AMD_C128;
+    pl->P = num_partitions;
+    pl->me = my_partition;
+    pl->n_local = my_partition < 0 ? num_partitions : 1;
+    if (operator_device(op, &pl->dop) != 0 || basis_device(op->basis, &pl->dbs) != 0) { free(pl); return -1; }
+    if (dtype == LS_AMD_F64) {
+        /* f64 vectors: characters must be real as well (the reference casts c128 -> f64, DMV:91,109) */
+        for (int g = 0; g < op->basis->ext->order; ++g)
+            if (op->basis->ext->elems[g].ch_im != 0.0) { free(pl); return set_error("complex characters need dtype c128"); }
+    }
+    /* kernel family */
+    if (num_partitions == 1 && pl->dbs.proj != LSK_PROJ_FULL) {
+        ls_amd_mode m = mode;
+        if (m == LS_AMD_MODE_AUTO) {
+            char const *e = getenv("LS_AMD_MODE");
+            if (e && strcmp(e, "pull") == 0) m = LS_AMD_MODE_PULL;
+            else if (e && strcmp(e, "push") == 0) m = LS_AMD_MODE_PUSH;
+            else m = LS_AMD_MODE_PUSH;
+        }
+        if (m == LS_AMD_MODE_PULL && !op->ext->is_hermitian) {
+            if (mode == LS_AMD_MODE_PULL) { free(pl); return set_error("pull mode needs a Hermitian operator"); }
+            m = LS_AMD_MODE_PUSH;
+        }
+        pl->family = m == LS_AMD_MODE_PULL ? FAMILY_DIRECT_PULL : FAMILY_DIRECT_PUSH;
+    } else pl->family = FAMILY_TILE;
+
+    void *p;
+    if (lsk_malloc(&p, 8 * LSK_MAX_PARTS) != 0) { free(pl); return dev_error(); }
+    pl->d_cursors = (unsigned long long *)p;
+    if (lsk_malloc(&p, 8 * LSK_MAX_PARTS) != 0) { free(pl); return dev_error(); }
+    pl->d_counts = (unsigned long long *)p;
+    if (lsk_malloc(&p, sizeof(int)) != 0) { free(pl); return dev_error(); }
+    pl->d_err = (int *)p;
+    int zero = 0;
+    lsk_h2d(pl->d_err, &zero, sizeof(int));
+
+    pl->parts = (part_state *)calloc(pl->n_local, sizeof(part_state));
+    for (int i = 0; i < pl->n_local; ++i) {
+        part_state *ps = &pl->parts[i];
+        ps->count = counts[i];
+        ps->d_reps = d_reps[i];
+        int pid = my_partition < 0 ? i : my_partition;
+        if (plan_setup_part(pl, ps, pid, num_rounds, stream) != 0) { ls_amd_plan_destroy(pl); return -1; }
+        if (ps->max_send_bytes > pl->send_capacity) pl->send_capacity = ps->max_send_bytes;
+    }
+    if (pl->family == FAMILY_TILE && my_partition < 0 && pl->send_capacity > 0) {
+        if (lsk_malloc(&pl->d_send, (size_t)pl->send_capacity) != 0) { ls_amd_plan_destroy(pl); return dev_error(); }
+    }
+    if (lsk_sync(stream) != 0) { ls_amd_plan_destroy(pl); return dev_error(); }
+    *out = pl;
+    return 0;
+}
+
+void ls_amd_plan_destroy(ls_amd_plan *pl) {
+    if (!pl) return;
+    if (pl->parts) {
+        for (int i = 0; i < pl->n_local; ++i) {
+            part_state *ps = &pl->parts[i];
+            if (ps->d_table) lsk_free(ps->d_table);
+            if (ps->d_norms) lsk_free(ps->d_norms);
+            if (ps->d_layouts) lsk_free(ps->d_layouts);
+            free(ps->send_counts); free(ps->h_beta_off); free(ps->h_val_off);
+        }
+        free(pl->parts);
+    }
+    if (pl->d_send) lsk_free(pl->d_send);
+    if (pl->d_cursors) lsk_free(pl->d_cursors);
+    if (pl->d_counts) lsk_free(pl->d_counts);
+    if (pl->d_err) lsk_free(pl->d_err);
+    ls_amd_plan_enable_timing(pl, 0);
+    free(pl);
+}
+
+int ls_amd_plan_num_rounds(ls_amd_plan const *pl) { return pl->family == FAMILY_TILE ? pl->parts[0].rounds : 1; }
+char const *ls_amd_plan_kernel_name(ls_amd_plan const *pl) {
+    switch (pl->family) {
+    case FAMILY_DIRECT_PUSH: return "direct-push";
+    case FAMILY_DIRECT_PULL: return "direct-pull";
+    default: return "tile";
+    }
+}
+int ls_amd_plan_packet_bytes(ls_amd_plan const *pl) { return pl->cplx ? 24 : 16; }
+int64_t ls_amd_plan_nnz(ls_amd_plan const *pl) { return pl->nnz; }
+int ls_amd_plan_send_counts(ls_amd_plan const *pl, int round, int64_t *counts) {
+    if (pl->family != FAMILY_TILE) { for (int d = 0; d < pl->P; ++d) counts[d] = 0; return 0; }
+    part_state const *ps = &pl->parts[0];
+    if (round < 0 || round >= ps->rounds) return set_error("round out of range");
+    memcpy(counts, ps->send_counts + (size_t)round * pl->P, sizeof(int64_t) * pl->P);
+    return 0;
+}
+
+int ls_amd_diag(ls_amd_plan *pl, void const *d_x, void *d_y, void *stream) {
+    part_state *ps = &pl->parts[0];
+    DEV(lsk_diag(pl->dop, pl->cplx, ps->count, ps->d_reps, d_x, d_y, stream));
+    return 0;
+}
+
+static int generate_round(ls_amd_plan *pl, part_state *ps, int pid, int round, void const *d_x, void *d_y,
+                          void *d_send, void *stream) {
+    int64_t row0 = ps->count * round / ps->rounds, row1 = ps->count * (round + 1) / ps->rounds;
+    if (pl->P > 1) DEV(lsk_memset_async(pl->d_cursors, 0, 8 * (size_t)pl->P, stream));
+    int slot = timing_begin(pl, stream);
+    DEV(lsk_tile(pl->dop, pl->dbs, ps->index, pl->cplx, 0, pl->P, pid, row0, row1, ps->d_reps, ps->d_norms, d_x,
+                 d_y, pl->d_cursors, ps->d_layouts + round, d_send, pl->d_counts, pl->d_err, stream));
+    timing_end(pl, slot, stream);
+    return 0;
+}
+
+int ls_amd_generate(ls_amd_plan *pl, int round, void const *d_x, void *d_y, void *d_send, void *stream) {
+    if (pl->family != FAMILY_TILE) return set_error("ls_amd_generate: the plan uses a direct kernel (P == 1)");
+    if (pl->me < 0) return set_error("ls_amd_generate: plan owns all partitions; use ls_amd_matvec");
+    part_state *ps = &pl->parts[0];
+    if (round < 0 || round >= ps->rounds) return set_error("round out of range");
+    return generate_round(pl, ps, pl->me, round, d_x, d_y, d_send, stream);
+}
+
+int ls_amd_scatter(ls_amd_plan *pl, int64_t n, uint64_t const *d_betas, void const *d_values, void *d_y,
+                   void *stream) {
+    part_state *ps = &pl->parts[0];
+    if (ps->index.kind == LSK_INDEX_COMBINADIC) return set_error("ls_amd_scatter: plan has no search index");
+    DEV(lsk_scatter(ps->index, pl->cplx, n, d_betas, d_values, d_y, pl->d_err, stream));
+    return 0;
+}
+
+int ls_amd_matvec(ls_amd_plan *pl, void const *const *d_x, void *const *d_y, void *stream) {
+    if (pl->me >= 0) return set_error("ls_amd_matvec: plan owns one partition; drive it with generate/scatter");
+    /* localDiagonal on every partition first: y is assigned (DMV:1062-1063) */
+    if (pl->family != FAMILY_DIRECT_PULL)
+        for (int p = 0; p < pl->n_local; ++p)
+            DEV(lsk_diag(pl->dop, pl->cplx, pl->parts[p].count, pl->parts[p].d_reps, d_x[p], d_y[p], stream));
+    if (pl->dop.n_groups == 0 && pl->family != FAMILY_DIRECT_PULL) return 0;
+    if (pl->family != FAMILY_TILE) {
+        part_state *ps = &pl->parts[0];
+        int slot = timing_begin(pl, stream);
+        DEV(lsk_direct(pl->dop, pl->dbs, ps->index, pl->cplx, pl->family == FAMILY_DIRECT_PULL, ps->count,
+                       ps->d_reps, d_x[0], d_y[0], pl->d_err, stream));
+        timing_end(pl, slot, stream);
+        return 0;
+    }
+    int const P = pl->P;
+    for (int p = 0; p < P; ++p) {
+        part_state *ps = &pl->parts[p];
+        for (int r = 0; r < ps->rounds; ++r) {
+            if (generate_round(pl, ps, p, r, d_x[p], d_y[p], pl->d_send, stream) != 0) return -1;
+            /* the "exchange": every destination consumes its segment straight from the send buffer */
+            for (int d = 0; d < P; ++d) {
+                int64_t c = ps->send_counts[(size_t)r * P + d];
+                if (d == p || c == 0) continue;
+                uint64_t const *betas = (uint64_t const *)((char *)pl->d_send + ps->h_beta_off[(size_t)r * P + d]);
+                void const *vals = (char *)pl->d_send + ps->h_val_off[(size_t)r * P + d];
+                DEV(lsk_scatter(pl->parts[d].index, pl->cplx, c, betas, vals, d_y[d], pl->d_err, stream));
+            }
+        }
+    }
+    return 0;
+}
+
+int ls_amd_plan_check(ls_amd_plan *pl, void *stream) {
+    int flag = 0, zero = 0;
+    DEV(lsk_sync(stream));
+    DEV(lsk_d2h(&flag, pl->d_err, sizeof(int)));
+    if (flag) {
+        DEV(lsk_h2d(pl->d_err, &zero, sizeof(int)));
+        return set_error("invalid index: the operator generated a state outside the basis "
+                         "(it does not respect the basis symmetries)"); /* DMV:115-118 */
+    }
+    return 0;
+}
+
+/* ============================================================================================ */
+/* enumeration and layout converters                                                            */
+/* ============================================================================================ */
+static int64_t candidate_count(ls_hs_basis const *b) {
+    int const Leff = b->number_sites - (b->spin_inversion != 0 ? 1 : 0);
+    int const h = b->ext->hamming_weight;
+    if (h >= 0) return (int64_t)binom(Leff, h);
+    if (Leff >= 62) return -1;
+    return (int64_t)1 << Leff;
+}
+
+int ls_amd_enumerate_states(ls_hs_basis const *basis, int num_locales, uint64_t **d_states, uint8_t **d_masks,
+                            int64_t *count, void *stream) {
+    lsk_basis dbs;
+    uint64_t const *d_binom;
+    if (basis_device(basis, &dbs) != 0 || device_binom(&d_binom) != 0) return -1;
+    int64_t ncand = candidate_count(basis);
+    if (ncand < 0) return set_error("basis too large to enumerate");
+    DEV(lsk_enumerate(dbs, d_binom, ncand, d_states, count, stream));
+    if (d_masks) {
+        void *p;
+        DEV(lsk_malloc(&p, (size_t)(*count > 0 ? *count : 1)));
+        *d_masks = (uint8_t *)p;
+        DEV(lsk_masks(*count, *d_states, num_locales < 1 ? 1 : num_locales, *d_masks, stream));
+        DEV(lsk_sync(stream));
+    }
+    return 0;
+}
+int ls_amd_mask_counts(int64_t n, uint8_t const *d_masks, int num_locales, int64_t *counts, void *stream) {
+    DEV(lsk_mask_counts(n, d_masks, num_locales, counts, stream));
+    return 0;
+}
+int ls_amd_block_to_hashed(int64_t n, uint8_t const *d_masks, int num_locales, int elt_size, void const *d_src,
+                           void *const *d_dest, void *stream) {
+    DEV(lsk_block_to_hashed(n, d_masks, num_locales, elt_size, d_src, d_dest, stream));
+    return 0;
+}
+int ls_amd_hashed_to_block(int64_t n, uint8_t const *d_masks, int num_locales, int elt_size,
+                           void const *const *d_src, void *d_dest, void *stream) {
+    DEV(lsk_hashed_to_block(n, d_masks, num_locales, elt_size, d_src, d_dest, stream));
+    return 0;
+}
+
+/* ============================================================================================ */
+/* ls_chpl_* exports (host pointers; stage through HBM)                                          */
+/* ============================================================================================ */
+void ls_chpl_enumerate_representatives(ls_hs_basis *basisPtr, uint64_t lower, uint64_t upper,
+                                       chpl_external_array *dest) {
+    (void)lower; (void)upper; /* ignored exactly as in the reference (StatesEnumeration.chpl:596) */
+    uint64_t *d_states = NULL;
+    int64_t count = 0;
+    if (ls_amd_enumerate_states(basisPtr, 1, &d_states, NULL, &count, NULL) != 0) {
+        halt_with("ls_chpl_enumerate_representatives: %s", g_last_error);
+        return;
+    }
+    uint64_t *h = (uint64_t *)malloc(8 * (size_t)(count > 0 ? count : 1));
+    if (lsk_d2h(h, d_states, 8 * (size_t)count) != 0) { free(h); lsk_free(d_states); halt_with("%s", lsk_last_error()); return; }
+    lsk_free(d_states);
+    dest->elts = h;
+    dest->num_elts = (uint64_t)count;
+    dest->freer = (void *)free;
+}
+
+static int ensure_device_reps(ls_hs_basis *b) {
+    struct ls_amd_basis_ext *e = b->ext;
+    if (!b->representatives.elts) return set_error("basis is not built"); /* ForeignTypes.chpl:113-114 */
+    if (e->d_reps_cache && e->d_reps_count == b->representatives.num_elts) return 0;
+    basis_drop_device_caches(b);
+    void *p;
+    DEV(lsk_malloc(&p, 8 * (size_t)b->representatives.num_elts));
+    DEV(lsk_h2d(p, b->representatives.elts, 8 * (size_t)b->representatives.num_elts));
+    e->d_reps_cache = (uint64_t *)p;
+    e->d_reps_count = b->representatives.num_elts;
+    return 0;
+}
+
+/* localMatrixVector on host vectors (numLocales == 1) */
+static int host_matvec_f64(ls_hs_operator *op, int64_t n, double const *x, double *y) {
+    ls_hs_basis *b = op->basis;
+    struct ls_amd_basis_ext *e = b->ext;
+    if (ensure_device_reps(b) != 0) return -1;
+    if ((uint64_t)n != e->d_reps_count) return set_error("vector length does not match the number of representatives");
+    if (!e->host_plan_f64) {
+        ls_amd_plan *pl;
+        uint64_t const *reps[1] = {e->d_reps_cache};
+        int64_t counts[1] = {n};
+        if (ls_amd_plan_create(&pl, op, LS_AMD_F64, 1, -1, reps, counts, 0, LS_AMD_MODE_AUTO, NULL) != 0) return -1;
+        e->host_plan_f64 = pl;
+    }
+    ls_amd_plan *pl = (ls_amd_plan *)e->host_plan_f64;
+    pl->op = op;
+    void *dx, *dy;
+    DEV(lsk_malloc(&dx, 8 * (size_t)n));
+    DEV(lsk_malloc(&dy, 8 * (size_t)n));
+    int rc = 0;
+    if (lsk_h2d(dx, x, 8 * (size_t)n) != 0 || lsk_h2d(dy, y, 8 * (size_t)n) != 0) rc = dev_error();
+    void const *xs[1] = {dx};
+    void *ys[1] = {dy};
+    if (rc == 0) rc = ls_amd_matvec(pl, xs, ys, NULL);
+    if (rc == 0) rc = ls_amd_plan_check(pl, NULL);
+    if (rc == 0 && lsk_d2h(y, dy, 8 * (size_t)n) != 0) rc = dev_error();
+    lsk_free(dx);
+    lsk_free(dy);
+    return rc;
+}
+
+void ls_chpl_matrix_vector_product(ls_hs_operator *matrixPtr, int numVectors, double *xPtr, double *yPtr) {
+    if (ls_hs_basis_number_words(matrixPtr->basis) != 1) { halt_with("bases with more than 64 bits are not yet implemented"); return; }
+    if (numVectors != 1) { halt_with("applying the Operator to more than 1 vector is not yet implemented"); return; }
+    if (!matrixPtr->basis->representatives.elts) { halt_with("basis is not built"); return; }
+    int64_t n = (int64_t)matrixPtr->basis->representatives.num_elts;
+    if (host_matvec_f64(matrixPtr, n, xPtr, yPtr) != 0) halt_with("%s", g_last_error);
+}
+
+void ls_chpl_primme_matvec(void *x, int64_t *ldx, void *y, int64_t *ldy, int *blockSize, void *primme,
+                           int *ierr) {
+    ls_primme_params_view *pp = (ls_primme_params_view *)primme;
+    ls_hs_operator *op = (ls_hs_operator *)pp->matrix;
+    int64_t n = pp->nLocal;
+    *ierr = 0;
+    if (*ldx < n || *ldy < n) { *ierr = -1; return; }
+    for (int k = 0; k < *blockSize; ++k)
+        if (host_matvec_f64(op, n, (double const *)x + *ldx * k, (double *)y + *ldy * k) != 0) {
+            halt_with("%s", g_last_error);
+            *ierr = -1;
+            return;
+        }
+}
+void primmeGlobalSumReal(void *sendBuf, void *recvBuf, int *count, void *primme, int *ierr) {
+    (void)primme;
+    if (sendBuf != recvBuf) memmove(recvBuf, sendBuf, sizeof(double) * (size_t)*count);
+    *ierr = 0;
+}
+void primmeBroadcastReal(void *buffer, int *count, void *primme, int *ierr) {
+    (void)buffer; (void)count; (void)primme;
+    *ierr = 0;
+}
+
+static void free_array(void *p) { free(p); }
+
+void ls_chpl_operator_apply_diag(ls_hs_operator *matrixPtr, int64_t count, uint64_t *alphas,
+                                 chpl_external_array *coeffs, int64_t numTasks) {
+    (void)numTasks;
+    if (ls_hs_basis_number_words(matrixPtr->basis) != 1) { halt_with("bases with more than 64 bits are not yet implemented"); return; }
+    if (matrixPtr->basis->requires_projection) { halt_with("bases that require projection are not yet supported"); return; }
+    lsk_operator dop;
+    if (operator_device(matrixPtr, &dop) != 0) { halt_with("%s", g_last_error); return; }
+    double *h = (double *)malloc(8 * (size_t)(count > 0 ? count : 1));
+    void *da = NULL, *dy = NULL;
+    int rc = lsk_malloc(&da, 8 * (size_t)count) || lsk_malloc(&dy, 8 * (size_t)count) ||
+             lsk_h2d(da, alphas, 8 * (size_t)count) ||
+             lsk_diag_coeffs(dop, count, (uint64_t const *)da, (double *)dy, NULL, NULL) || lsk_sync(NULL) ||
+             lsk_d2h(h, dy, 8 * (size_t)count);
+    lsk_free(da); lsk_free(dy);
+    if (rc) { free(h); halt_with("%s", lsk_last_error()); return; }
+    coeffs->elts = h;
+    coeffs->num_elts = (uint64_t)count;
+    coeffs->freer = (void *)free_array;
+}
+
+void ls_chpl_operator_apply_off_diag(ls_hs_operator *matrixPtr, int64_t count, uint64_t *alphas,
+                                     chpl_external_array *betas, chpl_external_array *coeffs,
+                                     chpl_external_array *offsets, int64_t numTasks) {
+    (void)numTasks;
+    if (ls_hs_basis_number_words(matrixPtr->basis) != 1) { halt_with("bases with more than 64 bits are not yet implemented"); return; }
+    if (matrixPtr->basis->requires_projection) { halt_with("bases that require projection are not yet supported"); return; }
+    int const T = matrixPtr->ext->n_groups;
+    int64_t *h_off = (int64_t *)calloc((size_t)count + 1, sizeof(int64_t));
+    if (T == 0) {
+        betas->elts = NULL; betas->num_elts = 0; betas->freer = NULL;
+        coeffs->elts = NULL; coeffs->num_elts = 0; coeffs->freer = NULL;
+        offsets->elts = h_off; offsets->num_elts = (uint64_t)count + 1; offsets->freer = (void *)free_array;
+        return;
+    }
+    lsk_operator dop;
+    if (operator_device(matrixPtr, &dop) != 0) { free(h_off); halt_with("%s", g_last_error); return; }
+    size_t cap = (size_t)count * (size_t)T;
+    uint64_t *h_b = (uint64_t *)calloc(cap ? cap : 1, 8);
+    double *h_c = (double *)calloc(cap ? cap : 1, 16);
+    void *da = NULL, *dcnt = NULL, *doff = NULL, *db = NULL, *dc = NULL;
+    int rc = lsk_malloc(&da, 8 * (size_t)count) || lsk_malloc(&dcnt, 8 * ((size_t)count + 1)) ||
+             lsk_malloc(&doff, 8 * ((size_t)count + 1)) || lsk_malloc(&db, 8 * cap) || lsk_malloc(&dc, 16 * cap) ||
+             lsk_h2d(da, alphas, 8 * (size_t)count) || lsk_memset_async(dcnt, 0, 8 * ((size_t)count + 1), NULL) ||
+             lsk_offdiag_counts(dop, count, (uint64_t const *)da, (int64_t *)dcnt, NULL) ||
+             lsk_exclusive_scan_i64(count + 1, (int64_t const *)dcnt, (int64_t *)doff, NULL) ||
+             lsk_offdiag_fill(dop, count, (uint64_t const *)da, (int64_t const *)doff, (uint64_t *)db, (double *)dc, NULL, NULL) ||
+             lsk_sync(NULL) || lsk_d2h(h_off, doff, 8 * ((size_t)count + 1));
+    if (!rc) {
+        size_t total = (size_t)h_off[count];
+        rc = lsk_d2h(h_b, db, 8 * total) || lsk_d2h(h_c, dc, 16 * total);
+    }
+    lsk_free(da); lsk_free(dcnt); lsk_free(doff); lsk_free(db); lsk_free(dc);
+    if (rc) { free(h_off); free(h_b); free(h_c); halt_with("%s", lsk_last_error()); return; }
+    betas->elts = h_b; betas->num_elts = cap; betas->freer = (void *)free_array;
+    coeffs->elts = h_c; coeffs->num_elts = cap; coeffs->freer = (void *)free_array;
+    offsets->elts = h_off; offsets->num_elts = (uint64_t)count + 1; offsets->freer = (void *)free_array;
+}

@@ -1,0 +1,1014 @@
+// kernels.hip -- hand-written HIP (gfx950 / CDNA4) kernels of the matrix-free y <- H x hot path and
+// the thin extern-"C" shim (lsk_*) the C host side calls.  No MFMA anywhere: this path is irregular
+// integer/bit work plus gather/scatter, bounded by HBM and (for symmetry-projected bases) integer ALU.
+//
+// Reference call sites replaced:
+//   K1 localDiagonalBatch            /root/reference/src/DistributedMatrixVector.chpl:36-53
+//   K2 computeOffDiag                /root/reference/src/BatchedOperator.chpl:82-116
+//   K3 spin-inversion canonicalise   /root/reference/src/BatchedOperator.chpl:139-153
+//   K4 symmetry projection           /root/reference/src/BatchedOperator.chpl:163-203
+//   K5 hash64_01 % numLocales        /root/reference/src/StatesEnumeration.chpl:122-136
+//   K6 radixOneStep                  /root/reference/src/DistributedMatrixVector.chpl:265-311
+//   K7 ls_hs_state_index             /root/reference/src/DistributedMatrixVector.chpl:96-103
+//   K8 ConcurrentAccessor.localAdd   /root/reference/src/ConcurrentAccessor.chpl:48-54
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+
+#include "lsk.h"
+
+// ---------------------------------------------------------------------------------------------
+// runtime shim
+// ---------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+#define LSK_CHECK(expr)                                                                          \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess) {                                                                  \
+            snprintf(g_err, sizeof(g_err), "%s:%d: %s failed: %s", __FILE__, __LINE__, #expr,    \
+                     hipGetErrorString(e_));                                                     \
+            return -1;                                                                           \
+        }                                                                                        \
+    } while (0)
+
+#define LSK_LAUNCH_CHECK() LSK_CHECK(hipGetLastError())
+
+extern "C" char const *lsk_last_error(void) { return g_err; }
+extern "C" int lsk_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+extern "C" int lsk_set_device(int device) { LSK_CHECK(hipSetDevice(device)); return 0; }
+extern "C" int lsk_malloc(void **p, size_t bytes) {
+    *p = nullptr;
+    if (bytes == 0) bytes = 8;
+    LSK_CHECK(hipMalloc(p, bytes));
+    return 0;
+}
+extern "C" int lsk_free(void *p) { if (p) LSK_CHECK(hipFree(p)); return 0; }
+extern "C" int lsk_h2d(void *dst, void const *src, size_t bytes) {
+    if (bytes) LSK_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return 0;
+}
+extern "C" int lsk_d2h(void *dst, void const *src, size_t bytes) {
+    if (bytes) LSK_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+extern "C" int lsk_d2d_async(void *dst, void const *src, size_t bytes, void *stream) {
+    if (bytes) LSK_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return 0;
+}
+extern "C" int lsk_memset_async(void *p, int value, size_t bytes, void *stream) {
+    if (bytes) LSK_CHECK(hipMemsetAsync(p, value, bytes, (hipStream_t)stream));
+    return 0;
+}
+extern "C" int lsk_sync(void *stream) { LSK_CHECK(hipStreamSynchronize((hipStream_t)stream)); return 0; }
+
+extern "C" int lsk_event_create(void **ev) { hipEvent_t e; LSK_CHECK(hipEventCreate(&e)); *ev = (void *)e; return 0; }
+extern "C" int lsk_event_destroy(void *ev) { if (ev) LSK_CHECK(hipEventDestroy((hipEvent_t)ev)); return 0; }
+extern "C" int lsk_event_record(void *ev, void *stream) { LSK_CHECK(hipEventRecord((hipEvent_t)ev, (hipStream_t)stream)); return 0; }
+extern "C" int lsk_event_elapsed_ms(void *start, void *stop, float *ms) {
+    LSK_CHECK(hipEventSynchronize((hipEvent_t)stop));
+    LSK_CHECK(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------------------------
+constexpr int kBlock = 256;
+constexpr int kMaxGrid = 256 * 8; // 256 CUs x 8 resident blocks: grid-stride beyond this
+
+static inline int grid_for(int64_t n, int per_block = kBlock) {
+    int64_t b = (n + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    if (b > kMaxGrid) b = kMaxGrid;
+    return (int)b;
+}
+
+// K5: splitmix64 finaliser (StatesEnumeration.chpl:122-127)
+__device__ __forceinline__ uint64_t hash64_01(uint64_t x) {
+    x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ULL;
+    x = (x ^ (x >> 27)) * 0x94d049bb133111ebULL;
+    x = x ^ (x >> 31);
+    return x;
+}
+
+// owner = hash % P with 32-bit arithmetic only (a true modulo: P = 3 must work, not just 2^k)
+struct Owner {
+    uint32_t P;
+    uint32_t pmask;    // P - 1 when P is a power of two, else 0xffffffff
+    uint32_t two32mod; // 2^32 mod P
+};
+static inline Owner make_owner(int P) {
+    Owner o;
+    o.P = (uint32_t)P;
+    o.pmask = ((P & (P - 1)) == 0) ? (uint32_t)(P - 1) : 0xffffffffu;
+    o.two32mod = (uint32_t)((1ULL << 32) % (uint64_t)P);
+    return o;
+}
+__device__ __forceinline__ int owner_of(uint64_t s, Owner o) {
+    uint64_t h = hash64_01(s);
+    if (o.pmask != 0xffffffffu) return (int)((uint32_t)h & o.pmask);
+    uint32_t hi = (uint32_t)(h >> 32), lo = (uint32_t)h;
+    uint32_t r = hi % o.P;
+    return (int)((r * o.two32mod + lo % o.P) % o.P);
+}
+
+// K8: relaxed, agent-scope f64 add.  unsafeAtomicAdd lowers to global_atomic_add_f64 on gfx950 for
+// coarse-grained (hipMalloc) memory -- checked in the ISA dump, see DESIGN.md.
+__device__ __forceinline__ void atomic_add_f64(double *p, double v) { unsafeAtomicAdd(p, v); }
+
+template <bool REAL>
+__device__ __forceinline__ void term_sum(lsk_term const *__restrict__ terms, int b, int e, uint64_t a,
+                                         double &cr, double &ci) {
+    cr = 0.0;
+    ci = 0.0;
+    for (int t = b; t < e; ++t) {
+        lsk_term T = terms[t];
+        if ((a & T.m) == T.r) {
+            bool neg = __popcll(a & T.s) & 1;
+            cr += neg ? -T.v_re : T.v_re;
+            if (!REAL) ci += neg ? -T.v_im : T.v_im;
+        }
+    }
+}
+
+// K2: coefficient of one flip-mask group on state a
+template <bool REAL>
+__device__ __forceinline__ void group_coeff(lsk_group const &G, lsk_term const *__restrict__ off,
+                                            uint64_t a, double &cr, double &ci) {
+    if (G.fast == LSK_GROUP_EXCHANGE) {
+        bool act = __popcll(a & G.x) == 1;
+        cr = act ? G.v_re : 0.0;
+        ci = (!REAL && act) ? G.v_im : 0.0;
+        return;
+    }
+    term_sum<REAL>(off, G.begin, G.end, a, cr, ci);
+}
+
+// combinadic rank among equal-popcount integers (ls_hs_fixed_hamming_state_to_index, FFI.chpl:165)
+__device__ __forceinline__ int64_t rank_combinadic(uint64_t s, uint64_t const *binom) {
+    int64_t idx = 0;
+    int k = 1;
+    while (s) {
+        int p = __ffsll((unsigned long long)s) - 1;
+        idx += (int64_t)binom[p * LSK_BINOM_K + k];
+        ++k;
+        s &= s - 1;
+    }
+    return idx;
+}
+__device__ __forceinline__ uint64_t unrank_combinadic(int64_t idx, int hamming, uint64_t const *binom) {
+    uint64_t s = 0;
+    int p = 63;
+    for (int k = hamming; k >= 1; --k) {
+        while (p > k - 1 && (int64_t)binom[p * LSK_BINOM_K + k] > idx) --p;
+        // p is now the largest position with C(p, k) <= idx
+        s |= 1ULL << p;
+        idx -= (int64_t)binom[p * LSK_BINOM_K + k];
+        --p;
+    }
+    return s;
+}
+// Gosper's hack (StatesEnumeration.chpl:31-34)
+__device__ __forceinline__ uint64_t next_fixed_hamming(uint64_t v) {
+    uint64_t t = v | (v - 1);
+    return (t + 1) | (((~t & (t + 1)) - 1) >> (__ffsll((unsigned long long)v)));
+}
+
+// K7: prefix-bucket table + binary search in the ascending representatives
+__device__ __forceinline__ int64_t search_index(lsk_index const &ix, uint64_t s) {
+    uint64_t b = s >> ix.shift;
+    uint32_t lo = ix.table[b], hi = ix.table[b + 1];
+    const uint32_t end = hi;
+    while (lo < hi) {
+        uint32_t mid = lo + ((hi - lo) >> 1);
+        if (ix.reps[mid] < s) lo = mid + 1; else hi = mid;
+    }
+    return (lo < end && ix.reps[lo] == s) ? (int64_t)lo : -1;
+}
+
+// one symmetry-group element applied to a state
+__device__ __forceinline__ uint64_t delta_swap(uint64_t x, uint64_t m, int d) {
+    uint64_t t = ((x >> d) ^ x) & m;
+    return x ^ t ^ (t << d);
+}
+__device__ __forceinline__ uint64_t apply_elem(lsk_group_elem const &e, uint64_t x, int L, uint64_t mask) {
+    if (e.kind == LSK_ELEM_BENES) {
+        if (e.masks[0]) x = delta_swap(x, e.masks[0], 32);
+        if (e.masks[1]) x = delta_swap(x, e.masks[1], 16);
+        if (e.masks[2]) x = delta_swap(x, e.masks[2], 8);
+        if (e.masks[3]) x = delta_swap(x, e.masks[3], 4);
+        if (e.masks[4]) x = delta_swap(x, e.masks[4], 2);
+        if (e.masks[5]) x = delta_swap(x, e.masks[5], 1);
+        if (e.masks[6]) x = delta_swap(x, e.masks[6], 2);
+        if (e.masks[7]) x = delta_swap(x, e.masks[7], 4);
+        if (e.masks[8]) x = delta_swap(x, e.masks[8], 8);
+        if (e.masks[9]) x = delta_swap(x, e.masks[9], 16);
+        if (e.masks[10]) x = delta_swap(x, e.masks[10], 32);
+        return x;
+    }
+    if (e.kind == LSK_ELEM_REVROT) x = __brevll(x) >> (64 - L);
+    int k = e.k;
+    if (k == 0) return x;
+    return ((x >> k) | (x << (L - k))) & mask;
+}
+
+// K4: ls_hs_state_info -- orbit minimum, conj(character) of a minimising element, stabiliser sum
+__device__ __forceinline__ void state_info(lsk_basis const &bs, lsk_group_elem const *__restrict__ elems,
+                                           uint64_t a, uint64_t &rep, double &chr, double &chi, double &stab) {
+    uint64_t best = ~0ULL;
+    double bcr = 1.0, bci = 0.0, st = 0.0;
+    const int inv = bs.spin_inversion;
+    const double dinv = (double)inv;
+    for (int g = 0; g < bs.n_elems; ++g) {
+        lsk_group_elem const &e = elems[g];
+        uint64_t t = apply_elem(e, a, bs.number_sites, bs.site_mask);
+        if (t == a) st += e.ch_re;
+        if (t < best) { best = t; bcr = e.ch_re; bci = e.ch_im; }
+        if (inv != 0) {
+            uint64_t tf = t ^ bs.site_mask;
+            if (tf == a) st += e.ch_re * dinv;
+            if (tf < best) { best = tf; bcr = e.ch_re * dinv; bci = e.ch_im * dinv; }
+        }
+    }
+    rep = best;
+    chr = bcr;
+    chi = -bci;
+    stab = st;
+}
+
+// ls_hs_is_representative with early exit: false as soon as some element maps below a
+__device__ __forceinline__ bool is_representative(lsk_basis const &bs, lsk_group_elem const *__restrict__ elems,
+                                                  uint64_t a) {
+    double st = 0.0;
+    const int inv = bs.spin_inversion;
+    for (int g = 0; g < bs.n_elems; ++g) {
+        lsk_group_elem const &e = elems[g];
+        uint64_t t = apply_elem(e, a, bs.number_sites, bs.site_mask);
+        if (t < a) return false;
+        if (t == a) st += e.ch_re;
+        if (inv != 0) {
+            uint64_t tf = t ^ bs.site_mask;
+            if (tf < a) return false;
+            if (tf == a) st += e.ch_re * (double)inv;
+        }
+    }
+    return st * bs.inv_order > 1e-12;
+}
+
+__device__ __forceinline__ void load_binom(uint64_t *s_binom, uint64_t const *__restrict__ g_binom) {
+    for (int i = threadIdx.x; i < 64 * LSK_BINOM_K; i += blockDim.x) s_binom[i] = g_binom[i];
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1: diagonal pass  y[i] = d(sigma_i) x[i]
+// ---------------------------------------------------------------------------------------------
+template <bool CPLX>
+__global__ __launch_bounds__(kBlock) void k_diag(int n_diag, lsk_term const *__restrict__ diag, int64_t n,
+                                                 uint64_t const *__restrict__ reps,
+                                                 double const *__restrict__ x, double *__restrict__ y) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        uint64_t a = reps[i];
+        double dr, di;
+        term_sum<false>(diag, 0, n_diag, a, dr, di);
+        if (CPLX) {
+            double xr = x[2 * i], xi = x[2 * i + 1];
+            y[2 * i] = dr * xr - di * xi;
+            y[2 * i + 1] = dr * xi + di * xr;
+        } else {
+            y[i] = dr * x[i];
+        }
+    }
+}
+
+extern "C" int lsk_diag(lsk_operator op, int cplx, int64_t n, uint64_t const *reps, void const *x, void *y,
+                        void *stream) {
+    if (n == 0 || op.n_diag == 0) return 0;
+    dim3 g(grid_for(n)), b(kBlock);
+    if (cplx) hipLaunchKernelGGL(k_diag<true>, g, b, 0, (hipStream_t)stream, op.n_diag, op.diag, n, reps, (double const *)x, (double *)y);
+    else hipLaunchKernelGGL(k_diag<false>, g, b, 0, (hipStream_t)stream, op.n_diag, op.diag, n, reps, (double const *)x, (double *)y);
+    LSK_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Direct fused kernel: one partition, no permutation symmetries.  One row per lane, uniform loop
+// over flip-mask groups.  Consecutive lanes hold consecutive basis states, so for a given group
+// the active lanes' targets are (piecewise) consecutive as well: the scatter / gather coalesces.
+//   PUSH: y[idx(beta)] += c x[i]                 (K2 + K3 + K7 + K8 fused; y holds the diagonal part)
+//   PULL: y[i] = d x[i] + sum conj(c) x[idx(beta)]   (Hermitian operators; no atomics, y written once)
+// Row tiles are dealt to XCDs in contiguous ranges (block b runs on XCD b % 8), so that each
+// XCD's L2 sees one eighth of x / y for the short-range flips.
+// ---------------------------------------------------------------------------------------------
+template <bool CPLX, int INDEX, bool INV, bool PULL, bool REAL>
+__global__ __launch_bounds__(kBlock) void k_direct(int n_groups, lsk_group const *__restrict__ groups,
+                                                   lsk_term const *__restrict__ off, int n_diag,
+                                                   lsk_term const *__restrict__ diag, lsk_basis bs,
+                                                   lsk_index ix, int64_t n, int64_t tiles_per_xcd,
+                                                   uint64_t const *__restrict__ reps,
+                                                   double const *__restrict__ x, double *y, int *err) {
+    __shared__ uint64_t s_binom[INDEX == LSK_INDEX_COMBINADIC ? 64 * LSK_BINOM_K : 1];
+    if (INDEX == LSK_INDEX_COMBINADIC) load_binom(s_binom, ix.binom);
+    const int xcd = blockIdx.x & 7;
+    const int64_t blocks_per_xcd = gridDim.x >> 3; // grid is a multiple of 8
+    for (int64_t t = blockIdx.x >> 3; t < tiles_per_xcd; t += blocks_per_xcd) {
+        const int64_t i = ((int64_t)xcd * tiles_per_xcd + t) * kBlock + threadIdx.x;
+        if (i >= n) continue;
+        const uint64_t a = reps[i];
+        double xr, xi = 0.0;
+        if (CPLX) { xr = x[2 * i]; xi = x[2 * i + 1]; } else xr = x[i];
+        double accr = 0.0, acci = 0.0;
+        if (PULL && n_diag == 0) { // no diagonal pass in the reference either: y is accumulated into (DMV:1062-1063)
+            if (CPLX) { accr = y[2 * i]; acci = y[2 * i + 1]; } else accr = y[i];
+        }
+        if (PULL && n_diag > 0) {
+            double dr, di;
+            term_sum<REAL>(diag, 0, n_diag, a, dr, di);
+            accr = dr * xr - (CPLX ? di * xi : 0.0);
+            if (CPLX) acci = dr * xi + di * xr;
+        }
+        for (int g = 0; g < n_groups; ++g) {
+            lsk_group const G = groups[g];
+            double cr, ci;
+            group_coeff<REAL>(G, off, a, cr, ci);
+            if (cr == 0.0 && (REAL || ci == 0.0)) continue;
+            uint64_t beta = a ^ G.x;
+            bool flipped = false;
+            if (INV) { // K3
+                uint64_t f = beta ^ bs.site_mask;
+                if (f < beta) { beta = f; flipped = true; cr *= (double)bs.spin_inversion; ci *= (double)bs.spin_inversion; }
+            }
+            int64_t idx;
+            if (INDEX == LSK_INDEX_IDENTITY) idx = (int64_t)beta;
+            else if (INDEX == LSK_INDEX_COMBINADIC) {
+                if (G.adj >= 0 && !flipped) {
+                    // adjacent transposition: rank changes by C(lo, #set bits below lo)
+                    int k = __popcll(a & ((1ULL << G.adj) - 1));
+                    int64_t d = (int64_t)s_binom[G.adj * LSK_BINOM_K + k];
+                    idx = ((a >> G.adj) & 1) ? i + d : i - d;
+                } else idx = rank_combinadic(beta, s_binom);
+            } else {
+                idx = search_index(ix, beta);
+                if (idx < 0) { atomicExch(err, 1); continue; } // DMV:115-118
+            }
+            if (PULL) {
+                // conj(c) * x[idx]
+                if (CPLX) {
+                    double yr = x[2 * idx], yi = x[2 * idx + 1];
+                    accr += cr * yr + ci * yi;
+                    acci += cr * yi - ci * yr;
+                } else accr += cr * x[idx];
+            } else {
+                if (CPLX) {
+                    atomic_add_f64(y + 2 * idx, cr * xr - ci * xi);
+                    atomic_add_f64(y + 2 * idx + 1, cr * xi + ci * xr);
+                } else atomic_add_f64(y + idx, cr * xr);
+            }
+        }
+        if (PULL) {
+            if (CPLX) { y[2 * i] = accr; y[2 * i + 1] = acci; } else y[i] = accr;
+        }
+    }
+}
+
+template <bool CPLX, int INDEX, bool INV, bool PULL>
+static int launch_direct2(lsk_operator op, lsk_basis bs, lsk_index ix, int64_t n, uint64_t const *reps,
+                          void const *x, void *y, int *d_err, void *stream) {
+    int64_t tiles = (n + kBlock - 1) / kBlock;
+    int64_t tiles_per_xcd = (tiles + 7) / 8;
+    int64_t gb = tiles_per_xcd * 8;
+    if (gb > kMaxGrid) gb = kMaxGrid;
+    dim3 g((unsigned)gb), b(kBlock);
+    if (op.is_real)
+        hipLaunchKernelGGL((k_direct<CPLX, INDEX, INV, PULL, true>), g, b, 0, (hipStream_t)stream, op.n_groups,
+                           op.groups, op.off, op.n_diag, op.diag, bs, ix, n, tiles_per_xcd, reps,
+                           (double const *)x, (double *)y, d_err);
+    else
+        hipLaunchKernelGGL((k_direct<CPLX, INDEX, INV, PULL, false>), g, b, 0, (hipStream_t)stream, op.n_groups,
+                           op.groups, op.off, op.n_diag, op.diag, bs, ix, n, tiles_per_xcd, reps,
+                           (double const *)x, (double *)y, d_err);
+    LSK_LAUNCH_CHECK();
+    return 0;
+}
+template <bool CPLX, int INDEX>
+static int launch_direct1(lsk_operator op, lsk_basis bs, lsk_index ix, int pull, int64_t n,
+                          uint64_t const *reps, void const *x, void *y, int *d_err, void *stream) {
+    const bool inv = bs.proj == LSK_PROJ_INVERSION;
+    if (inv) {
+        if (pull) return launch_direct2<CPLX, INDEX, true, true>(op, bs, ix, n, reps, x, y, d_err, stream);
+        return launch_direct2<CPLX, INDEX, true, false>(op, bs, ix, n, reps, x, y, d_err, stream);
+    }
+    if (pull) return launch_direct2<CPLX, INDEX, false, true>(op, bs, ix, n, reps, x, y, d_err, stream);
+    return launch_direct2<CPLX, INDEX, false, false>(op, bs, ix, n, reps, x, y, d_err, stream);
+}
+extern "C" int lsk_direct(lsk_operator op, lsk_basis bs, lsk_index ix, int cplx, int pull, int64_t n,
+                          uint64_t const *reps, void const *x, void *y, int *d_err, void *stream) {
+    if (n == 0) return 0;
+    if (bs.proj == LSK_PROJ_FULL) { snprintf(g_err, sizeof(g_err), "lsk_direct: basis needs projection"); return -1; }
+    switch (ix.kind) {
+    case LSK_INDEX_IDENTITY:
+        return cplx ? launch_direct1<true, LSK_INDEX_IDENTITY>(op, bs, ix, pull, n, reps, x, y, d_err, stream)
+                    : launch_direct1<false, LSK_INDEX_IDENTITY>(op, bs, ix, pull, n, reps, x, y, d_err, stream);
+    case LSK_INDEX_COMBINADIC:
+        return cplx ? launch_direct1<true, LSK_INDEX_COMBINADIC>(op, bs, ix, pull, n, reps, x, y, d_err, stream)
+                    : launch_direct1<false, LSK_INDEX_COMBINADIC>(op, bs, ix, pull, n, reps, x, y, d_err, stream);
+    default:
+        return cplx ? launch_direct1<true, LSK_INDEX_SEARCH>(op, bs, ix, pull, n, reps, x, y, d_err, stream)
+                    : launch_direct1<false, LSK_INDEX_SEARCH>(op, bs, ix, pull, n, reps, x, y, d_err, stream);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Staged ("tile") kernel: symmetry projection and/or hash-partitioned output.
+// A 256-row tile expands kGC flip-mask groups at a time into an LDS term list (stage A, K2), the
+// list is then processed densely, one packet per lane (stage B): K3/K4 projection, K5 owner hash,
+// and either K7+K8 (own partition) or a rank inside the (tile, destination) bucket.  Buckets are
+// reserved in the send buffer with ONE global atomic per (tile-chunk, destination) and written out
+// from LDS (K6: the radix partition by destination happens here, in LDS).
+// ---------------------------------------------------------------------------------------------
+constexpr int kGC = 8;
+constexpr int kCap = kBlock * kGC;
+constexpr uint32_t kDead = 0xffffffffu;
+
+template <bool CPLX, bool REAL>
+__global__ __launch_bounds__(kBlock) void k_tile(int n_groups, lsk_group const *__restrict__ groups,
+                                                 lsk_term const *__restrict__ off, lsk_basis bs,
+                                                 lsk_group_elem const *__restrict__ elems, lsk_index ix,
+                                                 int count_only, Owner owner, int me, int64_t row0, int64_t row1,
+                                                 uint64_t const *__restrict__ reps,
+                                                 double const *__restrict__ norms,
+                                                 double const *__restrict__ x, double *y,
+                                                 unsigned long long *cursors,
+                                                 lsk_round_layout const *__restrict__ layout, char *send,
+                                                 unsigned long long *counts, int *err) {
+    __shared__ uint64_t s_beta[kCap];
+    __shared__ double s_val[kCap * (CPLX ? 2 : 1)];
+    __shared__ uint32_t s_meta[kCap];
+    __shared__ unsigned s_cnt[LSK_MAX_PARTS];
+    __shared__ unsigned long long s_base[LSK_MAX_PARTS];
+    __shared__ int s_n;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int P = (int)owner.P;
+
+    for (int64_t t0 = row0 + (int64_t)blockIdx.x * kBlock; t0 < row1; t0 += (int64_t)gridDim.x * kBlock) {
+        const int64_t i = t0 + tid;
+        const bool valid = i < row1;
+        uint64_t a = 0;
+        double xr = 0.0, xi = 0.0;
+        if (valid) {
+            a = reps[i];
+            if (count_only) xr = 1.0; // the packet set must not depend on x (exact send counts)
+            else if (CPLX) { xr = x[2 * i]; xi = x[2 * i + 1]; } else xr = x[i];
+            if (!count_only && bs.proj == LSK_PROJ_FULL) { // fold 1 / norm(alpha) into x  (BatchedOperator.chpl:198-202)
+                double na = norms[i];
+                double s = na > 0.0 ? 1.0 / na : 0.0;
+                xr *= s;
+                xi *= s;
+            }
+        }
+        for (int g0 = 0; g0 < n_groups; g0 += kGC) {
+            if (tid == 0) s_n = 0;
+            for (int d = tid; d < P; d += kBlock) s_cnt[d] = 0;
+            __syncthreads();
+            // ---- stage A: expand terms of kGC groups into the LDS list --------------------------
+            const int g1 = min(g0 + kGC, n_groups);
+            for (int g = g0; g < g1; ++g) {
+                lsk_group const G = groups[g];
+                double cr = 0.0, ci = 0.0;
+                if (valid) group_coeff<REAL>(G, off, a, cr, ci);
+                const bool act = valid && (cr != 0.0 || (!REAL && ci != 0.0));
+                const unsigned long long ball = __ballot(act);
+                int base = 0;
+                if (lane == 0 && ball) base = atomicAdd(&s_n, __popcll(ball));
+                base = __shfl(base, 0);
+                if (act) {
+                    const int slot = base + __popcll(ball & ((1ULL << lane) - 1));
+                    s_beta[slot] = a ^ G.x;
+                    if (CPLX) {
+                        s_val[2 * slot] = cr * xr - ci * xi;
+                        s_val[2 * slot + 1] = cr * xi + ci * xr;
+                    } else s_val[slot] = cr * xr;
+                }
+            }
+            __syncthreads();
+            const int n = s_n;
+            // ---- stage B: project, hash, scatter locally or rank into a destination bucket --------
+            for (int e = tid; e < n; e += kBlock) {
+                uint64_t beta = s_beta[e];
+                double vr, vi = 0.0;
+                if (CPLX) { vr = s_val[2 * e]; vi = s_val[2 * e + 1]; } else vr = s_val[e];
+                bool dead = false;
+                if (bs.proj == LSK_PROJ_INVERSION) {
+                    uint64_t f = beta ^ bs.site_mask;
+                    if (f < beta) { beta = f; vr *= (double)bs.spin_inversion; vi *= (double)bs.spin_inversion; }
+                } else if (bs.proj == LSK_PROJ_FULL) {
+                    uint64_t rep; double chr, chi, stab;
+                    state_info(bs, elems, beta, rep, chr, chi, stab);
+                    double n2 = stab * bs.inv_order;
+                    if (n2 > 1e-12) {
+                        double nb = sqrt(n2);
+                        beta = rep;
+                        if (CPLX) {
+                            double tr = (vr * chr - vi * chi) * nb, ti = (vr * chi + vi * chr) * nb;
+                            vr = tr; vi = ti;
+                        } else vr = vr * chr * nb;
+                    } else dead = true; // zero-norm orbit: c == 0 => skipped (DMV:110)
+                }
+                uint32_t meta = kDead;
+                if (!dead) {
+                    const int dest = owner_of(beta, owner);
+                    if (count_only) {
+                        atomicAdd(&s_cnt[dest], 1u);
+                    } else if (dest == me) {
+                        int64_t idx = search_index(ix, beta);
+                        if (idx < 0) atomicExch(err, 1);
+                        else if (CPLX) { atomic_add_f64(y + 2 * idx, vr); atomic_add_f64(y + 2 * idx + 1, vi); }
+                        else atomic_add_f64(y + idx, vr);
+                    } else {
+                        unsigned rank = atomicAdd(&s_cnt[dest], 1u);
+                        meta = ((uint32_t)dest << 16) | rank;
+                        s_beta[e] = beta;
+                        if (CPLX) { s_val[2 * e] = vr; s_val[2 * e + 1] = vi; } else s_val[e] = vr;
+                    }
+                }
+                s_meta[e] = meta;
+            }
+            __syncthreads();
+            if (count_only) {
+                for (int d = tid; d < P; d += kBlock)
+                    if (s_cnt[d]) atomicAdd(&counts[d], (unsigned long long)s_cnt[d]);
+            } else if (P > 1) {
+                for (int d = tid; d < P; d += kBlock)
+                    if (s_cnt[d]) s_base[d] = atomicAdd(&cursors[d], (unsigned long long)s_cnt[d]);
+                __syncthreads();
+                for (int e = tid; e < n; e += kBlock) {
+                    const uint32_t meta = s_meta[e];
+                    if (meta == kDead) continue;
+                    const int dest = (int)(meta >> 16);
+                    const unsigned long long pos = s_base[dest] + (meta & 0xffffu);
+                    uint64_t *ob = (uint64_t *)(send + layout->beta_off[dest]);
+                    double *ov = (double *)(send + layout->val_off[dest]);
+                    ob[pos] = s_beta[e];
+                    if (CPLX) { ov[2 * pos] = s_val[2 * e]; ov[2 * pos + 1] = s_val[2 * e + 1]; }
+                    else ov[pos] = s_val[e];
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+extern "C" int lsk_tile(lsk_operator op, lsk_basis bs, lsk_index ix, int cplx, int count_only, int P, int me,
+                        int64_t row0, int64_t row1, uint64_t const *reps, double const *norms, void const *x,
+                        void *y, unsigned long long *d_cursors, lsk_round_layout const *d_layout, void *d_send,
+                        unsigned long long *d_counts, int *d_err, void *stream) {
+    if (row1 <= row0 || op.n_groups == 0) return 0;
+    if (P > LSK_MAX_PARTS || P < 1) { snprintf(g_err, sizeof(g_err), "lsk_tile: bad partition count %d", P); return -1; }
+    if (!count_only && ix.kind != LSK_INDEX_SEARCH) { snprintf(g_err, sizeof(g_err), "lsk_tile needs a SEARCH index"); return -1; }
+    Owner ow = make_owner(P);
+    dim3 g(grid_for(row1 - row0)), b(kBlock);
+    hipStream_t s = (hipStream_t)stream;
+#define LSK_TILE_ARGS op.n_groups, op.groups, op.off, bs, bs.elems, ix, count_only, ow, me, row0, row1, reps, norms, \
+        (double const *)x, (double *)y, d_cursors, d_layout, (char *)d_send, d_counts, d_err
+    if (cplx) {
+        if (op.is_real) hipLaunchKernelGGL((k_tile<true, true>), g, b, 0, s, LSK_TILE_ARGS);
+        else hipLaunchKernelGGL((k_tile<true, false>), g, b, 0, s, LSK_TILE_ARGS);
+    } else {
+        if (op.is_real) hipLaunchKernelGGL((k_tile<false, true>), g, b, 0, s, LSK_TILE_ARGS);
+        else hipLaunchKernelGGL((k_tile<false, false>), g, b, 0, s, LSK_TILE_ARGS);
+    }
+#undef LSK_TILE_ARGS
+    LSK_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Consumer side (K7 + K8): received packets -> local index -> atomic add
+// ---------------------------------------------------------------------------------------------
+template <bool CPLX>
+__global__ __launch_bounds__(kBlock) void k_scatter(lsk_index ix, int64_t n, uint64_t const *__restrict__ betas,
+                                                    double const *__restrict__ vals, double *y, int *err) {
+    for (int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x; k < n; k += (int64_t)gridDim.x * kBlock) {
+        double vr, vi = 0.0;
+        if (CPLX) { vr = vals[2 * k]; vi = vals[2 * k + 1]; } else vr = vals[k];
+        if (vr == 0.0 && vi == 0.0) continue; // DMV:110
+        int64_t idx = ix.kind == LSK_INDEX_IDENTITY ? (int64_t)betas[k] : search_index(ix, betas[k]);
+        if (idx < 0) { atomicExch(err, 1); continue; }
+        if (CPLX) { atomic_add_f64(y + 2 * idx, vr); atomic_add_f64(y + 2 * idx + 1, vi); }
+        else atomic_add_f64(y + idx, vr);
+    }
+}
+extern "C" int lsk_scatter(lsk_index ix, int cplx, int64_t n, uint64_t const *betas, void const *vals, void *y,
+                           int *d_err, void *stream) {
+    if (n == 0) return 0;
+    if (ix.kind == LSK_INDEX_COMBINADIC) { snprintf(g_err, sizeof(g_err), "lsk_scatter: SEARCH/IDENTITY index only"); return -1; }
+    dim3 g(grid_for(n)), b(kBlock);
+    if (cplx) hipLaunchKernelGGL(k_scatter<true>, g, b, 0, (hipStream_t)stream, ix, n, betas, (double const *)vals, (double *)y, d_err);
+    else hipLaunchKernelGGL(k_scatter<false>, g, b, 0, (hipStream_t)stream, ix, n, betas, (double const *)vals, (double *)y, d_err);
+    LSK_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// plan-time helpers
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_norms(lsk_basis bs, lsk_group_elem const *__restrict__ elems, int64_t n,
+                                                  uint64_t const *__restrict__ reps, double *__restrict__ norms) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        uint64_t rep; double chr, chi, stab;
+        state_info(bs, elems, reps[i], rep, chr, chi, stab);
+        double n2 = stab * bs.inv_order;
+        norms[i] = n2 > 1e-12 ? sqrt(n2) : 0.0;
+    }
+}
+extern "C" int lsk_norms(lsk_basis bs, int64_t n, uint64_t const *reps, double *norms, void *stream) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_norms, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, bs, bs.elems, n, reps, norms);
+    LSK_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ __launch_bounds__(kBlock) void k_check_combinadic(uint64_t const *__restrict__ g_binom, int64_t n,
+                                                             uint64_t const *__restrict__ reps, int *flag) {
+    __shared__ uint64_t s_binom[64 * LSK_BINOM_K];
+    load_binom(s_binom, g_binom);
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+        if (rank_combinadic(reps[i], s_binom) != i) atomicExch(flag, 1);
+}
+extern "C" int lsk_check_combinadic(lsk_index ix, int hamming_weight, int64_t n, uint64_t const *reps, int *d_flag,
+                                    void *stream) {
+    (void)hamming_weight;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_check_combinadic, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, ix.binom, n, reps, d_flag);
+    LSK_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ __launch_bounds__(kBlock) void k_build_table(int64_t n, uint64_t const *__restrict__ reps, int shift,
+                                                        int64_t nbuckets, uint32_t *__restrict__ table) {
+    // table[b] = first i with (reps[i] >> shift) >= b
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i <= n; i += (int64_t)gridDim.x * kBlock) {
+        int64_t lo = (i == 0) ? 0 : (int64_t)(reps[i - 1] >> shift) + 1;
+        int64_t hi = (i == n) ? nbuckets : (int64_t)(reps[i] >> shift);
+        for (int64_t b = lo; b <= hi; ++b) table[b] = (uint32_t)i;
+    }
+}
+extern "C" int lsk_build_table(int64_t n, uint64_t const *reps, int shift, int64_t nbuckets, uint32_t *table,
+                               void *stream) {
+    hipLaunchKernelGGL(k_build_table, dim3(grid_for(n + 1)), dim3(kBlock), 0, (hipStream_t)stream, n, reps, shift, nbuckets, table);
+    LSK_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// batched externs on device pointers
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_state_info(lsk_basis bs, lsk_group_elem const *__restrict__ elems,
+                                                       int64_t n, uint64_t const *__restrict__ alphas,
+                                                       uint64_t *__restrict__ betas, double *__restrict__ chars,
+                                                       double *__restrict__ norms) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        uint64_t rep; double chr, chi, stab;
+        uint64_t a = alphas[i];
+        if (bs.proj == LSK_PROJ_NONE) { rep = a; chr = 1.0; chi = 0.0; stab = 1.0 / bs.inv_order; }
+        else state_info(bs, elems, a, rep, chr, chi, stab);
+        double n2 = stab * bs.inv_order;
+        betas[i] = rep;
+        chars[2 * i] = chr;
+        chars[2 * i + 1] = chi;
+        norms[i] = n2 > 1e-12 ? sqrt(n2) : 0.0;
+    }
+}
+extern "C" int lsk_state_info(lsk_basis bs, int64_t n, uint64_t const *alphas, uint64_t *betas, double *characters,
+                              double *norms, void *stream) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_state_info, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, bs, bs.elems, n, alphas, betas, characters, norms);
+    LSK_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ __launch_bounds__(kBlock) void k_state_index(lsk_index ix, int64_t n, uint64_t const *__restrict__ spins,
+                                                        int64_t *__restrict__ indices) {
+    __shared__ uint64_t s_binom[64 * LSK_BINOM_K];
+    if (ix.kind == LSK_INDEX_COMBINADIC) load_binom(s_binom, ix.binom);
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        uint64_t s = spins[i];
+        int64_t idx;
+        if (ix.kind == LSK_INDEX_IDENTITY) idx = (int64_t)s < ix.count ? (int64_t)s : -1;
+        else if (ix.kind == LSK_INDEX_COMBINADIC) {
+            idx = rank_combinadic(s, s_binom);
+            // membership: the basis is the first `count` states of one popcount class
+            if (idx >= ix.count || __popcll(s) != __popcll(ix.reps[0])) idx = -1;
+        } else idx = search_index(ix, s);
+        indices[i] = idx;
+    }
+}
+extern "C" int lsk_state_index(lsk_index ix, int64_t n, uint64_t const *spins, int64_t *indices, void *stream) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_state_index, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, ix, n, spins, indices);
+    LSK_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ __launch_bounds__(kBlock) void k_offdiag_counts(int n_groups, lsk_group const *__restrict__ groups,
+                                                           lsk_term const *__restrict__ off, int64_t n,
+                                                           uint64_t const *__restrict__ alphas,
+                                                           int64_t *__restrict__ counts) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        uint64_t a = alphas[i];
+        int c = 0;
+        for (int g = 0; g < n_groups; ++g) {
+            lsk_group const G = groups[g];
+            double cr, ci;
+            group_coeff<false>(G, off, a, cr, ci);
+            c += (cr != 0.0 || ci != 0.0);
+        }
+        counts[i] = c;
+    }
+}
+extern "C" int lsk_offdiag_counts(lsk_operator op, int64_t n, uint64_t const *alphas, int64_t *counts, void *stream) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_offdiag_counts, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, op.n_groups, op.groups, op.off, n, alphas, counts);
+    LSK_LAUNCH_CHECK();
+    return 0;
+}
+__global__ __launch_bounds__(kBlock) void k_offdiag_fill(int n_groups, lsk_group const *__restrict__ groups,
+                                                         lsk_term const *__restrict__ off, int64_t n,
+                                                         uint64_t const *__restrict__ alphas,
+                                                         int64_t const *__restrict__ offsets,
+                                                         uint64_t *__restrict__ betas, double *__restrict__ coeffs,
+                                                         double const *__restrict__ xs) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        uint64_t a = alphas[i];
+        int64_t o = offsets[i];
+        double xv = xs ? xs[i] : 1.0;
+        for (int g = 0; g < n_groups; ++g) {
+            lsk_group const G = groups[g];
+            double cr, ci;
+            group_coeff<false>(G, off, a, cr, ci);
+            if (cr != 0.0 || ci != 0.0) {
+                betas[o] = a ^ G.x;
+                coeffs[2 * o] = cr * xv;
+                coeffs[2 * o + 1] = ci * xv;
+                ++o;
+            }
+        }
+    }
+}
+extern "C" int lsk_offdiag_fill(lsk_operator op, int64_t n, uint64_t const *alphas, int64_t const *offsets,
+                                uint64_t *betas, double *coeffs, double const *xs, void *stream) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_offdiag_fill, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, op.n_groups, op.groups, op.off, n, alphas, offsets, betas, coeffs, xs);
+    LSK_LAUNCH_CHECK();
+    return 0;
+}
+__global__ __launch_bounds__(kBlock) void k_diag_coeffs(int n_diag, lsk_term const *__restrict__ diag, int64_t n,
+                                                        uint64_t const *__restrict__ alphas, double *__restrict__ ys,
+                                                        double const *__restrict__ xs) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        double dr, di;
+        term_sum<true>(diag, 0, n_diag, alphas[i], dr, di);
+        ys[i] = xs ? dr * xs[i] : dr;
+    }
+}
+extern "C" int lsk_diag_coeffs(lsk_operator op, int64_t n, uint64_t const *alphas, double *ys, double const *xs,
+                               void *stream) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_diag_coeffs, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, op.n_diag, op.diag, n, alphas, ys, xs);
+    LSK_LAUNCH_CHECK();
+    return 0;
+}
+
+static int exclusive_scan_i64(int64_t n, int64_t const *in, int64_t *out, hipStream_t s) {
+    if (n == 0) return 0;
+    if (n > 0x7fffffff) { snprintf(g_err, sizeof(g_err), "scan too large"); return -1; }
+    void *tmp = nullptr;
+    size_t bytes = 0;
+    LSK_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, in, out, (int)n, s));
+    LSK_CHECK(hipMalloc(&tmp, bytes ? bytes : 8));
+    hipError_t e = hipcub::DeviceScan::ExclusiveSum(tmp, bytes, in, out, (int)n, s);
+    hipError_t e2 = hipStreamSynchronize(s);
+    (void)hipFree(tmp);
+    LSK_CHECK(e);
+    LSK_CHECK(e2);
+    return 0;
+}
+extern "C" int lsk_exclusive_scan_i64(int64_t n, int64_t const *in, int64_t *out, void *stream) {
+    return exclusive_scan_i64(n, in, out, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// enumeration of representatives (enumerateStates, StatesEnumeration.chpl:158-224,516-585)
+// Candidate c in [0, n_candidates) is the c-th state in ascending order of the candidate space:
+//   fixed Hamming weight -> unrank_combinadic(c) ; otherwise the integer c.
+// Each thread owns kEnumChunk consecutive candidates; survivors are flagged in a 64-bit mask, the
+// masks' popcounts are scanned, and a second (cheap) kernel writes the survivors in order.
+// ---------------------------------------------------------------------------------------------
+constexpr int kEnumChunk = 64;
+
+__global__ __launch_bounds__(kBlock) void k_enum_flags(lsk_basis bs, lsk_group_elem const *__restrict__ elems,
+                                                       uint64_t const *__restrict__ g_binom, int64_t n_cand,
+                                                       int64_t n_threads, uint64_t *__restrict__ flags,
+                                                       int64_t *__restrict__ counts) {
+    __shared__ uint64_t s_binom[64 * LSK_BINOM_K];
+    load_binom(s_binom, g_binom);
+    for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < n_threads; t += (int64_t)gridDim.x * kBlock) {
+        int64_t c0 = t * kEnumChunk;
+        int64_t c1 = c0 + kEnumChunk < n_cand ? c0 + kEnumChunk : n_cand;
+        uint64_t s = bs.hamming_weight >= 0 ? unrank_combinadic(c0, bs.hamming_weight, s_binom) : (uint64_t)c0;
+        uint64_t m = 0;
+        for (int64_t c = c0; c < c1; ++c) {
+            bool keep = bs.proj == LSK_PROJ_FULL ? is_representative(bs, elems, s) : true;
+            if (keep) m |= 1ULL << (c - c0);
+            if (c + 1 < c1) s = (bs.hamming_weight > 0) ? next_fixed_hamming(s) : s + 1;
+        }
+        flags[t] = m;
+        counts[t] = __popcll(m);
+    }
+}
+__global__ __launch_bounds__(kBlock) void k_enum_write(lsk_basis bs, uint64_t const *__restrict__ g_binom,
+                                                       int64_t n_cand, int64_t n_threads,
+                                                       uint64_t const *__restrict__ flags,
+                                                       int64_t const *__restrict__ offsets,
+                                                       uint64_t *__restrict__ out) {
+    __shared__ uint64_t s_binom[64 * LSK_BINOM_K];
+    load_binom(s_binom, g_binom);
+    for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < n_threads; t += (int64_t)gridDim.x * kBlock) {
+        uint64_t m = flags[t];
+        if (!m) continue;
+        int64_t c0 = t * kEnumChunk;
+        int64_t c1 = c0 + kEnumChunk < n_cand ? c0 + kEnumChunk : n_cand;
+        uint64_t s = bs.hamming_weight >= 0 ? unrank_combinadic(c0, bs.hamming_weight, s_binom) : (uint64_t)c0;
+        int64_t o = offsets[t];
+        for (int64_t c = c0; c < c1; ++c) {
+            if ((m >> (c - c0)) & 1) out[o++] = s;
+            if (c + 1 < c1) s = (bs.hamming_weight > 0) ? next_fixed_hamming(s) : s + 1;
+        }
+    }
+}
+
+extern "C" int lsk_enumerate(lsk_basis bs, uint64_t const *d_binom, int64_t n_cand, uint64_t **d_states,
+                             int64_t *count, void *stream) {
+    hipStream_t s = (hipStream_t)stream;
+    *d_states = nullptr;
+    *count = 0;
+    if (n_cand <= 0) { LSK_CHECK(hipMalloc((void **)d_states, 8)); return 0; }
+    int64_t n_threads = (n_cand + kEnumChunk - 1) / kEnumChunk;
+    uint64_t *flags = nullptr;
+    int64_t *counts = nullptr, *offsets = nullptr;
+    LSK_CHECK(hipMalloc((void **)&flags, 8 * n_threads));
+    LSK_CHECK(hipMalloc((void **)&counts, 8 * n_threads));
+    LSK_CHECK(hipMalloc((void **)&offsets, 8 * n_threads));
+    hipLaunchKernelGGL(k_enum_flags, dim3(grid_for(n_threads)), dim3(kBlock), 0, s, bs, bs.elems, d_binom, n_cand, n_threads, flags, counts);
+    LSK_LAUNCH_CHECK();
+    if (exclusive_scan_i64(n_threads, counts, offsets, s) != 0) return -1;
+    int64_t last_off = 0, last_cnt = 0;
+    LSK_CHECK(hipMemcpy(&last_off, offsets + (n_threads - 1), 8, hipMemcpyDeviceToHost));
+    LSK_CHECK(hipMemcpy(&last_cnt, counts + (n_threads - 1), 8, hipMemcpyDeviceToHost));
+    int64_t total = last_off + last_cnt;
+    LSK_CHECK(hipMalloc((void **)d_states, total > 0 ? 8 * total : 8));
+    hipLaunchKernelGGL(k_enum_write, dim3(grid_for(n_threads)), dim3(kBlock), 0, s, bs, d_binom, n_cand, n_threads, flags, offsets, *d_states);
+    LSK_LAUNCH_CHECK();
+    LSK_CHECK(hipStreamSynchronize(s));
+    (void)hipFree(flags); (void)hipFree(counts); (void)hipFree(offsets);
+    *count = total;
+    return 0;
+}
+
+// masks[i] = owner of states[i]  (_enumStatesComputeMasksAndCounts, StatesEnumeration.chpl:138-156)
+__global__ __launch_bounds__(kBlock) void k_masks(int64_t n, uint64_t const *__restrict__ states, Owner ow,
+                                                  uint8_t *__restrict__ masks) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+        masks[i] = (uint8_t)owner_of(states[i], ow);
+}
+extern "C" int lsk_masks(int64_t n, uint64_t const *states, int P, uint8_t *masks, void *stream) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_masks, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, n, states, make_owner(P), masks);
+    LSK_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ __launch_bounds__(kBlock) void k_mask_counts(int64_t n, uint8_t const *__restrict__ masks,
+                                                        unsigned long long *__restrict__ counts) {
+    __shared__ unsigned s_cnt[LSK_MAX_PARTS];
+    for (int d = threadIdx.x; d < LSK_MAX_PARTS; d += kBlock) s_cnt[d] = 0;
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+        atomicAdd(&s_cnt[masks[i]], 1u);
+    __syncthreads();
+    for (int d = threadIdx.x; d < LSK_MAX_PARTS; d += kBlock)
+        if (s_cnt[d]) atomicAdd(&counts[d], (unsigned long long)s_cnt[d]);
+}
+extern "C" int lsk_mask_counts(int64_t n, uint8_t const *masks, int P, int64_t *h_counts, void *stream) {
+    unsigned long long *d = nullptr;
+    LSK_CHECK(hipMalloc((void **)&d, 8 * LSK_MAX_PARTS));
+    LSK_CHECK(hipMemsetAsync(d, 0, 8 * LSK_MAX_PARTS, (hipStream_t)stream));
+    if (n > 0) {
+        hipLaunchKernelGGL(k_mask_counts, dim3(grid_for(n, kBlock * 16)), dim3(kBlock), 0, (hipStream_t)stream, n, masks, d);
+        LSK_LAUNCH_CHECK();
+    }
+    unsigned long long h[LSK_MAX_PARTS];
+    LSK_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    LSK_CHECK(hipMemcpy(h, d, 8 * LSK_MAX_PARTS, hipMemcpyDeviceToHost));
+    (void)hipFree(d);
+    for (int p = 0; p < P; ++p) h_counts[p] = (int64_t)h[p];
+    return 0;
+}
+
+// Layout converters.  position[i] = rank of element i among the elements with the same mask that
+// precede it (exclusive scan of the indicator, one pass per partition); block->hashed then is
+// dest[mask[i]][position[i]] = src[i] and hashed->block its inverse.  Stable by construction, which
+// is what keeps every hashed part ascending (BlockToHashed.chpl:87-208, HashedToBlock.chpl:67-153).
+struct MaskEq {
+    uint8_t const *masks;
+    uint8_t p;
+    __host__ __device__ int64_t operator()(int64_t i) const { return masks[i] == p ? 1 : 0; }
+};
+template <int ELT>
+__global__ __launch_bounds__(kBlock) void k_permute(int64_t n, uint8_t const *__restrict__ masks, uint8_t p,
+                                                    int64_t const *__restrict__ pos, char const *src, char *dst,
+                                                    int to_hashed) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        if (masks[i] != p) continue;
+        int64_t j = pos[i];
+        if (ELT == 8) {
+            if (to_hashed) ((uint64_t *)dst)[j] = ((uint64_t const *)src)[i];
+            else ((uint64_t *)dst)[i] = ((uint64_t const *)src)[j];
+        } else {
+            if (to_hashed) ((ulonglong2 *)dst)[j] = ((ulonglong2 const *)src)[i];
+            else ((ulonglong2 *)dst)[i] = ((ulonglong2 const *)src)[j];
+        }
+    }
+}
+static int permute_by_masks(int64_t n, uint8_t const *masks, int P, int elt_size, void const *block_const,
+                            void *block_mut, void *const *parts, int to_hashed, hipStream_t s) {
+    if (n == 0) return 0;
+    if (elt_size != 8 && elt_size != 16) { snprintf(g_err, sizeof(g_err), "layout converters support 8/16-byte elements"); return -1; }
+    if (n > 0x7fffffff) { snprintf(g_err, sizeof(g_err), "layout converter: n too large"); return -1; }
+    int64_t *pos = nullptr;
+    LSK_CHECK(hipMalloc((void **)&pos, 8 * n));
+    void *tmp = nullptr;
+    size_t tmp_bytes = 0;
+    hipcub::CountingInputIterator<int64_t> cnt(0);
+    for (int p = 0; p < P; ++p) {
+        MaskEq f{masks, (uint8_t)p};
+        hipcub::TransformInputIterator<int64_t, MaskEq, hipcub::CountingInputIterator<int64_t>> it(cnt, f);
+        size_t bytes = 0;
+        LSK_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, it, pos, (int)n, s));
+        if (bytes > tmp_bytes) {
+            if (tmp) (void)hipFree(tmp);
+            LSK_CHECK(hipMalloc(&tmp, bytes));
+            tmp_bytes = bytes;
+        }
+        LSK_CHECK(hipcub::DeviceScan::ExclusiveSum(tmp, bytes, it, pos, (int)n, s));
+        char const *src = to_hashed ? (char const *)block_const : (char const *)parts[p];
+        char *dst = to_hashed ? (char *)parts[p] : (char *)block_mut;
+        if (elt_size == 8) hipLaunchKernelGGL(k_permute<8>, dim3(grid_for(n)), dim3(kBlock), 0, s, n, masks, (uint8_t)p, pos, src, dst, to_hashed);
+        else hipLaunchKernelGGL(k_permute<16>, dim3(grid_for(n)), dim3(kBlock), 0, s, n, masks, (uint8_t)p, pos, src, dst, to_hashed);
+        LSK_LAUNCH_CHECK();
+    }
+    LSK_CHECK(hipStreamSynchronize(s));
+    if (tmp) (void)hipFree(tmp);
+    (void)hipFree(pos);
+    return 0;
+}
+extern "C" int lsk_block_to_hashed(int64_t n, uint8_t const *masks, int P, int elt_size, void const *src,
+                                   void *const *h_dest, void *stream) {
+    return permute_by_masks(n, masks, P, elt_size, src, nullptr, h_dest, 1, (hipStream_t)stream);
+}
+extern "C" int lsk_hashed_to_block(int64_t n, uint8_t const *masks, int P, int elt_size, void const *const *h_src,
+                                   void *dest, void *stream) {
+    return permute_by_masks(n, masks, P, elt_size, nullptr, dest, (void *const *)h_src, 0, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// deterministic vectors for tests / bench: the value depends only on (basis state, seed), so every
+// partitioning of the same basis sees the same logical vector.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_fill_random(int64_t n, uint64_t const *__restrict__ states, uint64_t seed,
+                                                        int cplx, double *__restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        uint64_t h = hash64_01(states[i] ^ (seed * 0x9e3779b97f4a7c15ULL + 0x632be59bd9b4e019ULL));
+        double re = (double)(h >> 11) * (1.0 / 9007199254740992.0) - 0.5;
+        if (cplx) {
+            uint64_t h2 = hash64_01(h ^ 0xd6e8feb86659fd93ULL);
+            out[2 * i] = re;
+            out[2 * i + 1] = (double)(h2 >> 11) * (1.0 / 9007199254740992.0) - 0.5;
+        } else out[i] = re;
+    }
+}
+extern "C" int lsk_fill_random(int64_t n, uint64_t const *states, uint64_t seed, int cplx, void *out, void *stream) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_fill_random, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, n, states, seed, cplx, (double *)out);
+    LSK_LAUNCH_CHECK();
+    return 0;
+}

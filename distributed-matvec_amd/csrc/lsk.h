@@ -1,0 +1,159 @@
+/* lsk.h -- internal interface between the C host side (host.c) and the HIP side (kernels.hip).
+ * "Thin extern-C shim": host.c never includes a HIP header; everything device-related goes through
+ * the lsk_* functions declared here.  All structs are plain C PODs passed by value to kernels.
+ */
+#ifndef LSK_H
+#define LSK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LSK_BENES_STAGES 11 /* distances 32,16,8,4,2,1,2,4,8,16,32 */
+#define LSK_BINOM_K 34      /* binomial table is [64][LSK_BINOM_K]: C(n, k), n < 64, k < 34 */
+#define LSK_MAX_PARTS 256   /* DMV:664 */
+
+typedef struct lsk_term {
+    double v_re, v_im;
+    uint64_t m, r, s;
+} lsk_term;
+
+/* how the coefficient of a flip-mask group is evaluated */
+enum { LSK_GROUP_GENERIC = 0, LSK_GROUP_EXCHANGE = 1 };
+
+/* one off-diagonal flip-mask group: beta = alpha ^ x, coefficient = sum over terms [begin, end) */
+typedef struct lsk_group {
+    uint64_t x;
+    double v_re, v_im; /* EXCHANGE: coefficient when popcount(alpha & x) == 1, else 0 */
+    int32_t begin, end;
+    int32_t adj;       /* lo if x == 3 << lo (adjacent pair) else -1 */
+    int32_t fast;      /* LSK_GROUP_* */
+} lsk_group;
+
+typedef struct lsk_operator {
+    int n_diag, n_off, n_groups, is_real;
+    lsk_term const *diag;    /* device [n_diag] */
+    lsk_term const *off;     /* device [n_off], sorted by group */
+    lsk_group const *groups; /* device [n_groups] */
+} lsk_operator;
+
+enum { LSK_ELEM_BENES = 0, LSK_ELEM_ROT = 1, LSK_ELEM_REVROT = 2 };
+
+typedef struct lsk_group_elem {
+    int32_t kind;
+    int32_t k; /* rotate-right amount within number_sites bits (ROT / REVROT) */
+    double ch_re, ch_im;
+    uint64_t masks[LSK_BENES_STAGES];
+} lsk_group_elem;
+
+enum { LSK_PROJ_NONE = 0, LSK_PROJ_INVERSION = 1, LSK_PROJ_FULL = 2 };
+
+typedef struct lsk_basis {
+    int number_sites, hamming_weight, spin_inversion, n_elems, proj;
+    uint64_t site_mask;
+    double inv_order; /* 1 / |G| including the inversion doubling */
+    lsk_group_elem const *elems; /* device [n_elems] */
+} lsk_basis;
+
+enum { LSK_INDEX_IDENTITY = 0, LSK_INDEX_COMBINADIC = 1, LSK_INDEX_SEARCH = 2 };
+
+typedef struct lsk_index {
+    int kind;
+    int shift;             /* SEARCH: bucket = state >> shift */
+    int64_t count;
+    uint64_t const *reps;  /* device, ascending */
+    uint32_t const *table; /* device [(max_state >> shift) + 2] lower bounds */
+    uint64_t const *binom; /* device [64 * LSK_BINOM_K] */
+} lsk_index;
+
+/* per-round send layout: byte offsets of the beta / value arrays of every destination segment */
+typedef struct lsk_round_layout {
+    int64_t beta_off[LSK_MAX_PARTS];
+    int64_t val_off[LSK_MAX_PARTS];
+} lsk_round_layout;
+
+/* runtime ---------------------------------------------------------------------------------- */
+char const *lsk_last_error(void);
+int lsk_device_count(void);
+int lsk_set_device(int device);
+int lsk_malloc(void **p, size_t bytes);
+int lsk_free(void *p);
+int lsk_h2d(void *dst, void const *src, size_t bytes);
+int lsk_d2h(void *dst, void const *src, size_t bytes);
+int lsk_d2d_async(void *dst, void const *src, size_t bytes, void *stream);
+int lsk_memset_async(void *p, int value, size_t bytes, void *stream);
+int lsk_sync(void *stream);
+
+/* events (kernel timing on the launch stream) */
+int lsk_event_create(void **ev);
+int lsk_event_destroy(void *ev);
+int lsk_event_record(void *ev, void *stream);
+int lsk_event_elapsed_ms(void *start, void *stop, float *ms);
+
+/* deterministic test / bench vectors keyed by the basis state: x_i = u(hash(state_i, seed)) - 0.5 */
+int lsk_fill_random(int64_t n, uint64_t const *states, uint64_t seed, int cplx, void *out, void *stream);
+
+/* hot path --------------------------------------------------------------------------------- */
+/* y[i] = d(reps[i]) * x[i] */
+int lsk_diag(lsk_operator op, int cplx, int64_t n, uint64_t const *reps, void const *x, void *y,
+             void *stream);
+/* fused single-partition kernel without permutation symmetries (row per lane).
+ * pull == 0: y[idx(beta)] += c x[i] (atomics; y must already hold the diagonal part)
+ * pull == 1: y[i] = d x[i] + sum conj(c) x[idx(beta)] */
+int lsk_direct(lsk_operator op, lsk_basis bs, lsk_index ix, int cplx, int pull, int64_t n,
+               uint64_t const *reps, void const *x, void *y, int *d_err, void *stream);
+/* staged kernel (LDS term lists): rows [row0, row1) of partition `me`.
+ * count_only != 0: adds the number of packets per destination to d_counts[P] and does nothing else.
+ * otherwise: local packets -> index + atomic add into y; remote packets -> d_send according to
+ * *d_layout using the per-destination cursors d_cursors[P] (must be zero on entry). */
+int lsk_tile(lsk_operator op, lsk_basis bs, lsk_index ix, int cplx, int count_only, int P, int me,
+             int64_t row0, int64_t row1, uint64_t const *reps, double const *norms, void const *x,
+             void *y, unsigned long long *d_cursors, lsk_round_layout const *d_layout, void *d_send,
+             unsigned long long *d_counts, int *d_err, void *stream);
+/* n packets -> y[idx(beta)] += value */
+int lsk_scatter(lsk_index ix, int cplx, int64_t n, uint64_t const *betas, void const *vals, void *y,
+                int *d_err, void *stream);
+
+/* plan-time helpers -------------------------------------------------------------------------- */
+/* norms[i] = sqrt(stab(reps[i]) / |G|) */
+int lsk_norms(lsk_basis bs, int64_t n, uint64_t const *reps, double *norms, void *stream);
+/* *d_flag = 1 unless reps[i] == unrank(i) for all i (full fixed-Hamming prefix) */
+int lsk_check_combinadic(lsk_index ix, int hamming_weight, int64_t n, uint64_t const *reps,
+                         int *d_flag, void *stream);
+/* SEARCH prefix table: table[b] = lower_bound(reps, b << shift), b in [0, nbuckets] */
+int lsk_build_table(int64_t n, uint64_t const *reps, int shift, int64_t nbuckets, uint32_t *table,
+                    void *stream);
+
+/* batched externs (device pointers) ---------------------------------------------------------- */
+int lsk_state_info(lsk_basis bs, int64_t n, uint64_t const *alphas, uint64_t *betas,
+                   double *characters /* (re, im) */, double *norms, void *stream);
+int lsk_state_index(lsk_index ix, int64_t n, uint64_t const *spins, int64_t *indices, void *stream);
+/* counts[i] = number of non-zero off-diagonal groups of alphas[i] */
+int lsk_offdiag_counts(lsk_operator op, int64_t n, uint64_t const *alphas, int64_t *counts,
+                       void *stream);
+/* writes (beta, c [* xs[i]]) of row i at offsets[i]...; xs may be NULL */
+int lsk_offdiag_fill(lsk_operator op, int64_t n, uint64_t const *alphas, int64_t const *offsets,
+                     uint64_t *betas, double *coeffs /* (re, im) */, double const *xs, void *stream);
+/* ys[i] = d(alphas[i]) [* xs[i]] (real part) */
+int lsk_diag_coeffs(lsk_operator op, int64_t n, uint64_t const *alphas, double *ys, double const *xs,
+                    void *stream);
+int lsk_exclusive_scan_i64(int64_t n, int64_t const *in, int64_t *out, void *stream);
+
+/* enumeration + layout ------------------------------------------------------------------------ */
+/* number of candidate states (fixed-Hamming rank space or 2^L), given the top-bit cut */
+int lsk_enumerate(lsk_basis bs, uint64_t const *d_binom, int64_t n_candidates, uint64_t **d_states,
+                  int64_t *count, void *stream);
+int lsk_masks(int64_t n, uint64_t const *states, int P, uint8_t *masks, void *stream);
+int lsk_mask_counts(int64_t n, uint8_t const *masks, int P, int64_t *h_counts, void *stream);
+int lsk_block_to_hashed(int64_t n, uint8_t const *masks, int P, int elt_size, void const *src,
+                        void *const *h_dest, void *stream);
+int lsk_hashed_to_block(int64_t n, uint8_t const *masks, int P, int elt_size,
+                        void const *const *h_src, void *dest, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LSK_H */

@@ -1,0 +1,144 @@
+"""One process per GPU: hash-partitioned y <- H x with an all-to-all-v of (sigma_j, c_j x_i) packets.
+
+Replaces the reference's locale-to-locale machinery
+(/root/reference/src/DistributedMatrixVector.chpl:313-853: _LocalBuffer/_RemoteBuffer mailboxes,
+Producer/Consumer tasks, one-sided PUTs + fast-on flag hand-shakes, 3 barriers per matvec) by
+bulk-synchronous rounds on each rank:
+
+    generate(round)      HIP: rows -> terms -> projection -> hash64_01 % P -> per-destination segments
+    all_to_all_single    RCCL over xGMI (backend "nccl"); exact split sizes are known from the plan's
+                         count pass, so no per-round size exchange and no host sync
+    scatter(segment)     HIP: local index lookup + 64-bit atomic add
+
+Packets owned by the generating rank never leave the GPU (scattered inside `generate`).  The engine
+is pluggable so that the exchange logic can be exercised on CPU with the gloo backend (tests inject
+an oracle-backed engine); the product engine is HipEngine and nothing else ships.
+"""
+from __future__ import annotations
+
+import os
+
+
+class HipEngine:
+    """ls_amd plan that owns exactly one partition (this rank's)."""
+
+    def __init__(self, matrix, representatives, dtype, num_partitions: int, my_partition: int, num_rounds: int):
+        import torch
+
+        from .api import MatvecPlan
+
+        self.torch = torch
+        self.plan = MatvecPlan(matrix, representatives, dtype, my_partition=my_partition,
+                               num_partitions=num_partitions, num_rounds=num_rounds)
+        self.device = representatives.device
+        self.num_rounds = self.plan.num_rounds
+        self.packet_bytes = self.plan.packet_bytes
+
+    def send_counts(self, rnd):
+        return self.plan.send_counts(rnd)
+
+    def alloc_bytes(self, n):
+        return self.torch.empty(max(int(n), 8), dtype=self.torch.uint8, device=self.device)
+
+    def diag(self, x, y):
+        self.plan.diag(x, y)
+
+    def generate(self, rnd, x, y, send):
+        self.plan.generate(rnd, x, y, send)
+
+    def scatter(self, recv, byte_offset, n, y):
+        base = recv.data_ptr() + byte_offset
+        self.plan.scatter(n, base, base + 8 * n, y)
+
+    def check(self):
+        self.plan.check()
+
+
+def _rows_per_round():
+    v = os.environ.get("LS_AMD_ROWS_PER_ROUND")
+    return int(v) if v else 1 << 24
+
+
+class DistributedOperator:
+    """matrixVectorProduct with one locale per process (rank == locale index == hash64_01 % P)."""
+
+    def __init__(self, matrix, representatives, dtype, group=None, engine_factory=None, num_rounds=None):
+        import torch
+        import torch.distributed as dist
+
+        self.torch, self.dist, self.group = torch, dist, group
+        self.rank = dist.get_rank(group)
+        self.P = dist.get_world_size(group)
+        backend = dist.get_backend(group)
+        self.meta_device = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+        n_local = int(representatives.numel()) if hasattr(representatives, "numel") else len(representatives)
+        # every rank must run the same number of rounds (the collectives are matched)
+        counts = torch.tensor([n_local], dtype=torch.int64, device=self.meta_device)
+        all_counts = [torch.zeros_like(counts) for _ in range(self.P)]
+        dist.all_gather(all_counts, counts, group=group)
+        self.counts = [int(c.item()) for c in all_counts]
+        if num_rounds is None:
+            rpr = _rows_per_round()
+            num_rounds = max(1, max((c + rpr - 1) // rpr for c in self.counts))
+        self.num_rounds = num_rounds
+        factory = engine_factory or HipEngine
+        self.engine = factory(matrix, representatives, dtype, self.P, self.rank, num_rounds)
+        assert self.engine.num_rounds == num_rounds
+        pb = self.engine.packet_bytes
+        # counts matrix exchange, once: S[d, r] = packets this rank sends to d in round r
+        S = torch.tensor([self.engine.send_counts(r) for r in range(num_rounds)], dtype=torch.int64).t().contiguous()
+        R = torch.zeros_like(S)
+        S_dev, R_dev = S.to(self.meta_device), R.to(self.meta_device)
+        dist.all_to_all_single(R_dev, S_dev, group=group)
+        self.send_counts = S.t().tolist()             # [round][dest]
+        self.recv_counts = R_dev.cpu().t().tolist()   # [round][src]
+        self.packet_bytes = pb
+        max_send = max(sum(c) for c in self.send_counts) * pb
+        max_recv = max(sum(c) for c in self.recv_counts) * pb
+        # double-buffered so that generate(r + 1) can be queued while exchange(r) is in flight
+        self.send_bufs = [self.engine.alloc_bytes(max_send) for _ in range(2)]
+        self.recv_bufs = [self.engine.alloc_bytes(max_recv) for _ in range(2)]
+        self.exchange_bytes_per_matvec = sum(sum(c) for c in self.send_counts) * pb
+
+    def matvec(self, x, y, check: bool = False):
+        """y <- H x for this rank's blocks of the hashed vectors."""
+        dist, pb = self.dist, self.packet_bytes
+        eng = self.engine
+        eng.diag(x, y)  # localDiagonal first: y is assigned (DMV:1062-1063)
+        for r in range(self.num_rounds):
+            send, recv = self.send_bufs[r & 1], self.recv_bufs[r & 1]
+            eng.generate(r, x, y, send)
+            in_splits = [c * pb for c in self.send_counts[r]]
+            out_splits = [c * pb for c in self.recv_counts[r]]
+            n_in, n_out = sum(in_splits), sum(out_splits)
+            dist.all_to_all_single(recv[:n_out], send[:n_in], out_splits, in_splits, group=self.group)
+            off = 0
+            for s in range(self.P):
+                n = self.recv_counts[r][s]
+                if n:
+                    eng.scatter(recv, off, n, y)
+                off += n * pb
+        if check:
+            eng.check()
+
+    # PRIMME-style reductions across locales (/root/reference/src/PRIMME.chpl:267-373) ------------
+    def global_sum(self, t):
+        """globalSumReal: in-place sum over all locales."""
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        return t
+
+    def broadcast(self, t, src: int = 0):
+        """broadcastReal."""
+        self.dist.broadcast(t, src=src, group=self.group)
+        return t
+
+    def dot(self, a, b):
+        """<a, b> over the whole hashed vector (conjugating a)."""
+        torch = self.torch
+        local = torch.vdot(a, b) if a.is_complex() else torch.dot(a, b)
+        local = local.reshape(1).clone()
+        if local.is_complex():
+            parts = torch.view_as_real(local).clone()
+            self.global_sum(parts)
+            return torch.view_as_complex(parts)[0]
+        return self.global_sum(local)[0]

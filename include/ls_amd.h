@@ -1,0 +1,150 @@
+/* ls_amd.h -- device-level C ABI of the MI355X-native matvec: plain pointers and sizes only.
+ *
+ * This is the surface the reference's Chapel-level entry matrixVectorProduct(H, x, y,
+ * representatives) (/root/reference/src/DistributedMatrixVector.chpl:1072-1093) maps onto:
+ * x, y and representatives are hash-partitioned, per-partition ascending arrays
+ * (partition of sigma = hash64_01(sigma) % P, /root/reference/src/StatesEnumeration.chpl:122-136)
+ * that live in HBM.  Pointers named d_* are DEVICE pointers (hipMalloc / torch allocations);
+ * `stream` is a hipStream_t passed as void* (NULL = the library's default stream).
+ *
+ * Two ways to run the off-diagonal exchange (DMV:856-1053 replaced):
+ *   - all P partitions in this process on one device  -> ls_amd_matvec (logical partitions; the
+ *     "exchange" is a pointer hand-off), and
+ *   - one partition per process / GPU               -> ls_amd_generate + an all-to-all-v done by
+ *     the caller (torch.distributed over RCCL) + ls_amd_scatter.
+ * All functions return 0 on success or a negative error code; ls_amd_last_error() explains.
+ */
+#ifndef LS_AMD_H
+#define LS_AMD_H
+
+#include "ls_hs.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum { LS_AMD_F64 = 0, LS_AMD_C128 = 1 } ls_amd_dtype;
+
+/* how y is produced when P == 1 and the operator is Hermitian */
+typedef enum {
+    LS_AMD_MODE_AUTO = 0, /* library default (LS_AMD_MODE env var overrides: "push" | "pull") */
+    LS_AMD_MODE_PUSH = 1, /* y[idx(beta)] += c x[i]   -- atomic scatter (ConcurrentAccessor) */
+    LS_AMD_MODE_PULL = 2  /* y[i] = d x[i] + sum conj(c) x[idx(beta)]  -- gather, no atomics  */
+} ls_amd_mode;
+
+typedef struct ls_amd_plan ls_amd_plan;
+
+/* error plumbing ------------------------------------------------------------------------- */
+char const *ls_amd_last_error(void);
+typedef void (*ls_amd_error_handler)(char const *message);
+/* handler used by the halting ls_chpl_* / ls_hs_* entry points; NULL restores print+abort */
+void ls_amd_set_error_handler(ls_amd_error_handler handler);
+
+/* device helpers (thin wrappers so that a C / ctypes caller needs no HIP headers) ---------- */
+int ls_amd_device_count(void);
+int ls_amd_set_device(int device);
+int ls_amd_malloc(void **d_ptr, size_t bytes);
+int ls_amd_free(void *d_ptr);
+int ls_amd_memcpy_h2d(void *d_dst, void const *h_src, size_t bytes);
+int ls_amd_memcpy_d2h(void *h_dst, void const *d_src, size_t bytes);
+int ls_amd_memcpy_d2d(void *d_dst, void const *d_src, size_t bytes, void *stream); /* async */
+int ls_amd_memset(void *d_ptr, int value, size_t bytes, void *stream);
+int ls_amd_synchronize(void *stream);
+
+/* hash64_01 / localeIdxOf on the host (StatesEnumeration.chpl:122-136) */
+uint64_t ls_amd_hash64_01(uint64_t x);
+int ls_amd_locale_idx_of(uint64_t basis_state, int num_locales);
+
+/* ------------------------------------------------------------------------------------------
+ * Plans.  A plan binds an operator to the partition layout and owns every per-basis device table:
+ * term tables, symmetry-group networks, per-row norms, index prefix tables, per-round send counts.
+ *
+ *   num_partitions   P >= 1 (<= 256, DMV:664)
+ *   my_partition     -1: all P partitions live in this process (counts[P], d_reps[P]);
+ *                    p >= 0: this process owns only partition p (counts[0], d_reps[0] describe it)
+ *   d_reps           device pointers to the ascending representatives of each owned partition;
+ *                    borrowed -- must outlive the plan
+ *   num_rounds       rows of a partition are processed in this many bulk-synchronous rounds
+ *                    (0 = choose from LS_AMD_ROWS_PER_ROUND, default 2^24 rows)
+ * ------------------------------------------------------------------------------------------ */
+int ls_amd_plan_create(ls_amd_plan **plan, ls_hs_operator const *op, ls_amd_dtype dtype,
+                       int num_partitions, int my_partition, uint64_t const *const *d_reps,
+                       int64_t const *counts, int num_rounds, ls_amd_mode mode, void *stream);
+void ls_amd_plan_destroy(ls_amd_plan *plan);
+
+int ls_amd_plan_num_rounds(ls_amd_plan const *plan);
+/* which kernel family the plan selected: "direct-push", "direct-pull", "tile" */
+char const *ls_amd_plan_kernel_name(ls_amd_plan const *plan);
+/* number of (beta, value) packets partition `my_partition` sends to every destination in `round`
+ * (counts[P]; the own slot is 0 because local contributions are scattered in place) */
+int ls_amd_plan_send_counts(ls_amd_plan const *plan, int round, int64_t *counts);
+/* bytes of one packet segment entry: 8 (beta) + 8 or 16 (value) */
+int ls_amd_plan_packet_bytes(ls_amd_plan const *plan);
+/* total off-diagonal non-zeros generated per matvec by the owned partitions (from the count pass;
+ * 0 when the plan runs a direct kernel and never counted) */
+int64_t ls_amd_plan_nnz(ls_amd_plan const *plan);
+
+/* matrixVectorProduct(H, x, y, representatives), all partitions in this process
+ * (DMV:1072-1093).  d_x[p], d_y[p]: device arrays of counts[p] elements of the plan's dtype.
+ * Asynchronous on `stream`; call ls_amd_plan_check to synchronise and collect the
+ * "invalid index" condition the reference halts on (DMV:115-118). */
+int ls_amd_matvec(ls_amd_plan *plan, void const *const *d_x, void *const *d_y, void *stream);
+int ls_amd_plan_check(ls_amd_plan *plan, void *stream);
+
+/* Kernel timing with HIP events recorded on the launch stream, around every launch of the plan's
+ * dominant kernel (direct-push/direct-pull: the fused row kernel; tile: the staged kernel).
+ * enable with max_samples > 0 (ring of that many event pairs; 0 disables); read back after
+ * ls_amd_plan_check / a stream sync.  *count receives the number of samples written (<= capacity)
+ * and the ring is reset. */
+int ls_amd_plan_enable_timing(ls_amd_plan *plan, int max_samples);
+int ls_amd_plan_kernel_times(ls_amd_plan *plan, float *ms, int capacity, int *count);
+
+/* x[i] = u(hash(states[i], seed)) - 0.5 (re and im for c128): deterministic vectors keyed by the
+ * basis state, identical for every partitioning (tests / bench input) */
+int ls_amd_fill_random(int64_t n, uint64_t const *d_states, uint64_t seed, ls_amd_dtype dtype,
+                       void *d_out, void *stream);
+
+/* one-partition-per-process building blocks -------------------------------------------------
+ * ls_amd_diag      y = d(sigma) x           (localDiagonal, DMV:59-71; no-op without diag terms)
+ * ls_amd_generate  rows of `round` -> term expansion, projection, hash bucketing; packets for
+ *                  remote owners are packed into d_send as P segments in destination order,
+ *                  segment d = [beta x count_d][value x count_d] with count_d from
+ *                  ls_amd_plan_send_counts; packets owned by this partition are indexed and
+ *                  atomically added into d_y directly   (Producer.run, DMV:663-734)
+ * ls_amd_scatter   n received packets (beta at d_betas, values at d_values) -> local index ->
+ *                  atomic y[idx] += value                 (Consumer.run / localProcess, DMV:73-127)
+ * ------------------------------------------------------------------------------------------ */
+int ls_amd_diag(ls_amd_plan *plan, void const *d_x, void *d_y, void *stream);
+int ls_amd_generate(ls_amd_plan *plan, int round, void const *d_x, void *d_y, void *d_send,
+                    void *stream);
+int ls_amd_scatter(ls_amd_plan *plan, int64_t n, uint64_t const *d_betas, void const *d_values,
+                   void *d_y, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Basis construction on the device (enumerateStates, StatesEnumeration.chpl:516-585) and the
+ * block <-> hashed layout converters (BlockToHashed.chpl:87-208, HashedToBlock.chpl:67-153).
+ * ------------------------------------------------------------------------------------------ */
+/* Enumerates all representatives in ascending order into a freshly allocated device array
+ * (*d_states, ls_amd_free it) and, when d_masks != NULL, the owner hash64_01 % num_locales of each
+ * state in the same (global ascending, "block") order. */
+int ls_amd_enumerate_states(ls_hs_basis const *basis, int num_locales, uint64_t **d_states,
+                            uint8_t **d_masks, int64_t *count, void *stream);
+/* counts[p] = number of masks equal to p */
+int ls_amd_mask_counts(int64_t n, uint8_t const *d_masks, int num_locales, int64_t *counts,
+                       void *stream);
+/* stable partition of a block-order array (elt_size 8 or 16 bytes) into P hashed parts */
+int ls_amd_block_to_hashed(int64_t n, uint8_t const *d_masks, int num_locales, int elt_size,
+                           void const *d_src, void *const *d_dest, void *stream);
+/* inverse: k-way unmerge by masks */
+int ls_amd_hashed_to_block(int64_t n, uint8_t const *d_masks, int num_locales, int elt_size,
+                           void const *const *d_src, void *d_dest, void *stream);
+
+/* test hooks: evaluate compiled host-side tables on the CPU (no device work) ------------------ */
+int ls_amd_basis_group_order(ls_hs_basis const *basis);
+uint64_t ls_amd_basis_apply_group_element(ls_hs_basis const *basis, int element, uint64_t state);
+int ls_amd_basis_group_character(ls_hs_basis const *basis, int element, double *re, double *im);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LS_AMD_H */

@@ -1,0 +1,146 @@
+/* ls_hs.h -- the subset of the lattice-symmetries-haskell C ABI ("ls_hs_*") that the reference's hot
+ * path consumes, re-provided natively.
+ *
+ * The reference declares these as `extern` in /root/reference/src/FFI.chpl:85-239 and gets them from
+ * liblattice_symmetries_haskell (pinned 14e7319, /root/reference/.github/workflows/ci.yml:6), which is
+ * not vendored.  Struct prefixes below are layout-compatible with what the reference looks inside
+ * (FFI.chpl:90-126); everything after the "other stuff" marker is ours.  Field lists of
+ * ls_hs_nonbranching_terms beyond number_terms/number_bits are [upstream-memory].
+ *
+ * Host side is plain C11; no HIP or torch types appear in any signature.
+ */
+#ifndef LS_HS_H
+#define LS_HS_H
+
+#include <stdbool.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Chapel runtime's external array descriptor (FFI.chpl:36-55 builds them with
+ * chpl_make_external_array_ptr); `freer` is a void(*)(void*) or NULL for borrowed storage. */
+typedef struct chpl_external_array {
+    void *elts;
+    uint64_t num_elts;
+    void *freer;
+} chpl_external_array;
+
+typedef int ls_hs_particle_type; /* FFI.chpl:85-88 */
+enum { LS_HS_SPIN = 0, LS_HS_SPINFUL_FERMION = 1, LS_HS_SPINLESS_FERMION = 2 };
+
+typedef struct ls_hs_scalar { double re, im; } ls_hs_scalar; /* == double _Complex */
+
+/* FFI.chpl:90-93 */
+typedef struct ls_hs_basis_kernels {
+    void *state_index_kernel;
+    void *state_index_data;
+} ls_hs_basis_kernels;
+
+struct ls_amd_basis_ext; /* symmetry group, device mirrors (private) */
+
+/* FFI.chpl:94-105 */
+typedef struct ls_hs_basis {
+    int number_sites;
+    int number_particles;
+    int number_up;
+    ls_hs_particle_type particle_type;
+    int spin_inversion;
+    bool state_index_is_identity;
+    bool requires_projection;
+    ls_hs_basis_kernels *kernels;
+    chpl_external_array representatives;
+    /* ... other stuff ... */
+    struct ls_amd_basis_ext *ext;
+} ls_hs_basis;
+
+/* FFI.chpl:109-113.  Term t acts on a basis state alpha as
+ *   active  iff (alpha & m[t]) == r[t]
+ *   beta    =  alpha ^ x[t]                      (l[t] = r[t] ^ (x[t] & m[t]) is the image pattern)
+ *   coeff   =  v[t] * (-1)^popcount(alpha & s[t])
+ * Diagonal terms have x == 0.  number_words == 1 only (DMV:1099-1100). */
+typedef struct ls_hs_nonbranching_terms {
+    int number_terms;
+    int number_bits;
+    ls_hs_scalar const *v;
+    uint64_t const *m;
+    uint64_t const *l;
+    uint64_t const *r;
+    uint64_t const *x;
+    uint64_t const *s;
+} ls_hs_nonbranching_terms;
+
+struct ls_amd_operator_ext;
+
+/* FFI.chpl:114-119 */
+typedef struct ls_hs_operator {
+    ls_hs_basis *basis;
+    ls_hs_nonbranching_terms *off_diag_terms;
+    ls_hs_nonbranching_terms *diag_terms;
+    /* ... other stuff ... */
+    struct ls_amd_operator_ext *ext;
+} ls_hs_operator;
+
+/* FFI.chpl:233-239 */
+typedef struct ls_chpl_kernels {
+    void *enumerate_states;
+    void *operator_apply_off_diag;
+    void *operator_apply_diag;
+    void *matrix_vector_product;
+} ls_chpl_kernels;
+
+void ls_hs_init(void);  /* FFI.chpl:128 */
+void ls_hs_exit(void);  /* FFI.chpl:129 */
+
+/* Constructors.  Upstream builds these from JSON / expressions (ls_hs_basis_from_json FFI.chpl:156,
+ * ls_hs_create_operator FFI.chpl:191-192); here the host mirror parses the YAML
+ * (distributed-matvec_amd/config.py) and hands over flat arrays.
+ *   hamming_weight < 0  : unrestricted;  spin_inversion in {0, +1, -1};
+ *   permutations[g*number_sites + i] = p_i of generator g ("output bit i = input bit p_i");
+ *   sectors[g] : character of generator g is exp(-2 pi i sector / order(g)).
+ * Returns NULL on error (message via ls_amd_last_error()). */
+ls_hs_basis *ls_hs_create_spin_basis(int number_sites, int hamming_weight, int spin_inversion,
+                                     int number_generators, int const *permutations,
+                                     int const *sectors);
+ls_hs_basis *ls_hs_clone_basis(ls_hs_basis const *basis);       /* FFI.chpl:141 */
+void ls_hs_destroy_basis(ls_hs_basis *basis);                   /* FFI.chpl:142 */
+
+/* v: interleaved (re, im) pairs.  Terms are split into diagonal / off-diagonal, merged and the
+ * off-diagonal ones grouped by flip mask. */
+ls_hs_operator *ls_hs_create_operator_from_terms(ls_hs_basis const *basis, int number_terms,
+                                                 double const *v, uint64_t const *m,
+                                                 uint64_t const *r, uint64_t const *x,
+                                                 uint64_t const *s);
+ls_hs_operator *ls_hs_clone_operator(ls_hs_operator const *op); /* FFI.chpl:193 */
+void ls_hs_destroy_operator(ls_hs_operator *op);                /* FFI.chpl:196 */
+
+uint64_t ls_hs_min_state_estimate(ls_hs_basis const *basis);            /* FFI.chpl:143 */
+uint64_t ls_hs_max_state_estimate(ls_hs_basis const *basis);            /* FFI.chpl:144 */
+int ls_hs_basis_number_bits(ls_hs_basis const *basis);                  /* FFI.chpl:145 */
+int ls_hs_basis_number_words(ls_hs_basis const *basis);                 /* FFI.chpl:146 */
+bool ls_hs_basis_has_fixed_hamming_weight(ls_hs_basis const *basis);    /* FFI.chpl:147 */
+bool ls_hs_basis_has_spin_inversion_symmetry(ls_hs_basis const *basis); /* FFI.chpl:148 */
+bool ls_hs_basis_has_permutation_symmetries(ls_hs_basis const *basis);  /* FFI.chpl:149 */
+bool ls_hs_basis_requires_projection(ls_hs_basis const *basis);         /* FFI.chpl:150 */
+
+ptrdiff_t ls_hs_fixed_hamming_state_to_index(uint64_t basis_state);                  /* FFI.chpl:165 */
+uint64_t ls_hs_fixed_hamming_index_to_state(ptrdiff_t state_index, int hamming_weight); /* FFI.chpl:166 */
+
+/* Builds basis->representatives through the registered enumerate_states kernel (FFI.chpl:168). */
+void ls_hs_basis_build(ls_hs_basis *basis);
+/* Borrows `states` (host memory) as the basis' representatives (FFI.chpl:170-171). */
+void ls_hs_unchecked_set_representatives(ls_hs_basis *basis, chpl_external_array const *states);
+
+int ls_hs_operator_max_number_off_diag(ls_hs_operator const *op); /* FFI.chpl:200 */
+bool ls_hs_operator_is_hermitian(ls_hs_operator const *op);       /* FFI.chpl:201 */
+bool ls_hs_operator_is_real(ls_hs_operator const *op);            /* FFI.chpl:202 */
+
+void ls_hs_internal_set_chpl_kernels(ls_chpl_kernels const *kernels); /* FFI.chpl:239 */
+ls_chpl_kernels const *ls_hs_internal_get_chpl_kernels(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LS_HS_H */

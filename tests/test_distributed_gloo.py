@@ -1,0 +1,164 @@
+"""world_size-2/3 exchange logic of distributed-matvec_amd/distributed.py on CPU (gloo).
+
+The HIP engine cannot run here, so an oracle-backed engine with the same interface is injected:
+what is under test is the host logic of the N>1 path -- round agreement, the counts exchange, exact
+all_to_all_single splits, segment layout, scatter of every received segment -- against the
+single-locale oracle result."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class OracleEngine:
+    """CPU stand-in for HipEngine (TEST ONLY): same interface, oracle arithmetic."""
+
+    def __init__(self, matrix, representatives, dtype, num_partitions, my_partition, num_rounds):
+        from oracle import c_oracle as CO
+
+        self.o = matrix  # a COracle
+        self.m = matrix.model
+        self.reps = np.ascontiguousarray(representatives.numpy().view(np.uint64))
+        self.P, self.me, self.num_rounds = num_partitions, my_partition, num_rounds
+        self.cplx = dtype == torch.complex128
+        self.packet_bytes = 24 if self.cplx else 16
+        self.CO = CO
+        n = len(self.reps)
+        self.bounds = [(n * r // num_rounds, n * (r + 1) // num_rounds) for r in range(num_rounds)]
+        self.norms = self.o.state_info(self.reps)[2] if self.m.has_permutations else None
+
+    def _expand(self, rnd, x):
+        lo, hi = self.bounds[rnd]
+        rows = self.reps[lo:hi]
+        betas, cs, offs = self.o.apply_off_diag(rows)
+        row_of = np.repeat(np.arange(lo, hi), np.diff(offs))
+        vals = cs * (x[row_of] if x is not None else 1.0)
+        if self.m.has_permutations:
+            reps, chars, norms = self.o.state_info(betas)
+            vals = vals * chars * norms / self.norms[row_of]
+            keep = norms > 0
+            betas, vals = reps[keep], vals[keep]
+        elif self.m.spin_inversion != 0:
+            flipped = betas ^ np.uint64(self.m.mask)
+            sw = flipped < betas
+            betas = np.where(sw, flipped, betas)
+            vals = np.where(sw, vals * self.m.spin_inversion, vals)
+        keys = self.CO.locale_idx_of(betas, self.P)
+        return betas, vals, keys
+
+    def send_counts(self, rnd):
+        _, _, keys = self._expand(rnd, None)
+        c = np.bincount(keys, minlength=self.P)
+        c[self.me] = 0
+        return [int(v) for v in c]
+
+    def alloc_bytes(self, n):
+        return torch.zeros(max(int(n), 8), dtype=torch.uint8)
+
+    def diag(self, x, y):
+        d = self.o.apply_diag(self.reps)
+        if self.m.diag.v.size:
+            y.copy_(torch.from_numpy(d * x.numpy()))
+
+    def _add(self, y, betas, vals):
+        idx = self.CO.state_index(self.reps, betas)
+        assert (idx >= 0).all()
+        yn = y.numpy()
+        np.add.at(yn, idx, vals if self.cplx else vals.real)
+
+    def generate(self, rnd, x, y, send):
+        betas, vals, keys = self._expand(rnd, x.numpy())
+        self._add(y, betas[keys == self.me], vals[keys == self.me])
+        buf = send.numpy()
+        off = 0
+        for d in range(self.P):
+            if d == self.me:
+                continue
+            sel = keys == d
+            n = int(sel.sum())
+            buf[off:off + 8 * n] = betas[sel].view(np.uint8)
+            v = vals[sel] if self.cplx else np.ascontiguousarray(vals[sel].real)
+            w = 16 if self.cplx else 8
+            buf[off + 8 * n:off + (8 + w) * n] = v.view(np.uint8)
+            off += (8 + w) * n
+
+    def scatter(self, recv, byte_offset, n, y):
+        buf = recv.numpy()
+        betas = buf[byte_offset:byte_offset + 8 * n].view(np.uint64)
+        w = 16 if self.cplx else 8
+        vals = buf[byte_offset + 8 * n:byte_offset + (8 + w) * n].view(np.complex128 if self.cplx else np.float64)
+        self._add(y, betas.copy(), vals.copy())
+
+    def check(self):
+        pass
+
+
+def _worker(rank, world, port, name, cplx, num_rounds, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import model_config
+    from oracle import c_oracle as CO
+    from oracle import model as M
+
+    from distributed_matvec_amd.distributed import DistributedOperator
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        o = CO.COracle(M.model_from_config(model_config(name)))
+        reps = o.enumerate()
+        rs = np.random.RandomState(5)
+        x = rs.rand(len(reps)) - 0.5
+        if cplx:
+            x = x + 1j * (rs.rand(len(reps)) - 0.5)
+        keys = CO.locale_idx_of(reps, world)
+        mine = keys == rank
+        my_reps = torch.from_numpy(reps[mine].view(np.int64).copy())
+        my_x = torch.from_numpy(x[mine].copy())
+        my_y = torch.full_like(my_x, 7.0)  # overwritten by the diagonal pass
+        op = DistributedOperator(o, my_reps, my_x.dtype, engine_factory=OracleEngine, num_rounds=num_rounds)
+        assert op.num_rounds == (num_rounds if num_rounds else 1)
+        # send/recv count matrices are transposes of each other across ranks
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (op.send_counts, op.recv_counts))
+        for r in range(op.num_rounds):
+            for a in range(world):
+                for b in range(world):
+                    assert gathered[a][0][r][b] == gathered[b][1][r][a]
+        op.matvec(my_x, my_y, check=True)
+        # reductions used by the eigensolver callbacks
+        nrm2 = op.dot(my_x, my_x)
+        assert abs(complex(nrm2) - np.vdot(x, x)) < 1e-9
+        np.save(os.path.join(out_dir, f"y{rank}.npy"), my_y.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,world,cplx,rounds", [
+    ("heisenberg_chain_12", 2, False, 1),
+    ("heisenberg_chain_10", 2, False, 3),
+    ("heisenberg_kagome_12_symm", 2, True, 2),
+    ("heisenberg_chain_16", 3, False, 2),
+])
+def test_all_to_all_exchange(tmp_path, name, world, cplx, rounds):
+    sys.path.insert(0, ROOT)
+    from helpers import oracle_for, oracle_reps
+    from oracle import c_oracle as CO
+
+    port = 29600 + (os.getpid() % 200) + world * 7 + rounds
+    mp.spawn(_worker, args=(world, port, name, cplx, rounds, str(tmp_path)), nprocs=world, join=True)
+    reps = oracle_reps(name)
+    rs = np.random.RandomState(5)
+    x = rs.rand(len(reps)) - 0.5
+    if cplx:
+        x = x + 1j * (rs.rand(len(reps)) - 0.5)
+    want = oracle_for(name).local_matvec(reps, x)
+    keys = CO.locale_idx_of(reps, world)
+    parts = [np.load(os.path.join(str(tmp_path), f"y{r}.npy")) for r in range(world)]
+    got = CO.hashed_to_block(parts, keys)
+    assert np.abs(got - want).max() <= 1e-12 * max(1.0, np.abs(want).max())

@@ -1,0 +1,338 @@
+"""Parity of the HIP path (through the C ABI) with the oracle.  Mirrors
+/root/reference/test/TestMatrixVectorProduct.chpl: load config -> enumerate -> block->hashed ->
+matrixVectorProduct -> hashed->block -> compare, same tolerance formula, same case matrix
+(/root/reference/Makefile:88-125), plus numLocales in {1,2,3,4,8} as logical partitions."""
+import numpy as np
+import pytest
+
+from helpers import (CHECK_MODELS, SMALL_MODELS, approx_equal, complex_translation_config, golden_vectors,
+                     model_config, oracle_for, oracle_reps)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch as t
+
+    if not t.cuda.is_available():
+        pytest.fail("GPU tests need a HIP device (the product has no CPU fallback)")
+    t.cuda.set_device(0)
+    return t
+
+
+def setup_model(torch, cfg, P):
+    import distributed_matvec_amd as D
+
+    basis, h = D.loadConfigFromDict(cfg, hamiltonian=True)
+    reps, masks = D.enumerateStates(basis, P)
+    return D, basis, h, reps, masks
+
+
+def run_matvec(torch, D, h, reps, masks, x_block, P, mode="auto"):
+    xb = torch.from_numpy(np.ascontiguousarray(x_block)).cuda()
+    x = D.arrFromBlockToHashed(xb, masks, P)
+    y = [torch.zeros_like(v) for v in x]
+    pl = D.matrixVectorProduct(h, x, y, reps, mode=mode)
+    return D.arrFromHashedToBlock(y, masks).cpu().numpy(), pl
+
+
+def assert_close(got, want, name=""):
+    ok = approx_equal(got, want)
+    if not ok.all():
+        bad = np.flatnonzero(~ok)[:5]
+        raise AssertionError(f"{name}: {len(np.flatnonzero(~ok))} mismatches, e.g. at {bad}: {got[bad]} vs {want[bad]}")
+
+
+@pytest.mark.parametrize("name", CHECK_MODELS)
+def test_enumeration_is_bit_exact(torch, name):
+    """TestStatesEnumeration.chpl: representatives == golden, exact."""
+    D, basis, h, reps, masks = setup_model(torch, model_config(name), 1)
+    want = oracle_reps(name)
+    got = reps[0].cpu().numpy().view(np.uint64)
+    assert got.shape == want.shape and np.array_equal(got, want)
+    assert masks.cpu().numpy().max(initial=0) == 0
+
+
+@pytest.mark.parametrize("name", ["heisenberg_chain_10", "heisenberg_chain_12", "heisenberg_chain_16", "heisenberg_chain_24_symm", "issue_01"])
+@pytest.mark.parametrize("P", [2, 3, 8])
+def test_hashed_layout_round_trip(torch, name, P):
+    from oracle import c_oracle as CO
+
+    D, basis, h, reps, masks = setup_model(torch, model_config(name), P)
+    want = oracle_reps(name)
+    keys = CO.locale_idx_of(want, P)
+    assert np.array_equal(masks.cpu().numpy(), keys)  # bit-exact owner of every state
+    parts = CO.block_to_hashed(want, keys, P)
+    for got, w in zip(reps, parts):
+        assert np.array_equal(got.cpu().numpy().view(np.uint64), w)
+    back = D.arrFromHashedToBlock(reps, masks).cpu().numpy().view(np.uint64)
+    assert np.array_equal(back, want)
+    # 16-byte elements (c128) through the converters
+    z = torch.from_numpy(np.random.RandomState(1).rand(len(want)) + 1j * np.random.RandomState(2).rand(len(want))).cuda()
+    zz = D.arrFromHashedToBlock(D.arrFromBlockToHashed(z, masks, P), masks)
+    assert torch.equal(z, zz)
+
+
+@pytest.mark.parametrize("name", CHECK_MODELS)
+@pytest.mark.parametrize("mode", ["push", "pull"])
+def test_single_locale_matvec_f64(torch, name, mode):
+    D, basis, h, reps, masks = setup_model(torch, model_config(name), 1)
+    want_reps = oracle_reps(name)
+    x = np.random.RandomState(42).rand(len(want_reps)) - 0.5
+    want = oracle_for(name).local_matvec(want_reps, x)
+    if mode == "pull" and basis.hasPermutationSymmetries():
+        pytest.skip("pull mode is a direct-kernel mode (no permutation symmetries)")
+    got, pl = run_matvec(torch, D, h, reps, masks, x, 1, mode)
+    assert pl.kernel == ("tile" if basis.hasPermutationSymmetries() else f"direct-{mode}")
+    assert_close(got, want, name)
+
+
+@pytest.mark.parametrize("name", CHECK_MODELS)
+def test_single_locale_matvec_c128(torch, name):
+    D, basis, h, reps, masks = setup_model(torch, model_config(name), 1)
+    want_reps = oracle_reps(name)
+    rs = np.random.RandomState(43)
+    x = (rs.rand(len(want_reps)) - 0.5) + 1j * (rs.rand(len(want_reps)) - 0.5)
+    want = oracle_for(name).local_matvec(want_reps, x)
+    for mode in ("push", "pull"):
+        if mode == "pull" and basis.hasPermutationSymmetries():
+            continue
+        got, _ = run_matvec(torch, D, h, reps, masks, x, 1, mode)
+        assert np.abs(got - want).max() <= 1e-10 * max(1.0, np.abs(want).max()), (name, mode)  # north-star tolerance
+        assert_close(got.real, want.real, name)
+        assert_close(got.imag, want.imag, name)
+
+
+@pytest.mark.parametrize("name", CHECK_MODELS)
+@pytest.mark.parametrize("P", [2, 3, 4, 8])
+def test_partitioned_matvec(torch, name, P):
+    """numLocales = P logical partitions on one device (hash64_01 % P ownership, true modulo)."""
+    D, basis, h, reps, masks = setup_model(torch, model_config(name), P)
+    want_reps = oracle_reps(name)
+    x = np.random.RandomState(44).rand(len(want_reps)) - 0.5
+    want = oracle_for(name).local_matvec(want_reps, x)
+    got, pl = run_matvec(torch, D, h, reps, masks, x, P)
+    assert pl.kernel == "tile"
+    assert_close(got, want, f"{name} P={P}")
+    if P == 4:
+        xc = x + 1j * (np.random.RandomState(45).rand(len(want_reps)) - 0.5)
+        gotc, _ = run_matvec(torch, D, h, reps, masks, xc, P)
+        wantc = oracle_for(name).local_matvec(want_reps, xc)
+        assert np.abs(gotc - wantc).max() <= 1e-12 * max(1.0, np.abs(wantc).max())
+
+
+def test_golden_vectors(torch):
+    """x from the recipe of input_for_matvec.py, y from the dense projector oracle (committed)."""
+    v = golden_vectors()
+    n = 0
+    for name in SMALL_MODELS:
+        if name + "/y" not in v:
+            continue
+        D, basis, h, reps, masks = setup_model(torch, model_config(name), 1)
+        assert np.array_equal(reps[0].cpu().numpy().view(np.uint64), v[name + "/representatives"])
+        got, _ = run_matvec(torch, D, h, reps, masks, v[name + "/x"], 1)
+        assert_close(got, v[name + "/y"], name)
+        n += 1
+    assert n >= 8
+
+
+def test_chain_24_all_paths(torch):
+    """BASELINE config[1]: heisenberg_chain_24 (2 704 156 states), f64 and c128, every kernel family."""
+    from oracle import c_oracle as CO
+
+    name = "heisenberg_chain_24"
+    o = oracle_for(name)
+    want_reps = o.enumerate()
+    x = np.random.RandomState(42).rand(len(want_reps)) - 0.5
+    want = o.local_matvec(want_reps, x)
+    for P, mode in ((1, "push"), (1, "pull"), (2, "auto"), (8, "auto")):
+        D, basis, h, reps, masks = setup_model(torch, model_config(name), P)
+        if P == 8:
+            counts = [int(r.numel()) for r in reps]
+            assert counts == [338991, 338013, 338427, 337639, 338337, 337518, 337261, 337970]  # Appendix B
+        got, pl = run_matvec(torch, D, h, reps, masks, x, P, mode)
+        assert_close(got, want, f"chain_24 P={P} {mode}")
+    xc = x + 1j * (np.random.RandomState(43).rand(len(want_reps)) - 0.5)
+    wantc = o.local_matvec(want_reps, xc)
+    D, basis, h, reps, masks = setup_model(torch, model_config(name), 1)
+    for mode in ("push", "pull"):
+        gotc, _ = run_matvec(torch, D, h, reps, masks, xc, 1, mode)
+        assert np.abs(gotc - wantc).max() <= 1e-10 * np.abs(wantc).max()
+
+
+@pytest.mark.parametrize("L,sector", [(8, 1), (12, 5), (10, 3)])
+@pytest.mark.parametrize("P", [1, 3])
+def test_complex_characters(torch, L, sector, P):
+    """momentum sectors with complex characters (c128 only) -- beyond the reference's own test matrix."""
+    from oracle import c_oracle as CO
+    from oracle import model as M
+
+    cfg = complex_translation_config(L, sector)
+    o = CO.COracle(M.model_from_config(cfg))
+    want_reps = o.enumerate()
+    D, basis, h, reps, masks = setup_model(torch, cfg, P)
+    assert np.array_equal(D.arrFromHashedToBlock(reps, masks).cpu().numpy().view(np.uint64), want_reps)
+    rs = np.random.RandomState(46)
+    x = (rs.rand(len(want_reps)) - 0.5) + 1j * (rs.rand(len(want_reps)) - 0.5)
+    want = o.local_matvec(want_reps, x)
+    got, _ = run_matvec(torch, D, h, reps, masks, x, P)
+    assert np.abs(got - want).max() <= 1e-12 * max(1.0, np.abs(want).max())
+    # f64 vectors cannot carry complex characters: loud error
+    with pytest.raises(D.LsAmdError):
+        run_matvec(torch, D, h, reps, masks, x.real.copy(), P)
+
+
+def test_y_is_overwritten_by_diagonal_then_accumulated(torch):
+    """DMV:1062-1069: with diagonal terms y is assigned first (garbage in y is harmless); without
+    them y is accumulated into."""
+    import distributed_matvec_amd as D
+    from distributed_matvec_amd import config
+
+    name = "heisenberg_chain_16"
+    Dm, basis, h, reps, masks = setup_model(torch, model_config(name), 1)
+    want_reps = oracle_reps(name)
+    x = np.random.RandomState(47).rand(len(want_reps)) - 0.5
+    want = oracle_for(name).local_matvec(want_reps, x)
+    for mode in ("push", "pull"):
+        xs = [torch.from_numpy(x).cuda()]
+        ys = [torch.full((len(x),), 123.0, dtype=torch.float64, device="cuda")]
+        D.matrixVectorProduct(h, xs, ys, reps, mode=mode)
+        assert_close(ys[0].cpu().numpy(), want)
+    # off-diagonal-only operator: y += H x
+    cfg = model_config(name)
+    cfg2 = {"basis": cfg["basis"], "hamiltonian": {"terms": [t for t in cfg["hamiltonian"]["terms"] if "ᶻ" not in t["expression"]]}}
+    from oracle import c_oracle as CO
+    from oracle import model as M
+
+    o2 = CO.COracle(M.model_from_config(cfg2))
+    basis2, h2 = D.loadConfigFromDict(cfg2, hamiltonian=True)
+    assert h2.numberDiagTerms() == 0
+    want2 = o2.local_matvec(want_reps, x, y=np.full(len(x), 5.0))
+    for mode in ("push", "pull"):
+        ys = [torch.full((len(x),), 5.0, dtype=torch.float64, device="cuda")]
+        D.matrixVectorProduct(h2, [torch.from_numpy(x).cuda()], ys, reps, mode=mode)
+        assert_close(ys[0].cpu().numpy(), want2)
+
+
+def test_invalid_operator_is_reported(torch):
+    """an operator that leaves the basis => the reference halts with "invalid index" (DMV:115-118)."""
+    import distributed_matvec_amd as D
+    from distributed_matvec_amd import config
+
+    cfg = config.heisenberg_chain_config(8)
+    cfg["hamiltonian"]["terms"].append({"expression": "σˣ₀", "sites": [[0]]})
+    basis, h = D.loadConfigFromDict(cfg, hamiltonian=True)
+    for P in (1, 2):
+        reps, masks = D.enumerateStates(basis, P)
+        x = [torch.ones(r.numel(), dtype=torch.float64, device="cuda") for r in reps]
+        y = [torch.zeros_like(v) for v in x]
+        with pytest.raises(D.LsAmdError, match="invalid index"):
+            D.matrixVectorProduct(h, x, y, reps, mode="push" if P == 1 else "auto")
+
+
+def test_kernel_table_entry_points(torch):
+    """the four ls_chpl_kernels entries on host pointers (LatticeSymmetries.chpl:16-25)."""
+    import distributed_matvec_amd as D
+
+    name = "heisenberg_chain_12"
+    basis, h = D.loadConfigFromDict(model_config(name), hamiltonian=True)
+    h.basis.build()  # kernels->enumerate_states
+    want_reps = oracle_reps(name)
+    assert np.array_equal(h.basis.representatives(), want_reps)
+    x = np.random.RandomState(48).rand(len(want_reps)) - 0.5
+    o = oracle_for(name)
+    assert_close(h @ x, o.local_matvec(want_reps, x))  # kernels->matrix_vector_product
+    alphas = want_reps[::7].copy()
+    assert np.array_equal(h.applyDiag(alphas), o.apply_diag(alphas))
+    betas, coeffs, offsets = h.applyOffDiag(alphas)
+    wb, wc, wo = o.apply_off_diag(alphas)
+    assert np.array_equal(offsets, wo)
+    n = offsets[-1]
+    for i in range(len(alphas)):
+        a, b = offsets[i], offsets[i + 1]
+        got = sorted(zip(betas[a:b].tolist(), coeffs[a:b].tolist()))
+        want = sorted(zip(wb[a:b].tolist(), wc[a:b].tolist()))
+        assert got == want
+    # projected bases: apply_* halt (BatchedOperator.chpl:226-227)
+    basis2, h2 = D.loadConfigFromDict(model_config("heisenberg_chain_10"), hamiltonian=True)
+    with pytest.raises(D.LsAmdError, match="projection"):
+        h2.applyDiag(np.array([31], dtype=np.uint64))
+    # inversion-only basis through the host entry
+    h2.basis.build()
+    r10 = oracle_reps("heisenberg_chain_10")
+    assert np.array_equal(h2.basis.representatives(), r10)
+    x10 = np.random.RandomState(42).rand(126) - 0.5
+    assert_close(h2 @ x10, oracle_for("heisenberg_chain_10").local_matvec(r10, x10))
+
+
+def test_primme_callback(torch):
+    """ls_chpl_primme_matvec (Diagonalize.chpl:134-162): block of columns with leading dimensions."""
+    import ctypes as C
+
+    import distributed_matvec_amd as D
+    from distributed_matvec_amd import _lib
+
+    name = "heisenberg_chain_16"
+    basis, h = D.loadConfigFromDict(model_config(name), hamiltonian=True)
+    h.basis.build()
+    reps = oracle_reps(name)
+    n, ld, bs = len(reps), len(reps) + 5, 3
+    X = np.zeros((bs, ld))
+    X[:, :n] = np.random.RandomState(49).rand(bs, n) - 0.5
+    Y = np.zeros((bs, ld))
+    lib = C.CDLL(_lib.LIB_PATH)
+
+    class View(C.Structure):  # the prefix of primme_params this library reads
+        _fields_ = [("n", C.c_int64), ("pad0", C.c_void_p), ("t0", C.c_int), ("pad1", C.c_void_p), ("t1", C.c_int),
+                    ("pad2", C.c_void_p), ("t2", C.c_int), ("numProcs", C.c_int), ("procID", C.c_int), ("nLocal", C.c_int64)]
+
+    # build a full ls_primme_params_view-sized buffer and set nLocal / matrix at their ABI offsets
+    buf = (C.c_char * 512)()
+    view = View.from_buffer(buf)
+    view.n = n
+    view.nLocal = n
+    matrix_offset = 264  # offsetof(ls_primme_params_view, matrix), asserted below via the C library
+    C.c_void_p.from_buffer(buf, matrix_offset).value = C.cast(h.payload, C.c_void_p).value
+    ldx, ldy, blk, ierr = C.c_int64(ld), C.c_int64(ld), C.c_int(bs), C.c_int(-7)
+    lib.ls_chpl_primme_matvec(X.ctypes.data_as(C.c_void_p), C.byref(ldx), Y.ctypes.data_as(C.c_void_p), C.byref(ldy),
+                              C.byref(blk), C.cast(buf, C.c_void_p), C.byref(ierr))
+    _lib.raise_pending_halt()
+    assert ierr.value == 0
+    o = oracle_for(name)
+    for k in range(bs):
+        assert_close(Y[k, :n], o.local_matvec(reps, X[k, :n].copy()))
+
+
+def test_properties_at_scale(torch):
+    """chain_28 (40 116 600 states): no oracle run; size-independent properties instead --
+    push == pull, 1 partition == 4 partitions, <u, H v> == <H u, v>."""
+    import distributed_matvec_amd as D
+    from distributed_matvec_amd import config
+
+    cfg = config.heisenberg_chain_config(28)
+    basis, h = D.loadConfigFromDict(cfg, hamiltonian=True)
+    reps, masks = D.enumerateStates(basis, 1)
+    n = reps[0].numel()
+    assert n == 40116600
+    # sortedness + popcount of the enumeration
+    r = reps[0]
+    assert bool((r[1:] > r[:-1]).all())
+    g = torch.Generator(device="cuda").manual_seed(1)
+    u = torch.rand(n, dtype=torch.float64, device="cuda", generator=g) - 0.5
+    v = torch.rand(n, dtype=torch.float64, device="cuda", generator=g) - 0.5
+    Hu_push, Hu_pull, Hv = torch.zeros_like(u), torch.zeros_like(u), torch.zeros_like(u)
+    D.matrixVectorProduct(h, [u], [Hu_push], reps, mode="push")
+    D.matrixVectorProduct(h, [u], [Hu_pull], reps, mode="pull")
+    D.matrixVectorProduct(h, [v], [Hv], reps, mode="pull")
+    scale = float(Hu_pull.abs().max())
+    assert float((Hu_push - Hu_pull).abs().max()) <= 1e-12 * scale
+    lhs, rhs = float(torch.dot(v, Hu_pull)), float(torch.dot(Hv, u))
+    assert abs(lhs - rhs) <= 1e-10 * max(1.0, abs(lhs))
+    # 4 logical partitions give the same vector
+    reps4, masks4 = D.enumerateStates(basis, 4)
+    u4 = D.arrFromBlockToHashed(u, masks4, 4)
+    y4 = [torch.zeros_like(t) for t in u4]
+    D.matrixVectorProduct(h, u4, y4, reps4)
+    back = D.arrFromHashedToBlock(y4, masks4)
+    assert float((back - Hu_pull).abs().max()) <= 1e-12 * scale

@@ -1,0 +1,230 @@
+"""CPU-side checks of the product's host logic (no kernels run): the C-ABI library loads and exports
+every symbol include/*.h declares; YAML -> term tables; symmetry groups, characters and the compiled
+bit-permutation networks; loud failure without a GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import distributed_matvec_amd as D
+from distributed_matvec_amd import _lib, config
+from helpers import (CHECK_MODELS, SMALL_MODELS, apply_terms_python, complex_translation_config, golden,
+                     model_config, oracle_for, product_terms)
+from oracle import model as M
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    names = set()
+    for h in ("ls_hs.h", "ls_chpl.h", "ls_amd.h"):
+        src = open(os.path.join(ROOT, "include", h)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        for m in re.finditer(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\([^;{]*\)\s*;", src):
+            name = m.group(1)
+            if name.startswith(("ls_", "primme")):
+                names.add(name)
+    return names
+
+
+def test_library_exports_every_declared_symbol():
+    lib = C.CDLL(_lib.LIB_PATH)
+    names = declared_symbols()
+    assert len(names) >= 60
+    missing = [n for n in sorted(names) if not hasattr(lib, n)]
+    assert not missing, missing
+    # and the typed binding covers them
+    _lib.load()
+
+
+def test_no_gpu_means_loud_failure():
+    L = _lib.load()
+    if L.ls_amd_device_count() > 0:
+        pytest.skip("a GPU is present")
+    basis, h = D.loadConfigFromDict(model_config("heisenberg_chain_10"), hamiltonian=True)
+    with pytest.raises(D.LsAmdError):
+        D.enumerateStates(basis)
+    with pytest.raises(D.LsAmdError):
+        basis.build()
+    with pytest.raises(D.LsAmdError):
+        h @ np.zeros(126)
+
+
+@pytest.mark.parametrize("name", sorted(golden()["models"].keys()))
+def test_basis_flags_and_groups_match_oracle(name):
+    cfg = model_config(name)
+    basis = D.loadConfigFromDict(cfg)
+    m = M.model_from_config(cfg)
+    assert basis.numberSites() == m.number_sites
+    assert basis.requiresProjection() == m.requires_projection
+    assert basis.isStateIndexIdentity() == m.state_index_is_identity
+    assert basis.hasPermutationSymmetries() == m.has_permutations
+    assert basis.hasSpinInversionSymmetry() == (m.spin_inversion != 0)
+    assert basis.isHammingWeightFixed() == (m.hamming_weight >= 0)
+    assert basis.groupOrder() == m.group.perms.shape[0]
+    assert basis.numberWords() == 1
+    # min/max state estimates bracket the candidates the enumerator walks
+    if m.hamming_weight >= 0:
+        assert bin(basis.minStateEstimate()).count("1") == m.hamming_weight
+        assert bin(basis.maxStateEstimate()).count("1") == m.hamming_weight
+    # same set of (permutation action, character): compare through the action on random states
+    L = _lib.load()
+    rs = np.random.RandomState(5)
+    states = [int(v) & m.mask for v in rs.randint(0, 2**62, size=16, dtype=np.int64)]
+    want = {}
+    for p, ch in zip(m.group.perms, m.group.chars):
+        key = tuple(M.apply_perm(p, s) for s in states)
+        want[key] = ch
+    got = {}
+    for g in range(basis.groupOrder()):
+        key = tuple(int(L.ls_amd_basis_apply_group_element(basis.payload, g, C.c_uint64(s))) for s in states)
+        re_, im_ = C.c_double(), C.c_double()
+        assert L.ls_amd_basis_group_character(basis.payload, g, C.byref(re_), C.byref(im_)) == 0
+        got[key] = complex(re_.value, im_.value)
+    assert set(got) == set(want)
+    for k in want:
+        assert abs(got[k] - want[k]) < 1e-12
+
+
+@pytest.mark.parametrize("L,sector", [(8, 1), (12, 5), (10, 3)])
+def test_complex_characters(L, sector):
+    cfg = complex_translation_config(L, sector)
+    basis = D.loadConfigFromDict(cfg)
+    m = M.model_from_config(cfg)
+    lib = _lib.load()
+    chars_oracle = sorted([(round(c.real, 12), round(c.imag, 12)) for c in m.group.chars])
+    chars = []
+    for g in range(basis.groupOrder()):
+        re_, im_ = C.c_double(), C.c_double()
+        lib.ls_amd_basis_group_character(basis.payload, g, C.byref(re_), C.byref(im_))
+        chars.append((round(re_.value, 12), round(im_.value, 12)))
+    assert sorted(chars) == chars_oracle
+
+
+def test_incompatible_sectors_are_rejected():
+    # reflection sector 1 together with translation sector 1 on a ring is not a 1-D representation
+    L = 6
+    cfg = M.heisenberg_chain_config(L)
+    cfg["basis"]["symmetries"] = [
+        {"permutation": [(i + 1) % L for i in range(L)], "sector": 1},
+        {"permutation": [L - 1 - i for i in range(L)], "sector": 1},
+    ]
+    with pytest.raises(D.LsAmdError):
+        D.loadConfigFromDict(cfg)
+    with pytest.raises(ValueError):
+        M.model_from_config(cfg)
+
+
+def test_random_permutation_networks():
+    """Benes compilation for arbitrary generators (not just rotations / reflections)."""
+    rs = np.random.RandomState(123)
+    lib = _lib.load()
+    for L in (5, 12, 31, 32, 33, 48, 64):
+        perm = list(rs.permutation(L))
+        spec = config.BasisSpec(number_sites=L, hamming_weight=-1, permutations=[[int(v) for v in perm]], sectors=[0])
+        order = 1
+        q = list(perm)
+        while q != list(range(L)):
+            q = [q[i] for i in perm]
+            order += 1
+            if order > 5000:
+                break
+        if order > 5000:
+            continue
+        basis = D.Basis.fromSpec(spec)
+        assert basis.groupOrder() == order
+        mask = (1 << L) - 1
+        states = [int(rs.randint(0, 2**62, dtype=np.int64)) * 4 + int(rs.randint(0, 4)) & mask for _ in range(8)]
+        actions = set()
+        for g in range(order):
+            actions.add(tuple(int(lib.ls_amd_basis_apply_group_element(basis.payload, g, C.c_uint64(s))) for s in states))
+        # the generator itself must be among the elements
+        assert tuple(M.apply_perm(perm, s) for s in states) in actions
+        # every element is a bijection on bits: popcount preserved
+        for act in actions:
+            assert all(bin(a).count("1") == bin(s).count("1") for a, s in zip(act, states))
+
+
+@pytest.mark.parametrize("name", CHECK_MODELS + ["heisenberg_chain_32", "heisenberg_chain_40_symm", "heisenberg_square_6x6"])
+def test_term_tables_equal_oracle_terms(name):
+    """config.py (symbolic Pauli compile) + C grouping vs the oracle's matrix-element compile: two
+    different decompositions, same operator -- compared as functions on random basis states."""
+    cfg = model_config(name)
+    basis, h = D.loadConfigFromDict(cfg, hamiltonian=True)
+    m = M.model_from_config(cfg)
+    diag, off = product_terms(h)
+    assert h.numberDiagTerms() == len(diag)
+    assert h.numberOffDiagTerms() == m.max_off_diag == len(set(t[3] for t in off))
+    assert h.isHermitian and h.isReal
+    rs = np.random.RandomState(9)
+    for _ in range(40):
+        a = int(rs.randint(0, 2**62, dtype=np.int64)) & m.mask
+        d_want = M._apply_terms(m.diag, a).get(a, 0)
+        d_got = apply_terms_python(diag, a).get(a, 0)
+        assert abs(d_want - d_got) < 1e-12
+        want = {k: v for k, v in M._apply_terms(m.offdiag, a).items() if v != 0}
+        got = apply_terms_python(off, a)
+        assert set(want) == set(got)
+        for k in want:
+            assert abs(want[k] - got[k]) < 1e-12
+
+
+def test_non_hermitian_and_complex_operators_are_flagged():
+    spec = config.BasisSpec(number_sites=4, hamming_weight=-1)
+    basis = D.Basis.fromSpec(spec)
+    raise_only = config.OperatorSpec(config.monomial_terms("σ⁺₀ σ⁻₁", [0, 1]))
+    op = D.Operator.fromSpec(basis, raise_only)
+    assert not op.isHermitian and op.isReal
+    herm = config.OperatorSpec(config.monomial_terms("σ⁺₀ σ⁻₁", [0, 1]) + config.monomial_terms("σ⁻₀ σ⁺₁", [0, 1]))
+    op2 = D.Operator.fromSpec(basis, herm)
+    assert op2.isHermitian
+    # sigma^x sigma^y is Hermitian with purely imaginary matrix elements
+    op3 = D.Operator.fromSpec(basis, config.OperatorSpec(config.monomial_terms("σˣ₀ σʸ₁", [2, 3])))
+    assert op3.isHermitian and not op3.isReal
+    # dense cross-check of the symbolic compile on a non-trivial monomial
+    k, mat = M.local_matrix("0.5 × σ⁺₀ σᶻ₁ σʸ₂")
+    terms = config.monomial_terms("0.5 × σ⁺₀ σᶻ₁ σʸ₂", [0, 1, 2])
+    for b in range(8):
+        got = apply_terms_python(terms, b)
+        for a in range(8):
+            assert abs(mat[a, b] - got.get(a, 0)) < 1e-14
+
+
+def test_host_scalars():
+    lib = _lib.load()
+    assert D.hash64_01(0x1f0) == 0xc56a3fa16c3a7f04
+    assert D.localeIdxOf(0x155, 8) == 2 and D.localeIdxOf(0x155, 3) == 2
+    for i in range(300):
+        s = int(lib.ls_hs_fixed_hamming_index_to_state(i, 6))
+        assert bin(s).count("1") == 6 and int(lib.ls_hs_fixed_hamming_state_to_index(C.c_uint64(s))) == i
+    basis = D.loadConfigFromDict(model_config("heisenberg_chain_10"))
+    assert basis.minStateEstimate() == 31 and basis.maxStateEstimate() == 496  # Appendix B
+
+
+def test_kernel_table_registration():
+    """ls_chpl_init_kernels fills the ls_chpl_kernels table (LatticeSymmetries.chpl:16-29)."""
+    lib = _lib.load()
+    lib.ls_chpl_init_kernels()
+    table = (C.c_void_p * 4).from_address(lib.ls_hs_internal_get_chpl_kernels())
+    want = [lib.ls_chpl_enumerate_representatives, lib.ls_chpl_operator_apply_off_diag,
+            lib.ls_chpl_operator_apply_diag, lib.ls_chpl_matrix_vector_product]
+    for got, fn in zip(table, want):
+        assert got == C.cast(fn, C.c_void_p).value
+
+
+def test_set_representatives_and_halts():
+    basis, h = D.loadConfigFromDict(model_config("heisenberg_chain_10"), hamiltonian=True)
+    with pytest.raises(D.LsAmdError, match="basis is not built"):
+        h.basis.representatives()
+    reps = oracle_for("heisenberg_chain_10").enumerate()
+    h.basis.uncheckedSetRepresentatives(reps)
+    assert np.array_equal(h.basis.representatives(), reps)
+    lib = _lib.load()
+    # numVectors != 1 halts (DMV:1101-1102); the handler turns the halt into an exception
+    x = np.zeros(126)
+    y = np.zeros(126)
+    lib.ls_chpl_matrix_vector_product(h.payload, 2, x.ctypes.data_as(_lib.c_f64p), y.ctypes.data_as(_lib.c_f64p))
+    with pytest.raises(D.LsAmdError, match="more than 1 vector"):
+        _lib.raise_pending_halt()
