@@ -81,6 +81,13 @@ def load():
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback."
         )
+    try:
+        # torch bundles its own HIP runtime (torch/lib/libamdhip64.so); it must be the one already
+        # mapped when libls_amd.so resolves libamdhip64.so.7, or the process ends up with two runtimes
+        # and this library sees no device.
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     bp, op = C.POINTER(LsHsBasis), C.POINTER(LsHsOperator)
     vp = C.c_void_p

@@ -349,12 +349,17 @@ __global__ __launch_bounds__(kBlock) void k_direct(int n_groups, lsk_group const
             int64_t idx;
             if (INDEX == LSK_INDEX_IDENTITY) idx = (int64_t)beta;
             else if (INDEX == LSK_INDEX_COMBINADIC) {
-                if (G.adj >= 0 && !flipped) {
+                if (G.adj >= 0 && !flipped && __popcll(a & G.x) == 1) {
                     // adjacent transposition: rank changes by C(lo, #set bits below lo)
                     int k = __popcll(a & ((1ULL << G.adj) - 1));
                     int64_t d = (int64_t)s_binom[G.adj * LSK_BINOM_K + k];
                     idx = ((a >> G.adj) & 1) ? i + d : i - d;
-                } else idx = rank_combinadic(beta, s_binom);
+                } else {
+                    // a state of another Hamming weight is outside the basis: ls_hs_state_index would
+                    // return a negative index and the reference halts (DMV:115-118)
+                    if (__popcll(beta) != bs.hamming_weight) { atomicExch(err, 1); continue; }
+                    idx = rank_combinadic(beta, s_binom);
+                }
             } else {
                 idx = search_index(ix, beta);
                 if (idx < 0) { atomicExch(err, 1); continue; } // DMV:115-118

@@ -27,7 +27,7 @@ typedef enum { LS_AMD_F64 = 0, LS_AMD_C128 = 1 } ls_amd_dtype;
 
 /* how y is produced when P == 1 and the operator is Hermitian */
 typedef enum {
-    LS_AMD_MODE_AUTO = 0, /* library default (LS_AMD_MODE env var overrides: "push" | "pull") */
+    LS_AMD_MODE_AUTO = 0, /* pull when the operator is Hermitian, else push (LS_AMD_MODE env: "push" | "pull") */
     LS_AMD_MODE_PUSH = 1, /* y[idx(beta)] += c x[i]   -- atomic scatter (ConcurrentAccessor) */
     LS_AMD_MODE_PULL = 2  /* y[i] = d x[i] + sum conj(c) x[idx(beta)]  -- gather, no atomics  */
 } ls_amd_mode;

@@ -228,3 +228,21 @@ def test_set_representatives_and_halts():
     lib.ls_chpl_matrix_vector_product(h.payload, 2, x.ctypes.data_as(_lib.c_f64p), y.ctypes.data_as(_lib.c_f64p))
     with pytest.raises(D.LsAmdError, match="more than 1 vector"):
         _lib.raise_pending_halt()
+
+
+def test_primme_view_matches_primme_header(have_reference, tmp_path):
+    """ls_primme_params_view (include/ls_chpl.h) must place nLocal and matrix where PRIMME 3.1 does."""
+    import subprocess
+
+    if not have_reference:
+        pytest.skip("reference (primme_headers/) not mounted")
+    src = tmp_path / "off.c"
+    src.write_text(
+        '#include <stdio.h>\n#include <stddef.h>\n#include "ls_chpl.h"\n#include "primme.h"\n'
+        'int main(void){printf("%zu %zu %zu %zu %zu %zu\\n", offsetof(ls_primme_params_view,n), offsetof(primme_params,n),'
+        ' offsetof(ls_primme_params_view,nLocal), offsetof(primme_params,nLocal),'
+        ' offsetof(ls_primme_params_view,matrix), offsetof(primme_params,matrix));return 0;}\n')
+    exe = tmp_path / "off"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), "-I", "/root/reference/primme_headers", str(src), "-o", str(exe)])
+    v = [int(t) for t in subprocess.check_output([str(exe)]).split()]
+    assert v[0] == v[1] and v[2] == v[3] and v[4] == v[5] == 264
