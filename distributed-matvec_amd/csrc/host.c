@@ -465,6 +465,7 @@ struct ls_amd_operator_ext {
     lsk_term *diag;    /* host */
     int n_off, n_diag;
     int is_real, is_hermitian;
+    lsk_runs runs;
     /* device mirrors */
     lsk_group *d_groups;
     lsk_term *d_off, *d_diag;
@@ -557,6 +558,79 @@ static void classify_groups(struct ls_amd_operator_ext *ext) {
     }
 }
 
+typedef struct { int lo; int index; double re, im; } run_item;
+static int run_item_cmp(void const *pa, void const *pb) {
+    run_item const *a = (run_item const *)pa, *b = (run_item const *)pb;
+    return a->lo < b->lo ? -1 : (a->lo > b->lo ? 1 : 0);
+}
+
+/* Recognise exchange runs among the groups and zz runs among the diagonal terms (lsk.h) and move
+ * them to the front of their arrays.  `number_sites`/`inversion`: runs must not touch the top site
+ * of a spin-inversion basis, where the image state may need the global flip. */
+static void detect_runs(struct ls_amd_operator_ext *ext, int number_sites, int inversion) {
+    lsk_runs *R = &ext->runs;
+    memset(R, 0, sizeof(*R));
+    /* ---- off-diagonal exchange runs ---- */
+    int ng = ext->n_groups;
+    run_item *items = (run_item *)malloc(sizeof(run_item) * (ng > 0 ? ng : 1));
+    int ni = 0;
+    for (int g = 0; g < ng; ++g) {
+        lsk_group const *G = &ext->groups[g];
+        if (G->fast != LSK_GROUP_EXCHANGE || G->adj < 0) continue;
+        if (inversion && G->adj + 1 >= number_sites - 1) continue;
+        run_item it = {G->adj, g, G->v_re, G->v_im};
+        items[ni++] = it;
+    }
+    qsort(items, ni, sizeof(run_item), run_item_cmp);
+    char *taken = (char *)calloc(ng > 0 ? ng : 1, 1);
+    lsk_group *reordered = (lsk_group *)malloc(sizeof(lsk_group) * (ng > 0 ? ng : 1));
+    int w = 0;
+    for (int i = 0; i < ni && R->n_runs < LSK_MAX_RUNS;) {
+        int j = i + 1;
+        while (j < ni && items[j].lo == items[j - 1].lo + 1 && items[j].re == items[i].re && items[j].im == items[i].im) ++j;
+        if (j - i >= 2) {
+            int r = R->n_runs++;
+            R->lo0[r] = items[i].lo; R->cnt[r] = j - i; R->v_re[r] = items[i].re; R->v_im[r] = items[i].im;
+            for (int k = i; k < j; ++k) { reordered[w++] = ext->groups[items[k].index]; taken[items[k].index] = 1; }
+        }
+        i = j;
+    }
+    R->n_run_groups = w;
+    for (int g = 0; g < ng; ++g) if (!taken[g]) reordered[w++] = ext->groups[g];
+    memcpy(ext->groups, reordered, sizeof(lsk_group) * ng);
+    free(items); free(taken); free(reordered);
+    /* ---- diagonal zz runs ---- */
+    int nd = ext->n_diag;
+    items = (run_item *)malloc(sizeof(run_item) * (nd > 0 ? nd : 1));
+    ni = 0;
+    for (int t = 0; t < nd; ++t) {
+        lsk_term const *T = &ext->diag[t];
+        if (T->m != 0 || T->r != 0 || T->v_im != 0.0 || __builtin_popcountll(T->s) != 2) continue;
+        int lo = __builtin_ctzll(T->s);
+        if (T->s != (3ULL << lo)) continue;
+        run_item it = {lo, t, T->v_re, 0.0};
+        items[ni++] = it;
+    }
+    qsort(items, ni, sizeof(run_item), run_item_cmp);
+    taken = (char *)calloc(nd > 0 ? nd : 1, 1);
+    lsk_term *dre = (lsk_term *)malloc(sizeof(lsk_term) * (nd > 0 ? nd : 1));
+    w = 0;
+    for (int i = 0; i < ni && R->n_zz < LSK_MAX_RUNS;) {
+        int j = i + 1;
+        while (j < ni && items[j].lo == items[j - 1].lo + 1 && items[j].re == items[i].re) ++j;
+        if (j - i >= 2) {
+            int r = R->n_zz++;
+            R->zz_lo0[r] = items[i].lo; R->zz_cnt[r] = j - i; R->zz_v[r] = items[i].re;
+            for (int k = i; k < j; ++k) { dre[w++] = ext->diag[items[k].index]; taken[items[k].index] = 1; }
+        }
+        i = j;
+    }
+    R->n_zz_terms = w;
+    for (int t = 0; t < nd; ++t) if (!taken[t]) dre[w++] = ext->diag[t];
+    memcpy(ext->diag, dre, sizeof(lsk_term) * nd);
+    free(items); free(taken); free(dre);
+}
+
 static ls_hs_nonbranching_terms *make_nbt(lsk_term const *t, uint64_t const *xs, int n, int nbits) {
     if (n == 0) return NULL; /* the reference tests `p == nil` (ForeignTypes.chpl:219-222) */
     ls_hs_nonbranching_terms *nb = (ls_hs_nonbranching_terms *)calloc(1, sizeof(*nb));
@@ -639,6 +713,7 @@ ls_hs_operator *ls_hs_create_operator_from_terms(ls_hs_basis const *basis, int n
         ext->groups[ext->n_groups - 1].end = i + 1;
     }
     classify_groups(ext);
+    detect_runs(ext, basis->number_sites, basis->spin_inversion != 0);
     op->diag_terms = make_nbt(ext->diag, NULL, ext->n_diag, basis->number_sites);
     op->off_diag_terms = make_nbt(ext->off, offx, ext->n_off, basis->number_sites);
     free(offx);
@@ -708,6 +783,7 @@ static int operator_device(ls_hs_operator const *op, lsk_operator *out) {
     out->diag = e->d_diag;
     out->off = e->d_off;
     out->groups = e->d_groups;
+    out->runs = e->runs;
     return 0;
 }
 

@@ -269,16 +269,64 @@ __device__ __forceinline__ void load_binom(uint64_t *s_binom, uint64_t const *__
 }
 
 // ---------------------------------------------------------------------------------------------
+// word-width helpers: bases with <= 32 sites run the row kernels on 32-bit states (half the VALU work)
+// ---------------------------------------------------------------------------------------------
+template <typename W> struct WordTraits;
+template <> struct WordTraits<uint32_t> {
+    typedef uint32_t binom_t;
+    static __device__ __forceinline__ int popc(uint32_t v) { return __popc(v); }
+    static __device__ __forceinline__ int ctz(uint32_t v) { return __ffs((int)v) - 1; }
+};
+template <> struct WordTraits<uint64_t> {
+    typedef uint64_t binom_t;
+    static __device__ __forceinline__ int popc(uint64_t v) { return __popcll(v); }
+    static __device__ __forceinline__ int ctz(uint64_t v) { return __ffsll((unsigned long long)v) - 1; }
+};
+template <typename W, typename BT>
+__device__ __forceinline__ int64_t rank_combinadic_w(W s, BT const *binom) {
+    int64_t idx = 0;
+    int k = 1;
+    while (s) {
+        int p = WordTraits<W>::ctz(s);
+        idx += (int64_t)binom[p * LSK_BINOM_K + k];
+        ++k;
+        s &= s - 1;
+    }
+    return idx;
+}
+
+// diagonal coefficient with the zz-run shortcut: sum_b v (-1)^{[bits b, b+1 differ]} = v (cnt - 2 #differ)
+template <typename W, bool REAL>
+__device__ __forceinline__ void diag_coeff(lsk_runs const &runs, int n_diag, lsk_term const *__restrict__ diag,
+                                           W a, double &dr, double &di) {
+    dr = 0.0;
+    di = 0.0;
+    if (runs.n_zz > 0) {
+        const W t = a ^ (a >> 1);
+        for (int r = 0; r < runs.n_zz; ++r) {
+            const W m = (W)(((uint64_t)1 << runs.zz_cnt[r]) - 1) << runs.zz_lo0[r];
+            dr += runs.zz_v[r] * (double)(runs.zz_cnt[r] - 2 * WordTraits<W>::popc(t & m));
+        }
+    }
+    if (runs.n_zz_terms < n_diag) {
+        double gr, gi;
+        term_sum<REAL>(diag, runs.n_zz_terms, n_diag, (uint64_t)a, gr, gi);
+        dr += gr;
+        di += gi;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // K1: diagonal pass  y[i] = d(sigma_i) x[i]
 // ---------------------------------------------------------------------------------------------
 template <bool CPLX>
-__global__ __launch_bounds__(kBlock) void k_diag(int n_diag, lsk_term const *__restrict__ diag, int64_t n,
-                                                 uint64_t const *__restrict__ reps,
+__global__ __launch_bounds__(kBlock) void k_diag(lsk_runs runs, int n_diag, lsk_term const *__restrict__ diag,
+                                                 int64_t n, uint64_t const *__restrict__ reps,
                                                  double const *__restrict__ x, double *__restrict__ y) {
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
         uint64_t a = reps[i];
         double dr, di;
-        term_sum<false>(diag, 0, n_diag, a, dr, di);
+        diag_coeff<uint64_t, false>(runs, n_diag, diag, a, dr, di);
         if (CPLX) {
             double xr = x[2 * i], xi = x[2 * i + 1];
             y[2 * i] = dr * xr - di * xi;
@@ -293,8 +341,8 @@ extern "C" int lsk_diag(lsk_operator op, int cplx, int64_t n, uint64_t const *re
                         void *stream) {
     if (n == 0 || op.n_diag == 0) return 0;
     dim3 g(grid_for(n)), b(kBlock);
-    if (cplx) hipLaunchKernelGGL(k_diag<true>, g, b, 0, (hipStream_t)stream, op.n_diag, op.diag, n, reps, (double const *)x, (double *)y);
-    else hipLaunchKernelGGL(k_diag<false>, g, b, 0, (hipStream_t)stream, op.n_diag, op.diag, n, reps, (double const *)x, (double *)y);
+    if (cplx) hipLaunchKernelGGL(k_diag<true>, g, b, 0, (hipStream_t)stream, op.runs, op.n_diag, op.diag, n, reps, (double const *)x, (double *)y);
+    else hipLaunchKernelGGL(k_diag<false>, g, b, 0, (hipStream_t)stream, op.runs, op.n_diag, op.diag, n, reps, (double const *)x, (double *)y);
     LSK_LAUNCH_CHECK();
     return 0;
 }
@@ -305,24 +353,34 @@ extern "C" int lsk_diag(lsk_operator op, int cplx, int64_t n, uint64_t const *re
 // the active lanes' targets are (piecewise) consecutive as well: the scatter / gather coalesces.
 //   PUSH: y[idx(beta)] += c x[i]                 (K2 + K3 + K7 + K8 fused; y holds the diagonal part)
 //   PULL: y[i] = d x[i] + sum conj(c) x[idx(beta)]   (Hermitian operators; no atomics, y written once)
+// Exchange runs (adjacent transpositions, e.g. the open bonds of a chain) take a branch-free inner
+// loop: the rank of the target differs from the row's own rank by +-C(lo, k) with k = number of set
+// bits below lo, which is carried incrementally; inactive lanes gather their own x and add 0, so
+// the compiler can unroll and keep several gathers in flight.
 // Row tiles are dealt to XCDs in contiguous ranges (block b runs on XCD b % 8), so that each
 // XCD's L2 sees one eighth of x / y for the short-range flips.
 // ---------------------------------------------------------------------------------------------
-template <bool CPLX, int INDEX, bool INV, bool PULL, bool REAL>
-__global__ __launch_bounds__(kBlock) void k_direct(int n_groups, lsk_group const *__restrict__ groups,
+template <typename W, bool CPLX, int INDEX, bool INV, bool PULL, bool REAL>
+__global__ __launch_bounds__(kBlock) void k_direct(lsk_runs runs, int n_groups, lsk_group const *__restrict__ groups,
                                                    lsk_term const *__restrict__ off, int n_diag,
                                                    lsk_term const *__restrict__ diag, lsk_basis bs,
                                                    lsk_index ix, int64_t n, int64_t tiles_per_xcd,
                                                    uint64_t const *__restrict__ reps,
                                                    double const *__restrict__ x, double *y, int *err) {
-    __shared__ uint64_t s_binom[INDEX == LSK_INDEX_COMBINADIC ? 64 * LSK_BINOM_K : 1];
-    if (INDEX == LSK_INDEX_COMBINADIC) load_binom(s_binom, ix.binom);
+    typedef typename WordTraits<W>::binom_t BT;
+    typedef WordTraits<W> WT;
+    __shared__ BT s_binom[INDEX == LSK_INDEX_COMBINADIC ? 64 * LSK_BINOM_K : 1];
+    if (INDEX == LSK_INDEX_COMBINADIC) {
+        for (int k = threadIdx.x; k < 64 * LSK_BINOM_K; k += blockDim.x) s_binom[k] = (BT)ix.binom[k];
+        __syncthreads();
+    }
     const int xcd = blockIdx.x & 7;
     const int64_t blocks_per_xcd = gridDim.x >> 3; // grid is a multiple of 8
+    const W site_mask = (W)bs.site_mask;
     for (int64_t t = blockIdx.x >> 3; t < tiles_per_xcd; t += blocks_per_xcd) {
         const int64_t i = ((int64_t)xcd * tiles_per_xcd + t) * kBlock + threadIdx.x;
         if (i >= n) continue;
-        const uint64_t a = reps[i];
+        const W a = (W)reps[i];
         double xr, xi = 0.0;
         if (CPLX) { xr = x[2 * i]; xi = x[2 * i + 1]; } else xr = x[i];
         double accr = 0.0, acci = 0.0;
@@ -331,37 +389,95 @@ __global__ __launch_bounds__(kBlock) void k_direct(int n_groups, lsk_group const
         }
         if (PULL && n_diag > 0) {
             double dr, di;
-            term_sum<REAL>(diag, 0, n_diag, a, dr, di);
+            diag_coeff<W, REAL>(runs, n_diag, diag, a, dr, di);
             accr = dr * xr - (CPLX ? di * xi : 0.0);
             if (CPLX) acci = dr * xi + di * xr;
         }
-        for (int g = 0; g < n_groups; ++g) {
+        int g_begin = 0;
+        if (INDEX == LSK_INDEX_COMBINADIC) {
+            // ---- exchange runs: branch-free ------------------------------------------------------
+            g_begin = runs.n_run_groups;
+            const W tdiff = a ^ (a >> 1);
+            for (int r = 0; r < runs.n_runs; ++r) {
+                const int lo0 = runs.lo0[r], cnt = runs.cnt[r];
+                const double vr = runs.v_re[r], vi = REAL ? 0.0 : runs.v_im[r];
+                int k = WT::popc(a & (W)(((uint64_t)1 << lo0) - 1));
+#pragma unroll 4
+                for (int lo = lo0; lo < lo0 + cnt; ++lo) {
+                    const bool bit = (a >> lo) & 1;
+                    const bool act = (tdiff >> lo) & 1;
+                    const BT d = s_binom[lo * LSK_BINOM_K + k];
+                    k += bit ? 1 : 0;
+                    if (sizeof(W) == 4) {
+                        const uint32_t i32 = (uint32_t)i;
+                        uint32_t idx = bit ? i32 + (uint32_t)d : i32 - (uint32_t)d;
+                        if (PULL) {
+                            idx = act ? idx : i32;
+                            if (CPLX) {
+                                double yr = x[2 * (size_t)idx], yi = x[2 * (size_t)idx + 1];
+                                // conj(v) * x[idx]
+                                accr += act ? (vr * yr + vi * yi) : 0.0;
+                                acci += act ? (vr * yi - vi * yr) : 0.0;
+                            } else {
+                                double yv = x[idx];
+                                accr += act ? vr * yv : 0.0;
+                            }
+                        } else if (act) {
+                            if (CPLX) {
+                                atomic_add_f64(y + 2 * (size_t)idx, vr * xr - vi * xi);
+                                atomic_add_f64(y + 2 * (size_t)idx + 1, vr * xi + vi * xr);
+                            } else atomic_add_f64(y + idx, vr * xr);
+                        }
+                    } else {
+                        int64_t idx = bit ? i + (int64_t)d : i - (int64_t)d;
+                        if (PULL) {
+                            idx = act ? idx : i;
+                            if (CPLX) {
+                                double yr = x[2 * idx], yi = x[2 * idx + 1];
+                                accr += act ? (vr * yr + vi * yi) : 0.0;
+                                acci += act ? (vr * yi - vi * yr) : 0.0;
+                            } else {
+                                double yv = x[idx];
+                                accr += act ? vr * yv : 0.0;
+                            }
+                        } else if (act) {
+                            if (CPLX) {
+                                atomic_add_f64(y + 2 * idx, vr * xr - vi * xi);
+                                atomic_add_f64(y + 2 * idx + 1, vr * xi + vi * xr);
+                            } else atomic_add_f64(y + idx, vr * xr);
+                        }
+                    }
+                }
+            }
+        }
+        // ---- everything else: generic groups ----------------------------------------------------
+        for (int g = g_begin; g < n_groups; ++g) {
             lsk_group const G = groups[g];
             double cr, ci;
-            group_coeff<REAL>(G, off, a, cr, ci);
+            group_coeff<REAL>(G, off, (uint64_t)a, cr, ci);
             if (cr == 0.0 && (REAL || ci == 0.0)) continue;
-            uint64_t beta = a ^ G.x;
+            W beta = a ^ (W)G.x;
             bool flipped = false;
             if (INV) { // K3
-                uint64_t f = beta ^ bs.site_mask;
+                W f = beta ^ site_mask;
                 if (f < beta) { beta = f; flipped = true; cr *= (double)bs.spin_inversion; ci *= (double)bs.spin_inversion; }
             }
             int64_t idx;
             if (INDEX == LSK_INDEX_IDENTITY) idx = (int64_t)beta;
             else if (INDEX == LSK_INDEX_COMBINADIC) {
-                if (G.adj >= 0 && !flipped && __popcll(a & G.x) == 1) {
+                if (G.adj >= 0 && !flipped && WT::popc(a & (W)G.x) == 1) {
                     // adjacent transposition: rank changes by C(lo, #set bits below lo)
-                    int k = __popcll(a & ((1ULL << G.adj) - 1));
+                    int k = WT::popc(a & (W)(((uint64_t)1 << G.adj) - 1));
                     int64_t d = (int64_t)s_binom[G.adj * LSK_BINOM_K + k];
                     idx = ((a >> G.adj) & 1) ? i + d : i - d;
                 } else {
                     // a state of another Hamming weight is outside the basis: ls_hs_state_index would
                     // return a negative index and the reference halts (DMV:115-118)
-                    if (__popcll(beta) != bs.hamming_weight) { atomicExch(err, 1); continue; }
-                    idx = rank_combinadic(beta, s_binom);
+                    if (WT::popc(beta) != bs.hamming_weight) { atomicExch(err, 1); continue; }
+                    idx = rank_combinadic_w<W, BT>(beta, s_binom);
                 }
             } else {
-                idx = search_index(ix, beta);
+                idx = search_index(ix, (uint64_t)beta);
                 if (idx < 0) { atomicExch(err, 1); continue; } // DMV:115-118
             }
             if (PULL) {
@@ -384,8 +500,8 @@ __global__ __launch_bounds__(kBlock) void k_direct(int n_groups, lsk_group const
     }
 }
 
-template <bool CPLX, int INDEX, bool INV, bool PULL>
-static int launch_direct2(lsk_operator op, lsk_basis bs, lsk_index ix, int64_t n, uint64_t const *reps,
+template <typename W, bool CPLX, int INDEX, bool INV, bool PULL>
+static int launch_direct3(lsk_operator op, lsk_basis bs, lsk_index ix, int64_t n, uint64_t const *reps,
                           void const *x, void *y, int *d_err, void *stream) {
     int64_t tiles = (n + kBlock - 1) / kBlock;
     int64_t tiles_per_xcd = (tiles + 7) / 8;
@@ -393,26 +509,34 @@ static int launch_direct2(lsk_operator op, lsk_basis bs, lsk_index ix, int64_t n
     if (gb > kMaxGrid) gb = kMaxGrid;
     dim3 g((unsigned)gb), b(kBlock);
     if (op.is_real)
-        hipLaunchKernelGGL((k_direct<CPLX, INDEX, INV, PULL, true>), g, b, 0, (hipStream_t)stream, op.n_groups,
-                           op.groups, op.off, op.n_diag, op.diag, bs, ix, n, tiles_per_xcd, reps,
+        hipLaunchKernelGGL((k_direct<W, CPLX, INDEX, INV, PULL, true>), g, b, 0, (hipStream_t)stream, op.runs,
+                           op.n_groups, op.groups, op.off, op.n_diag, op.diag, bs, ix, n, tiles_per_xcd, reps,
                            (double const *)x, (double *)y, d_err);
     else
-        hipLaunchKernelGGL((k_direct<CPLX, INDEX, INV, PULL, false>), g, b, 0, (hipStream_t)stream, op.n_groups,
-                           op.groups, op.off, op.n_diag, op.diag, bs, ix, n, tiles_per_xcd, reps,
+        hipLaunchKernelGGL((k_direct<W, CPLX, INDEX, INV, PULL, false>), g, b, 0, (hipStream_t)stream, op.runs,
+                           op.n_groups, op.groups, op.off, op.n_diag, op.diag, bs, ix, n, tiles_per_xcd, reps,
                            (double const *)x, (double *)y, d_err);
     LSK_LAUNCH_CHECK();
     return 0;
 }
-template <bool CPLX, int INDEX>
-static int launch_direct1(lsk_operator op, lsk_basis bs, lsk_index ix, int pull, int64_t n,
+template <typename W, bool CPLX, int INDEX>
+static int launch_direct2(lsk_operator op, lsk_basis bs, lsk_index ix, int pull, int64_t n,
                           uint64_t const *reps, void const *x, void *y, int *d_err, void *stream) {
     const bool inv = bs.proj == LSK_PROJ_INVERSION;
     if (inv) {
-        if (pull) return launch_direct2<CPLX, INDEX, true, true>(op, bs, ix, n, reps, x, y, d_err, stream);
-        return launch_direct2<CPLX, INDEX, true, false>(op, bs, ix, n, reps, x, y, d_err, stream);
+        if (pull) return launch_direct3<W, CPLX, INDEX, true, true>(op, bs, ix, n, reps, x, y, d_err, stream);
+        return launch_direct3<W, CPLX, INDEX, true, false>(op, bs, ix, n, reps, x, y, d_err, stream);
     }
-    if (pull) return launch_direct2<CPLX, INDEX, false, true>(op, bs, ix, n, reps, x, y, d_err, stream);
-    return launch_direct2<CPLX, INDEX, false, false>(op, bs, ix, n, reps, x, y, d_err, stream);
+    if (pull) return launch_direct3<W, CPLX, INDEX, false, true>(op, bs, ix, n, reps, x, y, d_err, stream);
+    return launch_direct3<W, CPLX, INDEX, false, false>(op, bs, ix, n, reps, x, y, d_err, stream);
+}
+template <bool CPLX, int INDEX>
+static int launch_direct1(lsk_operator op, lsk_basis bs, lsk_index ix, int pull, int64_t n,
+                          uint64_t const *reps, void const *x, void *y, int *d_err, void *stream) {
+    // 32-bit states: every site, and every rank, fits 32 bits (C(32, 16) < 2^31)
+    if (bs.number_sites <= 32 && INDEX == LSK_INDEX_COMBINADIC)
+        return launch_direct2<uint32_t, CPLX, INDEX>(op, bs, ix, pull, n, reps, x, y, d_err, stream);
+    return launch_direct2<uint64_t, CPLX, INDEX>(op, bs, ix, pull, n, reps, x, y, d_err, stream);
 }
 extern "C" int lsk_direct(lsk_operator op, lsk_basis bs, lsk_index ix, int cplx, int pull, int64_t n,
                           uint64_t const *reps, void const *x, void *y, int *d_err, void *stream) {

@@ -33,11 +33,27 @@ typedef struct lsk_group {
     int32_t fast;      /* LSK_GROUP_* */
 } lsk_group;
 
+/* Structure the host recognises so that the row kernels can run tight, branch-free inner loops:
+ *  - exchange runs: groups [0, n_run_groups) are EXCHANGE groups on adjacent pairs (lo, lo + 1) with
+ *    consecutive lo and one common amplitude v  (e.g. the 31 open bonds of the Heisenberg ring);
+ *  - zz runs: diagonal terms [0, n_zz_terms) are v * (-1)^popcount(alpha & (3 << lo)) with
+ *    consecutive lo and a common real v, whose sum is v * (cnt - 2 * #anti-aligned pairs). */
+#define LSK_MAX_RUNS 4
+typedef struct lsk_runs {
+    int n_runs, n_run_groups;
+    int lo0[LSK_MAX_RUNS], cnt[LSK_MAX_RUNS];
+    double v_re[LSK_MAX_RUNS], v_im[LSK_MAX_RUNS];
+    int n_zz, n_zz_terms;
+    int zz_lo0[LSK_MAX_RUNS], zz_cnt[LSK_MAX_RUNS];
+    double zz_v[LSK_MAX_RUNS];
+} lsk_runs;
+
 typedef struct lsk_operator {
     int n_diag, n_off, n_groups, is_real;
-    lsk_term const *diag;    /* device [n_diag] */
+    lsk_term const *diag;    /* device [n_diag]; zz-run terms first */
     lsk_term const *off;     /* device [n_off], sorted by group */
-    lsk_group const *groups; /* device [n_groups] */
+    lsk_group const *groups; /* device [n_groups]; exchange-run groups first */
+    lsk_runs runs;
 } lsk_operator;
 
 enum { LSK_ELEM_BENES = 0, LSK_ELEM_ROT = 1, LSK_ELEM_REVROT = 2 };
