@@ -452,6 +452,31 @@ static int basis_device(ls_hs_basis const *b, lsk_basis *out) {
     out->site_mask = b->number_sites >= 64 ? ~0ULL : ((1ULL << b->number_sites) - 1);
     out->inv_order = 1.0 / ((double)e->order * (b->spin_inversion != 0 ? 2.0 : 1.0));
     out->elems = e->d_elems;
+    out->chars_pm1 = 1;
+    int trivial = b->spin_inversion >= 0;
+    for (int g = 0; g < e->order; ++g) {
+        if (e->elems[g].ch_im != 0.0 || fabs(e->elems[g].ch_re) != 1.0) out->chars_pm1 = 0;
+        if (e->elems[g].ch_im != 0.0 || e->elems[g].ch_re != 1.0) trivial = 0;
+    }
+    out->k4_mode = 0;
+    out->reflect = 0;
+    if (trivial && e->order > 1 && !getenv("LS_AMD_GENERAL_K4")) {
+        out->k4_mode = 1;
+        /* full cyclic group of the ring (every rotation k = 0..L-1), optionally with all reflections? */
+        int const L = b->number_sites;
+        uint64_t rot = 0, rev = 0;
+        int other = 0;
+        for (int g = 0; g < e->order; ++g) {
+            if (e->elems[g].kind == LSK_ELEM_ROT) rot |= 1ULL << e->elems[g].k;
+            else if (e->elems[g].kind == LSK_ELEM_REVROT) rev |= 1ULL << e->elems[g].k;
+            else other = 1;
+        }
+        uint64_t const full = L >= 64 ? ~0ULL : ((1ULL << L) - 1);
+        if (!other && rot == full && (rev == 0 || rev == full) && e->order == L * (rev ? 2 : 1) && L >= 3) {
+            out->k4_mode = 2;
+            out->reflect = rev ? 1 : 0;
+        }
+    }
     return 0;
 }
 
@@ -1142,7 +1167,8 @@ int ls_amd_scatter(ls_amd_plan *pl, int64_t n, uint64_t const *d_betas, void con
                    void *stream) {
     part_state *ps = &pl->parts[0];
     if (ps->index.kind == LSK_INDEX_COMBINADIC) return set_error("ls_amd_scatter: plan has no search index");
-    DEV(lsk_scatter(ps->index, pl->cplx, n, d_betas, d_values, d_y, pl->d_err, stream));
+    DEV(lsk_scatter(ps->index, pl->cplx, n, d_betas, d_values, d_y, pl->dbs.k4_mode ? ps->d_norms : NULL, pl->d_err,
+                    stream));
     return 0;
 }
 
@@ -1172,7 +1198,8 @@ int ls_amd_matvec(ls_amd_plan *pl, void const *const *d_x, void *const *d_y, voi
                 if (d == p || c == 0) continue;
                 uint64_t const *betas = (uint64_t const *)((char *)pl->d_send + ps->h_beta_off[(size_t)r * P + d]);
                 void const *vals = (char *)pl->d_send + ps->h_val_off[(size_t)r * P + d];
-                DEV(lsk_scatter(pl->parts[d].index, pl->cplx, c, betas, vals, d_y[d], pl->d_err, stream));
+                DEV(lsk_scatter(pl->parts[d].index, pl->cplx, c, betas, vals, d_y[d],
+                                pl->dbs.k4_mode ? pl->parts[d].d_norms : NULL, pl->d_err, stream));
             }
         }
     }

@@ -220,28 +220,121 @@ __device__ __forceinline__ uint64_t apply_elem(lsk_group_elem const &e, uint64_t
     return ((x >> k) | (x << (L - k))) & mask;
 }
 
-// K4: ls_hs_state_info -- orbit minimum, conj(character) of a minimising element, stabiliser sum
-__device__ __forceinline__ void state_info(lsk_basis const &bs, lsk_group_elem const *__restrict__ elems,
-                                           uint64_t a, uint64_t &rep, double &chr, double &chi, double &stab) {
-    uint64_t best = ~0ULL;
-    double bcr = 1.0, bci = 0.0, st = 0.0;
+// 32-bit variant of apply_elem for bases with <= 32 sites: permutations only move the low 32 bits, so
+// the distance-32 Benes stages are empty and the remaining masks live in the low words.
+__device__ __forceinline__ uint32_t delta_swap32(uint32_t x, uint32_t m, int d) {
+    uint32_t t = ((x >> d) ^ x) & m;
+    return x ^ t ^ (t << d);
+}
+__device__ __forceinline__ uint32_t apply_elem32(lsk_group_elem const &e, uint32_t x, int L, uint32_t mask) {
+    if (e.kind == LSK_ELEM_BENES) {
+        if ((uint32_t)e.masks[1]) x = delta_swap32(x, (uint32_t)e.masks[1], 16);
+        if ((uint32_t)e.masks[2]) x = delta_swap32(x, (uint32_t)e.masks[2], 8);
+        if ((uint32_t)e.masks[3]) x = delta_swap32(x, (uint32_t)e.masks[3], 4);
+        if ((uint32_t)e.masks[4]) x = delta_swap32(x, (uint32_t)e.masks[4], 2);
+        if ((uint32_t)e.masks[5]) x = delta_swap32(x, (uint32_t)e.masks[5], 1);
+        if ((uint32_t)e.masks[6]) x = delta_swap32(x, (uint32_t)e.masks[6], 2);
+        if ((uint32_t)e.masks[7]) x = delta_swap32(x, (uint32_t)e.masks[7], 4);
+        if ((uint32_t)e.masks[8]) x = delta_swap32(x, (uint32_t)e.masks[8], 8);
+        if ((uint32_t)e.masks[9]) x = delta_swap32(x, (uint32_t)e.masks[9], 16);
+        return x;
+    }
+    if (e.kind == LSK_ELEM_REVROT) x = __brev(x) >> (32 - L);
+    int k = e.k;
+    if (k == 0) return x;
+    return ((x >> k) | (x << (L - k))) & mask;
+}
+template <typename W> __device__ __forceinline__ W apply_elem_w(lsk_group_elem const &e, W x, int L, W mask);
+template <> __device__ __forceinline__ uint64_t apply_elem_w<uint64_t>(lsk_group_elem const &e, uint64_t x, int L, uint64_t mask) {
+    return apply_elem(e, x, L, mask);
+}
+template <> __device__ __forceinline__ uint32_t apply_elem_w<uint32_t>(lsk_group_elem const &e, uint32_t x, int L, uint32_t mask) {
+    return apply_elem32(e, x, L, mask);
+}
+
+// K4: ls_hs_state_info -- orbit minimum, conj(character) of a minimising element, stabiliser sum.
+// One pass over the permutations; the optional global spin flip is folded in by canonicalising every
+// image to "top site bit clear" (t ^ mask < t iff the top bit of t is set), which halves the work.
+// The stabiliser sum needs no `g(a) == a` tests: the elements that map a onto its representative
+// form the coset g0 Stab(a), so  sum_{s in Stab(a)} chi(s) = conj(chi(g0)) * sum_{g: g(a) = rep} chi(g),
+// i.e. it is accumulated over the ties with the running minimum.
+// PM1: every character (and the inversion character) is +-1 -> integer accumulation.
+template <typename W, bool PM1>
+__device__ __forceinline__ void state_info_w(lsk_basis const &bs, lsk_group_elem const *__restrict__ elems,
+                                             W a, W &rep, double &chr, double &chi, double &stab) {
+    W best = ~(W)0;
+    int info = 0;
+    int si = 0;
+    double sr = 0.0, sim = 0.0;
     const int inv = bs.spin_inversion;
-    const double dinv = (double)inv;
+    const int L = bs.number_sites;
+    const W mask = (W)bs.site_mask;
     for (int g = 0; g < bs.n_elems; ++g) {
         lsk_group_elem const &e = elems[g];
-        uint64_t t = apply_elem(e, a, bs.number_sites, bs.site_mask);
-        if (t == a) st += e.ch_re;
-        if (t < best) { best = t; bcr = e.ch_re; bci = e.ch_im; }
+        W t = apply_elem_w<W>(e, a, L, mask);
+        int top = 0;
         if (inv != 0) {
-            uint64_t tf = t ^ bs.site_mask;
-            if (tf == a) st += e.ch_re * dinv;
-            if (tf < best) { best = tf; bcr = e.ch_re * dinv; bci = e.ch_im * dinv; }
+            top = (int)((t >> (L - 1)) & 1);
+            t = top ? (W)(t ^ mask) : t;
         }
+        const bool less = t < best, eq = t == best;
+        if (PM1) {
+            int ch = (int)e.ch_re;
+            ch = top ? ch * inv : ch;
+            si = less ? ch : (eq ? si + ch : si);
+        } else {
+            double cr = e.ch_re, ci = e.ch_im;
+            if (top) { cr *= (double)inv; ci *= (double)inv; }
+            sr = less ? cr : (eq ? sr + cr : sr);
+            sim = less ? ci : (eq ? sim + ci : sim);
+        }
+        best = less ? t : best;
+        info = less ? (2 * g + top) : info;
     }
     rep = best;
-    chr = bcr;
-    chi = -bci;
-    stab = st;
+    lsk_group_elem const &e0 = elems[info >> 1];
+    double c0r = e0.ch_re, c0i = e0.ch_im;
+    if (info & 1) { c0r *= (double)inv; c0i *= (double)inv; }
+    chr = c0r;
+    chi = -c0i;
+    if (PM1) stab = c0r * (double)si;
+    else stab = c0r * sr + c0i * sim; // Re(conj(chi0) * S)
+}
+// K4, trivial sector: only the orbit minimum.  mode 2 generates the L rotations incrementally
+// (rotr by one site = shift + move bit 0 to bit L-1) for a and, with reflections, for rev(a).
+template <typename W>
+__device__ __forceinline__ W rep_trivial(lsk_basis const &bs, lsk_group_elem const *__restrict__ elems, W a) {
+    const int L = bs.number_sites;
+    const W mask = (W)bs.site_mask;
+    const bool inv = bs.spin_inversion != 0;
+    W best = ~(W)0;
+    if (bs.k4_mode == 2) {
+        W r = a;
+        for (int pass = 0; pass <= bs.reflect; ++pass) {
+#pragma unroll 4
+            for (int k = 0; k < L; ++k) {
+                W c = r;
+                if (inv) c = ((r >> (L - 1)) & 1) ? (W)(r ^ mask) : r;
+                best = c < best ? c : best;
+                r = (W)(r >> 1) | (W)((r & 1) << (L - 1));
+            }
+            if (sizeof(W) == 4) r = (W)(__brev((uint32_t)a) >> (32 - L));
+            else r = (W)(__brevll((uint64_t)a) >> (64 - L));
+        }
+        return best;
+    }
+    for (int g = 0; g < bs.n_elems; ++g) {
+        W t = apply_elem_w<W>(elems[g], a, L, mask);
+        if (inv) t = ((t >> (L - 1)) & 1) ? (W)(t ^ mask) : t;
+        best = t < best ? t : best;
+    }
+    return best;
+}
+
+__device__ __forceinline__ void state_info(lsk_basis const &bs, lsk_group_elem const *__restrict__ elems,
+                                           uint64_t a, uint64_t &rep, double &chr, double &chi, double &stab) {
+    if (bs.chars_pm1) state_info_w<uint64_t, true>(bs, elems, a, rep, chr, chi, stab);
+    else state_info_w<uint64_t, false>(bs, elems, a, rep, chr, chi, stab);
 }
 
 // ls_hs_is_representative with early exit: false as soon as some element maps below a
@@ -567,7 +660,7 @@ constexpr int kGC = 8;
 constexpr int kCap = kBlock * kGC;
 constexpr uint32_t kDead = 0xffffffffu;
 
-template <bool CPLX, bool REAL>
+template <typename W, bool PM1, bool CPLX, bool REAL>
 __global__ __launch_bounds__(kBlock) void k_tile(int n_groups, lsk_group const *__restrict__ groups,
                                                  lsk_term const *__restrict__ off, lsk_basis bs,
                                                  lsk_group_elem const *__restrict__ elems, lsk_index ix,
@@ -639,13 +732,15 @@ __global__ __launch_bounds__(kBlock) void k_tile(int n_groups, lsk_group const *
                 if (bs.proj == LSK_PROJ_INVERSION) {
                     uint64_t f = beta ^ bs.site_mask;
                     if (f < beta) { beta = f; vr *= (double)bs.spin_inversion; vi *= (double)bs.spin_inversion; }
+                } else if (bs.proj == LSK_PROJ_FULL && bs.k4_mode != 0) {
+                    beta = (uint64_t)rep_trivial<W>(bs, elems, (W)beta); // norm(rep) applied at index time
                 } else if (bs.proj == LSK_PROJ_FULL) {
-                    uint64_t rep; double chr, chi, stab;
-                    state_info(bs, elems, beta, rep, chr, chi, stab);
+                    W rep; double chr, chi, stab;
+                    state_info_w<W, PM1>(bs, elems, (W)beta, rep, chr, chi, stab);
                     double n2 = stab * bs.inv_order;
                     if (n2 > 1e-12) {
                         double nb = sqrt(n2);
-                        beta = rep;
+                        beta = (uint64_t)rep;
                         if (CPLX) {
                             double tr = (vr * chr - vi * chi) * nb, ti = (vr * chi + vi * chr) * nb;
                             vr = tr; vi = ti;
@@ -660,8 +755,11 @@ __global__ __launch_bounds__(kBlock) void k_tile(int n_groups, lsk_group const *
                     } else if (dest == me) {
                         int64_t idx = search_index(ix, beta);
                         if (idx < 0) atomicExch(err, 1);
-                        else if (CPLX) { atomic_add_f64(y + 2 * idx, vr); atomic_add_f64(y + 2 * idx + 1, vi); }
-                        else atomic_add_f64(y + idx, vr);
+                        else {
+                            if (bs.proj == LSK_PROJ_FULL && bs.k4_mode != 0) { double nb = norms[idx]; vr *= nb; vi *= nb; }
+                            if (CPLX) { atomic_add_f64(y + 2 * idx, vr); atomic_add_f64(y + 2 * idx + 1, vi); }
+                            else atomic_add_f64(y + idx, vr);
+                        }
                     } else {
                         unsigned rank = atomicAdd(&s_cnt[dest], 1u);
                         meta = ((uint32_t)dest << 16) | rank;
@@ -708,13 +806,20 @@ extern "C" int lsk_tile(lsk_operator op, lsk_basis bs, lsk_index ix, int cplx, i
     hipStream_t s = (hipStream_t)stream;
 #define LSK_TILE_ARGS op.n_groups, op.groups, op.off, bs, bs.elems, ix, count_only, ow, me, row0, row1, reps, norms, \
         (double const *)x, (double *)y, d_cursors, d_layout, (char *)d_send, d_counts, d_err
-    if (cplx) {
-        if (op.is_real) hipLaunchKernelGGL((k_tile<true, true>), g, b, 0, s, LSK_TILE_ARGS);
-        else hipLaunchKernelGGL((k_tile<true, false>), g, b, 0, s, LSK_TILE_ARGS);
-    } else {
-        if (op.is_real) hipLaunchKernelGGL((k_tile<false, true>), g, b, 0, s, LSK_TILE_ARGS);
-        else hipLaunchKernelGGL((k_tile<false, false>), g, b, 0, s, LSK_TILE_ARGS);
-    }
+#define LSK_TILE_LAUNCH(W, PM1)                                                                            \
+    do {                                                                                                   \
+        if (cplx) {                                                                                        \
+            if (op.is_real) hipLaunchKernelGGL((k_tile<W, PM1, true, true>), g, b, 0, s, LSK_TILE_ARGS);   \
+            else hipLaunchKernelGGL((k_tile<W, PM1, true, false>), g, b, 0, s, LSK_TILE_ARGS);             \
+        } else {                                                                                           \
+            if (op.is_real) hipLaunchKernelGGL((k_tile<W, PM1, false, true>), g, b, 0, s, LSK_TILE_ARGS);  \
+            else hipLaunchKernelGGL((k_tile<W, PM1, false, false>), g, b, 0, s, LSK_TILE_ARGS);            \
+        }                                                                                                  \
+    } while (0)
+    const bool narrow = bs.number_sites <= 32 && bs.proj == LSK_PROJ_FULL;
+    if (narrow) { if (bs.chars_pm1) LSK_TILE_LAUNCH(uint32_t, true); else LSK_TILE_LAUNCH(uint32_t, false); }
+    else { if (bs.chars_pm1) LSK_TILE_LAUNCH(uint64_t, true); else LSK_TILE_LAUNCH(uint64_t, false); }
+#undef LSK_TILE_LAUNCH
 #undef LSK_TILE_ARGS
     LSK_LAUNCH_CHECK();
     return 0;
@@ -725,24 +830,26 @@ extern "C" int lsk_tile(lsk_operator op, lsk_basis bs, lsk_index ix, int cplx, i
 // ---------------------------------------------------------------------------------------------
 template <bool CPLX>
 __global__ __launch_bounds__(kBlock) void k_scatter(lsk_index ix, int64_t n, uint64_t const *__restrict__ betas,
-                                                    double const *__restrict__ vals, double *y, int *err) {
+                                                    double const *__restrict__ vals, double *y,
+                                                    double const *__restrict__ norms, int *err) {
     for (int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x; k < n; k += (int64_t)gridDim.x * kBlock) {
         double vr, vi = 0.0;
         if (CPLX) { vr = vals[2 * k]; vi = vals[2 * k + 1]; } else vr = vals[k];
         if (vr == 0.0 && vi == 0.0) continue; // DMV:110
         int64_t idx = ix.kind == LSK_INDEX_IDENTITY ? (int64_t)betas[k] : search_index(ix, betas[k]);
         if (idx < 0) { atomicExch(err, 1); continue; }
+        if (norms) { double nb = norms[idx]; vr *= nb; vi *= nb; }
         if (CPLX) { atomic_add_f64(y + 2 * idx, vr); atomic_add_f64(y + 2 * idx + 1, vi); }
         else atomic_add_f64(y + idx, vr);
     }
 }
 extern "C" int lsk_scatter(lsk_index ix, int cplx, int64_t n, uint64_t const *betas, void const *vals, void *y,
-                           int *d_err, void *stream) {
+                           double const *norms, int *d_err, void *stream) {
     if (n == 0) return 0;
     if (ix.kind == LSK_INDEX_COMBINADIC) { snprintf(g_err, sizeof(g_err), "lsk_scatter: SEARCH/IDENTITY index only"); return -1; }
     dim3 g(grid_for(n)), b(kBlock);
-    if (cplx) hipLaunchKernelGGL(k_scatter<true>, g, b, 0, (hipStream_t)stream, ix, n, betas, (double const *)vals, (double *)y, d_err);
-    else hipLaunchKernelGGL(k_scatter<false>, g, b, 0, (hipStream_t)stream, ix, n, betas, (double const *)vals, (double *)y, d_err);
+    if (cplx) hipLaunchKernelGGL(k_scatter<true>, g, b, 0, (hipStream_t)stream, ix, n, betas, (double const *)vals, (double *)y, norms, d_err);
+    else hipLaunchKernelGGL(k_scatter<false>, g, b, 0, (hipStream_t)stream, ix, n, betas, (double const *)vals, (double *)y, norms, d_err);
     LSK_LAUNCH_CHECK();
     return 0;
 }

@@ -69,6 +69,14 @@ enum { LSK_PROJ_NONE = 0, LSK_PROJ_INVERSION = 1, LSK_PROJ_FULL = 2 };
 
 typedef struct lsk_basis {
     int number_sites, hamming_weight, spin_inversion, n_elems, proj;
+    int chars_pm1; /* every character is +1 or -1 (integer stabiliser accumulation) */
+    /* K4 evaluation mode of the staged kernel:
+     *  0 general: orbit minimum + character + stabiliser norm per packet;
+     *  1 trivial sector (every character, incl. inversion, is +1): only the orbit minimum is needed,
+     *    norm(rep) is read from the owner's per-row norms when the index is looked up;
+     *  2 as 1, and the permutation group is the full cyclic (rotation) group of the ring, with
+     *    (reflect = 1) or without its reflections: rotations are generated incrementally. */
+    int k4_mode, reflect;
     uint64_t site_mask;
     double inv_order; /* 1 / |G| including the inversion doubling */
     lsk_group_elem const *elems; /* device [n_elems] */
@@ -131,7 +139,8 @@ int lsk_tile(lsk_operator op, lsk_basis bs, lsk_index ix, int cplx, int count_on
              unsigned long long *d_counts, int *d_err, void *stream);
 /* n packets -> y[idx(beta)] += value */
 int lsk_scatter(lsk_index ix, int cplx, int64_t n, uint64_t const *betas, void const *vals, void *y,
-                int *d_err, void *stream);
+                double const *norms /* NULL, or per-row norms multiplied in (K4 modes 1, 2) */, int *d_err,
+                void *stream);
 
 /* plan-time helpers -------------------------------------------------------------------------- */
 /* norms[i] = sqrt(stab(reps[i]) / |G|) */

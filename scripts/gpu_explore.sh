@@ -1,7 +1,6 @@
 set -x
 export TMPDIR=/tmp
-python scripts/tile_bench.py --L 28 --P 2
-python scripts/tile_bench.py --L 28 --P 8
+timeout 1500 python -m pytest tests -m gpu -q --maxfail=5 2>&1 | tail -8
 python scripts/tile_bench.py --L 24 --symm --P 1
 python scripts/tile_bench.py --L 32 --symm --P 1
 python scripts/tile_bench.py --L 32 --symm --P 8
