@@ -150,6 +150,11 @@ def load():
         "ls_hs_operator_max_number_off_diag": (C.c_int, [op]),
         "ls_hs_operator_is_hermitian": (C.c_bool, [op]),
         "ls_hs_operator_is_real": (C.c_bool, [op]),
+        "ls_hs_state_index": (None, [bp, C.c_ssize_t, c_u64p, C.c_ssize_t, C.POINTER(C.c_ssize_t), C.c_ssize_t]),
+        "ls_hs_is_representative": (None, [bp, C.c_ssize_t, c_u64p, C.c_ssize_t, C.POINTER(C.c_uint8), c_f64p]),
+        "ls_hs_state_info": (None, [bp, C.c_ssize_t, c_u64p, C.c_ssize_t, c_u64p, C.c_ssize_t, c_f64p, c_f64p]),
+        "ls_internal_operator_apply_diag_x1": (None, [op, C.c_ssize_t, c_u64p, c_f64p, c_f64p]),
+        "ls_internal_operator_apply_off_diag_x1": (None, [op, C.c_ssize_t, c_u64p, c_u64p, c_f64p, C.POINTER(C.c_ssize_t), c_f64p]),
         "ls_hs_internal_set_chpl_kernels": (None, [vp]),
         "ls_hs_internal_get_chpl_kernels": (vp, []),
         "ls_chpl_init": (None, []),

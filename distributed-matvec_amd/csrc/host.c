@@ -157,6 +157,8 @@ struct ls_amd_basis_ext {
     uint64_t *d_reps_cache; /* device copy of `representatives` for the host-pointer entry points */
     uint64_t d_reps_count;
     void *host_plan_f64;    /* ls_amd_plan* cached by the host-pointer entry points */
+    uint32_t *d_index_table; /* search table over d_reps_cache (ls_hs_state_index) */
+    int index_kind, index_shift;
 };
 
 void ls_hs_init(void) {}
@@ -385,6 +387,8 @@ static void basis_drop_device_caches(ls_hs_basis *b) {
     struct ls_amd_basis_ext *e = b->ext;
     if (e->host_plan_f64) { ls_amd_plan_destroy((ls_amd_plan *)e->host_plan_f64); e->host_plan_f64 = NULL; }
     if (e->d_reps_cache) { lsk_free(e->d_reps_cache); e->d_reps_cache = NULL; e->d_reps_count = 0; }
+    if (e->d_index_table) { lsk_free(e->d_index_table); e->d_index_table = NULL; }
+    e->index_kind = -1;
 }
 
 void ls_hs_destroy_basis(ls_hs_basis *b) {
@@ -1414,4 +1418,133 @@ void ls_chpl_operator_apply_off_diag(ls_hs_operator *matrixPtr, int64_t count, u
     betas->elts = h_b; betas->num_elts = cap; betas->freer = (void *)free_array;
     coeffs->elts = h_c; coeffs->num_elts = cap; coeffs->freer = (void *)free_array;
     offsets->elts = h_off; offsets->num_elts = (uint64_t)count + 1; offsets->freer = (void *)free_array;
+}
+
+/* ============================================================================================ */
+/* batched externs with the reference's signatures (host arrays, device kernels)                 */
+/* ============================================================================================ */
+static uint64_t *gather_u64(uint64_t const *src, ptrdiff_t n, ptrdiff_t stride) {
+    uint64_t *t = (uint64_t *)malloc(8 * (size_t)(n > 0 ? n : 1));
+    for (ptrdiff_t i = 0; i < n; ++i) t[i] = src[i * stride];
+    return t;
+}
+
+void ls_hs_state_index(ls_hs_basis const *basis_c, ptrdiff_t n, uint64_t const *spins, ptrdiff_t sstride,
+                       ptrdiff_t *indices, ptrdiff_t istride) {
+    ls_hs_basis *b = (ls_hs_basis *)basis_c;
+    struct ls_amd_basis_ext *e = b->ext;
+    if (n <= 0) return;
+    if (ensure_device_reps(b) != 0) { halt_with("%s", g_last_error); return; }
+    uint64_t const *d_binom;
+    if (device_binom(&d_binom) != 0) { halt_with("%s", g_last_error); return; }
+    lsk_index ix;
+    memset(&ix, 0, sizeof(ix));
+    ix.count = (int64_t)e->d_reps_count;
+    ix.reps = e->d_reps_cache;
+    ix.binom = d_binom;
+    if (b->state_index_is_identity) ix.kind = LSK_INDEX_IDENTITY;
+    else {
+        if (!e->d_index_table) {
+            part_state ps;
+            memset(&ps, 0, sizeof(ps));
+            ps.count = ix.count;
+            ps.d_reps = ix.reps;
+            if (build_search_index(&ps, b->number_sites, NULL) != 0 || lsk_sync(NULL) != 0) { halt_with("%s", g_last_error); return; }
+            e->d_index_table = ps.d_table;
+            e->index_shift = ps.index.shift;
+        }
+        ix.kind = LSK_INDEX_SEARCH;
+        ix.table = e->d_index_table;
+        ix.shift = e->index_shift;
+    }
+    uint64_t *h = gather_u64(spins, n, sstride);
+    int64_t *hi = (int64_t *)malloc(8 * (size_t)n);
+    void *ds = NULL, *di = NULL;
+    int rc = lsk_malloc(&ds, 8 * (size_t)n) || lsk_malloc(&di, 8 * (size_t)n) || lsk_h2d(ds, h, 8 * (size_t)n) ||
+             lsk_state_index(ix, n, (uint64_t const *)ds, (int64_t *)di, NULL) || lsk_sync(NULL) ||
+             lsk_d2h(hi, di, 8 * (size_t)n);
+    lsk_free(ds); lsk_free(di);
+    if (!rc) for (ptrdiff_t i = 0; i < n; ++i) indices[i * istride] = (ptrdiff_t)hi[i];
+    free(h); free(hi);
+    if (rc) halt_with("%s", lsk_last_error());
+}
+
+static int state_info_host(ls_hs_basis const *b, ptrdiff_t n, uint64_t const *alphas, ptrdiff_t astride,
+                           uint64_t *betas, double *chars, double *norms) {
+    lsk_basis dbs;
+    if (basis_device(b, &dbs) != 0) return -1;
+    uint64_t *h = gather_u64(alphas, n, astride);
+    void *da = NULL, *db = NULL, *dc = NULL, *dn = NULL;
+    int rc = lsk_malloc(&da, 8 * (size_t)n) || lsk_malloc(&db, 8 * (size_t)n) || lsk_malloc(&dc, 16 * (size_t)n) ||
+             lsk_malloc(&dn, 8 * (size_t)n) || lsk_h2d(da, h, 8 * (size_t)n) ||
+             lsk_state_info(dbs, n, (uint64_t const *)da, (uint64_t *)db, (double *)dc, (double *)dn, NULL) ||
+             lsk_sync(NULL) || lsk_d2h(betas, db, 8 * (size_t)n) || lsk_d2h(chars, dc, 16 * (size_t)n) ||
+             lsk_d2h(norms, dn, 8 * (size_t)n);
+    lsk_free(da); lsk_free(db); lsk_free(dc); lsk_free(dn);
+    free(h);
+    return rc ? dev_error() : 0;
+}
+
+void ls_hs_state_info(ls_hs_basis const *basis, ptrdiff_t n, uint64_t const *alphas, ptrdiff_t astride,
+                      uint64_t *betas, ptrdiff_t bstride, ls_hs_scalar *characters, double *norms) {
+    if (n <= 0) return;
+    uint64_t *hb = (uint64_t *)malloc(8 * (size_t)n);
+    if (state_info_host(basis, n, alphas, astride, hb, (double *)characters, norms) != 0) { free(hb); halt_with("%s", g_last_error); return; }
+    for (ptrdiff_t i = 0; i < n; ++i) betas[i * bstride] = hb[i];
+    free(hb);
+}
+
+void ls_hs_is_representative(ls_hs_basis const *basis, ptrdiff_t n, uint64_t const *alphas, ptrdiff_t astride,
+                             uint8_t *are_representatives, double *norms) {
+    if (n <= 0) return;
+    uint64_t *hb = (uint64_t *)malloc(8 * (size_t)n);
+    double *hc = (double *)malloc(16 * (size_t)n);
+    if (state_info_host(basis, n, alphas, astride, hb, hc, norms) != 0) { free(hb); free(hc); halt_with("%s", g_last_error); return; }
+    for (ptrdiff_t i = 0; i < n; ++i) are_representatives[i] = hb[i] == alphas[i * astride];
+    free(hb); free(hc);
+}
+
+void ls_internal_operator_apply_diag_x1(ls_hs_operator const *op, ptrdiff_t n, uint64_t const *alphas, double *ys,
+                                        double const *xs) {
+    if (n <= 0) return;
+    lsk_operator dop;
+    if (operator_device(op, &dop) != 0) { halt_with("%s", g_last_error); return; }
+    void *da = NULL, *dy = NULL, *dx = NULL;
+    int rc = lsk_malloc(&da, 8 * (size_t)n) || lsk_malloc(&dy, 8 * (size_t)n) || lsk_h2d(da, alphas, 8 * (size_t)n);
+    if (!rc && xs) rc = lsk_malloc(&dx, 8 * (size_t)n) || lsk_h2d(dx, xs, 8 * (size_t)n);
+    if (!rc) rc = lsk_diag_coeffs(dop, n, (uint64_t const *)da, (double *)dy, (double const *)dx, NULL) || lsk_sync(NULL) ||
+                  lsk_d2h(ys, dy, 8 * (size_t)n);
+    lsk_free(da); lsk_free(dy); lsk_free(dx);
+    if (rc) halt_with("%s", lsk_last_error());
+}
+
+void ls_internal_operator_apply_off_diag_x1(ls_hs_operator const *op, ptrdiff_t n, uint64_t const *alphas,
+                                            uint64_t *betas, ls_hs_scalar *coeffs, ptrdiff_t *offsets,
+                                            double const *xs) {
+    offsets[0] = 0;
+    if (n <= 0) return;
+    int const T = op->ext->n_groups;
+    if (T == 0) { for (ptrdiff_t i = 0; i <= n; ++i) offsets[i] = 0; return; }
+    lsk_operator dop;
+    if (operator_device(op, &dop) != 0) { halt_with("%s", g_last_error); return; }
+    size_t cap = (size_t)n * (size_t)T;
+    int64_t *h_off = (int64_t *)malloc(8 * ((size_t)n + 1));
+    void *da = NULL, *dcnt = NULL, *doff = NULL, *db = NULL, *dc = NULL, *dx = NULL;
+    int rc = lsk_malloc(&da, 8 * (size_t)n) || lsk_malloc(&dcnt, 8 * ((size_t)n + 1)) ||
+             lsk_malloc(&doff, 8 * ((size_t)n + 1)) || lsk_malloc(&db, 8 * cap) || lsk_malloc(&dc, 16 * cap) ||
+             lsk_h2d(da, alphas, 8 * (size_t)n) || lsk_memset_async(dcnt, 0, 8 * ((size_t)n + 1), NULL);
+    if (!rc && xs) rc = lsk_malloc(&dx, 8 * (size_t)n) || lsk_h2d(dx, xs, 8 * (size_t)n);
+    if (!rc) rc = lsk_offdiag_counts(dop, n, (uint64_t const *)da, (int64_t *)dcnt, NULL) ||
+                  lsk_exclusive_scan_i64(n + 1, (int64_t const *)dcnt, (int64_t *)doff, NULL) ||
+                  lsk_offdiag_fill(dop, n, (uint64_t const *)da, (int64_t const *)doff, (uint64_t *)db, (double *)dc,
+                                   (double const *)dx, NULL) ||
+                  lsk_sync(NULL) || lsk_d2h(h_off, doff, 8 * ((size_t)n + 1));
+    if (!rc) {
+        size_t total = (size_t)h_off[n];
+        rc = lsk_d2h(betas, db, 8 * total) || lsk_d2h(coeffs, dc, 16 * total);
+        for (ptrdiff_t i = 0; i <= n; ++i) offsets[i] = (ptrdiff_t)h_off[i];
+    }
+    lsk_free(da); lsk_free(dcnt); lsk_free(doff); lsk_free(db); lsk_free(dc); lsk_free(dx);
+    free(h_off);
+    if (rc) halt_with("%s", lsk_last_error());
 }

@@ -1,0 +1,231 @@
+"""Eigensolver driver: the caller of the matvec path in BASELINE config 5
+(`/root/reference/src/Diagonalize.chpl:258-332`: load YAML -> basis states -> PRIMME `dprimme` with
+`ls_chpl_primme_matvec` -> eigenpairs).
+
+libprimme is not available here (headers only, `/root/reference/primme_headers/`), so the PRIMME-ABI
+callbacks stay exported from the C library for a real PRIMME (include/ls_chpl.h) and
+this module ships a small restarted Lanczos that keeps every vector in HBM — PRIMME hands host
+pointers to its matvec callback, which costs a PCIe round trip of x and y per call,
+so a device-resident solver is the MI355X-first way to drive this path.
+
+The solver only needs three things from its operator: `matvec(x, y)`, a global dot product and the
+local vector length — provided both by a single-process plan (all partitions on one GPU) and by
+`DistributedOperator` (one partition per rank; dots = all_reduce = PRIMME's globalSumReal,
+`/root/reference/src/PRIMME.chpl:267-311`).
+"""
+from __future__ import annotations
+
+import math
+import time
+from dataclasses import dataclass, field
+
+
+class LocalOperator:
+    """H on one device: P logical partitions concatenated into flat per-partition vectors."""
+
+    def __init__(self, matrix, representatives, dtype, mode="auto"):
+        import torch
+
+        from .api import MatvecPlan
+
+        self.torch = torch
+        self.reps = list(representatives)
+        self.plan = MatvecPlan(matrix, self.reps, dtype, mode=mode)
+        self.dtype = dtype
+        self.sizes = [int(r.numel()) for r in self.reps]
+        self.n_local = sum(self.sizes)
+        self.device = self.reps[0].device
+        self.matvecs = 0
+
+    def _split(self, v):
+        return list(v.split(self.sizes)) if len(self.sizes) > 1 else [v]
+
+    def matvec(self, x, y):
+        y.zero_()
+        self.plan.matvec(self._split(x), self._split(y), check=False)
+        self.matvecs += 1
+
+    def check(self):
+        self.plan.check()
+
+    def dot(self, a, b):
+        return self.torch.vdot(a, b) if a.is_complex() else self.torch.dot(a, b)
+
+    def new_vector(self):
+        return self.torch.zeros(self.n_local, dtype=self.dtype, device=self.device)
+
+    def random_vector(self, seed):
+        from .api import fillRandom
+
+        return self.torch.cat([fillRandom(r, seed, self.dtype) for r in self.reps])
+
+
+class RankOperator:
+    """H with one partition per process (wraps distributed.DistributedOperator)."""
+
+    def __init__(self, dist_op, representatives, dtype):
+        import torch
+
+        self.torch = torch
+        self.op = dist_op
+        self.reps = representatives
+        self.dtype = dtype
+        self.n_local = int(representatives.numel())
+        self.device = representatives.device
+        self.matvecs = 0
+
+    def matvec(self, x, y):
+        y.zero_()
+        self.op.matvec(x, y, check=False)
+        self.matvecs += 1
+
+    def check(self):
+        self.op.engine.check()
+
+    def dot(self, a, b):
+        return self.op.dot(a, b)
+
+    def global_sum(self, t):
+        if t.is_complex():
+            r = self.torch.view_as_real(t).contiguous()
+            self.op.global_sum(r)
+            return self.torch.view_as_complex(r)
+        return self.op.global_sum(t)
+
+    def new_vector(self):
+        return self.torch.zeros(self.n_local, dtype=self.dtype, device=self.device)
+
+    def random_vector(self, seed):
+        from .api import fillRandom
+
+        return fillRandom(self.reps, seed, self.dtype)
+
+
+@dataclass
+class EigenResult:
+    eigenvalues: list
+    eigenvectors: list
+    residual_norms: list
+    matvecs: int
+    restarts: int
+    converged: bool
+    seconds: float
+    history: list = field(default_factory=list)
+
+
+def lanczos_smallest(op, num_evals: int = 1, eps: float = 1e-6, max_basis: int = 24, max_restarts: int = 500,
+                     seed: int = 1234, verbose: bool = False) -> EigenResult:
+    """Smallest `num_evals` eigenpairs of the Hermitian operator `op` (target = primme_smallest, eps as
+    in `/root/reference/src/Diagonalize.chpl:164-172,205`): thick-restart Lanczos (Wu & Simon) with
+    full re-orthogonalisation (classical Gram-Schmidt twice, one GEMV per pass) inside a window of
+    `max_basis` device vectors.  Residuals come from the Lanczos relation
+    ||H y_i - theta_i y_i|| = |beta_m s_{m,i}|, so a step costs exactly one matvec.
+    Converged when every wanted residual <= eps * ||H|| (estimated by the largest |Ritz value|)."""
+    import numpy as np
+    import torch
+
+    t0 = time.perf_counter()
+    k = num_evals
+    m = max(max_basis, 2 * k + 4)
+    v = op.random_vector(seed)
+    n = v.numel()
+    cplx = v.is_complex()
+    V = torch.empty((m + 1, n), dtype=v.dtype, device=v.device)
+    T = np.zeros((m + 1, m), dtype=complex if cplx else float)
+
+    def gsum(t):
+        return op.global_sum(t) if hasattr(op, "global_sum") else t
+
+    def norm(u):
+        return math.sqrt(float(gsum((u.abs() ** 2).sum().reshape(1))[0]))
+
+    V[0] = v / norm(v)
+    del v
+    w = op.new_vector()
+    j0 = 0  # number of locked (restarted) vectors at the front of V
+    restarts = 0
+    history = []
+    while True:
+        for j in range(j0, m):
+            op.matvec(V[j], w)
+            Vj = V[: j + 1]
+            h = gsum(torch.mv(Vj.conj() if cplx else Vj, w))
+            w -= torch.mv(Vj.t(), h)
+            h2 = gsum(torch.mv(Vj.conj() if cplx else Vj, w))
+            w -= torch.mv(Vj.t(), h2)
+            h = (h + h2).cpu().numpy()
+            beta = norm(w)
+            T[: j + 1, j] = h
+            T[j + 1, j] = beta
+            if beta < 1e-14 * max(1.0, float(np.abs(h).max())):
+                m_eff = j + 1
+                break
+            V[j + 1] = w / beta
+        else:
+            m_eff = m
+        Tm = T[:m_eff, :m_eff]
+        Tm = 0.5 * (Tm + Tm.conj().T)
+        theta, S = np.linalg.eigh(Tm)
+        beta_m = T[m_eff, m_eff - 1].real if m_eff == m else 0.0
+        kk = min(k, m_eff)
+        res = [abs(beta_m * S[m_eff - 1, i]) for i in range(kk)]
+        scale = max(float(np.abs(theta).max()), 1e-300)
+        history.append((op.matvecs, [float(t) for t in theta[:kk]], res))
+        if verbose:
+            print(f"[lanczos] restart {restarts}: matvecs={op.matvecs} theta={theta[:kk]} res={res}", flush=True)
+        done = all(r <= eps * scale for r in res) or m_eff < m
+        if done or restarts >= max_restarts:
+            St = torch.as_tensor(S[:, :kk], dtype=V.dtype, device=V.device)
+            Y = torch.mm(St.t(), V[:m_eff])  # Ritz vectors, [kk, n]
+            vecs = [Y[i].clone() for i in range(kk)]
+            op.check()
+            return EigenResult([float(t) for t in theta[:kk]], vecs, [float(r) for r in res], op.matvecs, restarts, bool(done),
+                               time.perf_counter() - t0, history)
+        # thick restart: keep `keep` Ritz vectors, then the next Lanczos vector
+        keep = min(m_eff - 2, kk + max(2, (m_eff - kk) // 3))
+        St = torch.as_tensor(S[:, :keep], dtype=V.dtype, device=V.device)
+        Y = torch.mm(St.t(), V[:m_eff])
+        V[:keep] = Y
+        V[keep] = V[m_eff]
+        T[:, :] = 0
+        for i in range(keep):
+            T[i, i] = theta[i]
+            T[keep, i] = beta_m * S[m_eff - 1, i]  # coupling of the kept Ritz vectors to the next vector
+            T[i, keep] = np.conj(T[keep, i])
+        j0 = keep
+        restarts += 1
+
+
+def diagonalize(config, num_evals: int = 1, eps: float = 1e-6, num_partitions: int = 1, dtype=None, output: str | None = None,
+                max_basis: int = 24, verbose: bool = False):
+    """`Diagonalize.main` (Diagonalize.chpl:258-332) on one device: config (dict or YAML path) ->
+    representatives (enumerated on the GPU, or reused from `output` like makeBasisStates :227-246) ->
+    eigenpairs; `output` (.npz) receives what the reference writes to its HDF5 groups:
+    basis/representatives, hamiltonian/eigenvalues, hamiltonian/eigenvectors, hamiltonian/residuals."""
+    import os
+
+    import numpy as np
+    import torch
+
+    from . import api
+
+    if isinstance(config, str):
+        basis, h = api.loadConfigFromYaml(config, hamiltonian=True)
+    else:
+        basis, h = api.loadConfigFromDict(config, hamiltonian=True)
+    dtype = dtype or torch.float64
+    reps, masks = api.enumerateStates(basis, num_partitions)
+    op = LocalOperator(h, reps, dtype)
+    r = lanczos_smallest(op, num_evals=num_evals, eps=eps, max_basis=max_basis, verbose=verbose)
+    if output:
+        parts_to_block = lambda v: api.arrFromHashedToBlock(list(v.split(op.sizes)), masks) if num_partitions > 1 else v  # noqa: E731
+        np.savez(
+            output,
+            **{
+                "basis/representatives": (api.arrFromHashedToBlock(reps, masks) if num_partitions > 1 else reps[0]).cpu().numpy().view(np.uint64),
+                "hamiltonian/eigenvalues": np.array(r.eigenvalues),
+                "hamiltonian/residuals": np.array(r.residual_norms),
+                "hamiltonian/eigenvectors": np.stack([parts_to_block(v).cpu().numpy() for v in r.eigenvectors]),
+            },
+        )
+    return r

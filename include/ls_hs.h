@@ -137,6 +137,29 @@ int ls_hs_operator_max_number_off_diag(ls_hs_operator const *op); /* FFI.chpl:20
 bool ls_hs_operator_is_hermitian(ls_hs_operator const *op);       /* FFI.chpl:201 */
 bool ls_hs_operator_is_real(ls_hs_operator const *op);            /* FFI.chpl:202 */
 
+/* Batched per-state queries with the reference's signatures (FFI.chpl:173-184, 219-225).  Upstream
+ * these are CPU loops of lattice-symmetries-haskell; here each call stages its HOST arrays through HBM
+ * and runs the corresponding HIP kernel (the matvec itself never calls them -- it fuses them).
+ *   ls_hs_state_index        indices[k] = position of spins[k] in basis->representatives, < 0 if absent
+ *   ls_hs_is_representative  flag = alpha is its orbit minimum; norm = sqrt(stabiliser sum / |G|)
+ *   ls_hs_state_info         beta = orbit minimum, character = conj(chi(g0)), norm as above
+ *   ls_internal_operator_apply_diag_x1      ys[i] = d(alphas[i]) * xs[i]   (xs == NULL: ys[i] = d)
+ *   ls_internal_operator_apply_off_diag_x1  CSR expansion, coefficients times xs[i] when xs != NULL;
+ *                                           betas/coeffs need batch_size * max_number_off_diag slots
+ * Strides are in elements. */
+void ls_hs_state_index(ls_hs_basis const *basis, ptrdiff_t batch_size, uint64_t const *spins,
+                       ptrdiff_t spins_stride, ptrdiff_t *indices, ptrdiff_t indices_stride);
+void ls_hs_is_representative(ls_hs_basis const *basis, ptrdiff_t batch_size, uint64_t const *alphas,
+                             ptrdiff_t alphas_stride, uint8_t *are_representatives, double *norms);
+void ls_hs_state_info(ls_hs_basis const *basis, ptrdiff_t batch_size, uint64_t const *alphas,
+                      ptrdiff_t alphas_stride, uint64_t *betas, ptrdiff_t betas_stride,
+                      ls_hs_scalar *characters, double *norms);
+void ls_internal_operator_apply_diag_x1(ls_hs_operator const *op, ptrdiff_t batch_size,
+                                        uint64_t const *alphas, double *ys, double const *xs);
+void ls_internal_operator_apply_off_diag_x1(ls_hs_operator const *op, ptrdiff_t batch_size,
+                                            uint64_t const *alphas, uint64_t *betas,
+                                            ls_hs_scalar *coeffs, ptrdiff_t *offsets, double const *xs);
+
 void ls_hs_internal_set_chpl_kernels(ls_chpl_kernels const *kernels); /* FFI.chpl:239 */
 ls_chpl_kernels const *ls_hs_internal_get_chpl_kernels(void);
 

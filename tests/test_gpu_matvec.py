@@ -336,3 +336,123 @@ def test_properties_at_scale(torch):
     D.matrixVectorProduct(h, u4, y4, reps4)
     back = D.arrFromHashedToBlock(y4, masks4)
     assert float((back - Hu_pull).abs().max()) <= 1e-12 * scale
+
+
+@pytest.mark.parametrize("name", ["heisenberg_chain_24_symm", "heisenberg_square_4x4", "issue_01", "heisenberg_kagome_12_symm", "heisenberg_chain_10"])
+def test_batched_externs_state_info(torch, name):
+    """ls_hs_state_info / ls_hs_is_representative / ls_hs_state_index (FFI.chpl:173-184) on the device
+    against the oracle's restatement, bit-exact representatives / flags / indices."""
+    import ctypes as C
+
+    import distributed_matvec_amd as D
+    from distributed_matvec_amd import _lib
+
+    lib = _lib.load()
+    basis, h = D.loadConfigFromDict(model_config(name), hamiltonian=True)
+    o = oracle_for(name)
+    m = o.model
+    rs = np.random.RandomState(50)
+    n = 3000
+    # random states of the right Hamming weight
+    states = np.zeros(n, dtype=np.uint64)
+    for i in range(n):
+        if m.hamming_weight >= 0:
+            bits = rs.choice(m.number_sites, size=m.hamming_weight, replace=False)
+            states[i] = sum(1 << int(b) for b in bits)
+        else:
+            states[i] = rs.randint(0, 1 << m.number_sites)
+    betas = np.zeros(n, dtype=np.uint64)
+    chars = np.zeros(2 * n)
+    norms = np.zeros(n)
+    lib.ls_hs_state_info(basis.payload, n, states.ctypes.data_as(_lib.c_u64p), 1, betas.ctypes.data_as(_lib.c_u64p), 1,
+                         chars.ctypes.data_as(_lib.c_f64p), norms.ctypes.data_as(_lib.c_f64p))
+    _lib.raise_pending_halt()
+    wb, wc, wn = o.state_info(states)
+    assert np.array_equal(betas, wb)
+    assert np.abs(norms - wn).max() < 1e-14
+    live = wn > 0
+    got_c = chars[0::2] + 1j * chars[1::2]
+    # the character of a minimising element is unique up to stabiliser elements; compare where it matters
+    assert np.abs((got_c * norms)[live] - (wc * wn)[live]).max() < 1e-13
+    flags = np.zeros(n, dtype=np.uint8)
+    norms2 = np.zeros(n)
+    lib.ls_hs_is_representative(basis.payload, n, states.ctypes.data_as(_lib.c_u64p), 1,
+                                flags.ctypes.data_as(C.POINTER(C.c_uint8)), norms2.ctypes.data_as(_lib.c_f64p))
+    _lib.raise_pending_halt()
+    wf, wn2 = o.is_representative(states)
+    assert np.array_equal(flags, wf) and np.abs(norms2 - wn2).max() < 1e-14
+    # state_index with strides, on the built basis
+    h.basis.build()
+    reps = oracle_reps(name)
+    assert np.array_equal(h.basis.representatives(), reps)
+    probe = np.zeros(2 * n, dtype=np.uint64)
+    probe[0::2] = np.where(rs.rand(n) < 0.5, reps[rs.randint(0, len(reps), size=n)], states)
+    idx = np.full(3 * n, -99, dtype=np.int64)
+    lib.ls_hs_state_index(h.basis.payload, n, probe.ctypes.data_as(_lib.c_u64p), 2,
+                          idx.ctypes.data_as(C.POINTER(C.c_ssize_t)), 3)
+    _lib.raise_pending_halt()
+    from oracle import c_oracle as CO
+
+    want = CO.state_index(reps, probe[0::2].copy())
+    got = idx[0::3]
+    assert np.array_equal(got >= 0, want >= 0)
+    assert np.array_equal(got[want >= 0], want[want >= 0])
+    assert (idx[1::3] == -99).all()
+
+
+@pytest.mark.parametrize("name", ["heisenberg_chain_16", "heisenberg_kagome_16", "heisenberg_chain_12"])
+def test_batched_externs_apply(torch, name):
+    """ls_internal_operator_apply_{diag,off_diag}_x1 (FFI.chpl:219-225)."""
+    import ctypes as C
+
+    import distributed_matvec_amd as D
+    from distributed_matvec_amd import _lib
+
+    lib = _lib.load()
+    basis, h = D.loadConfigFromDict(model_config(name), hamiltonian=True)
+    o = oracle_for(name)
+    reps = oracle_reps(name)
+    alphas = reps[:: max(1, len(reps) // 2000)].copy()
+    n = len(alphas)
+    xs = np.random.RandomState(51).rand(n) - 0.5
+    for use_x in (False, True):
+        ys = np.zeros(n)
+        lib.ls_internal_operator_apply_diag_x1(h.payload, n, alphas.ctypes.data_as(_lib.c_u64p), ys.ctypes.data_as(_lib.c_f64p),
+                                               xs.ctypes.data_as(_lib.c_f64p) if use_x else None)
+        assert np.array_equal(ys, o.apply_diag(alphas, xs if use_x else None))
+        T = h.numberOffDiagTerms()
+        betas = np.zeros(n * T, dtype=np.uint64)
+        coeffs = np.zeros(2 * n * T)
+        offs = np.zeros(n + 1, dtype=np.int64)
+        lib.ls_internal_operator_apply_off_diag_x1(h.payload, n, alphas.ctypes.data_as(_lib.c_u64p),
+                                                   betas.ctypes.data_as(_lib.c_u64p), coeffs.ctypes.data_as(_lib.c_f64p),
+                                                   offs.ctypes.data_as(C.POINTER(C.c_ssize_t)),
+                                                   xs.ctypes.data_as(_lib.c_f64p) if use_x else None)
+        _lib.raise_pending_halt()
+        wb, wc, wo = o.apply_off_diag(alphas, xs if use_x else None)
+        assert np.array_equal(offs, wo)
+        cc = coeffs[0::2] + 1j * coeffs[1::2]
+        for i in range(0, n, 37):
+            a, b = offs[i], offs[i + 1]
+            got = sorted(zip(betas[a:b].tolist(), cc[a:b].tolist()))
+            want = sorted(zip(wb[a:b].tolist(), wc[a:b].tolist()))
+            assert len(got) == len(want)
+            for (gb, gc), (wb_, wc_) in zip(got, want):
+                assert gb == wb_ and abs(gc - wc_) <= 1e-15 * max(1.0, abs(wc_))
+
+
+def test_general_k4_path_on_trivial_sector(torch, monkeypatch):
+    """the trivial-sector shortcuts (k4_mode 1/2) and the general K4 evaluation must agree."""
+    import distributed_matvec_amd as D
+
+    name = "heisenberg_chain_24_symm"
+    want_reps = oracle_reps(name)
+    x = np.random.RandomState(52).rand(len(want_reps)) - 0.5
+    want = oracle_for(name).local_matvec(want_reps, x)
+    for general in (False, True):
+        if general:
+            monkeypatch.setenv("LS_AMD_GENERAL_K4", "1")
+        for P in (1, 3):
+            D_, basis, h, reps, masks = setup_model(torch, model_config(name), P)
+            got, pl = run_matvec(torch, D_, h, reps, masks, x, P)
+            assert_close(got, want, f"{name} general={general} P={P}")
