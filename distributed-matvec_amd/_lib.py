@@ -106,6 +106,8 @@ def load():
         "ls_amd_hash64_01": (C.c_uint64, [C.c_uint64]),
         "ls_amd_locale_idx_of": (C.c_int, [C.c_uint64, C.c_int]),
         "ls_amd_plan_create": (C.c_int, [C.POINTER(vp), op, C.c_int, C.c_int, C.c_int, C.POINTER(vp), c_i64p, C.c_int, C.c_int, vp]),
+        "ls_amd_plan_create_replicated": (C.c_int, [C.POINTER(vp), op, C.c_int, C.c_int, C.c_int, vp, C.c_int64, vp, C.c_int64, vp]),
+        "ls_amd_matvec_replicated": (C.c_int, [vp, vp, vp, vp]),
         "ls_amd_plan_destroy": (None, [vp]),
         "ls_amd_plan_num_rounds": (C.c_int, [vp]),
         "ls_amd_plan_kernel_name": (C.c_char_p, [vp]),

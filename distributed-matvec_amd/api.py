@@ -24,7 +24,7 @@ from ._lib import LsAmdError
 __all__ = [
     "Basis", "Operator", "LsAmdError", "loadConfigFromYaml", "loadConfigFromDict", "enumerateStates",
     "arrFromBlockToHashed", "arrFromHashedToBlock", "matrixVectorProduct", "localMatrixVector",
-    "localeIdxOf", "hash64_01", "MatvecPlan", "build_library", "fillRandom",
+    "localeIdxOf", "hash64_01", "MatvecPlan", "ReplicatedPlan", "build_library", "fillRandom",
 ]
 
 
@@ -415,6 +415,35 @@ def fillRandom(states, seed: int, dtype):
     _lib.check(_lib.load().ls_amd_fill_random(states.numel(), C.c_void_p(states.data_ptr()), C.c_uint64(seed),
                                               1 if dtype == torch.complex128 else 0, C.c_void_p(out.data_ptr()), _stream_ptr()))
     return out
+
+
+class ReplicatedPlan:
+    """ls_amd replicated-x plan: this process owns partition `my_partition`'s rows and is handed the
+    whole x in global ascending order (include/ls_amd.h)."""
+
+    def __init__(self, matrix: "Operator", reps_local, reps_global, dtype, num_partitions: int, my_partition: int):
+        torch = _torch()
+        _lib.require_device()
+        self.matrix, self.reps_local, self.reps_global = matrix, reps_local, reps_global
+        self.cplx = dtype in (torch.complex128, "c128")
+        h = C.c_void_p()
+        _lib.check(_lib.load().ls_amd_plan_create_replicated(
+            C.byref(h), matrix.payload, 1 if self.cplx else 0, num_partitions, my_partition,
+            C.c_void_p(reps_local.data_ptr()), reps_local.numel(), C.c_void_p(reps_global.data_ptr()), reps_global.numel(),
+            _stream_ptr()))
+        self.h = h
+
+    destroy = MatvecPlan.destroy
+    __del__ = MatvecPlan.__del__
+    kernel = MatvecPlan.kernel
+    check = MatvecPlan.check
+    enable_timing = MatvecPlan.enable_timing
+    kernel_times_ms = MatvecPlan.kernel_times_ms
+
+    def matvec(self, x_global, y_local, check: bool = True):
+        _lib.check(_lib.load().ls_amd_matvec_replicated(self.h, C.c_void_p(x_global.data_ptr()), C.c_void_p(y_local.data_ptr()), _stream_ptr()))
+        if check:
+            self.check()
 
 
 def _plan_for(matrix: Operator, representatives, dtype, mode="auto"):

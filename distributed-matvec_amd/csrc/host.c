@@ -875,7 +875,8 @@ typedef struct part_state {
     int64_t *h_beta_off, *h_val_off; /* [rounds][P] host copies of the layout */
 } part_state;
 
-enum { FAMILY_DIRECT_PUSH = 0, FAMILY_DIRECT_PULL = 1, FAMILY_TILE = 2 };
+enum { FAMILY_DIRECT_PUSH = 0, FAMILY_DIRECT_PULL = 1, FAMILY_TILE = 2, FAMILY_TILE_PULL = 3,
+       FAMILY_REPL_DIRECT = 4, FAMILY_REPL_TILE = 5 };
 
 struct ls_amd_plan {
     ls_hs_operator const *op;
@@ -890,6 +891,11 @@ struct ls_amd_plan {
     unsigned long long *d_counts;  /* [P] */
     int *d_err;
     int64_t nnz;
+    /* replicated-x mode: index / norms of the GLOBAL basis, global index of every local row */
+    lsk_index gindex;
+    uint32_t *d_gtable;
+    int64_t *d_row_gidx;
+    double *d_norms_global;
     /* kernel timing ring */
     int t_capacity, t_count;
     void **t_start, **t_stop;
@@ -990,6 +996,14 @@ static int plan_setup_part(ls_amd_plan *pl, part_state *ps, int part_id, int num
     if (!closed_form && ps->count > 0) {
         if (build_search_index(ps, L, stream) != 0) return -1;
     }
+    if (pl->family == FAMILY_TILE_PULL) {
+        void *p;
+        DEV(lsk_malloc(&p, 8 * (size_t)(ps->count > 0 ? ps->count : 1)));
+        ps->d_norms = (double *)p;
+        DEV(lsk_norms(pl->dbs, ps->count, ps->d_reps, ps->d_norms, stream));
+        ps->rounds = 1;
+        return 0;
+    }
     if (pl->family != FAMILY_TILE) return 0;
 
     if (pl->dbs.proj == LSK_PROJ_FULL) {
@@ -1075,6 +1089,19 @@ int ls_amd_plan_create(ls_amd_plan **out, ls_hs_operator const *op, ls_amd_dtype
             m = LS_AMD_MODE_PUSH;
         }
         pl->family = m == LS_AMD_MODE_PULL ? FAMILY_DIRECT_PULL : FAMILY_DIRECT_PUSH;
+    } else if (num_partitions == 1 && pl->dbs.proj == LSK_PROJ_FULL) {
+        /* projected basis on one device: staged pull (no global atomics) when H is Hermitian */
+        ls_amd_mode m = mode;
+        if (m == LS_AMD_MODE_AUTO) {
+            char const *e = getenv("LS_AMD_MODE");
+            if (e && strcmp(e, "push") == 0) m = LS_AMD_MODE_PUSH;
+            else m = LS_AMD_MODE_PULL;
+        }
+        if (m == LS_AMD_MODE_PULL && !op->ext->is_hermitian) {
+            if (mode == LS_AMD_MODE_PULL) { free(pl); return set_error("pull mode needs a Hermitian operator"); }
+            m = LS_AMD_MODE_PUSH;
+        }
+        pl->family = m == LS_AMD_MODE_PULL ? FAMILY_TILE_PULL : FAMILY_TILE;
     } else pl->family = FAMILY_TILE;
 
     void *p;
@@ -1116,6 +1143,9 @@ void ls_amd_plan_destroy(ls_amd_plan *pl) {
         }
         free(pl->parts);
     }
+    if (pl->d_gtable) lsk_free(pl->d_gtable);
+    if (pl->d_row_gidx) lsk_free(pl->d_row_gidx);
+    if (pl->d_norms_global) lsk_free(pl->d_norms_global);
     if (pl->d_send) lsk_free(pl->d_send);
     if (pl->d_cursors) lsk_free(pl->d_cursors);
     if (pl->d_counts) lsk_free(pl->d_counts);
@@ -1125,10 +1155,106 @@ void ls_amd_plan_destroy(ls_amd_plan *pl) {
 }
 
 int ls_amd_plan_num_rounds(ls_amd_plan const *pl) { return pl->family == FAMILY_TILE ? pl->parts[0].rounds : 1; }
+
+/* -------------------------------------------------------------------------------------------- */
+/* replicated-x plans                                                                            */
+/* -------------------------------------------------------------------------------------------- */
+int ls_amd_plan_create_replicated(ls_amd_plan **out, ls_hs_operator const *op, ls_amd_dtype dtype,
+                                  int num_partitions, int my_partition, uint64_t const *d_reps_local,
+                                  int64_t count_local, uint64_t const *d_reps_global, int64_t count_global,
+                                  void *stream) {
+    *out = NULL;
+    if (!op || !op->basis) return set_error("null operator");
+    if (ls_hs_basis_number_words(op->basis) != 1) return set_error("bases with more than 64 bits are not yet implemented");
+    if (!op->ext->is_hermitian) return set_error("replicated-x (pull) plans need a Hermitian operator");
+    if (num_partitions < 1 || num_partitions > LSK_MAX_PARTS || my_partition < 0 || my_partition >= num_partitions)
+        return set_error("bad partition arguments");
+    if (dtype == LS_AMD_F64 && !op->ext->is_real) return set_error("an operator with complex coefficients needs dtype c128");
+    ls_amd_plan *pl = (ls_amd_plan *)calloc(1, sizeof(*pl));
+    pl->op = op;
+    pl->cplx = dtype == LS_AMD_C128;
+    pl->P = num_partitions;
+    pl->me = my_partition;
+    pl->n_local = 1;
+    if (operator_device(op, &pl->dop) != 0 || basis_device(op->basis, &pl->dbs) != 0) { free(pl); return -1; }
+    if (dtype == LS_AMD_F64)
+        for (int g = 0; g < op->basis->ext->order; ++g)
+            if (op->basis->ext->elems[g].ch_im != 0.0) { free(pl); return set_error("complex characters need dtype c128"); }
+    pl->family = pl->dbs.proj == LSK_PROJ_FULL ? FAMILY_REPL_TILE : FAMILY_REPL_DIRECT;
+    void *p;
+    if (lsk_malloc(&p, sizeof(int)) != 0) { free(pl); return dev_error(); }
+    pl->d_err = (int *)p;
+    int zero = 0;
+    lsk_h2d(pl->d_err, &zero, sizeof(int));
+    pl->parts = (part_state *)calloc(1, sizeof(part_state));
+    part_state *ps = &pl->parts[0];
+    ps->count = count_local;
+    ps->d_reps = d_reps_local;
+    ps->rounds = 1;
+    /* index of the GLOBAL basis: reuse the single-partition logic on a temporary part */
+    {
+        ls_amd_plan tmp = *pl;
+        part_state gps;
+        memset(&gps, 0, sizeof(gps));
+        gps.count = count_global;
+        gps.d_reps = d_reps_global;
+        tmp.P = 1;
+        tmp.family = FAMILY_DIRECT_PULL; /* no tile-side tables */
+        if (pl->dbs.proj == LSK_PROJ_FULL) {
+            uint64_t const *d_binom;
+            if (device_binom(&d_binom) != 0) { ls_amd_plan_destroy(pl); return -1; }
+            gps.index.count = count_global; gps.index.reps = d_reps_global; gps.index.binom = d_binom;
+            if (count_global > 0 && build_search_index(&gps, op->basis->number_sites, stream) != 0) { ls_amd_plan_destroy(pl); return -1; }
+        } else if (plan_setup_part(&tmp, &gps, 0, 1, stream) != 0) { ls_amd_plan_destroy(pl); return -1; }
+        pl->gindex = gps.index;
+        pl->d_gtable = gps.d_table;
+    }
+    if (pl->gindex.kind == LSK_INDEX_SEARCH && count_local > 0) {
+        if (lsk_malloc(&p, 8 * (size_t)count_local) != 0) { ls_amd_plan_destroy(pl); return dev_error(); }
+        pl->d_row_gidx = (int64_t *)p;
+        if (lsk_state_index(pl->gindex, count_local, d_reps_local, pl->d_row_gidx, stream) != 0) { ls_amd_plan_destroy(pl); return dev_error(); }
+    }
+    if (pl->family == FAMILY_REPL_TILE) {
+        if (lsk_malloc(&p, 8 * (size_t)(count_local > 0 ? count_local : 1)) != 0) { ls_amd_plan_destroy(pl); return dev_error(); }
+        ps->d_norms = (double *)p;
+        if (lsk_norms(pl->dbs, count_local, d_reps_local, ps->d_norms, stream) != 0) { ls_amd_plan_destroy(pl); return dev_error(); }
+        if (pl->dbs.k4_mode != 0) {
+            if (lsk_malloc(&p, 8 * (size_t)(count_global > 0 ? count_global : 1)) != 0) { ls_amd_plan_destroy(pl); return dev_error(); }
+            pl->d_norms_global = (double *)p;
+            if (lsk_norms(pl->dbs, count_global, d_reps_global, pl->d_norms_global, stream) != 0) { ls_amd_plan_destroy(pl); return dev_error(); }
+        }
+    }
+    if (lsk_sync(stream) != 0) { ls_amd_plan_destroy(pl); return dev_error(); }
+    *out = pl;
+    return 0;
+}
+
+int ls_amd_matvec_replicated(ls_amd_plan *pl, void const *d_x_global, void *d_y_local, void *stream) {
+    part_state *ps = &pl->parts[0];
+    int slot;
+    if (pl->family == FAMILY_REPL_DIRECT) {
+        slot = timing_begin(pl, stream);
+        DEV(lsk_direct_gx(pl->dop, pl->dbs, pl->gindex, pl->cplx, ps->count, ps->d_reps, pl->d_row_gidx, d_x_global,
+                          d_y_local, pl->d_err, stream));
+        timing_end(pl, slot, stream);
+        return 0;
+    }
+    if (pl->family == FAMILY_REPL_TILE) {
+        slot = timing_begin(pl, stream);
+        DEV(lsk_tile_pull(pl->dop, pl->dbs, pl->gindex, pl->cplx, 0, ps->count, ps->d_reps, ps->d_norms,
+                          pl->d_norms_global, pl->d_row_gidx, d_x_global, d_y_local, pl->d_err, stream));
+        timing_end(pl, slot, stream);
+        return 0;
+    }
+    return set_error("ls_amd_matvec_replicated: not a replicated-x plan");
+}
 char const *ls_amd_plan_kernel_name(ls_amd_plan const *pl) {
     switch (pl->family) {
     case FAMILY_DIRECT_PUSH: return "direct-push";
     case FAMILY_DIRECT_PULL: return "direct-pull";
+    case FAMILY_TILE_PULL: return "tile-pull";
+    case FAMILY_REPL_DIRECT: return "replicated-direct-pull";
+    case FAMILY_REPL_TILE: return "replicated-tile-pull";
     default: return "tile";
     }
 }
@@ -1178,6 +1304,14 @@ int ls_amd_scatter(ls_amd_plan *pl, int64_t n, uint64_t const *d_betas, void con
 
 int ls_amd_matvec(ls_amd_plan *pl, void const *const *d_x, void *const *d_y, void *stream) {
     if (pl->me >= 0) return set_error("ls_amd_matvec: plan owns one partition; drive it with generate/scatter");
+    if (pl->family == FAMILY_TILE_PULL) {
+        part_state *ps = &pl->parts[0];
+        int slot = timing_begin(pl, stream);
+        DEV(lsk_tile_pull(pl->dop, pl->dbs, ps->index, pl->cplx, 0, ps->count, ps->d_reps, ps->d_norms, ps->d_norms,
+                          NULL, d_x[0], d_y[0], pl->d_err, stream));
+        timing_end(pl, slot, stream);
+        return 0;
+    }
     /* localDiagonal on every partition first: y is assigned (DMV:1062-1063) */
     if (pl->family != FAMILY_DIRECT_PULL)
         for (int p = 0; p < pl->n_local; ++p)

@@ -459,7 +459,8 @@ __global__ __launch_bounds__(kBlock) void k_direct(lsk_runs runs, int n_groups, 
                                                    lsk_term const *__restrict__ diag, lsk_basis bs,
                                                    lsk_index ix, int64_t n, int64_t tiles_per_xcd,
                                                    uint64_t const *__restrict__ reps,
-                                                   double const *__restrict__ x, double *y, int *err) {
+                                                   double const *__restrict__ x, double *y, int *err, int gx,
+                                                   int64_t const *__restrict__ row_gidx) {
     typedef typename WordTraits<W>::binom_t BT;
     typedef WordTraits<W> WT;
     __shared__ BT s_binom[INDEX == LSK_INDEX_COMBINADIC ? 64 * LSK_BINOM_K : 1];
@@ -474,8 +475,16 @@ __global__ __launch_bounds__(kBlock) void k_direct(lsk_runs runs, int n_groups, 
         const int64_t i = ((int64_t)xcd * tiles_per_xcd + t) * kBlock + threadIdx.x;
         if (i >= n) continue;
         const W a = (W)reps[i];
+        // replicated-x mode (gx): rows are one hash partition, x is the whole vector in global ascending
+        // order; ig = global index of this row (closed form, or precomputed for searched bases)
+        int64_t ig = i;
+        if (gx) {
+            if (INDEX == LSK_INDEX_COMBINADIC) ig = rank_combinadic_w<W, BT>(a, s_binom);
+            else if (INDEX == LSK_INDEX_IDENTITY) ig = (int64_t)a;
+            else ig = row_gidx[i];
+        }
         double xr, xi = 0.0;
-        if (CPLX) { xr = x[2 * i]; xi = x[2 * i + 1]; } else xr = x[i];
+        if (CPLX) { xr = x[2 * ig]; xi = x[2 * ig + 1]; } else xr = x[ig];
         double accr = 0.0, acci = 0.0;
         if (PULL && n_diag == 0) { // no diagonal pass in the reference either: y is accumulated into (DMV:1062-1063)
             if (CPLX) { accr = y[2 * i]; acci = y[2 * i + 1]; } else accr = y[i];
@@ -502,7 +511,7 @@ __global__ __launch_bounds__(kBlock) void k_direct(lsk_runs runs, int n_groups, 
                     const BT d = s_binom[lo * LSK_BINOM_K + k];
                     k += bit ? 1 : 0;
                     if (sizeof(W) == 4) {
-                        const uint32_t i32 = (uint32_t)i;
+                        const uint32_t i32 = (uint32_t)ig;
                         uint32_t idx = bit ? i32 + (uint32_t)d : i32 - (uint32_t)d;
                         if (PULL) {
                             idx = act ? idx : i32;
@@ -522,9 +531,9 @@ __global__ __launch_bounds__(kBlock) void k_direct(lsk_runs runs, int n_groups, 
                             } else atomic_add_f64(y + idx, vr * xr);
                         }
                     } else {
-                        int64_t idx = bit ? i + (int64_t)d : i - (int64_t)d;
+                        int64_t idx = bit ? ig + (int64_t)d : ig - (int64_t)d;
                         if (PULL) {
-                            idx = act ? idx : i;
+                            idx = act ? idx : ig;
                             if (CPLX) {
                                 double yr = x[2 * idx], yi = x[2 * idx + 1];
                                 accr += act ? (vr * yr + vi * yi) : 0.0;
@@ -562,7 +571,7 @@ __global__ __launch_bounds__(kBlock) void k_direct(lsk_runs runs, int n_groups, 
                     // adjacent transposition: rank changes by C(lo, #set bits below lo)
                     int k = WT::popc(a & (W)(((uint64_t)1 << G.adj) - 1));
                     int64_t d = (int64_t)s_binom[G.adj * LSK_BINOM_K + k];
-                    idx = ((a >> G.adj) & 1) ? i + d : i - d;
+                    idx = ((a >> G.adj) & 1) ? ig + d : ig - d;
                 } else {
                     // a state of another Hamming weight is outside the basis: ls_hs_state_index would
                     // return a negative index and the reference halts (DMV:115-118)
@@ -595,7 +604,7 @@ __global__ __launch_bounds__(kBlock) void k_direct(lsk_runs runs, int n_groups, 
 
 template <typename W, bool CPLX, int INDEX, bool INV, bool PULL>
 static int launch_direct3(lsk_operator op, lsk_basis bs, lsk_index ix, int64_t n, uint64_t const *reps,
-                          void const *x, void *y, int *d_err, void *stream) {
+                          void const *x, void *y, int *d_err, void *stream, int gx, int64_t const *row_gidx) {
     int64_t tiles = (n + kBlock - 1) / kBlock;
     int64_t tiles_per_xcd = (tiles + 7) / 8;
     int64_t gb = tiles_per_xcd * 8;
@@ -604,48 +613,61 @@ static int launch_direct3(lsk_operator op, lsk_basis bs, lsk_index ix, int64_t n
     if (op.is_real)
         hipLaunchKernelGGL((k_direct<W, CPLX, INDEX, INV, PULL, true>), g, b, 0, (hipStream_t)stream, op.runs,
                            op.n_groups, op.groups, op.off, op.n_diag, op.diag, bs, ix, n, tiles_per_xcd, reps,
-                           (double const *)x, (double *)y, d_err);
+                           (double const *)x, (double *)y, d_err, gx, row_gidx);
     else
         hipLaunchKernelGGL((k_direct<W, CPLX, INDEX, INV, PULL, false>), g, b, 0, (hipStream_t)stream, op.runs,
                            op.n_groups, op.groups, op.off, op.n_diag, op.diag, bs, ix, n, tiles_per_xcd, reps,
-                           (double const *)x, (double *)y, d_err);
+                           (double const *)x, (double *)y, d_err, gx, row_gidx);
     LSK_LAUNCH_CHECK();
     return 0;
 }
 template <typename W, bool CPLX, int INDEX>
 static int launch_direct2(lsk_operator op, lsk_basis bs, lsk_index ix, int pull, int64_t n,
-                          uint64_t const *reps, void const *x, void *y, int *d_err, void *stream) {
+                          uint64_t const *reps, void const *x, void *y, int *d_err, void *stream, int gx,
+                          int64_t const *row_gidx) {
     const bool inv = bs.proj == LSK_PROJ_INVERSION;
     if (inv) {
-        if (pull) return launch_direct3<W, CPLX, INDEX, true, true>(op, bs, ix, n, reps, x, y, d_err, stream);
-        return launch_direct3<W, CPLX, INDEX, true, false>(op, bs, ix, n, reps, x, y, d_err, stream);
+        if (pull) return launch_direct3<W, CPLX, INDEX, true, true>(op, bs, ix, n, reps, x, y, d_err, stream, gx, row_gidx);
+        return launch_direct3<W, CPLX, INDEX, true, false>(op, bs, ix, n, reps, x, y, d_err, stream, gx, row_gidx);
     }
-    if (pull) return launch_direct3<W, CPLX, INDEX, false, true>(op, bs, ix, n, reps, x, y, d_err, stream);
-    return launch_direct3<W, CPLX, INDEX, false, false>(op, bs, ix, n, reps, x, y, d_err, stream);
+    if (pull) return launch_direct3<W, CPLX, INDEX, false, true>(op, bs, ix, n, reps, x, y, d_err, stream, gx, row_gidx);
+    return launch_direct3<W, CPLX, INDEX, false, false>(op, bs, ix, n, reps, x, y, d_err, stream, gx, row_gidx);
 }
 template <bool CPLX, int INDEX>
 static int launch_direct1(lsk_operator op, lsk_basis bs, lsk_index ix, int pull, int64_t n,
-                          uint64_t const *reps, void const *x, void *y, int *d_err, void *stream) {
+                          uint64_t const *reps, void const *x, void *y, int *d_err, void *stream, int gx,
+                          int64_t const *row_gidx) {
     // 32-bit states: every site, and every rank, fits 32 bits (C(32, 16) < 2^31)
     if (bs.number_sites <= 32 && INDEX == LSK_INDEX_COMBINADIC)
-        return launch_direct2<uint32_t, CPLX, INDEX>(op, bs, ix, pull, n, reps, x, y, d_err, stream);
-    return launch_direct2<uint64_t, CPLX, INDEX>(op, bs, ix, pull, n, reps, x, y, d_err, stream);
+        return launch_direct2<uint32_t, CPLX, INDEX>(op, bs, ix, pull, n, reps, x, y, d_err, stream, gx, row_gidx);
+    return launch_direct2<uint64_t, CPLX, INDEX>(op, bs, ix, pull, n, reps, x, y, d_err, stream, gx, row_gidx);
 }
-extern "C" int lsk_direct(lsk_operator op, lsk_basis bs, lsk_index ix, int cplx, int pull, int64_t n,
-                          uint64_t const *reps, void const *x, void *y, int *d_err, void *stream) {
+static int direct_dispatch(lsk_operator op, lsk_basis bs, lsk_index ix, int cplx, int pull, int64_t n,
+                           uint64_t const *reps, void const *x, void *y, int *d_err, void *stream, int gx,
+                           int64_t const *row_gidx) {
     if (n == 0) return 0;
     if (bs.proj == LSK_PROJ_FULL) { snprintf(g_err, sizeof(g_err), "lsk_direct: basis needs projection"); return -1; }
     switch (ix.kind) {
     case LSK_INDEX_IDENTITY:
-        return cplx ? launch_direct1<true, LSK_INDEX_IDENTITY>(op, bs, ix, pull, n, reps, x, y, d_err, stream)
-                    : launch_direct1<false, LSK_INDEX_IDENTITY>(op, bs, ix, pull, n, reps, x, y, d_err, stream);
+        return cplx ? launch_direct1<true, LSK_INDEX_IDENTITY>(op, bs, ix, pull, n, reps, x, y, d_err, stream, gx, row_gidx)
+                    : launch_direct1<false, LSK_INDEX_IDENTITY>(op, bs, ix, pull, n, reps, x, y, d_err, stream, gx, row_gidx);
     case LSK_INDEX_COMBINADIC:
-        return cplx ? launch_direct1<true, LSK_INDEX_COMBINADIC>(op, bs, ix, pull, n, reps, x, y, d_err, stream)
-                    : launch_direct1<false, LSK_INDEX_COMBINADIC>(op, bs, ix, pull, n, reps, x, y, d_err, stream);
+        return cplx ? launch_direct1<true, LSK_INDEX_COMBINADIC>(op, bs, ix, pull, n, reps, x, y, d_err, stream, gx, row_gidx)
+                    : launch_direct1<false, LSK_INDEX_COMBINADIC>(op, bs, ix, pull, n, reps, x, y, d_err, stream, gx, row_gidx);
     default:
-        return cplx ? launch_direct1<true, LSK_INDEX_SEARCH>(op, bs, ix, pull, n, reps, x, y, d_err, stream)
-                    : launch_direct1<false, LSK_INDEX_SEARCH>(op, bs, ix, pull, n, reps, x, y, d_err, stream);
+        return cplx ? launch_direct1<true, LSK_INDEX_SEARCH>(op, bs, ix, pull, n, reps, x, y, d_err, stream, gx, row_gidx)
+                    : launch_direct1<false, LSK_INDEX_SEARCH>(op, bs, ix, pull, n, reps, x, y, d_err, stream, gx, row_gidx);
     }
+}
+extern "C" int lsk_direct(lsk_operator op, lsk_basis bs, lsk_index ix, int cplx, int pull, int64_t n,
+                          uint64_t const *reps, void const *x, void *y, int *d_err, void *stream) {
+    return direct_dispatch(op, bs, ix, cplx, pull, n, reps, x, y, d_err, stream, 0, nullptr);
+}
+// replicated-x pull: `reps` = the n rows of one partition, `x` = whole vector in global order, `ix` = index
+// of the GLOBAL basis, row_gidx[i] = global index of row i (only read for SEARCH indices)
+extern "C" int lsk_direct_gx(lsk_operator op, lsk_basis bs, lsk_index ix, int cplx, int64_t n, uint64_t const *reps,
+                             int64_t const *row_gidx, void const *x_global, void *y, int *d_err, void *stream) {
+    return direct_dispatch(op, bs, ix, cplx, 1, n, reps, x_global, y, d_err, stream, 1, row_gidx);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -821,6 +843,147 @@ extern "C" int lsk_tile(lsk_operator op, lsk_basis bs, lsk_index ix, int cplx, i
     else { if (bs.chars_pm1) LSK_TILE_LAUNCH(uint64_t, true); else LSK_TILE_LAUNCH(uint64_t, false); }
 #undef LSK_TILE_LAUNCH
 #undef LSK_TILE_ARGS
+    LSK_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Staged PULL kernel for symmetry-projected bases (Hermitian operators):
+//   y[r] = d(r) x[r] + sum_j conj(H~[r'_j, r]) x[r'_j],   H~[r', r] = c conj(chi0) n(r') / n(r)
+// Same stage A as k_tile (LDS term list per 256-row tile), stage B projects every packet, looks the
+// representative up in the GLOBAL basis, gathers x there and accumulates into a per-tile LDS copy of
+// y (ds_add_f64) -- no global atomics, y written once.  With one partition "global" == "local"; with
+// one partition per GPU x is the all-gathered vector in global ascending order (replicated-x mode).
+// ---------------------------------------------------------------------------------------------
+template <typename W, bool PM1, bool CPLX, bool REAL>
+__global__ __launch_bounds__(kBlock) void k_tile_pull(lsk_runs runs, int n_groups, lsk_group const *__restrict__ groups,
+                                                      lsk_term const *__restrict__ off, int n_diag,
+                                                      lsk_term const *__restrict__ diag, lsk_basis bs,
+                                                      lsk_group_elem const *__restrict__ elems, lsk_index ixg,
+                                                      int64_t row0, int64_t row1,
+                                                      uint64_t const *__restrict__ reps,
+                                                      double const *__restrict__ norms_local,
+                                                      double const *__restrict__ norms_global,
+                                                      int64_t const *__restrict__ row_gidx,
+                                                      double const *__restrict__ x, double *__restrict__ y, int *err) {
+    __shared__ uint64_t s_beta[kCap];
+    __shared__ double s_coef[kCap * (REAL ? 1 : 2)];
+    __shared__ uint16_t s_row[kCap];
+    __shared__ double s_acc[kBlock * (CPLX ? 2 : 1)];
+    __shared__ int s_n;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    for (int64_t t0 = row0 + (int64_t)blockIdx.x * kBlock; t0 < row1; t0 += (int64_t)gridDim.x * kBlock) {
+        const int64_t i = t0 + tid;
+        const bool valid = i < row1;
+        uint64_t a = 0;
+        double inv_na = 0.0;
+        if (valid) {
+            a = reps[i];
+            double na = norms_local[i];
+            inv_na = na > 0.0 ? 1.0 / na : 0.0;
+        }
+        if (CPLX) { s_acc[2 * tid] = 0.0; s_acc[2 * tid + 1] = 0.0; } else s_acc[tid] = 0.0;
+        for (int g0 = 0; g0 < n_groups; g0 += kGC) {
+            if (tid == 0) s_n = 0;
+            __syncthreads();
+            const int g1 = min(g0 + kGC, n_groups);
+            for (int g = g0; g < g1; ++g) {
+                lsk_group const G = groups[g];
+                double cr = 0.0, ci = 0.0;
+                if (valid) group_coeff<REAL>(G, off, a, cr, ci);
+                const bool act = valid && (cr != 0.0 || (!REAL && ci != 0.0));
+                const unsigned long long ball = __ballot(act);
+                int base = 0;
+                if (lane == 0 && ball) base = atomicAdd(&s_n, __popcll(ball));
+                base = __shfl(base, 0);
+                if (act) {
+                    const int slot = base + __popcll(ball & ((1ULL << lane) - 1));
+                    s_beta[slot] = a ^ G.x;
+                    s_row[slot] = (uint16_t)tid;
+                    // conj(c) / n(alpha)
+                    if (REAL) s_coef[slot] = cr * inv_na;
+                    else { s_coef[2 * slot] = cr * inv_na; s_coef[2 * slot + 1] = -ci * inv_na; }
+                }
+            }
+            __syncthreads();
+            const int n = s_n;
+            for (int e = tid; e < n; e += kBlock) {
+                uint64_t beta = s_beta[e];
+                double hr, hi = 0.0; // conj(H~) so far
+                if (REAL) hr = s_coef[e]; else { hr = s_coef[2 * e]; hi = s_coef[2 * e + 1]; }
+                double nb = -1.0;
+                if (bs.k4_mode != 0) {
+                    beta = (uint64_t)rep_trivial<W>(bs, elems, (W)beta);
+                } else {
+                    W rep; double chr, chi, stab;
+                    state_info_w<W, PM1>(bs, elems, (W)beta, rep, chr, chi, stab);
+                    double n2 = stab * bs.inv_order;
+                    if (!(n2 > 1e-12)) continue; // zero-norm orbit: contributes nothing (DMV:110)
+                    nb = sqrt(n2);
+                    beta = (uint64_t)rep;
+                    // times chi0 = conj(conj(chi0)) = (chr, -chi)
+                    double tr = hr * chr + hi * chi, ti = hi * chr - hr * chi;
+                    hr = tr; hi = ti;
+                }
+                const int64_t idx = search_index(ixg, beta);
+                if (idx < 0) { atomicExch(err, 1); continue; }
+                if (nb < 0.0) nb = norms_global[idx];
+                hr *= nb; hi *= nb;
+                const int r = s_row[e];
+                if (CPLX) {
+                    const double xr = x[2 * idx], xi = x[2 * idx + 1];
+                    atomicAdd(&s_acc[2 * r], hr * xr - hi * xi);
+                    atomicAdd(&s_acc[2 * r + 1], hr * xi + hi * xr);
+                } else {
+                    atomicAdd(&s_acc[r], hr * x[idx]);
+                }
+            }
+            __syncthreads();
+        }
+        if (valid) {
+            const int64_t ig = row_gidx ? row_gidx[i] : i;
+            double dr = 0.0, di = 0.0;
+            if (n_diag > 0) diag_coeff<uint64_t, REAL>(runs, n_diag, diag, a, dr, di);
+            if (CPLX) {
+                const double xr = x[2 * ig], xi = x[2 * ig + 1];
+                double yr = dr * xr - di * xi + s_acc[2 * tid], yi = dr * xi + di * xr + s_acc[2 * tid + 1];
+                if (n_diag == 0) { yr += y[2 * i]; yi += y[2 * i + 1]; } // accumulate, DMV:1062-1063
+                y[2 * i] = yr; y[2 * i + 1] = yi;
+            } else {
+                double yr = dr * x[ig] + s_acc[tid];
+                if (n_diag == 0) yr += y[i];
+                y[i] = yr;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" int lsk_tile_pull(lsk_operator op, lsk_basis bs, lsk_index ix_global, int cplx, int64_t row0, int64_t row1,
+                             uint64_t const *reps, double const *norms_local, double const *norms_global,
+                             int64_t const *row_gidx, void const *x_global, void *y, int *d_err, void *stream) {
+    if (row1 <= row0) return 0;
+    if (ix_global.kind != LSK_INDEX_SEARCH) { snprintf(g_err, sizeof(g_err), "lsk_tile_pull needs a SEARCH index"); return -1; }
+    if (bs.proj != LSK_PROJ_FULL) { snprintf(g_err, sizeof(g_err), "lsk_tile_pull is for projected bases"); return -1; }
+    dim3 g(grid_for(row1 - row0)), b(kBlock);
+    hipStream_t s = (hipStream_t)stream;
+#define LSK_TP_ARGS op.runs, op.n_groups, op.groups, op.off, op.n_diag, op.diag, bs, bs.elems, ix_global, row0, row1, reps, \
+        norms_local, norms_global, row_gidx, (double const *)x_global, (double *)y, d_err
+#define LSK_TP_LAUNCH(W, PM1)                                                                                   \
+    do {                                                                                                        \
+        if (cplx) {                                                                                             \
+            if (op.is_real) hipLaunchKernelGGL((k_tile_pull<W, PM1, true, true>), g, b, 0, s, LSK_TP_ARGS);     \
+            else hipLaunchKernelGGL((k_tile_pull<W, PM1, true, false>), g, b, 0, s, LSK_TP_ARGS);               \
+        } else {                                                                                                \
+            if (op.is_real) hipLaunchKernelGGL((k_tile_pull<W, PM1, false, true>), g, b, 0, s, LSK_TP_ARGS);    \
+            else hipLaunchKernelGGL((k_tile_pull<W, PM1, false, false>), g, b, 0, s, LSK_TP_ARGS);              \
+        }                                                                                                       \
+    } while (0)
+    if (bs.number_sites <= 32) { if (bs.chars_pm1) LSK_TP_LAUNCH(uint32_t, true); else LSK_TP_LAUNCH(uint32_t, false); }
+    else { if (bs.chars_pm1) LSK_TP_LAUNCH(uint64_t, true); else LSK_TP_LAUNCH(uint64_t, false); }
+#undef LSK_TP_LAUNCH
+#undef LSK_TP_ARGS
     LSK_LAUNCH_CHECK();
     return 0;
 }

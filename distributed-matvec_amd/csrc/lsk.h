@@ -137,6 +137,15 @@ int lsk_tile(lsk_operator op, lsk_basis bs, lsk_index ix, int cplx, int count_on
              int64_t row0, int64_t row1, uint64_t const *reps, double const *norms, void const *x,
              void *y, unsigned long long *d_cursors, lsk_round_layout const *d_layout, void *d_send,
              unsigned long long *d_counts, int *d_err, void *stream);
+/* replicated-x pull (Hermitian operators): rows of ONE partition against the whole vector in global
+ * ascending order.  ix_global indexes the global basis; row_gidx[i] = global index of local row i
+ * (may be NULL for lsk_direct_gx with closed-form indices, and for lsk_tile_pull when local == global). */
+int lsk_direct_gx(lsk_operator op, lsk_basis bs, lsk_index ix_global, int cplx, int64_t n,
+                  uint64_t const *reps, int64_t const *row_gidx, void const *x_global, void *y, int *d_err,
+                  void *stream);
+int lsk_tile_pull(lsk_operator op, lsk_basis bs, lsk_index ix_global, int cplx, int64_t row0, int64_t row1,
+                  uint64_t const *reps, double const *norms_local, double const *norms_global,
+                  int64_t const *row_gidx, void const *x_global, void *y, int *d_err, void *stream);
 /* n packets -> y[idx(beta)] += value */
 int lsk_scatter(lsk_index ix, int cplx, int64_t n, uint64_t const *betas, void const *vals, void *y,
                 double const *norms /* NULL, or per-row norms multiplied in (K4 modes 1, 2) */, int *d_err,

@@ -101,23 +101,40 @@ class DistributedOperator:
         self.exchange_bytes_per_matvec = sum(sum(c) for c in self.send_counts) * pb
 
     def matvec(self, x, y, check: bool = False):
-        """y <- H x for this rank's blocks of the hashed vectors."""
+        """y <- H x for this rank's blocks of the hashed vectors.
+
+        Software pipeline, depth 2: exchange(r + 1) is issued (async) right after generate(r + 1) and
+        before scatter(r), so the all-to-all of one round overlaps the scatter of the previous and the
+        generate of the next one; send/recv buffers alternate between two slots."""
         dist, pb = self.dist, self.packet_bytes
         eng = self.engine
+        R = self.num_rounds
         eng.diag(x, y)  # localDiagonal first: y is assigned (DMV:1062-1063)
-        for r in range(self.num_rounds):
+
+        def exchange(r):
             send, recv = self.send_bufs[r & 1], self.recv_bufs[r & 1]
-            eng.generate(r, x, y, send)
             in_splits = [c * pb for c in self.send_counts[r]]
             out_splits = [c * pb for c in self.recv_counts[r]]
             n_in, n_out = sum(in_splits), sum(out_splits)
-            dist.all_to_all_single(recv[:n_out], send[:n_in], out_splits, in_splits, group=self.group)
+            return dist.all_to_all_single(recv[:max(n_out, 0)], send[:max(n_in, 0)], out_splits, in_splits,
+                                          group=self.group, async_op=True)
+
+        eng.generate(0, x, y, self.send_bufs[0])
+        work = exchange(0)
+        for r in range(R):
+            nxt = None
+            if r + 1 < R:
+                eng.generate(r + 1, x, y, self.send_bufs[(r + 1) & 1])
+                nxt = exchange(r + 1)
+            work.wait()
+            recv = self.recv_bufs[r & 1]
             off = 0
             for s in range(self.P):
                 n = self.recv_counts[r][s]
                 if n:
                     eng.scatter(recv, off, n, y)
                 off += n * pb
+            work = nxt
         if check:
             eng.check()
 

@@ -73,7 +73,8 @@ int ls_amd_plan_create(ls_amd_plan **plan, ls_hs_operator const *op, ls_amd_dtyp
 void ls_amd_plan_destroy(ls_amd_plan *plan);
 
 int ls_amd_plan_num_rounds(ls_amd_plan const *plan);
-/* which kernel family the plan selected: "direct-push", "direct-pull", "tile" */
+/* which kernel family the plan selected: "direct-push", "direct-pull", "tile", "tile-pull",
+ * "replicated-direct-pull", "replicated-tile-pull" */
 char const *ls_amd_plan_kernel_name(ls_amd_plan const *plan);
 /* number of (beta, value) packets partition `my_partition` sends to every destination in `round`
  * (counts[P]; the own slot is 0 because local contributions are scattered in place) */
@@ -90,6 +91,19 @@ int64_t ls_amd_plan_nnz(ls_amd_plan const *plan);
  * "invalid index" condition the reference halts on (DMV:115-118). */
 int ls_amd_matvec(ls_amd_plan *plan, void const *const *d_x, void *const *d_y, void *stream);
 int ls_amd_plan_check(ls_amd_plan *plan, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Replicated-x plans (Hermitian operators, one partition per process).  Instead of exchanging
+ * (sigma_j, c_j x_i) packets, every rank holds the whole x in global ascending ("block") order --
+ * the caller all-gathers it, nnz / N ~ 16 times fewer bytes than the packets -- and computes y for
+ * its own rows by the pull formulation  y_r = d x_r + sum conj(c) x[idx_global(beta)].
+ * d_reps_global: all representatives, ascending (borrowed, like d_reps_local).
+ * ------------------------------------------------------------------------------------------ */
+int ls_amd_plan_create_replicated(ls_amd_plan **plan, ls_hs_operator const *op, ls_amd_dtype dtype,
+                                  int num_partitions, int my_partition, uint64_t const *d_reps_local,
+                                  int64_t count_local, uint64_t const *d_reps_global,
+                                  int64_t count_global, void *stream);
+int ls_amd_matvec_replicated(ls_amd_plan *plan, void const *d_x_global, void *d_y_local, void *stream);
 
 /* Kernel timing with HIP events recorded on the launch stream, around every launch of the plan's
  * dominant kernel (direct-push/direct-pull: the fused row kernel; tile: the staged kernel).

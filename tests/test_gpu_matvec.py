@@ -81,10 +81,11 @@ def test_single_locale_matvec_f64(torch, name, mode):
     want_reps = oracle_reps(name)
     x = np.random.RandomState(42).rand(len(want_reps)) - 0.5
     want = oracle_for(name).local_matvec(want_reps, x)
-    if mode == "pull" and basis.hasPermutationSymmetries():
-        pytest.skip("pull mode is a direct-kernel mode (no permutation symmetries)")
     got, pl = run_matvec(torch, D, h, reps, masks, x, 1, mode)
-    assert pl.kernel == ("tile" if basis.hasPermutationSymmetries() else f"direct-{mode}")
+    if basis.hasPermutationSymmetries():
+        assert pl.kernel == ("tile" if mode == "push" else "tile-pull")
+    else:
+        assert pl.kernel == f"direct-{mode}"
     assert_close(got, want, name)
 
 
@@ -96,8 +97,6 @@ def test_single_locale_matvec_c128(torch, name):
     x = (rs.rand(len(want_reps)) - 0.5) + 1j * (rs.rand(len(want_reps)) - 0.5)
     want = oracle_for(name).local_matvec(want_reps, x)
     for mode in ("push", "pull"):
-        if mode == "pull" and basis.hasPermutationSymmetries():
-            continue
         got, _ = run_matvec(torch, D, h, reps, masks, x, 1, mode)
         assert np.abs(got - want).max() <= 1e-10 * max(1.0, np.abs(want).max()), (name, mode)  # north-star tolerance
         assert_close(got.real, want.real, name)
@@ -456,3 +455,30 @@ def test_general_k4_path_on_trivial_sector(torch, monkeypatch):
             D_, basis, h, reps, masks = setup_model(torch, model_config(name), P)
             got, pl = run_matvec(torch, D_, h, reps, masks, x, P)
             assert_close(got, want, f"{name} general={general} P={P}")
+
+
+@pytest.mark.parametrize("name", CHECK_MODELS)
+@pytest.mark.parametrize("P", [2, 3, 8])
+def test_replicated_x_mode(torch, name, P):
+    """one partition per process with the whole x replicated (all-gather instead of packets): every
+    "rank" is emulated in turn on the one device; f64 and c128."""
+    D, basis, h, reps, masks = setup_model(torch, model_config(name), P)
+    want_reps = oracle_reps(name)
+    reps_global = D.arrFromHashedToBlock(reps, masks)
+    assert np.array_equal(reps_global.cpu().numpy().view(np.uint64), want_reps)
+    rs = np.random.RandomState(60)
+    for cplx in (False, True):
+        x = rs.rand(len(want_reps)) - 0.5
+        if cplx:
+            x = x + 1j * (rs.rand(len(want_reps)) - 0.5)
+        want = oracle_for(name).local_matvec(want_reps, x)
+        xg = torch.from_numpy(x).cuda()
+        ys = []
+        for p in range(P):
+            pl = D.ReplicatedPlan(h, reps[p], reps_global, xg.dtype, P, p)
+            assert pl.kernel.startswith("replicated-")
+            y = torch.full((reps[p].numel(),), 3.0, dtype=xg.dtype, device="cuda")
+            pl.matvec(xg, y)
+            ys.append(y)
+        got = D.arrFromHashedToBlock(ys, masks).cpu().numpy()
+        assert np.abs(got - want).max() <= 1e-12 * max(1.0, np.abs(want).max()), (name, P, cplx)
