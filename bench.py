@@ -72,6 +72,10 @@ def main():
     ap.add_argument("--model", default="heisenberg_chain_32")
     ap.add_argument("--dtype", default="f64", choices=["f64", "c128"])
     ap.add_argument("--mode", default=os.environ.get("LS_AMD_MODE", "auto"), choices=["auto", "push", "pull"])
+    ap.add_argument("--exchange", default="auto", choices=["auto", "packets", "replicated"],
+                    help="N > 1: all-to-all-v of packets (reference formulation) or all-gather of x + pull")
+    ap.add_argument("--force-distributed", action="store_true",
+                    help="run the N > 1 code path (process group, exchange) even with one rank (test hook)")
     ap.add_argument("--cpu-sample", type=int, default=28, help="chain length of the CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary (other dtype / other mode) measurements")
@@ -90,9 +94,14 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    distributed = world > 1 or args.force_distributed
+    if distributed:
         import torch.distributed as dist
 
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29512")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     L, symm = parse_model(args.model)
@@ -110,13 +119,16 @@ def main():
     t_setup = time.perf_counter()
     reps_parts, masks = D.enumerateStates(basis, world)
     n_total = int(masks.numel())
-    my_reps = reps_parts[rank].clone() if world > 1 else reps_parts[0]
-    del reps_parts, masks
+    if distributed:
+        my_reps = reps_parts[rank].clone()
+        reps_global = D.arrFromHashedToBlock(reps_parts, masks) if world > 1 else reps_parts[0]
+    else:
+        my_reps = reps_parts[0]
+        reps_global = None
+    del reps_parts
     torch.cuda.empty_cache()
     x = D.fillRandom(my_reps, 42, tdtype)
     y = torch.zeros_like(x)
-
-    results = {}
 
     def time_steps(run, steps, warmup):
         for _ in range(warmup):
@@ -133,56 +145,78 @@ def main():
             dt = float(t.item())
         return dt
 
-    nnz = chain_nnz(L, n_total) if not symm else None
-    kernel_ms = None
-    if world == 1:
-        plan = D.MatvecPlan(h, [my_reps], tdtype, mode=args.mode)
-        plan.enable_timing(4096)
-        setup_s = time.perf_counter() - t_setup
-
-        def run():
-            plan.matvec([x], [y], check=False)
-
-        for _ in range(args.warmup):
-            run()
-        plan.check()
-        plan.kernel_times_ms()  # drop warm-up samples
-        dt = time_steps(run, args.steps, 0)
-        plan.check()
-        samples = plan.kernel_times_ms()
-        launches_per_step = max(1, len(samples) // max(1, args.steps))
-        kernel_ms = sum(samples) / max(1, len(samples))  # average duration of ONE launch
-        kernel_name = plan.kernel
-        if symm:
-            nnz = plan.nnz
-        exchange_bytes = 0
-    else:
-        from distributed_matvec_amd.distributed import DistributedOperator
-
-        op = DistributedOperator(h, my_reps, tdtype)
-        op.engine.plan.enable_timing(4096)
-        setup_s = time.perf_counter() - t_setup
-
-        def run():
-            op.matvec(x, y, check=False)
-
-        for _ in range(args.warmup):
-            run()
-        op.engine.check()
-        op.engine.plan.kernel_times_ms()
-        dt = time_steps(run, args.steps, 0)
-        op.engine.check()
-        samples = op.engine.plan.kernel_times_ms()
-        launches_per_step = max(1, len(samples) // max(1, args.steps))
-        kernel_ms = sum(samples) / max(1, len(samples))
-        kernel_name = "tile"
-        t = torch.tensor([op.exchange_bytes_per_matvec], dtype=torch.float64, device="cuda")
+    def allsum(v):
+        if dist is None:
+            return v
+        t = torch.tensor([float(v)], dtype=torch.float64, device="cuda")
         dist.all_reduce(t)
-        exchange_bytes = float(t.item())
-        if symm:
-            t = torch.tensor([op.engine.plan.nnz], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t)
-            nnz = int(t.item())
+        return float(t.item())
+
+    nnz = chain_nnz(L, n_total) if not symm else None
+    extra = {}
+
+    def measure(make_op, steps, warmup, label):
+        """returns (dt, kernel_ms, launches_per_step, kernel_name, exchange_bytes, plan)"""
+        op = make_op()
+        plan = op if isinstance(op, D.MatvecPlan) else op.engine.plan
+        plan.enable_timing(8192)
+        if isinstance(op, D.MatvecPlan):
+            run = lambda: op.matvec([x], [y], check=False)  # noqa: E731
+        else:
+            run = lambda: op.matvec(x, y, check=False)  # noqa: E731
+        for _ in range(warmup):
+            run()
+        plan.check()
+        plan.kernel_times_ms(8192)  # drop warm-up samples
+        dt = time_steps(run, steps, 0)
+        plan.check()
+        samples = plan.kernel_times_ms(8192)
+        lps = max(1, len(samples) // max(1, steps))
+        kms = sum(samples) / max(1, len(samples))  # average duration of ONE launch of the dominant kernel
+        xb = allsum(getattr(op, "exchange_bytes_per_matvec", 0))
+        return dt, kms, lps, plan.kernel, xb, plan, op
+
+    if not distributed:
+        make = lambda: D.MatvecPlan(h, [my_reps], tdtype, mode=args.mode)  # noqa: E731
+        exchange = "none"
+    else:
+        from distributed_matvec_amd.distributed import DistributedOperator, ReplicatedOperator
+
+        exchange = args.exchange
+        if exchange == "auto":
+            exchange = "replicated" if h.isHermitian else "packets"
+        if exchange == "replicated":
+            make = lambda: ReplicatedOperator(h, my_reps, reps_global, masks, tdtype)  # noqa: E731
+        else:
+            make = lambda: DistributedOperator(h, my_reps, tdtype)  # noqa: E731
+    setup_t0 = time.perf_counter()
+    dt, kernel_ms, launches_per_step, kernel_name, exchange_bytes, plan, op_obj = measure(make, args.steps, args.warmup, "main")
+    setup_s = (setup_t0 - t_setup)
+    if symm:
+        # non-zeros of the projected matrix: the packet count of a push plan's count pass
+        pp = D.MatvecPlan(h, [my_reps], tdtype, mode="push") if not distributed else None
+        nnz = int(allsum(pp.nnz)) if pp is not None else None
+        if pp is not None:
+            pp.destroy()
+        if nnz is None:
+            from distributed_matvec_amd.distributed import DistributedOperator
+
+            dop = DistributedOperator(h, my_reps, tdtype)
+            nnz = int(allsum(dop.engine.plan.nnz))
+            del dop
+    if distributed and not args.no_extra and h.isHermitian:
+        # the other exchange strategy, fewer steps
+        from distributed_matvec_amd.distributed import DistributedOperator, ReplicatedOperator
+
+        other = "packets" if exchange == "replicated" else "replicated"
+        del op_obj, plan
+        torch.cuda.empty_cache()
+        mk = (lambda: DistributedOperator(h, my_reps, tdtype)) if other == "packets" else (lambda: ReplicatedOperator(h, my_reps, reps_global, masks, tdtype))
+        dt2, kms2, lps2, kn2, xb2, plan2, op2 = measure(mk, max(2, args.steps // 4), 1, other)
+        s2 = max(2, args.steps // 4)
+        extra[f"exchange={other}"] = {"matvecs_per_s": s2 / dt2, "ms_per_step": 1e3 * dt2 / s2, "kernel": kn2,
+                                      "exchange_bytes_per_matvec": xb2}
+        del op2, plan2
 
     ms_per_step = 1e3 * dt / args.steps
     value = args.steps / dt
@@ -195,6 +229,10 @@ def main():
     nnz_here = nnz * rows_here // max(1, n_total)
     if kernel_name == "direct-push":
         bytes_per_launch = rows_here * (8 + w) + nnz_here * 2 * w  # diagonal pass (y write) is a separate kernel
+    elif kernel_name == "tile":
+        # the staged push kernel: term generation + local scatter; remote packets are written (8 + w) and
+        # scattered by k_scatter (not counted here)
+        bytes_per_launch = (rows_here * (8 + w) + nnz_here * 2 * w) / launches_per_step
     else:
         bytes_per_launch = (rows_here * (8 + 2 * w) + nnz_here * 2 * w) / launches_per_step
     achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms else None
@@ -207,19 +245,18 @@ def main():
         "whole_matvec_frac_of_Nx_peak": b_alg / (dt / args.steps) / 1e9 / (HBM_PEAK_GBPS * world),
     }
 
-    extra = {}
-    if world == 1 and not args.no_extra:
+    if not distributed and not args.no_extra and not symm:
         # secondary numbers in the same run: the other scatter/gather mode and the other dtype
-        for label, dt2, mode2 in (("f64" if args.dtype == "c128" else "c128", None, args.mode),
-                                  (args.dtype, None, "pull" if kernel_name == "direct-push" else "push")):
+        for label, mode2 in (("f64" if args.dtype == "c128" else "c128", args.mode),
+                             (args.dtype, "pull" if kernel_name == "direct-push" else "push")):
             try:
                 td = torch.float64 if label == "f64" else torch.complex128
                 x2 = D.fillRandom(my_reps, 42, td)
                 y2 = torch.zeros_like(x2)
                 p2 = D.MatvecPlan(h, [my_reps], td, mode=mode2)
-                t2 = time_steps(lambda: p2.matvec([x2], [y2], check=False), max(3, args.steps // 2), 2)
-                p2.check()
                 steps2 = max(3, args.steps // 2)
+                t2 = time_steps(lambda: p2.matvec([x2], [y2], check=False), steps2, 2)
+                p2.check()
                 w2 = 8 if label == "f64" else 16
                 extra[f"{label}/{p2.kernel}"] = {
                     "matvecs_per_s": steps2 / t2,
@@ -231,7 +268,7 @@ def main():
                 extra[f"{label}/{mode2}"] = {"error": str(e)}
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not distributed and not args.no_cpu_baseline:
         s = cpu_baseline(min(args.cpu_sample, L))
         # scale the measured per-non-zero cost of the sample to the benchmark workload
         per_nnz = s["seconds_per_matvec"] / s["nnz"]
@@ -255,6 +292,7 @@ def main():
                             f"{args.dtype} vectors, sigma/x/y resident in HBM",
                 "model_yaml": f"data/{args.model}.yaml (regenerated: periodic ring, sigma.sigma per bond)",
                 "partitions": world, "partitioning": "hash64_01(sigma) % n_gpus" if world > 1 else "single",
+                "exchange": exchange,
                 "kernel": kernel_name, "x": "u(hash(sigma, 42)) - 0.5",
                 "exchange_bytes_per_matvec": exchange_bytes,
             },

@@ -978,7 +978,7 @@ static int plan_setup_part(ls_amd_plan *pl, part_state *ps, int part_id, int num
     ps->index.shift = 0;
     ps->index.kind = LSK_INDEX_SEARCH;
     int closed_form = 0;
-    if (pl->P == 1 && pl->dbs.proj != LSK_PROJ_FULL) {
+    if (pl->P == 1 && pl->dbs.proj != LSK_PROJ_FULL && pl->family != FAMILY_TILE) {
         int const Leff = L - (b->spin_inversion != 0 ? 1 : 0);
         if (h < 0) {
             if (Leff < 63 && ps->count == ((int64_t)1 << Leff)) { ps->index.kind = LSK_INDEX_IDENTITY; closed_form = 1; }
@@ -1076,7 +1076,9 @@ int ls_amd_plan_create(ls_amd_plan **out, ls_hs_operator const *op, ls_amd_dtype
             if (op->basis->ext->elems[g].ch_im != 0.0) { free(pl); return set_error("complex characters need dtype c128"); }
     }
     /* kernel family */
-    if (num_partitions == 1 && pl->dbs.proj != LSK_PROJ_FULL) {
+    int const force_tile = getenv("LS_AMD_FORCE_TILE") != NULL; /* test hook: packets path with P == 1 */
+    if (force_tile) pl->family = FAMILY_TILE;
+    else if (num_partitions == 1 && pl->dbs.proj != LSK_PROJ_FULL) {
         ls_amd_mode m = mode;
         if (m == LS_AMD_MODE_AUTO) {
             char const *e = getenv("LS_AMD_MODE");

@@ -1,4 +1,10 @@
-"""One process per GPU: hash-partitioned y <- H x with an all-to-all-v of (sigma_j, c_j x_i) packets.
+"""One process per GPU: hash-partitioned y <- H x.
+
+Two exchange strategies (both keep x, y and the representatives hash-partitioned at the interface):
+  * DistributedOperator  -- all-to-all-v of (sigma_j, c_j x_i) packets, the reference's formulation;
+  * ReplicatedOperator   -- Hermitian operators: all-gather x (N w bytes instead of nnz (8 + w) bytes,
+                            ~ 30x fewer on the chains) and pull locally with no atomics.
+
 
 Replaces the reference's locale-to-locale machinery
 (/root/reference/src/DistributedMatrixVector.chpl:313-853: _LocalBuffer/_RemoteBuffer mailboxes,
@@ -159,3 +165,84 @@ class DistributedOperator:
             self.global_sum(parts)
             return torch.view_as_complex(parts)[0]
         return self.global_sum(local)[0]
+
+
+class HipReplicatedEngine:
+    """ls_amd replicated-x plan for this rank (include/ls_amd.h)."""
+
+    def __init__(self, matrix, reps_local, reps_global, dtype, num_partitions, my_partition):
+        from .api import ReplicatedPlan
+
+        self.plan = ReplicatedPlan(matrix, reps_local, reps_global, dtype, num_partitions, my_partition)
+
+    def matvec(self, x_global, y_local):
+        self.plan.matvec(x_global, y_local, check=False)
+
+    def check(self):
+        self.plan.check()
+
+
+class ReplicatedOperator:
+    """matrixVectorProduct with one locale per process, exchanging x instead of packets.
+
+    Per matvec: (1) every rank sends its block of x to every other rank directly (grouped
+    send/recv = all_to_all over all xGMI links at once, not a ring), (2) one gather pass puts the
+    blocks into global ascending order with a permutation built once from `masks`
+    (arrFromHashedToBlock semantics, /root/reference/src/HashedToBlock.chpl:67-153), (3) the pull
+    kernel computes this rank's rows.  Needs a Hermitian operator and N * w bytes of HBM per rank."""
+
+    def __init__(self, matrix, reps_local, reps_global, masks, dtype, group=None, engine_factory=None):
+        import torch
+        import torch.distributed as dist
+
+        self.torch, self.dist, self.group = torch, dist, group
+        self.rank = dist.get_rank(group)
+        self.P = dist.get_world_size(group)
+        self.dtype = dtype
+        dev = reps_local.device
+        n = int(masks.numel())
+        counts = torch.bincount(masks.to(torch.int64), minlength=self.P).tolist()
+        assert counts[self.rank] == int(reps_local.numel()), "masks do not describe this rank's block"
+        self.counts = counts
+        self.max_count = max(counts)
+        # perm[i] = position of global state i inside the [P, max_count] gathered buffer
+        m64 = masks.to(torch.int64)
+        perm = torch.empty(n, dtype=torch.int64, device=dev)
+        for p in range(self.P):
+            sel = (m64 == p).nonzero(as_tuple=True)[0]
+            perm[sel] = p * self.max_count + torch.arange(sel.numel(), device=dev, dtype=torch.int64)
+        self.perm = perm.to(torch.int32) if self.P * self.max_count < 2**31 else perm
+        del m64
+        self.gathered = torch.empty(self.P * self.max_count, dtype=dtype, device=dev)
+        self.x_global = torch.empty(n, dtype=dtype, device=dev)
+        factory = engine_factory or HipReplicatedEngine
+        self.engine = factory(matrix, reps_local, reps_global, dtype, self.P, self.rank)
+        self.exchange_bytes_per_matvec = (n - counts[self.rank]) * self.x_global.element_size()
+
+    def gather_x(self, x_local):
+        """all ranks' blocks -> self.x_global (global ascending order)."""
+        torch, dist = self.torch, self.dist
+        P, mc = self.P, self.max_count
+        outs = [self.gathered[p * mc:p * mc + self.counts[p]] for p in range(P)]
+        outs[self.rank].copy_(x_local)
+        if P > 1:
+            # every block goes straight to every peer: one grouped send/recv (RCCL uses all xGMI links
+            # at once; an all_gather would be a ring)
+            ops = []
+            for step in range(1, P):
+                dst, src = (self.rank + step) % P, (self.rank - step) % P
+                ops.append(dist.P2POp(dist.isend, x_local, dst, self.group))
+                ops.append(dist.P2POp(dist.irecv, outs[src], src, self.group))
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        torch.index_select(self.gathered, 0, self.perm, out=self.x_global)
+        return self.x_global
+
+    def matvec(self, x, y, check: bool = False):
+        self.engine.matvec(self.gather_x(x), y)
+        if check:
+            self.engine.check()
+
+    global_sum = DistributedOperator.global_sum
+    broadcast = DistributedOperator.broadcast
+    dot = DistributedOperator.dot

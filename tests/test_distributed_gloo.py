@@ -162,3 +162,73 @@ def test_all_to_all_exchange(tmp_path, name, world, cplx, rounds):
     parts = [np.load(os.path.join(str(tmp_path), f"y{r}.npy")) for r in range(world)]
     got = CO.hashed_to_block(parts, keys)
     assert np.abs(got - want).max() <= 1e-12 * max(1.0, np.abs(want).max())
+
+
+class OracleReplicatedEngine:
+    """CPU stand-in for HipReplicatedEngine (TEST ONLY): oracle arithmetic on this rank's rows."""
+
+    def __init__(self, matrix, reps_local, reps_global, dtype, num_partitions, my_partition):
+        self.o = matrix
+        self.reps_global = np.ascontiguousarray(reps_global.numpy().view(np.uint64))
+        self.reps_local = np.ascontiguousarray(reps_local.numpy().view(np.uint64))
+        from oracle import c_oracle as CO
+
+        self.rows = CO.state_index(self.reps_global, self.reps_local)
+
+    def matvec(self, x_global, y_local):
+        full = self.o.local_matvec(self.reps_global, x_global.numpy().copy())
+        y_local.copy_(torch.from_numpy(full[self.rows]))
+
+    def check(self):
+        pass
+
+
+def _worker_replicated(rank, world, port, name, cplx, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import model_config
+    from oracle import c_oracle as CO
+    from oracle import model as M
+
+    from distributed_matvec_amd.distributed import ReplicatedOperator
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        o = CO.COracle(M.model_from_config(model_config(name)))
+        reps = o.enumerate()
+        rs = np.random.RandomState(6)
+        x = rs.rand(len(reps)) - 0.5
+        if cplx:
+            x = x + 1j * (rs.rand(len(reps)) - 0.5)
+        keys = CO.locale_idx_of(reps, world)
+        mine = keys == rank
+        op = ReplicatedOperator(o, torch.from_numpy(reps[mine].view(np.int64).copy()), torch.from_numpy(reps.view(np.int64).copy()),
+                                torch.from_numpy(keys.copy()), torch.complex128 if cplx else torch.float64,
+                                engine_factory=OracleReplicatedEngine)
+        my_x = torch.from_numpy(x[mine].copy())
+        xg = op.gather_x(my_x)
+        assert np.array_equal(xg.numpy(), x)  # hashed blocks -> global ascending order, bit-exact
+        my_y = torch.zeros_like(my_x)
+        op.matvec(my_x, my_y, check=True)
+        np.save(os.path.join(out_dir, f"y{rank}.npy"), my_y.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,world,cplx", [("heisenberg_chain_12", 2, False), ("heisenberg_kagome_12_symm", 3, True)])
+def test_replicated_x_exchange(tmp_path, name, world, cplx):
+    sys.path.insert(0, ROOT)
+    from helpers import oracle_for, oracle_reps
+    from oracle import c_oracle as CO
+
+    port = 29900 + (os.getpid() % 90) + world
+    mp.spawn(_worker_replicated, args=(world, port, name, cplx, str(tmp_path)), nprocs=world, join=True)
+    reps = oracle_reps(name)
+    rs = np.random.RandomState(6)
+    x = rs.rand(len(reps)) - 0.5
+    if cplx:
+        x = x + 1j * (rs.rand(len(reps)) - 0.5)
+    want = oracle_for(name).local_matvec(reps, x)
+    keys = CO.locale_idx_of(reps, world)
+    got = CO.hashed_to_block([np.load(os.path.join(str(tmp_path), f"y{r}.npy")) for r in range(world)], keys)
+    assert np.abs(got - want).max() <= 1e-12 * max(1.0, np.abs(want).max())
