@@ -84,6 +84,38 @@ extern "C" int lsk_event_elapsed_ms(void *start, void *stop, float *ms) {
 constexpr int kBlock = 256;
 constexpr int kMaxGrid = 256 * 8; // 256 CUs x 8 resident blocks: grid-stride beyond this
 
+// Persistent (grid-stride) launches must not exceed what is co-resident, or the surplus blocks run as a
+// second, mostly idle wave (measured: +33 % on the row kernel when 7 instead of 8 blocks fit per CU).
+// resident_grid() asks the runtime once per kernel; note that on ROCm 7.2 the answer is one block per
+// CU too high for 256-thread kernels with 81..96 SGPRs (MI355X_MICROARCH.md), so the hot kernels are
+// kept at <= 80 SGPRs (asserted in tests/test_host_tables.py::test_hot_kernel_register_budget).
+#include <map>
+static int g_num_cus = 0;
+template <typename K>
+static int resident_grid(K kernel, int64_t work_blocks, size_t dyn_lds = 0) {
+    static std::map<void const *, int> cache;
+    if (g_num_cus == 0) {
+        hipDeviceProp_t prop;
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) g_num_cus = prop.multiProcessorCount;
+        if (g_num_cus <= 0) g_num_cus = 256;
+    }
+    void const *key = (void const *)kernel;
+    auto it = cache.find(key);
+    int per_cu;
+    if (it == cache.end()) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, kBlock, dyn_lds) != hipSuccess || nb < 1) nb = 1;
+        if (nb > 8) nb = 8;
+        cache[key] = nb;
+        per_cu = nb;
+    } else per_cu = it->second;
+    int64_t g = (int64_t)g_num_cus * per_cu;
+    if (work_blocks < g) g = work_blocks;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
 static inline int grid_for(int64_t n, int per_block = kBlock) {
     int64_t b = (n + per_block - 1) / per_block;
     if (b < 1) b = 1;
@@ -608,7 +640,11 @@ static int launch_direct3(lsk_operator op, lsk_basis bs, lsk_index ix, int64_t n
     int64_t tiles = (n + kBlock - 1) / kBlock;
     int64_t tiles_per_xcd = (tiles + 7) / 8;
     int64_t gb = tiles_per_xcd * 8;
-    if (gb > kMaxGrid) gb = kMaxGrid;
+    int64_t cap = op.is_real ? resident_grid(k_direct<W, CPLX, INDEX, INV, PULL, true>, gb)
+                             : resident_grid(k_direct<W, CPLX, INDEX, INV, PULL, false>, gb);
+    cap &= ~(int64_t)7; // XCD dealing needs a multiple of 8
+    if (cap < 8) cap = 8;
+    if (gb > cap) gb = cap;
     dim3 g((unsigned)gb), b(kBlock);
     if (op.is_real)
         hipLaunchKernelGGL((k_direct<W, CPLX, INDEX, INV, PULL, true>), g, b, 0, (hipStream_t)stream, op.runs,
@@ -824,18 +860,19 @@ extern "C" int lsk_tile(lsk_operator op, lsk_basis bs, lsk_index ix, int cplx, i
     if (P > LSK_MAX_PARTS || P < 1) { snprintf(g_err, sizeof(g_err), "lsk_tile: bad partition count %d", P); return -1; }
     if (!count_only && ix.kind != LSK_INDEX_SEARCH) { snprintf(g_err, sizeof(g_err), "lsk_tile needs a SEARCH index"); return -1; }
     Owner ow = make_owner(P);
-    dim3 g(grid_for(row1 - row0)), b(kBlock);
+    dim3 g(1), b(kBlock);
+    const int64_t work_blocks = (row1 - row0 + kBlock - 1) / kBlock;
     hipStream_t s = (hipStream_t)stream;
 #define LSK_TILE_ARGS op.n_groups, op.groups, op.off, bs, bs.elems, ix, count_only, ow, me, row0, row1, reps, norms, \
         (double const *)x, (double *)y, d_cursors, d_layout, (char *)d_send, d_counts, d_err
 #define LSK_TILE_LAUNCH(W, PM1)                                                                            \
     do {                                                                                                   \
         if (cplx) {                                                                                        \
-            if (op.is_real) hipLaunchKernelGGL((k_tile<W, PM1, true, true>), g, b, 0, s, LSK_TILE_ARGS);   \
-            else hipLaunchKernelGGL((k_tile<W, PM1, true, false>), g, b, 0, s, LSK_TILE_ARGS);             \
+            if (op.is_real) { g.x = resident_grid(k_tile<W, PM1, true, true>, work_blocks); hipLaunchKernelGGL((k_tile<W, PM1, true, true>), g, b, 0, s, LSK_TILE_ARGS); } \
+            else { g.x = resident_grid(k_tile<W, PM1, true, false>, work_blocks); hipLaunchKernelGGL((k_tile<W, PM1, true, false>), g, b, 0, s, LSK_TILE_ARGS); } \
         } else {                                                                                           \
-            if (op.is_real) hipLaunchKernelGGL((k_tile<W, PM1, false, true>), g, b, 0, s, LSK_TILE_ARGS);  \
-            else hipLaunchKernelGGL((k_tile<W, PM1, false, false>), g, b, 0, s, LSK_TILE_ARGS);            \
+            if (op.is_real) { g.x = resident_grid(k_tile<W, PM1, false, true>, work_blocks); hipLaunchKernelGGL((k_tile<W, PM1, false, true>), g, b, 0, s, LSK_TILE_ARGS); } \
+            else { g.x = resident_grid(k_tile<W, PM1, false, false>, work_blocks); hipLaunchKernelGGL((k_tile<W, PM1, false, false>), g, b, 0, s, LSK_TILE_ARGS); } \
         }                                                                                                  \
     } while (0)
     const bool narrow = bs.number_sites <= 32 && bs.proj == LSK_PROJ_FULL;
@@ -966,18 +1003,19 @@ extern "C" int lsk_tile_pull(lsk_operator op, lsk_basis bs, lsk_index ix_global,
     if (row1 <= row0) return 0;
     if (ix_global.kind != LSK_INDEX_SEARCH) { snprintf(g_err, sizeof(g_err), "lsk_tile_pull needs a SEARCH index"); return -1; }
     if (bs.proj != LSK_PROJ_FULL) { snprintf(g_err, sizeof(g_err), "lsk_tile_pull is for projected bases"); return -1; }
-    dim3 g(grid_for(row1 - row0)), b(kBlock);
+    dim3 g(1), b(kBlock);
+    const int64_t work_blocks = (row1 - row0 + kBlock - 1) / kBlock;
     hipStream_t s = (hipStream_t)stream;
 #define LSK_TP_ARGS op.runs, op.n_groups, op.groups, op.off, op.n_diag, op.diag, bs, bs.elems, ix_global, row0, row1, reps, \
         norms_local, norms_global, row_gidx, (double const *)x_global, (double *)y, d_err
 #define LSK_TP_LAUNCH(W, PM1)                                                                                   \
     do {                                                                                                        \
         if (cplx) {                                                                                             \
-            if (op.is_real) hipLaunchKernelGGL((k_tile_pull<W, PM1, true, true>), g, b, 0, s, LSK_TP_ARGS);     \
-            else hipLaunchKernelGGL((k_tile_pull<W, PM1, true, false>), g, b, 0, s, LSK_TP_ARGS);               \
+            if (op.is_real) { g.x = resident_grid(k_tile_pull<W, PM1, true, true>, work_blocks); hipLaunchKernelGGL((k_tile_pull<W, PM1, true, true>), g, b, 0, s, LSK_TP_ARGS); } \
+            else { g.x = resident_grid(k_tile_pull<W, PM1, true, false>, work_blocks); hipLaunchKernelGGL((k_tile_pull<W, PM1, true, false>), g, b, 0, s, LSK_TP_ARGS); } \
         } else {                                                                                                \
-            if (op.is_real) hipLaunchKernelGGL((k_tile_pull<W, PM1, false, true>), g, b, 0, s, LSK_TP_ARGS);    \
-            else hipLaunchKernelGGL((k_tile_pull<W, PM1, false, false>), g, b, 0, s, LSK_TP_ARGS);              \
+            if (op.is_real) { g.x = resident_grid(k_tile_pull<W, PM1, false, true>, work_blocks); hipLaunchKernelGGL((k_tile_pull<W, PM1, false, true>), g, b, 0, s, LSK_TP_ARGS); } \
+            else { g.x = resident_grid(k_tile_pull<W, PM1, false, false>, work_blocks); hipLaunchKernelGGL((k_tile_pull<W, PM1, false, false>), g, b, 0, s, LSK_TP_ARGS); } \
         }                                                                                                       \
     } while (0)
     if (bs.number_sites <= 32) { if (bs.chars_pm1) LSK_TP_LAUNCH(uint32_t, true); else LSK_TP_LAUNCH(uint32_t, false); }
