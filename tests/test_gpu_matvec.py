@@ -482,3 +482,73 @@ def test_replicated_x_mode(torch, name, P):
             ys.append(y)
         got = D.arrFromHashedToBlock(ys, masks).cpu().numpy()
         assert np.abs(got - want).max() <= 1e-12 * max(1.0, np.abs(want).max()), (name, P, cplx)
+
+
+def test_chain_32_full_size_properties(torch):
+    """BASELINE config[2]: heisenberg_chain_32 at full size (601 080 390 states).  The reference checks
+    against an HDF5 golden that is not available offline; size-independent properties instead:
+    enumeration count / sortedness / popcount, push == pull, <u, H v> == <H u, v>, and sampled rows
+    recomputed by the oracle's term expansion on the CPU."""
+    import distributed_matvec_amd as D
+    from distributed_matvec_amd import config
+    from oracle import c_oracle as CO
+    from oracle import model as M
+
+    cfg = config.heisenberg_chain_config(32)
+    basis, h = D.loadConfigFromDict(cfg, hamiltonian=True)
+    reps, masks = D.enumerateStates(basis, 1)
+    r = reps[0]
+    n = r.numel()
+    assert n == 601080390
+    assert bool((r[1:] > r[:-1]).all())
+    assert int(r[0]) == (1 << 16) - 1 and int(r[-1]) == ((1 << 16) - 1) << 16
+    u = D.fillRandom(r, 1, torch.float64)
+    v = D.fillRandom(r, 2, torch.float64)
+    Hu_pull, Hu_push, Hv = torch.empty_like(u), torch.zeros_like(u), torch.empty_like(u)
+    D.matrixVectorProduct(h, [u], [Hu_pull], reps, mode="pull")
+    D.matrixVectorProduct(h, [u], [Hu_push], reps, mode="push")
+    scale = float(Hu_pull.abs().max())
+    assert float((Hu_pull - Hu_push).abs().max()) <= 1e-12 * scale
+    del Hu_push
+    D.matrixVectorProduct(h, [v], [Hv], reps, mode="pull")
+    lhs, rhs = float(torch.dot(v, Hu_pull)), float(torch.dot(Hv, u))
+    assert abs(lhs - rhs) <= 1e-9 * max(1.0, abs(lhs))
+    # sampled rows against the oracle: y_i = d x_i + sum_j c_ij x_j  (pull form of the same expansion)
+    o = CO.COracle(M.model_from_config(cfg))
+    rs = np.random.RandomState(9)
+    rows = np.unique(rs.randint(0, n, size=400))
+    rows_t = torch.from_numpy(rows).cuda()
+    alphas = r[rows_t].cpu().numpy().view(np.uint64)
+    betas, cs, offs = o.apply_off_diag(alphas)
+    lib = CO.lib()
+    idx = np.array([lib.lso_fixed_hamming_state_to_index(int(b)) for b in betas], dtype=np.int64)
+    xb = u[torch.from_numpy(idx).cuda()].cpu().numpy()
+    xa = u[rows_t].cpu().numpy()
+    want = o.apply_diag(alphas) * xa + np.add.reduceat((cs.real * xb), offs[:-1])
+    got = Hu_pull[rows_t].cpu().numpy()
+    assert_close(got, want, "chain_32 sampled rows")
+
+
+def test_chain_36_symm_full_size_properties(torch):
+    """BASELINE config[3] basis: heisenberg_chain_36_symm (63 068 876 representatives, Burnside count
+    from SURVEY Appendix B): enumeration, push == pull through the projection, Hermiticity."""
+    import distributed_matvec_amd as D
+    from distributed_matvec_amd import config
+
+    basis, h = D.loadConfigFromDict(config.heisenberg_chain_config(36, symm=True), hamiltonian=True)
+    reps, masks = D.enumerateStates(basis, 1)
+    r = reps[0]
+    assert r.numel() == 63068876
+    assert bool((r[1:] > r[:-1]).all())
+    u = D.fillRandom(r, 3, torch.float64)
+    v = D.fillRandom(r, 4, torch.float64)
+    a, b, c = torch.empty_like(u), torch.zeros_like(u), torch.empty_like(u)
+    pl = D.matrixVectorProduct(h, [u], [a], reps, mode="pull")
+    assert pl.kernel == "tile-pull"
+    pl2 = D.matrixVectorProduct(h, [u], [b], reps, mode="push")
+    assert pl2.kernel == "tile"
+    scale = float(a.abs().max())
+    assert float((a - b).abs().max()) <= 1e-12 * scale
+    D.matrixVectorProduct(h, [v], [c], reps, mode="pull")
+    lhs, rhs = float(torch.dot(v, a)), float(torch.dot(c, u))
+    assert abs(lhs - rhs) <= 1e-9 * max(1.0, abs(lhs))
