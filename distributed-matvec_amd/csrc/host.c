@@ -477,7 +477,7 @@ static int basis_device(ls_hs_basis const *b, lsk_basis *out) {
         }
         uint64_t const full = L >= 64 ? ~0ULL : ((1ULL << L) - 1);
         if (!other && rot == full && (rev == 0 || rev == full) && e->order == L * (rev ? 2 : 1) && L >= 3) {
-            out->k4_mode = 2;
+            out->k4_mode = getenv("LS_AMD_K4_BRUTE") ? 2 : 3; /* 3: longest-zero-run candidate pruning */
             out->reflect = rev ? 1 : 0;
         }
     }

@@ -332,6 +332,73 @@ __device__ __forceinline__ void state_info_w(lsk_basis const &bs, lsk_group_elem
     if (PM1) stab = c0r * (double)si;
     else stab = c0r * sr + c0i * sim; // Re(conj(chi0) * S)
 }
+// K4, trivial sector, cyclic / dihedral group (mode 3): orbit minimum WITHOUT visiting every rotation.
+// The smallest rotation (as an integer, site L-1 = MSB) starts with the longest cyclic run of zeros, so
+//   1. R <- start positions (MSB ends) of the longest zero runs: R_1 = z, R_{j+1} = R_j & rotl(z, j)
+//      with z = ~a; the loop runs (longest run) times -- ~5-8 on typical states instead of L;
+//   2. only those start positions are candidates (usually 1-2): rotate each to the top and take the min;
+//   3. reflections: the runs of rev(a) are the mirrored runs of a, so their candidates come from R
+//      by one rotate + bit-reverse, no second search;
+//   4. global spin flip: the flipped images start with a run of *ones* of a, so only the family whose
+//      longest run is longer (both on a tie) can contain the minimum.
+template <typename W>
+__device__ __forceinline__ W rotl_sites(W x, int s, int L, W mask) {
+    return s == 0 ? x : (W)(((x << s) | (x >> (L - s))) & mask);
+}
+template <typename W>
+__device__ __forceinline__ W rev_sites(W x, int L) {
+    if (sizeof(W) == 4) return (W)(__brev((uint32_t)x) >> (32 - L));
+    return (W)(__brevll((uint64_t)x) >> (64 - L));
+}
+template <typename W>
+__device__ __forceinline__ W longest_runs(W z, int L, W mask, int &len) {
+    if (z == 0) { len = 0; return (W)1; }          // no zero site at all: every rotation is the same word
+    if (z == mask) { len = L; return (W)1; }        // all sites zero
+    W R = z;
+    int s = 1;
+    for (;;) {
+        W T = R & rotl_sites<W>(z, s, L, mask);
+        if (T == 0) break;
+        R = T;
+        ++s;
+    }
+    len = s;
+    return R;
+}
+template <typename W>
+__device__ __forceinline__ W min_over_starts(W word, W starts, int L, W mask, W best) {
+    while (starts) {
+        const int p = sizeof(W) == 4 ? __ffs((int)starts) - 1 : __ffsll((unsigned long long)starts) - 1;
+        starts &= starts - 1;
+        const W c = rotl_sites<W>(word, L - 1 - p, L, mask); // site p becomes the top site
+        best = c < best ? c : best;
+    }
+    return best;
+}
+template <typename W>
+__device__ __forceinline__ W family_min(W word, W R, int len, int L, W mask, bool reflect, W best) {
+    best = min_over_starts<W>(word, R, L, mask, best);
+    if (reflect) {
+        // LSB ends of the runs = MSB ends rotated down by len - 1; mirrored they are the MSB ends in rev(word)
+        const int down = len > 0 ? (len - 1) % L : 0;
+        const W lsb_ends = rotl_sites<W>(R, (L - down) % L, L, mask);
+        best = min_over_starts<W>(rev_sites<W>(word, L), rev_sites<W>(lsb_ends, L), L, mask, best);
+    }
+    return best;
+}
+template <typename W>
+__device__ __forceinline__ W rep_trivial_dihedral(W a, int L, W mask, bool inv, bool reflect) {
+    const W na = (W)(~a & mask);
+    int len0, len1 = -1;
+    const W R0 = longest_runs<W>(na, L, mask, len0); // zero runs of a
+    W R1 = 0;
+    if (inv) R1 = longest_runs<W>(a, L, mask, len1); // zero runs of the flipped state = one runs of a
+    W best = ~(W)0;
+    if (len0 >= len1) best = family_min<W>(a, R0, len0, L, mask, reflect, best);
+    if (inv && len1 >= len0) best = family_min<W>(na, R1, len1, L, mask, reflect, best);
+    return best;
+}
+
 // K4, trivial sector: only the orbit minimum.  mode 2 generates the L rotations incrementally
 // (rotr by one site = shift + move bit 0 to bit L-1) for a and, with reflections, for rev(a).
 template <typename W>
@@ -340,6 +407,7 @@ __device__ __forceinline__ W rep_trivial(lsk_basis const &bs, lsk_group_elem con
     const W mask = (W)bs.site_mask;
     const bool inv = bs.spin_inversion != 0;
     W best = ~(W)0;
+    if (bs.k4_mode == 3) return rep_trivial_dihedral<W>(a, L, mask, inv, bs.reflect != 0);
     if (bs.k4_mode == 2) {
         W r = a;
         for (int pass = 0; pass <= bs.reflect; ++pass) {
@@ -1264,7 +1332,13 @@ __global__ __launch_bounds__(kBlock) void k_enum_flags(lsk_basis bs, lsk_group_e
         uint64_t s = bs.hamming_weight >= 0 ? unrank_combinadic(c0, bs.hamming_weight, s_binom) : (uint64_t)c0;
         uint64_t m = 0;
         for (int64_t c = c0; c < c1; ++c) {
-            bool keep = bs.proj == LSK_PROJ_FULL ? is_representative(bs, elems, s) : true;
+            bool keep = true;
+            if (bs.proj == LSK_PROJ_FULL) {
+                // trivial sector: every orbit has non-zero norm, so "is its own orbit minimum" is the whole test
+                if (bs.k4_mode != 0) keep = bs.number_sites <= 32 ? rep_trivial<uint32_t>(bs, elems, (uint32_t)s) == (uint32_t)s
+                                                                   : rep_trivial<uint64_t>(bs, elems, s) == s;
+                else keep = is_representative(bs, elems, s);
+            }
             if (keep) m |= 1ULL << (c - c0);
             if (c + 1 < c1) s = (bs.hamming_weight > 0) ? next_fixed_hamming(s) : s + 1;
         }

@@ -75,7 +75,8 @@ typedef struct lsk_basis {
      *  1 trivial sector (every character, incl. inversion, is +1): only the orbit minimum is needed,
      *    norm(rep) is read from the owner's per-row norms when the index is looked up;
      *  2 as 1, and the permutation group is the full cyclic (rotation) group of the ring, with
-     *    (reflect = 1) or without its reflections: rotations are generated incrementally. */
+     *    (reflect = 1) or without its reflections: rotations are generated incrementally;
+     *  3 as 2, but only the rotations that start at a longest run of zeros are visited. */
     int k4_mode, reflect;
     uint64_t site_mask;
     double inv_order; /* 1 / |G| including the inversion doubling */
