@@ -464,6 +464,7 @@ static int basis_device(ls_hs_basis const *b, lsk_basis *out) {
     }
     out->k4_mode = 0;
     out->reflect = 0;
+    out->debug_ablate = getenv("LS_AMD_ABLATE") ? atoi(getenv("LS_AMD_ABLATE")) : 0;
     if (trivial && e->order > 1 && !getenv("LS_AMD_GENERAL_K4")) {
         out->k4_mode = 1;
         /* full cyclic group of the ring (every rotation k = 0..L-1), optionally with all reflections? */
@@ -896,6 +897,9 @@ struct ls_amd_plan {
     uint32_t *d_gtable;
     int64_t *d_row_gidx;
     double *d_norms_global;
+    void *d_htab;        /* hash table {rep -> x * norm(rep)} of the tile-pull families */
+    uint32_t *d_slot_of; /* slot of every (global) representative */
+    int htab_bits;
     /* kernel timing ring */
     int t_capacity, t_count;
     void **t_start, **t_stop;
@@ -938,6 +942,9 @@ int ls_amd_fill_random(int64_t n, uint64_t const *d_states, uint64_t seed, ls_am
     DEV(lsk_fill_random(n, d_states, seed, dtype == LS_AMD_C128, d_out, stream));
     return 0;
 }
+
+static int prescaled_x(ls_amd_plan *pl, int64_t n, uint64_t const *d_reps, void const *d_x, double const *d_norms,
+                       void const **out, void *stream);
 
 static int64_t rows_per_round_default(void) {
     char const *e = getenv("LS_AMD_ROWS_PER_ROUND");
@@ -1148,6 +1155,8 @@ void ls_amd_plan_destroy(ls_amd_plan *pl) {
     if (pl->d_gtable) lsk_free(pl->d_gtable);
     if (pl->d_row_gidx) lsk_free(pl->d_row_gidx);
     if (pl->d_norms_global) lsk_free(pl->d_norms_global);
+    if (pl->d_htab) lsk_free(pl->d_htab);
+    if (pl->d_slot_of) lsk_free(pl->d_slot_of);
     if (pl->d_send) lsk_free(pl->d_send);
     if (pl->d_cursors) lsk_free(pl->d_cursors);
     if (pl->d_counts) lsk_free(pl->d_counts);
@@ -1242,9 +1251,11 @@ int ls_amd_matvec_replicated(ls_amd_plan *pl, void const *d_x_global, void *d_y_
         return 0;
     }
     if (pl->family == FAMILY_REPL_TILE) {
+        void const *xg;
+        if (prescaled_x(pl, pl->gindex.count, pl->gindex.reps, d_x_global, pl->d_norms_global, &xg, stream) != 0) return -1;
         slot = timing_begin(pl, stream);
         DEV(lsk_tile_pull(pl->dop, pl->dbs, pl->gindex, pl->cplx, 0, ps->count, ps->d_reps, ps->d_norms,
-                          pl->d_norms_global, pl->d_row_gidx, d_x_global, d_y_local, pl->d_err, stream));
+                          pl->d_norms_global, pl->d_row_gidx, xg, pl->htab_bits, d_x_global, d_y_local, pl->d_err, stream));
         timing_end(pl, slot, stream);
         return 0;
     }
@@ -1267,6 +1278,25 @@ int ls_amd_plan_send_counts(ls_amd_plan const *pl, int round, int64_t *counts) {
     part_state const *ps = &pl->parts[0];
     if (round < 0 || round >= ps->rounds) return set_error("round out of range");
     memcpy(counts, ps->send_counts + (size_t)round * pl->P, sizeof(int64_t) * pl->P);
+    return 0;
+}
+
+/* hash table over `n` (global) representatives: built on first use, values refreshed per matvec */
+static int prescaled_x(ls_amd_plan *pl, int64_t n, uint64_t const *d_reps, void const *d_x, double const *d_norms,
+                       void const **out, void *stream) {
+    if (!pl->d_htab) {
+        int bits = 4;
+        while (((int64_t)1 << bits) < 2 * n) ++bits; /* load factor <= 0.5 */
+        if (bits > 32) return set_error("hash index: more than 2^31 representatives per table are not supported");
+        pl->htab_bits = bits;
+        DEV(lsk_malloc(&pl->d_htab, (size_t)(pl->cplx ? 32 : 16) << bits));
+        void *p;
+        DEV(lsk_malloc(&p, 4 * (size_t)(n > 0 ? n : 1)));
+        pl->d_slot_of = (uint32_t *)p;
+        DEV(lsk_hash_build(pl->cplx, n, d_reps, bits, pl->d_htab, pl->d_slot_of, stream));
+    }
+    DEV(lsk_hash_fill(pl->cplx, n, pl->d_slot_of, d_x, pl->dbs.k4_mode != 0 ? d_norms : NULL, pl->d_htab, stream));
+    *out = pl->d_htab;
     return 0;
 }
 
@@ -1308,9 +1338,11 @@ int ls_amd_matvec(ls_amd_plan *pl, void const *const *d_x, void *const *d_y, voi
     if (pl->me >= 0) return set_error("ls_amd_matvec: plan owns one partition; drive it with generate/scatter");
     if (pl->family == FAMILY_TILE_PULL) {
         part_state *ps = &pl->parts[0];
+        void const *xg;
+        if (prescaled_x(pl, ps->count, ps->d_reps, d_x[0], ps->d_norms, &xg, stream) != 0) return -1;
         int slot = timing_begin(pl, stream);
         DEV(lsk_tile_pull(pl->dop, pl->dbs, ps->index, pl->cplx, 0, ps->count, ps->d_reps, ps->d_norms, ps->d_norms,
-                          NULL, d_x[0], d_y[0], pl->d_err, stream));
+                          NULL, xg, pl->htab_bits, d_x[0], d_y[0], pl->d_err, stream));
         timing_end(pl, slot, stream);
         return 0;
     }

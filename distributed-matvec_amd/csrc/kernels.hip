@@ -226,6 +226,38 @@ __device__ __forceinline__ int64_t search_index(lsk_index const &ix, uint64_t s)
     return (lo < end && ix.reps[lo] == s) ? (int64_t)lo : -1;
 }
 
+// Open-addressing hash table {representative -> x * norm(rep)} used by the staged pull kernel.  The
+// uncoalesced per-lane loads of a search (table + ~5 probes + value = 8 line requests per packet) were what
+// bounded k_tile_pull (L1/TA issue: one line per lane per cycle); a hit in the home slot costs ONE 16-byte
+// request.  Keys are inserted once per plan (linear probing, load factor <= 0.5), values are refreshed
+// every matvec through slot_of[i].  Entry = {key, re[, im, pad]}: 2 (f64) or 4 (c128) u64 words.
+constexpr uint64_t kHashEmpty = ~0ULL;
+__device__ __forceinline__ uint64_t hash_slot(uint64_t key, int bits) {
+    return (key * 0x9E3779B97F4A7C15ULL) >> (64 - bits);
+}
+template <int ES>
+__device__ __forceinline__ bool hash_lookup(uint64_t const *__restrict__ tab, int bits, uint64_t key, double &vr,
+                                            double &vi) {
+    const uint64_t mask = (1ULL << bits) - 1;
+    uint64_t slot = hash_slot(key, bits);
+    for (;;) {
+        if (ES == 2) {
+            const ulonglong2 e = *(ulonglong2 const *)(tab + slot * 2);
+            if (e.x == key) { vr = __longlong_as_double((long long)e.y); vi = 0.0; return true; }
+            if (e.x == kHashEmpty) return false;
+        } else {
+            const ulonglong2 e = *(ulonglong2 const *)(tab + slot * 4);
+            if (e.x == key) {
+                vr = __longlong_as_double((long long)e.y);
+                vi = __longlong_as_double((long long)tab[slot * 4 + 2]);
+                return true;
+            }
+            if (e.x == kHashEmpty) return false;
+        }
+        slot = (slot + 1) & mask;
+    }
+}
+
 // one symmetry-group element applied to a state
 __device__ __forceinline__ uint64_t delta_swap(uint64_t x, uint64_t m, int d) {
     uint64_t t = ((x >> d) ^ x) & m;
@@ -960,6 +992,9 @@ extern "C" int lsk_tile(lsk_operator op, lsk_basis bs, lsk_index ix, int cplx, i
 // y (ds_add_f64) -- no global atomics, y written once.  With one partition "global" == "local"; with
 // one partition per GPU x is the all-gathered vector in global ascending order (replicated-x mode).
 // ---------------------------------------------------------------------------------------------
+constexpr int kGCPull = 4;
+constexpr int kCapPull = kBlock * kGCPull;
+
 template <typename W, bool PM1, bool CPLX, bool REAL>
 __global__ __launch_bounds__(kBlock) void k_tile_pull(lsk_runs runs, int n_groups, lsk_group const *__restrict__ groups,
                                                       lsk_term const *__restrict__ off, int n_diag,
@@ -970,10 +1005,12 @@ __global__ __launch_bounds__(kBlock) void k_tile_pull(lsk_runs runs, int n_group
                                                       double const *__restrict__ norms_local,
                                                       double const *__restrict__ norms_global,
                                                       int64_t const *__restrict__ row_gidx,
+                                                      uint64_t const *__restrict__ tab, int tab_bits,
                                                       double const *__restrict__ x, double *__restrict__ y, int *err) {
-    __shared__ uint64_t s_beta[kCap];
-    __shared__ double s_coef[kCap * (REAL ? 1 : 2)];
-    __shared__ uint16_t s_row[kCap];
+    constexpr int ES = CPLX ? 4 : 2; // u64 words per hash entry
+    __shared__ uint64_t s_beta[kCapPull];
+    __shared__ double s_coef[kCapPull * (REAL ? 1 : 2)];
+    __shared__ uint16_t s_row[kCapPull];
     __shared__ double s_acc[kBlock * (CPLX ? 2 : 1)];
     __shared__ int s_n;
     const int tid = threadIdx.x;
@@ -989,10 +1026,10 @@ __global__ __launch_bounds__(kBlock) void k_tile_pull(lsk_runs runs, int n_group
             inv_na = na > 0.0 ? 1.0 / na : 0.0;
         }
         if (CPLX) { s_acc[2 * tid] = 0.0; s_acc[2 * tid + 1] = 0.0; } else s_acc[tid] = 0.0;
-        for (int g0 = 0; g0 < n_groups; g0 += kGC) {
+        for (int g0 = 0; g0 < n_groups; g0 += kGCPull) {
             if (tid == 0) s_n = 0;
             __syncthreads();
-            const int g1 = min(g0 + kGC, n_groups);
+            const int g1 = min(g0 + kGCPull, n_groups);
             for (int g = g0; g < g1; ++g) {
                 lsk_group const G = groups[g];
                 double cr = 0.0, ci = 0.0;
@@ -1012,13 +1049,14 @@ __global__ __launch_bounds__(kBlock) void k_tile_pull(lsk_runs runs, int n_group
                 }
             }
             __syncthreads();
-            const int n = s_n;
+            const int n = (bs.debug_ablate & 1) ? 0 : s_n;
             for (int e = tid; e < n; e += kBlock) {
                 uint64_t beta = s_beta[e];
                 double hr, hi = 0.0; // conj(H~) so far
                 if (REAL) hr = s_coef[e]; else { hr = s_coef[2 * e]; hi = s_coef[2 * e + 1]; }
                 double nb = -1.0;
-                if (bs.k4_mode != 0) {
+                if (bs.debug_ablate & 4) {
+                } else if (bs.k4_mode != 0) {
                     beta = (uint64_t)rep_trivial<W>(bs, elems, (W)beta);
                 } else {
                     W rep; double chr, chi, stab;
@@ -1031,17 +1069,17 @@ __global__ __launch_bounds__(kBlock) void k_tile_pull(lsk_runs runs, int n_group
                     double tr = hr * chr + hi * chi, ti = hi * chr - hr * chi;
                     hr = tr; hi = ti;
                 }
-                const int64_t idx = search_index(ixg, beta);
-                if (idx < 0) { atomicExch(err, 1); continue; }
-                if (nb < 0.0) nb = norms_global[idx];
-                hr *= nb; hi *= nb;
+                double xr, xi;
+                if (bs.debug_ablate & 2) { if (beta == 12345) atomicExch(err, 1); continue; }
+                if (bs.debug_ablate & 4) beta = a; // a key that exists (this thread's own row)
+                if (!hash_lookup<ES>(tab, tab_bits, beta, xr, xi)) { atomicExch(err, 1); continue; }
+                if (nb >= 0.0) { hr *= nb; hi *= nb; } // k4 modes: x is pre-multiplied by norm(rep) (k_scale_by_norms)
                 const int r = s_row[e];
                 if (CPLX) {
-                    const double xr = x[2 * idx], xi = x[2 * idx + 1];
                     atomicAdd(&s_acc[2 * r], hr * xr - hi * xi);
                     atomicAdd(&s_acc[2 * r + 1], hr * xi + hi * xr);
                 } else {
-                    atomicAdd(&s_acc[r], hr * x[idx]);
+                    atomicAdd(&s_acc[r], hr * xr);
                 }
             }
             __syncthreads();
@@ -1065,17 +1103,69 @@ __global__ __launch_bounds__(kBlock) void k_tile_pull(lsk_runs runs, int n_group
     }
 }
 
+__global__ __launch_bounds__(kBlock) void k_hash_insert(int64_t n, uint64_t const *__restrict__ reps, int bits,
+                                                        int es, uint64_t *tab, uint32_t *__restrict__ slot_of) {
+    const uint64_t mask = (1ULL << bits) - 1;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        const uint64_t key = reps[i];
+        uint64_t slot = hash_slot(key, bits);
+        for (;;) {
+            unsigned long long old = atomicCAS((unsigned long long *)(tab + slot * es), (unsigned long long)kHashEmpty,
+                                               (unsigned long long)key);
+            if (old == kHashEmpty || old == key) break;
+            slot = (slot + 1) & mask;
+        }
+        slot_of[i] = (uint32_t)slot;
+    }
+}
+__global__ __launch_bounds__(kBlock) void k_hash_clear(int64_t entries, int es, uint64_t *__restrict__ tab) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < entries; i += (int64_t)gridDim.x * kBlock)
+        tab[i * es] = kHashEmpty;
+}
+// values: tab[slot_of[i]] <- x[i] * norms[i]   (norms == NULL: unscaled)
+template <bool CPLX>
+__global__ __launch_bounds__(kBlock) void k_hash_fill(int64_t n, uint32_t const *__restrict__ slot_of,
+                                                      double const *__restrict__ x, double const *__restrict__ norms,
+                                                      uint64_t *__restrict__ tab) {
+    constexpr int ES = CPLX ? 4 : 2;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        const double nb = norms ? norms[i] : 1.0;
+        double *val = (double *)(tab + (size_t)slot_of[i] * ES + 1);
+        if (CPLX) { val[0] = x[2 * i] * nb; val[1] = x[2 * i + 1] * nb; } else val[0] = x[i] * nb;
+    }
+}
+extern "C" int lsk_hash_build(int cplx, int64_t n, uint64_t const *reps, int bits, void *tab, uint32_t *slot_of,
+                              void *stream) {
+    const int es = cplx ? 4 : 2;
+    const int64_t entries = (int64_t)1 << bits;
+    hipLaunchKernelGGL(k_hash_clear, dim3(grid_for(entries)), dim3(kBlock), 0, (hipStream_t)stream, entries, es, (uint64_t *)tab);
+    LSK_LAUNCH_CHECK();
+    if (n > 0) {
+        hipLaunchKernelGGL(k_hash_insert, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, n, reps, bits, es, (uint64_t *)tab, slot_of);
+        LSK_LAUNCH_CHECK();
+    }
+    return 0;
+}
+extern "C" int lsk_hash_fill(int cplx, int64_t n, uint32_t const *slot_of, void const *x, double const *norms, void *tab,
+                             void *stream) {
+    if (n == 0) return 0;
+    if (cplx) hipLaunchKernelGGL(k_hash_fill<true>, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, n, slot_of, (double const *)x, norms, (uint64_t *)tab);
+    else hipLaunchKernelGGL(k_hash_fill<false>, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, n, slot_of, (double const *)x, norms, (uint64_t *)tab);
+    LSK_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int lsk_tile_pull(lsk_operator op, lsk_basis bs, lsk_index ix_global, int cplx, int64_t row0, int64_t row1,
                              uint64_t const *reps, double const *norms_local, double const *norms_global,
-                             int64_t const *row_gidx, void const *x_global, void *y, int *d_err, void *stream) {
+                             int64_t const *row_gidx, void const *tab, int tab_bits, void const *x_global, void *y,
+                             int *d_err, void *stream) {
     if (row1 <= row0) return 0;
-    if (ix_global.kind != LSK_INDEX_SEARCH) { snprintf(g_err, sizeof(g_err), "lsk_tile_pull needs a SEARCH index"); return -1; }
     if (bs.proj != LSK_PROJ_FULL) { snprintf(g_err, sizeof(g_err), "lsk_tile_pull is for projected bases"); return -1; }
     dim3 g(1), b(kBlock);
     const int64_t work_blocks = (row1 - row0 + kBlock - 1) / kBlock;
     hipStream_t s = (hipStream_t)stream;
 #define LSK_TP_ARGS op.runs, op.n_groups, op.groups, op.off, op.n_diag, op.diag, bs, bs.elems, ix_global, row0, row1, reps, \
-        norms_local, norms_global, row_gidx, (double const *)x_global, (double *)y, d_err
+        norms_local, norms_global, row_gidx, (uint64_t const *)tab, tab_bits, (double const *)x_global, (double *)y, d_err
 #define LSK_TP_LAUNCH(W, PM1)                                                                                   \
     do {                                                                                                        \
         if (cplx) {                                                                                             \

@@ -78,6 +78,7 @@ typedef struct lsk_basis {
      *    (reflect = 1) or without its reflections: rotations are generated incrementally;
      *  3 as 2, but only the rotations that start at a longest run of zeros are visited. */
     int k4_mode, reflect;
+    int debug_ablate; /* LS_AMD_ABLATE bitmask (profiling only): 1 skip stage B, 2 skip lookup+accumulate, 4 skip K4 */
     uint64_t site_mask;
     double inv_order; /* 1 / |G| including the inversion doubling */
     lsk_group_elem const *elems; /* device [n_elems] */
@@ -144,9 +145,15 @@ int lsk_tile(lsk_operator op, lsk_basis bs, lsk_index ix, int cplx, int count_on
 int lsk_direct_gx(lsk_operator op, lsk_basis bs, lsk_index ix_global, int cplx, int64_t n,
                   uint64_t const *reps, int64_t const *row_gidx, void const *x_global, void *y, int *d_err,
                   void *stream);
+/* hash table {rep -> x * norm(rep)} of the staged pull kernel: 2^bits entries of 16 (f64) / 32 (c128)
+ * bytes; build once (keys + slot_of[i]), fill the values every matvec (norms NULL: unscaled) */
+int lsk_hash_build(int cplx, int64_t n, uint64_t const *reps, int bits, void *tab, uint32_t *slot_of, void *stream);
+int lsk_hash_fill(int cplx, int64_t n, uint32_t const *slot_of, void const *x, double const *norms, void *tab,
+                  void *stream);
 int lsk_tile_pull(lsk_operator op, lsk_basis bs, lsk_index ix_global, int cplx, int64_t row0, int64_t row1,
                   uint64_t const *reps, double const *norms_local, double const *norms_global,
-                  int64_t const *row_gidx, void const *x_global, void *y, int *d_err, void *stream);
+                  int64_t const *row_gidx, void const *tab, int tab_bits, void const *x_global, void *y,
+                  int *d_err, void *stream);
 /* n packets -> y[idx(beta)] += value */
 int lsk_scatter(lsk_index ix, int cplx, int64_t n, uint64_t const *betas, void const *vals, void *y,
                 double const *norms /* NULL, or per-row norms multiplied in (K4 modes 1, 2) */, int *d_err,
