@@ -236,9 +236,17 @@ def main():
     else:
         bytes_per_launch = (rows_here * (8 + 2 * w) + nnz_here * 2 * w) / launches_per_step
     achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms else None
+    traffic = None
+    try:  # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside the timed bench)
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            t = json.load(f).get(f"{args.model}/{args.dtype}/{kernel_name}")
+        if t and world == 1:
+            traffic = t["traffic_bytes"]
+    except (OSError, ValueError):
+        pass
     roofline = {
         "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-        "frac": achieved / HBM_PEAK_GBPS if achieved else None, "traffic": None,
+        "frac": achieved / HBM_PEAK_GBPS if achieved else None, "traffic": traffic,
         "kernel": kernel_name, "kernel_ms_avg": kernel_ms, "launches_per_step": launches_per_step,
         "algorithmic_bytes_per_launch": bytes_per_launch,
         "whole_matvec_GBps": b_alg / (dt / args.steps) / 1e9,
