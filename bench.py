@@ -212,11 +212,14 @@ def main():
         del op_obj, plan
         torch.cuda.empty_cache()
         mk = (lambda: DistributedOperator(h, my_reps, tdtype)) if other == "packets" else (lambda: ReplicatedOperator(h, my_reps, reps_global, masks, tdtype))
-        dt2, kms2, lps2, kn2, xb2, plan2, op2 = measure(mk, max(2, args.steps // 4), 1, other)
-        s2 = max(2, args.steps // 4)
-        extra[f"exchange={other}"] = {"matvecs_per_s": s2 / dt2, "ms_per_step": 1e3 * dt2 / s2, "kernel": kn2,
-                                      "exchange_bytes_per_matvec": xb2}
-        del op2, plan2
+        try:
+            dt2, kms2, lps2, kn2, xb2, plan2, op2 = measure(mk, max(2, args.steps // 4), 1, other)
+            s2 = max(2, args.steps // 4)
+            extra[f"exchange={other}"] = {"matvecs_per_s": s2 / dt2, "ms_per_step": 1e3 * dt2 / s2, "kernel": kn2,
+                                          "exchange_bytes_per_matvec": xb2}
+            del op2, plan2
+        except Exception as e:  # the secondary measurement must never cost the primary one
+            extra[f"exchange={other}"] = {"error": repr(e)[:300]}
 
     ms_per_step = 1e3 * dt / args.steps
     value = args.steps / dt

@@ -217,7 +217,21 @@ def diagonalize(config, num_evals: int = 1, eps: float = 1e-6, num_partitions: i
     reps, masks = api.enumerateStates(basis, num_partitions)
     op = LocalOperator(h, reps, dtype)
     r = lanczos_smallest(op, num_evals=num_evals, eps=eps, max_basis=max_basis, verbose=verbose)
-    if output:
+    if output and output.endswith((".h5", ".hdf5")):
+        # same groups/datasets as the reference's output file (Diagonalize.chpl:241,248-256)
+        from . import hdf5
+
+        to_block = lambda v: api.arrFromHashedToBlock(list(v.split(op.sizes)), masks) if num_partitions > 1 else v  # noqa: E731
+        evecs = np.stack([to_block(v).cpu().numpy() for v in r.eigenvectors])
+        if np.iscomplexobj(evecs):
+            raise NotImplementedError("HDF5 output is implemented for real eigenvectors (the reference's eltType is real(64))")
+        hdf5.write_datasets(output, {
+            "/basis/representatives": (api.arrFromHashedToBlock(reps, masks) if num_partitions > 1 else reps[0]).cpu().numpy().view(np.uint64),
+            "/hamiltonian/eigenvalues": np.array(r.eigenvalues),
+            "/hamiltonian/residuals": np.array(r.residual_norms),
+            "/hamiltonian/eigenvectors": evecs,
+        })
+    elif output:
         parts_to_block = lambda v: api.arrFromHashedToBlock(list(v.split(op.sizes)), masks) if num_partitions > 1 else v  # noqa: E731
         np.savez(
             output,

@@ -1,0 +1,85 @@
+"""HDF5 layer (the reference's disk format either side of the path) + the mirrored integration tests."""
+import io
+import os
+
+import numpy as np
+import pytest
+
+from helpers import SMALL_MODELS, golden_vectors, model_config
+
+
+def _hdf5():
+    from distributed_matvec_amd import hdf5
+
+    try:
+        hdf5.lib()
+    except hdf5.Hdf5Unavailable:
+        pytest.skip("libhdf5 not available")
+    return hdf5
+
+
+def test_round_trip(tmp_path):
+    hdf5 = _hdf5()
+    rs = np.random.RandomState(0)
+    x = rs.rand(1, 1234)
+    reps = (rs.randint(0, 2**62, size=77, dtype=np.int64)).astype(np.uint64)
+    path = str(tmp_path / "a.h5")
+    hdf5.write_datasets(path, {"/x": x, "/representatives": reps, "/hamiltonian/eigenvalues": np.array([-1.0, 2.0])})
+    assert hdf5.dataset_shape(path, "/x") == (1, 1234)
+    assert np.array_equal(hdf5.read_dataset(path, "/x"), x)
+    got = hdf5.read_dataset(path, "/representatives")
+    assert got.dtype == np.uint64 and np.array_equal(got, reps)
+    assert np.array_equal(hdf5.read_dataset(path, "/hamiltonian/eigenvalues"), [-1.0, 2.0])
+    with pytest.raises(KeyError):
+        hdf5.read_dataset(path, "/nope")
+
+
+def _write_golden_like(tmp_path, name):
+    """a file with the layout of the reference's data/matvec/<name>.h5 (input_for_matvec.py:43-46), from the
+    committed golden vectors (x by the reference's recipe, y by the dense oracle)."""
+    import yaml
+
+    hdf5 = _hdf5()
+    v = golden_vectors()
+    h5 = str(tmp_path / f"{name}.h5")
+    hdf5.write_datasets(h5, {"/representatives": v[name + "/representatives"], "/x": v[name + "/x"][None, :], "/y": v[name + "/y"][None, :]})
+    yml = str(tmp_path / f"{name}.yaml")
+    with open(yml, "w", encoding="utf-8") as f:
+        yaml.safe_dump(model_config(name), f, allow_unicode=True)
+    return yml, h5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["heisenberg_chain_10", "heisenberg_chain_12", "heisenberg_kagome_12_symm", "heisenberg_square_4x4"])
+@pytest.mark.parametrize("num_locales", [1, 3])
+def test_mirrored_integration_tests(tmp_path, name, num_locales):
+    """TestMatrixVectorProduct.chpl / TestStatesEnumeration.chpl on YAML + HDF5 files."""
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.fail("needs a HIP device")
+    from distributed_matvec_amd import check
+
+    yml, h5 = _write_golden_like(tmp_path, name)
+    out = io.StringIO()
+    ok, _ = check.test_matrix_vector_product(yml, h5, num_locales, out=out)
+    assert ok and out.getvalue().splitlines()[0] == "true"
+    if num_locales == 1:
+        ok2, _ = check.test_states_enumeration(yml, h5, out=io.StringIO())
+        assert ok2
+
+
+@pytest.mark.gpu
+def test_diagonalize_writes_reference_style_hdf5(tmp_path):
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.fail("needs a HIP device")
+    hdf5 = _hdf5()
+    from distributed_matvec_amd.diagonalize import diagonalize
+
+    out = str(tmp_path / "exact_diagonalization_output.h5")
+    r = diagonalize(model_config("heisenberg_chain_10"), num_evals=1, eps=1e-10, output=out)
+    assert abs(hdf5.read_dataset(out, "/hamiltonian/eigenvalues")[0] - (-18.061785417968)) < 1e-8
+    assert hdf5.read_dataset(out, "/basis/representatives").shape == (126,)
+    assert hdf5.dataset_shape(out, "/hamiltonian/eigenvectors") == (1, 126)
