@@ -199,11 +199,10 @@ def main():
         if pp is not None:
             pp.destroy()
         if nnz is None:
-            from distributed_matvec_amd.distributed import DistributedOperator
-
-            dop = DistributedOperator(h, my_reps, tdtype)
-            nnz = int(allsum(dop.engine.plan.nnz))
-            del dop
+            # one partition per rank: the count pass of a push (packets) plan over this rank's rows
+            pp = D.MatvecPlan(h, my_reps, tdtype, my_partition=rank, num_partitions=world, mode="push")
+            nnz = int(allsum(pp.nnz))
+            pp.destroy()
     if distributed and not args.no_extra and h.isHermitian:
         # the other exchange strategy, fewer steps
         from distributed_matvec_amd.distributed import DistributedOperator, ReplicatedOperator

@@ -552,3 +552,26 @@ def test_chain_36_symm_full_size_properties(torch):
     D.matrixVectorProduct(h, [v], [c], reps, mode="pull")
     lhs, rhs = float(torch.dot(v, a)), float(torch.dot(c, u))
     assert abs(lhs - rhs) <= 1e-9 * max(1.0, abs(lhs))
+
+
+@pytest.mark.parametrize("name", ["heisenberg_chain_16", "heisenberg_chain_24_symm", "heisenberg_chain_10", "issue_01", "heisenberg_kagome_16"])
+def test_replicated_x_block_rows(torch, name):
+    """what distributed.ReplicatedOperator runs per rank: a CONTIGUOUS range of global rows against the
+    replicated x (rows of every emulated rank concatenated = H x in block order)."""
+    P = 3
+    D, basis, h, reps, masks = setup_model(torch, model_config(name), 1)
+    reps_global = reps[0]
+    want_reps = oracle_reps(name)
+    n = len(want_reps)
+    x = np.random.RandomState(61).rand(n) - 0.5
+    want = oracle_for(name).local_matvec(want_reps, x)
+    xg = torch.from_numpy(x).cuda()
+    pieces = []
+    for p in range(P):
+        n0, n1 = n * p // P, n * (p + 1) // P
+        pl = D.ReplicatedPlan(h, reps_global[n0:n1], reps_global, xg.dtype, P, p)
+        y = torch.zeros(n1 - n0, dtype=xg.dtype, device="cuda")
+        pl.matvec(xg, y)
+        pieces.append(y)
+    got = torch.cat(pieces).cpu().numpy()
+    assert_close(got, want, name)
