@@ -897,6 +897,11 @@ struct ls_amd_plan {
     uint32_t *d_gtable;
     int64_t *d_row_gidx;
     double *d_norms_global;
+    /* high-part pass of the direct pull kernel (lsk.h) */
+    int has_highpart;
+    lsk_highpart hp;
+    lsk_operator dop_low; /* dop with the exchange runs truncated to the pairs below the high part */
+    void *hp_alloc[7];
     void *d_htab;        /* hash table {rep -> x * norm(rep)} of the tile-pull families */
     uint32_t *d_slot_of; /* slot of every (global) representative */
     int htab_bits;
@@ -970,6 +975,113 @@ static int build_search_index(part_state *ps, int number_sites, void *stream) {
     ps->index.shift = shift;
     ps->index.table = ps->d_table;
     return 0;
+}
+
+static int upload(void **slot, void const *host, size_t bytes) {
+    DEV(lsk_malloc(slot, bytes ? bytes : 8));
+    DEV(lsk_h2d(*slot, host, bytes));
+    return 0;
+}
+
+/* builds the high-part tables (lsk.h) for the full fixed-Hamming basis; t = number of top site bits */
+static int setup_highpart(ls_amd_plan *pl, int t) {
+    ls_hs_basis const *b = pl->op->basis;
+    int const L = b->number_sites, h = b->ext->hamming_weight;
+    lsk_runs const *R = &pl->dop.runs;
+    if (t < 2 || t > 12 || L - t < 1 || h < 0 || b->spin_inversion != 0 || R->n_runs == 0) return 0;
+    int const lowbits = L - t;
+    /* pairs (lo, lo + 1) of the exchange runs that lie entirely in the high part */
+    int npairs = 0;
+    int pair_bit[64];
+    double pair_v[64][2];
+    pl->dop_low = pl->dop;
+    for (int r = 0; r < R->n_runs; ++r) {
+        int keep = lowbits - R->lo0[r];
+        if (keep < 0) keep = 0;
+        if (keep > R->cnt[r]) keep = R->cnt[r];
+        for (int lo = R->lo0[r] + keep; lo < R->lo0[r] + R->cnt[r]; ++lo) {
+            pair_bit[npairs] = lo - lowbits;
+            pair_v[npairs][0] = R->v_re[r];
+            pair_v[npairs][1] = R->v_im[r];
+            ++npairs;
+        }
+        pl->dop_low.runs.cnt[r] = keep;
+    }
+    if (npairs == 0) return 0;
+    int const nH = 1 << t;
+    int *row_of = (int *)malloc(sizeof(int) * nH);
+    int64_t *base_of = (int64_t *)malloc(sizeof(int64_t) * nH);
+    int64_t acc = 0;
+    int nrows = 0;
+    for (int H = 0; H < nH; ++H) {
+        int j = __builtin_popcount((unsigned)H);
+        row_of[H] = -1;
+        if (h - j < 0 || h - j > lowbits) continue;
+        base_of[H] = acc;
+        acc += (int64_t)binom(lowbits, h - j);
+        ++nrows;
+    }
+    if (acc != pl->parts[0].count) { free(row_of); free(base_of); return 0; } /* not the full set: leave it to pass A */
+    int32_t *class_rows = (int32_t *)calloc(t + 2, sizeof(int32_t));
+    int64_t *class_size = (int64_t *)calloc(t + 2, sizeof(int64_t));
+    int64_t *class_chunk0 = (int64_t *)calloc(t + 2, sizeof(int64_t));
+    int64_t *row_base = (int64_t *)malloc(sizeof(int64_t) * (nrows > 0 ? nrows : 1));
+    int *row_H = (int *)malloc(sizeof(int) * (nrows > 0 ? nrows : 1));
+    int nclasses = 0, row = 0, max_rows = 0;
+    for (int j = 0; j <= t; ++j) {
+        if (h - j < 0 || h - j > lowbits) continue;
+        class_rows[nclasses] = row;
+        class_size[nclasses] = (int64_t)binom(lowbits, h - j);
+        for (int H = 0; H < nH; ++H)
+            if (__builtin_popcount((unsigned)H) == j) { row_of[H] = row; row_base[row] = base_of[H]; row_H[row] = H; ++row; }
+        if (row - class_rows[nclasses] > max_rows) max_rows = row - class_rows[nclasses];
+        class_chunk0[nclasses + 1] = class_chunk0[nclasses] + (class_size[nclasses] + 63) / 64;
+        ++nclasses;
+    }
+    class_rows[nclasses] = row;
+    int32_t *pbegin = (int32_t *)calloc(nrows + 1, sizeof(int32_t));
+    int32_t *prow = (int32_t *)malloc(sizeof(int32_t) * ((size_t)nrows * npairs + 1));
+    double *pv = (double *)malloc(sizeof(double) * 2 * ((size_t)nrows * npairs + 1));
+    int np = 0;
+    for (int r = 0; r < nrows; ++r) {
+        pbegin[r] = np;
+        int H = row_H[r];
+        for (int k = 0; k < npairs; ++k) {
+            int bit = pair_bit[k];
+            if ((((H >> bit) ^ (H >> (bit + 1))) & 1) == 0) continue;
+            prow[np] = row_of[H ^ (3 << bit)];
+            pv[2 * np] = pair_v[k][0];
+            pv[2 * np + 1] = pair_v[k][1];
+            ++np;
+        }
+    }
+    pbegin[nrows] = np;
+    int rc = 0;
+    size_t lds = (size_t)max_rows * 64 * (pl->cplx ? 16 : 8);
+    if (lds <= 64 * 1024) {
+        rc = upload(&pl->hp_alloc[0], class_rows, sizeof(int32_t) * (nclasses + 1)) ||
+             upload(&pl->hp_alloc[1], class_size, sizeof(int64_t) * nclasses) ||
+             upload(&pl->hp_alloc[2], class_chunk0, sizeof(int64_t) * (nclasses + 1)) ||
+             upload(&pl->hp_alloc[3], row_base, sizeof(int64_t) * nrows) ||
+             upload(&pl->hp_alloc[4], pbegin, sizeof(int32_t) * (nrows + 1)) ||
+             upload(&pl->hp_alloc[5], prow, sizeof(int32_t) * (np > 0 ? np : 1)) ||
+             upload(&pl->hp_alloc[6], pv, sizeof(double) * 2 * (np > 0 ? np : 1));
+        if (!rc) {
+            pl->hp.n_classes = nclasses; pl->hp.n_rows = nrows; pl->hp.max_class_rows = max_rows;
+            pl->hp.n_items = class_chunk0[nclasses];
+            pl->hp.class_rows = (int32_t const *)pl->hp_alloc[0];
+            pl->hp.class_size = (int64_t const *)pl->hp_alloc[1];
+            pl->hp.class_chunk0 = (int64_t const *)pl->hp_alloc[2];
+            pl->hp.row_base = (int64_t const *)pl->hp_alloc[3];
+            pl->hp.row_pbegin = (int32_t const *)pl->hp_alloc[4];
+            pl->hp.partner_row = (int32_t const *)pl->hp_alloc[5];
+            pl->hp.partner_v = (double const *)pl->hp_alloc[6];
+            pl->has_highpart = 1;
+        }
+    }
+    free(row_of); free(base_of); free(class_rows); free(class_size); free(class_chunk0); free(row_base); free(row_H);
+    free(pbegin); free(prow); free(pv);
+    return rc;
 }
 
 static int plan_setup_part(ls_amd_plan *pl, part_state *ps, int part_id, int num_rounds, void *stream) {
@@ -1132,6 +1244,13 @@ int ls_amd_plan_create(ls_amd_plan **out, ls_hs_operator const *op, ls_amd_dtype
         if (plan_setup_part(pl, ps, pid, num_rounds, stream) != 0) { ls_amd_plan_destroy(pl); return -1; }
         if (ps->max_send_bytes > pl->send_capacity) pl->send_capacity = ps->max_send_bytes;
     }
+    if (pl->family == FAMILY_DIRECT_PULL && pl->parts[0].index.kind == LSK_INDEX_COMBINADIC) {
+        /* off by default: measured on chain_32 the two-pass scheme is slower (12.9 + 10.2 ms vs 15.7 ms);
+         * kept as an option because it bounds the far-bond traffic for longer chains */
+        char const *e = getenv("LS_AMD_HIGH_BITS");
+        int t = e ? atoi(e) : 0;
+        if (t > 0 && setup_highpart(pl, t) != 0) { ls_amd_plan_destroy(pl); return -1; }
+    }
     if (pl->family == FAMILY_TILE && my_partition < 0 && pl->send_capacity > 0) {
         if (lsk_malloc(&pl->d_send, (size_t)pl->send_capacity) != 0) { ls_amd_plan_destroy(pl); return dev_error(); }
     }
@@ -1155,6 +1274,7 @@ void ls_amd_plan_destroy(ls_amd_plan *pl) {
     if (pl->d_gtable) lsk_free(pl->d_gtable);
     if (pl->d_row_gidx) lsk_free(pl->d_row_gidx);
     if (pl->d_norms_global) lsk_free(pl->d_norms_global);
+    for (int i = 0; i < 7; ++i) if (pl->hp_alloc[i]) lsk_free(pl->hp_alloc[i]);
     if (pl->d_htab) lsk_free(pl->d_htab);
     if (pl->d_slot_of) lsk_free(pl->d_slot_of);
     if (pl->d_send) lsk_free(pl->d_send);
@@ -1264,7 +1384,7 @@ int ls_amd_matvec_replicated(ls_amd_plan *pl, void const *d_x_global, void *d_y_
 char const *ls_amd_plan_kernel_name(ls_amd_plan const *pl) {
     switch (pl->family) {
     case FAMILY_DIRECT_PUSH: return "direct-push";
-    case FAMILY_DIRECT_PULL: return "direct-pull";
+    case FAMILY_DIRECT_PULL: return pl->has_highpart ? "direct-pull+highpart" : "direct-pull";
     case FAMILY_TILE_PULL: return "tile-pull";
     case FAMILY_REPL_DIRECT: return "replicated-direct-pull";
     case FAMILY_REPL_TILE: return "replicated-tile-pull";
@@ -1354,8 +1474,9 @@ int ls_amd_matvec(ls_amd_plan *pl, void const *const *d_x, void *const *d_y, voi
     if (pl->family != FAMILY_TILE) {
         part_state *ps = &pl->parts[0];
         int slot = timing_begin(pl, stream);
-        DEV(lsk_direct(pl->dop, pl->dbs, ps->index, pl->cplx, pl->family == FAMILY_DIRECT_PULL, ps->count,
-                       ps->d_reps, d_x[0], d_y[0], pl->d_err, stream));
+        DEV(lsk_direct(pl->has_highpart ? pl->dop_low : pl->dop, pl->dbs, ps->index, pl->cplx,
+                       pl->family == FAMILY_DIRECT_PULL, ps->count, ps->d_reps, d_x[0], d_y[0], pl->d_err, stream));
+        if (pl->has_highpart) DEV(lsk_highpart_apply(pl->hp, pl->cplx, d_x[0], d_y[0], stream));
         timing_end(pl, slot, stream);
         return 0;
     }

@@ -93,14 +93,14 @@ constexpr int kMaxGrid = 256 * 8; // 256 CUs x 8 resident blocks: grid-stride be
 static int g_num_cus = 0;
 template <typename K>
 static int resident_grid(K kernel, int64_t work_blocks, size_t dyn_lds = 0) {
-    static std::map<void const *, int> cache;
+    static std::map<std::pair<void const *, size_t>, int> cache;
     if (g_num_cus == 0) {
         hipDeviceProp_t prop;
         int dev = 0;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) g_num_cus = prop.multiProcessorCount;
         if (g_num_cus <= 0) g_num_cus = 256;
     }
-    void const *key = (void const *)kernel;
+    const std::pair<void const *, size_t> key((void const *)kernel, dyn_lds);
     auto it = cache.find(key);
     int per_cu;
     if (it == cache.end()) {
@@ -804,6 +804,73 @@ extern "C" int lsk_direct(lsk_operator op, lsk_basis bs, lsk_index ix, int cplx,
 extern "C" int lsk_direct_gx(lsk_operator op, lsk_basis bs, lsk_index ix, int cplx, int64_t n, uint64_t const *reps,
                              int64_t const *row_gidx, void const *x_global, void *y, int *d_err, void *stream) {
     return direct_dispatch(op, bs, ix, cplx, 1, n, reps, x_global, y, d_err, stream, 1, row_gidx);
+}
+
+// ---------------------------------------------------------------------------------------------
+// High-part pass (see lsk.h): one work item = (popcount class of the top bits, 64 consecutive offsets).
+// The block stages the class's x slices in LDS (one coalesced 512-byte row per H), then every wave
+// combines partner rows from LDS and read-modify-writes its y rows.  Pure streaming: x read once,
+// y updated once, for all the far bonds of the class together.
+// ---------------------------------------------------------------------------------------------
+constexpr int kHpChunk = 64;
+template <bool CPLX>
+__global__ __launch_bounds__(kBlock) void k_highpart(lsk_highpart hp, double const *__restrict__ x, double *__restrict__ y) {
+    extern __shared__ double s_x[]; // [max_class_rows][kHpChunk] (x2 for complex)
+    constexpr int EW = CPLX ? 2 : 1;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    constexpr int n_waves = kBlock / 64;
+    for (int64_t item = blockIdx.x; item < hp.n_items; item += gridDim.x) {
+        // class of this work item (few classes: linear scan)
+        int c = 0;
+        while (c + 1 < hp.n_classes && hp.class_chunk0[c + 1] <= item) ++c;
+        const int64_t o0 = (item - hp.class_chunk0[c]) * kHpChunk;
+        const int64_t S = hp.class_size[c];
+        const int r0 = hp.class_rows[c], r1 = hp.class_rows[c + 1];
+        const bool in = o0 + lane < S;
+        __syncthreads(); // previous item's readers are done with s_x
+        for (int r = r0 + wave; r < r1; r += n_waves) {
+            const int64_t g = hp.row_base[r] + o0 + lane;
+            double *dst = s_x + ((size_t)(r - r0) * kHpChunk + lane) * EW;
+            if (CPLX) { dst[0] = in ? x[2 * g] : 0.0; dst[1] = in ? x[2 * g + 1] : 0.0; }
+            else dst[0] = in ? x[g] : 0.0;
+        }
+        __syncthreads();
+        for (int r = r0 + wave; r < r1; r += n_waves) {
+            const int pb = hp.row_pbegin[r], pe = hp.row_pbegin[r + 1];
+            if (pb == pe) continue;
+            double ar = 0.0, ai = 0.0;
+            for (int p = pb; p < pe; ++p) {
+                const double vr = hp.partner_v[2 * p], vi = hp.partner_v[2 * p + 1];
+                double const *src = s_x + ((size_t)(hp.partner_row[p] - r0) * kHpChunk + lane) * EW;
+                if (CPLX) { // conj(v) * x
+                    ar += vr * src[0] + vi * src[1];
+                    ai += vr * src[1] - vi * src[0];
+                } else ar += vr * src[0];
+            }
+            if (in) {
+                const int64_t g = hp.row_base[r] + o0 + lane;
+                if (CPLX) { y[2 * g] += ar; y[2 * g + 1] += ai; } else y[g] += ar;
+            }
+        }
+    }
+}
+extern "C" int lsk_highpart_apply(lsk_highpart hp, int cplx, void const *x, void *y, void *stream) {
+    if (hp.n_items == 0) return 0;
+    const size_t lds = (size_t)hp.max_class_rows * kHpChunk * (cplx ? 16 : 8);
+    if (lds > 160 * 1024) { snprintf(g_err, sizeof(g_err), "lsk_highpart: class too large for LDS"); return -1; }
+    int grid;
+    if (cplx) {
+        LSK_CHECK(hipFuncSetAttribute((void const *)k_highpart<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        grid = resident_grid(k_highpart<true>, hp.n_items, lds);
+        hipLaunchKernelGGL(k_highpart<true>, dim3(grid), dim3(kBlock), lds, (hipStream_t)stream, hp, (double const *)x, (double *)y);
+    } else {
+        LSK_CHECK(hipFuncSetAttribute((void const *)k_highpart<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        grid = resident_grid(k_highpart<false>, hp.n_items, lds);
+        hipLaunchKernelGGL(k_highpart<false>, dim3(grid), dim3(kBlock), lds, (hipStream_t)stream, hp, (double const *)x, (double *)y);
+    }
+    LSK_LAUNCH_CHECK();
+    return 0;
 }
 
 // ---------------------------------------------------------------------------------------------

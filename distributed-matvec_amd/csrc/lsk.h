@@ -154,6 +154,32 @@ int lsk_tile_pull(lsk_operator op, lsk_basis bs, lsk_index ix_global, int cplx, 
                   uint64_t const *reps, double const *norms_local, double const *norms_global,
                   int64_t const *row_gidx, void const *tab, int tab_bits, void const *x_global, void *y,
                   int *d_err, void *stream);
+/* "High-part" pass of the pull formulation for the full fixed-Hamming basis (P = 1).  States are sorted
+ * as integers, so all states with the same top `t` site bits H form one contiguous block
+ * [base(H), base(H) + S_pop(H)), ordered by their low part; an exchange on two adjacent HIGH sites maps
+ * block H onto block H' with the SAME offset.  The far bonds therefore act as a tiny sparse matrix on the
+ * block index, applied to 64-offset slices staged in LDS: every x element is read from HBM once and every
+ * y element updated once for ALL those bonds together (instead of one full sweep of x per far bond).
+ *   classes      c = 0..n_classes-1 (popcount classes of H that occur)
+ *   class_rows   [n_classes + 1]  rows (= H values) of class c are [class_rows[c], class_rows[c + 1])
+ *   class_size   [n_classes]      block length S of the class
+ *   class_chunk0 [n_classes + 1]  prefix sum of ceil(S / 64): work items
+ *   row_base     [n_rows]         base(H) of every row
+ *   row_pbegin   [n_rows + 1], partner_row [..] (row index inside the same class, absolute), partner_v [..][2] */
+typedef struct lsk_highpart {
+    int n_classes, n_rows, max_class_rows;
+    int64_t n_items;
+    int32_t const *class_rows;
+    int64_t const *class_size;
+    int64_t const *class_chunk0;
+    int64_t const *row_base;
+    int32_t const *row_pbegin;
+    int32_t const *partner_row;
+    double const *partner_v;
+} lsk_highpart;
+/* y[base(H) + o] += sum_partners conj(v) x[base(H') + o] */
+int lsk_highpart_apply(lsk_highpart hp, int cplx, void const *x, void *y, void *stream);
+
 /* n packets -> y[idx(beta)] += value */
 int lsk_scatter(lsk_index ix, int cplx, int64_t n, uint64_t const *betas, void const *vals, void *y,
                 double const *norms /* NULL, or per-row norms multiplied in (K4 modes 1, 2) */, int *d_err,

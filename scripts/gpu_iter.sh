@@ -1,9 +1,8 @@
-# GPU job: parity suite + symmetric benches (quick iteration loop)
+# GPU job: parity suite + headline bench A/B (quick iteration loop)
 set -x
 export TMPDIR=/tmp
 timeout 1500 python -m pytest tests -m gpu -q --maxfail=5 2>&1 | tail -6
-python scripts/tile_bench.py --L 36 --symm --P 1 --steps 3
-LS_AMD_K4_BRUTE=1 python scripts/tile_bench.py --L 36 --symm --P 1 --steps 3
-python scripts/tile_bench.py --L 32 --symm --P 1 --steps 5
-python scripts/tile_bench.py --L 36 --symm --P 8 --steps 3
-python scripts/tile_bench.py --L 40 --symm --P 1 --steps 2
+for t in 0 8 10; do
+  LS_AMD_HIGH_BITS=$t python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra
+done
+LS_AMD_HIGH_BITS=8 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extra --dtype c128

@@ -85,7 +85,7 @@ def test_single_locale_matvec_f64(torch, name, mode):
     if basis.hasPermutationSymmetries():
         assert pl.kernel == ("tile" if mode == "push" else "tile-pull")
     else:
-        assert pl.kernel == f"direct-{mode}"
+        assert pl.kernel.startswith(f"direct-{mode}")  # "direct-pull+highpart" when the far bonds are blocked
     assert_close(got, want, name)
 
 
@@ -575,3 +575,23 @@ def test_replicated_x_block_rows(torch, name):
         pieces.append(y)
     got = torch.cat(pieces).cpu().numpy()
     assert_close(got, want, name)
+
+
+def test_highpart_two_pass_option(torch, monkeypatch):
+    """LS_AMD_HIGH_BITS=t: far bonds of the pull kernel applied block-wise from LDS (optional path)."""
+    import distributed_matvec_amd as D
+
+    monkeypatch.setenv("LS_AMD_HIGH_BITS", "6")
+    for name in ("heisenberg_chain_16", "heisenberg_chain_20", "heisenberg_kagome_16"):
+        D_, basis, h, reps, masks = setup_model(torch, model_config(name), 1)
+        want_reps = oracle_reps(name)
+        rs = np.random.RandomState(62)
+        for cplx in (False, True):
+            x = rs.rand(len(want_reps)) - 0.5
+            if cplx:
+                x = x + 1j * (rs.rand(len(want_reps)) - 0.5)
+            want = oracle_for(name).local_matvec(want_reps, x)
+            got, pl = run_matvec(torch, D_, h, reps, masks, x, 1, "pull")
+            if name.startswith("heisenberg_chain"):
+                assert pl.kernel == "direct-pull+highpart"
+            assert np.abs(got - want).max() <= 1e-12 * max(1.0, np.abs(want).max())
