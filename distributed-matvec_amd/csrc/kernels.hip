@@ -654,7 +654,7 @@ __global__ __launch_bounds__(kBlock) void k_direct(lsk_runs runs, int n_groups, 
                                 acci += act ? (vr * yi - vi * yr) : 0.0;
                             } else {
                                 double yv = x[idx];
-                                accr += act ? vr * yv : 0.0;
+                                accr = fma(act ? vr : 0.0, yv, accr);
                             }
                         } else if (act) {
                             if (CPLX) {
@@ -672,7 +672,7 @@ __global__ __launch_bounds__(kBlock) void k_direct(lsk_runs runs, int n_groups, 
                                 acci += act ? (vr * yi - vi * yr) : 0.0;
                             } else {
                                 double yv = x[idx];
-                                accr += act ? vr * yv : 0.0;
+                                accr = fma(act ? vr : 0.0, yv, accr);
                             }
                         } else if (act) {
                             if (CPLX) {
