@@ -92,6 +92,8 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    if os.environ.get("LS_AMD_BENCH_SHARE_DEVICE"):  # test hook: several ranks on one GPU (if RCCL allows it)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     distributed = world > 1 or args.force_distributed

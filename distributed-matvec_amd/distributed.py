@@ -25,6 +25,59 @@ from __future__ import annotations
 import os
 
 
+class _Transport:
+    """torch.distributed calls used by the operators.  With the "nccl" backend (RCCL) device tensors are
+    handed over as they are; with any other backend (gloo in the 2-process tests) device tensors are
+    staged through host memory -- a transport detail only, the compute stays on the GPU."""
+
+    def __init__(self, group=None):
+        import torch
+        import torch.distributed as dist
+
+        self.torch, self.dist, self.group = torch, dist, group
+        self.direct = dist.get_backend(group) == "nccl"
+
+    class _Done:
+        def __init__(self, fn=None):
+            self.fn = fn
+
+        def wait(self):
+            if self.fn:
+                self.fn()
+
+    def all_to_all_single(self, out, inp, out_splits=None, in_splits=None, async_op=False):
+        dist = self.dist
+        if self.direct or not out.is_cuda:
+            work = dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group, async_op=async_op)
+            return work if async_op else None
+        inp_h = inp.cpu()
+        out_h = self.torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(out_h, inp_h, out_splits, in_splits, group=self.group)
+        out.copy_(out_h)
+        return self._Done() if async_op else None
+
+    def exchange_blocks(self, send, outs, rank, P):
+        """every rank's `send` lands in outs[rank] of every peer (outs[rank] itself is written locally)."""
+        dist = self.dist
+        outs[rank].copy_(send)
+        if P == 1:
+            return
+        stage = not self.direct and send.is_cuda
+        src_t = send.cpu() if stage else send
+        bufs = {}
+        ops = []
+        for step in range(1, P):
+            dst, src = (rank + step) % P, (rank - step) % P
+            bufs[src] = self.torch.empty(outs[src].shape, dtype=outs[src].dtype) if stage else outs[src]
+            ops.append(dist.P2POp(dist.isend, src_t, dst, self.group))
+            ops.append(dist.P2POp(dist.irecv, bufs[src], src, self.group))
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+        if stage:
+            for src, b in bufs.items():
+                outs[src].copy_(b)
+
+
 class HipEngine:
     """ls_amd plan that owns exactly one partition (this rank's)."""
 
@@ -94,6 +147,7 @@ class DistributedOperator:
         # counts matrix exchange, once: S[d, r] = packets this rank sends to d in round r
         S = torch.tensor([self.engine.send_counts(r) for r in range(num_rounds)], dtype=torch.int64).t().contiguous()
         R = torch.zeros_like(S)
+        self.transport = _Transport(group)
         S_dev, R_dev = S.to(self.meta_device), R.to(self.meta_device)
         dist.all_to_all_single(R_dev, S_dev, group=group)
         self.send_counts = S.t().tolist()             # [round][dest]
@@ -122,8 +176,8 @@ class DistributedOperator:
             in_splits = [c * pb for c in self.send_counts[r]]
             out_splits = [c * pb for c in self.recv_counts[r]]
             n_in, n_out = sum(in_splits), sum(out_splits)
-            return dist.all_to_all_single(recv[:max(n_out, 0)], send[:max(n_in, 0)], out_splits, in_splits,
-                                          group=self.group, async_op=True)
+            return self.transport.all_to_all_single(recv[:max(n_out, 0)], send[:max(n_in, 0)], out_splits, in_splits,
+                                                    async_op=True)
 
         eng.generate(0, x, y, self.send_bufs[0])
         work = exchange(0)
@@ -232,6 +286,7 @@ class ReplicatedOperator:
         S = torch.tensor(self.y_send_counts, dtype=torch.int64, device=meta_device)
         R = torch.zeros_like(S)
         dist.all_to_all_single(R, S, group=group)
+        self.transport = _Transport(group)
         self.y_recv_counts = R.cpu().tolist()
         assert sum(self.y_recv_counts) == counts[self.rank]
         del m64, mslice, order
@@ -249,17 +304,9 @@ class ReplicatedOperator:
         torch, dist = self.torch, self.dist
         P, mc = self.P, self.max_count
         outs = [self.gathered[p * mc:p * mc + self.counts[p]] for p in range(P)]
-        outs[self.rank].copy_(x_local)
-        if P > 1:
-            # every block goes straight to every peer: one grouped send/recv (RCCL uses all xGMI links
-            # at once; an all_gather would be a ring)
-            ops = []
-            for step in range(1, P):
-                dst, src = (self.rank + step) % P, (self.rank - step) % P
-                ops.append(dist.P2POp(dist.isend, x_local, dst, self.group))
-                ops.append(dist.P2POp(dist.irecv, outs[src], src, self.group))
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()
+        # every block goes straight to every peer: one grouped send/recv (RCCL uses all xGMI links at
+        # once; an all_gather would be a ring)
+        self.transport.exchange_blocks(x_local, outs, self.rank, P)
         torch.index_select(self.gathered, 0, self.perm, out=self.x_global)
         return self.x_global
 
@@ -271,7 +318,7 @@ class ReplicatedOperator:
         self.engine.matvec(xg, self.y_block)
         torch.index_select(self.y_block, 0, self.y_order, out=self.y_send)
         if self.P > 1:
-            dist.all_to_all_single(self.y_recv, self.y_send, self.y_recv_counts, self.y_send_counts, group=self.group)
+            self.transport.all_to_all_single(self.y_recv, self.y_send, self.y_recv_counts, self.y_send_counts)
         else:
             self.y_recv.copy_(self.y_send)
         if self.accumulate:
