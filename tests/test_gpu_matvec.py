@@ -595,3 +595,44 @@ def test_highpart_two_pass_option(torch, monkeypatch):
             if name.startswith("heisenberg_chain"):
                 assert pl.kernel == "direct-pull+highpart"
             assert np.abs(got - want).max() <= 1e-12 * max(1.0, np.abs(want).max())
+
+
+def test_non_hermitian_complex_operator(torch):
+    """push is the only formulation for a non-Hermitian operator: sigma^+ sigma^- hopping plus a term with
+    imaginary matrix elements, c128 vectors, 1 and 3 partitions; pull must refuse."""
+    import distributed_matvec_amd as D
+    from oracle import c_oracle as CO
+    from oracle import model as M
+
+    L = 12
+    bonds = [[i, (i + 1) % L] for i in range(L)]
+    cfg = {"basis": {"number_spins": L, "hamming_weight": L // 2, "symmetries": []},
+           "hamiltonian": {"terms": [{"expression": "σ⁺₀ σ⁻₁", "sites": bonds},
+                                     {"expression": "0.5 × σˣ₀ σʸ₁", "sites": bonds[:4]},
+                                     {"expression": "σᶻ₀ σᶻ₁", "sites": bonds}]}}
+    # sigma^x sigma^y does not conserve the magnetisation: drop it from the fixed-weight basis test ...
+    cfg_u1 = {"basis": cfg["basis"], "hamiltonian": {"terms": [cfg["hamiltonian"]["terms"][0], cfg["hamiltonian"]["terms"][2]]}}
+    # ... and use the full 2^L space for the complex one
+    cfg_full = {"basis": {"number_spins": 10, "hamming_weight": None, "symmetries": []},
+                "hamiltonian": {"terms": [{"expression": "σ⁺₀ σ⁻₁", "sites": [[i, (i + 1) % 10] for i in range(10)]},
+                                          {"expression": "0.5 × σˣ₀ σʸ₁", "sites": [[0, 1], [3, 4], [7, 8]]},
+                                          {"expression": "σᶻ₀ σᶻ₁", "sites": [[i, (i + 1) % 10] for i in range(10)]}]}}
+    for c, want_real in ((cfg_u1, True), (cfg_full, False)):
+        o = CO.COracle(M.model_from_config(c))
+        want_reps = o.enumerate()
+        rs = np.random.RandomState(63)
+        x = (rs.rand(len(want_reps)) - 0.5) + 1j * (rs.rand(len(want_reps)) - 0.5)
+        want = o.local_matvec(want_reps, x)
+        for P in (1, 3):
+            D_, basis, h, reps, masks = setup_model(torch, c, P)
+            assert not h.isHermitian and h.isReal == want_real
+            got, pl = run_matvec(torch, D_, h, reps, masks, x, P)
+            assert pl.kernel in ("direct-push", "tile")
+            assert np.abs(got - want).max() <= 1e-12 * max(1.0, np.abs(want).max())
+            if P == 1:
+                with pytest.raises(D.LsAmdError, match="Hermitian"):
+                    run_matvec(torch, D_, h, reps, masks, x, 1, "pull")
+        if not want_real:  # complex coefficients cannot act on f64 vectors
+            D_, basis, h, reps, masks = setup_model(torch, c, 1)
+            with pytest.raises(D.LsAmdError, match="c128"):
+                run_matvec(torch, D_, h, reps, masks, x.real.copy(), 1)

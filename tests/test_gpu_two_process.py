@@ -39,6 +39,13 @@ def _worker(rank, world, port, name, cplx, mode, out_dir):
             op = ReplicatedOperator(h, my_reps, reps_global, masks, dtype)
         op.matvec(x, y, check=True)
         op.matvec(x, y, check=True)  # twice: buffers / cursors must be reusable
+        if name == "heisenberg_chain_16" and not cplx:
+            # the eigensolver driver on top of the distributed operator (dots = all_reduce, PRIMME's globalSumReal)
+            from distributed_matvec_amd.diagonalize import RankOperator, lanczos_smallest
+
+            r = lanczos_smallest(RankOperator(op, my_reps, dtype), num_evals=1, eps=1e-9)
+            assert r.converged
+            np.save(os.path.join(out_dir, f"e{rank}.npy"), np.array(r.eigenvalues))
         np.save(os.path.join(out_dir, f"x{rank}.npy"), x.cpu().numpy())
         np.save(os.path.join(out_dir, f"y{rank}.npy"), y.cpu().numpy())
         np.save(os.path.join(out_dir, f"r{rank}.npy"), my_reps.cpu().numpy().view(np.uint64))
@@ -64,3 +71,11 @@ def test_two_processes_one_gpu(tmp_path, name, world, cplx, mode):
     got = CO.hashed_to_block([np.load(os.path.join(str(tmp_path), f"y{r}.npy")) for r in range(world)], keys)
     want = oracle_for(name).local_matvec(reps, x)
     assert np.abs(got - want).max() <= 1e-12 * max(1.0, np.abs(want).max())
+    if name == "heisenberg_chain_16" and not cplx:
+        import scipy.sparse.linalg as spla
+
+        o = oracle_for(name)
+        A = spla.LinearOperator((len(reps), len(reps)), matvec=lambda v: o.local_matvec(reps, np.ascontiguousarray(v, dtype=np.float64)), dtype=np.float64)
+        e0 = spla.eigsh(A, k=1, which="SA", tol=1e-10)[0][0]
+        for r in range(world):
+            assert abs(np.load(os.path.join(str(tmp_path), f"e{r}.npy"))[0] - e0) < 1e-6
