@@ -23,7 +23,7 @@ def build(force: bool = False):
     so = os.path.join(_HERE, "liblsoracle.so")
     src = os.path.join(_HERE, "ls_oracle.c")
     if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
-        # -march=native objects must not travel between machines: rebuild if the .so cannot be used
+        # the .so travels to the GPU box with the repo snapshot (built -march=x86-64-v3 for that reason)
         subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "liblsoracle.so"])
     return so
 
