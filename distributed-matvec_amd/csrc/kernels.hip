@@ -1076,7 +1076,8 @@ __global__ __launch_bounds__(kBlock) void k_tile_pull(lsk_runs runs, int n_group
                                                       double const *__restrict__ x, double *__restrict__ y, int *err) {
     constexpr int ES = CPLX ? 4 : 2; // u64 words per hash entry
     __shared__ uint64_t s_beta[kCapPull];
-    __shared__ double s_coef[kCapPull * (REAL ? 1 : 2)];
+    constexpr bool RC = REAL && PM1; // conj(H~) stays real: real coefficients and +-1 characters
+    __shared__ double s_coef[kCapPull * (RC ? 1 : 2)];
     __shared__ uint16_t s_row[kCapPull];
     __shared__ double s_acc[kBlock * (CPLX ? 2 : 1)];
     __shared__ int s_n;
@@ -1111,42 +1112,91 @@ __global__ __launch_bounds__(kBlock) void k_tile_pull(lsk_runs runs, int n_group
                     s_beta[slot] = a ^ G.x;
                     s_row[slot] = (uint16_t)tid;
                     // conj(c) / n(alpha)
-                    if (REAL) s_coef[slot] = cr * inv_na;
+                    if (RC) s_coef[slot] = cr * inv_na;
                     else { s_coef[2 * slot] = cr * inv_na; s_coef[2 * slot + 1] = -ci * inv_na; }
                 }
             }
             __syncthreads();
             const int n = (bs.debug_ablate & 1) ? 0 : s_n;
+            // ---- stage B1: K4 on every packet; representative and conj(H~) go back into the list ---------
             for (int e = tid; e < n; e += kBlock) {
                 uint64_t beta = s_beta[e];
                 double hr, hi = 0.0; // conj(H~) so far
-                if (REAL) hr = s_coef[e]; else { hr = s_coef[2 * e]; hi = s_coef[2 * e + 1]; }
-                double nb = -1.0;
+                if (RC) hr = s_coef[e]; else { hr = s_coef[2 * e]; hi = s_coef[2 * e + 1]; }
                 if (bs.debug_ablate & 4) {
+                    beta = a; // a key that exists (this thread's own row)
                 } else if (bs.k4_mode != 0) {
-                    beta = (uint64_t)rep_trivial<W>(bs, elems, (W)beta);
+                    beta = (uint64_t)rep_trivial<W>(bs, elems, (W)beta); // x is pre-multiplied by norm(rep)
                 } else {
                     W rep; double chr, chi, stab;
                     state_info_w<W, PM1>(bs, elems, (W)beta, rep, chr, chi, stab);
                     double n2 = stab * bs.inv_order;
-                    if (!(n2 > 1e-12)) continue; // zero-norm orbit: contributes nothing (DMV:110)
-                    nb = sqrt(n2);
+                    if (!(n2 > 1e-12)) { s_row[e] = 0xffff; continue; } // zero-norm orbit: contributes nothing (DMV:110)
+                    const double nb = sqrt(n2);
                     beta = (uint64_t)rep;
-                    // times chi0 = conj(conj(chi0)) = (chr, -chi)
-                    double tr = hr * chr + hi * chi, ti = hi * chr - hr * chi;
+                    // times chi0 = conj(conj(chi0)) = (chr, -chi), times norm(rep)
+                    double tr = (hr * chr + hi * chi) * nb, ti = (hi * chr - hr * chi) * nb;
                     hr = tr; hi = ti;
+                    if (RC) s_coef[e] = hr; else { s_coef[2 * e] = hr; s_coef[2 * e + 1] = hi; }
                 }
-                double xr, xi;
-                if (bs.debug_ablate & 2) { if (beta == 12345) atomicExch(err, 1); continue; }
-                if (bs.debug_ablate & 4) beta = a; // a key that exists (this thread's own row)
-                if (!hash_lookup<ES>(tab, tab_bits, beta, xr, xi)) { atomicExch(err, 1); continue; }
-                if (nb >= 0.0) { hr *= nb; hi *= nb; } // k4 modes: x is pre-multiplied by norm(rep) (k_scale_by_norms)
-                const int r = s_row[e];
-                if (CPLX) {
-                    atomicAdd(&s_acc[2 * r], hr * xr - hi * xi);
-                    atomicAdd(&s_acc[2 * r + 1], hr * xi + hi * xr);
-                } else {
-                    atomicAdd(&s_acc[r], hr * xr);
+                s_beta[e] = beta;
+            }
+            // ---- stage B2: gathers.  A thread's packets are independent: issue all home-slot loads first
+            // (kGCPull requests in flight per lane), then resolve and accumulate -----------------------------
+            if (!(bs.debug_ablate & 2)) {
+                const uint64_t hmask = (1ULL << tab_bits) - 1;
+                uint64_t key[kGCPull], slot[kGCPull];
+                ulonglong2 first[kGCPull];
+                double im0[kGCPull];
+                bool live[kGCPull];
+#pragma unroll
+                for (int k = 0; k < kGCPull; ++k) {
+                    const int e = tid + k * kBlock;
+                    live[k] = e < n && s_row[e] != 0xffff;
+                    key[k] = 0; slot[k] = 0; im0[k] = 0.0;
+                    first[k] = make_ulonglong2(0, 0);
+                    if (live[k]) {
+                        key[k] = s_beta[e];
+                        slot[k] = hash_slot(key[k], tab_bits);
+                        first[k] = *(ulonglong2 const *)(tab + slot[k] * ES);
+                        if (CPLX) im0[k] = __longlong_as_double((long long)tab[slot[k] * ES + 2]);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < kGCPull; ++k) {
+                    if (!live[k]) continue;
+                    const int e = tid + k * kBlock;
+                    double xr, xi = 0.0;
+                    if (first[k].x == key[k]) {
+                        xr = __longlong_as_double((long long)first[k].y);
+                        if (CPLX) xi = im0[k];
+                    } else {
+                        // collision (load factor <= 0.5: ~1 in 4): continue the probe sequence
+                        bool found = false;
+                        uint64_t sl = slot[k];
+                        uint64_t cur = first[k].x;
+                        while (cur != kHashEmpty) {
+                            sl = (sl + 1) & hmask;
+                            const ulonglong2 en = *(ulonglong2 const *)(tab + sl * ES);
+                            cur = en.x;
+                            if (cur == key[k]) {
+                                xr = __longlong_as_double((long long)en.y);
+                                if (CPLX) xi = __longlong_as_double((long long)tab[sl * ES + 2]);
+                                found = true;
+                                break;
+                            }
+                        }
+                        if (!found) { atomicExch(err, 1); continue; }
+                    }
+                    double hr, hi = 0.0;
+                    if (RC) hr = s_coef[e]; else { hr = s_coef[2 * e]; hi = s_coef[2 * e + 1]; }
+                    const int r = s_row[e];
+                    if (CPLX) {
+                        atomicAdd(&s_acc[2 * r], hr * xr - hi * xi);
+                        atomicAdd(&s_acc[2 * r + 1], hr * xi + hi * xr);
+                    } else {
+                        atomicAdd(&s_acc[r], hr * xr);
+                    }
                 }
             }
             __syncthreads();
