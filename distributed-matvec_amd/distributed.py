@@ -57,11 +57,37 @@ class _Transport:
         return self._Done() if async_op else None
 
     def exchange_blocks(self, send, outs, rank, P):
-        """every rank's `send` lands in outs[rank] of every peer (outs[rank] itself is written locally)."""
+        """every rank's `send` lands in outs[rank] of every peer (outs[rank] itself is written locally).
+        Grouped point-to-point by default; LS_AMD_XGATHER=allgather (or a failing P2P batch) switches to
+        all_gather on blocks padded to the largest one."""
         dist = self.dist
         outs[rank].copy_(send)
         if P == 1:
             return
+        if getattr(self, "use_allgather", None) is None:
+            self.use_allgather = os.environ.get("LS_AMD_XGATHER", "p2p") == "allgather"
+        if not self.use_allgather:
+            try:
+                return self._exchange_p2p(send, outs, rank, P)
+            except RuntimeError as e:  # e.g. a backend without grouped send/recv
+                import warnings
+
+                warnings.warn(f"grouped send/recv failed ({e!r}); falling back to all_gather")
+                self.use_allgather = True
+        torch = self.torch
+        mc = max(int(o.numel()) for o in outs)
+        stage = not self.direct and send.is_cuda
+        dev = "cpu" if stage else send.device
+        padded = torch.zeros(mc, dtype=send.dtype, device=dev)
+        padded[: send.numel()].copy_(send)
+        bufs = [torch.empty(mc, dtype=send.dtype, device=dev) for _ in range(P)]
+        dist.all_gather(bufs, padded, group=self.group)
+        for p in range(P):
+            if p != rank:
+                outs[p].copy_(bufs[p][: outs[p].numel()])
+
+    def _exchange_p2p(self, send, outs, rank, P):
+        dist = self.dist
         stage = not self.direct and send.is_cuda
         src_t = send.cpu() if stage else send
         bufs = {}

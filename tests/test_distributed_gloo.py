@@ -183,7 +183,8 @@ class OracleReplicatedEngine:
         pass
 
 
-def _worker_replicated(rank, world, port, name, cplx, out_dir):
+def _worker_replicated(rank, world, port, name, cplx, out_dir, xgather="p2p"):
+    os.environ["LS_AMD_XGATHER"] = xgather
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from helpers import model_config
@@ -215,14 +216,16 @@ def _worker_replicated(rank, world, port, name, cplx, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name,world,cplx", [("heisenberg_chain_12", 2, False), ("heisenberg_kagome_12_symm", 3, True)])
-def test_replicated_x_exchange(tmp_path, name, world, cplx):
+@pytest.mark.parametrize("name,world,cplx,xgather", [("heisenberg_chain_12", 2, False, "p2p"),
+                                                     ("heisenberg_kagome_12_symm", 3, True, "p2p"),
+                                                     ("heisenberg_chain_10", 3, False, "allgather")])
+def test_replicated_x_exchange(tmp_path, name, world, cplx, xgather):
     sys.path.insert(0, ROOT)
     from helpers import oracle_for, oracle_reps
     from oracle import c_oracle as CO
 
-    port = 29900 + (os.getpid() % 90) + world
-    mp.spawn(_worker_replicated, args=(world, port, name, cplx, str(tmp_path)), nprocs=world, join=True)
+    port = 29900 + (os.getpid() % 90) + world + (11 if xgather == "allgather" else 0)
+    mp.spawn(_worker_replicated, args=(world, port, name, cplx, str(tmp_path), xgather), nprocs=world, join=True)
     reps = oracle_reps(name)
     rs = np.random.RandomState(6)
     x = rs.rand(len(reps)) - 0.5
