@@ -902,6 +902,14 @@ struct ls_amd_plan {
     lsk_highpart hp;
     lsk_operator dop_low; /* dop with the exchange runs truncated to the pairs below the high part */
     void *hp_alloc[7];
+    /* tile map of the row kernels (lsk_tilemap in lsk.h) */
+    lsk_tilemap tilemap;
+    void *d_tilemap;
+    int tilemap_transposed;
+    /* two-table pull kernel (lsk_lin in lsk.h) */
+    int has_lin;
+    lsk_lin lin;
+    void *lin_alloc[3];
     void *d_htab;        /* hash table {rep -> x * norm(rep)} of the tile-pull families */
     uint32_t *d_slot_of; /* slot of every (global) representative */
     int htab_bits;
@@ -1084,6 +1092,161 @@ static int setup_highpart(ls_amd_plan *pl, int t) {
     return rc;
 }
 
+/* Tile map of the row kernels (lsk_tilemap in lsk.h).
+ *
+ * Default: XCD k gets the k-th contiguous eighth of the row tiles.
+ *
+ * Transposed (the full fixed-Hamming-weight basis in ascending order): write a state as (T, rest) with T its
+ * top `t` bits.  All states with one T form a contiguous segment of C(L - t, weight - popcount(T)) rows,
+ * and a flip mask that only touches top bits maps (T, rest) to (T', rest): the same offset in another
+ * segment of the same popcount class.  A *set* = the same window of offsets in every segment of a
+ * class; it is closed under the top flips, and under the low flips that stay inside the window.  Each
+ * set goes to one XCD, whose resident blocks work through it concurrently (consecutive slots = the same
+ * offsets in different segments), so the partners' lines are in that XCD's L2 while they are needed
+ * instead of being fetched again from HBM.  LS_AMD_TOP_BITS (t; 0 = default map) and LS_AMD_SET_ROWS
+ * (rows per set) tune it. */
+typedef struct { uint64_t *e; int64_t n, cap; } tile_list;
+static void tile_push(tile_list *l, int64_t row, int64_t cnt) {
+    if (l->n == l->cap) { l->cap = l->cap ? 2 * l->cap : 1024; l->e = (uint64_t *)realloc(l->e, sizeof(uint64_t) * (size_t)l->cap); }
+    l->e[l->n++] = (uint64_t)row | ((uint64_t)cnt << 48);
+}
+static int build_tilemap(ls_amd_plan *pl, int64_t n, int allow_transposed) {
+    enum { TILE = 256 };
+    tile_list lists[8];
+    memset(lists, 0, sizeof(lists));
+    ls_hs_basis const *b = pl->op->basis;
+    int const L = b->number_sites, hw = b->ext->hamming_weight;
+    char const *e = getenv("LS_AMD_TOP_BITS");
+    int t = e ? atoi(e) : 8;
+    e = getenv("LS_AMD_SET_ROWS");
+    int64_t set_rows = e ? atoll(e) : 65536;
+    if (set_rows < TILE) set_rows = TILE;
+    if (t > 12) t = 12;
+    if (t > L - 2) t = L - 2;
+    int const transposed = allow_transposed && t >= 2 && hw >= 0 && b->spin_inversion == 0 && (uint64_t)n == binom(L, hw);
+    if (!transposed) {
+        int64_t const tiles = (n + TILE - 1) / TILE, per = (tiles + 7) / 8;
+        for (int k = 0; k < 8; ++k)
+            for (int64_t q = k * per; q < (k + 1) * per && q < tiles; ++q)
+                tile_push(&lists[k], q * TILE, n - q * TILE < TILE ? n - q * TILE : TILE);
+    } else {
+        int const Lr = L - t, nT = 1 << t;
+        int64_t *base = (int64_t *)malloc(sizeof(int64_t) * (size_t)(nT + 1));
+        int64_t acc = 0;
+        for (int T = 0; T < nT; ++T) { /* ascending states <=> ascending top patterns */
+            base[T] = acc;
+            acc += (int64_t)binom(Lr, hw - __builtin_popcount((unsigned)T));
+        }
+        base[nT] = acc;
+        int64_t rows_of[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        int *segs = (int *)malloc(sizeof(int) * (size_t)nT);
+        for (int j = 0; j <= t; ++j) {
+            int64_t const len = (int64_t)binom(Lr, hw - j);
+            if (len == 0) continue;
+            int nseg = 0;
+            for (int T = 0; T < nT; ++T) if (__builtin_popcount((unsigned)T) == j) segs[nseg++] = T;
+            int64_t W = TILE;
+            while (W * 2 * nseg <= set_rows) W *= 2;
+            for (int64_t w0 = 0; w0 < len; w0 += W) {
+                int k = 0; /* the least loaded XCD takes the set */
+                for (int q = 1; q < 8; ++q) if (rows_of[q] < rows_of[k]) k = q;
+                for (int64_t off = w0; off < w0 + W && off < len; off += TILE)
+                    for (int sgi = 0; sgi < nseg; ++sgi) {
+                        int64_t const cnt = len - off < TILE ? len - off : TILE;
+                        tile_push(&lists[k], base[segs[sgi]] + off, cnt);
+                        rows_of[k] += cnt;
+                    }
+            }
+        }
+        free(base); free(segs);
+    }
+    int64_t slots = 0, total = 0;
+    for (int k = 0; k < 8; ++k) if (lists[k].n > slots) slots = lists[k].n;
+    uint64_t *flat = (uint64_t *)calloc((size_t)(8 * slots > 0 ? 8 * slots : 1), sizeof(uint64_t));
+    for (int k = 0; k < 8; ++k) {
+        for (int64_t q = 0; q < lists[k].n; ++q) { flat[k * slots + q] = lists[k].e[q]; total += (int64_t)(lists[k].e[q] >> 48); }
+        free(lists[k].e);
+    }
+    int rc = total == n ? upload(&pl->d_tilemap, flat, sizeof(uint64_t) * (size_t)(8 * slots > 0 ? 8 * slots : 1)) : -2;
+    free(flat);
+    if (rc == -2) return set_error("internal error: tile map covers %lld of %lld rows", (long long)total, (long long)n);
+    if (rc) return -1;
+    pl->tilemap.entries = (uint64_t const *)pl->d_tilemap;
+    pl->tilemap.slots_per_xcd = slots;
+    pl->tilemap_transposed = transposed;
+    return 0;
+}
+
+/* Two-table ranking for the row kernel (lsk_lin in lsk.h): applies to the full fixed-Hamming-weight basis
+ * without symmetries and a real Hermitian operator.  LS_AMD_LIN=0 keeps the combinadic row kernel,
+ * LS_AMD_LIN_BITS sets the width of the low part. */
+static int setup_lin(ls_amd_plan *pl) {
+    ls_hs_basis const *b = pl->op->basis;
+    struct ls_amd_operator_ext const *ext = pl->op->ext;
+    int const L = b->number_sites, hw = b->ext->hamming_weight;
+    char const *e = getenv("LS_AMD_LIN"); /* off by default: measured slower on chain_32 */
+    if (!e || atoi(e) == 0) return 0;
+    if (hw < 0 || b->spin_inversion != 0 || pl->dbs.proj != LSK_PROJ_NONE || !ext->is_real || !ext->is_hermitian) return 0;
+    e = getenv("LS_AMD_LIN_BITS");
+    int B = e ? atoi(e) : 14;
+    if (B > 15) B = 15;
+    if (B < 1) B = 1;
+    int const hb = L > B ? L - B : 0; /* width of the high part */
+    if (hb > 26) return 0;
+    int const n = ext->n_groups;
+    uint64_t const LM = (1ULL << B) - 1;
+    e = getenv("LS_AMD_NT_LO");
+    int const nt_lo = e ? atoi(e) : 64;
+    /* groups: low, mixed, high (EXCHANGE pairs), then generic */
+    lsk_lin_group *lg = (lsk_lin_group *)calloc(n > 0 ? n : 1, sizeof(lsk_lin_group));
+    int cnt[4] = {0, 0, 0, 0}, k = 0;
+    for (int pass = 0; pass < 4; ++pass)
+        for (int g = 0; g < n; ++g) {
+            lsk_group const *G = &ext->groups[g];
+            int cls = 3;
+            if (G->fast == LSK_GROUP_EXCHANGE && __builtin_popcountll(G->x) == 2 && G->v_im == 0.0)
+                cls = (G->x & ~LM) == 0 ? 0 : (G->x & LM) == 0 ? 2 : 1;
+            if (cls != pass) continue;
+            lg[k].xlo = (uint32_t)(G->x & LM);
+            lg[k].xhi = (uint32_t)(G->x >> B);
+            lg[k].v = G->v_re;
+            lg[k].g = g;
+            lg[k].pad = nt_lo < 64 && (__builtin_ctzll(G->x) >= nt_lo || G->adj < 0); /* far pair: streaming gathers */
+            ++k;
+            ++cnt[pass];
+        }
+    uint16_t *tlo = (uint16_t *)malloc(sizeof(uint16_t) << B);
+    for (uint32_t l = 0; l < (1u << B); ++l) {
+        uint64_t r = 0;
+        int j = 1;
+        for (uint32_t s = l; s; s &= s - 1, ++j) r += binom(__builtin_ctz(s), j);
+        tlo[l] = (uint16_t)r;
+    }
+    int const wide = L > 32;
+    size_t const nh = (size_t)1 << hb, es = wide ? 8 : 4;
+    void *thi = malloc(nh * es);
+    for (size_t h = 0; h < nh; ++h) {
+        int const kl = hw - __builtin_popcountll((unsigned long long)h);
+        uint64_t r = 0;
+        if (kl >= 0 && kl <= B) {
+            int j = kl + 1;
+            for (uint64_t s = h; s; s &= s - 1, ++j) r += binom(B + __builtin_ctzll(s), j);
+        }
+        if (wide) ((uint64_t *)thi)[h] = r; else ((uint32_t *)thi)[h] = (uint32_t)r;
+    }
+    int rc = upload(&pl->lin_alloc[0], lg, sizeof(lsk_lin_group) * (n > 0 ? n : 1)) ||
+             upload(&pl->lin_alloc[1], tlo, sizeof(uint16_t) << B) || upload(&pl->lin_alloc[2], thi, nh * es);
+    free(lg); free(tlo); free(thi);
+    if (rc) return -1;
+    pl->lin.bits = B;
+    pl->lin.n_low = cnt[0]; pl->lin.n_mixed = cnt[1]; pl->lin.n_high = cnt[2]; pl->lin.n_generic = cnt[3];
+    pl->lin.groups = (lsk_lin_group const *)pl->lin_alloc[0];
+    pl->lin.tlo = (uint16_t const *)pl->lin_alloc[1];
+    pl->lin.thi = pl->lin_alloc[2];
+    pl->has_lin = 1;
+    return 0;
+}
+
 static int plan_setup_part(ls_amd_plan *pl, part_state *ps, int part_id, int num_rounds, void *stream) {
     ls_hs_basis const *b = pl->op->basis;
     int const L = b->number_sites;
@@ -1244,12 +1407,17 @@ int ls_amd_plan_create(ls_amd_plan **out, ls_hs_operator const *op, ls_amd_dtype
         if (plan_setup_part(pl, ps, pid, num_rounds, stream) != 0) { ls_amd_plan_destroy(pl); return -1; }
         if (ps->max_send_bytes > pl->send_capacity) pl->send_capacity = ps->max_send_bytes;
     }
+    if (pl->family == FAMILY_DIRECT_PULL || pl->family == FAMILY_DIRECT_PUSH) {
+        int const combinadic = pl->parts[0].index.kind == LSK_INDEX_COMBINADIC;
+        if (build_tilemap(pl, pl->parts[0].count, combinadic && pl->family == FAMILY_DIRECT_PULL) != 0) { ls_amd_plan_destroy(pl); return -1; }
+    }
     if (pl->family == FAMILY_DIRECT_PULL && pl->parts[0].index.kind == LSK_INDEX_COMBINADIC) {
         /* off by default: measured on chain_32 the two-pass scheme is slower (12.9 + 10.2 ms vs 15.7 ms);
          * kept as an option because it bounds the far-bond traffic for longer chains */
         char const *e = getenv("LS_AMD_HIGH_BITS");
         int t = e ? atoi(e) : 0;
         if (t > 0 && setup_highpart(pl, t) != 0) { ls_amd_plan_destroy(pl); return -1; }
+        if (!pl->has_highpart && setup_lin(pl) != 0) { ls_amd_plan_destroy(pl); return -1; }
     }
     if (pl->family == FAMILY_TILE && my_partition < 0 && pl->send_capacity > 0) {
         if (lsk_malloc(&pl->d_send, (size_t)pl->send_capacity) != 0) { ls_amd_plan_destroy(pl); return dev_error(); }
@@ -1275,6 +1443,8 @@ void ls_amd_plan_destroy(ls_amd_plan *pl) {
     if (pl->d_row_gidx) lsk_free(pl->d_row_gidx);
     if (pl->d_norms_global) lsk_free(pl->d_norms_global);
     for (int i = 0; i < 7; ++i) if (pl->hp_alloc[i]) lsk_free(pl->hp_alloc[i]);
+    for (int i = 0; i < 3; ++i) if (pl->lin_alloc[i]) lsk_free(pl->lin_alloc[i]);
+    if (pl->d_tilemap) lsk_free(pl->d_tilemap);
     if (pl->d_htab) lsk_free(pl->d_htab);
     if (pl->d_slot_of) lsk_free(pl->d_slot_of);
     if (pl->d_send) lsk_free(pl->d_send);
@@ -1340,6 +1510,11 @@ int ls_amd_plan_create_replicated(ls_amd_plan **out, ls_hs_operator const *op, l
         pl->gindex = gps.index;
         pl->d_gtable = gps.d_table;
     }
+    if (pl->family == FAMILY_REPL_DIRECT && build_tilemap(pl, count_local, 0) != 0) { ls_amd_plan_destroy(pl); return -1; }
+    if (pl->family == FAMILY_REPL_DIRECT && pl->gindex.kind == LSK_INDEX_COMBINADIC && setup_lin(pl) != 0) {
+        ls_amd_plan_destroy(pl);
+        return -1;
+    }
     if (pl->gindex.kind == LSK_INDEX_SEARCH && count_local > 0) {
         if (lsk_malloc(&p, 8 * (size_t)count_local) != 0) { ls_amd_plan_destroy(pl); return dev_error(); }
         pl->d_row_gidx = (int64_t *)p;
@@ -1365,7 +1540,11 @@ int ls_amd_matvec_replicated(ls_amd_plan *pl, void const *d_x_global, void *d_y_
     int slot;
     if (pl->family == FAMILY_REPL_DIRECT) {
         slot = timing_begin(pl, stream);
-        DEV(lsk_direct_gx(pl->dop, pl->dbs, pl->gindex, pl->cplx, ps->count, ps->d_reps, pl->d_row_gidx, d_x_global,
+        if (pl->has_lin)
+            DEV(lsk_lin_pull(pl->lin, pl->dop, pl->dbs, pl->cplx, 1, ps->count, ps->d_reps, d_x_global, d_y_local,
+                             pl->d_err, stream));
+        else
+        DEV(lsk_direct_gx(pl->dop, pl->dbs, pl->gindex, pl->cplx, pl->tilemap, ps->d_reps, pl->d_row_gidx, d_x_global,
                           d_y_local, pl->d_err, stream));
         timing_end(pl, slot, stream);
         return 0;
@@ -1384,9 +1563,9 @@ int ls_amd_matvec_replicated(ls_amd_plan *pl, void const *d_x_global, void *d_y_
 char const *ls_amd_plan_kernel_name(ls_amd_plan const *pl) {
     switch (pl->family) {
     case FAMILY_DIRECT_PUSH: return "direct-push";
-    case FAMILY_DIRECT_PULL: return pl->has_highpart ? "direct-pull+highpart" : "direct-pull";
+    case FAMILY_DIRECT_PULL: return pl->has_highpart ? "direct-pull+highpart" : pl->has_lin ? "direct-pull+lin" : "direct-pull";
     case FAMILY_TILE_PULL: return "tile-pull";
-    case FAMILY_REPL_DIRECT: return "replicated-direct-pull";
+    case FAMILY_REPL_DIRECT: return pl->has_lin ? "replicated-direct-pull+lin" : "replicated-direct-pull";
     case FAMILY_REPL_TILE: return "replicated-tile-pull";
     default: return "tile";
     }
@@ -1474,8 +1653,12 @@ int ls_amd_matvec(ls_amd_plan *pl, void const *const *d_x, void *const *d_y, voi
     if (pl->family != FAMILY_TILE) {
         part_state *ps = &pl->parts[0];
         int slot = timing_begin(pl, stream);
+        if (pl->has_lin)
+            DEV(lsk_lin_pull(pl->lin, pl->dop, pl->dbs, pl->cplx, 0, ps->count, ps->d_reps, d_x[0], d_y[0], pl->d_err,
+                             stream));
+        else
         DEV(lsk_direct(pl->has_highpart ? pl->dop_low : pl->dop, pl->dbs, ps->index, pl->cplx,
-                       pl->family == FAMILY_DIRECT_PULL, ps->count, ps->d_reps, d_x[0], d_y[0], pl->d_err, stream));
+                       pl->family == FAMILY_DIRECT_PULL, pl->tilemap, ps->d_reps, d_x[0], d_y[0], pl->d_err, stream));
         if (pl->has_highpart) DEV(lsk_highpart_apply(pl->hp, pl->cplx, d_x[0], d_y[0], stream));
         timing_end(pl, slot, stream);
         return 0;

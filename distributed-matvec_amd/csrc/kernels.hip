@@ -92,7 +92,7 @@ constexpr int kMaxGrid = 256 * 8; // 256 CUs x 8 resident blocks: grid-stride be
 #include <map>
 static int g_num_cus = 0;
 template <typename K>
-static int resident_grid(K kernel, int64_t work_blocks, size_t dyn_lds = 0) {
+static int resident_grid(K kernel, int64_t work_blocks, size_t dyn_lds = 0, int block = kBlock) {
     static std::map<std::pair<void const *, size_t>, int> cache;
     if (g_num_cus == 0) {
         hipDeviceProp_t prop;
@@ -105,7 +105,7 @@ static int resident_grid(K kernel, int64_t work_blocks, size_t dyn_lds = 0) {
     int per_cu;
     if (it == cache.end()) {
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, kBlock, dyn_lds) != hipSuccess || nb < 1) nb = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, block, dyn_lds) != hipSuccess || nb < 1) nb = 1;
         if (nb > 8) nb = 8;
         cache[key] = nb;
         per_cu = nb;
@@ -582,15 +582,16 @@ extern "C" int lsk_diag(lsk_operator op, int cplx, int64_t n, uint64_t const *re
 // loop: the rank of the target differs from the row's own rank by +-C(lo, k) with k = number of set
 // bits below lo, which is carried incrementally; inactive lanes gather their own x and add 0, so
 // the compiler can unroll and keep several gathers in flight.
-// Row tiles are dealt to XCDs in contiguous ranges (block b runs on XCD b % 8), so that each
-// XCD's L2 sees one eighth of x / y for the short-range flips.
+// Row tiles come from a host-built tile map (lsk_tile_entry, lsk.h): block b runs on XCD b % 8 and
+// walks that XCD's list of tiles, so the traversal order -- which decides what the XCD's L2 can
+// reuse -- is data, not code.
 // ---------------------------------------------------------------------------------------------
 template <typename W, bool CPLX, int INDEX, bool INV, bool PULL, bool REAL>
 __global__ __launch_bounds__(kBlock) void k_direct(lsk_runs runs, int n_groups, lsk_group const *__restrict__ groups,
                                                    lsk_term const *__restrict__ off, int n_diag,
                                                    lsk_term const *__restrict__ diag, lsk_basis bs,
-                                                   lsk_index ix, int64_t n, int64_t tiles_per_xcd,
-                                                   uint64_t const *__restrict__ reps,
+                                                   lsk_index ix, uint64_t const *__restrict__ tilemap,
+                                                   int64_t slots_per_xcd, uint64_t const *__restrict__ reps,
                                                    double const *__restrict__ x, double *y, int *err, int gx,
                                                    int64_t const *__restrict__ row_gidx) {
     typedef typename WordTraits<W>::binom_t BT;
@@ -603,14 +604,16 @@ __global__ __launch_bounds__(kBlock) void k_direct(lsk_runs runs, int n_groups, 
     const int xcd = blockIdx.x & 7;
     const int64_t blocks_per_xcd = gridDim.x >> 3; // grid is a multiple of 8
     const W site_mask = (W)bs.site_mask;
-    for (int64_t t = blockIdx.x >> 3; t < tiles_per_xcd; t += blocks_per_xcd) {
-        const int64_t i = ((int64_t)xcd * tiles_per_xcd + t) * kBlock + threadIdx.x;
-        if (i >= n) continue;
-        const W a = (W)reps[i];
+    tilemap += (int64_t)xcd * slots_per_xcd;
+    for (int64_t t = blockIdx.x >> 3; t < slots_per_xcd; t += blocks_per_xcd) {
+        const uint64_t slot = tilemap[t]; // (first row, number of rows <= kBlock): lsk_tile_entry
+        if ((uint64_t)threadIdx.x >= (slot >> 48)) continue;
+        const int64_t i = (int64_t)(slot & 0xffffffffffffULL) + threadIdx.x;
+        const W a = (W)__builtin_nontemporal_load(reps + i);
         // replicated-x mode (gx): rows are one hash partition, x is the whole vector in global ascending
         // order; ig = global index of this row (closed form, or precomputed for searched bases)
         int64_t ig = i;
-        if (gx) {
+        if (gx & 1) {
             if (INDEX == LSK_INDEX_COMBINADIC) ig = rank_combinadic_w<W, BT>(a, s_binom);
             else if (INDEX == LSK_INDEX_IDENTITY) ig = (int64_t)a;
             else ig = row_gidx[i];
@@ -636,8 +639,45 @@ __global__ __launch_bounds__(kBlock) void k_direct(lsk_runs runs, int n_groups, 
                 const int lo0 = runs.lo0[r], cnt = runs.cnt[r];
                 const double vr = runs.v_re[r], vi = REAL ? 0.0 : runs.v_im[r];
                 int k = WT::popc(a & (W)(((uint64_t)1 << lo0) - 1));
+                int lo_begin = lo0, lo_end = lo0 + cnt;
+                if (sizeof(W) == 4 && PULL && !CPLX && REAL && !(gx & 1)) {
+                    // Far pairs (lo >= hb): the 64 consecutive states of a wave nearly always agree on every
+                    // bit >= hb, so such a pair is anti-aligned for the whole wave or for none of it.  The
+                    // test, the bit count below the pair and the rank shift are then wave-uniform (scalar
+                    // unit), an aligned pair issues no gather at all, and an anti-aligned one costs an
+                    // add, an address and an fma per lane.
+                    const int hb = (gx >> 24) & 63;
+                    const int split = hb == 0 ? lo_end : (hb < lo0 ? lo0 : (hb > lo_end ? lo_end : hb));
+                    const uint32_t a0 = __builtin_amdgcn_readfirstlane((uint32_t)a);
+                    const bool uni = split < lo_end &&
+                                     __builtin_amdgcn_ballot_w64((((uint32_t)a ^ a0) >> split) != 0) == 0;
+                    if (uni) {
+                        uint32_t m = (a0 ^ (a0 >> 1)) & (uint32_t)((((uint64_t)1 << lo_end) - 1) & ~(((uint64_t)1 << split) - 1));
+                        const uint32_t i32 = (uint32_t)ig;
+                        while (m) {
+                            double xv[4];
+                            bool ok[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                ok[u] = m != 0;
+                                xv[u] = 0.0;
+                                if (ok[u]) {
+                                    const int lo = __builtin_ctz(m);
+                                    m &= m - 1;
+                                    const int kk = bs.hamming_weight - __popc(a0 >> lo); // set bits below lo
+                                    const uint32_t d = (uint32_t)s_binom[lo * LSK_BINOM_K + kk];
+                                    const uint32_t idx = ((a0 >> lo) & 1) ? i32 + d : i32 - d;
+                                    xv[u] = x[idx];
+                                }
+                            }
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) accr = fma(ok[u] ? vr : 0.0, xv[u], accr);
+                        }
+                        lo_end = split;
+                    }
+                }
 #pragma unroll 4
-                for (int lo = lo0; lo < lo0 + cnt; ++lo) {
+                for (int lo = lo_begin; lo < lo_end; ++lo) {
                     const bool bit = (a >> lo) & 1;
                     const bool act = (tdiff >> lo) & 1;
                     const BT d = s_binom[lo * LSK_BINOM_K + k];
@@ -729,36 +769,64 @@ __global__ __launch_bounds__(kBlock) void k_direct(lsk_runs runs, int n_groups, 
             }
         }
         if (PULL) {
-            if (CPLX) { y[2 * i] = accr; y[2 * i + 1] = acci; } else y[i] = accr;
+            if (CPLX) { y[2 * i] = accr; y[2 * i + 1] = acci; } else __builtin_nontemporal_store(accr, y + i);
         }
     }
 }
 
+// first pair index handled wave-uniformly by the 32-bit pull row kernel (LS_AMD_HIGH_PAIR; 0 = off)
+static int high_pair_setting() {
+    static int v = -1;
+    if (v < 0) {
+        char const *e = getenv("LS_AMD_HIGH_PAIR");
+        v = e ? atoi(e) : 14;
+        if (v < 0 || v > 63) v = 0;
+    }
+    return v;
+}
+
+// log2 of the number of consecutive row tiles dealt to one XCD before moving to the next XCD
+// (LS_AMD_XCD_CHUNK; 0 = each XCD gets one contiguous eighth of the rows)
+static int xcd_chunk_setting() {
+    static int v = -1;
+    if (v < 0) {
+        char const *e = getenv("LS_AMD_XCD_CHUNK");
+        v = e ? atoi(e) : 0;
+        if (v < 0 || v > 24) v = 0;
+    }
+    return v;
+}
+
 template <typename W, bool CPLX, int INDEX, bool INV, bool PULL>
-static int launch_direct3(lsk_operator op, lsk_basis bs, lsk_index ix, int64_t n, uint64_t const *reps,
+static int launch_direct3(lsk_operator op, lsk_basis bs, lsk_index ix, lsk_tilemap tm, uint64_t const *reps,
                           void const *x, void *y, int *d_err, void *stream, int gx, int64_t const *row_gidx) {
-    int64_t tiles = (n + kBlock - 1) / kBlock;
-    int64_t tiles_per_xcd = (tiles + 7) / 8;
-    int64_t gb = tiles_per_xcd * 8;
+    int64_t gb = tm.slots_per_xcd * 8;
     int64_t cap = op.is_real ? resident_grid(k_direct<W, CPLX, INDEX, INV, PULL, true>, gb)
                              : resident_grid(k_direct<W, CPLX, INDEX, INV, PULL, false>, gb);
+    static int blocks_per_cu = -1; // LS_AMD_BLOCKS_PER_CU: occupancy experiments
+    if (blocks_per_cu < 0) {
+        char const *e = getenv("LS_AMD_BLOCKS_PER_CU");
+        blocks_per_cu = e ? atoi(e) : 0;
+    }
+    if (blocks_per_cu > 0 && (int64_t)blocks_per_cu * g_num_cus < cap) cap = (int64_t)blocks_per_cu * g_num_cus;
     cap &= ~(int64_t)7; // XCD dealing needs a multiple of 8
     if (cap < 8) cap = 8;
     if (gb > cap) gb = cap;
     dim3 g((unsigned)gb), b(kBlock);
+    gx = (gx & 1) | (high_pair_setting() << 24);
     if (op.is_real)
         hipLaunchKernelGGL((k_direct<W, CPLX, INDEX, INV, PULL, true>), g, b, 0, (hipStream_t)stream, op.runs,
-                           op.n_groups, op.groups, op.off, op.n_diag, op.diag, bs, ix, n, tiles_per_xcd, reps,
+                           op.n_groups, op.groups, op.off, op.n_diag, op.diag, bs, ix, tm.entries, tm.slots_per_xcd, reps,
                            (double const *)x, (double *)y, d_err, gx, row_gidx);
     else
         hipLaunchKernelGGL((k_direct<W, CPLX, INDEX, INV, PULL, false>), g, b, 0, (hipStream_t)stream, op.runs,
-                           op.n_groups, op.groups, op.off, op.n_diag, op.diag, bs, ix, n, tiles_per_xcd, reps,
+                           op.n_groups, op.groups, op.off, op.n_diag, op.diag, bs, ix, tm.entries, tm.slots_per_xcd, reps,
                            (double const *)x, (double *)y, d_err, gx, row_gidx);
     LSK_LAUNCH_CHECK();
     return 0;
 }
 template <typename W, bool CPLX, int INDEX>
-static int launch_direct2(lsk_operator op, lsk_basis bs, lsk_index ix, int pull, int64_t n,
+static int launch_direct2(lsk_operator op, lsk_basis bs, lsk_index ix, int pull, lsk_tilemap n,
                           uint64_t const *reps, void const *x, void *y, int *d_err, void *stream, int gx,
                           int64_t const *row_gidx) {
     const bool inv = bs.proj == LSK_PROJ_INVERSION;
@@ -770,7 +838,7 @@ static int launch_direct2(lsk_operator op, lsk_basis bs, lsk_index ix, int pull,
     return launch_direct3<W, CPLX, INDEX, false, false>(op, bs, ix, n, reps, x, y, d_err, stream, gx, row_gidx);
 }
 template <bool CPLX, int INDEX>
-static int launch_direct1(lsk_operator op, lsk_basis bs, lsk_index ix, int pull, int64_t n,
+static int launch_direct1(lsk_operator op, lsk_basis bs, lsk_index ix, int pull, lsk_tilemap n,
                           uint64_t const *reps, void const *x, void *y, int *d_err, void *stream, int gx,
                           int64_t const *row_gidx) {
     // 32-bit states: every site, and every rank, fits 32 bits (C(32, 16) < 2^31)
@@ -778,10 +846,11 @@ static int launch_direct1(lsk_operator op, lsk_basis bs, lsk_index ix, int pull,
         return launch_direct2<uint32_t, CPLX, INDEX>(op, bs, ix, pull, n, reps, x, y, d_err, stream, gx, row_gidx);
     return launch_direct2<uint64_t, CPLX, INDEX>(op, bs, ix, pull, n, reps, x, y, d_err, stream, gx, row_gidx);
 }
-static int direct_dispatch(lsk_operator op, lsk_basis bs, lsk_index ix, int cplx, int pull, int64_t n,
+static int direct_dispatch(lsk_operator op, lsk_basis bs, lsk_index ix, int cplx, int pull, lsk_tilemap n,
                            uint64_t const *reps, void const *x, void *y, int *d_err, void *stream, int gx,
                            int64_t const *row_gidx) {
-    if (n == 0) return 0;
+    if (n.slots_per_xcd == 0) return 0;
+    if (!n.entries) { snprintf(g_err, sizeof(g_err), "lsk_direct: no tile map"); return -1; }
     if (bs.proj == LSK_PROJ_FULL) { snprintf(g_err, sizeof(g_err), "lsk_direct: basis needs projection"); return -1; }
     switch (ix.kind) {
     case LSK_INDEX_IDENTITY:
@@ -795,15 +864,205 @@ static int direct_dispatch(lsk_operator op, lsk_basis bs, lsk_index ix, int cplx
                     : launch_direct1<false, LSK_INDEX_SEARCH>(op, bs, ix, pull, n, reps, x, y, d_err, stream, gx, row_gidx);
     }
 }
-extern "C" int lsk_direct(lsk_operator op, lsk_basis bs, lsk_index ix, int cplx, int pull, int64_t n,
+extern "C" int lsk_direct(lsk_operator op, lsk_basis bs, lsk_index ix, int cplx, int pull, lsk_tilemap tm,
                           uint64_t const *reps, void const *x, void *y, int *d_err, void *stream) {
-    return direct_dispatch(op, bs, ix, cplx, pull, n, reps, x, y, d_err, stream, 0, nullptr);
+    return direct_dispatch(op, bs, ix, cplx, pull, tm, reps, x, y, d_err, stream, 0, nullptr);
 }
 // replicated-x pull: `reps` = the n rows of one partition, `x` = whole vector in global order, `ix` = index
 // of the GLOBAL basis, row_gidx[i] = global index of row i (only read for SEARCH indices)
-extern "C" int lsk_direct_gx(lsk_operator op, lsk_basis bs, lsk_index ix, int cplx, int64_t n, uint64_t const *reps,
+extern "C" int lsk_direct_gx(lsk_operator op, lsk_basis bs, lsk_index ix, int cplx, lsk_tilemap tm, uint64_t const *reps,
                              int64_t const *row_gidx, void const *x_global, void *y, int *d_err, void *stream) {
-    return direct_dispatch(op, bs, ix, cplx, 1, n, reps, x_global, y, d_err, stream, 1, row_gidx);
+    return direct_dispatch(op, bs, ix, cplx, 1, tm, reps, x_global, y, d_err, stream, 1, row_gidx);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Two-table pull kernel (lsk_lin in lsk.h).  One row per lane; 64 consecutive rows of the ascending
+// fixed-weight basis nearly always share their high part h, and then
+//   * a flip mask that only touches high bits is active for the whole wave or not at all (scalar
+//     test; an inactive mask costs no vector instruction), and its target is  thi[h ^ xhi] + tlo[l]:
+//     one scalar load, one vector add, one gather of 64 contiguous x;
+//   * a mask with low bits needs one LDS read tlo[l ^ xlo] per lane.
+// Waves that straddle two high parts (64 * #high parts / N of them: 3 % for chain_32 at 14 bits) and
+// the gx mode (rows = a hash partition) take the per-lane form thi[beta >> bits] + tlo[beta & mask].
+// Blocks are 1024 threads so that a 2^15-entry tlo (64 KB) still leaves two blocks per CU.
+// ---------------------------------------------------------------------------------------------
+constexpr int kLinBlock = 1024;
+
+template <bool CPLX>
+__device__ __forceinline__ void lin_gather(double const *__restrict__ x, size_t idx, double c, double &accr, double &acci) {
+    if (CPLX) {
+        const double2 v = reinterpret_cast<double2 const *>(x)[idx];
+        accr = fma(c, v.x, accr);
+        acci = fma(c, v.y, acci);
+    } else accr = fma(c, x[idx], accr);
+}
+
+template <typename W, bool CPLX>
+__global__ __launch_bounds__(kLinBlock, 8) void k_lin(int B, int n_lm, int n_ex, int n_all,
+                                                      lsk_lin_group const *__restrict__ lg,
+                                                      uint16_t const *__restrict__ g_tlo,
+                                                      void const *__restrict__ thi_v, lsk_runs runs,
+                                                      lsk_group const *__restrict__ groups,
+                                                      lsk_term const *__restrict__ off, int n_diag,
+                                                      lsk_term const *__restrict__ diag, int hamming_weight,
+                                                      int64_t n, int64_t tiles_per_xcd,
+                                                      uint64_t const *__restrict__ reps,
+                                                      double const *__restrict__ x, double *__restrict__ y,
+                                                      int *__restrict__ err, int gx) {
+    typedef typename WordTraits<W>::binom_t BT;
+    typedef WordTraits<W> WT;
+    extern __shared__ uint16_t s_tlo[];
+    for (int k = threadIdx.x; k < (1 << B); k += blockDim.x) s_tlo[k] = g_tlo[k];
+    __syncthreads();
+    BT const *thi = (BT const *)thi_v;
+    const uint32_t LM = (1u << B) - 1u;
+    const int xcd = blockIdx.x & 7;
+    const int64_t blocks_per_xcd = gridDim.x >> 3;
+    for (int64_t t = blockIdx.x >> 3; t < tiles_per_xcd; t += blocks_per_xcd) {
+        const int cs = (gx >> 16) & 31;
+        const int64_t tile = cs == 0 ? (int64_t)xcd * tiles_per_xcd + t
+                                     : ((((t >> cs) << 3) + xcd) << cs) + (t & (((int64_t)1 << cs) - 1));
+        const int64_t i = tile * kLinBlock + threadIdx.x;
+        if (i >= n) continue;
+        const W a = (W)__builtin_nontemporal_load(reps + i);
+        const uint32_t l = (uint32_t)a & LM;
+        const uint32_t hv = (uint32_t)(a >> B);
+        const uint32_t h0 = __builtin_amdgcn_readfirstlane(hv);
+        const bool uni = __builtin_amdgcn_ballot_w64(hv != h0) == 0;
+        const BT t_own = (BT)s_tlo[l];
+        const BT ig = (gx & 1) ? (BT)(thi[hv] + t_own) : (BT)i;
+        double xr, xi = 0.0;
+        if (CPLX) { const double2 v = reinterpret_cast<double2 const *>(x)[ig]; xr = v.x; xi = v.y; } else xr = x[ig];
+        double accr = 0.0, acci = 0.0;
+        if (n_diag == 0) { // no diagonal pass in the reference either: y is accumulated into (DMV:1062-1063)
+            if (CPLX) { accr = y[2 * i]; acci = y[2 * i + 1]; } else accr = y[i];
+        } else {
+            double dr, di;
+            diag_coeff<W, true>(runs, n_diag, diag, a, dr, di);
+            accr = dr * xr;
+            if (CPLX) acci = dr * xi;
+        }
+        if (uni) {
+            // masks with a low bit: act <=> exactly one of the two bits is set; the high bit (if any) is
+            // uniform.  Four masks per batch: 4 scalar loads, 4 LDS reads, 4 gathers in flight.
+            int g = 0;
+            for (; g < n_lm; g += 4) {
+                BT idx[4];
+                double c[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int gg = g + u < n_lm ? g + u : n_lm - 1;
+                    const uint32_t xlo = lg[gg].xlo, xhi = lg[gg].xhi;
+                    const double v = g + u < n_lm ? lg[gg].v : 0.0;
+                    const BT thg = thi[h0 ^ xhi];
+                    const bool act = (uint32_t)__popc(l & xlo) + (uint32_t)__popc(h0 & xhi) == 1u;
+                    const BT cand = (BT)(thg + s_tlo[l ^ xlo]);
+                    idx[u] = act ? cand : ig;
+                    c[u] = act ? v : 0.0;
+                }
+                double vr[4], vi[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int gg = g + u < n_lm ? g + u : n_lm - 1;
+                    if (CPLX) { const double2 q = reinterpret_cast<double2 const *>(x)[idx[u]]; vr[u] = q.x; vi[u] = q.y; }
+                    else { vr[u] = lg[gg].pad ? __builtin_nontemporal_load(x + idx[u]) : x[idx[u]]; vi[u] = 0.0; }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    accr = fma(c[u], vr[u], accr);
+                    if (CPLX) acci = fma(c[u], vi[u], acci);
+                }
+            }
+            // masks with high bits only: active for the whole wave or not at all
+            for (g = n_lm; g < n_ex; g += 4) {
+                BT thg[4];
+                double cv[4], vr[4], vi[4];
+                bool act[4], nt[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int gg = g + u < n_ex ? g + u : n_ex - 1;
+                    const uint32_t xhi = lg[gg].xhi;
+                    thg[u] = thi[h0 ^ xhi];
+                    act[u] = g + u < n_ex && __popc(h0 & xhi) == 1;
+                    nt[u] = lg[gg].pad != 0;
+                    cv[u] = lg[gg].v;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    vr[u] = 0.0; vi[u] = 0.0;
+                    if (act[u]) {
+                        const size_t idx = (size_t)(BT)(thg[u] + t_own);
+                        if (CPLX) { const double2 q = reinterpret_cast<double2 const *>(x)[idx]; vr[u] = q.x; vi[u] = q.y; }
+                        else vr[u] = nt[u] ? __builtin_nontemporal_load(x + idx) : x[idx];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    accr = fma(cv[u], vr[u], accr);
+                    if (CPLX) acci = fma(cv[u], vi[u], acci);
+                }
+            }
+        } else {
+#pragma unroll 2
+            for (int g = 0; g < n_ex; ++g) {
+                const W xg = (W)lg[g].xlo | ((W)lg[g].xhi << B);
+                const double v = lg[g].v;
+                const bool act = WT::popc(a & xg) == 1;
+                const W b = act ? (W)(a ^ xg) : a;
+                const BT idx = (BT)(thi[(uint32_t)(b >> B)] + s_tlo[(uint32_t)b & LM]);
+                lin_gather<CPLX>(x, (size_t)idx, act ? v : 0.0, accr, acci);
+            }
+        }
+        for (int g = n_ex; g < n_all; ++g) {
+            lsk_group const G = groups[lg[g].g];
+            double cr, ci;
+            group_coeff<true>(G, off, (uint64_t)a, cr, ci);
+            if (cr == 0.0) continue;
+            const W b = a ^ (W)G.x;
+            // a state of another Hamming weight is outside the basis: the reference halts (DMV:115-118)
+            if (WT::popc(b) != hamming_weight) { atomicExch(err, 1); continue; }
+            const BT idx = (BT)(thi[(uint32_t)(b >> B)] + s_tlo[(uint32_t)b & LM]);
+            lin_gather<CPLX>(x, (size_t)idx, cr, accr, acci);
+        }
+        if (CPLX) { y[2 * i] = accr; y[2 * i + 1] = acci; } else __builtin_nontemporal_store(accr, y + i);
+    }
+}
+
+template <typename W, bool CPLX>
+static int launch_lin(lsk_lin lin, lsk_operator op, lsk_basis bs, int gx, int64_t n, uint64_t const *reps,
+                      void const *x, void *y, int *d_err, void *stream) {
+    const size_t lds = sizeof(uint16_t) << lin.bits;
+    int64_t tiles = (n + kLinBlock - 1) / kLinBlock;
+    int64_t tiles_per_xcd = (tiles + 7) / 8;
+    const int cs = xcd_chunk_setting();
+    if (cs > 0) tiles_per_xcd = (((tiles + ((int64_t)8 << cs) - 1) / ((int64_t)8 << cs))) << cs;
+    gx = (gx & 1) | (cs << 16);
+    int64_t gb = tiles_per_xcd * 8;
+    static bool attr_set = false;
+    if (!attr_set) {
+        LSK_CHECK(hipFuncSetAttribute((void const *)k_lin<W, CPLX>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+        attr_set = true;
+    }
+    int64_t cap = resident_grid(k_lin<W, CPLX>, gb, lds, kLinBlock);
+    cap &= ~(int64_t)7;
+    if (cap < 8) cap = 8;
+    if (gb > cap) gb = cap;
+    const int n_lm = lin.n_low + lin.n_mixed, n_ex = n_lm + lin.n_high;
+    hipLaunchKernelGGL((k_lin<W, CPLX>), dim3((unsigned)gb), dim3(kLinBlock), lds, (hipStream_t)stream, lin.bits, n_lm,
+                       n_ex, n_ex + lin.n_generic, lin.groups, lin.tlo, lin.thi, op.runs, op.groups, op.off, op.n_diag,
+                       op.diag, bs.hamming_weight, n, tiles_per_xcd, reps, (double const *)x, (double *)y, d_err, gx);
+    LSK_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int lsk_lin_pull(lsk_lin lin, lsk_operator op, lsk_basis bs, int cplx, int gx, int64_t n,
+                            uint64_t const *reps, void const *x, void *y, int *d_err, void *stream) {
+    if (n == 0) return 0;
+    if (lin.bits < 1 || lin.bits > 15) { snprintf(g_err, sizeof(g_err), "lsk_lin_pull: bits out of range"); return -1; }
+    if (bs.number_sites <= 32)
+        return cplx ? launch_lin<uint32_t, true>(lin, op, bs, gx, n, reps, x, y, d_err, stream)
+                    : launch_lin<uint32_t, false>(lin, op, bs, gx, n, reps, x, y, d_err, stream);
+    return cplx ? launch_lin<uint64_t, true>(lin, op, bs, gx, n, reps, x, y, d_err, stream)
+                : launch_lin<uint64_t, false>(lin, op, bs, gx, n, reps, x, y, d_err, stream);
 }
 
 // ---------------------------------------------------------------------------------------------

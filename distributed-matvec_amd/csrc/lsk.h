@@ -56,6 +56,28 @@ typedef struct lsk_operator {
     lsk_runs runs;
 } lsk_operator;
 
+/* Two-table ranking of a fixed-Hamming-weight basis ("Lin tables"): a state splits into its low `bits`
+ * bits l and the rest h, and  rank(state) = thi[h] + tlo[l]  where
+ *   tlo[l] = sum_j C(p_j, j + 1)                 over the set bits p_0 < p_1 < ... of l,
+ *   thi[h] = sum_i C(bits + q_i, k + i + 1)      over the set bits q_i of h, k = weight - popcount(h).
+ * 64 consecutive rows almost always share h, so a wave evaluates the high part of every target with
+ * scalar instructions (one scalar load of thi per flip mask) and the low part with one LDS read.
+ * Groups are ordered: EXCHANGE groups whose two bits are both low, then one low + one high, then both
+ * high, then everything else (evaluated per lane through its terms, g = index into op.groups). */
+typedef struct lsk_lin_group {
+    uint32_t xlo, xhi; /* flip mask = xlo | xhi << bits */
+    double v;          /* EXCHANGE amplitude */
+    int32_t g;
+    int32_t pad; /* != 0: the gathers of this mask are streamed (non-temporal) */
+} lsk_lin_group;
+
+typedef struct lsk_lin {
+    int bits, n_low, n_mixed, n_high, n_generic;
+    lsk_lin_group const *groups; /* device */
+    uint16_t const *tlo;         /* device [1 << bits] */
+    void const *thi;             /* device [1 << max(number_sites - bits, 0)]: u32 if number_sites <= 32, else u64 */
+} lsk_lin;
+
 enum { LSK_ELEM_BENES = 0, LSK_ELEM_ROT = 1, LSK_ELEM_REVROT = 2 };
 
 typedef struct lsk_group_elem {
@@ -101,6 +123,14 @@ typedef struct lsk_round_layout {
     int64_t val_off[LSK_MAX_PARTS];
 } lsk_round_layout;
 
+/* Tile map of the row kernels: entry = first row | number of rows (<= 256) << 48.  The map holds 8 lists of
+ * slots_per_xcd entries, one per XCD (block b of the launch runs on XCD b % 8 and walks list b % 8);
+ * empty slots have a zero row count.  Every row appears in exactly one tile. */
+typedef struct lsk_tilemap {
+    uint64_t const *entries; /* device [8 * slots_per_xcd] */
+    int64_t slots_per_xcd;
+} lsk_tilemap;
+
 /* runtime ---------------------------------------------------------------------------------- */
 char const *lsk_last_error(void);
 int lsk_device_count(void);
@@ -129,8 +159,13 @@ int lsk_diag(lsk_operator op, int cplx, int64_t n, uint64_t const *reps, void co
 /* fused single-partition kernel without permutation symmetries (row per lane).
  * pull == 0: y[idx(beta)] += c x[i] (atomics; y must already hold the diagonal part)
  * pull == 1: y[i] = d x[i] + sum conj(c) x[idx(beta)] */
-int lsk_direct(lsk_operator op, lsk_basis bs, lsk_index ix, int cplx, int pull, int64_t n,
+int lsk_direct(lsk_operator op, lsk_basis bs, lsk_index ix, int cplx, int pull, lsk_tilemap tm,
                uint64_t const *reps, void const *x, void *y, int *d_err, void *stream);
+/* two-table pull kernel: fixed Hamming weight, no symmetries, real coefficients, Hermitian.
+ * gx == 0: rows are the whole basis (row i has rank i); gx != 0: rows are any subset, x is the whole
+ * vector in ascending order of the global basis. */
+int lsk_lin_pull(lsk_lin lin, lsk_operator op, lsk_basis bs, int cplx, int gx, int64_t n, uint64_t const *reps,
+                 void const *x, void *y, int *d_err, void *stream);
 /* staged kernel (LDS term lists): rows [row0, row1) of partition `me`.
  * count_only != 0: adds the number of packets per destination to d_counts[P] and does nothing else.
  * otherwise: local packets -> index + atomic add into y; remote packets -> d_send according to
@@ -142,7 +177,7 @@ int lsk_tile(lsk_operator op, lsk_basis bs, lsk_index ix, int cplx, int count_on
 /* replicated-x pull (Hermitian operators): rows of ONE partition against the whole vector in global
  * ascending order.  ix_global indexes the global basis; row_gidx[i] = global index of local row i
  * (may be NULL for lsk_direct_gx with closed-form indices, and for lsk_tile_pull when local == global). */
-int lsk_direct_gx(lsk_operator op, lsk_basis bs, lsk_index ix_global, int cplx, int64_t n,
+int lsk_direct_gx(lsk_operator op, lsk_basis bs, lsk_index ix_global, int cplx, lsk_tilemap tm,
                   uint64_t const *reps, int64_t const *row_gidx, void const *x_global, void *y, int *d_err,
                   void *stream);
 /* hash table {rep -> x * norm(rep)} of the staged pull kernel: 2^bits entries of 16 (f64) / 32 (c128)
