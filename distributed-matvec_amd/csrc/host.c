@@ -906,6 +906,10 @@ struct ls_amd_plan {
     lsk_tilemap tilemap;
     void *d_tilemap;
     int tilemap_transposed;
+    int has_chain; /* staged row kernel (lsk_chain) */
+    int chain_cached;      /* leading non-adjacent exchange groups whose partner ranks are cached */
+    uint32_t *d_chain_cache; /* [chain_cached][count] */
+    double chain_v[2];
     /* two-table pull kernel (lsk_lin in lsk.h) */
     int has_lin;
     lsk_lin lin;
@@ -1110,8 +1114,7 @@ static void tile_push(tile_list *l, int64_t row, int64_t cnt) {
     if (l->n == l->cap) { l->cap = l->cap ? 2 * l->cap : 1024; l->e = (uint64_t *)realloc(l->e, sizeof(uint64_t) * (size_t)l->cap); }
     l->e[l->n++] = (uint64_t)row | ((uint64_t)cnt << 48);
 }
-static int build_tilemap(ls_amd_plan *pl, int64_t n, int allow_transposed) {
-    enum { TILE = 256 };
+static int build_tilemap(ls_amd_plan *pl, int64_t n, int allow_transposed, int TILE) {
     tile_list lists[8];
     memset(lists, 0, sizeof(lists));
     ls_hs_basis const *b = pl->op->basis;
@@ -1409,7 +1412,61 @@ int ls_amd_plan_create(ls_amd_plan **out, ls_hs_operator const *op, ls_amd_dtype
     }
     if (pl->family == FAMILY_DIRECT_PULL || pl->family == FAMILY_DIRECT_PUSH) {
         int const combinadic = pl->parts[0].index.kind == LSK_INDEX_COMBINADIC;
-        if (build_tilemap(pl, pl->parts[0].count, combinadic && pl->family == FAMILY_DIRECT_PULL) != 0) { ls_amd_plan_destroy(pl); return -1; }
+        /* staged row kernel (k_chain): f64, <= 32 sites, full fixed-weight basis, real operator with exchange runs */
+        char const *e = getenv("LS_AMD_CHAIN");
+        pl->has_chain = pl->family == FAMILY_DIRECT_PULL && combinadic && !pl->cplx && op->basis->number_sites <= 32 &&
+                        op->basis->spin_inversion == 0 && pl->dbs.proj == LSK_PROJ_NONE && op->ext->is_real &&
+                        pl->dop.runs.n_runs > 0 && !(e && atoi(e) == 0) && !getenv("LS_AMD_HIGH_BITS") &&
+                        !(getenv("LS_AMD_LIN") && atoi(getenv("LS_AMD_LIN")) != 0);
+        if (pl->has_chain) {
+            /* every group outside the runs must be a non-adjacent exchange pair (at most two: their partner
+             * ranks are cached below) */
+            struct ls_amd_operator_ext const *ext = op->ext;
+            int const extra = ext->n_groups - ext->runs.n_run_groups;
+            if (extra > 2) pl->has_chain = 0;
+            for (int g = ext->runs.n_run_groups; g < ext->n_groups && pl->has_chain; ++g) {
+                lsk_group const *G = &ext->groups[g];
+                if (G->fast != LSK_GROUP_EXCHANGE || G->v_im != 0.0 || __builtin_popcountll(G->x) != 2) pl->has_chain = 0;
+            }
+        }
+        int const chain_candidate = pl->has_chain;
+        e = getenv("LS_AMD_TRANSPOSED"); /* transposed tile order: measured neutral on chain_32, off by default */
+        int const transposed = combinadic && pl->family == FAMILY_DIRECT_PULL && !pl->has_chain && e && atoi(e) != 0;
+        if (build_tilemap(pl, pl->parts[0].count, transposed, pl->has_chain ? 1024 : 256) != 0) { ls_amd_plan_destroy(pl); return -1; }
+        if (pl->has_chain) {
+            /* partner ranks of the exchange pairs outside the runs -- for a ring, the bond that closes it:
+             * 4 bytes per row instead of a ranking loop of `weight` steps per row and matvec */
+            struct ls_amd_operator_ext const *ext = op->ext;
+            int const nc = ext->n_groups - ext->runs.n_run_groups;
+            int64_t const n = pl->parts[0].count;
+            if (nc > 0 && n > 0) {
+                void *q;
+                if (lsk_malloc(&q, sizeof(uint32_t) * (size_t)nc * (size_t)n) != 0) { ls_amd_plan_destroy(pl); return dev_error(); }
+                pl->d_chain_cache = (uint32_t *)q;
+                int zero2 = 0, flag = 0;
+                DEV(lsk_h2d(pl->d_err, &zero2, sizeof(int)));
+                for (int c = 0; c < nc; ++c)
+                    DEV(lsk_chain_cache(pl->dbs, pl->parts[0].index, n, pl->parts[0].d_reps, ext->groups[ext->runs.n_run_groups + c].x,
+                                        pl->d_chain_cache + (size_t)c * (size_t)n, pl->d_err, stream));
+                DEV(lsk_sync(stream));
+                DEV(lsk_d2h(&flag, pl->d_err, sizeof(int)));
+                DEV(lsk_h2d(pl->d_err, &zero2, sizeof(int)));
+                if (flag) { /* a partner leaves the basis: k_direct reports that at run time, as the reference does */
+                    pl->has_chain = 0;
+                    lsk_free(pl->d_chain_cache);
+                    pl->d_chain_cache = NULL;
+                } else {
+                    pl->chain_cached = nc;
+                    pl->chain_v[0] = ext->groups[ext->runs.n_run_groups].v_re;
+                    pl->chain_v[1] = nc > 1 ? ext->groups[ext->runs.n_run_groups + 1].v_re : 0.0;
+                }
+            }
+        }
+        if (chain_candidate && !pl->has_chain) { /* back to k_direct: its tile map has 256-row tiles */
+            lsk_free(pl->d_tilemap);
+            pl->d_tilemap = NULL;
+            if (build_tilemap(pl, pl->parts[0].count, 0, 256) != 0) { ls_amd_plan_destroy(pl); return -1; }
+        }
     }
     if (pl->family == FAMILY_DIRECT_PULL && pl->parts[0].index.kind == LSK_INDEX_COMBINADIC) {
         /* off by default: measured on chain_32 the two-pass scheme is slower (12.9 + 10.2 ms vs 15.7 ms);
@@ -1445,6 +1502,7 @@ void ls_amd_plan_destroy(ls_amd_plan *pl) {
     for (int i = 0; i < 7; ++i) if (pl->hp_alloc[i]) lsk_free(pl->hp_alloc[i]);
     for (int i = 0; i < 3; ++i) if (pl->lin_alloc[i]) lsk_free(pl->lin_alloc[i]);
     if (pl->d_tilemap) lsk_free(pl->d_tilemap);
+    if (pl->d_chain_cache) lsk_free(pl->d_chain_cache);
     if (pl->d_htab) lsk_free(pl->d_htab);
     if (pl->d_slot_of) lsk_free(pl->d_slot_of);
     if (pl->d_send) lsk_free(pl->d_send);
@@ -1510,7 +1568,7 @@ int ls_amd_plan_create_replicated(ls_amd_plan **out, ls_hs_operator const *op, l
         pl->gindex = gps.index;
         pl->d_gtable = gps.d_table;
     }
-    if (pl->family == FAMILY_REPL_DIRECT && build_tilemap(pl, count_local, 0) != 0) { ls_amd_plan_destroy(pl); return -1; }
+    if (pl->family == FAMILY_REPL_DIRECT && build_tilemap(pl, count_local, 0, 256) != 0) { ls_amd_plan_destroy(pl); return -1; }
     if (pl->family == FAMILY_REPL_DIRECT && pl->gindex.kind == LSK_INDEX_COMBINADIC && setup_lin(pl) != 0) {
         ls_amd_plan_destroy(pl);
         return -1;
@@ -1563,7 +1621,8 @@ int ls_amd_matvec_replicated(ls_amd_plan *pl, void const *d_x_global, void *d_y_
 char const *ls_amd_plan_kernel_name(ls_amd_plan const *pl) {
     switch (pl->family) {
     case FAMILY_DIRECT_PUSH: return "direct-push";
-    case FAMILY_DIRECT_PULL: return pl->has_highpart ? "direct-pull+highpart" : pl->has_lin ? "direct-pull+lin" : "direct-pull";
+    case FAMILY_DIRECT_PULL:
+        return pl->has_chain ? "direct-pull+staged" : pl->has_highpart ? "direct-pull+highpart" : pl->has_lin ? "direct-pull+lin" : "direct-pull";
     case FAMILY_TILE_PULL: return "tile-pull";
     case FAMILY_REPL_DIRECT: return pl->has_lin ? "replicated-direct-pull+lin" : "replicated-direct-pull";
     case FAMILY_REPL_TILE: return "replicated-tile-pull";
@@ -1653,7 +1712,10 @@ int ls_amd_matvec(ls_amd_plan *pl, void const *const *d_x, void *const *d_y, voi
     if (pl->family != FAMILY_TILE) {
         part_state *ps = &pl->parts[0];
         int slot = timing_begin(pl, stream);
-        if (pl->has_lin)
+        if (pl->has_chain)
+            DEV(lsk_chain(pl->dop, pl->dbs, ps->index, pl->tilemap, ps->count, ps->d_reps, d_x[0], d_y[0], pl->chain_cached,
+                          pl->d_chain_cache, pl->chain_v[0], pl->chain_v[1], stream));
+        else if (pl->has_lin)
             DEV(lsk_lin_pull(pl->lin, pl->dop, pl->dbs, pl->cplx, 0, ps->count, ps->d_reps, d_x[0], d_y[0], pl->d_err,
                              stream));
         else

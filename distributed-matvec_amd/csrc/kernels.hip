@@ -876,6 +876,190 @@ extern "C" int lsk_direct_gx(lsk_operator op, lsk_basis bs, lsk_index ix, int cp
 }
 
 // ---------------------------------------------------------------------------------------------
+// Staged row kernel for chain-like operators: f64 pull, 32-bit states, the full fixed-Hamming-weight
+// basis (row i = i-th state), exchange runs of adjacent pairs plus at most two other exchange pairs
+// whose partner ranks the plan caches (anything else stays with k_direct).
+//
+// The row kernel above is bound by the vector-memory address unit (TA busy > 80 %: every gather is a
+// wave instruction whatever it hits).  An adjacent pair (lo, lo + 1) moves a state by C(lo, k) <= C(11, 5)
+// = 462 ranks when lo < 12, so those twelve gathers stay inside a window of the block's own rows +- 512:
+// the block loads the window into LDS once (coalesced 16-byte loads -- the price of the old own-x load)
+// and reads the near partners from LDS.  Pairs 12 .. hb-1 gather from global memory as before; pairs
+// >= hb take the wave-uniform path of k_direct.
+// ---------------------------------------------------------------------------------------------
+constexpr int kChainTile = 1024;  // rows per tile (4 per thread)
+constexpr int kChainHalo = 512;   // >= C(11, 5)
+constexpr int kChainLdsPairs = 12; // pairs lo < 12 are served from the LDS window
+constexpr int kChainWindow = kChainTile + 2 * kChainHalo + 2; // +2: the window starts on an even row
+
+__global__ __launch_bounds__(kBlock) void k_chain(lsk_runs runs, int n_diag,
+                                                  lsk_term const *__restrict__ diag, int hamming_weight,
+                                                  uint64_t const *__restrict__ g_binom,
+                                                  uint64_t const *__restrict__ tilemap, int64_t slots_per_xcd,
+                                                  int64_t n, uint64_t const *__restrict__ reps,
+                                                  double const *__restrict__ x, double *__restrict__ y,
+                                                  int hb, int n_cached, uint32_t const *__restrict__ cache,
+                                                  double cv0, double cv1) {
+    __shared__ uint32_t s_binom[32 * LSK_BINOM_K]; // states have <= 32 bits
+    __shared__ double s_x[kChainWindow + 1]; // last slot: 0.0, read by the lanes whose pair is aligned
+    for (int k = threadIdx.x; k < 32 * LSK_BINOM_K; k += blockDim.x) s_binom[k] = (uint32_t)g_binom[k];
+    if (threadIdx.x == 0) s_x[kChainWindow] = 0.0;
+    const int xcd = blockIdx.x & 7;
+    const int64_t blocks_per_xcd = gridDim.x >> 3;
+    tilemap += (int64_t)xcd * slots_per_xcd;
+    for (int64_t t = blockIdx.x >> 3; t < slots_per_xcd; t += blocks_per_xcd) {
+        const uint64_t slot = tilemap[t];
+        const int cnt = (int)(slot >> 48);
+        if (cnt == 0) continue; // block-uniform
+        const int64_t i0 = (int64_t)(slot & 0xffffffffffffULL);
+        const int64_t w0 = (i0 - kChainHalo) & ~(int64_t)1; // first row of the window (even; may be < 0)
+        __syncthreads(); // every wave is done with the previous window (and s_binom is loaded)
+        for (int j = 2 * threadIdx.x; j < kChainWindow; j += 2 * kBlock) {
+            const int64_t row = w0 + j;
+            double2 v;
+            if (row >= 0 && row + 1 < n) v = *reinterpret_cast<double2 const *>(x + row);
+            else { v.x = (row >= 0 && row < n) ? x[row] : 0.0; v.y = (row + 1 >= 0 && row + 1 < n) ? x[row + 1] : 0.0; }
+            s_x[j] = v.x;
+            s_x[j + 1] = v.y;
+        }
+        __syncthreads();
+        const int own0 = (int)(i0 - w0);
+#pragma unroll 1
+        for (int sub = 0; sub < kChainTile / kBlock; ++sub) {
+            const int r = sub * kBlock + threadIdx.x;
+            if (r >= cnt) continue;
+            const int64_t i = i0 + r;
+            const uint32_t a = (uint32_t)__builtin_nontemporal_load(reps + i);
+            const int jr = own0 + r;
+            const double xr = s_x[jr];
+            double accr;
+            if (n_diag == 0) accr = y[i]; // no diagonal pass in the reference either (DMV:1062-1063)
+            else {
+                double dr, di;
+                diag_coeff<uint32_t, true>(runs, n_diag, diag, a, dr, di);
+                accr = dr * xr;
+            }
+            const uint32_t i32 = (uint32_t)i;
+            const uint32_t tdiff = a ^ (a >> 1);
+            for (int q = 0; q < runs.n_runs; ++q) {
+                const int lo0 = runs.lo0[q];
+                int lo_end = lo0 + runs.cnt[q];
+                const double vr = runs.v_re[q];
+                int k = __popc(a & (uint32_t)(((uint64_t)1 << lo0) - 1));
+                int lo = lo0;
+                // ---- near pairs: partner inside the LDS window ----------------------------------------
+                const int e1 = lo_end < kChainLdsPairs ? lo_end : kChainLdsPairs;
+#pragma unroll 4
+                for (; lo < e1; ++lo) {
+                    const bool bit = (a >> lo) & 1;
+                    const bool act = (tdiff >> lo) & 1;
+                    const int d = (int)s_binom[lo * LSK_BINOM_K + k];
+                    k += bit ? 1 : 0;
+                    const int j = bit ? jr + d : jr - d;
+                    accr = fma(vr, s_x[act ? j : kChainWindow], accr);
+                }
+                // ---- far pairs: wave-uniform (see k_direct) ---------------------------------------------
+                const int split = hb == 0 ? lo_end : (hb < lo ? lo : (hb > lo_end ? lo_end : hb));
+                const uint32_t a0 = __builtin_amdgcn_readfirstlane(a);
+                const bool uni = split < lo_end && __builtin_amdgcn_ballot_w64(((a ^ a0) >> split) != 0) == 0;
+                if (uni) {
+                    uint32_t m = (a0 ^ (a0 >> 1)) & (uint32_t)((((uint64_t)1 << lo_end) - 1) & ~(((uint64_t)1 << split) - 1));
+                    while (m) {
+                        double xv[4];
+                        bool ok[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            ok[u] = m != 0;
+                            xv[u] = 0.0;
+                            if (ok[u]) {
+                                const int p = __builtin_ctz(m);
+                                m &= m - 1;
+                                const int kk = hamming_weight - __popc(a0 >> p); // set bits below p
+                                const uint32_t d = s_binom[p * LSK_BINOM_K + kk];
+                                const uint32_t idx = ((a0 >> p) & 1) ? i32 + d : i32 - d;
+                                xv[u] = x[idx];
+                            }
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) accr = fma(ok[u] ? vr : 0.0, xv[u], accr);
+                    }
+                    lo_end = split;
+                }
+                // ---- middle pairs (and far pairs of a wave that straddles two high parts) --------------
+#pragma unroll 4
+                for (; lo < lo_end; ++lo) {
+                    const bool bit = (a >> lo) & 1;
+                    const bool act = (tdiff >> lo) & 1;
+                    const uint32_t d = s_binom[lo * LSK_BINOM_K + k];
+                    k += bit ? 1 : 0;
+                    uint32_t idx = bit ? i32 + d : i32 - d;
+                    idx = act ? idx : i32;
+                    accr = fma(act ? vr : 0.0, x[idx], accr);
+                }
+            }
+            // ---- exchange pairs that are not adjacent (the bond that closes a ring): the rank of the
+            //      partner has no closed form, it is read from the plan's cache (lsk_chain_cache) ---------
+            for (int c = 0; c < n_cached; ++c) {
+                const uint32_t tgt = __builtin_nontemporal_load(cache + (size_t)c * (size_t)n + (size_t)i);
+                const bool act = tgt != 0xffffffffu;
+                accr = fma(act ? (c == 0 ? cv0 : cv1) : 0.0, x[act ? tgt : i32], accr);
+            }
+            __builtin_nontemporal_store(accr, y + i);
+        }
+    }
+}
+
+// cache[i] = rank of reps[i] ^ xmask when exactly one of the two bits of xmask is set in reps[i], else ~0;
+// *flag is raised when a partner falls outside the basis (the caller then does not use the cache, and
+// the generic path reports the error at run time as the reference does)
+__global__ __launch_bounds__(kBlock) void k_chain_cache(int64_t n, uint64_t const *__restrict__ reps, uint32_t xmask,
+                                                        int hamming_weight, uint64_t const *__restrict__ g_binom,
+                                                        uint32_t *__restrict__ out, int *__restrict__ flag) {
+    __shared__ uint32_t s_binom[32 * LSK_BINOM_K];
+    for (int k = threadIdx.x; k < 32 * LSK_BINOM_K; k += blockDim.x) s_binom[k] = (uint32_t)g_binom[k];
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        const uint32_t a = (uint32_t)reps[i];
+        uint32_t t = 0xffffffffu;
+        if (__popc(a & xmask) == 1) {
+            const uint32_t beta = a ^ xmask;
+            if (__popc(beta) != hamming_weight) atomicExch(flag, 1);
+            else t = (uint32_t)rank_combinadic_w<uint32_t, uint32_t>(beta, s_binom);
+        }
+        out[i] = t;
+    }
+}
+extern "C" int lsk_chain_cache(lsk_basis bs, lsk_index ix, int64_t n, uint64_t const *reps, uint64_t xmask, uint32_t *out,
+                               int *d_flag, void *stream) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_chain_cache, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, n, reps, (uint32_t)xmask,
+                       bs.hamming_weight, ix.binom, out, d_flag);
+    LSK_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int lsk_chain(lsk_operator op, lsk_basis bs, lsk_index ix, lsk_tilemap tm, int64_t n, uint64_t const *reps,
+                         void const *x, void *y, int n_cached, uint32_t const *cache, double cv0, double cv1,
+                         void *stream) {
+    if (n == 0 || tm.slots_per_xcd == 0) return 0;
+    int64_t gb = tm.slots_per_xcd * 8;
+    int64_t cap = resident_grid(k_chain, gb);
+    {
+        char const *e = getenv("LS_AMD_BLOCKS_PER_CU"); // occupancy experiments
+        int const bpc = e ? atoi(e) : 0;
+        if (bpc > 0 && (int64_t)bpc * g_num_cus < cap) cap = (int64_t)bpc * g_num_cus;
+    }
+    cap &= ~(int64_t)7;
+    if (cap < 8) cap = 8;
+    if (gb > cap) gb = cap;
+    hipLaunchKernelGGL(k_chain, dim3((unsigned)gb), dim3(kBlock), 0, (hipStream_t)stream, op.runs, op.n_diag, op.diag,
+                       bs.hamming_weight, ix.binom, tm.entries, tm.slots_per_xcd, n, reps, (double const *)x, (double *)y,
+                       high_pair_setting(), n_cached, cache, cv0, cv1);
+    LSK_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Two-table pull kernel (lsk_lin in lsk.h).  One row per lane; 64 consecutive rows of the ascending
 // fixed-weight basis nearly always share their high part h, and then
 //   * a flip mask that only touches high bits is active for the whole wave or not at all (scalar

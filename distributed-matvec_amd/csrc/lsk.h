@@ -161,6 +161,14 @@ int lsk_diag(lsk_operator op, int cplx, int64_t n, uint64_t const *reps, void co
  * pull == 1: y[i] = d x[i] + sum conj(c) x[idx(beta)] */
 int lsk_direct(lsk_operator op, lsk_basis bs, lsk_index ix, int cplx, int pull, lsk_tilemap tm,
                uint64_t const *reps, void const *x, void *y, int *d_err, void *stream);
+/* staged row kernel (k_chain): f64 pull, <= 32 sites, full fixed-Hamming-weight basis without symmetries, real
+ * Hermitian operator; the tile map must have been built with 1024-row tiles. */
+int lsk_chain(lsk_operator op, lsk_basis bs, lsk_index ix, lsk_tilemap tm, int64_t n, uint64_t const *reps,
+              void const *x, void *y, int n_cached, uint32_t const *cache, double cv0, double cv1, void *stream);
+/* partner ranks of a non-adjacent exchange pair for every row (see k_chain); *d_flag is raised if a partner
+ * leaves the basis */
+int lsk_chain_cache(lsk_basis bs, lsk_index ix, int64_t n, uint64_t const *reps, uint64_t xmask, uint32_t *out,
+                    int *d_flag, void *stream);
 /* two-table pull kernel: fixed Hamming weight, no symmetries, real coefficients, Hermitian.
  * gx == 0: rows are the whole basis (row i has rank i); gx != 0: rows are any subset, x is the whole
  * vector in ascending order of the global basis. */

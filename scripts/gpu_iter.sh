@@ -1,8 +1,9 @@
-# GPU job: parity + A/B of the wave-uniform far pairs (LS_AMD_HIGH_PAIR = first pair handled that way)
+# GPU job: parity + timing of the staged row kernel (k_chain) with cached ring-closing partners
 export TMPDIR=/tmp
 timeout 600 python -m pytest tests -m gpu -q -x 2>&1 | tail -3
 B="timeout 120 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra"
-for v in 0 10 12 14 16 18; do
-  echo "+ HIGH_PAIR=$v"; LS_AMD_HIGH_PAIR=$v $B
-done
-echo "+ HIGH_PAIR=14 TOP_BITS=0"; LS_AMD_HIGH_PAIR=14 LS_AMD_TOP_BITS=0 $B
+echo "+ CHAIN=0"; LS_AMD_CHAIN=0 $B
+echo "+ CHAIN=1"; $B
+echo "+ CHAIN=1 HIGH_PAIR=12"; LS_AMD_HIGH_PAIR=12 $B
+echo "+ CHAIN=1 BLOCKS=6"; LS_AMD_BLOCKS_PER_CU=6 $B
+echo "+ CHAIN=1 BLOCKS=5"; LS_AMD_BLOCKS_PER_CU=5 $B

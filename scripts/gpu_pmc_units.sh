@@ -12,6 +12,7 @@ while read -r group; do
   timeout -k 5 70 rocprofv3 --pmc $group -d $OUT/p$i -o pmc -- $CMD > $OUT/p$i.log 2>&1 || echo "pass $i ($group) failed rc=$?"
 done <<'GROUPS'
 SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_SALU SQ_INST_CYCLES_VMEM_RD SQ_THREAD_CYCLES_VALU SQ_BUSY_CYCLES
+SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_SMEM
 TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum
 TA_DATA_STALLED_BY_TC_CYCLES_sum TA_FLAT_READ_WAVEFRONTS_sum
 TCP_PENDING_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum
@@ -22,4 +23,4 @@ TCP_READ_TAGCONFLICT_STALL_CYCLES_sum TCP_TOTAL_CACHE_ACCESSES_sum
 GROUPS
 python3 $ROOT/scripts/rocpd_summary.py $OUT > $OUT/summary.txt 2>&1
 rm -rf $OUT/*/*.db
-grep -E "k_direct|k_lin" $OUT/summary.txt | grep -E "SQ_|TA_|TCP_" | cut -c1-20,60-140
+grep -E "k_direct|k_lin|k_chain" $OUT/summary.txt | grep -E "SQ_|TA_|TCP_" | cut -c1-20,60-140
