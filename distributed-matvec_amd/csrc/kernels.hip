@@ -774,26 +774,21 @@ __global__ __launch_bounds__(kBlock) void k_direct(lsk_runs runs, int n_groups, 
     }
 }
 
-// first pair index handled wave-uniformly by the 32-bit pull row kernel (LS_AMD_HIGH_PAIR; 0 = off)
-static int high_pair_setting() {
-    static int v = -1;
-    if (v < 0) {
-        char const *e = getenv("LS_AMD_HIGH_PAIR");
-        v = e ? atoi(e) : 14;
-        if (v < 0 || v > 63) v = 0;
-    }
+// first pair index handled wave-uniformly by the 32-bit pull row kernels (LS_AMD_HIGH_PAIR; 0 = off).
+// Measured on chain_32: 14 is best for k_direct, 12 (= every pair outside the LDS window) for k_chain.
+static int high_pair_setting(int dflt) {
+    char const *e = getenv("LS_AMD_HIGH_PAIR");
+    int v = e ? atoi(e) : dflt;
+    if (v < 0 || v > 63) v = 0;
     return v;
 }
 
 // log2 of the number of consecutive row tiles dealt to one XCD before moving to the next XCD
 // (LS_AMD_XCD_CHUNK; 0 = each XCD gets one contiguous eighth of the rows)
 static int xcd_chunk_setting() {
-    static int v = -1;
-    if (v < 0) {
-        char const *e = getenv("LS_AMD_XCD_CHUNK");
-        v = e ? atoi(e) : 0;
-        if (v < 0 || v > 24) v = 0;
-    }
+    char const *e = getenv("LS_AMD_XCD_CHUNK");
+    int v = e ? atoi(e) : 0;
+    if (v < 0 || v > 24) v = 0;
     return v;
 }
 
@@ -803,17 +798,14 @@ static int launch_direct3(lsk_operator op, lsk_basis bs, lsk_index ix, lsk_tilem
     int64_t gb = tm.slots_per_xcd * 8;
     int64_t cap = op.is_real ? resident_grid(k_direct<W, CPLX, INDEX, INV, PULL, true>, gb)
                              : resident_grid(k_direct<W, CPLX, INDEX, INV, PULL, false>, gb);
-    static int blocks_per_cu = -1; // LS_AMD_BLOCKS_PER_CU: occupancy experiments
-    if (blocks_per_cu < 0) {
-        char const *e = getenv("LS_AMD_BLOCKS_PER_CU");
-        blocks_per_cu = e ? atoi(e) : 0;
-    }
+    int blocks_per_cu = 0; // LS_AMD_BLOCKS_PER_CU: occupancy experiments
+    { char const *e = getenv("LS_AMD_BLOCKS_PER_CU"); blocks_per_cu = e ? atoi(e) : 0; }
     if (blocks_per_cu > 0 && (int64_t)blocks_per_cu * g_num_cus < cap) cap = (int64_t)blocks_per_cu * g_num_cus;
     cap &= ~(int64_t)7; // XCD dealing needs a multiple of 8
     if (cap < 8) cap = 8;
     if (gb > cap) gb = cap;
     dim3 g((unsigned)gb), b(kBlock);
-    gx = (gx & 1) | (high_pair_setting() << 24);
+    gx = (gx & 1) | (high_pair_setting(14) << 24);
     if (op.is_real)
         hipLaunchKernelGGL((k_direct<W, CPLX, INDEX, INV, PULL, true>), g, b, 0, (hipStream_t)stream, op.runs,
                            op.n_groups, op.groups, op.off, op.n_diag, op.diag, bs, ix, tm.entries, tm.slots_per_xcd, reps,
@@ -1054,7 +1046,7 @@ extern "C" int lsk_chain(lsk_operator op, lsk_basis bs, lsk_index ix, lsk_tilema
     if (gb > cap) gb = cap;
     hipLaunchKernelGGL(k_chain, dim3((unsigned)gb), dim3(kBlock), 0, (hipStream_t)stream, op.runs, op.n_diag, op.diag,
                        bs.hamming_weight, ix.binom, tm.entries, tm.slots_per_xcd, n, reps, (double const *)x, (double *)y,
-                       high_pair_setting(), n_cached, cache, cv0, cv1);
+                       high_pair_setting(kChainLdsPairs), n_cached, cache, cv0, cv1);
     LSK_LAUNCH_CHECK();
     return 0;
 }

@@ -636,3 +636,68 @@ def test_non_hermitian_complex_operator(torch):
             D_, basis, h, reps, masks = setup_model(torch, c, 1)
             with pytest.raises(D.LsAmdError, match="c128"):
                 run_matvec(torch, D_, h, reps, masks, x.real.copy(), 1)
+
+
+def _chain_like_config(L, kind):
+    """ring / open chain / ring with next-nearest-neighbour bonds (two exchange pairs outside the runs are the
+    most the staged kernel caches: J1-J2 has more, so it must fall back to the generic row kernel)."""
+    from oracle import model as M
+
+    c = M.heisenberg_chain_config(L)
+    if kind == "open":
+        lattice = [[i, i + 1] for i in range(L - 1)]
+    elif kind == "j1j2":
+        lattice = [[i, (i + 1) % L] for i in range(L)] + [[i, (i + 2) % L] for i in range(L)]
+    else:
+        lattice = [[i, (i + 1) % L] for i in range(L)]
+    for t in c["hamiltonian"]["terms"]:
+        t["sites"] = lattice
+    return c
+
+
+ROW_KERNEL_VARIANTS = {
+    "default": {},
+    "generic-row-kernel": {"LS_AMD_CHAIN": "0"},
+    "no-uniform-pairs": {"LS_AMD_CHAIN": "0", "LS_AMD_HIGH_PAIR": "0"},
+    "uniform-from-4": {"LS_AMD_CHAIN": "0", "LS_AMD_HIGH_PAIR": "4"},
+    "staged-uniform-from-13": {"LS_AMD_HIGH_PAIR": "13"},
+    "staged-no-uniform": {"LS_AMD_HIGH_PAIR": "0"},
+    "transposed-tiles": {"LS_AMD_CHAIN": "0", "LS_AMD_TRANSPOSED": "1", "LS_AMD_TOP_BITS": "3", "LS_AMD_SET_ROWS": "2048"},
+    "two-table": {"LS_AMD_LIN": "1", "LS_AMD_LIN_BITS": "7"},
+    "two-table-chunked": {"LS_AMD_LIN": "1", "LS_AMD_LIN_BITS": "12", "LS_AMD_XCD_CHUNK": "2"},
+}
+
+
+@pytest.mark.parametrize("variant", sorted(ROW_KERNEL_VARIANTS))
+def test_row_kernel_variants(torch, monkeypatch, variant):
+    """Every selectable form of the single-partition pull kernel against the oracle: staged (LDS window +
+    cached ring partners), generic with / without wave-uniform far pairs, transposed tile order, two-table."""
+    from oracle import c_oracle as CO
+    from oracle import model as M
+
+    for k, v in ROW_KERNEL_VARIANTS[variant].items():
+        monkeypatch.setenv(k, v)
+    seen = set()
+    for L, kind in ((16, "ring"), (20, "ring"), (18, "open"), (14, "j1j2"), (22, "ring")):
+        cfg = _chain_like_config(L, kind)
+        o = CO.COracle(M.model_from_config(cfg))
+        want_reps = o.enumerate()
+        D, basis, h, reps, masks = setup_model(torch, cfg, 1)
+        assert np.array_equal(reps[0].cpu().numpy().view(np.uint64), want_reps)
+        rs = np.random.RandomState(L)
+        x = rs.rand(len(want_reps)) - 0.5
+        want = o.local_matvec(want_reps, x)
+        got, pl = run_matvec(torch, D, h, reps, masks, x, 1, "pull")
+        seen.add(pl.kernel)
+        assert np.abs(got - want).max() <= 1e-12 * max(1.0, np.abs(want).max()), (variant, L, kind, pl.kernel)
+        if variant == "default":
+            assert pl.kernel == ("direct-pull" if kind == "j1j2" else "direct-pull+staged"), (kind, pl.kernel)
+        # c128 vectors go through the generic row kernel
+        xc = x + 1j * (rs.rand(len(want_reps)) - 0.5)
+        gotc, plc = run_matvec(torch, D, h, reps, masks, xc, 1, "pull")
+        wantc = o.local_matvec(want_reps, xc)
+        assert np.abs(gotc - wantc).max() <= 1e-12 * max(1.0, np.abs(wantc).max()), (variant, L, kind, plc.kernel)
+    if variant.startswith("two-table"):
+        assert "direct-pull+lin" in seen
+    if variant in ("generic-row-kernel", "no-uniform-pairs", "uniform-from-4", "transposed-tiles"):
+        assert seen == {"direct-pull"}
