@@ -640,7 +640,7 @@ __global__ __launch_bounds__(kBlock) void k_direct(lsk_runs runs, int n_groups, 
                 const double vr = runs.v_re[r], vi = REAL ? 0.0 : runs.v_im[r];
                 int k = WT::popc(a & (W)(((uint64_t)1 << lo0) - 1));
                 int lo_begin = lo0, lo_end = lo0 + cnt;
-                if (sizeof(W) == 4 && PULL && !CPLX && REAL && !(gx & 1)) {
+                if (sizeof(W) == 4 && PULL && REAL && !(gx & 1)) {
                     // Far pairs (lo >= hb): the 64 consecutive states of a wave nearly always agree on every
                     // bit >= hb, so such a pair is anti-aligned for the whole wave or for none of it.  The
                     // test, the bit count below the pair and the rank shift are then wave-uniform (scalar
@@ -655,23 +655,29 @@ __global__ __launch_bounds__(kBlock) void k_direct(lsk_runs runs, int n_groups, 
                         uint32_t m = (a0 ^ (a0 >> 1)) & (uint32_t)((((uint64_t)1 << lo_end) - 1) & ~(((uint64_t)1 << split) - 1));
                         const uint32_t i32 = (uint32_t)ig;
                         while (m) {
-                            double xv[4];
-                            bool ok[4];
+                            double xv[4], xw[4];
 #pragma unroll
                             for (int u = 0; u < 4; ++u) {
-                                ok[u] = m != 0;
                                 xv[u] = 0.0;
-                                if (ok[u]) {
+                                xw[u] = 0.0;
+                                if (m) {
                                     const int lo = __builtin_ctz(m);
                                     m &= m - 1;
                                     const int kk = bs.hamming_weight - __popc(a0 >> lo); // set bits below lo
                                     const uint32_t d = (uint32_t)s_binom[lo * LSK_BINOM_K + kk];
                                     const uint32_t idx = ((a0 >> lo) & 1) ? i32 + d : i32 - d;
-                                    xv[u] = x[idx];
+                                    if (CPLX) {
+                                        const double2 q = reinterpret_cast<double2 const *>(x)[idx];
+                                        xv[u] = q.x;
+                                        xw[u] = q.y;
+                                    } else xv[u] = x[idx];
                                 }
                             }
 #pragma unroll
-                            for (int u = 0; u < 4; ++u) accr = fma(ok[u] ? vr : 0.0, xv[u], accr);
+                            for (int u = 0; u < 4; ++u) {
+                                accr = fma(vr, xv[u], accr);
+                                if (CPLX) acci = fma(vr, xw[u], acci);
+                            }
                         }
                         lo_end = split;
                     }
@@ -883,6 +889,7 @@ constexpr int kChainTile = 1024;  // rows per tile (4 per thread)
 constexpr int kChainHalo = 512;   // >= C(11, 5)
 constexpr int kChainLdsPairs = 12; // pairs lo < 12 are served from the LDS window
 constexpr int kChainWindow = kChainTile + 2 * kChainHalo + 2; // +2: the window starts on an even row
+constexpr int kChainFar = 8;      // far-pair gathers in flight per row before the first wait
 
 __global__ __launch_bounds__(kBlock) void k_chain(lsk_runs runs, int n_diag,
                                                   lsk_term const *__restrict__ diag, int hamming_weight,
@@ -905,6 +912,12 @@ __global__ __launch_bounds__(kBlock) void k_chain(lsk_runs runs, int n_diag,
         if (cnt == 0) continue; // block-uniform
         const int64_t i0 = (int64_t)(slot & 0xffffffffffffULL);
         const int64_t w0 = (i0 - kChainHalo) & ~(int64_t)1; // first row of the window (even; may be < 0)
+        uint32_t a_next = 0, t0_next = 0xffffffffu, t1_next = 0xffffffffu;
+        if ((int)threadIdx.x < cnt) { // first row of this thread: requested before the window is staged
+            a_next = (uint32_t)__builtin_nontemporal_load(reps + i0 + threadIdx.x);
+            if (n_cached > 0) t0_next = __builtin_nontemporal_load(cache + i0 + threadIdx.x);
+            if (n_cached > 1) t1_next = __builtin_nontemporal_load(cache + (size_t)n + (size_t)(i0 + threadIdx.x));
+        }
         __syncthreads(); // every wave is done with the previous window (and s_binom is loaded)
         for (int j = 2 * threadIdx.x; j < kChainWindow; j += 2 * kBlock) {
             const int64_t row = w0 + j;
@@ -919,9 +932,21 @@ __global__ __launch_bounds__(kBlock) void k_chain(lsk_runs runs, int n_diag,
 #pragma unroll 1
         for (int sub = 0; sub < kChainTile / kBlock; ++sub) {
             const int r = sub * kBlock + threadIdx.x;
+            // this row's state and cached partner ranks were requested one iteration ago; request the next row's
+            const uint32_t a = a_next, t0 = t0_next, t1 = t1_next;
+            if (sub + 1 < kChainTile / kBlock && r + kBlock < cnt) {
+                const int64_t in = i0 + r + kBlock;
+                a_next = (uint32_t)__builtin_nontemporal_load(reps + in);
+                if (n_cached > 0) t0_next = __builtin_nontemporal_load(cache + in);
+                if (n_cached > 1) t1_next = __builtin_nontemporal_load(cache + (size_t)n + (size_t)in);
+            }
             if (r >= cnt) continue;
             const int64_t i = i0 + r;
-            const uint32_t a = (uint32_t)__builtin_nontemporal_load(reps + i);
+            const uint32_t i32 = (uint32_t)i;
+            // ring-closing pairs (partner rank has no closed form: cached per plan, lsk_chain_cache): gathers
+            // issued now, consumed at the end
+            const double g0 = n_cached > 0 ? x[t0 != 0xffffffffu ? t0 : i32] : 0.0;
+            const double g1 = n_cached > 1 ? x[t1 != 0xffffffffu ? t1 : i32] : 0.0;
             const int jr = own0 + r;
             const double xr = s_x[jr];
             double accr;
@@ -931,7 +956,6 @@ __global__ __launch_bounds__(kBlock) void k_chain(lsk_runs runs, int n_diag,
                 diag_coeff<uint32_t, true>(runs, n_diag, diag, a, dr, di);
                 accr = dr * xr;
             }
-            const uint32_t i32 = (uint32_t)i;
             const uint32_t tdiff = a ^ (a >> 1);
             for (int q = 0; q < runs.n_runs; ++q) {
                 const int lo0 = runs.lo0[q];
@@ -939,8 +963,32 @@ __global__ __launch_bounds__(kBlock) void k_chain(lsk_runs runs, int n_diag,
                 const double vr = runs.v_re[q];
                 int k = __popc(a & (uint32_t)(((uint64_t)1 << lo0) - 1));
                 int lo = lo0;
-                // ---- near pairs: partner inside the LDS window ----------------------------------------
                 const int e1 = lo_end < kChainLdsPairs ? lo_end : kChainLdsPairs;
+                // ---- far pairs, wave-uniform (see k_direct): up to kChainFar gathers are issued before the near
+                //      pairs are served from LDS, so their latency overlaps that work --------------------------
+                const int near_end = lo0 > e1 ? lo0 : e1;
+                const int split = hb == 0 ? lo_end : (hb < near_end ? near_end : (hb > lo_end ? lo_end : hb));
+                const uint32_t a0 = __builtin_amdgcn_readfirstlane(a);
+                const bool uni = split < lo_end && __builtin_amdgcn_ballot_w64(((a ^ a0) >> split) != 0) == 0;
+                uint32_t m = 0;
+                double xv[kChainFar];
+#pragma unroll
+                for (int u = 0; u < kChainFar; ++u) xv[u] = 0.0;
+                if (uni) {
+                    m = (a0 ^ (a0 >> 1)) & (uint32_t)((((uint64_t)1 << lo_end) - 1) & ~(((uint64_t)1 << split) - 1));
+#pragma unroll
+                    for (int u = 0; u < kChainFar; ++u) {
+                        if (m) {
+                            const int p = __builtin_ctz(m);
+                            m &= m - 1;
+                            const int kk = hamming_weight - __popc(a0 >> p); // set bits below p
+                            const uint32_t d = s_binom[p * LSK_BINOM_K + kk];
+                            xv[u] = x[((a0 >> p) & 1) ? i32 + d : i32 - d];
+                        }
+                    }
+                    lo_end = split;
+                }
+                // ---- near pairs: partner inside the LDS window ----------------------------------------
 #pragma unroll 4
                 for (; lo < e1; ++lo) {
                     const bool bit = (a >> lo) & 1;
@@ -950,32 +998,23 @@ __global__ __launch_bounds__(kBlock) void k_chain(lsk_runs runs, int n_diag,
                     const int j = bit ? jr + d : jr - d;
                     accr = fma(vr, s_x[act ? j : kChainWindow], accr);
                 }
-                // ---- far pairs: wave-uniform (see k_direct) ---------------------------------------------
-                const int split = hb == 0 ? lo_end : (hb < lo ? lo : (hb > lo_end ? lo_end : hb));
-                const uint32_t a0 = __builtin_amdgcn_readfirstlane(a);
-                const bool uni = split < lo_end && __builtin_amdgcn_ballot_w64(((a ^ a0) >> split) != 0) == 0;
-                if (uni) {
-                    uint32_t m = (a0 ^ (a0 >> 1)) & (uint32_t)((((uint64_t)1 << lo_end) - 1) & ~(((uint64_t)1 << split) - 1));
-                    while (m) {
-                        double xv[4];
-                        bool ok[4];
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            ok[u] = m != 0;
-                            xv[u] = 0.0;
-                            if (ok[u]) {
-                                const int p = __builtin_ctz(m);
-                                m &= m - 1;
-                                const int kk = hamming_weight - __popc(a0 >> p); // set bits below p
-                                const uint32_t d = s_binom[p * LSK_BINOM_K + kk];
-                                const uint32_t idx = ((a0 >> p) & 1) ? i32 + d : i32 - d;
-                                xv[u] = x[idx];
-                            }
+                for (int u = 0; u < kChainFar; ++u) accr = fma(vr, xv[u], accr);
+                while (m) { // more than kChainFar anti-aligned far pairs
+                    double xw[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        xw[u] = 0.0;
+                        if (m) {
+                            const int p = __builtin_ctz(m);
+                            m &= m - 1;
+                            const int kk = hamming_weight - __popc(a0 >> p);
+                            const uint32_t d = s_binom[p * LSK_BINOM_K + kk];
+                            xw[u] = x[((a0 >> p) & 1) ? i32 + d : i32 - d];
                         }
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) accr = fma(ok[u] ? vr : 0.0, xv[u], accr);
                     }
-                    lo_end = split;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) accr = fma(vr, xw[u], accr);
                 }
                 // ---- middle pairs (and far pairs of a wave that straddles two high parts) --------------
 #pragma unroll 4
@@ -989,13 +1028,8 @@ __global__ __launch_bounds__(kBlock) void k_chain(lsk_runs runs, int n_diag,
                     accr = fma(act ? vr : 0.0, x[idx], accr);
                 }
             }
-            // ---- exchange pairs that are not adjacent (the bond that closes a ring): the rank of the
-            //      partner has no closed form, it is read from the plan's cache (lsk_chain_cache) ---------
-            for (int c = 0; c < n_cached; ++c) {
-                const uint32_t tgt = __builtin_nontemporal_load(cache + (size_t)c * (size_t)n + (size_t)i);
-                const bool act = tgt != 0xffffffffu;
-                accr = fma(act ? (c == 0 ? cv0 : cv1) : 0.0, x[act ? tgt : i32], accr);
-            }
+            accr = fma(t0 != 0xffffffffu ? cv0 : 0.0, g0, accr);
+            accr = fma(t1 != 0xffffffffu ? cv1 : 0.0, g1, accr);
             __builtin_nontemporal_store(accr, y + i);
         }
     }

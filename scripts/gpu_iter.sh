@@ -1,9 +1,9 @@
-# GPU job: parity + timing of the staged row kernel (k_chain) with cached ring-closing partners
+# GPU job: parity suite + c128 timing with the wave-uniform far pairs
 export TMPDIR=/tmp
-timeout 600 python -m pytest tests -m gpu -q -x 2>&1 | tail -3
-B="timeout 120 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra"
-echo "+ CHAIN=0"; LS_AMD_CHAIN=0 $B
-echo "+ CHAIN=1"; $B
-echo "+ CHAIN=1 HIGH_PAIR=12"; LS_AMD_HIGH_PAIR=12 $B
-echo "+ CHAIN=1 BLOCKS=6"; LS_AMD_BLOCKS_PER_CU=6 $B
-echo "+ CHAIN=1 BLOCKS=5"; LS_AMD_BLOCKS_PER_CU=5 $B
+cd $GRAFT_REPO_ROOT
+timeout 900 python -m pytest tests -m gpu -q --maxfail=5 2>&1 | tail -3
+B="timeout 120 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extra"
+echo "+ c128 HIGH_PAIR=0"; LS_AMD_HIGH_PAIR=0 $B --dtype c128
+echo "+ c128 default"; $B --dtype c128
+echo "+ c128 HIGH_PAIR=12"; LS_AMD_HIGH_PAIR=12 $B --dtype c128
+echo "+ f64 default"; $B
