@@ -910,6 +910,7 @@ struct ls_amd_plan {
     int chain_cached;      /* leading non-adjacent exchange groups whose partner ranks are cached */
     uint32_t *d_chain_cache; /* [chain_cached][count] */
     double chain_v[2];
+    int64_t chain_row0; /* global rank of the first local row (replicated-x plans) */
     /* two-table pull kernel (lsk_lin in lsk.h) */
     int has_lin;
     lsk_lin lin;
@@ -1250,6 +1251,57 @@ static int setup_lin(ls_amd_plan *pl) {
     return 0;
 }
 
+/* Staged row kernel (k_chain, lsk.h): f64 pull, <= 32 sites, the full fixed-weight basis without symmetries, a real
+ * operator made of exchange runs plus at most two other exchange pairs.  LS_AMD_CHAIN=0 keeps k_direct. */
+static int chain_eligible(ls_amd_plan const *pl) {
+    ls_hs_operator const *op = pl->op;
+    struct ls_amd_operator_ext const *ext = op->ext;
+    char const *e = getenv("LS_AMD_CHAIN");
+    if (e && atoi(e) == 0) return 0;
+    if (getenv("LS_AMD_HIGH_BITS") || (getenv("LS_AMD_LIN") && atoi(getenv("LS_AMD_LIN")) != 0)) return 0;
+    if (pl->cplx || op->basis->number_sites > 32 || op->basis->spin_inversion != 0 || pl->dbs.proj != LSK_PROJ_NONE ||
+        !ext->is_real || !ext->is_hermitian || ext->runs.n_runs <= 0)
+        return 0;
+    if (ext->n_groups - ext->runs.n_run_groups > 2) return 0;
+    for (int g = ext->runs.n_run_groups; g < ext->n_groups; ++g) {
+        lsk_group const *G = &ext->groups[g];
+        if (G->fast != LSK_GROUP_EXCHANGE || G->v_im != 0.0 || __builtin_popcountll(G->x) != 2) return 0;
+    }
+    return 1;
+}
+/* tile map with 1024-row tiles + the cache of partner ranks of the exchange pairs outside the runs (for a ring: the
+ * bond that closes it) -- 4 bytes per row instead of a ranking loop of `weight` steps per row and matvec.
+ * Leaves pl->has_chain == 0 (and no tile map) when a partner leaves the basis: k_direct reports that at run time,
+ * as the reference does. */
+static int setup_chain(ls_amd_plan *pl, lsk_index index, int64_t n, uint64_t const *d_reps, void *stream) {
+    struct ls_amd_operator_ext const *ext = pl->op->ext;
+    int const nc = ext->n_groups - ext->runs.n_run_groups;
+    if (nc > 0 && n > 0) {
+        void *q;
+        DEV(lsk_malloc(&q, sizeof(uint32_t) * (size_t)nc * (size_t)n));
+        pl->d_chain_cache = (uint32_t *)q;
+        int zero = 0, flag = 0;
+        DEV(lsk_h2d(pl->d_err, &zero, sizeof(int)));
+        for (int c = 0; c < nc; ++c)
+            DEV(lsk_chain_cache(pl->dbs, index, n, d_reps, ext->groups[ext->runs.n_run_groups + c].x,
+                                pl->d_chain_cache + (size_t)c * (size_t)n, pl->d_err, stream));
+        DEV(lsk_sync(stream));
+        DEV(lsk_d2h(&flag, pl->d_err, sizeof(int)));
+        DEV(lsk_h2d(pl->d_err, &zero, sizeof(int)));
+        if (flag) {
+            lsk_free(pl->d_chain_cache);
+            pl->d_chain_cache = NULL;
+            return 0;
+        }
+        pl->chain_cached = nc;
+        pl->chain_v[0] = ext->groups[ext->runs.n_run_groups].v_re;
+        pl->chain_v[1] = nc > 1 ? ext->groups[ext->runs.n_run_groups + 1].v_re : 0.0;
+    }
+    if (build_tilemap(pl, n, 0, 1024) != 0) return -1;
+    pl->has_chain = 1;
+    return 0;
+}
+
 static int plan_setup_part(ls_amd_plan *pl, part_state *ps, int part_id, int num_rounds, void *stream) {
     ls_hs_basis const *b = pl->op->basis;
     int const L = b->number_sites;
@@ -1412,60 +1464,13 @@ int ls_amd_plan_create(ls_amd_plan **out, ls_hs_operator const *op, ls_amd_dtype
     }
     if (pl->family == FAMILY_DIRECT_PULL || pl->family == FAMILY_DIRECT_PUSH) {
         int const combinadic = pl->parts[0].index.kind == LSK_INDEX_COMBINADIC;
-        /* staged row kernel (k_chain): f64, <= 32 sites, full fixed-weight basis, real operator with exchange runs */
-        char const *e = getenv("LS_AMD_CHAIN");
-        pl->has_chain = pl->family == FAMILY_DIRECT_PULL && combinadic && !pl->cplx && op->basis->number_sites <= 32 &&
-                        op->basis->spin_inversion == 0 && pl->dbs.proj == LSK_PROJ_NONE && op->ext->is_real &&
-                        pl->dop.runs.n_runs > 0 && !(e && atoi(e) == 0) && !getenv("LS_AMD_HIGH_BITS") &&
-                        !(getenv("LS_AMD_LIN") && atoi(getenv("LS_AMD_LIN")) != 0);
-        if (pl->has_chain) {
-            /* every group outside the runs must be a non-adjacent exchange pair (at most two: their partner
-             * ranks are cached below) */
-            struct ls_amd_operator_ext const *ext = op->ext;
-            int const extra = ext->n_groups - ext->runs.n_run_groups;
-            if (extra > 2) pl->has_chain = 0;
-            for (int g = ext->runs.n_run_groups; g < ext->n_groups && pl->has_chain; ++g) {
-                lsk_group const *G = &ext->groups[g];
-                if (G->fast != LSK_GROUP_EXCHANGE || G->v_im != 0.0 || __builtin_popcountll(G->x) != 2) pl->has_chain = 0;
-            }
-        }
-        int const chain_candidate = pl->has_chain;
-        e = getenv("LS_AMD_TRANSPOSED"); /* transposed tile order: measured neutral on chain_32, off by default */
-        int const transposed = combinadic && pl->family == FAMILY_DIRECT_PULL && !pl->has_chain && e && atoi(e) != 0;
-        if (build_tilemap(pl, pl->parts[0].count, transposed, pl->has_chain ? 1024 : 256) != 0) { ls_amd_plan_destroy(pl); return -1; }
-        if (pl->has_chain) {
-            /* partner ranks of the exchange pairs outside the runs -- for a ring, the bond that closes it:
-             * 4 bytes per row instead of a ranking loop of `weight` steps per row and matvec */
-            struct ls_amd_operator_ext const *ext = op->ext;
-            int const nc = ext->n_groups - ext->runs.n_run_groups;
-            int64_t const n = pl->parts[0].count;
-            if (nc > 0 && n > 0) {
-                void *q;
-                if (lsk_malloc(&q, sizeof(uint32_t) * (size_t)nc * (size_t)n) != 0) { ls_amd_plan_destroy(pl); return dev_error(); }
-                pl->d_chain_cache = (uint32_t *)q;
-                int zero2 = 0, flag = 0;
-                DEV(lsk_h2d(pl->d_err, &zero2, sizeof(int)));
-                for (int c = 0; c < nc; ++c)
-                    DEV(lsk_chain_cache(pl->dbs, pl->parts[0].index, n, pl->parts[0].d_reps, ext->groups[ext->runs.n_run_groups + c].x,
-                                        pl->d_chain_cache + (size_t)c * (size_t)n, pl->d_err, stream));
-                DEV(lsk_sync(stream));
-                DEV(lsk_d2h(&flag, pl->d_err, sizeof(int)));
-                DEV(lsk_h2d(pl->d_err, &zero2, sizeof(int)));
-                if (flag) { /* a partner leaves the basis: k_direct reports that at run time, as the reference does */
-                    pl->has_chain = 0;
-                    lsk_free(pl->d_chain_cache);
-                    pl->d_chain_cache = NULL;
-                } else {
-                    pl->chain_cached = nc;
-                    pl->chain_v[0] = ext->groups[ext->runs.n_run_groups].v_re;
-                    pl->chain_v[1] = nc > 1 ? ext->groups[ext->runs.n_run_groups + 1].v_re : 0.0;
-                }
-            }
-        }
-        if (chain_candidate && !pl->has_chain) { /* back to k_direct: its tile map has 256-row tiles */
-            lsk_free(pl->d_tilemap);
-            pl->d_tilemap = NULL;
-            if (build_tilemap(pl, pl->parts[0].count, 0, 256) != 0) { ls_amd_plan_destroy(pl); return -1; }
+        part_state *ps0 = &pl->parts[0];
+        if (pl->family == FAMILY_DIRECT_PULL && combinadic && chain_eligible(pl) &&
+            setup_chain(pl, ps0->index, ps0->count, ps0->d_reps, stream) != 0) { ls_amd_plan_destroy(pl); return -1; }
+        if (!pl->has_chain) {
+            char const *e = getenv("LS_AMD_TRANSPOSED"); /* transposed tile order: measured neutral on chain_32, off by default */
+            int const transposed = combinadic && pl->family == FAMILY_DIRECT_PULL && e && atoi(e) != 0;
+            if (build_tilemap(pl, ps0->count, transposed, 256) != 0) { ls_amd_plan_destroy(pl); return -1; }
         }
     }
     if (pl->family == FAMILY_DIRECT_PULL && pl->parts[0].index.kind == LSK_INDEX_COMBINADIC) {
@@ -1568,7 +1573,16 @@ int ls_amd_plan_create_replicated(ls_amd_plan **out, ls_hs_operator const *op, l
         pl->gindex = gps.index;
         pl->d_gtable = gps.d_table;
     }
-    if (pl->family == FAMILY_REPL_DIRECT && build_tilemap(pl, count_local, 0, 256) != 0) { ls_amd_plan_destroy(pl); return -1; }
+    if (pl->family == FAMILY_REPL_DIRECT) {
+        /* rows that are a contiguous block [row0, row0 + count_local) of the global basis (what ReplicatedOperator
+         * hands over: a slice of the global array) can take the staged kernel */
+        int const contiguous = d_reps_local >= d_reps_global && d_reps_local + count_local <= d_reps_global + count_global;
+        if (contiguous && pl->gindex.kind == LSK_INDEX_COMBINADIC && count_global < 0xffffffffLL && chain_eligible(pl)) {
+            pl->chain_row0 = (int64_t)(d_reps_local - d_reps_global);
+            if (setup_chain(pl, pl->gindex, count_local, d_reps_local, stream) != 0) { ls_amd_plan_destroy(pl); return -1; }
+        }
+        if (!pl->has_chain && build_tilemap(pl, count_local, 0, 256) != 0) { ls_amd_plan_destroy(pl); return -1; }
+    }
     if (pl->family == FAMILY_REPL_DIRECT && pl->gindex.kind == LSK_INDEX_COMBINADIC && setup_lin(pl) != 0) {
         ls_amd_plan_destroy(pl);
         return -1;
@@ -1598,7 +1612,10 @@ int ls_amd_matvec_replicated(ls_amd_plan *pl, void const *d_x_global, void *d_y_
     int slot;
     if (pl->family == FAMILY_REPL_DIRECT) {
         slot = timing_begin(pl, stream);
-        if (pl->has_lin)
+        if (pl->has_chain)
+            DEV(lsk_chain(pl->dop, pl->dbs, pl->gindex, pl->tilemap, ps->count, ps->d_reps, pl->chain_row0, pl->gindex.count,
+                          d_x_global, d_y_local, pl->chain_cached, pl->d_chain_cache, pl->chain_v[0], pl->chain_v[1], stream));
+        else if (pl->has_lin)
             DEV(lsk_lin_pull(pl->lin, pl->dop, pl->dbs, pl->cplx, 1, ps->count, ps->d_reps, d_x_global, d_y_local,
                              pl->d_err, stream));
         else
@@ -1624,7 +1641,8 @@ char const *ls_amd_plan_kernel_name(ls_amd_plan const *pl) {
     case FAMILY_DIRECT_PULL:
         return pl->has_chain ? "direct-pull+staged" : pl->has_highpart ? "direct-pull+highpart" : pl->has_lin ? "direct-pull+lin" : "direct-pull";
     case FAMILY_TILE_PULL: return "tile-pull";
-    case FAMILY_REPL_DIRECT: return pl->has_lin ? "replicated-direct-pull+lin" : "replicated-direct-pull";
+    case FAMILY_REPL_DIRECT:
+        return pl->has_chain ? "replicated-direct-pull+staged" : pl->has_lin ? "replicated-direct-pull+lin" : "replicated-direct-pull";
     case FAMILY_REPL_TILE: return "replicated-tile-pull";
     default: return "tile";
     }
@@ -1713,8 +1731,8 @@ int ls_amd_matvec(ls_amd_plan *pl, void const *const *d_x, void *const *d_y, voi
         part_state *ps = &pl->parts[0];
         int slot = timing_begin(pl, stream);
         if (pl->has_chain)
-            DEV(lsk_chain(pl->dop, pl->dbs, ps->index, pl->tilemap, ps->count, ps->d_reps, d_x[0], d_y[0], pl->chain_cached,
-                          pl->d_chain_cache, pl->chain_v[0], pl->chain_v[1], stream));
+            DEV(lsk_chain(pl->dop, pl->dbs, ps->index, pl->tilemap, ps->count, ps->d_reps, 0, ps->count, d_x[0], d_y[0],
+                          pl->chain_cached, pl->d_chain_cache, pl->chain_v[0], pl->chain_v[1], stream));
         else if (pl->has_lin)
             DEV(lsk_lin_pull(pl->lin, pl->dop, pl->dbs, pl->cplx, 0, ps->count, ps->d_reps, d_x[0], d_y[0], pl->d_err,
                              stream));

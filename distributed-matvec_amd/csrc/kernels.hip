@@ -898,7 +898,7 @@ __global__ __launch_bounds__(kBlock) void k_chain(lsk_runs runs, int n_diag,
                                                   int64_t n, uint64_t const *__restrict__ reps,
                                                   double const *__restrict__ x, double *__restrict__ y,
                                                   int hb, int n_cached, uint32_t const *__restrict__ cache,
-                                                  double cv0, double cv1) {
+                                                  double cv0, double cv1, uint32_t row0, int64_t n_x) {
     __shared__ uint32_t s_binom[32 * LSK_BINOM_K]; // states have <= 32 bits
     __shared__ double s_x[kChainWindow + 1]; // last slot: 0.0, read by the lanes whose pair is aligned
     for (int k = threadIdx.x; k < 32 * LSK_BINOM_K; k += blockDim.x) s_binom[k] = (uint32_t)g_binom[k];
@@ -911,7 +911,8 @@ __global__ __launch_bounds__(kBlock) void k_chain(lsk_runs runs, int n_diag,
         const int cnt = (int)(slot >> 48);
         if (cnt == 0) continue; // block-uniform
         const int64_t i0 = (int64_t)(slot & 0xffffffffffffULL);
-        const int64_t w0 = (i0 - kChainHalo) & ~(int64_t)1; // first row of the window (even; may be < 0)
+        // rows are local (reps, cache, y); x is indexed by the global rank = row0 + local row
+        const int64_t w0 = ((int64_t)row0 + i0 - kChainHalo) & ~(int64_t)1; // first row of the window (even; may be < 0)
         uint32_t a_next = 0, t0_next = 0xffffffffu, t1_next = 0xffffffffu;
         if ((int)threadIdx.x < cnt) { // first row of this thread: requested before the window is staged
             a_next = (uint32_t)__builtin_nontemporal_load(reps + i0 + threadIdx.x);
@@ -922,13 +923,13 @@ __global__ __launch_bounds__(kBlock) void k_chain(lsk_runs runs, int n_diag,
         for (int j = 2 * threadIdx.x; j < kChainWindow; j += 2 * kBlock) {
             const int64_t row = w0 + j;
             double2 v;
-            if (row >= 0 && row + 1 < n) v = *reinterpret_cast<double2 const *>(x + row);
-            else { v.x = (row >= 0 && row < n) ? x[row] : 0.0; v.y = (row + 1 >= 0 && row + 1 < n) ? x[row + 1] : 0.0; }
+            if (row >= 0 && row + 1 < n_x) v = *reinterpret_cast<double2 const *>(x + row);
+            else { v.x = (row >= 0 && row < n_x) ? x[row] : 0.0; v.y = (row + 1 >= 0 && row + 1 < n_x) ? x[row + 1] : 0.0; }
             s_x[j] = v.x;
             s_x[j + 1] = v.y;
         }
         __syncthreads();
-        const int own0 = (int)(i0 - w0);
+        const int own0 = (int)((int64_t)row0 + i0 - w0);
 #pragma unroll 1
         for (int sub = 0; sub < kChainTile / kBlock; ++sub) {
             const int r = sub * kBlock + threadIdx.x;
@@ -942,7 +943,7 @@ __global__ __launch_bounds__(kBlock) void k_chain(lsk_runs runs, int n_diag,
             }
             if (r >= cnt) continue;
             const int64_t i = i0 + r;
-            const uint32_t i32 = (uint32_t)i;
+            const uint32_t i32 = row0 + (uint32_t)i;
             // ring-closing pairs (partner rank has no closed form: cached per plan, lsk_chain_cache): gathers
             // issued now, consumed at the end
             const double g0 = n_cached > 0 ? x[t0 != 0xffffffffu ? t0 : i32] : 0.0;
@@ -1065,8 +1066,8 @@ extern "C" int lsk_chain_cache(lsk_basis bs, lsk_index ix, int64_t n, uint64_t c
 }
 
 extern "C" int lsk_chain(lsk_operator op, lsk_basis bs, lsk_index ix, lsk_tilemap tm, int64_t n, uint64_t const *reps,
-                         void const *x, void *y, int n_cached, uint32_t const *cache, double cv0, double cv1,
-                         void *stream) {
+                         int64_t row0, int64_t n_x, void const *x, void *y, int n_cached, uint32_t const *cache,
+                         double cv0, double cv1, void *stream) {
     if (n == 0 || tm.slots_per_xcd == 0) return 0;
     int64_t gb = tm.slots_per_xcd * 8;
     int64_t cap = resident_grid(k_chain, gb);
@@ -1080,7 +1081,7 @@ extern "C" int lsk_chain(lsk_operator op, lsk_basis bs, lsk_index ix, lsk_tilema
     if (gb > cap) gb = cap;
     hipLaunchKernelGGL(k_chain, dim3((unsigned)gb), dim3(kBlock), 0, (hipStream_t)stream, op.runs, op.n_diag, op.diag,
                        bs.hamming_weight, ix.binom, tm.entries, tm.slots_per_xcd, n, reps, (double const *)x, (double *)y,
-                       high_pair_setting(kChainLdsPairs), n_cached, cache, cv0, cv1);
+                       high_pair_setting(kChainLdsPairs), n_cached, cache, cv0, cv1, (uint32_t)row0, n_x);
     LSK_LAUNCH_CHECK();
     return 0;
 }

@@ -162,9 +162,11 @@ int lsk_diag(lsk_operator op, int cplx, int64_t n, uint64_t const *reps, void co
 int lsk_direct(lsk_operator op, lsk_basis bs, lsk_index ix, int cplx, int pull, lsk_tilemap tm,
                uint64_t const *reps, void const *x, void *y, int *d_err, void *stream);
 /* staged row kernel (k_chain): f64 pull, <= 32 sites, full fixed-Hamming-weight basis without symmetries, real
- * Hermitian operator; the tile map must have been built with 1024-row tiles. */
+ * Hermitian operator; the tile map must have been built with 1024-row tiles.  The n rows (reps, cache, y) are
+ * the global rows [row0, row0 + n) of the basis; x is the whole vector of n_x elements. */
 int lsk_chain(lsk_operator op, lsk_basis bs, lsk_index ix, lsk_tilemap tm, int64_t n, uint64_t const *reps,
-              void const *x, void *y, int n_cached, uint32_t const *cache, double cv0, double cv1, void *stream);
+              int64_t row0, int64_t n_x, void const *x, void *y, int n_cached, uint32_t const *cache, double cv0,
+              double cv1, void *stream);
 /* partner ranks of a non-adjacent exchange pair for every row (see k_chain); *d_flag is raised if a partner
  * leaves the basis */
 int lsk_chain_cache(lsk_basis bs, lsk_index ix, int64_t n, uint64_t const *reps, uint64_t xmask, uint32_t *out,

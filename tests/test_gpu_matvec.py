@@ -554,7 +554,7 @@ def test_chain_36_symm_full_size_properties(torch):
     assert abs(lhs - rhs) <= 1e-9 * max(1.0, abs(lhs))
 
 
-@pytest.mark.parametrize("name", ["heisenberg_chain_16", "heisenberg_chain_24_symm", "heisenberg_chain_10", "issue_01", "heisenberg_kagome_16"])
+@pytest.mark.parametrize("name", ["heisenberg_chain_16", "heisenberg_chain_20", "heisenberg_chain_24_symm", "heisenberg_chain_10", "issue_01", "heisenberg_kagome_16"])
 def test_replicated_x_block_rows(torch, name):
     """what distributed.ReplicatedOperator runs per rank: a CONTIGUOUS range of global rows against the
     replicated x (rows of every emulated rank concatenated = H x in block order)."""
@@ -570,6 +570,8 @@ def test_replicated_x_block_rows(torch, name):
     for p in range(P):
         n0, n1 = n * p // P, n * (p + 1) // P
         pl = D.ReplicatedPlan(h, reps_global[n0:n1], reps_global, xg.dtype, P, p)
+        if name in ("heisenberg_chain_16", "heisenberg_chain_20"):
+            assert pl.kernel == "replicated-direct-pull+staged"  # a slice of the global rows takes the staged kernel
         y = torch.zeros(n1 - n0, dtype=xg.dtype, device="cuda")
         pl.matvec(xg, y)
         pieces.append(y)
