@@ -1260,7 +1260,7 @@ static int chain_eligible(ls_amd_plan const *pl) {
     if (e && atoi(e) == 0) return 0;
     if (getenv("LS_AMD_HIGH_BITS") || (getenv("LS_AMD_LIN") && atoi(getenv("LS_AMD_LIN")) != 0)) return 0;
     if (pl->cplx || op->basis->number_sites > 32 || op->basis->spin_inversion != 0 || pl->dbs.proj != LSK_PROJ_NONE ||
-        !ext->is_real || !ext->is_hermitian || ext->runs.n_runs <= 0)
+        !ext->is_real || !ext->is_hermitian || ext->runs.n_runs <= 0 || ext->n_diag <= 0)
         return 0;
     if (ext->n_groups - ext->runs.n_run_groups > 2) return 0;
     for (int g = ext->runs.n_run_groups; g < ext->n_groups; ++g) {

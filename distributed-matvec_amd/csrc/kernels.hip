@@ -906,6 +906,9 @@ __global__ __launch_bounds__(kBlock) void k_chain(lsk_runs runs, int n_diag,
     const int xcd = blockIdx.x & 7;
     const int64_t blocks_per_xcd = gridDim.x >> 3;
     tilemap += (int64_t)xcd * slots_per_xcd;
+    // states have <= 32 bits: only the low word of every 64-bit state is loaded (one VGPR, so the
+    // prefetch below is not cut short by a wait on the unused high word)
+    uint32_t const *__restrict__ reps32 = reinterpret_cast<uint32_t const *>(reps);
     for (int64_t t = blockIdx.x >> 3; t < slots_per_xcd; t += blocks_per_xcd) {
         const uint64_t slot = tilemap[t];
         const int cnt = (int)(slot >> 48);
@@ -915,7 +918,7 @@ __global__ __launch_bounds__(kBlock) void k_chain(lsk_runs runs, int n_diag,
         const int64_t w0 = ((int64_t)row0 + i0 - kChainHalo) & ~(int64_t)1; // first row of the window (even; may be < 0)
         uint32_t a_next = 0, t0_next = 0xffffffffu, t1_next = 0xffffffffu;
         if ((int)threadIdx.x < cnt) { // first row of this thread: requested before the window is staged
-            a_next = (uint32_t)__builtin_nontemporal_load(reps + i0 + threadIdx.x);
+            a_next = __builtin_nontemporal_load(reps32 + 2 * (i0 + threadIdx.x));
             if (n_cached > 0) t0_next = __builtin_nontemporal_load(cache + i0 + threadIdx.x);
             if (n_cached > 1) t1_next = __builtin_nontemporal_load(cache + (size_t)n + (size_t)(i0 + threadIdx.x));
         }
@@ -930,14 +933,20 @@ __global__ __launch_bounds__(kBlock) void k_chain(lsk_runs runs, int n_diag,
         }
         __syncthreads();
         const int own0 = (int)((int64_t)row0 + i0 - w0);
+        // y of a row is stored one iteration late: the wait for the prefetched state at the end of an iteration
+        // (vmcnt counts loads and stores in order) then never waits for a store that was only just issued
+        double y_pending = 0.0;
+        int64_t i_pending = -1;
 #pragma unroll 1
         for (int sub = 0; sub < kChainTile / kBlock; ++sub) {
             const int r = sub * kBlock + threadIdx.x;
+            if (i_pending >= 0) __builtin_nontemporal_store(y_pending, y + i_pending);
+            i_pending = -1;
             // this row's state and cached partner ranks were requested one iteration ago; request the next row's
             const uint32_t a = a_next, t0 = t0_next, t1 = t1_next;
             if (sub + 1 < kChainTile / kBlock && r + kBlock < cnt) {
                 const int64_t in = i0 + r + kBlock;
-                a_next = (uint32_t)__builtin_nontemporal_load(reps + in);
+                a_next = __builtin_nontemporal_load(reps32 + 2 * in);
                 if (n_cached > 0) t0_next = __builtin_nontemporal_load(cache + in);
                 if (n_cached > 1) t1_next = __builtin_nontemporal_load(cache + (size_t)n + (size_t)in);
             }
@@ -950,13 +959,11 @@ __global__ __launch_bounds__(kBlock) void k_chain(lsk_runs runs, int n_diag,
             const double g1 = n_cached > 1 ? x[t1 != 0xffffffffu ? t1 : i32] : 0.0;
             const int jr = own0 + r;
             const double xr = s_x[jr];
-            double accr;
-            if (n_diag == 0) accr = y[i]; // no diagonal pass in the reference either (DMV:1062-1063)
-            else {
-                double dr, di;
-                diag_coeff<uint32_t, true>(runs, n_diag, diag, a, dr, di);
-                accr = dr * xr;
-            }
+            // (operators without diagonal terms accumulate into y, DMV:1062-1063: they stay with k_direct, so that
+            //  nothing here depends on a global load before the far gathers are consumed)
+            double dr, di;
+            diag_coeff<uint32_t, true>(runs, n_diag, diag, a, dr, di);
+            double accr = dr * xr;
             const uint32_t tdiff = a ^ (a >> 1);
             for (int q = 0; q < runs.n_runs; ++q) {
                 const int lo0 = runs.lo0[q];
@@ -1031,8 +1038,10 @@ __global__ __launch_bounds__(kBlock) void k_chain(lsk_runs runs, int n_diag,
             }
             accr = fma(t0 != 0xffffffffu ? cv0 : 0.0, g0, accr);
             accr = fma(t1 != 0xffffffffu ? cv1 : 0.0, g1, accr);
-            __builtin_nontemporal_store(accr, y + i);
+            y_pending = accr;
+            i_pending = i;
         }
+        if (i_pending >= 0) __builtin_nontemporal_store(y_pending, y + i_pending);
     }
 }
 
