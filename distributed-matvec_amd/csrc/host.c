@@ -1115,23 +1115,20 @@ static void tile_push(tile_list *l, int64_t row, int64_t cnt) {
     if (l->n == l->cap) { l->cap = l->cap ? 2 * l->cap : 1024; l->e = (uint64_t *)realloc(l->e, sizeof(uint64_t) * (size_t)l->cap); }
     l->e[l->n++] = (uint64_t)row | ((uint64_t)cnt << 48);
 }
-static int build_tilemap(ls_amd_plan *pl, int64_t n, int allow_transposed, int TILE) {
+/* host part: 8 lists of `*slots` entries in a malloc'ed array; `transposed` asks for the set order (needs the full
+ * fixed-weight basis: n == C(L, hw)), t / set_rows as described above */
+static int tilemap_host(int L, int hw, int64_t n, int transposed, int TILE, int t, int64_t set_rows, uint64_t **out,
+                        int64_t *slots_out) {
     tile_list lists[8];
     memset(lists, 0, sizeof(lists));
-    ls_hs_basis const *b = pl->op->basis;
-    int const L = b->number_sites, hw = b->ext->hamming_weight;
-    char const *e = getenv("LS_AMD_TOP_BITS");
-    int t = e ? atoi(e) : 8;
-    e = getenv("LS_AMD_SET_ROWS");
-    int64_t set_rows = e ? atoll(e) : 65536;
     if (set_rows < TILE) set_rows = TILE;
     if (t > 12) t = 12;
     if (t > L - 2) t = L - 2;
-    int const transposed = allow_transposed && t >= 2 && hw >= 0 && b->spin_inversion == 0 && (uint64_t)n == binom(L, hw);
+    if (transposed && !(t >= 2 && hw >= 0 && (uint64_t)n == binom(L, hw))) transposed = 0;
     if (!transposed) {
-        int64_t const tiles = (n + TILE - 1) / TILE, per = (tiles + 7) / 8;
-        for (int k = 0; k < 8; ++k)
-            for (int64_t q = k * per; q < (k + 1) * per && q < tiles; ++q)
+        int64_t const tiles = (n + TILE - 1) / TILE;
+        for (int k = 0; k < 8; ++k) /* XCD k: the k-th contiguous eighth of the tiles */
+            for (int64_t q = tiles * k / 8; q < tiles * (k + 1) / 8; ++q)
                 tile_push(&lists[k], q * TILE, n - q * TILE < TILE ? n - q * TILE : TILE);
     } else {
         int const Lr = L - t, nT = 1 << t;
@@ -1171,13 +1168,73 @@ static int build_tilemap(ls_amd_plan *pl, int64_t n, int allow_transposed, int T
         for (int64_t q = 0; q < lists[k].n; ++q) { flat[k * slots + q] = lists[k].e[q]; total += (int64_t)(lists[k].e[q] >> 48); }
         free(lists[k].e);
     }
-    int rc = total == n ? upload(&pl->d_tilemap, flat, sizeof(uint64_t) * (size_t)(8 * slots > 0 ? 8 * slots : 1)) : -2;
+    if (total != n) {
+        free(flat);
+        return set_error("internal error: tile map covers %lld of %lld rows", (long long)total, (long long)n);
+    }
+    *out = flat;
+    *slots_out = slots;
+    return transposed ? 1 : 0;
+}
+static int build_tilemap(ls_amd_plan *pl, int64_t n, int allow_transposed, int TILE) {
+    ls_hs_basis const *b = pl->op->basis;
+    char const *e = getenv("LS_AMD_TOP_BITS");
+    int const t = e ? atoi(e) : 8;
+    e = getenv("LS_AMD_SET_ROWS");
+    int64_t const set_rows = e ? atoll(e) : 65536;
+    uint64_t *flat = NULL;
+    int64_t slots = 0;
+    int const rc = tilemap_host(b->number_sites, b->ext->hamming_weight, n, allow_transposed && b->spin_inversion == 0, TILE, t,
+                                set_rows, &flat, &slots);
+    if (rc < 0) return -1;
+    int const up = upload(&pl->d_tilemap, flat, sizeof(uint64_t) * (size_t)(8 * slots > 0 ? 8 * slots : 1));
     free(flat);
-    if (rc == -2) return set_error("internal error: tile map covers %lld of %lld rows", (long long)total, (long long)n);
-    if (rc) return -1;
+    if (up) return -1;
     pl->tilemap.entries = (uint64_t const *)pl->d_tilemap;
     pl->tilemap.slots_per_xcd = slots;
-    pl->tilemap_transposed = transposed;
+    pl->tilemap_transposed = rc;
+    return 0;
+}
+/* test hook (host only): the tile map for the full basis of `number_sites` spins with `hamming_weight` up (or any n
+ * rows when transposed == 0).  Returns slots per XCD (< 0 on error); *entries is malloc'ed, free with
+ * ls_amd_test_free. */
+int64_t ls_amd_test_tilemap(int number_sites, int hamming_weight, int64_t n, int transposed, int tile_rows, int top_bits,
+                            int64_t set_rows, uint64_t **entries) {
+    int64_t slots = 0;
+    *entries = NULL;
+    if (tilemap_host(number_sites, hamming_weight, n, transposed, tile_rows, top_bits, set_rows, entries, &slots) < 0) return -1;
+    return slots;
+}
+void ls_amd_test_free(void *p) { free(p); }
+
+/* tables of the two-table ranking (lsk_lin in lsk.h): tlo[1 << B], thi[1 << hb] (u64 entries when wide) */
+static void lin_tables_host(int hw, int B, int hb, int wide, uint16_t *tlo, void *thi) {
+    for (uint32_t l = 0; l < (1u << B); ++l) {
+        uint64_t r = 0;
+        int j = 1;
+        for (uint32_t s = l; s; s &= s - 1, ++j) r += binom(__builtin_ctz(s), j);
+        tlo[l] = (uint16_t)r;
+    }
+    size_t const nh = (size_t)1 << hb;
+    for (size_t h = 0; h < nh; ++h) {
+        int const kl = hw - __builtin_popcountll((unsigned long long)h);
+        uint64_t r = 0;
+        if (kl >= 0 && kl <= B) {
+            int j = kl + 1;
+            for (uint64_t s = h; s; s &= s - 1, ++j) r += binom(B + __builtin_ctzll(s), j);
+        }
+        if (wide) ((uint64_t *)thi)[h] = r; else ((uint32_t *)thi)[h] = (uint32_t)r;
+    }
+}
+/* test hook (host only): ranks[i] = thi[state >> bits] + tlo[state & mask] for the given states of `hamming_weight` */
+int ls_amd_test_lin_rank(int number_sites, int hamming_weight, int bits, int64_t n, uint64_t const *states, int64_t *ranks) {
+    if (bits < 1 || bits > 15 || number_sites < 1 || number_sites > 41 || number_sites - bits > 26) return set_error("bad arguments");
+    int const hb = number_sites > bits ? number_sites - bits : 0;
+    uint16_t *tlo = (uint16_t *)malloc(sizeof(uint16_t) << bits);
+    uint64_t *thi = (uint64_t *)malloc(sizeof(uint64_t) << hb);
+    lin_tables_host(hamming_weight, bits, hb, 1, tlo, thi);
+    for (int64_t i = 0; i < n; ++i) ranks[i] = (int64_t)(thi[states[i] >> bits] + tlo[states[i] & ((1ULL << bits) - 1)]);
+    free(tlo); free(thi);
     return 0;
 }
 
@@ -1219,25 +1276,11 @@ static int setup_lin(ls_amd_plan *pl) {
             ++k;
             ++cnt[pass];
         }
-    uint16_t *tlo = (uint16_t *)malloc(sizeof(uint16_t) << B);
-    for (uint32_t l = 0; l < (1u << B); ++l) {
-        uint64_t r = 0;
-        int j = 1;
-        for (uint32_t s = l; s; s &= s - 1, ++j) r += binom(__builtin_ctz(s), j);
-        tlo[l] = (uint16_t)r;
-    }
     int const wide = L > 32;
     size_t const nh = (size_t)1 << hb, es = wide ? 8 : 4;
+    uint16_t *tlo = (uint16_t *)malloc(sizeof(uint16_t) << B);
     void *thi = malloc(nh * es);
-    for (size_t h = 0; h < nh; ++h) {
-        int const kl = hw - __builtin_popcountll((unsigned long long)h);
-        uint64_t r = 0;
-        if (kl >= 0 && kl <= B) {
-            int j = kl + 1;
-            for (uint64_t s = h; s; s &= s - 1, ++j) r += binom(B + __builtin_ctzll(s), j);
-        }
-        if (wide) ((uint64_t *)thi)[h] = r; else ((uint32_t *)thi)[h] = (uint32_t)r;
-    }
+    lin_tables_host(hw, B, hb, wide, tlo, thi);
     int rc = upload(&pl->lin_alloc[0], lg, sizeof(lsk_lin_group) * (n > 0 ? n : 1)) ||
              upload(&pl->lin_alloc[1], tlo, sizeof(uint16_t) << B) || upload(&pl->lin_alloc[2], thi, nh * es);
     free(lg); free(tlo); free(thi);

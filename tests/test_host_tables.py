@@ -277,3 +277,85 @@ def test_hot_kernel_register_budget():
     assert len(hot) >= 8, sorted(stats)[:5]
     for name, (sgpr, vgpr, occ) in hot.items():
         assert sgpr <= 80 and occ == 8, (name, sgpr, vgpr, occ)
+
+
+def _fixed_weight_states(L, hw):
+    """all states of L bits with hw set, ascending (Gosper)"""
+    import math
+
+    n = math.comb(L, hw)
+    out = np.empty(n, dtype=np.uint64)
+    s = (1 << hw) - 1
+    for i in range(n):
+        out[i] = s
+        c = s & -s
+        r = s + c
+        s = (((r ^ s) >> 2) // c) | r if c else 0
+    return out
+
+
+@pytest.mark.parametrize("L,hw", [(12, 6), (16, 8), (18, 7), (20, 10)])
+@pytest.mark.parametrize("tile,transposed,top,set_rows", [(256, 0, 0, 0), (1024, 0, 0, 0), (256, 1, 3, 2048), (256, 1, 8, 65536), (256, 1, 6, 256)])
+def test_tile_map_is_a_partition_of_the_rows(L, hw, tile, transposed, top, set_rows):
+    """lsk_tilemap: every row in exactly one tile, tiles <= tile_rows, and in the transposed order every tile lies
+    inside one segment (states sharing their top `t` bits) at an offset that is a multiple of the tile size."""
+    import math
+
+    lib = _lib.load()
+    n = math.comb(L, hw)
+    ptr = C.POINTER(C.c_uint64)()
+    slots = lib.ls_amd_test_tilemap(L, hw, n, transposed, tile, top, set_rows, C.byref(ptr))
+    assert slots >= 0
+    e = np.ctypeslib.as_array(ptr, shape=(8 * max(slots, 1),)).copy()
+    lib.ls_amd_test_free(ptr)
+    rows = e & np.uint64((1 << 48) - 1)
+    cnt = (e >> np.uint64(48)).astype(np.int64)
+    live = cnt > 0
+    assert cnt.max() <= tile and cnt[live].min() >= 1
+    cover = np.zeros(n + 1, dtype=np.int64)
+    np.add.at(cover, rows[live].astype(np.int64), 1)
+    np.add.at(cover, rows[live].astype(np.int64) + cnt[live], -1)
+    assert np.array_equal(np.cumsum(cover)[:n], np.ones(n, dtype=np.int64))
+    # the default dealing gives every XCD the same number of tiles (+-1); the transposed order deals whole sets
+    # (a window of every segment of a popcount class), so its balance is only as fine as a set
+    per_xcd = cnt.reshape(8, -1).sum(axis=1)
+    if not transposed:
+        assert per_xcd.max() - per_xcd.min() <= 2 * tile
+    if transposed and top >= 2 and top <= L - 2:
+        states = _fixed_weight_states(L, hw)
+        seg = states >> np.uint64(L - top)
+        first = rows[live].astype(np.int64)
+        last = first + cnt[live] - 1
+        assert np.array_equal(seg[first], seg[last])  # a tile never straddles two segments
+        seg_start = np.searchsorted(seg, seg[first], side="left")
+        assert np.all((first - seg_start) % tile == 0)
+
+
+@pytest.mark.parametrize("L,hw,bits", [(10, 5, 4), (16, 8, 7), (20, 10, 12), (24, 12, 14), (18, 3, 15), (14, 7, 14), (12, 6, 15)])
+def test_two_table_rank(L, hw, bits):
+    """lsk_lin: rank(state) == thi[state >> bits] + tlo[state & mask] for every state of the fixed-weight basis."""
+    lib = _lib.load()
+    states = _fixed_weight_states(L, hw)
+    if len(states) > 400000:
+        states = states[np.random.RandomState(3).choice(len(states), 400000, replace=False)]
+        want = None
+    else:
+        want = np.arange(len(states), dtype=np.int64)
+    ranks = np.empty(len(states), dtype=np.int64)
+    assert lib.ls_amd_test_lin_rank(L, hw, bits, len(states), states.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                    ranks.ctypes.data_as(C.POINTER(C.c_int64))) == 0
+    if want is None:
+        import math
+
+        def rank(s):  # combinadic rank: sum over set bits p_0 < p_1 < ... of C(p_j, j + 1)
+            r, j = 0, 1
+            while s:
+                p = (s & -s).bit_length() - 1
+                r += math.comb(p, j)
+                j += 1
+                s &= s - 1
+            return r
+
+        want = np.array([rank(int(s)) for s in states[:2000]], dtype=np.int64)
+        ranks = ranks[:2000]
+    assert np.array_equal(ranks, want)
