@@ -277,6 +277,13 @@ def test_hot_kernel_register_budget():
     assert len(hot) >= 8, sorted(stats)[:5]
     for name, (sgpr, vgpr, occ) in hot.items():
         assert sgpr <= 80 and occ == 8, (name, sgpr, vgpr, occ)
+    # the staged kernel is capped at 7 blocks per CU by its 20.3 KB LDS window; 7 waves per SIMD need <= 96 SGPRs
+    # (measured: 97 SGPRs dropped it to 6 resident blocks while the grid was sized for 7: 11.6 -> 16.2 ms) and
+    # <= 72 VGPRs
+    chain = [v for k, v in stats.items() if k.startswith("_Z7k_chain8lsk_runs")]
+    assert len(chain) == 1, sorted(stats)[:5]
+    sgpr, vgpr, occ = chain[0]
+    assert sgpr <= 96 and vgpr <= 72 and occ == 7, chain[0]
 
 
 def _fixed_weight_states(L, hw):
