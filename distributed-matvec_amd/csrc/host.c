@@ -1321,7 +1321,7 @@ static int setup_chain(ls_amd_plan *pl, lsk_index index, int64_t n, uint64_t con
     int const nc = ext->n_groups - ext->runs.n_run_groups;
     if (nc > 0 && n > 0) {
         void *q;
-        DEV(lsk_malloc(&q, sizeof(uint32_t) * (size_t)nc * (size_t)n));
+        if (lsk_malloc(&q, sizeof(uint32_t) * (size_t)nc * (size_t)n) != 0) return 0; /* no room for the cache: k_direct */
         pl->d_chain_cache = (uint32_t *)q;
         int zero = 0, flag = 0;
         DEV(lsk_h2d(pl->d_err, &zero, sizeof(int)));

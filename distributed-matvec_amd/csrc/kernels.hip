@@ -47,7 +47,13 @@ extern "C" int lsk_set_device(int device) { LSK_CHECK(hipSetDevice(device)); ret
 extern "C" int lsk_malloc(void **p, size_t bytes) {
     *p = nullptr;
     if (bytes == 0) bytes = 8;
-    LSK_CHECK(hipMalloc(p, bytes));
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess) {
+        (void)hipGetLastError(); // an allocation failure is recoverable: do not leave it for the next launch check
+        snprintf(g_err, sizeof(g_err), "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+        *p = nullptr;
+        return -1;
+    }
     return 0;
 }
 extern "C" int lsk_free(void *p) { if (p) LSK_CHECK(hipFree(p)); return 0; }

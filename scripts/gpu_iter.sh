@@ -1,6 +1,6 @@
-# GPU job: parity suite + three repeated default bench runs (run-to-run spread)
+# GPU job: smoke + parity suite + default bench line
 export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
+timeout 200 python __graft_entry__.py smoke 2>&1 | tail -2
 timeout 900 python -m pytest tests -m gpu -q --maxfail=5 2>&1 | tail -3
-B="timeout 120 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra"
-for i in 1 2 3; do echo "+ default run $i"; $B; done
+timeout 300 python bench.py --no-extra > gpurun_out/bench_default_last.json 2>/dev/null; cut -c1-330 gpurun_out/bench_default_last.json
