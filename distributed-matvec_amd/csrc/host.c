@@ -1109,7 +1109,10 @@ static int setup_highpart(ls_amd_plan *pl, int t) {
  * set goes to one XCD, whose resident blocks work through it concurrently (consecutive slots = the same
  * offsets in different segments), so the partners' lines are in that XCD's L2 while they are needed
  * instead of being fetched again from HBM.  LS_AMD_TOP_BITS (t; 0 = default map) and LS_AMD_SET_ROWS
- * (rows per set) tune it. */
+ * (rows per set) tune it.  (Measured on k_direct and modelled for k_chain, scripts/tools/l2sim.c: the in-flight
+ * footprint of one XCD exceeds its 4 MiB L2, so what the top pairs gain the middle pairs lose.)
+ *
+ * Chunked (LS_AMD_TILE_CHUNK = G tiles): chunks of G consecutive tiles dealt round-robin to the XCDs. */
 typedef struct { uint64_t *e; int64_t n, cap; } tile_list;
 static void tile_push(tile_list *l, int64_t row, int64_t cnt) {
     if (l->n == l->cap) { l->cap = l->cap ? 2 * l->cap : 1024; l->e = (uint64_t *)realloc(l->e, sizeof(uint64_t) * (size_t)l->cap); }
@@ -1117,8 +1120,8 @@ static void tile_push(tile_list *l, int64_t row, int64_t cnt) {
 }
 /* host part: 8 lists of `*slots` entries in a malloc'ed array; `transposed` asks for the set order (needs the full
  * fixed-weight basis: n == C(L, hw)), t / set_rows as described above */
-static int tilemap_host(int L, int hw, int64_t n, int transposed, int TILE, int t, int64_t set_rows, uint64_t **out,
-                        int64_t *slots_out) {
+static int tilemap_host(int L, int hw, int64_t n, int transposed, int TILE, int t, int64_t set_rows, int64_t chunk,
+                        uint64_t **out, int64_t *slots_out) {
     tile_list lists[8];
     memset(lists, 0, sizeof(lists));
     if (set_rows < TILE) set_rows = TILE;
@@ -1127,9 +1130,15 @@ static int tilemap_host(int L, int hw, int64_t n, int transposed, int TILE, int 
     if (transposed && !(t >= 2 && hw >= 0 && (uint64_t)n == binom(L, hw))) transposed = 0;
     if (!transposed) {
         int64_t const tiles = (n + TILE - 1) / TILE;
-        for (int k = 0; k < 8; ++k) /* XCD k: the k-th contiguous eighth of the tiles */
-            for (int64_t q = tiles * k / 8; q < tiles * (k + 1) / 8; ++q)
-                tile_push(&lists[k], q * TILE, n - q * TILE < TILE ? n - q * TILE : TILE);
+        if (chunk > 0) { /* chunks of `chunk` consecutive tiles dealt round-robin: all XCDs advance through the same
+                          * region of the vector together (what the shared Infinity Cache likes), each keeps runs of
+                          * consecutive tiles (what its own L2 likes) */
+            for (int64_t q = 0; q < tiles; ++q)
+                tile_push(&lists[(q / chunk) % 8], q * TILE, n - q * TILE < TILE ? n - q * TILE : TILE);
+        } else
+            for (int k = 0; k < 8; ++k) /* XCD k: the k-th contiguous eighth of the tiles */
+                for (int64_t q = tiles * k / 8; q < tiles * (k + 1) / 8; ++q)
+                    tile_push(&lists[k], q * TILE, n - q * TILE < TILE ? n - q * TILE : TILE);
     } else {
         int const Lr = L - t, nT = 1 << t;
         int64_t *base = (int64_t *)malloc(sizeof(int64_t) * (size_t)(nT + 1));
@@ -1184,8 +1193,10 @@ static int build_tilemap(ls_amd_plan *pl, int64_t n, int allow_transposed, int T
     int64_t const set_rows = e ? atoll(e) : 65536;
     uint64_t *flat = NULL;
     int64_t slots = 0;
+    e = getenv("LS_AMD_TILE_CHUNK"); /* tiles per round-robin chunk; 0 (default) = contiguous eighths */
+    int64_t const chunk = e ? atoll(e) : 0;
     int const rc = tilemap_host(b->number_sites, b->ext->hamming_weight, n, allow_transposed && b->spin_inversion == 0, TILE, t,
-                                set_rows, &flat, &slots);
+                                set_rows, chunk > 0 ? chunk : 0, &flat, &slots);
     if (rc < 0) return -1;
     int const up = upload(&pl->d_tilemap, flat, sizeof(uint64_t) * (size_t)(8 * slots > 0 ? 8 * slots : 1));
     free(flat);
@@ -1199,10 +1210,11 @@ static int build_tilemap(ls_amd_plan *pl, int64_t n, int allow_transposed, int T
  * rows when transposed == 0).  Returns slots per XCD (< 0 on error); *entries is malloc'ed, free with
  * ls_amd_test_free. */
 int64_t ls_amd_test_tilemap(int number_sites, int hamming_weight, int64_t n, int transposed, int tile_rows, int top_bits,
-                            int64_t set_rows, uint64_t **entries) {
+                            int64_t set_rows, int64_t chunk, uint64_t **entries) {
     int64_t slots = 0;
     *entries = NULL;
-    if (tilemap_host(number_sites, hamming_weight, n, transposed, tile_rows, top_bits, set_rows, entries, &slots) < 0) return -1;
+    if (tilemap_host(number_sites, hamming_weight, n, transposed, tile_rows, top_bits, set_rows, chunk, entries, &slots) < 0)
+        return -1;
     return slots;
 }
 void ls_amd_test_free(void *p) { free(p); }

@@ -164,7 +164,7 @@ int ls_amd_basis_group_character(ls_hs_basis const *basis, int element, double *
  *                        (malloc'ed: release with ls_amd_test_free); < 0 on error
  *   ls_amd_test_lin_rank ranks[i] = thi[state >> bits] + tlo[state & mask] */
 int64_t ls_amd_test_tilemap(int number_sites, int hamming_weight, int64_t n, int transposed, int tile_rows,
-                            int top_bits, int64_t set_rows, uint64_t **entries);
+                            int top_bits, int64_t set_rows, int64_t chunk, uint64_t **entries);
 void ls_amd_test_free(void *p);
 int ls_amd_test_lin_rank(int number_sites, int hamming_weight, int bits, int64_t n, uint64_t const *states,
                          int64_t *ranks);

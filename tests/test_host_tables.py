@@ -302,8 +302,9 @@ def _fixed_weight_states(L, hw):
 
 
 @pytest.mark.parametrize("L,hw", [(12, 6), (16, 8), (18, 7), (20, 10)])
-@pytest.mark.parametrize("tile,transposed,top,set_rows", [(256, 0, 0, 0), (1024, 0, 0, 0), (256, 1, 3, 2048), (256, 1, 8, 65536), (256, 1, 6, 256)])
-def test_tile_map_is_a_partition_of_the_rows(L, hw, tile, transposed, top, set_rows):
+@pytest.mark.parametrize("tile,transposed,top,set_rows,chunk", [(256, 0, 0, 0, 0), (1024, 0, 0, 0, 0), (256, 1, 3, 2048, 0), (256, 1, 8, 65536, 0),
+                                                              (256, 1, 6, 256, 0), (1024, 0, 0, 0, 3), (256, 0, 0, 0, 16)])
+def test_tile_map_is_a_partition_of_the_rows(L, hw, tile, transposed, top, set_rows, chunk):
     """lsk_tilemap: every row in exactly one tile, tiles <= tile_rows, and in the transposed order every tile lies
     inside one segment (states sharing their top `t` bits) at an offset that is a multiple of the tile size."""
     import math
@@ -311,7 +312,7 @@ def test_tile_map_is_a_partition_of_the_rows(L, hw, tile, transposed, top, set_r
     lib = _lib.load()
     n = math.comb(L, hw)
     ptr = C.POINTER(C.c_uint64)()
-    slots = lib.ls_amd_test_tilemap(L, hw, n, transposed, tile, top, set_rows, C.byref(ptr))
+    slots = lib.ls_amd_test_tilemap(L, hw, n, transposed, tile, top, set_rows, chunk, C.byref(ptr))
     assert slots >= 0
     e = np.ctypeslib.as_array(ptr, shape=(8 * max(slots, 1),)).copy()
     lib.ls_amd_test_free(ptr)
@@ -327,7 +328,12 @@ def test_tile_map_is_a_partition_of_the_rows(L, hw, tile, transposed, top, set_r
     # (a window of every segment of a popcount class), so its balance is only as fine as a set
     per_xcd = cnt.reshape(8, -1).sum(axis=1)
     if not transposed:
-        assert per_xcd.max() - per_xcd.min() <= 2 * tile
+        assert per_xcd.max() - per_xcd.min() <= 2 * tile * max(chunk, 1)
+    if chunk:  # chunks of `chunk` consecutive tiles go round-robin: tile q sits in list (q // chunk) % 8
+        lists = rows.reshape(8, -1)
+        for k in range(8):
+            q = (lists[k][cnt.reshape(8, -1)[k] > 0] // np.uint64(tile)).astype(np.int64)
+            assert np.all((q // chunk) % 8 == k) and np.all(np.diff(q) > 0)
     if transposed and top >= 2 and top <= L - 2:
         states = _fixed_weight_states(L, hw)
         seg = states >> np.uint64(L - top)
