@@ -1112,7 +1112,10 @@ static int setup_highpart(ls_amd_plan *pl, int t) {
  * (rows per set) tune it.  (Measured on k_direct and modelled for k_chain, scripts/tools/l2sim.c: the in-flight
  * footprint of one XCD exceeds its 4 MiB L2, so what the top pairs gain the middle pairs lose.)
  *
- * Chunked (LS_AMD_TILE_CHUNK = G tiles): chunks of G consecutive tiles dealt round-robin to the XCDs. */
+ * Chunked (LS_AMD_TILE_CHUNK = G tiles): chunks of G consecutive tiles dealt round-robin to the XCDs.  Together
+ * with the transposed order the sets become chip-wide (sized by LS_AMD_SET_ROWS for the 256 MiB Infinity Cache):
+ * modelled -27 % HBM reads for k_chain on chain_32 at t = 6, 2.6 M rows per set, G = 32
+ * (scripts/tools/mallsim.c); not measured yet. */
 typedef struct { uint64_t *e; int64_t n, cap; } tile_list;
 static void tile_push(tile_list *l, int64_t row, int64_t cnt) {
     if (l->n == l->cap) { l->cap = l->cap ? 2 * l->cap : 1024; l->e = (uint64_t *)realloc(l->e, sizeof(uint64_t) * (size_t)l->cap); }
@@ -1148,7 +1151,7 @@ static int tilemap_host(int L, int hw, int64_t n, int transposed, int TILE, int 
             acc += (int64_t)binom(Lr, hw - __builtin_popcount((unsigned)T));
         }
         base[nT] = acc;
-        int64_t rows_of[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        int64_t rows_of[8] = {0, 0, 0, 0, 0, 0, 0, 0}, global_q = 0;
         int *segs = (int *)malloc(sizeof(int) * (size_t)nT);
         for (int j = 0; j <= t; ++j) {
             int64_t const len = (int64_t)binom(Lr, hw - j);
@@ -1158,6 +1161,17 @@ static int tilemap_host(int L, int hw, int64_t n, int transposed, int TILE, int 
             int64_t W = TILE;
             while (W * 2 * nseg <= set_rows) W *= 2;
             for (int64_t w0 = 0; w0 < len; w0 += W) {
+                if (chunk > 0) {
+                    /* chip-wide sets: the whole chip works on one set at a time (its footprint is sized for the
+                     * shared Infinity Cache, not for one L2); inside the set the tiles run segment by segment and
+                     * are dealt to the XCDs in round-robin chunks of consecutive tiles */
+                    for (int sgi = 0; sgi < nseg; ++sgi)
+                        for (int64_t off = w0; off < w0 + W && off < len; off += TILE) {
+                            tile_push(&lists[(global_q / chunk) % 8], base[segs[sgi]] + off, len - off < TILE ? len - off : TILE);
+                            ++global_q;
+                        }
+                    continue;
+                }
                 int k = 0; /* the least loaded XCD takes the set */
                 for (int q = 1; q < 8; ++q) if (rows_of[q] < rows_of[k]) k = q;
                 for (int64_t off = w0; off < w0 + W && off < len; off += TILE)

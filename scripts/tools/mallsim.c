@@ -5,7 +5,10 @@
  *   chunk = 0: XCD k gets the k-th contiguous eighth of the tiles (the default tile map);
  *   chunk = G: tiles are dealt round-robin in chunks of G consecutive tiles, so all XCDs advance through the
  *              same region of the vector together.
- * Same access model as l2sim.c.  usage: mallsim L chunk tiles_per_xcd [blocks=224]
+ *   top_bits = t > 0: the tiles are first put into the global set order (all segments of a popcount class of
+ *              the top t bits x a window of set_rows / #segments rows, see build_tilemap in host.c), then dealt
+ *              in chunks as above: the whole chip works on one set at a time.
+ * Same access model as l2sim.c.  usage: mallsim L chunk tiles_per_xcd [blocks=224] [top_bits=0] [set_rows=0]
  * Exploration tool (not part of the product); cc -O2 -o mallsim mallsim.c */
 #include <stdint.h>
 #include <stdio.h>
@@ -70,7 +73,36 @@ int main(int argc, char **argv) {
     cache_init(&mall, 256 << 20);
     uint64_t const X = 0, REPS = (uint64_t)1 << 40, CACHE = (uint64_t)2 << 40, Y = (uint64_t)3 << 40;
     /* slot s of XCD k -> tile index; the simulated window starts in the middle of every XCD's list */
-    int64_t const list_len = tiles / 8, s0 = list_len / 2;
+    int const t = argc > 5 ? atoi(argv[5]) : 0;
+    int64_t const set_rows = argc > 6 ? atoll(argv[6]) : 0;
+    uint64_t *order = NULL; /* order[q] = first row of the q-th tile in the global order; cnts[q] its rows */
+    int *cnts = NULL;
+    int64_t n_order = 0;
+    if (t > 0) {
+        int Lr = L - t, nT = 1 << t;
+        int64_t *base = malloc(8 * (nT + 1)), acc = 0, cap = 0;
+        for (int T = 0; T < nT; ++T) { base[T] = acc; int j = __builtin_popcount(T); acc += (hw - j >= 0 && hw - j <= Lr) ? (int64_t)C[Lr][hw - j] : 0; }
+        int *segs = malloc(4 * nT);
+        for (int j = 0; j <= t; ++j) {
+            if (hw - j < 0 || hw - j > Lr) continue;
+            int64_t len = (int64_t)C[Lr][hw - j];
+            if (!len) continue;
+            int nseg = 0;
+            for (int T = 0; T < nT; ++T) if (__builtin_popcount(T) == j) segs[nseg++] = T;
+            int64_t W = TILE;
+            while (W * 2 * nseg <= set_rows) W *= 2;
+            for (int64_t w0 = 0; w0 < len; w0 += W)
+                for (int sg = 0; sg < nseg; ++sg) /* segment-major inside a set: runs of consecutive tiles */
+                    for (int64_t off = w0; off < w0 + W && off < len; off += TILE) {
+                        if (n_order == cap) { cap = cap ? 2 * cap : 1 << 16; order = realloc(order, 8 * cap); cnts = realloc(cnts, 4 * cap); }
+                        order[n_order] = (uint64_t)(base[segs[sg]] + off);
+                        cnts[n_order] = (int)(len - off < TILE ? len - off : TILE);
+                        ++n_order;
+                    }
+        }
+    }
+    int64_t const total_tiles = t > 0 ? n_order : tiles;
+    int64_t const list_len = total_tiles / 8, s0 = list_len / 2;
     uint64_t rows_done = 0, warm_rows = 0, warm_l2 = 0, warm_mall = 0;
     uint64_t *st = malloc(8 * TILE);
     int64_t rounds = (per_xcd + BLOCKS - 1) / BLOCKS;
@@ -85,9 +117,9 @@ int main(int argc, char **argv) {
                     int64_t s = s0 + rd * BLOCKS + b;
                     if (s >= s0 + per_xcd || s >= list_len) continue;
                     int64_t q = chunk == 0 ? cur * list_len + s : ((s / chunk) * 8 + cur) * chunk + s % chunk;
-                    if (q >= tiles) continue;
-                    uint64_t row = (uint64_t)q * TILE;
-                    int cnt = n - row < (uint64_t)TILE ? (int)(n - row) : TILE;
+                    if (q >= total_tiles) continue;
+                    uint64_t row = t > 0 ? order[q] : (uint64_t)q * TILE;
+                    int cnt = t > 0 ? cnts[q] : (n - row < (uint64_t)TILE ? (int)(n - row) : TILE);
                     if (sub < 0) {
                         int64_t w0 = (int64_t)row - HALO;
                         if (w0 < 0) w0 = 0;
@@ -136,8 +168,8 @@ int main(int argc, char **argv) {
     uint64_t l2m = 0;
     for (int k = 0; k < 8; ++k) l2m += l2[k].misses;
     double rows = (double)(rows_done - warm_rows);
-    printf("L=%d chunk=%lld tiles/xcd=%lld: rows %llu; second half: L2 misses/row %.3f (%.1f B/row), Infinity-Cache misses/row %.3f (%.1f B/row)\n",
-           L, (long long)chunk, (long long)per_xcd, (unsigned long long)rows_done, (double)(l2m - warm_l2) / rows,
+    printf("L=%d chunk=%lld t=%d set_rows=%lld tiles/xcd=%lld: rows %llu; second half: L2 misses/row %.3f (%.1f B/row), Infinity-Cache misses/row %.3f (%.1f B/row)\n",
+           L, (long long)chunk, t, (long long)set_rows, (long long)per_xcd, (unsigned long long)rows_done, (double)(l2m - warm_l2) / rows,
            128.0 * (double)(l2m - warm_l2) / rows, (double)(mall.misses - warm_mall) / rows, 128.0 * (double)(mall.misses - warm_mall) / rows);
     return 0;
 }

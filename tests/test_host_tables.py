@@ -303,7 +303,8 @@ def _fixed_weight_states(L, hw):
 
 @pytest.mark.parametrize("L,hw", [(12, 6), (16, 8), (18, 7), (20, 10)])
 @pytest.mark.parametrize("tile,transposed,top,set_rows,chunk", [(256, 0, 0, 0, 0), (1024, 0, 0, 0, 0), (256, 1, 3, 2048, 0), (256, 1, 8, 65536, 0),
-                                                              (256, 1, 6, 256, 0), (1024, 0, 0, 0, 3), (256, 0, 0, 0, 16)])
+                                                              (256, 1, 6, 256, 0), (1024, 0, 0, 0, 3), (256, 0, 0, 0, 16),
+                                                              (1024, 1, 4, 16384, 2), (256, 1, 6, 65536, 8)])
 def test_tile_map_is_a_partition_of_the_rows(L, hw, tile, transposed, top, set_rows, chunk):
     """lsk_tilemap: every row in exactly one tile, tiles <= tile_rows, and in the transposed order every tile lies
     inside one segment (states sharing their top `t` bits) at an offset that is a multiple of the tile size."""
@@ -329,7 +330,7 @@ def test_tile_map_is_a_partition_of_the_rows(L, hw, tile, transposed, top, set_r
     per_xcd = cnt.reshape(8, -1).sum(axis=1)
     if not transposed:
         assert per_xcd.max() - per_xcd.min() <= 2 * tile * max(chunk, 1)
-    if chunk:  # chunks of `chunk` consecutive tiles go round-robin: tile q sits in list (q // chunk) % 8
+    if chunk and not transposed:  # chunks of `chunk` consecutive tiles go round-robin: tile q sits in list (q // chunk) % 8
         lists = rows.reshape(8, -1)
         for k in range(8):
             q = (lists[k][cnt.reshape(8, -1)[k] > 0] // np.uint64(tile)).astype(np.int64)
@@ -342,6 +343,8 @@ def test_tile_map_is_a_partition_of_the_rows(L, hw, tile, transposed, top, set_r
         assert np.array_equal(seg[first], seg[last])  # a tile never straddles two segments
         seg_start = np.searchsorted(seg, seg[first], side="left")
         assert np.all((first - seg_start) % tile == 0)
+        if chunk:  # chip-wide sets: the lists are within one chunk of each other
+            assert per_xcd.max() - per_xcd.min() <= 2 * tile * chunk
 
 
 @pytest.mark.parametrize("L,hw,bits", [(10, 5, 4), (16, 8, 7), (20, 10, 12), (24, 12, 14), (18, 3, 15), (14, 7, 14), (12, 6, 15)])
