@@ -1366,10 +1366,9 @@ static int setup_chain(ls_amd_plan *pl, lsk_index index, int64_t n, uint64_t con
         pl->chain_v[0] = ext->groups[ext->runs.n_run_groups].v_re;
         pl->chain_v[1] = nc > 1 ? ext->groups[ext->runs.n_run_groups + 1].v_re : 0.0;
     }
-    /* LS_AMD_TRANSPOSED=1: sets closed under the top flips per XCD (see build_tilemap) -- the far gathers are issued
-     * right after the window is staged, so a partner tile staged by a sibling block of the same XCD may still be in
-     * its L2.  Not measured yet for this kernel; off by default.  Replicated block rows (row offset) keep the
-     * default order. */
+    /* LS_AMD_TRANSPOSED=1 selects the set order of build_tilemap for this kernel too (per XCD, or chip-wide together
+     * with LS_AMD_TILE_CHUNK).  Modelled (scripts/tools/l2sim.c, mallsim.c), not yet measured; off by default.
+     * Replicated block rows (row offset) keep the default order. */
     char const *et = getenv("LS_AMD_TRANSPOSED");
     int const transposed = et && atoi(et) != 0 && pl->family == FAMILY_DIRECT_PULL;
     if (build_tilemap(pl, n, transposed, 1024) != 0) return -1;
