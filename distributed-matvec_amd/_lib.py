@@ -122,6 +122,23 @@ def load():
         "ls_amd_diag": (C.c_int, [vp, vp, vp, vp]),
         "ls_amd_generate": (C.c_int, [vp, C.c_int, vp, vp, vp, vp]),
         "ls_amd_scatter": (C.c_int, [vp, C.c_int64, vp, vp, vp, vp]),
+        "ls_amd_comm_available": (C.c_int, []),
+        "ls_amd_comm_unique_id": (C.c_int, [vp]),
+        "ls_amd_comm_create": (C.c_int, [C.POINTER(vp), C.c_int, C.c_int, vp]),
+        "ls_amd_comm_destroy": (None, [vp]),
+        "ls_amd_comm_size": (C.c_int, [vp]),
+        "ls_amd_comm_rank": (C.c_int, [vp]),
+        "ls_amd_comm_allreduce_sum_f64": (C.c_int, [vp, vp, C.c_int64, vp]),
+        "ls_amd_comm_allreduce_max_i64": (C.c_int, [vp, vp, C.c_int64, vp]),
+        "ls_amd_comm_broadcast": (C.c_int, [vp, vp, C.c_int64, C.c_int, vp]),
+        "ls_amd_set_default_comm": (None, [vp]),
+        "ls_amd_default_comm": (vp, []),
+        "ls_amd_dist_create": (C.c_int, [C.POINTER(vp), vp, op, C.c_int, vp, C.c_int64, C.c_int, vp]),
+        "ls_amd_dist_destroy": (None, [vp]),
+        "ls_amd_dist_matvec": (C.c_int, [vp, vp, vp, vp]),
+        "ls_amd_dist_plan": (vp, [vp]),
+        "ls_amd_dist_exchange_bytes": (C.c_int64, [vp]),
+        "ls_amd_dist_num_rounds": (C.c_int, [vp]),
         "ls_amd_enumerate_states": (C.c_int, [bp, C.c_int, C.POINTER(vp), C.POINTER(vp), c_i64p, vp]),
         "ls_amd_mask_counts": (C.c_int, [C.c_int64, vp, C.c_int, c_i64p, vp]),
         "ls_amd_block_to_hashed": (C.c_int, [C.c_int64, vp, C.c_int, C.c_int, vp, C.POINTER(vp), vp]),

@@ -25,6 +25,7 @@ __all__ = [
     "Basis", "Operator", "LsAmdError", "loadConfigFromYaml", "loadConfigFromDict", "enumerateStates",
     "arrFromBlockToHashed", "arrFromHashedToBlock", "matrixVectorProduct", "localMatrixVector",
     "localeIdxOf", "hash64_01", "MatvecPlan", "ReplicatedPlan", "build_library", "fillRandom",
+    "Communicator", "DistMatvec",
 ]
 
 
@@ -405,6 +406,119 @@ class MatvecPlan:
     def scatter(self, n, betas_ptr: int, vals_ptr: int, y):
         _lib.check(_lib.load().ls_amd_scatter(self.h, n, C.c_void_p(betas_ptr), C.c_void_p(vals_ptr),
                                               C.c_void_p(y.data_ptr()), _stream_ptr()))
+
+
+class _BorrowedPlan(MatvecPlan):
+    """view of a plan owned by another object (ls_amd_dist): same accessors, no destroy."""
+
+    def __init__(self, handle, owner, P, me):  # noqa: super().__init__ deliberately not called
+        self.h, self.owner, self.P, self.me = handle, owner, P, me
+
+    def destroy(self):
+        self.h = None
+
+
+class Communicator:
+    """ls_amd_comm: RCCL communicator owned by the C host (include/ls_amd.h).  rank == locale index."""
+
+    def __init__(self, size: int, rank: int, unique_id: bytes):
+        _lib.require_device()
+        h = C.c_void_p()
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        _lib.check(_lib.load().ls_amd_comm_create(C.byref(h), size, rank, buf))
+        self.h, self.size, self.rank = h, size, rank
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = C.create_string_buffer(128)
+        _lib.check(_lib.load().ls_amd_comm_unique_id(buf))
+        return buf.raw
+
+    @staticmethod
+    def from_torch(group=None) -> "Communicator":
+        """bootstrap through an existing torch.distributed group (any backend): rank 0 creates the id,
+        the group's object broadcast carries it -- the role MPI_Bcast plays for a C caller."""
+        import torch.distributed as dist
+
+        rank, size = dist.get_rank(group), dist.get_world_size(group)
+        box = [Communicator.unique_id() if rank == 0 else None]
+        if size > 1:
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        return Communicator(size, rank, box[0])
+
+    def set_default(self):
+        """the communicator of primmeGlobalSumReal / primmeBroadcastReal / ls_chpl_primme_matvec"""
+        _lib.load().ls_amd_set_default_comm(self.h)
+
+    def allreduce_sum(self, t):
+        torch = _torch()
+        assert t.dtype == torch.float64 and t.is_cuda and t.is_contiguous()
+        _lib.check(_lib.load().ls_amd_comm_allreduce_sum_f64(self.h, C.c_void_p(t.data_ptr()), t.numel(), _stream_ptr()))
+        return t
+
+    def allreduce_max(self, t):
+        torch = _torch()
+        assert t.dtype == torch.int64 and t.is_cuda and t.is_contiguous()
+        _lib.check(_lib.load().ls_amd_comm_allreduce_max_i64(self.h, C.c_void_p(t.data_ptr()), t.numel(), _stream_ptr()))
+        return t
+
+    def broadcast(self, t, root: int = 0):
+        assert t.is_cuda and t.is_contiguous()
+        _lib.check(_lib.load().ls_amd_comm_broadcast(self.h, C.c_void_p(t.data_ptr()), t.numel() * t.element_size(), root,
+                                                     _stream_ptr()))
+        return t
+
+    def destroy(self):
+        if getattr(self, "h", None):
+            L = _lib.load()
+            if L.ls_amd_default_comm() == self.h.value:
+                L.ls_amd_set_default_comm(None)
+            L.ls_amd_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+class DistMatvec:
+    """ls_amd_dist: matrixVectorProduct for this rank's block, exchange inside the C host (RCCL)."""
+
+    def __init__(self, comm: Communicator, matrix: Operator, representatives, dtype, num_rounds: int = 0):
+        torch = _torch()
+        _lib.require_device()
+        self.comm, self.matrix, self.reps = comm, matrix, representatives  # borrowed by the C object: keep alive
+        self.cplx = dtype in (torch.complex128, "c128")
+        h = C.c_void_p()
+        _lib.check(_lib.load().ls_amd_dist_create(C.byref(h), comm.h, matrix.payload, 1 if self.cplx else 0,
+                                                  C.c_void_p(representatives.data_ptr()), representatives.numel(),
+                                                  num_rounds, _stream_ptr()))
+        self.h = h
+        self.plan = _BorrowedPlan(C.c_void_p(_lib.load().ls_amd_dist_plan(h)), self, comm.size, comm.rank)
+
+    @property
+    def num_rounds(self): return int(_lib.load().ls_amd_dist_num_rounds(self.h))
+    @property
+    def exchange_bytes(self): return int(_lib.load().ls_amd_dist_exchange_bytes(self.h))
+
+    def matvec(self, x, y, check: bool = True):
+        _lib.check(_lib.load().ls_amd_dist_matvec(self.h, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), _stream_ptr()))
+        if check:
+            self.plan.check()
+
+    def destroy(self):
+        if getattr(self, "h", None):
+            self.plan.destroy()
+            _lib.load().ls_amd_dist_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
 
 
 def fillRandom(states, seed: int, dtype):

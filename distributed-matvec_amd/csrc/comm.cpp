@@ -1,0 +1,185 @@
+// comm.cpp -- RCCL side of the thin extern-"C" shim (lsk_comm_*): the inter-GPU exchange of the packet path and the
+// PRIMME reductions, called by the C host (host.c).  One process per GPU; collectives go over xGMI.
+//
+// Replaces /root/reference/src/DistributedMatrixVector.chpl:313-449,638-661 (_RemoteBuffer.put: one-sided PUT + remote
+// flag store per mailbox) by ONE grouped ncclSend/ncclRecv per round with the exact byte counts of the plan, and
+// /root/reference/src/PRIMME.chpl:267-373 (atomic-buffer sum and copy-from-locale-0 broadcast behind three barriers)
+// by ncclAllReduce / ncclBroadcast.
+//
+// librccl is resolved at run time (dlopen): single-GPU users of libls_amd.so do not need it, and inside a PyTorch
+// process the already-loaded librccl.so.1 is reused, so the library and torch.distributed share one RCCL.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <dlfcn.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+
+#include "lsk.h"
+
+static thread_local char g_cerr[512] = "";
+extern "C" char const *lsk_comm_last_error(void) { return g_cerr; }
+
+namespace {
+struct Api {
+    void *handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+Api g_api;
+
+template <typename F> bool sym(F &slot, char const *name) {
+    slot = reinterpret_cast<F>(dlsym(g_api.handle, name));
+    if (!slot) snprintf(g_cerr, sizeof(g_cerr), "librccl: symbol %s not found", name);
+    return slot != nullptr;
+}
+
+int load_api() {
+    if (g_api.handle) return 0;
+    char const *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (char const *n : names) {
+        g_api.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (g_api.handle) break;
+    }
+    if (!g_api.handle) {
+        snprintf(g_cerr, sizeof(g_cerr), "cannot load librccl (%s)", dlerror());
+        return -1;
+    }
+    bool ok = sym(g_api.GetUniqueId, "ncclGetUniqueId") && sym(g_api.CommInitRank, "ncclCommInitRank") &&
+              sym(g_api.CommDestroy, "ncclCommDestroy") && sym(g_api.GroupStart, "ncclGroupStart") &&
+              sym(g_api.GroupEnd, "ncclGroupEnd") && sym(g_api.Send, "ncclSend") && sym(g_api.Recv, "ncclRecv") &&
+              sym(g_api.AllReduce, "ncclAllReduce") && sym(g_api.Broadcast, "ncclBroadcast") &&
+              sym(g_api.AllGather, "ncclAllGather") && sym(g_api.GetErrorString, "ncclGetErrorString");
+    if (!ok) { g_api.handle = nullptr; return -1; }
+    return 0;
+}
+} // namespace
+
+#define NCCL_CHECK(expr)                                                                                   \
+    do {                                                                                                   \
+        ncclResult_t r_ = (expr);                                                                          \
+        if (r_ != ncclSuccess) {                                                                           \
+            snprintf(g_cerr, sizeof(g_cerr), "%s:%d: %s failed: %s", __FILE__, __LINE__, #expr,            \
+                     g_api.GetErrorString ? g_api.GetErrorString(r_) : "?");                               \
+            return -1;                                                                                     \
+        }                                                                                                  \
+    } while (0)
+#define HIP_CHECK(expr)                                                                                    \
+    do {                                                                                                   \
+        hipError_t e_ = (expr);                                                                            \
+        if (e_ != hipSuccess) {                                                                            \
+            snprintf(g_cerr, sizeof(g_cerr), "%s:%d: %s failed: %s", __FILE__, __LINE__, #expr,            \
+                     hipGetErrorString(e_));                                                               \
+            return -1;                                                                                     \
+        }                                                                                                  \
+    } while (0)
+
+struct lsk_comm {
+    ncclComm_t comm;
+    int size, rank;
+    hipStream_t xstream;     // exchange stream: the collectives of round r overlap the kernels of round r +- 1
+    hipEvent_t ready[2], done[2];
+};
+
+extern "C" int lsk_comm_available(void) { return load_api() == 0; }
+
+extern "C" int lsk_comm_unique_id(void *id128) {
+    if (load_api() != 0) return -1;
+    static_assert(sizeof(ncclUniqueId) == 128, "ls_amd.h promises 128 bytes");
+    ncclUniqueId id;
+    NCCL_CHECK(g_api.GetUniqueId(&id));
+    memcpy(id128, &id, sizeof(id));
+    return 0;
+}
+
+extern "C" int lsk_comm_create(lsk_comm **out, int size, int rank, void const *id128) {
+    *out = nullptr;
+    if (load_api() != 0) return -1;
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof(id));
+    lsk_comm *c = new lsk_comm();
+    c->size = size;
+    c->rank = rank;
+    if (g_api.CommInitRank(&c->comm, size, id, rank) != ncclSuccess) {
+        snprintf(g_cerr, sizeof(g_cerr), "ncclCommInitRank(size %d, rank %d) failed", size, rank);
+        delete c;
+        return -1;
+    }
+    HIP_CHECK(hipStreamCreateWithFlags(&c->xstream, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) {
+        HIP_CHECK(hipEventCreateWithFlags(&c->ready[i], hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&c->done[i], hipEventDisableTiming));
+    }
+    *out = c;
+    return 0;
+}
+
+extern "C" void lsk_comm_destroy(lsk_comm *c) {
+    if (!c) return;
+    (void)hipStreamSynchronize(c->xstream);
+    if (g_api.CommDestroy) (void)g_api.CommDestroy(c->comm);
+    for (int i = 0; i < 2; ++i) { (void)hipEventDestroy(c->ready[i]); (void)hipEventDestroy(c->done[i]); }
+    (void)hipStreamDestroy(c->xstream);
+    delete c;
+}
+extern "C" int lsk_comm_size(lsk_comm const *c) { return c->size; }
+extern "C" int lsk_comm_rank(lsk_comm const *c) { return c->rank; }
+
+// in-place reductions / broadcast / gather on `stream` (device buffers)
+extern "C" int lsk_comm_allreduce(lsk_comm *c, void *d_buf, int64_t count, int dtype /* 0 f64, 1 f32, 2 i64 */,
+                                  int op /* 0 sum, 1 max */, void *stream) {
+    const ncclDataType_t t = dtype == 0 ? ncclDouble : dtype == 1 ? ncclFloat : ncclInt64;
+    NCCL_CHECK(g_api.AllReduce(d_buf, d_buf, (size_t)count, t, op == 0 ? ncclSum : ncclMax, c->comm, (hipStream_t)stream));
+    return 0;
+}
+extern "C" int lsk_comm_broadcast(lsk_comm *c, void *d_buf, int64_t bytes, int root, void *stream) {
+    NCCL_CHECK(g_api.Broadcast(d_buf, d_buf, (size_t)bytes, ncclChar, root, c->comm, (hipStream_t)stream));
+    return 0;
+}
+extern "C" int lsk_comm_allgather(lsk_comm *c, void const *d_send, void *d_recv, int64_t bytes_per_rank, void *stream) {
+    NCCL_CHECK(g_api.AllGather(d_send, d_recv, (size_t)bytes_per_rank, ncclChar, c->comm, (hipStream_t)stream));
+    return 0;
+}
+
+// all-to-all-v of bytes: segment d of the send buffer goes to rank d, segment s of the receive buffer comes from rank
+// s; one grouped send/recv, i.e. every pair of GPUs talks over its own xGMI link at the same time.  Issued on the
+// exchange stream between two events: `slot` (0/1) selects the event pair of the double-buffered pipeline.
+//   compute stream: ... generate(r) | record ready[slot]                      wait done[slot] | scatter(r) ...
+//   exchange stream:                  wait ready[slot] | grouped send/recv | record done[slot]
+extern "C" int lsk_comm_exchange_begin(lsk_comm *c, int slot, void *compute_stream) {
+    HIP_CHECK(hipEventRecord(c->ready[slot], (hipStream_t)compute_stream));
+    HIP_CHECK(hipStreamWaitEvent(c->xstream, c->ready[slot], 0));
+    return 0;
+}
+extern "C" int lsk_comm_alltoallv(lsk_comm *c, void const *d_send, int64_t const *send_off, int64_t const *send_bytes,
+                                  void *d_recv, int64_t const *recv_off, int64_t const *recv_bytes) {
+    NCCL_CHECK(g_api.GroupStart());
+    for (int step = 1; step < c->size; ++step) {
+        const int dst = (c->rank + step) % c->size, src = (c->rank - step + c->size) % c->size;
+        if (send_bytes[dst] > 0)
+            NCCL_CHECK(g_api.Send((char const *)d_send + send_off[dst], (size_t)send_bytes[dst], ncclChar, dst, c->comm, c->xstream));
+        if (recv_bytes[src] > 0)
+            NCCL_CHECK(g_api.Recv((char *)d_recv + recv_off[src], (size_t)recv_bytes[src], ncclChar, src, c->comm, c->xstream));
+    }
+    NCCL_CHECK(g_api.GroupEnd());
+    return 0;
+}
+extern "C" int lsk_comm_exchange_end(lsk_comm *c, int slot) {
+    HIP_CHECK(hipEventRecord(c->done[slot], c->xstream));
+    return 0;
+}
+extern "C" int lsk_comm_exchange_wait(lsk_comm *c, int slot, void *compute_stream) {
+    HIP_CHECK(hipStreamWaitEvent((hipStream_t)compute_stream, c->done[slot], 0));
+    return 0;
+}

@@ -1,0 +1,259 @@
+/* dist.c -- one locale per process / GPU: the inter-GPU side of matrixVectorProduct in the C host.
+ *
+ * Reference replaced:
+ *   /root/reference/src/DistributedMatrixVector.chpl:313-449   GlobalPtrStore, _LocalBuffer / _RemoteBuffer mailboxes
+ *   /root/reference/src/DistributedMatrixVector.chpl:638-661   trySubmit: one-sided PUT + remote isFull/isEmpty flags
+ *   /root/reference/src/DistributedMatrixVector.chpl:739-853   Consumer.run: polling, localProcess, acknowledgements
+ *   /root/reference/src/DistributedMatrixVector.chpl:856-1053  localOffDiagonalNoQueue: sizing, barriers
+ *   /root/reference/src/PRIMME.chpl:267-373                    globalSumReal / broadcastReal over all locales
+ * by bulk-synchronous rounds with exact byte counts (known from the plan's count pass, exchanged once at set-up):
+ *   generate(r) -> grouped ncclSend/ncclRecv (all-to-all-v of packets, RCCL over xGMI) -> scatter(r)
+ * software-pipelined, depth 2, over the compute stream and the communicator's exchange stream.
+ * Plain C; RCCL is reached through the lsk_comm_* shim (comm.cpp).
+ */
+#define _GNU_SOURCE
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/ls_amd.h"
+#include "../../include/ls_chpl.h"
+#include "lsk.h"
+
+int ls_amd_internal_error(char const *fmt, ...); /* host.c: formats into ls_amd_last_error(), returns -1 */
+
+#define COMM(expr) do { if ((expr) != 0) return ls_amd_internal_error("%s", lsk_comm_last_error()); } while (0)
+#define DEVC(expr) do { if ((expr) != 0) return ls_amd_internal_error("%s", lsk_last_error()); } while (0)
+#define TRY(expr) do { if ((expr) != 0) return -1; } while (0)
+
+struct ls_amd_comm {
+    lsk_comm *c;
+    void *d_scratch; /* staging for the host-pointer reductions and the set-up collectives */
+    size_t scratch_bytes;
+};
+
+static ls_amd_comm *g_default_comm = NULL;
+
+int ls_amd_comm_available(void) { return lsk_comm_available(); }
+int ls_amd_comm_unique_id(void *id) { COMM(lsk_comm_unique_id(id)); return 0; }
+
+int ls_amd_comm_create(ls_amd_comm **out, int size, int rank, void const *id) {
+    *out = NULL;
+    if (size < 1 || rank < 0 || rank >= size) return ls_amd_internal_error("ls_amd_comm_create: bad size / rank");
+    if (size > LSK_MAX_PARTS) return ls_amd_internal_error("at most %d locales", LSK_MAX_PARTS); /* DMV:664 */
+    ls_amd_comm *cm = (ls_amd_comm *)calloc(1, sizeof(*cm));
+    if (lsk_comm_create(&cm->c, size, rank, id) != 0) { free(cm); return ls_amd_internal_error("%s", lsk_comm_last_error()); }
+    *out = cm;
+    return 0;
+}
+void ls_amd_comm_destroy(ls_amd_comm *cm) {
+    if (!cm) return;
+    if (g_default_comm == cm) g_default_comm = NULL;
+    if (cm->d_scratch) lsk_free(cm->d_scratch);
+    lsk_comm_destroy(cm->c);
+    free(cm);
+}
+int ls_amd_comm_size(ls_amd_comm const *cm) { return lsk_comm_size(cm->c); }
+int ls_amd_comm_rank(ls_amd_comm const *cm) { return lsk_comm_rank(cm->c); }
+int ls_amd_comm_allreduce_sum_f64(ls_amd_comm *cm, double *d_buf, int64_t count, void *stream) {
+    COMM(lsk_comm_allreduce(cm->c, d_buf, count, 0, 0, stream));
+    return 0;
+}
+int ls_amd_comm_allreduce_max_i64(ls_amd_comm *cm, int64_t *d_buf, int64_t count, void *stream) {
+    COMM(lsk_comm_allreduce(cm->c, d_buf, count, 2, 1, stream));
+    return 0;
+}
+int ls_amd_comm_broadcast(ls_amd_comm *cm, void *d_buf, int64_t bytes, int root, void *stream) {
+    COMM(lsk_comm_broadcast(cm->c, d_buf, bytes, root, stream));
+    return 0;
+}
+void ls_amd_set_default_comm(ls_amd_comm *cm) { g_default_comm = cm; }
+ls_amd_comm *ls_amd_default_comm(void) { return g_default_comm; }
+
+static int scratch(ls_amd_comm *cm, size_t bytes, void **out) {
+    if (bytes > cm->scratch_bytes) {
+        if (cm->d_scratch) lsk_free(cm->d_scratch);
+        cm->d_scratch = NULL;
+        cm->scratch_bytes = 0;
+        size_t cap = bytes < 4096 ? 4096 : bytes;
+        DEVC(lsk_malloc(&cm->d_scratch, cap));
+        cm->scratch_bytes = cap;
+    }
+    *out = cm->d_scratch;
+    return 0;
+}
+
+/* ============================================================================================ */
+/* PRIMME reductions (host buffers, as PRIMME hands them over)                                  */
+/* ============================================================================================ */
+enum { PRIMME_OP_FLOAT = 2, PRIMME_OP_DOUBLE = 3 }; /* primme_headers/primme_eigs.h:100-107 */
+
+static ls_amd_comm *comm_of(void *primme) {
+    ls_primme_params_view *pp = (ls_primme_params_view *)primme;
+    if (pp && pp->commInfo) return (ls_amd_comm *)pp->commInfo;
+    return g_default_comm;
+}
+
+/* /root/reference/src/PRIMME.chpl:267-322: sum over all locales; sendBuf may alias recvBuf */
+void primmeGlobalSumReal(void *sendBuf, void *recvBuf, int *count, void *primme, int *ierr) {
+    ls_primme_params_view *pp = (ls_primme_params_view *)primme;
+    int const type = pp ? pp->globalSumReal_type : PRIMME_OP_DOUBLE;
+    int const is_float = type == PRIMME_OP_FLOAT;
+    size_t const es = is_float ? sizeof(float) : sizeof(double);
+    size_t const bytes = es * (size_t)(*count > 0 ? *count : 0);
+    ls_amd_comm *cm = comm_of(primme);
+    *ierr = 0;
+    if (!cm || ls_amd_comm_size(cm) == 1) { /* numLocales == 1 */
+        if (sendBuf != recvBuf) memmove(recvBuf, sendBuf, bytes);
+        return;
+    }
+    void *d;
+    if (scratch(cm, bytes, &d) != 0 || lsk_h2d(d, sendBuf, bytes) != 0 ||
+        lsk_comm_allreduce(cm->c, d, *count, is_float ? 1 : 0, 0, NULL) != 0 || lsk_sync(NULL) != 0 ||
+        lsk_d2h(recvBuf, d, bytes) != 0)
+        *ierr = -1;
+}
+/* /root/reference/src/PRIMME.chpl:324-373: locale 0's buffer to everyone (f64 only, as the reference) */
+void primmeBroadcastReal(void *buffer, int *count, void *primme, int *ierr) {
+    ls_amd_comm *cm = comm_of(primme);
+    *ierr = 0;
+    if (!cm || ls_amd_comm_size(cm) == 1) return;
+    size_t const bytes = sizeof(double) * (size_t)(*count > 0 ? *count : 0);
+    void *d;
+    if (scratch(cm, bytes, &d) != 0 || (ls_amd_comm_rank(cm) == 0 && lsk_h2d(d, buffer, bytes) != 0) ||
+        lsk_comm_broadcast(cm->c, d, (int64_t)bytes, 0, NULL) != 0 || lsk_sync(NULL) != 0 ||
+        (ls_amd_comm_rank(cm) != 0 && lsk_d2h(buffer, d, bytes) != 0))
+        *ierr = -1;
+}
+
+/* ============================================================================================ */
+/* distributed matrixVectorProduct                                                              */
+/* ============================================================================================ */
+struct ls_amd_dist {
+    ls_amd_comm *comm;
+    ls_amd_plan *plan;
+    int P, me, rounds, pb;
+    int64_t *send_counts; /* [rounds][P] packets to every destination */
+    int64_t *recv_counts; /* [rounds][P] packets from every source */
+    int64_t *send_off, *send_bytes, *recv_off, *recv_bytes; /* [rounds][P] byte layout of the two buffers */
+    void *d_send[2], *d_recv[2];
+    int64_t exchange_bytes;
+};
+
+static int64_t rows_per_round(void) {
+    char const *e = getenv("LS_AMD_ROWS_PER_ROUND");
+    if (e) { long long v = atoll(e); if (v > 0) return (int64_t)v; }
+    return (int64_t)1 << 24;
+}
+
+void ls_amd_dist_destroy(ls_amd_dist *d) {
+    if (!d) return;
+    lsk_sync(NULL);
+    for (int i = 0; i < 2; ++i) { if (d->d_send[i]) lsk_free(d->d_send[i]); if (d->d_recv[i]) lsk_free(d->d_recv[i]); }
+    if (d->plan) ls_amd_plan_destroy(d->plan);
+    free(d->send_counts); free(d->recv_counts);
+    free(d->send_off); free(d->send_bytes); free(d->recv_off); free(d->recv_bytes);
+    free(d);
+}
+
+int ls_amd_dist_create(ls_amd_dist **out, ls_amd_comm *cm, ls_hs_operator const *op, ls_amd_dtype dtype,
+                       uint64_t const *d_reps_local, int64_t count_local, int num_rounds, void *stream) {
+    *out = NULL;
+    if (!cm) return ls_amd_internal_error("ls_amd_dist_create: no communicator");
+    int const P = ls_amd_comm_size(cm), me = ls_amd_comm_rank(cm);
+    void *ds;
+    /* every rank must run the same number of rounds: the collectives are matched */
+    if (num_rounds <= 0) {
+        int64_t mx = count_local;
+        TRY(scratch(cm, sizeof(int64_t), &ds));
+        DEVC(lsk_h2d(ds, &mx, sizeof(mx)));
+        COMM(lsk_comm_allreduce(cm->c, ds, 1, 2, 1, stream));
+        DEVC(lsk_sync(stream));
+        DEVC(lsk_d2h(&mx, ds, sizeof(mx)));
+        int64_t const rpr = rows_per_round();
+        num_rounds = (int)((mx + rpr - 1) / rpr);
+        if (num_rounds < 1) num_rounds = 1;
+    }
+    ls_amd_dist *d = (ls_amd_dist *)calloc(1, sizeof(*d));
+    d->comm = cm; d->P = P; d->me = me; d->rounds = num_rounds;
+    uint64_t const *reps[1] = {d_reps_local};
+    int64_t counts[1] = {count_local};
+    if (ls_amd_plan_create(&d->plan, op, dtype, P, me, reps, counts, num_rounds, LS_AMD_MODE_AUTO, stream) != 0) { free(d); return -1; }
+    if (ls_amd_plan_num_rounds(d->plan) != num_rounds) { ls_amd_dist_destroy(d); return ls_amd_internal_error("internal error: rounds disagree"); }
+    d->pb = ls_amd_plan_packet_bytes(d->plan);
+    size_t const m = (size_t)num_rounds * (size_t)P;
+    d->send_counts = (int64_t *)calloc(m, sizeof(int64_t));
+    d->recv_counts = (int64_t *)calloc(m, sizeof(int64_t));
+    d->send_off = (int64_t *)calloc(m, sizeof(int64_t)); d->send_bytes = (int64_t *)calloc(m, sizeof(int64_t));
+    d->recv_off = (int64_t *)calloc(m, sizeof(int64_t)); d->recv_bytes = (int64_t *)calloc(m, sizeof(int64_t));
+    for (int r = 0; r < num_rounds; ++r)
+        if (ls_amd_plan_send_counts(d->plan, r, d->send_counts + (size_t)r * P) != 0) { ls_amd_dist_destroy(d); return -1; }
+    /* counts matrix, once: everybody learns everybody's [rounds][P] send counts (no per-round size exchange) */
+    int64_t *all = (int64_t *)calloc(m * (size_t)P, sizeof(int64_t));
+    int rc = scratch(cm, sizeof(int64_t) * m * (size_t)(P + 1), &ds);
+    if (rc == 0 && lsk_h2d(ds, d->send_counts, sizeof(int64_t) * m) != 0) rc = ls_amd_internal_error("%s", lsk_last_error());
+    if (rc == 0 && lsk_comm_allgather(cm->c, ds, (char *)ds + sizeof(int64_t) * m, (int64_t)(sizeof(int64_t) * m), stream) != 0)
+        rc = ls_amd_internal_error("%s", lsk_comm_last_error());
+    if (rc == 0 && (lsk_sync(stream) != 0 || lsk_d2h(all, (char *)ds + sizeof(int64_t) * m, sizeof(int64_t) * m * (size_t)P) != 0))
+        rc = ls_amd_internal_error("%s", lsk_last_error());
+    if (rc != 0) { free(all); ls_amd_dist_destroy(d); return -1; }
+    int64_t max_send = 0, max_recv = 0;
+    for (int r = 0; r < num_rounds; ++r) {
+        int64_t so = 0, ro = 0;
+        for (int q = 0; q < P; ++q) {
+            size_t const k = (size_t)r * P + q;
+            d->recv_counts[k] = all[(size_t)q * m + (size_t)r * P + me]; /* what rank q sends to me in round r */
+            d->send_off[k] = so; d->send_bytes[k] = d->send_counts[k] * d->pb; so += d->send_bytes[k];
+            d->recv_off[k] = ro; d->recv_bytes[k] = d->recv_counts[k] * d->pb; ro += d->recv_bytes[k];
+        }
+        if (so > max_send) max_send = so;
+        if (ro > max_recv) max_recv = ro;
+        d->exchange_bytes += so;
+    }
+    free(all);
+    for (int i = 0; i < 2; ++i) {
+        if (lsk_malloc(&d->d_send[i], (size_t)(max_send > 0 ? max_send : 8)) != 0 ||
+            lsk_malloc(&d->d_recv[i], (size_t)(max_recv > 0 ? max_recv : 8)) != 0) {
+            ls_amd_dist_destroy(d);
+            return ls_amd_internal_error("%s", lsk_last_error());
+        }
+    }
+    *out = d;
+    return 0;
+}
+
+ls_amd_plan *ls_amd_dist_plan(ls_amd_dist *d) { return d->plan; }
+int64_t ls_amd_dist_exchange_bytes(ls_amd_dist const *d) { return d->exchange_bytes; }
+int ls_amd_dist_num_rounds(ls_amd_dist const *d) { return d->rounds; }
+
+static int exchange(ls_amd_dist *d, int r, void *stream) {
+    size_t const k = (size_t)r * d->P;
+    int const slot = r & 1;
+    COMM(lsk_comm_exchange_begin(d->comm->c, slot, stream));
+    COMM(lsk_comm_alltoallv(d->comm->c, d->d_send[slot], d->send_off + k, d->send_bytes + k, d->d_recv[slot], d->recv_off + k,
+                            d->recv_bytes + k));
+    COMM(lsk_comm_exchange_end(d->comm->c, slot));
+    return 0;
+}
+
+int ls_amd_dist_matvec(ls_amd_dist *d, void const *d_x, void *d_y, void *stream) {
+    int const R = d->rounds, P = d->P;
+    TRY(ls_amd_diag(d->plan, d_x, d_y, stream)); /* localDiagonal first: y is assigned (DMV:1062-1063) */
+    TRY(ls_amd_generate(d->plan, 0, d_x, d_y, d->d_send[0], stream));
+    TRY(exchange(d, 0, stream));
+    for (int r = 0; r < R; ++r) {
+        if (r + 1 < R) { /* the next round's packets are generated and on the wire before this round is scattered */
+            TRY(ls_amd_generate(d->plan, r + 1, d_x, d_y, d->d_send[(r + 1) & 1], stream));
+            TRY(exchange(d, r + 1, stream));
+        }
+        COMM(lsk_comm_exchange_wait(d->comm->c, r & 1, stream));
+        char const *recv = (char const *)d->d_recv[r & 1];
+        for (int s = 0; s < P; ++s) {
+            int64_t const n = d->recv_counts[(size_t)r * P + s];
+            if (n == 0) continue;
+            char const *seg = recv + d->recv_off[(size_t)r * P + s]; /* SoA: n betas, then n values */
+            TRY(ls_amd_scatter(d->plan, n, (uint64_t const *)seg, seg + 8 * n, d_y, stream));
+        }
+    }
+    return 0;
+}

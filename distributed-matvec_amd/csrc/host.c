@@ -35,6 +35,14 @@ static int set_error(char const *fmt, ...) {
     return -1;
 }
 static int dev_error(void) { return set_error("%s", lsk_last_error()); }
+/* for the other host files (dist.c): same buffer, same -1 */
+int ls_amd_internal_error(char const *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_last_error, sizeof(g_last_error), fmt, ap);
+    va_end(ap);
+    return -1;
+}
 #define DEV(expr) do { if ((expr) != 0) return dev_error(); } while (0)
 
 char const *ls_amd_last_error(void) { return g_last_error; }
@@ -157,6 +165,7 @@ struct ls_amd_basis_ext {
     uint64_t *d_reps_cache; /* device copy of `representatives` for the host-pointer entry points */
     uint64_t d_reps_count;
     void *host_plan_f64;    /* ls_amd_plan* cached by the host-pointer entry points */
+    void *host_dist_f64;    /* ls_amd_dist* likewise, when a default communicator with > 1 ranks is installed */
     uint32_t *d_index_table; /* search table over d_reps_cache (ls_hs_state_index) */
     int index_kind, index_shift;
 };
@@ -386,6 +395,7 @@ ls_hs_basis *ls_hs_clone_basis(ls_hs_basis const *basis) {
 static void basis_drop_device_caches(ls_hs_basis *b) {
     struct ls_amd_basis_ext *e = b->ext;
     if (e->host_plan_f64) { ls_amd_plan_destroy((ls_amd_plan *)e->host_plan_f64); e->host_plan_f64 = NULL; }
+    if (e->host_dist_f64) { ls_amd_dist_destroy((ls_amd_dist *)e->host_dist_f64); e->host_dist_f64 = NULL; }
     if (e->d_reps_cache) { lsk_free(e->d_reps_cache); e->d_reps_cache = NULL; e->d_reps_count = 0; }
     if (e->d_index_table) { lsk_free(e->d_index_table); e->d_index_table = NULL; }
     e->index_kind = -1;
@@ -1487,7 +1497,10 @@ int ls_amd_plan_create(ls_amd_plan **out, ls_hs_operator const *op, ls_amd_dtype
             if (op->basis->ext->elems[g].ch_im != 0.0) { free(pl); return set_error("complex characters need dtype c128"); }
     }
     /* kernel family */
-    int const force_tile = getenv("LS_AMD_FORCE_TILE") != NULL; /* test hook: packets path with P == 1 */
+    /* a plan that owns ONE partition is driven by generate / exchange / scatter (one locale per process): always the
+     * packet kernels, also when numLocales == 1 (the reference's matrixVectorProduct works there too, DMV:1072-1093).
+     * LS_AMD_FORCE_TILE: test hook, packets path for an all-partitions plan with P == 1 */
+    int const force_tile = getenv("LS_AMD_FORCE_TILE") != NULL || my_partition >= 0;
     if (force_tile) pl->family = FAMILY_TILE;
     else if (num_partitions == 1 && pl->dbs.proj != LSK_PROJ_FULL) {
         ls_amd_mode m = mode;
@@ -1930,6 +1943,28 @@ static int host_matvec_f64(ls_hs_operator *op, int64_t n, double const *x, doubl
     struct ls_amd_basis_ext *e = b->ext;
     if (ensure_device_reps(b) != 0) return -1;
     if ((uint64_t)n != e->d_reps_count) return set_error("vector length does not match the number of representatives");
+    ls_amd_comm *cm = ls_amd_default_comm();
+    if (cm && ls_amd_comm_size(cm) > 1) {
+        /* one locale per process: `representatives` is this locale's block of the hashed basis and x, y are the
+         * matching blocks (Diagonalize.chpl:134-162 runs the callback on every locale in lock-step) */
+        if (!e->host_dist_f64) {
+            ls_amd_dist *dd;
+            if (ls_amd_dist_create(&dd, cm, op, LS_AMD_F64, e->d_reps_cache, n, 0, NULL) != 0) return -1;
+            e->host_dist_f64 = dd;
+        }
+        ls_amd_dist *dd = (ls_amd_dist *)e->host_dist_f64;
+        void *dx, *dy;
+        DEV(lsk_malloc(&dx, 8 * (size_t)n));
+        DEV(lsk_malloc(&dy, 8 * (size_t)n));
+        int rc = 0;
+        if (lsk_h2d(dx, x, 8 * (size_t)n) != 0 || lsk_h2d(dy, y, 8 * (size_t)n) != 0) rc = dev_error();
+        if (rc == 0) rc = ls_amd_dist_matvec(dd, dx, dy, NULL);
+        if (rc == 0) rc = ls_amd_plan_check(ls_amd_dist_plan(dd), NULL);
+        if (rc == 0 && lsk_d2h(y, dy, 8 * (size_t)n) != 0) rc = dev_error();
+        lsk_free(dx);
+        lsk_free(dy);
+        return rc;
+    }
     if (!e->host_plan_f64) {
         ls_amd_plan *pl;
         uint64_t const *reps[1] = {e->d_reps_cache};
@@ -1976,15 +2011,7 @@ void ls_chpl_primme_matvec(void *x, int64_t *ldx, void *y, int64_t *ldy, int *bl
             return;
         }
 }
-void primmeGlobalSumReal(void *sendBuf, void *recvBuf, int *count, void *primme, int *ierr) {
-    (void)primme;
-    if (sendBuf != recvBuf) memmove(recvBuf, sendBuf, sizeof(double) * (size_t)*count);
-    *ierr = 0;
-}
-void primmeBroadcastReal(void *buffer, int *count, void *primme, int *ierr) {
-    (void)buffer; (void)count; (void)primme;
-    *ierr = 0;
-}
+/* primmeGlobalSumReal / primmeBroadcastReal: dist.c (collective over the communicator) */
 
 static void free_array(void *p) { free(p); }
 

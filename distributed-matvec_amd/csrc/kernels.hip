@@ -1094,6 +1094,20 @@ extern "C" int lsk_chain(lsk_operator op, lsk_basis bs, lsk_index ix, lsk_tilema
     cap &= ~(int64_t)7;
     if (cap < 8) cap = 8;
     if (gb > cap) gb = cap;
+    {
+        // profiling only (wrong results): drop every pair >= LS_AMD_CHAIN_MAXLO and the cached pairs, to price the
+        // near / middle / far pairs separately
+        char const *e = getenv("LS_AMD_CHAIN_MAXLO");
+        if (e) {
+            int const maxlo = atoi(e);
+            for (int q = 0; q < op.runs.n_runs; ++q) {
+                int c = maxlo - op.runs.lo0[q];
+                if (c < 0) c = 0;
+                if (c < op.runs.cnt[q]) op.runs.cnt[q] = c;
+            }
+            n_cached = 0;
+        }
+    }
     hipLaunchKernelGGL(k_chain, dim3((unsigned)gb), dim3(kBlock), 0, (hipStream_t)stream, op.runs, op.n_diag, op.diag,
                        bs.hamming_weight, ix.binom, tm.entries, tm.slots_per_xcd, n, reps, (double const *)x, (double *)y,
                        high_pair_setting(kChainLdsPairs), n_cached, cache, cv0, cv1, (uint32_t)row0, n_x);

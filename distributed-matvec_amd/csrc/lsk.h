@@ -266,6 +266,26 @@ int lsk_block_to_hashed(int64_t n, uint8_t const *masks, int P, int elt_size, vo
 int lsk_hashed_to_block(int64_t n, uint8_t const *masks, int P, int elt_size,
                         void const *const *h_src, void *dest, void *stream);
 
+/* RCCL (comm.cpp) ------------------------------------------------------------------------------ */
+typedef struct lsk_comm lsk_comm;
+char const *lsk_comm_last_error(void);
+int lsk_comm_available(void);
+int lsk_comm_unique_id(void *id128);
+int lsk_comm_create(lsk_comm **out, int size, int rank, void const *id128);
+void lsk_comm_destroy(lsk_comm *c);
+int lsk_comm_size(lsk_comm const *c);
+int lsk_comm_rank(lsk_comm const *c);
+int lsk_comm_allreduce(lsk_comm *c, void *d_buf, int64_t count, int dtype /* 0 f64, 1 f32, 2 i64 */, int op /* 0 sum, 1 max */,
+                       void *stream);
+int lsk_comm_broadcast(lsk_comm *c, void *d_buf, int64_t bytes, int root, void *stream);
+int lsk_comm_allgather(lsk_comm *c, void const *d_send, void *d_recv, int64_t bytes_per_rank, void *stream);
+/* double-buffered all-to-all-v on the exchange stream (see comm.cpp) */
+int lsk_comm_exchange_begin(lsk_comm *c, int slot, void *compute_stream);
+int lsk_comm_alltoallv(lsk_comm *c, void const *d_send, int64_t const *send_off, int64_t const *send_bytes, void *d_recv,
+                       int64_t const *recv_off, int64_t const *recv_bytes);
+int lsk_comm_exchange_end(lsk_comm *c, int slot);
+int lsk_comm_exchange_wait(lsk_comm *c, int slot, void *compute_stream);
+
 #ifdef __cplusplus
 }
 #endif

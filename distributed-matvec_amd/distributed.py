@@ -247,6 +247,48 @@ class DistributedOperator:
         return self.global_sum(local)[0]
 
 
+class RcclDistributedOperator:
+    """matrixVectorProduct with one locale per process, the exchange done by the C host
+    (ls_amd_dist_matvec: generate -> grouped ncclSend/ncclRecv -> scatter, double-buffered over two HIP
+    streams; include/ls_amd.h).  Python only bootstraps the communicator's unique id through the existing
+    torch.distributed group and forwards pointers; nothing of the data path goes through torch."""
+
+    class _Engine:
+        def __init__(self, plan):
+            self.plan = plan
+
+    def __init__(self, matrix, representatives, dtype, group=None, comm=None, num_rounds: int = 0):
+        from .api import Communicator, DistMatvec
+
+        self.comm = comm if comm is not None else Communicator.from_torch(group)
+        self.rank, self.P = self.comm.rank, self.comm.size
+        self.dm = DistMatvec(self.comm, matrix, representatives, dtype, num_rounds)
+        self.engine = self._Engine(self.dm.plan)
+        self.num_rounds = self.dm.num_rounds
+        self.exchange_bytes_per_matvec = self.dm.exchange_bytes
+
+    def matvec(self, x, y, check: bool = False):
+        self.dm.matvec(x, y, check=check)
+
+    def global_sum(self, t):
+        """globalSumReal (PRIMME.chpl:267-322) on a device tensor, in place"""
+        import torch
+
+        if t.is_complex():
+            self.comm.allreduce_sum(torch.view_as_real(t))
+            return t
+        return self.comm.allreduce_sum(t)
+
+    def broadcast(self, t, src: int = 0):
+        return self.comm.broadcast(t, src)
+
+    def dot(self, a, b):
+        import torch
+
+        local = (torch.vdot(a, b) if a.is_complex() else torch.dot(a, b)).reshape(1).clone()
+        return self.global_sum(local)[0]
+
+
 class HipReplicatedEngine:
     """ls_amd replicated-x plan for this rank (include/ls_amd.h)."""
 

@@ -10,8 +10,9 @@
  * Two ways to run the off-diagonal exchange (DMV:856-1053 replaced):
  *   - all P partitions in this process on one device  -> ls_amd_matvec (logical partitions; the
  *     "exchange" is a pointer hand-off), and
- *   - one partition per process / GPU               -> ls_amd_generate + an all-to-all-v done by
- *     the caller (torch.distributed over RCCL) + ls_amd_scatter.
+ *   - one partition per process / GPU               -> ls_amd_dist_matvec (generate + RCCL all-to-all-v
+ *     + scatter inside the library), or the three stages separately (ls_amd_generate, an exchange of
+ *     the caller's, ls_amd_scatter).
  * All functions return 0 on success or a negative error code; ls_amd_last_error() explains.
  */
 #ifndef LS_AMD_H
@@ -54,6 +55,52 @@ int ls_amd_synchronize(void *stream);
 /* hash64_01 / localeIdxOf on the host (StatesEnumeration.chpl:122-136) */
 uint64_t ls_amd_hash64_01(uint64_t x);
 int ls_amd_locale_idx_of(uint64_t basis_state, int num_locales);
+
+/* ------------------------------------------------------------------------------------------
+ * One locale per process / GPU: the inter-GPU exchange lives in the C host (RCCL over xGMI).
+ *
+ * Replaces /root/reference/src/DistributedMatrixVector.chpl:313-853 (GlobalPtrStore, _LocalBuffer /
+ * _RemoteBuffer mailboxes with one-sided PUTs and remote flag stores, Producer / Consumer tasks,
+ * three barriers per matvec) by bulk-synchronous rounds:
+ *     generate(r)  ->  ONE grouped ncclSend / ncclRecv with the plan's exact per-round byte counts
+ *                      (all-to-all-v of (sigma_j, c_j x_i) packets; every GPU pair uses its own xGMI link)
+ *                  ->  scatter(r)
+ * double-buffered over two HIP streams: the exchange of round r overlaps generate(r + 1) and scatter(r - 1).
+ * librccl is loaded at run time (dlopen); the bootstrap of the 128-byte unique id is the caller's
+ * (MPI_Bcast, a file, torch.distributed's store, ...), exactly like ncclGetUniqueId / ncclCommInitRank.
+ * rank == locale index == hash64_01(sigma) % size (StatesEnumeration.chpl:133-136).
+ */
+typedef struct ls_amd_comm ls_amd_comm;
+#define LS_AMD_UNIQUE_ID_BYTES 128
+int ls_amd_comm_available(void);                 /* 1 when librccl can be loaded */
+int ls_amd_comm_unique_id(void *id /* [LS_AMD_UNIQUE_ID_BYTES], written on the calling rank */);
+int ls_amd_comm_create(ls_amd_comm **comm, int size, int rank, void const *id);
+void ls_amd_comm_destroy(ls_amd_comm *comm);
+int ls_amd_comm_size(ls_amd_comm const *comm);
+int ls_amd_comm_rank(ls_amd_comm const *comm);
+/* in-place collectives on device buffers (ordered on `stream`) */
+int ls_amd_comm_allreduce_sum_f64(ls_amd_comm *comm, double *d_buf, int64_t count, void *stream);
+int ls_amd_comm_allreduce_max_i64(ls_amd_comm *comm, int64_t *d_buf, int64_t count, void *stream);
+int ls_amd_comm_broadcast(ls_amd_comm *comm, void *d_buf, int64_t bytes, int root, void *stream);
+/* the communicator primmeGlobalSumReal / primmeBroadcastReal / ls_chpl_primme_matvec use when
+ * primme->commInfo is NULL (the reference's PRIMME callbacks are collective over all locales,
+ * /root/reference/src/PRIMME.chpl:267-373); NULL = single process */
+void ls_amd_set_default_comm(ls_amd_comm *comm);
+ls_amd_comm *ls_amd_default_comm(void);
+
+/* matrixVectorProduct for this rank's block of the hashed vectors (DMV:1072-1093, one locale per process).
+ * d_reps_local: this rank's representatives (ascending, device, borrowed for the lifetime of the object).
+ * num_rounds <= 0: agreed on collectively (max local count / LS_AMD_ROWS_PER_ROUND, default 2^24 rows). */
+typedef struct ls_amd_dist ls_amd_dist;
+int ls_amd_dist_create(ls_amd_dist **dist, ls_amd_comm *comm, ls_hs_operator const *op, ls_amd_dtype dtype,
+                       uint64_t const *d_reps_local, int64_t count_local, int num_rounds, void *stream);
+void ls_amd_dist_destroy(ls_amd_dist *dist);
+/* y <- H x (y is assigned by the diagonal pass, then accumulated into; untouched first when the operator has
+ * no diagonal terms, DMV:1062-1063).  Collective: every rank of the communicator must call it. */
+int ls_amd_dist_matvec(ls_amd_dist *dist, void const *d_x, void *d_y, void *stream);
+ls_amd_plan *ls_amd_dist_plan(ls_amd_dist *dist);          /* timing, check, nnz, kernel name */
+int64_t ls_amd_dist_exchange_bytes(ls_amd_dist const *dist); /* bytes this rank sends per matvec */
+int ls_amd_dist_num_rounds(ls_amd_dist const *dist);
 
 /* ------------------------------------------------------------------------------------------
  * Plans.  A plan binds an operator to the partition layout and owns every per-basis device table:
