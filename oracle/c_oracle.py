@@ -179,6 +179,14 @@ class COracle:
         return y_parts
 
 
+def fixed_hamming_ranks(states):
+    """ls_hs_fixed_hamming_state_to_index for an array of states"""
+    states = np.ascontiguousarray(states, dtype=np.uint64)
+    out = np.empty(len(states), dtype=np.int64)
+    lib().lso_fixed_hamming_state_to_index_batch(C.c_int64(len(states)), _p(states, _u64p), _p(out, _i64p))
+    return out
+
+
 def state_index(reps, spins):
     reps = np.ascontiguousarray(reps, dtype=np.uint64)
     spins = np.ascontiguousarray(spins, dtype=np.uint64)

@@ -186,6 +186,10 @@ int64_t lso_fixed_hamming_state_to_index(uint64_t s) {
     }
     return idx;
 }
+/* batch form for the sampled-row parity tests (one call instead of one ctypes call per state) */
+void lso_fixed_hamming_state_to_index_batch(int64_t n, const uint64_t *states, int64_t *out) {
+    for (int64_t i = 0; i < n; ++i) out[i] = lso_fixed_hamming_state_to_index(states[i]);
+}
 /* ls_hs_fixed_hamming_index_to_state (/root/reference/src/FFI.chpl:166) */
 uint64_t lso_fixed_hamming_index_to_state(int64_t idx, int hamming_weight) {
     binom_init();
