@@ -40,6 +40,94 @@ def chain_nnz(L, n_states):
     return n_states * L * L // (2 * (L - 1))
 
 
+def source_sha():
+    """sha256 of the kernel source the library was built from: ties a PMC measurement to the code it measured"""
+    import hashlib
+
+    hsh = hashlib.sha256()
+    for f in ("kernels.hip", "lsk.h"):
+        with open(os.path.join(ROOT, "distributed-matvec_amd", "csrc", f), "rb") as fh:
+            hsh.update(fh.read())
+    return hsh.hexdigest()[:16]
+
+
+PULL_KERNELS = ("direct-pull", "tile-pull", "replicated-")
+
+
+def roofline_object(args, kernel_name, kernel_ms, launches_per_step, rows_here, n_total, nnz, w, world, sec_per_step, symm):
+    """HBM roofline of the dominant kernel, per launch.
+
+    ALGORITHMIC bytes = the compulsory traffic of the formulation the kernel executes:
+      push (direct-push, tile: the reference's formulation):
+          rows (8 + w) [+ w for the y write of the separate diagonal pass] + nnz 2w   (RMW of y_j per non-zero)
+      pull (Hermitian operators; y written once, no RMW): rows (8 + 2w) + the per-row plan data the kernel streams
+          (4 B cached partner rank per cached pair for the staged kernel, 8 B norm for projected bases).
+    `achieved` = those bytes / average launch time, `frac` = achieved / peak: cannot exceed 1.
+    `traffic` = fabric bytes of the same launch from the committed PMC passes (profiles/pmc_traffic.json), attached
+    only when the entry was measured on this very kernel source (source_sha); `frac_traffic` = traffic / t / peak,
+    `wasted_traffic` = traffic / algorithmic bytes (> 1 = re-reads the caches did not absorb).
+    `survey_formula` keeps the SURVEY.md 8(d) push-formula figure for cross-reference; for a pull kernel it is NOT a
+    bandwidth (the kernel never performs the 2w read-modify-write per non-zero the formula charges)."""
+    nnz_here = nnz * rows_here // max(1, n_total)
+    pull = kernel_name.startswith(PULL_KERNELS)
+    per_row_extra = 0
+    if pull:
+        if "staged" in kernel_name:
+            per_row_extra = 4  # one cached partner rank per row (the ring-closing pair)
+        if "tile-pull" in kernel_name:
+            per_row_extra = 8  # norm(alpha)
+        alg = rows_here * (8 + 2 * w + per_row_extra)
+        formulation = "pull: rows (8 + 2w + plan bytes per row); y written once"
+    elif kernel_name == "direct-push":
+        alg = rows_here * (8 + w) + nnz_here * 2 * w  # the diagonal pass (y write) is a separate, tiny kernel
+        formulation = "push: rows (8 + w) + nnz 2w (SURVEY 8(d))"
+    else:  # tile: staged push; remote packets are written (8 + w) and scattered by k_scatter
+        alg = rows_here * (8 + w) + nnz_here * 2 * w
+        formulation = "push via packets: rows (8 + w) + nnz 2w (SURVEY 8(d)); all launches of one matvec"
+    alg_per_launch = alg / launches_per_step
+    t = kernel_ms * 1e-3 if kernel_ms else None
+    achieved = alg_per_launch / t / 1e9 if t else None
+    sha = source_sha()
+    traffic = int_alu = None
+    traffic_note = "no PMC entry for this workload / kernel"
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            ent = json.load(f).get(f"{args.model}/{args.dtype}/{kernel_name}")
+        if ent and world == 1:
+            if ent.get("source_sha") == sha:
+                traffic = ent["traffic_bytes"]
+                traffic_note = f"profiles/pmc_traffic.json ({ent.get('source')}), source_sha {sha}"
+                if ent.get("valu_insts"):
+                    # integer-ALU roofline of the projected bases (SURVEY 8(d)): wave64 VALU instructions x 64 lanes
+                    peak_lane_ops = 256 * 4 * 32 * 2.4e9  # CUs x SIMDs x lanes per clock x Hz
+                    ach = ent["valu_insts"] * 64 / t if t else None
+                    int_alu = {"valu_wave_insts_per_launch": ent["valu_insts"], "achieved_lane_ops_per_s": ach,
+                               "peak_lane_ops_per_s": peak_lane_ops, "frac": ach / peak_lane_ops if ach else None}
+            else:
+                traffic_note = (f"PMC entry is stale: measured on source_sha {ent.get('source_sha')}, this build is {sha}; "
+                                f"re-run scripts/gpu_pmc_traffic.sh")
+    except (OSError, ValueError):
+        pass
+    b_alg_push = n_total * (8 + 2 * w) + nnz * 2 * w
+    out = {
+        "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+        "frac": achieved / HBM_PEAK_GBPS if achieved else None, "traffic": traffic,
+        "frac_compulsory": achieved / HBM_PEAK_GBPS if achieved else None,
+        "frac_traffic": traffic / t / 1e9 / HBM_PEAK_GBPS if (traffic and t) else None,
+        "wasted_traffic": traffic / alg_per_launch if traffic else None,
+        "traffic_note": traffic_note,
+        "kernel": kernel_name, "formulation": formulation, "kernel_ms_avg": kernel_ms,
+        "launches_per_step": launches_per_step, "algorithmic_bytes_per_launch": alg_per_launch,
+        "measured_stream_peak_GBps": 6290.0,  # float4 copy on this part (MI355X_MICROARCH.md)
+        "survey_formula": {"B_alg_push_bytes_per_matvec": b_alg_push,
+                           "matvec_over_B_alg_GBps": b_alg_push / sec_per_step / 1e9 / world,
+                           "note": "push-formula bytes / time per GPU; a bandwidth only for push kernels"},
+    }
+    if int_alu:
+        out["int_alu"] = int_alu
+    return out
+
+
 def cpu_baseline(sample_L, threads=0, repeats=3):
     """oracle ("port") timed on the host cores: heisenberg_chain_<sample_L>, full matvec."""
     import numpy as np
@@ -73,7 +161,7 @@ def main():
     ap.add_argument("--dtype", default="f64", choices=["f64", "c128"])
     ap.add_argument("--mode", default=os.environ.get("LS_AMD_MODE", "auto"), choices=["auto", "push", "pull"])
     ap.add_argument("--exchange", default="auto", choices=["auto", "packets", "replicated"],
-                    help="N > 1: all-to-all-v of packets (reference formulation) or all-gather of x + pull")
+                    help="N > 1: all-to-all-v of packets (reference formulation), all-gather of x + pull, or (auto) both")
     ap.add_argument("--force-distributed", action="store_true",
                     help="run the N > 1 code path (process group, exchange) even with one rank (test hook)")
     ap.add_argument("--cpu-sample", type=int, default=28, help="chain length of the CPU-baseline sample")
@@ -178,94 +266,54 @@ def main():
         xb = allsum(getattr(op, "exchange_bytes_per_matvec", 0))
         return dt, kms, lps, plan.kernel, xb, plan, op
 
+    exchanges = {}
     if not distributed:
         make = lambda: D.MatvecPlan(h, [my_reps], tdtype, mode=args.mode)  # noqa: E731
         exchange = "none"
+        setup_t0 = time.perf_counter()
+        dt, kernel_ms, launches_per_step, kernel_name, exchange_bytes, plan, op_obj = measure(make, args.steps, args.warmup, "main")
     else:
-        from distributed_matvec_amd.distributed import DistributedOperator, ReplicatedOperator
+        from distributed_matvec_amd.distributed import RcclDistributedOperator, ReplicatedOperator
 
-        exchange = args.exchange
-        if exchange == "auto":
-            exchange = "replicated" if h.isHermitian else "packets"
-        if exchange == "replicated":
-            make = lambda: ReplicatedOperator(h, my_reps, reps_global, masks, tdtype)  # noqa: E731
-        else:
-            make = lambda: DistributedOperator(h, my_reps, tdtype)  # noqa: E731
-    setup_t0 = time.perf_counter()
-    try:
-        dt, kernel_ms, launches_per_step, kernel_name, exchange_bytes, plan, op_obj = measure(make, args.steps, args.warmup, "main")
-    except Exception as e:
-        if not (distributed and exchange == "replicated"):
-            raise
-        # insurance for the first multi-GPU runs: fall back to the packet exchange rather than report nothing
-        extra["exchange=replicated"] = {"error": repr(e)[:300]}
-        exchange = "packets"
-        torch.cuda.empty_cache()
-        make = lambda: DistributedOperator(h, my_reps, tdtype)  # noqa: E731
-        dt, kernel_ms, launches_per_step, kernel_name, exchange_bytes, plan, op_obj = measure(make, args.steps, args.warmup, "main")
+        # Both exchange strategies are first-class numbers (same hash-partitioned x / y / representatives at the
+        # interface, same result):
+        #   packets     the reference's formulation: (sigma_j, c_j x_i) packets, all-to-all-v inside the C host
+        #               (ls_amd_dist_matvec: grouped ncclSend/ncclRecv over xGMI, double-buffered rounds)
+        #   replicated  Hermitian operators: exchange x itself (N w bytes instead of nnz (8 + w)) and pull locally
+        # A failure of either is an error of the run, never a footnote.
+        comm = D.Communicator.from_torch()
+        makers = {"packets": lambda: RcclDistributedOperator(h, my_reps, tdtype, comm=comm)}
+        if h.isHermitian:
+            makers["replicated"] = lambda: ReplicatedOperator(h, my_reps, reps_global, masks, tdtype)
+        wanted = list(makers) if args.exchange == "auto" else [args.exchange]
+        setup_t0 = time.perf_counter()
+        results = {}
+        for name in wanted:
+            torch.cuda.empty_cache()
+            r = measure(makers[name], args.steps, args.warmup, name)
+            results[name] = r
+            exchanges[name] = {"matvecs_per_s": args.steps / r[0], "ms_per_step": 1e3 * r[0] / args.steps, "kernel": r[3],
+                               "kernel_ms_avg": r[1], "launches_per_step": r[2], "exchange_bytes_per_matvec": r[4]}
+            if len(wanted) > 1:  # keep only the numbers; the plans of the other strategy would pin HBM
+                results[name] = r[:5] + (None, None)
+                del r
+        exchange = min(wanted, key=lambda k: results[k][0])  # `value` is the faster strategy, named in config.exchange
+        dt, kernel_ms, launches_per_step, kernel_name, exchange_bytes, plan, op_obj = results[exchange]
     setup_s = (setup_t0 - t_setup)
     if symm:
         # non-zeros of the projected matrix: the packet count of a push plan's count pass
-        pp = D.MatvecPlan(h, [my_reps], tdtype, mode="push") if not distributed else None
-        nnz = int(allsum(pp.nnz)) if pp is not None else None
-        if pp is not None:
-            pp.destroy()
-        if nnz is None:
-            # one partition per rank: the count pass of a push (packets) plan over this rank's rows
+        if not distributed:
+            pp = D.MatvecPlan(h, [my_reps], tdtype, mode="push")
+        else:
             pp = D.MatvecPlan(h, my_reps, tdtype, my_partition=rank, num_partitions=world, mode="push")
-            nnz = int(allsum(pp.nnz))
-            pp.destroy()
-    if distributed and not args.no_extra and h.isHermitian and "exchange=replicated" not in extra:
-        # the other exchange strategy, fewer steps
-        from distributed_matvec_amd.distributed import DistributedOperator, ReplicatedOperator
-
-        other = "packets" if exchange == "replicated" else "replicated"
-        del op_obj, plan
-        torch.cuda.empty_cache()
-        mk = (lambda: DistributedOperator(h, my_reps, tdtype)) if other == "packets" else (lambda: ReplicatedOperator(h, my_reps, reps_global, masks, tdtype))
-        try:
-            dt2, kms2, lps2, kn2, xb2, plan2, op2 = measure(mk, max(2, args.steps // 4), 1, other)
-            s2 = max(2, args.steps // 4)
-            extra[f"exchange={other}"] = {"matvecs_per_s": s2 / dt2, "ms_per_step": 1e3 * dt2 / s2, "kernel": kn2,
-                                          "exchange_bytes_per_matvec": xb2}
-            del op2, plan2
-        except Exception as e:  # the secondary measurement must never cost the primary one
-            extra[f"exchange={other}"] = {"error": repr(e)[:300]}
+        nnz = int(allsum(pp.nnz))
+        pp.destroy()
 
     ms_per_step = 1e3 * dt / args.steps
     value = args.steps / dt
 
-    # ALGORITHMIC bytes per matvec: N (8 + 2w) + nnz 2w  (compulsory traffic of the
-    # push formulation: read sigma_i, x_i, write y_i; read-modify-write y_j per non-zero)
-    b_alg = n_total * (8 + 2 * w) + nnz * 2 * w
-    # the dominant kernel does the per-nnz part and (pull / tile) the per-row part of this rank
-    rows_here = int(my_reps.numel())
-    nnz_here = nnz * rows_here // max(1, n_total)
-    if kernel_name == "direct-push":
-        bytes_per_launch = rows_here * (8 + w) + nnz_here * 2 * w  # diagonal pass (y write) is a separate kernel
-    elif kernel_name == "tile":
-        # the staged push kernel: term generation + local scatter; remote packets are written (8 + w) and
-        # scattered by k_scatter (not counted here)
-        bytes_per_launch = (rows_here * (8 + w) + nnz_here * 2 * w) / launches_per_step
-    else:
-        bytes_per_launch = (rows_here * (8 + 2 * w) + nnz_here * 2 * w) / launches_per_step
-    achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms else None
-    traffic = None
-    try:  # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside the timed bench)
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            t = json.load(f).get(f"{args.model}/{args.dtype}/{kernel_name}")
-        if t and world == 1:
-            traffic = t["traffic_bytes"]
-    except (OSError, ValueError):
-        pass
-    roofline = {
-        "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-        "frac": achieved / HBM_PEAK_GBPS if achieved else None, "traffic": traffic,
-        "kernel": kernel_name, "kernel_ms_avg": kernel_ms, "launches_per_step": launches_per_step,
-        "algorithmic_bytes_per_launch": bytes_per_launch,
-        "whole_matvec_GBps": b_alg / (dt / args.steps) / 1e9,
-        "whole_matvec_frac_of_Nx_peak": b_alg / (dt / args.steps) / 1e9 / (HBM_PEAK_GBPS * world),
-    }
+    roofline = roofline_object(args, kernel_name, kernel_ms, launches_per_step, int(my_reps.numel()), n_total, nnz, w, world,
+                               dt / args.steps, symm)
 
     if not distributed and not args.no_extra and not symm:
         # secondary numbers in the same run: the other scatter/gather mode and the other dtype
@@ -318,6 +366,7 @@ def main():
                 "kernel": kernel_name, "x": "u(hash(sigma, 42)) - 0.5",
                 "exchange_bytes_per_matvec": exchange_bytes,
             },
+            "exchanges": exchanges,
             "roofline": roofline,
             "cpu_baseline": cpu,
             "setup_seconds": setup_s,

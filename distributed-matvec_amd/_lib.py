@@ -146,9 +146,8 @@ def load():
         "ls_amd_basis_group_order": (C.c_int, [bp]),
         "ls_amd_basis_apply_group_element": (C.c_uint64, [bp, C.c_int, C.c_uint64]),
         "ls_amd_basis_group_character": (C.c_int, [bp, C.c_int, c_f64p, c_f64p]),
-        "ls_amd_test_tilemap": (C.c_int64, [C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.POINTER(C.POINTER(C.c_uint64))]),
+        "ls_amd_test_tilemap": (C.c_int64, [C.c_int64, C.c_int, C.c_int64, C.POINTER(C.POINTER(C.c_uint64))]),
         "ls_amd_test_free": (None, [vp]),
-        "ls_amd_test_lin_rank": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int64, c_u64p, c_i64p]),
         "ls_hs_init": (None, []),
         "ls_hs_exit": (None, []),
         "ls_hs_create_spin_basis": (bp, [C.c_int, C.c_int, C.c_int, C.c_int, c_intp, c_intp]),

@@ -907,24 +907,15 @@ struct ls_amd_plan {
     uint32_t *d_gtable;
     int64_t *d_row_gidx;
     double *d_norms_global;
-    /* high-part pass of the direct pull kernel (lsk.h) */
-    int has_highpart;
-    lsk_highpart hp;
-    lsk_operator dop_low; /* dop with the exchange runs truncated to the pairs below the high part */
-    void *hp_alloc[7];
     /* tile map of the row kernels (lsk_tilemap in lsk.h) */
     lsk_tilemap tilemap;
     void *d_tilemap;
-    int tilemap_transposed;
     int has_chain; /* staged row kernel (lsk_chain) */
     int chain_cached;      /* leading non-adjacent exchange groups whose partner ranks are cached */
-    uint32_t *d_chain_cache; /* [chain_cached][count] */
+    void *d_chain_cache;   /* [chain_cached][count] u32, or u64 when chain_wide */
+    int chain_wide;        /* 64-bit ranks (>= 2^32 - 1 states) */
     double chain_v[2];
     int64_t chain_row0; /* global rank of the first local row (replicated-x plans) */
-    /* two-table pull kernel (lsk_lin in lsk.h) */
-    int has_lin;
-    lsk_lin lin;
-    void *lin_alloc[3];
     void *d_htab;        /* hash table {rep -> x * norm(rep)} of the tile-pull families */
     uint32_t *d_slot_of; /* slot of every (global) representative */
     int htab_bits;
@@ -1006,194 +997,31 @@ static int upload(void **slot, void const *host, size_t bytes) {
     return 0;
 }
 
-/* builds the high-part tables (lsk.h) for the full fixed-Hamming basis; t = number of top site bits */
-static int setup_highpart(ls_amd_plan *pl, int t) {
-    ls_hs_basis const *b = pl->op->basis;
-    int const L = b->number_sites, h = b->ext->hamming_weight;
-    lsk_runs const *R = &pl->dop.runs;
-    if (t < 2 || t > 12 || L - t < 1 || h < 0 || b->spin_inversion != 0 || R->n_runs == 0) return 0;
-    int const lowbits = L - t;
-    /* pairs (lo, lo + 1) of the exchange runs that lie entirely in the high part */
-    int npairs = 0;
-    int pair_bit[64];
-    double pair_v[64][2];
-    pl->dop_low = pl->dop;
-    for (int r = 0; r < R->n_runs; ++r) {
-        int keep = lowbits - R->lo0[r];
-        if (keep < 0) keep = 0;
-        if (keep > R->cnt[r]) keep = R->cnt[r];
-        for (int lo = R->lo0[r] + keep; lo < R->lo0[r] + R->cnt[r]; ++lo) {
-            pair_bit[npairs] = lo - lowbits;
-            pair_v[npairs][0] = R->v_re[r];
-            pair_v[npairs][1] = R->v_im[r];
-            ++npairs;
-        }
-        pl->dop_low.runs.cnt[r] = keep;
-    }
-    if (npairs == 0) return 0;
-    int const nH = 1 << t;
-    int *row_of = (int *)malloc(sizeof(int) * nH);
-    int64_t *base_of = (int64_t *)malloc(sizeof(int64_t) * nH);
-    int64_t acc = 0;
-    int nrows = 0;
-    for (int H = 0; H < nH; ++H) {
-        int j = __builtin_popcount((unsigned)H);
-        row_of[H] = -1;
-        if (h - j < 0 || h - j > lowbits) continue;
-        base_of[H] = acc;
-        acc += (int64_t)binom(lowbits, h - j);
-        ++nrows;
-    }
-    if (acc != pl->parts[0].count) { free(row_of); free(base_of); return 0; } /* not the full set: leave it to pass A */
-    int32_t *class_rows = (int32_t *)calloc(t + 2, sizeof(int32_t));
-    int64_t *class_size = (int64_t *)calloc(t + 2, sizeof(int64_t));
-    int64_t *class_chunk0 = (int64_t *)calloc(t + 2, sizeof(int64_t));
-    int64_t *row_base = (int64_t *)malloc(sizeof(int64_t) * (nrows > 0 ? nrows : 1));
-    int *row_H = (int *)malloc(sizeof(int) * (nrows > 0 ? nrows : 1));
-    int nclasses = 0, row = 0, max_rows = 0;
-    for (int j = 0; j <= t; ++j) {
-        if (h - j < 0 || h - j > lowbits) continue;
-        class_rows[nclasses] = row;
-        class_size[nclasses] = (int64_t)binom(lowbits, h - j);
-        for (int H = 0; H < nH; ++H)
-            if (__builtin_popcount((unsigned)H) == j) { row_of[H] = row; row_base[row] = base_of[H]; row_H[row] = H; ++row; }
-        if (row - class_rows[nclasses] > max_rows) max_rows = row - class_rows[nclasses];
-        class_chunk0[nclasses + 1] = class_chunk0[nclasses] + (class_size[nclasses] + 63) / 64;
-        ++nclasses;
-    }
-    class_rows[nclasses] = row;
-    int32_t *pbegin = (int32_t *)calloc(nrows + 1, sizeof(int32_t));
-    int32_t *prow = (int32_t *)malloc(sizeof(int32_t) * ((size_t)nrows * npairs + 1));
-    double *pv = (double *)malloc(sizeof(double) * 2 * ((size_t)nrows * npairs + 1));
-    int np = 0;
-    for (int r = 0; r < nrows; ++r) {
-        pbegin[r] = np;
-        int H = row_H[r];
-        for (int k = 0; k < npairs; ++k) {
-            int bit = pair_bit[k];
-            if ((((H >> bit) ^ (H >> (bit + 1))) & 1) == 0) continue;
-            prow[np] = row_of[H ^ (3 << bit)];
-            pv[2 * np] = pair_v[k][0];
-            pv[2 * np + 1] = pair_v[k][1];
-            ++np;
-        }
-    }
-    pbegin[nrows] = np;
-    int rc = 0;
-    size_t lds = (size_t)max_rows * 64 * (pl->cplx ? 16 : 8);
-    if (lds <= 64 * 1024) {
-        rc = upload(&pl->hp_alloc[0], class_rows, sizeof(int32_t) * (nclasses + 1)) ||
-             upload(&pl->hp_alloc[1], class_size, sizeof(int64_t) * nclasses) ||
-             upload(&pl->hp_alloc[2], class_chunk0, sizeof(int64_t) * (nclasses + 1)) ||
-             upload(&pl->hp_alloc[3], row_base, sizeof(int64_t) * nrows) ||
-             upload(&pl->hp_alloc[4], pbegin, sizeof(int32_t) * (nrows + 1)) ||
-             upload(&pl->hp_alloc[5], prow, sizeof(int32_t) * (np > 0 ? np : 1)) ||
-             upload(&pl->hp_alloc[6], pv, sizeof(double) * 2 * (np > 0 ? np : 1));
-        if (!rc) {
-            pl->hp.n_classes = nclasses; pl->hp.n_rows = nrows; pl->hp.max_class_rows = max_rows;
-            pl->hp.n_items = class_chunk0[nclasses];
-            pl->hp.class_rows = (int32_t const *)pl->hp_alloc[0];
-            pl->hp.class_size = (int64_t const *)pl->hp_alloc[1];
-            pl->hp.class_chunk0 = (int64_t const *)pl->hp_alloc[2];
-            pl->hp.row_base = (int64_t const *)pl->hp_alloc[3];
-            pl->hp.row_pbegin = (int32_t const *)pl->hp_alloc[4];
-            pl->hp.partner_row = (int32_t const *)pl->hp_alloc[5];
-            pl->hp.partner_v = (double const *)pl->hp_alloc[6];
-            pl->has_highpart = 1;
-        }
-    }
-    free(row_of); free(base_of); free(class_rows); free(class_size); free(class_chunk0); free(row_base); free(row_H);
-    free(pbegin); free(prow); free(pv);
-    return rc;
-}
-
-/* Tile map of the row kernels (lsk_tilemap in lsk.h).
- *
- * Default: XCD k gets the k-th contiguous eighth of the row tiles.
- *
- * Transposed (the full fixed-Hamming-weight basis in ascending order): write a state as (T, rest) with T its
- * top `t` bits.  All states with one T form a contiguous segment of C(L - t, weight - popcount(T)) rows,
- * and a flip mask that only touches top bits maps (T, rest) to (T', rest): the same offset in another
- * segment of the same popcount class.  A *set* = the same window of offsets in every segment of a
- * class; it is closed under the top flips, and under the low flips that stay inside the window.  Each
- * set goes to one XCD, whose resident blocks work through it concurrently (consecutive slots = the same
- * offsets in different segments), so the partners' lines are in that XCD's L2 while they are needed
- * instead of being fetched again from HBM.  LS_AMD_TOP_BITS (t; 0 = default map) and LS_AMD_SET_ROWS
- * (rows per set) tune it.  (Measured on k_direct and modelled for k_chain, scripts/tools/l2sim.c: the in-flight
- * footprint of one XCD exceeds its 4 MiB L2, so what the top pairs gain the middle pairs lose.)
- *
- * Chunked (LS_AMD_TILE_CHUNK = G tiles): chunks of G consecutive tiles dealt round-robin to the XCDs.  Together
- * with the transposed order the sets become chip-wide (sized by LS_AMD_SET_ROWS for the 256 MiB Infinity Cache):
- * modelled -27 % HBM reads for k_chain on chain_32 at t = 6, 2.6 M rows per set, G = 32
- * (scripts/tools/mallsim.c); not measured yet. */
+/* Tile map of the row kernels (lsk_tilemap in lsk.h): the traversal order is data, not code.
+ *   chunk == 0: XCD k gets the k-th contiguous eighth of the row tiles;
+ *   chunk  > 0: chunks of `chunk` consecutive tiles are dealt to the XCDs round-robin, so all XCDs advance through the
+ *               same region of the vector together (the shared Infinity Cache sees one moving front) while each keeps
+ *               runs of consecutive tiles for its own L2.
+ * Orders that were measured and removed (r2, chain_32 f64, gpurun_out/r2/order_sweep.log): sets closed under the flips of
+ * the top t site bits, per XCD or chip-wide (t = 6..12, 0.26 - 8 M rows per set): 10.97 - 11.67 ms against 11.09 ms
+ * contiguous and 10.60 ms chunked -- the far-pair gathers are bound by the L2-miss request rate, which no order of
+ * 1024-row tiles changes (a set small enough for one 4 MiB L2 is 70 tiles; 224 tiles are in flight per XCD). */
 typedef struct { uint64_t *e; int64_t n, cap; } tile_list;
 static void tile_push(tile_list *l, int64_t row, int64_t cnt) {
     if (l->n == l->cap) { l->cap = l->cap ? 2 * l->cap : 1024; l->e = (uint64_t *)realloc(l->e, sizeof(uint64_t) * (size_t)l->cap); }
     l->e[l->n++] = (uint64_t)row | ((uint64_t)cnt << 48);
 }
-/* host part: 8 lists of `*slots` entries in a malloc'ed array; `transposed` asks for the set order (needs the full
- * fixed-weight basis: n == C(L, hw)), t / set_rows as described above */
-static int tilemap_host(int L, int hw, int64_t n, int transposed, int TILE, int t, int64_t set_rows, int64_t chunk,
-                        uint64_t **out, int64_t *slots_out) {
+static int tilemap_host(int64_t n, int TILE, int64_t chunk, uint64_t **out, int64_t *slots_out) {
     tile_list lists[8];
     memset(lists, 0, sizeof(lists));
-    if (set_rows < TILE) set_rows = TILE;
-    if (t > 12) t = 12;
-    if (t > L - 2) t = L - 2;
-    if (transposed && !(t >= 2 && hw >= 0 && (uint64_t)n == binom(L, hw))) transposed = 0;
-    if (!transposed) {
-        int64_t const tiles = (n + TILE - 1) / TILE;
-        if (chunk > 0) { /* chunks of `chunk` consecutive tiles dealt round-robin: all XCDs advance through the same
-                          * region of the vector together (what the shared Infinity Cache likes), each keeps runs of
-                          * consecutive tiles (what its own L2 likes) */
-            for (int64_t q = 0; q < tiles; ++q)
-                tile_push(&lists[(q / chunk) % 8], q * TILE, n - q * TILE < TILE ? n - q * TILE : TILE);
-        } else
-            for (int k = 0; k < 8; ++k) /* XCD k: the k-th contiguous eighth of the tiles */
-                for (int64_t q = tiles * k / 8; q < tiles * (k + 1) / 8; ++q)
-                    tile_push(&lists[k], q * TILE, n - q * TILE < TILE ? n - q * TILE : TILE);
-    } else {
-        int const Lr = L - t, nT = 1 << t;
-        int64_t *base = (int64_t *)malloc(sizeof(int64_t) * (size_t)(nT + 1));
-        int64_t acc = 0;
-        for (int T = 0; T < nT; ++T) { /* ascending states <=> ascending top patterns */
-            base[T] = acc;
-            acc += (int64_t)binom(Lr, hw - __builtin_popcount((unsigned)T));
-        }
-        base[nT] = acc;
-        int64_t rows_of[8] = {0, 0, 0, 0, 0, 0, 0, 0}, global_q = 0;
-        int *segs = (int *)malloc(sizeof(int) * (size_t)nT);
-        for (int j = 0; j <= t; ++j) {
-            int64_t const len = (int64_t)binom(Lr, hw - j);
-            if (len == 0) continue;
-            int nseg = 0;
-            for (int T = 0; T < nT; ++T) if (__builtin_popcount((unsigned)T) == j) segs[nseg++] = T;
-            int64_t W = TILE;
-            while (W * 2 * nseg <= set_rows) W *= 2;
-            for (int64_t w0 = 0; w0 < len; w0 += W) {
-                if (chunk > 0) {
-                    /* chip-wide sets: the whole chip works on one set at a time (its footprint is sized for the
-                     * shared Infinity Cache, not for one L2); inside the set the tiles run segment by segment and
-                     * are dealt to the XCDs in round-robin chunks of consecutive tiles */
-                    for (int sgi = 0; sgi < nseg; ++sgi)
-                        for (int64_t off = w0; off < w0 + W && off < len; off += TILE) {
-                            tile_push(&lists[(global_q / chunk) % 8], base[segs[sgi]] + off, len - off < TILE ? len - off : TILE);
-                            ++global_q;
-                        }
-                    continue;
-                }
-                int k = 0; /* the least loaded XCD takes the set */
-                for (int q = 1; q < 8; ++q) if (rows_of[q] < rows_of[k]) k = q;
-                for (int64_t off = w0; off < w0 + W && off < len; off += TILE)
-                    for (int sgi = 0; sgi < nseg; ++sgi) {
-                        int64_t const cnt = len - off < TILE ? len - off : TILE;
-                        tile_push(&lists[k], base[segs[sgi]] + off, cnt);
-                        rows_of[k] += cnt;
-                    }
-            }
-        }
-        free(base); free(segs);
-    }
+    int64_t const tiles = (n + TILE - 1) / TILE;
+    if (chunk > 0) {
+        for (int64_t q = 0; q < tiles; ++q)
+            tile_push(&lists[(q / chunk) % 8], q * TILE, n - q * TILE < TILE ? n - q * TILE : TILE);
+    } else
+        for (int k = 0; k < 8; ++k) /* XCD k: the k-th contiguous eighth of the tiles */
+            for (int64_t q = tiles * k / 8; q < tiles * (k + 1) / 8; ++q)
+                tile_push(&lists[k], q * TILE, n - q * TILE < TILE ? n - q * TILE : TILE);
     int64_t slots = 0, total = 0;
     for (int k = 0; k < 8; ++k) if (lists[k].n > slots) slots = lists[k].n;
     uint64_t *flat = (uint64_t *)calloc((size_t)(8 * slots > 0 ? 8 * slots : 1), sizeof(uint64_t));
@@ -1207,138 +1035,41 @@ static int tilemap_host(int L, int hw, int64_t n, int transposed, int TILE, int 
     }
     *out = flat;
     *slots_out = slots;
-    return transposed ? 1 : 0;
+    return 0;
 }
-static int build_tilemap(ls_amd_plan *pl, int64_t n, int allow_transposed, int TILE) {
-    ls_hs_basis const *b = pl->op->basis;
-    char const *e = getenv("LS_AMD_TOP_BITS");
-    int const t = e ? atoi(e) : 8;
-    e = getenv("LS_AMD_SET_ROWS");
-    int64_t const set_rows = e ? atoll(e) : 65536;
+static int build_tilemap(ls_amd_plan *pl, int64_t n, int TILE) {
     uint64_t *flat = NULL;
     int64_t slots = 0;
-    e = getenv("LS_AMD_TILE_CHUNK"); /* tiles per round-robin chunk; 0 (default) = contiguous eighths */
-    int64_t const chunk = e ? atoll(e) : 0;
-    int const rc = tilemap_host(b->number_sites, b->ext->hamming_weight, n, allow_transposed && b->spin_inversion == 0, TILE, t,
-                                set_rows, chunk > 0 ? chunk : 0, &flat, &slots);
-    if (rc < 0) return -1;
+    /* Default for the staged kernel: chunks of 32 tiles -- measured on chain_32 (gpurun_out/r2/ablate_sweep.log):
+     * 11.09 ms contiguous, 10.87 / 10.70 / 10.60 / 10.59 / 10.59 ms at 8 / 16 / 32 / 64 / 128 */
+    char const *e = getenv("LS_AMD_TILE_CHUNK");
+    int64_t const chunk = e ? atoll(e) : (TILE >= 512 ? 32 : 0);
+    if (tilemap_host(n, TILE, chunk > 0 ? chunk : 0, &flat, &slots) < 0) return -1;
     int const up = upload(&pl->d_tilemap, flat, sizeof(uint64_t) * (size_t)(8 * slots > 0 ? 8 * slots : 1));
     free(flat);
     if (up) return -1;
     pl->tilemap.entries = (uint64_t const *)pl->d_tilemap;
     pl->tilemap.slots_per_xcd = slots;
-    pl->tilemap_transposed = rc;
     return 0;
 }
-/* test hook (host only): the tile map for the full basis of `number_sites` spins with `hamming_weight` up (or any n
- * rows when transposed == 0).  Returns slots per XCD (< 0 on error); *entries is malloc'ed, free with
- * ls_amd_test_free. */
-int64_t ls_amd_test_tilemap(int number_sites, int hamming_weight, int64_t n, int transposed, int tile_rows, int top_bits,
-                            int64_t set_rows, int64_t chunk, uint64_t **entries) {
+/* test hook (host only): the tile map of n rows.  Returns slots per XCD (< 0 on error); *entries is malloc'ed, free
+ * with ls_amd_test_free. */
+int64_t ls_amd_test_tilemap(int64_t n, int tile_rows, int64_t chunk, uint64_t **entries) {
     int64_t slots = 0;
     *entries = NULL;
-    if (tilemap_host(number_sites, hamming_weight, n, transposed, tile_rows, top_bits, set_rows, chunk, entries, &slots) < 0)
-        return -1;
+    if (tilemap_host(n, tile_rows, chunk, entries, &slots) < 0) return -1;
     return slots;
 }
 void ls_amd_test_free(void *p) { free(p); }
 
-/* tables of the two-table ranking (lsk_lin in lsk.h): tlo[1 << B], thi[1 << hb] (u64 entries when wide) */
-static void lin_tables_host(int hw, int B, int hb, int wide, uint16_t *tlo, void *thi) {
-    for (uint32_t l = 0; l < (1u << B); ++l) {
-        uint64_t r = 0;
-        int j = 1;
-        for (uint32_t s = l; s; s &= s - 1, ++j) r += binom(__builtin_ctz(s), j);
-        tlo[l] = (uint16_t)r;
-    }
-    size_t const nh = (size_t)1 << hb;
-    for (size_t h = 0; h < nh; ++h) {
-        int const kl = hw - __builtin_popcountll((unsigned long long)h);
-        uint64_t r = 0;
-        if (kl >= 0 && kl <= B) {
-            int j = kl + 1;
-            for (uint64_t s = h; s; s &= s - 1, ++j) r += binom(B + __builtin_ctzll(s), j);
-        }
-        if (wide) ((uint64_t *)thi)[h] = r; else ((uint32_t *)thi)[h] = (uint32_t)r;
-    }
-}
-/* test hook (host only): ranks[i] = thi[state >> bits] + tlo[state & mask] for the given states of `hamming_weight` */
-int ls_amd_test_lin_rank(int number_sites, int hamming_weight, int bits, int64_t n, uint64_t const *states, int64_t *ranks) {
-    if (bits < 1 || bits > 15 || number_sites < 1 || number_sites > 41 || number_sites - bits > 26) return set_error("bad arguments");
-    int const hb = number_sites > bits ? number_sites - bits : 0;
-    uint16_t *tlo = (uint16_t *)malloc(sizeof(uint16_t) << bits);
-    uint64_t *thi = (uint64_t *)malloc(sizeof(uint64_t) << hb);
-    lin_tables_host(hamming_weight, bits, hb, 1, tlo, thi);
-    for (int64_t i = 0; i < n; ++i) ranks[i] = (int64_t)(thi[states[i] >> bits] + tlo[states[i] & ((1ULL << bits) - 1)]);
-    free(tlo); free(thi);
-    return 0;
-}
-
-/* Two-table ranking for the row kernel (lsk_lin in lsk.h): applies to the full fixed-Hamming-weight basis
- * without symmetries and a real Hermitian operator.  LS_AMD_LIN=0 keeps the combinadic row kernel,
- * LS_AMD_LIN_BITS sets the width of the low part. */
-static int setup_lin(ls_amd_plan *pl) {
-    ls_hs_basis const *b = pl->op->basis;
-    struct ls_amd_operator_ext const *ext = pl->op->ext;
-    int const L = b->number_sites, hw = b->ext->hamming_weight;
-    char const *e = getenv("LS_AMD_LIN"); /* off by default: measured slower on chain_32 */
-    if (!e || atoi(e) == 0) return 0;
-    if (hw < 0 || b->spin_inversion != 0 || pl->dbs.proj != LSK_PROJ_NONE || !ext->is_real || !ext->is_hermitian) return 0;
-    e = getenv("LS_AMD_LIN_BITS");
-    int B = e ? atoi(e) : 14;
-    if (B > 15) B = 15;
-    if (B < 1) B = 1;
-    int const hb = L > B ? L - B : 0; /* width of the high part */
-    if (hb > 26) return 0;
-    int const n = ext->n_groups;
-    uint64_t const LM = (1ULL << B) - 1;
-    e = getenv("LS_AMD_NT_LO");
-    int const nt_lo = e ? atoi(e) : 64;
-    /* groups: low, mixed, high (EXCHANGE pairs), then generic */
-    lsk_lin_group *lg = (lsk_lin_group *)calloc(n > 0 ? n : 1, sizeof(lsk_lin_group));
-    int cnt[4] = {0, 0, 0, 0}, k = 0;
-    for (int pass = 0; pass < 4; ++pass)
-        for (int g = 0; g < n; ++g) {
-            lsk_group const *G = &ext->groups[g];
-            int cls = 3;
-            if (G->fast == LSK_GROUP_EXCHANGE && __builtin_popcountll(G->x) == 2 && G->v_im == 0.0)
-                cls = (G->x & ~LM) == 0 ? 0 : (G->x & LM) == 0 ? 2 : 1;
-            if (cls != pass) continue;
-            lg[k].xlo = (uint32_t)(G->x & LM);
-            lg[k].xhi = (uint32_t)(G->x >> B);
-            lg[k].v = G->v_re;
-            lg[k].g = g;
-            lg[k].pad = nt_lo < 64 && (__builtin_ctzll(G->x) >= nt_lo || G->adj < 0); /* far pair: streaming gathers */
-            ++k;
-            ++cnt[pass];
-        }
-    int const wide = L > 32;
-    size_t const nh = (size_t)1 << hb, es = wide ? 8 : 4;
-    uint16_t *tlo = (uint16_t *)malloc(sizeof(uint16_t) << B);
-    void *thi = malloc(nh * es);
-    lin_tables_host(hw, B, hb, wide, tlo, thi);
-    int rc = upload(&pl->lin_alloc[0], lg, sizeof(lsk_lin_group) * (n > 0 ? n : 1)) ||
-             upload(&pl->lin_alloc[1], tlo, sizeof(uint16_t) << B) || upload(&pl->lin_alloc[2], thi, nh * es);
-    free(lg); free(tlo); free(thi);
-    if (rc) return -1;
-    pl->lin.bits = B;
-    pl->lin.n_low = cnt[0]; pl->lin.n_mixed = cnt[1]; pl->lin.n_high = cnt[2]; pl->lin.n_generic = cnt[3];
-    pl->lin.groups = (lsk_lin_group const *)pl->lin_alloc[0];
-    pl->lin.tlo = (uint16_t const *)pl->lin_alloc[1];
-    pl->lin.thi = pl->lin_alloc[2];
-    pl->has_lin = 1;
-    return 0;
-}
-
-/* Staged row kernel (k_chain, lsk.h): f64 pull, <= 32 sites, the full fixed-weight basis without symmetries, a real
- * operator made of exchange runs plus at most two other exchange pairs.  LS_AMD_CHAIN=0 keeps k_direct. */
+/* Staged row kernel (k_chain_t, lsk.h): pull, f64 or c128 vectors, <= 64 sites, the full fixed-weight basis without
+ * symmetries, a real operator made of exchange runs plus at most two other exchange pairs.  LS_AMD_CHAIN=0 keeps k_direct. */
 static int chain_eligible(ls_amd_plan const *pl) {
     ls_hs_operator const *op = pl->op;
     struct ls_amd_operator_ext const *ext = op->ext;
     char const *e = getenv("LS_AMD_CHAIN");
     if (e && atoi(e) == 0) return 0;
-    if (getenv("LS_AMD_HIGH_BITS") || (getenv("LS_AMD_LIN") && atoi(getenv("LS_AMD_LIN")) != 0)) return 0;
-    if (pl->cplx || op->basis->number_sites > 32 || op->basis->spin_inversion != 0 || pl->dbs.proj != LSK_PROJ_NONE ||
+    if (op->basis->number_sites > 64 || op->basis->spin_inversion != 0 || pl->dbs.proj != LSK_PROJ_NONE ||
         !ext->is_real || !ext->is_hermitian || ext->runs.n_runs <= 0 || ext->n_diag <= 0)
         return 0;
     if (ext->n_groups - ext->runs.n_run_groups > 2) return 0;
@@ -1355,15 +1086,20 @@ static int chain_eligible(ls_amd_plan const *pl) {
 static int setup_chain(ls_amd_plan *pl, lsk_index index, int64_t n, uint64_t const *d_reps, void *stream) {
     struct ls_amd_operator_ext const *ext = pl->op->ext;
     int const nc = ext->n_groups - ext->runs.n_run_groups;
+    /* ranks are 32-bit while the whole basis (index.count states: x is indexed by global rank) has < 2^32 - 1 states;
+     * LS_AMD_CHAIN_WIDE=1 forces the 64-bit instantiation (test hook: no in-tree config is that large) */
+    char const *ew = getenv("LS_AMD_CHAIN_WIDE");
+    pl->chain_wide = index.count >= 0xffffffffLL || (ew && atoi(ew) != 0 && pl->op->basis->number_sites > 32);
+    size_t const es = pl->chain_wide ? sizeof(uint64_t) : sizeof(uint32_t);
     if (nc > 0 && n > 0) {
         void *q;
-        if (lsk_malloc(&q, sizeof(uint32_t) * (size_t)nc * (size_t)n) != 0) return 0; /* no room for the cache: k_direct */
-        pl->d_chain_cache = (uint32_t *)q;
+        if (lsk_malloc(&q, es * (size_t)nc * (size_t)n) != 0) return 0; /* no room for the cache: k_direct */
+        pl->d_chain_cache = q;
         int zero = 0, flag = 0;
         DEV(lsk_h2d(pl->d_err, &zero, sizeof(int)));
         for (int c = 0; c < nc; ++c)
             DEV(lsk_chain_cache(pl->dbs, index, n, d_reps, ext->groups[ext->runs.n_run_groups + c].x,
-                                pl->d_chain_cache + (size_t)c * (size_t)n, pl->d_err, stream));
+                                (char *)pl->d_chain_cache + es * (size_t)c * (size_t)n, pl->chain_wide, pl->d_err, stream));
         DEV(lsk_sync(stream));
         DEV(lsk_d2h(&flag, pl->d_err, sizeof(int)));
         DEV(lsk_h2d(pl->d_err, &zero, sizeof(int)));
@@ -1376,12 +1112,7 @@ static int setup_chain(ls_amd_plan *pl, lsk_index index, int64_t n, uint64_t con
         pl->chain_v[0] = ext->groups[ext->runs.n_run_groups].v_re;
         pl->chain_v[1] = nc > 1 ? ext->groups[ext->runs.n_run_groups + 1].v_re : 0.0;
     }
-    /* LS_AMD_TRANSPOSED=1 selects the set order of build_tilemap for this kernel too (per XCD, or chip-wide together
-     * with LS_AMD_TILE_CHUNK).  Modelled (scripts/tools/l2sim.c, mallsim.c), not yet measured; off by default.
-     * Replicated block rows (row offset) keep the default order. */
-    char const *et = getenv("LS_AMD_TRANSPOSED");
-    int const transposed = et && atoi(et) != 0 && pl->family == FAMILY_DIRECT_PULL;
-    if (build_tilemap(pl, n, transposed, 1024) != 0) return -1;
+    if (build_tilemap(pl, n, lsk_chain_tile_rows(pl->cplx)) != 0) return -1;
     pl->has_chain = 1;
     return 0;
 }
@@ -1554,19 +1285,7 @@ int ls_amd_plan_create(ls_amd_plan **out, ls_hs_operator const *op, ls_amd_dtype
         part_state *ps0 = &pl->parts[0];
         if (pl->family == FAMILY_DIRECT_PULL && combinadic && chain_eligible(pl) &&
             setup_chain(pl, ps0->index, ps0->count, ps0->d_reps, stream) != 0) { ls_amd_plan_destroy(pl); return -1; }
-        if (!pl->has_chain) {
-            char const *e = getenv("LS_AMD_TRANSPOSED"); /* transposed tile order: measured neutral on chain_32, off by default */
-            int const transposed = combinadic && pl->family == FAMILY_DIRECT_PULL && e && atoi(e) != 0;
-            if (build_tilemap(pl, ps0->count, transposed, 256) != 0) { ls_amd_plan_destroy(pl); return -1; }
-        }
-    }
-    if (pl->family == FAMILY_DIRECT_PULL && pl->parts[0].index.kind == LSK_INDEX_COMBINADIC) {
-        /* off by default: measured on chain_32 the two-pass scheme is slower (12.9 + 10.2 ms vs 15.7 ms);
-         * kept as an option because it bounds the far-bond traffic for longer chains */
-        char const *e = getenv("LS_AMD_HIGH_BITS");
-        int t = e ? atoi(e) : 0;
-        if (t > 0 && setup_highpart(pl, t) != 0) { ls_amd_plan_destroy(pl); return -1; }
-        if (!pl->has_highpart && setup_lin(pl) != 0) { ls_amd_plan_destroy(pl); return -1; }
+        if (!pl->has_chain && build_tilemap(pl, ps0->count, 256) != 0) { ls_amd_plan_destroy(pl); return -1; }
     }
     if (pl->family == FAMILY_TILE && my_partition < 0 && pl->send_capacity > 0) {
         if (lsk_malloc(&pl->d_send, (size_t)pl->send_capacity) != 0) { ls_amd_plan_destroy(pl); return dev_error(); }
@@ -1591,8 +1310,6 @@ void ls_amd_plan_destroy(ls_amd_plan *pl) {
     if (pl->d_gtable) lsk_free(pl->d_gtable);
     if (pl->d_row_gidx) lsk_free(pl->d_row_gidx);
     if (pl->d_norms_global) lsk_free(pl->d_norms_global);
-    for (int i = 0; i < 7; ++i) if (pl->hp_alloc[i]) lsk_free(pl->hp_alloc[i]);
-    for (int i = 0; i < 3; ++i) if (pl->lin_alloc[i]) lsk_free(pl->lin_alloc[i]);
     if (pl->d_tilemap) lsk_free(pl->d_tilemap);
     if (pl->d_chain_cache) lsk_free(pl->d_chain_cache);
     if (pl->d_htab) lsk_free(pl->d_htab);
@@ -1664,15 +1381,11 @@ int ls_amd_plan_create_replicated(ls_amd_plan **out, ls_hs_operator const *op, l
         /* rows that are a contiguous block [row0, row0 + count_local) of the global basis (what ReplicatedOperator
          * hands over: a slice of the global array) can take the staged kernel */
         int const contiguous = d_reps_local >= d_reps_global && d_reps_local + count_local <= d_reps_global + count_global;
-        if (contiguous && pl->gindex.kind == LSK_INDEX_COMBINADIC && count_global < 0xffffffffLL && chain_eligible(pl)) {
+        if (contiguous && pl->gindex.kind == LSK_INDEX_COMBINADIC && chain_eligible(pl)) {
             pl->chain_row0 = (int64_t)(d_reps_local - d_reps_global);
             if (setup_chain(pl, pl->gindex, count_local, d_reps_local, stream) != 0) { ls_amd_plan_destroy(pl); return -1; }
         }
-        if (!pl->has_chain && build_tilemap(pl, count_local, 0, 256) != 0) { ls_amd_plan_destroy(pl); return -1; }
-    }
-    if (pl->family == FAMILY_REPL_DIRECT && pl->gindex.kind == LSK_INDEX_COMBINADIC && setup_lin(pl) != 0) {
-        ls_amd_plan_destroy(pl);
-        return -1;
+        if (!pl->has_chain && build_tilemap(pl, count_local, 256) != 0) { ls_amd_plan_destroy(pl); return -1; }
     }
     if (pl->gindex.kind == LSK_INDEX_SEARCH && count_local > 0) {
         if (lsk_malloc(&p, 8 * (size_t)count_local) != 0) { ls_amd_plan_destroy(pl); return dev_error(); }
@@ -1700,13 +1413,11 @@ int ls_amd_matvec_replicated(ls_amd_plan *pl, void const *d_x_global, void *d_y_
     if (pl->family == FAMILY_REPL_DIRECT) {
         slot = timing_begin(pl, stream);
         if (pl->has_chain)
-            DEV(lsk_chain(pl->dop, pl->dbs, pl->gindex, pl->tilemap, ps->count, ps->d_reps, pl->chain_row0, pl->gindex.count,
-                          d_x_global, d_y_local, pl->chain_cached, pl->d_chain_cache, pl->chain_v[0], pl->chain_v[1], stream));
-        else if (pl->has_lin)
-            DEV(lsk_lin_pull(pl->lin, pl->dop, pl->dbs, pl->cplx, 1, ps->count, ps->d_reps, d_x_global, d_y_local,
-                             pl->d_err, stream));
+            DEV(lsk_chain(pl->dop, pl->dbs, pl->gindex, pl->cplx, pl->chain_wide, pl->tilemap, ps->count, ps->d_reps,
+                          pl->chain_row0, pl->gindex.count, d_x_global, d_y_local, pl->chain_cached, pl->d_chain_cache,
+                          pl->chain_v[0], pl->chain_v[1], stream));
         else
-        DEV(lsk_direct_gx(pl->dop, pl->dbs, pl->gindex, pl->cplx, pl->tilemap, ps->d_reps, pl->d_row_gidx, d_x_global,
+            DEV(lsk_direct_gx(pl->dop, pl->dbs, pl->gindex, pl->cplx, pl->tilemap, ps->d_reps, pl->d_row_gidx, d_x_global,
                           d_y_local, pl->d_err, stream));
         timing_end(pl, slot, stream);
         return 0;
@@ -1726,10 +1437,10 @@ char const *ls_amd_plan_kernel_name(ls_amd_plan const *pl) {
     switch (pl->family) {
     case FAMILY_DIRECT_PUSH: return "direct-push";
     case FAMILY_DIRECT_PULL:
-        return pl->has_chain ? "direct-pull+staged" : pl->has_highpart ? "direct-pull+highpart" : pl->has_lin ? "direct-pull+lin" : "direct-pull";
+        return pl->has_chain ? "direct-pull+staged" : "direct-pull";
     case FAMILY_TILE_PULL: return "tile-pull";
     case FAMILY_REPL_DIRECT:
-        return pl->has_chain ? "replicated-direct-pull+staged" : pl->has_lin ? "replicated-direct-pull+lin" : "replicated-direct-pull";
+        return pl->has_chain ? "replicated-direct-pull+staged" : "replicated-direct-pull";
     case FAMILY_REPL_TILE: return "replicated-tile-pull";
     default: return "tile";
     }
@@ -1818,15 +1529,12 @@ int ls_amd_matvec(ls_amd_plan *pl, void const *const *d_x, void *const *d_y, voi
         part_state *ps = &pl->parts[0];
         int slot = timing_begin(pl, stream);
         if (pl->has_chain)
-            DEV(lsk_chain(pl->dop, pl->dbs, ps->index, pl->tilemap, ps->count, ps->d_reps, 0, ps->count, d_x[0], d_y[0],
-                          pl->chain_cached, pl->d_chain_cache, pl->chain_v[0], pl->chain_v[1], stream));
-        else if (pl->has_lin)
-            DEV(lsk_lin_pull(pl->lin, pl->dop, pl->dbs, pl->cplx, 0, ps->count, ps->d_reps, d_x[0], d_y[0], pl->d_err,
-                             stream));
+            DEV(lsk_chain(pl->dop, pl->dbs, ps->index, pl->cplx, pl->chain_wide, pl->tilemap, ps->count, ps->d_reps, 0,
+                          ps->count, d_x[0], d_y[0], pl->chain_cached, pl->d_chain_cache, pl->chain_v[0], pl->chain_v[1],
+                          stream));
         else
-        DEV(lsk_direct(pl->has_highpart ? pl->dop_low : pl->dop, pl->dbs, ps->index, pl->cplx,
-                       pl->family == FAMILY_DIRECT_PULL, pl->tilemap, ps->d_reps, d_x[0], d_y[0], pl->d_err, stream));
-        if (pl->has_highpart) DEV(lsk_highpart_apply(pl->hp, pl->cplx, d_x[0], d_y[0], stream));
+            DEV(lsk_direct(pl->dop, pl->dbs, ps->index, pl->cplx, pl->family == FAMILY_DIRECT_PULL, pl->tilemap, ps->d_reps,
+                           d_x[0], d_y[0], pl->d_err, stream));
         timing_end(pl, slot, stream);
         return 0;
     }

@@ -795,15 +795,6 @@ static int high_pair_setting(int dflt) {
     return v;
 }
 
-// log2 of the number of consecutive row tiles dealt to one XCD before moving to the next XCD
-// (LS_AMD_XCD_CHUNK; 0 = each XCD gets one contiguous eighth of the rows)
-static int xcd_chunk_setting() {
-    char const *e = getenv("LS_AMD_XCD_CHUNK");
-    int v = e ? atoi(e) : 0;
-    if (v < 0 || v > 24) v = 0;
-    return v;
-}
-
 template <typename W, bool CPLX, int INDEX, bool INV, bool PULL>
 static int launch_direct3(lsk_operator op, lsk_basis bs, lsk_index ix, lsk_tilemap tm, uint64_t const *reps,
                           void const *x, void *y, int *d_err, void *stream, int gx, int64_t const *row_gidx) {
@@ -880,124 +871,202 @@ extern "C" int lsk_direct_gx(lsk_operator op, lsk_basis bs, lsk_index ix, int cp
 }
 
 // ---------------------------------------------------------------------------------------------
-// Staged row kernel for chain-like operators: f64 pull, 32-bit states, the full fixed-Hamming-weight
-// basis (row i = i-th state), exchange runs of adjacent pairs plus at most two other exchange pairs
-// whose partner ranks the plan caches (anything else stays with k_direct).
+// Staged row kernel for chain-like operators (pull): the full fixed-Hamming-weight basis (row i = i-th state), exchange
+// runs of adjacent pairs plus at most two other exchange pairs whose partner ranks the plan caches (anything else stays
+// with k_direct).
 //
-// The row kernel above is bound by the vector-memory address unit (TA busy > 80 %: every gather is a
-// wave instruction whatever it hits).  An adjacent pair (lo, lo + 1) moves a state by C(lo, k) <= C(11, 5)
-// = 462 ranks when lo < 12, so those twelve gathers stay inside a window of the block's own rows +- 512:
-// the block loads the window into LDS once (coalesced 16-byte loads -- the price of the old own-x load)
-// and reads the near partners from LDS.  Pairs 12 .. hb-1 gather from global memory as before; pairs
-// >= hb take the wave-uniform path of k_direct.
+// The generic row kernel above is bound by the vector-memory address unit (TA busy > 80 %: every gather is a wave
+// instruction whatever it hits).  An adjacent pair (lo, lo + 1) moves a state by C(lo, k) <= C(11, 5) = 462 ranks when
+// lo < 12, so those twelve gathers stay inside a window of the block's own rows +- 512: the block loads the window into
+// LDS once (coalesced 16-byte loads -- the price of the old own-x load) and reads the near partners from LDS.  Pairs
+// >= 12: the 64 consecutive states of a wave agree on every bit >= 12 in 92 % of the waves, so the anti-alignment test,
+// the bit count below the pair and the rank shift are the same for the whole wave: an aligned far pair issues nothing,
+// an anti-aligned one costs add + address + fma.  Waves that straddle two high parts take the per-lane loop.
+// Measured on chain_32 f64 (gpurun_out/r2/ablate_sweep.log, pairs dropped from the top): streaming part 2.85 ms, the 12
+// LDS pairs +2.2 ms, pairs 12..19 +1.25 ms (mostly L2 hits), pairs 20..30 +3.1-3.75 ms (every gather misses the L2:
+// 27 GB at the fabric rate), the cached ring-closing pair +1.0-1.6 ms.
 // ---------------------------------------------------------------------------------------------
-constexpr int kChainTile = 1024;  // rows per tile (4 per thread)
-constexpr int kChainHalo = 512;   // >= C(11, 5)
+constexpr int kChainHalo = 512;    // >= C(11, 5)
 constexpr int kChainLdsPairs = 12; // pairs lo < 12 are served from the LDS window
-constexpr int kChainWindow = kChainTile + 2 * kChainHalo + 2; // +2: the window starts on an even row
-constexpr int kChainFar = 8;      // far-pair gathers in flight per row before the first wait
+constexpr int kChainFar = 8;       // far-pair gathers in flight per row before the first wait
 
-__global__ __launch_bounds__(kBlock) void k_chain(lsk_runs runs, int n_diag,
-                                                  lsk_term const *__restrict__ diag, int hamming_weight,
-                                                  uint64_t const *__restrict__ g_binom,
-                                                  uint64_t const *__restrict__ tilemap, int64_t slots_per_xcd,
-                                                  int64_t n, uint64_t const *__restrict__ reps,
-                                                  double const *__restrict__ x, double *__restrict__ y,
-                                                  int hb, int n_cached, uint32_t const *__restrict__ cache,
-                                                  double cv0, double cv1, uint32_t row0, int64_t n_x) {
-    __shared__ uint32_t s_binom[32 * LSK_BINOM_K]; // states have <= 32 bits
-    __shared__ double s_x[kChainWindow + 1]; // last slot: 0.0, read by the lanes whose pair is aligned
-    for (int k = threadIdx.x; k < 32 * LSK_BINOM_K; k += blockDim.x) s_binom[k] = (uint32_t)g_binom[k];
-    if (threadIdx.x == 0) s_x[kChainWindow] = 0.0;
+// W = state word (u32 up to 32 sites, u64 up to 64), R = rank type (u32 while the basis has < 2^32 - 1 states, else u64),
+// CPLX = complex128 vectors (real operator; the window holds double2, gathers are 16 bytes per lane), TILE rows per
+// block iteration (1024 for f64, 512 for c128: 5 blocks per CU).
+// Far pairs (>= hb) of a wave-row are priced lane-parallel: lane l looks at pair split + l of the wave-uniform state a0
+// (anti-aligned?, bits below, binomial from LDS, sign), and the loop over the anti-aligned ones only does ballot-mask
+// ctz + v_readlane + add + gather.  (The round-1 kernel did that arithmetic on the scalar unit, ~340 scalar
+// instructions per 64 rows; moving it to the vector lanes changed nothing measurable: 10.70 vs 10.71 ms.)
+template <typename W, typename R> struct ChainTraits;
+template <> struct ChainTraits<uint32_t, uint32_t> { static constexpr int NB = 32; };
+template <> struct ChainTraits<uint64_t, uint32_t> { static constexpr int NB = 64; };
+template <> struct ChainTraits<uint64_t, uint64_t> { static constexpr int NB = 64; };
+
+template <typename T> __device__ __forceinline__ T readlane_t(T v, int lane);
+template <> __device__ __forceinline__ uint32_t readlane_t<uint32_t>(uint32_t v, int lane) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, lane);
+}
+template <> __device__ __forceinline__ uint64_t readlane_t<uint64_t>(uint64_t v, int lane) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, lane);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), lane);
+    return ((uint64_t)hi << 32) | lo;
+}
+template <typename T> __device__ __forceinline__ T readfirstlane_t(T v);
+template <> __device__ __forceinline__ uint32_t readfirstlane_t<uint32_t>(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+template <> __device__ __forceinline__ uint64_t readfirstlane_t<uint64_t>(uint64_t v) {
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+
+template <bool CPLX> struct ChainX { typedef double type; };
+template <> struct ChainX<true> { typedef double2 type; };
+__device__ __forceinline__ void cx_fma(double c, double v, double &acc) { acc = fma(c, v, acc); }
+__device__ __forceinline__ void cx_fma(double c, double2 v, double2 &acc) { acc.x = fma(c, v.x, acc.x); acc.y = fma(c, v.y, acc.y); }
+__device__ __forceinline__ double cx_scale(double c, double v) { return c * v; }
+__device__ __forceinline__ double2 cx_scale(double c, double2 v) { return make_double2(c * v.x, c * v.y); }
+template <typename X> __device__ __forceinline__ X cx_zero();
+template <> __device__ __forceinline__ double cx_zero<double>() { return 0.0; }
+template <> __device__ __forceinline__ double2 cx_zero<double2>() { return make_double2(0.0, 0.0); }
+__device__ __forceinline__ void cx_store_nt(double *p, double v) { __builtin_nontemporal_store(v, p); }
+__device__ __forceinline__ void cx_store_nt(double2 *p, double2 v) {
+    __builtin_nontemporal_store(v.x, &p->x);
+    __builtin_nontemporal_store(v.y, &p->y);
+}
+
+constexpr int kChainFarC = 6; // complex: 6 x 16 bytes in flight per lane
+
+// launch bounds, second argument = waves per SIMD the register allocation must allow.  256-thread blocks are admitted per CU
+// up to floor(800 / (ceil(sgpr / 16) * 16 + 16)): at 98 SGPRs the 7th block does not fit while the occupancy API still
+// answers 7 -- a straggler round of blocks, measured +24 % (13.1 vs 10.7 ms on chain_32)
+template <typename W, typename R, bool CPLX, int TILE>
+__global__ __launch_bounds__(kBlock, (CPLX ? 4 : 8)) void k_chain_t(lsk_runs runs, int n_diag, lsk_term const *__restrict__ diag,
+                                                    int hamming_weight, uint64_t const *__restrict__ g_binom,
+                                                    uint64_t const *__restrict__ tilemap, int64_t slots_per_xcd, int64_t n,
+                                                    uint64_t const *__restrict__ reps, void const *__restrict__ x_v,
+                                                    void *__restrict__ y_v, int hb, int n_cached,
+                                                    R const *__restrict__ cache, double cv0, double cv1, int64_t row0,
+                                                    int64_t n_x) {
+    typedef typename ChainX<CPLX>::type X;
+    typedef WordTraits<W> WT;
+    constexpr int NB = ChainTraits<W, R>::NB;
+    constexpr int WINDOW = TILE + 2 * kChainHalo + 2;
+    constexpr int FAR = CPLX ? kChainFarC : kChainFar;
+    constexpr R kNone = ~(R)0;
+    X const *__restrict__ x = (X const *)x_v;
+    X *__restrict__ y = (X *)y_v;
+    __shared__ R s_binom[NB * LSK_BINOM_K];
+    __shared__ X s_x[WINDOW + 1]; // last slot: 0, read by the lanes whose near pair is aligned
+    for (int k = threadIdx.x; k < NB * LSK_BINOM_K; k += blockDim.x) s_binom[k] = (R)g_binom[k];
+    if (threadIdx.x == 0) s_x[WINDOW] = cx_zero<X>();
     const int xcd = blockIdx.x & 7;
     const int64_t blocks_per_xcd = gridDim.x >> 3;
+    const int lane = threadIdx.x & 63;
     tilemap += (int64_t)xcd * slots_per_xcd;
-    // states have <= 32 bits: only the low word of every 64-bit state is loaded (one VGPR, so the
-    // prefetch below is not cut short by a wait on the unused high word)
     uint32_t const *__restrict__ reps32 = reinterpret_cast<uint32_t const *>(reps);
     for (int64_t t = blockIdx.x >> 3; t < slots_per_xcd; t += blocks_per_xcd) {
         const uint64_t slot = tilemap[t];
         const int cnt = (int)(slot >> 48);
         if (cnt == 0) continue; // block-uniform
         const int64_t i0 = (int64_t)(slot & 0xffffffffffffULL);
-        // rows are local (reps, cache, y); x is indexed by the global rank = row0 + local row
-        const int64_t w0 = ((int64_t)row0 + i0 - kChainHalo) & ~(int64_t)1; // first row of the window (even; may be < 0)
-        uint32_t a_next = 0, t0_next = 0xffffffffu, t1_next = 0xffffffffu;
-        if ((int)threadIdx.x < cnt) { // first row of this thread: requested before the window is staged
-            a_next = __builtin_nontemporal_load(reps32 + 2 * (i0 + threadIdx.x));
-            if (n_cached > 0) t0_next = __builtin_nontemporal_load(cache + i0 + threadIdx.x);
-            if (n_cached > 1) t1_next = __builtin_nontemporal_load(cache + (size_t)n + (size_t)(i0 + threadIdx.x));
+        const int64_t w0 = (row0 + i0 - kChainHalo) & ~(int64_t)1; // first row of the window (even; may be < 0)
+        W a_next = 0;
+        R t0_next = kNone, t1_next = kNone;
+        auto load_state = [&](int64_t row) -> W {
+            if (sizeof(W) == 4) return (W)__builtin_nontemporal_load(reps32 + 2 * row); // low word only
+            return (W)__builtin_nontemporal_load(reps + row);
+        };
+        // Lanes past the end of a partial tile stay ACTIVE as ghosts of the tile's last row (they recompute it and
+        // store nothing): the far pairs are priced lane-parallel, which needs every lane of a live wave.
+        const int wave0 = (int)(threadIdx.x & ~63u);
+        if (wave0 < cnt) { // first row of this thread: requested before the window is staged
+            const int64_t rr = i0 + ((int)threadIdx.x < cnt ? (int)threadIdx.x : cnt - 1);
+            a_next = load_state(rr);
+            if (n_cached > 0) t0_next = __builtin_nontemporal_load(cache + rr);
+            if (n_cached > 1) t1_next = __builtin_nontemporal_load(cache + (size_t)n + (size_t)rr);
         }
         __syncthreads(); // every wave is done with the previous window (and s_binom is loaded)
-        for (int j = 2 * threadIdx.x; j < kChainWindow; j += 2 * kBlock) {
-            const int64_t row = w0 + j;
-            double2 v;
-            if (row >= 0 && row + 1 < n_x) v = *reinterpret_cast<double2 const *>(x + row);
-            else { v.x = (row >= 0 && row < n_x) ? x[row] : 0.0; v.y = (row + 1 >= 0 && row + 1 < n_x) ? x[row + 1] : 0.0; }
-            s_x[j] = v.x;
-            s_x[j + 1] = v.y;
+        if (CPLX) {
+            for (int j = threadIdx.x; j < WINDOW; j += kBlock) {
+                const int64_t row = w0 + j;
+                s_x[j] = (row >= 0 && row < n_x) ? x[row] : cx_zero<X>();
+            }
+        } else {
+            double const *xd = (double const *)x_v;
+            double *sd = (double *)s_x;
+            for (int j = 2 * threadIdx.x; j < WINDOW; j += 2 * kBlock) {
+                const int64_t row = w0 + j;
+                double2 v;
+                if (row >= 0 && row + 1 < n_x) v = *reinterpret_cast<double2 const *>(xd + row);
+                else { v.x = (row >= 0 && row < n_x) ? xd[row] : 0.0; v.y = (row + 1 >= 0 && row + 1 < n_x) ? xd[row + 1] : 0.0; }
+                sd[j] = v.x;
+                sd[j + 1] = v.y;
+            }
         }
         __syncthreads();
-        const int own0 = (int)((int64_t)row0 + i0 - w0);
-        // y of a row is stored one iteration late: the wait for the prefetched state at the end of an iteration
-        // (vmcnt counts loads and stores in order) then never waits for a store that was only just issued
-        double y_pending = 0.0;
+        const int own0 = (int)(row0 + i0 - w0);
+        X y_pending = cx_zero<X>(); // stored one iteration late (see k_chain)
         int64_t i_pending = -1;
 #pragma unroll 1
-        for (int sub = 0; sub < kChainTile / kBlock; ++sub) {
+        for (int sub = 0; sub < TILE / kBlock; ++sub) {
             const int r = sub * kBlock + threadIdx.x;
-            if (i_pending >= 0) __builtin_nontemporal_store(y_pending, y + i_pending);
+            if (i_pending >= 0) cx_store_nt(y + i_pending, y_pending);
             i_pending = -1;
-            // this row's state and cached partner ranks were requested one iteration ago; request the next row's
-            const uint32_t a = a_next, t0 = t0_next, t1 = t1_next;
-            if (sub + 1 < kChainTile / kBlock && r + kBlock < cnt) {
-                const int64_t in = i0 + r + kBlock;
-                a_next = __builtin_nontemporal_load(reps32 + 2 * in);
+            const W a = a_next;
+            const R t0 = t0_next, t1 = t1_next;
+            if (sub + 1 < TILE / kBlock && (sub + 1) * kBlock + wave0 < cnt) {
+                const int64_t in = i0 + (r + kBlock < cnt ? r + kBlock : cnt - 1);
+                a_next = load_state(in);
                 if (n_cached > 0) t0_next = __builtin_nontemporal_load(cache + in);
                 if (n_cached > 1) t1_next = __builtin_nontemporal_load(cache + (size_t)n + (size_t)in);
             }
-            if (r >= cnt) continue;
-            const int64_t i = i0 + r;
-            const uint32_t i32 = row0 + (uint32_t)i;
-            // ring-closing pairs (partner rank has no closed form: cached per plan, lsk_chain_cache): gathers
-            // issued now, consumed at the end
-            const double g0 = n_cached > 0 ? x[t0 != 0xffffffffu ? t0 : i32] : 0.0;
-            const double g1 = n_cached > 1 ? x[t1 != 0xffffffffu ? t1 : i32] : 0.0;
-            const int jr = own0 + r;
-            const double xr = s_x[jr];
-            // (operators without diagonal terms accumulate into y, DMV:1062-1063: they stay with k_direct, so that
-            //  nothing here depends on a global load before the far gathers are consumed)
+            if (sub * kBlock + wave0 >= cnt) continue; // wave-uniform: the whole wave is past the end
+            const bool ghost = r >= cnt;
+            const int64_t i = i0 + (ghost ? cnt - 1 : r);
+            const R ig = (R)(row0 + i);
+            X g0 = cx_zero<X>(), g1 = cx_zero<X>();
+            if (n_cached > 0) g0 = x[t0 != kNone ? t0 : ig];
+            if (n_cached > 1) g1 = x[t1 != kNone ? t1 : ig];
+            const int jr = own0 + (int)(i - i0);
+            const X xr = s_x[jr];
             double dr, di;
-            diag_coeff<uint32_t, true>(runs, n_diag, diag, a, dr, di);
-            double accr = dr * xr;
-            const uint32_t tdiff = a ^ (a >> 1);
+            diag_coeff<W, true>(runs, n_diag, diag, a, dr, di);
+            X acc = cx_scale(dr, xr);
+            const W tdiff = a ^ (a >> 1);
             for (int q = 0; q < runs.n_runs; ++q) {
                 const int lo0 = runs.lo0[q];
                 int lo_end = lo0 + runs.cnt[q];
                 const double vr = runs.v_re[q];
-                int k = __popc(a & (uint32_t)(((uint64_t)1 << lo0) - 1));
+                int k = WT::popc(a & (W)(((uint64_t)1 << lo0) - 1));
                 int lo = lo0;
                 const int e1 = lo_end < kChainLdsPairs ? lo_end : kChainLdsPairs;
-                // ---- far pairs, wave-uniform (see k_direct): up to kChainFar gathers are issued before the near
-                //      pairs are served from LDS, so their latency overlaps that work --------------------------
                 const int near_end = lo0 > e1 ? lo0 : e1;
                 const int split = hb == 0 ? lo_end : (hb < near_end ? near_end : (hb > lo_end ? lo_end : hb));
-                const uint32_t a0 = __builtin_amdgcn_readfirstlane(a);
+                // ---- far pairs of a wave whose 64 states agree on every bit >= split ------------------------------
+                const W a0 = readfirstlane_t<W>(a);
                 const bool uni = split < lo_end && __builtin_amdgcn_ballot_w64(((a ^ a0) >> split) != 0) == 0;
-                uint32_t m = 0;
-                double xv[kChainFar];
+                unsigned long long m = 0;
+                R off = 0;
+                X xv[FAR];
 #pragma unroll
-                for (int u = 0; u < kChainFar; ++u) xv[u] = 0.0;
+                for (int u = 0; u < FAR; ++u) xv[u] = cx_zero<X>();
                 if (uni) {
-                    m = (a0 ^ (a0 >> 1)) & (uint32_t)((((uint64_t)1 << lo_end) - 1) & ~(((uint64_t)1 << split) - 1));
+                    // lane l prices pair p = split + l of the common state
+                    const int p = split + lane;
+                    const bool in_run = p < lo_end;
+                    const int ps = in_run ? p : 0;
+                    const W hi = a0 >> ps;
+                    const bool bit = hi & 1;
+                    const bool act = in_run && (((hi >> 1) & 1) != (W)bit);
+                    const int kk = hamming_weight - WT::popc(hi); // set bits below p
+                    const R d = s_binom[ps * LSK_BINOM_K + (kk < 0 ? 0 : kk)];
+                    off = bit ? d : (R)(0 - d);
+                    m = __builtin_amdgcn_ballot_w64(act);
 #pragma unroll
-                    for (int u = 0; u < kChainFar; ++u) {
+                    for (int u = 0; u < FAR; ++u) {
                         if (m) {
-                            const int p = __builtin_ctz(m);
+                            const int l = __builtin_ctzll(m);
                             m &= m - 1;
-                            const int kk = hamming_weight - __popc(a0 >> p); // set bits below p
-                            const uint32_t d = s_binom[p * LSK_BINOM_K + kk];
-                            xv[u] = x[((a0 >> p) & 1) ? i32 + d : i32 - d];
+                            xv[u] = x[(R)(ig + readlane_t<R>(off, l))];
                         }
                     }
                     lo_end = split;
@@ -1010,82 +1079,88 @@ __global__ __launch_bounds__(kBlock) void k_chain(lsk_runs runs, int n_diag,
                     const int d = (int)s_binom[lo * LSK_BINOM_K + k];
                     k += bit ? 1 : 0;
                     const int j = bit ? jr + d : jr - d;
-                    accr = fma(vr, s_x[act ? j : kChainWindow], accr);
+                    cx_fma(vr, s_x[act ? j : WINDOW], acc);
                 }
 #pragma unroll
-                for (int u = 0; u < kChainFar; ++u) accr = fma(vr, xv[u], accr);
-                while (m) { // more than kChainFar anti-aligned far pairs
-                    double xw[4];
+                for (int u = 0; u < FAR; ++u) cx_fma(vr, xv[u], acc);
+                while (m) { // more than FAR anti-aligned far pairs
+                    X xw[4];
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        xw[u] = 0.0;
+                        xw[u] = cx_zero<X>();
                         if (m) {
-                            const int p = __builtin_ctz(m);
+                            const int l = __builtin_ctzll(m);
                             m &= m - 1;
-                            const int kk = hamming_weight - __popc(a0 >> p);
-                            const uint32_t d = s_binom[p * LSK_BINOM_K + kk];
-                            xw[u] = x[((a0 >> p) & 1) ? i32 + d : i32 - d];
+                            xw[u] = x[(R)(ig + readlane_t<R>(off, l))];
                         }
                     }
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) accr = fma(vr, xw[u], accr);
+                    for (int u = 0; u < 4; ++u) cx_fma(vr, xw[u], acc);
                 }
                 // ---- middle pairs (and far pairs of a wave that straddles two high parts) --------------
 #pragma unroll 4
                 for (; lo < lo_end; ++lo) {
                     const bool bit = (a >> lo) & 1;
                     const bool act = (tdiff >> lo) & 1;
-                    const uint32_t d = s_binom[lo * LSK_BINOM_K + k];
+                    const R d = s_binom[lo * LSK_BINOM_K + k];
                     k += bit ? 1 : 0;
-                    uint32_t idx = bit ? i32 + d : i32 - d;
-                    idx = act ? idx : i32;
-                    accr = fma(act ? vr : 0.0, x[idx], accr);
+                    R idx = bit ? (R)(ig + d) : (R)(ig - d);
+                    idx = act ? idx : ig;
+                    cx_fma(act ? vr : 0.0, x[idx], acc);
                 }
             }
-            accr = fma(t0 != 0xffffffffu ? cv0 : 0.0, g0, accr);
-            accr = fma(t1 != 0xffffffffu ? cv1 : 0.0, g1, accr);
-            y_pending = accr;
-            i_pending = i;
+            cx_fma(t0 != kNone ? cv0 : 0.0, g0, acc);
+            cx_fma(t1 != kNone ? cv1 : 0.0, g1, acc);
+            y_pending = acc;
+            i_pending = ghost ? -1 : i;
         }
-        if (i_pending >= 0) __builtin_nontemporal_store(y_pending, y + i_pending);
+        if (i_pending >= 0) cx_store_nt(y + i_pending, y_pending);
     }
 }
 
 // cache[i] = rank of reps[i] ^ xmask when exactly one of the two bits of xmask is set in reps[i], else ~0;
 // *flag is raised when a partner falls outside the basis (the caller then does not use the cache, and
 // the generic path reports the error at run time as the reference does)
-__global__ __launch_bounds__(kBlock) void k_chain_cache(int64_t n, uint64_t const *__restrict__ reps, uint32_t xmask,
+template <typename W, typename R>
+__global__ __launch_bounds__(kBlock) void k_chain_cache(int64_t n, uint64_t const *__restrict__ reps, uint64_t xmask,
                                                         int hamming_weight, uint64_t const *__restrict__ g_binom,
-                                                        uint32_t *__restrict__ out, int *__restrict__ flag) {
-    __shared__ uint32_t s_binom[32 * LSK_BINOM_K];
-    for (int k = threadIdx.x; k < 32 * LSK_BINOM_K; k += blockDim.x) s_binom[k] = (uint32_t)g_binom[k];
+                                                        R *__restrict__ out, int *__restrict__ flag) {
+    constexpr int NB = ChainTraits<W, R>::NB;
+    __shared__ R s_binom[NB * LSK_BINOM_K];
+    for (int k = threadIdx.x; k < NB * LSK_BINOM_K; k += blockDim.x) s_binom[k] = (R)g_binom[k];
     __syncthreads();
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
-        const uint32_t a = (uint32_t)reps[i];
-        uint32_t t = 0xffffffffu;
-        if (__popc(a & xmask) == 1) {
-            const uint32_t beta = a ^ xmask;
-            if (__popc(beta) != hamming_weight) atomicExch(flag, 1);
-            else t = (uint32_t)rank_combinadic_w<uint32_t, uint32_t>(beta, s_binom);
+        const W a = (W)reps[i];
+        R t = ~(R)0;
+        if (WordTraits<W>::popc(a & (W)xmask) == 1) {
+            const W beta = a ^ (W)xmask;
+            if (WordTraits<W>::popc(beta) != hamming_weight) atomicExch(flag, 1);
+            else t = (R)rank_combinadic_w<W, R>(beta, s_binom);
         }
         out[i] = t;
     }
 }
-extern "C" int lsk_chain_cache(lsk_basis bs, lsk_index ix, int64_t n, uint64_t const *reps, uint64_t xmask, uint32_t *out,
-                               int *d_flag, void *stream) {
+extern "C" int lsk_chain_cache(lsk_basis bs, lsk_index ix, int64_t n, uint64_t const *reps, uint64_t xmask, void *out,
+                               int wide_ranks, int *d_flag, void *stream) {
     if (n == 0) return 0;
-    hipLaunchKernelGGL(k_chain_cache, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, n, reps, (uint32_t)xmask,
-                       bs.hamming_weight, ix.binom, out, d_flag);
+    dim3 g(grid_for(n)), b(kBlock);
+    hipStream_t s = (hipStream_t)stream;
+    if (bs.number_sites <= 32 && !wide_ranks)
+        hipLaunchKernelGGL((k_chain_cache<uint32_t, uint32_t>), g, b, 0, s, n, reps, xmask, bs.hamming_weight, ix.binom, (uint32_t *)out, d_flag);
+    else if (!wide_ranks)
+        hipLaunchKernelGGL((k_chain_cache<uint64_t, uint32_t>), g, b, 0, s, n, reps, xmask, bs.hamming_weight, ix.binom, (uint32_t *)out, d_flag);
+    else
+        hipLaunchKernelGGL((k_chain_cache<uint64_t, uint64_t>), g, b, 0, s, n, reps, xmask, bs.hamming_weight, ix.binom, (uint64_t *)out, d_flag);
     LSK_LAUNCH_CHECK();
     return 0;
 }
 
-extern "C" int lsk_chain(lsk_operator op, lsk_basis bs, lsk_index ix, lsk_tilemap tm, int64_t n, uint64_t const *reps,
-                         int64_t row0, int64_t n_x, void const *x, void *y, int n_cached, uint32_t const *cache,
-                         double cv0, double cv1, void *stream) {
-    if (n == 0 || tm.slots_per_xcd == 0) return 0;
+template <typename W, typename R, bool CPLX, int TILE>
+static int launch_chain(lsk_operator op, lsk_basis bs, lsk_index ix, lsk_tilemap tm, int64_t n, uint64_t const *reps,
+                        int64_t row0, int64_t n_x, void const *x, void *y, int n_cached, void const *cache, double cv0,
+                        double cv1, void *stream) {
     int64_t gb = tm.slots_per_xcd * 8;
-    int64_t cap = resident_grid(k_chain, gb);
+    int64_t cap = resident_grid(k_chain_t<W, R, CPLX, TILE>, gb);
     {
         char const *e = getenv("LS_AMD_BLOCKS_PER_CU"); // occupancy experiments
         int const bpc = e ? atoi(e) : 0;
@@ -1094,6 +1169,19 @@ extern "C" int lsk_chain(lsk_operator op, lsk_basis bs, lsk_index ix, lsk_tilema
     cap &= ~(int64_t)7;
     if (cap < 8) cap = 8;
     if (gb > cap) gb = cap;
+    hipLaunchKernelGGL((k_chain_t<W, R, CPLX, TILE>), dim3((unsigned)gb), dim3(kBlock), 0, (hipStream_t)stream, op.runs,
+                       op.n_diag, op.diag, bs.hamming_weight, ix.binom, tm.entries, tm.slots_per_xcd, n, reps, x, y,
+                       high_pair_setting(kChainLdsPairs), n_cached, (R const *)cache, cv0, cv1, row0, n_x);
+    LSK_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int lsk_chain_tile_rows(int cplx) { return cplx ? 512 : 1024; }
+
+extern "C" int lsk_chain(lsk_operator op, lsk_basis bs, lsk_index ix, int cplx, int wide_ranks, lsk_tilemap tm, int64_t n,
+                         uint64_t const *reps, int64_t row0, int64_t n_x, void const *x, void *y, int n_cached,
+                         void const *cache, double cv0, double cv1, void *stream) {
+    if (n == 0 || tm.slots_per_xcd == 0) return 0;
     {
         // profiling only (wrong results): drop every pair >= LS_AMD_CHAIN_MAXLO and the cached pairs, to price the
         // near / middle / far pairs separately
@@ -1108,268 +1196,12 @@ extern "C" int lsk_chain(lsk_operator op, lsk_basis bs, lsk_index ix, lsk_tilema
             n_cached = 0;
         }
     }
-    hipLaunchKernelGGL(k_chain, dim3((unsigned)gb), dim3(kBlock), 0, (hipStream_t)stream, op.runs, op.n_diag, op.diag,
-                       bs.hamming_weight, ix.binom, tm.entries, tm.slots_per_xcd, n, reps, (double const *)x, (double *)y,
-                       high_pair_setting(kChainLdsPairs), n_cached, cache, cv0, cv1, (uint32_t)row0, n_x);
-    LSK_LAUNCH_CHECK();
-    return 0;
-}
-
-// ---------------------------------------------------------------------------------------------
-// Two-table pull kernel (lsk_lin in lsk.h).  One row per lane; 64 consecutive rows of the ascending
-// fixed-weight basis nearly always share their high part h, and then
-//   * a flip mask that only touches high bits is active for the whole wave or not at all (scalar
-//     test; an inactive mask costs no vector instruction), and its target is  thi[h ^ xhi] + tlo[l]:
-//     one scalar load, one vector add, one gather of 64 contiguous x;
-//   * a mask with low bits needs one LDS read tlo[l ^ xlo] per lane.
-// Waves that straddle two high parts (64 * #high parts / N of them: 3 % for chain_32 at 14 bits) and
-// the gx mode (rows = a hash partition) take the per-lane form thi[beta >> bits] + tlo[beta & mask].
-// Blocks are 1024 threads so that a 2^15-entry tlo (64 KB) still leaves two blocks per CU.
-// ---------------------------------------------------------------------------------------------
-constexpr int kLinBlock = 1024;
-
-template <bool CPLX>
-__device__ __forceinline__ void lin_gather(double const *__restrict__ x, size_t idx, double c, double &accr, double &acci) {
-    if (CPLX) {
-        const double2 v = reinterpret_cast<double2 const *>(x)[idx];
-        accr = fma(c, v.x, accr);
-        acci = fma(c, v.y, acci);
-    } else accr = fma(c, x[idx], accr);
-}
-
-template <typename W, bool CPLX>
-__global__ __launch_bounds__(kLinBlock, 8) void k_lin(int B, int n_lm, int n_ex, int n_all,
-                                                      lsk_lin_group const *__restrict__ lg,
-                                                      uint16_t const *__restrict__ g_tlo,
-                                                      void const *__restrict__ thi_v, lsk_runs runs,
-                                                      lsk_group const *__restrict__ groups,
-                                                      lsk_term const *__restrict__ off, int n_diag,
-                                                      lsk_term const *__restrict__ diag, int hamming_weight,
-                                                      int64_t n, int64_t tiles_per_xcd,
-                                                      uint64_t const *__restrict__ reps,
-                                                      double const *__restrict__ x, double *__restrict__ y,
-                                                      int *__restrict__ err, int gx) {
-    typedef typename WordTraits<W>::binom_t BT;
-    typedef WordTraits<W> WT;
-    extern __shared__ uint16_t s_tlo[];
-    for (int k = threadIdx.x; k < (1 << B); k += blockDim.x) s_tlo[k] = g_tlo[k];
-    __syncthreads();
-    BT const *thi = (BT const *)thi_v;
-    const uint32_t LM = (1u << B) - 1u;
-    const int xcd = blockIdx.x & 7;
-    const int64_t blocks_per_xcd = gridDim.x >> 3;
-    for (int64_t t = blockIdx.x >> 3; t < tiles_per_xcd; t += blocks_per_xcd) {
-        const int cs = (gx >> 16) & 31;
-        const int64_t tile = cs == 0 ? (int64_t)xcd * tiles_per_xcd + t
-                                     : ((((t >> cs) << 3) + xcd) << cs) + (t & (((int64_t)1 << cs) - 1));
-        const int64_t i = tile * kLinBlock + threadIdx.x;
-        if (i >= n) continue;
-        const W a = (W)__builtin_nontemporal_load(reps + i);
-        const uint32_t l = (uint32_t)a & LM;
-        const uint32_t hv = (uint32_t)(a >> B);
-        const uint32_t h0 = __builtin_amdgcn_readfirstlane(hv);
-        const bool uni = __builtin_amdgcn_ballot_w64(hv != h0) == 0;
-        const BT t_own = (BT)s_tlo[l];
-        const BT ig = (gx & 1) ? (BT)(thi[hv] + t_own) : (BT)i;
-        double xr, xi = 0.0;
-        if (CPLX) { const double2 v = reinterpret_cast<double2 const *>(x)[ig]; xr = v.x; xi = v.y; } else xr = x[ig];
-        double accr = 0.0, acci = 0.0;
-        if (n_diag == 0) { // no diagonal pass in the reference either: y is accumulated into (DMV:1062-1063)
-            if (CPLX) { accr = y[2 * i]; acci = y[2 * i + 1]; } else accr = y[i];
-        } else {
-            double dr, di;
-            diag_coeff<W, true>(runs, n_diag, diag, a, dr, di);
-            accr = dr * xr;
-            if (CPLX) acci = dr * xi;
-        }
-        if (uni) {
-            // masks with a low bit: act <=> exactly one of the two bits is set; the high bit (if any) is
-            // uniform.  Four masks per batch: 4 scalar loads, 4 LDS reads, 4 gathers in flight.
-            int g = 0;
-            for (; g < n_lm; g += 4) {
-                BT idx[4];
-                double c[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int gg = g + u < n_lm ? g + u : n_lm - 1;
-                    const uint32_t xlo = lg[gg].xlo, xhi = lg[gg].xhi;
-                    const double v = g + u < n_lm ? lg[gg].v : 0.0;
-                    const BT thg = thi[h0 ^ xhi];
-                    const bool act = (uint32_t)__popc(l & xlo) + (uint32_t)__popc(h0 & xhi) == 1u;
-                    const BT cand = (BT)(thg + s_tlo[l ^ xlo]);
-                    idx[u] = act ? cand : ig;
-                    c[u] = act ? v : 0.0;
-                }
-                double vr[4], vi[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int gg = g + u < n_lm ? g + u : n_lm - 1;
-                    if (CPLX) { const double2 q = reinterpret_cast<double2 const *>(x)[idx[u]]; vr[u] = q.x; vi[u] = q.y; }
-                    else { vr[u] = lg[gg].pad ? __builtin_nontemporal_load(x + idx[u]) : x[idx[u]]; vi[u] = 0.0; }
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    accr = fma(c[u], vr[u], accr);
-                    if (CPLX) acci = fma(c[u], vi[u], acci);
-                }
-            }
-            // masks with high bits only: active for the whole wave or not at all
-            for (g = n_lm; g < n_ex; g += 4) {
-                BT thg[4];
-                double cv[4], vr[4], vi[4];
-                bool act[4], nt[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int gg = g + u < n_ex ? g + u : n_ex - 1;
-                    const uint32_t xhi = lg[gg].xhi;
-                    thg[u] = thi[h0 ^ xhi];
-                    act[u] = g + u < n_ex && __popc(h0 & xhi) == 1;
-                    nt[u] = lg[gg].pad != 0;
-                    cv[u] = lg[gg].v;
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    vr[u] = 0.0; vi[u] = 0.0;
-                    if (act[u]) {
-                        const size_t idx = (size_t)(BT)(thg[u] + t_own);
-                        if (CPLX) { const double2 q = reinterpret_cast<double2 const *>(x)[idx]; vr[u] = q.x; vi[u] = q.y; }
-                        else vr[u] = nt[u] ? __builtin_nontemporal_load(x + idx) : x[idx];
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    accr = fma(cv[u], vr[u], accr);
-                    if (CPLX) acci = fma(cv[u], vi[u], acci);
-                }
-            }
-        } else {
-#pragma unroll 2
-            for (int g = 0; g < n_ex; ++g) {
-                const W xg = (W)lg[g].xlo | ((W)lg[g].xhi << B);
-                const double v = lg[g].v;
-                const bool act = WT::popc(a & xg) == 1;
-                const W b = act ? (W)(a ^ xg) : a;
-                const BT idx = (BT)(thi[(uint32_t)(b >> B)] + s_tlo[(uint32_t)b & LM]);
-                lin_gather<CPLX>(x, (size_t)idx, act ? v : 0.0, accr, acci);
-            }
-        }
-        for (int g = n_ex; g < n_all; ++g) {
-            lsk_group const G = groups[lg[g].g];
-            double cr, ci;
-            group_coeff<true>(G, off, (uint64_t)a, cr, ci);
-            if (cr == 0.0) continue;
-            const W b = a ^ (W)G.x;
-            // a state of another Hamming weight is outside the basis: the reference halts (DMV:115-118)
-            if (WT::popc(b) != hamming_weight) { atomicExch(err, 1); continue; }
-            const BT idx = (BT)(thi[(uint32_t)(b >> B)] + s_tlo[(uint32_t)b & LM]);
-            lin_gather<CPLX>(x, (size_t)idx, cr, accr, acci);
-        }
-        if (CPLX) { y[2 * i] = accr; y[2 * i + 1] = acci; } else __builtin_nontemporal_store(accr, y + i);
-    }
-}
-
-template <typename W, bool CPLX>
-static int launch_lin(lsk_lin lin, lsk_operator op, lsk_basis bs, int gx, int64_t n, uint64_t const *reps,
-                      void const *x, void *y, int *d_err, void *stream) {
-    const size_t lds = sizeof(uint16_t) << lin.bits;
-    int64_t tiles = (n + kLinBlock - 1) / kLinBlock;
-    int64_t tiles_per_xcd = (tiles + 7) / 8;
-    const int cs = xcd_chunk_setting();
-    if (cs > 0) tiles_per_xcd = (((tiles + ((int64_t)8 << cs) - 1) / ((int64_t)8 << cs))) << cs;
-    gx = (gx & 1) | (cs << 16);
-    int64_t gb = tiles_per_xcd * 8;
-    static bool attr_set = false;
-    if (!attr_set) {
-        LSK_CHECK(hipFuncSetAttribute((void const *)k_lin<W, CPLX>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-        attr_set = true;
-    }
-    int64_t cap = resident_grid(k_lin<W, CPLX>, gb, lds, kLinBlock);
-    cap &= ~(int64_t)7;
-    if (cap < 8) cap = 8;
-    if (gb > cap) gb = cap;
-    const int n_lm = lin.n_low + lin.n_mixed, n_ex = n_lm + lin.n_high;
-    hipLaunchKernelGGL((k_lin<W, CPLX>), dim3((unsigned)gb), dim3(kLinBlock), lds, (hipStream_t)stream, lin.bits, n_lm,
-                       n_ex, n_ex + lin.n_generic, lin.groups, lin.tlo, lin.thi, op.runs, op.groups, op.off, op.n_diag,
-                       op.diag, bs.hamming_weight, n, tiles_per_xcd, reps, (double const *)x, (double *)y, d_err, gx);
-    LSK_LAUNCH_CHECK();
-    return 0;
-}
-extern "C" int lsk_lin_pull(lsk_lin lin, lsk_operator op, lsk_basis bs, int cplx, int gx, int64_t n,
-                            uint64_t const *reps, void const *x, void *y, int *d_err, void *stream) {
-    if (n == 0) return 0;
-    if (lin.bits < 1 || lin.bits > 15) { snprintf(g_err, sizeof(g_err), "lsk_lin_pull: bits out of range"); return -1; }
-    if (bs.number_sites <= 32)
-        return cplx ? launch_lin<uint32_t, true>(lin, op, bs, gx, n, reps, x, y, d_err, stream)
-                    : launch_lin<uint32_t, false>(lin, op, bs, gx, n, reps, x, y, d_err, stream);
-    return cplx ? launch_lin<uint64_t, true>(lin, op, bs, gx, n, reps, x, y, d_err, stream)
-                : launch_lin<uint64_t, false>(lin, op, bs, gx, n, reps, x, y, d_err, stream);
-}
-
-// ---------------------------------------------------------------------------------------------
-// High-part pass (see lsk.h): one work item = (popcount class of the top bits, 64 consecutive offsets).
-// The block stages the class's x slices in LDS (one coalesced 512-byte row per H), then every wave
-// combines partner rows from LDS and read-modify-writes its y rows.  Pure streaming: x read once,
-// y updated once, for all the far bonds of the class together.
-// ---------------------------------------------------------------------------------------------
-constexpr int kHpChunk = 64;
-template <bool CPLX>
-__global__ __launch_bounds__(kBlock) void k_highpart(lsk_highpart hp, double const *__restrict__ x, double *__restrict__ y) {
-    extern __shared__ double s_x[]; // [max_class_rows][kHpChunk] (x2 for complex)
-    constexpr int EW = CPLX ? 2 : 1;
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    constexpr int n_waves = kBlock / 64;
-    for (int64_t item = blockIdx.x; item < hp.n_items; item += gridDim.x) {
-        // class of this work item (few classes: linear scan)
-        int c = 0;
-        while (c + 1 < hp.n_classes && hp.class_chunk0[c + 1] <= item) ++c;
-        const int64_t o0 = (item - hp.class_chunk0[c]) * kHpChunk;
-        const int64_t S = hp.class_size[c];
-        const int r0 = hp.class_rows[c], r1 = hp.class_rows[c + 1];
-        const bool in = o0 + lane < S;
-        __syncthreads(); // previous item's readers are done with s_x
-        for (int r = r0 + wave; r < r1; r += n_waves) {
-            const int64_t g = hp.row_base[r] + o0 + lane;
-            double *dst = s_x + ((size_t)(r - r0) * kHpChunk + lane) * EW;
-            if (CPLX) { dst[0] = in ? x[2 * g] : 0.0; dst[1] = in ? x[2 * g + 1] : 0.0; }
-            else dst[0] = in ? x[g] : 0.0;
-        }
-        __syncthreads();
-        for (int r = r0 + wave; r < r1; r += n_waves) {
-            const int pb = hp.row_pbegin[r], pe = hp.row_pbegin[r + 1];
-            if (pb == pe) continue;
-            double ar = 0.0, ai = 0.0;
-            for (int p = pb; p < pe; ++p) {
-                const double vr = hp.partner_v[2 * p], vi = hp.partner_v[2 * p + 1];
-                double const *src = s_x + ((size_t)(hp.partner_row[p] - r0) * kHpChunk + lane) * EW;
-                if (CPLX) { // conj(v) * x
-                    ar += vr * src[0] + vi * src[1];
-                    ai += vr * src[1] - vi * src[0];
-                } else ar += vr * src[0];
-            }
-            if (in) {
-                const int64_t g = hp.row_base[r] + o0 + lane;
-                if (CPLX) { y[2 * g] += ar; y[2 * g + 1] += ai; } else y[g] += ar;
-            }
-        }
-    }
-}
-extern "C" int lsk_highpart_apply(lsk_highpart hp, int cplx, void const *x, void *y, void *stream) {
-    if (hp.n_items == 0) return 0;
-    const size_t lds = (size_t)hp.max_class_rows * kHpChunk * (cplx ? 16 : 8);
-    if (lds > 160 * 1024) { snprintf(g_err, sizeof(g_err), "lsk_highpart: class too large for LDS"); return -1; }
-    int grid;
-    if (cplx) {
-        LSK_CHECK(hipFuncSetAttribute((void const *)k_highpart<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        grid = resident_grid(k_highpart<true>, hp.n_items, lds);
-        hipLaunchKernelGGL(k_highpart<true>, dim3(grid), dim3(kBlock), lds, (hipStream_t)stream, hp, (double const *)x, (double *)y);
-    } else {
-        LSK_CHECK(hipFuncSetAttribute((void const *)k_highpart<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        grid = resident_grid(k_highpart<false>, hp.n_items, lds);
-        hipLaunchKernelGGL(k_highpart<false>, dim3(grid), dim3(kBlock), lds, (hipStream_t)stream, hp, (double const *)x, (double *)y);
-    }
-    LSK_LAUNCH_CHECK();
-    return 0;
+    const bool narrow = bs.number_sites <= 32 && !wide_ranks;
+#define LSK_CHAIN_ARGS op, bs, ix, tm, n, reps, row0, n_x, x, y, n_cached, cache, cv0, cv1, stream
+    if (narrow) return cplx ? launch_chain<uint32_t, uint32_t, true, 512>(LSK_CHAIN_ARGS) : launch_chain<uint32_t, uint32_t, false, 1024>(LSK_CHAIN_ARGS);
+    if (!wide_ranks) return cplx ? launch_chain<uint64_t, uint32_t, true, 512>(LSK_CHAIN_ARGS) : launch_chain<uint64_t, uint32_t, false, 1024>(LSK_CHAIN_ARGS);
+    return cplx ? launch_chain<uint64_t, uint64_t, true, 512>(LSK_CHAIN_ARGS) : launch_chain<uint64_t, uint64_t, false, 1024>(LSK_CHAIN_ARGS);
+#undef LSK_CHAIN_ARGS
 }
 
 // ---------------------------------------------------------------------------------------------

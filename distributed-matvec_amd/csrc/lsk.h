@@ -56,28 +56,6 @@ typedef struct lsk_operator {
     lsk_runs runs;
 } lsk_operator;
 
-/* Two-table ranking of a fixed-Hamming-weight basis ("Lin tables"): a state splits into its low `bits`
- * bits l and the rest h, and  rank(state) = thi[h] + tlo[l]  where
- *   tlo[l] = sum_j C(p_j, j + 1)                 over the set bits p_0 < p_1 < ... of l,
- *   thi[h] = sum_i C(bits + q_i, k + i + 1)      over the set bits q_i of h, k = weight - popcount(h).
- * 64 consecutive rows almost always share h, so a wave evaluates the high part of every target with
- * scalar instructions (one scalar load of thi per flip mask) and the low part with one LDS read.
- * Groups are ordered: EXCHANGE groups whose two bits are both low, then one low + one high, then both
- * high, then everything else (evaluated per lane through its terms, g = index into op.groups). */
-typedef struct lsk_lin_group {
-    uint32_t xlo, xhi; /* flip mask = xlo | xhi << bits */
-    double v;          /* EXCHANGE amplitude */
-    int32_t g;
-    int32_t pad; /* != 0: the gathers of this mask are streamed (non-temporal) */
-} lsk_lin_group;
-
-typedef struct lsk_lin {
-    int bits, n_low, n_mixed, n_high, n_generic;
-    lsk_lin_group const *groups; /* device */
-    uint16_t const *tlo;         /* device [1 << bits] */
-    void const *thi;             /* device [1 << max(number_sites - bits, 0)]: u32 if number_sites <= 32, else u64 */
-} lsk_lin;
-
 enum { LSK_ELEM_BENES = 0, LSK_ELEM_ROT = 1, LSK_ELEM_REVROT = 2 };
 
 typedef struct lsk_group_elem {
@@ -161,21 +139,18 @@ int lsk_diag(lsk_operator op, int cplx, int64_t n, uint64_t const *reps, void co
  * pull == 1: y[i] = d x[i] + sum conj(c) x[idx(beta)] */
 int lsk_direct(lsk_operator op, lsk_basis bs, lsk_index ix, int cplx, int pull, lsk_tilemap tm,
                uint64_t const *reps, void const *x, void *y, int *d_err, void *stream);
-/* staged row kernel (k_chain): f64 pull, <= 32 sites, full fixed-Hamming-weight basis without symmetries, real
- * Hermitian operator; the tile map must have been built with 1024-row tiles.  The n rows (reps, cache, y) are
- * the global rows [row0, row0 + n) of the basis; x is the whole vector of n_x elements. */
-int lsk_chain(lsk_operator op, lsk_basis bs, lsk_index ix, lsk_tilemap tm, int64_t n, uint64_t const *reps,
-              int64_t row0, int64_t n_x, void const *x, void *y, int n_cached, uint32_t const *cache, double cv0,
-              double cv1, void *stream);
-/* partner ranks of a non-adjacent exchange pair for every row (see k_chain); *d_flag is raised if a partner
- * leaves the basis */
-int lsk_chain_cache(lsk_basis bs, lsk_index ix, int64_t n, uint64_t const *reps, uint64_t xmask, uint32_t *out,
+/* staged row kernel (k_chain_t): pull, real Hermitian operator, the full fixed-Hamming-weight basis without symmetries
+ * (<= 64 sites; f64 or c128 vectors).  The tile map must have been built with lsk_chain_tile_rows(cplx)-row tiles.  The n
+ * rows (reps, cache, y) are the global rows [row0, row0 + n) of the basis; x is the whole vector of n_x elements.
+ * wide_ranks != 0: ranks (cache entries, indices into x) are 64-bit (bases with >= 2^32 states). */
+int lsk_chain_tile_rows(int cplx);
+int lsk_chain(lsk_operator op, lsk_basis bs, lsk_index ix, int cplx, int wide_ranks, lsk_tilemap tm, int64_t n,
+              uint64_t const *reps, int64_t row0, int64_t n_x, void const *x, void *y, int n_cached, void const *cache,
+              double cv0, double cv1, void *stream);
+/* partner ranks of a non-adjacent exchange pair for every row (u32, or u64 when wide_ranks); *d_flag is raised if a
+ * partner leaves the basis */
+int lsk_chain_cache(lsk_basis bs, lsk_index ix, int64_t n, uint64_t const *reps, uint64_t xmask, void *out, int wide_ranks,
                     int *d_flag, void *stream);
-/* two-table pull kernel: fixed Hamming weight, no symmetries, real coefficients, Hermitian.
- * gx == 0: rows are the whole basis (row i has rank i); gx != 0: rows are any subset, x is the whole
- * vector in ascending order of the global basis. */
-int lsk_lin_pull(lsk_lin lin, lsk_operator op, lsk_basis bs, int cplx, int gx, int64_t n, uint64_t const *reps,
-                 void const *x, void *y, int *d_err, void *stream);
 /* staged kernel (LDS term lists): rows [row0, row1) of partition `me`.
  * count_only != 0: adds the number of packets per destination to d_counts[P] and does nothing else.
  * otherwise: local packets -> index + atomic add into y; remote packets -> d_send according to
@@ -199,32 +174,6 @@ int lsk_tile_pull(lsk_operator op, lsk_basis bs, lsk_index ix_global, int cplx, 
                   uint64_t const *reps, double const *norms_local, double const *norms_global,
                   int64_t const *row_gidx, void const *tab, int tab_bits, void const *x_global, void *y,
                   int *d_err, void *stream);
-/* "High-part" pass of the pull formulation for the full fixed-Hamming basis (P = 1).  States are sorted
- * as integers, so all states with the same top `t` site bits H form one contiguous block
- * [base(H), base(H) + S_pop(H)), ordered by their low part; an exchange on two adjacent HIGH sites maps
- * block H onto block H' with the SAME offset.  The far bonds therefore act as a tiny sparse matrix on the
- * block index, applied to 64-offset slices staged in LDS: every x element is read from HBM once and every
- * y element updated once for ALL those bonds together (instead of one full sweep of x per far bond).
- *   classes      c = 0..n_classes-1 (popcount classes of H that occur)
- *   class_rows   [n_classes + 1]  rows (= H values) of class c are [class_rows[c], class_rows[c + 1])
- *   class_size   [n_classes]      block length S of the class
- *   class_chunk0 [n_classes + 1]  prefix sum of ceil(S / 64): work items
- *   row_base     [n_rows]         base(H) of every row
- *   row_pbegin   [n_rows + 1], partner_row [..] (row index inside the same class, absolute), partner_v [..][2] */
-typedef struct lsk_highpart {
-    int n_classes, n_rows, max_class_rows;
-    int64_t n_items;
-    int32_t const *class_rows;
-    int64_t const *class_size;
-    int64_t const *class_chunk0;
-    int64_t const *row_base;
-    int32_t const *row_pbegin;
-    int32_t const *partner_row;
-    double const *partner_v;
-} lsk_highpart;
-/* y[base(H) + o] += sum_partners conj(v) x[base(H') + o] */
-int lsk_highpart_apply(lsk_highpart hp, int cplx, void const *x, void *y, void *stream);
-
 /* n packets -> y[idx(beta)] += value */
 int lsk_scatter(lsk_index ix, int cplx, int64_t n, uint64_t const *betas, void const *vals, void *y,
                 double const *norms /* NULL, or per-row norms multiplied in (K4 modes 1, 2) */, int *d_err,

@@ -205,16 +205,12 @@ int ls_amd_basis_group_order(ls_hs_basis const *basis);
 uint64_t ls_amd_basis_apply_group_element(ls_hs_basis const *basis, int element, uint64_t state);
 int ls_amd_basis_group_character(ls_hs_basis const *basis, int element, double *re, double *im);
 
-/* Host-only test hooks (no device needed): the tile map of the row kernels and the two-table ranking
- * (distributed-matvec_amd/csrc/lsk.h: lsk_tilemap, lsk_lin).
- *   ls_amd_test_tilemap  8 lists of `return value` entries (first row | rows << 48; 0 = empty slot) in *entries
- *                        (malloc'ed: release with ls_amd_test_free); < 0 on error
- *   ls_amd_test_lin_rank ranks[i] = thi[state >> bits] + tlo[state & mask] */
-int64_t ls_amd_test_tilemap(int number_sites, int hamming_weight, int64_t n, int transposed, int tile_rows,
-                            int top_bits, int64_t set_rows, int64_t chunk, uint64_t **entries);
+/* Host-only test hook (no device needed): the tile map of the row kernels (distributed-matvec_amd/csrc/lsk.h: lsk_tilemap)
+ * for n rows in tiles of tile_rows, dealt to the 8 XCD lists contiguously (chunk == 0) or in round-robin chunks.
+ * Returns the number of entries per list; *entries (malloc'ed, release with ls_amd_test_free) holds the 8 lists
+ * (first row | rows << 48; 0 = empty slot); < 0 on error. */
+int64_t ls_amd_test_tilemap(int64_t n, int tile_rows, int64_t chunk, uint64_t **entries);
 void ls_amd_test_free(void *p);
-int ls_amd_test_lin_rank(int number_sites, int hamming_weight, int bits, int64_t n, uint64_t const *states,
-                         int64_t *ranks);
 
 #ifdef __cplusplus
 }

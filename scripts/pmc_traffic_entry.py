@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Turn the rocprofv3 PMC passes of one bench command into an entry of profiles/pmc_traffic.json.
+
+usage: pmc_traffic_entry.py <dir with pmc_fetch/ pmc_write/ [pmc_valu/] rocpd dbs> <model> <dtype> <plan kernel name>
+Prints {key: entry} as JSON.  FETCH_SIZE / WRITE_SIZE are KiB per dispatch; FETCH_SIZE is doubled (gfx950: the counter
+tallies 128-byte requests at 64 bytes, MI355X_MICROARCH.md; calibrated on k_diag in round 1)."""
+import glob
+import json
+import os
+import sqlite3
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+DEVICE_KERNEL = {"staged": "k_chain", "tile-pull": "k_tile_pull", "direct-push": "k_direct", "direct-pull": "k_direct",
+                 "tile": "k_tile<"}
+
+
+def mean_counter(root, sub, counter, needle):
+    vals = []
+    for db_path in glob.glob(os.path.join(root, sub, "**", "*_results.db"), recursive=True):
+        cur = sqlite3.connect(db_path).cursor()
+        cols = [c[1] for c in cur.execute("pragma table_info('counters_collection')")]
+        name_col = "kernel_name" if "kernel_name" in cols else cols[0]
+        for kn, v in cur.execute(f"select {name_col}, value from counters_collection where counter_name = ?", (counter,)):
+            if needle in kn:
+                vals.append(v)
+    return (sum(vals) / len(vals), len(vals)) if vals else (None, 0)
+
+
+def main():
+    root, model, dtype, kname = sys.argv[1:5]
+    from bench import source_sha
+
+    needle = next(v for k, v in DEVICE_KERNEL.items() if k in kname)
+    fetch, nf = mean_counter(root, "pmc_fetch", "FETCH_SIZE", needle)
+    write, nw = mean_counter(root, "pmc_write", "WRITE_SIZE", needle)
+    valu, nv = mean_counter(root, "pmc_valu", "SQ_INSTS_VALU", needle)
+    entry = {
+        "fetch_size_kib_raw": fetch, "fetch_correction": 2.0, "write_size_kib": write,
+        "traffic_bytes": (2.0 * fetch + write) * 1024.0 if fetch is not None and write is not None else None,
+        "dispatches": [nf, nw], "device_kernel": needle, "source_sha": source_sha(),
+        "source": os.environ.get("PMC_SOURCE", ""),
+    }
+    if valu is not None:
+        entry["valu_insts"] = valu
+    print(json.dumps({f"{model}/{dtype}/{kname}": entry}, indent=1))
+
+
+if __name__ == "__main__":
+    main()

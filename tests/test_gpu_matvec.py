@@ -85,7 +85,7 @@ def test_single_locale_matvec_f64(torch, name, mode):
     if basis.hasPermutationSymmetries():
         assert pl.kernel == ("tile" if mode == "push" else "tile-pull")
     else:
-        assert pl.kernel.startswith(f"direct-{mode}")  # "direct-pull+highpart" when the far bonds are blocked
+        assert pl.kernel.startswith(f"direct-{mode}")
     assert_close(got, want, name)
 
 
@@ -579,25 +579,6 @@ def test_replicated_x_block_rows(torch, name):
     assert_close(got, want, name)
 
 
-def test_highpart_two_pass_option(torch, monkeypatch):
-    """LS_AMD_HIGH_BITS=t: far bonds of the pull kernel applied block-wise from LDS (optional path)."""
-    import distributed_matvec_amd as D
-
-    monkeypatch.setenv("LS_AMD_HIGH_BITS", "6")
-    for name in ("heisenberg_chain_16", "heisenberg_chain_20", "heisenberg_kagome_16"):
-        D_, basis, h, reps, masks = setup_model(torch, model_config(name), 1)
-        want_reps = oracle_reps(name)
-        rs = np.random.RandomState(62)
-        for cplx in (False, True):
-            x = rs.rand(len(want_reps)) - 0.5
-            if cplx:
-                x = x + 1j * (rs.rand(len(want_reps)) - 0.5)
-            want = oracle_for(name).local_matvec(want_reps, x)
-            got, pl = run_matvec(torch, D_, h, reps, masks, x, 1, "pull")
-            if name.startswith("heisenberg_chain"):
-                assert pl.kernel == "direct-pull+highpart"
-            assert np.abs(got - want).max() <= 1e-12 * max(1.0, np.abs(want).max())
-
 
 def test_non_hermitian_complex_operator(torch):
     """push is the only formulation for a non-Hermitian operator: sigma^+ sigma^- hopping plus a term with
@@ -664,16 +645,15 @@ ROW_KERNEL_VARIANTS = {
     "uniform-from-4": {"LS_AMD_CHAIN": "0", "LS_AMD_HIGH_PAIR": "4"},
     "staged-uniform-from-13": {"LS_AMD_HIGH_PAIR": "13"},
     "staged-no-uniform": {"LS_AMD_HIGH_PAIR": "0"},
-    "transposed-tiles": {"LS_AMD_CHAIN": "0", "LS_AMD_TRANSPOSED": "1", "LS_AMD_TOP_BITS": "3", "LS_AMD_SET_ROWS": "2048"},
-    "two-table": {"LS_AMD_LIN": "1", "LS_AMD_LIN_BITS": "7"},
-    "two-table-chunked": {"LS_AMD_LIN": "1", "LS_AMD_LIN_BITS": "12", "LS_AMD_XCD_CHUNK": "2"},
+    "contiguous-tiles": {"LS_AMD_TILE_CHUNK": "0"},
+    "chunked-tiles-generic": {"LS_AMD_CHAIN": "0", "LS_AMD_TILE_CHUNK": "3"},
 }
 
 
 @pytest.mark.parametrize("variant", sorted(ROW_KERNEL_VARIANTS))
 def test_row_kernel_variants(torch, monkeypatch, variant):
     """Every selectable form of the single-partition pull kernel against the oracle: staged (LDS window +
-    cached ring partners), generic with / without wave-uniform far pairs, transposed tile order, two-table."""
+    cached ring partners), generic with / without wave-uniform far pairs, contiguous / chunked tile dealing."""
     from oracle import c_oracle as CO
     from oracle import model as M
 
@@ -694,12 +674,96 @@ def test_row_kernel_variants(torch, monkeypatch, variant):
         assert np.abs(got - want).max() <= 1e-12 * max(1.0, np.abs(want).max()), (variant, L, kind, pl.kernel)
         if variant == "default":
             assert pl.kernel == ("direct-pull" if kind == "j1j2" else "direct-pull+staged"), (kind, pl.kernel)
-        # c128 vectors go through the generic row kernel
+        # c128 vectors: the complex instantiation of the same kernel family
         xc = x + 1j * (rs.rand(len(want_reps)) - 0.5)
         gotc, plc = run_matvec(torch, D, h, reps, masks, xc, 1, "pull")
         wantc = o.local_matvec(want_reps, xc)
         assert np.abs(gotc - wantc).max() <= 1e-12 * max(1.0, np.abs(wantc).max()), (variant, L, kind, plc.kernel)
-    if variant.startswith("two-table"):
-        assert "direct-pull+lin" in seen
-    if variant in ("generic-row-kernel", "no-uniform-pairs", "uniform-from-4", "transposed-tiles"):
+    if variant in ("generic-row-kernel", "no-uniform-pairs", "uniform-from-4", "chunked-tiles-generic"):
         assert seen == {"direct-pull"}
+
+
+def _ring_config(L, weight):
+    """periodic Heisenberg ring of L sites in the sector with `weight` up spins (not half filling): small enough for the
+    oracle at any L <= 64"""
+    from oracle import model as M
+
+    cfg = M.heisenberg_chain_config(L)
+    cfg["basis"]["hamming_weight"] = weight
+    return cfg
+
+
+@pytest.mark.parametrize("L,weight", [(16, 8), (20, 10), (24, 5), (33, 3), (40, 4), (64, 3), (48, 5)])
+@pytest.mark.parametrize("cplx", [False, True])
+@pytest.mark.parametrize("wide", [False, True])
+def test_staged_kernel_instantiations(torch, monkeypatch, L, weight, cplx, wide):
+    """every instantiation of the staged row kernel k_chain_t<W, R, CPLX>: 32- and 64-bit states, 32- and 64-bit ranks
+    (LS_AMD_CHAIN_WIDE=1 forces the latter, which no in-tree config is large enough to need), f64 and c128 vectors,
+    against the oracle; and against the generic row kernel (LS_AMD_CHAIN=0)."""
+    import distributed_matvec_amd as D
+    from oracle import c_oracle as CO
+    from oracle import model as M
+
+    if wide and L <= 32:
+        pytest.skip("64-bit ranks are only instantiated for 64-bit states")
+    if wide:
+        monkeypatch.setenv("LS_AMD_CHAIN_WIDE", "1")
+    cfg = _ring_config(L, weight)
+    basis, h = D.loadConfigFromDict(cfg, hamiltonian=True)
+    reps, masks = D.enumerateStates(basis, 1)
+    o = CO.COracle(M.model_from_config(cfg))
+    want_reps = o.enumerate()
+    assert np.array_equal(reps[0].cpu().numpy().view(np.uint64), want_reps)
+    n = len(want_reps)
+    rs = np.random.RandomState(100 + L)
+    x = rs.rand(n) - 0.5
+    if cplx:
+        x = x + 1j * (rs.rand(n) - 0.5)
+    want = o.local_matvec(want_reps, x)
+    xt = torch.from_numpy(x).cuda()
+    y = torch.full_like(xt, 3.0)
+    pl = D.MatvecPlan(h, reps, xt.dtype, mode="pull")
+    assert pl.kernel == "direct-pull+staged", pl.kernel
+    pl.matvec([xt], [y])
+    assert np.abs(y.cpu().numpy() - want).max() <= 1e-12 * max(1.0, np.abs(want).max())
+    pl.destroy()
+    monkeypatch.setenv("LS_AMD_CHAIN", "0")
+    y2 = torch.full_like(xt, -1.0)
+    pl2 = D.MatvecPlan(h, reps, xt.dtype, mode="pull")
+    assert "staged" not in pl2.kernel
+    pl2.matvec([xt], [y2])
+    assert float((y - y2).abs().max()) <= 1e-12 * max(1.0, float(y.abs().max()))
+    pl2.destroy()
+
+
+@pytest.mark.parametrize("L,weight,cplx", [(20, 10, True), (40, 4, False), (40, 4, True)])
+def test_staged_kernel_block_rows_wide_states(torch, L, weight, cplx):
+    """replicated-x block rows (a slice of the global rows with a row offset) through the c128 / 64-bit-state
+    instantiations of the staged kernel"""
+    import distributed_matvec_amd as D
+    from oracle import c_oracle as CO
+    from oracle import model as M
+
+    cfg = _ring_config(L, weight)
+    basis, h = D.loadConfigFromDict(cfg, hamiltonian=True)
+    reps, masks = D.enumerateStates(basis, 1)
+    o = CO.COracle(M.model_from_config(cfg))
+    want_reps = o.enumerate()
+    n = len(want_reps)
+    rs = np.random.RandomState(7)
+    x = rs.rand(n) - 0.5
+    if cplx:
+        x = x + 1j * (rs.rand(n) - 0.5)
+    want = o.local_matvec(want_reps, x)
+    xg = torch.from_numpy(x).cuda()
+    P = 3
+    pieces = []
+    for p in range(P):
+        n0, n1 = n * p // P, n * (p + 1) // P
+        pl = D.ReplicatedPlan(h, reps[0][n0:n1], reps[0], xg.dtype, P, p)
+        assert pl.kernel == "replicated-direct-pull+staged"
+        yp = torch.zeros(n1 - n0, dtype=xg.dtype, device="cuda")
+        pl.matvec(xg, yp)
+        pieces.append(yp)
+    got = torch.cat(pieces).cpu().numpy()
+    assert np.abs(got - want).max() <= 1e-12 * max(1.0, np.abs(want).max())
