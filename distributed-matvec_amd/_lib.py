@@ -37,7 +37,6 @@ class LsHsBasis(C.Structure):
         ("requires_projection", C.c_bool),
         ("kernels", C.c_void_p),
         ("representatives", ChplExternalArray),
-        ("ext", C.c_void_p),
     ]
 
 
@@ -61,7 +60,6 @@ class LsHsOperator(C.Structure):
         ("basis", C.POINTER(LsHsBasis)),
         ("off_diag_terms", C.POINTER(LsHsNonbranchingTerms)),
         ("diag_terms", C.POINTER(LsHsNonbranchingTerms)),
-        ("ext", C.c_void_p),
     ]
 
 
@@ -122,6 +120,9 @@ def load():
         "ls_amd_diag": (C.c_int, [vp, vp, vp, vp]),
         "ls_amd_generate": (C.c_int, [vp, C.c_int, vp, vp, vp, vp]),
         "ls_amd_scatter": (C.c_int, [vp, C.c_int64, vp, vp, vp, vp]),
+        "ls_amd_adopt_basis": (C.c_int, [bp, C.c_int, c_intp, c_intp]),
+        "ls_amd_adopt_operator": (C.c_int, [op]),
+        "ls_amd_release": (None, [vp]),
         "ls_amd_comm_available": (C.c_int, []),
         "ls_amd_comm_unique_id": (C.c_int, [vp]),
         "ls_amd_comm_create": (C.c_int, [C.POINTER(vp), C.c_int, C.c_int, vp]),

@@ -155,11 +155,15 @@ class Operator:
         op.basis.spec = basis.spec
         return op
 
+    def clear_plans(self):
+        """destroy the cached matvec plans (and release the HBM they pin)"""
+        for pl in list(self._plans.values()):
+            pl.destroy()
+        self._plans.clear()
+
     def __del__(self):
         try:
-            for pl in list(self._plans.values()):
-                pl.destroy()
-            self._plans.clear()
+            self.clear_plans()
             if self.owning and self.payload:
                 _lib.load().ls_hs_destroy_operator(self.payload)
                 self.payload = None
@@ -562,10 +566,15 @@ class ReplicatedPlan:
 
 def _plan_for(matrix: Operator, representatives, dtype, mode="auto"):
     key = (tuple(int(r.data_ptr()) for r in representatives), tuple(int(r.numel()) for r in representatives), str(dtype), mode)
-    pl = matrix._plans.get(key)
+    pl = matrix._plans.pop(key, None)
     if pl is None:
+        # a plan pins its representative tensors and device tables (hash table, norms, tile map, partner-rank cache:
+        # several GB for the large chains): keep only the two most recently used ones per operator
+        while len(matrix._plans) >= 2:
+            oldest = next(iter(matrix._plans))
+            matrix._plans.pop(oldest).destroy()
         pl = MatvecPlan(matrix, representatives, dtype, mode=mode)
-        matrix._plans[key] = pl
+    matrix._plans[key] = pl  # (re)inserted last: dicts keep insertion order = LRU order
     return pl
 
 

@@ -64,6 +64,81 @@ static void halt_with(char const *fmt, ...) {
 /* ============================================================================================ */
 /* device helpers re-exported                                                                   */
 /* ============================================================================================ */
+/* object registry                                                                              */
+/* ============================================================================================ */
+/* Everything this library knows about a basis / an operator beyond the struct prefix the reference declares
+ * (/root/reference/src/FFI.chpl:94-119) lives in a side table keyed by the object's address -- NOT in a trailing struct
+ * field: an ls_hs_operator built by the real lattice-symmetries-haskell has "other stuff" of unknown layout behind the
+ * prefix, and reading a field of ours there would be out of bounds.  Objects created here are registered by their
+ * constructors; foreign ones by ls_amd_adopt_basis / ls_amd_adopt_operator. */
+#include <pthread.h>
+typedef struct { void const *key; void *val; int kind; } reg_slot;
+enum { REG_BASIS = 1, REG_OPERATOR = 2 };
+static reg_slot *g_reg = NULL;
+static size_t g_reg_cap = 0, g_reg_used = 0; /* used counts live entries and tombstones */
+static pthread_mutex_t g_reg_lock = PTHREAD_MUTEX_INITIALIZER;
+static void const *const REG_TOMB = (void const *)(uintptr_t)1;
+
+static size_t reg_hash(void const *k, size_t cap) { return (size_t)(((uintptr_t)k >> 4) * 0x9E3779B97F4A7C15ULL) & (cap - 1); }
+static void reg_put_nolock(void const *key, void *val, int kind);
+static void reg_grow(void) {
+    reg_slot *old = g_reg;
+    size_t const oc = g_reg_cap;
+    g_reg_cap = oc ? 2 * oc : 64;
+    g_reg = (reg_slot *)calloc(g_reg_cap, sizeof(reg_slot));
+    g_reg_used = 0;
+    for (size_t i = 0; i < oc; ++i)
+        if (old[i].key && old[i].key != REG_TOMB) reg_put_nolock(old[i].key, old[i].val, old[i].kind);
+    free(old);
+}
+static void reg_put_nolock(void const *key, void *val, int kind) {
+    if (2 * (g_reg_used + 1) > g_reg_cap) reg_grow();
+    size_t i = reg_hash(key, g_reg_cap);
+    while (g_reg[i].key && g_reg[i].key != REG_TOMB && g_reg[i].key != key) i = (i + 1) & (g_reg_cap - 1);
+    if (!g_reg[i].key) ++g_reg_used;
+    g_reg[i].key = key;
+    g_reg[i].val = val;
+    g_reg[i].kind = kind;
+}
+static void reg_put(void const *key, void *val, int kind) {
+    pthread_mutex_lock(&g_reg_lock);
+    reg_put_nolock(key, val, kind);
+    pthread_mutex_unlock(&g_reg_lock);
+}
+static void *reg_find(void const *key, int *kind) {
+    void *v = NULL;
+    pthread_mutex_lock(&g_reg_lock);
+    if (g_reg_cap) {
+        size_t i = reg_hash(key, g_reg_cap);
+        while (g_reg[i].key) {
+            if (g_reg[i].key == key) { v = g_reg[i].val; if (kind) *kind = g_reg[i].kind; break; }
+            i = (i + 1) & (g_reg_cap - 1);
+        }
+    }
+    pthread_mutex_unlock(&g_reg_lock);
+    return v;
+}
+static void *reg_get(void const *key) { return reg_find(key, NULL); }
+static void reg_del(void const *key) {
+    pthread_mutex_lock(&g_reg_lock);
+    if (g_reg_cap) {
+        size_t i = reg_hash(key, g_reg_cap);
+        while (g_reg[i].key) {
+            if (g_reg[i].key == key) { g_reg[i].key = REG_TOMB; g_reg[i].val = NULL; break; }
+            i = (i + 1) & (g_reg_cap - 1);
+        }
+    }
+    pthread_mutex_unlock(&g_reg_lock);
+}
+static void halt_with(char const *fmt, ...);
+struct ls_amd_basis_ext;
+struct ls_amd_operator_ext;
+static struct ls_amd_basis_ext *basis_ext_of(ls_hs_basis const *b);
+static struct ls_amd_operator_ext *operator_ext_of(ls_hs_operator const *op);
+#define BEXT(b) basis_ext_of(b)
+#define OEXT(op) operator_ext_of(op)
+
+/* ============================================================================================ */
 int ls_amd_device_count(void) { return lsk_device_count(); }
 int ls_amd_set_device(int device) { DEV(lsk_set_device(device)); return 0; }
 int ls_amd_malloc(void **d_ptr, size_t bytes) { DEV(lsk_malloc(d_ptr, bytes)); return 0; }
@@ -168,7 +243,20 @@ struct ls_amd_basis_ext {
     void *host_dist_f64;    /* ls_amd_dist* likewise, when a default communicator with > 1 ranks is installed */
     uint32_t *d_index_table; /* search table over d_reps_cache (ls_hs_state_index) */
     int index_kind, index_shift;
+    int refcount;           /* the creator's reference + one per operator built on the basis */
+    int adopted;            /* the struct belongs to somebody else (ls_amd_adopt_basis): never freed here */
 };
+
+static struct ls_amd_basis_ext g_dummy_basis_ext;
+static struct ls_amd_basis_ext *basis_ext_of(ls_hs_basis const *b) {
+    struct ls_amd_basis_ext *e = (struct ls_amd_basis_ext *)reg_get(b);
+    if (!e) {
+        halt_with("ls_hs_basis %p was not created by this library: register it with ls_amd_adopt_basis first", (void const *)b);
+        g_dummy_basis_ext.hamming_weight = -1;
+        return &g_dummy_basis_ext;
+    }
+    return e;
+}
 
 void ls_hs_init(void) {}
 void ls_hs_exit(void) {}
@@ -355,7 +443,8 @@ ls_hs_basis *ls_hs_create_spin_basis(int number_sites, int hamming_weight, int s
     }
     ls_hs_basis *b = (ls_hs_basis *)calloc(1, sizeof(ls_hs_basis));
     struct ls_amd_basis_ext *ext = (struct ls_amd_basis_ext *)calloc(1, sizeof(*ext));
-    b->ext = ext;
+    reg_put(b, ext, REG_BASIS);
+    ext->refcount = 1;
     b->number_sites = number_sites;
     b->number_particles = -1;
     b->number_up = hamming_weight >= 0 ? hamming_weight : -1;
@@ -377,7 +466,7 @@ ls_hs_basis *ls_hs_create_spin_basis(int number_sites, int hamming_weight, int s
 }
 
 ls_hs_basis *ls_hs_clone_basis(ls_hs_basis const *basis) {
-    struct ls_amd_basis_ext const *e = basis->ext;
+    struct ls_amd_basis_ext const *e = BEXT(basis);
     ls_hs_basis *b = ls_hs_create_spin_basis(basis->number_sites, e->hamming_weight, basis->spin_inversion,
                                              e->n_generators, e->gen_perms, e->gen_sectors);
     if (!b) return NULL;
@@ -387,13 +476,13 @@ ls_hs_basis *ls_hs_clone_basis(ls_hs_basis const *basis) {
         memcpy(b->representatives.elts, basis->representatives.elts, bytes);
         b->representatives.num_elts = basis->representatives.num_elts;
         b->representatives.freer = (void *)free;
-        b->ext->owns_representatives = 1;
+        BEXT(b)->owns_representatives = 1;
     }
     return b;
 }
 
 static void basis_drop_device_caches(ls_hs_basis *b) {
-    struct ls_amd_basis_ext *e = b->ext;
+    struct ls_amd_basis_ext *e = BEXT(b);
     if (e->host_plan_f64) { ls_amd_plan_destroy((ls_amd_plan *)e->host_plan_f64); e->host_plan_f64 = NULL; }
     if (e->host_dist_f64) { ls_amd_dist_destroy((ls_amd_dist *)e->host_dist_f64); e->host_dist_f64 = NULL; }
     if (e->d_reps_cache) { lsk_free(e->d_reps_cache); e->d_reps_cache = NULL; e->d_reps_count = 0; }
@@ -403,55 +492,57 @@ static void basis_drop_device_caches(ls_hs_basis *b) {
 
 void ls_hs_destroy_basis(ls_hs_basis *b) {
     if (!b) return;
-    struct ls_amd_basis_ext *e = b->ext;
-    if (e) {
-        basis_drop_device_caches(b);
-        if (e->d_elems) lsk_free(e->d_elems);
-        if (e->owns_representatives && b->representatives.elts) free(b->representatives.elts);
-        free(e->gen_perms); free(e->gen_sectors); free(e->perms); free(e->elems);
-        free(e);
-    }
-    free(b);
+    struct ls_amd_basis_ext *e = (struct ls_amd_basis_ext *)reg_get(b);
+    if (!e) return; /* not ours (or already gone): leave the struct alone */
+    if (--e->refcount > 0) return; /* operators built on this basis still share it */
+    basis_drop_device_caches(b);
+    if (e->d_elems) lsk_free(e->d_elems);
+    if (e->owns_representatives && b->representatives.elts) free(b->representatives.elts);
+    free(e->gen_perms); free(e->gen_sectors); free(e->perms); free(e->elems);
+    reg_del(b);
+    int const adopted = e->adopted;
+    free(e);
+    if (!adopted) free(b);
 }
 
 uint64_t ls_hs_min_state_estimate(ls_hs_basis const *b) {
-    int h = b->ext->hamming_weight;
+    int h = BEXT(b)->hamming_weight;
     return h > 0 ? ((1ULL << h) - 1) : 0;
 }
 /* with spin inversion the highest admissible state has the top site bit clear (see oracle notes) */
 uint64_t ls_hs_max_state_estimate(ls_hs_basis const *b) {
     int const L = b->number_sites - (b->spin_inversion != 0 ? 1 : 0);
-    int h = b->ext->hamming_weight;
+    int h = BEXT(b)->hamming_weight;
     if (h >= 0) return h == 0 ? 0 : ((1ULL << h) - 1) << (L - h);
     return L >= 64 ? ~0ULL : ((1ULL << L) - 1);
 }
 int ls_hs_basis_number_bits(ls_hs_basis const *b) { return b->number_sites; }
 int ls_hs_basis_number_words(ls_hs_basis const *b) { return (b->number_sites + 63) / 64; }
-bool ls_hs_basis_has_fixed_hamming_weight(ls_hs_basis const *b) { return b->ext->hamming_weight >= 0; }
+bool ls_hs_basis_has_fixed_hamming_weight(ls_hs_basis const *b) { return BEXT(b)->hamming_weight >= 0; }
 bool ls_hs_basis_has_spin_inversion_symmetry(ls_hs_basis const *b) { return b->spin_inversion != 0; }
-bool ls_hs_basis_has_permutation_symmetries(ls_hs_basis const *b) { return b->ext->order > 1; }
+bool ls_hs_basis_has_permutation_symmetries(ls_hs_basis const *b) { return BEXT(b)->order > 1; }
 bool ls_hs_basis_requires_projection(ls_hs_basis const *b) { return b->requires_projection; }
 
 void ls_hs_unchecked_set_representatives(ls_hs_basis *b, chpl_external_array const *states) {
     basis_drop_device_caches(b);
-    if (b->ext->owns_representatives && b->representatives.elts) free(b->representatives.elts);
+    if (BEXT(b)->owns_representatives && b->representatives.elts) free(b->representatives.elts);
     b->representatives = *states;
-    b->ext->owns_representatives = 0;
+    BEXT(b)->owns_representatives = 0;
 }
 
-int ls_amd_basis_group_order(ls_hs_basis const *b) { return b->ext->order; }
+int ls_amd_basis_group_order(ls_hs_basis const *b) { return BEXT(b)->order; }
 uint64_t ls_amd_basis_apply_group_element(ls_hs_basis const *b, int element, uint64_t state) {
-    return host_apply_elem(b->ext->elems + element, state, b->number_sites);
+    return host_apply_elem(BEXT(b)->elems + element, state, b->number_sites);
 }
 int ls_amd_basis_group_character(ls_hs_basis const *b, int element, double *re, double *im) {
-    if (element < 0 || element >= b->ext->order) return set_error("element out of range");
-    *re = b->ext->elems[element].ch_re;
-    *im = b->ext->elems[element].ch_im;
+    if (element < 0 || element >= BEXT(b)->order) return set_error("element out of range");
+    *re = BEXT(b)->elems[element].ch_re;
+    *im = BEXT(b)->elems[element].ch_im;
     return 0;
 }
 
 static int basis_device(ls_hs_basis const *b, lsk_basis *out) {
-    struct ls_amd_basis_ext *e = b->ext;
+    struct ls_amd_basis_ext *e = BEXT(b);
     if (!e->d_elems) {
         void *p;
         DEV(lsk_malloc(&p, sizeof(lsk_group_elem) * e->order));
@@ -509,8 +600,18 @@ struct ls_amd_operator_ext {
     /* device mirrors */
     lsk_group *d_groups;
     lsk_term *d_off, *d_diag;
-    int owns_basis;
+    int adopted; /* foreign struct (ls_amd_adopt_operator): only the side tables are ours */
 };
+
+static struct ls_amd_operator_ext g_dummy_operator_ext;
+static struct ls_amd_operator_ext *operator_ext_of(ls_hs_operator const *op) {
+    struct ls_amd_operator_ext *e = (struct ls_amd_operator_ext *)reg_get(op);
+    if (!e) {
+        halt_with("ls_hs_operator %p was not created by this library: register it with ls_amd_adopt_operator first", (void const *)op);
+        return &g_dummy_operator_ext;
+    }
+    return e;
+}
 
 typedef struct { double re, im; uint64_t m, r, x, s; } raw_term;
 
@@ -692,10 +793,12 @@ static void free_nbt(ls_hs_nonbranching_terms *nb) {
     free((void *)nb->x); free((void *)nb->s); free(nb);
 }
 
-ls_hs_operator *ls_hs_create_operator_from_terms(ls_hs_basis const *basis, int number_terms,
-                                                 double const *v, uint64_t const *m, uint64_t const *r,
-                                                 uint64_t const *x, uint64_t const *s) {
-    uint64_t const site_mask = basis->number_sites >= 64 ? ~0ULL : ((1ULL << basis->number_sites) - 1);
+/* term tables of an operator: filter / normalise / merge the raw terms, split them into diagonal and off-diagonal ones,
+ * group the latter by flip mask, classify.  *offx_out (malloc'ed, n_off entries): flip mask of every off-diagonal term. */
+static struct ls_amd_operator_ext *build_operator_ext(int number_sites, int has_inversion, int number_terms, double const *v,
+                                                      uint64_t const *m, uint64_t const *r, uint64_t const *x,
+                                                      uint64_t const *s, uint64_t **offx_out) {
+    uint64_t const site_mask = number_sites >= 64 ? ~0ULL : ((1ULL << number_sites) - 1);
     raw_term *raw = (raw_term *)malloc(sizeof(raw_term) * (number_terms > 0 ? number_terms : 1));
     int n = 0;
     double vmax = 0;
@@ -721,12 +824,7 @@ ls_hs_operator *ls_hs_create_operator_from_terms(ls_hs_basis const *basis, int n
         i = j;
     }
     n = w;
-    ls_hs_operator *op = (ls_hs_operator *)calloc(1, sizeof(*op));
     struct ls_amd_operator_ext *ext = (struct ls_amd_operator_ext *)calloc(1, sizeof(*ext));
-    op->ext = ext;
-    op->basis = ls_hs_clone_basis(basis);
-    ext->owns_basis = 1;
-    if (!op->basis) { free(raw); free(ext); free(op); return NULL; }
     int nd = 0;
     while (nd < n && raw[nd].x == 0) ++nd; /* sorted by x: the diagonal terms come first */
     ext->n_diag = nd;
@@ -753,16 +851,99 @@ ls_hs_operator *ls_hs_create_operator_from_terms(ls_hs_basis const *basis, int n
         ext->groups[ext->n_groups - 1].end = i + 1;
     }
     classify_groups(ext);
-    detect_runs(ext, basis->number_sites, basis->spin_inversion != 0);
+    detect_runs(ext, number_sites, has_inversion);
+    free(raw);
+    if (offx_out) *offx_out = offx; else free(offx);
+    return ext;
+}
+
+/* The operator SHARES its basis (one more reference), as upstream's ls_hs_operator does: representatives set or built
+ * on the basis after the operator exists are seen by the operator, and nothing is duplicated (the representatives of
+ * heisenberg_chain_32 are 4.8 GB of host memory). */
+ls_hs_operator *ls_hs_create_operator_from_terms(ls_hs_basis const *basis, int number_terms,
+                                                 double const *v, uint64_t const *m, uint64_t const *r,
+                                                 uint64_t const *x, uint64_t const *s) {
+    struct ls_amd_basis_ext *be = (struct ls_amd_basis_ext *)reg_get(basis);
+    if (!be) { set_error("unknown basis: create it with ls_hs_create_spin_basis or register it with ls_amd_adopt_basis"); return NULL; }
+    uint64_t *offx = NULL;
+    struct ls_amd_operator_ext *ext = build_operator_ext(basis->number_sites, basis->spin_inversion != 0, number_terms, v, m, r,
+                                                         x, s, &offx);
+    if (!ext) return NULL;
+    ls_hs_operator *op = (ls_hs_operator *)calloc(1, sizeof(*op));
+    reg_put(op, ext, REG_OPERATOR);
+    op->basis = (ls_hs_basis *)basis;
+    ++be->refcount;
     op->diag_terms = make_nbt(ext->diag, NULL, ext->n_diag, basis->number_sites);
     op->off_diag_terms = make_nbt(ext->off, offx, ext->n_off, basis->number_sites);
     free(offx);
-    free(raw);
     return op;
 }
 
+/* ---- foreign objects ------------------------------------------------------------------------ */
+/* A basis struct somebody else owns (e.g. built by lattice-symmetries-haskell): only the reference's prefix is read
+ * (number_sites, number_up = Hamming weight or -1, spin_inversion, representatives; FFI.chpl:94-105).  The symmetry
+ * group is not part of that prefix, so the caller passes the generators it built the basis from (the YAML's
+ * `symmetries`), in the convention of ls_hs_create_spin_basis. */
+int ls_amd_adopt_basis(ls_hs_basis const *basis, int number_generators, int const *permutations, int const *sectors) {
+    if (!basis) return set_error("null basis");
+    if (reg_get(basis)) return set_error("basis %p is already registered", (void const *)basis);
+    if (basis->particle_type != LS_HS_SPIN) return set_error("only spin bases are supported (DistributedMatrixVector.chpl works on spin configs)");
+    ls_hs_basis *tmp = ls_hs_create_spin_basis(basis->number_sites, basis->number_up >= 0 ? basis->number_up : -1, basis->spin_inversion,
+                                               number_generators, permutations, sectors);
+    if (!tmp) return -1;
+    if (tmp->requires_projection != basis->requires_projection) {
+        ls_hs_destroy_basis(tmp);
+        return set_error("generators do not reproduce the basis: requires_projection differs");
+    }
+    /* move the private part over to the foreign address */
+    struct ls_amd_basis_ext *e = (struct ls_amd_basis_ext *)reg_get(tmp);
+    reg_del(tmp);
+    free(tmp);
+    e->adopted = 1;
+    e->owns_representatives = 0;
+    reg_put(basis, e, REG_BASIS);
+    return 0;
+}
+/* An operator struct somebody else owns: the term tables are rebuilt from its off_diag_terms / diag_terms
+ * (ls_hs_nonbranching_terms, number_words == 1) and kept in the side table. */
+int ls_amd_adopt_operator(ls_hs_operator const *op) {
+    if (!op || !op->basis) return set_error("null operator");
+    if (reg_get(op)) return set_error("operator %p is already registered", (void const *)op);
+    if (!reg_get(op->basis)) return set_error("the operator's basis is unknown: ls_amd_adopt_basis first");
+    ls_hs_nonbranching_terms const *parts[2] = {op->diag_terms, op->off_diag_terms};
+    int n = 0;
+    for (int k = 0; k < 2; ++k)
+        if (parts[k]) {
+            if (parts[k]->number_bits > 64) return set_error("bases with more than 64 bits are not yet implemented"); /* DMV:1099 */
+            n += parts[k]->number_terms;
+        }
+    double *v = (double *)malloc(16 * (size_t)(n > 0 ? n : 1));
+    uint64_t *m = (uint64_t *)malloc(8 * (size_t)(n > 0 ? n : 1)), *r = (uint64_t *)malloc(8 * (size_t)(n > 0 ? n : 1)),
+             *x = (uint64_t *)malloc(8 * (size_t)(n > 0 ? n : 1)), *s = (uint64_t *)malloc(8 * (size_t)(n > 0 ? n : 1));
+    int k = 0;
+    for (int q = 0; q < 2; ++q)
+        for (int i = 0; parts[q] && i < parts[q]->number_terms; ++i, ++k) {
+            v[2 * k] = parts[q]->v[i].re; v[2 * k + 1] = parts[q]->v[i].im;
+            m[k] = parts[q]->m[i]; r[k] = parts[q]->r[i]; x[k] = parts[q]->x[i]; s[k] = parts[q]->s[i];
+        }
+    struct ls_amd_operator_ext *ext = build_operator_ext(op->basis->number_sites, op->basis->spin_inversion != 0, n, v, m, r, x, s, NULL);
+    free(v); free(m); free(r); free(x); free(s);
+    if (!ext) return -1;
+    ext->adopted = 1;
+    reg_put(op, ext, REG_OPERATOR);
+    ++BEXT(op->basis)->refcount;
+    return 0;
+}
+/* forget an adopted basis / operator (device tables are released; the foreign struct is not touched) */
+void ls_amd_release(void const *object) {
+    int kind = 0;
+    if (!reg_find(object, &kind)) return;
+    if (kind == REG_BASIS) ls_hs_destroy_basis((ls_hs_basis *)object);
+    else ls_hs_destroy_operator((ls_hs_operator *)object);
+}
+
 ls_hs_operator *ls_hs_clone_operator(ls_hs_operator const *op) {
-    struct ls_amd_operator_ext const *e = op->ext;
+    struct ls_amd_operator_ext const *e = OEXT(op);
     int n = e->n_diag + e->n_off;
     double *v = (double *)malloc(16 * (n > 0 ? n : 1));
     uint64_t *m = (uint64_t *)malloc(8 * (n > 0 ? n : 1)), *r = (uint64_t *)malloc(8 * (n > 0 ? n : 1)),
@@ -784,26 +965,28 @@ ls_hs_operator *ls_hs_clone_operator(ls_hs_operator const *op) {
 
 void ls_hs_destroy_operator(ls_hs_operator *op) {
     if (!op) return;
-    struct ls_amd_operator_ext *e = op->ext;
-    if (e) {
-        if (e->d_groups) lsk_free(e->d_groups);
-        if (e->d_off) lsk_free(e->d_off);
-        if (e->d_diag) lsk_free(e->d_diag);
-        free(e->groups); free(e->off); free(e->diag);
-        if (e->owns_basis) ls_hs_destroy_basis(op->basis);
-        free(e);
-    }
+    struct ls_amd_operator_ext *e = (struct ls_amd_operator_ext *)reg_get(op);
+    if (!e) return;
+    if (e->d_groups) lsk_free(e->d_groups);
+    if (e->d_off) lsk_free(e->d_off);
+    if (e->d_diag) lsk_free(e->d_diag);
+    free(e->groups); free(e->off); free(e->diag);
+    reg_del(op);
+    int const adopted = e->adopted;
+    free(e);
+    ls_hs_destroy_basis(op->basis); /* drops the operator's reference */
+    if (adopted) return;
     free_nbt(op->diag_terms);
     free_nbt(op->off_diag_terms);
     free(op);
 }
 
-int ls_hs_operator_max_number_off_diag(ls_hs_operator const *op) { return op->ext->n_groups; }
-bool ls_hs_operator_is_hermitian(ls_hs_operator const *op) { return op->ext->is_hermitian != 0; }
-bool ls_hs_operator_is_real(ls_hs_operator const *op) { return op->ext->is_real != 0; }
+int ls_hs_operator_max_number_off_diag(ls_hs_operator const *op) { return OEXT(op)->n_groups; }
+bool ls_hs_operator_is_hermitian(ls_hs_operator const *op) { return OEXT(op)->is_hermitian != 0; }
+bool ls_hs_operator_is_real(ls_hs_operator const *op) { return OEXT(op)->is_real != 0; }
 
 static int operator_device(ls_hs_operator const *op, lsk_operator *out) {
-    struct ls_amd_operator_ext *e = op->ext;
+    struct ls_amd_operator_ext *e = OEXT(op);
     if (!e->d_groups) {
         void *p;
         DEV(lsk_malloc(&p, sizeof(lsk_group) * (e->n_groups > 0 ? e->n_groups : 1)));
@@ -867,7 +1050,7 @@ void ls_hs_basis_build(ls_hs_basis *basis) {
     if (!arr.elts) return;
     basis_drop_device_caches(basis);
     basis->representatives = arr;
-    basis->ext->owns_representatives = 1;
+    BEXT(basis)->owns_representatives = 1;
 }
 
 /* ============================================================================================ */
@@ -1066,7 +1249,7 @@ void ls_amd_test_free(void *p) { free(p); }
  * symmetries, a real operator made of exchange runs plus at most two other exchange pairs.  LS_AMD_CHAIN=0 keeps k_direct. */
 static int chain_eligible(ls_amd_plan const *pl) {
     ls_hs_operator const *op = pl->op;
-    struct ls_amd_operator_ext const *ext = op->ext;
+    struct ls_amd_operator_ext const *ext = OEXT(op);
     char const *e = getenv("LS_AMD_CHAIN");
     if (e && atoi(e) == 0) return 0;
     if (op->basis->number_sites > 64 || op->basis->spin_inversion != 0 || pl->dbs.proj != LSK_PROJ_NONE ||
@@ -1084,7 +1267,7 @@ static int chain_eligible(ls_amd_plan const *pl) {
  * Leaves pl->has_chain == 0 (and no tile map) when a partner leaves the basis: k_direct reports that at run time,
  * as the reference does. */
 static int setup_chain(ls_amd_plan *pl, lsk_index index, int64_t n, uint64_t const *d_reps, void *stream) {
-    struct ls_amd_operator_ext const *ext = pl->op->ext;
+    struct ls_amd_operator_ext const *ext = OEXT(pl->op);
     int const nc = ext->n_groups - ext->runs.n_run_groups;
     /* ranks are 32-bit while the whole basis (index.count states: x is indexed by global rank) has < 2^32 - 1 states;
      * LS_AMD_CHAIN_WIDE=1 forces the 64-bit instantiation (test hook: no in-tree config is that large) */
@@ -1120,7 +1303,7 @@ static int setup_chain(ls_amd_plan *pl, lsk_index index, int64_t n, uint64_t con
 static int plan_setup_part(ls_amd_plan *pl, part_state *ps, int part_id, int num_rounds, void *stream) {
     ls_hs_basis const *b = pl->op->basis;
     int const L = b->number_sites;
-    int const h = b->ext->hamming_weight;
+    int const h = BEXT(b)->hamming_weight;
     uint64_t const *d_binom;
     if (device_binom(&d_binom) != 0) return -1;
     ps->index.count = ps->count;
@@ -1214,7 +1397,7 @@ int ls_amd_plan_create(ls_amd_plan **out, ls_hs_operator const *op, ls_amd_dtype
     if (ls_hs_basis_number_words(op->basis) != 1) return set_error("bases with more than 64 bits are not yet implemented"); /* DMV:1099 */
     if (num_partitions < 1 || num_partitions > LSK_MAX_PARTS) return set_error("num_partitions must be in [1, %d]", LSK_MAX_PARTS);
     if (my_partition >= num_partitions) return set_error("my_partition out of range");
-    if (dtype == LS_AMD_F64 && !op->ext->is_real) return set_error("an operator with complex coefficients needs dtype c128");
+    if (dtype == LS_AMD_F64 && !OEXT(op)->is_real) return set_error("an operator with complex coefficients needs dtype c128");
     ls_amd_plan *pl = (ls_amd_plan *)calloc(1, sizeof(*pl));
     pl->op = op;
     pl->cplx = dtype == LS_AMD_C128;
@@ -1224,8 +1407,8 @@ int ls_amd_plan_create(ls_amd_plan **out, ls_hs_operator const *op, ls_amd_dtype
     if (operator_device(op, &pl->dop) != 0 || basis_device(op->basis, &pl->dbs) != 0) { free(pl); return -1; }
     if (dtype == LS_AMD_F64) {
         /* f64 vectors: characters must be real as well (the reference casts c128 -> f64, DMV:91,109) */
-        for (int g = 0; g < op->basis->ext->order; ++g)
-            if (op->basis->ext->elems[g].ch_im != 0.0) { free(pl); return set_error("complex characters need dtype c128"); }
+        for (int g = 0; g < BEXT(op->basis)->order; ++g)
+            if (BEXT(op->basis)->elems[g].ch_im != 0.0) { free(pl); return set_error("complex characters need dtype c128"); }
     }
     /* kernel family */
     /* a plan that owns ONE partition is driven by generate / exchange / scatter (one locale per process): always the
@@ -1239,9 +1422,9 @@ int ls_amd_plan_create(ls_amd_plan **out, ls_hs_operator const *op, ls_amd_dtype
             char const *e = getenv("LS_AMD_MODE");
             if (e && strcmp(e, "pull") == 0) m = LS_AMD_MODE_PULL;
             else if (e && strcmp(e, "push") == 0) m = LS_AMD_MODE_PUSH;
-            else m = op->ext->is_hermitian ? LS_AMD_MODE_PULL : LS_AMD_MODE_PUSH; /* measured: pull is 2.6x push on chain_32 */
+            else m = OEXT(op)->is_hermitian ? LS_AMD_MODE_PULL : LS_AMD_MODE_PUSH; /* measured: pull is 2.6x push on chain_32 */
         }
-        if (m == LS_AMD_MODE_PULL && !op->ext->is_hermitian) {
+        if (m == LS_AMD_MODE_PULL && !OEXT(op)->is_hermitian) {
             if (mode == LS_AMD_MODE_PULL) { free(pl); return set_error("pull mode needs a Hermitian operator"); }
             m = LS_AMD_MODE_PUSH;
         }
@@ -1254,7 +1437,7 @@ int ls_amd_plan_create(ls_amd_plan **out, ls_hs_operator const *op, ls_amd_dtype
             if (e && strcmp(e, "push") == 0) m = LS_AMD_MODE_PUSH;
             else m = LS_AMD_MODE_PULL;
         }
-        if (m == LS_AMD_MODE_PULL && !op->ext->is_hermitian) {
+        if (m == LS_AMD_MODE_PULL && !OEXT(op)->is_hermitian) {
             if (mode == LS_AMD_MODE_PULL) { free(pl); return set_error("pull mode needs a Hermitian operator"); }
             m = LS_AMD_MODE_PUSH;
         }
@@ -1334,10 +1517,10 @@ int ls_amd_plan_create_replicated(ls_amd_plan **out, ls_hs_operator const *op, l
     *out = NULL;
     if (!op || !op->basis) return set_error("null operator");
     if (ls_hs_basis_number_words(op->basis) != 1) return set_error("bases with more than 64 bits are not yet implemented");
-    if (!op->ext->is_hermitian) return set_error("replicated-x (pull) plans need a Hermitian operator");
+    if (!OEXT(op)->is_hermitian) return set_error("replicated-x (pull) plans need a Hermitian operator");
     if (num_partitions < 1 || num_partitions > LSK_MAX_PARTS || my_partition < 0 || my_partition >= num_partitions)
         return set_error("bad partition arguments");
-    if (dtype == LS_AMD_F64 && !op->ext->is_real) return set_error("an operator with complex coefficients needs dtype c128");
+    if (dtype == LS_AMD_F64 && !OEXT(op)->is_real) return set_error("an operator with complex coefficients needs dtype c128");
     ls_amd_plan *pl = (ls_amd_plan *)calloc(1, sizeof(*pl));
     pl->op = op;
     pl->cplx = dtype == LS_AMD_C128;
@@ -1346,8 +1529,8 @@ int ls_amd_plan_create_replicated(ls_amd_plan **out, ls_hs_operator const *op, l
     pl->n_local = 1;
     if (operator_device(op, &pl->dop) != 0 || basis_device(op->basis, &pl->dbs) != 0) { free(pl); return -1; }
     if (dtype == LS_AMD_F64)
-        for (int g = 0; g < op->basis->ext->order; ++g)
-            if (op->basis->ext->elems[g].ch_im != 0.0) { free(pl); return set_error("complex characters need dtype c128"); }
+        for (int g = 0; g < BEXT(op->basis)->order; ++g)
+            if (BEXT(op->basis)->elems[g].ch_im != 0.0) { free(pl); return set_error("complex characters need dtype c128"); }
     pl->family = pl->dbs.proj == LSK_PROJ_FULL ? FAMILY_REPL_TILE : FAMILY_REPL_DIRECT;
     void *p;
     if (lsk_malloc(&p, sizeof(int)) != 0) { free(pl); return dev_error(); }
@@ -1574,7 +1757,7 @@ int ls_amd_plan_check(ls_amd_plan *pl, void *stream) {
 /* ============================================================================================ */
 static int64_t candidate_count(ls_hs_basis const *b) {
     int const Leff = b->number_sites - (b->spin_inversion != 0 ? 1 : 0);
-    int const h = b->ext->hamming_weight;
+    int const h = BEXT(b)->hamming_weight;
     if (h >= 0) return (int64_t)binom(Leff, h);
     if (Leff >= 62) return -1;
     return (int64_t)1 << Leff;
@@ -1633,7 +1816,7 @@ void ls_chpl_enumerate_representatives(ls_hs_basis *basisPtr, uint64_t lower, ui
 }
 
 static int ensure_device_reps(ls_hs_basis *b) {
-    struct ls_amd_basis_ext *e = b->ext;
+    struct ls_amd_basis_ext *e = BEXT(b);
     if (!b->representatives.elts) return set_error("basis is not built"); /* ForeignTypes.chpl:113-114 */
     if (e->d_reps_cache && e->d_reps_count == b->representatives.num_elts) return 0;
     basis_drop_device_caches(b);
@@ -1648,7 +1831,7 @@ static int ensure_device_reps(ls_hs_basis *b) {
 /* localMatrixVector on host vectors (numLocales == 1) */
 static int host_matvec_f64(ls_hs_operator *op, int64_t n, double const *x, double *y) {
     ls_hs_basis *b = op->basis;
-    struct ls_amd_basis_ext *e = b->ext;
+    struct ls_amd_basis_ext *e = BEXT(b);
     if (ensure_device_reps(b) != 0) return -1;
     if ((uint64_t)n != e->d_reps_count) return set_error("vector length does not match the number of representatives");
     ls_amd_comm *cm = ls_amd_default_comm();
@@ -1749,7 +1932,7 @@ void ls_chpl_operator_apply_off_diag(ls_hs_operator *matrixPtr, int64_t count, u
     (void)numTasks;
     if (ls_hs_basis_number_words(matrixPtr->basis) != 1) { halt_with("bases with more than 64 bits are not yet implemented"); return; }
     if (matrixPtr->basis->requires_projection) { halt_with("bases that require projection are not yet supported"); return; }
-    int const T = matrixPtr->ext->n_groups;
+    int const T = OEXT(matrixPtr)->n_groups;
     int64_t *h_off = (int64_t *)calloc((size_t)count + 1, sizeof(int64_t));
     if (T == 0) {
         betas->elts = NULL; betas->num_elts = 0; betas->freer = NULL;
@@ -1793,7 +1976,7 @@ static uint64_t *gather_u64(uint64_t const *src, ptrdiff_t n, ptrdiff_t stride) 
 void ls_hs_state_index(ls_hs_basis const *basis_c, ptrdiff_t n, uint64_t const *spins, ptrdiff_t sstride,
                        ptrdiff_t *indices, ptrdiff_t istride) {
     ls_hs_basis *b = (ls_hs_basis *)basis_c;
-    struct ls_amd_basis_ext *e = b->ext;
+    struct ls_amd_basis_ext *e = BEXT(b);
     if (n <= 0) return;
     if (ensure_device_reps(b) != 0) { halt_with("%s", g_last_error); return; }
     uint64_t const *d_binom;
@@ -1884,7 +2067,7 @@ void ls_internal_operator_apply_off_diag_x1(ls_hs_operator const *op, ptrdiff_t 
                                             double const *xs) {
     offsets[0] = 0;
     if (n <= 0) return;
-    int const T = op->ext->n_groups;
+    int const T = OEXT(op)->n_groups;
     if (T == 0) { for (ptrdiff_t i = 0; i <= n; ++i) offsets[i] = 0; return; }
     lsk_operator dop;
     if (operator_device(op, &dop) != 0) { halt_with("%s", g_last_error); return; }

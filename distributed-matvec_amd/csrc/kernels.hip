@@ -122,6 +122,20 @@ static int resident_grid(K kernel, int64_t work_blocks, size_t dyn_lds = 0, int 
     return (int)g;
 }
 
+// Grid of the staged (tile) kernels: one block per tile up to the whole tile count.  They walk rows with a plain grid
+// stride (no XCD tile lists), so nothing needs them to be persistent, and their 106 SGPRs put them where the occupancy
+// API over-reports the resident blocks by one (MI355X_MICROARCH.md): a CUs x API-answer grid runs a straggler round
+// with one block per CU.  LS_AMD_TILE_PERSISTENT=1 restores the resident-grid sizing (A/B measurements).
+template <typename K>
+static int tile_grid(K kernel, int64_t work_blocks) {
+    static int persistent = -1;
+    if (persistent < 0) { char const *e = getenv("LS_AMD_TILE_PERSISTENT"); persistent = e && atoi(e) != 0; }
+    if (persistent) return resident_grid(kernel, work_blocks);
+    if (work_blocks < 1) work_blocks = 1;
+    if (work_blocks > (int64_t)1 << 30) work_blocks = (int64_t)1 << 30;
+    return (int)work_blocks;
+}
+
 static inline int grid_for(int64_t n, int per_block = kBlock) {
     int64_t b = (n + per_block - 1) / per_block;
     if (b < 1) b = 1;
@@ -1366,11 +1380,11 @@ extern "C" int lsk_tile(lsk_operator op, lsk_basis bs, lsk_index ix, int cplx, i
 #define LSK_TILE_LAUNCH(W, PM1)                                                                            \
     do {                                                                                                   \
         if (cplx) {                                                                                        \
-            if (op.is_real) { g.x = resident_grid(k_tile<W, PM1, true, true>, work_blocks); hipLaunchKernelGGL((k_tile<W, PM1, true, true>), g, b, 0, s, LSK_TILE_ARGS); } \
-            else { g.x = resident_grid(k_tile<W, PM1, true, false>, work_blocks); hipLaunchKernelGGL((k_tile<W, PM1, true, false>), g, b, 0, s, LSK_TILE_ARGS); } \
+            if (op.is_real) { g.x = tile_grid(k_tile<W, PM1, true, true>, work_blocks); hipLaunchKernelGGL((k_tile<W, PM1, true, true>), g, b, 0, s, LSK_TILE_ARGS); } \
+            else { g.x = tile_grid(k_tile<W, PM1, true, false>, work_blocks); hipLaunchKernelGGL((k_tile<W, PM1, true, false>), g, b, 0, s, LSK_TILE_ARGS); } \
         } else {                                                                                           \
-            if (op.is_real) { g.x = resident_grid(k_tile<W, PM1, false, true>, work_blocks); hipLaunchKernelGGL((k_tile<W, PM1, false, true>), g, b, 0, s, LSK_TILE_ARGS); } \
-            else { g.x = resident_grid(k_tile<W, PM1, false, false>, work_blocks); hipLaunchKernelGGL((k_tile<W, PM1, false, false>), g, b, 0, s, LSK_TILE_ARGS); } \
+            if (op.is_real) { g.x = tile_grid(k_tile<W, PM1, false, true>, work_blocks); hipLaunchKernelGGL((k_tile<W, PM1, false, true>), g, b, 0, s, LSK_TILE_ARGS); } \
+            else { g.x = tile_grid(k_tile<W, PM1, false, false>, work_blocks); hipLaunchKernelGGL((k_tile<W, PM1, false, false>), g, b, 0, s, LSK_TILE_ARGS); } \
         }                                                                                                  \
     } while (0)
     const bool narrow = bs.number_sites <= 32 && bs.proj == LSK_PROJ_FULL;
@@ -1617,11 +1631,11 @@ extern "C" int lsk_tile_pull(lsk_operator op, lsk_basis bs, lsk_index ix_global,
 #define LSK_TP_LAUNCH(W, PM1)                                                                                   \
     do {                                                                                                        \
         if (cplx) {                                                                                             \
-            if (op.is_real) { g.x = resident_grid(k_tile_pull<W, PM1, true, true>, work_blocks); hipLaunchKernelGGL((k_tile_pull<W, PM1, true, true>), g, b, 0, s, LSK_TP_ARGS); } \
-            else { g.x = resident_grid(k_tile_pull<W, PM1, true, false>, work_blocks); hipLaunchKernelGGL((k_tile_pull<W, PM1, true, false>), g, b, 0, s, LSK_TP_ARGS); } \
+            if (op.is_real) { g.x = tile_grid(k_tile_pull<W, PM1, true, true>, work_blocks); hipLaunchKernelGGL((k_tile_pull<W, PM1, true, true>), g, b, 0, s, LSK_TP_ARGS); } \
+            else { g.x = tile_grid(k_tile_pull<W, PM1, true, false>, work_blocks); hipLaunchKernelGGL((k_tile_pull<W, PM1, true, false>), g, b, 0, s, LSK_TP_ARGS); } \
         } else {                                                                                                \
-            if (op.is_real) { g.x = resident_grid(k_tile_pull<W, PM1, false, true>, work_blocks); hipLaunchKernelGGL((k_tile_pull<W, PM1, false, true>), g, b, 0, s, LSK_TP_ARGS); } \
-            else { g.x = resident_grid(k_tile_pull<W, PM1, false, false>, work_blocks); hipLaunchKernelGGL((k_tile_pull<W, PM1, false, false>), g, b, 0, s, LSK_TP_ARGS); } \
+            if (op.is_real) { g.x = tile_grid(k_tile_pull<W, PM1, false, true>, work_blocks); hipLaunchKernelGGL((k_tile_pull<W, PM1, false, true>), g, b, 0, s, LSK_TP_ARGS); } \
+            else { g.x = tile_grid(k_tile_pull<W, PM1, false, false>, work_blocks); hipLaunchKernelGGL((k_tile_pull<W, PM1, false, false>), g, b, 0, s, LSK_TP_ARGS); } \
         }                                                                                                       \
     } while (0)
     if (bs.number_sites <= 32) { if (bs.chars_pm1) LSK_TP_LAUNCH(uint32_t, true); else LSK_TP_LAUNCH(uint32_t, false); }

@@ -199,7 +199,8 @@ def lanczos_smallest(op, num_evals: int = 1, eps: float = 1e-6, max_basis: int =
 def diagonalize(config, num_evals: int = 1, eps: float = 1e-6, num_partitions: int = 1, dtype=None, output: str | None = None,
                 max_basis: int = 24, verbose: bool = False):
     """`Diagonalize.main` (Diagonalize.chpl:258-332) on one device: config (dict or YAML path) ->
-    representatives (enumerated on the GPU, or reused from `output` like makeBasisStates :227-246) ->
+    representatives (enumerated on the GPU; an existing HDF5 `output` that already holds basis/representatives is
+    reused and extended, like makeBasisStates :227-246) ->
     eigenpairs; `output` (.npz) receives what the reference writes to its HDF5 groups:
     basis/representatives, hamiltonian/eigenvalues, hamiltonian/eigenvectors, hamiltonian/residuals."""
     import os
@@ -214,7 +215,17 @@ def diagonalize(config, num_evals: int = 1, eps: float = 1e-6, num_partitions: i
     else:
         basis, h = api.loadConfigFromDict(config, hamiltonian=True)
     dtype = dtype or torch.float64
-    reps, masks = api.enumerateStates(basis, num_partitions)
+    reps = None
+    if output and output.endswith((".h5", ".hdf5")) and num_partitions == 1:
+        # makeBasisStates (Diagonalize.chpl:227-246): representatives already stored in the output file are reused
+        from . import hdf5
+
+        if hdf5.has_dataset(output, "/basis/representatives"):
+            stored = hdf5.read_dataset(output, "/basis/representatives").astype(np.uint64)
+            reps = [torch.from_numpy(stored.view(np.int64).copy()).cuda()]
+            masks = torch.zeros(len(stored), dtype=torch.uint8, device="cuda")
+    if reps is None:
+        reps, masks = api.enumerateStates(basis, num_partitions)
     op = LocalOperator(h, reps, dtype)
     r = lanczos_smallest(op, num_evals=num_evals, eps=eps, max_basis=max_basis, verbose=verbose)
     if output and output.endswith((".h5", ".hdf5")):
@@ -225,7 +236,7 @@ def diagonalize(config, num_evals: int = 1, eps: float = 1e-6, num_partitions: i
         evecs = np.stack([to_block(v).cpu().numpy() for v in r.eigenvectors])
         if np.iscomplexobj(evecs):
             raise NotImplementedError("HDF5 output is implemented for real eigenvectors (the reference's eltType is real(64))")
-        hdf5.write_datasets(output, {
+        hdf5.write_datasets(output, append=True, datasets={
             "/basis/representatives": (api.arrFromHashedToBlock(reps, masks) if num_partitions > 1 else reps[0]).cpu().numpy().view(np.uint64),
             "/hamiltonian/eigenvalues": np.array(r.eigenvalues),
             "/hamiltonian/residuals": np.array(r.residual_norms),

@@ -18,7 +18,7 @@ import numpy as np
 _lib = None
 hid_t = C.c_int64
 hsize_t = C.c_uint64
-H5F_ACC_RDONLY, H5F_ACC_TRUNC = 0x0000, 0x0002
+H5F_ACC_RDONLY, H5F_ACC_RDWR, H5F_ACC_TRUNC = 0x0000, 0x0001, 0x0002
 H5P_DEFAULT = 0
 H5S_ALL = 0
 H5T_INTEGER, H5T_FLOAT = 0, 1
@@ -65,6 +65,7 @@ def lib():
         ("H5Gcreate2", hid_t, [hid_t, C.c_char_p, hid_t, hid_t, hid_t]),
         ("H5Gclose", C.c_int, [hid_t]),
         ("H5Lexists", C.c_int, [hid_t, C.c_char_p, hid_t]),
+        ("H5Ldelete", C.c_int, [hid_t, C.c_char_p, hid_t]),
     ]:
         fn = getattr(L, name)
         fn.restype, fn.argtypes = res, args
@@ -130,15 +131,50 @@ def read_dataset(path: str, name: str) -> np.ndarray:
         L.H5Fclose(f)
 
 
-def write_datasets(path: str, datasets: dict):
-    """creates `path` and writes every {"/group/name": array}; intermediate groups are created
-    (makeGroup + writeDataset, MyHDF5.chpl:288-333)."""
+def has_dataset(path: str, name: str) -> bool:
+    """doesObjectExist (MyHDF5.chpl) for a file that may not exist"""
+    import os
+
+    if not os.path.exists(path):
+        return False
     L = lib()
-    f = L.H5Fcreate(path.encode(), H5F_ACC_TRUNC, H5P_DEFAULT, H5P_DEFAULT)
+    f = L.H5Fopen(path.encode(), H5F_ACC_RDONLY, H5P_DEFAULT)
+    if f < 0:
+        return False
+    try:
+        prefix = ""
+        for g in [p for p in name.split("/") if p]:
+            prefix += "/" + g
+            if L.H5Lexists(f, prefix.encode(), H5P_DEFAULT) <= 0:
+                return False
+        return True
+    finally:
+        L.H5Fclose(f)
+
+
+def write_datasets(path: str, datasets: dict, append: bool = False):
+    """writes every {"/group/name": array}; intermediate groups are created (makeGroup + writeDataset,
+    MyHDF5.chpl:288-333).  append=False creates / truncates `path`; append=True opens an existing file read-write
+    and adds the datasets to it (the reference keeps basis/representatives in the output file and adds the
+    hamiltonian group later, Diagonalize.chpl:227-256); datasets that already exist are left as they are."""
+    import os
+
+    L = lib()
+    if append and os.path.exists(path):
+        f = L.H5Fopen(path.encode(), H5F_ACC_RDWR, H5P_DEFAULT)
+    else:
+        f = L.H5Fcreate(path.encode(), H5F_ACC_TRUNC, H5P_DEFAULT, H5P_DEFAULT)
     if f < 0:
         raise OSError(f"cannot create {path}")
     try:
         for name, arr in datasets.items():
+            if append:
+                comps = [p for p in name.split("/") if p]
+                exists = all(L.H5Lexists(f, ("/" + "/".join(comps[:k + 1])).encode(), H5P_DEFAULT) > 0 for k in range(len(comps)))
+                if exists and comps[0] == "basis":
+                    continue  # the stored basis is what this run was computed from
+                if exists and L.H5Ldelete(f, ("/" + "/".join(comps)).encode(), H5P_DEFAULT) < 0:
+                    raise OSError(f"cannot replace {name}")
             arr = np.ascontiguousarray(arr)
             if arr.dtype not in (np.float64, np.uint64, np.int64):
                 raise TypeError(f"{name}: only float64 / uint64 / int64 datasets are supported")

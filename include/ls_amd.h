@@ -57,6 +57,23 @@ uint64_t ls_amd_hash64_01(uint64_t x);
 int ls_amd_locale_idx_of(uint64_t basis_state, int num_locales);
 
 /* ------------------------------------------------------------------------------------------
+ * Objects built by somebody else (the real lattice-symmetries-haskell, /root/reference/src/FFI.chpl:94-119).
+ * This library keeps everything it knows beyond the reference's struct prefix in a side table keyed by the object's
+ * address, never in the struct: a foreign ls_hs_basis / ls_hs_operator only has to be registered once.
+ *   ls_amd_adopt_basis     reads number_sites, number_up (Hamming weight or -1), spin_inversion, requires_projection and
+ *                          `representatives` from the prefix; the symmetry generators are not part of the prefix and are
+ *                          passed in the convention of ls_hs_create_spin_basis (0 generators for an unsymmetrised basis)
+ *   ls_amd_adopt_operator  rebuilds the term / flip-mask-group tables from off_diag_terms / diag_terms
+ *                          (ls_hs_nonbranching_terms with number_bits <= 64); its basis must be known
+ *   ls_amd_release         forgets an adopted object and frees its tables (the foreign struct is left alone)
+ * After that every entry point (ls_chpl_matrix_vector_product, plans, ls_chpl_primme_matvec, ...) accepts the foreign
+ * pointers.  An unknown pointer halts with a message naming these functions.
+ */
+int ls_amd_adopt_basis(ls_hs_basis const *basis, int number_generators, int const *permutations, int const *sectors);
+int ls_amd_adopt_operator(ls_hs_operator const *op);
+void ls_amd_release(void const *object);
+
+/* ------------------------------------------------------------------------------------------
  * One locale per process / GPU: the inter-GPU exchange lives in the C host (RCCL over xGMI).
  *
  * Replaces /root/reference/src/DistributedMatrixVector.chpl:313-853 (GlobalPtrStore, _LocalBuffer /

@@ -39,7 +39,6 @@ typedef struct ls_hs_basis_kernels {
     void *state_index_data;
 } ls_hs_basis_kernels;
 
-struct ls_amd_basis_ext; /* symmetry group, device mirrors (private) */
 
 /* FFI.chpl:94-105 */
 typedef struct ls_hs_basis {
@@ -53,7 +52,6 @@ typedef struct ls_hs_basis {
     ls_hs_basis_kernels *kernels;
     chpl_external_array representatives;
     /* ... other stuff ... */
-    struct ls_amd_basis_ext *ext;
 } ls_hs_basis;
 
 /* FFI.chpl:109-113.  Term t acts on a basis state alpha as
@@ -72,7 +70,6 @@ typedef struct ls_hs_nonbranching_terms {
     uint64_t const *s;
 } ls_hs_nonbranching_terms;
 
-struct ls_amd_operator_ext;
 
 /* FFI.chpl:114-119 */
 typedef struct ls_hs_operator {
@@ -80,7 +77,6 @@ typedef struct ls_hs_operator {
     ls_hs_nonbranching_terms *off_diag_terms;
     ls_hs_nonbranching_terms *diag_terms;
     /* ... other stuff ... */
-    struct ls_amd_operator_ext *ext;
 } ls_hs_operator;
 
 /* FFI.chpl:233-239 */

@@ -83,3 +83,45 @@ def test_diagonalize_writes_reference_style_hdf5(tmp_path):
     assert abs(hdf5.read_dataset(out, "/hamiltonian/eigenvalues")[0] - (-18.061785417968)) < 1e-8
     assert hdf5.read_dataset(out, "/basis/representatives").shape == (126,)
     assert hdf5.dataset_shape(out, "/hamiltonian/eigenvectors") == (1, 126)
+
+
+def test_append_keeps_the_stored_basis_and_replaces_results(tmp_path):
+    """the reference's output file is opened read-write and extended (Diagonalize.chpl:227-256): an existing
+    basis/representatives survives, hamiltonian/* is replaced"""
+    hdf5 = _hdf5()
+    path = str(tmp_path / "out.h5")
+    reps = np.arange(5, dtype=np.uint64)
+    hdf5.write_datasets(path, {"/basis/representatives": reps, "/hamiltonian/eigenvalues": np.array([1.0])})
+    assert hdf5.has_dataset(path, "/basis/representatives") and not hdf5.has_dataset(path, "/hamiltonian/residuals")
+    assert not hdf5.has_dataset(str(tmp_path / "missing.h5"), "/basis/representatives")
+    hdf5.write_datasets(path, append=True, datasets={"/basis/representatives": np.arange(7, dtype=np.uint64),
+                                                     "/hamiltonian/eigenvalues": np.array([-2.0, 3.0]),
+                                                     "/hamiltonian/residuals": np.array([1e-9])})
+    assert np.array_equal(hdf5.read_dataset(path, "/basis/representatives"), reps)
+    assert np.array_equal(hdf5.read_dataset(path, "/hamiltonian/eigenvalues"), [-2.0, 3.0])
+    assert np.array_equal(hdf5.read_dataset(path, "/hamiltonian/residuals"), [1e-9])
+
+
+@pytest.mark.gpu
+def test_diagonalize_reuses_stored_representatives(tmp_path):
+    """makeBasisStates (Diagonalize.chpl:227-246): representatives found in the output file are not re-enumerated"""
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.fail("needs a HIP device")
+    hdf5 = _hdf5()
+    from distributed_matvec_amd import api
+    from distributed_matvec_amd.diagonalize import diagonalize
+
+    out = str(tmp_path / "ed.h5")
+    r1 = diagonalize(model_config("heisenberg_chain_10"), num_evals=1, eps=1e-10, output=out)
+    calls = []
+    orig = api.enumerateStates
+    api.enumerateStates = lambda *a, **k: calls.append(1) or orig(*a, **k)
+    try:
+        r2 = diagonalize(model_config("heisenberg_chain_10"), num_evals=1, eps=1e-10, output=out)
+    finally:
+        api.enumerateStates = orig
+    assert not calls, "stored representatives were re-enumerated"
+    assert abs(r1.eigenvalues[0] - r2.eigenvalues[0]) < 1e-9
+    assert hdf5.read_dataset(out, "/basis/representatives").shape == (126,)

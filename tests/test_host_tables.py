@@ -332,3 +332,90 @@ def test_tile_map_is_a_partition_of_the_rows(n, tile, chunk):
         for k in range(8):
             q = (lists[k][cnt.reshape(8, -1)[k] > 0] // np.uint64(tile)).astype(np.int64)
             assert np.all((q // chunk) % 8 == k) and np.all(np.diff(q) > 0)
+
+
+class _ForeignBasis(C.Structure):
+    """exactly the reference's struct prefix (/root/reference/src/FFI.chpl:94-105) followed by bytes that are NOT
+    this library's: what an ls_hs_basis built by lattice-symmetries-haskell looks like from here"""
+    _fields_ = _lib.LsHsBasis._fields_ + [("other_stuff", C.c_uint8 * 64)]
+
+
+class _ForeignOperator(C.Structure):
+    _fields_ = [("basis", C.POINTER(_ForeignBasis)), ("off_diag_terms", C.POINTER(_lib.LsHsNonbranchingTerms)),
+                ("diag_terms", C.POINTER(_lib.LsHsNonbranchingTerms)), ("other_stuff", C.c_uint8 * 64)]
+
+
+def _foreign_copy(name):
+    """(foreign basis, foreign operator, keep-alive) built from one of this library's operators by copying ONLY the
+    prefix fields and the public term arrays; the trailing bytes are poisoned"""
+    import distributed_matvec_amd as D
+
+    basis, h = D.loadConfigFromDict(model_config(name), hamiltonian=True)
+    src = basis.payload.contents
+    fb = _ForeignBasis()
+    for f, _ in _lib.LsHsBasis._fields_:
+        setattr(fb, f, getattr(src, f))
+    fb.kernels = None
+    fb.representatives = _lib.ChplExternalArray(None, 0, None)
+    C.memset(C.addressof(fb) + _ForeignBasis.other_stuff.offset, 0xAB, 64)
+    fo = _ForeignOperator()
+    fo.basis = C.pointer(fb)
+    fo.off_diag_terms = h.payload.contents.off_diag_terms
+    fo.diag_terms = h.payload.contents.diag_terms
+    C.memset(C.addressof(fo) + _ForeignOperator.other_stuff.offset, 0xCD, 64)
+    return fb, fo, (basis, h)
+
+
+@pytest.mark.parametrize("name", ["heisenberg_chain_10", "heisenberg_chain_12", "heisenberg_kagome_12_symm", "heisenberg_chain_24_symm"])
+def test_adopt_foreign_operator_rebuilds_the_tables(name):
+    """ls_amd_adopt_basis / ls_amd_adopt_operator (include/ls_amd.h): a struct WITHOUT any private field of ours is
+    registered in the side table, and the rebuilt tables answer like the original operator's"""
+    lib = _lib.load()
+    fb, fo, (basis, h) = _foreign_copy(name)
+    spec = basis.spec
+    ng = len(spec.permutations)
+    perms = (C.c_int * max(1, ng * spec.number_sites))(*[v for p in spec.permutations for v in p])
+    sectors = (C.c_int * max(1, ng))(*spec.sectors)
+    bp = C.cast(C.pointer(fb), C.POINTER(_lib.LsHsBasis))
+    op = C.cast(C.pointer(fo), C.POINTER(_lib.LsHsOperator))
+    # unknown objects are refused loudly
+    _lib._pending_halt.clear()
+    lib.ls_hs_basis_has_permutation_symmetries(bp)
+    with pytest.raises(_lib.LsAmdError, match="ls_amd_adopt_basis"):
+        _lib.raise_pending_halt()
+    assert lib.ls_amd_adopt_operator(op) != 0 and b"ls_amd_adopt_basis" in lib.ls_amd_last_error()
+    assert lib.ls_amd_adopt_basis(bp, ng, perms, sectors) == 0, lib.ls_amd_last_error()
+    assert lib.ls_amd_adopt_basis(bp, ng, perms, sectors) != 0  # twice is an error
+    assert lib.ls_amd_adopt_operator(op) == 0, lib.ls_amd_last_error()
+    assert lib.ls_amd_basis_group_order(bp) == lib.ls_amd_basis_group_order(basis.payload)
+    assert lib.ls_hs_basis_has_permutation_symmetries(bp) == lib.ls_hs_basis_has_permutation_symmetries(basis.payload)
+    assert lib.ls_hs_operator_max_number_off_diag(op) == h.numberOffDiagTerms()
+    assert bool(lib.ls_hs_operator_is_hermitian(op)) == h.isHermitian and bool(lib.ls_hs_operator_is_real(op)) == h.isReal
+    # the poisoned tail was never touched
+    assert bytes(fb.other_stuff) == b"\xab" * 64 and bytes(fo.other_stuff) == b"\xcd" * 64
+    lib.ls_amd_release(C.cast(op, C.c_void_p))
+    lib.ls_amd_release(C.cast(bp, C.c_void_p))
+    _lib._pending_halt.clear()
+    lib.ls_hs_operator_is_real(op)
+    with pytest.raises(_lib.LsAmdError, match="ls_amd_adopt_operator"):
+        _lib.raise_pending_halt()
+
+
+def test_operator_shares_its_basis():
+    """the operator holds a reference to the basis it was built on (no clone): representatives set on the basis
+    afterwards are the operator's, and the basis outlives its Python owner while an operator uses it"""
+    import gc
+
+    import distributed_matvec_amd as D
+
+    basis, h = D.loadConfigFromDict(model_config("heisenberg_chain_10"), hamiltonian=True)
+    assert C.addressof(h.payload.contents.basis.contents) == C.addressof(basis.payload.contents)
+    reps = np.array([31, 47, 55], dtype=np.uint64)
+    basis.uncheckedSetRepresentatives(reps)
+    assert h.basis.representatives().tolist() == [31, 47, 55]
+    addr = C.addressof(basis.payload.contents)
+    keep = basis._host_reps
+    del basis
+    gc.collect()
+    assert C.addressof(h.payload.contents.basis.contents) == addr and h.basis.numberSites() == 10
+    assert keep is not None
