@@ -374,7 +374,11 @@ def main():
         }
         if cpu:
             out["gpu_over_cpu"] = value / cpu["value"]
-        print(json.dumps(out))
+        # RCCL prints its version banner through C stdio, which would otherwise be flushed at exit, AFTER the JSON line
+        import ctypes
+
+        ctypes.CDLL(None).fflush(None)
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

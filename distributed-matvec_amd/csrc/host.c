@@ -1097,6 +1097,7 @@ struct ls_amd_plan {
     int chain_cached;      /* leading non-adjacent exchange groups whose partner ranks are cached */
     void *d_chain_cache;   /* [chain_cached][count] u32, or u64 when chain_wide */
     int chain_wide;        /* 64-bit ranks (>= 2^32 - 1 states) */
+    uint64_t *d_chain_rec; /* fused records (lsk_chain_pack) replacing reps + the first cached pair */
     double chain_v[2];
     int64_t chain_row0; /* global rank of the first local row (replicated-x plans) */
     void *d_htab;        /* hash table {rep -> x * norm(rep)} of the tile-pull families */
@@ -1223,10 +1224,11 @@ static int tilemap_host(int64_t n, int TILE, int64_t chunk, uint64_t **out, int6
 static int build_tilemap(ls_amd_plan *pl, int64_t n, int TILE) {
     uint64_t *flat = NULL;
     int64_t slots = 0;
-    /* Default for the staged kernel: chunks of 32 tiles -- measured on chain_32 (gpurun_out/r2/ablate_sweep.log):
-     * 11.09 ms contiguous, 10.87 / 10.70 / 10.60 / 10.59 / 10.59 ms at 8 / 16 / 32 / 64 / 128 */
+    /* Default for the staged kernel: chunks of 256 tiles -- measured on chain_32 with one block per tile
+     * (gpurun_out/r2: 9.35 ms contiguous eighths, 8.98 / 8.56 / 8.47 / 8.47 / 8.49 / 8.53 / 8.85 / 9.83 ms at
+     * 4 / 32 / 128 / 256 / 512 / 1024 / 4096 / 16384) */
     char const *e = getenv("LS_AMD_TILE_CHUNK");
-    int64_t const chunk = e ? atoll(e) : (TILE >= 512 ? 32 : 0);
+    int64_t const chunk = e ? atoll(e) : (TILE >= 512 ? 256 : 0);
     if (tilemap_host(n, TILE, chunk > 0 ? chunk : 0, &flat, &slots) < 0) return -1;
     int const up = upload(&pl->d_tilemap, flat, sizeof(uint64_t) * (size_t)(8 * slots > 0 ? 8 * slots : 1));
     free(flat);
@@ -1296,6 +1298,19 @@ static int setup_chain(ls_amd_plan *pl, lsk_index index, int64_t n, uint64_t con
         pl->chain_v[1] = nc > 1 ? ext->groups[ext->runs.n_run_groups + 1].v_re : 0.0;
     }
     if (build_tilemap(pl, n, lsk_chain_tile_rows(pl->cplx)) != 0) return -1;
+    /* 32-bit states and ranks, at most one cached pair: fuse state and partner rank into one 8-byte record per row
+     * (8 instead of 8 + 4 bytes per row from HBM, one load instead of two); LS_AMD_CHAIN_REC=0 keeps the two arrays */
+    char const *er = getenv("LS_AMD_CHAIN_REC");
+    /* f64 only: measured on chain_32 8.59 -> 8.41 ms (f64) but 15.40 -> 15.70 ms (c128) */
+    if (!pl->cplx && pl->op->basis->number_sites <= 32 && !pl->chain_wide && pl->chain_cached <= 1 && n > 0 && !(er && atoi(er) == 0)) {
+        void *q;
+        if (lsk_malloc(&q, sizeof(uint64_t) * (size_t)n) == 0) {
+            DEV(lsk_chain_pack(n, d_reps, pl->chain_cached ? pl->d_chain_cache : NULL, (uint64_t *)q, stream));
+            DEV(lsk_sync(stream));
+            pl->d_chain_rec = (uint64_t *)q;
+            if (pl->d_chain_cache) { lsk_free(pl->d_chain_cache); pl->d_chain_cache = NULL; }
+        }
+    }
     pl->has_chain = 1;
     return 0;
 }
@@ -1495,6 +1510,7 @@ void ls_amd_plan_destroy(ls_amd_plan *pl) {
     if (pl->d_norms_global) lsk_free(pl->d_norms_global);
     if (pl->d_tilemap) lsk_free(pl->d_tilemap);
     if (pl->d_chain_cache) lsk_free(pl->d_chain_cache);
+    if (pl->d_chain_rec) lsk_free(pl->d_chain_rec);
     if (pl->d_htab) lsk_free(pl->d_htab);
     if (pl->d_slot_of) lsk_free(pl->d_slot_of);
     if (pl->d_send) lsk_free(pl->d_send);
@@ -1596,9 +1612,9 @@ int ls_amd_matvec_replicated(ls_amd_plan *pl, void const *d_x_global, void *d_y_
     if (pl->family == FAMILY_REPL_DIRECT) {
         slot = timing_begin(pl, stream);
         if (pl->has_chain)
-            DEV(lsk_chain(pl->dop, pl->dbs, pl->gindex, pl->cplx, pl->chain_wide, pl->tilemap, ps->count, ps->d_reps,
-                          pl->chain_row0, pl->gindex.count, d_x_global, d_y_local, pl->chain_cached, pl->d_chain_cache,
-                          pl->chain_v[0], pl->chain_v[1], stream));
+            DEV(lsk_chain(pl->dop, pl->dbs, pl->gindex, pl->cplx, pl->chain_wide, pl->d_chain_rec != NULL, pl->tilemap, ps->count,
+                          pl->d_chain_rec ? pl->d_chain_rec : ps->d_reps, pl->chain_row0, pl->gindex.count, d_x_global, d_y_local,
+                          pl->chain_cached, pl->d_chain_cache, pl->chain_v[0], pl->chain_v[1], stream));
         else
             DEV(lsk_direct_gx(pl->dop, pl->dbs, pl->gindex, pl->cplx, pl->tilemap, ps->d_reps, pl->d_row_gidx, d_x_global,
                           d_y_local, pl->d_err, stream));
@@ -1712,9 +1728,9 @@ int ls_amd_matvec(ls_amd_plan *pl, void const *const *d_x, void *const *d_y, voi
         part_state *ps = &pl->parts[0];
         int slot = timing_begin(pl, stream);
         if (pl->has_chain)
-            DEV(lsk_chain(pl->dop, pl->dbs, ps->index, pl->cplx, pl->chain_wide, pl->tilemap, ps->count, ps->d_reps, 0,
-                          ps->count, d_x[0], d_y[0], pl->chain_cached, pl->d_chain_cache, pl->chain_v[0], pl->chain_v[1],
-                          stream));
+            DEV(lsk_chain(pl->dop, pl->dbs, ps->index, pl->cplx, pl->chain_wide, pl->d_chain_rec != NULL, pl->tilemap, ps->count,
+                          pl->d_chain_rec ? pl->d_chain_rec : ps->d_reps, 0, ps->count, d_x[0], d_y[0], pl->chain_cached,
+                          pl->d_chain_cache, pl->chain_v[0], pl->chain_v[1], stream));
         else
             DEV(lsk_direct(pl->dop, pl->dbs, ps->index, pl->cplx, pl->family == FAMILY_DIRECT_PULL, pl->tilemap, ps->d_reps,
                            d_x[0], d_y[0], pl->d_err, stream));

@@ -820,7 +820,7 @@ static int launch_direct3(lsk_operator op, lsk_basis bs, lsk_index ix, lsk_tilem
     if (blocks_per_cu > 0 && (int64_t)blocks_per_cu * g_num_cus < cap) cap = (int64_t)blocks_per_cu * g_num_cus;
     cap &= ~(int64_t)7; // XCD dealing needs a multiple of 8
     if (cap < 8) cap = 8;
-    if (gb > cap) gb = cap;
+    if (gb > cap) gb = cap; // persistent: one block per 256-row tile costs more than it gains here (13.3 -> 15.5 ms on chain_32)
     dim3 g((unsigned)gb), b(kBlock);
     gx = (gx & 1) | (high_pair_setting(14) << 24);
     if (op.is_real)
@@ -952,9 +952,9 @@ constexpr int kChainFarC = 6; // complex: 6 x 16 bytes in flight per lane
 // launch bounds, second argument = waves per SIMD the register allocation must allow.  256-thread blocks are admitted per CU
 // up to floor(800 / (ceil(sgpr / 16) * 16 + 16)): at 98 SGPRs the 7th block does not fit while the occupancy API still
 // answers 7 -- a straggler round of blocks, measured +24 % (13.1 vs 10.7 ms on chain_32)
-template <typename W, typename R, bool CPLX, int TILE>
+template <typename W, typename R, bool CPLX, int TILE, bool REC>
 __global__ __launch_bounds__(kBlock, (CPLX ? 4 : 8)) void k_chain_t(lsk_runs runs, int n_diag, lsk_term const *__restrict__ diag,
-                                                    int hamming_weight, uint64_t const *__restrict__ g_binom,
+                                                    int hamming_weight, R const *__restrict__ g_binom,
                                                     uint64_t const *__restrict__ tilemap, int64_t slots_per_xcd, int64_t n,
                                                     uint64_t const *__restrict__ reps, void const *__restrict__ x_v,
                                                     void *__restrict__ y_v, int hb, int n_cached,
@@ -968,9 +968,17 @@ __global__ __launch_bounds__(kBlock, (CPLX ? 4 : 8)) void k_chain_t(lsk_runs run
     constexpr R kNone = ~(R)0;
     X const *__restrict__ x = (X const *)x_v;
     X *__restrict__ y = (X *)y_v;
-    __shared__ R s_binom[NB * LSK_BINOM_K];
+    __shared__ __attribute__((aligned(16))) R s_binom[NB * LSK_BINOM_K];
     __shared__ X s_x[WINDOW + 1]; // last slot: 0, read by the lanes whose near pair is aligned
-    for (int k = threadIdx.x; k < NB * LSK_BINOM_K; k += blockDim.x) s_binom[k] = (R)g_binom[k];
+    {
+        // the binomial table (already in the rank type: lsk_chain narrows it once) with 16-byte loads: one block per tile
+        // means this runs once per 1024 rows
+        constexpr int N16 = NB * LSK_BINOM_K * (int)sizeof(R) / 16;
+        static_assert(NB * LSK_BINOM_K * sizeof(R) % 16 == 0, "table size");
+        uint4 const *src = reinterpret_cast<uint4 const *>(g_binom);
+        uint4 *dst = reinterpret_cast<uint4 *>(s_binom);
+        for (int k = threadIdx.x; k < N16; k += kBlock) dst[k] = src[k];
+    }
     if (threadIdx.x == 0) s_x[WINDOW] = cx_zero<X>();
     const int xcd = blockIdx.x & 7;
     const int64_t blocks_per_xcd = gridDim.x >> 3;
@@ -985,18 +993,27 @@ __global__ __launch_bounds__(kBlock, (CPLX ? 4 : 8)) void k_chain_t(lsk_runs run
         const int64_t w0 = (row0 + i0 - kChainHalo) & ~(int64_t)1; // first row of the window (even; may be < 0)
         W a_next = 0;
         R t0_next = kNone, t1_next = kNone;
-        auto load_state = [&](int64_t row) -> W {
-            if (sizeof(W) == 4) return (W)__builtin_nontemporal_load(reps32 + 2 * row); // low word only
-            return (W)__builtin_nontemporal_load(reps + row);
+        // REC: `reps` is the plan's fused record array, row -> sigma (low word) | partner rank of the first cached pair
+        // (high word, ~0 = none): one 8-byte load per row instead of a 4-byte state and a 4-byte cache load
+        auto load_row = [&](int64_t row, W &a_out, R &t0_out, R &t1_out) {
+            if (REC) {
+                const uint64_t rec = __builtin_nontemporal_load(reps + row);
+                a_out = (W)(uint32_t)rec;
+                t0_out = (R)(uint32_t)(rec >> 32);
+                if (n_cached == 0) t0_out = kNone;
+            } else {
+                if (sizeof(W) == 4) a_out = (W)__builtin_nontemporal_load(reps32 + 2 * row); // low word only
+                else a_out = (W)__builtin_nontemporal_load(reps + row);
+                if (n_cached > 0) t0_out = __builtin_nontemporal_load(cache + row);
+            }
+            if (n_cached > 1) t1_out = __builtin_nontemporal_load(cache + (size_t)n + (size_t)row);
         };
         // Lanes past the end of a partial tile stay ACTIVE as ghosts of the tile's last row (they recompute it and
         // store nothing): the far pairs are priced lane-parallel, which needs every lane of a live wave.
         const int wave0 = (int)(threadIdx.x & ~63u);
         if (wave0 < cnt) { // first row of this thread: requested before the window is staged
             const int64_t rr = i0 + ((int)threadIdx.x < cnt ? (int)threadIdx.x : cnt - 1);
-            a_next = load_state(rr);
-            if (n_cached > 0) t0_next = __builtin_nontemporal_load(cache + rr);
-            if (n_cached > 1) t1_next = __builtin_nontemporal_load(cache + (size_t)n + (size_t)rr);
+            load_row(rr, a_next, t0_next, t1_next);
         }
         __syncthreads(); // every wave is done with the previous window (and s_binom is loaded)
         if (CPLX) {
@@ -1029,9 +1046,7 @@ __global__ __launch_bounds__(kBlock, (CPLX ? 4 : 8)) void k_chain_t(lsk_runs run
             const R t0 = t0_next, t1 = t1_next;
             if (sub + 1 < TILE / kBlock && (sub + 1) * kBlock + wave0 < cnt) {
                 const int64_t in = i0 + (r + kBlock < cnt ? r + kBlock : cnt - 1);
-                a_next = load_state(in);
-                if (n_cached > 0) t0_next = __builtin_nontemporal_load(cache + in);
-                if (n_cached > 1) t1_next = __builtin_nontemporal_load(cache + (size_t)n + (size_t)in);
+                load_row(in, a_next, t0_next, t1_next);
             }
             if (sub * kBlock + wave0 >= cnt) continue; // wave-uniform: the whole wave is past the end
             const bool ghost = r >= cnt;
@@ -1169,12 +1184,42 @@ extern "C" int lsk_chain_cache(lsk_basis bs, lsk_index ix, int64_t n, uint64_t c
     return 0;
 }
 
-template <typename W, typename R, bool CPLX, int TILE>
+// fused per-row record of the 32-bit instantiation: sigma | partner rank << 32 (see k_chain_t, REC)
+__global__ __launch_bounds__(kBlock) void k_chain_pack(int64_t n, uint64_t const *__restrict__ reps,
+                                                       uint32_t const *__restrict__ cache, uint64_t *__restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+        out[i] = (uint64_t)(uint32_t)reps[i] | ((uint64_t)(cache ? cache[i] : 0xffffffffu) << 32);
+}
+extern "C" int lsk_chain_pack(int64_t n, uint64_t const *reps, void const *cache, uint64_t *out, void *stream) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_chain_pack, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, n, reps, (uint32_t const *)cache, out);
+    LSK_LAUNCH_CHECK();
+    return 0;
+}
+
+// binomial table in the rank type of the staged kernel: the u64 table as it is, or a u32 copy made once per device table
+__global__ void k_binom_narrow(uint64_t const *__restrict__ in, uint32_t *__restrict__ out, int n) {
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) out[k] = (uint32_t)in[k];
+}
+template <typename R> static R const *chain_binom(uint64_t const *g_binom, hipStream_t stream);
+template <> uint64_t const *chain_binom<uint64_t>(uint64_t const *g_binom, hipStream_t) { return g_binom; }
+template <> uint32_t const *chain_binom<uint32_t>(uint64_t const *g_binom, hipStream_t stream) {
+    static uint64_t const *src = nullptr;
+    static uint32_t *narrow = nullptr;
+    if (src != g_binom || !narrow) {
+        if (!narrow && hipMalloc((void **)&narrow, sizeof(uint32_t) * 64 * LSK_BINOM_K) != hipSuccess) return nullptr;
+        hipLaunchKernelGGL(k_binom_narrow, dim3(4), dim3(kBlock), 0, stream, g_binom, narrow, 64 * LSK_BINOM_K);
+        src = g_binom;
+    }
+    return narrow;
+}
+
+template <typename W, typename R, bool CPLX, int TILE, bool REC>
 static int launch_chain(lsk_operator op, lsk_basis bs, lsk_index ix, lsk_tilemap tm, int64_t n, uint64_t const *reps,
                         int64_t row0, int64_t n_x, void const *x, void *y, int n_cached, void const *cache, double cv0,
                         double cv1, void *stream) {
     int64_t gb = tm.slots_per_xcd * 8;
-    int64_t cap = resident_grid(k_chain_t<W, R, CPLX, TILE>, gb);
+    int64_t cap = resident_grid(k_chain_t<W, R, CPLX, TILE, REC>, gb);
     {
         char const *e = getenv("LS_AMD_BLOCKS_PER_CU"); // occupancy experiments
         int const bpc = e ? atoi(e) : 0;
@@ -1182,18 +1227,27 @@ static int launch_chain(lsk_operator op, lsk_basis bs, lsk_index ix, lsk_tilemap
     }
     cap &= ~(int64_t)7;
     if (cap < 8) cap = 8;
+    // One block per tile by default (block b -> tile b / 8 of XCD list b % 8), NOT a persistent grid: measured on chain_32
+    // 8.47 vs 10.85 ms (f64) and 15.7 vs 20.8 ms (c128).  Persistent blocks start together and stay phase-locked (window
+    // load, LDS pairs, far gathers), so the phases' costs add up; blocks dispatched one by one as others retire drift
+    // apart and the memory phases of some overlap the LDS / ALU phases of others.  LS_AMD_CHAIN_FULLGRID=0: persistent.
+    { char const *e = getenv("LS_AMD_CHAIN_FULLGRID"); if (!e || atoi(e) != 0) cap = gb; }
     if (gb > cap) gb = cap;
-    hipLaunchKernelGGL((k_chain_t<W, R, CPLX, TILE>), dim3((unsigned)gb), dim3(kBlock), 0, (hipStream_t)stream, op.runs,
-                       op.n_diag, op.diag, bs.hamming_weight, ix.binom, tm.entries, tm.slots_per_xcd, n, reps, x, y,
+    R const *binom_r = chain_binom<R>(ix.binom, (hipStream_t)stream);
+    if (!binom_r) { snprintf(g_err, sizeof(g_err), "lsk_chain: no memory for the narrow binomial table"); return -1; }
+    hipLaunchKernelGGL((k_chain_t<W, R, CPLX, TILE, REC>), dim3((unsigned)gb), dim3(kBlock), 0, (hipStream_t)stream, op.runs,
+                       op.n_diag, op.diag, bs.hamming_weight, binom_r, tm.entries, tm.slots_per_xcd, n, reps, x, y,
                        high_pair_setting(kChainLdsPairs), n_cached, (R const *)cache, cv0, cv1, row0, n_x);
     LSK_LAUNCH_CHECK();
     return 0;
 }
 
+// rows per tile: 1024 (f64) / 512 (c128).  Measured r2 on chain_32: doubling them (fewer blocks, 1.5x instead of 2x window
+// loads, but 5 instead of 7 blocks per CU) is slower, 8.72 vs 8.26 ms (f64), 15.5 vs 15.4 ms (c128).
 extern "C" int lsk_chain_tile_rows(int cplx) { return cplx ? 512 : 1024; }
 
-extern "C" int lsk_chain(lsk_operator op, lsk_basis bs, lsk_index ix, int cplx, int wide_ranks, lsk_tilemap tm, int64_t n,
-                         uint64_t const *reps, int64_t row0, int64_t n_x, void const *x, void *y, int n_cached,
+extern "C" int lsk_chain(lsk_operator op, lsk_basis bs, lsk_index ix, int cplx, int wide_ranks, int fused_records, lsk_tilemap tm,
+                         int64_t n, uint64_t const *reps, int64_t row0, int64_t n_x, void const *x, void *y, int n_cached,
                          void const *cache, double cv0, double cv1, void *stream) {
     if (n == 0 || tm.slots_per_xcd == 0) return 0;
     {
@@ -1212,9 +1266,13 @@ extern "C" int lsk_chain(lsk_operator op, lsk_basis bs, lsk_index ix, int cplx, 
     }
     const bool narrow = bs.number_sites <= 32 && !wide_ranks;
 #define LSK_CHAIN_ARGS op, bs, ix, tm, n, reps, row0, n_x, x, y, n_cached, cache, cv0, cv1, stream
-    if (narrow) return cplx ? launch_chain<uint32_t, uint32_t, true, 512>(LSK_CHAIN_ARGS) : launch_chain<uint32_t, uint32_t, false, 1024>(LSK_CHAIN_ARGS);
-    if (!wide_ranks) return cplx ? launch_chain<uint64_t, uint32_t, true, 512>(LSK_CHAIN_ARGS) : launch_chain<uint64_t, uint32_t, false, 1024>(LSK_CHAIN_ARGS);
-    return cplx ? launch_chain<uint64_t, uint64_t, true, 512>(LSK_CHAIN_ARGS) : launch_chain<uint64_t, uint64_t, false, 1024>(LSK_CHAIN_ARGS);
+    if (fused_records) { // `reps` is the record array made by lsk_chain_pack (32-bit states and ranks only)
+        if (!narrow) { snprintf(g_err, sizeof(g_err), "lsk_chain: fused records need 32-bit states and ranks"); return -1; }
+        return cplx ? launch_chain<uint32_t, uint32_t, true, 512, true>(LSK_CHAIN_ARGS) : launch_chain<uint32_t, uint32_t, false, 1024, true>(LSK_CHAIN_ARGS);
+    }
+    if (narrow) return cplx ? launch_chain<uint32_t, uint32_t, true, 512, false>(LSK_CHAIN_ARGS) : launch_chain<uint32_t, uint32_t, false, 1024, false>(LSK_CHAIN_ARGS);
+    if (!wide_ranks) return cplx ? launch_chain<uint64_t, uint32_t, true, 512, false>(LSK_CHAIN_ARGS) : launch_chain<uint64_t, uint32_t, false, 1024, false>(LSK_CHAIN_ARGS);
+    return cplx ? launch_chain<uint64_t, uint64_t, true, 512, false>(LSK_CHAIN_ARGS) : launch_chain<uint64_t, uint64_t, false, 1024, false>(LSK_CHAIN_ARGS);
 #undef LSK_CHAIN_ARGS
 }
 

@@ -144,9 +144,12 @@ int lsk_direct(lsk_operator op, lsk_basis bs, lsk_index ix, int cplx, int pull, 
  * rows (reps, cache, y) are the global rows [row0, row0 + n) of the basis; x is the whole vector of n_x elements.
  * wide_ranks != 0: ranks (cache entries, indices into x) are 64-bit (bases with >= 2^32 states). */
 int lsk_chain_tile_rows(int cplx);
-int lsk_chain(lsk_operator op, lsk_basis bs, lsk_index ix, int cplx, int wide_ranks, lsk_tilemap tm, int64_t n,
-              uint64_t const *reps, int64_t row0, int64_t n_x, void const *x, void *y, int n_cached, void const *cache,
-              double cv0, double cv1, void *stream);
+int lsk_chain(lsk_operator op, lsk_basis bs, lsk_index ix, int cplx, int wide_ranks, int fused_records, lsk_tilemap tm,
+              int64_t n, uint64_t const *reps, int64_t row0, int64_t n_x, void const *x, void *y, int n_cached,
+              void const *cache, double cv0, double cv1, void *stream);
+/* fused_records != 0 (32-bit states and ranks): `reps` is out[] of lsk_chain_pack -- state | partner rank of the first
+ * cached pair << 32 (cache == NULL: no cached pair) -- and `cache` only holds a second cached pair at cache + n */
+int lsk_chain_pack(int64_t n, uint64_t const *reps, void const *cache, uint64_t *out, void *stream);
 /* partner ranks of a non-adjacent exchange pair for every row (u32, or u64 when wide_ranks); *d_flag is raised if a
  * partner leaves the basis */
 int lsk_chain_cache(lsk_basis bs, lsk_index ix, int64_t n, uint64_t const *reps, uint64_t xmask, void *out, int wide_ranks,

@@ -13,7 +13,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-DEVICE_KERNEL = {"staged": "k_chain", "tile-pull": "k_tile_pull", "direct-push": "k_direct", "direct-pull": "k_direct",
+DEVICE_KERNEL = {"staged": "k_chain_t", "tile-pull": "k_tile_pull", "direct-push": "k_direct", "direct-pull": "k_direct",
                  "tile": "k_tile<"}
 
 
@@ -37,9 +37,12 @@ def main():
     fetch, nf = mean_counter(root, "pmc_fetch", "FETCH_SIZE", needle)
     write, nw = mean_counter(root, "pmc_write", "WRITE_SIZE", needle)
     valu, nv = mean_counter(root, "pmc_valu", "SQ_INSTS_VALU", needle)
+    # FETCH_SIZE tallies requests at 64 bytes: a wide streaming read issues 128-byte requests (x 2, calibrated on k_diag in
+    # round 1); the staged kernel of the projected bases reads one 16-byte hash entry per probe = one 64-byte request (x 1)
+    corr = 1.0 if "tile" in kname else 2.0
     entry = {
-        "fetch_size_kib_raw": fetch, "fetch_correction": 2.0, "write_size_kib": write,
-        "traffic_bytes": (2.0 * fetch + write) * 1024.0 if fetch is not None and write is not None else None,
+        "fetch_size_kib_raw": fetch, "fetch_correction": corr, "write_size_kib": write,
+        "traffic_bytes": (corr * fetch + write) * 1024.0 if fetch is not None and write is not None else None,
         "dispatches": [nf, nw], "device_kernel": needle, "source_sha": source_sha(),
         "source": os.environ.get("PMC_SOURCE", ""),
     }
