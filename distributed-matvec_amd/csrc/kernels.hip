@@ -1284,11 +1284,13 @@ extern "C" int lsk_chain(lsk_operator op, lsk_basis bs, lsk_index ix, int cplx, 
 // reserved in the send buffer with ONE global atomic per (tile-chunk, destination) and written out
 // from LDS (K6: the radix partition by destination happens here, in LDS).
 // ---------------------------------------------------------------------------------------------
-constexpr int kGC = 8;
-constexpr int kCap = kBlock * kGC;
+
 constexpr uint32_t kDead = 0xffffffffu;
 
-template <typename W, bool PM1, bool CPLX, bool REAL>
+// GC = flip-mask groups expanded per LDS list: 8 for cheap packets (fewer barriers: chain_28, P = 8: 11.0 vs 14.0 ms with 4), 4 for
+// symmetry-projected bases (20 instead of 40 KB of LDS per block: twice the blocks per CU to hide K4 and the index look-ups:
+// chain_36_symm push 46.1 -> 31.8 ms)
+template <typename W, bool PM1, bool CPLX, bool REAL, int GC>
 __global__ __launch_bounds__(kBlock) void k_tile(int n_groups, lsk_group const *__restrict__ groups,
                                                  lsk_term const *__restrict__ off, lsk_basis bs,
                                                  lsk_group_elem const *__restrict__ elems, lsk_index ix,
@@ -1299,6 +1301,7 @@ __global__ __launch_bounds__(kBlock) void k_tile(int n_groups, lsk_group const *
                                                  unsigned long long *cursors,
                                                  lsk_round_layout const *__restrict__ layout, char *send,
                                                  unsigned long long *counts, int *err) {
+    constexpr int kCap = kBlock * GC;
     __shared__ uint64_t s_beta[kCap];
     __shared__ double s_val[kCap * (CPLX ? 2 : 1)];
     __shared__ uint32_t s_meta[kCap];
@@ -1325,12 +1328,12 @@ __global__ __launch_bounds__(kBlock) void k_tile(int n_groups, lsk_group const *
                 xi *= s;
             }
         }
-        for (int g0 = 0; g0 < n_groups; g0 += kGC) {
+        for (int g0 = 0; g0 < n_groups; g0 += GC) {
             if (tid == 0) s_n = 0;
             for (int d = tid; d < P; d += kBlock) s_cnt[d] = 0;
             __syncthreads();
             // ---- stage A: expand terms of kGC groups into the LDS list --------------------------
-            const int g1 = min(g0 + kGC, n_groups);
+            const int g1 = min(g0 + GC, n_groups);
             for (int g = g0; g < g1; ++g) {
                 lsk_group const G = groups[g];
                 double cr = 0.0, ci = 0.0;
@@ -1435,19 +1438,20 @@ extern "C" int lsk_tile(lsk_operator op, lsk_basis bs, lsk_index ix, int cplx, i
     hipStream_t s = (hipStream_t)stream;
 #define LSK_TILE_ARGS op.n_groups, op.groups, op.off, bs, bs.elems, ix, count_only, ow, me, row0, row1, reps, norms, \
         (double const *)x, (double *)y, d_cursors, d_layout, (char *)d_send, d_counts, d_err
-#define LSK_TILE_LAUNCH(W, PM1)                                                                            \
+#define LSK_TILE_LAUNCH(W, PM1, GC)                                                                            \
     do {                                                                                                   \
         if (cplx) {                                                                                        \
-            if (op.is_real) { g.x = tile_grid(k_tile<W, PM1, true, true>, work_blocks); hipLaunchKernelGGL((k_tile<W, PM1, true, true>), g, b, 0, s, LSK_TILE_ARGS); } \
-            else { g.x = tile_grid(k_tile<W, PM1, true, false>, work_blocks); hipLaunchKernelGGL((k_tile<W, PM1, true, false>), g, b, 0, s, LSK_TILE_ARGS); } \
+            if (op.is_real) { g.x = tile_grid(k_tile<W, PM1, true, true, GC>, work_blocks); hipLaunchKernelGGL((k_tile<W, PM1, true, true, GC>), g, b, 0, s, LSK_TILE_ARGS); } \
+            else { g.x = tile_grid(k_tile<W, PM1, true, false, GC>, work_blocks); hipLaunchKernelGGL((k_tile<W, PM1, true, false, GC>), g, b, 0, s, LSK_TILE_ARGS); } \
         } else {                                                                                           \
-            if (op.is_real) { g.x = tile_grid(k_tile<W, PM1, false, true>, work_blocks); hipLaunchKernelGGL((k_tile<W, PM1, false, true>), g, b, 0, s, LSK_TILE_ARGS); } \
-            else { g.x = tile_grid(k_tile<W, PM1, false, false>, work_blocks); hipLaunchKernelGGL((k_tile<W, PM1, false, false>), g, b, 0, s, LSK_TILE_ARGS); } \
+            if (op.is_real) { g.x = tile_grid(k_tile<W, PM1, false, true, GC>, work_blocks); hipLaunchKernelGGL((k_tile<W, PM1, false, true, GC>), g, b, 0, s, LSK_TILE_ARGS); } \
+            else { g.x = tile_grid(k_tile<W, PM1, false, false, GC>, work_blocks); hipLaunchKernelGGL((k_tile<W, PM1, false, false, GC>), g, b, 0, s, LSK_TILE_ARGS); } \
         }                                                                                                  \
     } while (0)
     const bool narrow = bs.number_sites <= 32 && bs.proj == LSK_PROJ_FULL;
-    if (narrow) { if (bs.chars_pm1) LSK_TILE_LAUNCH(uint32_t, true); else LSK_TILE_LAUNCH(uint32_t, false); }
-    else { if (bs.chars_pm1) LSK_TILE_LAUNCH(uint64_t, true); else LSK_TILE_LAUNCH(uint64_t, false); }
+    if (narrow) { if (bs.chars_pm1) LSK_TILE_LAUNCH(uint32_t, true, 4); else LSK_TILE_LAUNCH(uint32_t, false, 4); }
+    else if (bs.proj == LSK_PROJ_FULL) { if (bs.chars_pm1) LSK_TILE_LAUNCH(uint64_t, true, 4); else LSK_TILE_LAUNCH(uint64_t, false, 4); }
+    else LSK_TILE_LAUNCH(uint64_t, true, 8); // no projection: PM1 is irrelevant
 #undef LSK_TILE_LAUNCH
 #undef LSK_TILE_ARGS
     LSK_LAUNCH_CHECK();
