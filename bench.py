@@ -167,6 +167,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=28, help="chain length of the CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary (other dtype / other mode) measurements")
+    ap.add_argument("--kDisplayTimings", action="store_true",
+                    help="print the per-stage timing tree (the reference's flag, DMV:1028-1052) to stderr after the timed steps")
     args = ap.parse_args()
 
     import torch
@@ -250,6 +252,8 @@ def main():
         op = make_op()
         plan = op if isinstance(op, D.MatvecPlan) else op.engine.plan
         plan.enable_timing(8192)
+        if args.kDisplayTimings:
+            plan.enable_stage_timing(65536)
         if isinstance(op, D.MatvecPlan):
             run = lambda: op.matvec([x], [y], check=False)  # noqa: E731
         else:
@@ -261,6 +265,8 @@ def main():
         dt = time_steps(run, steps, 0)
         plan.check()
         samples = plan.kernel_times_ms(8192)
+        if args.kDisplayTimings and rank == 0:
+            print(f"[{label}] " + plan.timing_report(), file=sys.stderr, flush=True)
         lps = max(1, len(samples) // max(1, steps))
         kms = sum(samples) / max(1, len(samples))  # average duration of ONE launch of the dominant kernel
         xb = allsum(getattr(op, "exchange_bytes_per_matvec", 0))

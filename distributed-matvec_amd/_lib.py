@@ -116,6 +116,9 @@ def load():
         "ls_amd_plan_check": (C.c_int, [vp, vp]),
         "ls_amd_plan_enable_timing": (C.c_int, [vp, C.c_int]),
         "ls_amd_plan_kernel_times": (C.c_int, [vp, C.POINTER(C.c_float), C.c_int, c_intp]),
+        "ls_amd_plan_enable_stage_timing": (C.c_int, [vp, C.c_int]),
+        "ls_amd_plan_stage_times": (C.c_int, [vp, c_f64p, c_i64p, c_i64p]),
+        "ls_amd_plan_timing_report": (C.c_int, [vp, C.c_char_p, C.c_size_t]),
         "ls_amd_fill_random": (C.c_int, [C.c_int64, vp, C.c_uint64, C.c_int, vp, vp]),
         "ls_amd_diag": (C.c_int, [vp, vp, vp, vp]),
         "ls_amd_generate": (C.c_int, [vp, C.c_int, vp, vp, vp, vp]),

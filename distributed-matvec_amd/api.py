@@ -400,6 +400,23 @@ class MatvecPlan:
         _lib.check(_lib.load().ls_amd_plan_kernel_times(self.h, buf, capacity, C.byref(n)))
         return [float(buf[i]) for i in range(n.value)]
 
+    def enable_stage_timing(self, max_events: int = 65536):
+        """the reference's kDisplayTimings (DMV:1028-1052): per-stage device time"""
+        _lib.check(_lib.load().ls_amd_plan_enable_stage_timing(self.h, max_events))
+
+    def stage_times(self):
+        ms = (C.c_double * 6)()
+        calls = (C.c_int64 * 6)()
+        mv = C.c_int64()
+        _lib.check(_lib.load().ls_amd_plan_stage_times(self.h, ms, calls, C.byref(mv)))
+        names = ("localDiagonal", "hashRefresh", "rowKernel", "producers", "exchangeWait", "consumers")
+        return {n: (float(ms[i]), int(calls[i])) for i, n in enumerate(names)}, int(mv.value)
+
+    def timing_report(self) -> str:
+        buf = C.create_string_buffer(4096)
+        _lib.check(_lib.load().ls_amd_plan_timing_report(self.h, buf, 4096))
+        return buf.value.decode("utf-8")
+
     def diag(self, x, y):
         _lib.check(_lib.load().ls_amd_diag(self.h, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), _stream_ptr()))
 
@@ -557,6 +574,9 @@ class ReplicatedPlan:
     check = MatvecPlan.check
     enable_timing = MatvecPlan.enable_timing
     kernel_times_ms = MatvecPlan.kernel_times_ms
+    enable_stage_timing = MatvecPlan.enable_stage_timing
+    stage_times = MatvecPlan.stage_times
+    timing_report = MatvecPlan.timing_report
 
     def matvec(self, x_global, y_local, check: bool = True):
         _lib.check(_lib.load().ls_amd_matvec_replicated(self.h, C.c_void_p(x_global.data_ptr()), C.c_void_p(y_local.data_ptr()), _stream_ptr()))

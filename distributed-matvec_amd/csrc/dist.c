@@ -21,6 +21,10 @@
 #include "lsk.h"
 
 int ls_amd_internal_error(char const *fmt, ...); /* host.c: formats into ls_amd_last_error(), returns -1 */
+int ls_amd_internal_stage_begin(ls_amd_plan *pl, int stage, void *stream); /* host.c: stage timers (kDisplayTimings) */
+void ls_amd_internal_stage_end(ls_amd_plan *pl, int slot, void *stream);
+void ls_amd_internal_count_matvec(ls_amd_plan *pl);
+enum { ST_EXCHANGE = 4 };
 
 #define COMM(expr) do { if ((expr) != 0) return ls_amd_internal_error("%s", lsk_comm_last_error()); } while (0)
 #define DEVC(expr) do { if ((expr) != 0) return ls_amd_internal_error("%s", lsk_last_error()); } while (0)
@@ -238,6 +242,7 @@ static int exchange(ls_amd_dist *d, int r, void *stream) {
 
 int ls_amd_dist_matvec(ls_amd_dist *d, void const *d_x, void *d_y, void *stream) {
     int const R = d->rounds, P = d->P;
+    ls_amd_internal_count_matvec(d->plan);
     TRY(ls_amd_diag(d->plan, d_x, d_y, stream)); /* localDiagonal first: y is assigned (DMV:1062-1063) */
     TRY(ls_amd_generate(d->plan, 0, d_x, d_y, d->d_send[0], stream));
     TRY(exchange(d, 0, stream));
@@ -246,7 +251,9 @@ int ls_amd_dist_matvec(ls_amd_dist *d, void const *d_x, void *d_y, void *stream)
             TRY(ls_amd_generate(d->plan, r + 1, d_x, d_y, d->d_send[(r + 1) & 1], stream));
             TRY(exchange(d, r + 1, stream));
         }
+        int const st = ls_amd_internal_stage_begin(d->plan, ST_EXCHANGE, stream);
         COMM(lsk_comm_exchange_wait(d->comm->c, r & 1, stream));
+        ls_amd_internal_stage_end(d->plan, st, stream);
         char const *recv = (char const *)d->d_recv[r & 1];
         for (int s = 0; s < P; ++s) {
             int64_t const n = d->recv_counts[(size_t)r * P + s];

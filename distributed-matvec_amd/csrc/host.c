@@ -1106,6 +1106,13 @@ struct ls_amd_plan {
     /* kernel timing ring */
     int t_capacity, t_count;
     void **t_start, **t_stop;
+    /* stage timers (the reference's kDisplayTimings tree, DMV:1028-1052): event pairs tagged with a stage */
+    int st_capacity, st_count;
+    void **st_start, **st_stop;
+    unsigned char *st_stage;
+    double st_ms[8];
+    int64_t st_calls[8];
+    int64_t st_matvecs;
 };
 
 static int timing_begin(ls_amd_plan *pl, void *stream) {
@@ -1116,6 +1123,78 @@ static int timing_begin(ls_amd_plan *pl, void *stream) {
 static void timing_end(ls_amd_plan *pl, int slot, void *stream) {
     if (slot < 0) return;
     if (lsk_event_record(pl->t_stop[slot], stream) == 0) pl->t_count = slot + 1;
+}
+
+/* ---- stage timers ----------------------------------------------------------------------------- */
+enum { ST_DIAG = 0, ST_REFRESH = 1, ST_ROWS = 2, ST_GENERATE = 3, ST_EXCHANGE = 4, ST_SCATTER = 5, ST_COUNT = 6 };
+static int stage_begin(ls_amd_plan *pl, int stage, void *stream) {
+    if (pl->st_count >= pl->st_capacity) return -1;
+    if (lsk_event_record(pl->st_start[pl->st_count], stream) != 0) return -1;
+    pl->st_stage[pl->st_count] = (unsigned char)stage;
+    return pl->st_count;
+}
+static void stage_end(ls_amd_plan *pl, int slot, void *stream) {
+    if (slot < 0) return;
+    if (lsk_event_record(pl->st_stop[slot], stream) == 0) pl->st_count = slot + 1;
+}
+int ls_amd_internal_stage_begin(ls_amd_plan *pl, int stage, void *stream) { return stage_begin(pl, stage, stream); }
+void ls_amd_internal_stage_end(ls_amd_plan *pl, int slot, void *stream) { stage_end(pl, slot, stream); }
+void ls_amd_internal_count_matvec(ls_amd_plan *pl) { if (pl->st_capacity) ++pl->st_matvecs; }
+/* folds the recorded event pairs into the per-stage totals (synchronises on the events) */
+static int stage_collect(ls_amd_plan *pl) {
+    for (int i = 0; i < pl->st_count; ++i) {
+        float ms = 0;
+        DEV(lsk_event_elapsed_ms(pl->st_start[i], pl->st_stop[i], &ms));
+        pl->st_ms[pl->st_stage[i]] += ms;
+        pl->st_calls[pl->st_stage[i]] += 1;
+    }
+    pl->st_count = 0;
+    return 0;
+}
+int ls_amd_plan_enable_stage_timing(ls_amd_plan *pl, int max_events) {
+    for (int i = 0; i < pl->st_capacity; ++i) { lsk_event_destroy(pl->st_start[i]); lsk_event_destroy(pl->st_stop[i]); }
+    free(pl->st_start); free(pl->st_stop); free(pl->st_stage);
+    pl->st_start = pl->st_stop = NULL; pl->st_stage = NULL;
+    pl->st_capacity = pl->st_count = 0;
+    memset(pl->st_ms, 0, sizeof(pl->st_ms)); memset(pl->st_calls, 0, sizeof(pl->st_calls));
+    pl->st_matvecs = 0;
+    if (max_events <= 0) return 0;
+    pl->st_start = (void **)calloc(max_events, sizeof(void *));
+    pl->st_stop = (void **)calloc(max_events, sizeof(void *));
+    pl->st_stage = (unsigned char *)calloc(max_events, 1);
+    for (int i = 0; i < max_events; ++i) {
+        DEV(lsk_event_create(&pl->st_start[i]));
+        DEV(lsk_event_create(&pl->st_stop[i]));
+        pl->st_capacity = i + 1;
+    }
+    return 0;
+}
+int ls_amd_plan_stage_times(ls_amd_plan *pl, double *ms, int64_t *calls, int64_t *matvecs) {
+    if (stage_collect(pl) != 0) return -1;
+    for (int k = 0; k < ST_COUNT; ++k) { ms[k] = pl->st_ms[k]; calls[k] = pl->st_calls[k]; }
+    if (matvecs) *matvecs = pl->st_matvecs;
+    return 0;
+}
+/* the reference prints this tree when kDisplayTimings is set (DMV:1028-1052); stages are mapped to what replaced them */
+int ls_amd_plan_timing_report(ls_amd_plan *pl, char *buf, size_t cap) {
+    if (stage_collect(pl) != 0) return -1;
+    double total = 0;
+    for (int k = 0; k < ST_COUNT; ++k) total += pl->st_ms[k];
+    int64_t const m = pl->st_matvecs > 0 ? pl->st_matvecs : 1;
+#define PER(k) (pl->st_ms[k] / (double)m), (long long)pl->st_calls[k]
+    snprintf(buf, cap,
+             "matrixVectorProduct [%s]: %.3f ms per matvec over %lld matvecs (device time of the stages, HIP events)\n"
+             " \xe2\x94\x9c\xe2\x94\x80 localDiagonal (k_diag):                         %9.3f ms  (%lld launches)\n"
+             " \xe2\x94\x9c\xe2\x94\x80 x -> hash table refresh (k_hash_fill):          %9.3f ms  (%lld launches)\n"
+             " \xe2\x94\x9c\xe2\x94\x80 row kernel (fused computeOffDiag + localProcess): %7.3f ms  (%lld launches)\n"
+             " \xe2\x94\x9c\xe2\x94\x80 producers (k_tile: computeOffDiag, stateInfo,\n"
+             " \xe2\x94\x82   localeIdxOf, radixOneStep, own localProcess):    %9.3f ms  (%lld launches)\n"
+             " \xe2\x94\x9c\xe2\x94\x80 exchange wait on the compute stream (all-to-all-v): %5.3f ms  (%lld waits)\n"
+             " \xe2\x94\x94\xe2\x94\x80 consumers (k_scatter: indexing + accessing):    %9.3f ms  (%lld launches)\n",
+             ls_amd_plan_kernel_name(pl), total / (double)m, (long long)pl->st_matvecs, PER(ST_DIAG), PER(ST_REFRESH), PER(ST_ROWS),
+             PER(ST_GENERATE), PER(ST_EXCHANGE), PER(ST_SCATTER));
+#undef PER
+    return 0;
 }
 
 int ls_amd_plan_enable_timing(ls_amd_plan *pl, int max_samples) {
@@ -1518,6 +1597,7 @@ void ls_amd_plan_destroy(ls_amd_plan *pl) {
     if (pl->d_counts) lsk_free(pl->d_counts);
     if (pl->d_err) lsk_free(pl->d_err);
     ls_amd_plan_enable_timing(pl, 0);
+    ls_amd_plan_enable_stage_timing(pl, 0);
     free(pl);
 }
 
@@ -1609,7 +1689,9 @@ int ls_amd_plan_create_replicated(ls_amd_plan **out, ls_hs_operator const *op, l
 int ls_amd_matvec_replicated(ls_amd_plan *pl, void const *d_x_global, void *d_y_local, void *stream) {
     part_state *ps = &pl->parts[0];
     int slot;
+    ls_amd_internal_count_matvec(pl);
     if (pl->family == FAMILY_REPL_DIRECT) {
+        int const st = stage_begin(pl, ST_ROWS, stream);
         slot = timing_begin(pl, stream);
         if (pl->has_chain)
             DEV(lsk_chain(pl->dop, pl->dbs, pl->gindex, pl->cplx, pl->chain_wide, pl->d_chain_rec != NULL, pl->tilemap, ps->count,
@@ -1619,15 +1701,18 @@ int ls_amd_matvec_replicated(ls_amd_plan *pl, void const *d_x_global, void *d_y_
             DEV(lsk_direct_gx(pl->dop, pl->dbs, pl->gindex, pl->cplx, pl->tilemap, ps->d_reps, pl->d_row_gidx, d_x_global,
                           d_y_local, pl->d_err, stream));
         timing_end(pl, slot, stream);
+        stage_end(pl, st, stream);
         return 0;
     }
     if (pl->family == FAMILY_REPL_TILE) {
         void const *xg;
         if (prescaled_x(pl, pl->gindex.count, pl->gindex.reps, d_x_global, pl->d_norms_global, &xg, stream) != 0) return -1;
+        int const st = stage_begin(pl, ST_ROWS, stream);
         slot = timing_begin(pl, stream);
         DEV(lsk_tile_pull(pl->dop, pl->dbs, pl->gindex, pl->cplx, 0, ps->count, ps->d_reps, ps->d_norms,
                           pl->d_norms_global, pl->d_row_gidx, xg, pl->htab_bits, d_x_global, d_y_local, pl->d_err, stream));
         timing_end(pl, slot, stream);
+        stage_end(pl, st, stream);
         return 0;
     }
     return set_error("ls_amd_matvec_replicated: not a replicated-x plan");
@@ -1668,14 +1753,18 @@ static int prescaled_x(ls_amd_plan *pl, int64_t n, uint64_t const *d_reps, void 
         pl->d_slot_of = (uint32_t *)p;
         DEV(lsk_hash_build(pl->cplx, n, d_reps, bits, pl->d_htab, pl->d_slot_of, stream));
     }
+    int const st = stage_begin(pl, ST_REFRESH, stream);
     DEV(lsk_hash_fill(pl->cplx, n, pl->d_slot_of, d_x, pl->dbs.k4_mode != 0 ? d_norms : NULL, pl->d_htab, stream));
+    stage_end(pl, st, stream);
     *out = pl->d_htab;
     return 0;
 }
 
 int ls_amd_diag(ls_amd_plan *pl, void const *d_x, void *d_y, void *stream) {
     part_state *ps = &pl->parts[0];
+    int const st = stage_begin(pl, ST_DIAG, stream);
     DEV(lsk_diag(pl->dop, pl->cplx, ps->count, ps->d_reps, d_x, d_y, stream));
+    stage_end(pl, st, stream);
     return 0;
 }
 
@@ -1683,10 +1772,12 @@ static int generate_round(ls_amd_plan *pl, part_state *ps, int pid, int round, v
                           void *d_send, void *stream) {
     int64_t row0 = ps->count * round / ps->rounds, row1 = ps->count * (round + 1) / ps->rounds;
     if (pl->P > 1) DEV(lsk_memset_async(pl->d_cursors, 0, 8 * (size_t)pl->P, stream));
+    int const st = stage_begin(pl, ST_GENERATE, stream);
     int slot = timing_begin(pl, stream);
     DEV(lsk_tile(pl->dop, pl->dbs, ps->index, pl->cplx, 0, pl->P, pid, row0, row1, ps->d_reps, ps->d_norms, d_x,
                  d_y, pl->d_cursors, ps->d_layouts + round, d_send, pl->d_counts, pl->d_err, stream));
     timing_end(pl, slot, stream);
+    stage_end(pl, st, stream);
     return 0;
 }
 
@@ -1702,30 +1793,39 @@ int ls_amd_scatter(ls_amd_plan *pl, int64_t n, uint64_t const *d_betas, void con
                    void *stream) {
     part_state *ps = &pl->parts[0];
     if (ps->index.kind == LSK_INDEX_COMBINADIC) return set_error("ls_amd_scatter: plan has no search index");
+    int const st = stage_begin(pl, ST_SCATTER, stream);
     DEV(lsk_scatter(ps->index, pl->cplx, n, d_betas, d_values, d_y, pl->dbs.k4_mode ? ps->d_norms : NULL, pl->d_err,
                     stream));
+    stage_end(pl, st, stream);
     return 0;
 }
 
 int ls_amd_matvec(ls_amd_plan *pl, void const *const *d_x, void *const *d_y, void *stream) {
     if (pl->me >= 0) return set_error("ls_amd_matvec: plan owns one partition; drive it with generate/scatter");
+    ls_amd_internal_count_matvec(pl);
     if (pl->family == FAMILY_TILE_PULL) {
         part_state *ps = &pl->parts[0];
         void const *xg;
         if (prescaled_x(pl, ps->count, ps->d_reps, d_x[0], ps->d_norms, &xg, stream) != 0) return -1;
+        int const st = stage_begin(pl, ST_ROWS, stream);
         int slot = timing_begin(pl, stream);
         DEV(lsk_tile_pull(pl->dop, pl->dbs, ps->index, pl->cplx, 0, ps->count, ps->d_reps, ps->d_norms, ps->d_norms,
                           NULL, xg, pl->htab_bits, d_x[0], d_y[0], pl->d_err, stream));
         timing_end(pl, slot, stream);
+        stage_end(pl, st, stream);
         return 0;
     }
     /* localDiagonal on every partition first: y is assigned (DMV:1062-1063) */
-    if (pl->family != FAMILY_DIRECT_PULL)
+    if (pl->family != FAMILY_DIRECT_PULL) {
+        int const st = stage_begin(pl, ST_DIAG, stream);
         for (int p = 0; p < pl->n_local; ++p)
             DEV(lsk_diag(pl->dop, pl->cplx, pl->parts[p].count, pl->parts[p].d_reps, d_x[p], d_y[p], stream));
+        stage_end(pl, st, stream);
+    }
     if (pl->dop.n_groups == 0 && pl->family != FAMILY_DIRECT_PULL) return 0;
     if (pl->family != FAMILY_TILE) {
         part_state *ps = &pl->parts[0];
+        int const st = stage_begin(pl, ST_ROWS, stream);
         int slot = timing_begin(pl, stream);
         if (pl->has_chain)
             DEV(lsk_chain(pl->dop, pl->dbs, ps->index, pl->cplx, pl->chain_wide, pl->d_chain_rec != NULL, pl->tilemap, ps->count,
@@ -1735,6 +1835,7 @@ int ls_amd_matvec(ls_amd_plan *pl, void const *const *d_x, void *const *d_y, voi
             DEV(lsk_direct(pl->dop, pl->dbs, ps->index, pl->cplx, pl->family == FAMILY_DIRECT_PULL, pl->tilemap, ps->d_reps,
                            d_x[0], d_y[0], pl->d_err, stream));
         timing_end(pl, slot, stream);
+        stage_end(pl, st, stream);
         return 0;
     }
     int const P = pl->P;
@@ -1748,8 +1849,10 @@ int ls_amd_matvec(ls_amd_plan *pl, void const *const *d_x, void *const *d_y, voi
                 if (d == p || c == 0) continue;
                 uint64_t const *betas = (uint64_t const *)((char *)pl->d_send + ps->h_beta_off[(size_t)r * P + d]);
                 void const *vals = (char *)pl->d_send + ps->h_val_off[(size_t)r * P + d];
+                int const st = stage_begin(pl, ST_SCATTER, stream);
                 DEV(lsk_scatter(pl->parts[d].index, pl->cplx, c, betas, vals, d_y[d],
                                 pl->dbs.k4_mode ? pl->parts[d].d_norms : NULL, pl->d_err, stream));
+                stage_end(pl, st, stream);
             }
         }
     }

@@ -175,6 +175,13 @@ int ls_amd_matvec_replicated(ls_amd_plan *plan, void const *d_x_global, void *d_
  * ls_amd_plan_check / a stream sync.  *count receives the number of samples written (<= capacity)
  * and the ring is reset. */
 int ls_amd_plan_enable_timing(ls_amd_plan *plan, int max_samples);
+/* Stage timers: the reference's --kDisplayTimings tree (DMV:1028-1052), HIP events around every stage launch on the
+ * launch stream.  stages: 0 localDiagonal, 1 hash-table refresh, 2 row kernel (fused paths), 3 producers (k_tile),
+ * 4 exchange wait, 5 consumers (k_scatter).  max_events = capacity of the event pool between two reads (0 disables). */
+#define LS_AMD_NUM_STAGES 6
+int ls_amd_plan_enable_stage_timing(ls_amd_plan *plan, int max_events);
+int ls_amd_plan_stage_times(ls_amd_plan *plan, double *ms /* [6] totals */, int64_t *calls /* [6] */, int64_t *matvecs);
+int ls_amd_plan_timing_report(ls_amd_plan *plan, char *buf, size_t capacity); /* the tree as text, per matvec */
 int ls_amd_plan_kernel_times(ls_amd_plan *plan, float *ms, int capacity, int *count);
 
 /* x[i] = u(hash(states[i], seed)) - 0.5 (re and im for c128): deterministic vectors keyed by the

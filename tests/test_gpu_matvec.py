@@ -767,3 +767,28 @@ def test_staged_kernel_block_rows_wide_states(torch, L, weight, cplx):
         pieces.append(yp)
     got = torch.cat(pieces).cpu().numpy()
     assert np.abs(got - want).max() <= 1e-12 * max(1.0, np.abs(want).max())
+
+
+def test_stage_timing_tree(torch):
+    """the reference's --kDisplayTimings tree (DMV:1028-1052): per-stage device time, HIP events on the launch stream"""
+    import distributed_matvec_amd as D
+
+    for name, P, expect in (("heisenberg_chain_16", 1, {"rowKernel"}), ("heisenberg_chain_16", 3, {"localDiagonal", "producers", "consumers"}),
+                            ("heisenberg_chain_24_symm", 1, {"hashRefresh", "rowKernel"})):
+        D_, basis, h, reps, masks = setup_model(torch, model_config(name), P)
+        x = [D.fillRandom(r, 3, torch.float64) for r in reps]
+        y = [torch.zeros_like(v) for v in x]
+        pl = D.MatvecPlan(h, reps, torch.float64)
+        pl.enable_stage_timing(4096)
+        for _ in range(3):
+            pl.matvec(x, y)
+        times, matvecs = pl.stage_times()
+        assert matvecs == 3
+        used = {k for k, (ms, calls) in times.items() if calls > 0}
+        assert used == expect, (name, P, used)
+        assert all(ms > 0 for k, (ms, calls) in times.items() if calls > 0)
+        if P == 3:
+            assert times["producers"][1] == 3 * 3 and times["consumers"][1] == 3 * 3 * 2  # rounds == 1: P launches, P (P - 1) segments
+        text = pl.timing_report()
+        assert "matrixVectorProduct" in text and "producers" in text and "consumers" in text and "over 3 matvecs" in text
+        pl.destroy()

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, name, cplx, mode, out_dir):
+def _worker(rank, world, port, name, cplx, mode, out_dir, backend="gloo"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch
@@ -23,8 +23,8 @@ def _worker(rank, world, port, name, cplx, mode, out_dir):
     from distributed_matvec_amd.distributed import DistributedOperator, ReplicatedOperator
     from helpers import model_config
 
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    torch.cuda.set_device(rank if backend == "nccl" else 0)
+    dist.init_process_group(backend, init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     try:
         basis, h = D.loadConfigFromDict(model_config(name), hamiltonian=True)
         reps, masks = D.enumerateStates(basis, world)
@@ -56,13 +56,22 @@ def _worker(rank, world, port, name, cplx, mode, out_dir):
 @pytest.mark.parametrize("name,world,cplx", [("heisenberg_chain_16", 2, False), ("heisenberg_chain_24_symm", 2, False),
                                              ("heisenberg_kagome_16", 3, True), ("issue_01", 2, False)])
 @pytest.mark.parametrize("mode", ["packets", "replicated"])
-def test_two_processes_one_gpu(tmp_path, name, world, cplx, mode):
+@pytest.mark.parametrize("backend", ["gloo", "nccl"])
+def test_two_processes_one_gpu(tmp_path, name, world, cplx, mode, backend):
+    """backend "gloo": every rank on the one GPU, host-staged transport.  backend "nccl" (RCCL, one rank per GPU): the
+    production transport of the torch drivers -- device tensors handed to all_to_all_single / batch_isend_irecv as they
+    are, async_op in the depth-2 pipeline (num_rounds = 3: buffer reuse); needs as many GPUs as ranks."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from helpers import oracle_for, oracle_reps
     from oracle import c_oracle as CO
 
-    port = 30100 + (os.getpid() % 300) + world + (7 if mode == "packets" else 0)
-    mp.spawn(_worker, args=(world, port, name, cplx, mode, str(tmp_path)), nprocs=world, join=True)
+    if backend == "nccl":
+        import torch
+
+        if torch.cuda.device_count() < world:
+            pytest.skip(f"RCCL needs one GPU per rank ({world}); this box has {torch.cuda.device_count()}")
+    port = 30100 + (os.getpid() % 300) + world + (7 if mode == "packets" else 0) + (13 if backend == "nccl" else 0)
+    mp.spawn(_worker, args=(world, port, name, cplx, mode, str(tmp_path), backend), nprocs=world, join=True)
     reps = oracle_reps(name)
     keys = CO.locale_idx_of(reps, world)
     parts_r = [np.load(os.path.join(str(tmp_path), f"r{r}.npy")) for r in range(world)]
