@@ -273,6 +273,7 @@ def main():
         return dt, kms, lps, plan.kernel, xb, plan, op
 
     exchanges = {}
+    failed = {}
     if not distributed:
         make = lambda: D.MatvecPlan(h, [my_reps], tdtype, mode=args.mode)  # noqa: E731
         exchange = "none"
@@ -294,16 +295,27 @@ def main():
         wanted = list(makers) if args.exchange == "auto" else [args.exchange]
         setup_t0 = time.perf_counter()
         results = {}
+        failed = {}
         for name in wanted:
             torch.cuda.empty_cache()
-            r = measure(makers[name], args.steps, args.warmup, name)
+            try:
+                r = measure(makers[name], args.steps, args.warmup, name)
+            except Exception as e:  # reported at the TOP level of the JSON line (failed_exchanges) and on stderr, never hidden
+                import traceback
+
+                traceback.print_exc()
+                failed[name] = repr(e)[:400]
+                exchanges[name] = {"error": failed[name]}
+                continue
             results[name] = r
             exchanges[name] = {"matvecs_per_s": args.steps / r[0], "ms_per_step": 1e3 * r[0] / args.steps, "kernel": r[3],
                                "kernel_ms_avg": r[1], "launches_per_step": r[2], "exchange_bytes_per_matvec": r[4]}
             if len(wanted) > 1:  # keep only the numbers; the plans of the other strategy would pin HBM
                 results[name] = r[:5] + (None, None)
                 del r
-        exchange = min(wanted, key=lambda k: results[k][0])  # `value` is the faster strategy, named in config.exchange
+        if not results:
+            raise SystemExit(f"every exchange strategy failed: {failed}")
+        exchange = min(results, key=lambda k: results[k][0])  # `value` is the faster strategy, named in config.exchange
         dt, kernel_ms, launches_per_step, kernel_name, exchange_bytes, plan, op_obj = results[exchange]
     setup_s = (setup_t0 - t_setup)
     if symm:
@@ -373,6 +385,7 @@ def main():
                 "exchange_bytes_per_matvec": exchange_bytes,
             },
             "exchanges": exchanges,
+            "failed_exchanges": sorted(failed) if distributed else [],
             "roofline": roofline,
             "cpu_baseline": cpu,
             "setup_seconds": setup_s,

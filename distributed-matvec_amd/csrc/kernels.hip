@@ -902,7 +902,7 @@ extern "C" int lsk_direct_gx(lsk_operator op, lsk_basis bs, lsk_index ix, int cp
 // ---------------------------------------------------------------------------------------------
 constexpr int kChainHalo = 512;    // >= C(11, 5)
 constexpr int kChainLdsPairs = 12; // pairs lo < 12 are served from the LDS window
-constexpr int kChainFar = 8;       // far-pair gathers in flight per row before the first wait
+constexpr int kChainFar = 12;      // far-pair gathers in flight per row before the first wait
 
 // W = state word (u32 up to 32 sites, u64 up to 64), R = rank type (u32 while the basis has < 2^32 - 1 states, else u64),
 // CPLX = complex128 vectors (real operator; the window holds double2, gathers are 16 bytes per lane), TILE rows per

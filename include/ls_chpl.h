@@ -100,9 +100,11 @@ typedef struct ls_primme_params_view {
 /* matrixMatvec: Y_k <- H X_k for k < *blockSize, columns at x + ldx*k, f64, n = primme->nLocal. */
 void ls_chpl_primme_matvec(void *x, int64_t *ldx, void *y, int64_t *ldy, int *blockSize,
                            void *primme, int *ierr);
-/* globalSumReal / broadcastReal: single-process build => sum over one rank (copy) / no-op; the
- * one-process-per-GPU driver installs torch.distributed versions instead
- * (distributed-matvec_amd/distributed.py). */
+/* globalSumReal / broadcastReal (/root/reference/src/PRIMME.chpl:267-373): collective over the communicator in
+ * primme->commInfo (an ls_amd_comm*) or, when that is NULL, the one installed with ls_amd_set_default_comm
+ * (include/ls_amd.h): host buffers are staged through the GPU and reduced with ncclAllReduce / ncclBroadcast over xGMI.
+ * No communicator, or one rank: the sum is a copy (sendBuf may alias recvBuf), the broadcast a no-op.  f32 and f64 sums,
+ * f64 broadcast, as the reference. */
 void primmeGlobalSumReal(void *sendBuf, void *recvBuf, int *count, void *primme, int *ierr);
 void primmeBroadcastReal(void *buffer, int *count, void *primme, int *ierr);
 
