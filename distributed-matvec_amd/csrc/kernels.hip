@@ -1267,8 +1267,8 @@ extern "C" int lsk_chain(lsk_operator op, lsk_basis bs, lsk_index ix, int cplx, 
     const bool narrow = bs.number_sites <= 32 && !wide_ranks;
 #define LSK_CHAIN_ARGS op, bs, ix, tm, n, reps, row0, n_x, x, y, n_cached, cache, cv0, cv1, stream
     if (fused_records) { // `reps` is the record array made by lsk_chain_pack (32-bit states and ranks only)
-        if (!narrow) { snprintf(g_err, sizeof(g_err), "lsk_chain: fused records need 32-bit states and ranks"); return -1; }
-        return cplx ? launch_chain<uint32_t, uint32_t, true, 512, true>(LSK_CHAIN_ARGS) : launch_chain<uint32_t, uint32_t, false, 1024, true>(LSK_CHAIN_ARGS);
+        if (!narrow || cplx) { snprintf(g_err, sizeof(g_err), "lsk_chain: fused records need 32-bit states and ranks and f64 vectors"); return -1; }
+        return launch_chain<uint32_t, uint32_t, false, 1024, true>(LSK_CHAIN_ARGS);
     }
     if (narrow) return cplx ? launch_chain<uint32_t, uint32_t, true, 512, false>(LSK_CHAIN_ARGS) : launch_chain<uint32_t, uint32_t, false, 1024, false>(LSK_CHAIN_ARGS);
     if (!wide_ranks) return cplx ? launch_chain<uint64_t, uint32_t, true, 512, false>(LSK_CHAIN_ARGS) : launch_chain<uint64_t, uint32_t, false, 1024, false>(LSK_CHAIN_ARGS);
