@@ -144,6 +144,7 @@ def load():
         "ls_amd_dist_exchange_bytes": (C.c_int64, [vp]),
         "ls_amd_dist_num_rounds": (C.c_int, [vp]),
         "ls_amd_enumerate_states": (C.c_int, [bp, C.c_int, C.POINTER(vp), C.POINTER(vp), c_i64p, vp]),
+        "ls_amd_gather": (C.c_int, [C.c_int64, vp, C.c_int, C.c_int, vp, vp, vp]),
         "ls_amd_mask_counts": (C.c_int, [C.c_int64, vp, C.c_int, c_i64p, vp]),
         "ls_amd_block_to_hashed": (C.c_int, [C.c_int64, vp, C.c_int, C.c_int, vp, C.POINTER(vp), vp]),
         "ls_amd_hashed_to_block": (C.c_int, [C.c_int64, vp, C.c_int, C.c_int, C.POINTER(vp), vp, vp]),

@@ -152,7 +152,7 @@ static int64_t rows_per_round(void) {
 
 void ls_amd_dist_destroy(ls_amd_dist *d) {
     if (!d) return;
-    lsk_sync(NULL);
+    lsk_device_sync(); /* the exchange stream and the caller's stream may still be using the buffers */
     for (int i = 0; i < 2; ++i) { if (d->d_send[i]) lsk_free(d->d_send[i]); if (d->d_recv[i]) lsk_free(d->d_recv[i]); }
     if (d->plan) ls_amd_plan_destroy(d->plan);
     free(d->send_counts); free(d->recv_counts);

@@ -1899,6 +1899,10 @@ int ls_amd_enumerate_states(ls_hs_basis const *basis, int num_locales, uint64_t 
     }
     return 0;
 }
+int ls_amd_gather(int64_t n, void const *d_perm, int perm_is_64, int elt_size, void const *d_src, void *d_out, void *stream) {
+    DEV(lsk_gather_perm(n, d_perm, perm_is_64, elt_size, d_src, d_out, stream));
+    return 0;
+}
 int ls_amd_mask_counts(int64_t n, uint8_t const *d_masks, int num_locales, int64_t *counts, void *stream) {
     DEV(lsk_mask_counts(n, d_masks, num_locales, counts, stream));
     return 0;

@@ -74,6 +74,7 @@ extern "C" int lsk_memset_async(void *p, int value, size_t bytes, void *stream) 
     return 0;
 }
 extern "C" int lsk_sync(void *stream) { LSK_CHECK(hipStreamSynchronize((hipStream_t)stream)); return 0; }
+extern "C" int lsk_device_sync(void) { LSK_CHECK(hipDeviceSynchronize()); return 0; }
 
 extern "C" int lsk_event_create(void **ev) { hipEvent_t e; LSK_CHECK(hipEventCreate(&e)); *ev = (void *)e; return 0; }
 extern "C" int lsk_event_destroy(void *ev) { if (ev) LSK_CHECK(hipEventDestroy((hipEvent_t)ev)); return 0; }
@@ -1733,6 +1734,38 @@ extern "C" int lsk_scatter(lsk_index ix, int cplx, int64_t n, uint64_t const *be
     dim3 g(grid_for(n)), b(kBlock);
     if (cplx) hipLaunchKernelGGL(k_scatter<true>, g, b, 0, (hipStream_t)stream, ix, n, betas, (double const *)vals, (double *)y, norms, d_err);
     else hipLaunchKernelGGL(k_scatter<false>, g, b, 0, (hipStream_t)stream, ix, n, betas, (double const *)vals, (double *)y, norms, d_err);
+    LSK_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// out[i] = src[perm[i]]: the hashed -> block permutation of the replicated-x exchange (P ascending streams interleaved).
+// Two outputs per thread so that f64 results leave as 16-byte stores; perm is read with 8- / 16-byte loads.
+// ---------------------------------------------------------------------------------------------
+template <typename I, typename T>
+__global__ __launch_bounds__(kBlock) void k_gather_perm(int64_t n, I const *__restrict__ perm, T const *__restrict__ src,
+                                                        T *__restrict__ out) {
+    const int64_t pairs = n >> 1;
+    for (int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x; k < pairs; k += (int64_t)gridDim.x * kBlock) {
+        const I p0 = __builtin_nontemporal_load(perm + 2 * k), p1 = __builtin_nontemporal_load(perm + 2 * k + 1);
+        const T a = src[p0], b = src[p1];
+        out[2 * k] = a;
+        out[2 * k + 1] = b;
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) out[n - 1] = src[perm[n - 1]];
+}
+extern "C" int lsk_gather_perm(int64_t n, void const *perm, int perm_is_64, int elt_size, void const *src, void *out, void *stream) {
+    if (n == 0) return 0;
+    const int64_t blocks = (n / 2 + kBlock - 1) / kBlock;
+    dim3 g((unsigned)(blocks < 1 ? 1 : (blocks > (1 << 20) ? (1 << 20) : blocks))), b(kBlock);
+    hipStream_t s = (hipStream_t)stream;
+    if (elt_size == 8) {
+        if (perm_is_64) hipLaunchKernelGGL((k_gather_perm<int64_t, double>), g, b, 0, s, n, (int64_t const *)perm, (double const *)src, (double *)out);
+        else hipLaunchKernelGGL((k_gather_perm<int32_t, double>), g, b, 0, s, n, (int32_t const *)perm, (double const *)src, (double *)out);
+    } else if (elt_size == 16) {
+        if (perm_is_64) hipLaunchKernelGGL((k_gather_perm<int64_t, double2>), g, b, 0, s, n, (int64_t const *)perm, (double2 const *)src, (double2 *)out);
+        else hipLaunchKernelGGL((k_gather_perm<int32_t, double2>), g, b, 0, s, n, (int32_t const *)perm, (double2 const *)src, (double2 *)out);
+    } else { snprintf(g_err, sizeof(g_err), "lsk_gather_perm: element size %d", elt_size); return -1; }
     LSK_LAUNCH_CHECK();
     return 0;
 }

@@ -120,6 +120,7 @@ int lsk_d2h(void *dst, void const *src, size_t bytes);
 int lsk_d2d_async(void *dst, void const *src, size_t bytes, void *stream);
 int lsk_memset_async(void *p, int value, size_t bytes, void *stream);
 int lsk_sync(void *stream);
+int lsk_device_sync(void);
 
 /* events (kernel timing on the launch stream) */
 int lsk_event_create(void **ev);
@@ -217,6 +218,9 @@ int lsk_block_to_hashed(int64_t n, uint8_t const *masks, int P, int elt_size, vo
                         void *const *h_dest, void *stream);
 int lsk_hashed_to_block(int64_t n, uint8_t const *masks, int P, int elt_size,
                         void const *const *h_src, void *dest, void *stream);
+
+/* out[i] = src[perm[i]], elements of 8 or 16 bytes, perm int32 or int64 */
+int lsk_gather_perm(int64_t n, void const *perm, int perm_is_64, int elt_size, void const *src, void *out, void *stream);
 
 /* RCCL (comm.cpp) ------------------------------------------------------------------------------ */
 typedef struct lsk_comm lsk_comm;

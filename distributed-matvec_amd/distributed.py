@@ -375,8 +375,22 @@ class ReplicatedOperator:
         # every block goes straight to every peer: one grouped send/recv (RCCL uses all xGMI links at
         # once; an all_gather would be a ring)
         self.transport.exchange_blocks(x_local, outs, self.rank, P)
-        torch.index_select(self.gathered, 0, self.perm, out=self.x_global)
+        self._gather(self.gathered, self.perm, self.x_global)
         return self.x_global
+
+    def _gather(self, src, perm, out):
+        """out[i] = src[perm[i]] on the device: the library's permutation kernel (ls_amd_gather); torch.index_select when the
+        tensors live on the CPU (gloo tests with injected engines)"""
+        if not src.is_cuda:
+            self.torch.index_select(src, 0, perm, out=out)
+            return
+        import ctypes as C
+
+        from . import _lib
+        from .api import _stream_ptr
+
+        _lib.check(_lib.load().ls_amd_gather(out.numel(), C.c_void_p(perm.data_ptr()), 1 if perm.dtype == self.torch.int64 else 0,
+                                             out.element_size(), C.c_void_p(src.data_ptr()), C.c_void_p(out.data_ptr()), _stream_ptr()))
 
     def matvec(self, x, y, check: bool = False):
         torch, dist = self.torch, self.dist
@@ -384,7 +398,7 @@ class ReplicatedOperator:
         if self.accumulate:
             self.y_block.zero_()
         self.engine.matvec(xg, self.y_block)
-        torch.index_select(self.y_block, 0, self.y_order, out=self.y_send)
+        self._gather(self.y_block, self.y_order, self.y_send)
         if self.P > 1:
             self.transport.all_to_all_single(self.y_recv, self.y_send, self.y_recv_counts, self.y_send_counts)
         else:

@@ -215,6 +215,10 @@ int ls_amd_scatter(ls_amd_plan *plan, int64_t n, uint64_t const *d_betas, void c
 int ls_amd_enumerate_states(ls_hs_basis const *basis, int num_locales, uint64_t **d_states,
                             uint8_t **d_masks, int64_t *count, void *stream);
 /* counts[p] = number of masks equal to p */
+/* d_out[i] = d_src[d_perm[i]] (elements of 8 or 16 bytes; perm int32 or int64): the permutation pass of the replicated-x
+ * exchange -- the received blocks (hashed order) into global ascending order, i.e. arrFromHashedToBlock
+ * (HashedToBlock.chpl:67-153) with the permutation precomputed from `masks` */
+int ls_amd_gather(int64_t n, void const *d_perm, int perm_is_64, int elt_size, void const *d_src, void *d_out, void *stream);
 int ls_amd_mask_counts(int64_t n, uint8_t const *d_masks, int num_locales, int64_t *counts,
                        void *stream);
 /* stable partition of a block-order array (elt_size 8 or 16 bytes) into P hashed parts */
