@@ -1,0 +1,34 @@
+"""examples/c_matvec.c: the C ABI from C -- no Python, no torch, no HIP headers on the caller's side.  Compiled with gcc
+against include/*.h and libls_amd.so, run as its own process, checked against the oracle."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("L", [12, 18])
+def test_c_caller(tmp_path, L):
+    from oracle import c_oracle as CO
+    from oracle import model as M
+
+    exe = str(tmp_path / "c_matvec")
+    libdir = os.path.join(ROOT, "distributed-matvec_amd")
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "c_matvec.c"), "-L", libdir, "-lls_amd", f"-Wl,-rpath,{libdir}", "-lm",
+                           "-o", exe])
+    out = subprocess.run([exe, str(L)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.strip().endswith("OK"), out.stdout
+    m = re.search(r"N = (\d+), <x\|H\|x>/<x\|x> = (-?[\d.]+)", out.stdout)
+    o = CO.COracle(M.model_from_config(M.heisenberg_chain_config(L)))
+    reps = o.enumerate()
+    assert int(m.group(1)) == len(reps)
+    x = np.sin(0.37 * np.arange(len(reps))) + 0.1
+    y = o.local_matvec(reps, x)
+    assert abs(float(m.group(2)) - float(x @ y) / float(x @ x)) < 1e-9
+    assert "one-rank RCCL path: 3 rounds, kernel tile" in out.stdout

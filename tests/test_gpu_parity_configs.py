@@ -241,3 +241,44 @@ def test_chain_40_symm_properties_and_ground_state(torch):
     # finite-size Heisenberg ring: e0 / (4 L) -> -0.443147 - pi^2 / (12 L^2) (1 + O(1/ln^3 L)), S.S units per site
     per_site = e0 / (4 * 40)
     assert -0.44385 < per_site < -0.44355, per_site
+
+
+def test_chain_32_and_36_symm_complex_vectors(torch):
+    """the north-star dtype (complex128) at the full BASELINE shapes: the c128 instantiation of the staged kernel on
+    chain_32 and the projected-basis pull kernel on chain_36_symm against oracle-recomputed rows (the operator is real, so
+    this is also H(x_re) + i H(x_im) against the f64 kernels)"""
+    import distributed_matvec_amd as D
+    from distributed_matvec_amd import config
+    from oracle import c_oracle as CO
+    from oracle import model as M
+
+    for L, symm, kernel in ((32, False, "direct-pull+staged"), (36, True, "tile-pull")):
+        cfg = config.heisenberg_chain_config(L, symm=symm)
+        basis, h = D.loadConfigFromDict(cfg, hamiltonian=True)
+        reps, masks = D.enumerateStates(basis, 1)
+        r = reps[0]
+        n = r.numel()
+        xc = D.fillRandom(r, 21, torch.complex128)
+        yc = torch.empty_like(xc)
+        pl = D.MatvecPlan(h, reps, torch.complex128, mode="pull")
+        assert pl.kernel == kernel
+        pl.matvec([xc], [yc])
+        pl.destroy()
+        o = CO.COracle(M.model_from_config(cfg))
+        rs = np.random.RandomState(L)
+        rows = np.unique(np.concatenate([rs.randint(0, n, size=20000), np.arange(1024), np.arange(n - 1024, n),
+                                         (rs.randint(0, n // 512, size=2000) * 512)]))
+        rows = rows[rows < n]
+        rows_t, want = oracle_rows(torch, o, r, rows, xc, projected=symm, rank_fn=None if symm else CO.fixed_hamming_ranks)
+        assert_rows(yc[rows_t].cpu().numpy(), want, f"chain_{L}{'_symm' if symm else ''} c128 rows")
+        # real and imaginary parts through the f64 kernels
+        xr, xi = xc.real.contiguous(), xc.imag.contiguous()
+        yr, yi = torch.empty_like(xr), torch.empty_like(xi)
+        plr = D.MatvecPlan(h, reps, torch.float64, mode="pull")
+        plr.matvec([xr], [yr])
+        plr.matvec([xi], [yi])
+        plr.destroy()
+        scale = float(yc.abs().max())
+        assert float((yc.real - yr).abs().max()) <= 1e-12 * scale and float((yc.imag - yi).abs().max()) <= 1e-12 * scale
+        del xc, yc, xr, xi, yr, yi
+        torch.cuda.empty_cache()
