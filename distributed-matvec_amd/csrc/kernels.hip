@@ -1354,7 +1354,7 @@ __global__ __launch_bounds__(kBlock) void k_tile(int n_groups, lsk_group const *
                 }
             }
             __syncthreads();
-            const int n = s_n;
+            const int n = (bs.debug_ablate & 1) ? 0 : s_n; // LS_AMD_ABLATE (profiling only): 1 no stage B, 8 drop own packets, 16 no packet writes
             // ---- stage B: project, hash, scatter locally or rank into a destination bucket --------
             for (int e = tid; e < n; e += kBlock) {
                 uint64_t beta = s_beta[e];
@@ -1385,6 +1385,7 @@ __global__ __launch_bounds__(kBlock) void k_tile(int n_groups, lsk_group const *
                     if (count_only) {
                         atomicAdd(&s_cnt[dest], 1u);
                     } else if (dest == me) {
+                        if (bs.debug_ablate & 8) { s_meta[e] = kDead; continue; }
                         int64_t idx = search_index(ix, beta);
                         if (idx < 0) atomicExch(err, 1);
                         else {
@@ -1411,7 +1412,7 @@ __global__ __launch_bounds__(kBlock) void k_tile(int n_groups, lsk_group const *
                 __syncthreads();
                 for (int e = tid; e < n; e += kBlock) {
                     const uint32_t meta = s_meta[e];
-                    if (meta == kDead) continue;
+                    if (meta == kDead || (bs.debug_ablate & 16)) continue;
                     const int dest = (int)(meta >> 16);
                     const unsigned long long pos = s_base[dest] + (meta & 0xffffu);
                     uint64_t *ob = (uint64_t *)(send + layout->beta_off[dest]);
