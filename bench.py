@@ -280,18 +280,19 @@ def main():
         setup_t0 = time.perf_counter()
         dt, kernel_ms, launches_per_step, kernel_name, exchange_bytes, plan, op_obj = measure(make, args.steps, args.warmup, "main")
     else:
-        from distributed_matvec_amd.distributed import RcclDistributedOperator, ReplicatedOperator
+        from distributed_matvec_amd.distributed import RcclDistributedOperator, RcclReplicatedOperator
 
         # Both exchange strategies are first-class numbers (same hash-partitioned x / y / representatives at the
         # interface, same result):
         #   packets     the reference's formulation: (sigma_j, c_j x_i) packets, all-to-all-v inside the C host
         #               (ls_amd_dist_matvec: grouped ncclSend/ncclRecv over xGMI, double-buffered rounds)
         #   replicated  Hermitian operators: exchange x itself (N w bytes instead of nnz (8 + w)) and pull locally
+        #               (ls_amd_repl_matvec: grouped ncclSend/ncclRecv of the blocks + permutation + pull + all-to-all-v of y)
         # A failure of either is an error of the run, never a footnote.
         comm = D.Communicator.from_torch()
         makers = {"packets": lambda: RcclDistributedOperator(h, my_reps, tdtype, comm=comm)}
         if h.isHermitian:
-            makers["replicated"] = lambda: ReplicatedOperator(h, my_reps, reps_global, masks, tdtype)
+            makers["replicated"] = lambda: RcclReplicatedOperator(h, reps_global, masks, tdtype, comm=comm)
         wanted = list(makers) if args.exchange == "auto" else [args.exchange]
         setup_t0 = time.perf_counter()
         results = {}

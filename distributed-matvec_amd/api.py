@@ -25,7 +25,7 @@ __all__ = [
     "Basis", "Operator", "LsAmdError", "loadConfigFromYaml", "loadConfigFromDict", "enumerateStates",
     "arrFromBlockToHashed", "arrFromHashedToBlock", "matrixVectorProduct", "localMatrixVector",
     "localeIdxOf", "hash64_01", "MatvecPlan", "ReplicatedPlan", "build_library", "fillRandom",
-    "Communicator", "DistMatvec",
+    "Communicator", "DistMatvec", "ReplMatvec",
 ]
 
 
@@ -533,6 +533,43 @@ class DistMatvec:
         if getattr(self, "h", None):
             self.plan.destroy()
             _lib.load().ls_amd_dist_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+class ReplMatvec:
+    """ls_amd_repl: matrixVectorProduct for this rank's block with the replicated-x exchange inside the C host (RCCL)."""
+
+    def __init__(self, comm: Communicator, matrix: Operator, reps_global, masks, dtype):
+        torch = _torch()
+        _lib.require_device()
+        self.comm, self.matrix, self.reps_global, self.masks = comm, matrix, reps_global, masks  # borrowed: keep alive
+        self.cplx = dtype in (torch.complex128, "c128")
+        assert masks.dtype == torch.uint8 and masks.is_cuda and masks.numel() == reps_global.numel()
+        h = C.c_void_p()
+        _lib.check(_lib.load().ls_amd_repl_create(C.byref(h), comm.h, matrix.payload, 1 if self.cplx else 0,
+                                                  C.c_void_p(reps_global.data_ptr()), C.c_void_p(masks.data_ptr()),
+                                                  reps_global.numel(), _stream_ptr()))
+        self.h = h
+        self.plan = _BorrowedPlan(C.c_void_p(_lib.load().ls_amd_repl_plan(h)), self, comm.size, comm.rank)
+
+    @property
+    def exchange_bytes(self): return int(_lib.load().ls_amd_repl_exchange_bytes(self.h))
+
+    def matvec(self, x, y, check: bool = True):
+        _lib.check(_lib.load().ls_amd_repl_matvec(self.h, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), _stream_ptr()))
+        if check:
+            self.plan.check()
+
+    def destroy(self):
+        if getattr(self, "h", None):
+            self.plan.destroy()
+            _lib.load().ls_amd_repl_destroy(self.h)
             self.h = None
 
     def __del__(self):

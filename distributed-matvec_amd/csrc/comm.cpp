@@ -162,18 +162,24 @@ extern "C" int lsk_comm_exchange_begin(lsk_comm *c, int slot, void *compute_stre
     HIP_CHECK(hipStreamWaitEvent(c->xstream, c->ready[slot], 0));
     return 0;
 }
-extern "C" int lsk_comm_alltoallv(lsk_comm *c, void const *d_send, int64_t const *send_off, int64_t const *send_bytes,
-                                  void *d_recv, int64_t const *recv_off, int64_t const *recv_bytes) {
+extern "C" int lsk_comm_alltoallv_on(lsk_comm *c, void *stream, void const *d_send, int64_t const *send_off,
+                                     int64_t const *send_bytes, void *d_recv, int64_t const *recv_off,
+                                     int64_t const *recv_bytes) {
+    hipStream_t s = (hipStream_t)stream;
     NCCL_CHECK(g_api.GroupStart());
     for (int step = 1; step < c->size; ++step) {
         const int dst = (c->rank + step) % c->size, src = (c->rank - step + c->size) % c->size;
         if (send_bytes[dst] > 0)
-            NCCL_CHECK(g_api.Send((char const *)d_send + send_off[dst], (size_t)send_bytes[dst], ncclChar, dst, c->comm, c->xstream));
+            NCCL_CHECK(g_api.Send((char const *)d_send + send_off[dst], (size_t)send_bytes[dst], ncclChar, dst, c->comm, s));
         if (recv_bytes[src] > 0)
-            NCCL_CHECK(g_api.Recv((char *)d_recv + recv_off[src], (size_t)recv_bytes[src], ncclChar, src, c->comm, c->xstream));
+            NCCL_CHECK(g_api.Recv((char *)d_recv + recv_off[src], (size_t)recv_bytes[src], ncclChar, src, c->comm, s));
     }
     NCCL_CHECK(g_api.GroupEnd());
     return 0;
+}
+extern "C" int lsk_comm_alltoallv(lsk_comm *c, void const *d_send, int64_t const *send_off, int64_t const *send_bytes,
+                                  void *d_recv, int64_t const *recv_off, int64_t const *recv_bytes) {
+    return lsk_comm_alltoallv_on(c, (void *)c->xstream, d_send, send_off, send_bytes, d_recv, recv_off, recv_bytes);
 }
 extern "C" int lsk_comm_exchange_end(lsk_comm *c, int slot) {
     HIP_CHECK(hipEventRecord(c->done[slot], c->xstream));

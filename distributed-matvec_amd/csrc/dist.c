@@ -264,3 +264,140 @@ int ls_amd_dist_matvec(ls_amd_dist *d, void const *d_x, void *d_y, void *stream)
     }
     return 0;
 }
+
+/* ============================================================================================ */
+/* replicated-x exchange (Hermitian operators)                                                  */
+/* ============================================================================================ */
+/* The packets of one matvec are nnz (8 + w) bytes, the vector only N w: on the chains nnz / N = 16..20, so exchanging x
+ * itself moves ~30x fewer bytes.  x, y and the representatives stay hash-partitioned at the interface
+ * (matrixVectorProduct's contract, DMV:1072-1093); per matvec
+ *   1. every rank sends its block of x to every peer (one grouped send/recv: all xGMI links at once), and ONE gather pass
+ *      through a permutation built from `masks` puts the blocks into global ascending order -- arrFromHashedToBlock
+ *      (/root/reference/src/HashedToBlock.chpl:67-153) with the merge precomputed;
+ *   2. the pull kernels compute the CONTIGUOUS global rows [N r / P, N (r + 1) / P): no packets, no atomics;
+ *   3. the results are grouped by owner (arrFromBlockToHashed restricted to the range, BlockToHashed.chpl:87-208; a
+ *      precomputed stable order) and returned with one all-to-all-v; the pieces arrive in source order = ascending. */
+struct ls_amd_repl {
+    ls_amd_comm *comm;
+    ls_amd_plan *plan;
+    int P, me, cplx, accumulate;
+    int64_t n, n0, n1, max_count, w;
+    int64_t *counts;                 /* [P] states per partition */
+    int64_t *d_perm;                 /* [n]        global row -> slot of the gathered buffer */
+    int64_t *d_yorder;               /* [n1 - n0]  rows of my range grouped by owner, ascending inside a group */
+    void *d_gathered, *d_xglobal, *d_yblock, *d_ysend, *d_yrecv;
+    int64_t *xs_off, *xs_bytes, *xr_off, *xr_bytes; /* [P] x exchange layout */
+    int64_t *ys_off, *ys_bytes, *yr_off, *yr_bytes; /* [P] y exchange layout */
+    int64_t y_self_bytes;            /* my rows of my own partition: copied, not sent */
+    int64_t exchange_bytes;
+};
+
+void ls_amd_repl_destroy(ls_amd_repl *r) {
+    if (!r) return;
+    lsk_device_sync();
+    void *bufs[] = {r->d_perm, r->d_yorder, r->d_gathered, r->d_xglobal, r->d_yblock, r->d_ysend, r->d_yrecv};
+    for (size_t i = 0; i < sizeof(bufs) / sizeof(bufs[0]); ++i) if (bufs[i]) lsk_free(bufs[i]);
+    if (r->plan) ls_amd_plan_destroy(r->plan);
+    free(r->counts);
+    free(r->xs_off); free(r->xs_bytes); free(r->xr_off); free(r->xr_bytes);
+    free(r->ys_off); free(r->ys_bytes); free(r->yr_off); free(r->yr_bytes);
+    free(r);
+}
+
+static int dmalloc(void **p, int64_t bytes) {
+    DEVC(lsk_malloc(p, (size_t)(bytes > 0 ? bytes : 8)));
+    return 0;
+}
+
+int ls_amd_repl_create(ls_amd_repl **out, ls_amd_comm *cm, ls_hs_operator const *op, ls_amd_dtype dtype,
+                       uint64_t const *d_reps_global, uint8_t const *d_masks, int64_t count_global, void *stream) {
+    *out = NULL;
+    if (!cm) return ls_amd_internal_error("ls_amd_repl_create: no communicator");
+    int const P = ls_amd_comm_size(cm), me = ls_amd_comm_rank(cm);
+    ls_amd_repl *r = (ls_amd_repl *)calloc(1, sizeof(*r));
+    r->comm = cm; r->P = P; r->me = me; r->cplx = dtype == LS_AMD_C128; r->w = r->cplx ? 16 : 8;
+    r->n = count_global;
+    r->n0 = count_global * me / P; r->n1 = count_global * (me + 1) / P;
+    r->accumulate = !op->diag_terms || op->diag_terms->number_terms == 0; /* y += H x when H has no diagonal (DMV:1062-1063) */
+    int64_t const nb = r->n1 - r->n0;
+    r->counts = (int64_t *)calloc(P, sizeof(int64_t));
+    int rc = ls_amd_mask_counts(count_global, d_masks, P, r->counts, stream);
+    for (int p = 0; p < P && rc == 0; ++p) if (r->counts[p] > r->max_count) r->max_count = r->counts[p];
+    /* --- x: permutation global row -> slot p * max_count + j of the gathered buffer (hashed -> block of the slots) --- */
+    void **pos = (void **)calloc(P, sizeof(void *));
+    if (rc == 0) rc = dmalloc((void **)&r->d_perm, 8 * r->n);
+    for (int p = 0; p < P && rc == 0; ++p) {
+        rc = dmalloc(&pos[p], 8 * r->counts[p]);
+        if (rc == 0 && lsk_iota_i64(r->counts[p], (int64_t)p * r->max_count, (int64_t *)pos[p], stream) != 0) rc = ls_amd_internal_error("%s", lsk_last_error());
+    }
+    if (rc == 0) rc = ls_amd_hashed_to_block(r->n, d_masks, P, 8, (void const *const *)pos, r->d_perm, stream);
+    for (int p = 0; p < P; ++p) if (pos[p]) lsk_free(pos[p]);
+    /* --- y: my rows grouped by owner (block -> hashed of the row numbers) --- */
+    int64_t *ycounts = (int64_t *)calloc(P, sizeof(int64_t));
+    void *iota = NULL;
+    if (rc == 0) rc = ls_amd_mask_counts(nb, d_masks + r->n0, P, ycounts, stream);
+    if (rc == 0) rc = dmalloc((void **)&r->d_yorder, 8 * nb);
+    if (rc == 0) rc = dmalloc(&iota, 8 * nb);
+    if (rc == 0 && lsk_iota_i64(nb, 0, (int64_t *)iota, stream) != 0) rc = ls_amd_internal_error("%s", lsk_last_error());
+    int64_t off = 0;
+    for (int p = 0; p < P; ++p) { pos[p] = (char *)r->d_yorder + 8 * off; off += ycounts[p]; }
+    if (rc == 0) rc = ls_amd_block_to_hashed(nb, d_masks + r->n0, P, 8, iota, pos, stream);
+    if (iota) lsk_free(iota);
+    free(pos);
+    /* --- exchange layouts: x block to everybody; y pieces by owner.  recv counts of y = what each peer's range holds
+     * of my partition: an all-gather of the [P] send counts --- */
+    r->xs_off = (int64_t *)calloc(P, 8); r->xs_bytes = (int64_t *)calloc(P, 8); r->xr_off = (int64_t *)calloc(P, 8); r->xr_bytes = (int64_t *)calloc(P, 8);
+    r->ys_off = (int64_t *)calloc(P, 8); r->ys_bytes = (int64_t *)calloc(P, 8); r->yr_off = (int64_t *)calloc(P, 8); r->yr_bytes = (int64_t *)calloc(P, 8);
+    int64_t *all = (int64_t *)calloc((size_t)P * P, 8);
+    void *ds;
+    if (rc == 0) rc = scratch(cm, 8 * (size_t)P * (size_t)(P + 1), &ds);
+    if (rc == 0 && lsk_h2d(ds, ycounts, 8 * (size_t)P) != 0) rc = ls_amd_internal_error("%s", lsk_last_error());
+    if (rc == 0 && lsk_comm_allgather(cm->c, ds, (char *)ds + 8 * P, 8 * P, stream) != 0) rc = ls_amd_internal_error("%s", lsk_comm_last_error());
+    if (rc == 0 && (lsk_sync(stream) != 0 || lsk_d2h(all, (char *)ds + 8 * P, 8 * (size_t)P * (size_t)P) != 0)) rc = ls_amd_internal_error("%s", lsk_last_error());
+    int64_t so = 0, ro = 0, mine = 0;
+    for (int p = 0; p < P; ++p) {
+        r->xs_off[p] = 0; r->xs_bytes[p] = p == me ? 0 : r->counts[me] * r->w;
+        r->xr_off[p] = (int64_t)p * r->max_count * r->w; r->xr_bytes[p] = p == me ? 0 : r->counts[p] * r->w;
+        r->ys_off[p] = so; r->ys_bytes[p] = p == me ? 0 : ycounts[p] * r->w; so += ycounts[p] * r->w;
+        int64_t const from_p = all[(size_t)p * P + me]; /* rank p's range holds this many states of my partition */
+        r->yr_off[p] = ro; r->yr_bytes[p] = p == me ? 0 : from_p * r->w; ro += from_p * r->w;
+        mine += from_p;
+        if (p == me) {
+            r->y_self_bytes = ycounts[p] * r->w;
+            if (from_p != ycounts[p] && rc == 0) rc = ls_amd_internal_error("internal error: own-partition row counts disagree");
+        } else r->exchange_bytes += r->counts[me] * r->w + ycounts[p] * r->w;
+    }
+    free(all); free(ycounts);
+    if (rc == 0 && mine != r->counts[me]) rc = ls_amd_internal_error("masks do not describe this communicator's partition (%lld vs %lld states)", (long long)mine, (long long)r->counts[me]);
+    if (rc == 0) rc = dmalloc(&r->d_gathered, (int64_t)P * r->max_count * r->w);
+    if (rc == 0) rc = dmalloc(&r->d_xglobal, r->n * r->w);
+    if (rc == 0) rc = dmalloc(&r->d_yblock, nb * r->w);
+    if (rc == 0) rc = dmalloc(&r->d_ysend, nb * r->w);
+    if (rc == 0) rc = dmalloc(&r->d_yrecv, r->counts[me] * r->w);
+    /* the pull plan over my contiguous rows of the global basis (takes the staged kernel with a row offset when it can) */
+    if (rc == 0) rc = ls_amd_plan_create_replicated(&r->plan, op, dtype, P, me, d_reps_global + r->n0, nb, d_reps_global, count_global, stream);
+    if (rc != 0) { ls_amd_repl_destroy(r); return -1; }
+    *out = r;
+    return 0;
+}
+
+ls_amd_plan *ls_amd_repl_plan(ls_amd_repl *r) { return r->plan; }
+int64_t ls_amd_repl_exchange_bytes(ls_amd_repl const *r) { return r->exchange_bytes; }
+
+int ls_amd_repl_matvec(ls_amd_repl *r, void const *d_x_local, void *d_y_local, void *stream) {
+    int64_t const nb = r->n1 - r->n0, w = r->w;
+    /* 1. blocks of x: mine by a device copy, the others straight from their owners */
+    DEVC(lsk_d2d_async((char *)r->d_gathered + r->xr_off[r->me], d_x_local, (size_t)(r->counts[r->me] * w), stream));
+    if (r->P > 1) COMM(lsk_comm_alltoallv_on(r->comm->c, stream, d_x_local, r->xs_off, r->xs_bytes, r->d_gathered, r->xr_off, r->xr_bytes));
+    DEVC(lsk_gather_perm(r->n, r->d_perm, 1, (int)w, r->d_gathered, r->d_xglobal, stream));
+    /* 2. my rows */
+    if (r->accumulate) DEVC(lsk_memset_async(r->d_yblock, 0, (size_t)(nb * w), stream));
+    TRY(ls_amd_matvec_replicated(r->plan, r->d_xglobal, r->d_yblock, stream));
+    /* 3. back to the owners: group my rows by owner, keep my own piece, one all-to-all-v for the rest */
+    DEVC(lsk_gather_perm(nb, r->d_yorder, 1, (int)w, r->d_yblock, r->d_ysend, stream));
+    DEVC(lsk_d2d_async((char *)r->d_yrecv + r->yr_off[r->me], (char *)r->d_ysend + r->ys_off[r->me], (size_t)r->y_self_bytes, stream));
+    if (r->P > 1) COMM(lsk_comm_alltoallv_on(r->comm->c, stream, r->d_ysend, r->ys_off, r->ys_bytes, r->d_yrecv, r->yr_off, r->yr_bytes));
+    if (r->accumulate) DEVC(lsk_add_into(r->cplx, r->counts[r->me], r->d_yrecv, d_y_local, stream));
+    else DEVC(lsk_d2d_async(d_y_local, r->d_yrecv, (size_t)(r->counts[r->me] * w), stream));
+    return 0;
+}

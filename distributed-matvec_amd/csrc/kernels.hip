@@ -1755,6 +1755,28 @@ __global__ __launch_bounds__(kBlock) void k_gather_perm(int64_t n, I const *__re
     }
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) out[n - 1] = src[perm[n - 1]];
 }
+__global__ __launch_bounds__(kBlock) void k_iota(int64_t n, int64_t base, int64_t *__restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) out[i] = base + i;
+}
+extern "C" int lsk_iota_i64(int64_t n, int64_t base, int64_t *out, void *stream) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_iota, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, n, base, out);
+    LSK_LAUNCH_CHECK();
+    return 0;
+}
+template <bool CPLX>
+__global__ __launch_bounds__(kBlock) void k_axpy1(int64_t n, double const *__restrict__ a, double *__restrict__ y) {
+    const int64_t m = CPLX ? 2 * n : n;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < m; i += (int64_t)gridDim.x * kBlock) y[i] += a[i];
+}
+// y += a (the accumulate semantics of operators without diagonal terms, DMV:1062-1063, in the replicated-x driver)
+extern "C" int lsk_add_into(int cplx, int64_t n, void const *a, void *y, void *stream) {
+    if (n == 0) return 0;
+    if (cplx) hipLaunchKernelGGL(k_axpy1<true>, dim3(grid_for(2 * n)), dim3(kBlock), 0, (hipStream_t)stream, n, (double const *)a, (double *)y);
+    else hipLaunchKernelGGL(k_axpy1<false>, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, n, (double const *)a, (double *)y);
+    LSK_LAUNCH_CHECK();
+    return 0;
+}
 extern "C" int lsk_gather_perm(int64_t n, void const *perm, int perm_is_64, int elt_size, void const *src, void *out, void *stream) {
     if (n == 0) return 0;
     const int64_t blocks = (n / 2 + kBlock - 1) / kBlock;

@@ -222,6 +222,9 @@ int lsk_hashed_to_block(int64_t n, uint8_t const *masks, int P, int elt_size,
 /* out[i] = src[perm[i]], elements of 8 or 16 bytes, perm int32 or int64 */
 int lsk_gather_perm(int64_t n, void const *perm, int perm_is_64, int elt_size, void const *src, void *out, void *stream);
 
+int lsk_iota_i64(int64_t n, int64_t base, int64_t *out, void *stream);
+int lsk_add_into(int cplx, int64_t n, void const *a, void *y, void *stream); /* y += a */
+
 /* RCCL (comm.cpp) ------------------------------------------------------------------------------ */
 typedef struct lsk_comm lsk_comm;
 char const *lsk_comm_last_error(void);
@@ -240,6 +243,9 @@ int lsk_comm_exchange_begin(lsk_comm *c, int slot, void *compute_stream);
 int lsk_comm_alltoallv(lsk_comm *c, void const *d_send, int64_t const *send_off, int64_t const *send_bytes, void *d_recv,
                        int64_t const *recv_off, int64_t const *recv_bytes);
 int lsk_comm_exchange_end(lsk_comm *c, int slot);
+/* the same grouped send/recv on a stream of the caller's (no second stream, no events) */
+int lsk_comm_alltoallv_on(lsk_comm *c, void *stream, void const *d_send, int64_t const *send_off, int64_t const *send_bytes,
+                          void *d_recv, int64_t const *recv_off, int64_t const *recv_bytes);
 int lsk_comm_exchange_wait(lsk_comm *c, int slot, void *compute_stream);
 
 #ifdef __cplusplus

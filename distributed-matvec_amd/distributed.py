@@ -289,6 +289,29 @@ class RcclDistributedOperator:
         return self.global_sum(local)[0]
 
 
+class RcclReplicatedOperator:
+    """matrixVectorProduct with one locale per process and the replicated-x exchange done by the C host
+    (ls_amd_repl_matvec, include/ls_amd.h): blocks of x to every peer with one grouped ncclSend/ncclRecv, one permutation
+    pass into global order, the pull kernels on a contiguous block of global rows, results back to their owners with one
+    all-to-all-v.  Same interface as RcclDistributedOperator; Hermitian operators only."""
+
+    def __init__(self, matrix, reps_global, masks, dtype, group=None, comm=None):
+        from .api import Communicator, ReplMatvec
+
+        self.comm = comm if comm is not None else Communicator.from_torch(group)
+        self.rank, self.P = self.comm.rank, self.comm.size
+        self.rm = ReplMatvec(self.comm, matrix, reps_global, masks, dtype)
+        self.engine = RcclDistributedOperator._Engine(self.rm.plan)
+        self.exchange_bytes_per_matvec = self.rm.exchange_bytes
+
+    def matvec(self, x, y, check: bool = False):
+        self.rm.matvec(x, y, check=check)
+
+    global_sum = RcclDistributedOperator.global_sum
+    broadcast = RcclDistributedOperator.broadcast
+    dot = RcclDistributedOperator.dot
+
+
 class HipReplicatedEngine:
     """ls_amd replicated-x plan for this rank (include/ls_amd.h)."""
 

@@ -119,6 +119,23 @@ ls_amd_plan *ls_amd_dist_plan(ls_amd_dist *dist);          /* timing, check, nnz
 int64_t ls_amd_dist_exchange_bytes(ls_amd_dist const *dist); /* bytes this rank sends per matvec */
 int ls_amd_dist_num_rounds(ls_amd_dist const *dist);
 
+/* The cheaper exchange for Hermitian operators: replicate x instead of sending packets (N w bytes instead of
+ * nnz (8 + w): ~30x fewer on the chains).  x, y and the representatives stay hash-partitioned at the interface; per matvec
+ * every rank's block of x goes to every peer (one grouped send/recv), one permutation pass built from `masks` puts the
+ * blocks into global ascending order (arrFromHashedToBlock, HashedToBlock.chpl:67-153), the pull kernels compute the
+ * contiguous global rows [N r / P, N (r + 1) / P) with no atomics, and the results return to their owners with one
+ * all-to-all-v (arrFromBlockToHashed restricted to the range).  Needs N w (+ the global representatives, and for projected
+ * bases the hash table) of HBM per rank.
+ * d_reps_global: the whole basis in ascending order; d_masks[i] = owner of state i (ls_amd_enumerate_states); both borrowed. */
+typedef struct ls_amd_repl ls_amd_repl;
+int ls_amd_repl_create(ls_amd_repl **repl, ls_amd_comm *comm, ls_hs_operator const *op, ls_amd_dtype dtype,
+                       uint64_t const *d_reps_global, uint8_t const *d_masks, int64_t count_global, void *stream);
+void ls_amd_repl_destroy(ls_amd_repl *repl);
+/* y_local <- (H x)_local for this rank's blocks of the hashed vectors; collective */
+int ls_amd_repl_matvec(ls_amd_repl *repl, void const *d_x_local, void *d_y_local, void *stream);
+ls_amd_plan *ls_amd_repl_plan(ls_amd_repl *repl);
+int64_t ls_amd_repl_exchange_bytes(ls_amd_repl const *repl);
+
 /* ------------------------------------------------------------------------------------------
  * Plans.  A plan binds an operator to the partition layout and owns every per-basis device table:
  * term tables, symmetry-group networks, per-row norms, index prefix tables, per-round send counts.

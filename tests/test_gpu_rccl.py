@@ -156,3 +156,106 @@ def test_dist_matvec_multi_gpu_rccl(tmp_path, name, world, cplx):
     assert np.abs(got - want).max() <= 1e-12 * max(1.0, np.abs(want).max())
     for v in load("n"):
         assert abs(v[0] - np.vdot(x, x)) < 1e-9
+
+
+@pytest.mark.parametrize("name,cplx", [("heisenberg_chain_16", False), ("heisenberg_chain_20", True), ("heisenberg_chain_24_symm", False),
+                                       ("heisenberg_kagome_16", True), ("issue_01", False)])
+def test_repl_matvec_one_rank_vs_oracle(name, cplx):
+    """the replicated-x exchange of the C host (ls_amd_repl_*) with a communicator of one rank: permutation tables from
+    masks, pull plan over the contiguous row range, owner regrouping of y; y starts dirty; called twice"""
+    import torch
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import distributed_matvec_amd as D
+    from distributed_matvec_amd.distributed import RcclReplicatedOperator
+    from helpers import model_config, oracle_for, oracle_reps
+
+    basis, h = D.loadConfigFromDict(model_config(name), hamiltonian=True)
+    reps, masks = D.enumerateStates(basis, 1)
+    want_reps = oracle_reps(name)
+    dtype = torch.complex128 if cplx else torch.float64
+    x = D.fillRandom(reps[0], 13, dtype)
+    y = torch.full_like(x, 4.0)
+    op = RcclReplicatedOperator(h, reps[0], masks, dtype, comm=D.Communicator(1, 0, D.Communicator.unique_id()))
+    assert op.engine.plan.kernel.startswith("replicated-")
+    op.matvec(x, y, check=True)
+    y2 = torch.full_like(x, -9.0)
+    op.matvec(x, y2, check=True)
+    want = oracle_for(name).local_matvec(want_reps, x.cpu().numpy())
+    assert np.abs(y.cpu().numpy() - want).max() <= 1e-12 * max(1.0, np.abs(want).max())
+    # (bitwise equality is not promised: the projected-basis kernel accumulates with LDS atomics in arrival order)
+    assert float((y - y2).abs().max()) <= 1e-12 * max(1.0, float(y.abs().max()))
+    # an operator without diagonal terms: y is accumulated into (DMV:1062-1063)
+    if name in ("heisenberg_chain_16", "heisenberg_chain_24_symm"):
+        from oracle import c_oracle as CO
+        from oracle import model as M
+
+        cfg = model_config(name)
+        cfg2 = {"basis": cfg["basis"], "hamiltonian": {"terms": [t for t in cfg["hamiltonian"]["terms"] if "ᶻ" not in t["expression"]]}}
+        basis2, h2 = D.loadConfigFromDict(cfg2, hamiltonian=True)
+        assert h2.numberDiagTerms() == 0
+        op2 = RcclReplicatedOperator(h2, reps[0], masks, dtype, comm=op.comm)
+        y3 = torch.full_like(x, 4.0)
+        op2.matvec(x, y3, check=True)
+        want2 = CO.COracle(M.model_from_config(cfg2)).local_matvec(want_reps, x.cpu().numpy(), y=np.full(len(want_reps), 4.0))
+        assert np.abs(y3.cpu().numpy() - want2).max() <= 1e-12 * max(1.0, np.abs(want2).max())
+
+
+def _repl_worker(rank, world, id_path, name, cplx, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import time
+
+    import torch
+
+    import distributed_matvec_amd as D
+    from distributed_matvec_amd.distributed import RcclReplicatedOperator
+    from helpers import model_config
+
+    torch.cuda.set_device(rank)
+    if rank == 0:
+        with open(id_path + ".tmp", "wb") as f:
+            f.write(D.Communicator.unique_id())
+        os.replace(id_path + ".tmp", id_path)
+    while not os.path.exists(id_path):
+        time.sleep(0.05)
+    with open(id_path, "rb") as f:
+        uid = f.read()
+    comm = D.Communicator(world, rank, uid)
+    basis, h = D.loadConfigFromDict(model_config(name), hamiltonian=True)
+    reps, masks = D.enumerateStates(basis, world)
+    reps_global = D.arrFromHashedToBlock(reps, masks)
+    my_reps = reps[rank].clone()
+    dtype = torch.complex128 if cplx else torch.float64
+    x = D.fillRandom(my_reps, 7, dtype)
+    y = torch.full_like(x, 9.0)
+    op = RcclReplicatedOperator(h, reps_global, masks, dtype, comm=comm)
+    op.matvec(x, y, check=True)
+    op.matvec(x, y, check=True)
+    np.save(os.path.join(out_dir, f"x{rank}.npy"), x.cpu().numpy())
+    np.save(os.path.join(out_dir, f"y{rank}.npy"), y.cpu().numpy())
+    np.save(os.path.join(out_dir, f"r{rank}.npy"), my_reps.cpu().numpy().view(np.uint64))
+
+
+@pytest.mark.parametrize("name,world,cplx", [("heisenberg_chain_16", 2, False), ("heisenberg_chain_24_symm", 2, False),
+                                             ("heisenberg_kagome_16", 3, True)])
+def test_repl_matvec_multi_gpu_rccl(tmp_path, name, world, cplx):
+    """one process per GPU, replicated-x exchange over RCCL inside the C host; skipped on the one-GPU box"""
+    import torch
+    import torch.multiprocessing as mp
+
+    if torch.cuda.device_count() < world:
+        pytest.skip(f"needs {world} GPUs (RCCL refuses two ranks on one device)")
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import oracle_for, oracle_reps
+    from oracle import c_oracle as CO
+
+    mp.spawn(_repl_worker, args=(world, str(tmp_path / "uid"), name, cplx, str(tmp_path)), nprocs=world, join=True)
+    reps = oracle_reps(name)
+    keys = CO.locale_idx_of(reps, world)
+    load = lambda k: [np.load(os.path.join(str(tmp_path), f"{k}{r}.npy")) for r in range(world)]  # noqa: E731
+    assert np.array_equal(CO.hashed_to_block(load("r"), keys), reps)
+    x = CO.hashed_to_block(load("x"), keys)
+    got = CO.hashed_to_block(load("y"), keys)
+    want = oracle_for(name).local_matvec(reps, x)
+    assert np.abs(got - want).max() <= 1e-12 * max(1.0, np.abs(want).max())
