@@ -283,8 +283,9 @@ struct ls_amd_repl {
     int P, me, cplx, accumulate;
     int64_t n, n0, n1, max_count, w;
     int64_t *counts;                 /* [P] states per partition */
-    int64_t *d_perm;                 /* [n]        global row -> slot of the gathered buffer */
-    int64_t *d_yorder;               /* [n1 - n0]  rows of my range grouped by owner, ascending inside a group */
+    void *d_perm;                    /* [n]        global row -> slot of the gathered buffer (i32 when the slots fit) */
+    void *d_yorder;                  /* [n1 - n0]  rows of my range grouped by owner, ascending inside a group */
+    int perm64, yorder64;
     void *d_gathered, *d_xglobal, *d_yblock, *d_ysend, *d_yrecv;
     int64_t *xs_off, *xs_bytes, *xr_off, *xr_bytes; /* [P] x exchange layout */
     int64_t *ys_off, *ys_bytes, *yr_off, *yr_bytes; /* [P] y exchange layout */
@@ -344,6 +345,19 @@ int ls_amd_repl_create(ls_amd_repl **out, ls_amd_comm *cm, ls_hs_operator const 
     if (rc == 0) rc = ls_amd_block_to_hashed(nb, d_masks + r->n0, P, 8, iota, pos, stream);
     if (iota) lsk_free(iota);
     free(pos);
+    /* 4-byte indices where they fit: the x permutation is the one full-size pass that remains at P > 1 */
+    r->perm64 = r->yorder64 = 1;
+    for (int which = 0; which < 2 && rc == 0; ++which) {
+        int64_t const cnt = which == 0 ? r->n : nb, top = which == 0 ? (int64_t)P * r->max_count : nb;
+        void **slot = which == 0 ? &r->d_perm : &r->d_yorder;
+        if (top >= 0x7fffffffLL || cnt == 0) continue;
+        void *narrow;
+        if (lsk_malloc(&narrow, 4 * (size_t)cnt) != 0) continue; /* no room: keep the 8-byte table */
+        if (lsk_narrow_i32(cnt, (int64_t const *)*slot, (int32_t *)narrow, stream) != 0 || lsk_sync(stream) != 0) { rc = ls_amd_internal_error("%s", lsk_last_error()); lsk_free(narrow); break; }
+        lsk_free(*slot);
+        *slot = narrow;
+        if (which == 0) r->perm64 = 0; else r->yorder64 = 0;
+    }
     /* --- exchange layouts: x block to everybody; y pieces by owner.  recv counts of y = what each peer's range holds
      * of my partition: an all-gather of the [P] send counts --- */
     r->xs_off = (int64_t *)calloc(P, 8); r->xs_bytes = (int64_t *)calloc(P, 8); r->xr_off = (int64_t *)calloc(P, 8); r->xr_bytes = (int64_t *)calloc(P, 8);
@@ -389,15 +403,16 @@ int ls_amd_repl_matvec(ls_amd_repl *r, void const *d_x_local, void *d_y_local, v
     /* 1. blocks of x: mine by a device copy, the others straight from their owners */
     DEVC(lsk_d2d_async((char *)r->d_gathered + r->xr_off[r->me], d_x_local, (size_t)(r->counts[r->me] * w), stream));
     if (r->P > 1) COMM(lsk_comm_alltoallv_on(r->comm->c, stream, d_x_local, r->xs_off, r->xs_bytes, r->d_gathered, r->xr_off, r->xr_bytes));
-    DEVC(lsk_gather_perm(r->n, r->d_perm, 1, (int)w, r->d_gathered, r->d_xglobal, stream));
+    DEVC(lsk_gather_perm(r->n, r->d_perm, r->perm64, (int)w, r->d_gathered, r->d_xglobal, stream));
     /* 2. my rows */
     if (r->accumulate) DEVC(lsk_memset_async(r->d_yblock, 0, (size_t)(nb * w), stream));
     TRY(ls_amd_matvec_replicated(r->plan, r->d_xglobal, r->d_yblock, stream));
     /* 3. back to the owners: group my rows by owner, keep my own piece, one all-to-all-v for the rest */
-    DEVC(lsk_gather_perm(nb, r->d_yorder, 1, (int)w, r->d_yblock, r->d_ysend, stream));
-    DEVC(lsk_d2d_async((char *)r->d_yrecv + r->yr_off[r->me], (char *)r->d_ysend + r->ys_off[r->me], (size_t)r->y_self_bytes, stream));
-    if (r->P > 1) COMM(lsk_comm_alltoallv_on(r->comm->c, stream, r->d_ysend, r->ys_off, r->ys_bytes, r->d_yrecv, r->yr_off, r->yr_bytes));
+    DEVC(lsk_gather_perm(nb, r->d_yorder, r->yorder64, (int)w, r->d_yblock, r->d_ysend, stream));
+    /* the pieces land in y itself (y is assigned), or in a staging buffer that is then added to y (no diagonal terms) */
+    void *dst = r->accumulate ? r->d_yrecv : d_y_local;
+    DEVC(lsk_d2d_async((char *)dst + r->yr_off[r->me], (char *)r->d_ysend + r->ys_off[r->me], (size_t)r->y_self_bytes, stream));
+    if (r->P > 1) COMM(lsk_comm_alltoallv_on(r->comm->c, stream, r->d_ysend, r->ys_off, r->ys_bytes, dst, r->yr_off, r->yr_bytes));
     if (r->accumulate) DEVC(lsk_add_into(r->cplx, r->counts[r->me], r->d_yrecv, d_y_local, stream));
-    else DEVC(lsk_d2d_async(d_y_local, r->d_yrecv, (size_t)(r->counts[r->me] * w), stream));
     return 0;
 }

@@ -1764,6 +1764,15 @@ extern "C" int lsk_iota_i64(int64_t n, int64_t base, int64_t *out, void *stream)
     LSK_LAUNCH_CHECK();
     return 0;
 }
+__global__ __launch_bounds__(kBlock) void k_narrow_i32(int64_t n, int64_t const *__restrict__ in, int32_t *__restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) out[i] = (int32_t)in[i];
+}
+extern "C" int lsk_narrow_i32(int64_t n, int64_t const *in, int32_t *out, void *stream) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_narrow_i32, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, n, in, out);
+    LSK_LAUNCH_CHECK();
+    return 0;
+}
 template <bool CPLX>
 __global__ __launch_bounds__(kBlock) void k_axpy1(int64_t n, double const *__restrict__ a, double *__restrict__ y) {
     const int64_t m = CPLX ? 2 * n : n;

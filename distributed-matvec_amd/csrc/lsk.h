@@ -223,6 +223,7 @@ int lsk_hashed_to_block(int64_t n, uint8_t const *masks, int P, int elt_size,
 int lsk_gather_perm(int64_t n, void const *perm, int perm_is_64, int elt_size, void const *src, void *out, void *stream);
 
 int lsk_iota_i64(int64_t n, int64_t base, int64_t *out, void *stream);
+int lsk_narrow_i32(int64_t n, int64_t const *in, int32_t *out, void *stream);
 int lsk_add_into(int cplx, int64_t n, void const *a, void *y, void *stream); /* y += a */
 
 /* RCCL (comm.cpp) ------------------------------------------------------------------------------ */
