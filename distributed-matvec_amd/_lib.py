@@ -130,6 +130,7 @@ def load():
         "ls_amd_comm_unique_id": (C.c_int, [vp]),
         "ls_amd_comm_create": (C.c_int, [C.POINTER(vp), C.c_int, C.c_int, vp]),
         "ls_amd_comm_destroy": (None, [vp]),
+        "ls_amd_comm_create_local": (C.c_int, [C.POINTER(vp), C.c_int]),
         "ls_amd_comm_size": (C.c_int, [vp]),
         "ls_amd_comm_rank": (C.c_int, [vp]),
         "ls_amd_comm_allreduce_sum_f64": (C.c_int, [vp, vp, C.c_int64, vp]),
@@ -158,6 +159,8 @@ def load():
         "ls_amd_basis_group_character": (C.c_int, [bp, C.c_int, c_f64p, c_f64p]),
         "ls_amd_test_tilemap": (C.c_int64, [C.c_int64, C.c_int, C.c_int64, C.POINTER(C.POINTER(C.c_uint64))]),
         "ls_amd_test_free": (None, [vp]),
+        "ls_amd_test_primme_comminfo_offset": (C.c_int, []),
+        "ls_amd_test_primme_sumtype_offset": (C.c_int, []),
         "ls_hs_init": (None, []),
         "ls_hs_exit": (None, []),
         "ls_hs_create_spin_basis": (bp, [C.c_int, C.c_int, C.c_int, C.c_int, c_intp, c_intp]),

@@ -450,6 +450,20 @@ class Communicator:
         self.h, self.size, self.rank = h, size, rank
 
     @staticmethod
+    def local_group(size: int):
+        """`size` loop-back communicators in this process (one per host thread): the multi-rank logic of the C host on a
+        one-GPU box, where RCCL refuses more than one rank per device (test infrastructure)"""
+        _lib.require_device()
+        arr = (C.c_void_p * size)()
+        _lib.check(_lib.load().ls_amd_comm_create_local(arr, size))
+        out = []
+        for r in range(size):
+            c = Communicator.__new__(Communicator)
+            c.h, c.size, c.rank = C.c_void_p(arr[r]), size, r
+            out.append(c)
+        return out
+
+    @staticmethod
     def unique_id() -> bytes:
         buf = C.create_string_buffer(128)
         _lib.check(_lib.load().ls_amd_comm_unique_id(buf))

@@ -12,6 +12,7 @@
 #include <rccl/rccl.h>
 
 #include <dlfcn.h>
+#include <pthread.h>
 
 #include <cstdint>
 #include <cstdio>
@@ -85,11 +86,24 @@ int load_api() {
         }                                                                                                  \
     } while (0)
 
+// Loop-back group: `size` communicators inside ONE process on ONE device, one per host thread, rendezvousing through a
+// barrier and moving the bytes with device-to-device copies.  Same call sequence, same buffers, same counts as the RCCL
+// path -- what differs is only the transport.  RCCL refuses two ranks on one device, so this is how the multi-rank logic
+// of the C host (set-up collectives, round pipeline, both exchange layouts) runs on a one-GPU box; the reference tests its
+// multi-locale code the same way, by oversubscribing one machine.  Test infrastructure: ls_amd_comm_create_local.
+struct LocalGroup {
+    int size, refs;
+    pthread_barrier_t bar;
+    struct Post { void const *send; int64_t const *off; int64_t const *bytes; void *buf; } post[LSK_MAX_PARTS];
+    double host[LSK_MAX_PARTS][64]; // small reductions (counts, dots)
+};
+
 struct lsk_comm {
     ncclComm_t comm;
     int size, rank;
     hipStream_t xstream;     // exchange stream: the collectives of round r overlap the kernels of round r +- 1
     hipEvent_t ready[2], done[2];
+    LocalGroup *local;       // non-null: loop-back transport
 };
 
 extern "C" int lsk_comm_available(void) { return load_api() == 0; }
@@ -111,6 +125,7 @@ extern "C" int lsk_comm_create(lsk_comm **out, int size, int rank, void const *i
     lsk_comm *c = new lsk_comm();
     c->size = size;
     c->rank = rank;
+    c->local = nullptr;
     if (g_api.CommInitRank(&c->comm, size, id, rank) != ncclSuccess) {
         snprintf(g_cerr, sizeof(g_cerr), "ncclCommInitRank(size %d, rank %d) failed", size, rank);
         delete c;
@@ -125,9 +140,38 @@ extern "C" int lsk_comm_create(lsk_comm **out, int size, int rank, void const *i
     return 0;
 }
 
+extern "C" int lsk_comm_create_local(lsk_comm **out, int size) {
+    if (size < 1 || size > LSK_MAX_PARTS) { snprintf(g_cerr, sizeof(g_cerr), "bad group size"); return -1; }
+    LocalGroup *g = new LocalGroup();
+    g->size = g->refs = size;
+    pthread_barrier_init(&g->bar, nullptr, (unsigned)size);
+    for (int r = 0; r < size; ++r) {
+        lsk_comm *c = new lsk_comm();
+        c->comm = nullptr; c->size = size; c->rank = r; c->local = g;
+        HIP_CHECK(hipStreamCreateWithFlags(&c->xstream, hipStreamNonBlocking));
+        for (int i = 0; i < 2; ++i) {
+            HIP_CHECK(hipEventCreateWithFlags(&c->ready[i], hipEventDisableTiming));
+            HIP_CHECK(hipEventCreateWithFlags(&c->done[i], hipEventDisableTiming));
+        }
+        out[r] = c;
+    }
+    return 0;
+}
+static pthread_mutex_t g_local_lock = PTHREAD_MUTEX_INITIALIZER;
+
 extern "C" void lsk_comm_destroy(lsk_comm *c) {
     if (!c) return;
     (void)hipStreamSynchronize(c->xstream);
+    if (c->local) {
+        pthread_mutex_lock(&g_local_lock);
+        const bool last = --c->local->refs == 0;
+        pthread_mutex_unlock(&g_local_lock);
+        if (last) { pthread_barrier_destroy(&c->local->bar); delete c->local; }
+        for (int i = 0; i < 2; ++i) { (void)hipEventDestroy(c->ready[i]); (void)hipEventDestroy(c->done[i]); }
+        (void)hipStreamDestroy(c->xstream);
+        delete c;
+        return;
+    }
     if (g_api.CommDestroy) (void)g_api.CommDestroy(c->comm);
     for (int i = 0; i < 2; ++i) { (void)hipEventDestroy(c->ready[i]); (void)hipEventDestroy(c->done[i]); }
     (void)hipStreamDestroy(c->xstream);
@@ -139,15 +183,53 @@ extern "C" int lsk_comm_rank(lsk_comm const *c) { return c->rank; }
 // in-place reductions / broadcast / gather on `stream` (device buffers)
 extern "C" int lsk_comm_allreduce(lsk_comm *c, void *d_buf, int64_t count, int dtype /* 0 f64, 1 f32, 2 i64 */,
                                   int op /* 0 sum, 1 max */, void *stream) {
+    if (c->local) { // every rank stages its (small) buffer on the host, everybody reduces everybody's copy
+        LocalGroup *g = c->local;
+        const size_t es = dtype == 1 ? 4 : 8;
+        if ((size_t)count * es > sizeof(g->host[0])) { snprintf(g_cerr, sizeof(g_cerr), "loop-back all-reduce: at most %zu bytes", sizeof(g->host[0])); return -1; }
+        HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+        HIP_CHECK(hipMemcpy(g->host[c->rank], d_buf, (size_t)count * es, hipMemcpyDeviceToHost));
+        pthread_barrier_wait(&g->bar);
+        double acc[64];
+        memcpy(acc, g->host[0], (size_t)count * es);
+        for (int r = 1; r < g->size; ++r)
+            for (int64_t k = 0; k < count; ++k) {
+                if (dtype == 0) { double v = g->host[r][k]; acc[k] = op == 0 ? acc[k] + v : (v > acc[k] ? v : acc[k]); }
+                else if (dtype == 1) { float v = ((float *)g->host[r])[k], &a = ((float *)acc)[k]; a = op == 0 ? a + v : (v > a ? v : a); }
+                else { int64_t v = ((int64_t *)g->host[r])[k], &a = ((int64_t *)acc)[k]; a = op == 0 ? a + v : (v > a ? v : a); }
+            }
+        pthread_barrier_wait(&g->bar); // everybody has read every copy
+        HIP_CHECK(hipMemcpy(d_buf, acc, (size_t)count * es, hipMemcpyHostToDevice));
+        return 0;
+    }
     const ncclDataType_t t = dtype == 0 ? ncclDouble : dtype == 1 ? ncclFloat : ncclInt64;
     NCCL_CHECK(g_api.AllReduce(d_buf, d_buf, (size_t)count, t, op == 0 ? ncclSum : ncclMax, c->comm, (hipStream_t)stream));
     return 0;
 }
 extern "C" int lsk_comm_broadcast(lsk_comm *c, void *d_buf, int64_t bytes, int root, void *stream) {
+    if (c->local) {
+        LocalGroup *g = c->local;
+        HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+        g->post[c->rank].buf = d_buf;
+        pthread_barrier_wait(&g->bar);
+        if (c->rank != root) HIP_CHECK(hipMemcpy(d_buf, g->post[root].buf, (size_t)bytes, hipMemcpyDeviceToDevice));
+        pthread_barrier_wait(&g->bar);
+        return 0;
+    }
     NCCL_CHECK(g_api.Broadcast(d_buf, d_buf, (size_t)bytes, ncclChar, root, c->comm, (hipStream_t)stream));
     return 0;
 }
 extern "C" int lsk_comm_allgather(lsk_comm *c, void const *d_send, void *d_recv, int64_t bytes_per_rank, void *stream) {
+    if (c->local) {
+        LocalGroup *g = c->local;
+        HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+        g->post[c->rank].send = d_send;
+        pthread_barrier_wait(&g->bar);
+        for (int r = 0; r < g->size; ++r)
+            HIP_CHECK(hipMemcpy((char *)d_recv + (size_t)r * (size_t)bytes_per_rank, g->post[r].send, (size_t)bytes_per_rank, hipMemcpyDeviceToDevice));
+        pthread_barrier_wait(&g->bar);
+        return 0;
+    }
     NCCL_CHECK(g_api.AllGather(d_send, d_recv, (size_t)bytes_per_rank, ncclChar, c->comm, (hipStream_t)stream));
     return 0;
 }
@@ -166,6 +248,26 @@ extern "C" int lsk_comm_alltoallv_on(lsk_comm *c, void *stream, void const *d_se
                                      int64_t const *send_bytes, void *d_recv, int64_t const *recv_off,
                                      int64_t const *recv_bytes) {
     hipStream_t s = (hipStream_t)stream;
+    if (c->local) { // every rank posts its send segments, then copies what is addressed to it out of its peers' buffers
+        LocalGroup *g = c->local;
+        HIP_CHECK(hipStreamSynchronize(s));
+        g->post[c->rank].send = d_send; g->post[c->rank].off = send_off; g->post[c->rank].bytes = send_bytes;
+        pthread_barrier_wait(&g->bar);
+        for (int src = 0; src < g->size; ++src) {
+            if (src == c->rank || recv_bytes[src] == 0) continue;
+            if (g->post[src].bytes[c->rank] != recv_bytes[src]) {
+                snprintf(g_cerr, sizeof(g_cerr), "loop-back all-to-all-v: rank %d sends %lld bytes to rank %d, which expects %lld", src,
+                         (long long)g->post[src].bytes[c->rank], c->rank, (long long)recv_bytes[src]);
+                pthread_barrier_wait(&g->bar);
+                return -1;
+            }
+            HIP_CHECK(hipMemcpyAsync((char *)d_recv + recv_off[src], (char const *)g->post[src].send + g->post[src].off[c->rank],
+                                     (size_t)recv_bytes[src], hipMemcpyDeviceToDevice, s));
+        }
+        HIP_CHECK(hipStreamSynchronize(s));
+        pthread_barrier_wait(&g->bar); // nobody reuses a send buffer before every peer has read it
+        return 0;
+    }
     NCCL_CHECK(g_api.GroupStart());
     for (int step = 1; step < c->size; ++step) {
         const int dst = (c->rank + step) % c->size, src = (c->rank - step + c->size) % c->size;

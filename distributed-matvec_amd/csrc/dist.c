@@ -50,6 +50,20 @@ int ls_amd_comm_create(ls_amd_comm **out, int size, int rank, void const *id) {
     *out = cm;
     return 0;
 }
+/* Loop-back group (test infrastructure): `size` communicators in THIS process on the current device, one per host thread;
+ * collectives rendezvous through a barrier and move bytes with device-to-device copies.  Runs the multi-rank logic of the
+ * host -- set-up collectives, the double-buffered round pipeline, both exchange layouts -- on a one-GPU box, where RCCL
+ * itself refuses more than one rank. */
+int ls_amd_comm_create_local(ls_amd_comm **out, int size) {
+    if (size < 1 || size > LSK_MAX_PARTS) return ls_amd_internal_error("ls_amd_comm_create_local: bad size");
+    lsk_comm *cs[LSK_MAX_PARTS];
+    COMM(lsk_comm_create_local(cs, size));
+    for (int r = 0; r < size; ++r) {
+        out[r] = (ls_amd_comm *)calloc(1, sizeof(ls_amd_comm));
+        out[r]->c = cs[r];
+    }
+    return 0;
+}
 void ls_amd_comm_destroy(ls_amd_comm *cm) {
     if (!cm) return;
     if (g_default_comm == cm) g_default_comm = NULL;
@@ -91,6 +105,11 @@ static int scratch(ls_amd_comm *cm, size_t bytes, void **out) {
 /* PRIMME reductions (host buffers, as PRIMME hands them over)                                  */
 /* ============================================================================================ */
 enum { PRIMME_OP_FLOAT = 2, PRIMME_OP_DOUBLE = 3 }; /* primme_headers/primme_eigs.h:100-107 */
+
+/* test hooks: where the two fields the reductions read sit inside primme_params (ls_primme_params_view, ls_chpl.h) */
+#include <stddef.h>
+int ls_amd_test_primme_comminfo_offset(void) { return (int)offsetof(ls_primme_params_view, commInfo); }
+int ls_amd_test_primme_sumtype_offset(void) { return (int)offsetof(ls_primme_params_view, globalSumReal_type); }
 
 static ls_amd_comm *comm_of(void *primme) {
     ls_primme_params_view *pp = (ls_primme_params_view *)primme;

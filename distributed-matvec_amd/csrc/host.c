@@ -541,7 +541,7 @@ int ls_amd_basis_group_character(ls_hs_basis const *b, int element, double *re, 
     return 0;
 }
 
-static int basis_device(ls_hs_basis const *b, lsk_basis *out) {
+static int basis_device_unlocked(ls_hs_basis const *b, lsk_basis *out) {
     struct ls_amd_basis_ext *e = BEXT(b);
     if (!e->d_elems) {
         void *p;
@@ -985,7 +985,7 @@ int ls_hs_operator_max_number_off_diag(ls_hs_operator const *op) { return OEXT(o
 bool ls_hs_operator_is_hermitian(ls_hs_operator const *op) { return OEXT(op)->is_hermitian != 0; }
 bool ls_hs_operator_is_real(ls_hs_operator const *op) { return OEXT(op)->is_real != 0; }
 
-static int operator_device(ls_hs_operator const *op, lsk_operator *out) {
+static int operator_device_unlocked(ls_hs_operator const *op, lsk_operator *out) {
     struct ls_amd_operator_ext *e = OEXT(op);
     if (!e->d_groups) {
         void *p;
@@ -1008,6 +1008,22 @@ static int operator_device(ls_hs_operator const *op, lsk_operator *out) {
     out->groups = e->d_groups;
     out->runs = e->runs;
     return 0;
+}
+
+/* the device mirrors of a basis / an operator are uploaded on first use; several host threads may create plans on the same
+ * objects at once (one communicator per thread) */
+static pthread_mutex_t g_device_tables_lock = PTHREAD_MUTEX_INITIALIZER;
+static int operator_device(ls_hs_operator const *op, lsk_operator *out) {
+    pthread_mutex_lock(&g_device_tables_lock);
+    int const rc = operator_device_unlocked(op, out);
+    pthread_mutex_unlock(&g_device_tables_lock);
+    return rc;
+}
+static int basis_device(ls_hs_basis const *b, lsk_basis *out) {
+    pthread_mutex_lock(&g_device_tables_lock);
+    int const rc = basis_device_unlocked(b, out);
+    pthread_mutex_unlock(&g_device_tables_lock);
+    return rc;
 }
 
 /* ============================================================================================ */

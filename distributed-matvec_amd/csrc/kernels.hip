@@ -97,10 +97,13 @@ constexpr int kMaxGrid = 256 * 8; // 256 CUs x 8 resident blocks: grid-stride be
 // CU too high for 256-thread kernels with 81..96 SGPRs (MI355X_MICROARCH.md), so the hot kernels are
 // kept at <= 80 SGPRs (asserted in tests/test_host_tables.py::test_hot_kernel_register_budget).
 #include <map>
+#include <mutex>
 static int g_num_cus = 0;
 template <typename K>
 static int resident_grid(K kernel, int64_t work_blocks, size_t dyn_lds = 0, int block = kBlock) {
     static std::map<std::pair<void const *, size_t>, int> cache;
+    static std::mutex lock; // plans may be created / launched from several host threads (loop-back communicators)
+    std::lock_guard<std::mutex> guard(lock);
     if (g_num_cus == 0) {
         hipDeviceProp_t prop;
         int dev = 0;

@@ -232,6 +232,7 @@ char const *lsk_comm_last_error(void);
 int lsk_comm_available(void);
 int lsk_comm_unique_id(void *id128);
 int lsk_comm_create(lsk_comm **out, int size, int rank, void const *id128);
+int lsk_comm_create_local(lsk_comm **out /* [size] */, int size); /* loop-back group: one process, one device, one thread per rank */
 void lsk_comm_destroy(lsk_comm *c);
 int lsk_comm_size(lsk_comm const *c);
 int lsk_comm_rank(lsk_comm const *c);

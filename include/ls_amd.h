@@ -93,6 +93,10 @@ int ls_amd_comm_available(void);                 /* 1 when librccl can be loaded
 int ls_amd_comm_unique_id(void *id /* [LS_AMD_UNIQUE_ID_BYTES], written on the calling rank */);
 int ls_amd_comm_create(ls_amd_comm **comm, int size, int rank, void const *id);
 void ls_amd_comm_destroy(ls_amd_comm *comm);
+/* Loop-back group (test infrastructure): `size` communicators inside this process on the current device, one per host
+ * thread; every ls_amd_comm_* / ls_amd_dist_* / ls_amd_repl_* call works on them unchanged, the transport being
+ * device-to-device copies behind a barrier.  The way to run more than one rank on a one-GPU box (RCCL refuses that). */
+int ls_amd_comm_create_local(ls_amd_comm **comms /* [size] */, int size);
 int ls_amd_comm_size(ls_amd_comm const *comm);
 int ls_amd_comm_rank(ls_amd_comm const *comm);
 /* in-place collectives on device buffers (ordered on `stream`) */
@@ -256,6 +260,9 @@ int ls_amd_basis_group_character(ls_hs_basis const *basis, int element, double *
  * (first row | rows << 48; 0 = empty slot); < 0 on error. */
 int64_t ls_amd_test_tilemap(int64_t n, int tile_rows, int64_t chunk, uint64_t **entries);
 void ls_amd_test_free(void *p);
+/* byte offsets of commInfo / globalSumReal_type inside primme_params as the PRIMME callbacks read them (ls_chpl.h) */
+int ls_amd_test_primme_comminfo_offset(void);
+int ls_amd_test_primme_sumtype_offset(void);
 
 #ifdef __cplusplus
 }

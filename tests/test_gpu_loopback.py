@@ -1,0 +1,142 @@
+"""The multi-rank logic of the C host on ONE GPU: a loop-back communicator group (ls_amd_comm_create_local) puts P ranks into
+this process, one per host thread; every collective rendezvouses through a barrier and moves its bytes with
+device-to-device copies.  Same calls, same buffers, same counts as over RCCL -- set-up collectives (round agreement,
+counts matrix), the double-buffered round pipeline of ls_amd_dist_matvec, the block / owner layouts of ls_amd_repl_matvec,
+the PRIMME reductions -- only the transport differs (RCCL refuses two ranks on one device).  The reference tests its
+multi-locale code the same way, by oversubscribing one machine."""
+import ctypes as C
+import threading
+
+import numpy as np
+import pytest
+
+from helpers import model_config, oracle_for, oracle_reps
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_ranks(P, body):
+    """body(rank, comm) on P threads; re-raises the first exception"""
+    import distributed_matvec_amd as D
+
+    comms = D.Communicator.local_group(P)
+    errors = [None] * P
+
+    def run(r):
+        try:
+            import torch
+
+            torch.cuda.set_device(0)
+            body(r, comms[r])
+        except BaseException as e:  # noqa: BLE001
+            errors[r] = e
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(P)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+    assert not any(t.is_alive() for t in threads), "a rank is stuck in a collective"
+    for e in errors:
+        if e is not None:
+            raise e
+    return comms
+
+
+@pytest.mark.parametrize("name,P,cplx", [("heisenberg_chain_16", 2, False), ("heisenberg_chain_16", 3, False),
+                                         ("heisenberg_chain_24_symm", 2, False), ("heisenberg_chain_24_symm", 4, False),
+                                         ("heisenberg_kagome_16", 3, True), ("issue_01", 2, False), ("heisenberg_chain_10", 8, False)])
+@pytest.mark.parametrize("mode", ["packets", "replicated"])
+def test_ranks_as_threads(name, P, cplx, mode):
+    import torch
+
+    import distributed_matvec_amd as D
+    from distributed_matvec_amd.distributed import RcclDistributedOperator, RcclReplicatedOperator
+    from oracle import c_oracle as CO
+
+    basis, h = D.loadConfigFromDict(model_config(name), hamiltonian=True)
+    if mode == "replicated" and not h.isHermitian:
+        pytest.skip("replicated-x needs a Hermitian operator")
+    reps, masks = D.enumerateStates(basis, P)
+    reps_global = D.arrFromHashedToBlock(reps, masks)
+    dtype = torch.complex128 if cplx else torch.float64
+    xs = [D.fillRandom(reps[p], 17, dtype) for p in range(P)]
+    ys = [torch.full_like(x, 6.0) for x in xs]
+    dots = [None] * P
+
+    def body(rank, comm):
+        if mode == "packets":
+            op = RcclDistributedOperator(h, reps[rank], dtype, comm=comm, num_rounds=3)
+            assert op.num_rounds == 3
+        else:
+            op = RcclReplicatedOperator(h, reps_global, masks, dtype, comm=comm)
+        op.matvec(xs[rank], ys[rank], check=True)
+        op.matvec(xs[rank], ys[rank], check=True)  # twice: double-buffered slots, cursors, staging buffers reused
+        dots[rank] = complex(op.dot(xs[rank], xs[rank]).cpu().item())
+        op.dm.destroy() if mode == "packets" else op.rm.destroy()
+
+    comms = _run_ranks(P, body)
+    want_reps = oracle_reps(name)
+    keys = CO.locale_idx_of(want_reps, P)
+    assert np.array_equal(CO.hashed_to_block([r.cpu().numpy().view(np.uint64) for r in reps], keys), want_reps)
+    x = CO.hashed_to_block([v.cpu().numpy() for v in xs], keys)
+    got = CO.hashed_to_block([v.cpu().numpy() for v in ys], keys)
+    want = oracle_for(name).local_matvec(want_reps, x)
+    assert np.abs(got - want).max() <= 1e-12 * max(1.0, np.abs(want).max())
+    for d in dots:  # globalSumReal over the ranks
+        assert abs(d - np.vdot(x, x)) < 1e-9
+    for c in comms:
+        c.destroy()
+
+
+def test_round_agreement_and_primme_reductions_across_ranks(monkeypatch):
+    """every rank must run the same number of rounds (all-reduce MAX of the local counts), and PRIMME's host-buffer
+    reductions (/root/reference/src/PRIMME.chpl:267-373) sum / broadcast across the ranks of primme->commInfo"""
+    import torch
+
+    import distributed_matvec_amd as D
+    from distributed_matvec_amd import _lib
+    from distributed_matvec_amd.distributed import RcclDistributedOperator
+
+    monkeypatch.setenv("LS_AMD_ROWS_PER_ROUND", "700")
+    name, P = "heisenberg_chain_16", 3
+    basis, h = D.loadConfigFromDict(model_config(name), hamiltonian=True)
+    reps, masks = D.enumerateStates(basis, P)
+    rounds = [None] * P
+    sums = [None] * P
+    bcast = [None] * P
+    L = _lib.load()
+
+    class View(C.Structure):  # just enough of primme_params for the callbacks: see include/ls_chpl.h
+        pass
+
+    def body(rank, comm):
+        op = RcclDistributedOperator(h, reps[rank], torch.float64, comm=comm)
+        rounds[rank] = op.num_rounds
+        # the reductions take the communicator from primme->commInfo: build a zeroed params view and set that field
+        buf = (C.c_char * 4096)()
+        off = L.ls_amd_test_primme_comminfo_offset()
+        C.c_void_p.from_buffer(buf, off).value = comm.h.value
+        C.c_int.from_buffer(buf, L.ls_amd_test_primme_sumtype_offset()).value = 3  # primme_op_double
+        send = np.array([1.0 + rank, -2.0 * rank, 0.5])
+        recv = np.zeros(3)
+        n, ierr = C.c_int(3), C.c_int(7)
+        L.primmeGlobalSumReal(send.ctypes.data, recv.ctypes.data, C.byref(n), buf, C.byref(ierr))
+        assert ierr.value == 0
+        sums[rank] = recv.copy()
+        b = np.array([10.0 + rank, 20.0 + rank])
+        n2 = C.c_int(2)
+        L.primmeBroadcastReal(b.ctypes.data, C.byref(n2), buf, C.byref(ierr))
+        assert ierr.value == 0
+        bcast[rank] = b.copy()
+        op.dm.destroy()
+
+    comms = _run_ranks(P, body)
+    want_rounds = max(-(-int(r.numel()) // 700) for r in reps)
+    assert rounds == [want_rounds] * P
+    for s in sums:
+        assert np.allclose(s, [1 + 2 + 3, -2.0 * (0 + 1 + 2), 1.5])
+    for b in bcast:
+        assert np.array_equal(b, [10.0, 20.0])
+    for c in comms:
+        c.destroy()
