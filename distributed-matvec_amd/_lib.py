@@ -161,6 +161,8 @@ def load():
         "ls_amd_test_free": (None, [vp]),
         "ls_amd_test_primme_comminfo_offset": (C.c_int, []),
         "ls_amd_test_primme_sumtype_offset": (C.c_int, []),
+        "ls_amd_test_primme_nlocal_offset": (C.c_int, []),
+        "ls_amd_test_primme_matrix_offset": (C.c_int, []),
         "ls_hs_init": (None, []),
         "ls_hs_exit": (None, []),
         "ls_hs_create_spin_basis": (bp, [C.c_int, C.c_int, C.c_int, C.c_int, c_intp, c_intp]),

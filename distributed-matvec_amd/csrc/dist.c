@@ -110,6 +110,8 @@ enum { PRIMME_OP_FLOAT = 2, PRIMME_OP_DOUBLE = 3 }; /* primme_headers/primme_eig
 #include <stddef.h>
 int ls_amd_test_primme_comminfo_offset(void) { return (int)offsetof(ls_primme_params_view, commInfo); }
 int ls_amd_test_primme_sumtype_offset(void) { return (int)offsetof(ls_primme_params_view, globalSumReal_type); }
+int ls_amd_test_primme_nlocal_offset(void) { return (int)offsetof(ls_primme_params_view, nLocal); }
+int ls_amd_test_primme_matrix_offset(void) { return (int)offsetof(ls_primme_params_view, matrix); }
 
 static ls_amd_comm *comm_of(void *primme) {
     ls_primme_params_view *pp = (ls_primme_params_view *)primme;

@@ -11,6 +11,7 @@
  */
 #define _GNU_SOURCE
 #include <math.h>
+#include <pthread.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -71,7 +72,6 @@ static void halt_with(char const *fmt, ...) {
  * field: an ls_hs_operator built by the real lattice-symmetries-haskell has "other stuff" of unknown layout behind the
  * prefix, and reading a field of ours there would be out of bounds.  Objects created here are registered by their
  * constructors; foreign ones by ls_amd_adopt_basis / ls_amd_adopt_operator. */
-#include <pthread.h>
 typedef struct { void const *key; void *val; int kind; } reg_slot;
 enum { REG_BASIS = 1, REG_OPERATOR = 2 };
 static reg_slot *g_reg = NULL;
@@ -188,7 +188,15 @@ static uint64_t binom(int n, int k) {
     for (int i = 1; i <= k; ++i) r = r * (n - k + i) / i;
     return (uint64_t)(r + 0.5L);
 }
-static int device_binom(uint64_t const **out) {
+static pthread_mutex_t g_binom_lock = PTHREAD_MUTEX_INITIALIZER;
+static int device_binom_unlocked(uint64_t const **out);
+static int device_binom(uint64_t const **out) { /* first use may come from several host threads at once */
+    pthread_mutex_lock(&g_binom_lock);
+    int const rc = device_binom_unlocked(out);
+    pthread_mutex_unlock(&g_binom_lock);
+    return rc;
+}
+static int device_binom_unlocked(uint64_t const **out) {
     binom_init();
     if (!g_d_binom) {
         void *p;
@@ -1968,12 +1976,12 @@ static int ensure_device_reps(ls_hs_basis *b) {
 }
 
 /* localMatrixVector on host vectors (numLocales == 1) */
-static int host_matvec_f64(ls_hs_operator *op, int64_t n, double const *x, double *y) {
+static int host_matvec_f64(ls_hs_operator *op, int64_t n, double const *x, double *y, ls_amd_comm *cm) {
     ls_hs_basis *b = op->basis;
     struct ls_amd_basis_ext *e = BEXT(b);
     if (ensure_device_reps(b) != 0) return -1;
     if ((uint64_t)n != e->d_reps_count) return set_error("vector length does not match the number of representatives");
-    ls_amd_comm *cm = ls_amd_default_comm();
+    if (!cm) cm = ls_amd_default_comm();
     if (cm && ls_amd_comm_size(cm) > 1) {
         /* one locale per process: `representatives` is this locale's block of the hashed basis and x, y are the
          * matching blocks (Diagonalize.chpl:134-162 runs the callback on every locale in lock-step) */
@@ -2024,7 +2032,7 @@ void ls_chpl_matrix_vector_product(ls_hs_operator *matrixPtr, int numVectors, do
     if (numVectors != 1) { halt_with("applying the Operator to more than 1 vector is not yet implemented"); return; }
     if (!matrixPtr->basis->representatives.elts) { halt_with("basis is not built"); return; }
     int64_t n = (int64_t)matrixPtr->basis->representatives.num_elts;
-    if (host_matvec_f64(matrixPtr, n, xPtr, yPtr) != 0) halt_with("%s", g_last_error);
+    if (host_matvec_f64(matrixPtr, n, xPtr, yPtr, NULL) != 0) halt_with("%s", g_last_error);
 }
 
 void ls_chpl_primme_matvec(void *x, int64_t *ldx, void *y, int64_t *ldy, int *blockSize, void *primme,
@@ -2035,7 +2043,7 @@ void ls_chpl_primme_matvec(void *x, int64_t *ldx, void *y, int64_t *ldy, int *bl
     *ierr = 0;
     if (*ldx < n || *ldy < n) { *ierr = -1; return; }
     for (int k = 0; k < *blockSize; ++k)
-        if (host_matvec_f64(op, n, (double const *)x + *ldx * k, (double *)y + *ldy * k) != 0) {
+        if (host_matvec_f64(op, n, (double const *)x + *ldx * k, (double *)y + *ldy * k, (ls_amd_comm *)pp->commInfo) != 0) {
             halt_with("%s", g_last_error);
             *ierr = -1;
             return;

@@ -1210,6 +1210,8 @@ template <> uint64_t const *chain_binom<uint64_t>(uint64_t const *g_binom, hipSt
 template <> uint32_t const *chain_binom<uint32_t>(uint64_t const *g_binom, hipStream_t stream) {
     static uint64_t const *src = nullptr;
     static uint32_t *narrow = nullptr;
+    static std::mutex lock;
+    std::lock_guard<std::mutex> guard(lock);
     if (src != g_binom || !narrow) {
         if (!narrow && hipMalloc((void **)&narrow, sizeof(uint32_t) * 64 * LSK_BINOM_K) != hipSuccess) return nullptr;
         hipLaunchKernelGGL(k_binom_narrow, dim3(4), dim3(kBlock), 0, stream, g_binom, narrow, 64 * LSK_BINOM_K);

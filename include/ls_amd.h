@@ -263,6 +263,8 @@ void ls_amd_test_free(void *p);
 /* byte offsets of commInfo / globalSumReal_type inside primme_params as the PRIMME callbacks read them (ls_chpl.h) */
 int ls_amd_test_primme_comminfo_offset(void);
 int ls_amd_test_primme_sumtype_offset(void);
+int ls_amd_test_primme_nlocal_offset(void);
+int ls_amd_test_primme_matrix_offset(void);
 
 #ifdef __cplusplus
 }

@@ -140,3 +140,52 @@ def test_round_agreement_and_primme_reductions_across_ranks(monkeypatch):
         assert np.array_equal(b, [10.0, 20.0])
     for c in comms:
         c.destroy()
+
+
+def test_primme_matvec_callback_across_ranks():
+    """ls_chpl_primme_matvec (/root/reference/src/Diagonalize.chpl:134-162) with one locale per rank: every rank's basis
+    holds ITS block of the hashed representatives, x and y are the matching host blocks (ldx > n, two columns), the
+    communicator comes from primme->commInfo; the callback runs on all ranks in lock-step."""
+    import distributed_matvec_amd as D
+    from distributed_matvec_amd import _lib
+    from oracle import c_oracle as CO
+
+    name, P = "heisenberg_chain_16", 3
+    L = _lib.load()
+    want_reps = oracle_reps(name)
+    keys = CO.locale_idx_of(want_reps, P)
+    parts = CO.block_to_hashed(want_reps, keys, P)
+    rs = np.random.RandomState(3)
+    x_block = [rs.rand(len(want_reps)) - 0.5 for _ in range(2)]
+    x_parts = [CO.block_to_hashed(v, keys, P) for v in x_block]
+    y_parts = [[None] * P for _ in range(2)]
+
+    def body(rank, comm):
+        basis, h = D.loadConfigFromDict(model_config(name), hamiltonian=True)  # every rank has its own objects
+        basis.uncheckedSetRepresentatives(parts[rank])
+        n = len(parts[rank])
+        ld = n + 5
+        X = np.zeros((2, ld)); Y = np.full((2, ld), 3.0)
+        for k in range(2):
+            X[k, :n] = x_parts[k][rank]
+        buf = (C.c_char * 4096)()
+        C.c_void_p.from_buffer(buf, L.ls_amd_test_primme_comminfo_offset()).value = comm.h.value
+        C.c_int64.from_buffer(buf, L.ls_amd_test_primme_nlocal_offset()).value = n
+        C.c_void_p.from_buffer(buf, L.ls_amd_test_primme_matrix_offset()).value = C.cast(h.payload, C.c_void_p).value
+        ldx, ldy, bs, ierr = C.c_int64(ld), C.c_int64(ld), C.c_int(2), C.c_int(5)
+        L.ls_chpl_primme_matvec(X.ctypes.data, C.byref(ldx), Y.ctypes.data, C.byref(ldy), C.byref(bs), buf, C.byref(ierr))
+        _lib.raise_pending_halt()
+        assert ierr.value == 0
+        assert np.all(Y[:, n:] == 3.0)  # padding untouched
+        for k in range(2):
+            y_parts[k][rank] = Y[k, :n].copy()
+        del h, basis
+
+    comms = _run_ranks(P, body)
+    o = oracle_for(name)
+    for k in range(2):
+        got = CO.hashed_to_block(y_parts[k], keys)
+        want = o.local_matvec(want_reps, x_block[k])
+        assert np.abs(got - want).max() <= 1e-12 * max(1.0, np.abs(want).max())
+    for c in comms:
+        c.destroy()
