@@ -95,7 +95,7 @@ struct LocalGroup {
     int size, refs;
     pthread_barrier_t bar;
     struct Post { void const *send; int64_t const *off; int64_t const *bytes; void *buf; } post[LSK_MAX_PARTS];
-    double host[LSK_MAX_PARTS][64]; // small reductions (counts, dots)
+    double host[LSK_MAX_PARTS][512]; // small reductions (counts, dots, Gram-Schmidt coefficients)
 };
 
 struct lsk_comm {
@@ -190,7 +190,7 @@ extern "C" int lsk_comm_allreduce(lsk_comm *c, void *d_buf, int64_t count, int d
         HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
         HIP_CHECK(hipMemcpy(g->host[c->rank], d_buf, (size_t)count * es, hipMemcpyDeviceToHost));
         pthread_barrier_wait(&g->bar);
-        double acc[64];
+        double acc[512];
         memcpy(acc, g->host[0], (size_t)count * es);
         for (int r = 1; r < g->size; ++r)
             for (int64_t k = 0; k < count; ++k) {

@@ -257,6 +257,9 @@ class RcclDistributedOperator:
         def __init__(self, plan):
             self.plan = plan
 
+        def check(self):
+            self.plan.check()
+
     def __init__(self, matrix, representatives, dtype, group=None, comm=None, num_rounds: int = 0):
         from .api import Communicator, DistMatvec
 

@@ -282,3 +282,122 @@ def test_chain_32_and_36_symm_complex_vectors(torch):
         assert float((yc.real - yr).abs().max()) <= 1e-12 * scale and float((yc.imag - yi).abs().max()) <= 1e-12 * scale
         del xc, yc, xr, xi, yr, yi
         torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("mode", ["packets", "replicated"])
+def test_chain_36_symm_eight_ranks(torch, mode):
+    """BASELINE config[3] as it will run on a node: heisenberg_chain_36_symm hash-partitioned over EIGHT ranks, the exchange
+    inside the C host (ls_amd_dist_matvec: all-to-all-v of packets; ls_amd_repl_matvec: blocks of x).  One GPU here, so the
+    ranks are host threads over the loop-back transport (tests/test_gpu_loopback.py); result vs the one-partition kernel and
+    vs oracle-recomputed rows."""
+    import distributed_matvec_amd as D
+    from distributed_matvec_amd import config
+    from distributed_matvec_amd.distributed import RcclDistributedOperator, RcclReplicatedOperator
+    from oracle import c_oracle as CO
+    from oracle import model as M
+    from test_gpu_loopback import _run_ranks
+
+    cfg = config.heisenberg_chain_config(36, symm=True)
+    basis, h = D.loadConfigFromDict(cfg, hamiltonian=True)
+    P = 8
+    reps, masks = D.enumerateStates(basis, P)
+    r_block = D.arrFromHashedToBlock(reps, masks)
+    n = r_block.numel()
+    assert n == 63068876
+    xs = [D.fillRandom(reps[p], 5, torch.float64) for p in range(P)]
+    ys = [torch.full_like(v, 2.0) for v in xs]
+
+    def body(rank, comm):
+        if mode == "packets":
+            op = RcclDistributedOperator(h, reps[rank], torch.float64, comm=comm, num_rounds=2)
+        else:
+            op = RcclReplicatedOperator(h, r_block, masks, torch.float64, comm=comm)
+        op.matvec(xs[rank], ys[rank], check=True)
+        op.dm.destroy() if mode == "packets" else op.rm.destroy()
+
+    comms = _run_ranks(P, body)
+    for c in comms:
+        c.destroy()
+    got = D.arrFromHashedToBlock(ys, masks)
+    x_block = D.arrFromHashedToBlock(xs, masks)
+    y1 = torch.empty_like(x_block)
+    pl1 = D.MatvecPlan(h, [r_block], torch.float64, mode="pull")
+    pl1.matvec([x_block], [y1])
+    pl1.destroy()
+    assert float((got - y1).abs().max()) <= 1e-12 * float(y1.abs().max())
+    o = CO.COracle(M.model_from_config(cfg))
+    rows = np.unique(np.random.RandomState(8).randint(0, n, size=10000))
+    rows_t, want = oracle_rows(torch, o, r_block, rows, x_block, projected=True)
+    assert_rows(got[rows_t].cpu().numpy(), want, f"chain_36_symm, 8 ranks, {mode}")
+
+
+def test_chain_40_symm_eight_ranks_packets(torch):
+    """BASELINE config[4] shape across eight ranks (loop-back transport): one matvec of heisenberg_chain_40_symm through
+    ls_amd_dist_matvec == the one-partition pull kernel"""
+    import distributed_matvec_amd as D
+    from distributed_matvec_amd import config
+    from distributed_matvec_amd.distributed import RcclDistributedOperator
+    from test_gpu_loopback import _run_ranks
+
+    basis, h = D.loadConfigFromDict(config.heisenberg_chain_config(40, symm=True), hamiltonian=True)
+    P = 8
+    reps, masks = D.enumerateStates(basis, P)
+    assert int(masks.numel()) == 861725794
+    xs = [D.fillRandom(reps[p], 9, torch.float64) for p in range(P)]
+    ys = [torch.full_like(v, -1.0) for v in xs]
+    rounds = [None] * P
+
+    def body(rank, comm):
+        op = RcclDistributedOperator(h, reps[rank], torch.float64, comm=comm)
+        rounds[rank] = op.num_rounds
+        op.matvec(xs[rank], ys[rank], check=True)
+        op.dm.destroy()
+
+    for c in _run_ranks(P, body):
+        c.destroy()
+    assert len(set(rounds)) == 1 and rounds[0] >= 7  # 108 M rows per rank at 2^24 rows per round
+    got = D.arrFromHashedToBlock(ys, masks)
+    del ys
+    x_block = D.arrFromHashedToBlock(xs, masks)
+    del xs
+    r_block = D.arrFromHashedToBlock(reps, masks)
+    del reps
+    torch.cuda.empty_cache()
+    y1 = torch.empty_like(x_block)
+    pl1 = D.MatvecPlan(h, [r_block], torch.float64, mode="pull")
+    pl1.matvec([x_block], [y1])
+    pl1.destroy()
+    assert float((got - y1).abs().max()) <= 1e-12 * float(y1.abs().max())
+
+
+def test_distributed_eigensolve_eight_ranks(torch):
+    """the caller of config[4] (/root/reference/src/Diagonalize.chpl:134-225): thick-restart Lanczos in lock-step on eight
+    ranks -- matvec = ls_amd_dist_matvec, dot products = globalSumReal over the communicator -- on heisenberg_chain_32_symm;
+    E0 equals the single-device solve."""
+    import distributed_matvec_amd as D
+    from distributed_matvec_amd import config
+    from distributed_matvec_amd.diagonalize import LocalOperator, RankOperator, lanczos_smallest
+    from distributed_matvec_amd.distributed import RcclDistributedOperator
+    from test_gpu_loopback import _run_ranks
+
+    basis, h = D.loadConfigFromDict(config.heisenberg_chain_config(32, symm=True), hamiltonian=True)
+    P = 8
+    reps, masks = D.enumerateStates(basis, P)
+    assert int(masks.numel()) == 4707969
+    e0 = [None] * P
+
+    def body(rank, comm):
+        op = RcclDistributedOperator(h, reps[rank], torch.float64, comm=comm)
+        res = lanczos_smallest(RankOperator(op, reps[rank], torch.float64), num_evals=1, eps=1e-9, max_basis=16)
+        assert res.converged
+        e0[rank] = res.eigenvalues[0]
+        op.dm.destroy()
+
+    for c in _run_ranks(P, body):
+        c.destroy()
+    r_block = D.arrFromHashedToBlock(reps, masks)
+    single = lanczos_smallest(LocalOperator(h, [r_block], torch.float64), num_evals=1, eps=1e-9, max_basis=16)
+    assert single.converged
+    for e in e0:
+        assert abs(e - single.eigenvalues[0]) <= 1e-7 * abs(single.eigenvalues[0])
+    assert -0.4442 < single.eigenvalues[0] / (4 * 32) < -0.4438  # finite-size Heisenberg ring
