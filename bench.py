@@ -118,7 +118,7 @@ def roofline_object(args, kernel_name, kernel_ms, launches_per_step, rows_here, 
         "traffic_note": traffic_note,
         "kernel": kernel_name, "formulation": formulation, "kernel_ms_avg": kernel_ms,
         "launches_per_step": launches_per_step, "algorithmic_bytes_per_launch": alg_per_launch,
-        "measured_stream_peak_GBps": 6290.0,  # float4 copy on this part (MI355X_MICROARCH.md)
+        "guide_stream_copy_GBps": 6290.0,  # float4 copy on this part (MI355X_MICROARCH.md); measured live below
         "survey_formula": {"B_alg_push_bytes_per_matvec": b_alg_push,
                            "matvec_over_B_alg_GBps": b_alg_push / sec_per_step / 1e9 / world,
                            "note": "push-formula bytes / time per GPU; a bandwidth only for push kernels"},
@@ -333,6 +333,22 @@ def main():
 
     roofline = roofline_object(args, kernel_name, kernel_ms, launches_per_step, int(my_reps.numel()), n_total, nnz, w, world,
                                dt / args.steps, symm)
+    # attainable streaming rate on THIS box ("measure the attainable peak with a device copy"): x -> y, 16-byte
+    # lanes, read + written bytes over HIP-event time
+    try:
+        nb = x.numel() * x.element_size()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        y.copy_(x)
+        ev0.record()
+        for _ in range(5):
+            y.copy_(x)
+        ev1.record()
+        torch.cuda.synchronize()
+        roofline["measured_stream_copy_GBps"] = 2 * nb * 5 / (ev0.elapsed_time(ev1) * 1e-3) / 1e9
+        if roofline.get("achieved"):
+            roofline["frac_of_measured_stream"] = roofline["achieved"] / roofline["measured_stream_copy_GBps"]
+    except RuntimeError:
+        pass
 
     if not distributed and not args.no_extra and not symm:
         # secondary numbers in the same run: the other scatter/gather mode and the other dtype
