@@ -338,10 +338,18 @@ def main():
     try:
         nb = x.numel() * x.element_size()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        y.copy_(x)
+        import ctypes as C
+
+        from distributed_matvec_amd import _lib
+
+        def copy():
+            _lib.check(_lib.load().ls_amd_stream_copy(C.c_void_p(y.data_ptr()), C.c_void_p(x.data_ptr()), nb,
+                                                      C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+
+        copy()
         ev0.record()
         for _ in range(5):
-            y.copy_(x)
+            copy()
         ev1.record()
         torch.cuda.synchronize()
         roofline["measured_stream_copy_GBps"] = 2 * nb * 5 / (ev0.elapsed_time(ev1) * 1e-3) / 1e9

@@ -52,6 +52,10 @@ int ls_amd_memcpy_d2d(void *d_dst, void const *d_src, size_t bytes, void *stream
 int ls_amd_memset(void *d_ptr, int value, size_t bytes, void *stream);
 int ls_amd_synchronize(void *stream);
 
+/* a plain streaming copy (16 bytes per lane): the device copy kernel the attainable HBM rate of the box is measured with
+ * (SURVEY.md 8(d)); bytes is rounded down to a multiple of 16 */
+int ls_amd_stream_copy(void *d_dst, void const *d_src, int64_t bytes, void *stream);
+
 /* hash64_01 / localeIdxOf on the host (StatesEnumeration.chpl:122-136) */
 uint64_t ls_amd_hash64_01(uint64_t x);
 int ls_amd_locale_idx_of(uint64_t basis_state, int num_locales);
