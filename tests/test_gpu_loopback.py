@@ -189,3 +189,40 @@ def test_primme_matvec_callback_across_ranks():
         assert np.abs(got - want).max() <= 1e-12 * max(1.0, np.abs(want).max())
     for c in comms:
         c.destroy()
+
+
+@pytest.mark.parametrize("mode", ["packets", "replicated"])
+def test_operator_without_diagonal_accumulates_across_ranks(mode):
+    """DMV:1062-1063: without diagonal terms y is not assigned first, so y += H x -- also when the rows of H x arrive from
+    other ranks (packets: atomics into y; replicated: the returned pieces are added to y)"""
+    import torch
+
+    import distributed_matvec_amd as D
+    from distributed_matvec_amd.distributed import RcclDistributedOperator, RcclReplicatedOperator
+    from oracle import c_oracle as CO
+    from oracle import model as M
+
+    name, P = "heisenberg_chain_16", 3
+    cfg = model_config(name)
+    cfg2 = {"basis": cfg["basis"], "hamiltonian": {"terms": [t for t in cfg["hamiltonian"]["terms"] if "ᶻ" not in t["expression"]]}}
+    basis, h = D.loadConfigFromDict(cfg2, hamiltonian=True)
+    assert h.numberDiagTerms() == 0
+    reps, masks = D.enumerateStates(basis, P)
+    reps_global = D.arrFromHashedToBlock(reps, masks)
+    xs = [D.fillRandom(reps[p], 23, torch.float64) for p in range(P)]
+    ys = [torch.full_like(x, 4.0) for x in xs]
+
+    def body(rank, comm):
+        op = (RcclDistributedOperator(h, reps[rank], torch.float64, comm=comm, num_rounds=2) if mode == "packets"
+              else RcclReplicatedOperator(h, reps_global, masks, torch.float64, comm=comm))
+        op.matvec(xs[rank], ys[rank], check=True)
+        op.dm.destroy() if mode == "packets" else op.rm.destroy()
+
+    for c in _run_ranks(P, body):
+        c.destroy()
+    want_reps = oracle_reps(name)
+    keys = CO.locale_idx_of(want_reps, P)
+    x = CO.hashed_to_block([v.cpu().numpy() for v in xs], keys)
+    got = CO.hashed_to_block([v.cpu().numpy() for v in ys], keys)
+    want = CO.COracle(M.model_from_config(cfg2)).local_matvec(want_reps, x, y=np.full(len(want_reps), 4.0))
+    assert np.abs(got - want).max() <= 1e-12 * max(1.0, np.abs(want).max())
