@@ -967,7 +967,11 @@ __global__ __launch_bounds__(kBlock, (CPLX ? 4 : 8)) void k_chain_t(lsk_runs run
     typedef typename ChainX<CPLX>::type X;
     typedef WordTraits<W> WT;
     constexpr int NB = ChainTraits<W, R>::NB;
-    constexpr int WINDOW = TILE + 2 * kChainHalo + 2;
+    // complex vectors: 11 LDS pairs and a 256-row halo (>= C(10, 5)) keep the block at 20.7 KB like the f64 one, i.e. more
+    // resident blocks per CU; pair 11 then gathers from global memory (its partners are <= 462 rows away: L1 / L2 hits)
+    constexpr int HALO = CPLX ? 256 : kChainHalo;
+    constexpr int LDSP = CPLX ? 11 : kChainLdsPairs;
+    constexpr int WINDOW = TILE + 2 * HALO + 2;
     constexpr int FAR = CPLX ? kChainFarC : kChainFar;
     constexpr R kNone = ~(R)0;
     X const *__restrict__ x = (X const *)x_v;
@@ -994,7 +998,7 @@ __global__ __launch_bounds__(kBlock, (CPLX ? 4 : 8)) void k_chain_t(lsk_runs run
         const int cnt = (int)(slot >> 48);
         if (cnt == 0) continue; // block-uniform
         const int64_t i0 = (int64_t)(slot & 0xffffffffffffULL);
-        const int64_t w0 = (row0 + i0 - kChainHalo) & ~(int64_t)1; // first row of the window (even; may be < 0)
+        const int64_t w0 = (row0 + i0 - HALO) & ~(int64_t)1; // first row of the window (even; may be < 0)
         W a_next = 0;
         R t0_next = kNone, t1_next = kNone;
         // REC: `reps` is the plan's fused record array, row -> sigma (low word) | partner rank of the first cached pair
@@ -1071,7 +1075,7 @@ __global__ __launch_bounds__(kBlock, (CPLX ? 4 : 8)) void k_chain_t(lsk_runs run
                 const double vr = runs.v_re[q];
                 int k = WT::popc(a & (W)(((uint64_t)1 << lo0) - 1));
                 int lo = lo0;
-                const int e1 = lo_end < kChainLdsPairs ? lo_end : kChainLdsPairs;
+                const int e1 = lo_end < LDSP ? lo_end : LDSP;
                 const int near_end = lo0 > e1 ? lo0 : e1;
                 const int split = hb == 0 ? lo_end : (hb < near_end ? near_end : (hb > lo_end ? lo_end : hb));
                 // ---- far pairs of a wave whose 64 states agree on every bit >= split ------------------------------
