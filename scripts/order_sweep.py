@@ -21,19 +21,17 @@ ap.add_argument("--dtype", default="f64")
 ap.add_argument("--configs", default="")
 args = ap.parse_args()
 
-KEYS = ("LS_AMD_TRANSPOSED", "LS_AMD_TOP_BITS", "LS_AMD_SET_ROWS", "LS_AMD_TILE_CHUNK", "LS_AMD_BLOCKS_PER_CU",
-        "LS_AMD_HIGH_PAIR", "LS_AMD_CHAIN_MAXLO")
+KEYS = ("LS_AMD_TILE_CHUNK", "LS_AMD_BLOCKS_PER_CU", "LS_AMD_HIGH_PAIR", "LS_AMD_CHAIN_MAXLO", "LS_AMD_CHAIN_FULLGRID",
+        "LS_AMD_CHAIN_REC", "LS_AMD_CHAIN")
+# the first configuration of a process runs 5-9 % faster than the later ones (clock / power state): compare variants in
+# separate processes (--configs ";" = one default run), or read the trailing {} against the leading one
 DEFAULT_CONFIGS = [
     {},
     {"LS_AMD_TILE_CHUNK": "32"},
     {"LS_AMD_TILE_CHUNK": "512"},
-    {"LS_AMD_TRANSPOSED": "1", "LS_AMD_TOP_BITS": "8", "LS_AMD_SET_ROWS": "262144"},
-    {"LS_AMD_TRANSPOSED": "1", "LS_AMD_TOP_BITS": "6", "LS_AMD_SET_ROWS": "5242880", "LS_AMD_TILE_CHUNK": "32"},
-    {"LS_AMD_TRANSPOSED": "1", "LS_AMD_TOP_BITS": "8", "LS_AMD_SET_ROWS": "4587520", "LS_AMD_TILE_CHUNK": "32"},
-    {"LS_AMD_TRANSPOSED": "1", "LS_AMD_TOP_BITS": "10", "LS_AMD_SET_ROWS": "2097152", "LS_AMD_TILE_CHUNK": "8"},
-    {"LS_AMD_TRANSPOSED": "1", "LS_AMD_TOP_BITS": "12", "LS_AMD_SET_ROWS": "1048576", "LS_AMD_TILE_CHUNK": "4"},
-    {"LS_AMD_TRANSPOSED": "1", "LS_AMD_TOP_BITS": "12", "LS_AMD_SET_ROWS": "4194304", "LS_AMD_TILE_CHUNK": "8"},
-    {"LS_AMD_TRANSPOSED": "1", "LS_AMD_TOP_BITS": "10", "LS_AMD_SET_ROWS": "8388608", "LS_AMD_TILE_CHUNK": "32"},
+    {"LS_AMD_CHAIN_FULLGRID": "0"},
+    {"LS_AMD_CHAIN_REC": "0"},
+    {"LS_AMD_CHAIN": "0"},
     {},
 ]
 configs = DEFAULT_CONFIGS
