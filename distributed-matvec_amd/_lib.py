@@ -159,6 +159,7 @@ def load():
         "ls_amd_basis_apply_group_element": (C.c_uint64, [bp, C.c_int, C.c_uint64]),
         "ls_amd_basis_group_character": (C.c_int, [bp, C.c_int, c_f64p, c_f64p]),
         "ls_amd_test_tilemap": (C.c_int64, [C.c_int64, C.c_int, C.c_int64, C.POINTER(C.POINTER(C.c_uint64))]),
+        "ls_amd_test_window_find": (C.c_int, [C.POINTER(C.c_uint64), C.c_int, C.c_uint64]),
         "ls_amd_test_free": (None, [vp]),
         "ls_amd_test_primme_comminfo_offset": (C.c_int, []),
         "ls_amd_test_primme_sumtype_offset": (C.c_int, []),

@@ -1127,6 +1127,8 @@ struct ls_amd_plan {
     void *d_htab;        /* hash table {rep -> x * norm(rep)} of the tile-pull families */
     uint32_t *d_slot_of; /* slot of every (global) representative */
     int htab_bits;
+    void *d_xs;          /* x * norm in index order (K4 modes that prescale x): values of the near window; else x itself */
+    int pull_halo;       /* near window of the staged pull kernel (entries either side of a tile), 0 = off */
     /* kernel timing ring */
     int t_capacity, t_count;
     void **t_start, **t_stop;
@@ -1342,6 +1344,7 @@ static int build_tilemap(ls_amd_plan *pl, int64_t n, int TILE) {
 }
 /* test hook (host only): the tile map of n rows.  Returns slots per XCD (< 0 on error); *entries is malloc'ed, free
  * with ls_amd_test_free. */
+int ls_amd_test_window_find(uint64_t const *reps, int n, uint64_t key) { return lsk_test_window_find(reps, n, key); }
 int64_t ls_amd_test_tilemap(int64_t n, int tile_rows, int64_t chunk, uint64_t **entries) {
     int64_t slots = 0;
     *entries = NULL;
@@ -1616,6 +1619,7 @@ void ls_amd_plan_destroy(ls_amd_plan *pl) {
     if (pl->d_chain_rec) lsk_free(pl->d_chain_rec);
     if (pl->d_htab) lsk_free(pl->d_htab);
     if (pl->d_slot_of) lsk_free(pl->d_slot_of);
+    if (pl->d_xs) lsk_free(pl->d_xs);
     if (pl->d_send) lsk_free(pl->d_send);
     if (pl->d_cursors) lsk_free(pl->d_cursors);
     if (pl->d_counts) lsk_free(pl->d_counts);
@@ -1734,7 +1738,8 @@ int ls_amd_matvec_replicated(ls_amd_plan *pl, void const *d_x_global, void *d_y_
         int const st = stage_begin(pl, ST_ROWS, stream);
         slot = timing_begin(pl, stream);
         DEV(lsk_tile_pull(pl->dop, pl->dbs, pl->gindex, pl->cplx, 0, ps->count, ps->d_reps, ps->d_norms,
-                          pl->d_norms_global, pl->d_row_gidx, xg, pl->htab_bits, d_x_global, d_y_local, pl->d_err, stream));
+                          pl->d_norms_global, pl->d_row_gidx, xg, pl->htab_bits, pl->gindex.reps, pl->gindex.count,
+                          pl->d_xs ? pl->d_xs : d_x_global, pl->pull_halo, d_x_global, d_y_local, pl->d_err, stream));
         timing_end(pl, slot, stream);
         stage_end(pl, st, stream);
         return 0;
@@ -1776,9 +1781,15 @@ static int prescaled_x(ls_amd_plan *pl, int64_t n, uint64_t const *d_reps, void 
         DEV(lsk_malloc(&p, 4 * (size_t)(n > 0 ? n : 1)));
         pl->d_slot_of = (uint32_t *)p;
         DEV(lsk_hash_build(pl->cplx, n, d_reps, bits, pl->d_htab, pl->d_slot_of, stream));
+        /* near window (LS_AMD_PULL_HALO entries either side of a tile, default 512, 0 = every partner through the table) */
+        char const *e = getenv("LS_AMD_PULL_HALO");
+        pl->pull_halo = e ? atoi(e) : 512;
+        if (pl->pull_halo < 0) pl->pull_halo = 0;
+        if (pl->pull_halo > 512) pl->pull_halo = 512;
+        if (pl->pull_halo > 0 && pl->dbs.k4_mode != 0) DEV(lsk_malloc(&pl->d_xs, (size_t)(pl->cplx ? 16 : 8) * (size_t)(n > 0 ? n : 1)));
     }
     int const st = stage_begin(pl, ST_REFRESH, stream);
-    DEV(lsk_hash_fill(pl->cplx, n, pl->d_slot_of, d_x, pl->dbs.k4_mode != 0 ? d_norms : NULL, pl->d_htab, stream));
+    DEV(lsk_hash_fill(pl->cplx, n, pl->d_slot_of, d_x, pl->dbs.k4_mode != 0 ? d_norms : NULL, pl->d_htab, pl->d_xs, stream));
     stage_end(pl, st, stream);
     *out = pl->d_htab;
     return 0;
@@ -1834,7 +1845,8 @@ int ls_amd_matvec(ls_amd_plan *pl, void const *const *d_x, void *const *d_y, voi
         int const st = stage_begin(pl, ST_ROWS, stream);
         int slot = timing_begin(pl, stream);
         DEV(lsk_tile_pull(pl->dop, pl->dbs, ps->index, pl->cplx, 0, ps->count, ps->d_reps, ps->d_norms, ps->d_norms,
-                          NULL, xg, pl->htab_bits, d_x[0], d_y[0], pl->d_err, stream));
+                          NULL, xg, pl->htab_bits, ps->d_reps, ps->count, pl->d_xs ? pl->d_xs : d_x[0], pl->pull_halo, d_x[0],
+                          d_y[0], pl->d_err, stream));
         timing_end(pl, slot, stream);
         stage_end(pl, st, stream);
         return 0;

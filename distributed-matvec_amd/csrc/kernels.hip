@@ -1479,6 +1479,37 @@ extern "C" int lsk_tile(lsk_operator op, lsk_basis bs, lsk_index ix, int cplx, i
 // ---------------------------------------------------------------------------------------------
 constexpr int kGCPull = 4;
 constexpr int kCapPull = kBlock * kGCPull;
+// Near window of the pull kernel.  In the sorted array of representatives the partners of a row cluster around the row
+// itself: on the symmetric chains 48 % of all projected states |rep(beta)> lie within 512 entries of the tile that
+// generated them (measured with the oracle, tests/test_partner_locality.py).  The tile therefore
+// stages the representatives [tile - 512, tile + 256 + 512) in LDS as 32-bit offsets from the first of them and
+// resolves those partners with a binary search there; their values come from the index-ordered (prescaled) x, whose
+// lines are shared by the whole neighbourhood in L1/L2.  Only the others pay the random 16-byte request into the hash
+// table, which is what bounds this kernel (one fabric request per probe).
+constexpr int kPullHalo = 512;
+constexpr int kPullWin = kBlock + 2 * kPullHalo;
+constexpr uint32_t kWinAbsent = 0xffffffffu; // offsets >= 2^32 - 1 are treated as "not in the window" (hash path)
+// position of offset d in the ascending window w[0, n), or -1.  n <= 2047.
+__host__ __device__ __forceinline__ int window_find(uint32_t const *w, int n, uint32_t d) {
+    int pos = 0; // lower bound: first entry >= d
+#pragma unroll
+    for (int step = 1024; step >= 1; step >>= 1)
+        if (pos + step <= n && w[pos + step - 1] < d) pos += step;
+    return (pos < n && w[pos] == d) ? pos : -1;
+}
+__host__ __device__ __forceinline__ uint32_t window_offset(uint64_t rep, uint64_t v0) {
+    const uint64_t d = rep - v0; // rep >= v0 inside the window (ascending)
+    return d >= (uint64_t)kWinAbsent ? kWinAbsent : (uint32_t)d;
+}
+
+extern "C" int lsk_test_window_find(uint64_t const *reps, int n, uint64_t key) {
+    if (n < 1 || n > kPullWin) return -2;
+    uint32_t w[kPullWin];
+    for (int i = 0; i < n; ++i) w[i] = window_offset(reps[i], reps[0]);
+    if (key < reps[0]) return -1;
+    const uint32_t d = window_offset(key, reps[0]);
+    return d == kWinAbsent ? -1 : window_find(w, n, d);
+}
 
 template <typename W, bool PM1, bool CPLX, bool REAL>
 __global__ __launch_bounds__(kBlock) void k_tile_pull(lsk_runs runs, int n_groups, lsk_group const *__restrict__ groups,
@@ -1491,8 +1522,11 @@ __global__ __launch_bounds__(kBlock) void k_tile_pull(lsk_runs runs, int n_group
                                                       double const *__restrict__ norms_global,
                                                       int64_t const *__restrict__ row_gidx,
                                                       uint64_t const *__restrict__ tab, int tab_bits,
+                                                      uint64_t const *__restrict__ greps, int64_t n_global,
+                                                      double const *__restrict__ xs, int halo,
                                                       double const *__restrict__ x, double *__restrict__ y, int *err) {
     constexpr int ES = CPLX ? 4 : 2; // u64 words per hash entry
+    __shared__ uint32_t s_win[kPullWin];
     __shared__ uint64_t s_beta[kCapPull];
     constexpr bool RC = REAL && PM1; // conj(H~) stays real: real coefficients and +-1 characters
     __shared__ double s_coef[kCapPull * (RC ? 1 : 2)];
@@ -1512,6 +1546,18 @@ __global__ __launch_bounds__(kBlock) void k_tile_pull(lsk_runs runs, int n_group
             inv_na = na > 0.0 ? 1.0 / na : 0.0;
         }
         if (CPLX) { s_acc[2 * tid] = 0.0; s_acc[2 * tid + 1] = 0.0; } else s_acc[tid] = 0.0;
+        // near window: global indices [gbase, gbase + wn) around the tile (the global index of its first row)
+        int64_t gbase = 0;
+        int wn = 0;
+        uint64_t v0 = 0;
+        if (halo > 0) {
+            const int64_t ig0 = row_gidx ? row_gidx[t0] : t0;
+            gbase = ig0 > halo ? ig0 - halo : 0;
+            const int64_t left = n_global - gbase;
+            wn = (int)(left < (int64_t)(kBlock + 2 * halo) ? left : (int64_t)(kBlock + 2 * halo));
+            v0 = greps[gbase];
+            for (int w = tid; w < wn; w += kBlock) s_win[w] = window_offset(greps[gbase + w], v0);
+        }
         for (int g0 = 0; g0 < n_groups; g0 += kGCPull) {
             if (tid == 0) s_n = 0;
             __syncthreads();
@@ -1567,14 +1613,30 @@ __global__ __launch_bounds__(kBlock) void k_tile_pull(lsk_runs runs, int n_group
                 ulonglong2 first[kGCPull];
                 double im0[kGCPull];
                 bool live[kGCPull];
+                int pos[kGCPull];
 #pragma unroll
-                for (int k = 0; k < kGCPull; ++k) {
+                for (int k = 0; k < kGCPull; ++k) { // the (independent) window searches first: LDS only
                     const int e = tid + k * kBlock;
                     live[k] = e < n && s_row[e] != 0xffff;
-                    key[k] = 0; slot[k] = 0; im0[k] = 0.0;
+                    key[k] = 0; slot[k] = 0; im0[k] = 0.0; pos[k] = -1;
                     first[k] = make_ulonglong2(0, 0);
                     if (live[k]) {
                         key[k] = s_beta[e];
+                        if (wn > 0 && key[k] >= v0) {
+                            const uint32_t d = window_offset(key[k], v0);
+                            if (d != kWinAbsent) pos[k] = window_find(s_win, wn, d);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < kGCPull; ++k) { // then every global load of this thread's packets
+                    if (!live[k]) continue;
+                    if (pos[k] >= 0) { // near partner: value from the index-ordered vector; looks like a home-slot hit below
+                        const int64_t j = gbase + pos[k];
+                        first[k].x = key[k];
+                        if (CPLX) { first[k].y = (unsigned long long)__double_as_longlong(xs[2 * j]); im0[k] = xs[2 * j + 1]; }
+                        else first[k].y = (unsigned long long)__double_as_longlong(xs[j]);
+                    } else {
                         slot[k] = hash_slot(key[k], tab_bits);
                         first[k] = *(ulonglong2 const *)(tab + slot[k] * ES);
                         if (CPLX) im0[k] = __longlong_as_double((long long)tab[slot[k] * ES + 2]);
@@ -1658,15 +1720,24 @@ __global__ __launch_bounds__(kBlock) void k_hash_clear(int64_t entries, int es, 
         tab[i * es] = kHashEmpty;
 }
 // values: tab[slot_of[i]] <- x[i] * norms[i]   (norms == NULL: unscaled)
+// xs (may be NULL): the same scaled values in index order, for the near window of k_tile_pull
 template <bool CPLX>
 __global__ __launch_bounds__(kBlock) void k_hash_fill(int64_t n, uint32_t const *__restrict__ slot_of,
                                                       double const *__restrict__ x, double const *__restrict__ norms,
-                                                      uint64_t *__restrict__ tab) {
+                                                      uint64_t *__restrict__ tab, double *__restrict__ xs) {
     constexpr int ES = CPLX ? 4 : 2;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
         const double nb = norms ? norms[i] : 1.0;
         double *val = (double *)(tab + (size_t)slot_of[i] * ES + 1);
-        if (CPLX) { val[0] = x[2 * i] * nb; val[1] = x[2 * i + 1] * nb; } else val[0] = x[i] * nb;
+        if (CPLX) {
+            const double vr = x[2 * i] * nb, vi = x[2 * i + 1] * nb;
+            val[0] = vr; val[1] = vi;
+            if (xs) { xs[2 * i] = vr; xs[2 * i + 1] = vi; }
+        } else {
+            const double v = x[i] * nb;
+            val[0] = v;
+            if (xs) xs[i] = v;
+        }
     }
 }
 extern "C" int lsk_hash_build(int cplx, int64_t n, uint64_t const *reps, int bits, void *tab, uint32_t *slot_of,
@@ -1682,25 +1753,28 @@ extern "C" int lsk_hash_build(int cplx, int64_t n, uint64_t const *reps, int bit
     return 0;
 }
 extern "C" int lsk_hash_fill(int cplx, int64_t n, uint32_t const *slot_of, void const *x, double const *norms, void *tab,
-                             void *stream) {
+                             void *xs, void *stream) {
     if (n == 0) return 0;
-    if (cplx) hipLaunchKernelGGL(k_hash_fill<true>, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, n, slot_of, (double const *)x, norms, (uint64_t *)tab);
-    else hipLaunchKernelGGL(k_hash_fill<false>, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, n, slot_of, (double const *)x, norms, (uint64_t *)tab);
+    if (cplx) hipLaunchKernelGGL(k_hash_fill<true>, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, n, slot_of, (double const *)x, norms, (uint64_t *)tab, (double *)xs);
+    else hipLaunchKernelGGL(k_hash_fill<false>, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, n, slot_of, (double const *)x, norms, (uint64_t *)tab, (double *)xs);
     LSK_LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" int lsk_tile_pull(lsk_operator op, lsk_basis bs, lsk_index ix_global, int cplx, int64_t row0, int64_t row1,
                              uint64_t const *reps, double const *norms_local, double const *norms_global,
-                             int64_t const *row_gidx, void const *tab, int tab_bits, void const *x_global, void *y,
+                             int64_t const *row_gidx, void const *tab, int tab_bits, uint64_t const *reps_global,
+                             int64_t n_global, void const *xs_global, int halo, void const *x_global, void *y,
                              int *d_err, void *stream) {
     if (row1 <= row0) return 0;
     if (bs.proj != LSK_PROJ_FULL) { snprintf(g_err, sizeof(g_err), "lsk_tile_pull is for projected bases"); return -1; }
+    if (halo < 0 || halo > kPullHalo || (halo > 0 && (!reps_global || !xs_global || n_global <= 0))) { snprintf(g_err, sizeof(g_err), "lsk_tile_pull: bad near window"); return -1; }
     dim3 g(1), b(kBlock);
     const int64_t work_blocks = (row1 - row0 + kBlock - 1) / kBlock;
     hipStream_t s = (hipStream_t)stream;
 #define LSK_TP_ARGS op.runs, op.n_groups, op.groups, op.off, op.n_diag, op.diag, bs, bs.elems, ix_global, row0, row1, reps, \
-        norms_local, norms_global, row_gidx, (uint64_t const *)tab, tab_bits, (double const *)x_global, (double *)y, d_err
+        norms_local, norms_global, row_gidx, (uint64_t const *)tab, tab_bits, reps_global, n_global, (double const *)xs_global, halo, \
+        (double const *)x_global, (double *)y, d_err
 #define LSK_TP_LAUNCH(W, PM1)                                                                                   \
     do {                                                                                                        \
         if (cplx) {                                                                                             \

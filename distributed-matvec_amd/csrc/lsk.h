@@ -173,11 +173,17 @@ int lsk_direct_gx(lsk_operator op, lsk_basis bs, lsk_index ix_global, int cplx, 
  * bytes; build once (keys + slot_of[i]), fill the values every matvec (norms NULL: unscaled) */
 int lsk_hash_build(int cplx, int64_t n, uint64_t const *reps, int bits, void *tab, uint32_t *slot_of, void *stream);
 int lsk_hash_fill(int cplx, int64_t n, uint32_t const *slot_of, void const *x, double const *norms, void *tab,
-                  void *stream);
+                  void *xs /* NULL, or the same scaled values in index order (near window of lsk_tile_pull) */, void *stream);
+/* halo > 0: partners within `halo` (<= 512) entries of the tile in the sorted global representatives are resolved in an
+ * LDS window and read from xs_global (= what the table holds, in index order); halo == 0: every partner through the table */
 int lsk_tile_pull(lsk_operator op, lsk_basis bs, lsk_index ix_global, int cplx, int64_t row0, int64_t row1,
                   uint64_t const *reps, double const *norms_local, double const *norms_global,
-                  int64_t const *row_gidx, void const *tab, int tab_bits, void const *x_global, void *y,
+                  int64_t const *row_gidx, void const *tab, int tab_bits, uint64_t const *reps_global,
+                  int64_t n_global, void const *xs_global, int halo, void const *x_global, void *y,
                   int *d_err, void *stream);
+/* host-side check of the window search (tests, no device): position of `key` among the ascending reps[0, n), n <= 1280,
+ * or -1 -- exactly what a tile resolves in LDS */
+int lsk_test_window_find(uint64_t const *reps, int n, uint64_t key);
 /* n packets -> y[idx(beta)] += value */
 int lsk_scatter(lsk_index ix, int cplx, int64_t n, uint64_t const *betas, void const *vals, void *y,
                 double const *norms /* NULL, or per-row norms multiplied in (K4 modes 1, 2) */, int *d_err,

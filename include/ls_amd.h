@@ -264,6 +264,10 @@ int ls_amd_basis_group_character(ls_hs_basis const *basis, int element, double *
  * (first row | rows << 48; 0 = empty slot); < 0 on error. */
 int64_t ls_amd_test_tilemap(int64_t n, int tile_rows, int64_t chunk, uint64_t **entries);
 void ls_amd_test_free(void *p);
+/* Host-only test hook: the near-window search of the staged pull kernel for projected bases (k_tile_pull): position of
+ * `key` among the ascending reps[0, n) (n <= 1280, stored as saturating 32-bit offsets from reps[0] exactly as a tile
+ * stores them in LDS), -1 if it is not there or not representable (then the kernel takes the hash table), -2 on bad n */
+int ls_amd_test_window_find(uint64_t const *reps, int n, uint64_t key);
 /* byte offsets of commInfo / globalSumReal_type inside primme_params as the PRIMME callbacks read them (ls_chpl.h) */
 int ls_amd_test_primme_comminfo_offset(void);
 int ls_amd_test_primme_sumtype_offset(void);

@@ -419,3 +419,32 @@ def test_operator_shares_its_basis():
     gc.collect()
     assert C.addressof(h.payload.contents.basis.contents) == addr and h.basis.numberSites() == 10
     assert keep is not None
+
+
+def test_near_window_search_of_the_pull_kernel():
+    """k_tile_pull resolves partners that lie in the tile's neighbourhood of the sorted representatives with a binary
+    search over saturating 32-bit offsets in LDS (window_find / window_offset in kernels.hip, compiled for the host too):
+    every member is found at its position, every non-member is a miss, gaps >= 2^32 - 1 fall back to the hash table."""
+    lib = _lib.load()
+    rng = np.random.RandomState(7)
+
+    def find(reps, key):
+        a = np.ascontiguousarray(reps, dtype=np.uint64)
+        return lib.ls_amd_test_window_find(a.ctypes.data_as(C.POINTER(C.c_uint64)), len(a), C.c_uint64(int(key)))
+
+    for n in (1, 2, 3, 255, 256, 1023, 1024, 1025, 1279, 1280):
+        reps = np.unique(rng.randint(0, (1 << 32) - 2, size=4 * n, dtype=np.int64).astype(np.uint64))[:n] + np.uint64(1 << 36)
+        if len(reps) < n:
+            continue
+        for pos in {0, n - 1, n // 2, *rng.randint(0, n, size=16).tolist()}:
+            assert find(reps, reps[pos]) == pos
+        present = set(reps.tolist())
+        for key in [int(reps[0]) - 1, int(reps[-1]) + 1, 0, (1 << 64) - 1, *[int(k) + 1 for k in reps[rng.randint(0, n, size=16)]]]:
+            if key not in present and 0 <= key < (1 << 64):
+                assert find(reps, key) == -1
+    # a window whose span exceeds 32 bits: entries past the 2^32 - 1 cut are "absent" (the kernel then asks the table)
+    base = 5 << 33
+    reps = np.array([base, base + 7, base + (1 << 32) - 2, base + (1 << 32) - 1, base + (1 << 32), base + (1 << 40)], dtype=np.uint64)
+    assert [find(reps, k) for k in reps] == [0, 1, 2, -1, -1, -1]
+    assert find(reps, base + 8) == -1 and find(reps, base + (1 << 32) + 5) == -1
+    assert find(reps[:1], base) == 0 and find(np.arange(1281, dtype=np.uint64), 3) == -2
