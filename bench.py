@@ -51,6 +51,20 @@ def source_sha():
     return hsh.hexdigest()[:16]
 
 
+def kernel_isa_sha(family):
+    """fingerprint of the machine code of one kernel family of this build (distributed-matvec_amd/kernel_isa.json, written
+    by the build from the device assembly: scripts/kernel_isa_sha.py), or None when the file does not belong to the
+    source in the tree"""
+    try:
+        with open(os.path.join(ROOT, "distributed-matvec_amd", "kernel_isa.json")) as f:
+            isa = json.load(f)
+    except (OSError, ValueError):
+        return None
+    if isa.get("source_sha") != source_sha():
+        return None
+    return isa.get("families", {}).get(family, {}).get("isa_sha")
+
+
 PULL_KERNELS = ("direct-pull", "tile-pull", "replicated-")
 
 
@@ -64,7 +78,8 @@ def roofline_object(args, kernel_name, kernel_ms, launches_per_step, rows_here, 
           (4 B cached partner rank per cached pair for the staged kernel, 8 B norm for projected bases).
     `achieved` = those bytes / average launch time, `frac` = achieved / peak: cannot exceed 1.
     `traffic` = fabric bytes of the same launch from the committed PMC passes (profiles/pmc_traffic.json), attached
-    only when the entry was measured on this very kernel source (source_sha); `frac_traffic` = traffic / t / peak,
+    only when the entry was measured on the very machine code of this build's kernel (isa_sha of the kernel family, or the
+    sha of the whole kernel source for entries without one); `frac_traffic` = traffic / t / peak,
     `wasted_traffic` = traffic / algorithmic bytes (> 1 = re-reads the caches did not absorb).
     `survey_formula` keeps the SURVEY.md 8(d) push-formula figure for cross-reference; for a pull kernel it is NOT a
     bandwidth (the kernel never performs the 2w read-modify-write per non-zero the formula charges)."""
@@ -94,9 +109,12 @@ def roofline_object(args, kernel_name, kernel_ms, launches_per_step, rows_here, 
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             ent = json.load(f).get(f"{args.model}/{args.dtype}/{kernel_name}")
         if ent and world == 1:
-            if ent.get("source_sha") == sha:
+            isa = kernel_isa_sha(ent.get("device_kernel", "").rstrip("<"))
+            same_code = (ent.get("isa_sha") is not None and ent.get("isa_sha") == isa) or ent.get("source_sha") == sha
+            if same_code:
                 traffic = ent["traffic_bytes"]
-                traffic_note = f"profiles/pmc_traffic.json ({ent.get('source')}), source_sha {sha}"
+                traffic_note = (f"profiles/pmc_traffic.json ({ent.get('source')}), measured on source_sha "
+                                f"{ent.get('source_sha')}; {ent.get('device_kernel')} ISA {ent.get('isa_sha')} == this build's")
                 if ent.get("valu_insts"):
                     # integer-ALU roofline of the projected bases: wave64 VALU instructions x 64 lanes
                     peak_lane_ops = 256 * 4 * 32 * 2.4e9  # CUs x SIMDs x lanes per clock x Hz
@@ -104,8 +122,9 @@ def roofline_object(args, kernel_name, kernel_ms, launches_per_step, rows_here, 
                     int_alu = {"valu_wave_insts_per_launch": ent["valu_insts"], "achieved_lane_ops_per_s": ach,
                                "peak_lane_ops_per_s": peak_lane_ops, "frac": ach / peak_lane_ops if ach else None}
             else:
-                traffic_note = (f"PMC entry is stale: measured on source_sha {ent.get('source_sha')}, this build is {sha}; "
-                                f"re-run scripts/gpu_pmc_traffic.sh")
+                traffic_note = (f"PMC entry is stale: measured on {ent.get('device_kernel')} ISA {ent.get('isa_sha')} (source_sha "
+                                f"{ent.get('source_sha')}), this build is ISA {isa} (source_sha {sha}); re-run "
+                                f"scripts/gpu_pmc_traffic.sh")
     except (OSError, ValueError):
         pass
     b_alg_push = n_total * (8 + 2 * w) + nnz * 2 * w

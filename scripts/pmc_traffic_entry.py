@@ -31,7 +31,7 @@ def mean_counter(root, sub, counter, needle):
 
 def main():
     root, model, dtype, kname = sys.argv[1:5]
-    from bench import source_sha
+    from bench import kernel_isa_sha, source_sha
 
     needle = next(v for k, v in DEVICE_KERNEL.items() if k in kname)
     fetch, nf = mean_counter(root, "pmc_fetch", "FETCH_SIZE", needle)
@@ -44,6 +44,7 @@ def main():
         "fetch_size_kib_raw": fetch, "fetch_correction": corr, "write_size_kib": write,
         "traffic_bytes": (corr * fetch + write) * 1024.0 if fetch is not None and write is not None else None,
         "dispatches": [nf, nw], "device_kernel": needle, "source_sha": source_sha(),
+        "isa_sha": kernel_isa_sha(needle.rstrip("<")),
         "source": os.environ.get("PMC_SOURCE", ""),
     }
     if valu is not None:

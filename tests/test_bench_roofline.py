@@ -1,0 +1,79 @@
+"""bench.py's roofline object (host logic only): fractions cannot exceed 1 by construction, and a PMC traffic entry is
+attached only to the machine code it was measured on ("Make the roofline object true")."""
+import argparse
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+N32, NNZ32 = 601080390, 9927521280
+
+
+def _roof(model="heisenberg_chain_32", dtype="f64", kernel="direct-pull+staged", ms=8.3, w=8, symm=False):
+    args = argparse.Namespace(model=model, dtype=dtype)
+    return bench.roofline_object(args, kernel, ms, 1, N32, N32, NNZ32, w, 1, ms * 1e-3, symm)
+
+
+def test_kernel_isa_file_belongs_to_the_tree():
+    path = os.path.join(ROOT, "distributed-matvec_amd", "kernel_isa.json")
+    assert os.path.exists(path), "run __graft_entry__.build() (csrc/Makefile writes kernel_isa.json)"
+    with open(path) as f:
+        isa = json.load(f)
+    assert isa["source_sha"] == bench.source_sha(), "kernel_isa.json is stale: rebuild"
+    for fam in ("k_chain_t", "k_tile_pull", "k_tile", "k_direct", "k_scatter", "k_diag"):
+        assert len(isa["families"][fam]["isa_sha"]) == 16
+    assert bench.kernel_isa_sha("k_chain_t") == isa["families"]["k_chain_t"]["isa_sha"]
+    assert bench.kernel_isa_sha("no_such_kernel") is None
+
+
+def test_pull_fractions_cannot_exceed_one_at_the_copy_rate():
+    # a pull kernel that moved only its compulsory bytes at the HBM peak would sit at frac == 1; at any real time below
+    r = _roof(ms=8.3)
+    assert r["formulation"].startswith("pull")
+    assert r["algorithmic_bytes_per_launch"] == N32 * (8 + 16 + 4)
+    assert 0 < r["frac"] < 1 and r["frac"] == r["frac_compulsory"]
+    t_peak_ms = r["algorithmic_bytes_per_launch"] / (bench.HBM_PEAK_GBPS * 1e9) * 1e3
+    assert abs(_roof(ms=t_peak_ms)["frac"] - 1.0) < 1e-12
+    # the push formula is only a cross-reference for pull kernels
+    assert r["survey_formula"]["B_alg_push_bytes_per_matvec"] == N32 * 24 + NNZ32 * 16
+    p = _roof(kernel="direct-push", ms=74.0)
+    assert p["formulation"].startswith("push") and p["algorithmic_bytes_per_launch"] == N32 * 16 + NNZ32 * 16
+    assert 0 < p["frac"] < 1
+
+
+def test_traffic_is_attached_only_to_the_code_it_measured(monkeypatch):
+    with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+        ent = json.load(f)["heisenberg_chain_32/f64/direct-pull+staged"]
+    assert ent["device_kernel"] == "k_chain_t" and ent.get("isa_sha")
+    # same machine code -> attached, with fractions <= 1 and the waste factor >= 1
+    monkeypatch.setattr(bench, "kernel_isa_sha", lambda fam: ent["isa_sha"] if fam == "k_chain_t" else None)
+    r = _roof(ms=8.3)
+    assert r["traffic"] == ent["traffic_bytes"]
+    assert 0 < r["frac_traffic"] <= 1.0 and r["wasted_traffic"] >= 1.0
+    # different machine code and different source -> refused, and the note says why
+    monkeypatch.setattr(bench, "kernel_isa_sha", lambda fam: "0" * 16)
+    monkeypatch.setattr(bench, "source_sha", lambda: "f" * 16)
+    r = _roof(ms=8.3)
+    assert r["traffic"] is None and r["frac_traffic"] is None and "stale" in r["traffic_note"]
+    # a fingerprint file that does not belong to the tree's source is ignored altogether
+    monkeypatch.undo()
+    monkeypatch.setattr(bench, "source_sha", lambda: "f" * 16)
+    assert bench.kernel_isa_sha("k_chain_t") is None
+
+
+@pytest.mark.parametrize("key", ["heisenberg_chain_32/f64/direct-pull+staged", "heisenberg_chain_32/c128/direct-pull+staged"])
+def test_headline_entries_describe_this_build(key):
+    """The driver's bench line carries `traffic` only if the committed PMC passes belong to the shipped k_chain_t.  This
+    test does not fail on a kernel edit -- it reports: a stale entry means re-running scripts/gpu_pmc_traffic.sh."""
+    with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+        ent = json.load(f)[key]
+    if bench.kernel_isa_sha("k_chain_t") != ent.get("isa_sha"):
+        pytest.skip("k_chain_t changed since the committed PMC passes: traffic will be null until re-measured")
+    model, dtype, kernel = key.split("/")
+    r = _roof(model=model, dtype=dtype, kernel=kernel, ms=8.3 if dtype == "f64" else 14.7, w=8 if dtype == "f64" else 16)
+    assert r["traffic"] == ent["traffic_bytes"] and r["frac_traffic"] <= 1.0
