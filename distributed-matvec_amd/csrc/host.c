@@ -1484,11 +1484,10 @@ static int plan_setup_part(ls_amd_plan *pl, part_state *ps, int part_id, int num
     unsigned long long hc[LSK_MAX_PARTS];
     for (int r = 0; r < rounds; ++r) {
         int64_t row0 = ps->count * r / rounds, row1 = ps->count * (r + 1) / rounds;
-        DEV(lsk_memset_async(pl->d_counts, 0, 8 * LSK_MAX_PARTS, stream));
-        DEV(lsk_tile(pl->dop, pl->dbs, ps->index, pl->cplx, 1, P, part_id, row0, row1, ps->d_reps, ps->d_norms,
-                     NULL, NULL, pl->d_cursors, NULL, NULL, pl->d_counts, pl->d_err, stream));
-        DEV(lsk_sync(stream));
-        DEV(lsk_d2h(hc, pl->d_counts, 8 * (size_t)P));
+        if (lsk_memset_async(pl->d_counts, 0, 8 * LSK_MAX_PARTS, stream) != 0 ||
+            lsk_tile(pl->dop, pl->dbs, ps->index, pl->cplx, 1, P, part_id, row0, row1, ps->d_reps, ps->d_norms,
+                     NULL, NULL, pl->d_cursors, NULL, NULL, pl->d_counts, pl->d_err, stream) != 0 ||
+            lsk_sync(stream) != 0 || lsk_d2h(hc, pl->d_counts, 8 * (size_t)P) != 0) { free(layouts); return dev_error(); }
         int64_t off = 0;
         for (int d = 0; d < P; ++d) {
             pl->nnz += (int64_t)hc[d];
@@ -1503,11 +1502,11 @@ static int plan_setup_part(ls_amd_plan *pl, part_state *ps, int part_id, int num
         if (off > ps->max_send_bytes) ps->max_send_bytes = off;
     }
     void *p;
-    DEV(lsk_malloc(&p, sizeof(lsk_round_layout) * (size_t)rounds));
-    DEV(lsk_h2d(p, layouts, sizeof(lsk_round_layout) * (size_t)rounds));
-    ps->d_layouts = (lsk_round_layout *)p;
+    if (lsk_malloc(&p, sizeof(lsk_round_layout) * (size_t)rounds) != 0) { free(layouts); return dev_error(); }
+    ps->d_layouts = (lsk_round_layout *)p; /* owned by the plan from here on */
+    int const rc = lsk_h2d(p, layouts, sizeof(lsk_round_layout) * (size_t)rounds);
     free(layouts);
-    return 0;
+    return rc != 0 ? dev_error() : 0;
 }
 
 int ls_amd_plan_create(ls_amd_plan **out, ls_hs_operator const *op, ls_amd_dtype dtype,
@@ -1566,14 +1565,14 @@ int ls_amd_plan_create(ls_amd_plan **out, ls_hs_operator const *op, ls_amd_dtype
     } else pl->family = FAMILY_TILE;
 
     void *p;
-    if (lsk_malloc(&p, 8 * LSK_MAX_PARTS) != 0) { free(pl); return dev_error(); }
+    if (lsk_malloc(&p, 8 * LSK_MAX_PARTS) != 0) { ls_amd_plan_destroy(pl); return dev_error(); }
     pl->d_cursors = (unsigned long long *)p;
-    if (lsk_malloc(&p, 8 * LSK_MAX_PARTS) != 0) { free(pl); return dev_error(); }
+    if (lsk_malloc(&p, 8 * LSK_MAX_PARTS) != 0) { ls_amd_plan_destroy(pl); return dev_error(); }
     pl->d_counts = (unsigned long long *)p;
-    if (lsk_malloc(&p, sizeof(int)) != 0) { free(pl); return dev_error(); }
+    if (lsk_malloc(&p, sizeof(int)) != 0) { ls_amd_plan_destroy(pl); return dev_error(); }
     pl->d_err = (int *)p;
     int zero = 0;
-    lsk_h2d(pl->d_err, &zero, sizeof(int));
+    if (lsk_h2d(pl->d_err, &zero, sizeof(int)) != 0) { ls_amd_plan_destroy(pl); return dev_error(); }
 
     pl->parts = (part_state *)calloc(pl->n_local, sizeof(part_state));
     for (int i = 0; i < pl->n_local; ++i) {
