@@ -65,17 +65,31 @@ def kernel_isa_sha(family):
     return isa.get("families", {}).get(family, {}).get("isa_sha")
 
 
+def kernel_instance_sha(instance):
+    """fingerprint of ONE template instantiation of this build ("k_chain_t<unsigned int, unsigned int, false, 1024, true>")"""
+    try:
+        with open(os.path.join(ROOT, "distributed-matvec_amd", "kernel_isa.json")) as f:
+            isa = json.load(f)
+    except (OSError, ValueError):
+        return None
+    if isa.get("source_sha") != source_sha():
+        return None
+    return isa.get("kernels", {}).get(instance)
+
+
 PULL_KERNELS = ("direct-pull", "tile-pull", "replicated-")
 
 
-def roofline_object(args, kernel_name, kernel_ms, launches_per_step, rows_here, n_total, nnz, w, world, sec_per_step, symm):
+def roofline_object(args, kernel_name, kernel_ms, launches_per_step, rows_here, n_total, nnz, w, world, sec_per_step, symm,
+                    row_bytes=8):
     """HBM roofline of the dominant kernel, per launch.
 
     ALGORITHMIC bytes = the compulsory traffic of the formulation the kernel executes:
       push (direct-push, tile: the reference's formulation):
           rows (8 + w) [+ w for the y write of the separate diagonal pass] + nnz 2w   (RMW of y_j per non-zero)
-      pull (Hermitian operators; y written once, no RMW): rows (8 + 2w) + the per-row plan data the kernel streams
-          (4 B cached partner rank per cached pair for the staged kernel, 8 B norm for projected bases).
+      pull (Hermitian operators; y written once, no RMW): rows (row_bytes + 2w), row_bytes = the per-row basis / plan data
+          the measured instantiation streams (ls_amd_plan_row_bytes: the 8-byte fused sigma|partner record of the staged
+          f64 kernel -- 24 B per row --, 4 + 4 for the c128 / unfused instantiations, 8 + 8 B norm for projected bases).
     `achieved` = those bytes / average launch time, `frac` = achieved / peak: cannot exceed 1.
     `traffic` = fabric bytes of the same launch from the committed PMC passes (profiles/pmc_traffic.json), attached
     only when the entry was measured on the very machine code of this build's kernel (isa_sha of the kernel family, or the
@@ -85,14 +99,9 @@ def roofline_object(args, kernel_name, kernel_ms, launches_per_step, rows_here, 
     bandwidth (the kernel never performs the 2w read-modify-write per non-zero the formula charges)."""
     nnz_here = nnz * rows_here // max(1, n_total)
     pull = kernel_name.startswith(PULL_KERNELS)
-    per_row_extra = 0
     if pull:
-        if "staged" in kernel_name:
-            per_row_extra = 4  # one cached partner rank per row (the ring-closing pair)
-        if "tile-pull" in kernel_name:
-            per_row_extra = 8  # norm(alpha)
-        alg = rows_here * (8 + 2 * w + per_row_extra)
-        formulation = "pull: rows (8 + 2w + plan bytes per row); y written once"
+        alg = rows_here * (row_bytes + 2 * w)
+        formulation = f"pull: rows ({row_bytes} B state / plan data + 2w); y written once"
     elif kernel_name == "direct-push":
         alg = rows_here * (8 + w) + nnz_here * 2 * w  # the diagonal pass (y write) is a separate, tiny kernel
         formulation = "push: rows (8 + w) + nnz 2w (SURVEY 8(d))"
@@ -111,6 +120,11 @@ def roofline_object(args, kernel_name, kernel_ms, launches_per_step, rows_here, 
         if ent and world == 1:
             isa = kernel_isa_sha(ent.get("device_kernel", "").rstrip("<"))
             same_code = (ent.get("isa_sha") is not None and ent.get("isa_sha") == isa) or ent.get("source_sha") == sha
+            if ent.get("instance_isa_sha"):  # the measured instantiation itself, whatever happened to its siblings
+                inst = kernel_instance_sha(ent.get("instance", ""))
+                same_code = same_code or inst == ent["instance_isa_sha"]
+                if inst == ent["instance_isa_sha"]:
+                    isa = f"{inst} ({ent['instance']})"
             if same_code:
                 traffic = ent["traffic_bytes"]
                 traffic_note = (f"profiles/pmc_traffic.json ({ent.get('source')}), measured on source_sha "
@@ -148,27 +162,51 @@ def roofline_object(args, kernel_name, kernel_ms, launches_per_step, rows_here, 
 
 
 def cpu_baseline(sample_L, threads=0, repeats=3):
-    """oracle ("port") timed on the host cores: heisenberg_chain_<sample_L>, full matvec."""
+    """oracle ("port") timed on the host cores: heisenberg_chain_<sample_L>, full matvec.  Large samples (the benchmark
+    workload itself: chain_32 is ~15-20 s per matvec on 128 threads) are timed ONCE, after a warm-up of the thread pool on a
+    small chain and with x / y already touched, so that the default bench run stays bounded."""
     import numpy as np
 
     from oracle import c_oracle as CO
     from oracle import model as M
 
+    big = sample_L >= 30
+    cores = CO.lib().lso_num_threads() if threads <= 0 else threads
+    if big:  # spin the OpenMP pool up on something small
+        ow = CO.COracle(M.model_from_config(M.heisenberg_chain_config(20)))
+        rw = ow.enumerate()
+        ow.local_matvec(rw, np.random.RandomState(1).rand(len(rw)) - 0.5, num_threads=cores)
     cfg = M.heisenberg_chain_config(sample_L)
     o = CO.COracle(M.model_from_config(cfg))
     reps = o.enumerate()
     n = len(reps)
     x = np.random.RandomState(42).rand(n) - 0.5
     y = np.zeros(n)
-    cores = CO.lib().lso_num_threads() if threads <= 0 else threads
-    o.local_matvec(reps, x, y, num_threads=cores)  # warm-up
+    if not big:
+        o.local_matvec(reps, x, y, num_threads=cores)  # warm-up
     times = []
-    for _ in range(repeats):
+    for _ in range(1 if big else repeats):
         t = time.perf_counter()
         o.local_matvec(reps, x, y, num_threads=cores)
         times.append(time.perf_counter() - t)
     best = min(times)
-    return {"seconds_per_matvec": best, "n": n, "nnz": chain_nnz(sample_L, n), "cores": int(cores), "L": sample_L}
+    return {"seconds_per_matvec": best, "n": n, "nnz": chain_nnz(sample_L, n), "cores": int(cores), "L": sample_L,
+            "timed_matvecs": len(times)}
+
+
+def default_cpu_sample(L):
+    """the benchmark workload itself when the host can hold and finish it (chain_32 f64 = 14.4 GB, ~17 s per matvec on the
+    GPU box's 128 threads); otherwise chain_28 with the per-non-zero cost scaled (and labelled so)"""
+    try:
+        cores = os.cpu_count() or 1
+        with open("/proc/meminfo") as f:
+            mem_kb = int(next(line for line in f if line.startswith("MemAvailable")).split()[1])
+    except (OSError, StopIteration, ValueError):
+        return min(L, 28)
+    if L <= 28:
+        return L
+    need_gb = 24.0 * math.comb(L, L // 2) / 1e9 * 1.5
+    return L if (cores >= 64 and mem_kb / 1e6 >= need_gb and L <= 32) else 28
 
 
 def main():
@@ -183,7 +221,9 @@ def main():
                     help="N > 1: all-to-all-v of packets (reference formulation), all-gather of x + pull, or (auto) both")
     ap.add_argument("--force-distributed", action="store_true",
                     help="run the N > 1 code path (process group, exchange) even with one rank (test hook)")
-    ap.add_argument("--cpu-sample", type=int, default=28, help="chain length of the CPU-baseline sample")
+    ap.add_argument("--cpu-sample", type=int, default=0,
+                    help="chain length of the CPU-baseline sample (0 = the workload itself when the host has >= 64 cores and "
+                         "the memory for it, else 28)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary (other dtype / other mode) measurements")
     ap.add_argument("--kDisplayTimings", action="store_true",
@@ -198,9 +238,23 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # invoked exactly like the N = 1 line (`python bench.py --gpus N ...`): become the launcher, one rank per GPU
+        # over RCCL, rendezvous on 127.0.0.1 (what the driver's own torch.distributed.run line does)
+        have = torch.cuda.device_count()
+        if have < args.gpus and not os.environ.get("LS_AMD_BENCH_SHARE_DEVICE"):
+            raise SystemExit(f"--gpus {args.gpus}: only {have} HIP device(s) visible")
+        import socket
+
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        sys.stdout.flush()
+        os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+                                  "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU")
     if os.environ.get("LS_AMD_BENCH_SHARE_DEVICE"):  # test hook: several ranks on one GPU (if RCCL allows it)
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -318,14 +372,20 @@ def main():
         failed = {}
         for name in wanted:
             torch.cuda.empty_cache()
+            r, err = None, None
             try:
                 r = measure(makers[name], args.steps, args.warmup, name)
             except Exception as e:  # reported at the TOP level of the JSON line (failed_exchanges) and on stderr, never hidden
                 import traceback
 
                 traceback.print_exc()
-                failed[name] = repr(e)[:400]
+                err = repr(e)[:400]
+            # every rank takes the same view of a strategy: failed anywhere = failed everywhere (a rank that raised outside a
+            # collective -- allocation, plan creation -- would otherwise leave its peers with a number it never produced)
+            if allsum(1.0 if err else 0.0) > 0:
+                failed[name] = err or "failed on another rank"
                 exchanges[name] = {"error": failed[name]}
+                r = None
                 continue
             results[name] = r
             exchanges[name] = {"matvecs_per_s": args.steps / r[0], "ms_per_step": 1e3 * r[0] / args.steps, "kernel": r[3],
@@ -335,7 +395,9 @@ def main():
                 del r
         if not results:
             raise SystemExit(f"every exchange strategy failed: {failed}")
-        exchange = min(results, key=lambda k: results[k][0])  # `value` is the faster strategy, named in config.exchange
+        # `value` is the faster strategy, named in config.exchange; the times are max-over-ranks (all-reduced in
+        # time_steps), so every rank picks the same one
+        exchange = min(sorted(results), key=lambda k: results[k][0])
         dt, kernel_ms, launches_per_step, kernel_name, exchange_bytes, plan, op_obj = results[exchange]
     setup_s = (setup_t0 - t_setup)
     if symm:
@@ -351,7 +413,7 @@ def main():
     value = args.steps / dt
 
     roofline = roofline_object(args, kernel_name, kernel_ms, launches_per_step, int(my_reps.numel()), n_total, nnz, w, world,
-                               dt / args.steps, symm)
+                               dt / args.steps, symm, row_bytes=plan.row_bytes if plan is not None else 8)
     # attainable streaming rate on THIS box ("measure the attainable peak with a device copy"): x -> y, 16-byte
     # lanes, read + written bytes over HIP-event time
     try:
@@ -401,7 +463,7 @@ def main():
 
     cpu = None
     if rank == 0 and not distributed and not args.no_cpu_baseline:
-        s = cpu_baseline(min(args.cpu_sample, L))
+        s = cpu_baseline(min(args.cpu_sample, L) if args.cpu_sample > 0 else default_cpu_sample(L))
         # scale the measured per-non-zero cost of the sample to the benchmark workload
         per_nnz = s["seconds_per_matvec"] / s["nnz"]
         est = per_nnz * nnz
@@ -410,7 +472,8 @@ def main():
             "sample": f"heisenberg_chain_{s['L']} full matvec (f64, {s['n']} states, {s['nnz']} nnz) "
                       f"{s['seconds_per_matvec']:.3f} s on {s['cores']} threads; per-nnz cost scaled to "
                       f"{args.model} ({nnz} nnz)" if s["L"] != L else
-                      f"{args.model} full matvec, {s['seconds_per_matvec']:.3f} s on {s['cores']} threads",
+                      f"{args.model} itself: one full matvec (f64, {s['n']} states, {s['nnz']} nnz), "
+                      f"{s['seconds_per_matvec']:.3f} s on {s['cores']} threads, measured (no extrapolation)",
             "sample_seconds_per_matvec": s["seconds_per_matvec"],
         }
 
@@ -429,6 +492,8 @@ def main():
                 "exchange_bytes_per_matvec": exchange_bytes,
             },
             "exchanges": exchanges,
+            "value_is": (f"best of {len(exchanges)} exchange strategies ({exchange})" if distributed and len(exchanges) > 1
+                         else "the single configuration measured"),
             "failed_exchanges": sorted(failed) if distributed else [],
             "roofline": roofline,
             "cpu_baseline": cpu,

@@ -112,6 +112,7 @@ def load():
         "ls_amd_plan_kernel_name": (C.c_char_p, [vp]),
         "ls_amd_plan_send_counts": (C.c_int, [vp, C.c_int, c_i64p]),
         "ls_amd_plan_packet_bytes": (C.c_int, [vp]),
+        "ls_amd_plan_row_bytes": (C.c_int, [vp]),
         "ls_amd_plan_nnz": (C.c_int64, [vp]),
         "ls_amd_matvec": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), vp]),
         "ls_amd_plan_check": (C.c_int, [vp, vp]),

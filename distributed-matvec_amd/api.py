@@ -375,6 +375,8 @@ class MatvecPlan:
     def nnz(self): return int(_lib.load().ls_amd_plan_nnz(self.h))
     @property
     def packet_bytes(self): return int(_lib.load().ls_amd_plan_packet_bytes(self.h))
+    @property
+    def row_bytes(self): return int(_lib.load().ls_amd_plan_row_bytes(self.h))
 
     def send_counts(self, rnd: int):
         c = (C.c_int64 * self.P)()

@@ -64,9 +64,11 @@ int ls_amd_comm_create_local(ls_amd_comm **out, int size) {
     }
     return 0;
 }
+void ls_amd_internal_forget_comm(void const *comm); /* host.c: drops the plans the host-pointer entry points cached for it */
 void ls_amd_comm_destroy(ls_amd_comm *cm) {
     if (!cm) return;
     if (g_default_comm == cm) g_default_comm = NULL;
+    ls_amd_internal_forget_comm(cm);
     if (cm->d_scratch) lsk_free(cm->d_scratch);
     lsk_comm_destroy(cm->c);
     free(cm);

@@ -247,8 +247,17 @@ struct ls_amd_basis_ext {
     int owns_representatives;
     uint64_t *d_reps_cache; /* device copy of `representatives` for the host-pointer entry points */
     uint64_t d_reps_count;
-    void *host_plan_f64;    /* ls_amd_plan* cached by the host-pointer entry points */
-    void *host_dist_f64;    /* ls_amd_dist* likewise, when a default communicator with > 1 ranks is installed */
+    /* plans cached by the host-pointer entry points (ls_chpl_matrix_vector_product, ls_chpl_primme_matvec), keyed by the
+     * OPERATOR and the communicator they were built for: several operators share one basis (H and an observable,
+     * ls_hs_clone_operator), and each needs its own device term tables */
+    struct host_plan_slot {
+        ls_hs_operator const *op;
+        void *comm;    /* ls_amd_comm* (NULL: single process) */
+        void *plan;    /* ls_amd_plan* when comm == NULL */
+        void *dist;    /* ls_amd_dist* otherwise */
+        uint64_t stamp;
+    } host_plans[4];
+    uint64_t host_plan_clock;
     uint32_t *d_index_table; /* search table over d_reps_cache (ls_hs_state_index) */
     int index_kind, index_shift;
     int refcount;           /* the creator's reference + one per operator built on the basis */
@@ -489,10 +498,36 @@ ls_hs_basis *ls_hs_clone_basis(ls_hs_basis const *basis) {
     return b;
 }
 
+#define HOST_PLAN_SLOTS ((int)(sizeof(((struct ls_amd_basis_ext *)0)->host_plans) / sizeof(struct host_plan_slot)))
+static void host_plan_slot_drop(struct host_plan_slot *sl) {
+    if (sl->plan) ls_amd_plan_destroy((ls_amd_plan *)sl->plan);
+    if (sl->dist) ls_amd_dist_destroy((ls_amd_dist *)sl->dist);
+    memset(sl, 0, sizeof(*sl));
+}
+/* forget the cached plans of one operator (op != NULL), of one communicator (comm != NULL), or all of them */
+static void basis_drop_host_plans(struct ls_amd_basis_ext *e, ls_hs_operator const *op, void const *comm) {
+    for (int i = 0; i < HOST_PLAN_SLOTS; ++i) {
+        struct host_plan_slot *sl = &e->host_plans[i];
+        if (!sl->op) continue;
+        if ((op && sl->op != op) || (comm && sl->comm != comm)) continue;
+        host_plan_slot_drop(sl);
+    }
+}
+/* a communicator is going away (ls_amd_comm_destroy, dist.c): no cached ls_amd_dist may keep pointing at it */
+void ls_amd_internal_forget_comm(void const *comm) {
+    pthread_mutex_lock(&g_reg_lock);
+    size_t n = 0;
+    struct ls_amd_basis_ext **es = (struct ls_amd_basis_ext **)calloc(g_reg_cap ? g_reg_cap : 1, sizeof(*es));
+    for (size_t i = 0; i < g_reg_cap; ++i)
+        if (g_reg[i].key && g_reg[i].key != REG_TOMB && g_reg[i].kind == REG_BASIS) es[n++] = (struct ls_amd_basis_ext *)g_reg[i].val;
+    pthread_mutex_unlock(&g_reg_lock);
+    for (size_t i = 0; i < n; ++i) basis_drop_host_plans(es[i], NULL, comm);
+    free(es);
+}
+
 static void basis_drop_device_caches(ls_hs_basis *b) {
     struct ls_amd_basis_ext *e = BEXT(b);
-    if (e->host_plan_f64) { ls_amd_plan_destroy((ls_amd_plan *)e->host_plan_f64); e->host_plan_f64 = NULL; }
-    if (e->host_dist_f64) { ls_amd_dist_destroy((ls_amd_dist *)e->host_dist_f64); e->host_dist_f64 = NULL; }
+    basis_drop_host_plans(e, NULL, NULL);
     if (e->d_reps_cache) { lsk_free(e->d_reps_cache); e->d_reps_cache = NULL; e->d_reps_count = 0; }
     if (e->d_index_table) { lsk_free(e->d_index_table); e->d_index_table = NULL; }
     e->index_kind = -1;
@@ -975,6 +1010,10 @@ void ls_hs_destroy_operator(ls_hs_operator *op) {
     if (!op) return;
     struct ls_amd_operator_ext *e = (struct ls_amd_operator_ext *)reg_get(op);
     if (!e) return;
+    { /* plans cached for this operator hold its device tables (and its address may be reused by the next operator) */
+        struct ls_amd_basis_ext *be = op->basis ? (struct ls_amd_basis_ext *)reg_get(op->basis) : NULL;
+        if (be) basis_drop_host_plans(be, op, NULL);
+    }
     if (e->d_groups) lsk_free(e->d_groups);
     if (e->d_off) lsk_free(e->d_off);
     if (e->d_diag) lsk_free(e->d_diag);
@@ -1404,18 +1443,23 @@ static int setup_chain(ls_amd_plan *pl, lsk_index index, int64_t n, uint64_t con
         pl->chain_v[1] = nc > 1 ? ext->groups[ext->runs.n_run_groups + 1].v_re : 0.0;
     }
     if (build_tilemap(pl, n, lsk_chain_tile_rows(pl->cplx)) != 0) return -1;
-    /* 32-bit states and ranks, at most one cached pair: fuse state and partner rank into one 8-byte record per row
-     * (8 instead of 8 + 4 bytes per row from HBM, one load instead of two); LS_AMD_CHAIN_REC=0 keeps the two arrays */
-    char const *er = getenv("LS_AMD_CHAIN_REC");
-    /* f64 only: measured on chain_32 8.59 -> 8.41 ms (f64) but 15.40 -> 15.70 ms (c128) */
-    if (!pl->cplx && pl->op->basis->number_sites <= 32 && !pl->chain_wide && pl->chain_cached <= 1 && n > 0 && !(er && atoi(er) == 0)) {
+    /* 32-bit states and ranks, f64 vectors: state and partner rank of the first cached pair are fused into one 8-byte
+     * record per row (8 instead of 8 + 4 bytes per row from HBM, one load instead of two: measured on chain_32
+     * 8.59 -> 8.41 ms; c128: 15.40 -> 15.70 ms, so complex vectors keep the two arrays).  This shape has no unfused
+     * instantiation (it sat at 98 SGPRs, one resident block per CU short); a second cached pair stays in the cache
+     * array, whose layout [pair][row] is what the kernel indexes.  No room for the records: the generic row kernel. */
+    if (!pl->cplx && pl->op->basis->number_sites <= 32 && !pl->chain_wide && n > 0) {
         void *q;
-        if (lsk_malloc(&q, sizeof(uint64_t) * (size_t)n) == 0) {
-            DEV(lsk_chain_pack(n, d_reps, pl->chain_cached ? pl->d_chain_cache : NULL, (uint64_t *)q, stream));
-            DEV(lsk_sync(stream));
-            pl->d_chain_rec = (uint64_t *)q;
+        if (lsk_malloc(&q, sizeof(uint64_t) * (size_t)n) != 0) {
             if (pl->d_chain_cache) { lsk_free(pl->d_chain_cache); pl->d_chain_cache = NULL; }
+            if (pl->d_tilemap) { lsk_free(pl->d_tilemap); pl->d_tilemap = NULL; memset(&pl->tilemap, 0, sizeof(pl->tilemap)); }
+            pl->chain_cached = 0;
+            return 0;
         }
+        pl->d_chain_rec = (uint64_t *)q;
+        DEV(lsk_chain_pack(n, d_reps, pl->chain_cached ? pl->d_chain_cache : NULL, (uint64_t *)q, stream));
+        DEV(lsk_sync(stream));
+        if (pl->chain_cached <= 1 && pl->d_chain_cache) { lsk_free(pl->d_chain_cache); pl->d_chain_cache = NULL; }
     }
     pl->has_chain = 1;
     return 0;
@@ -1758,6 +1802,19 @@ char const *ls_amd_plan_kernel_name(ls_amd_plan const *pl) {
     }
 }
 int ls_amd_plan_packet_bytes(ls_amd_plan const *pl) { return pl->cplx ? 24 : 16; }
+/* bytes of per-row plan / basis data the plan's dominant kernel streams from HBM next to x and y (the roofline's
+ * compulsory traffic is rows * (this + 2 w)): the staged row kernel reads the fused 8-byte record, or the low state word(s)
+ * plus one cached partner rank per cached pair; the generic row kernels read the 8-byte state; the projected pull kernel
+ * the state and norm(alpha) */
+int ls_amd_plan_row_bytes(ls_amd_plan const *pl) {
+    if (pl->has_chain) {
+        if (pl->d_chain_rec) return 8;
+        int const narrow = pl->op->basis->number_sites <= 32 && !pl->chain_wide;
+        return (narrow ? 4 : 8) + pl->chain_cached * (pl->chain_wide ? 8 : 4);
+    }
+    if (pl->family == FAMILY_TILE_PULL || pl->family == FAMILY_REPL_TILE) return 16;
+    return 8;
+}
 int64_t ls_amd_plan_nnz(ls_amd_plan const *pl) { return pl->nnz; }
 int ls_amd_plan_send_counts(ls_amd_plan const *pl, int round, int64_t *counts) {
     if (pl->family != FAMILY_TILE) { for (int d = 0; d < pl->P; ++d) counts[d] = 0; return 0; }
@@ -1993,15 +2050,37 @@ static int host_matvec_f64(ls_hs_operator *op, int64_t n, double const *x, doubl
     if (ensure_device_reps(b) != 0) return -1;
     if ((uint64_t)n != e->d_reps_count) return set_error("vector length does not match the number of representatives");
     if (!cm) cm = ls_amd_default_comm();
-    if (cm && ls_amd_comm_size(cm) > 1) {
-        /* one locale per process: `representatives` is this locale's block of the hashed basis and x, y are the
-         * matching blocks (Diagonalize.chpl:134-162 runs the callback on every locale in lock-step) */
-        if (!e->host_dist_f64) {
+    if (cm && ls_amd_comm_size(cm) <= 1) cm = NULL;
+    /* the cached plan of THIS operator on THIS communicator (least recently used slot is recycled) */
+    struct host_plan_slot *sl = NULL, *victim = &e->host_plans[0];
+    for (int i = 0; i < HOST_PLAN_SLOTS; ++i) {
+        struct host_plan_slot *c = &e->host_plans[i];
+        if (c->op == op && c->comm == (void *)cm) { sl = c; break; }
+        if (!c->op) { if (victim->op) victim = c; }
+        else if (victim->op && c->stamp < victim->stamp) victim = c;
+    }
+    if (!sl) {
+        host_plan_slot_drop(victim);
+        if (cm) {
+            /* one locale per process: `representatives` is this locale's block of the hashed basis and x, y are the
+             * matching blocks (Diagonalize.chpl:134-162 runs the callback on every locale in lock-step) */
             ls_amd_dist *dd;
             if (ls_amd_dist_create(&dd, cm, op, LS_AMD_F64, e->d_reps_cache, n, 0, NULL) != 0) return -1;
-            e->host_dist_f64 = dd;
+            victim->dist = dd;
+        } else {
+            ls_amd_plan *pl;
+            uint64_t const *reps[1] = {e->d_reps_cache};
+            int64_t counts[1] = {n};
+            if (ls_amd_plan_create(&pl, op, LS_AMD_F64, 1, -1, reps, counts, 0, LS_AMD_MODE_AUTO, NULL) != 0) return -1;
+            victim->plan = pl;
         }
-        ls_amd_dist *dd = (ls_amd_dist *)e->host_dist_f64;
+        victim->op = op;
+        victim->comm = cm;
+        sl = victim;
+    }
+    sl->stamp = ++e->host_plan_clock;
+    if (cm) {
+        ls_amd_dist *dd = (ls_amd_dist *)sl->dist;
         void *dx, *dy;
         DEV(lsk_malloc(&dx, 8 * (size_t)n));
         DEV(lsk_malloc(&dy, 8 * (size_t)n));
@@ -2014,15 +2093,7 @@ static int host_matvec_f64(ls_hs_operator *op, int64_t n, double const *x, doubl
         lsk_free(dy);
         return rc;
     }
-    if (!e->host_plan_f64) {
-        ls_amd_plan *pl;
-        uint64_t const *reps[1] = {e->d_reps_cache};
-        int64_t counts[1] = {n};
-        if (ls_amd_plan_create(&pl, op, LS_AMD_F64, 1, -1, reps, counts, 0, LS_AMD_MODE_AUTO, NULL) != 0) return -1;
-        e->host_plan_f64 = pl;
-    }
-    ls_amd_plan *pl = (ls_amd_plan *)e->host_plan_f64;
-    pl->op = op;
+    ls_amd_plan *pl = (ls_amd_plan *)sl->plan;
     void *dx, *dy;
     DEV(lsk_malloc(&dx, 8 * (size_t)n));
     DEV(lsk_malloc(&dy, 8 * (size_t)n));

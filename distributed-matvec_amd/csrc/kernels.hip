@@ -1280,7 +1280,10 @@ extern "C" int lsk_chain(lsk_operator op, lsk_basis bs, lsk_index ix, int cplx, 
         if (!narrow || cplx) { snprintf(g_err, sizeof(g_err), "lsk_chain: fused records need 32-bit states and ranks and f64 vectors"); return -1; }
         return launch_chain<uint32_t, uint32_t, false, 1024, true>(LSK_CHAIN_ARGS);
     }
-    if (narrow) return cplx ? launch_chain<uint32_t, uint32_t, true, 512, false>(LSK_CHAIN_ARGS) : launch_chain<uint32_t, uint32_t, false, 1024, false>(LSK_CHAIN_ARGS);
+    if (narrow) {
+        if (!cplx) { snprintf(g_err, sizeof(g_err), "lsk_chain: 32-bit states and ranks with f64 vectors run on fused records (lsk_chain_pack)"); return -1; }
+        return launch_chain<uint32_t, uint32_t, true, 512, false>(LSK_CHAIN_ARGS);
+    }
     if (!wide_ranks) return cplx ? launch_chain<uint64_t, uint32_t, true, 512, false>(LSK_CHAIN_ARGS) : launch_chain<uint64_t, uint32_t, false, 1024, false>(LSK_CHAIN_ARGS);
     return cplx ? launch_chain<uint64_t, uint64_t, true, 512, false>(LSK_CHAIN_ARGS) : launch_chain<uint64_t, uint64_t, false, 1024, false>(LSK_CHAIN_ARGS);
 #undef LSK_CHAIN_ARGS
@@ -1296,6 +1299,12 @@ extern "C" int lsk_chain(lsk_operator op, lsk_basis bs, lsk_index ix, int cplx, 
 // ---------------------------------------------------------------------------------------------
 
 constexpr uint32_t kDead = 0xffffffffu;
+// LS_AMD_ABLATE (lsk_basis.debug_ablate) switches stages of the tile kernels off to price them -- profiling builds only
+// (make ABLATE=1): the shipped kernels carry none of these branches.
+#ifndef LSK_ABLATE
+#define LSK_ABLATE 0
+#endif
+constexpr bool kAblate = LSK_ABLATE != 0;
 
 // GC = flip-mask groups expanded per LDS list: 8 for cheap packets (fewer barriers: chain_28, P = 8: 11.0 vs 14.0 ms with 4), 4 for
 // symmetry-projected bases (20 instead of 40 KB of LDS per block: twice the blocks per CU to hide K4 and the index look-ups:
@@ -1363,7 +1372,7 @@ __global__ __launch_bounds__(kBlock) void k_tile(int n_groups, lsk_group const *
                 }
             }
             __syncthreads();
-            const int n = (bs.debug_ablate & 1) ? 0 : s_n; // LS_AMD_ABLATE (profiling only): 1 no stage B, 8 drop own packets, 16 no packet writes
+            const int n = (kAblate && (bs.debug_ablate & 1)) ? 0 : s_n; // LS_AMD_ABLATE (profiling only): 1 no stage B, 8 drop own packets, 16 no packet writes
             // ---- stage B: project, hash, scatter locally or rank into a destination bucket --------
             for (int e = tid; e < n; e += kBlock) {
                 uint64_t beta = s_beta[e];
@@ -1394,7 +1403,7 @@ __global__ __launch_bounds__(kBlock) void k_tile(int n_groups, lsk_group const *
                     if (count_only) {
                         atomicAdd(&s_cnt[dest], 1u);
                     } else if (dest == me) {
-                        if (bs.debug_ablate & 8) { s_meta[e] = kDead; continue; }
+                        if (kAblate && (bs.debug_ablate & 8)) { s_meta[e] = kDead; continue; }
                         int64_t idx = search_index(ix, beta);
                         if (idx < 0) atomicExch(err, 1);
                         else {
@@ -1421,7 +1430,7 @@ __global__ __launch_bounds__(kBlock) void k_tile(int n_groups, lsk_group const *
                 __syncthreads();
                 for (int e = tid; e < n; e += kBlock) {
                     const uint32_t meta = s_meta[e];
-                    if (meta == kDead || (bs.debug_ablate & 16)) continue;
+                    if (meta == kDead || (kAblate && (bs.debug_ablate & 16))) continue;
                     const int dest = (int)(meta >> 16);
                     const unsigned long long pos = s_base[dest] + (meta & 0xffffu);
                     uint64_t *ob = (uint64_t *)(send + layout->beta_off[dest]);
@@ -1581,13 +1590,13 @@ __global__ __launch_bounds__(kBlock) void k_tile_pull(lsk_runs runs, int n_group
                 }
             }
             __syncthreads();
-            const int n = (bs.debug_ablate & 1) ? 0 : s_n;
+            const int n = (kAblate && (bs.debug_ablate & 1)) ? 0 : s_n;
             // ---- stage B1: K4 on every packet; representative and conj(H~) go back into the list ---------
             for (int e = tid; e < n; e += kBlock) {
                 uint64_t beta = s_beta[e];
                 double hr, hi = 0.0; // conj(H~) so far
                 if (RC) hr = s_coef[e]; else { hr = s_coef[2 * e]; hi = s_coef[2 * e + 1]; }
-                if (bs.debug_ablate & 4) {
+                if (kAblate && (bs.debug_ablate & 4)) {
                     beta = a; // a key that exists (this thread's own row)
                 } else if (bs.k4_mode != 0) {
                     beta = (uint64_t)rep_trivial<W>(bs, elems, (W)beta); // x is pre-multiplied by norm(rep)
@@ -1607,7 +1616,7 @@ __global__ __launch_bounds__(kBlock) void k_tile_pull(lsk_runs runs, int n_group
             }
             // ---- stage B2: gathers.  A thread's packets are independent: issue all home-slot loads first
             // (kGCPull requests in flight per lane), then resolve and accumulate -----------------------------
-            if (!(bs.debug_ablate & 2)) {
+            if (!(kAblate && (bs.debug_ablate & 2))) {
                 const uint64_t hmask = (1ULL << tab_bits) - 1;
                 uint64_t key[kGCPull], slot[kGCPull];
                 ulonglong2 first[kGCPull];

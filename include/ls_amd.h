@@ -170,6 +170,9 @@ char const *ls_amd_plan_kernel_name(ls_amd_plan const *plan);
 int ls_amd_plan_send_counts(ls_amd_plan const *plan, int round, int64_t *counts);
 /* bytes of one packet segment entry: 8 (beta) + 8 or 16 (value) */
 int ls_amd_plan_packet_bytes(ls_amd_plan const *plan);
+/* bytes of per-row plan / basis data the dominant kernel streams next to x and y (8-byte fused record of the staged row
+ * kernel, state words + cached partner ranks, state + norm for projected bases): compulsory traffic = rows (this + 2 w) */
+int ls_amd_plan_row_bytes(ls_amd_plan const *plan);
 /* total off-diagonal non-zeros generated per matvec by the owned partitions (from the count pass;
  * 0 when the plan runs a direct kernel and never counted) */
 int64_t ls_amd_plan_nnz(ls_amd_plan const *plan);

@@ -265,6 +265,53 @@ def test_kernel_table_entry_points(torch):
     assert_close(h2 @ x10, oracle_for("heisenberg_chain_10").local_matvec(r10, x10))
 
 
+def test_two_operators_share_one_basis_through_the_kernel_table(torch):
+    """ls_chpl_matrix_vector_product caches its device plan per (operator, communicator), not per basis: H and an
+    observable built on the SAME ls_hs_basis (the reference loads `observables` next to the Hamiltonian,
+    ForeignTypes.chpl:261-288) must each get their own term tables, in any call order, and a destroyed operator's plan
+    must not serve the next operator that reuses its address."""
+    import copy
+
+    import distributed_matvec_amd as D
+    from distributed_matvec_amd import config as cfgmod
+    from oracle import c_oracle as CO
+    from oracle import model as M
+
+    cfg_h = copy.deepcopy(model_config("heisenberg_chain_12"))
+    basis, h = D.loadConfigFromDict(cfg_h, hamiltonian=True)
+    basis.build()
+    reps = oracle_reps("heisenberg_chain_12")
+    x = np.random.RandomState(50).rand(len(reps)) - 0.5
+    o_h = oracle_for("heisenberg_chain_12")
+
+    def observable(sites, scale):
+        c = copy.deepcopy(cfg_h)
+        c["hamiltonian"] = {"name": "obs", "terms": [
+            {"expression": f"{scale} × σˣ₀ σˣ₁", "sites": sites}, {"expression": f"{scale} × σʸ₀ σʸ₁", "sites": sites},
+            {"expression": "σᶻ₀ σᶻ₁", "sites": sites}]}
+        return c, D.Operator.fromSpec(basis, cfgmod.parse_operator(c["hamiltonian"]))
+
+    cfg_a, op_a = observable([[0, 1], [2, 5], [3, 9]], 0.5)
+    o_a = CO.COracle(M.model_from_config(cfg_a))
+    want_h, want_a = o_h.local_matvec(reps, x), o_a.local_matvec(reps, x)
+    assert np.abs(want_h - want_a).max() > 1e-3
+    for _ in range(2):  # alternate: each call must use its own operator's plan
+        assert_close(h @ x, want_h)
+        assert_close(op_a @ x, want_a)
+    # more operators than cache slots, then the first ones again
+    others = [observable([[k, (k + 3) % 12]], 2.0) for k in range(5)]
+    for c, op in others:
+        assert_close(op @ x, CO.COracle(M.model_from_config(c)).local_matvec(reps, x))
+    assert_close(h @ x, want_h)
+    assert_close(op_a @ x, want_a)
+    # destroy + create: the new operator may land on the freed address
+    del op_a
+    for k in range(3):
+        c, op = observable([[1, 7 + k]], 1.5)
+        assert_close(op @ x, CO.COracle(M.model_from_config(c)).local_matvec(reps, x))
+        del op
+
+
 def test_primme_callback(torch):
     """ls_chpl_primme_matvec (Diagonalize.chpl:134-162): block of columns with leading dimensions."""
     import ctypes as C
