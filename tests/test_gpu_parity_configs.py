@@ -238,9 +238,12 @@ def test_chain_40_symm_properties_and_ground_state(torch):
     assert resid <= 1e-4 * abs(e0), (e0, resid)
     rq = float(torch.dot(vec, hv)) / float(torch.dot(vec, vec))
     assert abs(rq - e0) <= 1e-8 * abs(e0)
-    # finite-size Heisenberg ring: e0 / (4 L) -> -0.443147 - pi^2 / (12 L^2) (1 + O(1/ln^3 L)), S.S units per site
-    per_site = e0 / (4 * 40)
-    assert -0.44385 < per_site < -0.44355, per_site
+    # the Bethe-ansatz ground-state energy of the 40-site ring (oracle/bethe.py: 20 coupled Bethe equations, independent of
+    # every term table, projector and oracle of this repository) -- E0 of the trivial sector, 1e-8 relative
+    from oracle import bethe
+
+    want = bethe.ground_state_energy_sigma(40)
+    assert abs(e0 - want) <= 1e-8 * abs(want), (e0, want)
 
 
 def test_chain_32_and_36_symm_complex_vectors(torch):
@@ -400,4 +403,29 @@ def test_distributed_eigensolve_eight_ranks(torch):
     assert single.converged
     for e in e0:
         assert abs(e - single.eigenvalues[0]) <= 1e-7 * abs(single.eigenvalues[0])
-    assert -0.4442 < single.eigenvalues[0] / (4 * 32) < -0.4438  # finite-size Heisenberg ring
+    from oracle import bethe
+
+    want = bethe.ground_state_energy_sigma(32)  # Bethe ansatz: nothing of this repository went into this number
+    assert abs(single.eigenvalues[0] - want) <= 1e-8 * abs(want), (single.eigenvalues[0], want)
+    for e in e0:
+        assert abs(e - want) <= 1e-7 * abs(want)
+
+
+@pytest.mark.parametrize("L", [24, 36])
+def test_symmetric_chain_ground_state_equals_bethe_ansatz(torch, L):
+    """E0 of heisenberg_chain_{24,36}_symm (trivial sector of the 4L-element group) from the HIP path -- enumeration,
+    projected-basis pull kernel, device-resident Lanczos -- against the Bethe-ansatz energy of the L-site ring
+    (oracle/bethe.py), 1e-8 relative.  With chain_32_symm (eight-rank test above) and chain_40_symm this covers every
+    symmetric BASELINE shape; the number owes nothing to the term compiler, the K4 projection or either oracle."""
+    import distributed_matvec_amd as D
+    from distributed_matvec_amd import config
+    from distributed_matvec_amd.diagonalize import LocalOperator, lanczos_smallest
+    from oracle import bethe
+
+    basis, h = D.loadConfigFromDict(config.heisenberg_chain_config(L, symm=True), hamiltonian=True)
+    reps, masks = D.enumerateStates(basis, 1)
+    assert int(masks.numel()) == {24: 28968, 36: 63068876}[L]
+    res = lanczos_smallest(LocalOperator(h, reps, torch.float64), num_evals=1, eps=1e-7, max_basis=16, max_restarts=200)
+    assert res.converged, res.history[-2:]
+    want = bethe.ground_state_energy_sigma(L)
+    assert abs(res.eigenvalues[0] - want) <= 1e-8 * abs(want), (res.eigenvalues[0], want)
