@@ -407,11 +407,11 @@ class MatvecPlan:
         _lib.check(_lib.load().ls_amd_plan_enable_stage_timing(self.h, max_events))
 
     def stage_times(self):
-        ms = (C.c_double * 6)()
-        calls = (C.c_int64 * 6)()
+        ms = (C.c_double * 7)()
+        calls = (C.c_int64 * 7)()
         mv = C.c_int64()
         _lib.check(_lib.load().ls_amd_plan_stage_times(self.h, ms, calls, C.byref(mv)))
-        names = ("localDiagonal", "hashRefresh", "rowKernel", "producers", "exchangeWait", "consumers")
+        names = ("localDiagonal", "hashRefresh", "rowKernel", "producers", "exchangeWait", "consumers", "resultsToOwners")
         return {n: (float(ms[i]), int(calls[i])) for i, n in enumerate(names)}, int(mv.value)
 
     def timing_report(self) -> str:

@@ -24,7 +24,21 @@ int ls_amd_internal_error(char const *fmt, ...); /* host.c: formats into ls_amd_
 int ls_amd_internal_stage_begin(ls_amd_plan *pl, int stage, void *stream); /* host.c: stage timers (kDisplayTimings) */
 void ls_amd_internal_stage_end(ls_amd_plan *pl, int slot, void *stream);
 void ls_amd_internal_count_matvec(ls_amd_plan *pl);
-enum { ST_EXCHANGE = 4 };
+enum { ST_REFRESH = 1, ST_EXCHANGE = 4, ST_RETURN = 6 };
+/* host.c: static index tables shared per (global basis, partition layout) and the indexed replicated-x plan */
+typedef struct ls_amd_gtab ls_amd_gtab;
+int ls_amd_internal_gtab_acquire(ls_amd_gtab **out, int L, uint64_t const *d_reps, int64_t n, uint8_t const *d_masks, int P, void *stream);
+void ls_amd_internal_gtab_release(ls_amd_gtab *t);
+uint32_t const *ls_amd_internal_gtab_perm(ls_amd_gtab const *t);
+int64_t ls_amd_internal_gtab_max_count(ls_amd_gtab const *t);
+int64_t const *ls_amd_internal_gtab_counts(ls_amd_gtab const *t);
+int64_t ls_amd_internal_gtab_bytes(ls_amd_gtab const *t);
+int ls_amd_internal_basis_is_projected(ls_hs_basis const *b);
+int ls_amd_internal_plan_prescales(ls_amd_plan const *pl);
+int ls_amd_internal_owner_norms(ls_hs_operator const *op, ls_amd_gtab const *gt, int me, double **d_norms, void *stream);
+int ls_amd_internal_plan_create_replicated_indexed(ls_amd_plan **out, ls_hs_operator const *op, ls_amd_dtype dtype, int num_partitions,
+                                                   int my_partition, uint64_t const *d_reps_local, int64_t count_local,
+                                                   uint64_t const *d_reps_global, int64_t count_global, ls_amd_gtab *gt, void *stream);
 
 #define COMM(expr) do { if ((expr) != 0) return ls_amd_internal_error("%s", lsk_comm_last_error()); } while (0)
 #define DEVC(expr) do { if ((expr) != 0) return ls_amd_internal_error("%s", lsk_last_error()); } while (0)
@@ -314,6 +328,9 @@ struct ls_amd_repl {
     int64_t *ys_off, *ys_bytes, *yr_off, *yr_bytes; /* [P] y exchange layout */
     int64_t y_self_bytes;            /* my rows of my own partition: copied, not sent */
     int64_t exchange_bytes;
+    /* indexed mode (projected bases): x stays in the order it arrives in -- no permutation pass, no table refresh */
+    ls_amd_gtab *gt;                 /* static {rep -> slot} table + global row -> slot permutation (shared, host.c) */
+    double *d_norms_own;             /* norm(rep) of the representatives this rank owns (K4 modes that prescale), else NULL */
 };
 
 void ls_amd_repl_destroy(ls_amd_repl *r) {
@@ -322,6 +339,8 @@ void ls_amd_repl_destroy(ls_amd_repl *r) {
     void *bufs[] = {r->d_perm, r->d_yorder, r->d_gathered, r->d_xglobal, r->d_yblock, r->d_ysend, r->d_yrecv};
     for (size_t i = 0; i < sizeof(bufs) / sizeof(bufs[0]); ++i) if (bufs[i]) lsk_free(bufs[i]);
     if (r->plan) ls_amd_plan_destroy(r->plan);
+    if (r->d_norms_own) lsk_free(r->d_norms_own);
+    if (r->gt) ls_amd_internal_gtab_release(r->gt);
     free(r->counts);
     free(r->xs_off); free(r->xs_bytes); free(r->xr_off); free(r->xr_bytes);
     free(r->ys_off); free(r->ys_bytes); free(r->yr_off); free(r->yr_bytes);
@@ -345,17 +364,33 @@ int ls_amd_repl_create(ls_amd_repl **out, ls_amd_comm *cm, ls_hs_operator const 
     r->accumulate = !op->diag_terms || op->diag_terms->number_terms == 0; /* y += H x when H has no diagonal (DMV:1062-1063) */
     int64_t const nb = r->n1 - r->n0;
     r->counts = (int64_t *)calloc(P, sizeof(int64_t));
-    int rc = ls_amd_mask_counts(count_global, d_masks, P, r->counts, stream);
-    for (int p = 0; p < P && rc == 0; ++p) if (r->counts[p] > r->max_count) r->max_count = r->counts[p];
-    /* --- x: permutation global row -> slot p * max_count + j of the gathered buffer (hashed -> block of the slots) --- */
+    int rc = 0;
     void **pos = (void **)calloc(P, sizeof(void *));
-    if (rc == 0) rc = dmalloc((void **)&r->d_perm, 8 * r->n);
-    for (int p = 0; p < P && rc == 0; ++p) {
-        rc = dmalloc(&pos[p], 8 * r->counts[p]);
-        if (rc == 0 && lsk_iota_i64(r->counts[p], (int64_t)p * r->max_count, (int64_t *)pos[p], stream) != 0) rc = ls_amd_internal_error("%s", lsk_last_error());
+    /* Projected bases take the INDEXED mode (LS_AMD_REPL_INDEXED=0 keeps the value table + permutation pass): the pull
+     * kernel reads x through a static {rep -> slot} table in the order the blocks arrive in, so no rank does O(N) work per
+     * matvec -- no hashed -> block permutation of x (N random reads), no refresh of a whole-basis value table (N random
+     * writes); the owners send x * norm(rep). */
+    int indexed = ls_amd_internal_basis_is_projected(op->basis);
+    { char const *e = getenv("LS_AMD_REPL_INDEXED"); if (e && atoi(e) == 0) indexed = 0; }
+    if (indexed && ls_amd_internal_gtab_acquire(&r->gt, op->basis->number_sites, d_reps_global, count_global, d_masks, P, stream) != 0) {
+        r->gt = NULL; /* no admissible table (more than 2^32 - 1 slots, ...): the permutation path */
+        indexed = 0;
     }
-    if (rc == 0) rc = ls_amd_hashed_to_block(r->n, d_masks, P, 8, (void const *const *)pos, r->d_perm, stream);
-    for (int p = 0; p < P; ++p) if (pos[p]) lsk_free(pos[p]);
+    if (indexed) {
+        memcpy(r->counts, ls_amd_internal_gtab_counts(r->gt), sizeof(int64_t) * (size_t)P);
+        r->max_count = ls_amd_internal_gtab_max_count(r->gt);
+    } else {
+        rc = ls_amd_mask_counts(count_global, d_masks, P, r->counts, stream);
+        for (int p = 0; p < P && rc == 0; ++p) if (r->counts[p] > r->max_count) r->max_count = r->counts[p];
+        /* --- x: permutation global row -> slot p * max_count + j of the gathered buffer (hashed -> block of the slots) --- */
+        if (rc == 0) rc = dmalloc((void **)&r->d_perm, 8 * r->n);
+        for (int p = 0; p < P && rc == 0; ++p) {
+            rc = dmalloc(&pos[p], 8 * r->counts[p]);
+            if (rc == 0 && lsk_iota_i64(r->counts[p], (int64_t)p * r->max_count, (int64_t *)pos[p], stream) != 0) rc = ls_amd_internal_error("%s", lsk_last_error());
+        }
+        if (rc == 0) rc = ls_amd_hashed_to_block(r->n, d_masks, P, 8, (void const *const *)pos, r->d_perm, stream);
+        for (int p = 0; p < P; ++p) if (pos[p]) { lsk_free(pos[p]); pos[p] = NULL; }
+    }
     /* --- y: my rows grouped by owner (block -> hashed of the row numbers) --- */
     int64_t *ycounts = (int64_t *)calloc(P, sizeof(int64_t));
     void *iota = NULL;
@@ -370,7 +405,7 @@ int ls_amd_repl_create(ls_amd_repl **out, ls_amd_comm *cm, ls_hs_operator const 
     free(pos);
     /* 4-byte indices where they fit: the x permutation is the one full-size pass that remains at P > 1 */
     r->perm64 = r->yorder64 = 1;
-    for (int which = 0; which < 2 && rc == 0; ++which) {
+    for (int which = indexed ? 1 : 0; which < 2 && rc == 0; ++which) {
         int64_t const cnt = which == 0 ? r->n : nb, top = which == 0 ? (int64_t)P * r->max_count : nb;
         void **slot = which == 0 ? &r->d_perm : &r->d_yorder;
         if (top >= 0x7fffffffLL || cnt == 0) continue;
@@ -393,7 +428,8 @@ int ls_amd_repl_create(ls_amd_repl **out, ls_amd_comm *cm, ls_hs_operator const 
     if (rc == 0 && (lsk_sync(stream) != 0 || lsk_d2h(all, (char *)ds + 8 * P, 8 * (size_t)P * (size_t)P) != 0)) rc = ls_amd_internal_error("%s", lsk_last_error());
     int64_t so = 0, ro = 0, mine = 0;
     for (int p = 0; p < P; ++p) {
-        r->xs_off[p] = 0; r->xs_bytes[p] = p == me ? 0 : r->counts[me] * r->w;
+        /* the send buffer is d_x_local itself, or (indexed mode) my prescaled block inside the gathered buffer */
+        r->xs_off[p] = indexed ? (int64_t)me * r->max_count * r->w : 0; r->xs_bytes[p] = p == me ? 0 : r->counts[me] * r->w;
         r->xr_off[p] = (int64_t)p * r->max_count * r->w; r->xr_bytes[p] = p == me ? 0 : r->counts[p] * r->w;
         r->ys_off[p] = so; r->ys_bytes[p] = p == me ? 0 : ycounts[p] * r->w; so += ycounts[p] * r->w;
         int64_t const from_p = all[(size_t)p * P + me]; /* rank p's range holds this many states of my partition */
@@ -407,12 +443,16 @@ int ls_amd_repl_create(ls_amd_repl **out, ls_amd_comm *cm, ls_hs_operator const 
     free(all); free(ycounts);
     if (rc == 0 && mine != r->counts[me]) rc = ls_amd_internal_error("masks do not describe this communicator's partition (%lld vs %lld states)", (long long)mine, (long long)r->counts[me]);
     if (rc == 0) rc = dmalloc(&r->d_gathered, (int64_t)P * r->max_count * r->w);
-    if (rc == 0) rc = dmalloc(&r->d_xglobal, r->n * r->w);
+    if (rc == 0 && !indexed) rc = dmalloc(&r->d_xglobal, r->n * r->w);
     if (rc == 0) rc = dmalloc(&r->d_yblock, nb * r->w);
     if (rc == 0) rc = dmalloc(&r->d_ysend, nb * r->w);
     if (rc == 0) rc = dmalloc(&r->d_yrecv, r->counts[me] * r->w);
     /* the pull plan over my contiguous rows of the global basis (takes the staged kernel with a row offset when it can) */
-    if (rc == 0) rc = ls_amd_plan_create_replicated(&r->plan, op, dtype, P, me, d_reps_global + r->n0, nb, d_reps_global, count_global, stream);
+    if (rc == 0 && indexed) {
+        rc = ls_amd_internal_plan_create_replicated_indexed(&r->plan, op, dtype, P, me, d_reps_global + r->n0, nb, d_reps_global, count_global, r->gt, stream);
+        if (rc == 0 && ls_amd_internal_plan_prescales(r->plan)) rc = ls_amd_internal_owner_norms(op, r->gt, me, &r->d_norms_own, stream);
+    } else if (rc == 0)
+        rc = ls_amd_plan_create_replicated(&r->plan, op, dtype, P, me, d_reps_global + r->n0, nb, d_reps_global, count_global, stream);
     if (rc != 0) { ls_amd_repl_destroy(r); return -1; }
     *out = r;
     return 0;
@@ -423,19 +463,41 @@ int64_t ls_amd_repl_exchange_bytes(ls_amd_repl const *r) { return r->exchange_by
 
 int ls_amd_repl_matvec(ls_amd_repl *r, void const *d_x_local, void *d_y_local, void *stream) {
     int64_t const nb = r->n1 - r->n0, w = r->w;
-    /* 1. blocks of x: mine by a device copy, the others straight from their owners */
-    DEVC(lsk_d2d_async((char *)r->d_gathered + r->xr_off[r->me], d_x_local, (size_t)(r->counts[r->me] * w), stream));
-    if (r->P > 1) COMM(lsk_comm_alltoallv_on(r->comm->c, stream, d_x_local, r->xs_off, r->xs_bytes, r->d_gathered, r->xr_off, r->xr_bytes));
-    DEVC(lsk_gather_perm(r->n, r->d_perm, r->perm64, (int)w, r->d_gathered, r->d_xglobal, stream));
+    void const *x_rows;
+    if (r->gt) {
+        /* 1. (indexed) my block, times norm(rep) where the kernel's K4 mode wants it, goes to its place in the gathered
+         * buffer and from there to every peer; nothing else touches x: the kernel finds every partner's slot itself */
+        char *mine = (char *)r->d_gathered + r->xr_off[r->me];
+        int st = ls_amd_internal_stage_begin(r->plan, ST_REFRESH, stream);
+        if (r->d_norms_own) DEVC(lsk_scale(r->cplx, r->counts[r->me], d_x_local, r->d_norms_own, mine, stream));
+        else DEVC(lsk_d2d_async(mine, d_x_local, (size_t)(r->counts[r->me] * w), stream));
+        ls_amd_internal_stage_end(r->plan, st, stream);
+        st = ls_amd_internal_stage_begin(r->plan, ST_EXCHANGE, stream);
+        if (r->P > 1) COMM(lsk_comm_alltoallv_on(r->comm->c, stream, r->d_gathered, r->xs_off, r->xs_bytes, r->d_gathered, r->xr_off, r->xr_bytes));
+        ls_amd_internal_stage_end(r->plan, st, stream);
+        x_rows = r->d_gathered;
+    } else {
+        /* 1. blocks of x: mine by a device copy, the others straight from their owners */
+        int st = ls_amd_internal_stage_begin(r->plan, ST_EXCHANGE, stream);
+        DEVC(lsk_d2d_async((char *)r->d_gathered + r->xr_off[r->me], d_x_local, (size_t)(r->counts[r->me] * w), stream));
+        if (r->P > 1) COMM(lsk_comm_alltoallv_on(r->comm->c, stream, d_x_local, r->xs_off, r->xs_bytes, r->d_gathered, r->xr_off, r->xr_bytes));
+        ls_amd_internal_stage_end(r->plan, st, stream);
+        st = ls_amd_internal_stage_begin(r->plan, ST_REFRESH, stream);
+        DEVC(lsk_gather_perm(r->n, r->d_perm, r->perm64, (int)w, r->d_gathered, r->d_xglobal, stream));
+        ls_amd_internal_stage_end(r->plan, st, stream);
+        x_rows = r->d_xglobal;
+    }
     /* 2. my rows */
     if (r->accumulate) DEVC(lsk_memset_async(r->d_yblock, 0, (size_t)(nb * w), stream));
-    TRY(ls_amd_matvec_replicated(r->plan, r->d_xglobal, r->d_yblock, stream));
+    TRY(ls_amd_matvec_replicated(r->plan, x_rows, r->d_yblock, stream));
     /* 3. back to the owners: group my rows by owner, keep my own piece, one all-to-all-v for the rest */
+    int const st_ret = ls_amd_internal_stage_begin(r->plan, ST_RETURN, stream);
     DEVC(lsk_gather_perm(nb, r->d_yorder, r->yorder64, (int)w, r->d_yblock, r->d_ysend, stream));
     /* the pieces land in y itself (y is assigned), or in a staging buffer that is then added to y (no diagonal terms) */
     void *dst = r->accumulate ? r->d_yrecv : d_y_local;
     DEVC(lsk_d2d_async((char *)dst + r->yr_off[r->me], (char *)r->d_ysend + r->ys_off[r->me], (size_t)r->y_self_bytes, stream));
     if (r->P > 1) COMM(lsk_comm_alltoallv_on(r->comm->c, stream, r->d_ysend, r->ys_off, r->ys_bytes, dst, r->yr_off, r->yr_bytes));
     if (r->accumulate) DEVC(lsk_add_into(r->cplx, r->counts[r->me], r->d_yrecv, d_y_local, stream));
+    ls_amd_internal_stage_end(r->plan, st_ret, stream);
     return 0;
 }

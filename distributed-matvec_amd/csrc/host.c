@@ -1168,6 +1168,11 @@ struct ls_amd_plan {
     int htab_bits;
     void *d_xs;          /* x * norm in index order (K4 modes that prescale x): values of the near window; else x itself */
     int pull_halo;       /* near window of the staged pull kernel (entries either side of a tile), 0 = off */
+    /* indexed mode of the staged pull kernel (lsk_tile_pull_idx): static {rep -> slot} table shared by every plan over the
+     * same global basis and partition layout; nothing is refreshed per matvec */
+    int idx_mode;
+    struct ls_amd_gtab *gtab;
+    int64_t row_g0;      /* global index of the first local row (replicated-x plans over a contiguous block) */
     /* kernel timing ring */
     int t_capacity, t_count;
     void **t_start, **t_stop;
@@ -1180,6 +1185,119 @@ struct ls_amd_plan {
     int64_t st_matvecs;
 };
 
+/* ---- static index tables (lsk_gtab) ---------------------------------------------------------------------------------
+ * One table per (global basis, partition layout), shared by reference: every plan of a process over the same device array
+ * of representatives and the same masks gets the same table and the same global-row -> slot permutation (the loop-back
+ * ranks of the tests and of scripts/loopback_bench.py are threads of one process: eight private copies of a 17 GB table
+ * would not fit one device; separate processes each build their own). */
+typedef struct ls_amd_gtab {
+    uint64_t const *reps; /* key: device array of the global representatives (borrowed) */
+    uint8_t const *masks; /* key: owner of every global row (NULL: one partition, slot = global index) */
+    int64_t n;
+    int P, L;
+    lsk_gtab tab;
+    uint64_t *d_entries;
+    uint32_t *d_perm;     /* [n] global row -> slot owner * max_count + local index (NULL when masks == NULL) */
+    int64_t counts[LSK_MAX_PARTS], max_count;
+    int refs;
+    struct ls_amd_gtab *next;
+} ls_amd_gtab;
+static ls_amd_gtab *g_gtabs = NULL;
+static pthread_mutex_t g_gtab_lock = PTHREAD_MUTEX_INITIALIZER;
+
+static void gtab_free(ls_amd_gtab *t) {
+    if (t->d_entries) lsk_free(t->d_entries);
+    if (t->d_perm) lsk_free(t->d_perm);
+    free(t);
+}
+void ls_amd_internal_gtab_release(ls_amd_gtab *t) {
+    if (!t) return;
+    pthread_mutex_lock(&g_gtab_lock);
+    if (--t->refs == 0) {
+        for (ls_amd_gtab **q = &g_gtabs; *q; q = &(*q)->next)
+            if (*q == t) { *q = t->next; break; }
+        gtab_free(t);
+    }
+    pthread_mutex_unlock(&g_gtab_lock);
+}
+static int gtab_build(ls_amd_gtab *t, void *stream) {
+    int64_t const n = t->n;
+    int const P = t->P;
+    if (t->masks) {
+        /* slot of every global row: the hashed -> block merge of the slot numbers (arrFromHashedToBlock, HashedToBlock.chpl:67-153) */
+        DEV(lsk_mask_counts(n, t->masks, P, t->counts, stream));
+        for (int p = 0; p < P; ++p) if (t->counts[p] > t->max_count) t->max_count = t->counts[p];
+        if ((int64_t)P * t->max_count >= 0xffffffffLL) return set_error("indexed pull: more than 2^32 - 1 slots");
+        void *pos[LSK_MAX_PARTS];
+        memset(pos, 0, sizeof(pos));
+        void *perm64 = NULL, *perm32 = NULL;
+        int rc = lsk_malloc(&perm64, 8 * (size_t)(n > 0 ? n : 1));
+        for (int p = 0; p < P && rc == 0; ++p) {
+            rc = lsk_malloc(&pos[p], 8 * (size_t)(t->counts[p] > 0 ? t->counts[p] : 1));
+            if (rc == 0) rc = lsk_iota_i64(t->counts[p], (int64_t)p * t->max_count, (int64_t *)pos[p], stream);
+        }
+        if (rc == 0) rc = lsk_hashed_to_block(n, t->masks, P, 8, (void const *const *)pos, perm64, stream);
+        if (rc == 0) rc = lsk_malloc(&perm32, 4 * (size_t)(n > 0 ? n : 1));
+        if (rc == 0) rc = lsk_narrow_i32(n, (int64_t const *)perm64, (int32_t *)perm32, stream);
+        if (rc == 0) rc = lsk_sync(stream);
+        for (int p = 0; p < P; ++p) if (pos[p]) lsk_free(pos[p]);
+        if (perm64) lsk_free(perm64);
+        if (rc != 0) { if (perm32) lsk_free(perm32); return dev_error(); }
+        t->d_perm = (uint32_t *)perm32;
+    } else {
+        t->counts[0] = n;
+        t->max_count = n;
+    }
+    int64_t max_bytes = (int64_t)1 << 40;
+    { char const *e = getenv("LS_AMD_GTAB_MAX_BYTES"); if (e && atoll(e) > 0) max_bytes = atoll(e); }
+    int const bb = lsk_gtab_bits(t->L, n, max_bytes);
+    if (bb < 0) return set_error("indexed pull: no admissible index-table size for %lld keys of %d bits", (long long)n, t->L);
+    t->tab.L = t->L; t->tab.bbits = bb; t->tab.tbits = t->L - bb;
+    void *p, *flag;
+    DEV(lsk_malloc(&p, (size_t)16 << bb));
+    t->d_entries = (uint64_t *)p;
+    t->tab.entries = t->d_entries;
+    DEV(lsk_malloc(&flag, sizeof(int)));
+    int zero = 0, bad = 0;
+    int rc = lsk_h2d(flag, &zero, sizeof(int)) || lsk_gtab_build(t->tab, t->d_entries, n, t->reps, t->d_perm, (int *)flag, stream) ||
+             lsk_sync(stream) || lsk_d2h(&bad, flag, sizeof(int));
+    lsk_free(flag);
+    if (rc) return dev_error();
+    if (bad) return set_error("indexed pull: a key could not be placed within 255 buckets of its home");
+    return 0;
+}
+/* the table of (d_reps, n, d_masks, P), built on first use.  Holds g_gtab_lock while building: the other ranks of a
+ * loop-back group wait for the one that got there first. */
+int ls_amd_internal_gtab_acquire(ls_amd_gtab **out, int L, uint64_t const *d_reps, int64_t n, uint8_t const *d_masks, int P,
+                                 void *stream) {
+    *out = NULL;
+    pthread_mutex_lock(&g_gtab_lock);
+    for (ls_amd_gtab *t = g_gtabs; t; t = t->next)
+        if (t->reps == d_reps && t->n == n && t->masks == d_masks && t->P == P && t->L == L) {
+            ++t->refs;
+            pthread_mutex_unlock(&g_gtab_lock);
+            *out = t;
+            return 0;
+        }
+    ls_amd_gtab *t = (ls_amd_gtab *)calloc(1, sizeof(*t));
+    t->reps = d_reps; t->n = n; t->masks = d_masks; t->P = P; t->L = L;
+    if (gtab_build(t, stream) != 0) {
+        gtab_free(t);
+        pthread_mutex_unlock(&g_gtab_lock);
+        return -1;
+    }
+    t->refs = 1;
+    t->next = g_gtabs;
+    g_gtabs = t;
+    pthread_mutex_unlock(&g_gtab_lock);
+    *out = t;
+    return 0;
+}
+uint32_t const *ls_amd_internal_gtab_perm(ls_amd_gtab const *t) { return t->d_perm; }
+int64_t ls_amd_internal_gtab_max_count(ls_amd_gtab const *t) { return t->max_count; }
+int64_t const *ls_amd_internal_gtab_counts(ls_amd_gtab const *t) { return t->counts; }
+int64_t ls_amd_internal_gtab_bytes(ls_amd_gtab const *t) { return (int64_t)16 << t->tab.bbits; }
+
 static int timing_begin(ls_amd_plan *pl, void *stream) {
     if (pl->t_count >= pl->t_capacity) return -1;
     if (lsk_event_record(pl->t_start[pl->t_count], stream) != 0) return -1;
@@ -1191,7 +1309,7 @@ static void timing_end(ls_amd_plan *pl, int slot, void *stream) {
 }
 
 /* ---- stage timers ----------------------------------------------------------------------------- */
-enum { ST_DIAG = 0, ST_REFRESH = 1, ST_ROWS = 2, ST_GENERATE = 3, ST_EXCHANGE = 4, ST_SCATTER = 5, ST_COUNT = 6 };
+enum { ST_DIAG = 0, ST_REFRESH = 1, ST_ROWS = 2, ST_GENERATE = 3, ST_EXCHANGE = 4, ST_SCATTER = 5, ST_RETURN = 6, ST_COUNT = 7 };
 static int stage_begin(ls_amd_plan *pl, int stage, void *stream) {
     if (pl->st_count >= pl->st_capacity) return -1;
     if (lsk_event_record(pl->st_start[pl->st_count], stream) != 0) return -1;
@@ -1250,14 +1368,15 @@ int ls_amd_plan_timing_report(ls_amd_plan *pl, char *buf, size_t cap) {
     snprintf(buf, cap,
              "matrixVectorProduct [%s]: %.3f ms per matvec over %lld matvecs (device time of the stages, HIP events)\n"
              " \xe2\x94\x9c\xe2\x94\x80 localDiagonal (k_diag):                         %9.3f ms  (%lld launches)\n"
-             " \xe2\x94\x9c\xe2\x94\x80 x -> hash table refresh (k_hash_fill):          %9.3f ms  (%lld launches)\n"
+             " \xe2\x94\x9c\xe2\x94\x80 x preparation (table refresh | x n(rep) | permutation): %1.3f ms  (%lld launches)\n"
              " \xe2\x94\x9c\xe2\x94\x80 row kernel (fused computeOffDiag + localProcess): %7.3f ms  (%lld launches)\n"
              " \xe2\x94\x9c\xe2\x94\x80 producers (k_tile: computeOffDiag, stateInfo,\n"
              " \xe2\x94\x82   localeIdxOf, radixOneStep, own localProcess):    %9.3f ms  (%lld launches)\n"
              " \xe2\x94\x9c\xe2\x94\x80 exchange wait on the compute stream (all-to-all-v): %5.3f ms  (%lld waits)\n"
-             " \xe2\x94\x94\xe2\x94\x80 consumers (k_scatter: indexing + accessing):    %9.3f ms  (%lld launches)\n",
+             " \xe2\x94\x9c\xe2\x94\x80 consumers (k_scatter: indexing + accessing):    %9.3f ms  (%lld launches)\n"
+             " \xe2\x94\x94\xe2\x94\x80 replicated-x: y rows grouped by owner + returned: %8.3f ms  (%lld passes)\n",
              ls_amd_plan_kernel_name(pl), total / (double)m, (long long)pl->st_matvecs, PER(ST_DIAG), PER(ST_REFRESH), PER(ST_ROWS),
-             PER(ST_GENERATE), PER(ST_EXCHANGE), PER(ST_SCATTER));
+             PER(ST_GENERATE), PER(ST_EXCHANGE), PER(ST_SCATTER), PER(ST_RETURN));
 #undef PER
     return 0;
 }
@@ -1391,6 +1510,21 @@ int64_t ls_amd_test_tilemap(int64_t n, int tile_rows, int64_t chunk, uint64_t **
     return slots;
 }
 void ls_amd_test_free(void *p) { free(p); }
+/* host-only test hooks of the static index table (lsk_gtab): shape for n keys of L bits, sequential build into a malloc'ed
+ * array of 2 << bbits entries (*entries, ls_amd_test_free), lookup */
+int ls_amd_test_gtab_bits(int L, int64_t n) { return lsk_gtab_bits(L, n, (int64_t)1 << 40); }
+int ls_amd_test_gtab_build(int L, int bbits, int64_t n, uint64_t const *reps, uint32_t const *payload, uint64_t **entries) {
+    lsk_gtab t;
+    t.entries = NULL; t.L = L; t.bbits = bbits; t.tbits = L - bbits;
+    *entries = (uint64_t *)malloc(sizeof(uint64_t) * ((size_t)2 << bbits));
+    if (lsk_test_gtab_build_host(t, *entries, n, reps, payload) != 0) { free(*entries); *entries = NULL; return -1; }
+    return 0;
+}
+int64_t ls_amd_test_gtab_find(int L, int bbits, uint64_t const *entries, uint64_t key) {
+    lsk_gtab t;
+    t.entries = NULL; t.L = L; t.bbits = bbits; t.tbits = L - bbits;
+    return lsk_test_gtab_find(t, entries, key);
+}
 
 /* Staged row kernel (k_chain_t, lsk.h): pull, f64 or c128 vectors, <= 64 sites, the full fixed-weight basis without
  * symmetries, a real operator made of exchange runs plus at most two other exchange pairs.  LS_AMD_CHAIN=0 keeps k_direct. */
@@ -1606,6 +1740,13 @@ int ls_amd_plan_create(ls_amd_plan **out, ls_hs_operator const *op, ls_amd_dtype
             m = LS_AMD_MODE_PUSH;
         }
         pl->family = m == LS_AMD_MODE_PULL ? FAMILY_TILE_PULL : FAMILY_TILE;
+        if (pl->family == FAMILY_TILE_PULL) {
+            /* LS_AMD_PULL_INDEXED=1: static {rep -> index} table + x[index] (two requests per far partner, no refresh)
+             * instead of the {rep -> x n(rep)} value table (one request, N random writes per matvec) */
+            char const *e = getenv("LS_AMD_PULL_INDEXED");
+            pl->idx_mode = e ? atoi(e) != 0 : 0;
+            if (pl->idx_mode && (counts[0] >= 0xffffffffLL || lsk_gtab_bits(op->basis->number_sites, counts[0], (int64_t)1 << 40) < 0)) pl->idx_mode = 0;
+        }
     } else pl->family = FAMILY_TILE;
 
     void *p;
@@ -1663,6 +1804,7 @@ void ls_amd_plan_destroy(ls_amd_plan *pl) {
     if (pl->d_htab) lsk_free(pl->d_htab);
     if (pl->d_slot_of) lsk_free(pl->d_slot_of);
     if (pl->d_xs) lsk_free(pl->d_xs);
+    if (pl->gtab) ls_amd_internal_gtab_release(pl->gtab);
     if (pl->d_send) lsk_free(pl->d_send);
     if (pl->d_cursors) lsk_free(pl->d_cursors);
     if (pl->d_counts) lsk_free(pl->d_counts);
@@ -1677,10 +1819,30 @@ int ls_amd_plan_num_rounds(ls_amd_plan const *pl) { return pl->family == FAMILY_
 /* -------------------------------------------------------------------------------------------- */
 /* replicated-x plans                                                                            */
 /* -------------------------------------------------------------------------------------------- */
+static int plan_create_replicated_impl(ls_amd_plan **out, ls_hs_operator const *op, ls_amd_dtype dtype,
+                                       int num_partitions, int my_partition, uint64_t const *d_reps_local,
+                                       int64_t count_local, uint64_t const *d_reps_global, int64_t count_global,
+                                       ls_amd_gtab *gt, void *stream);
 int ls_amd_plan_create_replicated(ls_amd_plan **out, ls_hs_operator const *op, ls_amd_dtype dtype,
                                   int num_partitions, int my_partition, uint64_t const *d_reps_local,
                                   int64_t count_local, uint64_t const *d_reps_global, int64_t count_global,
                                   void *stream) {
+    return plan_create_replicated_impl(out, op, dtype, num_partitions, my_partition, d_reps_local, count_local, d_reps_global,
+                                       count_global, NULL, stream);
+}
+/* the replicated-x plan of the indexed exchange (dist.c): x arrives as the owners' blocks (slot order of `gt`), the rows are
+ * the contiguous global rows d_reps_local = d_reps_global + row0.  Projected bases only. */
+int ls_amd_internal_plan_create_replicated_indexed(ls_amd_plan **out, ls_hs_operator const *op, ls_amd_dtype dtype,
+                                                   int num_partitions, int my_partition, uint64_t const *d_reps_local,
+                                                   int64_t count_local, uint64_t const *d_reps_global, int64_t count_global,
+                                                   ls_amd_gtab *gt, void *stream) {
+    return plan_create_replicated_impl(out, op, dtype, num_partitions, my_partition, d_reps_local, count_local, d_reps_global,
+                                       count_global, gt, stream);
+}
+static int plan_create_replicated_impl(ls_amd_plan **out, ls_hs_operator const *op, ls_amd_dtype dtype,
+                                       int num_partitions, int my_partition, uint64_t const *d_reps_local,
+                                       int64_t count_local, uint64_t const *d_reps_global, int64_t count_global,
+                                       ls_amd_gtab *gt, void *stream) {
     *out = NULL;
     if (!op || !op->basis) return set_error("null operator");
     if (ls_hs_basis_number_words(op->basis) != 1) return set_error("bases with more than 64 bits are not yet implemented");
@@ -1709,6 +1871,32 @@ int ls_amd_plan_create_replicated(ls_amd_plan **out, ls_hs_operator const *op, l
     ps->count = count_local;
     ps->d_reps = d_reps_local;
     ps->rounds = 1;
+    if (gt) {
+        /* indexed mode: the static table replaces every other index of the global basis */
+        if (pl->family != FAMILY_REPL_TILE) { ls_amd_plan_destroy(pl); return set_error("indexed replicated-x plans are for projected bases"); }
+        if (!(d_reps_local >= d_reps_global && d_reps_local + count_local <= d_reps_global + count_global)) {
+            ls_amd_plan_destroy(pl);
+            return set_error("indexed replicated-x plans need a contiguous block of the global rows");
+        }
+        pthread_mutex_lock(&g_gtab_lock);
+        ++gt->refs;
+        pthread_mutex_unlock(&g_gtab_lock);
+        pl->gtab = gt;
+        pl->idx_mode = 1;
+        pl->row_g0 = (int64_t)(d_reps_local - d_reps_global);
+        pl->gindex.kind = LSK_INDEX_SEARCH;
+        pl->gindex.count = count_global;
+        pl->gindex.reps = d_reps_global;
+        char const *e = getenv("LS_AMD_PULL_HALO");
+        pl->pull_halo = e ? atoi(e) : 512;
+        if (pl->pull_halo < 0) pl->pull_halo = 0;
+        if (pl->pull_halo > 512) pl->pull_halo = 512;
+        if (lsk_malloc(&p, 8 * (size_t)(count_local > 0 ? count_local : 1)) != 0) { ls_amd_plan_destroy(pl); return dev_error(); }
+        ps->d_norms = (double *)p;
+        if (lsk_norms(pl->dbs, count_local, d_reps_local, ps->d_norms, stream) != 0 || lsk_sync(stream) != 0) { ls_amd_plan_destroy(pl); return dev_error(); }
+        *out = pl;
+        return 0;
+    }
     /* index of the GLOBAL basis: reuse the single-partition logic on a temporary part */
     {
         ls_amd_plan tmp = *pl;
@@ -1757,6 +1945,27 @@ int ls_amd_plan_create_replicated(ls_amd_plan **out, ls_hs_operator const *op, l
     return 0;
 }
 
+int ls_amd_internal_basis_is_projected(ls_hs_basis const *b) { return BEXT(b)->order > 1; }
+/* does the plan's K4 mode read x * norm(rep)?  (then the owners prescale their blocks in the indexed exchange) */
+int ls_amd_internal_plan_prescales(ls_amd_plan const *pl) { return pl->dbs.k4_mode != 0; }
+/* norm(rep) of the `count` representatives a rank owns, in its own order (freshly allocated; the caller lsk_free's it):
+ * the rows are pulled out of the global array through the slot permutation, then K4's stabiliser sum */
+int ls_amd_internal_owner_norms(ls_hs_operator const *op, ls_amd_gtab const *gt, int me, double **d_norms, void *stream) {
+    lsk_basis dbs;
+    *d_norms = NULL;
+    if (basis_device(op->basis, &dbs) != 0) return -1;
+    int64_t const cnt = gt->counts[me];
+    void *reps = NULL, *nrm = NULL;
+    if (lsk_malloc(&reps, 8 * (size_t)(cnt > 0 ? cnt : 1)) != 0) return dev_error();
+    if (lsk_malloc(&nrm, 8 * (size_t)(cnt > 0 ? cnt : 1)) != 0) { lsk_free(reps); return dev_error(); }
+    int const rc = lsk_scatter_owned(gt->n, gt->d_perm, (int64_t)me * gt->max_count, cnt, gt->reps, (uint64_t *)reps, stream) ||
+                   lsk_norms(dbs, cnt, (uint64_t const *)reps, (double *)nrm, stream) || lsk_sync(stream);
+    lsk_free(reps);
+    if (rc) { lsk_free(nrm); return dev_error(); }
+    *d_norms = (double *)nrm;
+    return 0;
+}
+
 int ls_amd_matvec_replicated(ls_amd_plan *pl, void const *d_x_global, void *d_y_local, void *stream) {
     part_state *ps = &pl->parts[0];
     int slot;
@@ -1771,6 +1980,20 @@ int ls_amd_matvec_replicated(ls_amd_plan *pl, void const *d_x_global, void *d_y_
         else
             DEV(lsk_direct_gx(pl->dop, pl->dbs, pl->gindex, pl->cplx, pl->tilemap, ps->d_reps, pl->d_row_gidx, d_x_global,
                           d_y_local, pl->d_err, stream));
+        timing_end(pl, slot, stream);
+        stage_end(pl, st, stream);
+        return 0;
+    }
+    if (pl->family == FAMILY_REPL_TILE && pl->idx_mode) {
+        /* d_x_global = the owners' blocks in slot order, already multiplied by norm(rep) where the K4 mode prescales */
+        lsk_pullidx ix;
+        ix.tab = pl->gtab->tab;
+        ix.perm = pl->gtab->d_perm;
+        ix.row_g0 = pl->row_g0;
+        int const st = stage_begin(pl, ST_ROWS, stream);
+        slot = timing_begin(pl, stream);
+        DEV(lsk_tile_pull_idx(pl->dop, pl->dbs, pl->cplx, 0, ps->count, ps->d_reps, ps->d_norms, ix, pl->gindex.reps,
+                              pl->gindex.count, d_x_global, pl->pull_halo, d_y_local, pl->d_err, stream));
         timing_end(pl, slot, stream);
         stage_end(pl, st, stream);
         return 0;
@@ -1794,10 +2017,10 @@ char const *ls_amd_plan_kernel_name(ls_amd_plan const *pl) {
     case FAMILY_DIRECT_PUSH: return "direct-push";
     case FAMILY_DIRECT_PULL:
         return pl->has_chain ? "direct-pull+staged" : "direct-pull";
-    case FAMILY_TILE_PULL: return "tile-pull";
+    case FAMILY_TILE_PULL: return pl->idx_mode ? "tile-pull+indexed" : "tile-pull";
     case FAMILY_REPL_DIRECT:
         return pl->has_chain ? "replicated-direct-pull+staged" : "replicated-direct-pull";
-    case FAMILY_REPL_TILE: return "replicated-tile-pull";
+    case FAMILY_REPL_TILE: return pl->idx_mode ? "replicated-tile-pull+indexed" : "replicated-tile-pull";
     default: return "tile";
     }
 }
@@ -1894,6 +2117,37 @@ int ls_amd_scatter(ls_amd_plan *pl, int64_t n, uint64_t const *d_betas, void con
 int ls_amd_matvec(ls_amd_plan *pl, void const *const *d_x, void *const *d_y, void *stream) {
     if (pl->me >= 0) return set_error("ls_amd_matvec: plan owns one partition; drive it with generate/scatter");
     ls_amd_internal_count_matvec(pl);
+    if (pl->family == FAMILY_TILE_PULL && pl->idx_mode) {
+        /* indexed mode on one device: slot = index; the only per-matvec preparation is x * norm(rep), a streaming pass
+         * (the value table of the other mode costs N random 16-byte writes) */
+        part_state *ps = &pl->parts[0];
+        if (!pl->gtab) {
+            if (ls_amd_internal_gtab_acquire(&pl->gtab, pl->op->basis->number_sites, ps->d_reps, ps->count, NULL, 1, stream) != 0) return -1;
+            char const *e = getenv("LS_AMD_PULL_HALO");
+            pl->pull_halo = e ? atoi(e) : 512;
+            if (pl->pull_halo < 0) pl->pull_halo = 0;
+            if (pl->pull_halo > 512) pl->pull_halo = 512;
+            if (pl->dbs.k4_mode != 0) DEV(lsk_malloc(&pl->d_xs, (size_t)(pl->cplx ? 16 : 8) * (size_t)(ps->count > 0 ? ps->count : 1)));
+        }
+        void const *xs = d_x[0];
+        if (pl->dbs.k4_mode != 0) {
+            int const sr = stage_begin(pl, ST_REFRESH, stream);
+            DEV(lsk_scale(pl->cplx, ps->count, d_x[0], ps->d_norms, pl->d_xs, stream));
+            stage_end(pl, sr, stream);
+            xs = pl->d_xs;
+        }
+        lsk_pullidx ix;
+        ix.tab = pl->gtab->tab;
+        ix.perm = NULL;
+        ix.row_g0 = 0;
+        int const st = stage_begin(pl, ST_ROWS, stream);
+        int slot = timing_begin(pl, stream);
+        DEV(lsk_tile_pull_idx(pl->dop, pl->dbs, pl->cplx, 0, ps->count, ps->d_reps, ps->d_norms, ix, ps->d_reps, ps->count, xs,
+                              pl->pull_halo, d_y[0], pl->d_err, stream));
+        timing_end(pl, slot, stream);
+        stage_end(pl, st, stream);
+        return 0;
+    }
     if (pl->family == FAMILY_TILE_PULL) {
         part_state *ps = &pl->parts[0];
         void const *xg;

@@ -1803,6 +1803,368 @@ extern "C" int lsk_tile_pull(lsk_operator op, lsk_basis bs, lsk_index ix_global,
 }
 
 // ---------------------------------------------------------------------------------------------
+// Static index table {representative -> 32-bit payload} (lsk_gtab, lsk.h) and the INDEXED mode of the staged pull
+// kernel.  The value table above costs one request per far partner but must be rewritten every matvec -- a pass of N
+// random 16-byte writes on EVERY rank (chain_40_symm: 43 of 373 ms on one GPU, and undivided by P in the replicated-x
+// exchange).  The index table is built once: a far partner costs two dependent requests (bucket, then x[slot]), nothing is
+// refreshed, and x is read wherever it already lies -- index order on one device, or the blocks of the replicated-x
+// exchange as they arrive from their owners (slot = owner * max_count + local index), which removes the hashed -> block
+// permutation pass as well.  Per-rank work then shrinks with P.
+// ---------------------------------------------------------------------------------------------
+constexpr uint64_t kGtEmpty = ~0ULL;
+constexpr int kGtMaxDist = 255;
+// an L-bit bijection (odd multiplications mod 2^L and xor-shifts): bucket and tag together identify the key
+__host__ __device__ __forceinline__ uint64_t gt_mix(uint64_t k, int L) {
+    const uint64_t m = L >= 64 ? ~0ULL : ((1ULL << L) - 1);
+    const int s = (L + 1) >> 1;
+    k = (k * 0x9E3779B97F4A7C15ULL) & m;
+    k ^= k >> s;
+    k = (k * 0xD6E8FEB86659FD93ULL) & m;
+    k ^= k >> s;
+    return k;
+}
+__host__ __device__ __forceinline__ void gt_split(lsk_gtab const &t, uint64_t key, uint64_t &bucket, uint32_t &tag) {
+    const uint64_t h = gt_mix(key, t.L);
+    bucket = h >> t.tbits;
+    tag = (uint32_t)(h & ((1ULL << t.tbits) - 1));
+}
+// upper word of an entry: tag << 8 | displacement
+__host__ __device__ __forceinline__ uint32_t gt_hi(uint32_t tag, int dist) { return (tag << 8) | (uint32_t)dist; }
+
+__global__ __launch_bounds__(kBlock) void k_gtab_clear(int64_t entries, uint64_t *__restrict__ tab) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < entries; i += (int64_t)gridDim.x * kBlock) tab[i] = kGtEmpty;
+}
+__global__ __launch_bounds__(kBlock) void k_gtab_insert(lsk_gtab t, uint64_t *tab, int64_t n, uint64_t const *__restrict__ reps,
+                                                        uint32_t const *__restrict__ payload, int *flag) {
+    const uint64_t bmask = (1ULL << t.bbits) - 1;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        uint64_t b;
+        uint32_t tag;
+        gt_split(t, reps[i], b, tag);
+        const uint32_t pay = payload ? payload[i] : (uint32_t)i;
+        bool placed = false;
+        for (int d = 0; d <= kGtMaxDist && !placed; ++d) {
+            const unsigned long long e = ((unsigned long long)gt_hi(tag, d) << 32) | pay;
+            for (int sl = 0; sl < 2 && !placed; ++sl)
+                placed = atomicCAS((unsigned long long *)(tab + 2 * b + sl), (unsigned long long)kGtEmpty, e) == kGtEmpty;
+            b = (b + 1) & bmask;
+        }
+        if (!placed) atomicExch(flag, 1);
+    }
+}
+// payload of `key`, or 0xffffffff; `first` is the home bucket when the caller has already loaded it
+__device__ __forceinline__ uint32_t gt_resolve(lsk_gtab const &t, uint64_t const *__restrict__ tab, uint64_t b, uint32_t tag,
+                                               ulonglong2 cur) {
+    const uint64_t bmask = (1ULL << t.bbits) - 1;
+    for (int d = 0;; ++d) {
+        const uint32_t want = gt_hi(tag, d);
+        if ((uint32_t)(cur.x >> 32) == want && cur.x != kGtEmpty) return (uint32_t)cur.x;
+        if ((uint32_t)(cur.y >> 32) == want && cur.y != kGtEmpty) return (uint32_t)cur.y;
+        if (cur.x == kGtEmpty || cur.y == kGtEmpty || d == kGtMaxDist) return 0xffffffffu; // inserts never skip an empty slot
+        b = (b + 1) & bmask;
+        cur = *(ulonglong2 const *)(tab + 2 * b);
+    }
+}
+__global__ __launch_bounds__(kBlock) void k_gtab_lookup(lsk_gtab t, int64_t n, uint64_t const *__restrict__ keys,
+                                                        uint32_t *__restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        uint64_t b;
+        uint32_t tag;
+        gt_split(t, keys[i], b, tag);
+        out[i] = gt_resolve(t, t.entries, b, tag, *(ulonglong2 const *)(t.entries + 2 * b));
+    }
+}
+extern "C" int lsk_gtab_bits(int L, int64_t n, int64_t max_bytes) {
+    if (L < 1 || L > 64 || n < 0) return -1;
+    int bb = 2;
+    while (((int64_t)2 << bb) < 2 * n) ++bb; // two entries per bucket, load factor <= 0.5
+    if (bb < L - 24) bb = L - 24;            // tag (L - bbits bits) + displacement (8) + payload (32) must fit 64 bits
+    if (bb > L) bb = L;
+    if (bb > 40 || ((int64_t)16 << bb) > max_bytes) return -1;
+    return bb;
+}
+extern "C" int lsk_gtab_build(lsk_gtab t, uint64_t *entries, int64_t n, uint64_t const *reps, uint32_t const *payload,
+                              int *d_flag, void *stream) {
+    if (t.tbits != t.L - t.bbits || t.tbits < 0 || t.tbits > 24 || n >= 0xffffffffLL) { snprintf(g_err, sizeof(g_err), "lsk_gtab_build: bad table shape"); return -1; }
+    const int64_t ne = (int64_t)2 << t.bbits;
+    hipLaunchKernelGGL(k_gtab_clear, dim3(grid_for(ne)), dim3(kBlock), 0, (hipStream_t)stream, ne, entries);
+    LSK_LAUNCH_CHECK();
+    if (n > 0) {
+        hipLaunchKernelGGL(k_gtab_insert, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, t, entries, n, reps, payload, d_flag);
+        LSK_LAUNCH_CHECK();
+    }
+    return 0;
+}
+extern "C" int lsk_gtab_lookup(lsk_gtab t, int64_t n, uint64_t const *keys, uint32_t *out, void *stream) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_gtab_lookup, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, t, n, keys, out);
+    LSK_LAUNCH_CHECK();
+    return 0;
+}
+// host-side sequential build with the placement rule of k_gtab_insert (tests: no device needed); -1 when a key does not fit
+extern "C" int lsk_test_gtab_build_host(lsk_gtab t, uint64_t *h, int64_t n, uint64_t const *reps, uint32_t const *payload) {
+    const int64_t ne = (int64_t)2 << t.bbits;
+    const uint64_t bmask = (1ULL << t.bbits) - 1;
+    for (int64_t i = 0; i < ne; ++i) h[i] = kGtEmpty;
+    for (int64_t i = 0; i < n; ++i) {
+        uint64_t b;
+        uint32_t tag;
+        gt_split(t, reps[i], b, tag);
+        bool placed = false;
+        for (int d = 0; d <= kGtMaxDist && !placed; ++d) {
+            for (int sl = 0; sl < 2 && !placed; ++sl)
+                if (h[2 * b + sl] == kGtEmpty) { h[2 * b + sl] = ((uint64_t)gt_hi(tag, d) << 32) | (payload ? payload[i] : (uint32_t)i); placed = true; }
+            b = (b + 1) & bmask;
+        }
+        if (!placed) return -1;
+    }
+    return 0;
+}
+extern "C" int64_t lsk_test_gtab_find(lsk_gtab t, uint64_t const *h, uint64_t key) {
+    uint64_t b;
+    uint32_t tag;
+    gt_split(t, key, b, tag);
+    const uint64_t bmask = (1ULL << t.bbits) - 1;
+    for (int d = 0; d <= kGtMaxDist; ++d) {
+        const uint32_t want = gt_hi(tag, d);
+        for (int sl = 0; sl < 2; ++sl) {
+            const uint64_t e = h[2 * b + sl];
+            if (e == kGtEmpty) return -1;
+            if ((uint32_t)(e >> 32) == want) return (int64_t)(uint32_t)e;
+        }
+        b = (b + 1) & bmask;
+    }
+    return -1;
+}
+
+template <bool CPLX>
+__global__ __launch_bounds__(kBlock) void k_scale(int64_t n, double const *__restrict__ x, double const *__restrict__ norms,
+                                                  double *__restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        const double nb = norms[i];
+        if (CPLX) { out[2 * i] = x[2 * i] * nb; out[2 * i + 1] = x[2 * i + 1] * nb; } else out[i] = x[i] * nb;
+    }
+}
+extern "C" int lsk_scale(int cplx, int64_t n, void const *x, double const *norms, void *out, void *stream) {
+    if (n == 0) return 0;
+    if (cplx) hipLaunchKernelGGL(k_scale<true>, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, n, (double const *)x, norms, (double *)out);
+    else hipLaunchKernelGGL(k_scale<false>, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, n, (double const *)x, norms, (double *)out);
+    LSK_LAUNCH_CHECK();
+    return 0;
+}
+__global__ __launch_bounds__(kBlock) void k_scatter_owned(int64_t n, uint32_t const *__restrict__ perm, int64_t base, int64_t count,
+                                                          uint64_t const *__restrict__ src, uint64_t *__restrict__ dst) {
+    for (int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x; g < n; g += (int64_t)gridDim.x * kBlock) {
+        const int64_t j = (int64_t)perm[g] - base;
+        if (j >= 0 && j < count) dst[j] = src[g];
+    }
+}
+extern "C" int lsk_scatter_owned(int64_t n, uint32_t const *perm, int64_t base, int64_t count, uint64_t const *src, uint64_t *dst,
+                                 void *stream) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_scatter_owned, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, n, perm, base, count, src, dst);
+    LSK_LAUNCH_CHECK();
+    return 0;
+}
+
+// Indexed mode of k_tile_pull: the same stage A (LDS term list per 256-row tile) and stage B1 (K4), then
+//   near partners (inside the LDS window of the sorted representatives): global index g -> slot (perm[g] or g) -> xsrc[slot]
+//   far partners: ONE 16-byte bucket of the static index table -> slot -> xsrc[slot]
+// All first-level loads of a thread's kGCPull packets are issued before any is consumed, then all value loads.
+template <typename W, bool PM1, bool CPLX, bool REAL>
+__global__ __launch_bounds__(kBlock) void k_tile_pull_idx(lsk_runs runs, int n_groups, lsk_group const *__restrict__ groups,
+                                                          lsk_term const *__restrict__ off, int n_diag,
+                                                          lsk_term const *__restrict__ diag, lsk_basis bs,
+                                                          lsk_group_elem const *__restrict__ elems, int64_t row0, int64_t row1,
+                                                          uint64_t const *__restrict__ reps,
+                                                          double const *__restrict__ norms_local, lsk_pullidx ix,
+                                                          uint64_t const *__restrict__ greps, int64_t n_global,
+                                                          double const *__restrict__ xsrc, int halo, double *__restrict__ y,
+                                                          int *err) {
+    typedef typename ChainX<CPLX>::type X;
+    X const *__restrict__ xv = (X const *)xsrc;
+    __shared__ uint32_t s_win[kPullWin];
+    __shared__ uint64_t s_beta[kCapPull];
+    constexpr bool RC = REAL && PM1;
+    __shared__ double s_coef[kCapPull * (RC ? 1 : 2)];
+    __shared__ uint16_t s_row[kCapPull];
+    __shared__ double s_acc[kBlock * (CPLX ? 2 : 1)];
+    __shared__ int s_n;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    uint64_t const *__restrict__ tab = ix.tab.entries;
+    for (int64_t t0 = row0 + (int64_t)blockIdx.x * kBlock; t0 < row1; t0 += (int64_t)gridDim.x * kBlock) {
+        const int64_t i = t0 + tid;
+        const bool valid = i < row1;
+        uint64_t a = 0;
+        double inv_na = 0.0;
+        if (valid) {
+            a = reps[i];
+            const double na = norms_local[i];
+            inv_na = na > 0.0 ? 1.0 / na : 0.0;
+        }
+        if (CPLX) { s_acc[2 * tid] = 0.0; s_acc[2 * tid + 1] = 0.0; } else s_acc[tid] = 0.0;
+        int64_t gbase = 0;
+        int wn = 0;
+        uint64_t v0 = 0;
+        if (halo > 0) {
+            const int64_t ig0 = ix.row_g0 + t0;
+            gbase = ig0 > halo ? ig0 - halo : 0;
+            const int64_t left = n_global - gbase;
+            wn = (int)(left < (int64_t)(kBlock + 2 * halo) ? left : (int64_t)(kBlock + 2 * halo));
+            v0 = greps[gbase];
+            for (int w = tid; w < wn; w += kBlock) s_win[w] = window_offset(greps[gbase + w], v0);
+        }
+        for (int g0 = 0; g0 < n_groups; g0 += kGCPull) {
+            if (tid == 0) s_n = 0;
+            __syncthreads();
+            const int g1 = min(g0 + kGCPull, n_groups);
+            for (int g = g0; g < g1; ++g) {
+                lsk_group const G = groups[g];
+                double cr = 0.0, ci = 0.0;
+                if (valid) group_coeff<REAL>(G, off, a, cr, ci);
+                const bool act = valid && (cr != 0.0 || (!REAL && ci != 0.0));
+                const unsigned long long ball = __ballot(act);
+                int base = 0;
+                if (lane == 0 && ball) base = atomicAdd(&s_n, __popcll(ball));
+                base = __shfl(base, 0);
+                if (act) {
+                    const int slot = base + __popcll(ball & ((1ULL << lane) - 1));
+                    s_beta[slot] = a ^ G.x;
+                    s_row[slot] = (uint16_t)tid;
+                    if (RC) s_coef[slot] = cr * inv_na;
+                    else { s_coef[2 * slot] = cr * inv_na; s_coef[2 * slot + 1] = -ci * inv_na; }
+                }
+            }
+            __syncthreads();
+            const int n = s_n;
+            // ---- stage B1: K4 on every packet ------------------------------------------------------------
+            for (int e = tid; e < n; e += kBlock) {
+                uint64_t beta = s_beta[e];
+                if (bs.k4_mode != 0) {
+                    beta = (uint64_t)rep_trivial<W>(bs, elems, (W)beta); // xsrc is pre-multiplied by norm(rep)
+                } else {
+                    double hr, hi = 0.0;
+                    if (RC) hr = s_coef[e]; else { hr = s_coef[2 * e]; hi = s_coef[2 * e + 1]; }
+                    W rep; double chr, chi, stab;
+                    state_info_w<W, PM1>(bs, elems, (W)beta, rep, chr, chi, stab);
+                    const double n2 = stab * bs.inv_order;
+                    if (!(n2 > 1e-12)) { s_row[e] = 0xffff; continue; } // zero-norm orbit: contributes nothing (DMV:110)
+                    const double nb = sqrt(n2);
+                    beta = (uint64_t)rep;
+                    const double tr = (hr * chr + hi * chi) * nb, ti = (hi * chr - hr * chi) * nb;
+                    if (RC) s_coef[e] = tr; else { s_coef[2 * e] = tr; s_coef[2 * e + 1] = ti; }
+                }
+                s_beta[e] = beta;
+            }
+            // ---- stage B2: slots, then values --------------------------------------------------------------
+            {
+                uint64_t bkt[kGCPull];
+                uint32_t tag[kGCPull], slot[kGCPull];
+                ulonglong2 first[kGCPull];
+                bool live[kGCPull];
+                int pos[kGCPull];
+#pragma unroll
+                for (int k = 0; k < kGCPull; ++k) { // window searches: LDS only
+                    const int e = tid + k * kBlock;
+                    live[k] = e < n && s_row[e] != 0xffff;
+                    pos[k] = -1;
+                    bkt[k] = 0; tag[k] = 0; slot[k] = 0;
+                    first[k] = make_ulonglong2(0, 0);
+                    if (live[k]) {
+                        const uint64_t key = s_beta[e];
+                        if (wn > 0 && key >= v0) {
+                            const uint32_t d = window_offset(key, v0);
+                            if (d != kWinAbsent) pos[k] = window_find(s_win, wn, d);
+                        }
+                        if (pos[k] < 0) gt_split(ix.tab, key, bkt[k], tag[k]);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < kGCPull; ++k) { // first-level loads: perm entry (near) or home bucket (far)
+                    if (!live[k]) continue;
+                    if (pos[k] >= 0) slot[k] = ix.perm ? ix.perm[gbase + pos[k]] : (uint32_t)(gbase + pos[k]);
+                    else first[k] = *(ulonglong2 const *)(tab + 2 * bkt[k]);
+                }
+#pragma unroll
+                for (int k = 0; k < kGCPull; ++k) { // resolve the far slots (a displaced key continues along its buckets)
+                    if (!live[k] || pos[k] >= 0) continue;
+                    slot[k] = gt_resolve(ix.tab, tab, bkt[k], tag[k], first[k]);
+                    if (slot[k] == 0xffffffffu) { atomicExch(err, 1); live[k] = false; }
+                }
+                X val[kGCPull];
+#pragma unroll
+                for (int k = 0; k < kGCPull; ++k) val[k] = live[k] ? xv[slot[k]] : cx_zero<X>();
+#pragma unroll
+                for (int k = 0; k < kGCPull; ++k) {
+                    if (!live[k]) continue;
+                    const int e = tid + k * kBlock;
+                    double hr, hi = 0.0;
+                    if (RC) hr = s_coef[e]; else { hr = s_coef[2 * e]; hi = s_coef[2 * e + 1]; }
+                    const int r = s_row[e];
+                    if constexpr (CPLX) {
+                        atomicAdd(&s_acc[2 * r], hr * val[k].x - hi * val[k].y);
+                        atomicAdd(&s_acc[2 * r + 1], hr * val[k].y + hi * val[k].x);
+                    } else {
+                        atomicAdd(&s_acc[r], hr * val[k]);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        if (valid) {
+            const int64_t ig = ix.row_g0 + i;
+            const uint32_t own = ix.perm ? ix.perm[ig] : (uint32_t)ig;
+            // x of this row: xsrc holds x * norm(rep) in the prescaling K4 modes
+            const double back = bs.k4_mode != 0 ? inv_na : 1.0;
+            double dr = 0.0, di = 0.0;
+            if (n_diag > 0) diag_coeff<uint64_t, REAL>(runs, n_diag, diag, a, dr, di);
+            if constexpr (CPLX) {
+                const X xo = xv[own];
+                const double xr = xo.x * back, xi = xo.y * back;
+                double yr = dr * xr - di * xi + s_acc[2 * tid], yi = dr * xi + di * xr + s_acc[2 * tid + 1];
+                if (n_diag == 0) { yr += y[2 * i]; yi += y[2 * i + 1]; } // accumulate, DMV:1062-1063
+                y[2 * i] = yr; y[2 * i + 1] = yi;
+            } else {
+                double yr = n_diag > 0 ? dr * (xv[own] * back) + s_acc[tid] : s_acc[tid];
+                if (n_diag == 0) yr += y[i];
+                y[i] = yr;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" int lsk_tile_pull_idx(lsk_operator op, lsk_basis bs, int cplx, int64_t row0, int64_t row1, uint64_t const *reps,
+                                 double const *norms_local, lsk_pullidx ix, uint64_t const *reps_global, int64_t n_global,
+                                 void const *xsrc, int halo, void *y, int *d_err, void *stream) {
+    if (row1 <= row0) return 0;
+    if (bs.proj != LSK_PROJ_FULL) { snprintf(g_err, sizeof(g_err), "lsk_tile_pull_idx is for projected bases"); return -1; }
+    if (halo < 0 || halo > kPullHalo || (halo > 0 && (!reps_global || n_global <= 0))) { snprintf(g_err, sizeof(g_err), "lsk_tile_pull_idx: bad near window"); return -1; }
+    dim3 g(1), b(kBlock);
+    const int64_t work_blocks = (row1 - row0 + kBlock - 1) / kBlock;
+    hipStream_t s = (hipStream_t)stream;
+#define LSK_TPI_ARGS op.runs, op.n_groups, op.groups, op.off, op.n_diag, op.diag, bs, bs.elems, row0, row1, reps, norms_local, ix, \
+        reps_global, n_global, (double const *)xsrc, halo, (double *)y, d_err
+#define LSK_TPI_LAUNCH(W, PM1)                                                                                  \
+    do {                                                                                                        \
+        if (cplx) {                                                                                             \
+            if (op.is_real) { g.x = tile_grid(k_tile_pull_idx<W, PM1, true, true>, work_blocks); hipLaunchKernelGGL((k_tile_pull_idx<W, PM1, true, true>), g, b, 0, s, LSK_TPI_ARGS); } \
+            else { g.x = tile_grid(k_tile_pull_idx<W, PM1, true, false>, work_blocks); hipLaunchKernelGGL((k_tile_pull_idx<W, PM1, true, false>), g, b, 0, s, LSK_TPI_ARGS); } \
+        } else {                                                                                                \
+            if (op.is_real) { g.x = tile_grid(k_tile_pull_idx<W, PM1, false, true>, work_blocks); hipLaunchKernelGGL((k_tile_pull_idx<W, PM1, false, true>), g, b, 0, s, LSK_TPI_ARGS); } \
+            else { g.x = tile_grid(k_tile_pull_idx<W, PM1, false, false>, work_blocks); hipLaunchKernelGGL((k_tile_pull_idx<W, PM1, false, false>), g, b, 0, s, LSK_TPI_ARGS); } \
+        }                                                                                                       \
+    } while (0)
+    if (bs.number_sites <= 32) { if (bs.chars_pm1) LSK_TPI_LAUNCH(uint32_t, true); else LSK_TPI_LAUNCH(uint32_t, false); }
+    else { if (bs.chars_pm1) LSK_TPI_LAUNCH(uint64_t, true); else LSK_TPI_LAUNCH(uint64_t, false); }
+#undef LSK_TPI_LAUNCH
+#undef LSK_TPI_ARGS
+    LSK_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Consumer side (K7 + K8): received packets -> local index -> atomic add
 // ---------------------------------------------------------------------------------------------
 template <bool CPLX>

@@ -181,6 +181,48 @@ int lsk_tile_pull(lsk_operator op, lsk_basis bs, lsk_index ix_global, int cplx, 
                   int64_t const *row_gidx, void const *tab, int tab_bits, uint64_t const *reps_global,
                   int64_t n_global, void const *xs_global, int halo, void const *x_global, void *y,
                   int *d_err, void *stream);
+/* Static index table {representative -> 32-bit payload} of the staged pull kernel's INDEXED mode (lsk_tile_pull_idx): built
+ * once per basis, never refreshed.  Open addressing over 16-byte buckets of two 8-byte entries (one 16-byte request per
+ * probe).  The key itself is not stored: h = an L-bit bijection of the state, bucket = its top `bbits` bits, and the entry
+ * keeps the other L - bbits bits (tag), its displacement from the home bucket (8 bits) and the payload:
+ *     entry = tag << 40 | displacement << 32 | payload,   empty = ~0
+ * so 2^(bbits + 1) entries of 8 bytes serve n <= 2^bbits keys at load <= 0.5 (half the bytes of a {key, value} table, and
+ * nothing to rewrite per matvec).  Needs tbits = L - bbits <= 24 and payloads < 2^32 - 1. */
+typedef struct lsk_gtab {
+    uint64_t const *entries; /* device [2 << bbits] */
+    int L, bbits, tbits;
+} lsk_gtab;
+/* choose bbits for n keys of L bits (returns -1 when no admissible size exists below max_bytes) */
+int lsk_gtab_bits(int L, int64_t n, int64_t max_bytes);
+/* fills entries (device, 16 << bbits bytes, allocated by the caller) with reps[i] -> payload[i] (payload NULL: i);
+ * *d_flag is raised when a key cannot be placed within 255 buckets of its home */
+int lsk_gtab_build(lsk_gtab t, uint64_t *entries, int64_t n, uint64_t const *reps, uint32_t const *payload, int *d_flag,
+                   void *stream);
+/* host-side mirror of the device lookup on a host copy of the entries (tests): payload or -1 */
+int64_t lsk_test_gtab_find(lsk_gtab t, uint64_t const *h_entries, uint64_t key);
+int lsk_test_gtab_build_host(lsk_gtab t, uint64_t *h_entries, int64_t n, uint64_t const *reps, uint32_t const *payload);
+/* out[i] = lookup(keys[i]) or 0xffffffff (tests / plan-time checks) */
+int lsk_gtab_lookup(lsk_gtab t, int64_t n, uint64_t const *keys, uint32_t *out, void *stream);
+
+/* INDEXED mode of the staged pull kernel: the table yields a SLOT and the value is xsrc[slot] -- xsrc is x (times norm(rep) in
+ * the K4 modes that prescale) in whatever order the caller holds it: index order on one device (perm == NULL, slot = global
+ * index), or the received blocks of the replicated-x exchange as they arrive, owner-major (perm[g] = slot of global row g).
+ * Rows are the contiguous global rows [row_g0 + row0, row_g0 + row1). */
+typedef struct lsk_pullidx {
+    lsk_gtab tab;
+    uint32_t const *perm; /* device [n_global] or NULL */
+    int64_t row_g0;
+} lsk_pullidx;
+int lsk_tile_pull_idx(lsk_operator op, lsk_basis bs, int cplx, int64_t row0, int64_t row1, uint64_t const *reps,
+                      double const *norms_local, lsk_pullidx ix, uint64_t const *reps_global, int64_t n_global,
+                      void const *xsrc, int halo, void *y, int *d_err, void *stream);
+/* out[i] = x[i] * norms[i] (f64 / c128): the owner-side prescaling of the indexed mode */
+int lsk_scale(int cplx, int64_t n, void const *x, double const *norms, void *out, void *stream);
+/* dst[perm[g] - base] = src[g] for every g with base <= perm[g] < base + count (8-byte elements): the rows one owner holds,
+ * out of the global array, in its own (ascending) order */
+int lsk_scatter_owned(int64_t n, uint32_t const *perm, int64_t base, int64_t count, uint64_t const *src, uint64_t *dst,
+                      void *stream);
+
 /* host-side check of the window search (tests, no device): position of `key` among the ascending reps[0, n), n <= 1280,
  * or -1 -- exactly what a tile resolves in LDS */
 int lsk_test_window_find(uint64_t const *reps, int n, uint64_t key);

@@ -204,11 +204,13 @@ int ls_amd_matvec_replicated(ls_amd_plan *plan, void const *d_x_global, void *d_
  * and the ring is reset. */
 int ls_amd_plan_enable_timing(ls_amd_plan *plan, int max_samples);
 /* Stage timers: the reference's --kDisplayTimings tree (DMV:1028-1052), HIP events around every stage launch on the
- * launch stream.  stages: 0 localDiagonal, 1 hash-table refresh, 2 row kernel (fused paths), 3 producers (k_tile),
- * 4 exchange wait, 5 consumers (k_scatter).  max_events = capacity of the event pool between two reads (0 disables). */
-#define LS_AMD_NUM_STAGES 6
+ * launch stream.  stages: 0 localDiagonal, 1 preparation of x (value-table refresh / x n(rep) / hashed -> block permutation),
+ * 2 row kernel (fused paths), 3 producers (k_tile), 4 exchange (wait on the compute stream; replicated-x: the all-to-all of x),
+ * 5 consumers (k_scatter), 6 replicated-x: y rows grouped by owner and returned.  max_events = capacity of the event pool
+ * between two reads (0 disables). */
+#define LS_AMD_NUM_STAGES 7
 int ls_amd_plan_enable_stage_timing(ls_amd_plan *plan, int max_events);
-int ls_amd_plan_stage_times(ls_amd_plan *plan, double *ms /* [6] totals */, int64_t *calls /* [6] */, int64_t *matvecs);
+int ls_amd_plan_stage_times(ls_amd_plan *plan, double *ms /* [LS_AMD_NUM_STAGES] totals */, int64_t *calls /* [LS_AMD_NUM_STAGES] */, int64_t *matvecs);
 int ls_amd_plan_timing_report(ls_amd_plan *plan, char *buf, size_t capacity); /* the tree as text, per matvec */
 int ls_amd_plan_kernel_times(ls_amd_plan *plan, float *ms, int capacity, int *count);
 
@@ -271,6 +273,13 @@ void ls_amd_test_free(void *p);
  * `key` among the ascending reps[0, n) (n <= 1280, stored as saturating 32-bit offsets from reps[0] exactly as a tile
  * stores them in LDS), -1 if it is not there or not representable (then the kernel takes the hash table), -2 on bad n */
 int ls_amd_test_window_find(uint64_t const *reps, int n, uint64_t key);
+/* Host-only test hooks of the static index table {representative -> 32-bit payload} of the indexed pull mode
+ * (distributed-matvec_amd/csrc/lsk.h: lsk_gtab): bucket bits for n keys of L bits (-1: no admissible shape), a sequential
+ * build with the device kernel's placement rule into a malloc'ed array of 2 << bbits entries (release with
+ * ls_amd_test_free; payload NULL: the key's position), and the lookup (payload, or -1 when absent) */
+int ls_amd_test_gtab_bits(int L, int64_t n);
+int ls_amd_test_gtab_build(int L, int bbits, int64_t n, uint64_t const *reps, uint32_t const *payload, uint64_t **entries);
+int64_t ls_amd_test_gtab_find(int L, int bbits, uint64_t const *entries, uint64_t key);
 /* byte offsets of commInfo / globalSumReal_type inside primme_params as the PRIMME callbacks read them (ls_chpl.h) */
 int ls_amd_test_primme_comminfo_offset(void);
 int ls_amd_test_primme_sumtype_offset(void);

@@ -57,8 +57,11 @@ for mode in (["packets", "replicated"] if args.mode == "both" else [args.mode]):
             for _ in range(args.steps):
                 op.matvec(xs[rank], ys[rank], check=False)
             torch.cuda.synchronize()
-            out[rank] = ((time.perf_counter() - t) / args.steps, plan.timing_report(), getattr(op, "exchange_bytes_per_matvec", 0),
-                         getattr(op, "num_rounds", 1))
+            wall_r = (time.perf_counter() - t) / args.steps
+            report = plan.timing_report()
+            stages, mv = plan.stage_times()
+            out[rank] = (wall_r, report, getattr(op, "exchange_bytes_per_matvec", 0), getattr(op, "num_rounds", 1),
+                         {k: v[0] / max(1, mv) for k, v in stages.items()}, plan.kernel)
             (op.dm if mode == "packets" else op.rm).destroy()
         except BaseException as e:  # noqa: BLE001
             errors.append(e)
@@ -77,6 +80,20 @@ for mode in (["packets", "replicated"] if args.mode == "both" else [args.mode]):
     print(f"[{mode}] {P} ranks sharing one GPU: {wall * 1e3:.2f} ms per matvec (all ranks), rounds = {out[0][3]}, "
           f"exchange {xb / 1e9:.2f} GB per matvec over all ranks, max |dy| / max |y| vs one partition = {err:.1e}")
     print("rank 0: " + out[0][1], flush=True)
+    # device time of every rank's stages (HIP events; the ranks share ONE device, so stages of different ranks overlap and
+    # each is slower than it would be alone): the aggregate is what P GPUs would have to do in total, transport excluded
+    # ("exchangeWait" here is device-to-device copies behind a host barrier, not xGMI)
+    names = list(out[0][4])
+    print(f"per-rank stage device time per matvec [ms] ({out[0][5]}):")
+    print("  rank  " + "  ".join(f"{n[:14]:>14s}" for n in names) + "     compute")
+    agg = 0.0
+    for r in range(P):
+        st = out[r][4]
+        compute = sum(v for k, v in st.items() if k != "exchangeWait")
+        agg += compute
+        print(f"  {r:4d}  " + "  ".join(f"{st[n]:14.3f}" for n in names) + f"  {compute:10.3f}")
+    print(f"aggregate compute-stage device time of the {P} ranks: {agg:.2f} ms per matvec -> {agg / P:.2f} ms per rank; "
+          f"wall on the shared device {wall * 1e3:.2f} ms -> {wall * 1e3 / P:.2f} ms per rank", flush=True)
     assert err <= 1e-12
     for c in comms:
         c.destroy()

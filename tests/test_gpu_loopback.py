@@ -89,6 +89,57 @@ def test_ranks_as_threads(name, P, cplx, mode):
         c.destroy()
 
 
+@pytest.mark.parametrize("indexed", ["1", "0"])
+@pytest.mark.parametrize("case", ["heisenberg_chain_24_symm/4/f64", "heisenberg_chain_24_symm/3/c128", "issue_01/2/f64",
+                                  "heisenberg_kagome_12_symm/8/f64", "translation_12_5/3/c128"])
+def test_replicated_exchange_indexed_and_value_table(monkeypatch, case, indexed):
+    """ls_amd_repl_matvec on projected bases, both ways of reading x: INDEXED (default: static {rep -> slot} table, x stays
+    in the owner-major order it arrives in, owners prescale -- no per-rank O(N) pass) and the value table + permutation pass
+    (LS_AMD_REPL_INDEXED=0), against the oracle; trivial sectors (prescaled), a -1 character and complex characters."""
+    import torch
+
+    import distributed_matvec_amd as D
+    from distributed_matvec_amd.distributed import RcclReplicatedOperator
+    from helpers import complex_translation_config
+    from oracle import c_oracle as CO
+    from oracle import model as M
+
+    name, P, dt = case.split("/")
+    P = int(P)
+    monkeypatch.setenv("LS_AMD_REPL_INDEXED", indexed)
+    if name.startswith("translation"):
+        _, L, sector = name.split("_")
+        cfg = complex_translation_config(int(L), int(sector))
+        o = CO.COracle(M.model_from_config(cfg))
+        want_reps = o.enumerate()
+    else:
+        cfg, o, want_reps = model_config(name), oracle_for(name), oracle_reps(name)
+    basis, h = D.loadConfigFromDict(cfg, hamiltonian=True)
+    reps, masks = D.enumerateStates(basis, P)
+    reps_global = D.arrFromHashedToBlock(reps, masks)
+    dtype = torch.complex128 if dt == "c128" else torch.float64
+    xs = [D.fillRandom(reps[p], 23, dtype) for p in range(P)]
+    ys = [torch.full_like(x, -3.0) for x in xs]
+    kernels = [None] * P
+
+    def body(rank, comm):
+        op = RcclReplicatedOperator(h, reps_global, masks, dtype, comm=comm)
+        kernels[rank] = op.engine.plan.kernel
+        for _ in range(2):
+            op.matvec(xs[rank], ys[rank], check=True)
+        op.rm.destroy()
+
+    comms = _run_ranks(P, body)
+    assert all(k == ("replicated-tile-pull+indexed" if indexed == "1" else "replicated-tile-pull") for k in kernels), kernels
+    keys = CO.locale_idx_of(want_reps, P)
+    x = CO.hashed_to_block([v.cpu().numpy() for v in xs], keys)
+    got = CO.hashed_to_block([v.cpu().numpy() for v in ys], keys)
+    want = o.local_matvec(want_reps, x)
+    assert np.abs(got - want).max() <= 1e-12 * max(1.0, np.abs(want).max())
+    for c in comms:
+        c.destroy()
+
+
 def test_round_agreement_and_primme_reductions_across_ranks(monkeypatch):
     """every rank must run the same number of rounds (all-reduce MAX of the local counts), and PRIMME's host-buffer
     reductions (/root/reference/src/PRIMME.chpl:267-373) sum / broadcast across the ranks of primme->commInfo"""

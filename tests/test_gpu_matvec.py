@@ -182,6 +182,65 @@ def test_complex_characters(torch, L, sector, P):
         run_matvec(torch, D, h, reps, masks, x.real.copy(), P)
 
 
+PROJECTED_MODELS = ["heisenberg_chain_24_symm", "heisenberg_kagome_12_symm", "issue_01"]
+
+
+@pytest.mark.parametrize("name", PROJECTED_MODELS)
+@pytest.mark.parametrize("halo", ["512", "0", "37"])
+def test_indexed_pull_mode_single_locale(torch, monkeypatch, name, halo):
+    """the INDEXED mode of the projected-basis pull kernel (static {rep -> index} table, x read through the index; no
+    per-matvec table refresh) == the oracle, f64 and c128, with the near window on, off and at an odd size; the trivial
+    sectors prescale x by norm(rep), issue_01 (character -1) does not"""
+    monkeypatch.setenv("LS_AMD_PULL_INDEXED", "1")
+    monkeypatch.setenv("LS_AMD_PULL_HALO", halo)
+    D, basis, h, reps, masks = setup_model(torch, model_config(name), 1)
+    want_reps = oracle_reps(name)
+    rs = np.random.RandomState(52)
+    x = rs.rand(len(want_reps)) - 0.5
+    got, pl = run_matvec(torch, D, h, reps, masks, x, 1, "pull")
+    assert pl.kernel == "tile-pull+indexed"
+    assert_close(got, oracle_for(name).local_matvec(want_reps, x), name)
+    got2, _ = run_matvec(torch, D, h, reps, masks, x, 1, "pull")  # second call: the table is reused, nothing is refreshed
+    assert np.array_equal(got, got2)
+    xc = x + 1j * (rs.rand(len(want_reps)) - 0.5)
+    gotc, plc = run_matvec(torch, D, h, reps, masks, xc, 1, "pull")
+    assert plc.kernel == "tile-pull+indexed"
+    wantc = oracle_for(name).local_matvec(want_reps, xc)
+    assert np.abs(gotc - wantc).max() <= 1e-12 * max(1.0, np.abs(wantc).max())
+
+
+@pytest.mark.parametrize("L,sector", [(8, 1), (12, 5)])
+def test_indexed_pull_mode_complex_characters(torch, monkeypatch, L, sector):
+    from oracle import c_oracle as CO
+    from oracle import model as M
+
+    monkeypatch.setenv("LS_AMD_PULL_INDEXED", "1")
+    cfg = complex_translation_config(L, sector)
+    o = CO.COracle(M.model_from_config(cfg))
+    want_reps = o.enumerate()
+    D, basis, h, reps, masks = setup_model(torch, cfg, 1)
+    rs = np.random.RandomState(53)
+    x = (rs.rand(len(want_reps)) - 0.5) + 1j * (rs.rand(len(want_reps)) - 0.5)
+    got, pl = run_matvec(torch, D, h, reps, masks, x, 1, "pull")
+    assert pl.kernel == "tile-pull+indexed"
+    want = o.local_matvec(want_reps, x)
+    assert np.abs(got - want).max() <= 1e-12 * max(1.0, np.abs(want).max())
+
+
+def test_indexed_pull_mode_reports_states_outside_the_basis(torch, monkeypatch):
+    """DMV:115-118 in the indexed mode: a partner the static table does not hold raises the plan's error flag"""
+    import distributed_matvec_amd as D
+
+    monkeypatch.setenv("LS_AMD_PULL_INDEXED", "1")
+    basis, h = D.loadConfigFromDict(model_config("heisenberg_chain_24_symm"), hamiltonian=True)
+    reps, masks = D.enumerateStates(basis, 1)
+    holed = [torch.cat([reps[0][:1000], reps[0][1001:]])]  # one representative missing: its partners' look-ups must fail
+    x = [torch.ones(holed[0].numel(), dtype=torch.float64, device="cuda")]
+    y = [torch.zeros_like(x[0])]
+    with pytest.raises(D.LsAmdError, match="invalid index"):
+        D.matrixVectorProduct(h, x, y, holed, mode="pull")
+
+
 def test_y_is_overwritten_by_diagonal_then_accumulated(torch):
     """DMV:1062-1069: with diagonal terms y is assigned first (garbage in y is harmless); without
     them y is accumulated into."""

@@ -460,3 +460,48 @@ def test_near_window_search_of_the_pull_kernel():
     assert [find(reps, k) for k in reps] == [0, 1, 2, -1, -1, -1]
     assert find(reps, base + 8) == -1 and find(reps, base + (1 << 32) + 5) == -1
     assert find(reps[:1], base) == 0 and find(np.arange(1281, dtype=np.uint64), 3) == -2
+
+
+@pytest.mark.parametrize("name", ["heisenberg_chain_24_symm", "heisenberg_chain_16", "heisenberg_kagome_12_symm"])
+def test_static_index_table_finds_every_representative(name):
+    """lsk_gtab (indexed pull mode): the key is not stored -- bucket and tag come from an L-bit bijection -- so the test is
+    that every representative is found with ITS payload, that states outside the basis are reported absent, and that the
+    table has the advertised shape (two 8-byte entries per 16-byte bucket, load <= 0.5, tag + displacement + payload in 64
+    bits).  Host mirror of the device build / lookup (same placement rule, same probe sequence)."""
+    from helpers import oracle_reps
+
+    lib = _lib.load()
+    reps = np.ascontiguousarray(oracle_reps(name), dtype=np.uint64)
+    n = len(reps)
+    L = int(model_config(name)["basis"]["number_spins"])
+    bb = lib.ls_amd_test_gtab_bits(L, n)
+    assert bb >= 2 and (2 << bb) >= 2 * n and L - bb <= 24 and (bb <= 3 or (2 << (bb - 1)) < 2 * n or bb == L - 24)
+    rs = np.random.RandomState(7)
+    payload = rs.permutation(n).astype(np.uint32)  # a slot permutation, as the replicated-x exchange has it
+    ent = C.POINTER(C.c_uint64)()
+    assert lib.ls_amd_test_gtab_build(L, bb, n, reps.ctypes.data_as(C.POINTER(C.c_uint64)), payload.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                      C.byref(ent)) == 0
+    try:
+        got = np.array([lib.ls_amd_test_gtab_find(L, bb, ent, C.c_uint64(int(k))) for k in reps])
+        assert np.array_equal(got, payload.astype(np.int64))
+        present = set(int(k) for k in reps)
+        absent = [int(k) for k in rs.randint(0, 1 << L, size=4000, dtype=np.int64) if int(k) not in present]
+        assert len(absent) > 100
+        assert all(lib.ls_amd_test_gtab_find(L, bb, ent, C.c_uint64(k)) == -1 for k in absent)
+        table = np.ctypeslib.as_array(ent, shape=(2 << bb,))
+        used = table != np.uint64(0xFFFFFFFFFFFFFFFF)
+        assert int(used.sum()) == n
+        disp = (table[used] >> np.uint64(32)) & np.uint64(0xFF)
+        assert float((disp > 0).mean()) < 0.2 and int(disp.max()) < 32  # the hash spreads the orbit minima
+    finally:
+        lib.ls_amd_test_free(ent)
+
+
+def test_static_index_table_shapes():
+    lib = _lib.load()
+    assert lib.ls_amd_test_gtab_bits(40, 861725794) == 30  # chain_40_symm: 2^31 entries of 8 bytes = 17 GB, tag 10 bits
+    assert lib.ls_amd_test_gtab_bits(36, 63068876) == 26
+    assert lib.ls_amd_test_gtab_bits(48, 1000) == 24  # few keys of many bits: the tag must still fit 24 bits (268 MB)
+    assert lib.ls_amd_test_gtab_bits(64, 1000) == -1  # ... and does not beyond 1 TiB: those plans keep the value table
+    assert lib.ls_amd_test_gtab_bits(64, 1 << 41) == -1
+    assert lib.ls_amd_test_gtab_bits(10, 13) >= 3
