@@ -1741,10 +1741,13 @@ int ls_amd_plan_create(ls_amd_plan **out, ls_hs_operator const *op, ls_amd_dtype
         }
         pl->family = m == LS_AMD_MODE_PULL ? FAMILY_TILE_PULL : FAMILY_TILE;
         if (pl->family == FAMILY_TILE_PULL) {
-            /* LS_AMD_PULL_INDEXED=1: static {rep -> index} table + x[index] (two requests per far partner, no refresh)
-             * instead of the {rep -> x n(rep)} value table (one request, N random writes per matvec) */
+            /* Default: the INDEXED mode -- static {rep -> index} table + x[index] (two dependent requests per far partner,
+             * nothing rewritten per matvec).  Measured r3 (profiles/r3_indexed_ab_*): chain_36_symm 24.8 -> 20.4 ms,
+             * chain_40_symm 373.5 -> 323.0 ms per matvec against the {rep -> x n(rep)} value table (one request per far
+             * partner, but N random 16-byte writes per matvec: 2.8 / 42.5 ms), which stays as LS_AMD_PULL_INDEXED=0 and
+             * as the fallback for bases whose keys do not fit the 8-byte entries (lsk_gtab_bits). */
             char const *e = getenv("LS_AMD_PULL_INDEXED");
-            pl->idx_mode = e ? atoi(e) != 0 : 0;
+            pl->idx_mode = e ? atoi(e) != 0 : 1;
             if (pl->idx_mode && (counts[0] >= 0xffffffffLL || lsk_gtab_bits(op->basis->number_sites, counts[0], (int64_t)1 << 40) < 0)) pl->idx_mode = 0;
         }
     } else pl->family = FAMILY_TILE;

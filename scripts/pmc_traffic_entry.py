@@ -13,8 +13,9 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-DEVICE_KERNEL = {"staged": "k_chain_t", "tile-pull": "k_tile_pull", "direct-push": "k_direct", "direct-pull": "k_direct",
-                 "tile": "k_tile<"}
+DEVICE_KERNEL = {"staged": "k_chain_t", "indexed": "k_tile_pull_idx", "tile-pull": "k_tile_pull<", "direct-push": "k_direct",
+                 "direct-pull": "k_direct", "tile": "k_tile<"}
+SEEN = []  # kernel names the counters were read from
 
 
 def mean_counter(root, sub, counter, needle):
@@ -26,12 +27,14 @@ def mean_counter(root, sub, counter, needle):
         for kn, v in cur.execute(f"select {name_col}, value from counters_collection where counter_name = ?", (counter,)):
             if needle in kn:
                 vals.append(v)
+                if kn not in SEEN:
+                    SEEN.append(kn)
     return (sum(vals) / len(vals), len(vals)) if vals else (None, 0)
 
 
 def main():
     root, model, dtype, kname = sys.argv[1:5]
-    from bench import kernel_isa_sha, source_sha
+    from bench import kernel_instance_sha, kernel_isa_sha, source_sha
 
     needle = next(v for k, v in DEVICE_KERNEL.items() if k in kname)
     fetch, nf = mean_counter(root, "pmc_fetch", "FETCH_SIZE", needle)
@@ -49,6 +52,11 @@ def main():
     }
     if valu is not None:
         entry["valu_insts"] = valu
+    if len(SEEN) == 1:  # the instantiation that ran: the entry is tied to ITS machine code (bench.py prefers this)
+        inst = SEEN[0].split("(")[0].replace("void ", "").strip()
+        sha = kernel_instance_sha(inst)
+        if sha:
+            entry["instance"], entry["instance_isa_sha"] = inst, sha
     print(json.dumps({f"{model}/{dtype}/{kname}": entry}, indent=1))
 
 

@@ -83,7 +83,7 @@ def test_single_locale_matvec_f64(torch, name, mode):
     want = oracle_for(name).local_matvec(want_reps, x)
     got, pl = run_matvec(torch, D, h, reps, masks, x, 1, mode)
     if basis.hasPermutationSymmetries():
-        assert pl.kernel == ("tile" if mode == "push" else "tile-pull")
+        assert pl.kernel == ("tile" if mode == "push" else "tile-pull+indexed")
     else:
         assert pl.kernel.startswith(f"direct-{mode}")
     assert_close(got, want, name)
@@ -201,7 +201,7 @@ def test_indexed_pull_mode_single_locale(torch, monkeypatch, name, halo):
     assert pl.kernel == "tile-pull+indexed"
     assert_close(got, oracle_for(name).local_matvec(want_reps, x), name)
     got2, _ = run_matvec(torch, D, h, reps, masks, x, 1, "pull")  # second call: the table is reused, nothing is refreshed
-    assert np.array_equal(got, got2)
+    assert_close(got2, got, name)  # (not bit-identical: the per-tile LDS accumulation order is not fixed)
     xc = x + 1j * (rs.rand(len(want_reps)) - 0.5)
     gotc, plc = run_matvec(torch, D, h, reps, masks, xc, 1, "pull")
     assert plc.kernel == "tile-pull+indexed"
@@ -650,7 +650,7 @@ def test_chain_36_symm_full_size_properties(torch):
     v = D.fillRandom(r, 4, torch.float64)
     a, b, c = torch.empty_like(u), torch.zeros_like(u), torch.empty_like(u)
     pl = D.matrixVectorProduct(h, [u], [a], reps, mode="pull")
-    assert pl.kernel == "tile-pull"
+    assert pl.kernel.startswith("tile-pull")
     pl2 = D.matrixVectorProduct(h, [u], [b], reps, mode="push")
     assert pl2.kernel == "tile"
     scale = float(a.abs().max())

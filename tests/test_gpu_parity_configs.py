@@ -171,7 +171,7 @@ def test_chain_36_symm_eight_partitions_packets(torch):
     got = D.arrFromHashedToBlock(y8, masks)
     y1 = torch.empty_like(x_block)
     pl1 = D.matrixVectorProduct(h, [x_block], [y1], [r_block], mode="pull")
-    assert pl1.kernel == "tile-pull"
+    assert pl1.kernel == "tile-pull+indexed"
     scale = float(y1.abs().max())
     assert float((got - y1).abs().max()) <= 1e-12 * scale
     o = CO.COracle(M.model_from_config(cfg))
@@ -205,7 +205,7 @@ def test_chain_40_symm_properties_and_ground_state(torch):
     u = D.fillRandom(r, 3, torch.float64)
     a = torch.empty_like(u)
     pull = D.MatvecPlan(h, reps, torch.float64, mode="pull")
-    assert pull.kernel == "tile-pull"
+    assert pull.kernel == "tile-pull+indexed"
     pull.matvec([u], [a])
     rows = np.unique(np.concatenate([rs.randint(0, n, size=12000), np.arange(256), np.arange(n - 256, n)]))
     rows_t, want = oracle_rows(torch, o, r, rows, u, projected=True)
@@ -255,7 +255,7 @@ def test_chain_32_and_36_symm_complex_vectors(torch):
     from oracle import c_oracle as CO
     from oracle import model as M
 
-    for L, symm, kernel in ((32, False, "direct-pull+staged"), (36, True, "tile-pull")):
+    for L, symm, kernel in ((32, False, "direct-pull+staged"), (36, True, "tile-pull+indexed")):
         cfg = config.heisenberg_chain_config(L, symm=symm)
         basis, h = D.loadConfigFromDict(cfg, hamiltonian=True)
         reps, masks = D.enumerateStates(basis, 1)
