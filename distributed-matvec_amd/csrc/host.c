@@ -1156,6 +1156,11 @@ struct ls_amd_plan {
     /* tile map of the row kernels (lsk_tilemap in lsk.h) */
     lsk_tilemap tilemap;
     void *d_tilemap;
+    int has_sib;   /* block-aligned row kernel with sibling tiles (lsk_chain_sib): the ring / open chain on <= 32 sites, f64 */
+    lsk_sibplan sib;
+    void *d_sib_units, *d_sib_order, *d_sib_unrank, *d_sib_rank, *d_sib_tab;
+    int sib_ring;
+    double sib_cv;
     int has_chain; /* staged row kernel (lsk_chain) */
     int chain_cached;      /* leading non-adjacent exchange groups whose partner ranks are cached */
     void *d_chain_cache;   /* [chain_cached][count] u32, or u64 when chain_wide */
@@ -1526,6 +1531,141 @@ int64_t ls_amd_test_gtab_find(int L, int bbits, uint64_t const *entries, uint64_
     return lsk_test_gtab_find(t, entries, key);
 }
 
+/* ---- sibling-tile plan (lsk_sibplan, lsk.h): host-side tables ------------------------------------------------------------- */
+int lsk_sibplan_host(lsk_sibplan *sp, lsk_sibtab *tb, int L, int hw, int nl, int t, int64_t chunk, lsk_sib_unit **units_out,
+                     uint32_t **order_out, uint16_t **unrank_out, uint16_t **rank_out) {
+    memset(sp, 0, sizeof(*sp));
+    memset(tb, 0, sizeof(*tb));
+    *units_out = NULL; *order_out = NULL; *unrank_out = NULL; *rank_out = NULL;
+    if (L < 4 || L > 32 || hw < 1 || hw >= L || nl < 2 || nl > 16 || t < 1 || t > LSK_SIB_MAX_T || nl + t > L) return -1;
+    if (binom(L, hw) >= 0xffffffffULL) return -1;
+    int const nm = L - t - nl;
+    sp->L = L; sp->hw = hw; sp->nl = nl; sp->t = t;
+    /* nl-bit words grouped by weight */
+    uint16_t *unrank = (uint16_t *)malloc(sizeof(uint16_t) << nl), *rank = (uint16_t *)malloc(sizeof(uint16_t) << nl);
+    uint32_t off = 0;
+    for (int k = 0; k <= nl; ++k) {
+        tb->uoff[k] = off;
+        for (uint32_t w = 0; w < (1u << nl); ++w)
+            if (__builtin_popcount(w) == k) { rank[w] = (uint16_t)(off - tb->uoff[k]); unrank[off++] = (uint16_t)w; }
+    }
+    for (int k = nl + 1; k < 34; ++k) tb->uoff[k] = off;
+    /* t-bit words grouped by weight; rank contribution of their bits */
+    int cnt[LSK_SIB_MAX_T + 1];
+    memset(cnt, 0, sizeof(cnt));
+    for (uint32_t T = 0; T < (1u << t); ++T) {
+        int const j = __builtin_popcount(T);
+        int const s_ = cnt[j]++;
+        tb->sidx[T] = (uint8_t)s_;
+        tb->tlist[j][s_] = (uint8_t)T;
+        tb->nsib[j] = (uint32_t)(s_ + 1);
+        uint64_t r = 0;
+        int i = 0;
+        for (int q = 0; q < t; ++q)
+            if ((T >> q) & 1) { r += binom(L - t + q, (hw - j) + i + 1); ++i; }
+        tb->rtr[j][s_] = (uint32_t)r;
+    }
+    /* units (mid, jT) */
+    int64_t cap = (int64_t)(t + 1) << nm, n = 0;
+    lsk_sib_unit *units = (lsk_sib_unit *)malloc(sizeof(lsk_sib_unit) * (size_t)cap);
+    for (int jT = 0; jT <= t; ++jT)
+        for (uint32_t mid = 0; mid < (1u << nm); ++mid) {
+            int const kL = hw - jT - __builtin_popcount(mid);
+            if (kL < 0 || kL > nl) continue;
+            uint64_t rest[3] = {0, 0, 0}; /* kL, kL + 1, kL - 1 bits below */
+            int i = 0;
+            for (int q = 0; q < nm; ++q)
+                if ((mid >> q) & 1) {
+                    rest[0] += binom(nl + q, kL + i + 1);
+                    rest[1] += binom(nl + q, kL + 1 + i + 1);
+                    rest[2] += kL >= 1 ? binom(nl + q, kL - 1 + i + 1) : 0;
+                    ++i;
+                }
+            lsk_sib_unit *u = &units[n++];
+            u->base_rest = (uint32_t)rest[0]; u->ring_up = (uint32_t)rest[1]; u->ring_dn = (uint32_t)rest[2];
+            u->mid = mid << nl;
+            u->kL_jT = (uint32_t)kL | ((uint32_t)jT << 8);
+            int const rows = (int)(binom(nl, kL) * binom(t, jT));
+            if (rows > sp->max_rows) sp->max_rows = rows;
+        }
+    sp->n_units = n;
+    /* XCD lists: chunks of consecutive units dealt round-robin (consecutive units = neighbouring blocks of every sibling) */
+    if (chunk < 1) chunk = 1;
+    int64_t per[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int64_t u = 0; u < n; ++u) ++per[(u / chunk) % 8];
+    int64_t slots = 0;
+    for (int k = 0; k < 8; ++k) if (per[k] > slots) slots = per[k];
+    uint32_t *order = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(8 * slots > 0 ? 8 * slots : 1));
+    for (int64_t i = 0; i < 8 * slots; ++i) order[i] = 0xffffffffu;
+    memset(per, 0, sizeof(per));
+    for (int64_t u = 0; u < n; ++u) { int const k = (int)((u / chunk) % 8); order[k * slots + per[k]++] = (uint32_t)u; }
+    sp->slots_per_xcd = slots;
+    *units_out = units; *order_out = order; *unrank_out = unrank; *rank_out = rank;
+    return 0;
+}
+/* host-only test hook: the tables as plain arrays (release each with ls_amd_test_free); returns the number of units */
+int64_t ls_amd_test_sibplan(int L, int hw, int nl, int t, int64_t chunk, void **plan_struct, void **tables, void **units,
+                            uint32_t **order, uint16_t **unrank, uint16_t **rank) {
+    lsk_sibplan *sp = (lsk_sibplan *)malloc(sizeof(lsk_sibplan));
+    lsk_sibtab *tb = (lsk_sibtab *)malloc(sizeof(lsk_sibtab));
+    if (lsk_sibplan_host(sp, tb, L, hw, nl, t, chunk, (lsk_sib_unit **)units, order, unrank, rank) != 0) { free(sp); free(tb); return -1; }
+    *plan_struct = sp;
+    *tables = tb;
+    return sp->n_units;
+}
+
+/* Block-aligned row kernel with sibling tiles (k_chain_sib, lsk.h): f64 vectors, <= 32 sites, the full fixed-weight basis on
+ * one device, and the operator of the ring / open chain: ONE exchange run over all adjacent pairs plus, at most, the
+ * ring-closing pair (0, L - 1).  LS_AMD_SIB=0 keeps the staged kernel; LS_AMD_SIB_NL / LS_AMD_SIB_T / LS_AMD_SIB_CHUNK set the
+ * split (low bits, sibling bits) and the XCD dealing.  Returns 0 with pl->has_sib == 0 when the plan is not of that shape. */
+static int setup_sib(ls_amd_plan *pl, int64_t n) {
+    ls_hs_operator const *op = pl->op;
+    struct ls_amd_operator_ext const *ext = OEXT(op);
+    int const L = op->basis->number_sites, hw = BEXT(op->basis)->hamming_weight;
+    char const *e = getenv("LS_AMD_SIB");
+    if (e && atoi(e) == 0) return 0;
+    if (pl->cplx || L > 32 || L < 8 || hw < 1 || hw >= L || (uint64_t)n != binom(L, hw)) return 0;
+    if (ext->runs.n_runs != 1 || ext->runs.lo0[0] != 0 || ext->runs.cnt[0] != L - 1 || ext->runs.v_im[0] != 0.0) return 0;
+    int const extra = ext->n_groups - ext->runs.n_run_groups;
+    if (extra > 1) return 0;
+    if (extra == 1 && ext->groups[ext->runs.n_run_groups].x != (1ULL | (1ULL << (L - 1)))) return 0;
+    /* default split: 12 low bits (blocks of <= 924 rows), 5 sibling bits (<= 10 blocks = 74 KB of LDS: two blocks per CU);
+     * small bases (tests) shrink both */
+    int nl = 12, t = 5;
+    if (L < 24) { t = L >= 16 ? 4 : 3; nl = (L - t) < 8 ? (L - t) : 8; }
+    if ((e = getenv("LS_AMD_SIB_NL"))) nl = atoi(e);
+    if ((e = getenv("LS_AMD_SIB_T"))) t = atoi(e);
+    int64_t chunk = 32;
+    if ((e = getenv("LS_AMD_SIB_CHUNK"))) chunk = atoll(e);
+    lsk_sibtab tab;
+    lsk_sib_unit *units = NULL;
+    uint32_t *order = NULL;
+    uint16_t *unrank = NULL, *rank = NULL;
+    if (lsk_sibplan_host(&pl->sib, &tab, L, hw, nl, t, chunk, &units, &order, &unrank, &rank) != 0) return 0;
+    int rc = 0;
+    if (lsk_chain_sib_lds_bytes(pl->sib.max_rows) > 160 * 1024) rc = 1; /* not an error: the staged kernel takes it */
+    if (rc == 0 && (upload(&pl->d_sib_units, units, sizeof(lsk_sib_unit) * (size_t)pl->sib.n_units) != 0 ||
+                    upload(&pl->d_sib_order, order, sizeof(uint32_t) * (size_t)(8 * pl->sib.slots_per_xcd)) != 0 ||
+                    upload(&pl->d_sib_unrank, unrank, sizeof(uint16_t) << nl) != 0 || upload(&pl->d_sib_rank, rank, sizeof(uint16_t) << nl) != 0 ||
+                    upload(&pl->d_sib_tab, &tab, sizeof(tab)) != 0))
+        rc = -1;
+    free(units); free(order); free(unrank); free(rank);
+    if (rc != 0) {
+        void **bufs[] = {&pl->d_sib_units, &pl->d_sib_order, &pl->d_sib_unrank, &pl->d_sib_rank, &pl->d_sib_tab};
+        for (size_t i = 0; i < sizeof(bufs) / sizeof(bufs[0]); ++i) if (*bufs[i]) { lsk_free(*bufs[i]); *bufs[i] = NULL; }
+        return rc < 0 ? -1 : 0;
+    }
+    pl->sib.units = (lsk_sib_unit const *)pl->d_sib_units;
+    pl->sib.order = (uint32_t const *)pl->d_sib_order;
+    pl->sib.unrankL = (uint16_t const *)pl->d_sib_unrank;
+    pl->sib.rankL = (uint16_t const *)pl->d_sib_rank;
+    pl->sib.tab = (lsk_sibtab const *)pl->d_sib_tab;
+    pl->sib_ring = extra == 1;
+    pl->sib_cv = extra == 1 ? ext->groups[ext->runs.n_run_groups].v_re : 0.0;
+    pl->has_sib = 1;
+    return 0;
+}
+
 /* Staged row kernel (k_chain_t, lsk.h): pull, f64 or c128 vectors, <= 64 sites, the full fixed-weight basis without
  * symmetries, a real operator made of exchange runs plus at most two other exchange pairs.  LS_AMD_CHAIN=0 keeps k_direct. */
 static int chain_eligible(ls_amd_plan const *pl) {
@@ -1774,9 +1914,11 @@ int ls_amd_plan_create(ls_amd_plan **out, ls_hs_operator const *op, ls_amd_dtype
     if (pl->family == FAMILY_DIRECT_PULL || pl->family == FAMILY_DIRECT_PUSH) {
         int const combinadic = pl->parts[0].index.kind == LSK_INDEX_COMBINADIC;
         part_state *ps0 = &pl->parts[0];
-        if (pl->family == FAMILY_DIRECT_PULL && combinadic && chain_eligible(pl) &&
+        if (pl->family == FAMILY_DIRECT_PULL && combinadic && chain_eligible(pl) && OEXT(op)->n_diag > 0 &&
+            setup_sib(pl, ps0->count) != 0) { ls_amd_plan_destroy(pl); return -1; }
+        if (!pl->has_sib && pl->family == FAMILY_DIRECT_PULL && combinadic && chain_eligible(pl) &&
             setup_chain(pl, ps0->index, ps0->count, ps0->d_reps, stream) != 0) { ls_amd_plan_destroy(pl); return -1; }
-        if (!pl->has_chain && build_tilemap(pl, ps0->count, 256) != 0) { ls_amd_plan_destroy(pl); return -1; }
+        if (!pl->has_chain && !pl->has_sib && build_tilemap(pl, ps0->count, 256) != 0) { ls_amd_plan_destroy(pl); return -1; }
     }
     if (pl->family == FAMILY_TILE && my_partition < 0 && pl->send_capacity > 0) {
         if (lsk_malloc(&pl->d_send, (size_t)pl->send_capacity) != 0) { ls_amd_plan_destroy(pl); return dev_error(); }
@@ -1802,6 +1944,11 @@ void ls_amd_plan_destroy(ls_amd_plan *pl) {
     if (pl->d_row_gidx) lsk_free(pl->d_row_gidx);
     if (pl->d_norms_global) lsk_free(pl->d_norms_global);
     if (pl->d_tilemap) lsk_free(pl->d_tilemap);
+    if (pl->d_sib_units) lsk_free(pl->d_sib_units);
+    if (pl->d_sib_order) lsk_free(pl->d_sib_order);
+    if (pl->d_sib_unrank) lsk_free(pl->d_sib_unrank);
+    if (pl->d_sib_rank) lsk_free(pl->d_sib_rank);
+    if (pl->d_sib_tab) lsk_free(pl->d_sib_tab);
     if (pl->d_chain_cache) lsk_free(pl->d_chain_cache);
     if (pl->d_chain_rec) lsk_free(pl->d_chain_rec);
     if (pl->d_htab) lsk_free(pl->d_htab);
@@ -2019,7 +2166,7 @@ char const *ls_amd_plan_kernel_name(ls_amd_plan const *pl) {
     switch (pl->family) {
     case FAMILY_DIRECT_PUSH: return "direct-push";
     case FAMILY_DIRECT_PULL:
-        return pl->has_chain ? "direct-pull+staged" : "direct-pull";
+        return pl->has_sib ? "direct-pull+sibling" : pl->has_chain ? "direct-pull+staged" : "direct-pull";
     case FAMILY_TILE_PULL: return pl->idx_mode ? "tile-pull+indexed" : "tile-pull";
     case FAMILY_REPL_DIRECT:
         return pl->has_chain ? "replicated-direct-pull+staged" : "replicated-direct-pull";
@@ -2033,6 +2180,7 @@ int ls_amd_plan_packet_bytes(ls_amd_plan const *pl) { return pl->cplx ? 24 : 16;
  * plus one cached partner rank per cached pair; the generic row kernels read the 8-byte state; the projected pull kernel
  * the state and norm(alpha) */
 int ls_amd_plan_row_bytes(ls_amd_plan const *pl) {
+    if (pl->has_sib) return 0; /* state and partner ranks are computed, not read */
     if (pl->has_chain) {
         if (pl->d_chain_rec) return 8;
         int const narrow = pl->op->basis->number_sites <= 32 && !pl->chain_wide;
@@ -2176,7 +2324,9 @@ int ls_amd_matvec(ls_amd_plan *pl, void const *const *d_x, void *const *d_y, voi
         part_state *ps = &pl->parts[0];
         int const st = stage_begin(pl, ST_ROWS, stream);
         int slot = timing_begin(pl, stream);
-        if (pl->has_chain)
+        if (pl->has_sib)
+            DEV(lsk_chain_sib(pl->dop, pl->sib, ps->index.binom, pl->sib_ring, pl->sib_cv, d_x[0], d_y[0], stream));
+        else if (pl->has_chain)
             DEV(lsk_chain(pl->dop, pl->dbs, ps->index, pl->cplx, pl->chain_wide, pl->d_chain_rec != NULL, pl->tilemap, ps->count,
                           pl->d_chain_rec ? pl->d_chain_rec : ps->d_reps, 0, ps->count, d_x[0], d_y[0], pl->chain_cached,
                           pl->d_chain_cache, pl->chain_v[0], pl->chain_v[1], stream));

@@ -1290,6 +1290,212 @@ extern "C" int lsk_chain(lsk_operator op, lsk_basis bs, lsk_index ix, int cplx, 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Block-aligned row kernel with sibling tiles (lsk_sibplan, lsk.h) -- the Heisenberg-ring shape on <= 32 sites, f64.
+//
+// What bounds k_chain_t is its L2-miss traffic (53.5 GB on chain_32 at the rate of a plain copy), and half of that is the
+// far pairs: every tile re-reads, once per anti-aligned far pair, the tile of the partner high part from HBM.  Here a
+// work unit holds the blocks of ALL high parts that differ only inside the top t bits (same weight there: "siblings") in
+// LDS at once, so the pairs inside those t bits read LDS, and each x element of the unit is fetched once for all of them.
+// Blocks are the natural ones of the combinadic order (all words of one weight in the low nl bits under a fixed upper
+// part = C(nl, kL) consecutive rows): the pairs inside the low bits never leave the block, so there is no halo, and
+// neither the state (unrankL[row]) nor the ring partner's rank (rankL[word ^ 1] + a per-sibling constant) is read from a
+// per-row array: the kernel streams x and y and nothing else.
+// One block (512 threads) per unit; wave w walks the (sibling, 64-row chunk) items w, w + 8, ...; everything above the low
+// bits is uniform across an item, so the pairs >= nl are priced once per item, lane-parallel (lane l <-> pair nl + l), as
+// k_chain_t prices its far pairs.
+// ---------------------------------------------------------------------------------------------
+constexpr int kSibBlock = 512;
+constexpr int kSibFar = 12; // uniform-pair gathers in flight per row before the first wait
+constexpr int kSibBinomRows = 32;
+extern "C" int64_t lsk_chain_sib_lds_bytes(int max_rows) {
+    return (int64_t)sizeof(uint32_t) * (kSibBinomRows * LSK_BINOM_K + 2 * LSK_SIB_MAX_S + 64 + 2) + 8 * ((int64_t)max_rows + 2);
+}
+
+__global__ __launch_bounds__(kSibBlock) void k_chain_sib(lsk_runs runs, int n_diag, lsk_term const *__restrict__ diag, lsk_sibplan sp,
+                                                         uint32_t const *__restrict__ g_binom, int ring, double cv,
+                                                         double const *__restrict__ x, double *__restrict__ y) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t *s_binom = reinterpret_cast<uint32_t *>(smem);      // [32][LSK_BINOM_K] C(n, k), n < 32
+    uint32_t *s_base = s_binom + kSibBinomRows * LSK_BINOM_K;    // [S] rank of row 0 of sibling s
+    uint32_t *s_ring = s_base + LSK_SIB_MAX_S;                   // [S] rank of row 0 of the ring partner's block
+    uint32_t *s_sidx = s_ring + LSK_SIB_MAX_S;                   // [2^t] T -> sibling number (entries of other weights unused)
+    double *s_x = reinterpret_cast<double *>(s_sidx + 64 + 2);   // [S * nL + 1], last = 0.0
+    static_assert((kSibBinomRows * LSK_BINOM_K + 2 * LSK_SIB_MAX_S + 64 + 2) % 2 == 0, "s_x must be 8-byte aligned");
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t un = sp.order[(int64_t)(blockIdx.x & 7) * sp.slots_per_xcd + (blockIdx.x >> 3)];
+    if (un == 0xffffffffu) return; // block-uniform
+    lsk_sibtab const *__restrict__ tb = sp.tab;
+    const lsk_sib_unit U = sp.units[un];
+    const int kL = (int)(U.kL_jT & 0xff), jT = (int)(U.kL_jT >> 8);
+    const uint32_t uoff = tb->uoff[kL];
+    const int nL = (int)(tb->uoff[kL + 1] - uoff);
+    const int nS = (int)tb->nsib[jT];
+    const int L = sp.L, t = sp.t, nl = sp.nl, hw = sp.hw;
+    const int tshift = L - t;
+    {
+        constexpr int N16 = kSibBinomRows * LSK_BINOM_K * (int)sizeof(uint32_t) / 16;
+        uint4 const *src = reinterpret_cast<uint4 const *>(g_binom);
+        uint4 *dst = reinterpret_cast<uint4 *>(s_binom);
+        for (int k = tid; k < N16; k += kSibBlock) dst[k] = src[k];
+    }
+    if (tid < nS) {
+        const uint32_t T = tb->tlist[jT][tid];
+        s_base[tid] = tb->rtr[jT][tid] + U.base_rest;
+        // ring-closing pair (0, L - 1): the partner has T' = T ^ top bit (one sibling class up or down), the same mid bits and
+        // Lw ^ 1; its block starts at rtr[jT'][T'] + the mid bits' contribution with one more / one fewer bit below them
+        const uint32_t top = (T >> (t - 1)) & 1u;
+        const uint32_t T2 = T ^ (1u << (t - 1));
+        const int j2 = top ? jT - 1 : jT + 1;
+        s_ring[tid] = tb->rtr[j2][tb->sidx[T2]] + (top ? U.ring_up : U.ring_dn);
+    }
+    if (tid < (1 << t)) s_sidx[tid] = tb->sidx[tid];
+    __syncthreads();
+    const int ZERO = nS * nL;
+    for (int s = 0; s < nS; ++s) {
+        double const *__restrict__ xb = x + s_base[s];
+        for (int r = tid; r < nL; r += kSibBlock) s_x[s * nL + r] = xb[r];
+    }
+    if (tid == 0) s_x[ZERO] = 0.0;
+    __syncthreads();
+
+    const double v = runs.v_re[0];
+    const int nchunk = (nL + 63) >> 6;
+    const int n_glob = tshift - nl; // pairs nl .. L - t - 1 gather from global memory, pairs L - t .. L - 2 read a sibling
+    int s = 0, c = wave;
+    while (c >= nchunk) { c -= nchunk; ++s; }
+#pragma unroll 1
+    for (; s < nS;) {
+        const int r0 = c * 64 + lane;
+        const bool ghost = r0 >= nL; // lanes past the end of the block stay active as copies of its last row, store nothing
+        const int r = ghost ? nL - 1 : r0;
+        const uint32_t Lw = sp.unrankL[uoff + r];
+        const uint32_t T = __builtin_amdgcn_readfirstlane((uint32_t)tb->tlist[jT][s]);
+        const uint32_t a = (T << tshift) | U.mid | Lw;
+        const uint32_t ig = s_base[s] + (uint32_t)r;
+        const int jr = s * nL + r;
+        // ---- ring pair, first hop: rank of the partner's low word (a 2^nl-entry table that lives in L1 / L2) ------------
+        const uint32_t top = (T >> (t - 1)) & 1u;
+        const bool ring_act = ring && ((Lw & 1u) != top);
+        uint32_t ring_rank = ig;
+        if (ring_act) ring_rank = s_ring[s] + (uint32_t)sp.rankL[Lw ^ 1u];
+        // ---- pairs >= nl: uniform across the item; lane l prices pair nl + l ------------------------------------------
+        const uint32_t a_hi = (T << tshift) | U.mid; // the item's state without its low word
+        unsigned long long m;
+        uint32_t off;
+        int sib = 0;
+        {
+            const int p = nl + lane;
+            const bool in_run = p <= L - 2;
+            const int ps = in_run ? p : 0;
+            const uint32_t hi = a_hi >> ps;
+            const bool bit = hi & 1u;
+            const bool act = in_run && (((hi >> 1) & 1u) != (uint32_t)bit);
+            const int kk = hw - __popc(hi); // set bits below p
+            const uint32_t d = s_binom[ps * LSK_BINOM_K + (kk < 0 ? 0 : kk)];
+            off = bit ? d : (uint32_t)(0 - d);
+            m = __builtin_amdgcn_ballot_w64(act);
+            if (p >= tshift && in_run) sib = (int)s_sidx[T ^ (3u << (p - tshift))] * nL; // LDS base of the partner sibling
+        }
+        unsigned long long m_glob = m & ((1ULL << n_glob) - 1ULL);
+        unsigned long long m_sib = m >> n_glob;
+        double xv[kSibFar];
+#pragma unroll
+        for (int u = 0; u < kSibFar; ++u) {
+            xv[u] = 0.0;
+            if (m_glob) {
+                const int l = __builtin_ctzll(m_glob);
+                m_glob &= m_glob - 1;
+                xv[u] = x[(uint32_t)(ig + (uint32_t)__builtin_amdgcn_readlane((int)off, l))];
+            }
+        }
+        // ---- the pair that straddles Lw | mid: per lane, a near partner (<= C(nl - 1, .) rows away) ----------------------
+        const uint32_t tdiff = a ^ (a >> 1);
+        int k = __popc(Lw & ((1u << (nl - 1)) - 1u));
+        double xc;
+        {
+            const int lo = nl - 1;
+            const bool bit = (a >> lo) & 1u, act = (tdiff >> lo) & 1u;
+            const uint32_t d = s_binom[lo * LSK_BINOM_K + k];
+            const uint32_t idx = bit ? ig + d : ig - d;
+            xc = x[act ? idx : ig];
+            xc = act ? xc : 0.0;
+        }
+        const double g_ring = x[ring_rank];
+        // ---- diagonal and the pairs inside the low word: LDS, no halo ------------------------------------------------------
+        double dr, di;
+        diag_coeff<uint32_t, true>(runs, n_diag, diag, a, dr, di);
+        double acc = dr * s_x[jr];
+        double near = 0.0;
+        k = 0;
+#pragma unroll 4
+        for (int lo = 0; lo < nl - 1; ++lo) {
+            const bool bit = (a >> lo) & 1u, act = (tdiff >> lo) & 1u;
+            const int d = (int)s_binom[lo * LSK_BINOM_K + k];
+            k += bit ? 1 : 0;
+            const int j = bit ? jr + d : jr - d;
+            near += s_x[act ? j : ZERO];
+        }
+        // ---- sibling pairs: the partner block is in LDS at the same row ---------------------------------------------------
+        while (m_sib) {
+            const int l = __builtin_ctzll(m_sib);
+            m_sib &= m_sib - 1;
+            near += s_x[__builtin_amdgcn_readlane(sib, l + n_glob) + r];
+        }
+        near += xc;
+#pragma unroll
+        for (int u = 0; u < kSibFar; ++u) near += xv[u];
+        while (m_glob) { // more than kSibFar anti-aligned global pairs
+            double xw[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                xw[u] = 0.0;
+                if (m_glob) {
+                    const int l = __builtin_ctzll(m_glob);
+                    m_glob &= m_glob - 1;
+                    xw[u] = x[(uint32_t)(ig + (uint32_t)__builtin_amdgcn_readlane((int)off, l))];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) near += xw[u];
+        }
+        acc = fma(v, near, acc);
+        acc = fma(ring_act ? cv : 0.0, g_ring, acc);
+        if (!ghost) __builtin_nontemporal_store(acc, y + ig);
+        c += kSibBlock / 64;
+        while (c >= nchunk && s < nS) { c -= nchunk; ++s; }
+    }
+}
+
+// binomial table as u32 (ranks < 2^32): shared with the staged kernel
+template <typename R> static R const *chain_binom(uint64_t const *g_binom, hipStream_t stream);
+extern "C" int lsk_chain_sib(lsk_operator op, lsk_sibplan sp, uint64_t const *g_binom, int ring, double cv, void const *x, void *y,
+                             void *stream) {
+    if (sp.n_units == 0 || sp.slots_per_xcd == 0) return 0;
+    if (op.runs.n_runs != 1 || op.runs.lo0[0] != 0 || op.runs.cnt[0] != sp.L - 1 || sp.L > 32) {
+        snprintf(g_err, sizeof(g_err), "lsk_chain_sib: the operator is not one exchange run over all adjacent pairs of <= 32 sites");
+        return -1;
+    }
+    const int64_t lds = lsk_chain_sib_lds_bytes(sp.max_rows);
+    if (lds > 160 * 1024) { snprintf(g_err, sizeof(g_err), "lsk_chain_sib: a unit needs %lld bytes of LDS", (long long)lds); return -1; }
+    static std::mutex lock;
+    static int64_t configured = 0;
+    {
+        std::lock_guard<std::mutex> guard(lock);
+        if (lds > configured) {
+            LSK_CHECK(hipFuncSetAttribute((void const *)k_chain_sib, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            configured = lds;
+        }
+    }
+    uint32_t const *binom_r = chain_binom<uint32_t>(g_binom, (hipStream_t)stream);
+    if (!binom_r) { snprintf(g_err, sizeof(g_err), "lsk_chain_sib: no memory for the narrow binomial table"); return -1; }
+    hipLaunchKernelGGL(k_chain_sib, dim3((unsigned)(8 * sp.slots_per_xcd)), dim3(kSibBlock), (size_t)lds, (hipStream_t)stream, op.runs,
+                       op.n_diag, op.diag, sp, binom_r, ring, cv, (double const *)x, (double *)y);
+    LSK_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Staged ("tile") kernel: symmetry projection and/or hash-partitioned output.
 // A 256-row tile expands kGC flip-mask groups at a time into an LDS term list (stage A, K2), the
 // list is then processed densely, one packet per lane (stage B): K3/K4 projection, K5 owner hash,

@@ -148,6 +148,56 @@ int lsk_chain_tile_rows(int cplx);
 int lsk_chain(lsk_operator op, lsk_basis bs, lsk_index ix, int cplx, int wide_ranks, int fused_records, lsk_tilemap tm,
               int64_t n, uint64_t const *reps, int64_t row0, int64_t n_x, void const *x, void *y, int n_cached,
               void const *cache, double cv0, double cv1, void *stream);
+/* ---- block-aligned row kernel with sibling tiles (k_chain_sib): the Heisenberg-ring shape on <= 32 sites ------------------
+ * A state of the full fixed-weight basis is T | mid | Lw: Lw = the low `nl` bits, T = the top `t` bits, mid the rest.  In the
+ * ascending (combinadic) order all Lw of one weight kL under fixed (T, mid) are CONTIGUOUS rows -- a block of C(nl, kL)
+ * rows -- and rank = rtr[jT][T] + base_rest(mid, kL) + rankL(Lw), jT = popcount(T), kL = weight - jT - popcount(mid).
+ *   - exchanges inside Lw (pairs lo < nl - 1) stay inside the block: LDS reads with NO halo;
+ *   - exchanges inside T (pairs >= L - t) map a block onto the block of a SIBLING T' of the same weight at the same
+ *     offset: a work unit = (mid, jT) holds the blocks of all C(t, jT) siblings in LDS, so those pairs are LDS reads too
+ *     and every x element of the unit is fetched from HBM once for all of them (the far pairs are what the staged
+ *     kernel re-reads from HBM: 27 of its 53 GB on chain_32);
+ *   - everything else (the pair that straddles Lw | mid per lane, the pairs inside mid and the one that straddles
+ *     mid | T wave-uniformly, the ring-closing pair through rankL) gathers from global memory;
+ *   - the state is reconstructed (unrankL), the ring partner's rank computed (rankL): no per-row plan data is streamed,
+ *     compulsory traffic = x + y = 2 w bytes per row. */
+typedef struct lsk_sib_unit {
+    uint32_t base_rest; /* rank contribution of the mid bits with kL set bits below them */
+    uint32_t mid;       /* the mid bits in place (mid << nl) */
+    uint32_t ring_up;   /* the same contribution with kL + 1 bits below: rows whose top bit moves to bit 0 */
+    uint32_t ring_dn;   /* ... with kL - 1 bits below: rows whose bit 0 moves to the top */
+    uint32_t kL_jT;     /* kL | jT << 8 */
+} lsk_sib_unit;
+#define LSK_SIB_MAX_T 6
+#define LSK_SIB_MAX_S 20 /* C(6, 3) */
+typedef struct lsk_sibtab { /* small tables, read through a device pointer */
+    uint32_t uoff[34];            /* class kL occupies unrankL[uoff[kL], uoff[kL + 1]) */
+    uint32_t nsib[LSK_SIB_MAX_T + 1];              /* C(t, jT) */
+    uint32_t rtr[LSK_SIB_MAX_T + 1][LSK_SIB_MAX_S];  /* [jT][s] -> rank contribution of the bits of T (hw - jT bits below) */
+    uint8_t tlist[LSK_SIB_MAX_T + 1][LSK_SIB_MAX_S]; /* [jT][s] -> T */
+    uint8_t sidx[1 << LSK_SIB_MAX_T];              /* T -> its number among the t-bit words of the same weight */
+} lsk_sibtab;
+typedef struct lsk_sibplan {
+    int L, hw, nl, t;
+    int max_rows;                 /* largest unit: siblings * block rows (sizes the LDS window) */
+    int64_t n_units, slots_per_xcd;
+    lsk_sib_unit const *units;    /* device [n_units] */
+    uint32_t const *order;        /* device [8 * slots_per_xcd]: per-XCD lists of unit numbers, 0xffffffff = empty slot */
+    uint16_t const *unrankL;      /* device [2^nl]: the nl-bit words grouped by weight, ascending inside a weight */
+    uint16_t const *rankL;        /* device [2^nl]: position of a word inside its weight class */
+    lsk_sibtab const *tab;        /* device */
+} lsk_sibplan;
+/* host-side construction of the tables above (plain malloc'ed arrays in *units / *order / *unrank / *rank); chunk = units per
+ * round-robin chunk of the XCD lists.  Returns 0, or -1 when the shape is not admissible (ranks beyond 32 bits, ...). */
+int lsk_sibplan_host(lsk_sibplan *sp, lsk_sibtab *tab, int L, int hw, int nl, int t, int64_t chunk, lsk_sib_unit **units,
+                     uint32_t **order, uint16_t **unrank, uint16_t **rank);
+/* y = H x for the ring / open chain: one exchange run over all adjacent pairs (amplitude v), the ring-closing pair (0, L - 1)
+ * with amplitude cv (ring == 0: none), the diagonal through op.runs / op.diag.  x, y: n = C(L, hw) f64 elements. */
+int lsk_chain_sib(lsk_operator op, lsk_sibplan sp, uint64_t const *g_binom, int ring, double cv, void const *x, void *y,
+                  void *stream);
+/* bytes of LDS one block of k_chain_sib needs for a plan with `max_rows` (the host checks it against the 160 KB of a CU) */
+int64_t lsk_chain_sib_lds_bytes(int max_rows);
+
 /* fused_records != 0 (32-bit states and ranks): `reps` is out[] of lsk_chain_pack -- state | partner rank of the first
  * cached pair << 32 (cache == NULL: no cached pair) -- and `cache` only holds a second cached pair at cache + n */
 int lsk_chain_pack(int64_t n, uint64_t const *reps, void const *cache, uint64_t *out, void *stream);

@@ -280,6 +280,13 @@ int ls_amd_test_window_find(uint64_t const *reps, int n, uint64_t key);
 int ls_amd_test_gtab_bits(int L, int64_t n);
 int ls_amd_test_gtab_build(int L, int bbits, int64_t n, uint64_t const *reps, uint32_t const *payload, uint64_t **entries);
 int64_t ls_amd_test_gtab_find(int L, int bbits, uint64_t const *entries, uint64_t key);
+/* Host-only test hook: the plan of the block-aligned sibling-tile row kernel (distributed-matvec_amd/csrc/lsk.h: lsk_sibplan)
+ * for the full basis of `hw` set bits on L <= 32 sites split into T (top t bits) | mid | Lw (low nl bits).  Returns the
+ * number of work units (< 0: shape not admissible) and malloc'ed arrays: the lsk_sibplan struct itself, its small tables (lsk_sibtab), the units
+ * (5 x uint32 each), the 8 XCD lists of unit numbers, unrankL / rankL of the nl-bit words (release each with
+ * ls_amd_test_free). */
+int64_t ls_amd_test_sibplan(int L, int hw, int nl, int t, int64_t chunk, void **plan_struct, void **tables, void **units,
+                            uint32_t **order, uint16_t **unrank, uint16_t **rank);
 /* byte offsets of commInfo / globalSumReal_type inside primme_params as the PRIMME callbacks read them (ls_chpl.h) */
 int ls_amd_test_primme_comminfo_offset(void);
 int ls_amd_test_primme_sumtype_offset(void);

@@ -505,3 +505,74 @@ def test_static_index_table_shapes():
     assert lib.ls_amd_test_gtab_bits(64, 1000) == -1  # ... and does not beyond 1 TiB: those plans keep the value table
     assert lib.ls_amd_test_gtab_bits(64, 1 << 41) == -1
     assert lib.ls_amd_test_gtab_bits(10, 13) >= 3
+
+
+class _SibPlan(C.Structure):  # lsk_sibplan (csrc/lsk.h)
+    _fields_ = [("L", C.c_int), ("hw", C.c_int), ("nl", C.c_int), ("t", C.c_int), ("max_rows", C.c_int),
+                ("n_units", C.c_int64), ("slots_per_xcd", C.c_int64), ("units", C.c_void_p), ("order", C.c_void_p),
+                ("unrankL", C.c_void_p), ("rankL", C.c_void_p), ("tab", C.c_void_p)]
+
+
+class _SibTab(C.Structure):  # lsk_sibtab
+    _fields_ = [("uoff", C.c_uint32 * 34), ("nsib", C.c_uint32 * 7), ("rtr", (C.c_uint32 * 20) * 7),
+                ("tlist", (C.c_uint8 * 20) * 7), ("sidx", C.c_uint8 * 64)]
+
+
+@pytest.mark.parametrize("L,hw,nl,t,chunk", [(12, 6, 5, 3, 4), (16, 8, 6, 4, 7), (16, 5, 7, 5, 1), (20, 10, 8, 5, 16), (14, 7, 4, 6, 3)])
+def test_sibling_tile_plan_tiles_the_basis(L, hw, nl, t, chunk):
+    """lsk_sibplan: state = T | mid | Lw.  Every state of the full fixed-weight basis belongs to exactly one (unit, sibling,
+    row); its combinadic rank is rtr[jT][T] + base_rest + rankL[Lw]; the rows of one block are contiguous and ascending in
+    Lw; the ring-closing partner's rank follows from ring_up / ring_dn; the XCD lists hold every unit once."""
+    import math
+
+    lib = _lib.load()
+    ps, pt, pu = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    po, pun, prk = C.POINTER(C.c_uint32)(), C.POINTER(C.c_uint16)(), C.POINTER(C.c_uint16)()
+    n_units = lib.ls_amd_test_sibplan(L, hw, nl, t, chunk, C.byref(ps), C.byref(pt), C.byref(pu), C.byref(po), C.byref(pun), C.byref(prk))
+    assert n_units > 0
+    try:
+        sp = _SibPlan.from_address(ps.value)
+        tb = _SibTab.from_address(pt.value)
+        assert [tb.nsib[j] for j in range(t + 1)] == [math.comb(t, j) for j in range(t + 1)]
+        units = np.ctypeslib.as_array(C.cast(pu, C.POINTER(C.c_uint32)), shape=(n_units, 5)).copy()
+        order = np.ctypeslib.as_array(po, shape=(8 * sp.slots_per_xcd,)).copy()
+        unrank = np.ctypeslib.as_array(pun, shape=(1 << nl,)).copy()
+        rankl = np.ctypeslib.as_array(prk, shape=(1 << nl,)).copy()
+        assert (sp.L, sp.hw, sp.nl, sp.t) == (L, hw, nl, t)
+        live = order[order != 0xFFFFFFFF]
+        assert sorted(live.tolist()) == list(range(n_units))
+        for k in range(8):  # chunked dealing: list k holds the chunks k, k + 8, ...
+            lst = order[k * sp.slots_per_xcd:(k + 1) * sp.slots_per_xcd]
+            lst = lst[lst != 0xFFFFFFFF]
+            assert all(((int(u) // chunk) % 8) == k for u in lst) and np.all(np.diff(lst.astype(np.int64)) > 0)
+        states = _fixed_weight_states(L, hw)
+        rank_of = {int(a): i for i, a in enumerate(states)}
+        unit_of = {(int(u[1]), int(u[4]) >> 8): i for i, u in enumerate(units)}
+        assert len(unit_of) == n_units
+        lmask, tshift = (1 << nl) - 1, L - t
+        seen = np.zeros(len(states), dtype=np.int32)
+        for a in states.tolist():
+            T, lw = a >> tshift, a & lmask
+            mid_in_place = a & (((1 << tshift) - 1) & ~lmask)
+            jT, kL = bin(T).count("1"), bin(lw).count("1")
+            u = units[unit_of[(mid_in_place, jT)]]
+            assert int(u[4]) & 0xFF == kL
+            s_ = tb.sidx[T]
+            assert tb.tlist[jT][s_] == T
+            r = int(rankl[lw])
+            assert int(unrank[tb.uoff[kL] + r]) == lw and tb.uoff[kL + 1] - tb.uoff[kL] == math.comb(nl, kL)
+            rk = tb.rtr[jT][s_] + int(u[0]) + r
+            assert rk == rank_of[a]
+            seen[rk] += 1
+            # ring-closing pair (0, L - 1): partner T' = T ^ top, Lw' = Lw ^ 1, same mid
+            top = (a >> (L - 1)) & 1
+            if top != (a & 1):
+                b = a ^ (1 | (1 << (L - 1)))
+                T2, lw2 = b >> tshift, b & lmask
+                rest = int(u[2]) if top else int(u[3])  # the top bit came down: kL + 1 bits below mid; else kL - 1
+                assert tb.rtr[bin(T2).count("1")][tb.sidx[T2]] + rest + int(rankl[lw2]) == rank_of[b]
+        assert np.all(seen == 1)
+        assert sp.max_rows == max(math.comb(nl, int(u[4]) & 0xFF) * math.comb(t, int(u[4]) >> 8) for u in units)
+    finally:
+        for ptr in (ps, pt, pu, po, pun, prk):
+            lib.ls_amd_test_free(ptr)
