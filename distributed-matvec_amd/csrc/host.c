@@ -1587,6 +1587,7 @@ int lsk_sibplan_host(lsk_sibplan *sp, lsk_sibtab *tb, int L, int hw, int nl, int
             u->kL_jT = (uint32_t)kL | ((uint32_t)jT << 8);
             int const rows = (int)(binom(nl, kL) * binom(t, jT));
             if (rows > sp->max_rows) sp->max_rows = rows;
+            if ((int)binom(nl, kL) > sp->max_block) sp->max_block = (int)binom(nl, kL);
         }
     sp->n_units = n;
     /* XCD lists: chunks of consecutive units dealt round-robin (consecutive units = neighbouring blocks of every sibling) */
@@ -1643,7 +1644,7 @@ static int setup_sib(ls_amd_plan *pl, int64_t n) {
     uint16_t *unrank = NULL, *rank = NULL;
     if (lsk_sibplan_host(&pl->sib, &tab, L, hw, nl, t, chunk, &units, &order, &unrank, &rank) != 0) return 0;
     int rc = 0;
-    if (lsk_chain_sib_lds_bytes(pl->sib.max_rows) > 160 * 1024) rc = 1; /* not an error: the staged kernel takes it */
+    if (lsk_chain_sib_lds_bytes(pl->sib.max_rows, pl->sib.max_block) > 160 * 1024) rc = 1; /* not an error: the staged kernel takes it */
     if (rc == 0 && (upload(&pl->d_sib_units, units, sizeof(lsk_sib_unit) * (size_t)pl->sib.n_units) != 0 ||
                     upload(&pl->d_sib_order, order, sizeof(uint32_t) * (size_t)(8 * pl->sib.slots_per_xcd)) != 0 ||
                     upload(&pl->d_sib_unrank, unrank, sizeof(uint16_t) << nl) != 0 || upload(&pl->d_sib_rank, rank, sizeof(uint16_t) << nl) != 0 ||

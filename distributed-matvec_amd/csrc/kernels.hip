@@ -1304,14 +1304,15 @@ extern "C" int lsk_chain(lsk_operator op, lsk_basis bs, lsk_index ix, int cplx, 
 // bits is uniform across an item, so the pairs >= nl are priced once per item, lane-parallel (lane l <-> pair nl + l), as
 // k_chain_t prices its far pairs.
 // ---------------------------------------------------------------------------------------------
-constexpr int kSibBlock = 512;
+constexpr int kSibMaxBlock = 1024;
 constexpr int kSibFar = 12; // uniform-pair gathers in flight per row before the first wait
 constexpr int kSibBinomRows = 32;
-extern "C" int64_t lsk_chain_sib_lds_bytes(int max_rows) {
-    return (int64_t)sizeof(uint32_t) * (kSibBinomRows * LSK_BINOM_K + 2 * LSK_SIB_MAX_S + 64 + 2) + 8 * ((int64_t)max_rows + 2);
+constexpr int kSibHead = kSibBinomRows * LSK_BINOM_K + 2 * LSK_SIB_MAX_S + 64; // u32 words in front of the unrank slice
+extern "C" int64_t lsk_chain_sib_lds_bytes(int max_rows, int max_block) {
+    return (int64_t)sizeof(uint32_t) * kSibHead + 2 * (((int64_t)max_block + 7) & ~(int64_t)3) + 8 * ((int64_t)max_rows + 2);
 }
 
-__global__ __launch_bounds__(kSibBlock) void k_chain_sib(lsk_runs runs, int n_diag, lsk_term const *__restrict__ diag, lsk_sibplan sp,
+__global__ __launch_bounds__(kSibMaxBlock) void k_chain_sib(lsk_runs runs, int n_diag, lsk_term const *__restrict__ diag, lsk_sibplan sp,
                                                          uint32_t const *__restrict__ g_binom, int ring, double cv,
                                                          double const *__restrict__ x, double *__restrict__ y) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1319,10 +1320,12 @@ __global__ __launch_bounds__(kSibBlock) void k_chain_sib(lsk_runs runs, int n_di
     uint32_t *s_base = s_binom + kSibBinomRows * LSK_BINOM_K;    // [S] rank of row 0 of sibling s
     uint32_t *s_ring = s_base + LSK_SIB_MAX_S;                   // [S] rank of row 0 of the ring partner's block
     uint32_t *s_sidx = s_ring + LSK_SIB_MAX_S;                   // [2^t] T -> sibling number (entries of other weights unused)
-    double *s_x = reinterpret_cast<double *>(s_sidx + 64 + 2);   // [S * nL + 1], last = 0.0
-    static_assert((kSibBinomRows * LSK_BINOM_K + 2 * LSK_SIB_MAX_S + 64 + 2) % 2 == 0, "s_x must be 8-byte aligned");
+    uint16_t *s_unr = reinterpret_cast<uint16_t *>(s_sidx + 64); // [nL] the low words of this unit's weight class, ascending
+    double *s_x = reinterpret_cast<double *>(s_unr + ((sp.max_block + 7) & ~3)); // [S * nL + 1], last = 0.0
+    static_assert(kSibHead % 2 == 0, "s_x must be 8-byte aligned");
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nthreads = blockDim.x;
     const uint32_t un = sp.order[(int64_t)(blockIdx.x & 7) * sp.slots_per_xcd + (blockIdx.x >> 3)];
     if (un == 0xffffffffu) return; // block-uniform
     lsk_sibtab const *__restrict__ tb = sp.tab;
@@ -1337,8 +1340,9 @@ __global__ __launch_bounds__(kSibBlock) void k_chain_sib(lsk_runs runs, int n_di
         constexpr int N16 = kSibBinomRows * LSK_BINOM_K * (int)sizeof(uint32_t) / 16;
         uint4 const *src = reinterpret_cast<uint4 const *>(g_binom);
         uint4 *dst = reinterpret_cast<uint4 *>(s_binom);
-        for (int k = tid; k < N16; k += kSibBlock) dst[k] = src[k];
+        for (int k = tid; k < N16; k += nthreads) dst[k] = src[k];
     }
+    for (int r = tid; r < nL; r += nthreads) s_unr[r] = sp.unrankL[uoff + r];
     if (tid < nS) {
         const uint32_t T = tb->tlist[jT][tid];
         s_base[tid] = tb->rtr[jT][tid] + U.base_rest;
@@ -1354,7 +1358,7 @@ __global__ __launch_bounds__(kSibBlock) void k_chain_sib(lsk_runs runs, int n_di
     const int ZERO = nS * nL;
     for (int s = 0; s < nS; ++s) {
         double const *__restrict__ xb = x + s_base[s];
-        for (int r = tid; r < nL; r += kSibBlock) s_x[s * nL + r] = xb[r];
+        for (int r = tid; r < nL; r += nthreads) s_x[s * nL + r] = xb[r];
     }
     if (tid == 0) s_x[ZERO] = 0.0;
     __syncthreads();
@@ -1362,23 +1366,35 @@ __global__ __launch_bounds__(kSibBlock) void k_chain_sib(lsk_runs runs, int n_di
     const double v = runs.v_re[0];
     const int nchunk = (nL + 63) >> 6;
     const int n_glob = tshift - nl; // pairs nl .. L - t - 1 gather from global memory, pairs L - t .. L - 2 read a sibling
+    const int nwaves = nthreads >> 6;
     int s = 0, c = wave;
     while (c >= nchunk) { c -= nchunk; ++s; }
+    // ring pair, first hop: rank of the partner's low word -- a 2^nl-entry table in L1 / L2, requested one item ahead
+    uint32_t rk_next = 0;
+    if (ring && s < nS) {
+        const int rn = c * 64 + lane;
+        rk_next = sp.rankL[(uint32_t)s_unr[rn < nL ? rn : nL - 1] ^ 1u];
+    }
 #pragma unroll 1
     for (; s < nS;) {
         const int r0 = c * 64 + lane;
         const bool ghost = r0 >= nL; // lanes past the end of the block stay active as copies of its last row, store nothing
         const int r = ghost ? nL - 1 : r0;
-        const uint32_t Lw = sp.unrankL[uoff + r];
+        const uint32_t Lw = s_unr[r];
         const uint32_t T = __builtin_amdgcn_readfirstlane((uint32_t)tb->tlist[jT][s]);
         const uint32_t a = (T << tshift) | U.mid | Lw;
         const uint32_t ig = s_base[s] + (uint32_t)r;
         const int jr = s * nL + r;
-        // ---- ring pair, first hop: rank of the partner's low word (a 2^nl-entry table that lives in L1 / L2) ------------
         const uint32_t top = (T >> (t - 1)) & 1u;
         const bool ring_act = ring && ((Lw & 1u) != top);
-        uint32_t ring_rank = ig;
-        if (ring_act) ring_rank = s_ring[s] + (uint32_t)sp.rankL[Lw ^ 1u];
+        const uint32_t ring_rank = ring_act ? s_ring[s] + rk_next : ig;
+        // the item after this one (same wave)
+        int s_n = s, c_n = c + nwaves;
+        while (c_n >= nchunk && s_n < nS) { c_n -= nchunk; ++s_n; }
+        if (ring && s_n < nS) {
+            const int rn = c_n * 64 + lane;
+            rk_next = sp.rankL[(uint32_t)s_unr[rn < nL ? rn : nL - 1] ^ 1u];
+        }
         // ---- pairs >= nl: uniform across the item; lane l prices pair nl + l ------------------------------------------
         const uint32_t a_hi = (T << tshift) | U.mid; // the item's state without its low word
         unsigned long long m;
@@ -1462,8 +1478,8 @@ __global__ __launch_bounds__(kSibBlock) void k_chain_sib(lsk_runs runs, int n_di
         acc = fma(v, near, acc);
         acc = fma(ring_act ? cv : 0.0, g_ring, acc);
         if (!ghost) __builtin_nontemporal_store(acc, y + ig);
-        c += kSibBlock / 64;
-        while (c >= nchunk && s < nS) { c -= nchunk; ++s; }
+        s = s_n;
+        c = c_n;
     }
 }
 
@@ -1476,7 +1492,7 @@ extern "C" int lsk_chain_sib(lsk_operator op, lsk_sibplan sp, uint64_t const *g_
         snprintf(g_err, sizeof(g_err), "lsk_chain_sib: the operator is not one exchange run over all adjacent pairs of <= 32 sites");
         return -1;
     }
-    const int64_t lds = lsk_chain_sib_lds_bytes(sp.max_rows);
+    const int64_t lds = lsk_chain_sib_lds_bytes(sp.max_rows, sp.max_block);
     if (lds > 160 * 1024) { snprintf(g_err, sizeof(g_err), "lsk_chain_sib: a unit needs %lld bytes of LDS", (long long)lds); return -1; }
     static std::mutex lock;
     static int64_t configured = 0;
@@ -1489,7 +1505,9 @@ extern "C" int lsk_chain_sib(lsk_operator op, lsk_sibplan sp, uint64_t const *g_
     }
     uint32_t const *binom_r = chain_binom<uint32_t>(g_binom, (hipStream_t)stream);
     if (!binom_r) { snprintf(g_err, sizeof(g_err), "lsk_chain_sib: no memory for the narrow binomial table"); return -1; }
-    hipLaunchKernelGGL(k_chain_sib, dim3((unsigned)(8 * sp.slots_per_xcd)), dim3(kSibBlock), (size_t)lds, (hipStream_t)stream, op.runs,
+    int threads = kSibMaxBlock; // measured r3 (profiles/r3_sib_sweep*): occupancy is what this kernel is short of
+    { char const *e = getenv("LS_AMD_SIB_THREADS"); if (e && atoi(e) >= 64 && atoi(e) <= kSibMaxBlock) threads = atoi(e) & ~63; }
+    hipLaunchKernelGGL(k_chain_sib, dim3((unsigned)(8 * sp.slots_per_xcd)), dim3(threads), (size_t)lds, (hipStream_t)stream, op.runs,
                        op.n_diag, op.diag, sp, binom_r, ring, cv, (double const *)x, (double *)y);
     LSK_LAUNCH_CHECK();
     return 0;

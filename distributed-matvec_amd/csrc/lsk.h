@@ -180,6 +180,7 @@ typedef struct lsk_sibtab { /* small tables, read through a device pointer */
 typedef struct lsk_sibplan {
     int L, hw, nl, t;
     int max_rows;                 /* largest unit: siblings * block rows (sizes the LDS window) */
+    int max_block;                /* largest block: C(nl, nl / 2) rows */
     int64_t n_units, slots_per_xcd;
     lsk_sib_unit const *units;    /* device [n_units] */
     uint32_t const *order;        /* device [8 * slots_per_xcd]: per-XCD lists of unit numbers, 0xffffffff = empty slot */
@@ -196,7 +197,7 @@ int lsk_sibplan_host(lsk_sibplan *sp, lsk_sibtab *tab, int L, int hw, int nl, in
 int lsk_chain_sib(lsk_operator op, lsk_sibplan sp, uint64_t const *g_binom, int ring, double cv, void const *x, void *y,
                   void *stream);
 /* bytes of LDS one block of k_chain_sib needs for a plan with `max_rows` (the host checks it against the 160 KB of a CU) */
-int64_t lsk_chain_sib_lds_bytes(int max_rows);
+int64_t lsk_chain_sib_lds_bytes(int max_rows, int max_block);
 
 /* fused_records != 0 (32-bit states and ranks): `reps` is out[] of lsk_chain_pack -- state | partner rank of the first
  * cached pair << 32 (cache == NULL: no cached pair) -- and `cache` only holds a second cached pair at cache + n */

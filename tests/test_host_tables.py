@@ -508,7 +508,7 @@ def test_static_index_table_shapes():
 
 
 class _SibPlan(C.Structure):  # lsk_sibplan (csrc/lsk.h)
-    _fields_ = [("L", C.c_int), ("hw", C.c_int), ("nl", C.c_int), ("t", C.c_int), ("max_rows", C.c_int),
+    _fields_ = [("L", C.c_int), ("hw", C.c_int), ("nl", C.c_int), ("t", C.c_int), ("max_rows", C.c_int), ("max_block", C.c_int),
                 ("n_units", C.c_int64), ("slots_per_xcd", C.c_int64), ("units", C.c_void_p), ("order", C.c_void_p),
                 ("unrankL", C.c_void_p), ("rankL", C.c_void_p), ("tab", C.c_void_p)]
 
