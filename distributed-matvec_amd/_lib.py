@@ -164,6 +164,7 @@ def load():
         "ls_amd_test_free": (None, [vp]),
         "ls_amd_test_sibplan": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp),
                                            C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.POINTER(C.c_uint16)), C.POINTER(C.POINTER(C.c_uint16))]),
+        "ls_amd_test_sibplan_free": (None, [vp]),
         "ls_amd_test_gtab_bits": (C.c_int, [C.c_int, C.c_int64]),
         "ls_amd_test_gtab_build": (C.c_int, [C.c_int, C.c_int, C.c_int64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.POINTER(C.c_uint64))]),
         "ls_amd_test_gtab_find": (C.c_int64, [C.c_int, C.c_int, C.POINTER(C.c_uint64), C.c_uint64]),

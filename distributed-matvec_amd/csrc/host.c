@@ -1604,12 +1604,40 @@ int lsk_sibplan_host(lsk_sibplan *sp, lsk_sibtab *tb, int L, int hw, int nl, int
     *units_out = units; *order_out = order; *unrank_out = unrank; *rank_out = rank;
     return 0;
 }
+lsk_sib_rec *lsk_sibrecs_host(lsk_sibplan const *sp, lsk_sibtab const *tb, lsk_sib_unit const *units, uint32_t const *order) {
+    int64_t const slots = sp->slots_per_xcd, n = 8 * slots;
+    lsk_sib_rec *recs = (lsk_sib_rec *)calloc((size_t)(n > 0 ? n : 1), sizeof(lsk_sib_rec));
+    for (int64_t sl = 0; sl < slots; ++sl)
+        for (int k = 0; k < 8; ++k) {
+            uint32_t const un = order[k * slots + sl];
+            if (un == 0xffffffffu) continue; /* nS stays 0: empty slot */
+            lsk_sib_unit const *u = &units[un];
+            lsk_sib_rec *r = &recs[sl * 8 + k]; /* block b runs on XCD b % 8 */
+            int const kL = (int)(u->kL_jT & 0xff), jT = (int)(u->kL_jT >> 8), t = sp->t;
+            r->mid = u->mid; r->uoff = tb->uoff[kL];
+            r->nL = (uint16_t)(tb->uoff[kL + 1] - tb->uoff[kL]); r->nS = (uint16_t)tb->nsib[jT];
+            r->kL = (uint8_t)kL; r->jT = (uint8_t)jT;
+            for (int s_ = 0; s_ < (int)tb->nsib[jT]; ++s_) {
+                uint32_t const T = tb->tlist[jT][s_];
+                r->T[s_] = (uint8_t)T;
+                r->base[s_] = tb->rtr[jT][s_] + u->base_rest;
+                /* ring-closing pair (0, L - 1): the partner has T' = T ^ top bit (one sibling class up or down), the same mid bits
+                 * and Lw ^ 1; its block starts at rtr[jT'][T'] + the mid bits' contribution with one more / fewer bit below */
+                uint32_t const top = (T >> (t - 1)) & 1u, T2 = T ^ (1u << (t - 1));
+                int const j2 = top ? jT - 1 : jT + 1;
+                r->ring[s_] = tb->rtr[j2][tb->sidx[T2]] + (top ? u->ring_up : u->ring_dn);
+            }
+        }
+    return recs;
+}
 /* host-only test hook: the tables as plain arrays (release each with ls_amd_test_free); returns the number of units */
 int64_t ls_amd_test_sibplan(int L, int hw, int nl, int t, int64_t chunk, void **plan_struct, void **tables, void **units,
                             uint32_t **order, uint16_t **unrank, uint16_t **rank) {
     lsk_sibplan *sp = (lsk_sibplan *)malloc(sizeof(lsk_sibplan));
     lsk_sibtab *tb = (lsk_sibtab *)malloc(sizeof(lsk_sibtab));
     if (lsk_sibplan_host(sp, tb, L, hw, nl, t, chunk, (lsk_sib_unit **)units, order, unrank, rank) != 0) { free(sp); free(tb); return -1; }
+    sp->recs = lsk_sibrecs_host(sp, tb, (lsk_sib_unit const *)*units, *order); /* released with the struct: see ls_amd_test_sibplan_free */
+    sp->n_recs = 8 * sp->slots_per_xcd;
     *plan_struct = sp;
     *tables = tb;
     return sp->n_units;
@@ -1617,14 +1645,18 @@ int64_t ls_amd_test_sibplan(int L, int hw, int nl, int t, int64_t chunk, void **
 
 /* Block-aligned row kernel with sibling tiles (k_chain_sib, lsk.h): f64 vectors, <= 32 sites, the full fixed-weight basis on
  * one device, and the operator of the ring / open chain: ONE exchange run over all adjacent pairs plus, at most, the
- * ring-closing pair (0, L - 1).  LS_AMD_SIB=0 keeps the staged kernel; LS_AMD_SIB_NL / LS_AMD_SIB_T / LS_AMD_SIB_CHUNK set the
+ * ring-closing pair (0, L - 1).  LS_AMD_SIB=1 selects it (default: the staged kernel); LS_AMD_SIB_NL / LS_AMD_SIB_T / LS_AMD_SIB_CHUNK set the
  * split (low bits, sibling bits) and the XCD dealing.  Returns 0 with pl->has_sib == 0 when the plan is not of that shape. */
 static int setup_sib(ls_amd_plan *pl, int64_t n) {
     ls_hs_operator const *op = pl->op;
     struct ls_amd_operator_ext const *ext = OEXT(op);
     int const L = op->basis->number_sites, hw = BEXT(op->basis)->hamming_weight;
+    /* Opt-in (LS_AMD_SIB=1).  Measured r3 on chain_32 (profiles/r3_sib_*): fabric traffic 53.5 -> 44.7 GB (t = 5) with the same
+     * instruction counts as the staged kernel (3.34e9 VALU, 1.33e8 vector-memory wave instructions), but 9.4 - 9.9 ms against
+     * 8.3 ms: the LDS window of the siblings caps the kernel at 24 waves per CU behind one block-wide barrier per unit, and
+     * it runs at 4.5 - 4.8 TB/s instead of the 6.5 TB/s the staged kernel sustains.  Kept selectable, not default. */
     char const *e = getenv("LS_AMD_SIB");
-    if (e && atoi(e) == 0) return 0;
+    if (!e || atoi(e) == 0) return 0;
     if (pl->cplx || L > 32 || L < 8 || hw < 1 || hw >= L || (uint64_t)n != binom(L, hw)) return 0;
     if (ext->runs.n_runs != 1 || ext->runs.lo0[0] != 0 || ext->runs.cnt[0] != L - 1 || ext->runs.v_im[0] != 0.0) return 0;
     int const extra = ext->n_groups - ext->runs.n_run_groups;
@@ -1645,19 +1677,21 @@ static int setup_sib(ls_amd_plan *pl, int64_t n) {
     if (lsk_sibplan_host(&pl->sib, &tab, L, hw, nl, t, chunk, &units, &order, &unrank, &rank) != 0) return 0;
     int rc = 0;
     if (lsk_chain_sib_lds_bytes(pl->sib.max_rows, pl->sib.max_block) > 160 * 1024) rc = 1; /* not an error: the staged kernel takes it */
-    if (rc == 0 && (upload(&pl->d_sib_units, units, sizeof(lsk_sib_unit) * (size_t)pl->sib.n_units) != 0 ||
-                    upload(&pl->d_sib_order, order, sizeof(uint32_t) * (size_t)(8 * pl->sib.slots_per_xcd)) != 0 ||
+    lsk_sib_rec *recs = rc == 0 ? lsk_sibrecs_host(&pl->sib, &tab, units, order) : NULL;
+    pl->sib.n_recs = 8 * pl->sib.slots_per_xcd;
+    if (rc == 0 && (upload(&pl->d_sib_units, recs, sizeof(lsk_sib_rec) * (size_t)pl->sib.n_recs) != 0 ||
                     upload(&pl->d_sib_unrank, unrank, sizeof(uint16_t) << nl) != 0 || upload(&pl->d_sib_rank, rank, sizeof(uint16_t) << nl) != 0 ||
                     upload(&pl->d_sib_tab, &tab, sizeof(tab)) != 0))
         rc = -1;
-    free(units); free(order); free(unrank); free(rank);
+    free(units); free(order); free(unrank); free(rank); free(recs);
     if (rc != 0) {
         void **bufs[] = {&pl->d_sib_units, &pl->d_sib_order, &pl->d_sib_unrank, &pl->d_sib_rank, &pl->d_sib_tab};
         for (size_t i = 0; i < sizeof(bufs) / sizeof(bufs[0]); ++i) if (*bufs[i]) { lsk_free(*bufs[i]); *bufs[i] = NULL; }
         return rc < 0 ? -1 : 0;
     }
-    pl->sib.units = (lsk_sib_unit const *)pl->d_sib_units;
-    pl->sib.order = (uint32_t const *)pl->d_sib_order;
+    pl->sib.units = NULL;
+    pl->sib.order = NULL;
+    pl->sib.recs = (lsk_sib_rec const *)pl->d_sib_units;
     pl->sib.unrankL = (uint16_t const *)pl->d_sib_unrank;
     pl->sib.rankL = (uint16_t const *)pl->d_sib_rank;
     pl->sib.tab = (lsk_sibtab const *)pl->d_sib_tab;
@@ -1665,6 +1699,11 @@ static int setup_sib(ls_amd_plan *pl, int64_t n) {
     pl->sib_cv = extra == 1 ? ext->groups[ext->runs.n_run_groups].v_re : 0.0;
     pl->has_sib = 1;
     return 0;
+}
+
+void ls_amd_test_sibplan_free(void *plan_struct) {
+    lsk_sibplan *sp = (lsk_sibplan *)plan_struct;
+    if (sp) { free((void *)sp->recs); free(sp); }
 }
 
 /* Staged row kernel (k_chain_t, lsk.h): pull, f64 or c128 vectors, <= 64 sites, the full fixed-weight basis without

@@ -1305,98 +1305,111 @@ extern "C" int lsk_chain(lsk_operator op, lsk_basis bs, lsk_index ix, int cplx, 
 // k_chain_t prices its far pairs.
 // ---------------------------------------------------------------------------------------------
 constexpr int kSibMaxBlock = 1024;
-constexpr int kSibFar = 12; // uniform-pair gathers in flight per row before the first wait
+template <int ROWS> struct SibFar { static constexpr int value = ROWS == 1 ? 12 : 10; }; // uniform-pair gathers in flight per row before the first wait
 constexpr int kSibBinomRows = 32;
-constexpr int kSibHead = kSibBinomRows * LSK_BINOM_K + 2 * LSK_SIB_MAX_S + 64; // u32 words in front of the unrank slice
+constexpr int kSibHead = kSibBinomRows * LSK_BINOM_K + 3 * LSK_SIB_MAX_S + 64; // u32 words in front of the unrank slice
 extern "C" int64_t lsk_chain_sib_lds_bytes(int max_rows, int max_block) {
     return (int64_t)sizeof(uint32_t) * kSibHead + 2 * (((int64_t)max_block + 7) & ~(int64_t)3) + 8 * ((int64_t)max_rows + 2);
 }
 
+// One block per launch record (lsk_sib_rec: record b belongs to block b; the host wrote them in XCD-interleaved order).
+// Phase 1: header + per-sibling bases straight from the record (one memory latency), then the window: the blocks of all
+// siblings, the low words of the unit's weight class, the small tables -- one barrier.  Phase 2: wave w walks the items
+// (sibling, pair of 64-row chunks) w, w + W, ...: the pairs >= nl are priced once per item (lane l <-> pair nl + l) and
+// every gather of the item's ROWS chunks is issued before anything is consumed (ROWS = 2: two rows per lane in flight, at
+// 99 instead of 61 VGPRs -- measured r3: no gain, the waves lost cost what the rows in flight bring; ROWS = 1 ships).
+template <int ROWS>
 __global__ __launch_bounds__(kSibMaxBlock) void k_chain_sib(lsk_runs runs, int n_diag, lsk_term const *__restrict__ diag, lsk_sibplan sp,
-                                                         uint32_t const *__restrict__ g_binom, int ring, double cv,
-                                                         double const *__restrict__ x, double *__restrict__ y) {
+                                                            uint32_t const *__restrict__ g_binom, int ring, double cv,
+                                                            double const *__restrict__ x, double *__restrict__ y) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *s_binom = reinterpret_cast<uint32_t *>(smem);      // [32][LSK_BINOM_K] C(n, k), n < 32
     uint32_t *s_base = s_binom + kSibBinomRows * LSK_BINOM_K;    // [S] rank of row 0 of sibling s
     uint32_t *s_ring = s_base + LSK_SIB_MAX_S;                   // [S] rank of row 0 of the ring partner's block
-    uint32_t *s_sidx = s_ring + LSK_SIB_MAX_S;                   // [2^t] T -> sibling number (entries of other weights unused)
+    uint32_t *s_T = s_ring + LSK_SIB_MAX_S;                      // [S] top bits of sibling s
+    uint32_t *s_sidx = s_T + LSK_SIB_MAX_S;                      // [2^t] T -> sibling number (entries of other weights unused)
     uint16_t *s_unr = reinterpret_cast<uint16_t *>(s_sidx + 64); // [nL] the low words of this unit's weight class, ascending
     double *s_x = reinterpret_cast<double *>(s_unr + ((sp.max_block + 7) & ~3)); // [S * nL + 1], last = 0.0
     static_assert(kSibHead % 2 == 0, "s_x must be 8-byte aligned");
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nthreads = blockDim.x;
-    const uint32_t un = sp.order[(int64_t)(blockIdx.x & 7) * sp.slots_per_xcd + (blockIdx.x >> 3)];
-    if (un == 0xffffffffu) return; // block-uniform
-    lsk_sibtab const *__restrict__ tb = sp.tab;
-    const lsk_sib_unit U = sp.units[un];
-    const int kL = (int)(U.kL_jT & 0xff), jT = (int)(U.kL_jT >> 8);
-    const uint32_t uoff = tb->uoff[kL];
-    const int nL = (int)(tb->uoff[kL + 1] - uoff);
-    const int nS = (int)tb->nsib[jT];
+    lsk_sib_rec const *__restrict__ rec = sp.recs + blockIdx.x;
+    const int nS = (int)rec->nS;
+    if (nS == 0) return; // empty slot of a shorter XCD list (block-uniform)
+    const int nL = (int)rec->nL;
+    const uint32_t mid = rec->mid, uoff = rec->uoff;
     const int L = sp.L, t = sp.t, nl = sp.nl, hw = sp.hw;
     const int tshift = L - t;
+    const int ZERO = nS * nL;
+    // ---- phase 1 ----------------------------------------------------------------------------------------------------
+    for (int s = 0; s < nS; ++s) {
+        double const *__restrict__ xb = x + rec->base[s];
+        for (int r = tid; r < nL; r += nthreads) s_x[s * nL + r] = xb[r];
+    }
+    for (int r = tid; r < nL; r += nthreads) s_unr[r] = sp.unrankL[uoff + r];
     {
         constexpr int N16 = kSibBinomRows * LSK_BINOM_K * (int)sizeof(uint32_t) / 16;
         uint4 const *src = reinterpret_cast<uint4 const *>(g_binom);
         uint4 *dst = reinterpret_cast<uint4 *>(s_binom);
         for (int k = tid; k < N16; k += nthreads) dst[k] = src[k];
     }
-    for (int r = tid; r < nL; r += nthreads) s_unr[r] = sp.unrankL[uoff + r];
-    if (tid < nS) {
-        const uint32_t T = tb->tlist[jT][tid];
-        s_base[tid] = tb->rtr[jT][tid] + U.base_rest;
-        // ring-closing pair (0, L - 1): the partner has T' = T ^ top bit (one sibling class up or down), the same mid bits and
-        // Lw ^ 1; its block starts at rtr[jT'][T'] + the mid bits' contribution with one more / one fewer bit below them
-        const uint32_t top = (T >> (t - 1)) & 1u;
-        const uint32_t T2 = T ^ (1u << (t - 1));
-        const int j2 = top ? jT - 1 : jT + 1;
-        s_ring[tid] = tb->rtr[j2][tb->sidx[T2]] + (top ? U.ring_up : U.ring_dn);
-    }
-    if (tid < (1 << t)) s_sidx[tid] = tb->sidx[tid];
-    __syncthreads();
-    const int ZERO = nS * nL;
-    for (int s = 0; s < nS; ++s) {
-        double const *__restrict__ xb = x + s_base[s];
-        for (int r = tid; r < nL; r += nthreads) s_x[s * nL + r] = xb[r];
-    }
+    if (tid < nS) { s_base[tid] = rec->base[tid]; s_ring[tid] = rec->ring[tid]; s_T[tid] = rec->T[tid]; }
+    if (tid < (1 << t)) s_sidx[tid] = sp.tab->sidx[tid];
     if (tid == 0) s_x[ZERO] = 0.0;
     __syncthreads();
-
+    // ---- phase 2 ----------------------------------------------------------------------------------------------------
     const double v = runs.v_re[0];
     const int nchunk = (nL + 63) >> 6;
+    const int npair = (nchunk + ROWS - 1) / ROWS;
+    constexpr int kSibFar = SibFar<ROWS>::value;
     const int n_glob = tshift - nl; // pairs nl .. L - t - 1 gather from global memory, pairs L - t .. L - 2 read a sibling
     const int nwaves = nthreads >> 6;
     int s = 0, c = wave;
-    while (c >= nchunk) { c -= nchunk; ++s; }
+    while (c >= npair && s < nS) { c -= npair; ++s; }
     // ring pair, first hop: rank of the partner's low word -- a 2^nl-entry table in L1 / L2, requested one item ahead
-    uint32_t rk_next = 0;
+    uint32_t rk_next[ROWS];
+#pragma unroll
+    for (int u = 0; u < ROWS; ++u) rk_next[u] = 0;
     if (ring && s < nS) {
-        const int rn = c * 64 + lane;
-        rk_next = sp.rankL[(uint32_t)s_unr[rn < nL ? rn : nL - 1] ^ 1u];
+#pragma unroll
+        for (int u = 0; u < ROWS; ++u) {
+            const int rn = (ROWS * c + u) * 64 + lane;
+            rk_next[u] = sp.rankL[(uint32_t)s_unr[rn < nL ? rn : nL - 1] ^ 1u];
+        }
     }
 #pragma unroll 1
     for (; s < nS;) {
-        const int r0 = c * 64 + lane;
-        const bool ghost = r0 >= nL; // lanes past the end of the block stay active as copies of its last row, store nothing
-        const int r = ghost ? nL - 1 : r0;
-        const uint32_t Lw = s_unr[r];
-        const uint32_t T = __builtin_amdgcn_readfirstlane((uint32_t)tb->tlist[jT][s]);
-        const uint32_t a = (T << tshift) | U.mid | Lw;
-        const uint32_t ig = s_base[s] + (uint32_t)r;
-        const int jr = s * nL + r;
+        const uint32_t T = s_T[s];
+        const uint32_t a_hi = (T << tshift) | mid; // the item's state without its low word
+        const uint32_t base = s_base[s];
         const uint32_t top = (T >> (t - 1)) & 1u;
-        const bool ring_act = ring && ((Lw & 1u) != top);
-        const uint32_t ring_rank = ring_act ? s_ring[s] + rk_next : ig;
+        int r[ROWS], jr[ROWS];
+        bool ghost[ROWS], ring_act[ROWS];
+        uint32_t a[ROWS], ig[ROWS], ring_rank[ROWS];
+#pragma unroll
+        for (int u = 0; u < ROWS; ++u) {
+            const int r0 = (ROWS * c + u) * 64 + lane;
+            ghost[u] = r0 >= nL; // lanes past the end of the block stay active as copies of its last row, store nothing
+            r[u] = ghost[u] ? nL - 1 : r0;
+            const uint32_t Lw = s_unr[r[u]];
+            a[u] = a_hi | Lw;
+            ig[u] = base + (uint32_t)r[u];
+            jr[u] = s * nL + r[u];
+            ring_act[u] = ring && ((Lw & 1u) != top);
+            ring_rank[u] = ring_act[u] ? s_ring[s] + rk_next[u] : ig[u];
+        }
         // the item after this one (same wave)
         int s_n = s, c_n = c + nwaves;
-        while (c_n >= nchunk && s_n < nS) { c_n -= nchunk; ++s_n; }
+        while (c_n >= npair && s_n < nS) { c_n -= npair; ++s_n; }
         if (ring && s_n < nS) {
-            const int rn = c_n * 64 + lane;
-            rk_next = sp.rankL[(uint32_t)s_unr[rn < nL ? rn : nL - 1] ^ 1u];
+#pragma unroll
+            for (int u = 0; u < ROWS; ++u) {
+                const int rn = (ROWS * c_n + u) * 64 + lane;
+                rk_next[u] = sp.rankL[(uint32_t)s_unr[rn < nL ? rn : nL - 1] ^ 1u];
+            }
         }
         // ---- pairs >= nl: uniform across the item; lane l prices pair nl + l ------------------------------------------
-        const uint32_t a_hi = (T << tshift) | U.mid; // the item's state without its low word
         unsigned long long m;
         uint32_t off;
         int sib = 0;
@@ -1415,69 +1428,96 @@ __global__ __launch_bounds__(kSibMaxBlock) void k_chain_sib(lsk_runs runs, int n
         }
         unsigned long long m_glob = m & ((1ULL << n_glob) - 1ULL);
         unsigned long long m_sib = m >> n_glob;
-        double xv[kSibFar];
+        double xv[ROWS][kSibFar];
 #pragma unroll
-        for (int u = 0; u < kSibFar; ++u) {
-            xv[u] = 0.0;
+        for (int q = 0; q < kSibFar; ++q) {
+#pragma unroll
+            for (int u = 0; u < ROWS; ++u) xv[u][q] = 0.0;
             if (m_glob) {
                 const int l = __builtin_ctzll(m_glob);
                 m_glob &= m_glob - 1;
-                xv[u] = x[(uint32_t)(ig + (uint32_t)__builtin_amdgcn_readlane((int)off, l))];
+                const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)off, l);
+#pragma unroll
+                for (int u = 0; u < ROWS; ++u) xv[u][q] = x[(uint32_t)(ig[u] + o)];
             }
         }
-        // ---- the pair that straddles Lw | mid: per lane, a near partner (<= C(nl - 1, .) rows away) ----------------------
-        const uint32_t tdiff = a ^ (a >> 1);
-        int k = __popc(Lw & ((1u << (nl - 1)) - 1u));
-        double xc;
-        {
+        // ---- the pair that straddles Lw | mid: per lane, a near partner (<= C(nl - 1, .) rows away); the ring partner -----
+        double xc[ROWS], g_ring[ROWS];
+        uint32_t tdiff[ROWS];
+#pragma unroll
+        for (int u = 0; u < ROWS; ++u) {
+            tdiff[u] = a[u] ^ (a[u] >> 1);
             const int lo = nl - 1;
-            const bool bit = (a >> lo) & 1u, act = (tdiff >> lo) & 1u;
+            const int k = __popc(a[u] & ((1u << lo) - 1u));
+            const bool bit = (a[u] >> lo) & 1u, act = (tdiff[u] >> lo) & 1u;
             const uint32_t d = s_binom[lo * LSK_BINOM_K + k];
-            const uint32_t idx = bit ? ig + d : ig - d;
-            xc = x[act ? idx : ig];
-            xc = act ? xc : 0.0;
+            const uint32_t idx = bit ? ig[u] + d : ig[u] - d;
+            xc[u] = x[act ? idx : ig[u]];
+            xc[u] = act ? xc[u] : 0.0;
+            g_ring[u] = x[ring_rank[u]];
         }
-        const double g_ring = x[ring_rank];
         // ---- diagonal and the pairs inside the low word: LDS, no halo ------------------------------------------------------
-        double dr, di;
-        diag_coeff<uint32_t, true>(runs, n_diag, diag, a, dr, di);
-        double acc = dr * s_x[jr];
-        double near = 0.0;
-        k = 0;
-#pragma unroll 4
+        double acc[ROWS], near[ROWS];
+        int k[ROWS];
+#pragma unroll
+        for (int u = 0; u < ROWS; ++u) k[u] = 0;
+#pragma unroll
+        for (int u = 0; u < ROWS; ++u) {
+            double dr, di;
+            diag_coeff<uint32_t, true>(runs, n_diag, diag, a[u], dr, di);
+            acc[u] = dr * s_x[jr[u]];
+            near[u] = 0.0;
+        }
+#pragma unroll 2
         for (int lo = 0; lo < nl - 1; ++lo) {
-            const bool bit = (a >> lo) & 1u, act = (tdiff >> lo) & 1u;
-            const int d = (int)s_binom[lo * LSK_BINOM_K + k];
-            k += bit ? 1 : 0;
-            const int j = bit ? jr + d : jr - d;
-            near += s_x[act ? j : ZERO];
+#pragma unroll
+            for (int u = 0; u < ROWS; ++u) {
+                const bool bit = (a[u] >> lo) & 1u, act = (tdiff[u] >> lo) & 1u;
+                const int d = (int)s_binom[lo * LSK_BINOM_K + k[u]];
+                k[u] += bit ? 1 : 0;
+                const int j = bit ? jr[u] + d : jr[u] - d;
+                near[u] += s_x[act ? j : ZERO];
+            }
         }
         // ---- sibling pairs: the partner block is in LDS at the same row ---------------------------------------------------
         while (m_sib) {
             const int l = __builtin_ctzll(m_sib);
             m_sib &= m_sib - 1;
-            near += s_x[__builtin_amdgcn_readlane(sib, l + n_glob) + r];
+            const int sb = __builtin_amdgcn_readlane(sib, l + n_glob);
+#pragma unroll
+            for (int u = 0; u < ROWS; ++u) near[u] += s_x[sb + r[u]];
         }
-        near += xc;
 #pragma unroll
-        for (int u = 0; u < kSibFar; ++u) near += xv[u];
+        for (int u = 0; u < ROWS; ++u) {
+            near[u] += xc[u];
+#pragma unroll
+            for (int q = 0; q < kSibFar; ++q) near[u] += xv[u][q];
+        }
         while (m_glob) { // more than kSibFar anti-aligned global pairs
-            double xw[4];
+            double xw[ROWS][3];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                xw[u] = 0.0;
+            for (int q = 0; q < 3; ++q) {
+#pragma unroll
+                for (int u = 0; u < ROWS; ++u) xw[u][q] = 0.0;
                 if (m_glob) {
                     const int l = __builtin_ctzll(m_glob);
                     m_glob &= m_glob - 1;
-                    xw[u] = x[(uint32_t)(ig + (uint32_t)__builtin_amdgcn_readlane((int)off, l))];
+                    const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)off, l);
+#pragma unroll
+                    for (int u = 0; u < ROWS; ++u) xw[u][q] = x[(uint32_t)(ig[u] + o)];
                 }
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) near += xw[u];
+            for (int q = 0; q < 3; ++q)
+#pragma unroll
+                for (int u = 0; u < ROWS; ++u) near[u] += xw[u][q];
         }
-        acc = fma(v, near, acc);
-        acc = fma(ring_act ? cv : 0.0, g_ring, acc);
-        if (!ghost) __builtin_nontemporal_store(acc, y + ig);
+#pragma unroll
+        for (int u = 0; u < ROWS; ++u) {
+            acc[u] = fma(v, near[u], acc[u]);
+            acc[u] = fma(ring_act[u] ? cv : 0.0, g_ring[u], acc[u]);
+            if (!ghost[u]) __builtin_nontemporal_store(acc[u], y + ig[u]);
+        }
         s = s_n;
         c = c_n;
     }
@@ -1487,7 +1527,7 @@ __global__ __launch_bounds__(kSibMaxBlock) void k_chain_sib(lsk_runs runs, int n
 template <typename R> static R const *chain_binom(uint64_t const *g_binom, hipStream_t stream);
 extern "C" int lsk_chain_sib(lsk_operator op, lsk_sibplan sp, uint64_t const *g_binom, int ring, double cv, void const *x, void *y,
                              void *stream) {
-    if (sp.n_units == 0 || sp.slots_per_xcd == 0) return 0;
+    if (sp.n_units == 0 || sp.n_recs == 0) return 0;
     if (op.runs.n_runs != 1 || op.runs.lo0[0] != 0 || op.runs.cnt[0] != sp.L - 1 || sp.L > 32) {
         snprintf(g_err, sizeof(g_err), "lsk_chain_sib: the operator is not one exchange run over all adjacent pairs of <= 32 sites");
         return -1;
@@ -1499,15 +1539,15 @@ extern "C" int lsk_chain_sib(lsk_operator op, lsk_sibplan sp, uint64_t const *g_
     {
         std::lock_guard<std::mutex> guard(lock);
         if (lds > configured) {
-            LSK_CHECK(hipFuncSetAttribute((void const *)k_chain_sib, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            LSK_CHECK(hipFuncSetAttribute((void const *)k_chain_sib<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             configured = lds;
         }
     }
     uint32_t const *binom_r = chain_binom<uint32_t>(g_binom, (hipStream_t)stream);
     if (!binom_r) { snprintf(g_err, sizeof(g_err), "lsk_chain_sib: no memory for the narrow binomial table"); return -1; }
-    int threads = kSibMaxBlock; // measured r3 (profiles/r3_sib_sweep*): occupancy is what this kernel is short of
+    int threads = 768; // measured r3 (profiles/r3_sib_sweep*): 24 waves per CU (two blocks of 12) beat 16 and 32
     { char const *e = getenv("LS_AMD_SIB_THREADS"); if (e && atoi(e) >= 64 && atoi(e) <= kSibMaxBlock) threads = atoi(e) & ~63; }
-    hipLaunchKernelGGL(k_chain_sib, dim3((unsigned)(8 * sp.slots_per_xcd)), dim3(threads), (size_t)lds, (hipStream_t)stream, op.runs,
+    hipLaunchKernelGGL(k_chain_sib<1>, dim3((unsigned)sp.n_recs), dim3(threads), (size_t)lds, (hipStream_t)stream, op.runs,
                        op.n_diag, op.diag, sp, binom_r, ring, cv, (double const *)x, (double *)y);
     LSK_LAUNCH_CHECK();
     return 0;

@@ -170,6 +170,17 @@ typedef struct lsk_sib_unit {
 } lsk_sib_unit;
 #define LSK_SIB_MAX_T 6
 #define LSK_SIB_MAX_S 20 /* C(6, 3) */
+/* launch record: everything block b needs to start, in ONE 256-byte read (record b <-> block b: the host writes the
+ * records in XCD-interleaved order, so there is no order list to chase); nS == 0: empty slot */
+typedef struct lsk_sib_rec {
+    uint32_t mid, uoff;   /* the mid bits in place; start of the unit's weight class in unrankL */
+    uint16_t nL, nS;      /* rows per block, siblings */
+    uint8_t kL, jT, pad0[2];
+    uint32_t base[LSK_SIB_MAX_S]; /* rank of row 0 of sibling s */
+    uint32_t ring[LSK_SIB_MAX_S]; /* rank of row 0 of the block that holds the ring partners of sibling s */
+    uint8_t T[LSK_SIB_MAX_S];     /* top bits of sibling s */
+    uint8_t pad1[60];
+} lsk_sib_rec;
 typedef struct lsk_sibtab { /* small tables, read through a device pointer */
     uint32_t uoff[34];            /* class kL occupies unrankL[uoff[kL], uoff[kL + 1]) */
     uint32_t nsib[LSK_SIB_MAX_T + 1];              /* C(t, jT) */
@@ -187,7 +198,11 @@ typedef struct lsk_sibplan {
     uint16_t const *unrankL;      /* device [2^nl]: the nl-bit words grouped by weight, ascending inside a weight */
     uint16_t const *rankL;        /* device [2^nl]: position of a word inside its weight class */
     lsk_sibtab const *tab;        /* device */
+    lsk_sib_rec const *recs;      /* device [n_recs] = [8 * slots_per_xcd], launch order */
+    int64_t n_recs;
 } lsk_sibplan;
+/* expands units + order (host arrays of lsk_sibplan_host) into the launch records (malloc'ed, 8 * slots_per_xcd of them) */
+lsk_sib_rec *lsk_sibrecs_host(lsk_sibplan const *sp, lsk_sibtab const *tab, lsk_sib_unit const *units, uint32_t const *order);
 /* host-side construction of the tables above (plain malloc'ed arrays in *units / *order / *unrank / *rank); chunk = units per
  * round-robin chunk of the XCD lists.  Returns 0, or -1 when the shape is not admissible (ranks beyond 32 bits, ...). */
 int lsk_sibplan_host(lsk_sibplan *sp, lsk_sibtab *tab, int L, int hw, int nl, int t, int64_t chunk, lsk_sib_unit **units,

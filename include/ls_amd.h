@@ -284,9 +284,10 @@ int64_t ls_amd_test_gtab_find(int L, int bbits, uint64_t const *entries, uint64_
  * for the full basis of `hw` set bits on L <= 32 sites split into T (top t bits) | mid | Lw (low nl bits).  Returns the
  * number of work units (< 0: shape not admissible) and malloc'ed arrays: the lsk_sibplan struct itself, its small tables (lsk_sibtab), the units
  * (5 x uint32 each), the 8 XCD lists of unit numbers, unrankL / rankL of the nl-bit words (release each with
- * ls_amd_test_free). */
+ * ls_amd_test_free; the plan struct, whose `recs` are the 256-byte launch records, with ls_amd_test_sibplan_free). */
 int64_t ls_amd_test_sibplan(int L, int hw, int nl, int t, int64_t chunk, void **plan_struct, void **tables, void **units,
                             uint32_t **order, uint16_t **unrank, uint16_t **rank);
+void ls_amd_test_sibplan_free(void *plan_struct); /* the struct of ls_amd_test_sibplan and its launch records */
 /* byte offsets of commInfo / globalSumReal_type inside primme_params as the PRIMME callbacks read them (ls_chpl.h) */
 int ls_amd_test_primme_comminfo_offset(void);
 int ls_amd_test_primme_sumtype_offset(void);

@@ -749,16 +749,16 @@ ROW_KERNEL_VARIANTS = {
     "generic-row-kernel": {"LS_AMD_CHAIN": "0"},
     "no-uniform-pairs": {"LS_AMD_CHAIN": "0", "LS_AMD_HIGH_PAIR": "0"},
     "uniform-from-4": {"LS_AMD_CHAIN": "0", "LS_AMD_HIGH_PAIR": "4"},
-    "staged": {"LS_AMD_SIB": "0"},
-    "staged-uniform-from-13": {"LS_AMD_SIB": "0", "LS_AMD_HIGH_PAIR": "13"},
-    "staged-no-uniform": {"LS_AMD_SIB": "0", "LS_AMD_HIGH_PAIR": "0"},
-    "contiguous-tiles": {"LS_AMD_SIB": "0", "LS_AMD_TILE_CHUNK": "0"},
-    # block-aligned kernel with sibling tiles: other splits T | mid | Lw than the default, other XCD dealings
-    "sibling-nl5-t3": {"LS_AMD_SIB_NL": "5", "LS_AMD_SIB_T": "3", "LS_AMD_SIB_CHUNK": "1"},
-    "sibling-nl9-t5": {"LS_AMD_SIB_NL": "9", "LS_AMD_SIB_T": "5", "LS_AMD_SIB_CHUNK": "5"},
-    "sibling-nl7-t6": {"LS_AMD_SIB_NL": "7", "LS_AMD_SIB_T": "6"},
-    "sibling-nl10-t1": {"LS_AMD_SIB_NL": "10", "LS_AMD_SIB_T": "1", "LS_AMD_SIB_CHUNK": "1000"},
-    "sibling-no-mid": {"LS_AMD_SIB_NL": "8", "LS_AMD_SIB_T": "6"},  # L = 14: T | Lw with no bits between them
+    "staged-uniform-from-13": {"LS_AMD_HIGH_PAIR": "13"},
+    "staged-no-uniform": {"LS_AMD_HIGH_PAIR": "0"},
+    "contiguous-tiles": {"LS_AMD_TILE_CHUNK": "0"},
+    # block-aligned kernel with sibling tiles (opt-in): the default split T | mid | Lw and others, other XCD dealings, block sizes
+    "sibling": {"LS_AMD_SIB": "1"},
+    "sibling-nl5-t3": {"LS_AMD_SIB": "1", "LS_AMD_SIB_NL": "5", "LS_AMD_SIB_T": "3", "LS_AMD_SIB_CHUNK": "1"},
+    "sibling-nl9-t5": {"LS_AMD_SIB": "1", "LS_AMD_SIB_NL": "9", "LS_AMD_SIB_T": "5", "LS_AMD_SIB_CHUNK": "5", "LS_AMD_SIB_THREADS": "256"},
+    "sibling-nl7-t6": {"LS_AMD_SIB": "1", "LS_AMD_SIB_NL": "7", "LS_AMD_SIB_T": "6", "LS_AMD_SIB_THREADS": "1024"},
+    "sibling-nl10-t1": {"LS_AMD_SIB": "1", "LS_AMD_SIB_NL": "10", "LS_AMD_SIB_T": "1", "LS_AMD_SIB_CHUNK": "1000"},
+    "sibling-no-mid": {"LS_AMD_SIB": "1", "LS_AMD_SIB_NL": "8", "LS_AMD_SIB_T": "6"},  # L = 14: T | Lw with no bits between them
     "chunked-tiles-generic": {"LS_AMD_CHAIN": "0", "LS_AMD_TILE_CHUNK": "3"},
 }
 
@@ -793,10 +793,10 @@ def test_row_kernel_variants(torch, monkeypatch, variant):
         got, pl = run_matvec(torch, D, h, reps, masks, x, 1, "pull")
         seen.add(pl.kernel)
         assert np.abs(got - want).max() <= 1e-12 * max(1.0, np.abs(want).max()), (variant, L, kind, pl.kernel)
-        if variant == "default" or variant.startswith("sibling"):
+        if variant.startswith("sibling"):
             # f64 vectors, one exchange run over all adjacent pairs (+ the ring-closing pair): the block-aligned kernel
             assert pl.kernel == ("direct-pull" if kind == "j1j2" else "direct-pull+sibling"), (kind, pl.kernel)
-        if variant.startswith("staged") or variant == "contiguous-tiles":
+        if variant == "default" or variant.startswith("staged") or variant == "contiguous-tiles":
             assert pl.kernel == ("direct-pull" if kind == "j1j2" else "direct-pull+staged"), (kind, pl.kernel)
         # c128 vectors: the complex instantiation of the same kernel family
         xc = x + 1j * (rs.rand(len(want_reps)) - 0.5)
@@ -832,7 +832,6 @@ def test_staged_kernel_instantiations(torch, monkeypatch, L, weight, cplx, wide)
         pytest.skip("64-bit ranks are only instantiated for 64-bit states")
     if wide:
         monkeypatch.setenv("LS_AMD_CHAIN_WIDE", "1")
-    monkeypatch.setenv("LS_AMD_SIB", "0")  # this test is about k_chain_t; the sibling kernel has its own (test_row_kernel_variants)
     cfg = _ring_config(L, weight)
     basis, h = D.loadConfigFromDict(cfg, hamiltonian=True)
     reps, masks = D.enumerateStates(basis, 1)

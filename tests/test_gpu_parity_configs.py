@@ -106,7 +106,7 @@ def test_chain_32_edge_targeted_rows(torch):
     u = D.fillRandom(r, 1, torch.float64)
     y = torch.empty_like(u)
     pl = D.matrixVectorProduct(h, [u], [y], reps, mode="pull")
-    assert pl.kernel == "direct-pull+sibling"
+    assert pl.kernel == "direct-pull+staged"
     rs = np.random.RandomState(2024)
     tiles = rs.randint(0, n // 1024, size=20000).astype(np.int64)
     rows = [tiles * 1024 + k for k in (0, 1, 511, 512, 1023)]
@@ -140,12 +140,12 @@ def test_chain_32_edge_targeted_rows(torch):
     finally:
         del os.environ["LS_AMD_CHAIN"]
     assert float((y - y2).abs().max()) <= 1e-12 * float(y.abs().max())
-    # ... and through the staged kernel (1024-row tiles with halo, cached ring partners): all 6e8 rows
-    os.environ["LS_AMD_SIB"] = "0"
+    # ... and through the block-aligned kernel with sibling tiles (opt-in; state and ring partner computed, no halo): all 6e8 rows
+    os.environ["LS_AMD_SIB"] = "1"
     try:
         y3 = torch.empty_like(u)
         pl3 = D.MatvecPlan(h, reps, torch.float64, mode="pull")
-        assert pl3.kernel == "direct-pull+staged"
+        assert pl3.kernel == "direct-pull+sibling"
         pl3.matvec([u], [y3])
         pl3.destroy()
     finally:
@@ -159,7 +159,7 @@ def test_chain_32_edge_targeted_rows(torch):
     rows = np.unique(np.concatenate([pick - 1, pick, pick + 1, pick + 2]))
     rows = rows[(rows >= 0) & (rows < n)]
     rows_t, want = oracle_rows(torch, o, r, rows, u, projected=False, rank_fn=CO.fixed_hamming_ranks)
-    assert_rows(y[rows_t].cpu().numpy(), want, f"chain_32 {len(rows)} block-edge rows")
+    assert_rows(y3[rows_t].cpu().numpy(), want, f"chain_32 {len(rows)} block-edge rows")
 
 
 def test_chain_36_symm_eight_partitions_packets(torch):

@@ -510,7 +510,12 @@ def test_static_index_table_shapes():
 class _SibPlan(C.Structure):  # lsk_sibplan (csrc/lsk.h)
     _fields_ = [("L", C.c_int), ("hw", C.c_int), ("nl", C.c_int), ("t", C.c_int), ("max_rows", C.c_int), ("max_block", C.c_int),
                 ("n_units", C.c_int64), ("slots_per_xcd", C.c_int64), ("units", C.c_void_p), ("order", C.c_void_p),
-                ("unrankL", C.c_void_p), ("rankL", C.c_void_p), ("tab", C.c_void_p)]
+                ("unrankL", C.c_void_p), ("rankL", C.c_void_p), ("tab", C.c_void_p), ("recs", C.c_void_p), ("n_recs", C.c_int64)]
+
+
+class _SibRec(C.Structure):  # lsk_sib_rec: 256 bytes
+    _fields_ = [("mid", C.c_uint32), ("uoff", C.c_uint32), ("nL", C.c_uint16), ("nS", C.c_uint16), ("kL", C.c_uint8), ("jT", C.c_uint8),
+                ("pad0", C.c_uint8 * 2), ("base", C.c_uint32 * 20), ("ring", C.c_uint32 * 20), ("T", C.c_uint8 * 20), ("pad1", C.c_uint8 * 60)]
 
 
 class _SibTab(C.Structure):  # lsk_sibtab
@@ -572,7 +577,34 @@ def test_sibling_tile_plan_tiles_the_basis(L, hw, nl, t, chunk):
                 rest = int(u[2]) if top else int(u[3])  # the top bit came down: kL + 1 bits below mid; else kL - 1
                 assert tb.rtr[bin(T2).count("1")][tb.sidx[T2]] + rest + int(rankl[lw2]) == rank_of[b]
         assert np.all(seen == 1)
+        # launch records: record b <-> block b, XCD-interleaved (block b runs on XCD b % 8); self-contained copies of the above
+        assert C.sizeof(_SibRec) == 256 and sp.n_recs == 8 * sp.slots_per_xcd
+        recs = (_SibRec * sp.n_recs).from_address(sp.recs)
+        covered = 0
+        for b in range(sp.n_recs):
+            un = int(order[(b % 8) * sp.slots_per_xcd + b // 8])
+            rc = recs[b]
+            if un == 0xFFFFFFFF:
+                assert rc.nS == 0
+                continue
+            u = units[un]
+            kL, jT = int(u[4]) & 0xFF, int(u[4]) >> 8
+            assert (rc.mid, rc.kL, rc.jT, rc.nL, rc.nS, rc.uoff) == (int(u[1]), kL, jT, math.comb(nl, kL), math.comb(t, jT), tb.uoff[kL])
+            for s_ in range(rc.nS):
+                T = tb.tlist[jT][s_]
+                assert rc.T[s_] == T and rc.base[s_] == tb.rtr[jT][s_] + int(u[0])
+                first = (T << tshift) | int(u[1]) | int(unrank[tb.uoff[kL]])  # the block's first state
+                assert rank_of[first] == rc.base[s_]
+                top = (T >> (t - 1)) & 1
+                lw_first = [w for w in unrank[tb.uoff[kL]:tb.uoff[kL + 1]].tolist() if (w & 1) != top]
+                if lw_first:  # some row of this block has an active ring pair: its partner's block starts at rc.ring
+                    a0 = (T << tshift) | int(u[1]) | lw_first[0]
+                    b0 = a0 ^ (1 | (1 << (L - 1)))
+                    assert rank_of[b0] == rc.ring[s_] + int(rankl[b0 & lmask])
+            covered += rc.nL * rc.nS
+        assert covered == len(states)
         assert sp.max_rows == max(math.comb(nl, int(u[4]) & 0xFF) * math.comb(t, int(u[4]) >> 8) for u in units)
     finally:
-        for ptr in (ps, pt, pu, po, pun, prk):
+        for ptr in (pt, pu, po, pun, prk):
             lib.ls_amd_test_free(ptr)
+        lib.ls_amd_test_sibplan_free(ps)
