@@ -117,6 +117,25 @@ extern "C" int lsk_comm_unique_id(void *id128) {
     return 0;
 }
 
+// stream + event pairs of a communicator; on failure everything created so far is released again
+static int comm_resources(lsk_comm *c) {
+    c->xstream = nullptr;
+    for (int i = 0; i < 2; ++i) c->ready[i] = c->done[i] = nullptr;
+    hipError_t e = hipStreamCreateWithFlags(&c->xstream, hipStreamNonBlocking);
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) {
+        e = hipEventCreateWithFlags(&c->ready[i], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->done[i], hipEventDisableTiming);
+    }
+    if (e == hipSuccess) return 0;
+    snprintf(g_cerr, sizeof(g_cerr), "communicator stream / events: %s", hipGetErrorString(e));
+    for (int i = 0; i < 2; ++i) {
+        if (c->ready[i]) (void)hipEventDestroy(c->ready[i]);
+        if (c->done[i]) (void)hipEventDestroy(c->done[i]);
+    }
+    if (c->xstream) (void)hipStreamDestroy(c->xstream);
+    return -1;
+}
+
 extern "C" int lsk_comm_create(lsk_comm **out, int size, int rank, void const *id128) {
     *out = nullptr;
     if (load_api() != 0) return -1;
@@ -131,10 +150,10 @@ extern "C" int lsk_comm_create(lsk_comm **out, int size, int rank, void const *i
         delete c;
         return -1;
     }
-    HIP_CHECK(hipStreamCreateWithFlags(&c->xstream, hipStreamNonBlocking));
-    for (int i = 0; i < 2; ++i) {
-        HIP_CHECK(hipEventCreateWithFlags(&c->ready[i], hipEventDisableTiming));
-        HIP_CHECK(hipEventCreateWithFlags(&c->done[i], hipEventDisableTiming));
+    if (comm_resources(c) != 0) {
+        if (g_api.CommDestroy) (void)g_api.CommDestroy(c->comm);
+        delete c;
+        return -1;
     }
     *out = c;
     return 0;
@@ -148,10 +167,17 @@ extern "C" int lsk_comm_create_local(lsk_comm **out, int size) {
     for (int r = 0; r < size; ++r) {
         lsk_comm *c = new lsk_comm();
         c->comm = nullptr; c->size = size; c->rank = r; c->local = g;
-        HIP_CHECK(hipStreamCreateWithFlags(&c->xstream, hipStreamNonBlocking));
-        for (int i = 0; i < 2; ++i) {
-            HIP_CHECK(hipEventCreateWithFlags(&c->ready[i], hipEventDisableTiming));
-            HIP_CHECK(hipEventCreateWithFlags(&c->done[i], hipEventDisableTiming));
+        if (comm_resources(c) != 0) { // unwind: the ranks created so far, the barrier, the group
+            delete c;
+            for (int q = 0; q < r; ++q) {
+                for (int i = 0; i < 2; ++i) { (void)hipEventDestroy(out[q]->ready[i]); (void)hipEventDestroy(out[q]->done[i]); }
+                (void)hipStreamDestroy(out[q]->xstream);
+                delete out[q];
+                out[q] = nullptr;
+            }
+            pthread_barrier_destroy(&g->bar);
+            delete g;
+            return -1;
         }
         out[r] = c;
     }
@@ -187,9 +213,11 @@ extern "C" int lsk_comm_allreduce(lsk_comm *c, void *d_buf, int64_t count, int d
         LocalGroup *g = c->local;
         const size_t es = dtype == 1 ? 4 : 8;
         if ((size_t)count * es > sizeof(g->host[0])) { snprintf(g_cerr, sizeof(g_cerr), "loop-back all-reduce: at most %zu bytes", sizeof(g->host[0])); return -1; }
-        HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
-        HIP_CHECK(hipMemcpy(g->host[c->rank], d_buf, (size_t)count * es, hipMemcpyDeviceToHost));
+        // (a failing copy must not skip a barrier: the other ranks' threads would wait for ever)
+        hipError_t e0 = hipStreamSynchronize((hipStream_t)stream);
+        if (e0 == hipSuccess) e0 = hipMemcpy(g->host[c->rank], d_buf, (size_t)count * es, hipMemcpyDeviceToHost);
         pthread_barrier_wait(&g->bar);
+        if (e0 != hipSuccess) { pthread_barrier_wait(&g->bar); snprintf(g_cerr, sizeof(g_cerr), "loop-back all-reduce: %s", hipGetErrorString(e0)); return -1; }
         double acc[512];
         memcpy(acc, g->host[0], (size_t)count * es);
         for (int r = 1; r < g->size; ++r)
@@ -212,8 +240,10 @@ extern "C" int lsk_comm_broadcast(lsk_comm *c, void *d_buf, int64_t bytes, int r
         HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
         g->post[c->rank].buf = d_buf;
         pthread_barrier_wait(&g->bar);
-        if (c->rank != root) HIP_CHECK(hipMemcpy(d_buf, g->post[root].buf, (size_t)bytes, hipMemcpyDeviceToDevice));
+        hipError_t e0 = hipSuccess;
+        if (c->rank != root) e0 = hipMemcpy(d_buf, g->post[root].buf, (size_t)bytes, hipMemcpyDeviceToDevice);
         pthread_barrier_wait(&g->bar);
+        if (e0 != hipSuccess) { snprintf(g_cerr, sizeof(g_cerr), "loop-back broadcast: %s", hipGetErrorString(e0)); return -1; }
         return 0;
     }
     NCCL_CHECK(g_api.Broadcast(d_buf, d_buf, (size_t)bytes, ncclChar, root, c->comm, (hipStream_t)stream));
@@ -225,9 +255,11 @@ extern "C" int lsk_comm_allgather(lsk_comm *c, void const *d_send, void *d_recv,
         HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
         g->post[c->rank].send = d_send;
         pthread_barrier_wait(&g->bar);
-        for (int r = 0; r < g->size; ++r)
-            HIP_CHECK(hipMemcpy((char *)d_recv + (size_t)r * (size_t)bytes_per_rank, g->post[r].send, (size_t)bytes_per_rank, hipMemcpyDeviceToDevice));
+        hipError_t e0 = hipSuccess;
+        for (int r = 0; r < g->size && e0 == hipSuccess; ++r)
+            e0 = hipMemcpy((char *)d_recv + (size_t)r * (size_t)bytes_per_rank, g->post[r].send, (size_t)bytes_per_rank, hipMemcpyDeviceToDevice);
         pthread_barrier_wait(&g->bar);
+        if (e0 != hipSuccess) { snprintf(g_cerr, sizeof(g_cerr), "loop-back all-gather: %s", hipGetErrorString(e0)); return -1; }
         return 0;
     }
     NCCL_CHECK(g_api.AllGather(d_send, d_recv, (size_t)bytes_per_rank, ncclChar, c->comm, (hipStream_t)stream));
@@ -261,11 +293,13 @@ extern "C" int lsk_comm_alltoallv_on(lsk_comm *c, void *stream, void const *d_se
                 pthread_barrier_wait(&g->bar);
                 return -1;
             }
-            HIP_CHECK(hipMemcpyAsync((char *)d_recv + recv_off[src], (char const *)g->post[src].send + g->post[src].off[c->rank],
-                                     (size_t)recv_bytes[src], hipMemcpyDeviceToDevice, s));
+            const hipError_t e1 = hipMemcpyAsync((char *)d_recv + recv_off[src], (char const *)g->post[src].send + g->post[src].off[c->rank],
+                                                 (size_t)recv_bytes[src], hipMemcpyDeviceToDevice, s);
+            if (e1 != hipSuccess) { pthread_barrier_wait(&g->bar); snprintf(g_cerr, sizeof(g_cerr), "loop-back all-to-all-v: %s", hipGetErrorString(e1)); return -1; }
         }
-        HIP_CHECK(hipStreamSynchronize(s));
+        const hipError_t e2 = hipStreamSynchronize(s);
         pthread_barrier_wait(&g->bar); // nobody reuses a send buffer before every peer has read it
+        if (e2 != hipSuccess) { snprintf(g_cerr, sizeof(g_cerr), "loop-back all-to-all-v: %s", hipGetErrorString(e2)); return -1; }
         return 0;
     }
     NCCL_CHECK(g_api.GroupStart());

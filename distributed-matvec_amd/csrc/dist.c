@@ -61,6 +61,8 @@ int ls_amd_comm_create(ls_amd_comm **out, int size, int rank, void const *id) {
     if (size > LSK_MAX_PARTS) return ls_amd_internal_error("at most %d locales", LSK_MAX_PARTS); /* DMV:664 */
     ls_amd_comm *cm = (ls_amd_comm *)calloc(1, sizeof(*cm));
     if (lsk_comm_create(&cm->c, size, rank, id) != 0) { free(cm); return ls_amd_internal_error("%s", lsk_comm_last_error()); }
+    if (lsk_malloc(&cm->d_scratch, 4096) != 0) { lsk_comm_destroy(cm->c); free(cm); return ls_amd_internal_error("%s", lsk_last_error()); }
+    cm->scratch_bytes = 4096;
     *out = cm;
     return 0;
 }
@@ -75,6 +77,7 @@ int ls_amd_comm_create_local(ls_amd_comm **out, int size) {
     for (int r = 0; r < size; ++r) {
         out[r] = (ls_amd_comm *)calloc(1, sizeof(ls_amd_comm));
         out[r]->c = cs[r];
+        if (lsk_malloc(&out[r]->d_scratch, 4096) == 0) out[r]->scratch_bytes = 4096;
     }
     return 0;
 }
@@ -115,6 +118,21 @@ static int scratch(ls_amd_comm *cm, size_t bytes, void **out) {
     }
     *out = cm->d_scratch;
     return 0;
+}
+
+/* Set-up is collective: a rank that fails locally (an allocation, a plan) must not return while its peers sit in the next
+ * matched collective.  Every block of local work is therefore followed by this agreement -- an all-reduce(max) of the local
+ * status that every rank enters whatever its own status is -- and all ranks fail together.  (An error INSIDE a collective,
+ * or in the middle of ls_amd_dist_matvec / ls_amd_repl_matvec, leaves grouped sends / receives unmatched: it is fatal for
+ * the communicator.) */
+static int agree(ls_amd_comm *cm, int rc, void *stream) {
+    int64_t flag = rc != 0;
+    if (!cm->d_scratch || cm->scratch_bytes < sizeof(flag)) return ls_amd_internal_error("communicator has no scratch buffer");
+    if (lsk_h2d(cm->d_scratch, &flag, sizeof(flag)) != 0 || lsk_comm_allreduce(cm->c, cm->d_scratch, 1, 2, 1, stream) != 0 ||
+        lsk_sync(stream) != 0 || lsk_d2h(&flag, cm->d_scratch, sizeof(flag)) != 0)
+        return ls_amd_internal_error("status agreement failed: %s", lsk_comm_last_error());
+    if (flag && rc == 0) return ls_amd_internal_error("set-up failed on another rank");
+    return flag ? -1 : 0;
 }
 
 /* ============================================================================================ */
@@ -206,8 +224,9 @@ int ls_amd_dist_create(ls_amd_dist **out, ls_amd_comm *cm, ls_hs_operator const 
     /* every rank must run the same number of rounds: the collectives are matched */
     if (num_rounds <= 0) {
         int64_t mx = count_local;
-        TRY(scratch(cm, sizeof(int64_t), &ds));
-        DEVC(lsk_h2d(ds, &mx, sizeof(mx)));
+        int rc0 = scratch(cm, sizeof(int64_t), &ds);
+        if (rc0 == 0 && lsk_h2d(ds, &mx, sizeof(mx)) != 0) rc0 = ls_amd_internal_error("%s", lsk_last_error());
+        TRY(agree(cm, rc0, stream));
         COMM(lsk_comm_allreduce(cm->c, ds, 1, 2, 1, stream));
         DEVC(lsk_sync(stream));
         DEVC(lsk_d2h(&mx, ds, sizeof(mx)));
@@ -219,21 +238,23 @@ int ls_amd_dist_create(ls_amd_dist **out, ls_amd_comm *cm, ls_hs_operator const 
     d->comm = cm; d->P = P; d->me = me; d->rounds = num_rounds;
     uint64_t const *reps[1] = {d_reps_local};
     int64_t counts[1] = {count_local};
-    if (ls_amd_plan_create(&d->plan, op, dtype, P, me, reps, counts, num_rounds, LS_AMD_MODE_AUTO, stream) != 0) { free(d); return -1; }
-    if (ls_amd_plan_num_rounds(d->plan) != num_rounds) { ls_amd_dist_destroy(d); return ls_amd_internal_error("internal error: rounds disagree"); }
-    d->pb = ls_amd_plan_packet_bytes(d->plan);
     size_t const m = (size_t)num_rounds * (size_t)P;
-    d->send_counts = (int64_t *)calloc(m, sizeof(int64_t));
-    d->recv_counts = (int64_t *)calloc(m, sizeof(int64_t));
-    d->send_off = (int64_t *)calloc(m, sizeof(int64_t)); d->send_bytes = (int64_t *)calloc(m, sizeof(int64_t));
-    d->recv_off = (int64_t *)calloc(m, sizeof(int64_t)); d->recv_bytes = (int64_t *)calloc(m, sizeof(int64_t));
-    for (int r = 0; r < num_rounds; ++r)
-        if (ls_amd_plan_send_counts(d->plan, r, d->send_counts + (size_t)r * P) != 0) { ls_amd_dist_destroy(d); return -1; }
+    int rc = ls_amd_plan_create(&d->plan, op, dtype, P, me, reps, counts, num_rounds, LS_AMD_MODE_AUTO, stream);
+    if (rc == 0 && ls_amd_plan_num_rounds(d->plan) != num_rounds) rc = ls_amd_internal_error("internal error: rounds disagree");
+    if (rc == 0) {
+        d->pb = ls_amd_plan_packet_bytes(d->plan);
+        d->send_counts = (int64_t *)calloc(m, sizeof(int64_t));
+        d->recv_counts = (int64_t *)calloc(m, sizeof(int64_t));
+        d->send_off = (int64_t *)calloc(m, sizeof(int64_t)); d->send_bytes = (int64_t *)calloc(m, sizeof(int64_t));
+        d->recv_off = (int64_t *)calloc(m, sizeof(int64_t)); d->recv_bytes = (int64_t *)calloc(m, sizeof(int64_t));
+        for (int r = 0; r < num_rounds && rc == 0; ++r) rc = ls_amd_plan_send_counts(d->plan, r, d->send_counts + (size_t)r * P);
+    }
     /* counts matrix, once: everybody learns everybody's [rounds][P] send counts (no per-round size exchange) */
     int64_t *all = (int64_t *)calloc(m * (size_t)P, sizeof(int64_t));
-    int rc = scratch(cm, sizeof(int64_t) * m * (size_t)(P + 1), &ds);
+    if (rc == 0) rc = scratch(cm, sizeof(int64_t) * m * (size_t)(P + 1), &ds);
     if (rc == 0 && lsk_h2d(ds, d->send_counts, sizeof(int64_t) * m) != 0) rc = ls_amd_internal_error("%s", lsk_last_error());
-    if (rc == 0 && lsk_comm_allgather(cm->c, ds, (char *)ds + sizeof(int64_t) * m, (int64_t)(sizeof(int64_t) * m), stream) != 0)
+    if (agree(cm, rc, stream) != 0) { free(all); ls_amd_dist_destroy(d); return -1; } /* plan + staging exist on every rank, or on none */
+    if (lsk_comm_allgather(cm->c, ds, (char *)ds + sizeof(int64_t) * m, (int64_t)(sizeof(int64_t) * m), stream) != 0)
         rc = ls_amd_internal_error("%s", lsk_comm_last_error());
     if (rc == 0 && (lsk_sync(stream) != 0 || lsk_d2h(all, (char *)ds + sizeof(int64_t) * m, sizeof(int64_t) * m * (size_t)P) != 0))
         rc = ls_amd_internal_error("%s", lsk_last_error());
@@ -252,13 +273,12 @@ int ls_amd_dist_create(ls_amd_dist **out, ls_amd_comm *cm, ls_hs_operator const 
         d->exchange_bytes += so;
     }
     free(all);
-    for (int i = 0; i < 2; ++i) {
+    rc = 0;
+    for (int i = 0; i < 2 && rc == 0; ++i)
         if (lsk_malloc(&d->d_send[i], (size_t)(max_send > 0 ? max_send : 8)) != 0 ||
-            lsk_malloc(&d->d_recv[i], (size_t)(max_recv > 0 ? max_recv : 8)) != 0) {
-            ls_amd_dist_destroy(d);
-            return ls_amd_internal_error("%s", lsk_last_error());
-        }
-    }
+            lsk_malloc(&d->d_recv[i], (size_t)(max_recv > 0 ? max_recv : 8)) != 0)
+            rc = ls_amd_internal_error("%s", lsk_last_error());
+    if (agree(cm, rc, stream) != 0) { ls_amd_dist_destroy(d); return -1; } /* nobody enters a matvec some peer cannot serve */
     *out = d;
     return 0;
 }
@@ -372,8 +392,13 @@ int ls_amd_repl_create(ls_amd_repl **out, ls_amd_comm *cm, ls_hs_operator const 
      * writes); the owners send x * norm(rep). */
     int indexed = ls_amd_internal_basis_is_projected(op->basis);
     { char const *e = getenv("LS_AMD_REPL_INDEXED"); if (e && atoi(e) == 0) indexed = 0; }
+    int const want_indexed = indexed;
     if (indexed && ls_amd_internal_gtab_acquire(&r->gt, op->basis->number_sites, d_reps_global, count_global, d_masks, P, stream) != 0) {
-        r->gt = NULL; /* no admissible table (more than 2^32 - 1 slots, ...): the permutation path */
+        r->gt = NULL; /* no admissible table (more than 2^32 - 1 slots, no memory, ...): the permutation path */
+        indexed = 0;
+    }
+    if (want_indexed && agree(cm, !indexed, stream) != 0) { /* the layout of the exchange is one decision of all ranks */
+        if (r->gt) { ls_amd_internal_gtab_release(r->gt); r->gt = NULL; }
         indexed = 0;
     }
     if (indexed) {
@@ -424,6 +449,7 @@ int ls_amd_repl_create(ls_amd_repl **out, ls_amd_comm *cm, ls_hs_operator const 
     void *ds;
     if (rc == 0) rc = scratch(cm, 8 * (size_t)P * (size_t)(P + 1), &ds);
     if (rc == 0 && lsk_h2d(ds, ycounts, 8 * (size_t)P) != 0) rc = ls_amd_internal_error("%s", lsk_last_error());
+    rc = agree(cm, rc, stream); /* every rank enters the all-gather below, or none does */
     if (rc == 0 && lsk_comm_allgather(cm->c, ds, (char *)ds + 8 * P, 8 * P, stream) != 0) rc = ls_amd_internal_error("%s", lsk_comm_last_error());
     if (rc == 0 && (lsk_sync(stream) != 0 || lsk_d2h(all, (char *)ds + 8 * P, 8 * (size_t)P * (size_t)P) != 0)) rc = ls_amd_internal_error("%s", lsk_last_error());
     int64_t so = 0, ro = 0, mine = 0;
@@ -453,7 +479,7 @@ int ls_amd_repl_create(ls_amd_repl **out, ls_amd_comm *cm, ls_hs_operator const 
         if (rc == 0 && ls_amd_internal_plan_prescales(r->plan)) rc = ls_amd_internal_owner_norms(op, r->gt, me, &r->d_norms_own, stream);
     } else if (rc == 0)
         rc = ls_amd_plan_create_replicated(&r->plan, op, dtype, P, me, d_reps_global + r->n0, nb, d_reps_global, count_global, stream);
-    if (rc != 0) { ls_amd_repl_destroy(r); return -1; }
+    if (agree(cm, rc, stream) != 0) { ls_amd_repl_destroy(r); return -1; } /* buffers and plan exist on every rank, or the object on none */
     *out = r;
     return 0;
 }

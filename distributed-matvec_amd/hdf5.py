@@ -156,7 +156,9 @@ def write_datasets(path: str, datasets: dict, append: bool = False):
     """writes every {"/group/name": array}; intermediate groups are created (makeGroup + writeDataset,
     MyHDF5.chpl:288-333).  append=False creates / truncates `path`; append=True opens an existing file read-write
     and adds the datasets to it (the reference keeps basis/representatives in the output file and adds the
-    hamiltonian group later, Diagonalize.chpl:227-256); datasets that already exist are left as they are."""
+    hamiltonian group later, Diagonalize.chpl:227-256): an existing /basis/* dataset is left as it is (it is what the run
+    was computed from; diagonalize() validates it against the configured basis before using it), every other existing
+    dataset -- hamiltonian/* of an earlier run -- is deleted and replaced."""
     import os
 
     L = lib()

@@ -125,3 +125,20 @@ def test_diagonalize_reuses_stored_representatives(tmp_path):
     assert not calls, "stored representatives were re-enumerated"
     assert abs(r1.eigenvalues[0] - r2.eigenvalues[0]) < 1e-9
     assert hdf5.read_dataset(out, "/basis/representatives").shape == (126,)
+
+
+@pytest.mark.gpu
+def test_diagonalize_refuses_a_stale_output_file(tmp_path):
+    """an output file whose /basis/representatives belongs to ANOTHER model or sector is an error, not a silent wrong answer"""
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.fail("needs a HIP device")
+    from distributed_matvec_amd import api
+    from distributed_matvec_amd.diagonalize import diagonalize
+
+    out = str(tmp_path / "ed.h5")
+    diagonalize(model_config("heisenberg_chain_12"), num_evals=1, eps=1e-8, output=out)  # 924 states of 12 sites
+    for other in ("heisenberg_chain_10", "heisenberg_chain_16", "heisenberg_kagome_12_symm"):
+        with pytest.raises(api.LsAmdError, match="does not belong"):
+            diagonalize(model_config(other), num_evals=1, eps=1e-8, output=out)
