@@ -235,6 +235,9 @@ def diagonalize(config, num_evals: int = 1, eps: float = 1e-6, num_partitions: i
                                            flags.ctypes.data_as(api.C.POINTER(api.C.c_uint8)), norms.ctypes.data_as(api._lib.c_f64p))
                 api._lib.raise_pending_halt()
                 ok = bool(np.all(flags == 1) and np.all(norms > 0))
+                hw = basis.spec.hamming_weight if getattr(basis, "spec", None) is not None else -1
+                if ok and hw >= 0:
+                    ok = bool(np.all(np.bitwise_count(sample) == hw))
             if not ok:
                 raise api.LsAmdError(f"halt: /basis/representatives of '{output}' does not belong to the configured basis "
                                      "(stale output file?); remove the dataset or the file")
