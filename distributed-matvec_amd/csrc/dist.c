@@ -48,6 +48,7 @@ struct ls_amd_comm {
     lsk_comm *c;
     void *d_scratch; /* staging for the host-pointer reductions and the set-up collectives */
     size_t scratch_bytes;
+    void *d_status;  /* 8 bytes of its own for the status agreement (the scratch buffer may hold staged data at that point) */
 };
 
 static ls_amd_comm *g_default_comm = NULL;
@@ -61,8 +62,7 @@ int ls_amd_comm_create(ls_amd_comm **out, int size, int rank, void const *id) {
     if (size > LSK_MAX_PARTS) return ls_amd_internal_error("at most %d locales", LSK_MAX_PARTS); /* DMV:664 */
     ls_amd_comm *cm = (ls_amd_comm *)calloc(1, sizeof(*cm));
     if (lsk_comm_create(&cm->c, size, rank, id) != 0) { free(cm); return ls_amd_internal_error("%s", lsk_comm_last_error()); }
-    if (lsk_malloc(&cm->d_scratch, 4096) != 0) { lsk_comm_destroy(cm->c); free(cm); return ls_amd_internal_error("%s", lsk_last_error()); }
-    cm->scratch_bytes = 4096;
+    if (lsk_malloc(&cm->d_status, 8) != 0) { lsk_comm_destroy(cm->c); free(cm); return ls_amd_internal_error("%s", lsk_last_error()); }
     *out = cm;
     return 0;
 }
@@ -77,7 +77,7 @@ int ls_amd_comm_create_local(ls_amd_comm **out, int size) {
     for (int r = 0; r < size; ++r) {
         out[r] = (ls_amd_comm *)calloc(1, sizeof(ls_amd_comm));
         out[r]->c = cs[r];
-        if (lsk_malloc(&out[r]->d_scratch, 4096) == 0) out[r]->scratch_bytes = 4096;
+        if (lsk_malloc(&out[r]->d_status, 8) != 0) out[r]->d_status = NULL; /* agree() reports it */
     }
     return 0;
 }
@@ -87,6 +87,7 @@ void ls_amd_comm_destroy(ls_amd_comm *cm) {
     if (g_default_comm == cm) g_default_comm = NULL;
     ls_amd_internal_forget_comm(cm);
     if (cm->d_scratch) lsk_free(cm->d_scratch);
+    if (cm->d_status) lsk_free(cm->d_status);
     lsk_comm_destroy(cm->c);
     free(cm);
 }
@@ -127,9 +128,9 @@ static int scratch(ls_amd_comm *cm, size_t bytes, void **out) {
  * the communicator.) */
 static int agree(ls_amd_comm *cm, int rc, void *stream) {
     int64_t flag = rc != 0;
-    if (!cm->d_scratch || cm->scratch_bytes < sizeof(flag)) return ls_amd_internal_error("communicator has no scratch buffer");
-    if (lsk_h2d(cm->d_scratch, &flag, sizeof(flag)) != 0 || lsk_comm_allreduce(cm->c, cm->d_scratch, 1, 2, 1, stream) != 0 ||
-        lsk_sync(stream) != 0 || lsk_d2h(&flag, cm->d_scratch, sizeof(flag)) != 0)
+    if (!cm->d_status) return ls_amd_internal_error("communicator has no status buffer");
+    if (lsk_h2d(cm->d_status, &flag, sizeof(flag)) != 0 || lsk_comm_allreduce(cm->c, cm->d_status, 1, 2, 1, stream) != 0 ||
+        lsk_sync(stream) != 0 || lsk_d2h(&flag, cm->d_status, sizeof(flag)) != 0)
         return ls_amd_internal_error("status agreement failed: %s", lsk_comm_last_error());
     if (flag && rc == 0) return ls_amd_internal_error("set-up failed on another rank");
     return flag ? -1 : 0;

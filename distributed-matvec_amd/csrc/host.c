@@ -1590,6 +1590,38 @@ int lsk_sibplan_host(lsk_sibplan *sp, lsk_sibtab *tb, int L, int hw, int nl, int
             if ((int)binom(nl, kL) > sp->max_block) sp->max_block = (int)binom(nl, kL);
         }
     sp->n_units = n;
+    {
+        /* LS_AMD_SIB_L2SETS=v (experiment): order the units so that those which differ only inside the top v bits of `mid`
+         * (same weight there) are consecutive -- dispatched back to back onto one XCD, their far-pair gathers can meet each
+         * other's window loads in that XCD's L2 instead of sharing an LDS window */
+        char const *e = getenv("LS_AMD_SIB_L2SETS");
+        int const vs = e ? atoi(e) : 0;
+        if (vs > 0 && vs <= nm && n > 1) {
+            uint64_t *keys = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)n);
+            for (int64_t i = 0; i < n; ++i) {
+                uint32_t const mid = units[i].mid >> nl, top = mid >> (nm - vs), low = mid & ((1u << (nm - vs)) - 1u);
+                uint64_t const jT = units[i].kL_jT >> 8;
+                keys[i] = (jT << 56) | ((uint64_t)__builtin_popcount(top) << 48) | ((uint64_t)low << 16) | ((uint64_t)top << 8);
+            }
+            /* insertion of the key into the unit for qsort: sort an index array */
+            int64_t *idx = (int64_t *)malloc(sizeof(int64_t) * (size_t)n);
+            for (int64_t i = 0; i < n; ++i) idx[i] = i;
+            /* simple LSD radix on 64-bit keys (n up to a few 10^5) */
+            int64_t *tmp = (int64_t *)malloc(sizeof(int64_t) * (size_t)n);
+            for (int pass = 0; pass < 8; ++pass) {
+                size_t cnt256[257];
+                memset(cnt256, 0, sizeof(cnt256));
+                for (int64_t i = 0; i < n; ++i) ++cnt256[((keys[idx[i]] >> (8 * pass)) & 0xff) + 1];
+                for (int b = 0; b < 256; ++b) cnt256[b + 1] += cnt256[b];
+                for (int64_t i = 0; i < n; ++i) tmp[cnt256[(keys[idx[i]] >> (8 * pass)) & 0xff]++] = idx[i];
+                int64_t *sw = idx; idx = tmp; tmp = sw;
+            }
+            lsk_sib_unit *sorted = (lsk_sib_unit *)malloc(sizeof(lsk_sib_unit) * (size_t)cap);
+            for (int64_t i = 0; i < n; ++i) sorted[i] = units[idx[i]];
+            free(units); free(keys); free(idx); free(tmp);
+            units = sorted;
+        }
+    }
     /* XCD lists: chunks of consecutive units dealt round-robin (consecutive units = neighbouring blocks of every sibling) */
     if (chunk < 1) chunk = 1;
     int64_t per[8] = {0, 0, 0, 0, 0, 0, 0, 0};
