@@ -63,6 +63,11 @@ class LsHsOperator(C.Structure):
     ]
 
 
+class YamlConfig(C.Structure):  # ls_hs_yaml_config (include/ls_hs.h; /root/reference/src/FFI.chpl:121-126)
+    _fields_ = [("basis", C.POINTER(LsHsBasis)), ("hamiltonian", C.POINTER(LsHsOperator)), ("number_observables", C.c_int),
+                ("observables", C.POINTER(C.POINTER(LsHsOperator)))]
+
+
 class LsAmdError(RuntimeError):
     pass
 
@@ -179,6 +184,9 @@ def load():
         "ls_hs_destroy_basis": (None, [bp]),
         "ls_hs_create_operator_from_terms": (op, [bp, C.c_int, c_f64p, c_u64p, c_u64p, c_u64p, c_u64p]),
         "ls_hs_clone_operator": (op, [op]),
+        "ls_hs_load_yaml_config": (C.POINTER(YamlConfig), [C.c_char_p]),
+        "ls_amd_load_yaml_config_from_string": (C.POINTER(YamlConfig), [C.c_char_p]),
+        "ls_hs_destroy_yaml_config": (None, [C.POINTER(YamlConfig)]),
         "ls_hs_destroy_operator": (None, [op]),
         "ls_hs_min_state_estimate": (C.c_uint64, [bp]),
         "ls_hs_max_state_estimate": (C.c_uint64, [bp]),

@@ -252,15 +252,30 @@ def loadConfigFromDict(cfg: dict, hamiltonian: bool = False, observables: bool =
 
 
 def loadConfigFromYaml(filename: str, hamiltonian: bool = False, observables: bool = False):
-    """ForeignTypes.chpl:261-288."""
-    import yaml
-
+    """ForeignTypes.chpl:261-288, step by step: ls_hs_load_yaml_config (the C library's own loader, csrc/yaml.c) -> clone
+    basis / hamiltonian / observables -> ls_hs_destroy_yaml_config."""
+    L = _lib.load()
+    conf = L.ls_hs_load_yaml_config(filename.encode())
+    if not conf:
+        raise LsAmdError(f"halt: failed to load Config from '{filename}' ({L.ls_amd_last_error().decode()})")
     try:
-        with open(filename, "r", encoding="utf-8") as f:
-            cfg = yaml.safe_load(f)
-    except OSError as e:
-        raise LsAmdError(f"halt: failed to load Config from '{filename}'") from e
-    return loadConfigFromDict(cfg, hamiltonian, observables)
+        c = conf.contents
+        basis = Basis(L.ls_hs_clone_basis(c.basis), owning=True)
+        h = None
+        if hamiltonian:
+            if not c.hamiltonian:
+                raise LsAmdError(f"halt: '{filename}' does not contain a Hamiltonian")  # ForeignTypes.chpl:273-274
+            h = Operator(L.ls_hs_clone_operator(c.hamiltonian), owning=True)
+        obs = [Operator(L.ls_hs_clone_operator(c.observables[i]), owning=True) for i in range(c.number_observables)] if observables else []
+    finally:
+        L.ls_hs_destroy_yaml_config(conf)
+    if not hamiltonian and not observables:
+        return basis
+    if hamiltonian and not observables:
+        return basis, h
+    if not hamiltonian and observables:
+        return basis, obs
+    return basis, h, obs
 
 
 # ------------------------------------------------------------------------------------------------

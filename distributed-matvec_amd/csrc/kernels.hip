@@ -2247,7 +2247,7 @@ __global__ __launch_bounds__(kBlock) void k_tile_pull_idx(lsk_runs runs, int n_g
                                                           int *err) {
     typedef typename ChainX<CPLX>::type X;
     X const *__restrict__ xv = (X const *)xsrc;
-    __shared__ uint32_t s_win[kPullWin];
+    extern __shared__ uint32_t s_win[]; // [kBlock + 2 * halo]: sized at launch, so that a smaller window buys resident blocks
     __shared__ uint64_t s_beta[kCapPull];
     constexpr bool RC = REAL && PM1;
     __shared__ double s_coef[kCapPull * (RC ? 1 : 2)];
@@ -2410,14 +2410,15 @@ extern "C" int lsk_tile_pull_idx(lsk_operator op, lsk_basis bs, int cplx, int64_
     hipStream_t s = (hipStream_t)stream;
 #define LSK_TPI_ARGS op.runs, op.n_groups, op.groups, op.off, op.n_diag, op.diag, bs, bs.elems, row0, row1, reps, norms_local, ix, \
         reps_global, n_global, (double const *)xsrc, halo, (double *)y, d_err
+    const size_t win_bytes = sizeof(uint32_t) * (size_t)(kBlock + 2 * halo);
 #define LSK_TPI_LAUNCH(W, PM1)                                                                                  \
     do {                                                                                                        \
         if (cplx) {                                                                                             \
-            if (op.is_real) { g.x = tile_grid(k_tile_pull_idx<W, PM1, true, true>, work_blocks); hipLaunchKernelGGL((k_tile_pull_idx<W, PM1, true, true>), g, b, 0, s, LSK_TPI_ARGS); } \
-            else { g.x = tile_grid(k_tile_pull_idx<W, PM1, true, false>, work_blocks); hipLaunchKernelGGL((k_tile_pull_idx<W, PM1, true, false>), g, b, 0, s, LSK_TPI_ARGS); } \
+            if (op.is_real) { g.x = tile_grid(k_tile_pull_idx<W, PM1, true, true>, work_blocks); hipLaunchKernelGGL((k_tile_pull_idx<W, PM1, true, true>), g, b, win_bytes, s, LSK_TPI_ARGS); } \
+            else { g.x = tile_grid(k_tile_pull_idx<W, PM1, true, false>, work_blocks); hipLaunchKernelGGL((k_tile_pull_idx<W, PM1, true, false>), g, b, win_bytes, s, LSK_TPI_ARGS); } \
         } else {                                                                                                \
-            if (op.is_real) { g.x = tile_grid(k_tile_pull_idx<W, PM1, false, true>, work_blocks); hipLaunchKernelGGL((k_tile_pull_idx<W, PM1, false, true>), g, b, 0, s, LSK_TPI_ARGS); } \
-            else { g.x = tile_grid(k_tile_pull_idx<W, PM1, false, false>, work_blocks); hipLaunchKernelGGL((k_tile_pull_idx<W, PM1, false, false>), g, b, 0, s, LSK_TPI_ARGS); } \
+            if (op.is_real) { g.x = tile_grid(k_tile_pull_idx<W, PM1, false, true>, work_blocks); hipLaunchKernelGGL((k_tile_pull_idx<W, PM1, false, true>), g, b, win_bytes, s, LSK_TPI_ARGS); } \
+            else { g.x = tile_grid(k_tile_pull_idx<W, PM1, false, false>, work_blocks); hipLaunchKernelGGL((k_tile_pull_idx<W, PM1, false, false>), g, b, win_bytes, s, LSK_TPI_ARGS); } \
         }                                                                                                       \
     } while (0)
     if (bs.number_sites <= 32) { if (bs.chars_pm1) LSK_TPI_LAUNCH(uint32_t, true); else LSK_TPI_LAUNCH(uint32_t, false); }

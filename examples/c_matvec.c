@@ -2,7 +2,9 @@
  *
  * What the reference's hosts do through the plug-in table (/root/reference/src/library.c:19-34,
  * /root/reference/src/DistributedMatrixVector.chpl:1095-1110), spelled out:
- *   ls_chpl_init -> build a basis and an operator -> ls_hs_basis_build (the registered enumerate_states kernel)
+ *   ls_chpl_init -> a basis and an operator, either loaded from a YAML file of the reference's schema by the library itself
+ *   (c_matvec model.yaml: ls_hs_load_yaml_config) or built from flat term arrays (c_matvec L) -> ls_hs_basis_build (the
+ *   registered enumerate_states kernel)
  *   -> kernels->matrix_vector_product(op, 1, x, y) on host arrays,
  * then the same product through the device-level API with 3 hash partitions (ls_amd_matvec) and, when librccl is
  * there, through the one-locale-per-process path with a single rank (ls_amd_dist_matvec) -- all three must agree.
@@ -23,21 +25,38 @@
 #define CHECK(expr) do { if ((expr) != 0) { fprintf(stderr, "%s failed: %s\n", #expr, ls_amd_last_error()); return 1; } } while (0)
 
 int main(int argc, char **argv) {
-    int const L = argc > 1 ? atoi(argv[1]) : 16;
+    char const *arg = argc > 1 ? argv[1] : "16";
+    size_t const alen = strlen(arg);
+    int const from_yaml = alen > 5 && strcmp(arg + alen - 5, ".yaml") == 0;
+    int L = from_yaml ? 0 : atoi(arg);
     ls_chpl_init();
-    ls_hs_basis *basis = ls_hs_create_spin_basis(L, L / 2, 0, 0, NULL, NULL);
-    if (!basis) { fprintf(stderr, "%s\n", ls_amd_last_error()); return 1; }
-    /* terms: per bond one diagonal term and two off-diagonal ones (01 -> 10 and 10 -> 01) */
-    int const nt = 3 * L;
-    double *v = calloc(2 * (size_t)nt, sizeof(double));
-    uint64_t *m = calloc(nt, 8), *r = calloc(nt, 8), *x = calloc(nt, 8), *s = calloc(nt, 8);
-    for (int b = 0; b < L; ++b) {
-        uint64_t const i = 1ULL << b, j = 1ULL << ((b + 1) % L), pair = i | j;
-        v[2 * (3 * b)] = 1.0; m[3 * b] = 0; r[3 * b] = 0; x[3 * b] = 0; s[3 * b] = pair;       /* zz */
-        v[2 * (3 * b + 1)] = 2.0; m[3 * b + 1] = pair; r[3 * b + 1] = i; x[3 * b + 1] = pair;   /* |..1..0..> -> |..0..1..> */
-        v[2 * (3 * b + 2)] = 2.0; m[3 * b + 2] = pair; r[3 * b + 2] = j; x[3 * b + 2] = pair;
+    ls_hs_basis *basis;
+    ls_hs_operator *op;
+    if (from_yaml) {
+        /* loadConfigFromYaml (/root/reference/src/ForeignTypes.chpl:261-288): load, clone what is wanted, destroy the config */
+        ls_hs_yaml_config *conf = ls_hs_load_yaml_config(arg);
+        if (!conf) { fprintf(stderr, "failed to load Config from '%s': %s\n", arg, ls_amd_last_error()); return 1; }
+        if (!conf->hamiltonian) { fprintf(stderr, "'%s' does not contain a Hamiltonian\n", arg); return 1; }
+        basis = ls_hs_clone_basis(conf->basis);
+        op = ls_hs_clone_operator(conf->hamiltonian);
+        ls_hs_destroy_yaml_config(conf);
+        L = basis->number_sites;
+    } else {
+        basis = ls_hs_create_spin_basis(L, L / 2, 0, 0, NULL, NULL);
+        if (!basis) { fprintf(stderr, "%s\n", ls_amd_last_error()); return 1; }
+        /* terms: per bond one diagonal term and two off-diagonal ones (01 -> 10 and 10 -> 01) */
+        int const nt = 3 * L;
+        double *v = calloc(2 * (size_t)nt, sizeof(double));
+        uint64_t *m = calloc(nt, 8), *r = calloc(nt, 8), *x = calloc(nt, 8), *s = calloc(nt, 8);
+        for (int b = 0; b < L; ++b) {
+            uint64_t const i = 1ULL << b, j = 1ULL << ((b + 1) % L), pair = i | j;
+            v[2 * (3 * b)] = 1.0; m[3 * b] = 0; r[3 * b] = 0; x[3 * b] = 0; s[3 * b] = pair;       /* zz */
+            v[2 * (3 * b + 1)] = 2.0; m[3 * b + 1] = pair; r[3 * b + 1] = i; x[3 * b + 1] = pair;   /* |..1..0..> -> |..0..1..> */
+            v[2 * (3 * b + 2)] = 2.0; m[3 * b + 2] = pair; r[3 * b + 2] = j; x[3 * b + 2] = pair;
+        }
+        op = ls_hs_create_operator_from_terms(basis, nt, v, m, r, x, s);
+        free(v); free(m); free(r); free(x); free(s);
     }
-    ls_hs_operator *op = ls_hs_create_operator_from_terms(basis, nt, v, m, r, x, s);
     if (!op) { fprintf(stderr, "%s\n", ls_amd_last_error()); return 1; }
     if (!ls_hs_operator_is_hermitian(op) || !ls_hs_operator_is_real(op)) { fprintf(stderr, "operator flags\n"); return 1; }
 

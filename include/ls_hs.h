@@ -112,6 +112,22 @@ ls_hs_operator *ls_hs_create_operator_from_terms(ls_hs_basis const *basis, int n
 ls_hs_operator *ls_hs_clone_operator(ls_hs_operator const *op); /* FFI.chpl:193 */
 void ls_hs_destroy_operator(ls_hs_operator *op);                /* FFI.chpl:196 */
 
+/* /root/reference/src/FFI.chpl:121-126: what ls_hs_load_yaml_config hands back; loadConfigFromYaml
+ * (/root/reference/src/ForeignTypes.chpl:261-288) clones basis / hamiltonian / observables out of it and destroys it */
+typedef struct ls_hs_yaml_config {
+    ls_hs_basis *basis;
+    ls_hs_operator *hamiltonian; /* NULL when the file has no `hamiltonian` section */
+    int number_observables;
+    ls_hs_operator **observables;
+} ls_hs_yaml_config;
+/* /root/reference/src/FFI.chpl:208-209.  The YAML subset of the YAML files under /root/reference/data (basis: number_spins, hamming_weight,
+ * spin_inversion, symmetries; hamiltonian / observables: terms of `expression` + `sites`; anchors and aliases, block and
+ * flow collections).  NULL on failure, with the reason in ls_amd_last_error(). */
+ls_hs_yaml_config *ls_hs_load_yaml_config(char const *filename);
+void ls_hs_destroy_yaml_config(ls_hs_yaml_config *config);
+/* the same from a NUL-terminated YAML text in memory (not in the reference's ABI) */
+ls_hs_yaml_config *ls_amd_load_yaml_config_from_string(char const *text);
+
 uint64_t ls_hs_min_state_estimate(ls_hs_basis const *basis);            /* FFI.chpl:143 */
 uint64_t ls_hs_max_state_estimate(ls_hs_basis const *basis);            /* FFI.chpl:144 */
 int ls_hs_basis_number_bits(ls_hs_basis const *basis);                  /* FFI.chpl:145 */

@@ -11,17 +11,25 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("L", [12, 18])
+@pytest.mark.parametrize("L", [12, 18, "yaml-16"])
 def test_c_caller(tmp_path, L):
     from oracle import c_oracle as CO
     from oracle import model as M
 
+    arg = str(L)
+    if isinstance(L, str):  # the model comes from a YAML file in the reference's layout, loaded by the C library itself
+        from test_yaml_loader import reference_style
+
+        L = int(L.split("-")[1])
+        arg = str(tmp_path / f"heisenberg_chain_{L}.yaml")
+        with open(arg, "w", encoding="utf-8") as f:
+            f.write(reference_style(M.heisenberg_chain_config(L)))
     exe = str(tmp_path / "c_matvec")
     libdir = os.path.join(ROOT, "distributed-matvec_amd")
     subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "examples", "c_matvec.c"), "-L", libdir, "-lls_amd", f"-Wl,-rpath,{libdir}", "-lm",
                            "-o", exe])
-    out = subprocess.run([exe, str(L)], capture_output=True, text=True, timeout=600)
+    out = subprocess.run([exe, arg], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.strip().endswith("OK"), out.stdout
     m = re.search(r"N = (\d+), <x\|H\|x>/<x\|x> = (-?[\d.]+)", out.stdout)

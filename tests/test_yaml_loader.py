@@ -1,0 +1,177 @@
+"""ls_hs_load_yaml_config in the C library (csrc/yaml.c; /root/reference/src/FFI.chpl:121-126,208-209,
+/root/reference/src/ForeignTypes.chpl:261-288): the YAML subset of the reference's data files parsed and compiled by the
+library itself -- a C or Chapel caller needs no Python.  Checked against the Python mirror (PyYAML + config.py, an independent
+implementation of the same compilation) on every model of tests/golden/models.json written out in two YAML styles, and on
+the reference's own files when the reference tree is present (this container; never on the GPU box)."""
+import ctypes as C
+import glob
+import os
+
+import numpy as np
+import pytest
+import yaml
+
+import distributed_matvec_amd as D
+from distributed_matvec_amd import _lib
+from helpers import golden, product_terms
+
+
+def reference_style(cfg):
+    """the layout of the reference's data files: flow sequences (wrapped over several lines), anchored lattices, comments"""
+    b = cfg["basis"]
+    out = ["# written by tests/test_yaml_loader.py", "basis:", f"  number_spins: {b['number_spins']}"]
+    out.append(f"  hamming_weight: {'null' if b.get('hamming_weight') is None else b['hamming_weight']}")
+    if b.get("spin_inversion") is not None:
+        out.append(f"  spin_inversion: {b['spin_inversion']}")
+    syms = b.get("symmetries") or []
+    out.append("  symmetries:" + ("" if syms else " []"))
+    for s in syms:
+        perm = s["permutation"]
+        rows = [", ".join(f"{v:2d}" for v in perm[i:i + 4]) for i in range(0, len(perm), 4)]
+        out.append("    # a generator")
+        out.append("    - permutation: [" + (",\n                    ").join(rows) + "]")
+        out.append(f"      sector: {s['sector']}")
+    if cfg.get("hamiltonian"):
+        out += ["hamiltonian:", '  name: "Heisenberg Hamiltonian"']
+        lattices = []
+        for t in cfg["hamiltonian"]["terms"]:
+            if t["sites"] not in lattices:
+                lattices.append(t["sites"])
+        for k, lat in enumerate(lattices):
+            body = ", ".join(str(list(p)) for p in lat)
+            out.append(f"  lattice_{k}: &lattice_{k} [{body}]  # bonds")
+        out.append("  terms:")
+        for t in cfg["hamiltonian"]["terms"]:
+            out.append(f'    - expression: "{t["expression"]}"')
+            out.append(f"      sites: *lattice_{lattices.index(t['sites'])}")
+    out.append("observables: []")
+    return "\n".join(out) + "\n"
+
+
+def load_c(text):
+    L = _lib.load()
+    conf = L.ls_amd_load_yaml_config_from_string(text.encode("utf-8"))
+    if not conf:
+        raise D.LsAmdError(L.ls_amd_last_error().decode())
+    return conf
+
+
+def same_model(conf, cfg):
+    L = _lib.load()
+    c = conf.contents
+    basis, h = D.loadConfigFromDict(cfg, hamiltonian=True)
+    b = c.basis.contents
+    assert (b.number_sites, b.spin_inversion, bool(b.requires_projection)) == (basis.numberSites(), basis.spinInversion(), basis.requiresProjection())
+    order = L.ls_amd_basis_group_order(c.basis)
+    assert order == basis.groupOrder()
+    rs = np.random.RandomState(3)
+    for _ in range(16):  # the same group: every element maps every state alike, with the same character
+        g = int(rs.randint(order))
+        st = int(rs.randint(0, 1 << min(62, b.number_sites)))
+        assert L.ls_amd_basis_apply_group_element(c.basis, g, C.c_uint64(st)) == L.ls_amd_basis_apply_group_element(basis.payload, g, C.c_uint64(st))
+        ch = [(C.c_double(), C.c_double()) for _ in range(2)]
+        L.ls_amd_basis_group_character(c.basis, g, C.byref(ch[0][0]), C.byref(ch[0][1]))
+        L.ls_amd_basis_group_character(basis.payload, g, C.byref(ch[1][0]), C.byref(ch[1][1]))
+        assert (ch[0][0].value, ch[0][1].value) == (ch[1][0].value, ch[1][1].value)
+    assert int(L.ls_hs_min_state_estimate(c.basis)) == basis.minStateEstimate()
+    assert int(L.ls_hs_max_state_estimate(c.basis)) == basis.maxStateEstimate()
+    op_c = D.Operator(c.hamiltonian, owning=False)
+    assert product_terms(op_c) == product_terms(h)
+    assert op_c.isHermitian == h.isHermitian and op_c.isReal == h.isReal and op_c.numberOffDiagTerms() == h.numberOffDiagTerms()
+
+
+@pytest.mark.parametrize("name", sorted(golden()["models"]))
+@pytest.mark.parametrize("style", ["reference", "pyyaml-block", "pyyaml-flow"])
+def test_c_loader_equals_python_mirror(name, style):
+    cfg = golden()["models"][name]["config"]
+    if style == "reference":
+        text = reference_style(cfg)
+    else:
+        text = yaml.safe_dump(cfg, allow_unicode=True, default_flow_style=(style == "pyyaml-flow") and None)
+    assert yaml.safe_load(text)["basis"]["number_spins"] == cfg["basis"]["number_spins"]
+    conf = load_c(text)
+    try:
+        same_model(conf, cfg)
+    finally:
+        _lib.load().ls_hs_destroy_yaml_config(conf)
+
+
+def test_reference_data_files_when_present():
+    files = sorted(glob.glob("/root/reference/data/*.yaml"))
+    if not files:
+        pytest.skip("the reference tree is not mounted (GPU box)")
+    L = _lib.load()
+    for f in files:
+        with open(f, encoding="utf-8") as fh:
+            cfg = yaml.safe_load(fh)
+        conf = L.ls_hs_load_yaml_config(f.encode())
+        assert conf, (f, L.ls_amd_last_error().decode())
+        try:
+            same_model(conf, cfg)
+        finally:
+            L.ls_hs_destroy_yaml_config(conf)
+    # and through the host mirror of loadConfigFromYaml, which now is load -> clone -> destroy as in ForeignTypes.chpl:261-288
+    basis, h = D.loadConfigFromYaml("/root/reference/data/heisenberg_chain_10.yaml", hamiltonian=True)
+    assert basis.numberSites() == 10 and basis.spinInversion() == -1 and h.numberOffDiagTerms() == 10
+
+
+def test_observables_and_missing_sections(tmp_path):
+    text = """
+basis:
+  number_spins: 4
+  hamming_weight: 2
+hamiltonian:
+  terms:
+    - expression: "σᶻ₀ σᶻ₁"
+      sites: [[0, 1], [1, 2]]
+observables:
+  - name: staggered
+    terms:
+      - expression: "0.5 × σᶻ₀"
+        sites: [[0], [2]]
+      - expression: "-0.5 × σᶻ₀"
+        sites: [[1], [3]]
+  - terms:
+    - expression: "σ⁺₀ σ⁻₁"
+      sites:
+      - [0, 1]
+      - - 2
+        - 3
+"""
+    conf = load_c(text)
+    L = _lib.load()
+    try:
+        c = conf.contents
+        assert c.number_observables == 2
+        d, _ = product_terms(D.Operator(c.observables[0], owning=False))
+        assert sorted((v.real, bin(s).count("1")) for v, m, r, x, s in d) == [(-0.5, 1), (-0.5, 1), (0.5, 1), (0.5, 1)]
+        _, off = product_terms(D.Operator(c.observables[1], owning=False))
+        assert sorted(x for v, m, r, x, s in off) == [0b0011, 0b1100]
+        assert not D.Operator(c.observables[1], owning=False).isHermitian
+    finally:
+        L.ls_hs_destroy_yaml_config(conf)
+    p = tmp_path / "only_basis.yaml"
+    p.write_text("basis:\n  number_spins: 6\n  hamming_weight: ~   # full space\n  particle: spin-1/2\n")
+    assert D.loadConfigFromYaml(str(p)).numberSites() == 6
+    with pytest.raises(D.LsAmdError, match="does not contain a Hamiltonian"):
+        D.loadConfigFromYaml(str(p), hamiltonian=True)
+    with pytest.raises(D.LsAmdError, match="failed to load Config"):
+        D.loadConfigFromYaml(str(tmp_path / "missing.yaml"))
+
+
+@pytest.mark.parametrize("text,why", [
+    ("hamiltonian:\n  terms: []\n", "no `basis`"),
+    ("basis:\n  number_spins: 4\nhamiltonian:\n  terms:\n    - expression: \"σᶻ₀ σᶻ₁\"\n      sites: *nowhere\n", "unknown alias"),
+    ("basis:\n  number_spins: 4\nhamiltonian:\n  terms:\n    - expression: \"σᶻ₀ σᶻ₁\"\n      sites: [[0, 7]]\n", "out of range"),
+    ("basis:\n  number_spins: 4\nhamiltonian:\n  terms:\n    - expression: \"σᶻ₀ σᶻ₁\"\n      sites: [[0, 1, 2]]\n", "needs 2 sites"),
+    ("basis:\n  number_spins: 4\nhamiltonian:\n  terms:\n    - expression: \"σq₀\"\n      sites: [[0]]\n", "cannot parse"),
+    ("basis:\n  number_spins: 4\nhamiltonian:\n  terms:\n    - matrix: [[1, 0], [0, 1]]\n      sites: [[0]]\n", "expression"),
+    ("basis:\n  number_spins: 4\n  symmetries:\n    - permutation: [1, 2, 3]\n      sector: 0\n", "permutation"),
+    ("basis:\n  number_spins: 4\n  particle: spinless-fermion\n", "spin-1/2"),
+    ("basis:\n  number_spins: 4\n  hamming_weight: [1, 2\n", "flow sequence"),
+    ("basis:\n  number_spins: 4\n  hamming_weight: \"2\n", "unterminated string"),
+    ("basis:\n\tnumber_spins: 4\n", "tabs"),
+])
+def test_c_loader_reports_errors(text, why):
+    with pytest.raises(D.LsAmdError, match=why):
+        load_c(text)
