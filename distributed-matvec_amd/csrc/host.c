@@ -1636,8 +1636,9 @@ int lsk_sibplan_host(lsk_sibplan *sp, lsk_sibtab *tb, int L, int hw, int nl, int
     *units_out = units; *order_out = order; *unrank_out = unrank; *rank_out = rank;
     return 0;
 }
-lsk_sib_rec *lsk_sibrecs_host(lsk_sibplan const *sp, lsk_sibtab const *tb, lsk_sib_unit const *units, uint32_t const *order) {
+lsk_sib_rec *lsk_sibrecs_host(lsk_sibplan *sp, lsk_sibtab const *tb, lsk_sib_unit const *units, uint32_t const *order) {
     int64_t const slots = sp->slots_per_xcd, n = 8 * slots;
+    sp->n_recs = n;
     lsk_sib_rec *recs = (lsk_sib_rec *)calloc((size_t)(n > 0 ? n : 1), sizeof(lsk_sib_rec));
     for (int64_t sl = 0; sl < slots; ++sl)
         for (int k = 0; k < 8; ++k) {
@@ -1668,8 +1669,7 @@ int64_t ls_amd_test_sibplan(int L, int hw, int nl, int t, int64_t chunk, void **
     lsk_sibplan *sp = (lsk_sibplan *)malloc(sizeof(lsk_sibplan));
     lsk_sibtab *tb = (lsk_sibtab *)malloc(sizeof(lsk_sibtab));
     if (lsk_sibplan_host(sp, tb, L, hw, nl, t, chunk, (lsk_sib_unit **)units, order, unrank, rank) != 0) { free(sp); free(tb); return -1; }
-    sp->recs = lsk_sibrecs_host(sp, tb, (lsk_sib_unit const *)*units, *order); /* released with the struct: see ls_amd_test_sibplan_free */
-    sp->n_recs = 8 * sp->slots_per_xcd;
+    sp->recs = lsk_sibrecs_host(sp, tb, (lsk_sib_unit const *)*units, *order); /* released with the struct: ls_amd_test_sibplan_free */
     *plan_struct = sp;
     *tables = tb;
     return sp->n_units;
@@ -1710,7 +1710,6 @@ static int setup_sib(ls_amd_plan *pl, int64_t n) {
     int rc = 0;
     if (lsk_chain_sib_lds_bytes(pl->sib.max_rows, pl->sib.max_block) > 160 * 1024) rc = 1; /* not an error: the staged kernel takes it */
     lsk_sib_rec *recs = rc == 0 ? lsk_sibrecs_host(&pl->sib, &tab, units, order) : NULL;
-    pl->sib.n_recs = 8 * pl->sib.slots_per_xcd;
     if (rc == 0 && (upload(&pl->d_sib_units, recs, sizeof(lsk_sib_rec) * (size_t)pl->sib.n_recs) != 0 ||
                     upload(&pl->d_sib_unrank, unrank, sizeof(uint16_t) << nl) != 0 || upload(&pl->d_sib_rank, rank, sizeof(uint16_t) << nl) != 0 ||
                     upload(&pl->d_sib_tab, &tab, sizeof(tab)) != 0))

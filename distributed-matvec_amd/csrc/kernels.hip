@@ -140,6 +140,13 @@ static int tile_grid(K kernel, int64_t work_blocks) {
     return (int)work_blocks;
 }
 
+// LS_AMD_ABLATE (lsk_basis.debug_ablate) / LS_AMD_SIB_ABLATE switch stages of the tile / sibling kernels off to price them --
+// profiling builds only (make ABLATE=1): the shipped kernels carry none of these branches.
+#ifndef LSK_ABLATE
+#define LSK_ABLATE 0
+#endif
+constexpr bool kAblate = LSK_ABLATE != 0;
+
 static inline int grid_for(int64_t n, int per_block = kBlock) {
     int64_t b = (n + per_block - 1) / per_block;
     if (b < 1) b = 1;
@@ -1316,53 +1323,35 @@ extern "C" int64_t lsk_chain_sib_lds_bytes(int max_rows, int max_block) {
 // Phase 1: header + per-sibling bases straight from the record (one memory latency), then the window: the blocks of all
 // siblings, the low words of the unit's weight class, the small tables -- one barrier.  Phase 2: wave w walks the items
 // (sibling, pair of 64-row chunks) w, w + W, ...: the pairs >= nl are priced once per item (lane l <-> pair nl + l) and
-// every gather of the item's ROWS chunks is issued before anything is consumed (ROWS = 2: two rows per lane in flight, at
-// 99 instead of 61 VGPRs -- measured r3: no gain, the waves lost cost what the rows in flight bring; ROWS = 1 ships).
-template <int ROWS>
-__global__ __launch_bounds__(kSibMaxBlock) void k_chain_sib(lsk_runs runs, int n_diag, lsk_term const *__restrict__ diag, lsk_sibplan sp,
-                                                            uint32_t const *__restrict__ g_binom, int ring, double cv,
-                                                            double const *__restrict__ x, double *__restrict__ y) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint32_t *s_binom = reinterpret_cast<uint32_t *>(smem);      // [32][LSK_BINOM_K] C(n, k), n < 32
-    uint32_t *s_base = s_binom + kSibBinomRows * LSK_BINOM_K;    // [S] rank of row 0 of sibling s
-    uint32_t *s_ring = s_base + LSK_SIB_MAX_S;                   // [S] rank of row 0 of the ring partner's block
-    uint32_t *s_T = s_ring + LSK_SIB_MAX_S;                      // [S] top bits of sibling s
-    uint32_t *s_sidx = s_T + LSK_SIB_MAX_S;                      // [2^t] T -> sibling number (entries of other weights unused)
-    uint16_t *s_unr = reinterpret_cast<uint16_t *>(s_sidx + 64); // [nL] the low words of this unit's weight class, ascending
-    double *s_x = reinterpret_cast<double *>(s_unr + ((sp.max_block + 7) & ~3)); // [S * nL + 1], last = 0.0
-    static_assert(kSibHead % 2 == 0, "s_x must be 8-byte aligned");
-
+// every gather of the item's ROWS chunks is issued before anything is consumed.  Measured r3 and not kept as variants
+// (profiles/r3_sib_sweep3_*, r3_sib_sweep6_*): ROWS = 2 (two rows per lane in flight, 99 instead of 59 VGPRs) 10.6 - 12.8 ms,
+// K units per block with the next unit's window prefetched into registers behind the compute phase (80 VGPRs + spills,
+// 24 waves per CU) 10.6 - 11.0 ms, against 9.4 - 9.9 ms for this form: the waves lost cost more than the latency hidden.
+struct SibLds {
+    uint32_t *binom, *base, *ring, *T, *sidx;
+    uint16_t *unr;
+    double *x;
+};
+// phase 2 of the sibling-tile kernels: the rows of one unit whose window (s_x), low words (s_unr) and per-sibling constants are
+// in LDS.  Wave w of the block walks the items (sibling, ROWS consecutive 64-row chunks) w, w + W, ...
+template <int ROWS, int FAR>
+__device__ __forceinline__ void sib_compute(lsk_runs const &runs, int n_diag, lsk_term const *__restrict__ diag, lsk_sibplan const &sp,
+                                            SibLds const &lds, int nS, int nL, uint32_t mid, int ring, double cv,
+                                            double const *__restrict__ x, double *__restrict__ y, int ablate) {
+    uint32_t *const s_binom = lds.binom, *const s_base = lds.base, *const s_ring = lds.ring, *const s_T = lds.T, *const s_sidx = lds.sidx;
+    uint16_t *const s_unr = lds.unr;
+    double *const s_x = lds.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nthreads = blockDim.x;
-    lsk_sib_rec const *__restrict__ rec = sp.recs + blockIdx.x;
-    const int nS = (int)rec->nS;
-    if (nS == 0) return; // empty slot of a shorter XCD list (block-uniform)
-    const int nL = (int)rec->nL;
-    const uint32_t mid = rec->mid, uoff = rec->uoff;
     const int L = sp.L, t = sp.t, nl = sp.nl, hw = sp.hw;
     const int tshift = L - t;
     const int ZERO = nS * nL;
-    // ---- phase 1 ----------------------------------------------------------------------------------------------------
-    for (int s = 0; s < nS; ++s) {
-        double const *__restrict__ xb = x + rec->base[s];
-        for (int r = tid; r < nL; r += nthreads) s_x[s * nL + r] = xb[r];
-    }
-    for (int r = tid; r < nL; r += nthreads) s_unr[r] = sp.unrankL[uoff + r];
-    {
-        constexpr int N16 = kSibBinomRows * LSK_BINOM_K * (int)sizeof(uint32_t) / 16;
-        uint4 const *src = reinterpret_cast<uint4 const *>(g_binom);
-        uint4 *dst = reinterpret_cast<uint4 *>(s_binom);
-        for (int k = tid; k < N16; k += nthreads) dst[k] = src[k];
-    }
-    if (tid < nS) { s_base[tid] = rec->base[tid]; s_ring[tid] = rec->ring[tid]; s_T[tid] = rec->T[tid]; }
-    if (tid < (1 << t)) s_sidx[tid] = sp.tab->sidx[tid];
-    if (tid == 0) s_x[ZERO] = 0.0;
-    __syncthreads();
-    // ---- phase 2 ----------------------------------------------------------------------------------------------------
+    if (kAblate && (ablate & 1)) return; // LS_AMD_SIB_ABLATE (profiling builds only): 1 window loads only, 2 no global gathers,
+                                         // 4 no LDS near pairs, 8 no window load
     const double v = runs.v_re[0];
     const int nchunk = (nL + 63) >> 6;
     const int npair = (nchunk + ROWS - 1) / ROWS;
-    constexpr int kSibFar = SibFar<ROWS>::value;
+    constexpr int kSibFar = FAR;
     const int n_glob = tshift - nl; // pairs nl .. L - t - 1 gather from global memory, pairs L - t .. L - 2 read a sibling
     const int nwaves = nthreads >> 6;
     int s = 0, c = wave;
@@ -1428,6 +1417,7 @@ __global__ __launch_bounds__(kSibMaxBlock) void k_chain_sib(lsk_runs runs, int n
         }
         unsigned long long m_glob = m & ((1ULL << n_glob) - 1ULL);
         unsigned long long m_sib = m >> n_glob;
+        if (kAblate && (ablate & 2)) m_glob = 0;
         double xv[ROWS][kSibFar];
 #pragma unroll
         for (int q = 0; q < kSibFar; ++q) {
@@ -1452,6 +1442,7 @@ __global__ __launch_bounds__(kSibMaxBlock) void k_chain_sib(lsk_runs runs, int n
             const bool bit = (a[u] >> lo) & 1u, act = (tdiff[u] >> lo) & 1u;
             const uint32_t d = s_binom[lo * LSK_BINOM_K + k];
             const uint32_t idx = bit ? ig[u] + d : ig[u] - d;
+            if (kAblate && (ablate & 2)) { xc[u] = 0.0; g_ring[u] = 0.0; continue; }
             xc[u] = x[act ? idx : ig[u]];
             xc[u] = act ? xc[u] : 0.0;
             g_ring[u] = x[ring_rank[u]];
@@ -1469,7 +1460,7 @@ __global__ __launch_bounds__(kSibMaxBlock) void k_chain_sib(lsk_runs runs, int n
             near[u] = 0.0;
         }
 #pragma unroll 2
-        for (int lo = 0; lo < nl - 1; ++lo) {
+        for (int lo = 0; lo < ((kAblate && (ablate & 4)) ? 0 : nl - 1); ++lo) {
 #pragma unroll
             for (int u = 0; u < ROWS; ++u) {
                 const bool bit = (a[u] >> lo) & 1u, act = (tdiff[u] >> lo) & 1u;
@@ -1523,6 +1514,51 @@ __global__ __launch_bounds__(kSibMaxBlock) void k_chain_sib(lsk_runs runs, int n
     }
 }
 
+template <int ROWS>
+__global__ __launch_bounds__(kSibMaxBlock) void k_chain_sib(lsk_runs runs, int n_diag, lsk_term const *__restrict__ diag, lsk_sibplan sp,
+                                                            uint32_t const *__restrict__ g_binom, int ring, double cv,
+                                                            double const *__restrict__ x, double *__restrict__ y, int ablate) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t *s_binom = reinterpret_cast<uint32_t *>(smem);      // [32][LSK_BINOM_K] C(n, k), n < 32
+    uint32_t *s_base = s_binom + kSibBinomRows * LSK_BINOM_K;    // [S] rank of row 0 of sibling s
+    uint32_t *s_ring = s_base + LSK_SIB_MAX_S;                   // [S] rank of row 0 of the ring partner's block
+    uint32_t *s_T = s_ring + LSK_SIB_MAX_S;                      // [S] top bits of sibling s
+    uint32_t *s_sidx = s_T + LSK_SIB_MAX_S;                      // [2^t] T -> sibling number (entries of other weights unused)
+    uint16_t *s_unr = reinterpret_cast<uint16_t *>(s_sidx + 64); // [nL] the low words of this unit's weight class, ascending
+    double *s_x = reinterpret_cast<double *>(s_unr + ((sp.max_block + 7) & ~3)); // [S * nL + 1], last = 0.0
+    static_assert(kSibHead % 2 == 0, "s_x must be 8-byte aligned");
+
+    const int tid = threadIdx.x;
+    const int nthreads = blockDim.x;
+    lsk_sib_rec const *__restrict__ rec = sp.recs + blockIdx.x;
+    const int nS = (int)rec->nS;
+    if (nS == 0) return; // empty slot of a shorter XCD list (block-uniform)
+    const int nL = (int)rec->nL;
+    const uint32_t mid = rec->mid, uoff = rec->uoff;
+    const int t = sp.t;
+    const int ZERO = nS * nL;
+    // ---- phase 1 ----------------------------------------------------------------------------------------------------
+    if (!(kAblate && (ablate & 8)))
+        for (int s = 0; s < nS; ++s) {
+            double const *__restrict__ xb = x + rec->base[s];
+            for (int r = tid; r < nL; r += nthreads) s_x[s * nL + r] = xb[r];
+        }
+    for (int r = tid; r < nL; r += nthreads) s_unr[r] = sp.unrankL[uoff + r];
+    {
+        constexpr int N16 = kSibBinomRows * LSK_BINOM_K * (int)sizeof(uint32_t) / 16;
+        uint4 const *src = reinterpret_cast<uint4 const *>(g_binom);
+        uint4 *dst = reinterpret_cast<uint4 *>(s_binom);
+        for (int k = tid; k < N16; k += nthreads) dst[k] = src[k];
+    }
+    if (tid < nS) { s_base[tid] = rec->base[tid]; s_ring[tid] = rec->ring[tid]; s_T[tid] = rec->T[tid]; }
+    if (tid < (1 << t)) s_sidx[tid] = sp.tab->sidx[tid];
+    if (tid == 0) s_x[ZERO] = 0.0;
+    __syncthreads();
+    // ---- phase 2 ----------------------------------------------------------------------------------------------------
+    SibLds lds = {s_binom, s_base, s_ring, s_T, s_sidx, s_unr, s_x};
+    sib_compute<ROWS, SibFar<ROWS>::value>(runs, n_diag, diag, sp, lds, nS, nL, mid, ring, cv, x, y, ablate);
+}
+
 // binomial table as u32 (ranks < 2^32): shared with the staged kernel
 template <typename R> static R const *chain_binom(uint64_t const *g_binom, hipStream_t stream);
 extern "C" int lsk_chain_sib(lsk_operator op, lsk_sibplan sp, uint64_t const *g_binom, int ring, double cv, void const *x, void *y,
@@ -1548,7 +1584,8 @@ extern "C" int lsk_chain_sib(lsk_operator op, lsk_sibplan sp, uint64_t const *g_
     int threads = 768; // measured r3 (profiles/r3_sib_sweep*): 24 waves per CU (two blocks of 12) beat 16 and 32
     { char const *e = getenv("LS_AMD_SIB_THREADS"); if (e && atoi(e) >= 64 && atoi(e) <= kSibMaxBlock) threads = atoi(e) & ~63; }
     hipLaunchKernelGGL(k_chain_sib<1>, dim3((unsigned)sp.n_recs), dim3(threads), (size_t)lds, (hipStream_t)stream, op.runs,
-                       op.n_diag, op.diag, sp, binom_r, ring, cv, (double const *)x, (double *)y);
+                       op.n_diag, op.diag, sp, binom_r, ring, cv, (double const *)x, (double *)y,
+                       getenv("LS_AMD_SIB_ABLATE") ? atoi(getenv("LS_AMD_SIB_ABLATE")) : 0);
     LSK_LAUNCH_CHECK();
     return 0;
 }
@@ -1563,12 +1600,6 @@ extern "C" int lsk_chain_sib(lsk_operator op, lsk_sibplan sp, uint64_t const *g_
 // ---------------------------------------------------------------------------------------------
 
 constexpr uint32_t kDead = 0xffffffffu;
-// LS_AMD_ABLATE (lsk_basis.debug_ablate) switches stages of the tile kernels off to price them -- profiling builds only
-// (make ABLATE=1): the shipped kernels carry none of these branches.
-#ifndef LSK_ABLATE
-#define LSK_ABLATE 0
-#endif
-constexpr bool kAblate = LSK_ABLATE != 0;
 
 // GC = flip-mask groups expanded per LDS list: 8 for cheap packets (fewer barriers: chain_28, P = 8: 11.0 vs 14.0 ms with 4), 4 for
 // symmetry-projected bases (20 instead of 40 KB of LDS per block: twice the blocks per CU to hide K4 and the index look-ups:

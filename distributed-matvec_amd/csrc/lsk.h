@@ -198,11 +198,12 @@ typedef struct lsk_sibplan {
     uint16_t const *unrankL;      /* device [2^nl]: the nl-bit words grouped by weight, ascending inside a weight */
     uint16_t const *rankL;        /* device [2^nl]: position of a word inside its weight class */
     lsk_sibtab const *tab;        /* device */
-    lsk_sib_rec const *recs;      /* device [n_recs] = [8 * slots_per_xcd], launch order */
+    lsk_sib_rec const *recs;      /* device [n_recs] = [8 * slots_per_xcd], launch order: record b belongs to block b */
     int64_t n_recs;
 } lsk_sibplan;
-/* expands units + order (host arrays of lsk_sibplan_host) into the launch records (malloc'ed, 8 * slots_per_xcd of them) */
-lsk_sib_rec *lsk_sibrecs_host(lsk_sibplan const *sp, lsk_sibtab const *tab, lsk_sib_unit const *units, uint32_t const *order);
+/* expands units + order (host arrays of lsk_sibplan_host) into the launch records (malloc'ed; sets sp->n_recs): block b runs on
+ * XCD b % 8 and gets entry b / 8 of that XCD's list */
+lsk_sib_rec *lsk_sibrecs_host(lsk_sibplan *sp, lsk_sibtab const *tab, lsk_sib_unit const *units, uint32_t const *order);
 /* host-side construction of the tables above (plain malloc'ed arrays in *units / *order / *unrank / *rank); chunk = units per
  * round-robin chunk of the XCD lists.  Returns 0, or -1 when the shape is not admissible (ranks beyond 32 bits, ...). */
 int lsk_sibplan_host(lsk_sibplan *sp, lsk_sibtab *tab, int L, int hw, int nl, int t, int64_t chunk, lsk_sib_unit **units,
