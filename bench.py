@@ -436,6 +436,22 @@ def main():
         roofline["measured_stream_copy_GBps"] = 2 * nb * 5 / (ev0.elapsed_time(ev1) * 1e-3) / 1e9
         if roofline.get("achieved"):
             roofline["frac_of_measured_stream"] = roofline["achieved"] / roofline["measured_stream_copy_GBps"]
+        # ... and the read-only rate: the pull kernels' traffic is > 90 % reads, so this is the line that traffic can reach
+        sink = torch.zeros(4, dtype=torch.int32, device=x.device)
+
+        def read():
+            _lib.check(_lib.load().ls_amd_stream_read(C.c_void_p(x.data_ptr()), nb, 2, C.c_void_p(sink.data_ptr()),
+                                                      C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+
+        read()
+        ev0.record()
+        for _ in range(5):
+            read()
+        ev1.record()
+        torch.cuda.synchronize()
+        roofline["measured_stream_read_GBps"] = nb * 5 / (ev0.elapsed_time(ev1) * 1e-3) / 1e9
+        if roofline.get("traffic") and kernel_ms:
+            roofline["traffic_over_measured_read_rate"] = roofline["traffic"] / (kernel_ms * 1e-3) / 1e9 / roofline["measured_stream_read_GBps"]
     except RuntimeError:
         pass
 

@@ -55,6 +55,10 @@ int ls_amd_synchronize(void *stream);
 /* a plain streaming copy (16 bytes per lane): the device copy kernel the attainable HBM rate of the box is measured with
  * (SURVEY.md 8(d)); bytes is rounded down to a multiple of 16 */
 int ls_amd_stream_copy(void *d_dst, void const *d_src, int64_t bytes, void *stream);
+/* the read-only counterpart: every thread reads `per_thread` 16-byte elements and keeps an xor of them (d_sink: 4 bytes of device
+ * memory, practically never written): the attainable READ rate of the box, the line the pull kernels' traffic (> 90 % reads)
+ * is held against */
+int ls_amd_stream_read(void const *d_src, int64_t bytes, int per_thread, void *d_sink, void *stream);
 
 /* hash64_01 / localeIdxOf on the host (StatesEnumeration.chpl:122-136) */
 uint64_t ls_amd_hash64_01(uint64_t x);
