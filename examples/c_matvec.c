@@ -37,9 +37,10 @@ int main(int argc, char **argv) {
         ls_hs_yaml_config *conf = ls_hs_load_yaml_config(arg);
         if (!conf) { fprintf(stderr, "failed to load Config from '%s': %s\n", arg, ls_amd_last_error()); return 1; }
         if (!conf->hamiltonian) { fprintf(stderr, "'%s' does not contain a Hamiltonian\n", arg); return 1; }
-        basis = ls_hs_clone_basis(conf->basis);
         op = ls_hs_clone_operator(conf->hamiltonian);
         ls_hs_destroy_yaml_config(conf);
+        if (!op) { fprintf(stderr, "%s\n", ls_amd_last_error()); return 1; }
+        basis = op->basis; /* the operator's own basis (what Operator.basis is in ForeignTypes.chpl): built below, released with op */
         L = basis->number_sites;
     } else {
         basis = ls_hs_create_spin_basis(L, L / 2, 0, 0, NULL, NULL);
@@ -122,7 +123,7 @@ int main(int argc, char **argv) {
     printf("L = %d, N = %lld, <x|H|x>/<x|x> = %.12f, max|y| = %.6f, |plug-in - partitions| = %.2e, |plug-in - rccl| = %.2e\n",
            L, (long long)n, dot / nrm, scale, e2, e3);
     ls_hs_destroy_operator(op);
-    ls_hs_destroy_basis(basis);
+    if (!from_yaml) ls_hs_destroy_basis(basis); /* the creator's reference of the hand-built basis */
     ls_chpl_finalize();
     if (e2 > 1e-12 * scale || e3 > 1e-12 * scale) { fprintf(stderr, "MISMATCH\n"); return 2; }
     printf("OK\n");
