@@ -2332,7 +2332,8 @@ __global__ __launch_bounds__(kBlock) void k_tile_pull_idx(lsk_runs runs, int n_g
                 }
             }
             __syncthreads();
-            const int n = s_n;
+            const int n = (kAblate && (bs.debug_ablate & 1)) ? 0 : s_n; // LS_AMD_ABLATE (profiling builds): 1 no stage B, 2 no look-ups,
+                                                                        // 32 no value loads (slots resolved, x not read)
             // ---- stage B1: K4 on every packet ------------------------------------------------------------
             for (int e = tid; e < n; e += kBlock) {
                 uint64_t beta = s_beta[e];
@@ -2353,7 +2354,7 @@ __global__ __launch_bounds__(kBlock) void k_tile_pull_idx(lsk_runs runs, int n_g
                 s_beta[e] = beta;
             }
             // ---- stage B2: slots, then values --------------------------------------------------------------
-            {
+            if (!(kAblate && (bs.debug_ablate & 2))) {
                 uint64_t bkt[kGCPull];
                 uint32_t tag[kGCPull], slot[kGCPull];
                 ulonglong2 first[kGCPull];
@@ -2389,7 +2390,7 @@ __global__ __launch_bounds__(kBlock) void k_tile_pull_idx(lsk_runs runs, int n_g
                 }
                 X val[kGCPull];
 #pragma unroll
-                for (int k = 0; k < kGCPull; ++k) val[k] = live[k] ? xv[slot[k]] : cx_zero<X>();
+                for (int k = 0; k < kGCPull; ++k) val[k] = (live[k] && !(kAblate && (bs.debug_ablate & 32))) ? xv[slot[k]] : cx_zero<X>();
 #pragma unroll
                 for (int k = 0; k < kGCPull; ++k) {
                     if (!live[k]) continue;
