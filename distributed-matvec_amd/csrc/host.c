@@ -1508,6 +1508,7 @@ static int build_tilemap(ls_amd_plan *pl, int64_t n, int TILE) {
 /* test hook (host only): the tile map of n rows.  Returns slots per XCD (< 0 on error); *entries is malloc'ed, free
  * with ls_amd_test_free. */
 int ls_amd_test_window_find(uint64_t const *reps, int n, uint64_t key) { return lsk_test_window_find(reps, n, key); }
+int ls_amd_test_chain_near_table(int elem, int ldsp, int16_t *out) { return lsk_test_chain_near_table(elem, ldsp, out); }
 int64_t ls_amd_test_tilemap(int64_t n, int tile_rows, int64_t chunk, uint64_t **entries) {
     int64_t slots = 0;
     *entries = NULL;

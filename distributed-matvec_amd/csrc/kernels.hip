@@ -98,6 +98,7 @@ constexpr int kMaxGrid = 256 * 8; // 256 CUs x 8 resident blocks: grid-stride be
 // kept at <= 80 SGPRs (asserted in tests/test_host_tables.py::test_hot_kernel_register_budget).
 #include <map>
 #include <mutex>
+#include <vector>
 static int g_num_cus = 0;
 template <typename K>
 static int resident_grid(K kernel, int64_t work_blocks, size_t dyn_lds = 0, int block = kBlock) {
@@ -913,7 +914,7 @@ extern "C" int lsk_direct_gx(lsk_operator op, lsk_basis bs, lsk_index ix, int cp
 // ---------------------------------------------------------------------------------------------
 constexpr int kChainHalo = 512;    // >= C(11, 5)
 constexpr int kChainLdsPairs = 12; // pairs lo < 12 are served from the LDS window
-constexpr int kChainFar = 12;      // far-pair gathers in flight per row before the first wait
+constexpr int kChainFar = 12;      // far-pair gathers in flight per row before the first wait (8 / 10 / 12: 7.67 / 7.66 / 7.63 ms)
 
 // W = state word (u32 up to 32 sites, u64 up to 64), R = rank type (u32 while the basis has < 2^32 - 1 states, else u64),
 // CPLX = complex128 vectors (real operator; the window holds double2, gathers are 16 bytes per lane), TILE rows per
@@ -963,9 +964,11 @@ constexpr int kChainFarC = 6; // complex: 6 x 16 bytes in flight per lane
 // launch bounds, second argument = waves per SIMD the register allocation must allow.  256-thread blocks are admitted per CU
 // up to floor(800 / (ceil(sgpr / 16) * 16 + 16)): at 98 SGPRs the 7th block does not fit while the occupancy API still
 // answers 7 -- a straggler round of blocks, measured +24 % (13.1 vs 10.7 ms on chain_32)
+// (f64: 7 blocks = what 22.5 KB of LDS admit; c128: bounds 4 / 5 / 6 measure 14.56 / 14.55 / 14.57 ms)
 template <typename W, typename R, bool CPLX, int TILE, bool REC>
-__global__ __launch_bounds__(kBlock, (CPLX ? 4 : 8)) void k_chain_t(lsk_runs runs, int n_diag, lsk_term const *__restrict__ diag,
-                                                    int hamming_weight, R const *__restrict__ g_binom,
+__global__ __launch_bounds__(kBlock, (CPLX ? 5 : 7)) void k_chain_t(lsk_runs runs, int n_diag, lsk_term const *__restrict__ diag,
+                                                    int hamming_weight, uint4 const *__restrict__ g_img, int img16, int kc,
+                                                    int near_off,
                                                     uint64_t const *__restrict__ tilemap, int64_t slots_per_xcd, int64_t n,
                                                     uint64_t const *__restrict__ reps, void const *__restrict__ x_v,
                                                     void *__restrict__ y_v, int hb, int n_cached,
@@ -983,17 +986,14 @@ __global__ __launch_bounds__(kBlock, (CPLX ? 4 : 8)) void k_chain_t(lsk_runs run
     constexpr R kNone = ~(R)0;
     X const *__restrict__ x = (X const *)x_v;
     X *__restrict__ y = (X *)y_v;
-    __shared__ __attribute__((aligned(16))) R s_binom[NB * LSK_BINOM_K];
+    // LDS image made once by the host (chain_lds_image): the binomial table in the rank type, NB rows of kc = weight + 2
+    // columns, then the near-pair table (below); copied with 16-byte loads -- one block per tile means once per 1024 rows
+    extern __shared__ uint4 s_img[];
+    R const *const s_binom = reinterpret_cast<R const *>(s_img);
+    uint2 const *const s_near = reinterpret_cast<uint2 const *>(reinterpret_cast<char const *>(s_img) + near_off);
     __shared__ X s_x[WINDOW + 1]; // last slot: 0, read by the lanes whose near pair is aligned
-    {
-        // the binomial table (already in the rank type: lsk_chain narrows it once) with 16-byte loads: one block per tile
-        // means this runs once per 1024 rows
-        constexpr int N16 = NB * LSK_BINOM_K * (int)sizeof(R) / 16;
-        static_assert(NB * LSK_BINOM_K * sizeof(R) % 16 == 0, "table size");
-        uint4 const *src = reinterpret_cast<uint4 const *>(g_binom);
-        uint4 *dst = reinterpret_cast<uint4 *>(s_binom);
-        for (int k = threadIdx.x; k < N16; k += kBlock) dst[k] = src[k];
-    }
+    for (int k = threadIdx.x; k < img16; k += kBlock) s_img[k] = g_img[k];
+    (void)NB;
     if (threadIdx.x == 0) s_x[WINDOW] = cx_zero<X>();
     const int xcd = blockIdx.x & 7;
     const int64_t blocks_per_xcd = gridDim.x >> 3;
@@ -1076,6 +1076,15 @@ __global__ __launch_bounds__(kBlock, (CPLX ? 4 : 8)) void k_chain_t(lsk_runs run
             diag_coeff<W, true>(runs, n_diag, diag, a, dr, di);
             X acc = cx_scale(dr, xr);
             const W tdiff = a ^ (a >> 1);
+            // The rows of a wave ascend, so every lane shares the common prefix of the first and the last state: pairs at or
+            // above `ubit` (one past the highest bit on which those two differ) are wave-uniform.  92 % of the waves of
+            // chain_32 have ubit <= 12; the others used to fall back to the per-lane loop for ALL their far pairs and now
+            // only walk the pairs below ubit per lane.
+            const W a0 = readfirstlane_t<W>(a);
+            const W adiff = a0 ^ readlane_t<W>(a, 63);
+            const int ubit = adiff == 0 ? 0 : (int)(8 * sizeof(W)) - (sizeof(W) == 4 ? __clz((int)(uint32_t)adiff) : __clzll((long long)(uint64_t)adiff));
+            const R ig0 = readfirstlane_t<R>(ig);
+            const uint32_t dl = (uint32_t)(ig - ig0); // 0..63: the far gathers address x as (uniform base) + dl
             for (int q = 0; q < runs.n_runs; ++q) {
                 const int lo0 = runs.lo0[q];
                 int lo_end = lo0 + runs.cnt[q];
@@ -1084,10 +1093,10 @@ __global__ __launch_bounds__(kBlock, (CPLX ? 4 : 8)) void k_chain_t(lsk_runs run
                 int lo = lo0;
                 const int e1 = lo_end < LDSP ? lo_end : LDSP;
                 const int near_end = lo0 > e1 ? lo0 : e1;
-                const int split = hb == 0 ? lo_end : (hb < near_end ? near_end : (hb > lo_end ? lo_end : hb));
-                // ---- far pairs of a wave whose 64 states agree on every bit >= split ------------------------------
-                const W a0 = readfirstlane_t<W>(a);
-                const bool uni = split < lo_end && __builtin_amdgcn_ballot_w64(((a ^ a0) >> split) != 0) == 0;
+                int split = hb == 0 ? lo_end : (hb < near_end ? near_end : (hb > lo_end ? lo_end : hb));
+                if (hb != 0 && split < ubit) split = ubit < lo_end ? ubit : lo_end;
+                // ---- far pairs: the 64 states of the wave agree on every bit >= split ------------------------------
+                const bool uni = split < lo_end;
                 unsigned long long m = 0;
                 R off = 0;
                 X xv[FAR];
@@ -1102,7 +1111,7 @@ __global__ __launch_bounds__(kBlock, (CPLX ? 4 : 8)) void k_chain_t(lsk_runs run
                     const bool bit = hi & 1;
                     const bool act = in_run && (((hi >> 1) & 1) != (W)bit);
                     const int kk = hamming_weight - WT::popc(hi); // set bits below p
-                    const R d = s_binom[ps * LSK_BINOM_K + (kk < 0 ? 0 : kk)];
+                    const R d = s_binom[ps * kc + (kk < 0 ? 0 : kk)];
                     off = bit ? d : (R)(0 - d);
                     m = __builtin_amdgcn_ballot_w64(act);
 #pragma unroll
@@ -1110,23 +1119,60 @@ __global__ __launch_bounds__(kBlock, (CPLX ? 4 : 8)) void k_chain_t(lsk_runs run
                         if (m) {
                             const int l = __builtin_ctzll(m);
                             m &= m - 1;
-                            xv[u] = x[(R)(ig + readlane_t<R>(off, l))];
+                            xv[u] = (x + (size_t)(R)(ig0 + readlane_t<R>(off, l)))[dl];
                         }
                     }
                     lo_end = split;
                 }
                 // ---- near pairs: partner inside the LDS window ----------------------------------------
+                if (lo0 == 0 && e1 == LDSP) {
+                    // The usual case, the run covers every LDS pair: the byte displacements of four pairs at a time come
+                    // from a table indexed by the five state bits they touch and the number of set bits below them
+                    // (chain_lds_image); an aligned pair holds a displacement that clamps to the zero slot.  3-4 VALU
+                    // instructions per pair instead of 12 (two bit tests, binomial address, sign, select, scale).
+                    const uint32_t al = (uint32_t)a;
+                    const uint32_t jb = (uint32_t)jr * (uint32_t)sizeof(X);
+                    constexpr uint32_t ZOFF = (uint32_t)WINDOW * (uint32_t)sizeof(X);
+                    char const *const sb = reinterpret_cast<char const *>(s_x);
+                    const uint2 q0 = s_near[al & 31u];
+                    const uint2 q1 = s_near[32 + 32 * __popc(al & 15u) + ((al >> 4) & 31u)];
+                    const uint2 q2 = s_near[192 + 32 * __popc(al & 255u) + ((al >> 8) & 31u)];
+                    const uint32_t wq[6] = {q0.x, q0.y, q1.x, q1.y, q2.x, q2.y};
+                    // LDS reads in flight before their fmas (pair order kept).  Measured on chain_32 f64: 1 / 2 / 3 / 4 in flight
+                    // 7.64 / 7.63 / 7.93 / 7.93 ms -- the registers of a deeper batch cost more than its latency hiding buys;
+                    // c128 is indifferent (14.55-14.67 ms with or without the table)
+                    constexpr int NBATCH = 2;
+#pragma unroll
+                    for (int p0 = 0; p0 < LDSP; p0 += NBATCH) {
+                        X nv[NBATCH];
+#pragma unroll
+                        for (int u = 0; u < NBATCH; ++u) {
+                            const int p = p0 + u;
+                            const uint32_t w = wq[(p < LDSP ? p : 0) >> 1];
+                            const int32_t d = (p & 1) ? ((int32_t)w >> 16) : (int32_t)(int16_t)(w & 0xffffu);
+                            uint32_t o = jb + (uint32_t)d;
+                            o = o < ZOFF ? o : ZOFF;
+                            nv[u] = p < LDSP ? *reinterpret_cast<X const *>(sb + o) : cx_zero<X>();
+                        }
+#pragma unroll
+                        for (int u = 0; u < NBATCH; ++u)
+                            if (p0 + u < LDSP) cx_fma(vr, nv[u], acc);
+                    }
+                    lo = LDSP;
+                    k = __popc(al & ((1u << LDSP) - 1u));
+                }
 #pragma unroll 4
                 for (; lo < e1; ++lo) {
                     const bool bit = (a >> lo) & 1;
                     const bool act = (tdiff >> lo) & 1;
-                    const int d = (int)s_binom[lo * LSK_BINOM_K + k];
+                    const int d = (int)s_binom[lo * kc + k];
                     k += bit ? 1 : 0;
                     const int j = bit ? jr + d : jr - d;
                     cx_fma(vr, s_x[act ? j : WINDOW], acc);
                 }
 #pragma unroll
-                for (int u = 0; u < FAR; ++u) cx_fma(vr, xv[u], acc);
+                for (int u = 0; u < FAR; ++u) cx_fma(vr, xv[u], acc); // zero-filled slots included: counting the gathers and
+                                                                      // branching around idle fmas measured slower (7.72 vs 7.59 ms)
                 while (m) { // more than FAR anti-aligned far pairs
                     X xw[4];
 #pragma unroll
@@ -1135,7 +1181,7 @@ __global__ __launch_bounds__(kBlock, (CPLX ? 4 : 8)) void k_chain_t(lsk_runs run
                         if (m) {
                             const int l = __builtin_ctzll(m);
                             m &= m - 1;
-                            xw[u] = x[(R)(ig + readlane_t<R>(off, l))];
+                            xw[u] = (x + (size_t)(R)(ig0 + readlane_t<R>(off, l)))[dl];
                         }
                     }
 #pragma unroll
@@ -1146,7 +1192,7 @@ __global__ __launch_bounds__(kBlock, (CPLX ? 4 : 8)) void k_chain_t(lsk_runs run
                 for (; lo < lo_end; ++lo) {
                     const bool bit = (a >> lo) & 1;
                     const bool act = (tdiff >> lo) & 1;
-                    const R d = s_binom[lo * LSK_BINOM_K + k];
+                    const R d = s_binom[lo * kc + k];
                     k += bit ? 1 : 0;
                     R idx = bit ? (R)(ig + d) : (R)(ig - d);
                     idx = act ? idx : ig;
@@ -1231,12 +1277,78 @@ template <> uint32_t const *chain_binom<uint32_t>(uint64_t const *g_binom, hipSt
     return narrow;
 }
 
+// LDS image of k_chain_t, made once per (rank type, rows, weight, vector type) and kept on the device:
+//   [rows][kc] binomials C(n, k), k < kc = weight + 2, in the rank type (low 32 bits for 32-bit ranks), padded to 16 bytes;
+//   near-pair table: for g = 0..2 (pairs 4g..4g+3), kidx = number of set bits below bit 4g (0..4g), pat = state bits
+//   4g..4g+4: four int16 = signed byte displacement of the partner inside the LDS window of x (elem bytes per row,
+//   +C(lo, k) rows when the lower bit of the pair is set, -C(lo, k) when the upper one is), 0x7000 for an aligned pair
+//   or a pair >= ldsp (added to any row offset it lands past the window and clamps to the zero slot).
+//   Entry index = {0, 32, 192}[g] + 32 kidx + pat.
+static int chain_near_fill(uint64_t const (*C)[LSK_BINOM_K], int elem, int ldsp, int16_t *near) {
+    int const base[3] = {0, 32, 192};
+    for (int g = 0; g < 3; ++g)
+        for (int kidx = 0; kidx <= 4 * g; ++kidx)
+            for (int pat = 0; pat < 32; ++pat)
+                for (int p = 0; p < 4; ++p) {
+                    int const lo = 4 * g + p;
+                    int const bit = (pat >> p) & 1, nxt = (pat >> (p + 1)) & 1;
+                    int const k = kidx + __builtin_popcount(pat & ((1 << p) - 1));
+                    int64_t const d = (int64_t)C[lo][k < LSK_BINOM_K ? k : 0] * elem;
+                    int16_t v = 0x7000;
+                    if (lo < ldsp && bit != nxt && k <= lo) {
+                        if (d >= 0x7000) { snprintf(g_err, sizeof(g_err), "chain_near_fill: displacement out of range"); return -1; }
+                        v = (int16_t)(bit ? d : -d);
+                    }
+                    near[4 * (base[g] + 32 * kidx + pat) + p] = v;
+                }
+    return 0;
+}
+static void chain_binomials(uint64_t (*C)[LSK_BINOM_K]) {
+    for (int n = 0; n < 64; ++n)
+        for (int k = 0; k < LSK_BINOM_K; ++k) C[n][k] = k == 0 ? 1 : (n == 0 ? 0 : C[n - 1][k - 1] + C[n - 1][k]);
+}
+// host test hook: the near-pair table alone (480 entries of four int16)
+extern "C" int lsk_test_chain_near_table(int elem, int ldsp, int16_t *out) {
+    uint64_t C[64][LSK_BINOM_K];
+    chain_binomials(C);
+    return chain_near_fill(C, elem, ldsp, out);
+}
+struct ChainImage { int rsize, rows, kc, elem, ldsp; uint4 *dev; int bytes, near_off; };
+static int chain_lds_image(int rsize, int rows, int weight, int elem, int ldsp, ChainImage *out) {
+    static std::vector<ChainImage> cache;
+    static std::mutex lock;
+    std::lock_guard<std::mutex> guard(lock);
+    int kc = (weight < 0 ? rows : weight) + 2;
+    if (kc > LSK_BINOM_K) kc = LSK_BINOM_K;
+    for (ChainImage const &c : cache)
+        if (c.rsize == rsize && c.rows == rows && c.kc == kc && c.elem == elem && c.ldsp == ldsp) { *out = c; return 0; }
+    uint64_t C[64][LSK_BINOM_K];
+    chain_binomials(C);
+    int const near_off = (rows * kc * rsize + 15) & ~15;
+    int const bytes = near_off + 480 * 8;
+    std::vector<unsigned char> img((size_t)bytes, 0);
+    for (int n = 0; n < rows; ++n)
+        for (int k = 0; k < kc; ++k) {
+            if (rsize == 4) reinterpret_cast<uint32_t *>(img.data())[n * kc + k] = (uint32_t)C[n][k];
+            else reinterpret_cast<uint64_t *>(img.data())[n * kc + k] = C[n][k];
+        }
+    if (chain_near_fill(C, elem, ldsp, reinterpret_cast<int16_t *>(img.data() + near_off)) != 0) return -1;
+    ChainImage c = {rsize, rows, kc, elem, ldsp, nullptr, bytes, near_off};
+    if (hipMalloc((void **)&c.dev, (size_t)bytes) != hipSuccess) { snprintf(g_err, sizeof(g_err), "chain_lds_image: no device memory"); return -1; }
+    if (hipMemcpy(c.dev, img.data(), (size_t)bytes, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(c.dev); snprintf(g_err, sizeof(g_err), "chain_lds_image: copy failed"); return -1; }
+    cache.push_back(c);
+    *out = c;
+    return 0;
+}
+
 template <typename W, typename R, bool CPLX, int TILE, bool REC>
 static int launch_chain(lsk_operator op, lsk_basis bs, lsk_index ix, lsk_tilemap tm, int64_t n, uint64_t const *reps,
                         int64_t row0, int64_t n_x, void const *x, void *y, int n_cached, void const *cache, double cv0,
                         double cv1, void *stream) {
     int64_t gb = tm.slots_per_xcd * 8;
-    int64_t cap = resident_grid(k_chain_t<W, R, CPLX, TILE, REC>, gb);
+    ChainImage img;
+    if (chain_lds_image((int)sizeof(R), ChainTraits<W, R>::NB, bs.hamming_weight, CPLX ? 16 : 8, CPLX ? 11 : kChainLdsPairs, &img) != 0) return -1;
+    int64_t cap = resident_grid(k_chain_t<W, R, CPLX, TILE, REC>, gb, (size_t)img.bytes);
     {
         char const *e = getenv("LS_AMD_BLOCKS_PER_CU"); // occupancy experiments
         int const bpc = e ? atoi(e) : 0;
@@ -1250,10 +1362,8 @@ static int launch_chain(lsk_operator op, lsk_basis bs, lsk_index ix, lsk_tilemap
     // apart and the memory phases of some overlap the LDS / ALU phases of others.  LS_AMD_CHAIN_FULLGRID=0: persistent.
     { char const *e = getenv("LS_AMD_CHAIN_FULLGRID"); if (!e || atoi(e) != 0) cap = gb; }
     if (gb > cap) gb = cap;
-    R const *binom_r = chain_binom<R>(ix.binom, (hipStream_t)stream);
-    if (!binom_r) { snprintf(g_err, sizeof(g_err), "lsk_chain: no memory for the narrow binomial table"); return -1; }
-    hipLaunchKernelGGL((k_chain_t<W, R, CPLX, TILE, REC>), dim3((unsigned)gb), dim3(kBlock), 0, (hipStream_t)stream, op.runs,
-                       op.n_diag, op.diag, bs.hamming_weight, binom_r, tm.entries, tm.slots_per_xcd, n, reps, x, y,
+    hipLaunchKernelGGL((k_chain_t<W, R, CPLX, TILE, REC>), dim3((unsigned)gb), dim3(kBlock), (size_t)img.bytes, (hipStream_t)stream, op.runs,
+                       op.n_diag, op.diag, bs.hamming_weight, img.dev, img.bytes / 16, img.kc, img.near_off, tm.entries, tm.slots_per_xcd, n, reps, x, y,
                        high_pair_setting(kChainLdsPairs), n_cached, (R const *)cache, cv0, cv1, row0, n_x);
     LSK_LAUNCH_CHECK();
     return 0;
@@ -2266,8 +2376,13 @@ extern "C" int lsk_scatter_owned(int64_t n, uint32_t const *perm, int64_t base, 
 //   near partners (inside the LDS window of the sorted representatives): global index g -> slot (perm[g] or g) -> xsrc[slot]
 //   far partners: ONE 16-byte bucket of the static index table -> slot -> xsrc[slot]
 // All first-level loads of a thread's kGCPull packets are issued before any is consumed, then all value loads.
+#ifdef LSK_PULLIDX_OCC7
+#define LSK_PULLIDX_BOUNDS __launch_bounds__(kBlock, 7) __attribute__((amdgpu_num_sgpr(94)))
+#else
+#define LSK_PULLIDX_BOUNDS __launch_bounds__(kBlock)
+#endif
 template <typename W, bool PM1, bool CPLX, bool REAL>
-__global__ __launch_bounds__(kBlock) void k_tile_pull_idx(lsk_runs runs, int n_groups, lsk_group const *__restrict__ groups,
+__global__ LSK_PULLIDX_BOUNDS void k_tile_pull_idx(lsk_runs runs, int n_groups, lsk_group const *__restrict__ groups,
                                                           lsk_term const *__restrict__ off, int n_diag,
                                                           lsk_term const *__restrict__ diag, lsk_basis bs,
                                                           lsk_group_elem const *__restrict__ elems, int64_t row0, int64_t row1,

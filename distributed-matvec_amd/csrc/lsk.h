@@ -293,6 +293,7 @@ int lsk_scatter_owned(int64_t n, uint32_t const *perm, int64_t base, int64_t cou
 /* host-side check of the window search (tests, no device): position of `key` among the ascending reps[0, n), n <= 1280,
  * or -1 -- exactly what a tile resolves in LDS */
 int lsk_test_window_find(uint64_t const *reps, int n, uint64_t key);
+int lsk_test_chain_near_table(int elem, int ldsp, int16_t *out);
 /* n packets -> y[idx(beta)] += value */
 int lsk_scatter(lsk_index ix, int cplx, int64_t n, uint64_t const *betas, void const *vals, void *y,
                 double const *norms /* NULL, or per-row norms multiplied in (K4 modes 1, 2) */, int *d_err,

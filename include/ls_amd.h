@@ -277,6 +277,9 @@ void ls_amd_test_free(void *p);
  * `key` among the ascending reps[0, n) (n <= 1280, stored as saturating 32-bit offsets from reps[0] exactly as a tile
  * stores them in LDS), -1 if it is not there or not representable (then the kernel takes the hash table), -2 on bad n */
 int ls_amd_test_window_find(uint64_t const *reps, int n, uint64_t key);
+/* Host-only test hook: the near-pair table of the staged row kernel (distributed-matvec_amd/csrc/kernels.hip: chain_lds_image) for
+ * vectors of `elem` bytes per entry and `ldsp` pairs served from the LDS window: 480 entries of four int16 into `out`. */
+int ls_amd_test_chain_near_table(int elem, int ldsp, int16_t *out);
 /* Host-only test hooks of the static index table {representative -> 32-bit payload} of the indexed pull mode
  * (distributed-matvec_amd/csrc/lsk.h: lsk_gtab): bucket bits for n keys of L bits (-1: no admissible shape), a sequential
  * build with the device kernel's placement rule into a malloc'ed array of 2 << bbits entries (release with
