@@ -1509,6 +1509,11 @@ static int build_tilemap(ls_amd_plan *pl, int64_t n, int TILE) {
  * with ls_amd_test_free. */
 int ls_amd_test_window_find(uint64_t const *reps, int n, uint64_t key) { return lsk_test_window_find(reps, n, key); }
 int ls_amd_test_chain_near_table(int elem, int ldsp, int16_t *out) { return lsk_test_chain_near_table(elem, ldsp, out); }
+uint64_t ls_amd_test_rep_trivial_dihedral(uint64_t a, int L, int inv, int reflect) { return lsk_test_rep_trivial_dihedral(a, L, inv, reflect); }
+int ls_amd_bench_k4(int L, int inv, int reflect, int variant, int64_t n, uint64_t const *d_reps, uint64_t *d_out, void *stream) {
+    if (lsk_bench_k4(L, inv, reflect, variant, n, d_reps, d_out, stream) != 0) { set_error("%s", lsk_last_error()); return -1; }
+    return 0;
+}
 int64_t ls_amd_test_tilemap(int64_t n, int tile_rows, int64_t chunk, uint64_t **entries) {
     int64_t slots = 0;
     *entries = NULL;

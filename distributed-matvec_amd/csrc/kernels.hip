@@ -405,53 +405,96 @@ __device__ __forceinline__ void state_info_w(lsk_basis const &bs, lsk_group_elem
 //      by one rotate + bit-reverse, no second search;
 //   4. global spin flip: the flipped images start with a run of *ones* of a, so only the family whose
 //      longest run is longer (both on a tie) can contain the minimum.
+// (host-callable as well: tests/test_host_tables.py checks it against the brute-force orbit minimum through
+// lsk_test_rep_trivial_dihedral)
+__host__ __device__ __forceinline__ int k4_ctz32(uint32_t v) { return __builtin_ctz(v); }
+__host__ __device__ __forceinline__ int k4_ctz64(uint64_t v) { return __builtin_ctzll(v); }
+__host__ __device__ __forceinline__ uint32_t k4_brev32(uint32_t v) { return __builtin_bitreverse32(v); }
+__host__ __device__ __forceinline__ uint64_t k4_brev64(uint64_t v) { return __builtin_bitreverse64(v); }
 template <typename W>
-__device__ __forceinline__ W rotl_sites(W x, int s, int L, W mask) {
+__host__ __device__ __forceinline__ W rotl_sites(W x, int s, int L, W mask) {
     return s == 0 ? x : (W)(((x << s) | (x >> (L - s))) & mask);
 }
 template <typename W>
-__device__ __forceinline__ W rev_sites(W x, int L) {
-    if (sizeof(W) == 4) return (W)(__brev((uint32_t)x) >> (32 - L));
-    return (W)(__brevll((uint64_t)x) >> (64 - L));
+__host__ __device__ __forceinline__ W rev_sites(W x, int L) {
+    if (sizeof(W) == 4) return (W)(k4_brev32((uint32_t)x) >> (32 - L));
+    return (W)(k4_brev64((uint64_t)x) >> (64 - L));
 }
+// Start positions (MSB ends) of the longest cyclic runs of set bits of z, and their length.  The run length is found by
+// doubling and refining instead of one rotation per unit of length: R2 = z & rot(z,1), R4 = R2 & rot(R2,2), R8 = R4 &
+// rot(R4,4) hold the starts of runs >= 2, 4, 8; below 8 two more rotations settle the exact length (R6 = R4 & rot(R2,4), then
+// one step of 1) -- five rotations, no data-dependent trip count, where the step-by-step loop makes every lane of a wave wait
+// for the longest run among 64 packets (8.5 steps on half-filled 36-site states against 5.3 on average).  Runs >= 8
+// continue step by step from R8.
 template <typename W>
-__device__ __forceinline__ W longest_runs(W z, int L, W mask, int &len) {
+__host__ __device__ __forceinline__ W longest_runs(W z, int L, W mask, int &len) {
     if (z == 0) { len = 0; return (W)1; }          // no zero site at all: every rotation is the same word
     if (z == mask) { len = L; return (W)1; }        // all sites zero
-    W R = z;
-    int s = 1;
-    for (;;) {
-        W T = R & rotl_sites<W>(z, s, L, mask);
-        if (T == 0) break;
-        R = T;
-        ++s;
+#ifdef LSK_K4_STEPWISE
+    const bool stepwise = true; // A/B builds: the round-2 loop, one rotation per unit of run length
+#else
+    const bool stepwise = false;
+#endif
+    if (stepwise || L < 9) { // tiny rings: the doubling steps would wrap around the ring
+        W R = z;
+        int s = 1;
+        for (;;) {
+            const W T = R & rotl_sites<W>(z, s, L, mask);
+            if (T == 0) break;
+            R = T;
+            ++s;
+        }
+        len = s;
+        return R;
     }
+    const W R2 = z & rotl_sites<W>(z, 1, L, mask);
+    const W R4 = R2 & rotl_sites<W>(R2, 2, L, mask);
+    const W R8 = R4 & rotl_sites<W>(R4, 4, L, mask);
+    W R;
+    int s;
+    if (R8 != 0) { // rare per packet; the tail of the old loop
+        R = R8;
+        s = 8;
+        for (;;) {
+            const W T = R & rotl_sites<W>(z, s, L, mask);
+            if (T == 0 || s + 1 >= L) break;
+            R = T;
+            ++s;
+        }
+        len = s;
+        return R;
+    }
+    const bool c4 = R4 != 0, c2 = R2 != 0;
+    R = c4 ? R4 : (c2 ? R2 : z);
+    s = c4 ? 4 : (c2 ? 2 : 1);
+    const W R6 = R4 & rotl_sites<W>(R2, 4, L, mask);
+    if (R6 != 0) { R = R6; s = 6; }
+    const W T = R & rotl_sites<W>(z, s, L, mask);
+    if (T != 0) { R = T; ++s; }
     len = s;
     return R;
 }
+// minimum over the rotations that put the MSB end of a longest run on top and, with reflections, over the mirrored
+// words that start with the same run: the run whose MSB end is p has the candidate c = rotl(word, L-1-p); mirrored, the
+// run leads again when its LSB end is on top of rev(word), and that word is rev(rotl(c, len)) -- one more rotation of c
+// and a bit reversal, inside the same loop (round 2 ran a second loop over rev(word) and the mirrored end positions).
 template <typename W>
-__device__ __forceinline__ W min_over_starts(W word, W starts, int L, W mask, W best) {
-    while (starts) {
-        const int p = sizeof(W) == 4 ? __ffs((int)starts) - 1 : __ffsll((unsigned long long)starts) - 1;
-        starts &= starts - 1;
+__host__ __device__ __forceinline__ W family_min(W word, W R, int len, int L, W mask, bool reflect, W best) {
+    const int lr = len >= L ? 0 : len; // len == L only for the all-equal words, whose rotations coincide
+    while (R) {
+        const int p = sizeof(W) == 4 ? k4_ctz32((uint32_t)R) : k4_ctz64((uint64_t)R);
+        R &= R - 1;
         const W c = rotl_sites<W>(word, L - 1 - p, L, mask); // site p becomes the top site
         best = c < best ? c : best;
+        if (reflect) {
+            const W m = rev_sites<W>(rotl_sites<W>(c, lr, L, mask), L);
+            best = m < best ? m : best;
+        }
     }
     return best;
 }
 template <typename W>
-__device__ __forceinline__ W family_min(W word, W R, int len, int L, W mask, bool reflect, W best) {
-    best = min_over_starts<W>(word, R, L, mask, best);
-    if (reflect) {
-        // LSB ends of the runs = MSB ends rotated down by len - 1; mirrored they are the MSB ends in rev(word)
-        const int down = len > 0 ? (len - 1) % L : 0;
-        const W lsb_ends = rotl_sites<W>(R, (L - down) % L, L, mask);
-        best = min_over_starts<W>(rev_sites<W>(word, L), rev_sites<W>(lsb_ends, L), L, mask, best);
-    }
-    return best;
-}
-template <typename W>
-__device__ __forceinline__ W rep_trivial_dihedral(W a, int L, W mask, bool inv, bool reflect) {
+__host__ __device__ __forceinline__ W rep_trivial_dihedral(W a, int L, W mask, bool inv, bool reflect) {
     const W na = (W)(~a & mask);
     int len0, len1 = -1;
     const W R0 = longest_runs<W>(na, L, mask, len0); // zero runs of a
@@ -461,6 +504,45 @@ __device__ __forceinline__ W rep_trivial_dihedral(W a, int L, W mask, bool inv, 
     if (len0 >= len1) best = family_min<W>(a, R0, len0, L, mask, reflect, best);
     if (inv && len1 >= len0) best = family_min<W>(na, R1, len1, L, mask, reflect, best);
     return best;
+}
+// host test hook: mode-3 orbit minimum of `a` on a ring of L sites (32-bit words for L <= 32, as the kernels choose)
+extern "C" uint64_t lsk_test_rep_trivial_dihedral(uint64_t a, int L, int inv, int reflect) {
+    const uint64_t mask = L >= 64 ? ~0ULL : ((1ULL << L) - 1);
+    if (L <= 32) return (uint64_t)rep_trivial_dihedral<uint32_t>((uint32_t)a, L, (uint32_t)mask, inv != 0, reflect != 0);
+    return rep_trivial_dihedral<uint64_t>(a, L, mask, inv != 0, reflect != 0);
+}
+
+// Profiling entry (scripts/k4_rate.py): K4 alone over the packets of a ring -- every row's state with each adjacent pair
+// (b, b + 1 mod L) flipped, all lanes busy -- to price it outside the tile kernels.  variant 0: the whole orbit minimum;
+// 1: the two run searches only; 2: the packets only (loop and flip, no K4).
+template <typename W>
+__global__ __launch_bounds__(kBlock) void k_bench_k4(int L, int inv, int reflect, int variant, int64_t n,
+                                                     uint64_t const *__restrict__ reps, uint64_t *__restrict__ out) {
+    const W mask = (W)(L >= 64 ? ~0ULL : ((1ULL << L) - 1));
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        const W a = (W)reps[i];
+        W acc = 0;
+        for (int b = 0; b < L; ++b) {
+            const W pm = (W)(((W)1 << b) | ((W)1 << (b + 1 == L ? 0 : b + 1)));
+            const W beta = a ^ pm;
+            if (variant == 0) acc ^= rep_trivial_dihedral<W>(beta, L, mask, inv != 0, reflect != 0);
+            else if (variant == 1) {
+                int l0, l1;
+                const W r0 = longest_runs<W>((W)(~beta & mask), L, mask, l0);
+                const W r1 = longest_runs<W>(beta, L, mask, l1);
+                acc ^= r0 + r1 + (W)(l0 + 64 * l1);
+            } else acc ^= beta + (W)b;
+        }
+        out[i] = (uint64_t)acc;
+    }
+}
+extern "C" int lsk_bench_k4(int L, int inv, int reflect, int variant, int64_t n, uint64_t const *reps, uint64_t *out, void *stream) {
+    if (n <= 0 || L < 2 || L > 64) return 0;
+    const dim3 g((unsigned)grid_for(n)), b(kBlock);
+    if (L <= 32) hipLaunchKernelGGL(k_bench_k4<uint32_t>, g, b, 0, (hipStream_t)stream, L, inv, reflect, variant, n, reps, out);
+    else hipLaunchKernelGGL(k_bench_k4<uint64_t>, g, b, 0, (hipStream_t)stream, L, inv, reflect, variant, n, reps, out);
+    LSK_LAUNCH_CHECK();
+    return 0;
 }
 
 // K4, trivial sector: only the orbit minimum.  mode 2 generates the L rotations incrementally

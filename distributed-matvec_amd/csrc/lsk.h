@@ -294,6 +294,8 @@ int lsk_scatter_owned(int64_t n, uint32_t const *perm, int64_t base, int64_t cou
  * or -1 -- exactly what a tile resolves in LDS */
 int lsk_test_window_find(uint64_t const *reps, int n, uint64_t key);
 int lsk_test_chain_near_table(int elem, int ldsp, int16_t *out);
+uint64_t lsk_test_rep_trivial_dihedral(uint64_t a, int L, int inv, int reflect);
+int lsk_bench_k4(int L, int inv, int reflect, int variant, int64_t n, uint64_t const *reps, uint64_t *out, void *stream);
 /* n packets -> y[idx(beta)] += value */
 int lsk_scatter(lsk_index ix, int cplx, int64_t n, uint64_t const *betas, void const *vals, void *y,
                 double const *norms /* NULL, or per-row norms multiplied in (K4 modes 1, 2) */, int *d_err,

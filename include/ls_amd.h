@@ -280,6 +280,11 @@ int ls_amd_test_window_find(uint64_t const *reps, int n, uint64_t key);
 /* Host-only test hook: the near-pair table of the staged row kernel (distributed-matvec_amd/csrc/kernels.hip: chain_lds_image) for
  * vectors of `elem` bytes per entry and `ldsp` pairs served from the LDS window: 480 entries of four int16 into `out`. */
 int ls_amd_test_chain_near_table(int elem, int ldsp, int16_t *out);
+/* Host-only test hook: the orbit minimum of `a` under the translations of a ring of L sites (and its reflections / the global
+ * spin flip when asked), computed by the candidate-pruning routine the projected-basis kernels use (K4, trivial sector). */
+uint64_t ls_amd_test_rep_trivial_dihedral(uint64_t a, int L, int inv, int reflect);
+/* Profiling entry: K4 alone over the packets of a ring (every state of d_reps with each adjacent pair flipped), see scripts/k4_rate.py */
+int ls_amd_bench_k4(int L, int inv, int reflect, int variant, int64_t n, uint64_t const *d_reps, uint64_t *d_out, void *stream);
 /* Host-only test hooks of the static index table {representative -> 32-bit payload} of the indexed pull mode
  * (distributed-matvec_amd/csrc/lsk.h: lsk_gtab): bucket bits for n keys of L bits (-1: no admissible shape), a sequential
  * build with the device kernel's placement rule into a malloc'ed array of 2 << bbits entries (release with

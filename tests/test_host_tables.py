@@ -644,3 +644,42 @@ def test_chain_near_pair_table(elem, ldsp):
     # every real displacement stays inside the halo of the window (512 rows for f64, 256 for c128)
     real = tab[tab != 0x7000]
     assert np.abs(real).max() <= elem * (512 if elem == 8 else 256)
+
+
+def _orbit_min(a, L, inv, reflect):
+    mask = (1 << L) - 1
+    words = [a] + ([a ^ mask] if inv else [])
+    if reflect:
+        words += [int(format(w, f"0{L}b")[::-1], 2) for w in list(words)]
+    best = mask
+    for w in words:
+        for s in range(L):
+            best = min(best, ((w << s) | (w >> (L - s))) & mask)
+    return best
+
+
+@pytest.mark.parametrize("inv,reflect", [(0, 0), (1, 0), (0, 1), (1, 1)])
+def test_k4_trivial_sector_orbit_minimum(inv, reflect):
+    """K4 of the trivial sector on rings (mode 3: longest-run candidates; the run length by doubling and refinement) against
+    the brute-force minimum over all translations / reflections / spin flips: every state of the small rings (including the
+    < 9-site ones that take the step-by-step path), random states of every weight on 32-, 33-, 36-, 40-, 63- and 64-site
+    rings, and states with long runs (>= 8: the step-by-step tail)."""
+    lib = _lib.load()
+    f = lib.ls_amd_test_rep_trivial_dihedral
+    for L in (2, 3, 5, 8, 9, 10, 13):
+        for a in range(1 << L):
+            assert f(a, L, inv, reflect) == _orbit_min(a, L, inv, reflect), (L, a)
+    rng = np.random.default_rng(11)
+    for L in (16, 31, 32, 33, 36, 40, 63, 64):
+        samples = []
+        for w in (1, 2, L // 4, L // 2, L - 3, L - 1):
+            for _ in range(25):
+                bits = rng.choice(L, size=w, replace=False)
+                samples.append(sum(1 << int(b) for b in bits))
+        for run in (8, 9, 15, L - 2):  # long runs of zeros and of ones, at the seam and inside
+            for shift in (0, 1, L - 3):
+                block = ((1 << run) - 1)
+                z = ((block << shift) | (block >> (L - shift))) & ((1 << L) - 1) if shift else block
+                samples += [z, z ^ ((1 << L) - 1), z | (1 << ((shift + run + 2) % L))]
+        for a in samples:
+            assert f(a, L, inv, reflect) == _orbit_min(a, L, inv, reflect), (L, hex(a))
