@@ -133,8 +133,13 @@ def roofline_object(args, kernel_name, kernel_ms, launches_per_step, rows_here, 
                     # integer-ALU roofline of the projected bases: wave64 VALU instructions x 64 lanes
                     peak_lane_ops = 256 * 4 * 32 * 2.4e9  # CUs x SIMDs x lanes per clock x Hz
                     ach = ent["valu_insts"] * 64 / t if t else None
+                    # ... against the spec rate (2 cycles per wave64 instruction), and as issue time at the ~4 cycles the shifts,
+                    # bit-field / count instructions, multiplies and f64 ops of these kernels measure on this part
+                    # (profiles/r3_valu_issue_rates.txt; = the VALUBusy formula of the SQ counters)
+                    busy4 = ent["valu_insts"] * 4 / (256 * 4 * 2.4e9) / t if t else None
                     int_alu = {"valu_wave_insts_per_launch": ent["valu_insts"], "achieved_lane_ops_per_s": ach,
-                               "peak_lane_ops_per_s": peak_lane_ops, "frac": ach / peak_lane_ops if ach else None}
+                               "peak_lane_ops_per_s": peak_lane_ops, "frac": ach / peak_lane_ops if ach else None,
+                               "issue_time_frac_at_4_cycles": busy4}
             else:
                 traffic_note = (f"PMC entry is stale: measured on {ent.get('device_kernel')} ISA {ent.get('isa_sha')} (source_sha "
                                 f"{ent.get('source_sha')}), this build is ISA {isa} (source_sha {sha}); re-run "

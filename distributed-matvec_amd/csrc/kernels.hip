@@ -415,6 +415,11 @@ template <typename W>
 __host__ __device__ __forceinline__ W rotl_sites(W x, int s, int L, W mask) {
     return s == 0 ? x : (W)(((x << s) | (x >> (L - s))) & mask);
 }
+// rotl_sites without the final mask: for the run searches, where the result only meets words inside the mask
+template <typename W>
+__host__ __device__ __forceinline__ W rotl_raw(W x, int s, int L) {
+    return s == 0 ? x : (W)((x << s) | (x >> (L - s)));
+}
 template <typename W>
 __host__ __device__ __forceinline__ W rev_sites(W x, int L) {
     if (sizeof(W) == 4) return (W)(k4_brev32((uint32_t)x) >> (32 - L));
@@ -439,7 +444,7 @@ __host__ __device__ __forceinline__ W longest_runs(W z, int L, W mask, int &len)
         W R = z;
         int s = 1;
         for (;;) {
-            const W T = R & rotl_sites<W>(z, s, L, mask);
+            const W T = R & rotl_raw<W>(z, s, L);
             if (T == 0) break;
             R = T;
             ++s;
@@ -447,16 +452,16 @@ __host__ __device__ __forceinline__ W longest_runs(W z, int L, W mask, int &len)
         len = s;
         return R;
     }
-    const W R2 = z & rotl_sites<W>(z, 1, L, mask);
-    const W R4 = R2 & rotl_sites<W>(R2, 2, L, mask);
-    const W R8 = R4 & rotl_sites<W>(R4, 4, L, mask);
+    const W R2 = z & rotl_raw<W>(z, 1, L);
+    const W R4 = R2 & rotl_raw<W>(R2, 2, L);
+    const W R8 = R4 & rotl_raw<W>(R4, 4, L);
     W R;
     int s;
     if (R8 != 0) { // rare per packet; the tail of the old loop
         R = R8;
         s = 8;
         for (;;) {
-            const W T = R & rotl_sites<W>(z, s, L, mask);
+            const W T = R & rotl_raw<W>(z, s, L);
             if (T == 0 || s + 1 >= L) break;
             R = T;
             ++s;
@@ -467,9 +472,9 @@ __host__ __device__ __forceinline__ W longest_runs(W z, int L, W mask, int &len)
     const bool c4 = R4 != 0, c2 = R2 != 0;
     R = c4 ? R4 : (c2 ? R2 : z);
     s = c4 ? 4 : (c2 ? 2 : 1);
-    const W R6 = R4 & rotl_sites<W>(R2, 4, L, mask);
+    const W R6 = R4 & rotl_raw<W>(R2, 4, L);
     if (R6 != 0) { R = R6; s = 6; }
-    const W T = R & rotl_sites<W>(z, s, L, mask);
+    const W T = R & rotl_raw<W>(z, s, L);
     if (T != 0) { R = T; ++s; }
     len = s;
     return R;
@@ -493,6 +498,9 @@ __host__ __device__ __forceinline__ W family_min(W word, W R, int len, int L, W 
     }
     return best;
 }
+// (Both families through ONE loop -- a lane walking the starts of the first, then of the second, with the second's
+// candidates as complements of the rotations of a -- measured slower: 15.7 vs 14.4 ms for the packets of chain_36_symm,
+// scripts/k4_rate.py; the selects per iteration cost more than the shorter trip count saves.)
 template <typename W>
 __host__ __device__ __forceinline__ W rep_trivial_dihedral(W a, int L, W mask, bool inv, bool reflect) {
     const W na = (W)(~a & mask);

@@ -26,4 +26,5 @@ except Exception as e:
     print('$f', 'NO JSON', e); sys.exit(0)
 r=d['roofline']
 print('$f'.split('/')[-1], round(d['value'],2), 'matvec/s', round(d['ms_per_step'],3),'ms', r['kernel'], 'frac', round(r['frac'],3) if r['frac'] else None, 'traffic', r.get('traffic'), 'frac_traffic', r.get('frac_traffic'), d.get('exchanges') and {k:(v.get('ms_per_step') or v.get('error')) for k,v in d['exchanges'].items()})"; done
+timeout 300 python scripts/k4_rate.py heisenberg_chain_36_symm 2>&1 | grep variant > $OUT/k4_rate.txt; cat $OUT/k4_rate.txt
 echo "--- self-launch on a one-GPU box:"; python bench.py --gpus 2 --steps 2 --warmup 1 --no-cpu-baseline 2>&1 | tail -2
