@@ -503,14 +503,37 @@ __host__ __device__ __forceinline__ W family_min(W word, W R, int len, int L, W 
 // scripts/k4_rate.py; the selects per iteration cost more than the shorter trip count saves.)
 template <typename W>
 __host__ __device__ __forceinline__ W rep_trivial_dihedral(W a, int L, W mask, bool inv, bool reflect) {
-    const W na = (W)(~a & mask);
-    int len0, len1 = -1;
-    const W R0 = longest_runs<W>(na, L, mask, len0); // zero runs of a
-    W R1 = 0;
-    if (inv) R1 = longest_runs<W>(a, L, mask, len1); // zero runs of the flipped state = one runs of a
+    if (!inv) {
+        int len0;
+        const W R0 = longest_runs<W>((W)(~a & mask), L, mask, len0); // zero runs of a
+        return family_min<W>(a, R0, len0, L, mask, reflect, ~(W)0);
+    }
+    // With the global spin flip the minimum starts with the longest run of EQUAL bits of a, zeros or ones (a run of ones
+    // leads the flipped word).  Those runs are the zero runs of the transition word t = a ^ rotl(a, 1) (t_p = 1 where
+    // a changes between p-1 and p), one site shorter and with the same MSB ends -- so ONE run search finds the longest
+    // runs of both kinds, ties between the kinds included, and ONE loop walks their starts; the kind of a run is the top bit
+    // of the rotated word.  (Until late round 3: a search for zeros, one for ones, and two candidate passes that nearly
+    // every wave entered both of; K4 alone 7.0 ms for the packets of chain_36_symm.)
+    const W zt = (W)(~(a ^ rotl_sites<W>(a, 1, L, mask)) & mask);
+    W R;
+    int ell; // length of the longest run of equal bits
+    if (zt == 0) { R = mask; ell = 1; }            // a alternates: every site starts a run of one
+    else if (zt == mask) { R = (W)1; ell = L; }    // all sites equal
+    else { int lt; R = longest_runs<W>(zt, L, mask, lt); ell = lt + 1; }
+    const int lr = ell >= L ? 0 : ell;
     W best = ~(W)0;
-    if (len0 >= len1) best = family_min<W>(a, R0, len0, L, mask, reflect, best);
-    if (inv && len1 >= len0) best = family_min<W>(na, R1, len1, L, mask, reflect, best);
+    while (R) {
+        const int p = sizeof(W) == 4 ? k4_ctz32((uint32_t)R) : k4_ctz64((uint64_t)R);
+        R &= R - 1;
+        const W r = rotl_sites<W>(a, L - 1 - p, L, mask); // site p becomes the top site
+        const W flip = ((r >> (L - 1)) & 1) ? mask : (W)0;  // a run of ones: its flipped image competes
+        const W c = r ^ flip;
+        best = c < best ? c : best;
+        if (reflect) {
+            const W m = rev_sites<W>(rotl_sites<W>(r, lr, L, mask), L) ^ flip;
+            best = m < best ? m : best;
+        }
+    }
     return best;
 }
 // host test hook: mode-3 orbit minimum of `a` on a ring of L sites (32-bit words for L <= 32, as the kernels choose)
