@@ -17,6 +17,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <type_traits>
 
 #include "lsk.h"
 
@@ -2659,6 +2660,196 @@ __global__ LSK_PULLIDX_BOUNDS void k_tile_pull_idx(lsk_runs runs, int n_groups, 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_tile_pull_wv: k_tile_pull_idx with the packet list PER WAVE.  Each wave owns a 256-slot ring of the LDS list and the
+// rows of its 64 lanes: stage A appends the packets of three groups (<= 192) behind what is left in the ring, stage B takes
+// full chunks of 64 packets out of it -- K4 with every lane busy -- and leaves the remainder (< 64) for the next round; the
+// tile ends with one partial chunk.  No block barrier inside a tile except around the shared near window: the four waves
+// of a block drift apart, so the ALU phase (K4) of one overlaps the look-ups of another (k_tile_pull_idx synchronises all
+// four twice per four groups, and its last pass over the list runs K4 for a handful of packets).  Accumulation stays
+// ds_add_f64 into the tile's LDS copy of y; the rows of a wave are only touched by that wave.
+// ---------------------------------------------------------------------------------------------
+constexpr int kWvRing = 256; // slots per wave: < 64 left over + 3 groups x 64 lanes
+constexpr int kWvGroups = 3;
+template <typename W, bool PM1, bool CPLX, bool REAL>
+__global__ __launch_bounds__(kBlock) void k_tile_pull_wv(lsk_runs runs, int n_groups, lsk_group const *__restrict__ groups,
+                                                         lsk_term const *__restrict__ off, int n_diag,
+                                                         lsk_term const *__restrict__ diag, lsk_basis bs,
+                                                         lsk_group_elem const *__restrict__ elems, int64_t row0, int64_t row1,
+                                                         uint64_t const *__restrict__ reps,
+                                                         double const *__restrict__ norms_local, lsk_pullidx ix,
+                                                         uint64_t const *__restrict__ greps, int64_t n_global,
+                                                         double const *__restrict__ xsrc, int halo, double *__restrict__ y,
+                                                         int *err) {
+    typedef typename ChainX<CPLX>::type X;
+    X const *__restrict__ xv = (X const *)xsrc;
+    extern __shared__ uint32_t s_win[];
+    constexpr int kCap = (kBlock / 64) * kWvRing;
+    constexpr bool RC = REAL && PM1;
+    __shared__ uint64_t s_beta[kCap];
+    __shared__ double s_coef[kCap * (RC ? 1 : 2)];
+    __shared__ uint16_t s_row[kCap];
+    __shared__ double s_acc[kBlock * (CPLX ? 2 : 1)];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int rb = (tid >> 6) * kWvRing; // this wave's ring
+    uint64_t const *__restrict__ tab = ix.tab.entries;
+    for (int64_t t0 = row0 + (int64_t)blockIdx.x * kBlock; t0 < row1; t0 += (int64_t)gridDim.x * kBlock) {
+        const int64_t i = t0 + tid;
+        const bool valid = i < row1;
+        uint64_t a = 0;
+        double inv_na = 0.0;
+        if (valid) {
+            a = reps[i];
+            const double na = norms_local[i];
+            inv_na = na > 0.0 ? 1.0 / na : 0.0;
+        }
+        if (CPLX) { s_acc[2 * tid] = 0.0; s_acc[2 * tid + 1] = 0.0; } else s_acc[tid] = 0.0;
+        int64_t gbase = 0;
+        int wn = 0;
+        uint64_t v0 = 0;
+        if (halo > 0) {
+            const int64_t ig0 = ix.row_g0 + t0;
+            gbase = ig0 > halo ? ig0 - halo : 0;
+            const int64_t left = n_global - gbase;
+            wn = (int)(left < (int64_t)(kBlock + 2 * halo) ? left : (int64_t)(kBlock + 2 * halo));
+            v0 = greps[gbase];
+            for (int w = tid; w < wn; w += kBlock) s_win[w] = window_offset(greps[gbase + w], v0);
+        }
+        __syncthreads(); // the window is staged
+        int head = 0, cnt = 0; // wave-uniform: the ring holds [head, head + cnt) mod kWvRing
+        // K chunks at once: the packets at ring positions head + 64 k + lane (the last chunk holds m <= 64 of them):
+        // K4 -> slot -> value -> ds_add_f64, the loads of the K packets of a lane issued together
+        auto chunks = [&](auto KC, int m) {
+            constexpr int K = decltype(KC)::value;
+            uint64_t beta[K], bkt[K];
+            double hr[K], hi[K];
+            int r[K], pos[K];
+            bool live[K];
+            uint32_t tag[K], slot[K];
+            ulonglong2 first[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                live[k] = k + 1 < K || lane < m;
+                const int e = rb + ((head + 64 * k + lane) & (kWvRing - 1));
+                beta[k] = live[k] ? s_beta[e] : 0;
+                hr[k] = 0.0; hi[k] = 0.0;
+                if (live[k]) { if (RC) hr[k] = s_coef[e]; else { hr[k] = s_coef[2 * e]; hi[k] = s_coef[2 * e + 1]; } }
+                r[k] = live[k] ? (int)s_row[e] : 0;
+            }
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                if (bs.k4_mode != 0) {
+                    beta[k] = (uint64_t)rep_trivial<W>(bs, elems, (W)beta[k]); // xsrc is pre-multiplied by norm(rep)
+                } else if (live[k]) {
+                    W rep; double chr, chi, stab;
+                    state_info_w<W, PM1>(bs, elems, (W)beta[k], rep, chr, chi, stab);
+                    const double n2 = stab * bs.inv_order;
+                    if (!(n2 > 1e-12)) live[k] = false; // zero-norm orbit: contributes nothing (DMV:110)
+                    else {
+                        const double nb = sqrt(n2);
+                        beta[k] = (uint64_t)rep;
+                        const double tr = (hr[k] * chr + hi[k] * chi) * nb, ti = (hi[k] * chr - hr[k] * chi) * nb;
+                        hr[k] = tr; hi[k] = ti;
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < K; ++k) { // window searches: LDS only
+                pos[k] = -1; bkt[k] = 0; tag[k] = 0; slot[k] = 0;
+                first[k] = make_ulonglong2(0, 0);
+                if (live[k]) {
+                    if (wn > 0 && beta[k] >= v0) {
+                        const uint32_t d = window_offset(beta[k], v0);
+                        if (d != kWinAbsent) pos[k] = window_find(s_win, wn, d);
+                    }
+                    if (pos[k] < 0) gt_split(ix.tab, beta[k], bkt[k], tag[k]);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < K; ++k) { // first-level loads: perm entry (near) or home bucket (far)
+                if (!live[k]) continue;
+                if (pos[k] >= 0) slot[k] = ix.perm ? ix.perm[gbase + pos[k]] : (uint32_t)(gbase + pos[k]);
+                else first[k] = *(ulonglong2 const *)(tab + 2 * bkt[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                if (!live[k] || pos[k] >= 0) continue;
+                slot[k] = gt_resolve(ix.tab, tab, bkt[k], tag[k], first[k]);
+                if (slot[k] == 0xffffffffu) { atomicExch(err, 1); live[k] = false; }
+            }
+            X val[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) val[k] = live[k] ? xv[slot[k]] : cx_zero<X>();
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                if (!live[k]) continue;
+                if constexpr (CPLX) {
+                    atomicAdd(&s_acc[2 * r[k]], hr[k] * val[k].x - hi[k] * val[k].y);
+                    atomicAdd(&s_acc[2 * r[k] + 1], hr[k] * val[k].y + hi[k] * val[k].x);
+                } else {
+                    atomicAdd(&s_acc[r[k]], hr[k] * val[k]);
+                }
+            }
+        };
+        for (int g0 = 0; g0 < n_groups; g0 += kWvGroups) {
+            const int g1 = min(g0 + kWvGroups, n_groups);
+            for (int g = g0; g < g1; ++g) { // stage A: append
+                lsk_group const G = groups[g];
+                double cr = 0.0, ci = 0.0;
+                if (valid) group_coeff<REAL>(G, off, a, cr, ci);
+                const bool act = valid && (cr != 0.0 || (!REAL && ci != 0.0));
+                const unsigned long long ball = __ballot(act);
+                if (act) {
+                    const int slot = rb + ((head + cnt + __popcll(ball & ((1ULL << lane) - 1))) & (kWvRing - 1));
+                    s_beta[slot] = a ^ G.x;
+                    s_row[slot] = (uint16_t)tid;
+                    if (RC) s_coef[slot] = cr * inv_na;
+                    else { s_coef[2 * slot] = cr * inv_na; s_coef[2 * slot + 1] = -ci * inv_na; }
+                }
+                cnt += __popcll(ball);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            while (cnt >= 128) { // stage B on full chunks, two at a time while the ring has them
+                chunks(std::integral_constant<int, 2>(), 64);
+                head = (head + 128) & (kWvRing - 1);
+                cnt -= 128;
+            }
+            if (cnt >= 64) {
+                chunks(std::integral_constant<int, 1>(), 64);
+                head = (head + 64) & (kWvRing - 1);
+                cnt -= 64;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (cnt > 0) chunks(std::integral_constant<int, 1>(), cnt);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (valid) {
+            const int64_t ig = ix.row_g0 + i;
+            const uint32_t own = ix.perm ? ix.perm[ig] : (uint32_t)ig;
+            const double back = bs.k4_mode != 0 ? inv_na : 1.0; // xsrc holds x * norm(rep) in the prescaling K4 modes
+            double dr = 0.0, di = 0.0;
+            if (n_diag > 0) diag_coeff<uint64_t, REAL>(runs, n_diag, diag, a, dr, di);
+            if constexpr (CPLX) {
+                const X xo = xv[own];
+                const double xr = xo.x * back, xi = xo.y * back;
+                double yr = dr * xr - di * xi + s_acc[2 * tid], yi = dr * xi + di * xr + s_acc[2 * tid + 1];
+                if (n_diag == 0) { yr += y[2 * i]; yi += y[2 * i + 1]; } // accumulate, DMV:1062-1063
+                y[2 * i] = yr; y[2 * i + 1] = yi;
+            } else {
+                double yr = n_diag > 0 ? dr * (xv[own] * back) + s_acc[tid] : s_acc[tid];
+                if (n_diag == 0) yr += y[i];
+                y[i] = yr;
+            }
+        }
+        __syncthreads(); // every wave is done with the window
+    }
+}
+
 extern "C" int lsk_tile_pull_idx(lsk_operator op, lsk_basis bs, int cplx, int64_t row0, int64_t row1, uint64_t const *reps,
                                  double const *norms_local, lsk_pullidx ix, uint64_t const *reps_global, int64_t n_global,
                                  void const *xsrc, int halo, void *y, int *d_err, void *stream) {
@@ -2671,6 +2862,20 @@ extern "C" int lsk_tile_pull_idx(lsk_operator op, lsk_basis bs, int cplx, int64_
 #define LSK_TPI_ARGS op.runs, op.n_groups, op.groups, op.off, op.n_diag, op.diag, bs, bs.elems, row0, row1, reps, norms_local, ix, \
         reps_global, n_global, (double const *)xsrc, halo, (double *)y, d_err
     const size_t win_bytes = sizeof(uint32_t) * (size_t)(kBlock + 2 * halo);
+    // per-wave packet rings (k_tile_pull_wv) by default; LS_AMD_PULL_WAVE=0: the block-wide list (k_tile_pull_idx).  Measured in
+    // one job each: chain_36_symm 18.34 -> 18.13 ms, chain_40_symm 290.8 -> 275.0 ms (309.7 -> 283.5 on another box)
+    int wave_lists = 1;
+    { char const *e = getenv("LS_AMD_PULL_WAVE"); if (e) wave_lists = atoi(e); }
+#define LSK_TPW_LAUNCH(W, PM1)                                                                                  \
+    do {                                                                                                        \
+        if (cplx) {                                                                                             \
+            if (op.is_real) { g.x = tile_grid(k_tile_pull_wv<W, PM1, true, true>, work_blocks); hipLaunchKernelGGL((k_tile_pull_wv<W, PM1, true, true>), g, b, win_bytes, s, LSK_TPI_ARGS); } \
+            else { g.x = tile_grid(k_tile_pull_wv<W, PM1, true, false>, work_blocks); hipLaunchKernelGGL((k_tile_pull_wv<W, PM1, true, false>), g, b, win_bytes, s, LSK_TPI_ARGS); } \
+        } else {                                                                                                \
+            if (op.is_real) { g.x = tile_grid(k_tile_pull_wv<W, PM1, false, true>, work_blocks); hipLaunchKernelGGL((k_tile_pull_wv<W, PM1, false, true>), g, b, win_bytes, s, LSK_TPI_ARGS); } \
+            else { g.x = tile_grid(k_tile_pull_wv<W, PM1, false, false>, work_blocks); hipLaunchKernelGGL((k_tile_pull_wv<W, PM1, false, false>), g, b, win_bytes, s, LSK_TPI_ARGS); } \
+        }                                                                                                       \
+    } while (0)
 #define LSK_TPI_LAUNCH(W, PM1)                                                                                  \
     do {                                                                                                        \
         if (cplx) {                                                                                             \
@@ -2681,8 +2886,12 @@ extern "C" int lsk_tile_pull_idx(lsk_operator op, lsk_basis bs, int cplx, int64_
             else { g.x = tile_grid(k_tile_pull_idx<W, PM1, false, false>, work_blocks); hipLaunchKernelGGL((k_tile_pull_idx<W, PM1, false, false>), g, b, win_bytes, s, LSK_TPI_ARGS); } \
         }                                                                                                       \
     } while (0)
-    if (bs.number_sites <= 32) { if (bs.chars_pm1) LSK_TPI_LAUNCH(uint32_t, true); else LSK_TPI_LAUNCH(uint32_t, false); }
+    if (wave_lists) {
+        if (bs.number_sites <= 32) { if (bs.chars_pm1) LSK_TPW_LAUNCH(uint32_t, true); else LSK_TPW_LAUNCH(uint32_t, false); }
+        else { if (bs.chars_pm1) LSK_TPW_LAUNCH(uint64_t, true); else LSK_TPW_LAUNCH(uint64_t, false); }
+    } else if (bs.number_sites <= 32) { if (bs.chars_pm1) LSK_TPI_LAUNCH(uint32_t, true); else LSK_TPI_LAUNCH(uint32_t, false); }
     else { if (bs.chars_pm1) LSK_TPI_LAUNCH(uint64_t, true); else LSK_TPI_LAUNCH(uint64_t, false); }
+#undef LSK_TPW_LAUNCH
 #undef LSK_TPI_LAUNCH
 #undef LSK_TPI_ARGS
     LSK_LAUNCH_CHECK();

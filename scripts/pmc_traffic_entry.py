@@ -37,6 +37,8 @@ def main():
     from bench import kernel_instance_sha, kernel_isa_sha, source_sha
 
     needle = next(v for k, v in DEVICE_KERNEL.items() if k in kname)
+    if needle == "k_tile_pull_idx" and os.environ.get("LS_AMD_PULL_WAVE", "1") != "0":
+        needle = "k_tile_pull_wv"  # the default indexed kernel since late round 3 (per-wave packet rings)
     fetch, nf = mean_counter(root, "pmc_fetch", "FETCH_SIZE", needle)
     write, nw = mean_counter(root, "pmc_write", "WRITE_SIZE", needle)
     valu, nv = mean_counter(root, "pmc_valu", "SQ_INSTS_VALU", needle)

@@ -186,13 +186,15 @@ PROJECTED_MODELS = ["heisenberg_chain_24_symm", "heisenberg_kagome_12_symm", "is
 
 
 @pytest.mark.parametrize("name", PROJECTED_MODELS)
-@pytest.mark.parametrize("halo", ["512", "0", "37"])
-def test_indexed_pull_mode_single_locale(torch, monkeypatch, name, halo):
+@pytest.mark.parametrize("halo,wave", [("512", "1"), ("0", "1"), ("37", "1"), ("512", "0"), ("37", "0")])
+def test_indexed_pull_mode_single_locale(torch, monkeypatch, name, halo, wave):
     """the INDEXED mode of the projected-basis pull kernel (static {rep -> index} table, x read through the index; no
-    per-matvec table refresh) == the oracle, f64 and c128, with the near window on, off and at an odd size; the trivial
+    per-matvec table refresh) == the oracle, f64 and c128, with the near window on, off and at an odd size, through both of
+    its device kernels (per-wave packet rings = the default, and the block-wide list); the trivial
     sectors prescale x by norm(rep), issue_01 (character -1) does not"""
     monkeypatch.setenv("LS_AMD_PULL_INDEXED", "1")
     monkeypatch.setenv("LS_AMD_PULL_HALO", halo)
+    monkeypatch.setenv("LS_AMD_PULL_WAVE", wave)
     D, basis, h, reps, masks = setup_model(torch, model_config(name), 1)
     want_reps = oracle_reps(name)
     rs = np.random.RandomState(52)
