@@ -1427,15 +1427,17 @@ extern "C" int lsk_test_chain_near_table(int elem, int ldsp, int16_t *out) {
     chain_binomials(C);
     return chain_near_fill(C, elem, ldsp, out);
 }
-struct ChainImage { int rsize, rows, kc, elem, ldsp; uint4 *dev; int bytes, near_off; };
+struct ChainImage { int rsize, rows, kc, elem, ldsp, device; uint4 *dev; int bytes, near_off; };
 static int chain_lds_image(int rsize, int rows, int weight, int elem, int ldsp, ChainImage *out) {
     static std::vector<ChainImage> cache;
     static std::mutex lock;
     std::lock_guard<std::mutex> guard(lock);
     int kc = (weight < 0 ? rows : weight) + 2;
     if (kc > LSK_BINOM_K) kc = LSK_BINOM_K;
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess) device = 0; // the image lives in the memory of the device it was made on
     for (ChainImage const &c : cache)
-        if (c.rsize == rsize && c.rows == rows && c.kc == kc && c.elem == elem && c.ldsp == ldsp) { *out = c; return 0; }
+        if (c.rsize == rsize && c.rows == rows && c.kc == kc && c.elem == elem && c.ldsp == ldsp && c.device == device) { *out = c; return 0; }
     uint64_t C[64][LSK_BINOM_K];
     chain_binomials(C);
     int const near_off = (rows * kc * rsize + 15) & ~15;
@@ -1447,7 +1449,7 @@ static int chain_lds_image(int rsize, int rows, int weight, int elem, int ldsp, 
             else reinterpret_cast<uint64_t *>(img.data())[n * kc + k] = C[n][k];
         }
     if (chain_near_fill(C, elem, ldsp, reinterpret_cast<int16_t *>(img.data() + near_off)) != 0) return -1;
-    ChainImage c = {rsize, rows, kc, elem, ldsp, nullptr, bytes, near_off};
+    ChainImage c = {rsize, rows, kc, elem, ldsp, device, nullptr, bytes, near_off};
     if (hipMalloc((void **)&c.dev, (size_t)bytes) != hipSuccess) { snprintf(g_err, sizeof(g_err), "chain_lds_image: no device memory"); return -1; }
     if (hipMemcpy(c.dev, img.data(), (size_t)bytes, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(c.dev); snprintf(g_err, sizeof(g_err), "chain_lds_image: copy failed"); return -1; }
     cache.push_back(c);
