@@ -252,15 +252,23 @@ def diagonalize(config, num_evals: int = 1, eps: float = 1e-6, num_partitions: i
         from . import hdf5
 
         to_block = lambda v: api.arrFromHashedToBlock(list(v.split(op.sizes)), masks) if num_partitions > 1 else v  # noqa: E731
-        evecs = np.stack([to_block(v).cpu().numpy() for v in r.eigenvectors])
-        if np.iscomplexobj(evecs):
+        if any(v.is_complex() for v in r.eigenvectors):
             raise NotImplementedError("HDF5 output is implemented for real eigenvectors (the reference's eltType is real(64))")
         hdf5.write_datasets(output, append=True, datasets={
             "/basis/representatives": (api.arrFromHashedToBlock(reps, masks) if num_partitions > 1 else reps[0]).cpu().numpy().view(np.uint64),
             "/hamiltonian/eigenvalues": np.array(r.eigenvalues),
             "/hamiltonian/residuals": np.array(r.residual_norms),
-            "/hamiltonian/eigenvectors": evecs,
         })
+        # the eigenvectors go out block by block (writeDatasetAsBlocks, MyHDF5.chpl:303-333: every locale its own hyperslab of
+        # the last dimension): the host holds one block at a time -- chain_40_symm vectors are 6.9 GB each
+        n_states = int(sum(op.sizes)) if num_partitions > 1 else int(reps[0].numel())
+        num_blocks = max(num_partitions, -(-n_states // (1 << 27)))
+        hdf5.create_dataset(output, "/hamiltonian/eigenvectors", (len(r.eigenvectors), n_states), np.float64)
+        for row, v in enumerate(r.eigenvectors):
+            vb = to_block(v)
+            for b in range(num_blocks):
+                lo, hi = hdf5.block_range(n_states, num_blocks, b)
+                hdf5.write_dataset_chunk(output, "/hamiltonian/eigenvectors", (row, lo), vb[lo:hi].cpu().numpy()[None, :])
     elif output:
         parts_to_block = lambda v: api.arrFromHashedToBlock(list(v.split(op.sizes)), masks) if num_partitions > 1 else v  # noqa: E731
         np.savez(

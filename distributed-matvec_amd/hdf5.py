@@ -1,5 +1,5 @@
 """Minimal HDF5 reader/writer for the reference's on-disk format either side of the matvec path
-(/root/reference/src/MyHDF5.chpl:71-144,272-333; produced by /root/reference/input_for_matvec.py:43-46):
+(/root/reference/src/MyHDF5.chpl:71-144,214-333; produced by /root/reference/input_for_matvec.py:43-46):
     /x, /y               float64, rank 2, shape [batch, N]   (vectors in global ascending order)
     /representatives     uint64,  rank 1
 and the groups `basis`, `hamiltonian` the eigensolver driver writes (Diagonalize.chpl:241,252-255).
@@ -22,6 +22,7 @@ H5F_ACC_RDONLY, H5F_ACC_RDWR, H5F_ACC_TRUNC = 0x0000, 0x0001, 0x0002
 H5P_DEFAULT = 0
 H5S_ALL = 0
 H5T_INTEGER, H5T_FLOAT = 0, 1
+H5S_SELECT_SET = 0
 
 
 class Hdf5Unavailable(RuntimeError):
@@ -64,6 +65,8 @@ def lib():
         ("H5Dcreate2", hid_t, [hid_t, C.c_char_p, hid_t, hid_t, hid_t, hid_t, hid_t]),
         ("H5Gcreate2", hid_t, [hid_t, C.c_char_p, hid_t, hid_t, hid_t]),
         ("H5Gclose", C.c_int, [hid_t]),
+        ("H5Sselect_hyperslab", C.c_int, [hid_t, C.c_int, C.POINTER(hsize_t), C.POINTER(hsize_t), C.POINTER(hsize_t), C.POINTER(hsize_t)]),
+        ("H5Tequal", C.c_int, [hid_t, hid_t]),
         ("H5Lexists", C.c_int, [hid_t, C.c_char_p, hid_t]),
         ("H5Ldelete", C.c_int, [hid_t, C.c_char_p, hid_t]),
     ]:
@@ -196,3 +199,164 @@ def write_datasets(path: str, datasets: dict, append: bool = False):
                 raise OSError(f"H5Dwrite failed for {name}")
     finally:
         L.H5Fclose(f)
+
+
+# ---------------------------------------------------------------------------------------------
+# Block-distributed I/O (MyHDF5.chpl:105-144, 214-253, 272-333): every locale reads / writes its own hyperslab of a
+# dataset, so a vector that does not fit one host buffer (chain_40_symm eigenvectors: 6.9 GB each) never has to.  The blocks
+# are Chapel's Block distribution of the LAST dimension over the locales (rank 1: the only one; rank 2: [batch, N] split along
+# N, `reshape(Locales, {0 ..# 1, 0 ..# numLocales})`): locale p owns the indices i with floor(i * P / n) == p.
+# ---------------------------------------------------------------------------------------------
+def block_range(n: int, num_blocks: int, block: int):
+    """[lo, hi) of the indices of 0..n-1 that Chapel's Block distribution over `num_blocks` locales gives locale `block`"""
+    if not (0 <= block < num_blocks):
+        raise ValueError(f"block {block} of {num_blocks}")
+    lo = -((-block * n) // num_blocks)
+    hi = -((-(block + 1) * n) // num_blocks)
+    return lo, hi
+
+
+def _open_checked(L, f, path, name, rank, dtype):
+    d = L.H5Dopen2(f, name.encode(), H5P_DEFAULT)
+    if d < 0:
+        raise KeyError(name)
+    s = L.H5Dget_space(d)
+    nd = L.H5Sget_simple_extent_ndims(s)
+    if nd != rank:  # MyHDF5.chpl:119-121 / 228-230
+        L.H5Sclose(s)
+        L.H5Dclose(d)
+        raise ValueError(f"halt: rank mismatch in file: '{path}' dataset: '{name}'  {rank} != {nd}")
+    t = L.H5Dget_type(d)
+    same = L.H5Tequal(_native(dtype), t) > 0
+    L.H5Tclose(t)
+    if not same:  # MyHDF5.chpl:125-127 / 233-235
+        L.H5Sclose(s)
+        L.H5Dclose(d)
+        raise TypeError(f"halt: type mismatch in file: '{path}' dataset: '{name}'  (expected {np.dtype(dtype).name})")
+    return d, s
+
+
+def _select(L, s, offset, shape):
+    nd = len(shape)
+    c_off = (hsize_t * nd)(*[int(v) for v in offset])
+    c_shape = (hsize_t * nd)(*[int(v) for v in shape])
+    dims = (hsize_t * nd)()
+    L.H5Sget_simple_extent_dims(s, dims, None)
+    if any(int(c_off[k]) + int(c_shape[k]) > int(dims[k]) for k in range(nd)):
+        raise IndexError(f"hyperslab {tuple(offset)} + {tuple(shape)} exceeds the dataset {tuple(int(v) for v in dims)}")
+    if L.H5Sselect_hyperslab(s, H5S_SELECT_SET, c_off, None, c_shape, None) < 0:
+        raise OSError("H5Sselect_hyperslab failed")
+    return L.H5Screate_simple(nd, c_shape, None)
+
+
+def read_dataset_chunk(path: str, name: str, offset, shape, dtype=np.float64) -> np.ndarray:
+    """readDatasetChunk (MyHDF5.chpl:105-159): the hyperslab `offset` + `shape` of a dataset; the rank and the element type
+    must be the file's (the reference halts on either mismatch)."""
+    L = lib()
+    shape = tuple(int(v) for v in shape)
+    if len(offset) != len(shape):
+        raise ValueError("offset and shape differ in rank")
+    f = L.H5Fopen(path.encode(), H5F_ACC_RDONLY, H5P_DEFAULT)
+    if f < 0:
+        raise OSError(f"cannot open {path}")
+    try:
+        d, s = _open_checked(L, f, path, name, len(shape), dtype)
+        try:
+            out = np.empty(shape, dtype=dtype)
+            if out.size == 0:
+                return out
+            m = _select(L, s, offset, shape)
+            rc = L.H5Dread(d, _native(dtype), m, s, H5P_DEFAULT, out.ctypes.data_as(C.c_void_p))
+            L.H5Sclose(m)
+            if rc < 0:
+                raise OSError(f"H5Dread failed for {name}")
+            return out
+        finally:
+            L.H5Sclose(s)
+            L.H5Dclose(d)
+    finally:
+        L.H5Fclose(f)
+
+
+def create_dataset(path: str, name: str, shape, dtype=np.float64):
+    """the first half of writeDatasetAsBlocks (MyHDF5.chpl:303-322): an empty dataset of the full shape (an existing one of
+    that name is replaced; the file and the intermediate groups are created when missing)."""
+    L = lib()
+    f = L.H5Fopen(path.encode(), H5F_ACC_RDWR, H5P_DEFAULT) if os.path.exists(path) else \
+        L.H5Fcreate(path.encode(), H5F_ACC_TRUNC, H5P_DEFAULT, H5P_DEFAULT)
+    if f < 0:
+        raise OSError(f"cannot open {path}")
+    try:
+        parts = [p for p in name.split("/") if p]
+        prefix = ""
+        for g in parts[:-1]:
+            prefix += "/" + g
+            if L.H5Lexists(f, prefix.encode(), H5P_DEFAULT) <= 0:
+                L.H5Gclose(L.H5Gcreate2(f, prefix.encode(), H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT))
+        full = "/" + "/".join(parts)
+        if L.H5Lexists(f, full.encode(), H5P_DEFAULT) > 0 and L.H5Ldelete(f, full.encode(), H5P_DEFAULT) < 0:
+            raise OSError(f"cannot replace {name}")
+        shape = tuple(int(v) for v in shape)
+        dims = (hsize_t * max(len(shape), 1))(*shape)
+        s = L.H5Screate_simple(len(shape), dims, None)
+        d = L.H5Dcreate2(f, full.encode(), _native(dtype), s, H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT)
+        L.H5Sclose(s)
+        if d < 0:
+            raise OSError(f"cannot create {name}")
+        L.H5Dclose(d)
+    finally:
+        L.H5Fclose(f)
+
+
+def write_dataset_chunk(path: str, name: str, offset, arr):
+    """writeDatasetChunk (MyHDF5.chpl:214-253): `arr` into the hyperslab at `offset` of an existing dataset of the same rank
+    and element type."""
+    L = lib()
+    arr = np.ascontiguousarray(arr)
+    if len(offset) != arr.ndim:
+        raise ValueError("offset and array differ in rank")
+    f = L.H5Fopen(path.encode(), H5F_ACC_RDWR, H5P_DEFAULT)
+    if f < 0:
+        raise OSError(f"cannot open {path}")
+    try:
+        d, s = _open_checked(L, f, path, name, arr.ndim, arr.dtype)
+        try:
+            if arr.size == 0:
+                return
+            m = _select(L, s, offset, arr.shape)
+            rc = L.H5Dwrite(d, _native(arr.dtype), m, s, H5P_DEFAULT, arr.ctypes.data_as(C.c_void_p))
+            L.H5Sclose(m)
+            if rc < 0:
+                raise OSError(f"halt: HDF5 error: could not write array to dataset {name}")
+        finally:
+            L.H5Sclose(s)
+            L.H5Dclose(d)
+    finally:
+        L.H5Fclose(f)
+
+
+def read_dataset_block(path: str, name: str, num_blocks: int, block: int, dtype=np.float64) -> np.ndarray:
+    """what one locale does inside readDatasetAsBlocks (MyHDF5.chpl:272-287): its block of the last dimension"""
+    shape = dataset_shape(path, name)
+    lo, hi = block_range(shape[-1], num_blocks, block)
+    offset = (0,) * (len(shape) - 1) + (lo,)
+    return read_dataset_chunk(path, name, offset, shape[:-1] + (hi - lo,), dtype)
+
+
+def read_dataset_as_blocks(path: str, name: str, num_blocks: int, dtype=np.float64):
+    """readDatasetAsBlocks: the blocks of all locales, in locale order (one process standing in for every locale)"""
+    return [read_dataset_block(path, name, num_blocks, b, dtype) for b in range(num_blocks)]
+
+
+def write_dataset_as_blocks(path: str, name: str, blocks):
+    """writeDatasetAsBlocks (MyHDF5.chpl:303-333): create the dataset at its full shape, then every locale's block goes to its
+    hyperslab of the last dimension.  `blocks[p]` must have the extent block_range gives locale p."""
+    blocks = [np.ascontiguousarray(b) for b in blocks]
+    n = sum(b.shape[-1] for b in blocks)
+    lead = blocks[0].shape[:-1]
+    create_dataset(path, name, lead + (n,), blocks[0].dtype)
+    for p, b in enumerate(blocks):
+        lo, hi = block_range(n, len(blocks), p)
+        if b.shape[:-1] != lead or b.shape[-1] != hi - lo:
+            raise ValueError(f"block {p} has shape {b.shape}; the Block distribution of {n} over {len(blocks)} gives it {hi - lo}")
+        write_dataset_chunk(path, name, (0,) * len(lead) + (lo,), b)

@@ -34,6 +34,50 @@ def test_round_trip(tmp_path):
         hdf5.read_dataset(path, "/nope")
 
 
+def test_block_distributed_io(tmp_path):
+    """MyHDF5.chpl:105-144, 214-253, 272-333: every locale reads / writes its own hyperslab.  Chapel's Block distribution of the
+    last dimension (locale p owns floor(i P / n) == p), rank 1 and rank 2, uneven splits, more locales than elements, and the
+    reference's halts on a rank or element-type mismatch."""
+    hdf5 = _hdf5()
+    for n, P in ((10, 3), (7, 7), (3, 5), (1000, 8), (0, 2)):
+        owners = [i * P // n for i in range(n)]
+        for p in range(P):
+            lo, hi = hdf5.block_range(n, P, p)
+            assert [i for i in range(n) if owners[i] == p] == list(range(lo, hi))
+    rs = np.random.RandomState(3)
+    path = str(tmp_path / "blocks.h5")
+    n = 1003
+    x = rs.rand(2, n)
+    reps = rs.randint(0, 2**62, size=n, dtype=np.int64).astype(np.uint64)
+    hdf5.write_datasets(path, {"/x": x, "/basis/representatives": reps})
+    for P in (1, 3, 8):
+        blocks = hdf5.read_dataset_as_blocks(path, "/x", P)
+        assert [b.shape for b in blocks] == [(2, hdf5.block_range(n, P, p)[1] - hdf5.block_range(n, P, p)[0]) for p in range(P)]
+        assert np.array_equal(np.concatenate(blocks, axis=1), x)
+        rb = hdf5.read_dataset_as_blocks(path, "/basis/representatives", P, dtype=np.uint64)
+        assert rb[0].dtype == np.uint64 and np.array_equal(np.concatenate(rb), reps)
+        assert np.array_equal(hdf5.read_dataset_block(path, "/x", P, P - 1), blocks[-1])
+        # every "locale" writes its own block; the file then holds the whole vector
+        hdf5.write_dataset_as_blocks(path, f"/hamiltonian/eigenvectors_{P}", [2.0 * b for b in blocks])
+        assert np.array_equal(hdf5.read_dataset(path, f"/hamiltonian/eigenvectors_{P}"), 2.0 * x)
+    # an arbitrary chunk, and an existing dataset replaced by create_dataset
+    assert np.array_equal(hdf5.read_dataset_chunk(path, "/x", (1, 17), (1, 40)), x[1:2, 17:57])
+    hdf5.create_dataset(path, "/y", (1, n))
+    hdf5.write_dataset_chunk(path, "/y", (0, 100), x[:1, 100:300])
+    got = hdf5.read_dataset(path, "/y")
+    assert np.array_equal(got[:, 100:300], x[:1, 100:300]) and hdf5.dataset_shape(path, "/y") == (1, n)
+    with pytest.raises(ValueError, match="rank mismatch"):
+        hdf5.read_dataset_chunk(path, "/x", (0,), (5,))
+    with pytest.raises(TypeError, match="type mismatch"):
+        hdf5.read_dataset_chunk(path, "/x", (0, 0), (1, 5), dtype=np.uint64)
+    with pytest.raises(TypeError, match="type mismatch"):
+        hdf5.write_dataset_chunk(path, "/y", (0, 0), np.zeros((1, 5), dtype=np.uint64))
+    with pytest.raises(IndexError):
+        hdf5.read_dataset_chunk(path, "/x", (0, n - 3), (2, 10))
+    with pytest.raises(ValueError, match="Block distribution"):
+        hdf5.write_dataset_as_blocks(path, "/z", [np.zeros((1, 5)), np.zeros((1, 3))])
+
+
 def _write_golden_like(tmp_path, name):
     """a file with the layout of the reference's data/matvec/<name>.h5 (input_for_matvec.py:43-46), from the
     committed golden vectors (x by the reference's recipe, y by the dense oracle)."""
@@ -83,6 +127,14 @@ def test_diagonalize_writes_reference_style_hdf5(tmp_path):
     assert abs(hdf5.read_dataset(out, "/hamiltonian/eigenvalues")[0] - (-18.061785417968)) < 1e-8
     assert hdf5.read_dataset(out, "/basis/representatives").shape == (126,)
     assert hdf5.dataset_shape(out, "/hamiltonian/eigenvectors") == (1, 126)
+    v = hdf5.read_dataset(out, "/hamiltonian/eigenvectors")[0]
+    assert np.allclose(v, r.eigenvectors[0].cpu().numpy(), rtol=0, atol=1e-15) and abs(np.linalg.norm(v) - 1.0) < 1e-12
+    # three hash partitions: the vector is converted to block order and written as three hyperslabs (Block distribution)
+    out3 = str(tmp_path / "three_locales.h5")
+    r3 = diagonalize(model_config("heisenberg_chain_10"), num_evals=1, eps=1e-10, output=out3, num_partitions=3)
+    v3 = hdf5.read_dataset(out3, "/hamiltonian/eigenvectors")[0]
+    assert abs(r3.eigenvalues[0] - r.eigenvalues[0]) < 1e-9 and abs(abs(np.dot(v3, v)) - 1.0) < 1e-8
+    assert np.array_equal(hdf5.read_dataset(out3, "/basis/representatives"), hdf5.read_dataset(out, "/basis/representatives"))
 
 
 def test_append_keeps_the_stored_basis_and_replaces_results(tmp_path):
