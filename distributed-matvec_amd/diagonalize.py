@@ -281,3 +281,54 @@ def diagonalize(config, num_evals: int = 1, eps: float = 1e-6, num_partitions: i
             },
         )
     return r
+
+
+def diagonalize_distributed(config, group=None, num_evals: int = 1, eps: float = 1e-6, dtype=None, output: str | None = None,
+                            exchange: str = "auto", max_basis: int = 24, verbose: bool = False):
+    """`Diagonalize.main` (Diagonalize.chpl:258-332) with one process per GPU: every rank enumerates the basis on its device,
+    keeps its hash partition of the states and of the Lanczos vectors, the matvec goes through the C host's exchange
+    (replicated-x for Hermitian operators, packets otherwise / on request), the reductions through RCCL, and the output file
+    (HDF5, visible to every rank) is written block-distributed: /basis/representatives and /hamiltonian/eigenvectors [k, N]
+    in global ascending order, every rank its own hyperslab (MyHDF5.chpl:303-333), eigenvalues and residuals by rank 0.
+    Must be called by every rank of `group` (torch.distributed, backend "nccl")."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from . import api, hdf5
+    from .distributed import RcclDistributedOperator, RcclReplicatedOperator, hashed_to_block, write_hashed_vectors
+
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    if isinstance(config, str):
+        basis, h = api.loadConfigFromYaml(config, hamiltonian=True)
+    else:
+        basis, h = api.loadConfigFromDict(config, hamiltonian=True)
+    dtype = dtype or torch.float64
+    parts, masks = api.enumerateStates(basis, world)
+    my_reps = parts[rank]
+    if exchange == "auto":
+        exchange = "replicated" if h.isHermitian() else "packets"
+    if exchange == "replicated":
+        reps_global = api.arrFromHashedToBlock(parts, masks) if world > 1 else parts[0]
+        op = RcclReplicatedOperator(h, reps_global, masks, dtype, group=group)
+        del reps_global
+    else:
+        op = RcclDistributedOperator(h, my_reps, dtype, group=group)
+    del parts
+    r = lanczos_smallest(RankOperator(op, my_reps, dtype), num_evals=num_evals, eps=eps, max_basis=max_basis, verbose=verbose)
+    if output:
+        if not output.endswith((".h5", ".hdf5")):
+            raise ValueError("diagonalize_distributed writes HDF5 (the block-distributed format of the reference)")
+        if rank == 0:
+            hdf5.write_datasets(output, {"/hamiltonian/eigenvalues": np.array(r.eigenvalues),
+                                         "/hamiltonian/residuals": np.array(r.residual_norms)})
+            hdf5.create_dataset(output, "/basis/representatives", (int(masks.numel()),), np.uint64)
+        dist.barrier(group)
+        blk = hashed_to_block(my_reps, masks, group).cpu().numpy().view(np.uint64)
+        lo, _ = hdf5.block_range(int(masks.numel()), world, rank)
+        for w in range(world):  # one writer at a time
+            if w == rank:
+                hdf5.write_dataset_chunk(output, "/basis/representatives", (lo,), blk)
+            dist.barrier(group)
+        write_hashed_vectors(output, "/hamiltonian/eigenvectors", list(r.eigenvectors), masks, group)
+    return r

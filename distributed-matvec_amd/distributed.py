@@ -439,3 +439,105 @@ class ReplicatedOperator:
     global_sum = DistributedOperator.global_sum
     broadcast = DistributedOperator.broadcast
     dot = DistributedOperator.dot
+
+
+# ---------------------------------------------------------------------------------------------
+# Layout converters ACROSS processes and per-rank block I/O: the reference keeps vectors hash-partitioned while it
+# computes and block-distributed on disk (HashedToBlock.chpl:67-153, BlockToHashed.chpl:87-208, MyHDF5.chpl:272-333); with
+# one process per GPU the conversion is one all-to-all-v whose counts every rank derives from `masks` (the owner of every
+# state in global ascending order) without talking to anyone, and every rank reads / writes its own hyperslab.
+# ---------------------------------------------------------------------------------------------
+def _layout_counts(masks, rank: int, world: int):
+    """counts[s][b] = states of hash partition s that fall into block b (Chapel's Block distribution of the global order),
+    the block of this rank, and the position of every state of that block inside its owner's part of the block."""
+    import torch
+
+    from . import hdf5
+
+    n = int(masks.numel())
+    bounds = [hdf5.block_range(n, world, b) for b in range(world)]
+    m = masks.to(torch.int64)
+    counts = torch.zeros((world, world), dtype=torch.int64)
+    for b, (lo, hi) in enumerate(bounds):
+        if hi > lo:
+            counts[:, b] = torch.bincount(m[lo:hi].cpu(), minlength=world)[:world]
+    return counts, bounds[rank]
+
+
+def hashed_to_block(part, masks, group=None):
+    """arrFromHashedToBlock across processes: `part` = this rank's elements (its states in ascending order); returns this
+    rank's block of the vector in global ascending order.  Every run a source sends is contiguous in its part (a part is
+    ascending in the global index), so the send buffer is the part itself."""
+    import torch
+    import torch.distributed as dist
+
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    counts, (lo, hi) = _layout_counts(masks, rank, world)
+    if int(counts[rank].sum()) != int(part.numel()):
+        raise ValueError(f"rank {rank} holds {part.numel()} elements, the masks give it {int(counts[rank].sum())}")
+    recv = torch.empty(hi - lo, dtype=part.dtype, device=part.device)
+    _Transport(group).all_to_all_single(recv, part.contiguous(), [int(c) for c in counts[:, rank]], [int(c) for c in counts[rank]])
+    # recv = [elements owned by 0 | owned by 1 | ...] of this block, each run ascending: a stable sort of the block's owners
+    # gives the position every global index of the block takes in that arrangement
+    order = torch.sort(masks[lo:hi].to(torch.int64).to(part.device), stable=True).indices
+    out = torch.empty_like(recv)
+    out[order] = recv
+    return out
+
+
+def block_to_hashed(block, masks, group=None):
+    """arrFromBlockToHashed across processes: the inverse of hashed_to_block"""
+    import torch
+    import torch.distributed as dist
+
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    counts, (lo, hi) = _layout_counts(masks, rank, world)
+    if int(block.numel()) != hi - lo:
+        raise ValueError(f"rank {rank} holds a block of {block.numel()} elements, the Block distribution gives it {hi - lo}")
+    order = torch.sort(masks[lo:hi].to(torch.int64).to(block.device), stable=True).indices
+    send = block.contiguous()[order]
+    part = torch.empty(int(counts[rank].sum()), dtype=block.dtype, device=block.device)
+    _Transport(group).all_to_all_single(part, send, [int(c) for c in counts[rank]], [int(c) for c in counts[:, rank]])
+    return part
+
+
+def write_hashed_vectors(path: str, name: str, parts, masks, group=None):
+    """writeDatasetAsBlocks for hash-partitioned vectors (Diagonalize.chpl:248-256 -> MyHDF5.chpl:303-333): `parts` = this
+    rank's pieces of k vectors; dataset [k, N] in global ascending order, every rank writing its own hyperslab.  The file
+    must be visible to every rank (one node, or a shared file system -- as in the reference)."""
+    import numpy as np
+    import torch.distributed as dist
+
+    from . import hdf5
+
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    if any(p.is_complex() for p in parts):
+        raise NotImplementedError("HDF5 output is implemented for real vectors (the reference's eltType is real(64))")
+    n = int(masks.numel())
+    lo, _ = hdf5.block_range(n, world, rank)
+    if rank == 0:
+        hdf5.create_dataset(path, name, (len(parts), n), np.float64)
+    dist.barrier(group)  # "without the barrier, H5Dopen fails when called from multiple locales" (MyHDF5.chpl:219-221)
+    for row, p in enumerate(parts):
+        blk = hashed_to_block(p, masks, group).cpu().numpy()
+        for r in range(world):  # one writer at a time: serial HDF5 has no file locking across processes worth trusting
+            if r == rank:
+                hdf5.write_dataset_chunk(path, name, (row, lo), blk[None, :])
+            dist.barrier(group)
+
+
+def read_hashed_vector(path: str, name: str, row: int, masks, group=None, device=None):
+    """readDatasetAsBlocks + arrFromBlockToHashed: every rank reads its block of row `row` of dataset [k, N] and the ranks
+    exchange them into the hash partition"""
+    import torch
+    import torch.distributed as dist
+
+    from . import hdf5
+
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    n = int(masks.numel())
+    lo, hi = hdf5.block_range(n, world, rank)
+    blk = torch.from_numpy(hdf5.read_dataset_chunk(path, name, (row, lo), (1, hi - lo))[0])
+    if device is not None:
+        blk = blk.to(device)
+    return block_to_hashed(blk, masks, group)

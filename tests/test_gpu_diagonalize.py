@@ -62,3 +62,37 @@ def test_chain_12_symmetric_known_energy(torch):
 
     r = diagonalize(config.heisenberg_chain_config(12, symm=True), num_evals=1, eps=1e-10, dtype=torch.complex128)
     assert r.converged and abs(r.eigenvalues[0] - (-21.549563669781)) < 1e-8
+
+
+@pytest.mark.parametrize("name,exchange", [("heisenberg_chain_12", "replicated"), ("heisenberg_chain_24_symm", "replicated"),
+                                           ("heisenberg_chain_12", "packets")])
+def test_diagonalize_distributed_one_rank(torch, tmp_path, name, exchange):
+    """Diagonalize.main with one process per GPU (diagonalize_distributed) on the one rank this box has: the C host's
+    exchange with a single rank, RCCL reductions, and the block-distributed output file == what the one-process driver
+    writes.  (With more ranks the same code runs under torchrun; the layout conversion and the per-rank hyperslab I/O are
+    covered at world_size 2 and 3 by tests/test_distributed_gloo.py.)"""
+    import os
+
+    import torch.distributed as dist
+
+    from distributed_matvec_amd import hdf5
+    from distributed_matvec_amd.diagonalize import diagonalize, diagonalize_distributed
+
+    try:
+        hdf5.lib()
+    except hdf5.Hdf5Unavailable:
+        pytest.skip("libhdf5 not available")
+    port = 29700 + os.getpid() % 200
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        out = str(tmp_path / "distributed.h5")
+        r = diagonalize_distributed(model_config(name), num_evals=1, eps=1e-10, output=out, exchange=exchange)
+    finally:
+        dist.destroy_process_group()
+    ref_out = str(tmp_path / "one_process.h5")
+    ref = diagonalize(model_config(name), num_evals=1, eps=1e-10, output=ref_out)
+    assert r.converged and abs(r.eigenvalues[0] - ref.eigenvalues[0]) < 1e-9
+    assert np.array_equal(hdf5.read_dataset(out, "/basis/representatives"), hdf5.read_dataset(ref_out, "/basis/representatives"))
+    v, w = hdf5.read_dataset(out, "/hamiltonian/eigenvectors")[0], hdf5.read_dataset(ref_out, "/hamiltonian/eigenvectors")[0]
+    assert v.shape == w.shape and abs(abs(np.dot(v, w)) - 1.0) < 1e-8
+    assert abs(hdf5.read_dataset(out, "/hamiltonian/eigenvalues")[0] - r.eigenvalues[0]) < 1e-12
