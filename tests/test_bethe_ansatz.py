@@ -94,3 +94,12 @@ def test_hash64_01_and_partition_sizes_match_survey_appendix_b():
     states = np.array([0x1, 0x1F, 0x1F0, 0x155, 0xFFFF, 0xFFFF0000FFFF], dtype=np.uint64)
     assert CO.locale_idx_of(states, 8).tolist() == [5, 5, 4, 2, 5, 7]
     assert CO.locale_idx_of(states, 3).tolist() == [1, 0, 2, 2, 2, 1]
+
+
+def test_c_oracle_square_4x4_equals_the_published_energy():
+    """A two-dimensional pin: the 4 x 4 periodic square-lattice Heisenberg antiferromagnet has E0 / N = -0.7017802 J in S.S units
+    (Schulz, Ziman, Poilblanc, PRB 54, 12946 (1996), table of finite-cluster energies; the textbook exact-diagonalisation
+    benchmark), i.e. E0 = -11.228483 J = -44.913933 in the sigma.sigma units of data/heisenberg_square_4x4.yaml.  Lanczos on
+    the C oracle's matvec (vertical and wrap-around bonds: the non-adjacent exchange groups no chain exercises)."""
+    e0 = _oracle_e0("heisenberg_square_4x4")
+    assert abs(e0 / (4 * 16) - (-0.7017802)) < 5e-8, e0

@@ -96,3 +96,13 @@ def test_diagonalize_distributed_one_rank(torch, tmp_path, name, exchange):
     v, w = hdf5.read_dataset(out, "/hamiltonian/eigenvectors")[0], hdf5.read_dataset(ref_out, "/hamiltonian/eigenvectors")[0]
     assert v.shape == w.shape and abs(abs(np.dot(v, w)) - 1.0) < 1e-8
     assert abs(hdf5.read_dataset(out, "/hamiltonian/eigenvalues")[0] - r.eigenvalues[0]) < 1e-12
+
+
+def test_square_4x4_published_energy(torch):
+    """the 4 x 4 periodic square lattice (generic row kernel: vertical and wrap-around bonds) against the published
+    E0 / N = -0.7017802 J (Schulz, Ziman, Poilblanc, PRB 54, 12946 (1996)) -- a two-dimensional third-party pin next to
+    the Bethe-ansatz energies of the rings"""
+    from distributed_matvec_amd.diagonalize import diagonalize
+
+    r = diagonalize(model_config("heisenberg_square_4x4"), num_evals=1, eps=1e-10)
+    assert r.converged and abs(r.eigenvalues[0] / (4 * 16) - (-0.7017802)) < 5e-8, r.eigenvalues
