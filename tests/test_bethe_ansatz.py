@@ -100,6 +100,7 @@ def test_c_oracle_square_4x4_equals_the_published_energy():
     """A two-dimensional pin: the 4 x 4 periodic square-lattice Heisenberg antiferromagnet has E0 / N = -0.7017802 J in S.S units
     (Schulz, Ziman, Poilblanc, PRB 54, 12946 (1996), table of finite-cluster energies; the textbook exact-diagonalisation
     benchmark), i.e. E0 = -11.228483 J = -44.913933 in the sigma.sigma units of data/heisenberg_square_4x4.yaml.  Lanczos on
-    the C oracle's matvec (vertical and wrap-around bonds: the non-adjacent exchange groups no chain exercises)."""
+    the C oracle's matvec in the symmetry-adapted sector the file names (107 representatives of a non-cyclic lattice group;
+    vertical and wrap-around bonds: exchange groups no chain exercises)."""
     e0 = _oracle_e0("heisenberg_square_4x4")
     assert abs(e0 / (4 * 16) - (-0.7017802)) < 5e-8, e0

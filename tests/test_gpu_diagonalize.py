@@ -99,7 +99,8 @@ def test_diagonalize_distributed_one_rank(torch, tmp_path, name, exchange):
 
 
 def test_square_4x4_published_energy(torch):
-    """the 4 x 4 periodic square lattice (generic row kernel: vertical and wrap-around bonds) against the published
+    """the 4 x 4 periodic square lattice (data/heisenberg_square_4x4.yaml: 107 symmetry-adapted states, a non-cyclic lattice
+    group -- the general K4 path -- with vertical and wrap-around bonds) against the published
     E0 / N = -0.7017802 J (Schulz, Ziman, Poilblanc, PRB 54, 12946 (1996)) -- a two-dimensional third-party pin next to
     the Bethe-ansatz energies of the rings"""
     from distributed_matvec_amd.diagonalize import diagonalize
