@@ -107,3 +107,12 @@ def test_square_4x4_published_energy(torch):
 
     r = diagonalize(model_config("heisenberg_square_4x4"), num_evals=1, eps=1e-10)
     assert r.converged and abs(r.eigenvalues[0] / (4 * 16) - (-0.7017802)) < 5e-8, r.eigenvalues
+    # the same lattice without any symmetry: all 12 870 S^z = 0 states through the generic row kernel (k_direct); the global
+    # ground state lives in the symmetric sector, so the energy is the same
+    import copy
+
+    cfg = copy.deepcopy(model_config("heisenberg_square_4x4"))
+    cfg["basis"]["symmetries"] = []
+    cfg["basis"]["spin_inversion"] = None
+    full = diagonalize(cfg, num_evals=1, eps=1e-10)
+    assert full.converged and abs(full.eigenvalues[0] / (4 * 16) - (-0.7017802)) < 5e-8, full.eigenvalues
