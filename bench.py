@@ -125,10 +125,6 @@ def roofline_object(args, kernel_name, kernel_ms, launches_per_step, rows_here, 
                 same_code = same_code or inst == ent["instance_isa_sha"]
                 if inst == ent["instance_isa_sha"]:
                     isa = f"{inst} ({ent['instance']})"
-            # the indexed pull mode has two device kernels behind one plan name: the entry must be of the one that runs
-            if "indexed" in kernel_name and ent.get("device_kernel", "").startswith("k_tile_pull_"):
-                runs_wave = os.environ.get("LS_AMD_PULL_WAVE", "1") != "0"
-                same_code = same_code and (ent["device_kernel"] == ("k_tile_pull_wv" if runs_wave else "k_tile_pull_idx"))
             if same_code:
                 traffic = ent["traffic_bytes"]
                 traffic_note = (f"profiles/pmc_traffic.json ({ent.get('source')}), measured on source_sha "

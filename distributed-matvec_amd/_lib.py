@@ -167,13 +167,11 @@ def load():
         "ls_amd_basis_group_character": (C.c_int, [bp, C.c_int, c_f64p, c_f64p]),
         "ls_amd_test_tilemap": (C.c_int64, [C.c_int64, C.c_int, C.c_int64, C.POINTER(C.POINTER(C.c_uint64))]),
         "ls_amd_test_window_find": (C.c_int, [C.POINTER(C.c_uint64), C.c_int, C.c_uint64]),
+        "ls_amd_test_nw_find": (C.c_int, [C.POINTER(C.c_uint64), C.c_int, C.c_uint64]),
         "ls_amd_test_chain_near_table": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int16)]),
         "ls_amd_test_rep_trivial_dihedral": (C.c_uint64, [C.c_uint64, C.c_int, C.c_int, C.c_int]),
         "ls_amd_bench_k4": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, vp, vp, vp]),
         "ls_amd_test_free": (None, [vp]),
-        "ls_amd_test_sibplan": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp),
-                                           C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.POINTER(C.c_uint16)), C.POINTER(C.POINTER(C.c_uint16))]),
-        "ls_amd_test_sibplan_free": (None, [vp]),
         "ls_amd_test_gtab_bits": (C.c_int, [C.c_int, C.c_int64]),
         "ls_amd_test_gtab_build": (C.c_int, [C.c_int, C.c_int, C.c_int64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.POINTER(C.c_uint64))]),
         "ls_amd_test_gtab_find": (C.c_int64, [C.c_int, C.c_int, C.POINTER(C.c_uint64), C.c_uint64]),

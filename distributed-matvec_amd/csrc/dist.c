@@ -25,6 +25,11 @@ int ls_amd_internal_stage_begin(ls_amd_plan *pl, int stage, void *stream); /* ho
 void ls_amd_internal_stage_end(ls_amd_plan *pl, int slot, void *stream);
 void ls_amd_internal_count_matvec(ls_amd_plan *pl);
 enum { ST_REFRESH = 1, ST_EXCHANGE = 4, ST_RETURN = 6 };
+/* host.c: the indexed replicated-x matvec in two kernels -- BEGIN resolves the packets (needs no x), FINISH gathers */
+int64_t ls_amd_internal_plan_split_enable(ls_amd_plan *pl, int64_t max_bytes);
+int64_t ls_amd_internal_plan_split_rows(ls_amd_plan const *pl);
+int ls_amd_internal_repl_split_begin(ls_amd_plan *pl, void *stream);
+int ls_amd_internal_repl_split_finish(ls_amd_plan *pl, void const *d_x_global, void *d_y_local, void *stream);
 /* host.c: static index tables shared per (global basis, partition layout) and the indexed replicated-x plan */
 typedef struct ls_amd_gtab ls_amd_gtab;
 int ls_amd_internal_gtab_acquire(ls_amd_gtab **out, int L, uint64_t const *d_reps, int64_t n, uint8_t const *d_masks, int P, void *stream);
@@ -478,6 +483,15 @@ int ls_amd_repl_create(ls_amd_repl **out, ls_amd_comm *cm, ls_hs_operator const 
     if (rc == 0 && indexed) {
         rc = ls_amd_internal_plan_create_replicated_indexed(&r->plan, op, dtype, P, me, d_reps_global + r->n0, nb, d_reps_global, count_global, r->gt, stream);
         if (rc == 0 && ls_amd_internal_plan_prescales(r->plan)) rc = ls_amd_internal_owner_norms(op, r->gt, me, &r->d_norms_own, stream);
+        if (rc == 0) {
+            /* Overlap (P > 1): slot resolution -- stage A, K4 and the index-table probes, ~90 % of the row kernel -- needs no x
+             * and runs while the blocks of x are on the wire; it leaves 5 bytes per packet for the gather kernel that runs
+             * when they have arrived.  LS_AMD_PULL_SPLIT = bytes of packet buffer per rank (default 32 GB, i.e. every row of
+             * chain_40_symm at P >= 2; rows that do not fit take the fused kernel after the exchange), 0 = off. */
+            char const *e = getenv("LS_AMD_PULL_SPLIT");
+            int64_t const budget = e ? atoll(e) : (P > 1 ? (int64_t)32 << 30 : 0);
+            if (budget > 0) (void)ls_amd_internal_plan_split_enable(r->plan, budget);
+        }
     } else if (rc == 0)
         rc = ls_amd_plan_create_replicated(&r->plan, op, dtype, P, me, d_reps_global + r->n0, nb, d_reps_global, count_global, stream);
     if (agree(cm, rc, stream) != 0) { ls_amd_repl_destroy(r); return -1; } /* buffers and plan exist on every rank, or the object on none */
@@ -499,9 +513,22 @@ int ls_amd_repl_matvec(ls_amd_repl *r, void const *d_x_local, void *d_y_local, v
         if (r->d_norms_own) DEVC(lsk_scale(r->cplx, r->counts[r->me], d_x_local, r->d_norms_own, mine, stream));
         else DEVC(lsk_d2d_async(mine, d_x_local, (size_t)(r->counts[r->me] * w), stream));
         ls_amd_internal_stage_end(r->plan, st, stream);
-        st = ls_amd_internal_stage_begin(r->plan, ST_EXCHANGE, stream);
-        if (r->P > 1) COMM(lsk_comm_alltoallv_on(r->comm->c, stream, r->d_gathered, r->xs_off, r->xs_bytes, r->d_gathered, r->xr_off, r->xr_bytes));
-        ls_amd_internal_stage_end(r->plan, st, stream);
+        if (r->P > 1 && ls_amd_internal_plan_split_rows(r->plan) > 0) {
+            /* compute stream:  x n(rep) | ready |  RESOLVE (no x) ..................... | wait done | GATHER
+             * exchange stream:          wait ready | grouped send/recv of the blocks | done                  */
+            COMM(lsk_comm_exchange_begin(r->comm->c, 0, stream));
+            TRY(ls_amd_internal_repl_split_begin(r->plan, stream));
+            COMM(lsk_comm_alltoallv(r->comm->c, r->d_gathered, r->xs_off, r->xs_bytes, r->d_gathered, r->xr_off, r->xr_bytes));
+            COMM(lsk_comm_exchange_end(r->comm->c, 0));
+            st = ls_amd_internal_stage_begin(r->plan, ST_EXCHANGE, stream); /* what of the exchange the resolve kernel did not hide */
+            COMM(lsk_comm_exchange_wait(r->comm->c, 0, stream));
+            ls_amd_internal_stage_end(r->plan, st, stream);
+        } else {
+            st = ls_amd_internal_stage_begin(r->plan, ST_EXCHANGE, stream);
+            if (r->P > 1) COMM(lsk_comm_alltoallv_on(r->comm->c, stream, r->d_gathered, r->xs_off, r->xs_bytes, r->d_gathered, r->xr_off, r->xr_bytes));
+            ls_amd_internal_stage_end(r->plan, st, stream);
+            TRY(ls_amd_internal_repl_split_begin(r->plan, stream)); /* (one rank with a forced packet buffer: nothing to hide behind) */
+        }
         x_rows = r->d_gathered;
     } else {
         /* 1. blocks of x: mine by a device copy, the others straight from their owners */
@@ -516,7 +543,7 @@ int ls_amd_repl_matvec(ls_amd_repl *r, void const *d_x_local, void *d_y_local, v
     }
     /* 2. my rows */
     if (r->accumulate) DEVC(lsk_memset_async(r->d_yblock, 0, (size_t)(nb * w), stream));
-    TRY(ls_amd_matvec_replicated(r->plan, x_rows, r->d_yblock, stream));
+    TRY(ls_amd_internal_repl_split_finish(r->plan, x_rows, r->d_yblock, stream)); /* = ls_amd_matvec_replicated when nothing was resolved ahead */
     /* 3. back to the owners: group my rows by owner, keep my own piece, one all-to-all-v for the rest */
     int const st_ret = ls_amd_internal_stage_begin(r->plan, ST_RETURN, stream);
     DEVC(lsk_gather_perm(nb, r->d_yorder, r->yorder64, (int)w, r->d_yblock, r->d_ysend, stream));

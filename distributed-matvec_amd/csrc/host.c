@@ -1054,6 +1054,14 @@ static int operator_device_unlocked(ls_hs_operator const *op, lsk_operator *out)
     out->off = e->d_off;
     out->groups = e->d_groups;
     out->runs = e->runs;
+    /* one real amplitude on every off-diagonal group, all of them exchange pairs: the projected pull kernels then carry no
+     * coefficient per packet */
+    out->uni = e->is_real && e->n_groups > 0;
+    out->uni_v = e->n_groups > 0 ? e->groups[0].v_re : 0.0;
+    for (int g = 0; g < e->n_groups && out->uni; ++g)
+        if (e->groups[g].fast != LSK_GROUP_EXCHANGE || e->groups[g].v_im != 0.0 || e->groups[g].v_re != out->uni_v ||
+            __builtin_popcountll(e->groups[g].x) != 2)
+            out->uni = 0;
     return 0;
 }
 
@@ -1156,11 +1164,6 @@ struct ls_amd_plan {
     /* tile map of the row kernels (lsk_tilemap in lsk.h) */
     lsk_tilemap tilemap;
     void *d_tilemap;
-    int has_sib;   /* block-aligned row kernel with sibling tiles (lsk_chain_sib): the ring / open chain on <= 32 sites, f64 */
-    lsk_sibplan sib;
-    void *d_sib_units, *d_sib_order, *d_sib_unrank, *d_sib_rank, *d_sib_tab;
-    int sib_ring;
-    double sib_cv;
     int has_chain; /* staged row kernel (lsk_chain) */
     int chain_cached;      /* leading non-adjacent exchange groups whose partner ranks are cached */
     void *d_chain_cache;   /* [chain_cached][count] u32, or u64 when chain_wide */
@@ -1178,6 +1181,10 @@ struct ls_amd_plan {
     int idx_mode;
     struct ls_amd_gtab *gtab;
     int64_t row_g0;      /* global index of the first local row (replicated-x plans over a contiguous block) */
+    /* split matvec of the indexed mode (lsk_tile_pull_resolve | lsk_tile_pull_gather): packet streams of the first
+     * split_rows rows (a multiple of 256, or all of them); 0 = the fused kernel only */
+    lsk_pullbuf pbuf;
+    int64_t split_rows;
     /* kernel timing ring */
     int t_capacity, t_count;
     void **t_start, **t_stop;
@@ -1417,6 +1424,58 @@ int ls_amd_fill_random(int64_t n, uint64_t const *d_states, uint64_t seed, ls_am
 static int prescaled_x(ls_amd_plan *pl, int64_t n, uint64_t const *d_reps, void const *d_x, double const *d_norms,
                        void const **out, void *stream);
 
+/* near window of the staged pull kernels: entries either side of a 256-row tile that are resolved in LDS (LS_AMD_PULL_HALO;
+ * 0 = every partner through the table).  The indexed kernels hold the window as a hash set of <= 1024 entries and measure
+ * alike from 64 to 512 (profiles/r3_indexed_ab_*): 256; the value-table kernel keeps its sorted window of +-512. */
+static int pull_halo_setting(int indexed) {
+    int const mx = indexed ? lsk_pull_max_halo() : 512;
+    char const *e = getenv("LS_AMD_PULL_HALO");
+    int h = e ? atoi(e) : (indexed ? 256 : 512);
+    if (h < 0) h = 0;
+    if (h > mx) h = mx;
+    return h;
+}
+
+/* ---- split matvec: packet streams ------------------------------------------------------------------------------------- */
+static void split_free(ls_amd_plan *pl) {
+    if (pl->pbuf.slots) lsk_free(pl->pbuf.slots);
+    if (pl->pbuf.rows) lsk_free(pl->pbuf.rows);
+    if (pl->pbuf.coefs) lsk_free(pl->pbuf.coefs);
+    if (pl->pbuf.counts) lsk_free(pl->pbuf.counts);
+    memset(&pl->pbuf, 0, sizeof(pl->pbuf));
+    pl->split_rows = 0;
+}
+/* room for the packet streams of as many of the plan's rows as `max_bytes` allow (all of them if it can); returns the number
+ * of rows covered (0: none -- the plan keeps the fused kernel) */
+int64_t ls_amd_internal_plan_split_enable(ls_amd_plan *pl, int64_t max_bytes) {
+    split_free(pl);
+    if (!pl->idx_mode || pl->dbs.proj != LSK_PROJ_FULL || pl->parts[0].count <= 0) return 0;
+    int64_t const cap = lsk_pullbuf_cap(pl->dop);
+    int const nc = lsk_pullbuf_coef_doubles(pl->dop, pl->dbs);
+    int64_t const per_stream = cap * (4 + 1 + 8 * nc) + 4; /* 64 rows */
+    int64_t streams = (pl->parts[0].count + 63) / 64;
+    streams = (streams + 3) & ~(int64_t)3; /* whole 256-row tiles */
+    if (max_bytes > 0 && streams * per_stream > max_bytes) streams = (max_bytes / per_stream) & ~(int64_t)3;
+    while (streams >= 4) {
+        void *a = NULL, *b = NULL, *c = NULL, *d = NULL;
+        if (lsk_malloc(&a, (size_t)(streams * cap * 4)) == 0 && lsk_malloc(&b, (size_t)(streams * cap)) == 0 &&
+            (nc == 0 || lsk_malloc(&c, (size_t)(streams * cap * 8 * nc)) == 0) && lsk_malloc(&d, (size_t)(streams * 4)) == 0) {
+            pl->pbuf.slots = (uint32_t *)a; pl->pbuf.rows = (uint8_t *)b; pl->pbuf.coefs = (double *)c; pl->pbuf.counts = (uint32_t *)d;
+            pl->pbuf.cap = cap;
+            pl->pbuf.row0 = 0;
+            pl->split_rows = streams * 64 < pl->parts[0].count ? streams * 64 : pl->parts[0].count;
+            return pl->split_rows;
+        }
+        if (a) lsk_free(a);
+        if (b) lsk_free(b);
+        if (c) lsk_free(c);
+        if (d) lsk_free(d);
+        streams = (streams / 2) & ~(int64_t)3; /* no room: half as many rows */
+    }
+    return 0;
+}
+int64_t ls_amd_internal_plan_split_rows(ls_amd_plan const *pl) { return pl->split_rows; }
+
 static int64_t rows_per_round_default(void) {
     char const *e = getenv("LS_AMD_ROWS_PER_ROUND");
     if (e) { long long v = atoll(e); if (v > 0) return (int64_t)v; }
@@ -1489,9 +1548,70 @@ static int tilemap_host(int64_t n, int TILE, int64_t chunk, uint64_t **out, int6
     *slots_out = slots;
     return 0;
 }
+/* EXPERIMENT (LS_AMD_TILE_SETS = "t[,W]"): sets closed under the exchanges inside the top t site bits.  The states with one
+ * value T of the top t bits are a contiguous segment of C(L - t, hw - popcount(T)) rows; segments of equal popcount are
+ * parallel (an exchange inside T maps row `off` of one onto row `off` of another).  A set = the tiles [off, off + W TILE) of
+ * every segment of one popcount; all its tiles go to ONE XCD, the siblings of one offset back to back. */
+static int tilemap_sets_host(int64_t n, int TILE, int L, int hw, int t, int W, uint64_t **out, int64_t *slots_out) {
+    tile_list lists[8];
+    memset(lists, 0, sizeof(lists));
+    int const Lr = L - t, nT = 1 << t;
+    int64_t *base = (int64_t *)malloc(sizeof(int64_t) * (size_t)(nT + 1)), acc = 0, rows_of[8] = {0};
+    int *segs = (int *)malloc(sizeof(int) * (size_t)nT);
+    for (int T = 0; T < nT; ++T) {
+        base[T] = acc;
+        int const j = __builtin_popcount((unsigned)T);
+        acc += (hw - j >= 0 && hw - j <= Lr) ? (int64_t)binom(Lr, hw - j) : 0;
+    }
+    for (int j = 0; j <= t; ++j) {
+        if (hw - j < 0 || hw - j > Lr) continue;
+        int64_t const len = (int64_t)binom(Lr, hw - j);
+        if (!len) continue;
+        int nseg = 0;
+        for (int T = 0; T < nT; ++T) if (__builtin_popcount((unsigned)T) == j) segs[nseg++] = T;
+        for (int64_t w0 = 0; w0 < len; w0 += (int64_t)W * TILE) {
+            int k = 0;
+            for (int q = 1; q < 8; ++q) if (rows_of[q] < rows_of[k]) k = q;
+            for (int64_t off = w0; off < w0 + (int64_t)W * TILE && off < len; off += TILE)
+                for (int sg = 0; sg < nseg; ++sg) {
+                    int64_t const c = len - off < TILE ? len - off : TILE;
+                    tile_push(&lists[k], base[segs[sg]] + off, c);
+                    rows_of[k] += c;
+                }
+        }
+    }
+    free(base); free(segs);
+    int64_t slots = 0, total = 0;
+    for (int k = 0; k < 8; ++k) if (lists[k].n > slots) slots = lists[k].n;
+    uint64_t *flat = (uint64_t *)calloc((size_t)(8 * slots > 0 ? 8 * slots : 1), sizeof(uint64_t));
+    for (int k = 0; k < 8; ++k) {
+        for (int64_t q = 0; q < lists[k].n; ++q) { flat[k * slots + q] = lists[k].e[q]; total += (int64_t)(lists[k].e[q] >> 48); }
+        free(lists[k].e);
+    }
+    if (total != n) { free(flat); return set_error("internal error: set tile map covers %lld of %lld rows", (long long)total, (long long)n); }
+    *out = flat;
+    *slots_out = slots;
+    return 0;
+}
 static int build_tilemap(ls_amd_plan *pl, int64_t n, int TILE) {
     uint64_t *flat = NULL;
     int64_t slots = 0;
+    {
+        char const *es = getenv("LS_AMD_TILE_SETS");
+        int const L = pl->op->basis->number_sites, hw = BEXT(pl->op->basis)->hamming_weight;
+        if (es && TILE >= 512 && hw >= 0 && L <= 62 && (uint64_t)n == binom(L, hw) && pl->chain_row0 == 0) {
+            int t = 0, W = 1;
+            if (sscanf(es, "%d%*[,:]%d", &t, &W) >= 1 && t >= 1 && t <= 16 && t < L && W >= 1) {
+                if (tilemap_sets_host(n, TILE, L, hw, t, W, &flat, &slots) < 0) return -1;
+                int const up = upload(&pl->d_tilemap, flat, sizeof(uint64_t) * (size_t)(8 * slots > 0 ? 8 * slots : 1));
+                free(flat);
+                if (up) return -1;
+                pl->tilemap.entries = (uint64_t const *)pl->d_tilemap;
+                pl->tilemap.slots_per_xcd = slots;
+                return 0;
+            }
+        }
+    }
     /* Default for the staged kernel: chunks of 256 tiles -- measured on chain_32 with one block per tile
      * (gpurun_out/r2: 9.35 ms contiguous eighths, 8.98 / 8.56 / 8.47 / 8.47 / 8.49 / 8.53 / 8.85 / 9.83 ms at
      * 4 / 32 / 128 / 256 / 512 / 1024 / 4096 / 16384) */
@@ -1508,6 +1628,7 @@ static int build_tilemap(ls_amd_plan *pl, int64_t n, int TILE) {
 /* test hook (host only): the tile map of n rows.  Returns slots per XCD (< 0 on error); *entries is malloc'ed, free
  * with ls_amd_test_free. */
 int ls_amd_test_window_find(uint64_t const *reps, int n, uint64_t key) { return lsk_test_window_find(reps, n, key); }
+int ls_amd_test_nw_find(uint64_t const *reps, int n, uint64_t key) { return lsk_test_nw_find(reps, n, key); }
 int ls_amd_test_chain_near_table(int elem, int ldsp, int16_t *out) { return lsk_test_chain_near_table(elem, ldsp, out); }
 uint64_t ls_amd_test_rep_trivial_dihedral(uint64_t a, int L, int inv, int reflect) { return lsk_test_rep_trivial_dihedral(a, L, inv, reflect); }
 int ls_amd_bench_k4(int L, int inv, int reflect, int variant, int64_t n, uint64_t const *d_reps, uint64_t *d_out, void *stream) {
@@ -1535,212 +1656,6 @@ int64_t ls_amd_test_gtab_find(int L, int bbits, uint64_t const *entries, uint64_
     lsk_gtab t;
     t.entries = NULL; t.L = L; t.bbits = bbits; t.tbits = L - bbits;
     return lsk_test_gtab_find(t, entries, key);
-}
-
-/* ---- sibling-tile plan (lsk_sibplan, lsk.h): host-side tables ------------------------------------------------------------- */
-int lsk_sibplan_host(lsk_sibplan *sp, lsk_sibtab *tb, int L, int hw, int nl, int t, int64_t chunk, lsk_sib_unit **units_out,
-                     uint32_t **order_out, uint16_t **unrank_out, uint16_t **rank_out) {
-    memset(sp, 0, sizeof(*sp));
-    memset(tb, 0, sizeof(*tb));
-    *units_out = NULL; *order_out = NULL; *unrank_out = NULL; *rank_out = NULL;
-    if (L < 4 || L > 32 || hw < 1 || hw >= L || nl < 2 || nl > 16 || t < 1 || t > LSK_SIB_MAX_T || nl + t > L) return -1;
-    if (binom(L, hw) >= 0xffffffffULL) return -1;
-    int const nm = L - t - nl;
-    sp->L = L; sp->hw = hw; sp->nl = nl; sp->t = t;
-    /* nl-bit words grouped by weight */
-    uint16_t *unrank = (uint16_t *)malloc(sizeof(uint16_t) << nl), *rank = (uint16_t *)malloc(sizeof(uint16_t) << nl);
-    uint32_t off = 0;
-    for (int k = 0; k <= nl; ++k) {
-        tb->uoff[k] = off;
-        for (uint32_t w = 0; w < (1u << nl); ++w)
-            if (__builtin_popcount(w) == k) { rank[w] = (uint16_t)(off - tb->uoff[k]); unrank[off++] = (uint16_t)w; }
-    }
-    for (int k = nl + 1; k < 34; ++k) tb->uoff[k] = off;
-    /* t-bit words grouped by weight; rank contribution of their bits */
-    int cnt[LSK_SIB_MAX_T + 1];
-    memset(cnt, 0, sizeof(cnt));
-    for (uint32_t T = 0; T < (1u << t); ++T) {
-        int const j = __builtin_popcount(T);
-        int const s_ = cnt[j]++;
-        tb->sidx[T] = (uint8_t)s_;
-        tb->tlist[j][s_] = (uint8_t)T;
-        tb->nsib[j] = (uint32_t)(s_ + 1);
-        uint64_t r = 0;
-        int i = 0;
-        for (int q = 0; q < t; ++q)
-            if ((T >> q) & 1) { r += binom(L - t + q, (hw - j) + i + 1); ++i; }
-        tb->rtr[j][s_] = (uint32_t)r;
-    }
-    /* units (mid, jT) */
-    int64_t cap = (int64_t)(t + 1) << nm, n = 0;
-    lsk_sib_unit *units = (lsk_sib_unit *)malloc(sizeof(lsk_sib_unit) * (size_t)cap);
-    for (int jT = 0; jT <= t; ++jT)
-        for (uint32_t mid = 0; mid < (1u << nm); ++mid) {
-            int const kL = hw - jT - __builtin_popcount(mid);
-            if (kL < 0 || kL > nl) continue;
-            uint64_t rest[3] = {0, 0, 0}; /* kL, kL + 1, kL - 1 bits below */
-            int i = 0;
-            for (int q = 0; q < nm; ++q)
-                if ((mid >> q) & 1) {
-                    rest[0] += binom(nl + q, kL + i + 1);
-                    rest[1] += binom(nl + q, kL + 1 + i + 1);
-                    rest[2] += kL >= 1 ? binom(nl + q, kL - 1 + i + 1) : 0;
-                    ++i;
-                }
-            lsk_sib_unit *u = &units[n++];
-            u->base_rest = (uint32_t)rest[0]; u->ring_up = (uint32_t)rest[1]; u->ring_dn = (uint32_t)rest[2];
-            u->mid = mid << nl;
-            u->kL_jT = (uint32_t)kL | ((uint32_t)jT << 8);
-            int const rows = (int)(binom(nl, kL) * binom(t, jT));
-            if (rows > sp->max_rows) sp->max_rows = rows;
-            if ((int)binom(nl, kL) > sp->max_block) sp->max_block = (int)binom(nl, kL);
-        }
-    sp->n_units = n;
-    {
-        /* LS_AMD_SIB_L2SETS=v (experiment): order the units so that those which differ only inside the top v bits of `mid`
-         * (same weight there) are consecutive -- dispatched back to back onto one XCD, their far-pair gathers can meet each
-         * other's window loads in that XCD's L2 instead of sharing an LDS window */
-        char const *e = getenv("LS_AMD_SIB_L2SETS");
-        int const vs = e ? atoi(e) : 0;
-        if (vs > 0 && vs <= nm && n > 1) {
-            uint64_t *keys = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)n);
-            for (int64_t i = 0; i < n; ++i) {
-                uint32_t const mid = units[i].mid >> nl, top = mid >> (nm - vs), low = mid & ((1u << (nm - vs)) - 1u);
-                uint64_t const jT = units[i].kL_jT >> 8;
-                keys[i] = (jT << 56) | ((uint64_t)__builtin_popcount(top) << 48) | ((uint64_t)low << 16) | ((uint64_t)top << 8);
-            }
-            /* insertion of the key into the unit for qsort: sort an index array */
-            int64_t *idx = (int64_t *)malloc(sizeof(int64_t) * (size_t)n);
-            for (int64_t i = 0; i < n; ++i) idx[i] = i;
-            /* simple LSD radix on 64-bit keys (n up to a few 10^5) */
-            int64_t *tmp = (int64_t *)malloc(sizeof(int64_t) * (size_t)n);
-            for (int pass = 0; pass < 8; ++pass) {
-                size_t cnt256[257];
-                memset(cnt256, 0, sizeof(cnt256));
-                for (int64_t i = 0; i < n; ++i) ++cnt256[((keys[idx[i]] >> (8 * pass)) & 0xff) + 1];
-                for (int b = 0; b < 256; ++b) cnt256[b + 1] += cnt256[b];
-                for (int64_t i = 0; i < n; ++i) tmp[cnt256[(keys[idx[i]] >> (8 * pass)) & 0xff]++] = idx[i];
-                int64_t *sw = idx; idx = tmp; tmp = sw;
-            }
-            lsk_sib_unit *sorted = (lsk_sib_unit *)malloc(sizeof(lsk_sib_unit) * (size_t)cap);
-            for (int64_t i = 0; i < n; ++i) sorted[i] = units[idx[i]];
-            free(units); free(keys); free(idx); free(tmp);
-            units = sorted;
-        }
-    }
-    /* XCD lists: chunks of consecutive units dealt round-robin (consecutive units = neighbouring blocks of every sibling) */
-    if (chunk < 1) chunk = 1;
-    int64_t per[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int64_t u = 0; u < n; ++u) ++per[(u / chunk) % 8];
-    int64_t slots = 0;
-    for (int k = 0; k < 8; ++k) if (per[k] > slots) slots = per[k];
-    uint32_t *order = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(8 * slots > 0 ? 8 * slots : 1));
-    for (int64_t i = 0; i < 8 * slots; ++i) order[i] = 0xffffffffu;
-    memset(per, 0, sizeof(per));
-    for (int64_t u = 0; u < n; ++u) { int const k = (int)((u / chunk) % 8); order[k * slots + per[k]++] = (uint32_t)u; }
-    sp->slots_per_xcd = slots;
-    *units_out = units; *order_out = order; *unrank_out = unrank; *rank_out = rank;
-    return 0;
-}
-lsk_sib_rec *lsk_sibrecs_host(lsk_sibplan *sp, lsk_sibtab const *tb, lsk_sib_unit const *units, uint32_t const *order) {
-    int64_t const slots = sp->slots_per_xcd, n = 8 * slots;
-    sp->n_recs = n;
-    lsk_sib_rec *recs = (lsk_sib_rec *)calloc((size_t)(n > 0 ? n : 1), sizeof(lsk_sib_rec));
-    for (int64_t sl = 0; sl < slots; ++sl)
-        for (int k = 0; k < 8; ++k) {
-            uint32_t const un = order[k * slots + sl];
-            if (un == 0xffffffffu) continue; /* nS stays 0: empty slot */
-            lsk_sib_unit const *u = &units[un];
-            lsk_sib_rec *r = &recs[sl * 8 + k]; /* block b runs on XCD b % 8 */
-            int const kL = (int)(u->kL_jT & 0xff), jT = (int)(u->kL_jT >> 8), t = sp->t;
-            r->mid = u->mid; r->uoff = tb->uoff[kL];
-            r->nL = (uint16_t)(tb->uoff[kL + 1] - tb->uoff[kL]); r->nS = (uint16_t)tb->nsib[jT];
-            r->kL = (uint8_t)kL; r->jT = (uint8_t)jT;
-            for (int s_ = 0; s_ < (int)tb->nsib[jT]; ++s_) {
-                uint32_t const T = tb->tlist[jT][s_];
-                r->T[s_] = (uint8_t)T;
-                r->base[s_] = tb->rtr[jT][s_] + u->base_rest;
-                /* ring-closing pair (0, L - 1): the partner has T' = T ^ top bit (one sibling class up or down), the same mid bits
-                 * and Lw ^ 1; its block starts at rtr[jT'][T'] + the mid bits' contribution with one more / fewer bit below */
-                uint32_t const top = (T >> (t - 1)) & 1u, T2 = T ^ (1u << (t - 1));
-                int const j2 = top ? jT - 1 : jT + 1;
-                r->ring[s_] = tb->rtr[j2][tb->sidx[T2]] + (top ? u->ring_up : u->ring_dn);
-            }
-        }
-    return recs;
-}
-/* host-only test hook: the tables as plain arrays (release each with ls_amd_test_free); returns the number of units */
-int64_t ls_amd_test_sibplan(int L, int hw, int nl, int t, int64_t chunk, void **plan_struct, void **tables, void **units,
-                            uint32_t **order, uint16_t **unrank, uint16_t **rank) {
-    lsk_sibplan *sp = (lsk_sibplan *)malloc(sizeof(lsk_sibplan));
-    lsk_sibtab *tb = (lsk_sibtab *)malloc(sizeof(lsk_sibtab));
-    if (lsk_sibplan_host(sp, tb, L, hw, nl, t, chunk, (lsk_sib_unit **)units, order, unrank, rank) != 0) { free(sp); free(tb); return -1; }
-    sp->recs = lsk_sibrecs_host(sp, tb, (lsk_sib_unit const *)*units, *order); /* released with the struct: ls_amd_test_sibplan_free */
-    *plan_struct = sp;
-    *tables = tb;
-    return sp->n_units;
-}
-
-/* Block-aligned row kernel with sibling tiles (k_chain_sib, lsk.h): f64 vectors, <= 32 sites, the full fixed-weight basis on
- * one device, and the operator of the ring / open chain: ONE exchange run over all adjacent pairs plus, at most, the
- * ring-closing pair (0, L - 1).  LS_AMD_SIB=1 selects it (default: the staged kernel); LS_AMD_SIB_NL / LS_AMD_SIB_T / LS_AMD_SIB_CHUNK set the
- * split (low bits, sibling bits) and the XCD dealing.  Returns 0 with pl->has_sib == 0 when the plan is not of that shape. */
-static int setup_sib(ls_amd_plan *pl, int64_t n) {
-    ls_hs_operator const *op = pl->op;
-    struct ls_amd_operator_ext const *ext = OEXT(op);
-    int const L = op->basis->number_sites, hw = BEXT(op->basis)->hamming_weight;
-    /* Opt-in (LS_AMD_SIB=1).  Measured r3 on chain_32 (profiles/r3_sib_*): fabric traffic 53.5 -> 44.7 GB (t = 5) with the same
-     * instruction counts as the staged kernel (3.34e9 VALU, 1.33e8 vector-memory wave instructions), but 9.4 - 9.9 ms against
-     * 8.3 ms: the LDS window of the siblings caps the kernel at 24 waves per CU behind one block-wide barrier per unit, and
-     * it runs at 4.5 - 4.8 TB/s instead of the 6.5 TB/s the staged kernel sustains.  Kept selectable, not default. */
-    char const *e = getenv("LS_AMD_SIB");
-    if (!e || atoi(e) == 0) return 0;
-    if (pl->cplx || L > 32 || L < 8 || hw < 1 || hw >= L || (uint64_t)n != binom(L, hw)) return 0;
-    if (ext->runs.n_runs != 1 || ext->runs.lo0[0] != 0 || ext->runs.cnt[0] != L - 1 || ext->runs.v_im[0] != 0.0) return 0;
-    int const extra = ext->n_groups - ext->runs.n_run_groups;
-    if (extra > 1) return 0;
-    if (extra == 1 && ext->groups[ext->runs.n_run_groups].x != (1ULL | (1ULL << (L - 1)))) return 0;
-    /* default split: 12 low bits (blocks of <= 924 rows), 5 sibling bits (<= 10 blocks = 74 KB of LDS: two blocks per CU);
-     * small bases (tests) shrink both */
-    int nl = 12, t = 5;
-    if (L < 24) { t = L >= 16 ? 4 : 3; nl = (L - t) < 8 ? (L - t) : 8; }
-    if ((e = getenv("LS_AMD_SIB_NL"))) nl = atoi(e);
-    if ((e = getenv("LS_AMD_SIB_T"))) t = atoi(e);
-    int64_t chunk = 32;
-    if ((e = getenv("LS_AMD_SIB_CHUNK"))) chunk = atoll(e);
-    lsk_sibtab tab;
-    lsk_sib_unit *units = NULL;
-    uint32_t *order = NULL;
-    uint16_t *unrank = NULL, *rank = NULL;
-    if (lsk_sibplan_host(&pl->sib, &tab, L, hw, nl, t, chunk, &units, &order, &unrank, &rank) != 0) return 0;
-    int rc = 0;
-    if (lsk_chain_sib_lds_bytes(pl->sib.max_rows, pl->sib.max_block) > 160 * 1024) rc = 1; /* not an error: the staged kernel takes it */
-    lsk_sib_rec *recs = rc == 0 ? lsk_sibrecs_host(&pl->sib, &tab, units, order) : NULL;
-    if (rc == 0 && (upload(&pl->d_sib_units, recs, sizeof(lsk_sib_rec) * (size_t)pl->sib.n_recs) != 0 ||
-                    upload(&pl->d_sib_unrank, unrank, sizeof(uint16_t) << nl) != 0 || upload(&pl->d_sib_rank, rank, sizeof(uint16_t) << nl) != 0 ||
-                    upload(&pl->d_sib_tab, &tab, sizeof(tab)) != 0))
-        rc = -1;
-    free(units); free(order); free(unrank); free(rank); free(recs);
-    if (rc != 0) {
-        void **bufs[] = {&pl->d_sib_units, &pl->d_sib_order, &pl->d_sib_unrank, &pl->d_sib_rank, &pl->d_sib_tab};
-        for (size_t i = 0; i < sizeof(bufs) / sizeof(bufs[0]); ++i) if (*bufs[i]) { lsk_free(*bufs[i]); *bufs[i] = NULL; }
-        return rc < 0 ? -1 : 0;
-    }
-    pl->sib.units = NULL;
-    pl->sib.order = NULL;
-    pl->sib.recs = (lsk_sib_rec const *)pl->d_sib_units;
-    pl->sib.unrankL = (uint16_t const *)pl->d_sib_unrank;
-    pl->sib.rankL = (uint16_t const *)pl->d_sib_rank;
-    pl->sib.tab = (lsk_sibtab const *)pl->d_sib_tab;
-    pl->sib_ring = extra == 1;
-    pl->sib_cv = extra == 1 ? ext->groups[ext->runs.n_run_groups].v_re : 0.0;
-    pl->has_sib = 1;
-    return 0;
-}
-
-void ls_amd_test_sibplan_free(void *plan_struct) {
-    lsk_sibplan *sp = (lsk_sibplan *)plan_struct;
-    if (sp) { free((void *)sp->recs); free(sp); }
 }
 
 /* Staged row kernel (k_chain_t, lsk.h): pull, f64 or c128 vectors, <= 64 sites, the full fixed-weight basis without
@@ -1991,14 +1906,31 @@ int ls_amd_plan_create(ls_amd_plan **out, ls_hs_operator const *op, ls_amd_dtype
     if (pl->family == FAMILY_DIRECT_PULL || pl->family == FAMILY_DIRECT_PUSH) {
         int const combinadic = pl->parts[0].index.kind == LSK_INDEX_COMBINADIC;
         part_state *ps0 = &pl->parts[0];
-        if (pl->family == FAMILY_DIRECT_PULL && combinadic && chain_eligible(pl) && OEXT(op)->n_diag > 0 &&
-            setup_sib(pl, ps0->count) != 0) { ls_amd_plan_destroy(pl); return -1; }
-        if (!pl->has_sib && pl->family == FAMILY_DIRECT_PULL && combinadic && chain_eligible(pl) &&
+        if (pl->family == FAMILY_DIRECT_PULL && combinadic && chain_eligible(pl) &&
             setup_chain(pl, ps0->index, ps0->count, ps0->d_reps, stream) != 0) { ls_amd_plan_destroy(pl); return -1; }
-        if (!pl->has_chain && !pl->has_sib && build_tilemap(pl, ps0->count, 256) != 0) { ls_amd_plan_destroy(pl); return -1; }
+        if (!pl->has_chain && build_tilemap(pl, ps0->count, 256) != 0) { ls_amd_plan_destroy(pl); return -1; }
     }
     if (pl->family == FAMILY_TILE && my_partition < 0 && pl->send_capacity > 0) {
         if (lsk_malloc(&pl->d_send, (size_t)pl->send_capacity) != 0) { ls_amd_plan_destroy(pl); return dev_error(); }
+    }
+    if (pl->family == FAMILY_TILE_PULL && pl->idx_mode) {
+        /* static index table + room for x * norm(rep), acquired here: a table that cannot be built (no memory, a key that
+         * finds no place within 255 buckets) puts the plan on the value-table path instead of failing the first matvec */
+        part_state *ps = &pl->parts[0];
+        int ok = ls_amd_internal_gtab_acquire(&pl->gtab, op->basis->number_sites, ps->d_reps, ps->count, NULL, 1, stream) == 0;
+        if (ok && pl->dbs.k4_mode != 0 &&
+            lsk_malloc(&pl->d_xs, (size_t)(pl->cplx ? 16 : 8) * (size_t)(ps->count > 0 ? ps->count : 1)) != 0) {
+            ls_amd_internal_gtab_release(pl->gtab);
+            pl->gtab = NULL;
+            pl->d_xs = NULL;
+            ok = 0;
+        }
+        if (!ok) pl->idx_mode = 0;
+        else {
+            pl->pull_halo = pull_halo_setting(1);
+            char const *e = getenv("LS_AMD_PULL_SPLIT"); /* bytes of packet buffer; measurement of the two-kernel form */
+            if (e && atoll(e) > 0) ls_amd_internal_plan_split_enable(pl, atoll(e));
+        }
     }
     if (lsk_sync(stream) != 0) { ls_amd_plan_destroy(pl); return dev_error(); }
     *out = pl;
@@ -2021,17 +1953,13 @@ void ls_amd_plan_destroy(ls_amd_plan *pl) {
     if (pl->d_row_gidx) lsk_free(pl->d_row_gidx);
     if (pl->d_norms_global) lsk_free(pl->d_norms_global);
     if (pl->d_tilemap) lsk_free(pl->d_tilemap);
-    if (pl->d_sib_units) lsk_free(pl->d_sib_units);
-    if (pl->d_sib_order) lsk_free(pl->d_sib_order);
-    if (pl->d_sib_unrank) lsk_free(pl->d_sib_unrank);
-    if (pl->d_sib_rank) lsk_free(pl->d_sib_rank);
-    if (pl->d_sib_tab) lsk_free(pl->d_sib_tab);
     if (pl->d_chain_cache) lsk_free(pl->d_chain_cache);
     if (pl->d_chain_rec) lsk_free(pl->d_chain_rec);
     if (pl->d_htab) lsk_free(pl->d_htab);
     if (pl->d_slot_of) lsk_free(pl->d_slot_of);
     if (pl->d_xs) lsk_free(pl->d_xs);
     if (pl->gtab) ls_amd_internal_gtab_release(pl->gtab);
+    split_free(pl);
     if (pl->d_send) lsk_free(pl->d_send);
     if (pl->d_cursors) lsk_free(pl->d_cursors);
     if (pl->d_counts) lsk_free(pl->d_counts);
@@ -2114,10 +2042,7 @@ static int plan_create_replicated_impl(ls_amd_plan **out, ls_hs_operator const *
         pl->gindex.kind = LSK_INDEX_SEARCH;
         pl->gindex.count = count_global;
         pl->gindex.reps = d_reps_global;
-        char const *e = getenv("LS_AMD_PULL_HALO");
-        pl->pull_halo = e ? atoi(e) : 512;
-        if (pl->pull_halo < 0) pl->pull_halo = 0;
-        if (pl->pull_halo > 512) pl->pull_halo = 512;
+        pl->pull_halo = pull_halo_setting(1);
         if (lsk_malloc(&p, 8 * (size_t)(count_local > 0 ? count_local : 1)) != 0) { ls_amd_plan_destroy(pl); return dev_error(); }
         ps->d_norms = (double *)p;
         if (lsk_norms(pl->dbs, count_local, d_reps_local, ps->d_norms, stream) != 0 || lsk_sync(stream) != 0) { ls_amd_plan_destroy(pl); return dev_error(); }
@@ -2239,11 +2164,46 @@ int ls_amd_matvec_replicated(ls_amd_plan *pl, void const *d_x_global, void *d_y_
     }
     return set_error("ls_amd_matvec_replicated: not a replicated-x plan");
 }
+/* The indexed replicated-x matvec in two steps (dist.c): BEGIN resolves the packets of the first split_rows rows -- stage A,
+ * K4 and every slot look-up, nothing of x -- and is enqueued while the blocks of x travel; FINISH gathers them from the
+ * received x and runs the fused kernel on whatever rows the packet buffer did not cover. */
+int ls_amd_internal_repl_split_begin(ls_amd_plan *pl, void *stream) {
+    if (pl->family != FAMILY_REPL_TILE || !pl->idx_mode || pl->split_rows <= 0) return 0;
+    part_state *ps = &pl->parts[0];
+    lsk_pullidx ix;
+    ix.tab = pl->gtab->tab;
+    ix.perm = pl->gtab->d_perm;
+    ix.row_g0 = pl->row_g0;
+    int const st = stage_begin(pl, ST_GENERATE, stream);
+    int const slot = timing_begin(pl, stream);
+    DEV(lsk_tile_pull_resolve(pl->dop, pl->dbs, 0, pl->split_rows, ps->d_reps, ps->d_norms, ix, pl->gindex.reps, pl->gindex.count,
+                              pl->pull_halo, pl->pbuf, pl->d_err, stream));
+    timing_end(pl, slot, stream);
+    stage_end(pl, st, stream);
+    return 0;
+}
+int ls_amd_internal_repl_split_finish(ls_amd_plan *pl, void const *d_x_global, void *d_y_local, void *stream) {
+    if (pl->family != FAMILY_REPL_TILE || !pl->idx_mode || pl->split_rows <= 0) return ls_amd_matvec_replicated(pl, d_x_global, d_y_local, stream);
+    part_state *ps = &pl->parts[0];
+    ls_amd_internal_count_matvec(pl);
+    lsk_pullidx ix;
+    ix.tab = pl->gtab->tab;
+    ix.perm = pl->gtab->d_perm;
+    ix.row_g0 = pl->row_g0;
+    int const st = stage_begin(pl, ST_ROWS, stream);
+    DEV(lsk_tile_pull_gather(pl->dop, pl->dbs, pl->cplx, 0, pl->split_rows, ps->d_reps, ps->d_norms, ix, d_x_global, pl->pbuf, d_y_local,
+                             stream));
+    if (pl->split_rows < ps->count)
+        DEV(lsk_tile_pull_idx(pl->dop, pl->dbs, pl->cplx, pl->split_rows, ps->count, ps->d_reps, ps->d_norms, ix, pl->gindex.reps,
+                              pl->gindex.count, d_x_global, pl->pull_halo, d_y_local, pl->d_err, stream));
+    stage_end(pl, st, stream);
+    return 0;
+}
 char const *ls_amd_plan_kernel_name(ls_amd_plan const *pl) {
     switch (pl->family) {
     case FAMILY_DIRECT_PUSH: return "direct-push";
     case FAMILY_DIRECT_PULL:
-        return pl->has_sib ? "direct-pull+sibling" : pl->has_chain ? "direct-pull+staged" : "direct-pull";
+        return pl->has_chain ? "direct-pull+staged" : "direct-pull";
     case FAMILY_TILE_PULL: return pl->idx_mode ? "tile-pull+indexed" : "tile-pull";
     case FAMILY_REPL_DIRECT:
         return pl->has_chain ? "replicated-direct-pull+staged" : "replicated-direct-pull";
@@ -2257,7 +2217,6 @@ int ls_amd_plan_packet_bytes(ls_amd_plan const *pl) { return pl->cplx ? 24 : 16;
  * plus one cached partner rank per cached pair; the generic row kernels read the 8-byte state; the projected pull kernel
  * the state and norm(alpha) */
 int ls_amd_plan_row_bytes(ls_amd_plan const *pl) {
-    if (pl->has_sib) return 0; /* state and partner ranks are computed, not read */
     if (pl->has_chain) {
         if (pl->d_chain_rec) return 8;
         int const narrow = pl->op->basis->number_sites <= 32 && !pl->chain_wide;
@@ -2289,10 +2248,7 @@ static int prescaled_x(ls_amd_plan *pl, int64_t n, uint64_t const *d_reps, void 
         pl->d_slot_of = (uint32_t *)p;
         DEV(lsk_hash_build(pl->cplx, n, d_reps, bits, pl->d_htab, pl->d_slot_of, stream));
         /* near window (LS_AMD_PULL_HALO entries either side of a tile, default 512, 0 = every partner through the table) */
-        char const *e = getenv("LS_AMD_PULL_HALO");
-        pl->pull_halo = e ? atoi(e) : 512;
-        if (pl->pull_halo < 0) pl->pull_halo = 0;
-        if (pl->pull_halo > 512) pl->pull_halo = 512;
+        pl->pull_halo = pull_halo_setting(0);
         if (pl->pull_halo > 0 && pl->dbs.k4_mode != 0) DEV(lsk_malloc(&pl->d_xs, (size_t)(pl->cplx ? 16 : 8) * (size_t)(n > 0 ? n : 1)));
     }
     int const st = stage_begin(pl, ST_REFRESH, stream);
@@ -2349,14 +2305,6 @@ int ls_amd_matvec(ls_amd_plan *pl, void const *const *d_x, void *const *d_y, voi
         /* indexed mode on one device: slot = index; the only per-matvec preparation is x * norm(rep), a streaming pass
          * (the value table of the other mode costs N random 16-byte writes) */
         part_state *ps = &pl->parts[0];
-        if (!pl->gtab) {
-            if (ls_amd_internal_gtab_acquire(&pl->gtab, pl->op->basis->number_sites, ps->d_reps, ps->count, NULL, 1, stream) != 0) return -1;
-            char const *e = getenv("LS_AMD_PULL_HALO");
-            pl->pull_halo = e ? atoi(e) : 512;
-            if (pl->pull_halo < 0) pl->pull_halo = 0;
-            if (pl->pull_halo > 512) pl->pull_halo = 512;
-            if (pl->dbs.k4_mode != 0) DEV(lsk_malloc(&pl->d_xs, (size_t)(pl->cplx ? 16 : 8) * (size_t)(ps->count > 0 ? ps->count : 1)));
-        }
         void const *xs = d_x[0];
         if (pl->dbs.k4_mode != 0) {
             int const sr = stage_begin(pl, ST_REFRESH, stream);
@@ -2368,6 +2316,25 @@ int ls_amd_matvec(ls_amd_plan *pl, void const *const *d_x, void *const *d_y, voi
         ix.tab = pl->gtab->tab;
         ix.perm = NULL;
         ix.row_g0 = 0;
+        if (pl->split_rows > 0) {
+            /* the split form on one device (LS_AMD_PULL_SPLIT: measurement of what the replicated-x exchange runs, dist.c):
+             * rounds of resolve | gather over the rows the packet buffer holds */
+            for (int64_t r0 = 0; r0 < ps->count; r0 += pl->split_rows) {
+                int64_t const r1 = r0 + pl->split_rows < ps->count ? r0 + pl->split_rows : ps->count;
+                lsk_pullbuf pb = pl->pbuf;
+                pb.row0 = r0;
+                int st = stage_begin(pl, ST_GENERATE, stream);
+                int slot = timing_begin(pl, stream);
+                DEV(lsk_tile_pull_resolve(pl->dop, pl->dbs, r0, r1, ps->d_reps, ps->d_norms, ix, ps->d_reps, ps->count, pl->pull_halo, pb,
+                                          pl->d_err, stream));
+                timing_end(pl, slot, stream);
+                stage_end(pl, st, stream);
+                st = stage_begin(pl, ST_ROWS, stream);
+                DEV(lsk_tile_pull_gather(pl->dop, pl->dbs, pl->cplx, r0, r1, ps->d_reps, ps->d_norms, ix, xs, pb, d_y[0], stream));
+                stage_end(pl, st, stream);
+            }
+            return 0;
+        }
         int const st = stage_begin(pl, ST_ROWS, stream);
         int slot = timing_begin(pl, stream);
         DEV(lsk_tile_pull_idx(pl->dop, pl->dbs, pl->cplx, 0, ps->count, ps->d_reps, ps->d_norms, ix, ps->d_reps, ps->count, xs,
@@ -2401,9 +2368,7 @@ int ls_amd_matvec(ls_amd_plan *pl, void const *const *d_x, void *const *d_y, voi
         part_state *ps = &pl->parts[0];
         int const st = stage_begin(pl, ST_ROWS, stream);
         int slot = timing_begin(pl, stream);
-        if (pl->has_sib)
-            DEV(lsk_chain_sib(pl->dop, pl->sib, ps->index.binom, pl->sib_ring, pl->sib_cv, d_x[0], d_y[0], stream));
-        else if (pl->has_chain)
+        if (pl->has_chain)
             DEV(lsk_chain(pl->dop, pl->dbs, ps->index, pl->cplx, pl->chain_wide, pl->d_chain_rec != NULL, pl->tilemap, ps->count,
                           pl->d_chain_rec ? pl->d_chain_rec : ps->d_reps, 0, ps->count, d_x[0], d_y[0], pl->chain_cached,
                           pl->d_chain_cache, pl->chain_v[0], pl->chain_v[1], stream));

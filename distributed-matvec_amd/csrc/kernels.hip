@@ -1074,6 +1074,9 @@ __device__ __forceinline__ void cx_store_nt(double2 *p, double2 v) {
 }
 
 constexpr int kChainFarC = 6; // complex: 6 x 16 bytes in flight per lane
+// gather with a wave-uniform choice of cache policy: nt = the line is not worth keeping in the L2 (experiment, LS_AMD_CHAIN_NT)
+__device__ __forceinline__ double cx_load(double const *p, bool nt) { return nt ? __builtin_nontemporal_load(p) : *p; }
+__device__ __forceinline__ double2 cx_load(double2 const *p, bool) { return *p; }
 
 // launch bounds, second argument = waves per SIMD the register allocation must allow.  256-thread blocks are admitted per CU
 // up to floor(800 / (ceil(sgpr / 16) * 16 + 16)): at 98 SGPRs the 7th block does not fit while the occupancy API still
@@ -1087,7 +1090,7 @@ __global__ __launch_bounds__(kBlock, (CPLX ? 5 : 7)) void k_chain_t(lsk_runs run
                                                     uint64_t const *__restrict__ reps, void const *__restrict__ x_v,
                                                     void *__restrict__ y_v, int hb, int n_cached,
                                                     R const *__restrict__ cache, double cv0, double cv1, int64_t row0,
-                                                    int64_t n_x) {
+                                                    int64_t n_x, int nt_below) {
     typedef typename ChainX<CPLX>::type X;
     typedef WordTraits<W> WT;
     constexpr int NB = ChainTraits<W, R>::NB;
@@ -1182,8 +1185,8 @@ __global__ __launch_bounds__(kBlock, (CPLX ? 5 : 7)) void k_chain_t(lsk_runs run
             const int64_t i = i0 + (ghost ? cnt - 1 : r);
             const R ig = (R)(row0 + i);
             X g0 = cx_zero<X>(), g1 = cx_zero<X>();
-            if (n_cached > 0) g0 = x[t0 != kNone ? t0 : ig];
-            if (n_cached > 1) g1 = x[t1 != kNone ? t1 : ig];
+            if (n_cached > 0) g0 = cx_load(x + (t0 != kNone ? t0 : ig), nt_below > 0);
+            if (n_cached > 1) g1 = cx_load(x + (t1 != kNone ? t1 : ig), nt_below > 0);
             const int jr = own0 + (int)(i - i0);
             const X xr = s_x[jr];
             double dr, di;
@@ -1233,7 +1236,7 @@ __global__ __launch_bounds__(kBlock, (CPLX ? 5 : 7)) void k_chain_t(lsk_runs run
                         if (m) {
                             const int l = __builtin_ctzll(m);
                             m &= m - 1;
-                            xv[u] = (x + (size_t)(R)(ig0 + readlane_t<R>(off, l)))[dl];
+                            xv[u] = cx_load((x + (size_t)(R)(ig0 + readlane_t<R>(off, l))) + dl, (unsigned)(split + l - (nt_below & 255)) < (unsigned)(nt_below >> 8));
                         }
                     }
                     lo_end = split;
@@ -1457,6 +1460,14 @@ static int chain_lds_image(int rsize, int rows, int weight, int elem, int ldsp, 
     return 0;
 }
 
+// EXPERIMENT LS_AMD_CHAIN_NT="lo,hi": the far-pair gathers of pairs [lo, hi) and the cached-pair gathers use the
+// non-temporal policy; packed as lo | (hi - lo) << 8, 0 = off
+static int chain_nt_setting() {
+    char const *e = getenv("LS_AMD_CHAIN_NT");
+    int lo = 0, hi = 0;
+    if (!e || sscanf(e, "%d%*[,:]%d", &lo, &hi) != 2 || lo < 0 || hi <= lo || hi > 64) return 0;
+    return lo | ((hi - lo) << 8);
+}
 template <typename W, typename R, bool CPLX, int TILE, bool REC>
 static int launch_chain(lsk_operator op, lsk_basis bs, lsk_index ix, lsk_tilemap tm, int64_t n, uint64_t const *reps,
                         int64_t row0, int64_t n_x, void const *x, void *y, int n_cached, void const *cache, double cv0,
@@ -1480,14 +1491,18 @@ static int launch_chain(lsk_operator op, lsk_basis bs, lsk_index ix, lsk_tilemap
     if (gb > cap) gb = cap;
     hipLaunchKernelGGL((k_chain_t<W, R, CPLX, TILE, REC>), dim3((unsigned)gb), dim3(kBlock), (size_t)img.bytes, (hipStream_t)stream, op.runs,
                        op.n_diag, op.diag, bs.hamming_weight, img.dev, img.bytes / 16, img.kc, img.near_off, tm.entries, tm.slots_per_xcd, n, reps, x, y,
-                       high_pair_setting(kChainLdsPairs), n_cached, (R const *)cache, cv0, cv1, row0, n_x);
+                       high_pair_setting(kChainLdsPairs), n_cached, (R const *)cache, cv0, cv1, row0, n_x,
+                       chain_nt_setting());
     LSK_LAUNCH_CHECK();
     return 0;
 }
 
 // rows per tile: 1024 (f64) / 512 (c128).  Measured r2 on chain_32: doubling them (fewer blocks, 1.5x instead of 2x window
 // loads, but 5 instead of 7 blocks per CU) is slower, 8.72 vs 8.26 ms (f64), 15.5 vs 15.4 ms (c128).
-extern "C" int lsk_chain_tile_rows(int cplx) { return cplx ? 512 : 1024; }
+extern "C" int lsk_chain_tile_rows(int cplx) {
+    if (!cplx && getenv("LS_AMD_CHAIN_TILE") && atoi(getenv("LS_AMD_CHAIN_TILE")) == 512) return 512; // experiment
+    return cplx ? 512 : 1024;
+}
 
 extern "C" int lsk_chain(lsk_operator op, lsk_basis bs, lsk_index ix, int cplx, int wide_ranks, int fused_records, lsk_tilemap tm,
                          int64_t n, uint64_t const *reps, int64_t row0, int64_t n_x, void const *x, void *y, int n_cached,
@@ -1511,6 +1526,7 @@ extern "C" int lsk_chain(lsk_operator op, lsk_basis bs, lsk_index ix, int cplx, 
 #define LSK_CHAIN_ARGS op, bs, ix, tm, n, reps, row0, n_x, x, y, n_cached, cache, cv0, cv1, stream
     if (fused_records) { // `reps` is the record array made by lsk_chain_pack (32-bit states and ranks only)
         if (!narrow || cplx) { snprintf(g_err, sizeof(g_err), "lsk_chain: fused records need 32-bit states and ranks and f64 vectors"); return -1; }
+        if (lsk_chain_tile_rows(0) == 512) return launch_chain<uint32_t, uint32_t, false, 512, true>(LSK_CHAIN_ARGS);
         return launch_chain<uint32_t, uint32_t, false, 1024, true>(LSK_CHAIN_ARGS);
     }
     if (narrow) {
@@ -1520,300 +1536,6 @@ extern "C" int lsk_chain(lsk_operator op, lsk_basis bs, lsk_index ix, int cplx, 
     if (!wide_ranks) return cplx ? launch_chain<uint64_t, uint32_t, true, 512, false>(LSK_CHAIN_ARGS) : launch_chain<uint64_t, uint32_t, false, 1024, false>(LSK_CHAIN_ARGS);
     return cplx ? launch_chain<uint64_t, uint64_t, true, 512, false>(LSK_CHAIN_ARGS) : launch_chain<uint64_t, uint64_t, false, 1024, false>(LSK_CHAIN_ARGS);
 #undef LSK_CHAIN_ARGS
-}
-
-// ---------------------------------------------------------------------------------------------
-// Block-aligned row kernel with sibling tiles (lsk_sibplan, lsk.h) -- the Heisenberg-ring shape on <= 32 sites, f64.
-//
-// What bounds k_chain_t is its L2-miss traffic (53.5 GB on chain_32 at the rate of a plain copy), and half of that is the
-// far pairs: every tile re-reads, once per anti-aligned far pair, the tile of the partner high part from HBM.  Here a
-// work unit holds the blocks of ALL high parts that differ only inside the top t bits (same weight there: "siblings") in
-// LDS at once, so the pairs inside those t bits read LDS, and each x element of the unit is fetched once for all of them.
-// Blocks are the natural ones of the combinadic order (all words of one weight in the low nl bits under a fixed upper
-// part = C(nl, kL) consecutive rows): the pairs inside the low bits never leave the block, so there is no halo, and
-// neither the state (unrankL[row]) nor the ring partner's rank (rankL[word ^ 1] + a per-sibling constant) is read from a
-// per-row array: the kernel streams x and y and nothing else.
-// One block (512 threads) per unit; wave w walks the (sibling, 64-row chunk) items w, w + 8, ...; everything above the low
-// bits is uniform across an item, so the pairs >= nl are priced once per item, lane-parallel (lane l <-> pair nl + l), as
-// k_chain_t prices its far pairs.
-// ---------------------------------------------------------------------------------------------
-constexpr int kSibMaxBlock = 1024;
-template <int ROWS> struct SibFar { static constexpr int value = ROWS == 1 ? 12 : 10; }; // uniform-pair gathers in flight per row before the first wait
-constexpr int kSibBinomRows = 32;
-constexpr int kSibHead = kSibBinomRows * LSK_BINOM_K + 3 * LSK_SIB_MAX_S + 64; // u32 words in front of the unrank slice
-extern "C" int64_t lsk_chain_sib_lds_bytes(int max_rows, int max_block) {
-    return (int64_t)sizeof(uint32_t) * kSibHead + 2 * (((int64_t)max_block + 7) & ~(int64_t)3) + 8 * ((int64_t)max_rows + 2);
-}
-
-// One block per launch record (lsk_sib_rec: record b belongs to block b; the host wrote them in XCD-interleaved order).
-// Phase 1: header + per-sibling bases straight from the record (one memory latency), then the window: the blocks of all
-// siblings, the low words of the unit's weight class, the small tables -- one barrier.  Phase 2: wave w walks the items
-// (sibling, pair of 64-row chunks) w, w + W, ...: the pairs >= nl are priced once per item (lane l <-> pair nl + l) and
-// every gather of the item's ROWS chunks is issued before anything is consumed.  Measured r3 and not kept as variants
-// (profiles/r3_sib_sweep3_*, r3_sib_sweep6_*): ROWS = 2 (two rows per lane in flight, 99 instead of 59 VGPRs) 10.6 - 12.8 ms,
-// K units per block with the next unit's window prefetched into registers behind the compute phase (80 VGPRs + spills,
-// 24 waves per CU) 10.6 - 11.0 ms, against 9.4 - 9.9 ms for this form: the waves lost cost more than the latency hidden.
-struct SibLds {
-    uint32_t *binom, *base, *ring, *T, *sidx;
-    uint16_t *unr;
-    double *x;
-};
-// phase 2 of the sibling-tile kernels: the rows of one unit whose window (s_x), low words (s_unr) and per-sibling constants are
-// in LDS.  Wave w of the block walks the items (sibling, ROWS consecutive 64-row chunks) w, w + W, ...
-template <int ROWS, int FAR>
-__device__ __forceinline__ void sib_compute(lsk_runs const &runs, int n_diag, lsk_term const *__restrict__ diag, lsk_sibplan const &sp,
-                                            SibLds const &lds, int nS, int nL, uint32_t mid, int ring, double cv,
-                                            double const *__restrict__ x, double *__restrict__ y, int ablate) {
-    uint32_t *const s_binom = lds.binom, *const s_base = lds.base, *const s_ring = lds.ring, *const s_T = lds.T, *const s_sidx = lds.sidx;
-    uint16_t *const s_unr = lds.unr;
-    double *const s_x = lds.x;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nthreads = blockDim.x;
-    const int L = sp.L, t = sp.t, nl = sp.nl, hw = sp.hw;
-    const int tshift = L - t;
-    const int ZERO = nS * nL;
-    if (kAblate && (ablate & 1)) return; // LS_AMD_SIB_ABLATE (profiling builds only): 1 window loads only, 2 no global gathers,
-                                         // 4 no LDS near pairs, 8 no window load
-    const double v = runs.v_re[0];
-    const int nchunk = (nL + 63) >> 6;
-    const int npair = (nchunk + ROWS - 1) / ROWS;
-    constexpr int kSibFar = FAR;
-    const int n_glob = tshift - nl; // pairs nl .. L - t - 1 gather from global memory, pairs L - t .. L - 2 read a sibling
-    const int nwaves = nthreads >> 6;
-    int s = 0, c = wave;
-    while (c >= npair && s < nS) { c -= npair; ++s; }
-    // ring pair, first hop: rank of the partner's low word -- a 2^nl-entry table in L1 / L2, requested one item ahead
-    uint32_t rk_next[ROWS];
-#pragma unroll
-    for (int u = 0; u < ROWS; ++u) rk_next[u] = 0;
-    if (ring && s < nS) {
-#pragma unroll
-        for (int u = 0; u < ROWS; ++u) {
-            const int rn = (ROWS * c + u) * 64 + lane;
-            rk_next[u] = sp.rankL[(uint32_t)s_unr[rn < nL ? rn : nL - 1] ^ 1u];
-        }
-    }
-#pragma unroll 1
-    for (; s < nS;) {
-        const uint32_t T = s_T[s];
-        const uint32_t a_hi = (T << tshift) | mid; // the item's state without its low word
-        const uint32_t base = s_base[s];
-        const uint32_t top = (T >> (t - 1)) & 1u;
-        int r[ROWS], jr[ROWS];
-        bool ghost[ROWS], ring_act[ROWS];
-        uint32_t a[ROWS], ig[ROWS], ring_rank[ROWS];
-#pragma unroll
-        for (int u = 0; u < ROWS; ++u) {
-            const int r0 = (ROWS * c + u) * 64 + lane;
-            ghost[u] = r0 >= nL; // lanes past the end of the block stay active as copies of its last row, store nothing
-            r[u] = ghost[u] ? nL - 1 : r0;
-            const uint32_t Lw = s_unr[r[u]];
-            a[u] = a_hi | Lw;
-            ig[u] = base + (uint32_t)r[u];
-            jr[u] = s * nL + r[u];
-            ring_act[u] = ring && ((Lw & 1u) != top);
-            ring_rank[u] = ring_act[u] ? s_ring[s] + rk_next[u] : ig[u];
-        }
-        // the item after this one (same wave)
-        int s_n = s, c_n = c + nwaves;
-        while (c_n >= npair && s_n < nS) { c_n -= npair; ++s_n; }
-        if (ring && s_n < nS) {
-#pragma unroll
-            for (int u = 0; u < ROWS; ++u) {
-                const int rn = (ROWS * c_n + u) * 64 + lane;
-                rk_next[u] = sp.rankL[(uint32_t)s_unr[rn < nL ? rn : nL - 1] ^ 1u];
-            }
-        }
-        // ---- pairs >= nl: uniform across the item; lane l prices pair nl + l ------------------------------------------
-        unsigned long long m;
-        uint32_t off;
-        int sib = 0;
-        {
-            const int p = nl + lane;
-            const bool in_run = p <= L - 2;
-            const int ps = in_run ? p : 0;
-            const uint32_t hi = a_hi >> ps;
-            const bool bit = hi & 1u;
-            const bool act = in_run && (((hi >> 1) & 1u) != (uint32_t)bit);
-            const int kk = hw - __popc(hi); // set bits below p
-            const uint32_t d = s_binom[ps * LSK_BINOM_K + (kk < 0 ? 0 : kk)];
-            off = bit ? d : (uint32_t)(0 - d);
-            m = __builtin_amdgcn_ballot_w64(act);
-            if (p >= tshift && in_run) sib = (int)s_sidx[T ^ (3u << (p - tshift))] * nL; // LDS base of the partner sibling
-        }
-        unsigned long long m_glob = m & ((1ULL << n_glob) - 1ULL);
-        unsigned long long m_sib = m >> n_glob;
-        if (kAblate && (ablate & 2)) m_glob = 0;
-        double xv[ROWS][kSibFar];
-#pragma unroll
-        for (int q = 0; q < kSibFar; ++q) {
-#pragma unroll
-            for (int u = 0; u < ROWS; ++u) xv[u][q] = 0.0;
-            if (m_glob) {
-                const int l = __builtin_ctzll(m_glob);
-                m_glob &= m_glob - 1;
-                const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)off, l);
-#pragma unroll
-                for (int u = 0; u < ROWS; ++u) xv[u][q] = x[(uint32_t)(ig[u] + o)];
-            }
-        }
-        // ---- the pair that straddles Lw | mid: per lane, a near partner (<= C(nl - 1, .) rows away); the ring partner -----
-        double xc[ROWS], g_ring[ROWS];
-        uint32_t tdiff[ROWS];
-#pragma unroll
-        for (int u = 0; u < ROWS; ++u) {
-            tdiff[u] = a[u] ^ (a[u] >> 1);
-            const int lo = nl - 1;
-            const int k = __popc(a[u] & ((1u << lo) - 1u));
-            const bool bit = (a[u] >> lo) & 1u, act = (tdiff[u] >> lo) & 1u;
-            const uint32_t d = s_binom[lo * LSK_BINOM_K + k];
-            const uint32_t idx = bit ? ig[u] + d : ig[u] - d;
-            if (kAblate && (ablate & 2)) { xc[u] = 0.0; g_ring[u] = 0.0; continue; }
-            xc[u] = x[act ? idx : ig[u]];
-            xc[u] = act ? xc[u] : 0.0;
-            g_ring[u] = x[ring_rank[u]];
-        }
-        // ---- diagonal and the pairs inside the low word: LDS, no halo ------------------------------------------------------
-        double acc[ROWS], near[ROWS];
-        int k[ROWS];
-#pragma unroll
-        for (int u = 0; u < ROWS; ++u) k[u] = 0;
-#pragma unroll
-        for (int u = 0; u < ROWS; ++u) {
-            double dr, di;
-            diag_coeff<uint32_t, true>(runs, n_diag, diag, a[u], dr, di);
-            acc[u] = dr * s_x[jr[u]];
-            near[u] = 0.0;
-        }
-#pragma unroll 2
-        for (int lo = 0; lo < ((kAblate && (ablate & 4)) ? 0 : nl - 1); ++lo) {
-#pragma unroll
-            for (int u = 0; u < ROWS; ++u) {
-                const bool bit = (a[u] >> lo) & 1u, act = (tdiff[u] >> lo) & 1u;
-                const int d = (int)s_binom[lo * LSK_BINOM_K + k[u]];
-                k[u] += bit ? 1 : 0;
-                const int j = bit ? jr[u] + d : jr[u] - d;
-                near[u] += s_x[act ? j : ZERO];
-            }
-        }
-        // ---- sibling pairs: the partner block is in LDS at the same row ---------------------------------------------------
-        while (m_sib) {
-            const int l = __builtin_ctzll(m_sib);
-            m_sib &= m_sib - 1;
-            const int sb = __builtin_amdgcn_readlane(sib, l + n_glob);
-#pragma unroll
-            for (int u = 0; u < ROWS; ++u) near[u] += s_x[sb + r[u]];
-        }
-#pragma unroll
-        for (int u = 0; u < ROWS; ++u) {
-            near[u] += xc[u];
-#pragma unroll
-            for (int q = 0; q < kSibFar; ++q) near[u] += xv[u][q];
-        }
-        while (m_glob) { // more than kSibFar anti-aligned global pairs
-            double xw[ROWS][3];
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-#pragma unroll
-                for (int u = 0; u < ROWS; ++u) xw[u][q] = 0.0;
-                if (m_glob) {
-                    const int l = __builtin_ctzll(m_glob);
-                    m_glob &= m_glob - 1;
-                    const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)off, l);
-#pragma unroll
-                    for (int u = 0; u < ROWS; ++u) xw[u][q] = x[(uint32_t)(ig[u] + o)];
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < 3; ++q)
-#pragma unroll
-                for (int u = 0; u < ROWS; ++u) near[u] += xw[u][q];
-        }
-#pragma unroll
-        for (int u = 0; u < ROWS; ++u) {
-            acc[u] = fma(v, near[u], acc[u]);
-            acc[u] = fma(ring_act[u] ? cv : 0.0, g_ring[u], acc[u]);
-            if (!ghost[u]) __builtin_nontemporal_store(acc[u], y + ig[u]);
-        }
-        s = s_n;
-        c = c_n;
-    }
-}
-
-template <int ROWS>
-__global__ __launch_bounds__(kSibMaxBlock) void k_chain_sib(lsk_runs runs, int n_diag, lsk_term const *__restrict__ diag, lsk_sibplan sp,
-                                                            uint32_t const *__restrict__ g_binom, int ring, double cv,
-                                                            double const *__restrict__ x, double *__restrict__ y, int ablate) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint32_t *s_binom = reinterpret_cast<uint32_t *>(smem);      // [32][LSK_BINOM_K] C(n, k), n < 32
-    uint32_t *s_base = s_binom + kSibBinomRows * LSK_BINOM_K;    // [S] rank of row 0 of sibling s
-    uint32_t *s_ring = s_base + LSK_SIB_MAX_S;                   // [S] rank of row 0 of the ring partner's block
-    uint32_t *s_T = s_ring + LSK_SIB_MAX_S;                      // [S] top bits of sibling s
-    uint32_t *s_sidx = s_T + LSK_SIB_MAX_S;                      // [2^t] T -> sibling number (entries of other weights unused)
-    uint16_t *s_unr = reinterpret_cast<uint16_t *>(s_sidx + 64); // [nL] the low words of this unit's weight class, ascending
-    double *s_x = reinterpret_cast<double *>(s_unr + ((sp.max_block + 7) & ~3)); // [S * nL + 1], last = 0.0
-    static_assert(kSibHead % 2 == 0, "s_x must be 8-byte aligned");
-
-    const int tid = threadIdx.x;
-    const int nthreads = blockDim.x;
-    lsk_sib_rec const *__restrict__ rec = sp.recs + blockIdx.x;
-    const int nS = (int)rec->nS;
-    if (nS == 0) return; // empty slot of a shorter XCD list (block-uniform)
-    const int nL = (int)rec->nL;
-    const uint32_t mid = rec->mid, uoff = rec->uoff;
-    const int t = sp.t;
-    const int ZERO = nS * nL;
-    // ---- phase 1 ----------------------------------------------------------------------------------------------------
-    if (!(kAblate && (ablate & 8)))
-        for (int s = 0; s < nS; ++s) {
-            double const *__restrict__ xb = x + rec->base[s];
-            for (int r = tid; r < nL; r += nthreads) s_x[s * nL + r] = xb[r];
-        }
-    for (int r = tid; r < nL; r += nthreads) s_unr[r] = sp.unrankL[uoff + r];
-    {
-        constexpr int N16 = kSibBinomRows * LSK_BINOM_K * (int)sizeof(uint32_t) / 16;
-        uint4 const *src = reinterpret_cast<uint4 const *>(g_binom);
-        uint4 *dst = reinterpret_cast<uint4 *>(s_binom);
-        for (int k = tid; k < N16; k += nthreads) dst[k] = src[k];
-    }
-    if (tid < nS) { s_base[tid] = rec->base[tid]; s_ring[tid] = rec->ring[tid]; s_T[tid] = rec->T[tid]; }
-    if (tid < (1 << t)) s_sidx[tid] = sp.tab->sidx[tid];
-    if (tid == 0) s_x[ZERO] = 0.0;
-    __syncthreads();
-    // ---- phase 2 ----------------------------------------------------------------------------------------------------
-    SibLds lds = {s_binom, s_base, s_ring, s_T, s_sidx, s_unr, s_x};
-    sib_compute<ROWS, SibFar<ROWS>::value>(runs, n_diag, diag, sp, lds, nS, nL, mid, ring, cv, x, y, ablate);
-}
-
-// binomial table as u32 (ranks < 2^32): shared with the staged kernel
-template <typename R> static R const *chain_binom(uint64_t const *g_binom, hipStream_t stream);
-extern "C" int lsk_chain_sib(lsk_operator op, lsk_sibplan sp, uint64_t const *g_binom, int ring, double cv, void const *x, void *y,
-                             void *stream) {
-    if (sp.n_units == 0 || sp.n_recs == 0) return 0;
-    if (op.runs.n_runs != 1 || op.runs.lo0[0] != 0 || op.runs.cnt[0] != sp.L - 1 || sp.L > 32) {
-        snprintf(g_err, sizeof(g_err), "lsk_chain_sib: the operator is not one exchange run over all adjacent pairs of <= 32 sites");
-        return -1;
-    }
-    const int64_t lds = lsk_chain_sib_lds_bytes(sp.max_rows, sp.max_block);
-    if (lds > 160 * 1024) { snprintf(g_err, sizeof(g_err), "lsk_chain_sib: a unit needs %lld bytes of LDS", (long long)lds); return -1; }
-    static std::mutex lock;
-    static int64_t configured = 0;
-    {
-        std::lock_guard<std::mutex> guard(lock);
-        if (lds > configured) {
-            LSK_CHECK(hipFuncSetAttribute((void const *)k_chain_sib<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            configured = lds;
-        }
-    }
-    uint32_t const *binom_r = chain_binom<uint32_t>(g_binom, (hipStream_t)stream);
-    if (!binom_r) { snprintf(g_err, sizeof(g_err), "lsk_chain_sib: no memory for the narrow binomial table"); return -1; }
-    int threads = 768; // measured r3 (profiles/r3_sib_sweep*): 24 waves per CU (two blocks of 12) beat 16 and 32
-    { char const *e = getenv("LS_AMD_SIB_THREADS"); if (e && atoi(e) >= 64 && atoi(e) <= kSibMaxBlock) threads = atoi(e) & ~63; }
-    hipLaunchKernelGGL(k_chain_sib<1>, dim3((unsigned)sp.n_recs), dim3(threads), (size_t)lds, (hipStream_t)stream, op.runs,
-                       op.n_diag, op.diag, sp, binom_r, ring, cv, (double const *)x, (double *)y,
-                       getenv("LS_AMD_SIB_ABLATE") ? atoi(getenv("LS_AMD_SIB_ABLATE")) : 0);
-    LSK_LAUNCH_CHECK();
-    return 0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2488,213 +2210,104 @@ extern "C" int lsk_scatter_owned(int64_t n, uint32_t const *perm, int64_t base, 
     return 0;
 }
 
-// Indexed mode of k_tile_pull: the same stage A (LDS term list per 256-row tile) and stage B1 (K4), then
-//   near partners (inside the LDS window of the sorted representatives): global index g -> slot (perm[g] or g) -> xsrc[slot]
-//   far partners: ONE 16-byte bucket of the static index table -> slot -> xsrc[slot]
-// All first-level loads of a thread's kGCPull packets are issued before any is consumed, then all value loads.
-#ifdef LSK_PULLIDX_OCC7
-#define LSK_PULLIDX_BOUNDS __launch_bounds__(kBlock, 7) __attribute__((amdgpu_num_sgpr(94)))
-#else
-#define LSK_PULLIDX_BOUNDS __launch_bounds__(kBlock)
-#endif
-template <typename W, bool PM1, bool CPLX, bool REAL>
-__global__ LSK_PULLIDX_BOUNDS void k_tile_pull_idx(lsk_runs runs, int n_groups, lsk_group const *__restrict__ groups,
-                                                          lsk_term const *__restrict__ off, int n_diag,
-                                                          lsk_term const *__restrict__ diag, lsk_basis bs,
-                                                          lsk_group_elem const *__restrict__ elems, int64_t row0, int64_t row1,
-                                                          uint64_t const *__restrict__ reps,
-                                                          double const *__restrict__ norms_local, lsk_pullidx ix,
-                                                          uint64_t const *__restrict__ greps, int64_t n_global,
-                                                          double const *__restrict__ xsrc, int halo, double *__restrict__ y,
-                                                          int *err) {
-    typedef typename ChainX<CPLX>::type X;
-    X const *__restrict__ xv = (X const *)xsrc;
-    extern __shared__ uint32_t s_win[]; // [kBlock + 2 * halo]: sized at launch, so that a smaller window buys resident blocks
-    __shared__ uint64_t s_beta[kCapPull];
-    constexpr bool RC = REAL && PM1;
-    __shared__ double s_coef[kCapPull * (RC ? 1 : 2)];
-    __shared__ uint16_t s_row[kCapPull];
-    __shared__ double s_acc[kBlock * (CPLX ? 2 : 1)];
-    __shared__ int s_n;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    uint64_t const *__restrict__ tab = ix.tab.entries;
-    for (int64_t t0 = row0 + (int64_t)blockIdx.x * kBlock; t0 < row1; t0 += (int64_t)gridDim.x * kBlock) {
-        const int64_t i = t0 + tid;
-        const bool valid = i < row1;
-        uint64_t a = 0;
-        double inv_na = 0.0;
-        if (valid) {
-            a = reps[i];
-            const double na = norms_local[i];
-            inv_na = na > 0.0 ? 1.0 / na : 0.0;
-        }
-        if (CPLX) { s_acc[2 * tid] = 0.0; s_acc[2 * tid + 1] = 0.0; } else s_acc[tid] = 0.0;
-        int64_t gbase = 0;
-        int wn = 0;
-        uint64_t v0 = 0;
-        if (halo > 0) {
-            const int64_t ig0 = ix.row_g0 + t0;
-            gbase = ig0 > halo ? ig0 - halo : 0;
-            const int64_t left = n_global - gbase;
-            wn = (int)(left < (int64_t)(kBlock + 2 * halo) ? left : (int64_t)(kBlock + 2 * halo));
-            v0 = greps[gbase];
-            for (int w = tid; w < wn; w += kBlock) s_win[w] = window_offset(greps[gbase + w], v0);
-        }
-        for (int g0 = 0; g0 < n_groups; g0 += kGCPull) {
-            if (tid == 0) s_n = 0;
-            __syncthreads();
-            const int g1 = min(g0 + kGCPull, n_groups);
-            for (int g = g0; g < g1; ++g) {
-                lsk_group const G = groups[g];
-                double cr = 0.0, ci = 0.0;
-                if (valid) group_coeff<REAL>(G, off, a, cr, ci);
-                const bool act = valid && (cr != 0.0 || (!REAL && ci != 0.0));
-                const unsigned long long ball = __ballot(act);
-                int base = 0;
-                if (lane == 0 && ball) base = atomicAdd(&s_n, __popcll(ball));
-                base = __shfl(base, 0);
-                if (act) {
-                    const int slot = base + __popcll(ball & ((1ULL << lane) - 1));
-                    s_beta[slot] = a ^ G.x;
-                    s_row[slot] = (uint16_t)tid;
-                    if (RC) s_coef[slot] = cr * inv_na;
-                    else { s_coef[2 * slot] = cr * inv_na; s_coef[2 * slot + 1] = -ci * inv_na; }
-                }
-            }
-            __syncthreads();
-            const int n = (kAblate && (bs.debug_ablate & 1)) ? 0 : s_n; // LS_AMD_ABLATE (profiling builds): 1 no stage B, 2 no look-ups,
-                                                                        // 32 no value loads (slots resolved, x not read)
-            // ---- stage B1: K4 on every packet ------------------------------------------------------------
-            for (int e = tid; e < n; e += kBlock) {
-                uint64_t beta = s_beta[e];
-                if (bs.k4_mode != 0) {
-                    beta = (uint64_t)rep_trivial<W>(bs, elems, (W)beta); // xsrc is pre-multiplied by norm(rep)
-                } else {
-                    double hr, hi = 0.0;
-                    if (RC) hr = s_coef[e]; else { hr = s_coef[2 * e]; hi = s_coef[2 * e + 1]; }
-                    W rep; double chr, chi, stab;
-                    state_info_w<W, PM1>(bs, elems, (W)beta, rep, chr, chi, stab);
-                    const double n2 = stab * bs.inv_order;
-                    if (!(n2 > 1e-12)) { s_row[e] = 0xffff; continue; } // zero-norm orbit: contributes nothing (DMV:110)
-                    const double nb = sqrt(n2);
-                    beta = (uint64_t)rep;
-                    const double tr = (hr * chr + hi * chi) * nb, ti = (hi * chr - hr * chi) * nb;
-                    if (RC) s_coef[e] = tr; else { s_coef[2 * e] = tr; s_coef[2 * e + 1] = ti; }
-                }
-                s_beta[e] = beta;
-            }
-            // ---- stage B2: slots, then values --------------------------------------------------------------
-            if (!(kAblate && (bs.debug_ablate & 2))) {
-                uint64_t bkt[kGCPull];
-                uint32_t tag[kGCPull], slot[kGCPull];
-                ulonglong2 first[kGCPull];
-                bool live[kGCPull];
-                int pos[kGCPull];
-#pragma unroll
-                for (int k = 0; k < kGCPull; ++k) { // window searches: LDS only
-                    const int e = tid + k * kBlock;
-                    live[k] = e < n && s_row[e] != 0xffff;
-                    pos[k] = -1;
-                    bkt[k] = 0; tag[k] = 0; slot[k] = 0;
-                    first[k] = make_ulonglong2(0, 0);
-                    if (live[k]) {
-                        const uint64_t key = s_beta[e];
-                        if (wn > 0 && key >= v0) {
-                            const uint32_t d = window_offset(key, v0);
-                            if (d != kWinAbsent) pos[k] = window_find(s_win, wn, d);
-                        }
-                        if (pos[k] < 0) gt_split(ix.tab, key, bkt[k], tag[k]);
-                    }
-                }
-#pragma unroll
-                for (int k = 0; k < kGCPull; ++k) { // first-level loads: perm entry (near) or home bucket (far)
-                    if (!live[k]) continue;
-                    if (pos[k] >= 0) slot[k] = ix.perm ? ix.perm[gbase + pos[k]] : (uint32_t)(gbase + pos[k]);
-                    else first[k] = *(ulonglong2 const *)(tab + 2 * bkt[k]);
-                }
-#pragma unroll
-                for (int k = 0; k < kGCPull; ++k) { // resolve the far slots (a displaced key continues along its buckets)
-                    if (!live[k] || pos[k] >= 0) continue;
-                    slot[k] = gt_resolve(ix.tab, tab, bkt[k], tag[k], first[k]);
-                    if (slot[k] == 0xffffffffu) { atomicExch(err, 1); live[k] = false; }
-                }
-                X val[kGCPull];
-#pragma unroll
-                for (int k = 0; k < kGCPull; ++k) val[k] = (live[k] && !(kAblate && (bs.debug_ablate & 32))) ? xv[slot[k]] : cx_zero<X>();
-#pragma unroll
-                for (int k = 0; k < kGCPull; ++k) {
-                    if (!live[k]) continue;
-                    const int e = tid + k * kBlock;
-                    double hr, hi = 0.0;
-                    if (RC) hr = s_coef[e]; else { hr = s_coef[2 * e]; hi = s_coef[2 * e + 1]; }
-                    const int r = s_row[e];
-                    if constexpr (CPLX) {
-                        atomicAdd(&s_acc[2 * r], hr * val[k].x - hi * val[k].y);
-                        atomicAdd(&s_acc[2 * r + 1], hr * val[k].y + hi * val[k].x);
-                    } else {
-                        atomicAdd(&s_acc[r], hr * val[k]);
-                    }
-                }
-            }
-            __syncthreads();
-        }
-        if (valid) {
-            const int64_t ig = ix.row_g0 + i;
-            const uint32_t own = ix.perm ? ix.perm[ig] : (uint32_t)ig;
-            // x of this row: xsrc holds x * norm(rep) in the prescaling K4 modes
-            const double back = bs.k4_mode != 0 ? inv_na : 1.0;
-            double dr = 0.0, di = 0.0;
-            if (n_diag > 0) diag_coeff<uint64_t, REAL>(runs, n_diag, diag, a, dr, di);
-            if constexpr (CPLX) {
-                const X xo = xv[own];
-                const double xr = xo.x * back, xi = xo.y * back;
-                double yr = dr * xr - di * xi + s_acc[2 * tid], yi = dr * xi + di * xr + s_acc[2 * tid + 1];
-                if (n_diag == 0) { yr += y[2 * i]; yi += y[2 * i + 1]; } // accumulate, DMV:1062-1063
-                y[2 * i] = yr; y[2 * i + 1] = yi;
-            } else {
-                double yr = n_diag > 0 ? dr * (xv[own] * back) + s_acc[tid] : s_acc[tid];
-                if (n_diag == 0) yr += y[i];
-                y[i] = yr;
-            }
-        }
-        __syncthreads();
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
-// k_tile_pull_wv: k_tile_pull_idx with the packet list PER WAVE.  Each wave owns a 256-slot ring of the LDS list and the
-// rows of its 64 lanes: stage A appends the packets of three groups (<= 192) behind what is left in the ring, stage B takes
+// INDEXED pull kernels of the projected bases (k_pull_t / k_pull_gather).
+//
+// One block per 256-row tile, the packet list PER WAVE: each wave owns a 256-slot ring of the LDS list and the rows of its
+// 64 lanes.  Stage A appends the packets of three flip-mask groups (<= 192) behind what is left in the ring, stage B takes
 // full chunks of 64 packets out of it -- K4 with every lane busy -- and leaves the remainder (< 64) for the next round; the
-// tile ends with one partial chunk.  No block barrier inside a tile except around the shared near window: the four waves
-// of a block drift apart, so the ALU phase (K4) of one overlaps the look-ups of another (k_tile_pull_idx synchronises all
-// four twice per four groups, and its last pass over the list runs K4 for a handful of packets).  Accumulation stays
-// ds_add_f64 into the tile's LDS copy of y; the rows of a wave are only touched by that wave.
+// tile ends with one partial chunk.  No block barrier inside a tile except around the shared near window, so the four waves
+// of a block drift apart and the ALU phase (K4) of one overlaps the look-ups of another.
+//
+// Stage B per packet: K4 (orbit minimum [+ character, norm]) -> SLOT of the representative:
+//   near partners: the tile stages the sorted representatives [tile - halo, tile + 256 + halo) as a two-way hash set in LDS
+//     (nw_*, below): one ds_read_b64 instead of the 11-step binary search of round 3; global index -> slot (perm[g] or g);
+//   far partners: ONE 16-byte bucket of the static index table (lsk_gtab) -> slot.
+// What happens with the slot is the SINK:
+//   SINK_FUSED   : value = xsrc[slot], ds_add_f64 into the tile's LDS copy of y, y written once (the one-GPU default);
+//   SINK_RESOLVE : the slot (and, unless every packet has the same real amplitude, its coefficient) is written to the
+//                  per-wave packet stream of lsk_pullbuf and NOTHING of x is read -- this half of the matvec runs while the
+//                  blocks of x are still on the wire (ls_amd_repl_matvec, dist.c); k_pull_gather then streams the slots,
+//                  gathers x and accumulates.  The stream is recomputed every matvec: the path stays matrix-free.
 // ---------------------------------------------------------------------------------------------
 constexpr int kWvRing = 256; // slots per wave: < 64 left over + 3 groups x 64 lanes
 constexpr int kWvGroups = 3;
-template <typename W, bool PM1, bool CPLX, bool REAL>
-__global__ __launch_bounds__(kBlock) void k_tile_pull_wv(lsk_runs runs, int n_groups, lsk_group const *__restrict__ groups,
-                                                         lsk_term const *__restrict__ off, int n_diag,
-                                                         lsk_term const *__restrict__ diag, lsk_basis bs,
-                                                         lsk_group_elem const *__restrict__ elems, int64_t row0, int64_t row1,
-                                                         uint64_t const *__restrict__ reps,
-                                                         double const *__restrict__ norms_local, lsk_pullidx ix,
-                                                         uint64_t const *__restrict__ greps, int64_t n_global,
-                                                         double const *__restrict__ xsrc, int halo, double *__restrict__ y,
-                                                         int *err) {
+enum { K4_TRIVIAL = 0, K4_PM1 = 1, K4_GENERAL = 2 };     // what K4 has to deliver (lsk_basis.k4_mode != 0 -> TRIVIAL)
+enum { COEF_UNI = 0, COEF_REAL = 1, COEF_CPLX = 2 };      // per-packet coefficient: none (one real amplitude), f64, 2 x f64
+enum { SINK_FUSED = 0, SINK_RESOLVE = 1 };
+constexpr uint32_t kNoSlot = 0xffffffffu;
+
+// Near window as a hash set in LDS: kNwSets sets of two 4-byte entries.  h = d * odd constant is a bijection of the 32-bit
+// offset d = rep - v0, set = top 10 bits, entry = (low 22 bits of h) << 10 | position in the window (< 1024) -- so set and
+// tag together identify d and a match cannot be a false positive.  A set that is already full DROPS the third arrival: the
+// window is only an accelerator, whatever it does not answer goes through the static index table (which holds every
+// representative).  At <= 768 staged entries ~2 % are dropped.
+constexpr int kNwSets = 1024;
+constexpr int kNwMaxWin = 1024;
+constexpr uint32_t kNwEmpty = 0xffffffffu;
+__host__ __device__ __forceinline__ uint32_t nw_mix(uint32_t d) { return d * 0x9E3779B1u; }
+__host__ __device__ __forceinline__ uint32_t nw_entry(uint32_t h, int pos) { return (h << 10) | (uint32_t)pos; }
+__device__ __forceinline__ void nw_insert(uint32_t *tab, uint32_t d, int pos) {
+    const uint32_t h = nw_mix(d), e = nw_entry(h, pos);
+    uint32_t *s = tab + 2 * (h >> 22);
+    if (atomicCAS(s, kNwEmpty, e) != kNwEmpty) (void)atomicCAS(s + 1, kNwEmpty, e);
+}
+__host__ __device__ __forceinline__ int nw_match(uint32_t e0, uint32_t e1, uint32_t h) {
+    const uint32_t want = h << 10;
+    if (((e0 ^ want) >> 10) == 0 && e0 != kNwEmpty) return (int)(e0 & 1023u);
+    if (((e1 ^ want) >> 10) == 0 && e1 != kNwEmpty) return (int)(e1 & 1023u);
+    return -1;
+}
+__device__ __forceinline__ int nw_find(uint32_t const *tab, uint32_t d) {
+    const uint32_t h = nw_mix(d);
+    const uint2 e = *reinterpret_cast<uint2 const *>(tab + 2 * (h >> 22));
+    return nw_match(e.x, e.y, h);
+}
+// host mirror (tests, no device): stage reps[0, n) (ascending, n <= 1024) with the rule of the kernel, sequentially, then look
+// `key` up: its position, -1 when the window does not answer (absent, or dropped from a full set), -2 on bad arguments
+extern "C" int lsk_test_nw_find(uint64_t const *reps, int n, uint64_t key) {
+    if (n < 1 || n > kNwMaxWin) return -2;
+    static thread_local uint32_t tab[2 * kNwSets];
+    for (int i = 0; i < 2 * kNwSets; ++i) tab[i] = kNwEmpty;
+    for (int i = 0; i < n; ++i) {
+        const uint32_t d = window_offset(reps[i], reps[0]);
+        if (d == kWinAbsent) continue;
+        const uint32_t h = nw_mix(d), e = nw_entry(h, i);
+        uint32_t *s = tab + 2 * (h >> 22);
+        if (s[0] == kNwEmpty) s[0] = e; else if (s[1] == kNwEmpty) s[1] = e;
+    }
+    if (key < reps[0]) return -1;
+    const uint32_t d = window_offset(key, reps[0]);
+    if (d == kWinAbsent) return -1;
+    const uint32_t h = nw_mix(d);
+    return nw_match(tab[2 * (h >> 22)], tab[2 * (h >> 22) + 1], h);
+}
+
+template <typename W, int K4M, int COEF, bool CPLX, int SINK>
+__global__ __launch_bounds__(kBlock) void k_pull_t(lsk_runs runs, int n_groups, lsk_group const *__restrict__ groups,
+                                                   lsk_term const *__restrict__ off, int n_diag,
+                                                   lsk_term const *__restrict__ diag, lsk_basis bs,
+                                                   lsk_group_elem const *__restrict__ elems, int64_t row0, int64_t row1,
+                                                   uint64_t const *__restrict__ reps,
+                                                   double const *__restrict__ norms_local, lsk_pullidx ix,
+                                                   uint64_t const *__restrict__ greps, int64_t n_global,
+                                                   double const *__restrict__ xsrc, int halo, double uni_v,
+                                                   double *__restrict__ y, lsk_pullbuf buf, int *err) {
     typedef typename ChainX<CPLX>::type X;
+    constexpr bool REAL = COEF != COEF_CPLX;
+    constexpr bool FUSED = SINK == SINK_FUSED;
+    constexpr int NC = COEF == COEF_UNI ? 0 : (COEF == COEF_REAL ? 1 : 2);
     X const *__restrict__ xv = (X const *)xsrc;
-    extern __shared__ uint32_t s_win[];
     constexpr int kCap = (kBlock / 64) * kWvRing;
-    constexpr bool RC = REAL && PM1;
-    __shared__ uint64_t s_beta[kCap];
-    __shared__ double s_coef[kCap * (RC ? 1 : 2)];
-    __shared__ uint16_t s_row[kCap];
-    __shared__ double s_acc[kBlock * (CPLX ? 2 : 1)];
+    __shared__ uint32_t s_nw[2 * kNwSets];
+    __shared__ W s_beta[kCap];
+    __shared__ double s_coef[NC ? kCap * NC : 1];
+    __shared__ uint8_t s_row[kCap]; // row inside the wave (0..63)
+    __shared__ double s_acc[FUSED ? kBlock * (CPLX ? 2 : 1) : 1];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int rb = (tid >> 6) * kWvRing; // this wave's ring
+    const int wave = tid >> 6;
+    const int rb = wave * kWvRing; // this wave's ring
     uint64_t const *__restrict__ tab = ix.tab.entries;
     for (int64_t t0 = row0 + (int64_t)blockIdx.x * kBlock; t0 < row1; t0 += (int64_t)gridDim.x * kBlock) {
         const int64_t i = t0 + tid;
@@ -2706,7 +2319,7 @@ __global__ __launch_bounds__(kBlock) void k_tile_pull_wv(lsk_runs runs, int n_gr
             const double na = norms_local[i];
             inv_na = na > 0.0 ? 1.0 / na : 0.0;
         }
-        if (CPLX) { s_acc[2 * tid] = 0.0; s_acc[2 * tid + 1] = 0.0; } else s_acc[tid] = 0.0;
+        if (FUSED) { if (CPLX) { s_acc[2 * tid] = 0.0; s_acc[2 * tid + 1] = 0.0; } else s_acc[tid] = 0.0; }
         int64_t gbase = 0;
         int wn = 0;
         uint64_t v0 = 0;
@@ -2716,12 +2329,22 @@ __global__ __launch_bounds__(kBlock) void k_tile_pull_wv(lsk_runs runs, int n_gr
             const int64_t left = n_global - gbase;
             wn = (int)(left < (int64_t)(kBlock + 2 * halo) ? left : (int64_t)(kBlock + 2 * halo));
             v0 = greps[gbase];
-            for (int w = tid; w < wn; w += kBlock) s_win[w] = window_offset(greps[gbase + w], v0);
+            uint4 *const z = reinterpret_cast<uint4 *>(s_nw);
+            for (int w = tid; w < 2 * kNwSets / 4; w += kBlock) z[w] = make_uint4(kNwEmpty, kNwEmpty, kNwEmpty, kNwEmpty);
+            __syncthreads();
+            for (int w = tid; w < wn; w += kBlock) {
+                const uint32_t d = window_offset(greps[gbase + w], v0);
+                if (d != kWinAbsent) nw_insert(s_nw, d, w);
+            }
         }
         __syncthreads(); // the window is staged
         int head = 0, cnt = 0; // wave-uniform: the ring holds [head, head + cnt) mod kWvRing
+        // packet stream of this wave's 64 rows (SINK_RESOLVE)
+        const int64_t wg = ((t0 - buf.row0) >> 6) + wave;
+        const int64_t sbase = wg * buf.cap;
+        int emitted = 0;
         // K chunks at once: the packets at ring positions head + 64 k + lane (the last chunk holds m <= 64 of them):
-        // K4 -> slot -> value -> ds_add_f64, the loads of the K packets of a lane issued together
+        // K4 -> slot [-> value -> ds_add_f64], the loads of the K packets of a lane issued together
         auto chunks = [&](auto KC, int m) {
             constexpr int K = decltype(KC)::value;
             uint64_t beta[K], bkt[K];
@@ -2734,18 +2357,19 @@ __global__ __launch_bounds__(kBlock) void k_tile_pull_wv(lsk_runs runs, int n_gr
             for (int k = 0; k < K; ++k) {
                 live[k] = k + 1 < K || lane < m;
                 const int e = rb + ((head + 64 * k + lane) & (kWvRing - 1));
-                beta[k] = live[k] ? s_beta[e] : 0;
-                hr[k] = 0.0; hi[k] = 0.0;
-                if (live[k]) { if (RC) hr[k] = s_coef[e]; else { hr[k] = s_coef[2 * e]; hi[k] = s_coef[2 * e + 1]; } }
-                r[k] = live[k] ? (int)s_row[e] : 0;
+                beta[k] = live[k] ? (uint64_t)s_beta[e] : 0;
+                hr[k] = 1.0; hi[k] = 0.0;
+                if (NC == 1) hr[k] = s_coef[e];
+                if (NC == 2) { hr[k] = s_coef[2 * e]; hi[k] = s_coef[2 * e + 1]; }
+                r[k] = (int)s_row[e];
             }
 #pragma unroll
             for (int k = 0; k < K; ++k) {
-                if (bs.k4_mode != 0) {
+                if (K4M == K4_TRIVIAL) {
                     beta[k] = (uint64_t)rep_trivial<W>(bs, elems, (W)beta[k]); // xsrc is pre-multiplied by norm(rep)
                 } else if (live[k]) {
                     W rep; double chr, chi, stab;
-                    state_info_w<W, PM1>(bs, elems, (W)beta[k], rep, chr, chi, stab);
+                    state_info_w<W, K4M == K4_PM1>(bs, elems, (W)beta[k], rep, chr, chi, stab);
                     const double n2 = stab * bs.inv_order;
                     if (!(n2 > 1e-12)) live[k] = false; // zero-norm orbit: contributes nothing (DMV:110)
                     else {
@@ -2757,13 +2381,13 @@ __global__ __launch_bounds__(kBlock) void k_tile_pull_wv(lsk_runs runs, int n_gr
                 }
             }
 #pragma unroll
-            for (int k = 0; k < K; ++k) { // window searches: LDS only
-                pos[k] = -1; bkt[k] = 0; tag[k] = 0; slot[k] = 0;
+            for (int k = 0; k < K; ++k) { // near window: LDS only
+                pos[k] = -1; bkt[k] = 0; tag[k] = 0; slot[k] = kNoSlot;
                 first[k] = make_ulonglong2(0, 0);
                 if (live[k]) {
                     if (wn > 0 && beta[k] >= v0) {
                         const uint32_t d = window_offset(beta[k], v0);
-                        if (d != kWinAbsent) pos[k] = window_find(s_win, wn, d);
+                        if (d != kWinAbsent) pos[k] = nw_find(s_nw, d);
                     }
                     if (pos[k] < 0) gt_split(ix.tab, beta[k], bkt[k], tag[k]);
                 }
@@ -2778,36 +2402,58 @@ __global__ __launch_bounds__(kBlock) void k_tile_pull_wv(lsk_runs runs, int n_gr
             for (int k = 0; k < K; ++k) {
                 if (!live[k] || pos[k] >= 0) continue;
                 slot[k] = gt_resolve(ix.tab, tab, bkt[k], tag[k], first[k]);
-                if (slot[k] == 0xffffffffu) { atomicExch(err, 1); live[k] = false; }
+                if (slot[k] == kNoSlot) { atomicExch(err, 1); live[k] = false; }
             }
-            X val[K];
+            if constexpr (FUSED) {
+                X val[K];
 #pragma unroll
-            for (int k = 0; k < K; ++k) val[k] = live[k] ? xv[slot[k]] : cx_zero<X>();
+                for (int k = 0; k < K; ++k) val[k] = live[k] ? xv[slot[k]] : cx_zero<X>();
 #pragma unroll
-            for (int k = 0; k < K; ++k) {
-                if (!live[k]) continue;
-                if constexpr (CPLX) {
-                    atomicAdd(&s_acc[2 * r[k]], hr[k] * val[k].x - hi[k] * val[k].y);
-                    atomicAdd(&s_acc[2 * r[k] + 1], hr[k] * val[k].y + hi[k] * val[k].x);
-                } else {
-                    atomicAdd(&s_acc[r[k]], hr[k] * val[k]);
+                for (int k = 0; k < K; ++k) {
+                    if (!live[k]) continue;
+                    const int ra = (wave << 6) + r[k];
+                    if constexpr (CPLX) {
+                        atomicAdd(&s_acc[2 * ra], hr[k] * val[k].x - hi[k] * val[k].y);
+                        atomicAdd(&s_acc[2 * ra + 1], hr[k] * val[k].y + hi[k] * val[k].x);
+                    } else if constexpr (NC == 0) {
+                        atomicAdd(&s_acc[ra], val[k]);
+                    } else {
+                        atomicAdd(&s_acc[ra], hr[k] * val[k]);
+                    }
                 }
+            } else {
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    if (k + 1 == K && lane >= m) continue;
+                    const int64_t o = sbase + emitted + 64 * k + lane;
+                    __builtin_nontemporal_store(live[k] ? slot[k] : kNoSlot, buf.slots + o);
+                    __builtin_nontemporal_store((uint8_t)r[k], buf.rows + o);
+                    if (NC == 1) __builtin_nontemporal_store(hr[k], buf.coefs + o);
+                    if (NC == 2) { __builtin_nontemporal_store(hr[k], buf.coefs + 2 * o); __builtin_nontemporal_store(hi[k], buf.coefs + 2 * o + 1); }
+                }
+                emitted += 64 * (K - 1) + m;
             }
         };
+        const W tdiff = (W)a ^ (W)((W)a >> 1); // bit b set: sites b, b + 1 differ (adjacent exchange groups)
         for (int g0 = 0; g0 < n_groups; g0 += kWvGroups) {
             const int g1 = min(g0 + kWvGroups, n_groups);
             for (int g = g0; g < g1; ++g) { // stage A: append
                 lsk_group const G = groups[g];
                 double cr = 0.0, ci = 0.0;
-                if (valid) group_coeff<REAL>(G, off, a, cr, ci);
-                const bool act = valid && (cr != 0.0 || (!REAL && ci != 0.0));
+                bool act;
+                if (NC == 0) { // every group is an exchange pair with the amplitude uni_v
+                    act = valid && (G.adj >= 0 ? (bool)((tdiff >> G.adj) & 1) : WordTraits<W>::popc((W)a & (W)G.x) == 1);
+                } else {
+                    if (valid) group_coeff<REAL>(G, off, a, cr, ci);
+                    act = valid && (cr != 0.0 || (!REAL && ci != 0.0));
+                }
                 const unsigned long long ball = __ballot(act);
                 if (act) {
                     const int slot = rb + ((head + cnt + __popcll(ball & ((1ULL << lane) - 1))) & (kWvRing - 1));
-                    s_beta[slot] = a ^ G.x;
-                    s_row[slot] = (uint16_t)tid;
-                    if (RC) s_coef[slot] = cr * inv_na;
-                    else { s_coef[2 * slot] = cr * inv_na; s_coef[2 * slot + 1] = -ci * inv_na; }
+                    s_beta[slot] = (W)(a ^ G.x);
+                    s_row[slot] = (uint8_t)lane;
+                    if (NC == 1) s_coef[slot] = cr * inv_na;
+                    if (NC == 2) { s_coef[2 * slot] = cr * inv_na; s_coef[2 * slot + 1] = -ci * inv_na; }
                 }
                 cnt += __popcll(ball);
             }
@@ -2828,77 +2474,229 @@ __global__ __launch_bounds__(kBlock) void k_tile_pull_wv(lsk_runs runs, int n_gr
             __builtin_amdgcn_wave_barrier();
         }
         if (cnt > 0) chunks(std::integral_constant<int, 1>(), cnt);
+        if constexpr (FUSED) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (valid) {
+                const int64_t ig = ix.row_g0 + i;
+                const uint32_t own = ix.perm ? ix.perm[ig] : (uint32_t)ig;
+                const double back = K4M == K4_TRIVIAL ? inv_na : 1.0; // xsrc holds x * norm(rep) in the prescaling K4 modes
+                const double sc = NC == 0 ? uni_v * inv_na : 1.0;     // one amplitude for every packet: applied once per row
+                double dr = 0.0, di = 0.0;
+                if (n_diag > 0) diag_coeff<uint64_t, REAL>(runs, n_diag, diag, a, dr, di);
+                if constexpr (CPLX) {
+                    const X xo = xv[own];
+                    const double xr = xo.x * back, xi = xo.y * back;
+                    double yr = dr * xr - di * xi + sc * s_acc[2 * tid], yi = dr * xi + di * xr + sc * s_acc[2 * tid + 1];
+                    if (n_diag == 0) { yr += y[2 * i]; yi += y[2 * i + 1]; } // accumulate, DMV:1062-1063
+                    y[2 * i] = yr; y[2 * i + 1] = yi;
+                } else {
+                    double yr = n_diag > 0 ? dr * (xv[own] * back) + sc * s_acc[tid] : sc * s_acc[tid];
+                    if (n_diag == 0) yr += y[i];
+                    y[i] = yr;
+                }
+            }
+        } else if (lane == 0) buf.counts[wg] = (uint32_t)emitted;
+        __syncthreads(); // every wave is done with the window
+    }
+}
+
+// Second half of the split matvec: the packet stream of k_pull_t<..., SINK_RESOLVE> -> x[slot] -> y.  One wave per 64 rows,
+// no barrier at all: a wave only touches the LDS accumulators of its own rows.  GU chunks of 64 packets in flight per wave.
+template <int COEF, bool CPLX>
+__global__ __launch_bounds__(kBlock) void k_pull_gather(lsk_runs runs, int n_diag, lsk_term const *__restrict__ diag, int k4_mode,
+                                                        int64_t row0, int64_t row1, uint64_t const *__restrict__ reps,
+                                                        double const *__restrict__ norms_local, lsk_pullidx ix,
+                                                        double const *__restrict__ xsrc, double uni_v, double *__restrict__ y,
+                                                        lsk_pullbuf buf) {
+    typedef typename ChainX<CPLX>::type X;
+    constexpr bool REAL = COEF != COEF_CPLX;
+    constexpr int NC = COEF == COEF_UNI ? 0 : (COEF == COEF_REAL ? 1 : 2);
+    constexpr int GU = 4;
+    X const *__restrict__ xv = (X const *)xsrc;
+    __shared__ double s_acc[kBlock * (CPLX ? 2 : 1)];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    for (int64_t t0 = row0 + (int64_t)blockIdx.x * kBlock; t0 < row1; t0 += (int64_t)gridDim.x * kBlock) {
+        if ((t0 + (wave << 6)) >= row1) continue; // wave-uniform
+        const int64_t i = t0 + tid;
+        const bool valid = i < row1;
+        if (CPLX) { s_acc[2 * tid] = 0.0; s_acc[2 * tid + 1] = 0.0; } else s_acc[tid] = 0.0;
+        const int64_t wg = ((t0 - buf.row0) >> 6) + wave;
+        const int64_t sbase = wg * buf.cap;
+        const int n = (int)buf.counts[wg];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int c = 0; c < n; c += 64 * GU) {
+            uint32_t slot[GU];
+            int r[GU];
+            double hr[GU], hi[GU];
+#pragma unroll
+            for (int u = 0; u < GU; ++u) {
+                const int p = c + 64 * u + lane;
+                slot[u] = kNoSlot; r[u] = 0; hr[u] = 1.0; hi[u] = 0.0;
+                if (p < n) {
+                    const int64_t o = sbase + p;
+                    slot[u] = __builtin_nontemporal_load(buf.slots + o);
+                    r[u] = (int)__builtin_nontemporal_load(buf.rows + o);
+                    if (NC == 1) hr[u] = __builtin_nontemporal_load(buf.coefs + o);
+                    if (NC == 2) { hr[u] = __builtin_nontemporal_load(buf.coefs + 2 * o); hi[u] = __builtin_nontemporal_load(buf.coefs + 2 * o + 1); }
+                }
+            }
+            X val[GU];
+#pragma unroll
+            for (int u = 0; u < GU; ++u) val[u] = slot[u] != kNoSlot ? xv[slot[u]] : cx_zero<X>();
+#pragma unroll
+            for (int u = 0; u < GU; ++u) {
+                if (slot[u] == kNoSlot) continue;
+                const int ra = (wave << 6) + r[u];
+                if constexpr (CPLX) {
+                    atomicAdd(&s_acc[2 * ra], hr[u] * val[u].x - hi[u] * val[u].y);
+                    atomicAdd(&s_acc[2 * ra + 1], hr[u] * val[u].y + hi[u] * val[u].x);
+                } else if constexpr (NC == 0) {
+                    atomicAdd(&s_acc[ra], val[u]);
+                } else {
+                    atomicAdd(&s_acc[ra], hr[u] * val[u]);
+                }
+            }
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (valid) {
+            const uint64_t a = reps[i];
+            const double na = norms_local[i];
+            const double inv_na = na > 0.0 ? 1.0 / na : 0.0;
             const int64_t ig = ix.row_g0 + i;
             const uint32_t own = ix.perm ? ix.perm[ig] : (uint32_t)ig;
-            const double back = bs.k4_mode != 0 ? inv_na : 1.0; // xsrc holds x * norm(rep) in the prescaling K4 modes
+            const double back = k4_mode != 0 ? inv_na : 1.0;
+            const double sc = NC == 0 ? uni_v * inv_na : 1.0;
             double dr = 0.0, di = 0.0;
             if (n_diag > 0) diag_coeff<uint64_t, REAL>(runs, n_diag, diag, a, dr, di);
             if constexpr (CPLX) {
                 const X xo = xv[own];
                 const double xr = xo.x * back, xi = xo.y * back;
-                double yr = dr * xr - di * xi + s_acc[2 * tid], yi = dr * xi + di * xr + s_acc[2 * tid + 1];
-                if (n_diag == 0) { yr += y[2 * i]; yi += y[2 * i + 1]; } // accumulate, DMV:1062-1063
+                double yr = dr * xr - di * xi + sc * s_acc[2 * tid], yi = dr * xi + di * xr + sc * s_acc[2 * tid + 1];
+                if (n_diag == 0) { yr += y[2 * i]; yi += y[2 * i + 1]; }
                 y[2 * i] = yr; y[2 * i + 1] = yi;
             } else {
-                double yr = n_diag > 0 ? dr * (xv[own] * back) + s_acc[tid] : s_acc[tid];
+                double yr = n_diag > 0 ? dr * (xv[own] * back) + sc * s_acc[tid] : sc * s_acc[tid];
                 if (n_diag == 0) yr += y[i];
                 y[i] = yr;
             }
         }
-        __syncthreads(); // every wave is done with the window
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // this wave's accumulators are free again
+        __builtin_amdgcn_wave_barrier();
     }
 }
+
+// kind of K4 work and of per-packet coefficient for (operator, basis) -- one decision for the fused, the resolve and the
+// gather kernel
+static void pull_kinds(lsk_operator const &op, lsk_basis const &bs, int &k4m, int &coef) {
+    if (bs.k4_mode != 0) { k4m = K4_TRIVIAL; coef = !op.is_real ? COEF_CPLX : (op.uni ? COEF_UNI : COEF_REAL); }
+    else if (bs.chars_pm1) { k4m = K4_PM1; coef = op.is_real ? COEF_REAL : COEF_CPLX; }
+    else { k4m = K4_GENERAL; coef = COEF_CPLX; }
+}
+extern "C" int64_t lsk_pullbuf_cap(lsk_operator op) { return (int64_t)64 * (op.n_groups > 0 ? op.n_groups : 1); }
+extern "C" int lsk_pullbuf_coef_doubles(lsk_operator op, lsk_basis bs) {
+    int k4m, coef;
+    pull_kinds(op, bs, k4m, coef);
+    return coef == COEF_UNI ? 0 : (coef == COEF_REAL ? 1 : 2);
+}
+
+template <typename W, int K4M, int COEF, bool CPLX, int SINK>
+static void launch_pull_t(lsk_operator const &op, lsk_basis const &bs, int64_t row0, int64_t row1, uint64_t const *reps,
+                          double const *norms_local, lsk_pullidx ix, uint64_t const *reps_global, int64_t n_global, void const *xsrc,
+                          int halo, void *y, lsk_pullbuf buf, int *d_err, hipStream_t s) {
+    const int64_t work_blocks = (row1 - row0 + kBlock - 1) / kBlock;
+    dim3 g((unsigned)tile_grid(k_pull_t<W, K4M, COEF, CPLX, SINK>, work_blocks)), b(kBlock);
+    hipLaunchKernelGGL((k_pull_t<W, K4M, COEF, CPLX, SINK>), g, b, 0, s, op.runs, op.n_groups, op.groups, op.off, op.n_diag, op.diag, bs,
+                       bs.elems, row0, row1, reps, norms_local, ix, reps_global, n_global, (double const *)xsrc, halo, op.uni_v,
+                       (double *)y, buf, d_err);
+}
+template <typename W, bool CPLX, int SINK>
+static int dispatch_pull_t(lsk_operator const &op, lsk_basis const &bs, int64_t row0, int64_t row1, uint64_t const *reps,
+                           double const *norms_local, lsk_pullidx ix, uint64_t const *reps_global, int64_t n_global,
+                           void const *xsrc, int halo, void *y, lsk_pullbuf buf, int *d_err, hipStream_t s) {
+    int k4m, coef;
+    pull_kinds(op, bs, k4m, coef);
+#define LSK_PT(K4M, COEF) launch_pull_t<W, K4M, COEF, CPLX, SINK>(op, bs, row0, row1, reps, norms_local, ix, reps_global, n_global, xsrc, halo, y, buf, d_err, s)
+    if (coef == COEF_CPLX) {
+        if constexpr (!CPLX && SINK == SINK_FUSED) { snprintf(g_err, sizeof(g_err), "lsk_tile_pull: complex coefficients need c128 vectors"); return -1; }
+        else { if (k4m == K4_TRIVIAL) LSK_PT(K4_TRIVIAL, COEF_CPLX); else if (k4m == K4_PM1) LSK_PT(K4_PM1, COEF_CPLX); else LSK_PT(K4_GENERAL, COEF_CPLX); }
+    } else if (coef == COEF_REAL) { if (k4m == K4_TRIVIAL) LSK_PT(K4_TRIVIAL, COEF_REAL); else LSK_PT(K4_PM1, COEF_REAL); }
+    else LSK_PT(K4_TRIVIAL, COEF_UNI);
+#undef LSK_PT
+    return 0;
+}
+static int pull_args_ok(lsk_basis const &bs, int halo, uint64_t const *reps_global, int64_t n_global, char const *who) {
+    if (bs.proj != LSK_PROJ_FULL) { snprintf(g_err, sizeof(g_err), "%s is for projected bases", who); return -1; }
+    if (halo < 0 || kBlock + 2 * halo > kNwMaxWin || (halo > 0 && (!reps_global || n_global <= 0))) { snprintf(g_err, sizeof(g_err), "%s: bad near window", who); return -1; }
+    return 0;
+}
+extern "C" int lsk_pull_max_halo(void) { return (kNwMaxWin - kBlock) / 2; }
 
 extern "C" int lsk_tile_pull_idx(lsk_operator op, lsk_basis bs, int cplx, int64_t row0, int64_t row1, uint64_t const *reps,
                                  double const *norms_local, lsk_pullidx ix, uint64_t const *reps_global, int64_t n_global,
                                  void const *xsrc, int halo, void *y, int *d_err, void *stream) {
     if (row1 <= row0) return 0;
-    if (bs.proj != LSK_PROJ_FULL) { snprintf(g_err, sizeof(g_err), "lsk_tile_pull_idx is for projected bases"); return -1; }
-    if (halo < 0 || halo > kPullHalo || (halo > 0 && (!reps_global || n_global <= 0))) { snprintf(g_err, sizeof(g_err), "lsk_tile_pull_idx: bad near window"); return -1; }
-    dim3 g(1), b(kBlock);
-    const int64_t work_blocks = (row1 - row0 + kBlock - 1) / kBlock;
+    if (pull_args_ok(bs, halo, reps_global, n_global, "lsk_tile_pull_idx") != 0) return -1;
+    lsk_pullbuf none;
+    memset(&none, 0, sizeof(none));
     hipStream_t s = (hipStream_t)stream;
-#define LSK_TPI_ARGS op.runs, op.n_groups, op.groups, op.off, op.n_diag, op.diag, bs, bs.elems, row0, row1, reps, norms_local, ix, \
-        reps_global, n_global, (double const *)xsrc, halo, (double *)y, d_err
-    const size_t win_bytes = sizeof(uint32_t) * (size_t)(kBlock + 2 * halo);
-    // per-wave packet rings (k_tile_pull_wv) by default; LS_AMD_PULL_WAVE=0: the block-wide list (k_tile_pull_idx).  Measured in
-    // one job each: chain_36_symm 18.34 -> 18.13 ms, chain_40_symm 290.8 -> 275.0 ms (309.7 -> 283.5 on another box)
-    int wave_lists = 1;
-    { char const *e = getenv("LS_AMD_PULL_WAVE"); if (e) wave_lists = atoi(e); }
-#define LSK_TPW_LAUNCH(W, PM1)                                                                                  \
-    do {                                                                                                        \
-        if (cplx) {                                                                                             \
-            if (op.is_real) { g.x = tile_grid(k_tile_pull_wv<W, PM1, true, true>, work_blocks); hipLaunchKernelGGL((k_tile_pull_wv<W, PM1, true, true>), g, b, win_bytes, s, LSK_TPI_ARGS); } \
-            else { g.x = tile_grid(k_tile_pull_wv<W, PM1, true, false>, work_blocks); hipLaunchKernelGGL((k_tile_pull_wv<W, PM1, true, false>), g, b, win_bytes, s, LSK_TPI_ARGS); } \
-        } else {                                                                                                \
-            if (op.is_real) { g.x = tile_grid(k_tile_pull_wv<W, PM1, false, true>, work_blocks); hipLaunchKernelGGL((k_tile_pull_wv<W, PM1, false, true>), g, b, win_bytes, s, LSK_TPI_ARGS); } \
-            else { g.x = tile_grid(k_tile_pull_wv<W, PM1, false, false>, work_blocks); hipLaunchKernelGGL((k_tile_pull_wv<W, PM1, false, false>), g, b, win_bytes, s, LSK_TPI_ARGS); } \
-        }                                                                                                       \
-    } while (0)
-#define LSK_TPI_LAUNCH(W, PM1)                                                                                  \
-    do {                                                                                                        \
-        if (cplx) {                                                                                             \
-            if (op.is_real) { g.x = tile_grid(k_tile_pull_idx<W, PM1, true, true>, work_blocks); hipLaunchKernelGGL((k_tile_pull_idx<W, PM1, true, true>), g, b, win_bytes, s, LSK_TPI_ARGS); } \
-            else { g.x = tile_grid(k_tile_pull_idx<W, PM1, true, false>, work_blocks); hipLaunchKernelGGL((k_tile_pull_idx<W, PM1, true, false>), g, b, win_bytes, s, LSK_TPI_ARGS); } \
-        } else {                                                                                                \
-            if (op.is_real) { g.x = tile_grid(k_tile_pull_idx<W, PM1, false, true>, work_blocks); hipLaunchKernelGGL((k_tile_pull_idx<W, PM1, false, true>), g, b, win_bytes, s, LSK_TPI_ARGS); } \
-            else { g.x = tile_grid(k_tile_pull_idx<W, PM1, false, false>, work_blocks); hipLaunchKernelGGL((k_tile_pull_idx<W, PM1, false, false>), g, b, win_bytes, s, LSK_TPI_ARGS); } \
-        }                                                                                                       \
-    } while (0)
-    if (wave_lists) {
-        if (bs.number_sites <= 32) { if (bs.chars_pm1) LSK_TPW_LAUNCH(uint32_t, true); else LSK_TPW_LAUNCH(uint32_t, false); }
-        else { if (bs.chars_pm1) LSK_TPW_LAUNCH(uint64_t, true); else LSK_TPW_LAUNCH(uint64_t, false); }
-    } else if (bs.number_sites <= 32) { if (bs.chars_pm1) LSK_TPI_LAUNCH(uint32_t, true); else LSK_TPI_LAUNCH(uint32_t, false); }
-    else { if (bs.chars_pm1) LSK_TPI_LAUNCH(uint64_t, true); else LSK_TPI_LAUNCH(uint64_t, false); }
-#undef LSK_TPW_LAUNCH
-#undef LSK_TPI_LAUNCH
-#undef LSK_TPI_ARGS
+    int rc;
+#define LSK_PA op, bs, row0, row1, reps, norms_local, ix, reps_global, n_global, xsrc, halo, y, none, d_err, s
+    if (bs.number_sites <= 32) rc = cplx ? dispatch_pull_t<uint32_t, true, SINK_FUSED>(LSK_PA) : dispatch_pull_t<uint32_t, false, SINK_FUSED>(LSK_PA);
+    else rc = cplx ? dispatch_pull_t<uint64_t, true, SINK_FUSED>(LSK_PA) : dispatch_pull_t<uint64_t, false, SINK_FUSED>(LSK_PA);
+#undef LSK_PA
+    if (rc != 0) return -1;
     LSK_LAUNCH_CHECK();
     return 0;
 }
+// first half of the split matvec: rows [row0, row1) -> packet stream in `buf` (buf.row0 = the row that owns stream 0; a
+// multiple of 64 rows below row0).  Reads neither x nor y.
+extern "C" int lsk_tile_pull_resolve(lsk_operator op, lsk_basis bs, int64_t row0, int64_t row1, uint64_t const *reps,
+                                     double const *norms_local, lsk_pullidx ix, uint64_t const *reps_global, int64_t n_global,
+                                     int halo, lsk_pullbuf buf, int *d_err, void *stream) {
+    if (row1 <= row0) return 0;
+    if (pull_args_ok(bs, halo, reps_global, n_global, "lsk_tile_pull_resolve") != 0) return -1;
+    if (!buf.slots || !buf.rows || !buf.counts || buf.cap < lsk_pullbuf_cap(op) || ((row0 - buf.row0) & 255) != 0 || row0 < buf.row0 ||
+        (lsk_pullbuf_coef_doubles(op, bs) > 0 && !buf.coefs)) { snprintf(g_err, sizeof(g_err), "lsk_tile_pull_resolve: bad packet buffer"); return -1; }
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+#define LSK_PA op, bs, row0, row1, reps, norms_local, ix, reps_global, n_global, nullptr, halo, nullptr, buf, d_err, s
+    if (bs.number_sites <= 32) rc = dispatch_pull_t<uint32_t, false, SINK_RESOLVE>(LSK_PA);
+    else rc = dispatch_pull_t<uint64_t, false, SINK_RESOLVE>(LSK_PA);
+#undef LSK_PA
+    if (rc != 0) return -1;
+    LSK_LAUNCH_CHECK();
+    return 0;
+}
+// second half: y[row0, row1) from the packet stream and xsrc
+extern "C" int lsk_tile_pull_gather(lsk_operator op, lsk_basis bs, int cplx, int64_t row0, int64_t row1, uint64_t const *reps,
+                                    double const *norms_local, lsk_pullidx ix, void const *xsrc, lsk_pullbuf buf, void *y,
+                                    void *stream) {
+    if (row1 <= row0) return 0;
+    int k4m, coef;
+    pull_kinds(op, bs, k4m, coef);
+    if (coef == COEF_CPLX && !cplx) { snprintf(g_err, sizeof(g_err), "lsk_tile_pull_gather: complex coefficients need c128 vectors"); return -1; }
+    const int64_t work_blocks = (row1 - row0 + kBlock - 1) / kBlock;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 g(1), b(kBlock);
+#define LSK_PG(COEF, CPLX)                                                                                              \
+    do {                                                                                                                \
+        g.x = (unsigned)tile_grid(k_pull_gather<COEF, CPLX>, work_blocks);                                              \
+        hipLaunchKernelGGL((k_pull_gather<COEF, CPLX>), g, b, 0, s, op.runs, op.n_diag, op.diag, bs.k4_mode, row0, row1, reps, \
+                           norms_local, ix, (double const *)xsrc, op.uni_v, (double *)y, buf);                          \
+    } while (0)
+    if (coef == COEF_CPLX) LSK_PG(COEF_CPLX, true);
+    else if (coef == COEF_REAL) { if (cplx) LSK_PG(COEF_REAL, true); else LSK_PG(COEF_REAL, false); }
+    else { if (cplx) LSK_PG(COEF_UNI, true); else LSK_PG(COEF_UNI, false); }
+#undef LSK_PG
+    LSK_LAUNCH_CHECK();
+    return 0;
+}
+
 
 // ---------------------------------------------------------------------------------------------
 // Consumer side (K7 + K8): received packets -> local index -> atomic add

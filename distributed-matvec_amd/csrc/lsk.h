@@ -50,6 +50,8 @@ typedef struct lsk_runs {
 
 typedef struct lsk_operator {
     int n_diag, n_off, n_groups, is_real;
+    int uni;      /* every off-diagonal group is an exchange pair (LSK_GROUP_EXCHANGE) with ONE real amplitude uni_v: the projected */
+    double uni_v; /* pull kernels then keep no coefficient per packet */
     lsk_term const *diag;    /* device [n_diag]; zz-run terms first */
     lsk_term const *off;     /* device [n_off], sorted by group */
     lsk_group const *groups; /* device [n_groups]; exchange-run groups first */
@@ -148,73 +150,6 @@ int lsk_chain_tile_rows(int cplx);
 int lsk_chain(lsk_operator op, lsk_basis bs, lsk_index ix, int cplx, int wide_ranks, int fused_records, lsk_tilemap tm,
               int64_t n, uint64_t const *reps, int64_t row0, int64_t n_x, void const *x, void *y, int n_cached,
               void const *cache, double cv0, double cv1, void *stream);
-/* ---- block-aligned row kernel with sibling tiles (k_chain_sib): the Heisenberg-ring shape on <= 32 sites ------------------
- * A state of the full fixed-weight basis is T | mid | Lw: Lw = the low `nl` bits, T = the top `t` bits, mid the rest.  In the
- * ascending (combinadic) order all Lw of one weight kL under fixed (T, mid) are CONTIGUOUS rows -- a block of C(nl, kL)
- * rows -- and rank = rtr[jT][T] + base_rest(mid, kL) + rankL(Lw), jT = popcount(T), kL = weight - jT - popcount(mid).
- *   - exchanges inside Lw (pairs lo < nl - 1) stay inside the block: LDS reads with NO halo;
- *   - exchanges inside T (pairs >= L - t) map a block onto the block of a SIBLING T' of the same weight at the same
- *     offset: a work unit = (mid, jT) holds the blocks of all C(t, jT) siblings in LDS, so those pairs are LDS reads too
- *     and every x element of the unit is fetched from HBM once for all of them (the far pairs are what the staged
- *     kernel re-reads from HBM: 27 of its 53 GB on chain_32);
- *   - everything else (the pair that straddles Lw | mid per lane, the pairs inside mid and the one that straddles
- *     mid | T wave-uniformly, the ring-closing pair through rankL) gathers from global memory;
- *   - the state is reconstructed (unrankL), the ring partner's rank computed (rankL): no per-row plan data is streamed,
- *     compulsory traffic = x + y = 2 w bytes per row. */
-typedef struct lsk_sib_unit {
-    uint32_t base_rest; /* rank contribution of the mid bits with kL set bits below them */
-    uint32_t mid;       /* the mid bits in place (mid << nl) */
-    uint32_t ring_up;   /* the same contribution with kL + 1 bits below: rows whose top bit moves to bit 0 */
-    uint32_t ring_dn;   /* ... with kL - 1 bits below: rows whose bit 0 moves to the top */
-    uint32_t kL_jT;     /* kL | jT << 8 */
-} lsk_sib_unit;
-#define LSK_SIB_MAX_T 6
-#define LSK_SIB_MAX_S 20 /* C(6, 3) */
-/* launch record: everything block b needs to start, in ONE 256-byte read (record b <-> block b: the host writes the
- * records in XCD-interleaved order, so there is no order list to chase); nS == 0: empty slot */
-typedef struct lsk_sib_rec {
-    uint32_t mid, uoff;   /* the mid bits in place; start of the unit's weight class in unrankL */
-    uint16_t nL, nS;      /* rows per block, siblings */
-    uint8_t kL, jT, pad0[2];
-    uint32_t base[LSK_SIB_MAX_S]; /* rank of row 0 of sibling s */
-    uint32_t ring[LSK_SIB_MAX_S]; /* rank of row 0 of the block that holds the ring partners of sibling s */
-    uint8_t T[LSK_SIB_MAX_S];     /* top bits of sibling s */
-    uint8_t pad1[60];
-} lsk_sib_rec;
-typedef struct lsk_sibtab { /* small tables, read through a device pointer */
-    uint32_t uoff[34];            /* class kL occupies unrankL[uoff[kL], uoff[kL + 1]) */
-    uint32_t nsib[LSK_SIB_MAX_T + 1];              /* C(t, jT) */
-    uint32_t rtr[LSK_SIB_MAX_T + 1][LSK_SIB_MAX_S];  /* [jT][s] -> rank contribution of the bits of T (hw - jT bits below) */
-    uint8_t tlist[LSK_SIB_MAX_T + 1][LSK_SIB_MAX_S]; /* [jT][s] -> T */
-    uint8_t sidx[1 << LSK_SIB_MAX_T];              /* T -> its number among the t-bit words of the same weight */
-} lsk_sibtab;
-typedef struct lsk_sibplan {
-    int L, hw, nl, t;
-    int max_rows;                 /* largest unit: siblings * block rows (sizes the LDS window) */
-    int max_block;                /* largest block: C(nl, nl / 2) rows */
-    int64_t n_units, slots_per_xcd;
-    lsk_sib_unit const *units;    /* device [n_units] */
-    uint32_t const *order;        /* device [8 * slots_per_xcd]: per-XCD lists of unit numbers, 0xffffffff = empty slot */
-    uint16_t const *unrankL;      /* device [2^nl]: the nl-bit words grouped by weight, ascending inside a weight */
-    uint16_t const *rankL;        /* device [2^nl]: position of a word inside its weight class */
-    lsk_sibtab const *tab;        /* device */
-    lsk_sib_rec const *recs;      /* device [n_recs] = [8 * slots_per_xcd], launch order: record b belongs to block b */
-    int64_t n_recs;
-} lsk_sibplan;
-/* expands units + order (host arrays of lsk_sibplan_host) into the launch records (malloc'ed; sets sp->n_recs): block b runs on
- * XCD b % 8 and gets entry b / 8 of that XCD's list */
-lsk_sib_rec *lsk_sibrecs_host(lsk_sibplan *sp, lsk_sibtab const *tab, lsk_sib_unit const *units, uint32_t const *order);
-/* host-side construction of the tables above (plain malloc'ed arrays in *units / *order / *unrank / *rank); chunk = units per
- * round-robin chunk of the XCD lists.  Returns 0, or -1 when the shape is not admissible (ranks beyond 32 bits, ...). */
-int lsk_sibplan_host(lsk_sibplan *sp, lsk_sibtab *tab, int L, int hw, int nl, int t, int64_t chunk, lsk_sib_unit **units,
-                     uint32_t **order, uint16_t **unrank, uint16_t **rank);
-/* y = H x for the ring / open chain: one exchange run over all adjacent pairs (amplitude v), the ring-closing pair (0, L - 1)
- * with amplitude cv (ring == 0: none), the diagonal through op.runs / op.diag.  x, y: n = C(L, hw) f64 elements. */
-int lsk_chain_sib(lsk_operator op, lsk_sibplan sp, uint64_t const *g_binom, int ring, double cv, void const *x, void *y,
-                  void *stream);
-/* bytes of LDS one block of k_chain_sib needs for a plan with `max_rows` (the host checks it against the 160 KB of a CU) */
-int64_t lsk_chain_sib_lds_bytes(int max_rows, int max_block);
-
 /* fused_records != 0 (32-bit states and ranks): `reps` is out[] of lsk_chain_pack -- state | partner rank of the first
  * cached pair << 32 (cache == NULL: no cached pair) -- and `cache` only holds a second cached pair at cache + n */
 int lsk_chain_pack(int64_t n, uint64_t const *reps, void const *cache, uint64_t *out, void *stream);
@@ -283,6 +218,26 @@ typedef struct lsk_pullidx {
 int lsk_tile_pull_idx(lsk_operator op, lsk_basis bs, int cplx, int64_t row0, int64_t row1, uint64_t const *reps,
                       double const *norms_local, lsk_pullidx ix, uint64_t const *reps_global, int64_t n_global,
                       void const *xsrc, int halo, void *y, int *d_err, void *stream);
+int lsk_pull_max_halo(void); /* largest near window (entries either side of a tile) the LDS hash set of the kernels takes */
+/* The same matvec in TWO kernels, for the replicated-x exchange (dist.c): RESOLVE = stage A + K4 + slot look-ups, everything
+ * that does not need x, writes one 4-byte slot per packet (+ its row inside the wave, + its coefficient unless the operator
+ * has one real amplitude) to a per-wave packet stream; GATHER streams that, reads xsrc[slot] and writes y.  RESOLVE runs
+ * while the blocks of x are on the wire.  Stream w belongs to rows [row0 + 64 w, row0 + 64 w + 64): `cap` packets of room
+ * each (lsk_pullbuf_cap: 64 x number of flip-mask groups, the most 64 rows can generate), counts[w] of them valid. */
+typedef struct lsk_pullbuf {
+    uint32_t *slots;  /* device [streams * cap]; 0xffffffff = dead packet (zero-norm orbit) */
+    uint8_t *rows;    /* device [streams * cap] */
+    double *coefs;    /* device [streams * cap * lsk_pullbuf_coef_doubles] or NULL */
+    uint32_t *counts; /* device [streams] */
+    int64_t cap, row0;
+} lsk_pullbuf;
+int64_t lsk_pullbuf_cap(lsk_operator op);
+int lsk_pullbuf_coef_doubles(lsk_operator op, lsk_basis bs);
+int lsk_tile_pull_resolve(lsk_operator op, lsk_basis bs, int64_t row0, int64_t row1, uint64_t const *reps,
+                          double const *norms_local, lsk_pullidx ix, uint64_t const *reps_global, int64_t n_global, int halo,
+                          lsk_pullbuf buf, int *d_err, void *stream);
+int lsk_tile_pull_gather(lsk_operator op, lsk_basis bs, int cplx, int64_t row0, int64_t row1, uint64_t const *reps,
+                         double const *norms_local, lsk_pullidx ix, void const *xsrc, lsk_pullbuf buf, void *y, void *stream);
 /* out[i] = x[i] * norms[i] (f64 / c128): the owner-side prescaling of the indexed mode */
 int lsk_scale(int cplx, int64_t n, void const *x, double const *norms, void *out, void *stream);
 /* dst[perm[g] - base] = src[g] for every g with base <= perm[g] < base + count (8-byte elements): the rows one owner holds,
@@ -290,9 +245,12 @@ int lsk_scale(int cplx, int64_t n, void const *x, double const *norms, void *out
 int lsk_scatter_owned(int64_t n, uint32_t const *perm, int64_t base, int64_t count, uint64_t const *src, uint64_t *dst,
                       void *stream);
 
-/* host-side check of the window search (tests, no device): position of `key` among the ascending reps[0, n), n <= 1280,
- * or -1 -- exactly what a tile resolves in LDS */
+/* host-side check of the window search of the value-table kernel (tests, no device): position of `key` among the ascending
+ * reps[0, n), n <= 1280, or -1 */
 int lsk_test_window_find(uint64_t const *reps, int n, uint64_t key);
+/* ... and of the LDS hash set of the indexed kernels (n <= 1024): position, or -1 when the window does not answer (absent,
+ * or dropped from a full set -- such a partner goes through the static index table) */
+int lsk_test_nw_find(uint64_t const *reps, int n, uint64_t key);
 int lsk_test_chain_near_table(int elem, int ldsp, int16_t *out);
 uint64_t lsk_test_rep_trivial_dihedral(uint64_t a, int L, int inv, int reflect);
 int lsk_bench_k4(int L, int inv, int reflect, int variant, int64_t n, uint64_t const *reps, uint64_t *out, void *stream);

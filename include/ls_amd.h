@@ -277,6 +277,10 @@ void ls_amd_test_free(void *p);
  * `key` among the ascending reps[0, n) (n <= 1280, stored as saturating 32-bit offsets from reps[0] exactly as a tile
  * stores them in LDS), -1 if it is not there or not representable (then the kernel takes the hash table), -2 on bad n */
 int ls_amd_test_window_find(uint64_t const *reps, int n, uint64_t key);
+/* ... and the near window of the INDEXED kernels (k_pull_t), a two-way hash set in LDS over the same offsets (n <= 1024): the
+ * position of `key`, or -1 when the window does not answer -- the key is absent, or its set was already full when it was
+ * staged (the kernel then takes the static index table, which holds every representative); never a wrong position */
+int ls_amd_test_nw_find(uint64_t const *reps, int n, uint64_t key);
 /* Host-only test hook: the near-pair table of the staged row kernel (distributed-matvec_amd/csrc/kernels.hip: chain_lds_image) for
  * vectors of `elem` bytes per entry and `ldsp` pairs served from the LDS window: 480 entries of four int16 into `out`. */
 int ls_amd_test_chain_near_table(int elem, int ldsp, int16_t *out);
@@ -292,14 +296,6 @@ int ls_amd_bench_k4(int L, int inv, int reflect, int variant, int64_t n, uint64_
 int ls_amd_test_gtab_bits(int L, int64_t n);
 int ls_amd_test_gtab_build(int L, int bbits, int64_t n, uint64_t const *reps, uint32_t const *payload, uint64_t **entries);
 int64_t ls_amd_test_gtab_find(int L, int bbits, uint64_t const *entries, uint64_t key);
-/* Host-only test hook: the plan of the block-aligned sibling-tile row kernel (distributed-matvec_amd/csrc/lsk.h: lsk_sibplan)
- * for the full basis of `hw` set bits on L <= 32 sites split into T (top t bits) | mid | Lw (low nl bits).  Returns the
- * number of work units (< 0: shape not admissible) and malloc'ed arrays: the lsk_sibplan struct itself, its small tables (lsk_sibtab), the units
- * (5 x uint32 each), the 8 XCD lists of unit numbers, unrankL / rankL of the nl-bit words (release each with
- * ls_amd_test_free; the plan struct, whose `recs` are the 256-byte launch records, with ls_amd_test_sibplan_free). */
-int64_t ls_amd_test_sibplan(int L, int hw, int nl, int t, int64_t chunk, void **plan_struct, void **tables, void **units,
-                            uint32_t **order, uint16_t **unrank, uint16_t **rank);
-void ls_amd_test_sibplan_free(void *plan_struct); /* the struct of ls_amd_test_sibplan and its launch records */
 /* byte offsets of commInfo / globalSumReal_type inside primme_params as the PRIMME callbacks read them (ls_chpl.h) */
 int ls_amd_test_primme_comminfo_offset(void);
 int ls_amd_test_primme_sumtype_offset(void);

@@ -21,8 +21,7 @@ ap.add_argument("--dtype", default="f64")
 ap.add_argument("--configs", default="")
 args = ap.parse_args()
 
-KEYS = ("LS_AMD_TILE_CHUNK", "LS_AMD_BLOCKS_PER_CU", "LS_AMD_HIGH_PAIR", "LS_AMD_CHAIN_MAXLO", "LS_AMD_CHAIN_FULLGRID",
-        "LS_AMD_CHAIN_REC", "LS_AMD_CHAIN", "LS_AMD_SIB", "LS_AMD_SIB_NL", "LS_AMD_SIB_T", "LS_AMD_SIB_CHUNK", "LS_AMD_SIB_THREADS", "LS_AMD_SIB_L2SETS", "LS_AMD_SIB_ABLATE")
+KEYS = ("LS_AMD_TILE_CHUNK", "LS_AMD_HIGH_PAIR", "LS_AMD_CHAIN", "LS_AMD_TILE_SETS", "LS_AMD_CHAIN_NT", "LS_AMD_CHAIN_TILE")
 # the first configuration of a process runs 5-9 % faster than the later ones (clock / power state): compare variants in
 # separate processes (--configs ";" = one default run), or read the trailing {} against the leading one
 DEFAULT_CONFIGS = [

@@ -13,7 +13,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-DEVICE_KERNEL = {"sibling": "k_chain_sib", "staged": "k_chain_t", "indexed": "k_tile_pull_idx", "tile-pull": "k_tile_pull<", "direct-push": "k_direct",
+DEVICE_KERNEL = {"staged": "k_chain_t", "indexed": "k_pull_t", "tile-pull": "k_tile_pull<", "direct-push": "k_direct",
                  "direct-pull": "k_direct", "tile": "k_tile<"}
 SEEN = []  # kernel names the counters were read from
 
@@ -37,8 +37,6 @@ def main():
     from bench import kernel_instance_sha, kernel_isa_sha, source_sha
 
     needle = next(v for k, v in DEVICE_KERNEL.items() if k in kname)
-    if needle == "k_tile_pull_idx" and os.environ.get("LS_AMD_PULL_WAVE", "1") != "0":
-        needle = "k_tile_pull_wv"  # the default indexed kernel since late round 3 (per-wave packet rings)
     fetch, nf = mean_counter(root, "pmc_fetch", "FETCH_SIZE", needle)
     write, nw = mean_counter(root, "pmc_write", "WRITE_SIZE", needle)
     valu, nv = mean_counter(root, "pmc_valu", "SQ_INSTS_VALU", needle)

@@ -89,13 +89,22 @@ def test_ranks_as_threads(name, P, cplx, mode):
         c.destroy()
 
 
-@pytest.mark.parametrize("indexed", ["1", "0"])
+@pytest.mark.parametrize("indexed", ["1", "0", "fused", "part"])
 @pytest.mark.parametrize("case", ["heisenberg_chain_24_symm/4/f64", "heisenberg_chain_24_symm/3/c128", "issue_01/2/f64",
                                   "heisenberg_kagome_12_symm/8/f64", "translation_12_5/3/c128"])
 def test_replicated_exchange_indexed_and_value_table(monkeypatch, case, indexed):
     """ls_amd_repl_matvec on projected bases, both ways of reading x: INDEXED (default: static {rep -> slot} table, x stays
     in the owner-major order it arrives in, owners prescale -- no per-rank O(N) pass) and the value table + permutation pass
-    (LS_AMD_REPL_INDEXED=0), against the oracle; trivial sectors (prescaled), a -1 character and complex characters."""
+    (LS_AMD_REPL_INDEXED=0), against the oracle; trivial sectors (prescaled), a -1 character and complex characters.
+    The indexed mode runs as resolve (on the compute stream, while the blocks of x are exchanged on the communicator's
+    stream) + gather by default; "fused": one kernel after the exchange (LS_AMD_PULL_SPLIT=0); "part": a packet buffer that
+    only holds the first rows -- the others take the fused kernel."""
+    if indexed == "fused":
+        monkeypatch.setenv("LS_AMD_PULL_SPLIT", "0")
+        indexed = "1"
+    elif indexed == "part":
+        monkeypatch.setenv("LS_AMD_PULL_SPLIT", "70000")
+        indexed = "1"
     import torch
 
     import distributed_matvec_amd as D

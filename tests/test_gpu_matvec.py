@@ -186,15 +186,16 @@ PROJECTED_MODELS = ["heisenberg_chain_24_symm", "heisenberg_kagome_12_symm", "is
 
 
 @pytest.mark.parametrize("name", PROJECTED_MODELS)
-@pytest.mark.parametrize("halo,wave", [("512", "1"), ("0", "1"), ("37", "1"), ("512", "0"), ("37", "0")])
-def test_indexed_pull_mode_single_locale(torch, monkeypatch, name, halo, wave):
+@pytest.mark.parametrize("halo,split", [("256", "0"), ("0", "0"), ("37", "0"), ("384", "0"), ("256", "1000000000"), ("37", "300000"), ("0", "90000")])
+def test_indexed_pull_mode_single_locale(torch, monkeypatch, name, halo, split):
     """the INDEXED mode of the projected-basis pull kernel (static {rep -> index} table, x read through the index; no
-    per-matvec table refresh) == the oracle, f64 and c128, with the near window on, off and at an odd size, through both of
-    its device kernels (per-wave packet rings = the default, and the block-wide list); the trivial
-    sectors prescale x by norm(rep), issue_01 (character -1) does not"""
+    per-matvec table refresh) == the oracle, f64 and c128, with the near window (an LDS hash set) on, off and at an odd
+    size, as ONE kernel (the default on one device) and as the resolve | gather pair the replicated-x exchange overlaps
+    with its all-gather (LS_AMD_PULL_SPLIT = bytes of packet buffer: every row in one round, or many rounds); the
+    trivial sectors prescale x by norm(rep) and carry no coefficient per packet, issue_01 (character -1) does neither"""
     monkeypatch.setenv("LS_AMD_PULL_INDEXED", "1")
     monkeypatch.setenv("LS_AMD_PULL_HALO", halo)
-    monkeypatch.setenv("LS_AMD_PULL_WAVE", wave)
+    monkeypatch.setenv("LS_AMD_PULL_SPLIT", split)
     D, basis, h, reps, masks = setup_model(torch, model_config(name), 1)
     want_reps = oracle_reps(name)
     rs = np.random.RandomState(52)
@@ -212,11 +213,13 @@ def test_indexed_pull_mode_single_locale(torch, monkeypatch, name, halo, wave):
 
 
 @pytest.mark.parametrize("L,sector", [(8, 1), (12, 5)])
-def test_indexed_pull_mode_complex_characters(torch, monkeypatch, L, sector):
+@pytest.mark.parametrize("split", ["0", "200000"])
+def test_indexed_pull_mode_complex_characters(torch, monkeypatch, L, sector, split):
     from oracle import c_oracle as CO
     from oracle import model as M
 
     monkeypatch.setenv("LS_AMD_PULL_INDEXED", "1")
+    monkeypatch.setenv("LS_AMD_PULL_SPLIT", split)
     cfg = complex_translation_config(L, sector)
     o = CO.COracle(M.model_from_config(cfg))
     want_reps = o.enumerate()
@@ -754,13 +757,6 @@ ROW_KERNEL_VARIANTS = {
     "staged-uniform-from-13": {"LS_AMD_HIGH_PAIR": "13"},
     "staged-no-uniform": {"LS_AMD_HIGH_PAIR": "0"},
     "contiguous-tiles": {"LS_AMD_TILE_CHUNK": "0"},
-    # block-aligned kernel with sibling tiles (opt-in): the default split T | mid | Lw and others, other XCD dealings, block sizes
-    "sibling": {"LS_AMD_SIB": "1"},
-    "sibling-nl5-t3": {"LS_AMD_SIB": "1", "LS_AMD_SIB_NL": "5", "LS_AMD_SIB_T": "3", "LS_AMD_SIB_CHUNK": "1"},
-    "sibling-nl9-t5": {"LS_AMD_SIB": "1", "LS_AMD_SIB_NL": "9", "LS_AMD_SIB_T": "5", "LS_AMD_SIB_CHUNK": "5", "LS_AMD_SIB_THREADS": "256"},
-    "sibling-nl7-t6": {"LS_AMD_SIB": "1", "LS_AMD_SIB_NL": "7", "LS_AMD_SIB_T": "6", "LS_AMD_SIB_THREADS": "1024"},
-    "sibling-nl10-t1": {"LS_AMD_SIB": "1", "LS_AMD_SIB_NL": "10", "LS_AMD_SIB_T": "1", "LS_AMD_SIB_CHUNK": "1000"},
-    "sibling-no-mid": {"LS_AMD_SIB": "1", "LS_AMD_SIB_NL": "8", "LS_AMD_SIB_T": "6"},  # L = 14: T | Lw with no bits between them
     "chunked-tiles-generic": {"LS_AMD_CHAIN": "0", "LS_AMD_TILE_CHUNK": "3"},
 }
 
@@ -795,9 +791,6 @@ def test_row_kernel_variants(torch, monkeypatch, variant):
         got, pl = run_matvec(torch, D, h, reps, masks, x, 1, "pull")
         seen.add(pl.kernel)
         assert np.abs(got - want).max() <= 1e-12 * max(1.0, np.abs(want).max()), (variant, L, kind, pl.kernel)
-        if variant.startswith("sibling"):
-            # f64 vectors, one exchange run over all adjacent pairs (+ the ring-closing pair): the block-aligned kernel
-            assert pl.kernel == ("direct-pull" if kind == "j1j2" else "direct-pull+sibling"), (kind, pl.kernel)
         if variant == "default" or variant.startswith("staged") or variant == "contiguous-tiles":
             assert pl.kernel == ("direct-pull" if kind == "j1j2" else "direct-pull+staged"), (kind, pl.kernel)
         # c128 vectors: the complex instantiation of the same kernel family

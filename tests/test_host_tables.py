@@ -468,6 +468,43 @@ def test_near_window_search_of_the_pull_kernel():
     assert find(reps[:1], base) == 0 and find(np.arange(1281, dtype=np.uint64), 3) == -2
 
 
+@pytest.mark.parametrize("name", ["heisenberg_chain_24_symm", "heisenberg_chain_16", "heisenberg_square_4x4"])
+def test_near_window_hash_set_of_the_indexed_pull_kernels(name):
+    """k_pull_t stages the tile's neighbourhood of the sorted representatives as a two-way hash set in LDS (nw_* in
+    kernels.hip, compiled for the host too).  It may DROP an entry (full set: the partner then goes through the static index
+    table), it must never answer with a wrong position or answer for a state that is not in the window; on real windows of
+    768 consecutive representatives it answers for >= 93 % of them."""
+    from helpers import oracle_reps
+
+    lib = _lib.load()
+    reps = np.ascontiguousarray(oracle_reps(name), dtype=np.uint64)
+    rng = np.random.RandomState(11)
+
+    def find(win, key):
+        return lib.ls_amd_test_nw_find(win.ctypes.data_as(C.POINTER(C.c_uint64)), len(win), C.c_uint64(int(key)))
+
+    answered = total = 0
+    for start in [0, max(0, len(reps) - 768), *rng.randint(0, max(1, len(reps) - 768), size=6).tolist()]:
+        win = np.ascontiguousarray(reps[start:start + 768])
+        n = len(win)
+        for pos in range(n):
+            got = find(win, win[pos])
+            assert got in (pos, -1), (start, pos, got)
+            answered += got == pos
+            total += 1
+        present = set(win.tolist())
+        for key in [int(win[0]) - 1, int(win[-1]) + 1, *[int(k) + 1 for k in win[rng.randint(0, n, size=64)]],
+                    *[int(k) ^ 6 for k in win[rng.randint(0, n, size=64)]]]:
+            if key not in present and 0 <= key < (1 << 64):
+                assert find(win, key) == -1, (start, key)
+    assert answered >= 0.93 * total, (answered, total)
+    assert find(np.arange(1025, dtype=np.uint64), 3) == -2
+    # offsets beyond 32 bits are never staged
+    base = 5 << 33
+    win = np.array([base, base + 7, base + (1 << 32) - 2, base + (1 << 32) - 1, base + (1 << 40)], dtype=np.uint64)
+    assert [find(win, k) for k in win] == [0, 1, 2, -1, -1]
+
+
 @pytest.mark.parametrize("name", ["heisenberg_chain_24_symm", "heisenberg_chain_16", "heisenberg_kagome_12_symm"])
 def test_static_index_table_finds_every_representative(name):
     """lsk_gtab (indexed pull mode): the key is not stored -- bucket and tag come from an L-bit bijection -- so the test is
@@ -511,109 +548,6 @@ def test_static_index_table_shapes():
     assert lib.ls_amd_test_gtab_bits(64, 1000) == -1  # ... and does not beyond 1 TiB: those plans keep the value table
     assert lib.ls_amd_test_gtab_bits(64, 1 << 41) == -1
     assert lib.ls_amd_test_gtab_bits(10, 13) >= 3
-
-
-class _SibPlan(C.Structure):  # lsk_sibplan (csrc/lsk.h)
-    _fields_ = [("L", C.c_int), ("hw", C.c_int), ("nl", C.c_int), ("t", C.c_int), ("max_rows", C.c_int), ("max_block", C.c_int),
-                ("n_units", C.c_int64), ("slots_per_xcd", C.c_int64), ("units", C.c_void_p), ("order", C.c_void_p),
-                ("unrankL", C.c_void_p), ("rankL", C.c_void_p), ("tab", C.c_void_p), ("recs", C.c_void_p), ("n_recs", C.c_int64)]
-
-
-class _SibRec(C.Structure):  # lsk_sib_rec: 256 bytes
-    _fields_ = [("mid", C.c_uint32), ("uoff", C.c_uint32), ("nL", C.c_uint16), ("nS", C.c_uint16), ("kL", C.c_uint8), ("jT", C.c_uint8),
-                ("pad0", C.c_uint8 * 2), ("base", C.c_uint32 * 20), ("ring", C.c_uint32 * 20), ("T", C.c_uint8 * 20), ("pad1", C.c_uint8 * 60)]
-
-
-class _SibTab(C.Structure):  # lsk_sibtab
-    _fields_ = [("uoff", C.c_uint32 * 34), ("nsib", C.c_uint32 * 7), ("rtr", (C.c_uint32 * 20) * 7),
-                ("tlist", (C.c_uint8 * 20) * 7), ("sidx", C.c_uint8 * 64)]
-
-
-@pytest.mark.parametrize("L,hw,nl,t,chunk", [(12, 6, 5, 3, 4), (16, 8, 6, 4, 7), (16, 5, 7, 5, 1), (20, 10, 8, 5, 16), (14, 7, 4, 6, 3)])
-def test_sibling_tile_plan_tiles_the_basis(L, hw, nl, t, chunk):
-    """lsk_sibplan: state = T | mid | Lw.  Every state of the full fixed-weight basis belongs to exactly one (unit, sibling,
-    row); its combinadic rank is rtr[jT][T] + base_rest + rankL[Lw]; the rows of one block are contiguous and ascending in
-    Lw; the ring-closing partner's rank follows from ring_up / ring_dn; the XCD lists hold every unit once."""
-    import math
-
-    lib = _lib.load()
-    ps, pt, pu = C.c_void_p(), C.c_void_p(), C.c_void_p()
-    po, pun, prk = C.POINTER(C.c_uint32)(), C.POINTER(C.c_uint16)(), C.POINTER(C.c_uint16)()
-    n_units = lib.ls_amd_test_sibplan(L, hw, nl, t, chunk, C.byref(ps), C.byref(pt), C.byref(pu), C.byref(po), C.byref(pun), C.byref(prk))
-    assert n_units > 0
-    try:
-        sp = _SibPlan.from_address(ps.value)
-        tb = _SibTab.from_address(pt.value)
-        assert [tb.nsib[j] for j in range(t + 1)] == [math.comb(t, j) for j in range(t + 1)]
-        units = np.ctypeslib.as_array(C.cast(pu, C.POINTER(C.c_uint32)), shape=(n_units, 5)).copy()
-        order = np.ctypeslib.as_array(po, shape=(8 * sp.slots_per_xcd,)).copy()
-        unrank = np.ctypeslib.as_array(pun, shape=(1 << nl,)).copy()
-        rankl = np.ctypeslib.as_array(prk, shape=(1 << nl,)).copy()
-        assert (sp.L, sp.hw, sp.nl, sp.t) == (L, hw, nl, t)
-        live = order[order != 0xFFFFFFFF]
-        assert sorted(live.tolist()) == list(range(n_units))
-        for k in range(8):  # chunked dealing: list k holds the chunks k, k + 8, ...
-            lst = order[k * sp.slots_per_xcd:(k + 1) * sp.slots_per_xcd]
-            lst = lst[lst != 0xFFFFFFFF]
-            assert all(((int(u) // chunk) % 8) == k for u in lst) and np.all(np.diff(lst.astype(np.int64)) > 0)
-        states = _fixed_weight_states(L, hw)
-        rank_of = {int(a): i for i, a in enumerate(states)}
-        unit_of = {(int(u[1]), int(u[4]) >> 8): i for i, u in enumerate(units)}
-        assert len(unit_of) == n_units
-        lmask, tshift = (1 << nl) - 1, L - t
-        seen = np.zeros(len(states), dtype=np.int32)
-        for a in states.tolist():
-            T, lw = a >> tshift, a & lmask
-            mid_in_place = a & (((1 << tshift) - 1) & ~lmask)
-            jT, kL = bin(T).count("1"), bin(lw).count("1")
-            u = units[unit_of[(mid_in_place, jT)]]
-            assert int(u[4]) & 0xFF == kL
-            s_ = tb.sidx[T]
-            assert tb.tlist[jT][s_] == T
-            r = int(rankl[lw])
-            assert int(unrank[tb.uoff[kL] + r]) == lw and tb.uoff[kL + 1] - tb.uoff[kL] == math.comb(nl, kL)
-            rk = tb.rtr[jT][s_] + int(u[0]) + r
-            assert rk == rank_of[a]
-            seen[rk] += 1
-            # ring-closing pair (0, L - 1): partner T' = T ^ top, Lw' = Lw ^ 1, same mid
-            top = (a >> (L - 1)) & 1
-            if top != (a & 1):
-                b = a ^ (1 | (1 << (L - 1)))
-                T2, lw2 = b >> tshift, b & lmask
-                rest = int(u[2]) if top else int(u[3])  # the top bit came down: kL + 1 bits below mid; else kL - 1
-                assert tb.rtr[bin(T2).count("1")][tb.sidx[T2]] + rest + int(rankl[lw2]) == rank_of[b]
-        assert np.all(seen == 1)
-        # launch records: record b <-> block b, XCD-interleaved (block b runs on XCD b % 8); self-contained copies of the above
-        assert C.sizeof(_SibRec) == 256 and sp.n_recs == 8 * sp.slots_per_xcd
-        recs = (_SibRec * sp.n_recs).from_address(sp.recs)
-        covered = 0
-        for b in range(sp.n_recs):
-            un = int(order[(b % 8) * sp.slots_per_xcd + b // 8])
-            rc = recs[b]
-            if un == 0xFFFFFFFF:
-                assert rc.nS == 0
-                continue
-            u = units[un]
-            kL, jT = int(u[4]) & 0xFF, int(u[4]) >> 8
-            assert (rc.mid, rc.kL, rc.jT, rc.nL, rc.nS, rc.uoff) == (int(u[1]), kL, jT, math.comb(nl, kL), math.comb(t, jT), tb.uoff[kL])
-            for s_ in range(rc.nS):
-                T = tb.tlist[jT][s_]
-                assert rc.T[s_] == T and rc.base[s_] == tb.rtr[jT][s_] + int(u[0])
-                first = (T << tshift) | int(u[1]) | int(unrank[tb.uoff[kL]])  # the block's first state
-                assert rank_of[first] == rc.base[s_]
-                top = (T >> (t - 1)) & 1
-                lw_first = [w for w in unrank[tb.uoff[kL]:tb.uoff[kL + 1]].tolist() if (w & 1) != top]
-                if lw_first:  # some row of this block has an active ring pair: its partner's block starts at rc.ring
-                    a0 = (T << tshift) | int(u[1]) | lw_first[0]
-                    b0 = a0 ^ (1 | (1 << (L - 1)))
-                    assert rank_of[b0] == rc.ring[s_] + int(rankl[b0 & lmask])
-            covered += rc.nL * rc.nS
-        assert covered == len(states)
-        assert sp.max_rows == max(math.comb(nl, int(u[4]) & 0xFF) * math.comb(t, int(u[4]) >> 8) for u in units)
-    finally:
-        for ptr in (pt, pu, po, pun, prk):
-            lib.ls_amd_test_free(ptr)
-        lib.ls_amd_test_sibplan_free(ps)
 
 
 @pytest.mark.parametrize("elem,ldsp", [(8, 12), (16, 11)])
