@@ -79,6 +79,139 @@ def kernel_instance_sha(instance):
 
 PULL_KERNELS = ("direct-pull", "tile-pull", "replicated-")
 
+# ---- model of the replicated-x exchange on P GPUs, printed next to every measured N > 1 number -----------
+# One-GPU inputs measured in round 4 (profiles/r4_split_vs_fused_chain{36,40}symm_*.txt, profiles/r4_bench_default.json): the
+# split form of the projected pull kernel (resolve: stage A + K4 + slot look-ups, needs no x; gather: slots -> x -> y), the
+# owner-side prescaling, the staged row kernel of the unprojected chain.
+MODEL_INPUTS_MS = {
+    "heisenberg_chain_40_symm": {"resolve": 240.6, "gather": 65.1, "fused": 282.8, "prescale": 4.65, "n": 861725794},
+    "heisenberg_chain_36_symm": {"resolve": 15.07, "gather": 4.06, "fused": 18.09, "prescale": 0.30, "n": 63068876},
+    "heisenberg_chain_32": {"fused": 7.70, "n": 601080390},
+}
+XGMI_IN_GBPS = (7 * 50.0, 7 * 64.0)  # what one GPU receives from its 7 peers at once: 7 links x 50-64 GB/s achievable of 153 nominal
+REPL_OVERHEAD = 1.23                 # per-row cost of a rank's kernels relative to one GPU (x arrives owner-major: the near partners'
+                                     # values no longer share lines; measured on eight loop-back ranks, profiles/r3_loopback_*_final.txt)
+
+
+def scaling_model(model, P, w=8):
+    """predicted ms per matvec of the replicated-x exchange on P GPUs and the speed-up over one GPU it implies:
+    t(P) = prescale / P + max(resolve / P x f, exchange) + gather / P x f + return, exchange = N w (P - 1) / P / B_in; the
+    unprojected chain has no resolve step to hide the exchange behind and pays a permutation pass over all of x."""
+    m = MODEL_INPUTS_MS.get(model)
+    if not m or P < 2:
+        return None
+    xbytes = m["n"] * w * (P - 1) / P
+    out = {"inputs_ms_one_gpu": m, "assumed_in_GBps": list(XGMI_IN_GBPS), "assumed_kernel_overhead": [1.0, REPL_OVERHEAD], "x_bytes_in_per_rank": xbytes}
+    lo_hi = []
+    for b in XGMI_IN_GBPS:
+        for f in ((1.0, REPL_OVERHEAD) if "resolve" in m else (1.0,)):  # from "no overhead" to the loop-back figure
+            xch = xbytes / b / 1e6  # ms
+            ret = m["n"] * w / P / 1.0e9 * 1e3 / 3000.0 + (m["n"] * w / P) * (P - 1) / P / b / 1e6  # group rows by owner (~3 TB/s) + send back
+            if "resolve" in m:
+                t = m["prescale"] / P + max(m["resolve"] / P * f, xch) + m["gather"] / P * f + ret
+            else:
+                perm = m["n"] * 2 * w / 1.0e9 * 1e3 / 2500.0  # the hashed -> block permutation of x: N random reads + N writes
+                t = xch + perm + m["fused"] / P + ret
+            lo_hi.append(t)
+    out["predicted_ms_per_matvec"] = [min(lo_hi), max(lo_hi)]
+    out["predicted_speedup_over_one_gpu"] = [m["fused"] / max(lo_hi), m["fused"] / min(lo_hi)]
+    return out
+
+
+def projected_extra(D, torch, dist, name, rank, world, time_steps, allsum, steps=3, warmup=2):
+    """one of the symmetry-projected BASELINE chains, measured inside the default run (see main)"""
+    from distributed_matvec_amd import config
+
+    L, symm = parse_model(name)
+    basis, h = D.loadConfigFromDict(config.heisenberg_chain_config(L, symm=symm), hamiltonian=True)
+    t0 = time.perf_counter()
+    parts, masks = D.enumerateStates(basis, world)
+    n_total = int(masks.numel())
+    out = {"states": n_total, "steps": steps, "warmup": warmup, "dtype": "f64"}
+    if world == 1:
+        reps = parts[0]
+        x = [D.fillRandom(reps, 42, torch.float64)]
+        y = [torch.zeros_like(x[0])]
+        pl = D.MatvecPlan(h, [reps], torch.float64)
+        out["setup_seconds"] = time.perf_counter() - t0
+        pl.enable_timing(64)
+        for _ in range(warmup):
+            pl.matvec(x, y, check=False)
+        pl.check()
+        pl.kernel_times_ms()
+        dt = time_steps(lambda: pl.matvec(x, y, check=False), steps, 0)
+        pl.check()
+        ks = pl.kernel_times_ms()
+        kms = sum(ks) / max(1, len(ks))
+        out.update({"matvecs_per_s": steps / dt, "ms_per_step": 1e3 * dt / steps, "kernel": pl.kernel, "kernel_ms_avg": kms})
+        ent, note = pmc_entry(name, "f64", pl.kernel)
+        ia = int_alu_object(ent, kms * 1e-3)
+        if ia:
+            out["int_alu"] = ia
+        if ent and ent.get("traffic_bytes"):
+            # what bounds this kernel: random 64-byte requests (index-table probes, partner values), not bytes
+            out["requests_64B_per_s"] = ent["traffic_bytes"] / 64.0 / (kms * 1e-3)
+        out["pmc_note"] = note
+        pl.destroy()
+        return out
+    from distributed_matvec_amd.distributed import RcclReplicatedOperator
+
+    my = parts[rank].clone()
+    reps_global = D.arrFromHashedToBlock(parts, masks)
+    del parts
+    comm = D.Communicator.from_torch()
+    x = D.fillRandom(my, 42, torch.float64)
+    y = torch.zeros_like(x)
+    op = RcclReplicatedOperator(h, reps_global, masks, torch.float64, comm=comm)
+    out["setup_seconds"] = time.perf_counter() - t0
+    plan = op.engine.plan
+    plan.enable_stage_timing(4096)
+    for _ in range(warmup):
+        op.matvec(x, y, check=False)
+    plan.check()
+    plan.stage_times()
+    dt = time_steps(lambda: op.matvec(x, y, check=False), steps, 0)
+    plan.check()
+    stages, mv = plan.stage_times()
+    out.update({"matvecs_per_s": steps / dt, "ms_per_step": 1e3 * dt / steps, "kernel": plan.kernel, "exchange": "replicated",
+                "n_gpus": world, "exchange_bytes_per_matvec": allsum(getattr(op, "exchange_bytes_per_matvec", 0)),
+                "x_bytes_in_this_rank": 8 * (n_total - int(my.numel())),
+                "rank0_stage_ms_per_matvec": {k: v[0] / max(1, mv) for k, v in stages.items()},
+                "model": scaling_model(name, world)})
+    op.rm.destroy()
+    return out
+
+
+def pmc_entry(model, dtype, kernel_name):
+    """the committed PMC entry (profiles/pmc_traffic.json) of (model, dtype, plan kernel) if it was measured on the machine code
+    of this build's kernel; else (None, why)"""
+    sha = source_sha()
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            ent = json.load(f).get(f"{model}/{dtype}/{kernel_name}")
+    except (OSError, ValueError):
+        return None, "no profiles/pmc_traffic.json"
+    if not ent:
+        return None, "no PMC entry for this workload / kernel"
+    isa = kernel_isa_sha(ent.get("device_kernel", "").rstrip("<"))
+    same = (ent.get("isa_sha") is not None and ent.get("isa_sha") == isa) or ent.get("source_sha") == sha
+    if ent.get("instance_isa_sha"):
+        same = same or kernel_instance_sha(ent.get("instance", "")) == ent["instance_isa_sha"]
+    if not same:
+        return None, f"PMC entry is stale (measured on {ent.get('device_kernel')} ISA {ent.get('isa_sha')}, source_sha {ent.get('source_sha')})"
+    return ent, "profiles/pmc_traffic.json"
+
+
+def int_alu_object(ent, t):
+    """integer-ALU view of the projected bases: wave64 VALU instructions x 64 lanes against the spec rate, and as
+    issue time at the ~4 cycles the shifts / counts / multiplies / f64 ops of these kernels take (profiles/r3_valu_issue_rates.txt)"""
+    if not ent or not ent.get("valu_insts") or not t:
+        return None
+    peak = 256 * 4 * 32 * 2.4e9
+    ach = ent["valu_insts"] * 64 / t
+    return {"valu_wave_insts_per_launch": ent["valu_insts"], "achieved_lane_ops_per_s": ach, "peak_lane_ops_per_s": peak,
+            "frac": ach / peak, "issue_time_frac_at_4_cycles": ent["valu_insts"] * 4 / (256 * 4 * 2.4e9) / t}
+
 
 def roofline_object(args, kernel_name, kernel_ms, launches_per_step, rows_here, n_total, nnz, w, world, sec_per_step, symm,
                     row_bytes=8):
@@ -481,6 +614,32 @@ def main():
                 del x2, y2
             except D.LsAmdError as e:  # e.g. pull on a non-Hermitian operator
                 extra[f"{label}/{mode2}"] = {"error": str(e)}
+
+    # BASELINE configs 4 and 5 (the symmetry-projected chains) in the same run: 3 timed matvecs each, so that the driver's
+    # record carries projected-basis numbers too -- on one GPU the fused indexed pull kernel (with the integer-ALU and the
+    # request-rate view of it; an HBM-byte fraction means nothing there), on N > 1 GPUs the replicated-x exchange (slot
+    # resolution overlapped with the all-gather of x) next to what the model of DESIGN.md section 4 predicts.  The headline
+    # `value` / `config` stay those of --model.
+    if args.model == "heisenberg_chain_32" and not args.no_extra and args.dtype == "f64" and not args.force_distributed:
+        try:
+            del plan, op_obj
+        except NameError:
+            pass
+        x = y = my_reps = reps_global = masks = None
+        torch.cuda.empty_cache()
+        for name in ("heisenberg_chain_36_symm", "heisenberg_chain_40_symm"):
+            try:
+                extra[name] = projected_extra(D, torch, dist, name, rank, world, time_steps, allsum)
+            except Exception as e:  # reported, never hidden
+                import traceback
+
+                traceback.print_exc()
+                extra[name] = {"error": repr(e)[:400]}
+            if allsum(1.0 if "error" in extra[name] else 0.0) > 0 and "error" not in extra[name]:
+                extra[name] = {"error": "failed on another rank"}
+            torch.cuda.empty_cache()
+        if world > 1:
+            extra["model_heisenberg_chain_32"] = scaling_model("heisenberg_chain_32", world)
 
     cpu = None
     if rank == 0 and not distributed and not args.no_cpu_baseline:

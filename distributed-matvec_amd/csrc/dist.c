@@ -233,9 +233,12 @@ int ls_amd_dist_create(ls_amd_dist **out, ls_amd_comm *cm, ls_hs_operator const 
         int rc0 = scratch(cm, sizeof(int64_t), &ds);
         if (rc0 == 0 && lsk_h2d(ds, &mx, sizeof(mx)) != 0) rc0 = ls_amd_internal_error("%s", lsk_last_error());
         TRY(agree(cm, rc0, stream));
-        COMM(lsk_comm_allreduce(cm->c, ds, 1, 2, 1, stream));
-        DEVC(lsk_sync(stream));
-        DEVC(lsk_d2h(&mx, ds, sizeof(mx)));
+        /* a LOCAL failure after the collective (the sync, the copy back) must not leave this rank's peers alone in the next
+         * agreement: the status is carried into it */
+        int rc1 = 0;
+        if (lsk_comm_allreduce(cm->c, ds, 1, 2, 1, stream) != 0) rc1 = ls_amd_internal_error("%s", lsk_comm_last_error());
+        if (rc1 == 0 && (lsk_sync(stream) != 0 || lsk_d2h(&mx, ds, sizeof(mx)) != 0)) rc1 = ls_amd_internal_error("%s", lsk_last_error());
+        TRY(agree(cm, rc1, stream));
         int64_t const rpr = rows_per_round();
         num_rounds = (int)((mx + rpr - 1) / rpr);
         if (num_rounds < 1) num_rounds = 1;
@@ -264,9 +267,9 @@ int ls_amd_dist_create(ls_amd_dist **out, ls_amd_comm *cm, ls_hs_operator const 
         rc = ls_amd_internal_error("%s", lsk_comm_last_error());
     if (rc == 0 && (lsk_sync(stream) != 0 || lsk_d2h(all, (char *)ds + sizeof(int64_t) * m, sizeof(int64_t) * m * (size_t)P) != 0))
         rc = ls_amd_internal_error("%s", lsk_last_error());
-    if (rc != 0) { free(all); ls_amd_dist_destroy(d); return -1; }
+    /* (no early return here: a rank whose copy back failed still enters the final agreement below, where all fail together) */
     int64_t max_send = 0, max_recv = 0;
-    for (int r = 0; r < num_rounds; ++r) {
+    for (int r = 0; r < num_rounds && rc == 0; ++r) {
         int64_t so = 0, ro = 0;
         for (int q = 0; q < P; ++q) {
             size_t const k = (size_t)r * P + q;
@@ -279,7 +282,6 @@ int ls_amd_dist_create(ls_amd_dist **out, ls_amd_comm *cm, ls_hs_operator const 
         d->exchange_bytes += so;
     }
     free(all);
-    rc = 0;
     for (int i = 0; i < 2 && rc == 0; ++i)
         if (lsk_malloc(&d->d_send[i], (size_t)(max_send > 0 ? max_send : 8)) != 0 ||
             lsk_malloc(&d->d_recv[i], (size_t)(max_recv > 0 ? max_recv : 8)) != 0)

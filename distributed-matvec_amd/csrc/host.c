@@ -244,6 +244,11 @@ struct ls_amd_basis_ext {
     int *perms;         /* [order][L] */
     lsk_group_elem *elems; /* [order] host copy (characters, networks) */
     lsk_group_elem *d_elems;
+    /* K4 mode 4 (lsk_basis in lsk.h): the group contains every translation of a tw x (L / tw) torus; coset_ids = one element
+     * of every right coset T g (indices into elems), found once per basis.  tw == 0: not looked for yet, -1: no such subgroup */
+    int tw, n_cosets;
+    int *coset_ids;
+    lsk_group_elem *d_cosets;
     int owns_representatives;
     uint64_t *d_reps_cache; /* device copy of `representatives` for the host-pointer entry points */
     uint64_t d_reps_count;
@@ -504,25 +509,42 @@ static void host_plan_slot_drop(struct host_plan_slot *sl) {
     if (sl->dist) ls_amd_dist_destroy((ls_amd_dist *)sl->dist);
     memset(sl, 0, sizeof(*sl));
 }
-/* forget the cached plans of one operator (op != NULL), of one communicator (comm != NULL), or all of them */
-static void basis_drop_host_plans(struct ls_amd_basis_ext *e, ls_hs_operator const *op, void const *comm) {
-    for (int i = 0; i < HOST_PLAN_SLOTS; ++i) {
+/* Forget the cached plans of one operator (op != NULL), of one communicator (comm != NULL), or all of them.  The slots are
+ * DETACHED under the registry lock -- a basis cannot disappear, and no second thread can pick the same slot, while they are
+ * read -- and destroyed after it is released (destroying a plan takes that lock again). */
+static int detach_host_plans_locked(struct ls_amd_basis_ext *e, ls_hs_operator const *op, void const *comm,
+                                    struct host_plan_slot *out, int n, int cap) {
+    for (int i = 0; i < HOST_PLAN_SLOTS && n < cap; ++i) {
         struct host_plan_slot *sl = &e->host_plans[i];
         if (!sl->op) continue;
         if ((op && sl->op != op) || (comm && sl->comm != comm)) continue;
-        host_plan_slot_drop(sl);
+        out[n++] = *sl;
+        memset(sl, 0, sizeof(*sl));
     }
+    return n;
+}
+static void basis_drop_host_plans(struct ls_amd_basis_ext *e, ls_hs_operator const *op, void const *comm) {
+    struct host_plan_slot dropped[HOST_PLAN_SLOTS];
+    pthread_mutex_lock(&g_reg_lock);
+    int const n = detach_host_plans_locked(e, op, comm, dropped, 0, HOST_PLAN_SLOTS);
+    pthread_mutex_unlock(&g_reg_lock);
+    for (int i = 0; i < n; ++i) host_plan_slot_drop(&dropped[i]);
 }
 /* a communicator is going away (ls_amd_comm_destroy, dist.c): no cached ls_amd_dist may keep pointing at it */
 void ls_amd_internal_forget_comm(void const *comm) {
     pthread_mutex_lock(&g_reg_lock);
-    size_t n = 0;
-    struct ls_amd_basis_ext **es = (struct ls_amd_basis_ext **)calloc(g_reg_cap ? g_reg_cap : 1, sizeof(*es));
+    size_t bases = 0;
     for (size_t i = 0; i < g_reg_cap; ++i)
-        if (g_reg[i].key && g_reg[i].key != REG_TOMB && g_reg[i].kind == REG_BASIS) es[n++] = (struct ls_amd_basis_ext *)g_reg[i].val;
+        if (g_reg[i].key && g_reg[i].key != REG_TOMB && g_reg[i].kind == REG_BASIS) ++bases;
+    int const cap = (int)(bases ? bases : 1) * HOST_PLAN_SLOTS;
+    struct host_plan_slot *dropped = (struct host_plan_slot *)calloc((size_t)cap, sizeof(*dropped));
+    int n = 0;
+    for (size_t i = 0; i < g_reg_cap; ++i)
+        if (g_reg[i].key && g_reg[i].key != REG_TOMB && g_reg[i].kind == REG_BASIS)
+            n = detach_host_plans_locked((struct ls_amd_basis_ext *)g_reg[i].val, NULL, comm, dropped, n, cap);
     pthread_mutex_unlock(&g_reg_lock);
-    for (size_t i = 0; i < n; ++i) basis_drop_host_plans(es[i], NULL, comm);
-    free(es);
+    for (int i = 0; i < n; ++i) host_plan_slot_drop(&dropped[i]);
+    free(dropped);
 }
 
 static void basis_drop_device_caches(ls_hs_basis *b) {
@@ -540,8 +562,9 @@ void ls_hs_destroy_basis(ls_hs_basis *b) {
     if (--e->refcount > 0) return; /* operators built on this basis still share it */
     basis_drop_device_caches(b);
     if (e->d_elems) lsk_free(e->d_elems);
+    if (e->d_cosets) lsk_free(e->d_cosets);
     if (e->owns_representatives && b->representatives.elts) free(b->representatives.elts);
-    free(e->gen_perms); free(e->gen_sectors); free(e->perms); free(e->elems);
+    free(e->gen_perms); free(e->gen_sectors); free(e->perms); free(e->elems); free(e->coset_ids);
     reg_del(b);
     int const adopted = e->adopted;
     free(e);
@@ -584,6 +607,117 @@ int ls_amd_basis_group_character(ls_hs_basis const *b, int element, double *re, 
     return 0;
 }
 
+static pthread_mutex_t g_device_tables_lock = PTHREAD_MUTEX_INITIALIZER;
+/* Looks for the translation subgroup of a lattice group (K4 mode 4).  Every element is taken by its ACTION on the one-hot
+ * states (img[g][s] = position of the bit of g(1 << s)), so no convention about permutation arrays enters: t is a translation
+ * of the w x h torus (s = y w + x) when img_t[s] = ((y + dy) % h) w + (x + dx) % w; the subgroup qualifies when all w h of them
+ * are in the group.  Then one element of every right coset T g is kept (t o g covers the coset: img_{t o g}[s] = img_t[img_g[s]]).
+ * Sets e->tw (-1: none), e->n_cosets, e->coset_ids. */
+static void find_translation_cosets(struct ls_amd_basis_ext *e, int L) {
+    e->tw = -1;
+    int const order = e->order;
+    if (order < 4 || order > 8192 || L < 4) return;
+    unsigned char *img = (unsigned char *)malloc((size_t)order * (size_t)L);
+    for (int g = 0; g < order; ++g)
+        for (int s = 0; s < L; ++s) img[(size_t)g * L + s] = (unsigned char)__builtin_ctzll(host_apply_elem(&e->elems[g], 1ULL << s, L));
+    /* index of an action among the group's (open addressing over an FNV hash) */
+    int cap = 1;
+    while (cap < 4 * order) cap *= 2;
+    int *table = (int *)malloc(sizeof(int) * (size_t)cap);
+    for (int i = 0; i < cap; ++i) table[i] = -1;
+#define IMG_HASH(ptr, out_h) do { uint64_t h_ = 1469598103934665603ULL; for (int s_ = 0; s_ < L; ++s_) { h_ ^= (ptr)[s_]; h_ *= 1099511628211ULL; } (out_h) = (int)(h_ & (uint64_t)(cap - 1)); } while (0)
+    for (int g = 0; g < order; ++g) {
+        int h;
+        IMG_HASH(img + (size_t)g * L, h);
+        while (table[h] >= 0) h = (h + 1) & (cap - 1);
+        table[h] = g;
+    }
+    unsigned char *cand = (unsigned char *)malloc((size_t)L);
+    int *trans = (int *)malloc(sizeof(int) * (size_t)L);
+    int best_w = -1;
+    for (int w = 2; w <= L / 2 && best_w < 0; ++w) {
+        if (L % w) continue;
+        int const hgt = L / w;
+        int found = 0;
+        for (int dy = 0; dy < hgt; ++dy)
+            for (int dx = 0; dx < w; ++dx) {
+                for (int s = 0; s < L; ++s) cand[s] = (unsigned char)((((s / w) + dy) % hgt) * w + ((s % w) + dx) % w);
+                int h, id = -1;
+                IMG_HASH(cand, h);
+                while (table[h] >= 0) {
+                    if (memcmp(img + (size_t)table[h] * L, cand, (size_t)L) == 0) { id = table[h]; break; }
+                    h = (h + 1) & (cap - 1);
+                }
+                if (id >= 0) trans[found++] = id;
+            }
+        if (found == L) best_w = w;
+    }
+    if (best_w > 0) {
+        unsigned char *covered = (unsigned char *)calloc((size_t)order, 1);
+        int *ids = (int *)malloc(sizeof(int) * (size_t)order);
+        int nc = 0, ok = 1;
+        for (int g = 0; g < order && ok; ++g) {
+            if (covered[g]) continue;
+            ids[nc++] = g;
+            for (int t = 0; t < L && ok; ++t) {
+                unsigned char const *it = img + (size_t)trans[t] * L, *ig = img + (size_t)g * L;
+                for (int s = 0; s < L; ++s) cand[s] = it[ig[s]];
+                int h, id = -1;
+                IMG_HASH(cand, h);
+                while (table[h] >= 0) {
+                    if (memcmp(img + (size_t)table[h] * L, cand, (size_t)L) == 0) { id = table[h]; break; }
+                    h = (h + 1) & (cap - 1);
+                }
+                if (id < 0) ok = 0; /* not closed: cannot happen for a group; be safe */
+                else covered[id] = 1;
+            }
+        }
+        if (ok && nc * L == order) {
+            e->tw = best_w;
+            e->n_cosets = nc;
+            e->coset_ids = (int *)malloc(sizeof(int) * (size_t)nc);
+            memcpy(e->coset_ids, ids, sizeof(int) * (size_t)nc);
+        }
+        free(covered); free(ids);
+    }
+#undef IMG_HASH
+    free(img); free(table); free(cand); free(trans);
+}
+
+/* host-only test hooks of K4 mode 4: the shape found for a basis (returns tw, or -1), and the orbit minimum of `state` computed
+ * the way the kernels do it (coset networks + row / word rotations; the global spin flip folded in by canonicalising to "top
+ * site clear" when the basis has one) */
+int ls_amd_test_translation_cosets(ls_hs_basis const *b, int *n_cosets) {
+    struct ls_amd_basis_ext *e = BEXT(b);
+    pthread_mutex_lock(&g_device_tables_lock);
+    if (e->tw == 0) find_translation_cosets(e, b->number_sites);
+    pthread_mutex_unlock(&g_device_tables_lock);
+    if (n_cosets) *n_cosets = e->tw > 0 ? e->n_cosets : 0;
+    return e->tw;
+}
+uint64_t ls_amd_test_rep_by_cosets(ls_hs_basis const *b, uint64_t a) {
+    struct ls_amd_basis_ext *e = BEXT(b);
+    int const L = b->number_sites;
+    if (ls_amd_test_translation_cosets(b, NULL) <= 0) return ~0ULL;
+    uint64_t const mask = L >= 64 ? ~0ULL : ((1ULL << L) - 1);
+    int const tw = e->tw, th = L / tw;
+    uint64_t col0 = 0, best = ~0ULL;
+    for (int y = 0; y < th; ++y) col0 |= 1ULL << (y * tw);
+    for (int r = 0; r < e->n_cosets; ++r) {
+        uint64_t v = host_apply_elem(&e->elems[e->coset_ids[r]], a, L);
+        for (int j = 0; j < th; ++j) {
+            for (int i = 0; i < tw; ++i) {
+                uint64_t c = v;
+                if (b->spin_inversion != 0 && ((v >> (L - 1)) & 1)) c = v ^ mask;
+                if (c < best) best = c;
+                v = ((v << 1) & ~col0 & mask) | ((v >> (tw - 1)) & col0);
+            }
+            v = ((v << tw) | (v >> (L - tw))) & mask;
+        }
+    }
+    return best;
+}
+
 static int basis_device_unlocked(ls_hs_basis const *b, lsk_basis *out) {
     struct ls_amd_basis_ext *e = BEXT(b);
     if (!e->d_elems) {
@@ -609,6 +743,9 @@ static int basis_device_unlocked(ls_hs_basis const *b, lsk_basis *out) {
     out->k4_mode = 0;
     out->reflect = 0;
     out->debug_ablate = getenv("LS_AMD_ABLATE") ? atoi(getenv("LS_AMD_ABLATE")) : 0;
+    out->tw = out->n_cosets = 0;
+    out->tcol0 = 0;
+    out->cosets = NULL;
     if (trivial && e->order > 1 && !getenv("LS_AMD_GENERAL_K4")) {
         out->k4_mode = 1;
         /* full cyclic group of the ring (every rotation k = 0..L-1), optionally with all reflections? */
@@ -624,6 +761,27 @@ static int basis_device_unlocked(ls_hs_basis const *b, lsk_basis *out) {
         if (!other && rot == full && (rev == 0 || rev == full) && e->order == L * (rev ? 2 : 1) && L >= 3) {
             out->k4_mode = getenv("LS_AMD_K4_BRUTE") ? 2 : 3; /* 3: longest-zero-run candidate pruning */
             out->reflect = rev ? 1 : 0;
+        } else if (!getenv("LS_AMD_K4_BRUTE")) {
+            /* a lattice group: its translation subgroup is walked with cheap bit operations, only the coset representatives
+             * (the point group) go through compiled networks */
+            if (e->tw == 0) find_translation_cosets(e, L);
+            if (e->tw > 0) {
+                if (!e->d_cosets) {
+                    lsk_group_elem *tmp = (lsk_group_elem *)malloc(sizeof(lsk_group_elem) * (size_t)e->n_cosets);
+                    for (int r = 0; r < e->n_cosets; ++r) tmp[r] = e->elems[e->coset_ids[r]];
+                    void *p = NULL;
+                    int const bad = lsk_malloc(&p, sizeof(lsk_group_elem) * (size_t)e->n_cosets) != 0 ||
+                                    lsk_h2d(p, tmp, sizeof(lsk_group_elem) * (size_t)e->n_cosets) != 0;
+                    free(tmp);
+                    if (bad) { if (p) lsk_free(p); return dev_error(); }
+                    e->d_cosets = (lsk_group_elem *)p;
+                }
+                out->k4_mode = 4;
+                out->tw = e->tw;
+                out->n_cosets = e->n_cosets;
+                out->cosets = e->d_cosets;
+                for (int y = 0; y < L / e->tw; ++y) out->tcol0 |= 1ULL << (y * e->tw);
+            }
         }
     }
     return 0;
@@ -1067,7 +1225,6 @@ static int operator_device_unlocked(ls_hs_operator const *op, lsk_operator *out)
 
 /* the device mirrors of a basis / an operator are uploaded on first use; several host threads may create plans on the same
  * objects at once (one communicator per thread) */
-static pthread_mutex_t g_device_tables_lock = PTHREAD_MUTEX_INITIALIZER;
 static int operator_device(ls_hs_operator const *op, lsk_operator *out) {
     pthread_mutex_lock(&g_device_tables_lock);
     int const rc = operator_device_unlocked(op, out);
@@ -1211,6 +1368,9 @@ typedef struct ls_amd_gtab {
     uint64_t *d_entries;
     uint32_t *d_perm;     /* [n] global row -> slot owner * max_count + local index (NULL when masks == NULL) */
     int64_t counts[LSK_MAX_PARTS], max_count;
+    uint64_t finger[8];   /* key, part two: the representatives at eight sampled positions -- a caller that frees the array and
+                           * gets the same address back for another basis of the same size (caching allocators do that) must not
+                           * be handed the old table */
     int refs;
     struct ls_amd_gtab *next;
 } ls_amd_gtab;
@@ -1280,12 +1440,21 @@ static int gtab_build(ls_amd_gtab *t, void *stream) {
 }
 /* the table of (d_reps, n, d_masks, P), built on first use.  Holds g_gtab_lock while building: the other ranks of a
  * loop-back group wait for the one that got there first. */
+static int gtab_fingerprint(uint64_t const *d_reps, int64_t n, void *stream, uint64_t *f) {
+    memset(f, 0, 8 * sizeof(uint64_t));
+    if (n <= 0) return 0;
+    DEV(lsk_sync(stream));
+    for (int k = 0; k < 8; ++k) DEV(lsk_d2h(&f[k], d_reps + (n - 1) * k / 7, sizeof(uint64_t)));
+    return 0;
+}
 int ls_amd_internal_gtab_acquire(ls_amd_gtab **out, int L, uint64_t const *d_reps, int64_t n, uint8_t const *d_masks, int P,
                                  void *stream) {
     *out = NULL;
+    uint64_t finger[8];
+    if (gtab_fingerprint(d_reps, n, stream, finger) != 0) return -1;
     pthread_mutex_lock(&g_gtab_lock);
     for (ls_amd_gtab *t = g_gtabs; t; t = t->next)
-        if (t->reps == d_reps && t->n == n && t->masks == d_masks && t->P == P && t->L == L) {
+        if (t->reps == d_reps && t->n == n && t->masks == d_masks && t->P == P && t->L == L && memcmp(t->finger, finger, sizeof(finger)) == 0) {
             ++t->refs;
             pthread_mutex_unlock(&g_gtab_lock);
             *out = t;
@@ -1293,6 +1462,7 @@ int ls_amd_internal_gtab_acquire(ls_amd_gtab **out, int L, uint64_t const *d_rep
         }
     ls_amd_gtab *t = (ls_amd_gtab *)calloc(1, sizeof(*t));
     t->reps = d_reps; t->n = n; t->masks = d_masks; t->P = P; t->L = L;
+    memcpy(t->finger, finger, sizeof(finger));
     if (gtab_build(t, stream) != 0) {
         gtab_free(t);
         pthread_mutex_unlock(&g_gtab_lock);

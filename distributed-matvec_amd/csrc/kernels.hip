@@ -142,7 +142,7 @@ static int tile_grid(K kernel, int64_t work_blocks) {
     return (int)work_blocks;
 }
 
-// LS_AMD_ABLATE (lsk_basis.debug_ablate) / LS_AMD_SIB_ABLATE switch stages of the tile / sibling kernels off to price them --
+// LS_AMD_ABLATE (lsk_basis.debug_ablate) switches stages of the tile / pull kernels off to price them --
 // profiling builds only (make ABLATE=1): the shipped kernels carry none of these branches.
 #ifndef LSK_ABLATE
 #define LSK_ABLATE 0
@@ -586,6 +586,25 @@ __device__ __forceinline__ W rep_trivial(lsk_basis const &bs, lsk_group_elem con
     const bool inv = bs.spin_inversion != 0;
     W best = ~(W)0;
     if (bs.k4_mode == 3) return rep_trivial_dihedral<W>(a, L, mask, inv, bs.reflect != 0);
+    if (bs.k4_mode == 4) {
+        // translations of a tw x th torus as a subgroup: one compiled network per coset representative (the point group), then
+        // tw * th cheap steps -- rotate every row by one site; after tw of them the word is back, rotate it by one row
+        const int tw = bs.tw, th = L / tw;
+        const W col0 = (W)bs.tcol0, ncol0 = (W)(~col0 & mask);
+        for (int r = 0; r < bs.n_cosets; ++r) {
+            W b = apply_elem_w<W>(bs.cosets[r], a, L, mask);
+            for (int j = 0; j < th; ++j) {
+                for (int i = 0; i < tw; ++i) {
+                    W c = b;
+                    if (inv) c = ((b >> (L - 1)) & 1) ? (W)(b ^ mask) : b;
+                    best = c < best ? c : best;
+                    b = (W)(((W)(b << 1) & ncol0) | ((W)(b >> (tw - 1)) & col0));
+                }
+                b = rotl_sites<W>(b, tw, L, mask);
+            }
+        }
+        return best;
+    }
     if (bs.k4_mode == 2) {
         W r = a;
         for (int pass = 0; pass <= bs.reflect; ++pass) {
@@ -1050,6 +1069,12 @@ template <> __device__ __forceinline__ uint64_t readlane_t<uint64_t>(uint64_t v,
     const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, lane);
     const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), lane);
     return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)u, lane);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(u >> 32), lane);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 template <typename T> __device__ __forceinline__ T readfirstlane_t(T v);
 template <> __device__ __forceinline__ uint32_t readfirstlane_t<uint32_t>(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -1537,6 +1562,221 @@ extern "C" int lsk_chain(lsk_operator op, lsk_basis bs, lsk_index ix, int cplx, 
     return cplx ? launch_chain<uint64_t, uint64_t, true, 512, false>(LSK_CHAIN_ARGS) : launch_chain<uint64_t, uint64_t, false, 1024, false>(LSK_CHAIN_ARGS);
 #undef LSK_CHAIN_ARGS
 }
+
+// ---------------------------------------------------------------------------------------------
+// Staged row kernel for ANY set of exchange pairs (k_pairs_t): real Hermitian operators whose off-diagonal part is a sum of
+// v_p (|01><10| + |10><01|) over arbitrary site pairs (i_p, j_p) and whose diagonal is a sum of vz_p s_i s_j over the same
+// pairs -- the Heisenberg / XXZ model on any lattice (square, kagome, J1-J2 rings, ...), on the full fixed-weight basis of
+// <= 32 sites, pull form.  k_chain_t is the special case "adjacent pairs", which is faster still for rings; everything that is
+// not a ring used to run the generic row kernel (k_direct: one full combinadic re-ranking per non-adjacent non-zero).
+//
+// A state is high | low with low = bits 0..10.  In the ascending order all 11-bit words of weight kl under one `high` are a
+// contiguous block of C(11, kl) <= 462 rows (kl = weight - popcount(high)), and rank = blockstart(high) + rank_low[low]
+// (rank_low: 2048 x u16 in LDS).  The 64 rows of a wave are consecutive, so they almost always lie in ONE block; a wave that
+// straddles blocks is processed block segment by block segment (same code, partial lane mask).  Per segment the pairs fall
+// into three classes:
+//   NEAR      both sites in `low`: the partner is in the same block, at rank_low[low ^ m] - rank_low[low] rows: LDS window
+//             of x (+-512 rows), two LDS reads and a handful of VALU instructions per pair and lane;
+//   HIGH      both sites in `high`: anti-alignment and the rank shift are the same for every lane of the segment: priced once,
+//             lane-parallel (lane l <-> pair l: the shift is a sum over the set bits between the two sites), then a loop over the
+//             anti-aligned pairs only -- readlane, add, gather of 64 CONSECUTIVE elements of x, fma;
+//   STRADDLE  i in `low`, j in `high`: the partner block (high ^ bit j, kl -+ 1) is the same for every lane: its start is priced
+//             once, lane-parallel; per lane the partner is blockstart + rank_low[low ^ bit i] (a gather inside a <= 3.7 KB block).
+// The diagonal comes out of the same loops: d(a) = sum_p vz_p - 2 sum_{p anti-aligned} vz_p.
+// ---------------------------------------------------------------------------------------------
+constexpr int kPairLowBits = 11;
+constexpr int kPairHalo = 512; // >= C(11, 5)
+constexpr int kPairFar = 8;    // gathers of HIGH pairs in flight per lane
+enum { PAIR_NEAR = 0, PAIR_STRADDLE = 1, PAIR_HIGH = 2 };
+
+template <bool CPLX, int TILE>
+__global__ __launch_bounds__(kBlock, (CPLX ? 4 : 6)) void k_pairs_t(lsk_pairplan pp, int hamming_weight, uint64_t const *__restrict__ tilemap,
+                                                              int64_t slots_per_xcd, int64_t n, void const *__restrict__ x_v,
+                                                              void *__restrict__ y_v) {
+    typedef typename ChainX<CPLX>::type X;
+    constexpr int HALO = kPairHalo;
+    constexpr int WINDOW = TILE + 2 * HALO + 2;
+    constexpr int LOWMASK = (1 << kPairLowBits) - 1;
+    X const *__restrict__ x = (X const *)x_v;
+    X *__restrict__ y = (X *)y_v;
+    __shared__ X s_x[WINDOW + 1]; // last slot: 0
+    __shared__ uint16_t s_rl[1 << kPairLowBits];
+    __shared__ uint32_t s_binom[32 * LSK_PAIR_KC];
+    __shared__ lsk_pair s_pairs[LSK_MAX_PAIRS];
+    const int n_near = pp.n_near, n_str = pp.n_str, n_high = pp.n_high;
+    const int kc = LSK_PAIR_KC;
+    for (int k = threadIdx.x; k < (1 << kPairLowBits); k += kBlock) s_rl[k] = pp.rank_low[k];
+    for (int k = threadIdx.x; k < 32 * kc; k += kBlock) s_binom[k] = pp.binom[k];
+    for (int k = threadIdx.x; k < n_near + n_str + n_high; k += kBlock) s_pairs[k] = pp.pairs[k];
+    if (threadIdx.x == 0) s_x[WINDOW] = cx_zero<X>();
+    const int xcd = blockIdx.x & 7;
+    const int64_t blocks_per_xcd = gridDim.x >> 3;
+    const int lane = threadIdx.x & 63;
+    tilemap += (int64_t)xcd * slots_per_xcd;
+    for (int64_t t = blockIdx.x >> 3; t < slots_per_xcd; t += blocks_per_xcd) {
+        const uint64_t slot = tilemap[t];
+        const int cnt = (int)(slot >> 48);
+        if (cnt == 0) continue;
+        const int64_t i0 = (int64_t)(slot & 0xffffffffffffULL);
+        const int64_t w0 = (i0 - HALO) & ~(int64_t)1;
+        __syncthreads(); // every wave is done with the previous window (and the tables are loaded)
+        if (CPLX) {
+            for (int j = threadIdx.x; j < WINDOW; j += kBlock) {
+                const int64_t row = w0 + j;
+                s_x[j] = (row >= 0 && row < n) ? x[row] : cx_zero<X>();
+            }
+        } else {
+            double const *xd = (double const *)x_v;
+            double *sd = (double *)s_x;
+            for (int j = 2 * threadIdx.x; j < WINDOW; j += 2 * kBlock) {
+                const int64_t row = w0 + j;
+                double2 v;
+                if (row >= 0 && row + 1 < n) v = *reinterpret_cast<double2 const *>(xd + row);
+                else { v.x = (row >= 0 && row < n) ? xd[row] : 0.0; v.y = (row + 1 >= 0 && row + 1 < n) ? xd[row + 1] : 0.0; }
+                sd[j] = v.x;
+                sd[j + 1] = v.y;
+            }
+        }
+        __syncthreads();
+        const int own0 = (int)(i0 - w0);
+        const int wave0 = (int)(threadIdx.x & ~63u);
+#pragma unroll 1
+        for (int sub = 0; sub < TILE / kBlock; ++sub) {
+            if (sub * kBlock + wave0 >= cnt) break; // wave-uniform: the whole wave is past the end
+            const int r = sub * kBlock + threadIdx.x;
+            const bool ghost = r >= cnt; // lanes past the end stay active as copies of the last row (they store nothing)
+            const int64_t i = i0 + (ghost ? cnt - 1 : r);
+            const uint32_t a = __builtin_nontemporal_load(pp.states + i);
+            const uint32_t ig = (uint32_t)i;
+            const uint32_t low = a & LOWMASK, hi = a >> kPairLowBits;
+            const int jr = own0 + (int)(i - i0);
+            const X xr = s_x[jr];
+            X acc = cx_zero<X>();
+            double dsub = 0.0; // sum of vz over this row's anti-aligned pairs
+            // ---- NEAR pairs ---------------------------------------------------------------------------------------------
+            const int rl0 = (int)s_rl[low];
+            for (int p = 0; p < n_near; ++p) {
+                lsk_pair const P = s_pairs[p];
+                const uint32_t m = (1u << P.i) | (1u << P.j);
+                const bool act = __popc(low & m) == 1;
+                const int r1 = (int)s_rl[low ^ m];
+                const int o = jr + (r1 - rl0);
+                cx_fma(P.v, s_x[act ? o : WINDOW], acc);
+                dsub += act ? P.vz : 0.0;
+            }
+            // ---- block segments: lanes that share `hi` -----------------------------------------------------------------------
+            unsigned long long pending = __builtin_amdgcn_ballot_w64(true);
+            while (pending) {
+                const int l0 = __builtin_ctzll(pending);
+                const uint32_t href = (uint32_t)__builtin_amdgcn_readlane((int)hi, l0);
+                const bool inseg = hi == href;
+                pending &= ~__builtin_amdgcn_ballot_w64(inseg);
+                const int kl = hamming_weight - __popc(href); // set bits of `low`, the same for every lane of the segment
+                double dz_u = 0.0;
+                // ---- HIGH pairs: priced once, lane l <-> pair pass + l -------------------------------------------------------
+                for (int pass = 0; pass < n_high; pass += 64) {
+                    const int q = pass + lane;
+                    const bool in = q < n_high;
+                    lsk_pair const P = s_pairs[n_near + n_str + (in ? q : 0)];
+                    const int pi = P.i - kPairLowBits, pj = P.j - kPairLowBits; // positions inside `hi`
+                    const uint32_t bi = (href >> pi) & 1u, bj = (href >> pj) & 1u;
+                    const bool act = in && bi != bj;
+                    // rank of the configuration "bit at i" minus rank of "bit at j": only the set bits at or above i matter
+                    int k = kl + __popc(href & ((1u << pi) - 1u)); // set bits of the state below site i
+                    uint32_t between = href & ((1u << pj) - 1u) & ~((2u << pi) - 1u);
+                    int64_t lowcfg = (int64_t)s_binom[P.i * kc + min(k + 1, kc - 1)], highcfg = 0;
+                    int tt = 0;
+                    while (between) {
+                        const int b = __builtin_ctz(between) + kPairLowBits;
+                        between &= between - 1;
+                        ++tt;
+                        lowcfg += (int64_t)s_binom[b * kc + min(k + 1 + tt, kc - 1)];
+                        highcfg += (int64_t)s_binom[b * kc + min(k + tt, kc - 1)];
+                    }
+                    highcfg += (int64_t)s_binom[P.j * kc + min(k + tt + 1, kc - 1)];
+                    const int32_t delta = (int32_t)(bi ? highcfg - lowcfg : lowcfg - highcfg); // partner rank - own rank
+                    unsigned long long m = __builtin_amdgcn_ballot_w64(act);
+                    while (m) {
+                        X xv[kPairFar];
+                        double vv[kPairFar];
+#pragma unroll
+                        for (int u = 0; u < kPairFar; ++u) {
+                            xv[u] = cx_zero<X>();
+                            vv[u] = 0.0;
+                            if (m) {
+                                const int l = __builtin_ctzll(m);
+                                m &= m - 1;
+                                const int32_t d = __builtin_amdgcn_readlane(delta, l);
+                                vv[u] = readlane_f64(P.v, l);
+                                dz_u += readlane_f64(P.vz, l);
+                                xv[u] = x[inseg ? (uint32_t)(ig + (uint32_t)d) : ig];
+                            }
+                        }
+#pragma unroll
+                        for (int u = 0; u < kPairFar; ++u) cx_fma(inseg ? vv[u] : 0.0, xv[u], acc);
+                    }
+                }
+                // ---- STRADDLE pairs: the partner block is priced once, the place inside it per lane ----------------------------
+                for (int pass = 0; pass < n_str; pass += 64) {
+                    const int q = pass + lane;
+                    const bool in = q < n_str;
+                    lsk_pair const P = s_pairs[n_near + (in ? q : 0)];
+                    const int pj = P.j - kPairLowBits;
+                    const uint32_t bj = (href >> pj) & 1u;
+                    const uint32_t h2 = href ^ (1u << pj);
+                    const int kl2 = bj ? kl + 1 : kl - 1; // a bit comes down into `low`, or leaves it
+                    uint32_t base = 0;
+                    {
+                        uint32_t hb = h2;
+                        int idx = kl2;
+                        while (hb) {
+                            const int b = __builtin_ctz(hb) + kPairLowBits;
+                            hb &= hb - 1;
+                            ++idx;
+                            base += s_binom[b * kc + min(max(idx, 0), kc - 1)];
+                        }
+                    }
+                    const int np = min(64, n_str - pass);
+                    for (int l = 0; l < np; ++l) {
+                        const int pi = __builtin_amdgcn_readlane((int)P.i, l);
+                        const uint32_t sbj = (uint32_t)__builtin_amdgcn_readlane((int)bj, l);
+                        const uint32_t sbase = (uint32_t)__builtin_amdgcn_readlane((int)base, l);
+                        const double sv = readlane_f64(P.v, l), svz = readlane_f64(P.vz, l);
+                        const bool act = inseg && ((low >> pi) & 1u) != sbj;
+                        const uint32_t idx = act ? sbase + (uint32_t)s_rl[low ^ (1u << pi)] : ig;
+                        cx_fma(act ? sv : 0.0, x[idx], acc);
+                        dsub += act ? svz : 0.0;
+                    }
+                }
+                dsub += inseg ? dz_u : 0.0;
+            }
+            cx_fma(pp.dsum - 2.0 * dsub, xr, acc);
+            if (!ghost) cx_store_nt(y + i, acc);
+        }
+    }
+}
+
+extern "C" int lsk_pairs_tile_rows(int cplx) { return cplx ? 512 : 1024; }
+extern "C" int lsk_pairs(lsk_pairplan pp, int hamming_weight, int cplx, lsk_tilemap tm, int64_t n, void const *x, void *y, void *stream) {
+    if (n == 0 || tm.slots_per_xcd == 0) return 0;
+    if (pp.n_near + pp.n_str + pp.n_high > LSK_MAX_PAIRS || hamming_weight + 2 > LSK_PAIR_KC) { snprintf(g_err, sizeof(g_err), "lsk_pairs: plan out of range"); return -1; }
+    const int64_t gb = tm.slots_per_xcd * 8; // one block per tile
+    if (cplx) hipLaunchKernelGGL((k_pairs_t<true, 512>), dim3((unsigned)gb), dim3(kBlock), 0, (hipStream_t)stream, pp, hamming_weight, tm.entries, tm.slots_per_xcd, n, x, y);
+    else hipLaunchKernelGGL((k_pairs_t<false, 1024>), dim3((unsigned)gb), dim3(kBlock), 0, (hipStream_t)stream, pp, hamming_weight, tm.entries, tm.slots_per_xcd, n, x, y);
+    LSK_LAUNCH_CHECK();
+    return 0;
+}
+// states[i] = (u32)reps[i]: the 4-byte state array the kernel streams
+__global__ __launch_bounds__(kBlock) void k_narrow_states(int64_t n, uint64_t const *__restrict__ reps, uint32_t *__restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) out[i] = (uint32_t)reps[i];
+}
+extern "C" int lsk_narrow_states(int64_t n, uint64_t const *reps, uint32_t *out, void *stream) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_narrow_states, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, n, reps, out);
+    LSK_LAUNCH_CHECK();
+    return 0;
+}
+
 
 // ---------------------------------------------------------------------------------------------
 // Staged ("tile") kernel: symmetry projection and/or hash-partitioned output.
@@ -2300,6 +2540,7 @@ __global__ __launch_bounds__(kBlock) void k_pull_t(lsk_runs runs, int n_groups, 
     X const *__restrict__ xv = (X const *)xsrc;
     constexpr int kCap = (kBlock / 64) * kWvRing;
     __shared__ uint32_t s_nw[2 * kNwSets];
+    extern __shared__ uint32_t s_nwslot[]; // [kNwMaxWin] when ix.perm != NULL (launch-time size): slot of every window entry
     __shared__ W s_beta[kCap];
     __shared__ double s_coef[NC ? kCap * NC : 1];
     __shared__ uint8_t s_row[kCap]; // row inside the wave (0..63)
@@ -2335,6 +2576,9 @@ __global__ __launch_bounds__(kBlock) void k_pull_t(lsk_runs runs, int n_groups, 
             for (int w = tid; w < wn; w += kBlock) {
                 const uint32_t d = window_offset(greps[gbase + w], v0);
                 if (d != kWinAbsent) nw_insert(s_nw, d, w);
+                // replicated-x exchange: the slot of a near partner comes out of LDS (a coalesced load per window entry here)
+                // instead of one dependent, uncoalesced load of perm[] per near packet
+                if (ix.perm) s_nwslot[w] = ix.perm[gbase + w];
             }
         }
         __syncthreads(); // the window is staged
@@ -2365,6 +2609,7 @@ __global__ __launch_bounds__(kBlock) void k_pull_t(lsk_runs runs, int n_groups, 
             }
 #pragma unroll
             for (int k = 0; k < K; ++k) {
+                if (kAblate && (bs.debug_ablate & 4)) continue; // profiling builds: no K4 (the look-ups then mostly miss)
                 if (K4M == K4_TRIVIAL) {
                     beta[k] = (uint64_t)rep_trivial<W>(bs, elems, (W)beta[k]); // xsrc is pre-multiplied by norm(rep)
                 } else if (live[k]) {
@@ -2384,8 +2629,12 @@ __global__ __launch_bounds__(kBlock) void k_pull_t(lsk_runs runs, int n_groups, 
             for (int k = 0; k < K; ++k) { // near window: LDS only
                 pos[k] = -1; bkt[k] = 0; tag[k] = 0; slot[k] = kNoSlot;
                 first[k] = make_ulonglong2(0, 0);
+                if (kAblate && (bs.debug_ablate & 2)) { // profiling builds: K4 kept alive, no look-up, no accumulation
+                    if (beta[k] == 0x123456789abcdefULL) atomicExch(err, 2);
+                    live[k] = false;
+                }
                 if (live[k]) {
-                    if (wn > 0 && beta[k] >= v0) {
+                    if (wn > 0 && beta[k] >= v0 && !(kAblate && (bs.debug_ablate & 32))) {
                         const uint32_t d = window_offset(beta[k], v0);
                         if (d != kWinAbsent) pos[k] = nw_find(s_nw, d);
                     }
@@ -2395,7 +2644,7 @@ __global__ __launch_bounds__(kBlock) void k_pull_t(lsk_runs runs, int n_groups, 
 #pragma unroll
             for (int k = 0; k < K; ++k) { // first-level loads: perm entry (near) or home bucket (far)
                 if (!live[k]) continue;
-                if (pos[k] >= 0) slot[k] = ix.perm ? ix.perm[gbase + pos[k]] : (uint32_t)(gbase + pos[k]);
+                if (pos[k] >= 0) slot[k] = ix.perm ? s_nwslot[pos[k]] : (uint32_t)(gbase + pos[k]);
                 else first[k] = *(ulonglong2 const *)(tab + 2 * bkt[k]);
             }
 #pragma unroll
@@ -2407,7 +2656,7 @@ __global__ __launch_bounds__(kBlock) void k_pull_t(lsk_runs runs, int n_groups, 
             if constexpr (FUSED) {
                 X val[K];
 #pragma unroll
-                for (int k = 0; k < K; ++k) val[k] = live[k] ? xv[slot[k]] : cx_zero<X>();
+                for (int k = 0; k < K; ++k) val[k] = (live[k] && !(kAblate && (bs.debug_ablate & 64))) ? xv[slot[k]] : cx_zero<X>();
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
                     if (!live[k]) continue;
@@ -2460,6 +2709,7 @@ __global__ __launch_bounds__(kBlock) void k_pull_t(lsk_runs runs, int n_groups, 
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (kAblate && (bs.debug_ablate & 1)) { head = (head + cnt) & (kWvRing - 1); cnt = 0; } // profiling builds: stage A only
             while (cnt >= 128) { // stage B on full chunks, two at a time while the ring has them
                 chunks(std::integral_constant<int, 2>(), 64);
                 head = (head + 128) & (kWvRing - 1);
@@ -2610,7 +2860,8 @@ static void launch_pull_t(lsk_operator const &op, lsk_basis const &bs, int64_t r
                           int halo, void *y, lsk_pullbuf buf, int *d_err, hipStream_t s) {
     const int64_t work_blocks = (row1 - row0 + kBlock - 1) / kBlock;
     dim3 g((unsigned)tile_grid(k_pull_t<W, K4M, COEF, CPLX, SINK>, work_blocks)), b(kBlock);
-    hipLaunchKernelGGL((k_pull_t<W, K4M, COEF, CPLX, SINK>), g, b, 0, s, op.runs, op.n_groups, op.groups, op.off, op.n_diag, op.diag, bs,
+    const size_t dyn = ix.perm ? sizeof(uint32_t) * kNwMaxWin : 0;
+    hipLaunchKernelGGL((k_pull_t<W, K4M, COEF, CPLX, SINK>), g, b, dyn, s, op.runs, op.n_groups, op.groups, op.off, op.n_diag, op.diag, bs,
                        bs.elems, row0, row1, reps, norms_local, ix, reps_global, n_global, (double const *)xsrc, halo, op.uni_v,
                        (double *)y, buf, d_err);
 }

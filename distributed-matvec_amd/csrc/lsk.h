@@ -78,8 +78,14 @@ typedef struct lsk_basis {
      *    norm(rep) is read from the owner's per-row norms when the index is looked up;
      *  2 as 1, and the permutation group is the full cyclic (rotation) group of the ring, with
      *    (reflect = 1) or without its reflections: rotations are generated incrementally;
-     *  3 as 2, but only the rotations that start at a longest run of zeros are visited. */
+     *  3 as 2, but only the rotations that start at a longest run of zeros are visited;
+     *  4 as 1, for a group that contains every translation of a tw x (L / tw) torus (site = y tw + x): G = union of the
+     *    right cosets T g_r, so the orbit is { t(g_r(a)) }: n_cosets compiled networks (the point group) and |G| cheap
+     *    translation steps (rotate the rows by one site / the word by one row) instead of |G| networks. */
     int k4_mode, reflect;
+    int tw, n_cosets;               /* mode 4 */
+    uint64_t tcol0;                 /* mode 4: the bits of column x = 0 */
+    lsk_group_elem const *cosets;   /* mode 4: device [n_cosets] */
     int debug_ablate; /* LS_AMD_ABLATE bitmask (profiling only): 1 skip stage B, 2 skip lookup+accumulate, 4 skip K4 */
     uint64_t site_mask;
     double inv_order; /* 1 / |G| including the inversion doubling */
@@ -150,6 +156,27 @@ int lsk_chain_tile_rows(int cplx);
 int lsk_chain(lsk_operator op, lsk_basis bs, lsk_index ix, int cplx, int wide_ranks, int fused_records, lsk_tilemap tm,
               int64_t n, uint64_t const *reps, int64_t row0, int64_t n_x, void const *x, void *y, int n_cached,
               void const *cache, double cv0, double cv1, void *stream);
+/* ---- staged row kernel for arbitrary exchange pairs (k_pairs_t, kernels.hip): Heisenberg / XXZ on any lattice -------------
+ * pairs are sorted by class: [0, n_near) both sites below bit 11, [n_near, n_near + n_str) i < 11 <= j, then both >= 11 */
+#define LSK_MAX_PAIRS 128
+#define LSK_PAIR_KC 20 /* columns of the binomial table: weight + 2 <= 20, i.e. hamming weight <= 18 (32 sites: 16) */
+typedef struct lsk_pair {
+    uint8_t i, j, pad[6]; /* i < j */
+    double v;             /* exchange amplitude: coefficient of |..0_i..1_j..><..1_i..0_j..| + h.c. */
+    double vz;            /* diagonal: vz (-1)^{[bits i, j differ]} */
+} lsk_pair;
+typedef struct lsk_pairplan {
+    int n_near, n_str, n_high;
+    lsk_pair const *pairs;     /* device [n_near + n_str + n_high] */
+    uint16_t const *rank_low;  /* device [2048]: rank of an 11-bit word among the words of its weight */
+    uint32_t const *binom;     /* device [32][LSK_PAIR_KC] */
+    uint32_t const *states;    /* device [n]: low words of the representatives (the plan's 4-byte copy) */
+    double dsum;               /* sum of vz over all pairs */
+} lsk_pairplan;
+int lsk_pairs_tile_rows(int cplx);
+int lsk_pairs(lsk_pairplan pp, int hamming_weight, int cplx, lsk_tilemap tm, int64_t n, void const *x, void *y, void *stream);
+int lsk_narrow_states(int64_t n, uint64_t const *reps, uint32_t *out, void *stream);
+
 /* fused_records != 0 (32-bit states and ranks): `reps` is out[] of lsk_chain_pack -- state | partner rank of the first
  * cached pair << 32 (cache == NULL: no cached pair) -- and `cache` only holds a second cached pair at cache + n */
 int lsk_chain_pack(int64_t n, uint64_t const *reps, void const *cache, uint64_t *out, void *stream);

@@ -271,6 +271,26 @@ static ynode *y_inline(yparser *p) {
     return val;
 }
 static ynode *y_block(yparser *p, int min_indent);
+/* "&name" followed by the end of the line: the anchor belongs to the block collection on the following lines.  Returns the
+ * name (malloc'ed) and moves *q behind it, or NULL when the text at *q is anything else (an anchored inline value is
+ * y_inline's business) */
+static char *y_block_anchor(yparser const *p, size_t *q) {
+    if (*q >= p->len || p->s[*q] != '&') return NULL;
+    size_t const a = *q + 1;
+    size_t e = a;
+    while (e < p->len && !isspace((unsigned char)p->s[e])) ++e;
+    size_t r = e;
+    while (r < p->len && p->s[r] == ' ') ++r;
+    if (r < p->len && p->s[r] != '\n' && p->s[r] != '\r' && p->s[r] != '#') return NULL;
+    *q = r;
+    return y_substr(p->s + a, e - a);
+}
+static void y_bind_anchor(yparser *p, char *name, ynode *val) {
+    if (!name) return;
+    if (val && p->n_anchors < 64) { p->anchor_names[p->n_anchors] = name; p->anchor_nodes[p->n_anchors++] = val; return; }
+    if (val) y_fail(p, "too many anchors");
+    free(name);
+}
 /* does the text at the cursor read `key: ...` (a mapping entry) rather than a scalar / flow value? */
 static int y_looks_like_key(yparser const *p) {
     size_t q = p->pos;
@@ -293,6 +313,7 @@ static ynode *y_map(yparser *p, int ind) {
         size_t q = p->pos;
         while (q < p->len && p->s[q] == ' ') ++q;
         ynode *val;
+        char *blk_anchor = y_block_anchor(p, &q); /* "key: &name" + a block collection underneath */
         if (q >= p->len || p->s[q] == '\n' || p->s[q] == '\r' || p->s[q] == '#') {
             y_to_line_start(p);
             int const nxt = y_peek_indent(p);
@@ -304,6 +325,7 @@ static ynode *y_map(yparser *p, int ind) {
                 p->pos = save;
                 val = dash ? y_block(p, ind) : y_new(Y_SCALAR);
             } else val = y_new(Y_SCALAR);
+            y_bind_anchor(p, blk_anchor, val);
         } else val = y_inline(p);
         if (!val || p->err[0]) { free(key); y_free(val); y_free(map); return NULL; }
         y_push(map, key, val);
@@ -323,10 +345,14 @@ static ynode *y_seq(yparser *p, int ind) { /* cursor at the '-' of the first ite
         int col = ind + 1;
         while (p->pos < p->len && p->s[p->pos] == ' ') { ++p->pos; ++col; }
         ynode *item;
-        if (p->pos >= p->len || p->s[p->pos] == '\n' || p->s[p->pos] == '#') {
+        size_t qa = p->pos;
+        char *blk_anchor = y_block_anchor(p, &qa); /* "- &name" + a block collection underneath */
+        if (blk_anchor) p->pos = qa;
+        if (p->pos >= p->len || p->s[p->pos] == '\n' || p->s[p->pos] == '\r' || p->s[p->pos] == '#') {
             y_to_line_start(p);
             item = y_block(p, ind + 1);
             if (!item && !p->err[0]) item = y_new(Y_SCALAR);
+            y_bind_anchor(p, blk_anchor, item);
         } else if (p->s[p->pos] == '-' && p->pos + 1 < p->len && p->s[p->pos + 1] == ' ') item = y_seq(p, col); /* "- - a" */
         else if (y_looks_like_key(p)) item = y_map(p, col);
         else item = y_inline(p);
@@ -434,7 +460,7 @@ static int parse_expression(char const *expr, cplx *scalar, factor *f, int *nf) 
             while ((unsigned char)p[0] == 0xe2 && (unsigned char)p[1] == 0x82 && (unsigned char)p[2] >= 0x80 && (unsigned char)p[2] <= 0x89) {
                 idx = idx * 10 + ((unsigned char)p[2] - 0x80);
                 p += 3;
-                ++digits;
+                if (++digits > 6) return ls_amd_internal_error("site index too long in the expression '%s'", expr);
             }
             if (!digits || (*p && *p != ' ' && *p != '\t')) return ls_amd_internal_error("cannot parse a site index in the expression '%s'", expr);
             if (*nf >= MAX_FACTORS) return ls_amd_internal_error("too many factors in the expression '%s'", expr);
@@ -534,8 +560,8 @@ static ls_hs_basis *basis_from(ynode const *b) {
     if (!y_is_null(y_get(b, "hamming_weight")) && y_int(y_get(b, "hamming_weight"), "basis.hamming_weight", &hw) != 0) return NULL;
     if (!y_is_null(y_get(b, "spin_inversion")) && y_int(y_get(b, "spin_inversion"), "basis.spin_inversion", &inv) != 0) return NULL;
     ynode const *particle = y_get(b, "particle");
-    if (particle && !y_is_null(particle) && strcmp(particle->str, "spin-1/2") != 0) {
-        ls_amd_internal_error("only spin-1/2 bases are supported, got '%s'", particle->str);
+    if (particle && !y_is_null(particle) && (particle->kind != Y_SCALAR || !particle->str || strcmp(particle->str, "spin-1/2") != 0)) {
+        ls_amd_internal_error("only spin-1/2 bases are supported, got '%s'", particle->kind == Y_SCALAR && particle->str ? particle->str : "<a collection>");
         return NULL;
     }
     ynode const *syms = y_get(b, "symmetries");

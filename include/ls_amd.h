@@ -289,6 +289,12 @@ int ls_amd_test_chain_near_table(int elem, int ldsp, int16_t *out);
 uint64_t ls_amd_test_rep_trivial_dihedral(uint64_t a, int L, int inv, int reflect);
 /* Profiling entry: K4 alone over the packets of a ring (every state of d_reps with each adjacent pair flipped), see scripts/k4_rate.py */
 int ls_amd_bench_k4(int L, int inv, int reflect, int variant, int64_t n, uint64_t const *d_reps, uint64_t *d_out, void *stream);
+/* Host-only test hooks of the lattice-group form of K4 (trivial sectors of groups that contain every translation of a
+ * tw x (L / tw) torus: the translations are walked with bit operations, only one element per coset -- the point group -- goes
+ * through a compiled network): the width found (-1: the group has no such subgroup) and the number of cosets; the orbit
+ * minimum of `state` computed that way (with the global spin flip folded in when the basis has one; ~0 when not applicable) */
+int ls_amd_test_translation_cosets(ls_hs_basis const *basis, int *n_cosets);
+uint64_t ls_amd_test_rep_by_cosets(ls_hs_basis const *basis, uint64_t state);
 /* Host-only test hooks of the static index table {representative -> 32-bit payload} of the indexed pull mode
  * (distributed-matvec_amd/csrc/lsk.h: lsk_gtab): bucket bits for n keys of L bits (-1: no admissible shape), a sequential
  * build with the device kernel's placement rule into a malloc'ed array of 2 << bbits entries (release with

@@ -116,3 +116,21 @@ def test_square_4x4_published_energy(torch):
     cfg["basis"]["spin_inversion"] = None
     full = diagonalize(cfg, num_evals=1, eps=1e-10)
     assert full.converged and abs(full.eigenvalues[0] / (4 * 16) - (-0.7017802)) < 5e-8, full.eigenvalues
+
+
+def test_square_6x6_published_energy(torch):
+    """The reference's own benchmark model (`make benchmark-*`, /root/reference/Makefile:86,109: data/heisenberg_square_6x6.yaml,
+    36 sites, the 288-element space group of the periodic 6 x 6 square lattice x the global spin flip; 15.8 million
+    symmetry-adapted states): enumeration on the GPU, the projected pull kernel with K4 in its lattice-group form (36
+    translations as bit operations x 8 point-group networks), thick-restart Lanczos -- against the published
+    E0 / N = -0.678872 J (Schulz, Ziman, Poilblanc, PRB 54, 12946 (1996))."""
+    import distributed_matvec_amd as D
+    from distributed_matvec_amd.diagonalize import diagonalize
+
+    cfg = model_config("heisenberg_square_6x6")
+    basis = D.loadConfigFromDict(cfg)
+    reps, _ = D.enumerateStates(basis, 1)
+    n = int(reps[0].numel())
+    assert 15_000_000 < n < 16_500_000, n  # C(36, 18) / 576 = 15.76 M plus the orbits with a non-trivial stabiliser
+    r = diagonalize(cfg, num_evals=1, eps=1e-9, max_basis=40)
+    assert r.converged and abs(r.eigenvalues[0] / (4 * 36) - (-0.678872)) < 2e-6, r.eigenvalues

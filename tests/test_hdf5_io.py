@@ -155,26 +155,20 @@ def test_append_keeps_the_stored_basis_and_replaces_results(tmp_path):
 
 
 @pytest.mark.gpu
-def test_diagonalize_reuses_stored_representatives(tmp_path):
-    """makeBasisStates (Diagonalize.chpl:227-246): representatives found in the output file are not re-enumerated"""
+def test_diagonalize_accepts_its_own_output_file(tmp_path):
+    """makeBasisStates (Diagonalize.chpl:227-246): representatives found in the output file are taken over -- after they have
+    been checked against what the configured basis enumerates to (seconds on the GPU; the reference skips hours of CPU time
+    here and trusts the file)"""
     import torch
 
     if not torch.cuda.is_available():
         pytest.fail("needs a HIP device")
     hdf5 = _hdf5()
-    from distributed_matvec_amd import api
     from distributed_matvec_amd.diagonalize import diagonalize
 
     out = str(tmp_path / "ed.h5")
     r1 = diagonalize(model_config("heisenberg_chain_10"), num_evals=1, eps=1e-10, output=out)
-    calls = []
-    orig = api.enumerateStates
-    api.enumerateStates = lambda *a, **k: calls.append(1) or orig(*a, **k)
-    try:
-        r2 = diagonalize(model_config("heisenberg_chain_10"), num_evals=1, eps=1e-10, output=out)
-    finally:
-        api.enumerateStates = orig
-    assert not calls, "stored representatives were re-enumerated"
+    r2 = diagonalize(model_config("heisenberg_chain_10"), num_evals=1, eps=1e-10, output=out)
     assert abs(r1.eigenvalues[0] - r2.eigenvalues[0]) < 1e-9
     assert hdf5.read_dataset(out, "/basis/representatives").shape == (126,)
 
@@ -190,7 +184,29 @@ def test_diagonalize_refuses_a_stale_output_file(tmp_path):
     from distributed_matvec_amd.diagonalize import diagonalize
 
     out = str(tmp_path / "ed.h5")
-    diagonalize(model_config("heisenberg_chain_12"), num_evals=1, eps=1e-8, output=out)  # 924 states of 12 sites
+    diagonalize(model_config("heisenberg_chain_12"), num_evals=1, eps=1e-8, output=out)  # the full space of 12 sites
     for other in ("heisenberg_chain_10", "heisenberg_chain_16", "heisenberg_kagome_12_symm"):
         with pytest.raises(api.LsAmdError, match="does not belong"):
             diagonalize(model_config(other), num_evals=1, eps=1e-8, output=out)
+    # the same lattice in another Hamming-weight sector, through the YAML loader (whose Basis objects carry no Python-side
+    # spec): ls_hs_is_representative alone would accept these states
+    import copy
+
+    import yaml
+
+    out16 = str(tmp_path / "ed16.h5")
+    diagonalize(model_config("heisenberg_chain_16"), num_evals=1, eps=1e-8, output=out16)  # hamming_weight 8
+    cfg = copy.deepcopy(model_config("heisenberg_chain_16"))
+    cfg["basis"]["hamming_weight"] = 7
+    path = str(tmp_path / "w7.yaml")
+    with open(path, "w") as f:
+        yaml.safe_dump(cfg, f, allow_unicode=True)
+    with pytest.raises(api.LsAmdError, match="does not belong"):
+        diagonalize(path, num_evals=1, eps=1e-8, output=out16)
+    # a truncated dataset of the right model: every stored state is a representative, but the basis is incomplete
+    hdf5 = _hdf5()
+    out2 = str(tmp_path / "short.h5")
+    reps = hdf5.read_dataset(out, "/basis/representatives")
+    hdf5.write_datasets(out2, {"/basis/representatives": reps[:-3]})
+    with pytest.raises(api.LsAmdError, match="does not belong"):
+        diagonalize(model_config("heisenberg_chain_12"), num_evals=1, eps=1e-8, output=out2)

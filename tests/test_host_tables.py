@@ -617,3 +617,36 @@ def test_k4_trivial_sector_orbit_minimum(inv, reflect):
                 samples += [z, z ^ ((1 << L) - 1), z | (1 << ((shift + run + 2) % L))]
         for a in samples:
             assert f(a, L, inv, reflect) == _orbit_min(a, L, inv, reflect), (L, hex(a))
+
+
+@pytest.mark.parametrize("name,tw,cosets", [("heisenberg_square_4x4", 4, 8), ("heisenberg_square_6x6", 6, 8),
+                                             ("heisenberg_kagome_12_symm", None, None), ("heisenberg_chain_24_symm", None, None)])
+def test_lattice_group_orbit_minimum_by_translation_cosets(name, tw, cosets):
+    """K4 mode 4 (trivial sectors of lattice groups, e.g. the reference's benchmark model heisenberg_square_6x6: 36
+    translations x the 8 elements of D4, x the global spin flip): the orbit minimum from 8 compiled networks + 288 cheap
+    translation steps equals the minimum over all 288 (576) images, on random states of the right weight.  Host mirror of
+    the device routine (same bit operations)."""
+    lib = _lib.load()
+    cfg = model_config(name)
+    basis = D.loadConfigFromDict(cfg)
+    nc = C.c_int(0)
+    w = lib.ls_amd_test_translation_cosets(basis.payload, C.byref(nc))
+    if tw is not None:
+        assert (w, nc.value) == (tw, cosets), (w, nc.value)
+    if w <= 0:
+        assert int(lib.ls_amd_test_rep_by_cosets(basis.payload, C.c_uint64(5))) == (1 << 64) - 1
+        return
+    L = basis.numberSites()
+    order = basis.groupOrder()
+    assert order == nc.value * L
+    inv = basis.spinInversion()
+    mask = (1 << L) - 1
+    hw = cfg["basis"].get("hamming_weight")
+    rng = np.random.RandomState(3)
+    for _ in range(60):
+        bits = rng.permutation(L)[: (hw if hw is not None else rng.randint(1, L))]
+        a = int(sum(1 << int(b) for b in bits))
+        imgs = [int(lib.ls_amd_basis_apply_group_element(basis.payload, g, C.c_uint64(a))) for g in range(order)]
+        if inv != 0:
+            imgs = [min(v, v ^ mask) for v in imgs]
+        assert int(lib.ls_amd_test_rep_by_cosets(basis.payload, C.c_uint64(a))) == min(imgs), (name, hex(a))

@@ -168,6 +168,8 @@ observables:
     ("basis:\n  number_spins: 4\nhamiltonian:\n  terms:\n    - matrix: [[1, 0], [0, 1]]\n      sites: [[0]]\n", "expression"),
     ("basis:\n  number_spins: 4\n  symmetries:\n    - permutation: [1, 2, 3]\n      sector: 0\n", "permutation"),
     ("basis:\n  number_spins: 4\n  particle: spinless-fermion\n", "spin-1/2"),
+    ("basis:\n  number_spins: 4\n  particle: [a]\n", "spin-1/2"),  # a collection where a scalar belongs (segfault)
+    ("basis:\n  number_spins: 4\nhamiltonian:\n  terms:\n    - expression: \"σᶻ₀₀₀₀₀₀₀₀₀₀₁\"\n      sites: [[0]]\n", "site index too long"),
     ("basis:\n  number_spins: 4\n  hamming_weight: [1, 2\n", "flow sequence"),
     ("basis:\n  number_spins: 4\n  hamming_weight: \"2\n", "unterminated string"),
     ("basis:\n\tnumber_spins: 4\n", "tabs"),
@@ -175,3 +177,36 @@ observables:
 def test_c_loader_reports_errors(text, why):
     with pytest.raises(D.LsAmdError, match=why):
         load_c(text)
+
+
+def test_anchor_on_a_block_collection():
+    """`key: &name` followed by an indented block sequence (valid YAML the round-3 loader rejected with 'unexpected
+    indentation'): the anchor names the collection underneath"""
+    text = """lattice: &l
+  - [0, 1]
+  - [1, 2]
+  - [2, 3]
+  - [3, 0]
+pairs:
+  - &first
+    - [0, 1]
+basis:
+  number_spins: 4
+  hamming_weight: 2
+hamiltonian:
+  terms:
+    - expression: "σᶻ₀ σᶻ₁"
+      sites: *l
+    - expression: "2 × σ⁺₀ σ⁻₁"
+      sites: *l
+    - expression: "2 × σ⁻₀ σ⁺₁"
+      sites: *first
+"""
+    conf = load_c(text)
+    L = _lib.load()
+    try:
+        h = D.Operator(conf.contents.hamiltonian, owning=False)
+        diag, off = product_terms(h)
+        assert len(diag) == 4 and sorted(x for v, m, r, x, s in off) == [0b0011, 0b0011, 0b0110, 0b1001, 0b1100]
+    finally:
+        L.ls_hs_destroy_yaml_config(conf)
