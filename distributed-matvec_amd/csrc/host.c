@@ -1321,6 +1321,9 @@ struct ls_amd_plan {
     /* tile map of the row kernels (lsk_tilemap in lsk.h) */
     lsk_tilemap tilemap;
     void *d_tilemap;
+    int has_pairs; /* staged row kernel for arbitrary exchange pairs (lsk_pairs): non-ring lattices */
+    lsk_pairplan pairs;
+    void *d_pair_recs, *d_rank_low, *d_pair_binom, *d_states32;
     int has_chain; /* staged row kernel (lsk_chain) */
     int chain_cached;      /* leading non-adjacent exchange groups whose partner ranks are cached */
     void *d_chain_cache;   /* [chain_cached][count] u32, or u64 when chain_wide */
@@ -1829,12 +1832,12 @@ int64_t ls_amd_test_gtab_find(int L, int bbits, uint64_t const *entries, uint64_
 }
 
 /* Staged row kernel (k_chain_t, lsk.h): pull, f64 or c128 vectors, <= 64 sites, the full fixed-weight basis without
- * symmetries, a real operator made of exchange runs plus at most two other exchange pairs.  LS_AMD_CHAIN=0 keeps k_direct. */
+ * symmetries, a real operator made of exchange runs plus at most two other exchange pairs.  LS_AMD_ROW_KERNEL=generic keeps k_direct. */
 static int chain_eligible(ls_amd_plan const *pl) {
     ls_hs_operator const *op = pl->op;
     struct ls_amd_operator_ext const *ext = OEXT(op);
-    char const *e = getenv("LS_AMD_CHAIN");
-    if (e && atoi(e) == 0) return 0;
+    char const *e = getenv("LS_AMD_ROW_KERNEL"); /* auto (default) | generic: k_direct | pairs: k_pairs_t where it applies */
+    if (e && (strcmp(e, "generic") == 0 || strcmp(e, "pairs") == 0)) return 0;
     if (op->basis->number_sites > 64 || op->basis->spin_inversion != 0 || pl->dbs.proj != LSK_PROJ_NONE ||
         !ext->is_real || !ext->is_hermitian || ext->runs.n_runs <= 0 || ext->n_diag <= 0)
         return 0;
@@ -1898,6 +1901,79 @@ static int setup_chain(ls_amd_plan *pl, lsk_index index, int64_t n, uint64_t con
         if (pl->chain_cached <= 1 && pl->d_chain_cache) { lsk_free(pl->d_chain_cache); pl->d_chain_cache = NULL; }
     }
     pl->has_chain = 1;
+    return 0;
+}
+
+/* Staged row kernel for arbitrary exchange pairs (k_pairs_t, lsk.h): pull, the full fixed-weight basis of <= 32 sites without
+ * symmetries, a real Hermitian operator whose off-diagonal groups are all exchange pairs (any two sites, any real amplitude)
+ * and whose diagonal terms are zz terms on those same pairs -- Heisenberg / XXZ on any lattice.  Rings and open chains keep
+ * k_chain_t.  LS_AMD_ROW_KERNEL=generic keeps the generic row kernel (k_direct), =pairs sends rings here too. */
+static int pair_cmp(void const *pa, void const *pb) {
+    lsk_pair const *a = (lsk_pair const *)pa, *b = (lsk_pair const *)pb;
+    int const ca = a->j < 11 ? 0 : (a->i < 11 ? 1 : 2), cb = b->j < 11 ? 0 : (b->i < 11 ? 1 : 2);
+    if (ca != cb) return ca - cb;
+    if (a->i != b->i) return (int)a->i - (int)b->i;
+    return (int)a->j - (int)b->j;
+}
+static int setup_pairs(ls_amd_plan *pl, int64_t n, uint64_t const *d_reps, void *stream) {
+    ls_hs_operator const *op = pl->op;
+    struct ls_amd_operator_ext const *ext = OEXT(op);
+    int const L = op->basis->number_sites, hw = BEXT(op->basis)->hamming_weight;
+    char const *e = getenv("LS_AMD_ROW_KERNEL");
+    if (e && strcmp(e, "generic") == 0) return 0;
+    if (L > 32 || hw < 0 || hw + 2 > LSK_PAIR_KC || op->basis->spin_inversion != 0 || pl->dbs.proj != LSK_PROJ_NONE || !ext->is_real ||
+        !ext->is_hermitian || ext->n_groups < 1 || ext->n_groups > LSK_MAX_PAIRS || n <= 0 || n >= 0xffffffffLL ||
+        ext->n_diag <= 0) /* (no diagonal terms: y is accumulated into, DMV:1062-1063 -- left to the generic kernel) */
+        return 0;
+    lsk_pair recs[LSK_MAX_PAIRS];
+    memset(recs, 0, sizeof(recs));
+    for (int g = 0; g < ext->n_groups; ++g) {
+        lsk_group const *G = &ext->groups[g];
+        if (G->fast != LSK_GROUP_EXCHANGE || G->v_im != 0.0 || __builtin_popcountll(G->x) != 2) return 0;
+        recs[g].i = (uint8_t)__builtin_ctzll(G->x);
+        recs[g].j = (uint8_t)(63 - __builtin_clzll(G->x));
+        recs[g].v = G->v_re;
+    }
+    double dsum = 0.0;
+    for (int t = 0; t < ext->n_diag; ++t) { /* every diagonal term must be a zz term on one of the pairs */
+        lsk_term const *T = &ext->diag[t];
+        if (T->m != 0 || T->r != 0 || T->v_im != 0.0) return 0;
+        int g = 0;
+        while (g < ext->n_groups && ext->groups[g].x != T->s) ++g;
+        if (g == ext->n_groups) return 0;
+        recs[g].vz += T->v_re;
+        dsum += T->v_re;
+    }
+    qsort(recs, (size_t)ext->n_groups, sizeof(lsk_pair), pair_cmp);
+    lsk_pairplan pp;
+    memset(&pp, 0, sizeof(pp));
+    for (int g = 0; g < ext->n_groups; ++g) {
+        if (recs[g].j < 11) ++pp.n_near; else if (recs[g].i < 11) ++pp.n_str; else ++pp.n_high;
+    }
+    pp.dsum = dsum;
+    uint16_t rank_low[2048];
+    for (int w = 0; w < 2048; ++w) {
+        uint64_t r = 0;
+        int k = 0;
+        for (int b = 0; b < 11; ++b) if ((w >> b) & 1) r += binom(b, ++k);
+        rank_low[w] = (uint16_t)r;
+    }
+    uint32_t bin[32 * LSK_PAIR_KC];
+    for (int a = 0; a < 32; ++a) for (int k = 0; k < LSK_PAIR_KC; ++k) bin[a * LSK_PAIR_KC + k] = (uint32_t)binom(a, k);
+    void *q = NULL;
+    if (lsk_malloc(&q, 4 * (size_t)n) != 0) return 0; /* no room for the 4-byte states: the generic kernel */
+    pl->d_states32 = q;
+    if (upload(&pl->d_pair_recs, recs, sizeof(lsk_pair) * (size_t)ext->n_groups) != 0 || upload(&pl->d_rank_low, rank_low, sizeof(rank_low)) != 0 ||
+        upload(&pl->d_pair_binom, bin, sizeof(bin)) != 0)
+        return -1;
+    DEV(lsk_narrow_states(n, d_reps, (uint32_t *)pl->d_states32, stream));
+    pp.pairs = (lsk_pair const *)pl->d_pair_recs;
+    pp.rank_low = (uint16_t const *)pl->d_rank_low;
+    pp.binom = (uint32_t const *)pl->d_pair_binom;
+    pp.states = (uint32_t const *)pl->d_states32;
+    if (build_tilemap(pl, n, lsk_pairs_tile_rows(pl->cplx)) != 0) return -1;
+    pl->pairs = pp;
+    pl->has_pairs = 1;
     return 0;
 }
 
@@ -2078,7 +2154,11 @@ int ls_amd_plan_create(ls_amd_plan **out, ls_hs_operator const *op, ls_amd_dtype
         part_state *ps0 = &pl->parts[0];
         if (pl->family == FAMILY_DIRECT_PULL && combinadic && chain_eligible(pl) &&
             setup_chain(pl, ps0->index, ps0->count, ps0->d_reps, stream) != 0) { ls_amd_plan_destroy(pl); return -1; }
-        if (!pl->has_chain && build_tilemap(pl, ps0->count, 256) != 0) { ls_amd_plan_destroy(pl); return -1; }
+        if (!pl->has_chain && pl->family == FAMILY_DIRECT_PULL && combinadic && setup_pairs(pl, ps0->count, ps0->d_reps, stream) != 0) {
+            ls_amd_plan_destroy(pl);
+            return -1;
+        }
+        if (!pl->has_chain && !pl->has_pairs && build_tilemap(pl, ps0->count, 256) != 0) { ls_amd_plan_destroy(pl); return -1; }
     }
     if (pl->family == FAMILY_TILE && my_partition < 0 && pl->send_capacity > 0) {
         if (lsk_malloc(&pl->d_send, (size_t)pl->send_capacity) != 0) { ls_amd_plan_destroy(pl); return dev_error(); }
@@ -2125,6 +2205,10 @@ void ls_amd_plan_destroy(ls_amd_plan *pl) {
     if (pl->d_tilemap) lsk_free(pl->d_tilemap);
     if (pl->d_chain_cache) lsk_free(pl->d_chain_cache);
     if (pl->d_chain_rec) lsk_free(pl->d_chain_rec);
+    if (pl->d_pair_recs) lsk_free(pl->d_pair_recs);
+    if (pl->d_rank_low) lsk_free(pl->d_rank_low);
+    if (pl->d_pair_binom) lsk_free(pl->d_pair_binom);
+    if (pl->d_states32) lsk_free(pl->d_states32);
     if (pl->d_htab) lsk_free(pl->d_htab);
     if (pl->d_slot_of) lsk_free(pl->d_slot_of);
     if (pl->d_xs) lsk_free(pl->d_xs);
@@ -2373,7 +2457,7 @@ char const *ls_amd_plan_kernel_name(ls_amd_plan const *pl) {
     switch (pl->family) {
     case FAMILY_DIRECT_PUSH: return "direct-push";
     case FAMILY_DIRECT_PULL:
-        return pl->has_chain ? "direct-pull+staged" : "direct-pull";
+        return pl->has_chain ? "direct-pull+staged" : pl->has_pairs ? "direct-pull+pairs" : "direct-pull";
     case FAMILY_TILE_PULL: return pl->idx_mode ? "tile-pull+indexed" : "tile-pull";
     case FAMILY_REPL_DIRECT:
         return pl->has_chain ? "replicated-direct-pull+staged" : "replicated-direct-pull";
@@ -2387,6 +2471,7 @@ int ls_amd_plan_packet_bytes(ls_amd_plan const *pl) { return pl->cplx ? 24 : 16;
  * plus one cached partner rank per cached pair; the generic row kernels read the 8-byte state; the projected pull kernel
  * the state and norm(alpha) */
 int ls_amd_plan_row_bytes(ls_amd_plan const *pl) {
+    if (pl->has_pairs) return 4; /* the plan's 4-byte copy of the states */
     if (pl->has_chain) {
         if (pl->d_chain_rec) return 8;
         int const narrow = pl->op->basis->number_sites <= 32 && !pl->chain_wide;
@@ -2542,6 +2627,8 @@ int ls_amd_matvec(ls_amd_plan *pl, void const *const *d_x, void *const *d_y, voi
             DEV(lsk_chain(pl->dop, pl->dbs, ps->index, pl->cplx, pl->chain_wide, pl->d_chain_rec != NULL, pl->tilemap, ps->count,
                           pl->d_chain_rec ? pl->d_chain_rec : ps->d_reps, 0, ps->count, d_x[0], d_y[0], pl->chain_cached,
                           pl->d_chain_cache, pl->chain_v[0], pl->chain_v[1], stream));
+        else if (pl->has_pairs)
+            DEV(lsk_pairs(pl->pairs, pl->dbs.hamming_weight, pl->cplx, pl->tilemap, ps->count, d_x[0], d_y[0], stream));
         else
             DEV(lsk_direct(pl->dop, pl->dbs, ps->index, pl->cplx, pl->family == FAMILY_DIRECT_PULL, pl->tilemap, ps->d_reps,
                            d_x[0], d_y[0], pl->d_err, stream));

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""What the GENERIC row kernel (k_direct) does on models the staged chain kernels do not take: a periodic
+"""Models the staged CHAIN kernel does not take -- the staged kernel for arbitrary exchange pairs (k_pairs_t, round 4) against the
+generic row kernel (k_direct) and the push formulation: a periodic
 square lattice (Lx x Ly sites, half filling, no symmetries) and the J1-J2 ring, at sizes that leave every cache.
 Prints one JSON line per (model, mode): ms per matvec (HIP events), matvec/s, non-zeros, compulsory bytes and rates."""
 import argparse
@@ -50,7 +51,9 @@ for name in args.models.split(","):
     nnz = n * nb * L // (2 * (L - 1))  # every bond is anti-aligned in a fraction L / (2 (L - 1)) of the half-filling states
     x = [D.fillRandom(reps[0], 42, torch.float64)]
     y = [torch.zeros_like(x[0])]
-    for mode in ("pull", "push"):
+    y_ref = None
+    for mode, rk in (("pull", "auto"), ("pull", "generic"), ("push", "auto")):
+        os.environ["LS_AMD_ROW_KERNEL"] = rk  # auto: the staged kernel for arbitrary exchange pairs; generic: k_direct
         pl = D.MatvecPlan(h, reps, torch.float64, mode=mode)
         pl.enable_timing(256)
         pl.matvec(x, y)
@@ -61,10 +64,14 @@ for name in args.models.split(","):
         pl.check()
         ks = pl.kernel_times_ms()
         ms = sum(ks) / len(ks)
-        alg = n * 24 if mode == "pull" else n * 16 + nnz * 16
+        if y_ref is None:
+            y_ref = y[0].clone()
+        err = float((y[0] - y_ref).abs().max() / y_ref.abs().max())
+        alg = n * (pl.row_bytes + 16) if mode == "pull" else n * 16 + nnz * 16
         print(json.dumps({"model": name, "sites": L, "bonds": nb, "flip_mask_groups": h.numberOffDiagTerms(), "states": n, "nnz": nnz,
                           "mode": mode, "kernel": pl.kernel, "kernel_ms": ms, "matvecs_per_s": 1e3 / ms, "gnnz_per_s": nnz / ms / 1e6,
-                          "algorithmic_GB": alg / 1e9, "algorithmic_GBps": alg / ms / 1e6}), flush=True)
+                          "algorithmic_GB": alg / 1e9, "algorithmic_GBps": alg / ms / 1e6,
+                          "max_rel_diff_vs_first": err}), flush=True)
         pl.destroy()
     del x, y, reps, masks
     torch.cuda.empty_cache()

@@ -751,13 +751,16 @@ def _chain_like_config(L, kind):
 
 ROW_KERNEL_VARIANTS = {
     "default": {},
-    "generic-row-kernel": {"LS_AMD_CHAIN": "0"},
-    "no-uniform-pairs": {"LS_AMD_CHAIN": "0", "LS_AMD_HIGH_PAIR": "0"},
-    "uniform-from-4": {"LS_AMD_CHAIN": "0", "LS_AMD_HIGH_PAIR": "4"},
+    "generic-row-kernel": {"LS_AMD_ROW_KERNEL": "generic"},
+    "no-uniform-pairs": {"LS_AMD_ROW_KERNEL": "generic", "LS_AMD_HIGH_PAIR": "0"},
+    "uniform-from-4": {"LS_AMD_ROW_KERNEL": "generic", "LS_AMD_HIGH_PAIR": "4"},
     "staged-uniform-from-13": {"LS_AMD_HIGH_PAIR": "13"},
     "staged-no-uniform": {"LS_AMD_HIGH_PAIR": "0"},
     "contiguous-tiles": {"LS_AMD_TILE_CHUNK": "0"},
-    "chunked-tiles-generic": {"LS_AMD_CHAIN": "0", "LS_AMD_TILE_CHUNK": "3"},
+    "chunked-tiles-generic": {"LS_AMD_ROW_KERNEL": "generic", "LS_AMD_TILE_CHUNK": "3"},
+    # the staged kernel for arbitrary exchange pairs (the default of everything that is not a ring), here on the rings too
+    "pairs-kernel": {"LS_AMD_ROW_KERNEL": "pairs"},
+    "pairs-kernel-contiguous-tiles": {"LS_AMD_ROW_KERNEL": "pairs", "LS_AMD_TILE_CHUNK": "0"},
 }
 
 
@@ -792,7 +795,9 @@ def test_row_kernel_variants(torch, monkeypatch, variant):
         seen.add(pl.kernel)
         assert np.abs(got - want).max() <= 1e-12 * max(1.0, np.abs(want).max()), (variant, L, kind, pl.kernel)
         if variant == "default" or variant.startswith("staged") or variant == "contiguous-tiles":
-            assert pl.kernel == ("direct-pull" if kind == "j1j2" else "direct-pull+staged"), (kind, pl.kernel)
+            assert pl.kernel == ("direct-pull+pairs" if kind == "j1j2" else "direct-pull+staged"), (kind, pl.kernel)
+        if variant.startswith("pairs-kernel"):
+            assert pl.kernel == "direct-pull+pairs", (kind, pl.kernel)
         # c128 vectors: the complex instantiation of the same kernel family
         xc = x + 1j * (rs.rand(len(want_reps)) - 0.5)
         gotc, plc = run_matvec(torch, D, h, reps, masks, xc, 1, "pull")
@@ -818,7 +823,7 @@ def _ring_config(L, weight):
 def test_staged_kernel_instantiations(torch, monkeypatch, L, weight, cplx, wide):
     """every instantiation of the staged row kernel k_chain_t<W, R, CPLX>: 32- and 64-bit states, 32- and 64-bit ranks
     (LS_AMD_CHAIN_WIDE=1 forces the latter, which no in-tree config is large enough to need), f64 and c128 vectors,
-    against the oracle; and against the generic row kernel (LS_AMD_CHAIN=0)."""
+    against the oracle; and against the generic row kernel (LS_AMD_ROW_KERNEL=generic)."""
     import distributed_matvec_amd as D
     from oracle import c_oracle as CO
     from oracle import model as M
@@ -846,7 +851,7 @@ def test_staged_kernel_instantiations(torch, monkeypatch, L, weight, cplx, wide)
     pl.matvec([xt], [y])
     assert np.abs(y.cpu().numpy() - want).max() <= 1e-12 * max(1.0, np.abs(want).max())
     pl.destroy()
-    monkeypatch.setenv("LS_AMD_CHAIN", "0")
+    monkeypatch.setenv("LS_AMD_ROW_KERNEL", "generic")
     y2 = torch.full_like(xt, -1.0)
     pl2 = D.MatvecPlan(h, reps, xt.dtype, mode="pull")
     assert "staged" not in pl2.kernel
@@ -911,3 +916,64 @@ def test_stage_timing_tree(torch):
         text = pl.timing_report()
         assert "matrixVectorProduct" in text and "producers" in text and "consumers" in text and "over 3 matvecs" in text
         pl.destroy()
+
+
+def _lattice_config(L, weight, bonds, jz=1.0, jxy=1.0, extra=None):
+    """sum over bonds of jxy (sx sx + sy sy) + jz sz sz, optionally a second family `extra` = (bonds, jz, jxy)"""
+    from oracle import model as M
+
+    cfg = M.heisenberg_chain_config(L)
+    cfg["basis"]["hamming_weight"] = weight
+    terms = []
+    for bs_, z, xy in ([(bonds, jz, jxy)] + ([extra] if extra else [])):
+        lat = [list(b) for b in bs_]
+        terms += [{"expression": f"{xy} × σˣ₀ σˣ₁", "sites": lat}, {"expression": f"{xy} × σʸ₀ σʸ₁", "sites": lat},
+                  {"expression": f"{z} × σᶻ₀ σᶻ₁", "sites": lat}]
+    cfg["hamiltonian"]["terms"] = terms
+    return cfg
+
+
+def _square_bonds(w, h):
+    return [(y * w + x, y * w + (x + 1) % w) for y in range(h) for x in range(w)] + [(y * w + x, ((y + 1) % h) * w + x) for y in range(h) for x in range(w)]
+
+
+PAIR_KERNEL_CASES = {
+    "square-4x4": lambda: _lattice_config(16, 8, _square_bonds(4, 4)),
+    "square-5x4-w9": lambda: _lattice_config(20, 9, _square_bonds(5, 4)),                      # not half filling; blocks of odd sizes
+    "square-6x4-xxz": lambda: _lattice_config(24, 12, _square_bonds(6, 4), jz=0.7, jxy=1.3),    # amplitude != zz coupling
+    "j1j2-22": lambda: _lattice_config(22, 11, [(i, (i + 1) % 22) for i in range(22)], extra=([(i, (i + 2) % 22) for i in range(22)], 0.5, 0.5)),
+    "all-near-11": lambda: _lattice_config(11, 5, [(i, j) for i in range(11) for j in range(i + 1, 11)]),   # every pair inside the low part
+    "complete-14": lambda: _lattice_config(14, 7, [(i, j) for i in range(14) for j in range(i + 1, 14)]),   # 91 pairs of every class
+    "star-18-w2": lambda: _lattice_config(18, 2, [(0, j) for j in range(1, 18)] + [(17, j) for j in range(1, 17)]),  # tiny blocks: many segments per wave
+    "xy-only-16": lambda: {**_lattice_config(16, 8, _square_bonds(4, 4)), "drop_zz": True},                  # no diagonal at all: y is accumulated into
+}
+
+
+@pytest.mark.parametrize("case", sorted(PAIR_KERNEL_CASES))
+def test_pairs_kernel_lattices(torch, case):
+    """k_pairs_t (staged row kernel for arbitrary exchange pairs -- what every non-ring lattice runs on one GPU) against the
+    oracle: two-dimensional lattices with wrap-around bonds, J1-J2, XXZ amplitudes, all pairs in the low part, the complete
+    graph (near / straddling / high pairs, long spans), tiny blocks (waves of many segments); f64 and c128."""
+    from oracle import c_oracle as CO
+    from oracle import model as M
+
+    cfg = PAIR_KERNEL_CASES[case]()
+    if cfg.pop("drop_zz", False):
+        cfg["hamiltonian"]["terms"] = [t for t in cfg["hamiltonian"]["terms"] if "ᶻ" not in t["expression"]]
+    o = CO.COracle(M.model_from_config(cfg))
+    want_reps = o.enumerate()
+    D, basis, h, reps, masks = setup_model(torch, cfg, 1)
+    assert np.array_equal(reps[0].cpu().numpy().view(np.uint64), want_reps)
+    rs = np.random.RandomState(7)
+    x = rs.rand(len(want_reps)) - 0.5
+    want = o.local_matvec(want_reps, x)
+    got, pl = run_matvec(torch, D, h, reps, masks, x, 1, "pull")
+    if case == "xy-only-16":
+        assert pl.kernel == "direct-pull"  # no diagonal terms: y is accumulated into (DMV:1062-1063) -- the generic kernel's job
+    else:
+        assert pl.kernel == "direct-pull+pairs", pl.kernel
+    assert np.abs(got - want).max() <= 1e-12 * max(1.0, np.abs(want).max()), (case, np.abs(got - want).max())
+    xc = x + 1j * (rs.rand(len(want_reps)) - 0.5)
+    gotc, plc = run_matvec(torch, D, h, reps, masks, xc, 1, "pull")
+    wantc = o.local_matvec(want_reps, xc)
+    assert np.abs(gotc - wantc).max() <= 1e-12 * max(1.0, np.abs(wantc).max()), case

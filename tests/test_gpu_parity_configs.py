@@ -130,7 +130,7 @@ def test_chain_32_edge_targeted_rows(torch):
     # the same rows through the generic row kernel and through the push (atomics) formulation
     import os
 
-    os.environ["LS_AMD_CHAIN"] = "0"
+    os.environ["LS_AMD_ROW_KERNEL"] = "generic"
     try:
         y2 = torch.empty_like(u)
         pl2 = D.MatvecPlan(h, reps, torch.float64, mode="pull")
@@ -138,7 +138,7 @@ def test_chain_32_edge_targeted_rows(torch):
         pl2.matvec([u], [y2])
         pl2.destroy()
     finally:
-        del os.environ["LS_AMD_CHAIN"]
+        del os.environ["LS_AMD_ROW_KERNEL"]
     assert float((y - y2).abs().max()) <= 1e-12 * float(y.abs().max())
     # the rows around every point where the bits above the low 12 change (where the wave-uniform far-pair split of the staged
     # kernel changes inside a wave) -- a sample of them against the oracle
