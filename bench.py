@@ -381,7 +381,7 @@ def main():
         # invoked exactly like the N = 1 line (`python bench.py --gpus N ...`): become the launcher, one rank per GPU
         # over RCCL, rendezvous on 127.0.0.1 (what the driver's own torch.distributed.run line does)
         have = torch.cuda.device_count()
-        if have < args.gpus and not os.environ.get("LS_AMD_BENCH_SHARE_DEVICE"):
+        if have < args.gpus:
             raise SystemExit(f"--gpus {args.gpus}: only {have} HIP device(s) visible")
         import socket
 
@@ -393,8 +393,6 @@ def main():
                                   "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU")
-    if os.environ.get("LS_AMD_BENCH_SHARE_DEVICE"):  # test hook: several ranks on one GPU (if RCCL allows it)
-        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     distributed = world > 1 or args.force_distributed

@@ -742,11 +742,15 @@ static int basis_device_unlocked(ls_hs_basis const *b, lsk_basis *out) {
     }
     out->k4_mode = 0;
     out->reflect = 0;
-    out->debug_ablate = getenv("LS_AMD_ABLATE") ? atoi(getenv("LS_AMD_ABLATE")) : 0;
+    out->debug_ablate = lsk_ablate_mask(); /* 0 in the shipped library; LS_AMD_ABLATE in profiling builds (make ablate) */
     out->tw = out->n_cosets = 0;
     out->tcol0 = 0;
     out->cosets = NULL;
-    if (trivial && e->order > 1 && !getenv("LS_AMD_GENERAL_K4")) {
+    /* LS_AMD_K4 (test hook): general = the element loop with characters and norms even in trivial sectors; brute = trivial
+     * sectors by the plain loop over every element (no run pruning, no translation cosets) */
+    char const *k4env = getenv("LS_AMD_K4");
+    int const k4_general = k4env && strcmp(k4env, "general") == 0, k4_brute = k4env && strcmp(k4env, "brute") == 0;
+    if (trivial && e->order > 1 && !k4_general) {
         out->k4_mode = 1;
         /* full cyclic group of the ring (every rotation k = 0..L-1), optionally with all reflections? */
         int const L = b->number_sites;
@@ -759,9 +763,9 @@ static int basis_device_unlocked(ls_hs_basis const *b, lsk_basis *out) {
         }
         uint64_t const full = L >= 64 ? ~0ULL : ((1ULL << L) - 1);
         if (!other && rot == full && (rev == 0 || rev == full) && e->order == L * (rev ? 2 : 1) && L >= 3) {
-            out->k4_mode = getenv("LS_AMD_K4_BRUTE") ? 2 : 3; /* 3: longest-zero-run candidate pruning */
+            out->k4_mode = k4_brute ? 2 : 3; /* 3: longest-zero-run candidate pruning */
             out->reflect = rev ? 1 : 0;
-        } else if (!getenv("LS_AMD_K4_BRUTE")) {
+        } else if (!k4_brute) {
             /* a lattice group: its translation subgroup is walked with cheap bit operations, only the coset representatives
              * (the point group) go through compiled networks */
             if (e->tw == 0) find_translation_cosets(e, L);
@@ -1721,70 +1725,9 @@ static int tilemap_host(int64_t n, int TILE, int64_t chunk, uint64_t **out, int6
     *slots_out = slots;
     return 0;
 }
-/* EXPERIMENT (LS_AMD_TILE_SETS = "t[,W]"): sets closed under the exchanges inside the top t site bits.  The states with one
- * value T of the top t bits are a contiguous segment of C(L - t, hw - popcount(T)) rows; segments of equal popcount are
- * parallel (an exchange inside T maps row `off` of one onto row `off` of another).  A set = the tiles [off, off + W TILE) of
- * every segment of one popcount; all its tiles go to ONE XCD, the siblings of one offset back to back. */
-static int tilemap_sets_host(int64_t n, int TILE, int L, int hw, int t, int W, uint64_t **out, int64_t *slots_out) {
-    tile_list lists[8];
-    memset(lists, 0, sizeof(lists));
-    int const Lr = L - t, nT = 1 << t;
-    int64_t *base = (int64_t *)malloc(sizeof(int64_t) * (size_t)(nT + 1)), acc = 0, rows_of[8] = {0};
-    int *segs = (int *)malloc(sizeof(int) * (size_t)nT);
-    for (int T = 0; T < nT; ++T) {
-        base[T] = acc;
-        int const j = __builtin_popcount((unsigned)T);
-        acc += (hw - j >= 0 && hw - j <= Lr) ? (int64_t)binom(Lr, hw - j) : 0;
-    }
-    for (int j = 0; j <= t; ++j) {
-        if (hw - j < 0 || hw - j > Lr) continue;
-        int64_t const len = (int64_t)binom(Lr, hw - j);
-        if (!len) continue;
-        int nseg = 0;
-        for (int T = 0; T < nT; ++T) if (__builtin_popcount((unsigned)T) == j) segs[nseg++] = T;
-        for (int64_t w0 = 0; w0 < len; w0 += (int64_t)W * TILE) {
-            int k = 0;
-            for (int q = 1; q < 8; ++q) if (rows_of[q] < rows_of[k]) k = q;
-            for (int64_t off = w0; off < w0 + (int64_t)W * TILE && off < len; off += TILE)
-                for (int sg = 0; sg < nseg; ++sg) {
-                    int64_t const c = len - off < TILE ? len - off : TILE;
-                    tile_push(&lists[k], base[segs[sg]] + off, c);
-                    rows_of[k] += c;
-                }
-        }
-    }
-    free(base); free(segs);
-    int64_t slots = 0, total = 0;
-    for (int k = 0; k < 8; ++k) if (lists[k].n > slots) slots = lists[k].n;
-    uint64_t *flat = (uint64_t *)calloc((size_t)(8 * slots > 0 ? 8 * slots : 1), sizeof(uint64_t));
-    for (int k = 0; k < 8; ++k) {
-        for (int64_t q = 0; q < lists[k].n; ++q) { flat[k * slots + q] = lists[k].e[q]; total += (int64_t)(lists[k].e[q] >> 48); }
-        free(lists[k].e);
-    }
-    if (total != n) { free(flat); return set_error("internal error: set tile map covers %lld of %lld rows", (long long)total, (long long)n); }
-    *out = flat;
-    *slots_out = slots;
-    return 0;
-}
 static int build_tilemap(ls_amd_plan *pl, int64_t n, int TILE) {
     uint64_t *flat = NULL;
     int64_t slots = 0;
-    {
-        char const *es = getenv("LS_AMD_TILE_SETS");
-        int const L = pl->op->basis->number_sites, hw = BEXT(pl->op->basis)->hamming_weight;
-        if (es && TILE >= 512 && hw >= 0 && L <= 62 && (uint64_t)n == binom(L, hw) && pl->chain_row0 == 0) {
-            int t = 0, W = 1;
-            if (sscanf(es, "%d%*[,:]%d", &t, &W) >= 1 && t >= 1 && t <= 16 && t < L && W >= 1) {
-                if (tilemap_sets_host(n, TILE, L, hw, t, W, &flat, &slots) < 0) return -1;
-                int const up = upload(&pl->d_tilemap, flat, sizeof(uint64_t) * (size_t)(8 * slots > 0 ? 8 * slots : 1));
-                free(flat);
-                if (up) return -1;
-                pl->tilemap.entries = (uint64_t const *)pl->d_tilemap;
-                pl->tilemap.slots_per_xcd = slots;
-                return 0;
-            }
-        }
-    }
     /* Default for the staged kernel: chunks of 256 tiles -- measured on chain_32 with one block per tile
      * (gpurun_out/r2: 9.35 ms contiguous eighths, 8.98 / 8.56 / 8.47 / 8.47 / 8.49 / 8.53 / 8.85 / 9.83 ms at
      * 4 / 32 / 128 / 256 / 512 / 1024 / 4096 / 16384) */

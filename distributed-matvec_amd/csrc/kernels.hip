@@ -12,7 +12,6 @@
 //   K7 ls_hs_state_index             /root/reference/src/DistributedMatrixVector.chpl:96-103
 //   K8 ConcurrentAccessor.localAdd   /root/reference/src/ConcurrentAccessor.chpl:48-54
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
 
 #include <cstdint>
 #include <cstdio>
@@ -131,12 +130,9 @@ static int resident_grid(K kernel, int64_t work_blocks, size_t dyn_lds = 0, int 
 // Grid of the staged (tile) kernels: one block per tile up to the whole tile count.  They walk rows with a plain grid
 // stride (no XCD tile lists), so nothing needs them to be persistent, and their 106 SGPRs put them where the occupancy
 // API over-reports the resident blocks by one (MI355X_MICROARCH.md): a CUs x API-answer grid runs a straggler round
-// with one block per CU.  LS_AMD_TILE_PERSISTENT=1 restores the resident-grid sizing (A/B measurements).
+// with one block per CU (measured r2: k_tile_pull on chain_36_symm 34.8 -> 24.5 ms with the plain grid).
 template <typename K>
-static int tile_grid(K kernel, int64_t work_blocks) {
-    static int persistent = -1;
-    if (persistent < 0) { char const *e = getenv("LS_AMD_TILE_PERSISTENT"); persistent = e && atoi(e) != 0; }
-    if (persistent) return resident_grid(kernel, work_blocks);
+static int tile_grid(K, int64_t work_blocks) {
     if (work_blocks < 1) work_blocks = 1;
     if (work_blocks > (int64_t)1 << 30) work_blocks = (int64_t)1 << 30;
     return (int)work_blocks;
@@ -148,6 +144,11 @@ static int tile_grid(K kernel, int64_t work_blocks) {
 #define LSK_ABLATE 0
 #endif
 constexpr bool kAblate = LSK_ABLATE != 0;
+extern "C" int lsk_ablate_mask(void) {
+    if (!kAblate) return 0;
+    char const *e = getenv("LS_AMD_ABLATE");
+    return e ? atoi(e) : 0;
+}
 
 static inline int grid_for(int64_t n, int per_block = kBlock) {
     int64_t b = (n + per_block - 1) / per_block;
@@ -325,15 +326,17 @@ __device__ __forceinline__ uint32_t delta_swap32(uint32_t x, uint32_t m, int d) 
 }
 __device__ __forceinline__ uint32_t apply_elem32(lsk_group_elem const &e, uint32_t x, int L, uint32_t mask) {
     if (e.kind == LSK_ELEM_BENES) {
-        if ((uint32_t)e.masks[1]) x = delta_swap32(x, (uint32_t)e.masks[1], 16);
-        if ((uint32_t)e.masks[2]) x = delta_swap32(x, (uint32_t)e.masks[2], 8);
-        if ((uint32_t)e.masks[3]) x = delta_swap32(x, (uint32_t)e.masks[3], 4);
-        if ((uint32_t)e.masks[4]) x = delta_swap32(x, (uint32_t)e.masks[4], 2);
-        if ((uint32_t)e.masks[5]) x = delta_swap32(x, (uint32_t)e.masks[5], 1);
-        if ((uint32_t)e.masks[6]) x = delta_swap32(x, (uint32_t)e.masks[6], 2);
-        if ((uint32_t)e.masks[7]) x = delta_swap32(x, (uint32_t)e.masks[7], 4);
-        if ((uint32_t)e.masks[8]) x = delta_swap32(x, (uint32_t)e.masks[8], 8);
-        if ((uint32_t)e.masks[9]) x = delta_swap32(x, (uint32_t)e.masks[9], 16);
+        // only the low words of the masks are read (4-byte scalar loads: half the scalar registers of the 8-byte ones)
+        uint32_t const *const m32 = reinterpret_cast<uint32_t const *>(e.masks);
+        if (m32[2]) x = delta_swap32(x, m32[2], 16);
+        if (m32[4]) x = delta_swap32(x, m32[4], 8);
+        if (m32[6]) x = delta_swap32(x, m32[6], 4);
+        if (m32[8]) x = delta_swap32(x, m32[8], 2);
+        if (m32[10]) x = delta_swap32(x, m32[10], 1);
+        if (m32[12]) x = delta_swap32(x, m32[12], 2);
+        if (m32[14]) x = delta_swap32(x, m32[14], 4);
+        if (m32[16]) x = delta_swap32(x, m32[16], 8);
+        if (m32[18]) x = delta_swap32(x, m32[18], 16);
         return x;
     }
     if (e.kind == LSK_ELEM_REVROT) x = __brev(x) >> (32 - L);
@@ -945,34 +948,28 @@ __global__ __launch_bounds__(kBlock) void k_direct(lsk_runs runs, int n_groups, 
     }
 }
 
-// first pair index handled wave-uniformly by the 32-bit pull row kernels (LS_AMD_HIGH_PAIR; 0 = off).
-// Measured on chain_32: 14 is best for k_direct, 12 (= every pair outside the LDS window) for k_chain.
-static int high_pair_setting(int dflt) {
-    char const *e = getenv("LS_AMD_HIGH_PAIR");
-    int v = e ? atoi(e) : dflt;
-    if (v < 0 || v > 63) v = 0;
-    return v;
-}
-
+// first pair index handled wave-uniformly by the 32-bit pull row kernels.  Measured on chain_32: 14 is best for k_direct,
+// 12 (= every pair outside the LDS window) for k_chain_t.
+constexpr int kDirectHighPair = 14;
 template <typename W, bool CPLX, int INDEX, bool INV, bool PULL>
 static int launch_direct3(lsk_operator op, lsk_basis bs, lsk_index ix, lsk_tilemap tm, uint64_t const *reps,
                           void const *x, void *y, int *d_err, void *stream, int gx, int64_t const *row_gidx) {
     int64_t gb = tm.slots_per_xcd * 8;
-    int64_t cap = op.is_real ? resident_grid(k_direct<W, CPLX, INDEX, INV, PULL, true>, gb)
-                             : resident_grid(k_direct<W, CPLX, INDEX, INV, PULL, false>, gb);
-    int blocks_per_cu = 0; // LS_AMD_BLOCKS_PER_CU: occupancy experiments
-    { char const *e = getenv("LS_AMD_BLOCKS_PER_CU"); blocks_per_cu = e ? atoi(e) : 0; }
-    if (blocks_per_cu > 0 && (int64_t)blocks_per_cu * g_num_cus < cap) cap = (int64_t)blocks_per_cu * g_num_cus;
+    // (f64 vectors only ever meet real operators: the plan refuses the other combination, so it is not instantiated)
+    constexpr bool kCplxOp = CPLX;
+    int64_t cap;
+    if constexpr (kCplxOp) cap = op.is_real ? resident_grid(k_direct<W, CPLX, INDEX, INV, PULL, true>, gb) : resident_grid(k_direct<W, CPLX, INDEX, INV, PULL, false>, gb);
+    else cap = resident_grid(k_direct<W, CPLX, INDEX, INV, PULL, true>, gb);
     cap &= ~(int64_t)7; // XCD dealing needs a multiple of 8
     if (cap < 8) cap = 8;
     if (gb > cap) gb = cap; // persistent: one block per 256-row tile costs more than it gains here (13.3 -> 15.5 ms on chain_32)
     dim3 g((unsigned)gb), b(kBlock);
-    gx = (gx & 1) | (high_pair_setting(14) << 24);
-    if (op.is_real)
+    gx = (gx & 1) | (kDirectHighPair << 24);
+    if (op.is_real || !kCplxOp)
         hipLaunchKernelGGL((k_direct<W, CPLX, INDEX, INV, PULL, true>), g, b, 0, (hipStream_t)stream, op.runs,
                            op.n_groups, op.groups, op.off, op.n_diag, op.diag, bs, ix, tm.entries, tm.slots_per_xcd, reps,
                            (double const *)x, (double *)y, d_err, gx, row_gidx);
-    else
+    else if constexpr (kCplxOp)
         hipLaunchKernelGGL((k_direct<W, CPLX, INDEX, INV, PULL, false>), g, b, 0, (hipStream_t)stream, op.runs,
                            op.n_groups, op.groups, op.off, op.n_diag, op.diag, bs, ix, tm.entries, tm.slots_per_xcd, reps,
                            (double const *)x, (double *)y, d_err, gx, row_gidx);
@@ -996,8 +993,8 @@ static int launch_direct1(lsk_operator op, lsk_basis bs, lsk_index ix, int pull,
                           uint64_t const *reps, void const *x, void *y, int *d_err, void *stream, int gx,
                           int64_t const *row_gidx) {
     // 32-bit states: every site, and every rank, fits 32 bits (C(32, 16) < 2^31)
-    if (bs.number_sites <= 32 && INDEX == LSK_INDEX_COMBINADIC)
-        return launch_direct2<uint32_t, CPLX, INDEX>(op, bs, ix, pull, n, reps, x, y, d_err, stream, gx, row_gidx);
+    if constexpr (INDEX == LSK_INDEX_COMBINADIC)
+        if (bs.number_sites <= 32) return launch_direct2<uint32_t, CPLX, INDEX>(op, bs, ix, pull, n, reps, x, y, d_err, stream, gx, row_gidx);
     return launch_direct2<uint64_t, CPLX, INDEX>(op, bs, ix, pull, n, reps, x, y, d_err, stream, gx, row_gidx);
 }
 static int direct_dispatch(lsk_operator op, lsk_basis bs, lsk_index ix, int cplx, int pull, lsk_tilemap n,
@@ -1099,23 +1096,21 @@ __device__ __forceinline__ void cx_store_nt(double2 *p, double2 v) {
 }
 
 constexpr int kChainFarC = 6; // complex: 6 x 16 bytes in flight per lane
-// gather with a wave-uniform choice of cache policy: nt = the line is not worth keeping in the L2 (experiment, LS_AMD_CHAIN_NT)
-__device__ __forceinline__ double cx_load(double const *p, bool nt) { return nt ? __builtin_nontemporal_load(p) : *p; }
-__device__ __forceinline__ double2 cx_load(double2 const *p, bool) { return *p; }
 
 // launch bounds, second argument = waves per SIMD the register allocation must allow.  256-thread blocks are admitted per CU
 // up to floor(800 / (ceil(sgpr / 16) * 16 + 16)): at 98 SGPRs the 7th block does not fit while the occupancy API still
 // answers 7 -- a straggler round of blocks, measured +24 % (13.1 vs 10.7 ms on chain_32)
-// (f64: 7 blocks = what 22.5 KB of LDS admit; c128: bounds 4 / 5 / 6 measure 14.56 / 14.55 / 14.57 ms)
+// (f64: 7 blocks = what 22.5 KB of LDS admit; c128: bounds 4 / 5 / 6 measure 14.56 / 14.55 / 14.57 ms; the 64-bit f64
+// instantiations -- 33..64 sites, no in-tree config -- need 6: at 7 they spill 20-40 bytes per lane to scratch)
 template <typename W, typename R, bool CPLX, int TILE, bool REC>
-__global__ __launch_bounds__(kBlock, (CPLX ? 5 : 7)) void k_chain_t(lsk_runs runs, int n_diag, lsk_term const *__restrict__ diag,
+__global__ __launch_bounds__(kBlock, (CPLX || sizeof(R) == 8 ? 5 : (sizeof(W) == 8 ? 6 : 7))) void k_chain_t(lsk_runs runs, int n_diag, lsk_term const *__restrict__ diag,
                                                     int hamming_weight, uint4 const *__restrict__ g_img, int img16, int kc,
                                                     int near_off,
                                                     uint64_t const *__restrict__ tilemap, int64_t slots_per_xcd, int64_t n,
                                                     uint64_t const *__restrict__ reps, void const *__restrict__ x_v,
                                                     void *__restrict__ y_v, int hb, int n_cached,
                                                     R const *__restrict__ cache, double cv0, double cv1, int64_t row0,
-                                                    int64_t n_x, int nt_below) {
+                                                    int64_t n_x) {
     typedef typename ChainX<CPLX>::type X;
     typedef WordTraits<W> WT;
     constexpr int NB = ChainTraits<W, R>::NB;
@@ -1210,8 +1205,8 @@ __global__ __launch_bounds__(kBlock, (CPLX ? 5 : 7)) void k_chain_t(lsk_runs run
             const int64_t i = i0 + (ghost ? cnt - 1 : r);
             const R ig = (R)(row0 + i);
             X g0 = cx_zero<X>(), g1 = cx_zero<X>();
-            if (n_cached > 0) g0 = cx_load(x + (t0 != kNone ? t0 : ig), nt_below > 0);
-            if (n_cached > 1) g1 = cx_load(x + (t1 != kNone ? t1 : ig), nt_below > 0);
+            if (n_cached > 0) g0 = x[t0 != kNone ? t0 : ig];
+            if (n_cached > 1) g1 = x[t1 != kNone ? t1 : ig];
             const int jr = own0 + (int)(i - i0);
             const X xr = s_x[jr];
             double dr, di;
@@ -1261,7 +1256,7 @@ __global__ __launch_bounds__(kBlock, (CPLX ? 5 : 7)) void k_chain_t(lsk_runs run
                         if (m) {
                             const int l = __builtin_ctzll(m);
                             m &= m - 1;
-                            xv[u] = cx_load((x + (size_t)(R)(ig0 + readlane_t<R>(off, l))) + dl, (unsigned)(split + l - (nt_below & 255)) < (unsigned)(nt_below >> 8));
+                            xv[u] = (x + (size_t)(R)(ig0 + readlane_t<R>(off, l)))[dl];
                         }
                     }
                     lo_end = split;
@@ -1485,14 +1480,6 @@ static int chain_lds_image(int rsize, int rows, int weight, int elem, int ldsp, 
     return 0;
 }
 
-// EXPERIMENT LS_AMD_CHAIN_NT="lo,hi": the far-pair gathers of pairs [lo, hi) and the cached-pair gathers use the
-// non-temporal policy; packed as lo | (hi - lo) << 8, 0 = off
-static int chain_nt_setting() {
-    char const *e = getenv("LS_AMD_CHAIN_NT");
-    int lo = 0, hi = 0;
-    if (!e || sscanf(e, "%d%*[,:]%d", &lo, &hi) != 2 || lo < 0 || hi <= lo || hi > 64) return 0;
-    return lo | ((hi - lo) << 8);
-}
 template <typename W, typename R, bool CPLX, int TILE, bool REC>
 static int launch_chain(lsk_operator op, lsk_basis bs, lsk_index ix, lsk_tilemap tm, int64_t n, uint64_t const *reps,
                         int64_t row0, int64_t n_x, void const *x, void *y, int n_cached, void const *cache, double cv0,
@@ -1500,58 +1487,29 @@ static int launch_chain(lsk_operator op, lsk_basis bs, lsk_index ix, lsk_tilemap
     int64_t gb = tm.slots_per_xcd * 8;
     ChainImage img;
     if (chain_lds_image((int)sizeof(R), ChainTraits<W, R>::NB, bs.hamming_weight, CPLX ? 16 : 8, CPLX ? 11 : kChainLdsPairs, &img) != 0) return -1;
-    int64_t cap = resident_grid(k_chain_t<W, R, CPLX, TILE, REC>, gb, (size_t)img.bytes);
-    {
-        char const *e = getenv("LS_AMD_BLOCKS_PER_CU"); // occupancy experiments
-        int const bpc = e ? atoi(e) : 0;
-        if (bpc > 0 && (int64_t)bpc * g_num_cus < cap) cap = (int64_t)bpc * g_num_cus;
-    }
-    cap &= ~(int64_t)7;
-    if (cap < 8) cap = 8;
-    // One block per tile by default (block b -> tile b / 8 of XCD list b % 8), NOT a persistent grid: measured on chain_32
-    // 8.47 vs 10.85 ms (f64) and 15.7 vs 20.8 ms (c128).  Persistent blocks start together and stay phase-locked (window
-    // load, LDS pairs, far gathers), so the phases' costs add up; blocks dispatched one by one as others retire drift
-    // apart and the memory phases of some overlap the LDS / ALU phases of others.  LS_AMD_CHAIN_FULLGRID=0: persistent.
-    { char const *e = getenv("LS_AMD_CHAIN_FULLGRID"); if (!e || atoi(e) != 0) cap = gb; }
-    if (gb > cap) gb = cap;
+    // One block per tile (block b -> tile b / 8 of XCD list b % 8), NOT a persistent grid: measured on chain_32 8.47 vs 10.85 ms
+    // (f64) and 15.7 vs 20.8 ms (c128).  Persistent blocks start together and stay phase-locked (window load, LDS pairs, far
+    // gathers), so the phases' costs add up; blocks dispatched one by one as others retire drift apart and the memory phases of
+    // some overlap the LDS / ALU phases of others.
     hipLaunchKernelGGL((k_chain_t<W, R, CPLX, TILE, REC>), dim3((unsigned)gb), dim3(kBlock), (size_t)img.bytes, (hipStream_t)stream, op.runs,
                        op.n_diag, op.diag, bs.hamming_weight, img.dev, img.bytes / 16, img.kc, img.near_off, tm.entries, tm.slots_per_xcd, n, reps, x, y,
-                       high_pair_setting(kChainLdsPairs), n_cached, (R const *)cache, cv0, cv1, row0, n_x,
-                       chain_nt_setting());
+                       kChainLdsPairs, n_cached, (R const *)cache, cv0, cv1, row0, n_x);
     LSK_LAUNCH_CHECK();
     return 0;
 }
 
 // rows per tile: 1024 (f64) / 512 (c128).  Measured r2 on chain_32: doubling them (fewer blocks, 1.5x instead of 2x window
 // loads, but 5 instead of 7 blocks per CU) is slower, 8.72 vs 8.26 ms (f64), 15.5 vs 15.4 ms (c128).
-extern "C" int lsk_chain_tile_rows(int cplx) {
-    if (!cplx && getenv("LS_AMD_CHAIN_TILE") && atoi(getenv("LS_AMD_CHAIN_TILE")) == 512) return 512; // experiment
-    return cplx ? 512 : 1024;
-}
+extern "C" int lsk_chain_tile_rows(int cplx) { return cplx ? 512 : 1024; }
 
 extern "C" int lsk_chain(lsk_operator op, lsk_basis bs, lsk_index ix, int cplx, int wide_ranks, int fused_records, lsk_tilemap tm,
                          int64_t n, uint64_t const *reps, int64_t row0, int64_t n_x, void const *x, void *y, int n_cached,
                          void const *cache, double cv0, double cv1, void *stream) {
     if (n == 0 || tm.slots_per_xcd == 0) return 0;
-    {
-        // profiling only (wrong results): drop every pair >= LS_AMD_CHAIN_MAXLO and the cached pairs, to price the
-        // near / middle / far pairs separately
-        char const *e = getenv("LS_AMD_CHAIN_MAXLO");
-        if (e) {
-            int const maxlo = atoi(e);
-            for (int q = 0; q < op.runs.n_runs; ++q) {
-                int c = maxlo - op.runs.lo0[q];
-                if (c < 0) c = 0;
-                if (c < op.runs.cnt[q]) op.runs.cnt[q] = c;
-            }
-            n_cached = 0;
-        }
-    }
     const bool narrow = bs.number_sites <= 32 && !wide_ranks;
 #define LSK_CHAIN_ARGS op, bs, ix, tm, n, reps, row0, n_x, x, y, n_cached, cache, cv0, cv1, stream
     if (fused_records) { // `reps` is the record array made by lsk_chain_pack (32-bit states and ranks only)
         if (!narrow || cplx) { snprintf(g_err, sizeof(g_err), "lsk_chain: fused records need 32-bit states and ranks and f64 vectors"); return -1; }
-        if (lsk_chain_tile_rows(0) == 512) return launch_chain<uint32_t, uint32_t, false, 512, true>(LSK_CHAIN_ARGS);
         return launch_chain<uint32_t, uint32_t, false, 1024, true>(LSK_CHAIN_ARGS);
     }
     if (narrow) {
@@ -1946,9 +1904,8 @@ extern "C" int lsk_tile(lsk_operator op, lsk_basis bs, lsk_index ix, int cplx, i
         if (cplx) {                                                                                        \
             if (op.is_real) { g.x = tile_grid(k_tile<W, PM1, true, true, GC>, work_blocks); hipLaunchKernelGGL((k_tile<W, PM1, true, true, GC>), g, b, 0, s, LSK_TILE_ARGS); } \
             else { g.x = tile_grid(k_tile<W, PM1, true, false, GC>, work_blocks); hipLaunchKernelGGL((k_tile<W, PM1, true, false, GC>), g, b, 0, s, LSK_TILE_ARGS); } \
-        } else {                                                                                           \
-            if (op.is_real) { g.x = tile_grid(k_tile<W, PM1, false, true, GC>, work_blocks); hipLaunchKernelGGL((k_tile<W, PM1, false, true, GC>), g, b, 0, s, LSK_TILE_ARGS); } \
-            else { g.x = tile_grid(k_tile<W, PM1, false, false, GC>, work_blocks); hipLaunchKernelGGL((k_tile<W, PM1, false, false, GC>), g, b, 0, s, LSK_TILE_ARGS); } \
+        } else { /* f64 vectors: real operators only (the plan refuses the rest) */                        \
+            g.x = tile_grid(k_tile<W, PM1, false, true, GC>, work_blocks); hipLaunchKernelGGL((k_tile<W, PM1, false, true, GC>), g, b, 0, s, LSK_TILE_ARGS); \
         }                                                                                                  \
     } while (0)
     const bool narrow = bs.number_sites <= 32 && bs.proj == LSK_PROJ_FULL;
@@ -2273,8 +2230,7 @@ extern "C" int lsk_tile_pull(lsk_operator op, lsk_basis bs, lsk_index ix_global,
             if (op.is_real) { g.x = tile_grid(k_tile_pull<W, PM1, true, true>, work_blocks); hipLaunchKernelGGL((k_tile_pull<W, PM1, true, true>), g, b, 0, s, LSK_TP_ARGS); } \
             else { g.x = tile_grid(k_tile_pull<W, PM1, true, false>, work_blocks); hipLaunchKernelGGL((k_tile_pull<W, PM1, true, false>), g, b, 0, s, LSK_TP_ARGS); } \
         } else {                                                                                                \
-            if (op.is_real) { g.x = tile_grid(k_tile_pull<W, PM1, false, true>, work_blocks); hipLaunchKernelGGL((k_tile_pull<W, PM1, false, true>), g, b, 0, s, LSK_TP_ARGS); } \
-            else { g.x = tile_grid(k_tile_pull<W, PM1, false, false>, work_blocks); hipLaunchKernelGGL((k_tile_pull<W, PM1, false, false>), g, b, 0, s, LSK_TP_ARGS); } \
+            g.x = tile_grid(k_tile_pull<W, PM1, false, true>, work_blocks); hipLaunchKernelGGL((k_tile_pull<W, PM1, false, true>), g, b, 0, s, LSK_TP_ARGS); /* f64: real operators only */ \
         }                                                                                                       \
     } while (0)
     if (bs.number_sites <= 32) { if (bs.chars_pm1) LSK_TP_LAUNCH(uint32_t, true); else LSK_TP_LAUNCH(uint32_t, false); }
@@ -2524,7 +2480,7 @@ extern "C" int lsk_test_nw_find(uint64_t const *reps, int n, uint64_t key) {
 }
 
 template <typename W, int K4M, int COEF, bool CPLX, int SINK>
-__global__ __launch_bounds__(kBlock) void k_pull_t(lsk_runs runs, int n_groups, lsk_group const *__restrict__ groups,
+__global__ __launch_bounds__(kBlock, (COEF == COEF_CPLX ? 4 : 6)) void k_pull_t(lsk_runs runs, int n_groups, lsk_group const *__restrict__ groups,
                                                    lsk_term const *__restrict__ off, int n_diag,
                                                    lsk_term const *__restrict__ diag, lsk_basis bs,
                                                    lsk_group_elem const *__restrict__ elems, int64_t row0, int64_t row1,
@@ -2561,6 +2517,9 @@ __global__ __launch_bounds__(kBlock) void k_pull_t(lsk_runs runs, int n_groups, 
             inv_na = na > 0.0 ? 1.0 / na : 0.0;
         }
         if (FUSED) { if (CPLX) { s_acc[2 * tid] = 0.0; s_acc[2 * tid + 1] = 0.0; } else s_acc[tid] = 0.0; }
+        // the diagonal coefficient now, not in the epilogue: the run tables then do not stay in scalar registers across stage B
+        double dr = 0.0, di = 0.0;
+        if (FUSED && valid && n_diag > 0) diag_coeff<uint64_t, REAL>(runs, n_diag, diag, a, dr, di);
         int64_t gbase = 0;
         int wn = 0;
         uint64_t v0 = 0;
@@ -2710,16 +2669,20 @@ __global__ __launch_bounds__(kBlock) void k_pull_t(lsk_runs runs, int n_groups, 
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             if (kAblate && (bs.debug_ablate & 1)) { head = (head + cnt) & (kWvRing - 1); cnt = 0; } // profiling builds: stage A only
-            while (cnt >= 128) { // stage B on full chunks, two at a time while the ring has them
-                chunks(std::integral_constant<int, 2>(), 64);
-                head = (head + 128) & (kWvRing - 1);
-                cnt -= 128;
+            // stage B on full chunks: two at a time while the ring has them (trivial sectors; the element loops of the other
+            // sectors are long enough by themselves, and two chunks of their state do not fit the scalar registers)
+            constexpr int KMAX = K4M == K4_TRIVIAL ? 2 : 1;
+            while (cnt >= 64 * KMAX) {
+                chunks(std::integral_constant<int, KMAX>(), 64);
+                head = (head + 64 * KMAX) & (kWvRing - 1);
+                cnt -= 64 * KMAX;
             }
-            if (cnt >= 64) {
-                chunks(std::integral_constant<int, 1>(), 64);
-                head = (head + 64) & (kWvRing - 1);
-                cnt -= 64;
-            }
+            if constexpr (KMAX == 2)
+                if (cnt >= 64) {
+                    chunks(std::integral_constant<int, 1>(), 64);
+                    head = (head + 64) & (kWvRing - 1);
+                    cnt -= 64;
+                }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
@@ -2732,8 +2695,6 @@ __global__ __launch_bounds__(kBlock) void k_pull_t(lsk_runs runs, int n_groups, 
                 const uint32_t own = ix.perm ? ix.perm[ig] : (uint32_t)ig;
                 const double back = K4M == K4_TRIVIAL ? inv_na : 1.0; // xsrc holds x * norm(rep) in the prescaling K4 modes
                 const double sc = NC == 0 ? uni_v * inv_na : 1.0;     // one amplitude for every packet: applied once per row
-                double dr = 0.0, di = 0.0;
-                if (n_diag > 0) diag_coeff<uint64_t, REAL>(runs, n_diag, diag, a, dr, di);
                 if constexpr (CPLX) {
                     const X xo = xv[own];
                     const double xr = xo.x * back, xi = xo.y * back;
@@ -3211,17 +3172,84 @@ extern "C" int lsk_diag_coeffs(lsk_operator op, int64_t n, uint64_t const *alpha
     return 0;
 }
 
+// Exclusive prefix sum of int64 values (the layout converters, the enumeration, ls_chpl_operator_apply_off_diag): three small
+// kernels per level -- per-block scan of kScanPer elements + block totals, the totals scanned recursively, the offsets added
+// back.  (Hand-written: hipCUB's DeviceScan brought 225 trampoline kernels into the library for these three call sites.)
+constexpr int kScanItems = 8;
+constexpr int kScanPer = kBlock * kScanItems;
+struct ScanArrayIn {
+    int64_t const *v;
+    __device__ __forceinline__ int64_t operator()(int64_t i) const { return v[i]; }
+};
+struct ScanMaskIn { // 1 where masks[i] == p
+    uint8_t const *masks;
+    uint8_t p;
+    __device__ __forceinline__ int64_t operator()(int64_t i) const { return masks[i] == p ? 1 : 0; }
+};
+template <typename In>
+__global__ __launch_bounds__(kBlock) void k_scan_block(In in, int64_t n, int64_t *__restrict__ out, int64_t *__restrict__ totals) {
+    __shared__ int64_t s_wave[kBlock / 64];
+    const int64_t base = (int64_t)blockIdx.x * kScanPer + (int64_t)threadIdx.x * kScanItems;
+    int64_t v[kScanItems], sum = 0;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) { v[k] = base + k < n ? in(base + k) : 0; sum += v[k]; }
+    // inclusive scan of the per-thread sums inside the wave, then across the four waves
+    int64_t inc = sum;
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int64_t o = __shfl_up(inc, d);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) s_wave[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    int64_t wave_off = 0, total = 0;
+    for (int w = 0; w < kBlock / 64; ++w) { if (w < (int)(threadIdx.x >> 6)) wave_off += s_wave[w]; total += s_wave[w]; }
+    int64_t run = wave_off + inc - sum;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) { if (base + k < n) out[base + k] = run; run += v[k]; }
+    if (threadIdx.x == 0) totals[blockIdx.x] = total;
+}
+__global__ __launch_bounds__(kBlock) void k_scan_add(int64_t n, int64_t *__restrict__ out, int64_t const *__restrict__ offsets) {
+    const int64_t off = offsets[blockIdx.x];
+    const int64_t base = (int64_t)blockIdx.x * kScanPer;
+    for (int k = threadIdx.x; k < kScanPer; k += kBlock)
+        if (base + k < n) out[base + k] += off;
+}
+// scratch for n elements: totals of every level, one after the other
+static int64_t scan_scratch_elems(int64_t n) {
+    int64_t e = 0;
+    while (n > 1) { n = (n + kScanPer - 1) / kScanPer; e += n; if (n == 1) break; }
+    return e > 0 ? e : 1;
+}
+template <typename In>
+static int scan_level(In in, int64_t n, int64_t *out, int64_t *scratch, hipStream_t s) {
+    const int64_t blocks = (n + kScanPer - 1) / kScanPer;
+    hipLaunchKernelGGL((k_scan_block<In>), dim3((unsigned)blocks), dim3(kBlock), 0, s, in, n, out, scratch);
+    LSK_LAUNCH_CHECK();
+    if (blocks > 1) {
+        ScanArrayIn t{scratch};
+        if (scan_level<ScanArrayIn>(t, blocks, scratch, scratch + blocks, s) != 0) return -1; // in place: totals -> their exclusive sums
+        hipLaunchKernelGGL(k_scan_add, dim3((unsigned)blocks), dim3(kBlock), 0, s, n, out, scratch);
+        LSK_LAUNCH_CHECK();
+    }
+    return 0;
+}
+template <typename In>
+static int exclusive_scan(In in, int64_t n, int64_t *out, int64_t *scratch, hipStream_t s) {
+    if (n <= 0) return 0;
+    if ((n + kScanPer - 1) / kScanPer > 0x7fffffffLL) { snprintf(g_err, sizeof(g_err), "scan too large"); return -1; }
+    return scan_level<In>(in, n, out, scratch, s);
+}
 static int exclusive_scan_i64(int64_t n, int64_t const *in, int64_t *out, hipStream_t s) {
     if (n == 0) return 0;
-    if (n > 0x7fffffff) { snprintf(g_err, sizeof(g_err), "scan too large"); return -1; }
-    void *tmp = nullptr;
-    size_t bytes = 0;
-    LSK_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, in, out, (int)n, s));
-    LSK_CHECK(hipMalloc(&tmp, bytes ? bytes : 8));
-    hipError_t e = hipcub::DeviceScan::ExclusiveSum(tmp, bytes, in, out, (int)n, s);
-    hipError_t e2 = hipStreamSynchronize(s);
-    (void)hipFree(tmp);
-    LSK_CHECK(e);
+    int64_t *scratch = nullptr;
+    LSK_CHECK(hipMalloc((void **)&scratch, 8 * (size_t)scan_scratch_elems(n)));
+    ScanArrayIn src{in};
+    const int rc = exclusive_scan<ScanArrayIn>(src, n, out, scratch, s);
+    const hipError_t e2 = hipStreamSynchronize(s);
+    (void)hipFree(scratch);
+    if (rc != 0) return -1;
     LSK_CHECK(e2);
     return 0;
 }
@@ -3357,11 +3385,6 @@ extern "C" int lsk_mask_counts(int64_t n, uint8_t const *masks, int P, int64_t *
 // precede it (exclusive scan of the indicator, one pass per partition); block->hashed then is
 // dest[mask[i]][position[i]] = src[i] and hashed->block its inverse.  Stable by construction, which
 // is what keeps every hashed part ascending (BlockToHashed.chpl:87-208, HashedToBlock.chpl:67-153).
-struct MaskEq {
-    uint8_t const *masks;
-    uint8_t p;
-    __host__ __device__ int64_t operator()(int64_t i) const { return masks[i] == p ? 1 : 0; }
-};
 template <int ELT>
 __global__ __launch_bounds__(kBlock) void k_permute(int64_t n, uint8_t const *__restrict__ masks, uint8_t p,
                                                     int64_t const *__restrict__ pos, char const *src, char *dst,
@@ -3382,23 +3405,12 @@ static int permute_by_masks(int64_t n, uint8_t const *masks, int P, int elt_size
                             void *block_mut, void *const *parts, int to_hashed, hipStream_t s) {
     if (n == 0) return 0;
     if (elt_size != 8 && elt_size != 16) { snprintf(g_err, sizeof(g_err), "layout converters support 8/16-byte elements"); return -1; }
-    if (n > 0x7fffffff) { snprintf(g_err, sizeof(g_err), "layout converter: n too large"); return -1; }
-    int64_t *pos = nullptr;
+    int64_t *pos = nullptr, *tmp = nullptr;
     LSK_CHECK(hipMalloc((void **)&pos, 8 * n));
-    void *tmp = nullptr;
-    size_t tmp_bytes = 0;
-    hipcub::CountingInputIterator<int64_t> cnt(0);
+    if (hipMalloc((void **)&tmp, 8 * (size_t)scan_scratch_elems(n)) != hipSuccess) { (void)hipFree(pos); snprintf(g_err, sizeof(g_err), "layout converter: no memory"); return -1; }
     for (int p = 0; p < P; ++p) {
-        MaskEq f{masks, (uint8_t)p};
-        hipcub::TransformInputIterator<int64_t, MaskEq, hipcub::CountingInputIterator<int64_t>> it(cnt, f);
-        size_t bytes = 0;
-        LSK_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, it, pos, (int)n, s));
-        if (bytes > tmp_bytes) {
-            if (tmp) (void)hipFree(tmp);
-            LSK_CHECK(hipMalloc(&tmp, bytes));
-            tmp_bytes = bytes;
-        }
-        LSK_CHECK(hipcub::DeviceScan::ExclusiveSum(tmp, bytes, it, pos, (int)n, s));
+        ScanMaskIn f{masks, (uint8_t)p};
+        if (exclusive_scan<ScanMaskIn>(f, n, pos, tmp, s) != 0) { (void)hipFree(pos); (void)hipFree(tmp); return -1; }
         char const *src = to_hashed ? (char const *)block_const : (char const *)parts[p];
         char *dst = to_hashed ? (char *)parts[p] : (char *)block_mut;
         if (elt_size == 8) hipLaunchKernelGGL(k_permute<8>, dim3(grid_for(n)), dim3(kBlock), 0, s, n, masks, (uint8_t)p, pos, src, dst, to_hashed);

@@ -119,6 +119,7 @@ typedef struct lsk_tilemap {
 
 /* runtime ---------------------------------------------------------------------------------- */
 char const *lsk_last_error(void);
+int lsk_ablate_mask(void); /* profiling builds (make ablate): the LS_AMD_ABLATE stage switches; the shipped library returns 0 */
 int lsk_device_count(void);
 int lsk_set_device(int device);
 int lsk_malloc(void **p, size_t bytes);

@@ -5,7 +5,7 @@ export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/r4job3; mkdir -p $OUT
 timeout 600 python scripts/lattice_bench.py heisenberg_square_6x6 5 2>&1 | grep model | tee $OUT/square6x6_cosets.json
-LS_AMD_K4_BRUTE=1 timeout 900 python scripts/lattice_bench.py heisenberg_square_6x6 2 2>&1 | grep model | tee $OUT/square6x6_element_loop.json
+LS_AMD_K4=brute timeout 900 python scripts/lattice_bench.py heisenberg_square_6x6 2 2>&1 | grep model | tee $OUT/square6x6_element_loop.json
 ( time timeout 1500 python -m pytest tests/test_gpu_diagonalize.py tests/test_gpu_matvec.py tests/test_gpu_loopback.py tests/test_hdf5_io.py -m gpu -q -x > $OUT/pytest_b.log 2>&1 ) 2>&1 | grep real; tail -5 $OUT/pytest_b.log
 ( time python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err ) 2>&1 | grep real; tail -3 $OUT/bench_default.err
 python - <<'PY'

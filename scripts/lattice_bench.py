@@ -47,4 +47,4 @@ pp.destroy()
 print(json.dumps({"model": name, "sites": basis.numberSites(), "group_order": basis.groupOrder(), "spin_inversion": basis.spinInversion(),
                   "states": n, "nnz": nnz, "enumerate_s": t_enum, "plan_s": t_plan, "kernel": pl.kernel, "ms_per_matvec": dt * 1e3,
                   "kernel_ms_avg": sum(ks) / max(1, len(ks)), "matvecs_per_s": 1.0 / dt, "gnnz_per_s": nnz / dt / 1e9,
-                  "k4_env": {k: os.environ[k] for k in ("LS_AMD_K4_BRUTE", "LS_AMD_GENERAL_K4") if k in os.environ}}), flush=True)
+                  "k4_env": {k: os.environ[k] for k in ("LS_AMD_K4",) if k in os.environ}}), flush=True)

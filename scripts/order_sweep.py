@@ -21,15 +21,14 @@ ap.add_argument("--dtype", default="f64")
 ap.add_argument("--configs", default="")
 args = ap.parse_args()
 
-KEYS = ("LS_AMD_TILE_CHUNK", "LS_AMD_HIGH_PAIR", "LS_AMD_ROW_KERNEL", "LS_AMD_TILE_SETS", "LS_AMD_CHAIN_NT", "LS_AMD_CHAIN_TILE")
+KEYS = ("LS_AMD_TILE_CHUNK", "LS_AMD_ROW_KERNEL")
 # the first configuration of a process runs 5-9 % faster than the later ones (clock / power state): compare variants in
 # separate processes (--configs ";" = one default run), or read the trailing {} against the leading one
 DEFAULT_CONFIGS = [
     {},
     {"LS_AMD_TILE_CHUNK": "32"},
     {"LS_AMD_TILE_CHUNK": "512"},
-    {"LS_AMD_CHAIN_FULLGRID": "0"},
-    {"LS_AMD_CHAIN_REC": "0"},
+    {"LS_AMD_ROW_KERNEL": "pairs"},
     {"LS_AMD_ROW_KERNEL": "generic"},
     {},
 ]

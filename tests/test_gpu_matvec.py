@@ -561,7 +561,7 @@ def test_general_k4_path_on_trivial_sector(torch, monkeypatch):
     want = oracle_for(name).local_matvec(want_reps, x)
     for general in (False, True):
         if general:
-            monkeypatch.setenv("LS_AMD_GENERAL_K4", "1")
+            monkeypatch.setenv("LS_AMD_K4", "general")
         for P in (1, 3):
             D_, basis, h, reps, masks = setup_model(torch, model_config(name), P)
             got, pl = run_matvec(torch, D_, h, reps, masks, x, P)
@@ -752,10 +752,6 @@ def _chain_like_config(L, kind):
 ROW_KERNEL_VARIANTS = {
     "default": {},
     "generic-row-kernel": {"LS_AMD_ROW_KERNEL": "generic"},
-    "no-uniform-pairs": {"LS_AMD_ROW_KERNEL": "generic", "LS_AMD_HIGH_PAIR": "0"},
-    "uniform-from-4": {"LS_AMD_ROW_KERNEL": "generic", "LS_AMD_HIGH_PAIR": "4"},
-    "staged-uniform-from-13": {"LS_AMD_HIGH_PAIR": "13"},
-    "staged-no-uniform": {"LS_AMD_HIGH_PAIR": "0"},
     "contiguous-tiles": {"LS_AMD_TILE_CHUNK": "0"},
     "chunked-tiles-generic": {"LS_AMD_ROW_KERNEL": "generic", "LS_AMD_TILE_CHUNK": "3"},
     # the staged kernel for arbitrary exchange pairs (the default of everything that is not a ring), here on the rings too
@@ -794,7 +790,7 @@ def test_row_kernel_variants(torch, monkeypatch, variant):
         got, pl = run_matvec(torch, D, h, reps, masks, x, 1, "pull")
         seen.add(pl.kernel)
         assert np.abs(got - want).max() <= 1e-12 * max(1.0, np.abs(want).max()), (variant, L, kind, pl.kernel)
-        if variant == "default" or variant.startswith("staged") or variant == "contiguous-tiles":
+        if variant in ("default", "contiguous-tiles"):
             assert pl.kernel == ("direct-pull+pairs" if kind == "j1j2" else "direct-pull+staged"), (kind, pl.kernel)
         if variant.startswith("pairs-kernel"):
             assert pl.kernel == "direct-pull+pairs", (kind, pl.kernel)
@@ -803,7 +799,7 @@ def test_row_kernel_variants(torch, monkeypatch, variant):
         gotc, plc = run_matvec(torch, D, h, reps, masks, xc, 1, "pull")
         wantc = o.local_matvec(want_reps, xc)
         assert np.abs(gotc - wantc).max() <= 1e-12 * max(1.0, np.abs(wantc).max()), (variant, L, kind, plc.kernel)
-    if variant in ("generic-row-kernel", "no-uniform-pairs", "uniform-from-4", "chunked-tiles-generic"):
+    if variant in ("generic-row-kernel", "chunked-tiles-generic"):
         assert seen == {"direct-pull"}
 
 
