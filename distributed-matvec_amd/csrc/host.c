@@ -1299,6 +1299,10 @@ typedef struct part_state {
     lsk_round_layout *d_layouts; /* [rounds] device */
     int64_t max_send_bytes;
     int64_t *h_beta_off, *h_val_off; /* [rounds][P] host copies of the layout */
+    /* packet producer with per-wave rings (lsk_tile_wv, P <= 64): position of every (wave of 64 rows, destination) inside the
+     * round's send segments, fixed by the plan's count pass -- [sum over rounds of waves][P] u32 */
+    uint32_t *d_wtab;     /* owned */
+    int64_t *wtab_first;  /* [rounds] first wave of the round in d_wtab */
 } part_state;
 
 enum { FAMILY_DIRECT_PUSH = 0, FAMILY_DIRECT_PULL = 1, FAMILY_TILE = 2, FAMILY_TILE_PULL = 3,
@@ -1653,6 +1657,11 @@ int64_t ls_amd_internal_plan_split_enable(ls_amd_plan *pl, int64_t max_bytes) {
 }
 int64_t ls_amd_internal_plan_split_rows(ls_amd_plan const *pl) { return pl->split_rows; }
 
+/* LS_AMD_PACKETS=block keeps the block-wide packet lists of k_tile (cursor atomics); default: per-wave rings (k_tile_wv) */
+static int packets_wave_rings(void) {
+    char const *e = getenv("LS_AMD_PACKETS");
+    return !(e && strcmp(e, "block") == 0);
+}
 static int64_t rows_per_round_default(void) {
     char const *e = getenv("LS_AMD_ROWS_PER_ROUND");
     if (e) { long long v = atoll(e); if (v > 0) return (int64_t)v; }
@@ -1981,12 +1990,52 @@ static int plan_setup_part(ls_amd_plan *pl, part_state *ps, int part_id, int num
     lsk_round_layout *layouts = (lsk_round_layout *)calloc(rounds, sizeof(lsk_round_layout));
     int const w = pl->cplx ? 16 : 8;
     unsigned long long hc[LSK_MAX_PARTS];
+    /* the per-wave producer (deterministic send layout) whenever lane d of a wave can stand for destination d */
+    int const wave_rings = P <= lsk_tile_wv_max_parts() && packets_wave_rings();
+    uint32_t *h_wtab = NULL;
+    int64_t n_waves = 0;
+    if (wave_rings) {
+        ps->wtab_first = (int64_t *)calloc((size_t)rounds + 1, sizeof(int64_t));
+        for (int r = 0; r < rounds; ++r) {
+            int64_t row0 = ps->count * r / rounds, row1 = ps->count * (r + 1) / rounds;
+            ps->wtab_first[r] = n_waves;
+            n_waves += (row1 - row0 + 63) / 64;
+        }
+        ps->wtab_first[rounds] = n_waves;
+        void *pw;
+        size_t const bytes = sizeof(uint32_t) * (size_t)(n_waves > 0 ? n_waves : 1) * (size_t)P;
+        if (lsk_malloc(&pw, bytes) != 0) { free(layouts); return dev_error(); }
+        ps->d_wtab = (uint32_t *)pw;
+        if (lsk_memset_async(pw, 0, bytes, stream) != 0) { free(layouts); return dev_error(); }
+        for (int r = 0; r < rounds; ++r) {
+            int64_t row0 = ps->count * r / rounds, row1 = ps->count * (r + 1) / rounds;
+            if (lsk_tile_wv(pl->dop, pl->dbs, ps->index, pl->cplx, 1, P, part_id, row0, row1, ps->d_reps, ps->d_norms, NULL, NULL,
+                            ps->d_wtab + (size_t)ps->wtab_first[r] * P, NULL, NULL, pl->d_err, stream) != 0) { free(layouts); return dev_error(); }
+        }
+        h_wtab = (uint32_t *)malloc(bytes);
+        if (!h_wtab || lsk_sync(stream) != 0 || lsk_d2h(h_wtab, pw, bytes) != 0) { free(h_wtab); free(layouts); return dev_error(); }
+    }
     for (int r = 0; r < rounds; ++r) {
         int64_t row0 = ps->count * r / rounds, row1 = ps->count * (r + 1) / rounds;
-        if (lsk_memset_async(pl->d_counts, 0, 8 * LSK_MAX_PARTS, stream) != 0 ||
-            lsk_tile(pl->dop, pl->dbs, ps->index, pl->cplx, 1, P, part_id, row0, row1, ps->d_reps, ps->d_norms,
-                     NULL, NULL, pl->d_cursors, NULL, NULL, pl->d_counts, pl->d_err, stream) != 0 ||
-            lsk_sync(stream) != 0 || lsk_d2h(hc, pl->d_counts, 8 * (size_t)P) != 0) { free(layouts); return dev_error(); }
+        if (wave_rings) {
+            /* counts -> exclusive offsets along the waves of the round, destination by destination; the own partition's
+             * packets never enter the send buffer */
+            for (int d = 0; d < P; ++d) hc[d] = 0;
+            for (int64_t wv = ps->wtab_first[r]; wv < ps->wtab_first[r + 1]; ++wv) {
+                uint32_t *row = h_wtab + (size_t)wv * P;
+                for (int d = 0; d < P; ++d) {
+                    uint32_t const c = row[d];
+                    if (d != part_id && hc[d] + c > 0xffffffffULL) { free(h_wtab); free(layouts); return set_error("more than 2^32 packets for one destination in one round: raise the number of rounds"); }
+                    row[d] = (uint32_t)hc[d];
+                    hc[d] += c;
+                }
+            }
+        } else {
+            if (lsk_memset_async(pl->d_counts, 0, 8 * LSK_MAX_PARTS, stream) != 0 ||
+                lsk_tile(pl->dop, pl->dbs, ps->index, pl->cplx, 1, P, part_id, row0, row1, ps->d_reps, ps->d_norms,
+                         NULL, NULL, pl->d_cursors, NULL, NULL, pl->d_counts, pl->d_err, stream) != 0 ||
+                lsk_sync(stream) != 0 || lsk_d2h(hc, pl->d_counts, 8 * (size_t)P) != 0) { free(layouts); return dev_error(); }
+        }
         int64_t off = 0;
         for (int d = 0; d < P; ++d) {
             pl->nnz += (int64_t)hc[d];
@@ -1999,6 +2048,11 @@ static int plan_setup_part(ls_amd_plan *pl, part_state *ps, int part_id, int num
             off += (8 + w) * c;
         }
         if (off > ps->max_send_bytes) ps->max_send_bytes = off;
+    }
+    if (wave_rings) {
+        int const rcw = lsk_h2d(ps->d_wtab, h_wtab, sizeof(uint32_t) * (size_t)(n_waves > 0 ? n_waves : 1) * (size_t)P);
+        free(h_wtab);
+        if (rcw != 0) { free(layouts); return dev_error(); }
     }
     void *p;
     if (lsk_malloc(&p, sizeof(lsk_round_layout) * (size_t)rounds) != 0) { free(layouts); return dev_error(); }
@@ -2138,6 +2192,8 @@ void ls_amd_plan_destroy(ls_amd_plan *pl) {
             if (ps->d_table) lsk_free(ps->d_table);
             if (ps->d_norms) lsk_free(ps->d_norms);
             if (ps->d_layouts) lsk_free(ps->d_layouts);
+            if (ps->d_wtab) lsk_free(ps->d_wtab);
+            free(ps->wtab_first);
             free(ps->send_counts); free(ps->h_beta_off); free(ps->h_val_off);
         }
         free(pl->parts);
@@ -2467,11 +2523,15 @@ int ls_amd_diag(ls_amd_plan *pl, void const *d_x, void *d_y, void *stream) {
 static int generate_round(ls_amd_plan *pl, part_state *ps, int pid, int round, void const *d_x, void *d_y,
                           void *d_send, void *stream) {
     int64_t row0 = ps->count * round / ps->rounds, row1 = ps->count * (round + 1) / ps->rounds;
-    if (pl->P > 1) DEV(lsk_memset_async(pl->d_cursors, 0, 8 * (size_t)pl->P, stream));
+    if (pl->P > 1 && !ps->d_wtab) DEV(lsk_memset_async(pl->d_cursors, 0, 8 * (size_t)pl->P, stream));
     int const st = stage_begin(pl, ST_GENERATE, stream);
     int slot = timing_begin(pl, stream);
-    DEV(lsk_tile(pl->dop, pl->dbs, ps->index, pl->cplx, 0, pl->P, pid, row0, row1, ps->d_reps, ps->d_norms, d_x,
-                 d_y, pl->d_cursors, ps->d_layouts + round, d_send, pl->d_counts, pl->d_err, stream));
+    if (ps->d_wtab)
+        DEV(lsk_tile_wv(pl->dop, pl->dbs, ps->index, pl->cplx, 0, pl->P, pid, row0, row1, ps->d_reps, ps->d_norms, d_x, d_y,
+                        ps->d_wtab + (size_t)ps->wtab_first[round] * pl->P, ps->d_layouts + round, d_send, pl->d_err, stream));
+    else
+        DEV(lsk_tile(pl->dop, pl->dbs, ps->index, pl->cplx, 0, pl->P, pid, row0, row1, ps->d_reps, ps->d_norms, d_x,
+                     d_y, pl->d_cursors, ps->d_layouts + round, d_send, pl->d_counts, pl->d_err, stream));
     timing_end(pl, slot, stream);
     stage_end(pl, st, stream);
     return 0;

@@ -1919,6 +1919,202 @@ extern "C" int lsk_tile(lsk_operator op, lsk_basis bs, lsk_index ix, int cplx, i
 }
 
 // ---------------------------------------------------------------------------------------------
+// Packet producer with per-WAVE packet rings and a DETERMINISTIC send layout (k_tile_wv; P <= 64).
+//
+// k_tile above synchronises its four waves three times per list (stage A | stage B | bucket reservation | write-out), ranks
+// the packets of a list with 64-lane LDS atomics on P addresses and reserves the buckets with global atomics on P cursors:
+// 75 % of its wave cycles wait (profiles/r2_packets_chain28_P8_sq_counters.txt).  Here a wave owns its 64 rows, a 256-slot
+// ring of the LDS list and -- in lane d -- the cursor of destination d inside the round's send segment:
+//   * the plan's count pass (COUNT) leaves the number of packets of every (wave, destination) in wtab[wave][P]; the host
+//     turns them into exclusive offsets along the waves of a round, so the position of every packet in the send buffer is
+//     fixed by the plan: no cursor atomics, no bucket reservation, and the packet order (hence the order in which the
+//     consumer's atomics arrive) no longer depends on the block schedule;
+//   * stage A appends the packets of three flip-mask groups to the ring, stage B takes chunks of 64 out of it: projection
+//     (inversion | orbit minimum | state_info), owner hash, then a loop over the DISTINCT destinations of the chunk:
+//     ballot + mbcnt = rank inside the chunk, readlane of the destination's cursor and segment offsets, one store of beta
+//     and one of the value straight into the send segment (consecutive chunks continue the same run of every segment).
+//   No block barrier anywhere; LDS holds only the rings (16 KB f64, 24 KB c128 per block).
+// ---------------------------------------------------------------------------------------------
+constexpr int kTwRing = 256;
+constexpr int kTwGroups = 3;
+__device__ __forceinline__ int64_t readlane_i64(int64_t v, int lane) {
+    return (int64_t)readlane_t<uint64_t>((uint64_t)v, lane);
+}
+template <typename W, bool PM1, bool CPLX, bool REAL, bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_tile_wv(int n_groups, lsk_group const *__restrict__ groups,
+                                                    lsk_term const *__restrict__ off, lsk_basis bs,
+                                                    lsk_group_elem const *__restrict__ elems, lsk_index ix, Owner owner,
+                                                    int me, int64_t row0, int64_t row1, uint64_t const *__restrict__ reps,
+                                                    double const *__restrict__ norms, double const *__restrict__ x, double *y,
+                                                    uint32_t *__restrict__ wtab, lsk_round_layout const *__restrict__ layout,
+                                                    char *send, int *err) {
+    constexpr int kCap = (kBlock / 64) * kTwRing;
+    __shared__ uint64_t s_beta[kCap];
+    __shared__ double s_val[COUNT ? 1 : kCap * (CPLX ? 2 : 1)];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int rb = wave * kTwRing;
+    const int P = (int)owner.P;
+    // lane d keeps what the wave knows about destination d: segment offsets of the round and the running cursor
+    int64_t seg_b = 0, seg_v = 0;
+    if (!COUNT && lane < P) { seg_b = layout->beta_off[lane]; seg_v = layout->val_off[lane]; }
+    for (int64_t t0 = row0 + (int64_t)blockIdx.x * kBlock; t0 < row1; t0 += (int64_t)gridDim.x * kBlock) {
+        if (t0 + (wave << 6) >= row1) continue; // wave-uniform: nothing below synchronises the block
+        const int64_t i = t0 + tid;
+        const bool valid = i < row1;
+        uint64_t a = 0;
+        double xr = 0.0, xi = 0.0;
+        if (valid) {
+            a = reps[i];
+            if (COUNT) xr = 1.0; // the packet set must not depend on x (exact send counts)
+            else {
+                if (CPLX) { xr = x[2 * i]; xi = x[2 * i + 1]; } else xr = x[i];
+                if (bs.proj == LSK_PROJ_FULL) { // fold 1 / norm(alpha) into x  (BatchedOperator.chpl:198-202)
+                    const double na = norms[i];
+                    const double s = na > 0.0 ? 1.0 / na : 0.0;
+                    xr *= s;
+                    xi *= s;
+                }
+            }
+        }
+        const int64_t wg = ((t0 - row0) >> 6) + wave; // this wave's 64 rows inside the round
+        uint32_t cur = 0;                             // lane d: packets so far (COUNT) | next position in segment d
+        if (!COUNT && lane < P) cur = wtab[wg * P + lane];
+        int head = 0, cnt = 0; // wave-uniform: the ring holds [head, head + cnt) mod kTwRing
+        auto chunk = [&](int m) {
+            bool live = lane < m;
+            const int e = rb + ((head + lane) & (kTwRing - 1));
+            uint64_t beta = live ? s_beta[e] : 0;
+            double vr = 0.0, vi = 0.0;
+            if (!COUNT) { if (CPLX) { vr = s_val[2 * e]; vi = s_val[2 * e + 1]; } else vr = s_val[e]; }
+            if (bs.proj == LSK_PROJ_INVERSION) {
+                const uint64_t f = beta ^ bs.site_mask;
+                if (f < beta) { beta = f; vr *= (double)bs.spin_inversion; vi *= (double)bs.spin_inversion; }
+            } else if (bs.proj == LSK_PROJ_FULL && bs.k4_mode != 0) {
+                beta = (uint64_t)rep_trivial<W>(bs, elems, (W)beta); // norm(rep) applied at index time
+            } else if (bs.proj == LSK_PROJ_FULL) {
+                if (live) {
+                    W rep; double chr, chi, stab;
+                    state_info_w<W, PM1>(bs, elems, (W)beta, rep, chr, chi, stab);
+                    const double n2 = stab * bs.inv_order;
+                    if (n2 > 1e-12) {
+                        const double nb = sqrt(n2);
+                        beta = (uint64_t)rep;
+                        if (CPLX) { const double tr = (vr * chr - vi * chi) * nb, ti = (vr * chi + vi * chr) * nb; vr = tr; vi = ti; }
+                        else vr = vr * chr * nb;
+                    } else live = false; // zero-norm orbit: c == 0 => skipped (DMV:110)
+                }
+            }
+            const int dest = live ? owner_of(beta, owner) : -1;
+            bool remote = live;
+            if (!COUNT) {
+                if (live && dest == me) {
+                    remote = false;
+                    const int64_t idx = search_index(ix, beta);
+                    if (idx < 0) atomicExch(err, 1);
+                    else {
+                        if (bs.proj == LSK_PROJ_FULL && bs.k4_mode != 0) { const double nb = norms[idx]; vr *= nb; vi *= nb; }
+                        if (CPLX) { atomic_add_f64(y + 2 * idx, vr); atomic_add_f64(y + 2 * idx + 1, vi); }
+                        else atomic_add_f64(y + idx, vr);
+                    }
+                }
+            }
+            // one pass per distinct destination of the chunk (<= min(P, 64))
+            unsigned long long rem = __ballot(remote);
+            while (rem) {
+                const int l = __builtin_ctzll(rem);
+                const int d = __builtin_amdgcn_readlane(dest, l);
+                const bool mine = remote && dest == d;
+                const unsigned long long mm = __ballot(mine);
+                if (!COUNT) {
+                    const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)cur, d);
+                    const int64_t ob = readlane_i64(seg_b, d), ov = readlane_i64(seg_v, d);
+                    if (mine) {
+                        const size_t pos = (size_t)base + (size_t)__popcll(mm & ((1ULL << lane) - 1));
+                        reinterpret_cast<uint64_t *>(send + ob)[pos] = beta;
+                        double *pv = reinterpret_cast<double *>(send + ov);
+                        if (CPLX) { pv[2 * pos] = vr; pv[2 * pos + 1] = vi; } else pv[pos] = vr;
+                    }
+                }
+                if (lane == d) cur += (uint32_t)__popcll(mm);
+                rem &= ~mm;
+            }
+        };
+        for (int g0 = 0; g0 < n_groups; g0 += kTwGroups) {
+            const int g1 = min(g0 + kTwGroups, n_groups);
+            for (int g = g0; g < g1; ++g) { // stage A: append
+                lsk_group const G = groups[g];
+                double cr = 0.0, ci = 0.0;
+                if (valid) group_coeff<REAL>(G, off, a, cr, ci);
+                const bool act = valid && (cr != 0.0 || (!REAL && ci != 0.0));
+                const unsigned long long ball = __ballot(act);
+                if (act) {
+                    const int slot = rb + ((head + cnt + __popcll(ball & ((1ULL << lane) - 1))) & (kTwRing - 1));
+                    s_beta[slot] = a ^ G.x;
+                    if (!COUNT) {
+                        if (CPLX) { s_val[2 * slot] = cr * xr - ci * xi; s_val[2 * slot + 1] = cr * xi + ci * xr; }
+                        else s_val[slot] = cr * xr;
+                    }
+                }
+                cnt += __popcll(ball);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            while (cnt >= 64) {
+                chunk(64);
+                head = (head + 64) & (kTwRing - 1);
+                cnt -= 64;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (cnt > 0) chunk(cnt);
+        if (COUNT && lane < P) wtab[wg * P + lane] = cur;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+extern "C" int lsk_tile_wv_max_parts(void) { return 64; }
+// rows [row0, row1) of partition `me` (row0 = first row of the round: wave w of the round owns rows row0 + 64 w ...).
+// count_only: wtab[w][P] <- packets of wave w per destination (the own partition included); otherwise wtab holds the
+// exclusive offsets of every (wave, destination) inside the round's segments and the packets are written to d_send.
+extern "C" int lsk_tile_wv(lsk_operator op, lsk_basis bs, lsk_index ix, int cplx, int count_only, int P, int me,
+                           int64_t row0, int64_t row1, uint64_t const *reps, double const *norms, void const *x, void *y,
+                           uint32_t *d_wtab, lsk_round_layout const *d_layout, void *d_send, int *d_err, void *stream) {
+    if (row1 <= row0 || op.n_groups == 0) return 0;
+    if (P > lsk_tile_wv_max_parts() || P < 1 || !d_wtab) { snprintf(g_err, sizeof(g_err), "lsk_tile_wv: bad partition count %d or no wave table", P); return -1; }
+    if (!count_only && ix.kind != LSK_INDEX_SEARCH) { snprintf(g_err, sizeof(g_err), "lsk_tile_wv needs a SEARCH index"); return -1; }
+    Owner ow = make_owner(P);
+    dim3 g(1), b(kBlock);
+    const int64_t work_blocks = (row1 - row0 + kBlock - 1) / kBlock;
+    hipStream_t s = (hipStream_t)stream;
+#define LSK_TW_ARGS op.n_groups, op.groups, op.off, bs, bs.elems, ix, ow, me, row0, row1, reps, norms, (double const *)x, (double *)y, \
+        d_wtab, d_layout, (char *)d_send, d_err
+#define LSK_TW_ONE(W, PM1, CPLX, REAL)                                                                                           \
+    do {                                                                                                                         \
+        if (count_only) { g.x = tile_grid(k_tile_wv<W, PM1, CPLX, REAL, true>, work_blocks); hipLaunchKernelGGL((k_tile_wv<W, PM1, CPLX, REAL, true>), g, b, 0, s, LSK_TW_ARGS); } \
+        else { g.x = tile_grid(k_tile_wv<W, PM1, CPLX, REAL, false>, work_blocks); hipLaunchKernelGGL((k_tile_wv<W, PM1, CPLX, REAL, false>), g, b, 0, s, LSK_TW_ARGS); } \
+    } while (0)
+#define LSK_TW_LAUNCH(W, PM1)                                                                                  \
+    do {                                                                                                       \
+        if (cplx) { if (op.is_real) LSK_TW_ONE(W, PM1, true, true); else LSK_TW_ONE(W, PM1, true, false); }    \
+        else LSK_TW_ONE(W, PM1, false, true); /* f64 vectors: real operators only (the plan refuses the rest) */ \
+    } while (0)
+    const bool narrow = bs.number_sites <= 32 && bs.proj == LSK_PROJ_FULL;
+    if (narrow) { if (bs.chars_pm1) LSK_TW_LAUNCH(uint32_t, true); else LSK_TW_LAUNCH(uint32_t, false); }
+    else if (bs.proj == LSK_PROJ_FULL) { if (bs.chars_pm1) LSK_TW_LAUNCH(uint64_t, true); else LSK_TW_LAUNCH(uint64_t, false); }
+    else LSK_TW_LAUNCH(uint64_t, true); // no projection: PM1 is irrelevant
+#undef LSK_TW_LAUNCH
+#undef LSK_TW_ONE
+#undef LSK_TW_ARGS
+    LSK_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Staged PULL kernel for symmetry-projected bases (Hermitian operators):
 //   y[r] = d(r) x[r] + sum_j conj(H~[r'_j, r]) x[r'_j],   H~[r', r] = c conj(chi0) n(r') / n(r)
 // Same stage A as k_tile (LDS term list per 256-row tile), stage B projects every packet, looks the

@@ -193,6 +193,14 @@ int lsk_tile(lsk_operator op, lsk_basis bs, lsk_index ix, int cplx, int count_on
              int64_t row0, int64_t row1, uint64_t const *reps, double const *norms, void const *x,
              void *y, unsigned long long *d_cursors, lsk_round_layout const *d_layout, void *d_send,
              unsigned long long *d_counts, int *d_err, void *stream);
+/* the same producer with per-wave packet rings and a send layout fixed by the plan (P <= lsk_tile_wv_max_parts()):
+ * count_only: d_wtab[wave][P] <- packets of every (wave of 64 rows counted from row0, destination); otherwise d_wtab holds
+ * the exclusive offsets of every (wave, destination) inside the round's segments of *d_layout.  No cursors, no atomics on
+ * the send side; the packet order does not depend on the block schedule. */
+int lsk_tile_wv_max_parts(void);
+int lsk_tile_wv(lsk_operator op, lsk_basis bs, lsk_index ix, int cplx, int count_only, int P, int me,
+                int64_t row0, int64_t row1, uint64_t const *reps, double const *norms, void const *x, void *y,
+                uint32_t *d_wtab, lsk_round_layout const *d_layout, void *d_send, int *d_err, void *stream);
 /* replicated-x pull (Hermitian operators): rows of ONE partition against the whole vector in global
  * ascending order.  ix_global indexes the global basis; row_gidx[i] = global index of local row i
  * (may be NULL for lsk_direct_gx with closed-form indices, and for lsk_tile_pull when local == global). */

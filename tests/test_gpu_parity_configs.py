@@ -296,6 +296,43 @@ def test_chain_32_and_36_symm_complex_vectors(torch):
         torch.cuda.empty_cache()
 
 
+def test_chain_40_symm_complex_vectors(torch):
+    """the north-star dtype on BASELINE config[4]/[5]: complex128 vectors on all 861 725 794 representatives of the 40-site ring --
+    oracle-recomputed rows, and H(x_re) + i H(x_im) through the f64 kernel on every row"""
+    import distributed_matvec_amd as D
+    from distributed_matvec_amd import config
+    from oracle import c_oracle as CO
+    from oracle import model as M
+
+    cfg = config.heisenberg_chain_config(40, symm=True)
+    basis, h = D.loadConfigFromDict(cfg, hamiltonian=True)
+    reps, masks = D.enumerateStates(basis, 1)
+    r = reps[0]
+    n = r.numel()
+    xc = D.fillRandom(r, 23, torch.complex128)
+    yc = torch.empty_like(xc)
+    pl = D.MatvecPlan(h, reps, torch.complex128, mode="pull")
+    assert pl.kernel == "tile-pull+indexed"
+    pl.matvec([xc], [yc])
+    pl.destroy()
+    o = CO.COracle(M.model_from_config(cfg))
+    rs = np.random.RandomState(41)
+    rows = np.unique(np.concatenate([rs.randint(0, n, size=4000), np.arange(256), np.arange(n - 256, n)]))
+    rows_t, want = oracle_rows(torch, o, r, rows, xc, projected=True)
+    assert_rows(yc[rows_t].cpu().numpy(), want, "chain_40_symm c128 rows")
+    plr = D.MatvecPlan(h, reps, torch.float64, mode="pull")
+    scale = float(yc.abs().max())
+    for part in ("real", "imag"):
+        xp = getattr(xc, part).contiguous()
+        yp = torch.empty_like(xp)
+        plr.matvec([xp], [yp])
+        assert float((getattr(yc, part) - yp).abs().max()) <= 1e-12 * scale, part
+        del xp, yp
+    plr.destroy()
+    del xc, yc
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("mode", ["packets", "replicated"])
 def test_chain_36_symm_eight_ranks(torch, mode):
     """BASELINE config[3] as it will run on a node: heisenberg_chain_36_symm hash-partitioned over EIGHT ranks, the exchange
