@@ -249,6 +249,7 @@ struct ls_amd_basis_ext {
     int tw, n_cosets;
     int *coset_ids;
     lsk_group_elem *d_cosets;
+    uint32_t *d_trow;    /* mode 4, tw <= 8: the row table of torus_min on the device */
     int owns_representatives;
     uint64_t *d_reps_cache; /* device copy of `representatives` for the host-pointer entry points */
     uint64_t d_reps_count;
@@ -563,6 +564,7 @@ void ls_hs_destroy_basis(ls_hs_basis *b) {
     basis_drop_device_caches(b);
     if (e->d_elems) lsk_free(e->d_elems);
     if (e->d_cosets) lsk_free(e->d_cosets);
+    if (e->d_trow) lsk_free(e->d_trow);
     if (e->owns_representatives && b->representatives.elts) free(b->representatives.elts);
     free(e->gen_perms); free(e->gen_sectors); free(e->perms); free(e->elems); free(e->coset_ids);
     reg_del(b);
@@ -703,6 +705,13 @@ uint64_t ls_amd_test_rep_by_cosets(ls_hs_basis const *b, uint64_t a) {
     int const tw = e->tw, th = L / tw;
     uint64_t col0 = 0, best = ~0ULL;
     for (int y = 0; y < th; ++y) col0 |= 1ULL << (y * tw);
+    if (tw <= 8) { /* what the kernels run: the row table picks the translations that can be minimal */
+        uint32_t rowtab[256];
+        lsk_torus_rowtab(tw, rowtab);
+        for (int r = 0; r < e->n_cosets; ++r)
+            best = lsk_test_torus_min(host_apply_elem(&e->elems[e->coset_ids[r]], a, L), L, tw, b->spin_inversion != 0, rowtab, best);
+        return best;
+    }
     for (int r = 0; r < e->n_cosets; ++r) {
         uint64_t v = host_apply_elem(&e->elems[e->coset_ids[r]], a, L);
         for (int j = 0; j < th; ++j) {
@@ -746,6 +755,7 @@ static int basis_device_unlocked(ls_hs_basis const *b, lsk_basis *out) {
     out->tw = out->n_cosets = 0;
     out->tcol0 = 0;
     out->cosets = NULL;
+    out->trow = NULL;
     /* LS_AMD_K4 (test hook): general = the element loop with characters and norms even in trivial sectors; brute = trivial
      * sectors by the plain loop over every element (no run pruning, no translation cosets) */
     char const *k4env = getenv("LS_AMD_K4");
@@ -780,6 +790,14 @@ static int basis_device_unlocked(ls_hs_basis const *b, lsk_basis *out) {
                     if (bad) { if (p) lsk_free(p); return dev_error(); }
                     e->d_cosets = (lsk_group_elem *)p;
                 }
+                if (!e->d_trow && e->tw <= 8) {
+                    uint32_t rowtab[256];
+                    void *p = NULL;
+                    lsk_torus_rowtab(e->tw, rowtab);
+                    if (lsk_malloc(&p, sizeof(rowtab)) != 0 || lsk_h2d(p, rowtab, sizeof(uint32_t) << e->tw) != 0) { if (p) lsk_free(p); return dev_error(); }
+                    e->d_trow = (uint32_t *)p;
+                }
+                out->trow = e->d_trow;
                 out->k4_mode = 4;
                 out->tw = e->tw;
                 out->n_cosets = e->n_cosets;

@@ -580,6 +580,75 @@ extern "C" int lsk_bench_k4(int L, int inv, int reflect, int variant, int64_t n,
     return 0;
 }
 
+// Minimum of a word over the tw * th translations of a tw x th torus (site = y tw + x) and, with `inv`, of its complement:
+// the rows are the digits of the word, so the minimum puts on top the smallest value ANY row takes under ANY rotation inside
+// the row.  rowtab[r] (made by the host, lsk_torus_rowtab) holds for a row value r: bits 0-7 the minimum over its rotations,
+// 8-15 the set of rotation amounts that reach it, 16-23 the maximum, 24-31 the amounts that reach that (the rows of the
+// complemented word are the complements, so its row minima are the complements of the maxima).  One table load per row, then
+// only the (row, amount) pairs that put the overall row minimum on top are built and compared -- 1-2 of the 2 tw th
+// candidates on a half-filled 6 x 6 lattice -- and none at all when an earlier coset already has a smaller top row.
+// (tw <= 8.  Until mid round 4: tw * th steps of "rotate the rows by one site / the word by one row" per coset.)
+template <typename W>
+__host__ __device__ __forceinline__ W torus_min(W v, int L, int tw, W mask, W col0, bool inv, uint32_t const *__restrict__ rowtab, W best) {
+    const int th = L / tw;
+    const uint32_t rmask = (1u << tw) - 1u;
+    uint32_t mstar = 0xffffffffu;
+    for (int k = 0; k < th; ++k) {
+        const uint32_t e = rowtab[(uint32_t)(v >> (k * tw)) & rmask];
+        uint32_t m = e & 0xffu;
+        if (inv) { const uint32_t m2 = ~(e >> 16) & rmask; m = m2 < m ? m2 : m; }
+        mstar = m < mstar ? m : mstar;
+    }
+    if ((W)mstar > (W)(best >> (L - tw))) return best; // (best == ~0 at the start: never true)
+    const W nv = (W)(~v & mask);
+    for (int k = 0; k < th; ++k) {
+        const uint32_t e = rowtab[(uint32_t)(v >> (k * tw)) & rmask];
+        const int up = tw * (th - 1 - k); // row k -> top row
+        for (int fam = 0; fam <= (inv ? 1 : 0); ++fam) {
+            const uint32_t m = fam == 0 ? (e & 0xffu) : (~(e >> 16) & rmask);
+            if (m != mstar) continue;
+            uint32_t amounts = fam == 0 ? ((e >> 8) & 0xffu) : (e >> 24);
+            const W word = fam == 0 ? v : nv;
+            while (amounts) {
+                const int i = k4_ctz32(amounts);
+                amounts &= amounts - 1;
+                const W lo = (W)(col0 * (W)((1u << i) - 1u)); // columns 0 .. i-1 of every row (no carries: 2^i - 1 < 2^tw)
+                W c = i == 0 ? word : (W)((((W)(word << i)) & (W)~lo & mask) | ((W)(word >> (tw - i)) & lo));
+                c = rotl_sites<W>(c, up, L, mask);
+                best = c < best ? c : best;
+            }
+        }
+    }
+    return best;
+}
+// the row table of torus_min for rows of tw <= 8 bits: out[2^tw]
+extern "C" int lsk_torus_rowtab(int tw, uint32_t *out) {
+    if (tw < 1 || tw > 8) return -1;
+    const uint32_t rmask = (1u << tw) - 1u;
+    for (uint32_t r = 0; r <= rmask; ++r) {
+        uint32_t mn = r, mx = r, amn = 0, amx = 0;
+        for (int i = 1; i < tw; ++i) {
+            const uint32_t q = ((r << i) | (r >> (tw - i))) & rmask;
+            mn = q < mn ? q : mn;
+            mx = q > mx ? q : mx;
+        }
+        for (int i = 0; i < tw; ++i) {
+            const uint32_t q = i == 0 ? r : (((r << i) | (r >> (tw - i))) & rmask);
+            if (q == mn) amn |= 1u << i;
+            if (q == mx) amx |= 1u << i;
+        }
+        out[r] = mn | (amn << 8) | (mx << 16) | (amx << 24);
+    }
+    return 0;
+}
+// host test hook: torus_min of one word (64-bit arithmetic)
+extern "C" uint64_t lsk_test_torus_min(uint64_t v, int L, int tw, int inv, uint32_t const *rowtab, uint64_t best) {
+    const uint64_t mask = L >= 64 ? ~0ULL : ((1ULL << L) - 1);
+    uint64_t col0 = 0;
+    for (int y = 0; y < L / tw; ++y) col0 |= 1ULL << (y * tw);
+    return torus_min<uint64_t>(v, L, tw, mask, col0, inv != 0, rowtab, best);
+}
+
 // K4, trivial sector: only the orbit minimum.  mode 2 generates the L rotations incrementally
 // (rotr by one site = shift + move bit 0 to bit L-1) for a and, with reflections, for rev(a).
 template <typename W>
@@ -594,6 +663,11 @@ __device__ __forceinline__ W rep_trivial(lsk_basis const &bs, lsk_group_elem con
         // tw * th cheap steps -- rotate every row by one site; after tw of them the word is back, rotate it by one row
         const int tw = bs.tw, th = L / tw;
         const W col0 = (W)bs.tcol0, ncol0 = (W)(~col0 & mask);
+        if (bs.trow) { // tw <= 8: the row table picks the few translations that can be minimal (torus_min)
+            for (int r = 0; r < bs.n_cosets; ++r)
+                best = torus_min<W>(apply_elem_w<W>(bs.cosets[r], a, L, mask), L, tw, mask, col0, inv, bs.trow, best);
+            return best;
+        }
         for (int r = 0; r < bs.n_cosets; ++r) {
             W b = apply_elem_w<W>(bs.cosets[r], a, L, mask);
             for (int j = 0; j < th; ++j) {

@@ -86,6 +86,7 @@ typedef struct lsk_basis {
     int tw, n_cosets;               /* mode 4 */
     uint64_t tcol0;                 /* mode 4: the bits of column x = 0 */
     lsk_group_elem const *cosets;   /* mode 4: device [n_cosets] */
+    uint32_t const *trow;           /* mode 4, tw <= 8: device [2^tw] row table of torus_min (lsk_torus_rowtab), else NULL */
     int debug_ablate; /* LS_AMD_ABLATE bitmask (profiling only): 1 skip stage B, 2 skip lookup+accumulate, 4 skip K4 */
     uint64_t site_mask;
     double inv_order; /* 1 / |G| including the inversion doubling */
@@ -289,6 +290,10 @@ int lsk_test_window_find(uint64_t const *reps, int n, uint64_t key);
 int lsk_test_nw_find(uint64_t const *reps, int n, uint64_t key);
 int lsk_test_chain_near_table(int elem, int ldsp, int16_t *out);
 uint64_t lsk_test_rep_trivial_dihedral(uint64_t a, int L, int inv, int reflect);
+/* K4 mode 4: the row table of torus_min (out[2^tw], tw <= 8) and the minimum of v (and, with inv, of its complement) over the
+ * translations of the tw x (L / tw) torus, starting from `best` (host mirrors of the device code) */
+int lsk_torus_rowtab(int tw, uint32_t *out);
+uint64_t lsk_test_torus_min(uint64_t v, int L, int tw, int inv, uint32_t const *rowtab, uint64_t best);
 int lsk_bench_k4(int L, int inv, int reflect, int variant, int64_t n, uint64_t const *reps, uint64_t *out, void *stream);
 /* n packets -> y[idx(beta)] += value */
 int lsk_scatter(lsk_index ix, int cplx, int64_t n, uint64_t const *betas, void const *vals, void *y,

@@ -19,6 +19,7 @@ ap.add_argument("--P", type=int, default=1)
 ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--dtype", default="f64")
 ap.add_argument("--mode", default="auto")
+ap.add_argument("--tree", action="store_true", help="per-stage timing tree (HIP events around every stage)")
 args = ap.parse_args()
 
 cfg = config.heisenberg_chain_config(args.L, symm=args.symm)
@@ -37,6 +38,8 @@ pl = D.MatvecPlan(h, reps, td, mode=args.mode)
 torch.cuda.synchronize()
 t_plan = time.perf_counter() - t
 pl.enable_timing(4096)
+if args.tree:
+    pl.enable_stage_timing(65536)
 pl.matvec(x, y)
 pl.kernel_times_ms()
 torch.cuda.synchronize()
@@ -49,3 +52,5 @@ ks = pl.kernel_times_ms()
 print(f"L={args.L} symm={args.symm} P={args.P} {args.dtype} N={n} kernel={pl.kernel} rounds={pl.num_rounds} nnz={pl.nnz} "
       f"enum={t_enum:.3f}s plan={t_plan:.3f}s matvec={dt*1e3:.3f}ms ({1/dt:.2f}/s) dominant-kernel-total={sum(ks)/args.steps:.3f}ms "
       f"launches/step={len(ks)//args.steps}", flush=True)
+if args.tree:
+    print(pl.timing_report(), flush=True)

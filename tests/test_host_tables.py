@@ -613,6 +613,53 @@ def test_k4_trivial_sector_orbit_minimum(inv, reflect):
             assert f(a, L, inv, reflect) == _orbit_min(a, L, inv, reflect), (L, hex(a))
 
 
+@pytest.mark.parametrize("inv", [0, 1])
+def test_torus_minimum_by_row_table(inv):
+    """torus_min (K4 mode 4 since mid round 4): the minimum over the tw x th translations (and the complement) from one table
+    look-up per row + the few (row, rotation) candidates that put the smallest row on top == the minimum over all tw * th
+    translations done one by one, on random words, periodic rows, identical rows, the empty and the full word; and a `best`
+    handed in (an earlier coset's result) is only ever lowered.  Host mirror of the device routine (same code)."""
+    lib = _lib.load()
+    lib.lsk_torus_rowtab.restype = C.c_int
+    lib.lsk_torus_rowtab.argtypes = [C.c_int, C.POINTER(C.c_uint32)]
+    lib.lsk_test_torus_min.restype = C.c_uint64
+    lib.lsk_test_torus_min.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint32), C.c_uint64]
+    rng = np.random.RandomState(5 + inv)
+
+    def brute(v, tw, th):
+        L = tw * th
+        mask = (1 << L) - 1
+        rmask = (1 << tw) - 1
+        rows = [(v >> (k * tw)) & rmask for k in range(th)]
+        best = mask
+        for i in range(tw):
+            rr = [((r << i) | (r >> (tw - i))) & rmask for r in rows]
+            for j in range(th):
+                c = sum(rr[k] << (((k + j) % th) * tw) for k in range(th))
+                best = min(best, c, (c ^ mask) if inv else c)
+        return best
+
+    for tw, th in ((2, 2), (2, 8), (3, 4), (4, 4), (4, 6), (5, 5), (6, 6), (6, 4), (7, 9), (8, 8), (8, 3), (1, 7)):
+        L = tw * th
+        tab = (C.c_uint32 * (1 << tw))()
+        assert lib.lsk_torus_rowtab(tw, tab) == 0
+        mask = (1 << L) - 1
+        samples = [0, mask, 1, 1 << (L - 1), int("01" * 64, 2) & mask, int("0011" * 32, 2) & mask]
+        row = int(rng.randint(0, 1 << tw))
+        samples.append(sum(row << (k * tw) for k in range(th)))  # identical rows
+        for _ in range(150):
+            w = int(rng.randint(0, L + 1))
+            samples.append(int(sum(1 << int(b) for b in rng.permutation(L)[:w])))
+        for v in samples:
+            want = brute(v, tw, th)
+            got = int(lib.lsk_test_torus_min(C.c_uint64(v), L, tw, inv, tab, C.c_uint64((1 << 64) - 1)))
+            assert got == want, (tw, th, hex(v), hex(got), hex(want))
+            for prev in (want, max(want - 1, 0), min(want + 1, mask), int(rng.randint(0, 1 << 30)) & mask):
+                got = int(lib.lsk_test_torus_min(C.c_uint64(v), L, tw, inv, tab, C.c_uint64(prev)))
+                assert got == min(prev, want), (tw, th, hex(v), hex(prev))
+    assert lib.lsk_torus_rowtab(9, (C.c_uint32 * 512)()) == -1
+
+
 @pytest.mark.parametrize("name,tw,cosets", [("heisenberg_square_4x4", 4, 8), ("heisenberg_square_6x6", 6, 8),
                                              ("heisenberg_kagome_12_symm", None, None), ("heisenberg_chain_24_symm", None, None)])
 def test_lattice_group_orbit_minimum_by_translation_cosets(name, tw, cosets):
