@@ -118,6 +118,24 @@ def scaling_model(model, P, w=8):
     return out
 
 
+def slot_cache_leg(plan, run, check, kernel_times, time_steps, steps):
+    """the same plan with ls_amd_plan_cache_slots: the packet streams (slot of every partner: 5 B per non-zero here) are resolved
+    by the first matvec and kept in HBM, later matvecs only gather -- what an eigensolver that applies one plan hundreds of
+    times runs.  Opt-in and NOT matrix-free, therefore a separate leg and never the headline."""
+    rows = plan.cache_slots(0)
+    if rows <= 0:
+        return {"rows": 0, "note": "not enabled (no room for the packet streams, or nothing to cache)"}
+    run()  # resolves
+    check()
+    kernel_times()
+    dt = time_steps(run, steps, 1)
+    check()
+    ks = kernel_times()
+    crow, cbytes = plan.slot_cache
+    return {"rows": crow, "hbm_bytes": cbytes, "kernel": plan.kernel, "matvecs_per_s": steps / dt, "ms_per_step": 1e3 * dt / steps,
+            "kernel_ms_avg": sum(ks) / max(1, len(ks)), "matrix_free": False}
+
+
 def projected_extra(D, torch, dist, name, rank, world, time_steps, allsum, steps=3, warmup=2):
     """one of the symmetry-projected BASELINE chains, measured inside the default run (see main)"""
     from distributed_matvec_amd import config
@@ -152,6 +170,7 @@ def projected_extra(D, torch, dist, name, rank, world, time_steps, allsum, steps
             # what bounds this kernel: random 64-byte requests (index-table probes, partner values), not bytes
             out["requests_64B_per_s"] = ent["traffic_bytes"] / 64.0 / (kms * 1e-3)
         out["pmc_note"] = note
+        out["slot_cache"] = slot_cache_leg(pl, lambda: pl.matvec(x, y, check=False), pl.check, pl.kernel_times_ms, time_steps, steps)
         pl.destroy()
         return out
     from distributed_matvec_amd.distributed import RcclReplicatedOperator
@@ -178,6 +197,7 @@ def projected_extra(D, torch, dist, name, rank, world, time_steps, allsum, steps
                 "x_bytes_in_this_rank": 8 * (n_total - int(my.numel())),
                 "rank0_stage_ms_per_matvec": {k: v[0] / max(1, mv) for k, v in stages.items()},
                 "model": scaling_model(name, world)})
+    out["slot_cache"] = slot_cache_leg(plan, lambda: op.matvec(x, y, check=False), plan.check, plan.kernel_times_ms, time_steps, steps)
     op.rm.destroy()
     return out
 

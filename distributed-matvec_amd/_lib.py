@@ -120,6 +120,8 @@ def load():
         "ls_amd_plan_packet_bytes": (C.c_int, [vp]),
         "ls_amd_plan_row_bytes": (C.c_int, [vp]),
         "ls_amd_plan_nnz": (C.c_int64, [vp]),
+        "ls_amd_plan_cache_slots": (C.c_int64, [vp, C.c_int64]),
+        "ls_amd_plan_slot_cache_rows": (C.c_int, [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
         "ls_amd_matvec": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), vp]),
         "ls_amd_plan_check": (C.c_int, [vp, vp]),
         "ls_amd_plan_enable_timing": (C.c_int, [vp, C.c_int]),

@@ -393,6 +393,22 @@ class MatvecPlan:
     @property
     def row_bytes(self): return int(_lib.load().ls_amd_plan_row_bytes(self.h))
 
+    def cache_slots(self, max_bytes: int = 0) -> int:
+        """keep the resolved packet streams (slot of every partner, 5 B per non-zero on the Heisenberg models) across matvecs:
+        the first matvec resolves them, later ones only gather -- for plans that are applied many times (eigensolvers).  Opt-in,
+        not matrix-free; returns the rows cached (0: nothing, e.g. an unprojected basis or no room)."""
+        rows = int(_lib.load().ls_amd_plan_cache_slots(self.h, int(max_bytes)))
+        if rows < 0:
+            _lib.check(-1)
+        return rows
+
+    @property
+    def slot_cache(self):
+        """(rows, bytes) held by the slot cache"""
+        r, b = C.c_int64(0), C.c_int64(0)
+        _lib.load().ls_amd_plan_slot_cache_rows(self.h, C.byref(r), C.byref(b))
+        return int(r.value), int(b.value)
+
     def send_counts(self, rnd: int):
         c = (C.c_int64 * self.P)()
         _lib.check(_lib.load().ls_amd_plan_send_counts(self.h, rnd, c))

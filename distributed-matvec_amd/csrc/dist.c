@@ -493,6 +493,8 @@ int ls_amd_repl_create(ls_amd_repl **out, ls_amd_comm *cm, ls_hs_operator const 
             char const *e = getenv("LS_AMD_PULL_SPLIT");
             int64_t const budget = e ? atoll(e) : (P > 1 ? (int64_t)32 << 30 : 0);
             if (budget > 0) (void)ls_amd_internal_plan_split_enable(r->plan, budget);
+            e = getenv("LS_AMD_SLOT_CACHE"); /* bytes per rank: keep the resolved streams across matvecs (ls_amd_plan_cache_slots) */
+            if (e && atoll(e) > 0 && ls_amd_plan_cache_slots(r->plan, atoll(e)) < 0) rc = -1;
         }
     } else if (rc == 0)
         rc = ls_amd_plan_create_replicated(&r->plan, op, dtype, P, me, d_reps_global + r->n0, nb, d_reps_global, count_global, stream);

@@ -1371,6 +1371,12 @@ struct ls_amd_plan {
      * split_rows rows (a multiple of 256, or all of them); 0 = the fused kernel only */
     lsk_pullbuf pbuf;
     int64_t split_rows;
+    /* slot cache (ls_amd_plan_cache_slots): the packet streams of the split form are plan data -- they depend on the operator,
+     * the basis and the partition layout only -- so a plan that is applied many times (an eigensolver) resolves them ONCE and
+     * every later matvec is the gather kernel alone.  Opt-in: the path is then no longer matrix-free (5 bytes per non-zero of
+     * HBM for one-amplitude operators, 13 / 21 with real / complex coefficients). */
+    int slot_cache, slot_cache_valid;
+    int64_t slot_cache_bytes;
     /* kernel timing ring */
     int t_capacity, t_count;
     void **t_start, **t_stop;
@@ -1637,12 +1643,14 @@ static int pull_halo_setting(int indexed) {
 
 /* ---- split matvec: packet streams ------------------------------------------------------------------------------------- */
 static void split_free(ls_amd_plan *pl) {
+    if (pl->pbuf.offs) lsk_free((void *)pl->pbuf.offs);
     if (pl->pbuf.slots) lsk_free(pl->pbuf.slots);
     if (pl->pbuf.rows) lsk_free(pl->pbuf.rows);
     if (pl->pbuf.coefs) lsk_free(pl->pbuf.coefs);
     if (pl->pbuf.counts) lsk_free(pl->pbuf.counts);
     memset(&pl->pbuf, 0, sizeof(pl->pbuf));
     pl->split_rows = 0;
+    pl->slot_cache = pl->slot_cache_valid = 0;
 }
 /* room for the packet streams of as many of the plan's rows as `max_bytes` allow (all of them if it can); returns the number
  * of rows covered (0: none -- the plan keeps the fused kernel) */
@@ -1674,6 +1682,63 @@ int64_t ls_amd_internal_plan_split_enable(ls_amd_plan *pl, int64_t max_bytes) {
     return 0;
 }
 int64_t ls_amd_internal_plan_split_rows(ls_amd_plan const *pl) { return pl->split_rows; }
+/* Keep the resolved packet streams across matvecs (see slot_cache above).  max_bytes = ceiling for the packet buffers (<= 0:
+ * whatever the device has).  One-partition plans need every row covered (else nothing is cached and 0 is returned: the plan
+ * stays matrix-free); plans of the replicated-x exchange cache the rows the buffer covers and run the fused kernel on the
+ * rest.  Returns the number of rows whose streams are cached. */
+/* every row, streams laid out back to back at their exact lengths (a count pass of stage A + a scan): about half of what the
+ * worst-case stride of the split form reserves.  0 on success; 1 = does not fit `max_bytes` / the device (nothing is left
+ * allocated), -1 = device error */
+static int split_enable_exact(ls_amd_plan *pl, int64_t max_bytes) {
+    split_free(pl);
+    part_state *ps = &pl->parts[0];
+    int64_t const streams = (ps->count + 63) / 64;
+    int const nc = lsk_pullbuf_coef_doubles(pl->dop, pl->dbs);
+    void *offs = NULL, *a = NULL, *b = NULL, *c = NULL, *d = NULL;
+    if (lsk_malloc(&offs, 8 * (size_t)(streams + 1)) != 0) return 1;
+    int64_t total = 0;
+    if (lsk_tile_pull_stream_offsets(pl->dop, pl->dbs, 0, ps->count, ps->d_reps, (int64_t *)offs, NULL) != 0 ||
+        lsk_d2h(&total, (char *)offs + 8 * (size_t)streams, 8) != 0) { lsk_free(offs); return -1; }
+    int64_t const bytes = total * (4 + 1 + 8 * nc) + 12 * streams + 8;
+    if (total >= ((int64_t)1 << 40) || (max_bytes > 0 && bytes > max_bytes)) { lsk_free(offs); return 1; }
+    if (lsk_malloc(&a, (size_t)(4 * total + 4)) != 0 || lsk_malloc(&b, (size_t)(total + 4)) != 0 ||
+        (nc > 0 && lsk_malloc(&c, (size_t)(8 * nc * total + 8)) != 0) || lsk_malloc(&d, (size_t)(4 * streams)) != 0) {
+        if (a) lsk_free(a);
+        if (b) lsk_free(b);
+        if (c) lsk_free(c);
+        if (d) lsk_free(d);
+        lsk_free(offs);
+        return 1;
+    }
+    pl->pbuf.slots = (uint32_t *)a; pl->pbuf.rows = (uint8_t *)b; pl->pbuf.coefs = (double *)c; pl->pbuf.counts = (uint32_t *)d;
+    pl->pbuf.offs = (int64_t const *)offs;
+    pl->pbuf.cap = lsk_pullbuf_cap(pl->dop);
+    pl->pbuf.row0 = 0;
+    pl->split_rows = ps->count;
+    pl->slot_cache_bytes = bytes;
+    return 0;
+}
+int64_t ls_amd_plan_cache_slots(ls_amd_plan *pl, int64_t max_bytes) {
+    if (!pl || !pl->idx_mode || pl->dbs.proj != LSK_PROJ_FULL || pl->parts[0].count <= 0 ||
+        (pl->family != FAMILY_TILE_PULL && pl->family != FAMILY_REPL_TILE)) return 0;
+    int const rc = split_enable_exact(pl, max_bytes);
+    if (rc < 0) return dev_error();
+    if (rc > 0) {
+        /* no room for every row: a replicated-x plan keeps the streams of the rows that do fit (worst-case stride) and runs
+         * the fused kernel on the others; a one-partition plan stays matrix-free */
+        if (pl->family != FAMILY_REPL_TILE || ls_amd_internal_plan_split_enable(pl, max_bytes) <= 0) { split_free(pl); return 0; }
+        int64_t const streams = (pl->split_rows + 63) / 64;
+        pl->slot_cache_bytes = streams * (pl->pbuf.cap * (4 + 1 + 8 * lsk_pullbuf_coef_doubles(pl->dop, pl->dbs)) + 4);
+    }
+    pl->slot_cache = 1;
+    pl->slot_cache_valid = 0;
+    return pl->split_rows;
+}
+int ls_amd_plan_slot_cache_rows(ls_amd_plan const *pl, int64_t *rows, int64_t *bytes) {
+    if (rows) *rows = pl->slot_cache ? pl->split_rows : 0;
+    if (bytes) *bytes = pl->slot_cache ? pl->slot_cache_bytes : 0;
+    return 0;
+}
 
 /* LS_AMD_PACKETS=block keeps the block-wide packet lists of k_tile (cursor atomics); default: per-wave rings (k_tile_wv) */
 static int packets_wave_rings(void) {
@@ -2195,6 +2260,11 @@ int ls_amd_plan_create(ls_amd_plan **out, ls_hs_operator const *op, ls_amd_dtype
             pl->pull_halo = pull_halo_setting(1);
             char const *e = getenv("LS_AMD_PULL_SPLIT"); /* bytes of packet buffer; measurement of the two-kernel form */
             if (e && atoll(e) > 0) ls_amd_internal_plan_split_enable(pl, atoll(e));
+            /* LS_AMD_SLOT_CACHE = bytes: ls_amd_plan_cache_slots for callers that cannot reach the plan -- the host-pointer entry
+             * points under Diagonalize / PRIMME (ls_chpl_matrix_vector_product, ls_chpl_primme_matvec) keep one plan per
+             * operator, which then resolves its packet streams on the first matvec only */
+            e = getenv("LS_AMD_SLOT_CACHE");
+            if (e && atoll(e) > 0 && ls_amd_plan_cache_slots(pl, atoll(e)) < 0) { ls_amd_plan_destroy(pl); return -1; }
         }
     }
     if (lsk_sync(stream) != 0) { ls_amd_plan_destroy(pl); return dev_error(); }
@@ -2440,11 +2510,13 @@ int ls_amd_matvec_replicated(ls_amd_plan *pl, void const *d_x_global, void *d_y_
  * received x and runs the fused kernel on whatever rows the packet buffer did not cover. */
 int ls_amd_internal_repl_split_begin(ls_amd_plan *pl, void *stream) {
     if (pl->family != FAMILY_REPL_TILE || !pl->idx_mode || pl->split_rows <= 0) return 0;
+    if (pl->slot_cache && pl->slot_cache_valid) return 0; /* the streams of an earlier matvec are still good */
     part_state *ps = &pl->parts[0];
     lsk_pullidx ix;
     ix.tab = pl->gtab->tab;
     ix.perm = pl->gtab->d_perm;
     ix.row_g0 = pl->row_g0;
+    pl->slot_cache_valid = pl->slot_cache;
     int const st = stage_begin(pl, ST_GENERATE, stream);
     int const slot = timing_begin(pl, stream);
     DEV(lsk_tile_pull_resolve(pl->dop, pl->dbs, 0, pl->split_rows, ps->d_reps, ps->d_norms, ix, pl->gindex.reps, pl->gindex.count,
@@ -2462,8 +2534,10 @@ int ls_amd_internal_repl_split_finish(ls_amd_plan *pl, void const *d_x_global, v
     ix.perm = pl->gtab->d_perm;
     ix.row_g0 = pl->row_g0;
     int const st = stage_begin(pl, ST_ROWS, stream);
+    int const slot = pl->slot_cache ? timing_begin(pl, stream) : -1; /* cached: the gather kernel is the dominant (only) one */
     DEV(lsk_tile_pull_gather(pl->dop, pl->dbs, pl->cplx, 0, pl->split_rows, ps->d_reps, ps->d_norms, ix, d_x_global, pl->pbuf, d_y_local,
                              stream));
+    if (slot >= 0) timing_end(pl, slot, stream);
     if (pl->split_rows < ps->count)
         DEV(lsk_tile_pull_idx(pl->dop, pl->dbs, pl->cplx, pl->split_rows, ps->count, ps->d_reps, ps->d_norms, ix, pl->gindex.reps,
                               pl->gindex.count, d_x_global, pl->pull_halo, d_y_local, pl->d_err, stream));
@@ -2475,10 +2549,10 @@ char const *ls_amd_plan_kernel_name(ls_amd_plan const *pl) {
     case FAMILY_DIRECT_PUSH: return "direct-push";
     case FAMILY_DIRECT_PULL:
         return pl->has_chain ? "direct-pull+staged" : pl->has_pairs ? "direct-pull+pairs" : "direct-pull";
-    case FAMILY_TILE_PULL: return pl->idx_mode ? "tile-pull+indexed" : "tile-pull";
+    case FAMILY_TILE_PULL: return pl->idx_mode ? (pl->slot_cache ? "tile-pull+indexed+cached" : "tile-pull+indexed") : "tile-pull";
     case FAMILY_REPL_DIRECT:
         return pl->has_chain ? "replicated-direct-pull+staged" : "replicated-direct-pull";
-    case FAMILY_REPL_TILE: return pl->idx_mode ? "replicated-tile-pull+indexed" : "replicated-tile-pull";
+    case FAMILY_REPL_TILE: return pl->idx_mode ? (pl->slot_cache ? "replicated-tile-pull+indexed+cached" : "replicated-tile-pull+indexed") : "replicated-tile-pull";
     default: return "tile";
     }
 }
@@ -2599,14 +2673,20 @@ int ls_amd_matvec(ls_amd_plan *pl, void const *const *d_x, void *const *d_y, voi
                 int64_t const r1 = r0 + pl->split_rows < ps->count ? r0 + pl->split_rows : ps->count;
                 lsk_pullbuf pb = pl->pbuf;
                 pb.row0 = r0;
-                int st = stage_begin(pl, ST_GENERATE, stream);
-                int slot = timing_begin(pl, stream);
-                DEV(lsk_tile_pull_resolve(pl->dop, pl->dbs, r0, r1, ps->d_reps, ps->d_norms, ix, ps->d_reps, ps->count, pl->pull_halo, pb,
-                                          pl->d_err, stream));
-                timing_end(pl, slot, stream);
-                stage_end(pl, st, stream);
+                int st, slot;
+                if (!(pl->slot_cache && pl->slot_cache_valid)) { /* (a cached plan covers every row: one round) */
+                    st = stage_begin(pl, ST_GENERATE, stream);
+                    slot = timing_begin(pl, stream);
+                    DEV(lsk_tile_pull_resolve(pl->dop, pl->dbs, r0, r1, ps->d_reps, ps->d_norms, ix, ps->d_reps, ps->count, pl->pull_halo, pb,
+                                              pl->d_err, stream));
+                    timing_end(pl, slot, stream);
+                    stage_end(pl, st, stream);
+                    pl->slot_cache_valid = pl->slot_cache;
+                }
                 st = stage_begin(pl, ST_ROWS, stream);
+                slot = pl->slot_cache ? timing_begin(pl, stream) : -1; /* cached: the gather kernel is the dominant (only) one */
                 DEV(lsk_tile_pull_gather(pl->dop, pl->dbs, pl->cplx, r0, r1, ps->d_reps, ps->d_norms, ix, xs, pb, d_y[0], stream));
+                if (slot >= 0) timing_end(pl, slot, stream);
                 stage_end(pl, st, stream);
             }
             return 0;

@@ -600,24 +600,29 @@ __host__ __device__ __forceinline__ W torus_min(W v, int L, int tw, W mask, W co
         mstar = m < mstar ? m : mstar;
     }
     if ((W)mstar > (W)(best >> (L - tw))) return best; // (best == ~0 at the start: never true)
+    // the candidates as site masks: bit k tw + i of cand[fam] = "rotate the rows by i, then row k to the top".  Collected
+    // first and then popped ONE PER LANE AND ITERATION: the lanes of a wave hold different words, and a loop over
+    // (row, family) with the construction inside its body made every wave run that body for nearly all 2 th combinations
+    // (some lane always matches) -- 62.8 ms per matvec on heisenberg_square_6x6 -- instead of for the 1-3 its lanes need.
     const W nv = (W)(~v & mask);
+    W cand0 = 0, cand1 = 0;
     for (int k = 0; k < th; ++k) {
         const uint32_t e = rowtab[(uint32_t)(v >> (k * tw)) & rmask];
-        const int up = tw * (th - 1 - k); // row k -> top row
-        for (int fam = 0; fam <= (inv ? 1 : 0); ++fam) {
-            const uint32_t m = fam == 0 ? (e & 0xffu) : (~(e >> 16) & rmask);
-            if (m != mstar) continue;
-            uint32_t amounts = fam == 0 ? ((e >> 8) & 0xffu) : (e >> 24);
-            const W word = fam == 0 ? v : nv;
-            while (amounts) {
-                const int i = k4_ctz32(amounts);
-                amounts &= amounts - 1;
-                const W lo = (W)(col0 * (W)((1u << i) - 1u)); // columns 0 .. i-1 of every row (no carries: 2^i - 1 < 2^tw)
-                W c = i == 0 ? word : (W)((((W)(word << i)) & (W)~lo & mask) | ((W)(word >> (tw - i)) & lo));
-                c = rotl_sites<W>(c, up, L, mask);
-                best = c < best ? c : best;
-            }
-        }
+        if ((e & 0xffu) == mstar) cand0 |= (W)((e >> 8) & 0xffu) << (k * tw);
+        if (inv && (~(e >> 16) & rmask) == mstar) cand1 |= (W)(e >> 24) << (k * tw);
+    }
+    const uint32_t inv_tw = 65536u / (uint32_t)tw + 1u; // p / tw for p < 64, tw <= 8
+    while (cand0 | cand1) {
+        const bool first = cand0 != 0;
+        const W cm = first ? cand0 : cand1;
+        const int p = sizeof(W) == 4 ? k4_ctz32((uint32_t)cm) : k4_ctz64((uint64_t)cm);
+        if (first) cand0 &= cand0 - 1; else cand1 &= cand1 - 1;
+        const int k = (int)(((uint32_t)p * inv_tw) >> 16), i = p - k * tw;
+        const W word = first ? v : nv;
+        const W lo = (W)(col0 * (W)((1u << i) - 1u)); // columns 0 .. i-1 of every row (no carries: 2^i - 1 < 2^tw)
+        W c = (W)((((W)(word << i)) & (W)~lo & mask) | ((W)(word >> (tw - i)) & lo)); // (i == 0: lo == 0, the first term is the word)
+        c = rotl_sites<W>(c, tw * (th - 1 - k), L, mask);
+        best = c < best ? c : best;
     }
     return best;
 }
@@ -2814,7 +2819,7 @@ __global__ __launch_bounds__(kBlock, (COEF == COEF_CPLX ? 4 : 6)) void k_pull_t(
         int head = 0, cnt = 0; // wave-uniform: the ring holds [head, head + cnt) mod kWvRing
         // packet stream of this wave's 64 rows (SINK_RESOLVE)
         const int64_t wg = ((t0 - buf.row0) >> 6) + wave;
-        const int64_t sbase = wg * buf.cap;
+        const int64_t sbase = buf.offs ? buf.offs[wg] : wg * buf.cap; // exact layout (slot cache) | `cap` packets of room each
         int emitted = 0;
         // K chunks at once: the packets at ring positions head + 64 k + lane (the last chunk holds m <= 64 of them):
         // K4 -> slot [-> value -> ds_add_f64], the loads of the K packets of a lane issued together
@@ -3005,7 +3010,7 @@ __global__ __launch_bounds__(kBlock) void k_pull_gather(lsk_runs runs, int n_dia
         const bool valid = i < row1;
         if (CPLX) { s_acc[2 * tid] = 0.0; s_acc[2 * tid + 1] = 0.0; } else s_acc[tid] = 0.0;
         const int64_t wg = ((t0 - buf.row0) >> 6) + wave;
-        const int64_t sbase = wg * buf.cap;
+        const int64_t sbase = buf.offs ? buf.offs[wg] : wg * buf.cap;
         const int n = (int)buf.counts[wg];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -3135,6 +3140,56 @@ extern "C" int lsk_tile_pull_idx(lsk_operator op, lsk_basis bs, int cplx, int64_
     LSK_LAUNCH_CHECK();
     return 0;
 }
+static int exclusive_scan_i64(int64_t n, int64_t const *in, int64_t *out, hipStream_t s);
+// Packets that stage A of k_pull_t generates for every 64 rows (the streams' exact lengths): out[w] for the rows
+// [row0 + 64 w, row0 + 64 w + 64).  Same activity test as stage A -- dead packets (zero-norm orbits) keep their place in a
+// stream, so this is what the resolve kernel emits.
+template <int COEF>
+__global__ __launch_bounds__(kBlock) void k_pull_count(int n_groups, lsk_group const *__restrict__ groups, lsk_term const *__restrict__ off,
+                                                       int64_t row0, int64_t row1, uint64_t const *__restrict__ reps,
+                                                       int64_t *__restrict__ out) {
+    constexpr bool REAL = COEF != COEF_CPLX;
+    const int lane = threadIdx.x & 63;
+    for (int64_t t0 = row0 + (int64_t)blockIdx.x * kBlock; t0 < row1; t0 += (int64_t)gridDim.x * kBlock) {
+        const int64_t w0 = t0 + (threadIdx.x & ~63u);
+        if (w0 >= row1) continue;
+        const int64_t i = t0 + threadIdx.x;
+        const bool valid = i < row1;
+        const uint64_t a = valid ? reps[i] : 0;
+        const uint64_t tdiff = a ^ (a >> 1);
+        int cnt = 0;
+        for (int g = 0; g < n_groups; ++g) {
+            lsk_group const G = groups[g];
+            bool act;
+            if (COEF == COEF_UNI) act = valid && (G.adj >= 0 ? (bool)((tdiff >> G.adj) & 1) : __popcll(a & G.x) == 1);
+            else {
+                double cr = 0.0, ci = 0.0;
+                if (valid) group_coeff<REAL>(G, off, a, cr, ci);
+                act = valid && (cr != 0.0 || (!REAL && ci != 0.0));
+            }
+            cnt += __popcll(__ballot(act));
+        }
+        if (lane == 0) out[(w0 - row0) >> 6] = cnt;
+    }
+}
+// out[0, streams] <- exclusive offsets of the packet streams of rows [row0, row1) (streams = ceil(rows / 64); out[streams] =
+// total); synchronises the stream
+extern "C" int lsk_tile_pull_stream_offsets(lsk_operator op, lsk_basis bs, int64_t row0, int64_t row1, uint64_t const *reps,
+                                            int64_t *out, void *stream) {
+    if (row1 <= row0) return 0;
+    const int64_t streams = (row1 - row0 + 63) / 64;
+    int k4m, coef;
+    pull_kinds(op, bs, k4m, coef);
+    hipStream_t s = (hipStream_t)stream;
+    LSK_CHECK(hipMemsetAsync(out, 0, 8 * (size_t)(streams + 1), s));
+    const dim3 g((unsigned)grid_for(row1 - row0)), b(kBlock);
+    if (coef == COEF_UNI) hipLaunchKernelGGL(k_pull_count<COEF_UNI>, g, b, 0, s, op.n_groups, op.groups, op.off, row0, row1, reps, out);
+    else if (coef == COEF_REAL) hipLaunchKernelGGL(k_pull_count<COEF_REAL>, g, b, 0, s, op.n_groups, op.groups, op.off, row0, row1, reps, out);
+    else hipLaunchKernelGGL(k_pull_count<COEF_CPLX>, g, b, 0, s, op.n_groups, op.groups, op.off, row0, row1, reps, out);
+    LSK_LAUNCH_CHECK();
+    return exclusive_scan_i64(streams + 1, out, out, s);
+}
+
 // first half of the split matvec: rows [row0, row1) -> packet stream in `buf` (buf.row0 = the row that owns stream 0; a
 // multiple of 64 rows below row0).  Reads neither x nor y.
 extern "C" int lsk_tile_pull_resolve(lsk_operator op, lsk_basis bs, int64_t row0, int64_t row1, uint64_t const *reps,
@@ -3142,7 +3197,7 @@ extern "C" int lsk_tile_pull_resolve(lsk_operator op, lsk_basis bs, int64_t row0
                                      int halo, lsk_pullbuf buf, int *d_err, void *stream) {
     if (row1 <= row0) return 0;
     if (pull_args_ok(bs, halo, reps_global, n_global, "lsk_tile_pull_resolve") != 0) return -1;
-    if (!buf.slots || !buf.rows || !buf.counts || buf.cap < lsk_pullbuf_cap(op) || ((row0 - buf.row0) & 255) != 0 || row0 < buf.row0 ||
+    if (!buf.slots || !buf.rows || !buf.counts || (!buf.offs && buf.cap < lsk_pullbuf_cap(op)) || ((row0 - buf.row0) & 255) != 0 || row0 < buf.row0 ||
         (lsk_pullbuf_coef_doubles(op, bs) > 0 && !buf.coefs)) { snprintf(g_err, sizeof(g_err), "lsk_tile_pull_resolve: bad packet buffer"); return -1; }
     hipStream_t s = (hipStream_t)stream;
     int rc;

@@ -267,7 +267,10 @@ typedef struct lsk_pullbuf {
     double *coefs;    /* device [streams * cap * lsk_pullbuf_coef_doubles] or NULL */
     uint32_t *counts; /* device [streams] */
     int64_t cap, row0;
+    int64_t const *offs; /* NULL: stream w starts at w * cap; else device [streams + 1] exact offsets (lsk_tile_pull_stream_offsets) */
 } lsk_pullbuf;
+int lsk_tile_pull_stream_offsets(lsk_operator op, lsk_basis bs, int64_t row0, int64_t row1, uint64_t const *reps, int64_t *out,
+                                 void *stream);
 int64_t lsk_pullbuf_cap(lsk_operator op);
 int lsk_pullbuf_coef_doubles(lsk_operator op, lsk_basis bs);
 int lsk_tile_pull_resolve(lsk_operator op, lsk_basis bs, int64_t row0, int64_t row1, uint64_t const *reps,

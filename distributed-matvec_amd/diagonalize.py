@@ -23,7 +23,7 @@ from dataclasses import dataclass, field
 class LocalOperator:
     """H on one device: P logical partitions concatenated into flat per-partition vectors."""
 
-    def __init__(self, matrix, representatives, dtype, mode="auto"):
+    def __init__(self, matrix, representatives, dtype, mode="auto", slot_cache_bytes=0):
         import torch
 
         from .api import MatvecPlan
@@ -31,6 +31,9 @@ class LocalOperator:
         self.torch = torch
         self.reps = list(representatives)
         self.plan = MatvecPlan(matrix, self.reps, dtype, mode=mode)
+        # an eigensolver applies ONE plan hundreds of times: keep the resolved packet streams of a projected basis in HBM
+        # when the caller has room for them (ls_amd_plan_cache_slots; 0 rows = the plan stays matrix-free)
+        self.cached_rows = self.plan.cache_slots(slot_cache_bytes) if slot_cache_bytes > 0 and len(self.reps) == 1 else 0
         self.dtype = dtype
         self.sizes = [int(r.numel()) for r in self.reps]
         self.n_local = sum(self.sizes)
@@ -238,7 +241,16 @@ def diagonalize(config, num_evals: int = 1, eps: float = 1e-6, num_partitions: i
             masks = torch.zeros(len(stored), dtype=torch.uint8, device="cuda")
     if reps is None:
         reps, masks = api.enumerateStates(basis, num_partitions)
-    op = LocalOperator(h, reps, dtype)
+    # one plan, hundreds of matvecs: what is left of HBM after the Krylov basis may hold the resolved packet streams
+    # (ls_amd_plan_cache_slots; LS_AMD_SLOT_CACHE=0 keeps the solver matrix-free)
+    cache_bytes = 0
+    if num_partitions == 1 and os.environ.get("LS_AMD_SLOT_CACHE", "1") != "0":
+        n_states = int(reps[0].numel())
+        free, _total = torch.cuda.mem_get_info()
+        cache_bytes = max(0, int(free) - (max_basis + 6) * n_states * (16 if dtype == torch.complex128 else 8) - (4 << 30))
+    op = LocalOperator(h, reps, dtype, slot_cache_bytes=cache_bytes)
+    if verbose and op.cached_rows:
+        print(f"[diagonalize] slot cache: {op.cached_rows} rows, {op.plan.slot_cache[1] / 1e9:.2f} GB", flush=True)
     r = lanczos_smallest(op, num_evals=num_evals, eps=eps, max_basis=max_basis, verbose=verbose)
     if output and output.endswith((".h5", ".hdf5")):
         # same groups/datasets as the reference's output file (Diagonalize.chpl:241,248-256)

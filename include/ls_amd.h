@@ -181,6 +181,18 @@ int ls_amd_plan_row_bytes(ls_amd_plan const *plan);
  * 0 when the plan runs a direct kernel and never counted) */
 int64_t ls_amd_plan_nnz(ls_amd_plan const *plan);
 
+/* Slot cache of the projected-basis pull path (opt-in; NOT matrix-free).  The indexed pull kernel spends ~80 % of a matvec
+ * on work that does not depend on x: term expansion (BatchedOperator.chpl:163-213), the orbit minimum of every generated state
+ * and the look-up of its representative (ls_hs_state_index, DMV:102) -- per non-zero one 4-byte slot + one row byte (+ the
+ * coefficient unless every packet has the same real amplitude).  A plan that is applied many times (Diagonalize / PRIMME)
+ * can keep those streams in HBM: the first matvec resolves them, every later one only gathers x[slot] and accumulates.
+ * max_bytes = ceiling for the streams (<= 0: whatever the device can allocate).  Returns the number of rows whose streams
+ * are kept; 0 = nothing cached, the plan stays matrix-free (unprojected bases, value-table mode, no room).  Plans over one
+ * partition cache all rows or none; plans of the replicated-x exchange run the fused kernel on the rows that did not fit. */
+int64_t ls_amd_plan_cache_slots(ls_amd_plan *plan, int64_t max_bytes);
+/* rows covered by the slot cache and the HBM it holds (0 / 0 when off) */
+int ls_amd_plan_slot_cache_rows(ls_amd_plan const *plan, int64_t *rows, int64_t *bytes);
+
 /* matrixVectorProduct(H, x, y, representatives), all partitions in this process
  * (DMV:1072-1093).  d_x[p], d_y[p]: device arrays of counts[p] elements of the plan's dtype.
  * Asynchronous on `stream`; call ls_amd_plan_check to synchronise and collect the

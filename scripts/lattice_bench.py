@@ -44,7 +44,20 @@ ks = pl.kernel_times_ms()
 pp = D.MatvecPlan(h, reps, torch.float64, mode="push")
 nnz = pp.nnz
 pp.destroy()
+# the same plan with the slot cache (opt-in, not matrix-free): resolve once, then only gather
+cached = None
+if pl.cache_slots(0) > 0:
+    pl.matvec(x, y)
+    pl.kernel_times_ms()
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(steps):
+        pl.matvec(x, y, check=False)
+    pl.check()
+    torch.cuda.synchronize()
+    cached = {"ms_per_matvec": (time.perf_counter() - t) / steps * 1e3, "hbm_bytes": pl.slot_cache[1], "kernel": pl.kernel}
 print(json.dumps({"model": name, "sites": basis.numberSites(), "group_order": basis.groupOrder(), "spin_inversion": basis.spinInversion(),
                   "states": n, "nnz": nnz, "enumerate_s": t_enum, "plan_s": t_plan, "kernel": pl.kernel, "ms_per_matvec": dt * 1e3,
                   "kernel_ms_avg": sum(ks) / max(1, len(ks)), "matvecs_per_s": 1.0 / dt, "gnnz_per_s": nnz / dt / 1e9,
+                  "slot_cache": cached,
                   "k4_env": {k: os.environ[k] for k in ("LS_AMD_K4",) if k in os.environ}}), flush=True)

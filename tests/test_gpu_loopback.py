@@ -5,6 +5,7 @@ counts matrix), the double-buffered round pipeline of ls_amd_dist_matvec, the bl
 the PRIMME reductions -- only the transport differs (RCCL refuses two ranks on one device).  The reference tests its
 multi-locale code the same way, by oversubscribing one machine."""
 import ctypes as C
+import os
 import threading
 
 import numpy as np
@@ -89,7 +90,7 @@ def test_ranks_as_threads(name, P, cplx, mode):
         c.destroy()
 
 
-@pytest.mark.parametrize("indexed", ["1", "0", "fused", "part"])
+@pytest.mark.parametrize("indexed", ["1", "0", "fused", "part", "cached", "cached-part"])
 @pytest.mark.parametrize("case", ["heisenberg_chain_24_symm/4/f64", "heisenberg_chain_24_symm/3/c128", "issue_01/2/f64",
                                   "heisenberg_kagome_12_symm/8/f64", "translation_12_5/3/c128"])
 def test_replicated_exchange_indexed_and_value_table(monkeypatch, case, indexed):
@@ -104,6 +105,11 @@ def test_replicated_exchange_indexed_and_value_table(monkeypatch, case, indexed)
         indexed = "1"
     elif indexed == "part":
         monkeypatch.setenv("LS_AMD_PULL_SPLIT", "70000")
+        indexed = "1"
+    cached = indexed.startswith("cached")  # slot cache: resolve once, later matvecs gather only ("-part": a buffer for some rows)
+    if cached:
+        if indexed == "cached-part":
+            monkeypatch.setenv("LS_AMD_PULL_SPLIT", "70000")
         indexed = "1"
     import torch
 
@@ -131,15 +137,21 @@ def test_replicated_exchange_indexed_and_value_table(monkeypatch, case, indexed)
     ys = [torch.full_like(x, -3.0) for x in xs]
     kernels = [None] * P
 
+    others = [D.fillRandom(reps[p], 77, dtype) for p in range(P)]
+
     def body(rank, comm):
         op = RcclReplicatedOperator(h, reps_global, masks, dtype, comm=comm)
+        if cached:
+            assert op.engine.plan.cache_slots(70000 if "LS_AMD_PULL_SPLIT" in os.environ else 0) > 0
+            op.matvec(others[rank], ys[rank], check=True)  # resolves; the checked calls below reuse the streams on another x
         kernels[rank] = op.engine.plan.kernel
         for _ in range(2):
             op.matvec(xs[rank], ys[rank], check=True)
         op.rm.destroy()
 
     comms = _run_ranks(P, body)
-    assert all(k == ("replicated-tile-pull+indexed" if indexed == "1" else "replicated-tile-pull") for k in kernels), kernels
+    want_kernel = ("replicated-tile-pull+indexed" if indexed == "1" else "replicated-tile-pull") + ("+cached" if cached else "")
+    assert all(k == want_kernel for k in kernels), kernels
     keys = CO.locale_idx_of(want_reps, P)
     x = CO.hashed_to_block([v.cpu().numpy() for v in xs], keys)
     got = CO.hashed_to_block([v.cpu().numpy() for v in ys], keys)

@@ -232,6 +232,52 @@ def test_indexed_pull_mode_complex_characters(torch, monkeypatch, L, sector, spl
     assert np.abs(got - want).max() <= 1e-12 * max(1.0, np.abs(want).max())
 
 
+@pytest.mark.parametrize("case", ["heisenberg_chain_24_symm/f64", "heisenberg_chain_24_symm/c128", "heisenberg_kagome_12_symm/f64",
+                                  "heisenberg_square_4x4/f64", "issue_01/f64", "issue_01/c128", "translation_12_5/c128"])
+def test_slot_cache_single_locale(torch, case):
+    """ls_amd_plan_cache_slots (opt-in, not matrix-free): the first matvec resolves the packet streams -- slot of every
+    partner, row byte, coefficient unless all packets share one amplitude --, every later one is the gather kernel alone.  The
+    cached plan must give what the oracle gives for EVERY x it is applied to (the streams depend on operator and basis only):
+    two different vectors after the resolving call, trivial sectors (prescaled x, no coefficient), a -1 character (real
+    coefficient), complex characters (complex coefficient), a lattice group (K4 by translation cosets); an unprojected basis
+    has nothing to cache and stays as it is."""
+    from oracle import c_oracle as CO
+    from oracle import model as M
+
+    name, dt = case.split("/")
+    if name.startswith("translation"):
+        _, L, sector = name.split("_")
+        cfg = complex_translation_config(int(L), int(sector))
+        o = CO.COracle(M.model_from_config(cfg))
+        want_reps = o.enumerate()
+    else:
+        cfg, o, want_reps = model_config(name), oracle_for(name), oracle_reps(name)
+    D, basis, h, reps, masks = setup_model(torch, cfg, 1)
+    dtype = torch.complex128 if dt == "c128" else torch.float64
+    pl = D.MatvecPlan(h, reps, dtype, mode="pull")
+    assert pl.kernel == "tile-pull+indexed"
+    rows = pl.cache_slots(0)
+    assert rows == len(want_reps) and pl.kernel == "tile-pull+indexed+cached"
+    crow, cbytes = pl.slot_cache
+    assert crow == rows and cbytes > 0
+    rs = np.random.RandomState(61)
+    for trial in range(3):  # 0 resolves + gathers, 1 and 2 only gather
+        x = rs.rand(len(want_reps)) - 0.5
+        if dt == "c128":
+            x = x + 1j * (rs.rand(len(want_reps)) - 0.5)
+        xd = torch.from_numpy(x).cuda()
+        yd = torch.full_like(xd, -7.0)
+        pl.matvec([xd], [yd])
+        want = o.local_matvec(want_reps, x)
+        assert np.abs(yd.cpu().numpy() - want).max() <= 1e-12 * max(1.0, np.abs(want).max()), (case, trial)
+    pl.destroy()
+    # nothing to cache on an unprojected basis
+    D2, b2, h2, reps2, _ = setup_model(torch, model_config("heisenberg_chain_16"), 1)
+    p2 = D2.MatvecPlan(h2, reps2, torch.float64, mode="pull")
+    assert p2.cache_slots(0) == 0 and "cached" not in p2.kernel and p2.slot_cache == (0, 0)
+    p2.destroy()
+
+
 def test_indexed_pull_mode_reports_states_outside_the_basis(torch, monkeypatch):
     """DMV:115-118 in the indexed mode: a partner the static table does not hold raises the plan's error flag"""
     import distributed_matvec_amd as D

@@ -475,3 +475,14 @@ def test_symmetric_chain_ground_state_equals_bethe_ansatz(torch, L):
     assert res.converged, res.history[-2:]
     want = bethe.ground_state_energy_sigma(L)
     assert abs(res.eigenvalues[0] - want) <= 1e-8 * abs(want), (res.eigenvalues[0], want)
+    # the same solve with the slot cache (what diagonalize() runs when HBM has room: the first matvec resolves the packet
+    # streams, the other ~100 only gather): same pin, same number of matvecs
+    matvecs = res.matvecs
+    del res
+    torch.cuda.empty_cache()
+    op = LocalOperator(h, reps, torch.float64, slot_cache_bytes=64 << 30)
+    assert op.cached_rows == int(masks.numel()) and op.plan.kernel == "tile-pull+indexed+cached"
+    assert 0 < op.plan.slot_cache[1] <= 25 * 5 * int(masks.numel())  # exact stream lengths: <= 20 packets per row on average, 5 B each
+    res = lanczos_smallest(op, num_evals=1, eps=1e-7, max_basis=16, max_restarts=200)
+    assert res.converged and abs(res.matvecs - matvecs) <= 16
+    assert abs(res.eigenvalues[0] - want) <= 1e-8 * abs(want), (res.eigenvalues[0], want)
