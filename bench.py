@@ -115,6 +115,14 @@ def scaling_model(model, P, w=8):
             lo_hi.append(t)
     out["predicted_ms_per_matvec"] = [min(lo_hi), max(lo_hi)]
     out["predicted_speedup_over_one_gpu"] = [m["fused"] / max(lo_hi), m["fused"] / min(lo_hi)]
+    if "resolve" in m:
+        # with the slot cache the resolve step runs once per plan: a matvec is exchange + gather (+ prescale, + return)
+        c = []
+        for b in XGMI_IN_GBPS:
+            for f in (1.0, REPL_OVERHEAD):
+                ret = m["n"] * w / P / 1.0e9 * 1e3 / 3000.0 + (m["n"] * w / P) * (P - 1) / P / b / 1e6
+                c.append(m["prescale"] / P + xbytes / b / 1e6 + m["gather"] / P * f + ret)
+        out["predicted_ms_per_matvec_slot_cache"] = [min(c), max(c)]
     return out
 
 

@@ -1455,8 +1455,7 @@ static int gtab_build(ls_amd_gtab *t, void *stream) {
         t->counts[0] = n;
         t->max_count = n;
     }
-    int64_t max_bytes = (int64_t)1 << 40;
-    { char const *e = getenv("LS_AMD_GTAB_MAX_BYTES"); if (e && atoll(e) > 0) max_bytes = atoll(e); }
+    int64_t const max_bytes = (int64_t)1 << 40;
     int const bb = lsk_gtab_bits(t->L, n, max_bytes);
     if (bb < 0) return set_error("indexed pull: no admissible index-table size for %lld keys of %d bits", (long long)n, t->L);
     t->tab.L = t->L; t->tab.bbits = bb; t->tab.tbits = t->L - bb;
@@ -2168,9 +2167,8 @@ int ls_amd_plan_create(ls_amd_plan **out, ls_hs_operator const *op, ls_amd_dtype
     }
     /* kernel family */
     /* a plan that owns ONE partition is driven by generate / exchange / scatter (one locale per process): always the
-     * packet kernels, also when numLocales == 1 (the reference's matrixVectorProduct works there too, DMV:1072-1093).
-     * LS_AMD_FORCE_TILE: test hook, packets path for an all-partitions plan with P == 1 */
-    int const force_tile = getenv("LS_AMD_FORCE_TILE") != NULL || my_partition >= 0;
+     * packet kernels, also when numLocales == 1 (the reference's matrixVectorProduct works there too, DMV:1072-1093) */
+    int const force_tile = my_partition >= 0;
     if (force_tile) pl->family = FAMILY_TILE;
     else if (num_partitions == 1 && pl->dbs.proj != LSK_PROJ_FULL) {
         ls_amd_mode m = mode;
