@@ -89,6 +89,7 @@ MODEL_INPUTS_MS = {
     "heisenberg_chain_32": {"fused": 7.70, "n": 601080390},
 }
 XGMI_IN_GBPS = (7 * 50.0, 7 * 64.0)  # what one GPU receives from its 7 peers at once: 7 links x 50-64 GB/s achievable of 153 nominal
+REACH_SHARE_MAX = 0.56               # 2.358 / 4.208 GB: the rank in the middle of the basis; the average over ranks is 0.44
 REPL_OVERHEAD = 1.23                 # per-row cost of a rank's kernels relative to one GPU (x arrives owner-major: the near partners'
                                      # values no longer share lines; measured on eight loop-back ranks, profiles/r3_loopback_*_final.txt)
 
@@ -101,6 +102,10 @@ def scaling_model(model, P, w=8):
     if not m or P < 2:
         return None
     xbytes = m["n"] * w * (P - 1) / P
+    if "resolve" not in m:
+        # unprojected bases: the sub-range exchange (dist.c::setup_reach) -- the largest share a rank receives, measured with
+        # loop-back ranks on chain_28 / chain_32 at P = 8 (profiles/r4_loopback_chain32_8ranks_subrange_exchange.txt: 2.36 of 4.21 GB)
+        xbytes *= REACH_SHARE_MAX
     out = {"inputs_ms_one_gpu": m, "assumed_in_GBps": list(XGMI_IN_GBPS), "assumed_kernel_overhead": [1.0, REPL_OVERHEAD], "x_bytes_in_per_rank": xbytes}
     lo_hi = []
     for b in XGMI_IN_GBPS:
@@ -110,7 +115,7 @@ def scaling_model(model, P, w=8):
             if "resolve" in m:
                 t = m["prescale"] / P + max(m["resolve"] / P * f, xch) + m["gather"] / P * f + ret
             else:
-                perm = m["n"] * 2 * w / 1.0e9 * 1e3 / 2500.0  # the hashed -> block permutation of x: N random reads + N writes
+                perm = REACH_SHARE_MAX * m["n"] * 2 * w / 1.0e9 * 1e3 / 2500.0  # the hashed -> block permutation of what arrived: random reads + writes
                 t = xch + perm + m["fused"] / P + ret
             lo_hi.append(t)
     out["predicted_ms_per_matvec"] = [min(lo_hi), max(lo_hi)]
@@ -202,7 +207,7 @@ def projected_extra(D, torch, dist, name, rank, world, time_steps, allsum, steps
     stages, mv = plan.stage_times()
     out.update({"matvecs_per_s": steps / dt, "ms_per_step": 1e3 * dt / steps, "kernel": plan.kernel, "exchange": "replicated",
                 "n_gpus": world, "exchange_bytes_per_matvec": allsum(getattr(op, "exchange_bytes_per_matvec", 0)),
-                "x_bytes_in_this_rank": 8 * (n_total - int(my.numel())),
+                "x_bytes_in_this_rank": op.x_bytes_in,
                 "rank0_stage_ms_per_matvec": {k: v[0] / max(1, mv) for k, v in stages.items()},
                 "model": scaling_model(name, world)})
     out["slot_cache"] = slot_cache_leg(plan, lambda: op.matvec(x, y, check=False), plan.check, plan.kernel_times_ms, time_steps, steps)
@@ -507,10 +512,14 @@ def main():
         lps = max(1, len(samples) // max(1, steps))
         kms = sum(samples) / max(1, len(samples))  # average duration of ONE launch of the dominant kernel
         xb = allsum(getattr(op, "exchange_bytes_per_matvec", 0))
+        x_in = getattr(op, "x_bytes_in", None)
+        if x_in is not None:  # replicated-x: what this rank and all ranks receive of x per matvec (sub-range exchange: < N - N/P elements)
+            x_in_info[label] = {"rank0": x_in, "all_ranks": allsum(x_in), "whole_vector_all_ranks": allsum((n_total - int(my_reps.numel())) * w)}
         return dt, kms, lps, plan.kernel, xb, plan, op
 
     exchanges = {}
     failed = {}
+    x_in_info = {}
     if not distributed:
         make = lambda: D.MatvecPlan(h, [my_reps], tdtype, mode=args.mode)  # noqa: E731
         exchange = "none"
@@ -554,6 +563,8 @@ def main():
             results[name] = r
             exchanges[name] = {"matvecs_per_s": args.steps / r[0], "ms_per_step": 1e3 * r[0] / args.steps, "kernel": r[3],
                                "kernel_ms_avg": r[1], "launches_per_step": r[2], "exchange_bytes_per_matvec": r[4]}
+            if name in x_in_info:
+                exchanges[name]["x_bytes_in"] = x_in_info[name]
             if len(wanted) > 1:  # keep only the numbers; the plans of the other strategy would pin HBM
                 results[name] = r[:5] + (None, None)
                 del r

@@ -159,6 +159,7 @@ def load():
         "ls_amd_repl_matvec": (C.c_int, [vp, vp, vp, vp]),
         "ls_amd_repl_plan": (vp, [vp]),
         "ls_amd_repl_exchange_bytes": (C.c_int64, [vp]),
+        "ls_amd_repl_x_in_bytes": (C.c_int64, [vp]),
         "ls_amd_enumerate_states": (C.c_int, [bp, C.c_int, C.POINTER(vp), C.POINTER(vp), c_i64p, vp]),
         "ls_amd_gather": (C.c_int, [C.c_int64, vp, C.c_int, C.c_int, vp, vp, vp]),
         "ls_amd_mask_counts": (C.c_int, [C.c_int64, vp, C.c_int, c_i64p, vp]),

@@ -607,6 +607,8 @@ class ReplMatvec:
 
     @property
     def exchange_bytes(self): return int(_lib.load().ls_amd_repl_exchange_bytes(self.h))
+    @property
+    def x_in_bytes(self): return int(_lib.load().ls_amd_repl_x_in_bytes(self.h))
 
     def matvec(self, x, y, check: bool = True):
         _lib.check(_lib.load().ls_amd_repl_matvec(self.h, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), _stream_ptr()))

@@ -276,42 +276,58 @@ extern "C" int lsk_comm_exchange_begin(lsk_comm *c, int slot, void *compute_stre
     HIP_CHECK(hipStreamWaitEvent(c->xstream, c->ready[slot], 0));
     return 0;
 }
-extern "C" int lsk_comm_alltoallv_on(lsk_comm *c, void *stream, void const *d_send, int64_t const *send_off,
-                                     int64_t const *send_bytes, void *d_recv, int64_t const *recv_off,
-                                     int64_t const *recv_bytes) {
+// K segments per peer in ONE exchange: segment k for / from peer p is entry [k * size + p] of the offset / byte arrays (a
+// segment of 0 bytes is skipped on both sides; the k-th message of a pair matches the k-th).  One ncclGroup: every pair's
+// segments travel over that pair's link at once.
+extern "C" int lsk_comm_alltoallv_multi_on(lsk_comm *c, void *stream, int K, void const *d_send, int64_t const *send_off,
+                                           int64_t const *send_bytes, void *d_recv, int64_t const *recv_off,
+                                           int64_t const *recv_bytes) {
     hipStream_t s = (hipStream_t)stream;
+    if (K < 1) return 0;
     if (c->local) { // every rank posts its send segments, then copies what is addressed to it out of its peers' buffers
         LocalGroup *g = c->local;
         HIP_CHECK(hipStreamSynchronize(s));
         g->post[c->rank].send = d_send; g->post[c->rank].off = send_off; g->post[c->rank].bytes = send_bytes;
         pthread_barrier_wait(&g->bar);
-        for (int src = 0; src < g->size; ++src) {
-            if (src == c->rank || recv_bytes[src] == 0) continue;
-            if (g->post[src].bytes[c->rank] != recv_bytes[src]) {
-                snprintf(g_cerr, sizeof(g_cerr), "loop-back all-to-all-v: rank %d sends %lld bytes to rank %d, which expects %lld", src,
-                         (long long)g->post[src].bytes[c->rank], c->rank, (long long)recv_bytes[src]);
-                pthread_barrier_wait(&g->bar);
-                return -1;
+        for (int k = 0; k < K; ++k)
+            for (int src = 0; src < g->size; ++src) {
+                const int64_t want = recv_bytes[(size_t)k * g->size + src];
+                const int64_t have = src == c->rank ? want : g->post[src].bytes[(size_t)k * g->size + c->rank];
+                if (src == c->rank) continue;
+                if (have != want) {
+                    snprintf(g_cerr, sizeof(g_cerr), "loop-back all-to-all-v: rank %d sends %lld bytes (segment %d) to rank %d, which expects %lld",
+                             src, (long long)have, k, c->rank, (long long)want);
+                    pthread_barrier_wait(&g->bar);
+                    return -1;
+                }
+                if (want == 0) continue;
+                const hipError_t e1 = hipMemcpyAsync((char *)d_recv + recv_off[(size_t)k * g->size + src],
+                                                     (char const *)g->post[src].send + g->post[src].off[(size_t)k * g->size + c->rank],
+                                                     (size_t)want, hipMemcpyDeviceToDevice, s);
+                if (e1 != hipSuccess) { pthread_barrier_wait(&g->bar); snprintf(g_cerr, sizeof(g_cerr), "loop-back all-to-all-v: %s", hipGetErrorString(e1)); return -1; }
             }
-            const hipError_t e1 = hipMemcpyAsync((char *)d_recv + recv_off[src], (char const *)g->post[src].send + g->post[src].off[c->rank],
-                                                 (size_t)recv_bytes[src], hipMemcpyDeviceToDevice, s);
-            if (e1 != hipSuccess) { pthread_barrier_wait(&g->bar); snprintf(g_cerr, sizeof(g_cerr), "loop-back all-to-all-v: %s", hipGetErrorString(e1)); return -1; }
-        }
         const hipError_t e2 = hipStreamSynchronize(s);
         pthread_barrier_wait(&g->bar); // nobody reuses a send buffer before every peer has read it
         if (e2 != hipSuccess) { snprintf(g_cerr, sizeof(g_cerr), "loop-back all-to-all-v: %s", hipGetErrorString(e2)); return -1; }
         return 0;
     }
     NCCL_CHECK(g_api.GroupStart());
-    for (int step = 1; step < c->size; ++step) {
-        const int dst = (c->rank + step) % c->size, src = (c->rank - step + c->size) % c->size;
-        if (send_bytes[dst] > 0)
-            NCCL_CHECK(g_api.Send((char const *)d_send + send_off[dst], (size_t)send_bytes[dst], ncclChar, dst, c->comm, s));
-        if (recv_bytes[src] > 0)
-            NCCL_CHECK(g_api.Recv((char *)d_recv + recv_off[src], (size_t)recv_bytes[src], ncclChar, src, c->comm, s));
-    }
+    for (int k = 0; k < K; ++k)
+        for (int step = 1; step < c->size; ++step) {
+            const int dst = (c->rank + step) % c->size, src = (c->rank - step + c->size) % c->size;
+            const size_t ks = (size_t)k * c->size + dst, kr = (size_t)k * c->size + src;
+            if (send_bytes[ks] > 0)
+                NCCL_CHECK(g_api.Send((char const *)d_send + send_off[ks], (size_t)send_bytes[ks], ncclChar, dst, c->comm, s));
+            if (recv_bytes[kr] > 0)
+                NCCL_CHECK(g_api.Recv((char *)d_recv + recv_off[kr], (size_t)recv_bytes[kr], ncclChar, src, c->comm, s));
+        }
     NCCL_CHECK(g_api.GroupEnd());
     return 0;
+}
+extern "C" int lsk_comm_alltoallv_on(lsk_comm *c, void *stream, void const *d_send, int64_t const *send_off,
+                                     int64_t const *send_bytes, void *d_recv, int64_t const *recv_off,
+                                     int64_t const *recv_bytes) {
+    return lsk_comm_alltoallv_multi_on(c, stream, 1, d_send, send_off, send_bytes, d_recv, recv_off, recv_bytes);
 }
 extern "C" int lsk_comm_alltoallv(lsk_comm *c, void const *d_send, int64_t const *send_off, int64_t const *send_bytes,
                                   void *d_recv, int64_t const *recv_off, int64_t const *recv_bytes) {

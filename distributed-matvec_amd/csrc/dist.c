@@ -38,6 +38,7 @@ uint32_t const *ls_amd_internal_gtab_perm(ls_amd_gtab const *t);
 int64_t ls_amd_internal_gtab_max_count(ls_amd_gtab const *t);
 int64_t const *ls_amd_internal_gtab_counts(ls_amd_gtab const *t);
 int64_t ls_amd_internal_gtab_bytes(ls_amd_gtab const *t);
+int ls_amd_internal_plan_reach(ls_amd_plan *pl, int shift, int64_t row0, int64_t halo, int64_t nwords, uint32_t *h_bitmap, void *stream);
 int ls_amd_internal_basis_is_projected(ls_hs_basis const *b);
 int ls_amd_internal_plan_prescales(ls_amd_plan const *pl);
 int ls_amd_internal_owner_norms(ls_hs_operator const *op, ls_amd_gtab const *gt, int me, double **d_norms, void *stream);
@@ -357,6 +358,14 @@ struct ls_amd_repl {
     int64_t y_self_bytes;            /* my rows of my own partition: copied, not sent */
     int64_t exchange_bytes;
     /* indexed mode (projected bases): x stays in the order it arrives in -- no permutation pass, no table refresh */
+    /* sub-range exchange (unprojected bases, P > 1): a rank's contiguous rows read only part of x -- their own neighbourhood
+     * and the partner blocks of the top bonds (44 % of it on chain_32 at P = 8).  The part is kept as <= REACH_K intervals of
+     * global rows; every owner's elements are ascending in global rank, so what a peer needs of an owner's array is one
+     * contiguous piece per interval: sent as it lies, no packing.  reach_k == 0: the whole vector is exchanged. */
+    int reach_k;
+    int64_t reach_iv[2 * 16];        /* my intervals [a_k, b_k) of global rows */
+    int64_t *rx_soff, *rx_sbytes, *rx_roff, *rx_rbytes; /* [reach_k * P] segment k for / from peer p */
+    int64_t x_in_bytes;              /* bytes of x this rank receives per matvec */
     ls_amd_gtab *gt;                 /* static {rep -> slot} table + global row -> slot permutation (shared, host.c) */
     double *d_norms_own;             /* norm(rep) of the representatives this rank owns (K4 modes that prescale), else NULL */
 };
@@ -372,12 +381,132 @@ void ls_amd_repl_destroy(ls_amd_repl *r) {
     free(r->counts);
     free(r->xs_off); free(r->xs_bytes); free(r->xr_off); free(r->xr_bytes);
     free(r->ys_off); free(r->ys_bytes); free(r->yr_off); free(r->yr_bytes);
+    free(r->rx_soff); free(r->rx_sbytes); free(r->rx_roff); free(r->rx_rbytes);
     free(r);
 }
 
 static int dmalloc(void **p, int64_t bytes) {
     DEVC(lsk_malloc(p, (size_t)(bytes > 0 ? bytes : 8)));
     return 0;
+}
+
+enum { REACH_K = 16, REACH_HALO = 1024 };
+/* LS_AMD_REPL_REACH: 0 = exchange the whole vector; s in 1..30 = blocks of 2^s rows (default 14: 128 KB of f64); -s = the same
+ * and use the sub-range layout whatever share of the vector it covers (tests on small bases) */
+static int reach_setting(int *force) {
+    char const *e = getenv("LS_AMD_REPL_REACH");
+    int v = e ? atoi(e) : 14;
+    *force = v < 0;
+    if (v < 0) v = -v;
+    return v > 30 ? 30 : v;
+}
+static int cmp_i64(void const *a, void const *b) { int64_t const x = *(int64_t const *)a, y = *(int64_t const *)b; return x < y ? -1 : x > y; }
+/* Collective.  Decides (all ranks alike) whether the sub-range exchange pays, and lays it out.  `rc_in` = this rank's status so
+ * far; returns the agreed status.  On any "does not apply" the object simply keeps reach_k == 0. */
+static int setup_reach(ls_amd_repl *r, uint8_t const *d_masks, int rc_in, void *stream) {
+    ls_amd_comm *cm = r->comm;
+    int const P = r->P, me = r->me;
+    int force = 0;
+    int const REACH_SHIFT = reach_setting(&force);
+    int64_t const nblocks = ((r->n - 1) >> REACH_SHIFT) + 1, nwords = (nblocks + 31) / 32;
+    int64_t iv[2 * REACH_K];
+    memset(iv, 0, sizeof(iv));
+    int use = 0, rc = rc_in;
+    if (rc == 0) {
+        uint32_t *bm = (uint32_t *)malloc(4 * (size_t)nwords);
+        int const q = ls_amd_internal_plan_reach(r->plan, REACH_SHIFT, r->n0, REACH_HALO, nwords, bm, stream);
+        if (q < 0) rc = -1;
+        else if (q == 0) {
+            /* runs of marked blocks -> intervals; gaps are closed smallest first until REACH_K intervals are left */
+            int64_t *a = (int64_t *)malloc(8 * (size_t)(nblocks + 1)), *b = (int64_t *)malloc(8 * (size_t)(nblocks + 1));
+            int64_t k = 0, covered = 0;
+            for (int64_t blk = 0; blk < nblocks; ++blk) {
+                if (!((bm[blk >> 5] >> (blk & 31)) & 1)) continue;
+                if (k > 0 && b[k - 1] == blk) b[k - 1] = blk + 1;
+                else { a[k] = blk; b[k] = blk + 1; ++k; }
+            }
+            while (k > REACH_K) {
+                int64_t best = 0, gap = -1;
+                for (int64_t j = 0; j + 1 < k; ++j) if (gap < 0 || a[j + 1] - b[j] < gap) { gap = a[j + 1] - b[j]; best = j; }
+                b[best] = b[best + 1];
+                for (int64_t j = best + 1; j + 1 < k; ++j) { a[j] = a[j + 1]; b[j] = b[j + 1]; }
+                --k;
+            }
+            for (int64_t j = 0; j < k; ++j) {
+                iv[2 * j] = a[j] << REACH_SHIFT;
+                iv[2 * j + 1] = (b[j] << REACH_SHIFT) < r->n ? (b[j] << REACH_SHIFT) : r->n;
+                covered += iv[2 * j + 1] - iv[2 * j];
+            }
+            free(a); free(b);
+            use = k > 0 && (force || covered * 10 <= r->n * 8); /* below 80 % of the vector: worth a second exchange layout */
+        }
+        free(bm);
+    }
+    rc = agree(cm, rc, stream);
+    if (rc != 0) return rc;
+    /* one layout decision for all ranks: every rank's intervals, and "use" only if every rank says so */
+    int64_t *all = (int64_t *)calloc((size_t)P * (2 * REACH_K + 1), 8), mine[2 * REACH_K + 1];
+    memcpy(mine, iv, sizeof(iv));
+    mine[2 * REACH_K] = use;
+    void *ds = NULL;
+    size_t const per = 8 * (2 * REACH_K + 1);
+    rc = scratch(cm, per * (size_t)(P + 1), &ds);
+    if (rc == 0 && lsk_h2d(ds, mine, per) != 0) rc = ls_amd_internal_error("%s", lsk_last_error());
+    rc = agree(cm, rc, stream);
+    if (rc == 0 && lsk_comm_allgather(cm->c, ds, (char *)ds + per, (int64_t)per, stream) != 0) rc = ls_amd_internal_error("%s", lsk_comm_last_error());
+    if (rc == 0 && (lsk_sync(stream) != 0 || lsk_d2h(all, (char *)ds + per, per * (size_t)P) != 0)) rc = ls_amd_internal_error("%s", lsk_last_error());
+    int every = rc == 0;
+    for (int p = 0; p < P && rc == 0; ++p) if (!all[(size_t)p * (2 * REACH_K + 1) + 2 * REACH_K]) every = 0;
+    if (rc == 0 && every) {
+        /* counts of every partition's states below every interval end: one pass over `masks` in ascending order of the ends */
+        int const nb = 2 * REACH_K * P;
+        int64_t *ends = (int64_t *)malloc(8 * (size_t)(nb + 1)), *below = (int64_t *)calloc((size_t)(nb + 1) * (size_t)P, 8), cnt[LSK_MAX_PARTS];
+        int ne = 0;
+        for (int p = 0; p < P; ++p) for (int j = 0; j < 2 * REACH_K; ++j) ends[ne++] = all[(size_t)p * (2 * REACH_K + 1) + j];
+        qsort(ends, (size_t)ne, 8, cmp_i64);
+        int nu = 0;
+        for (int j = 0; j < ne; ++j) if (nu == 0 || ends[j] != ends[nu - 1]) ends[nu++] = ends[j];
+        int64_t prev = 0;
+        for (int j = 0; j < nu && rc == 0; ++j) { /* below[j][p] = states of partition p with global rank < ends[j] */
+            if (j > 0) memcpy(below + (size_t)j * P, below + (size_t)(j - 1) * P, 8 * (size_t)P);
+            if (ends[j] > prev) {
+                if (ls_amd_mask_counts(ends[j] - prev, d_masks + prev, P, cnt, stream) != 0) { rc = -1; break; }
+                for (int p = 0; p < P; ++p) below[(size_t)j * P + p] += cnt[p];
+                prev = ends[j];
+            }
+        }
+        if (rc == 0) {
+            r->rx_soff = (int64_t *)calloc((size_t)REACH_K * P, 8); r->rx_sbytes = (int64_t *)calloc((size_t)REACH_K * P, 8);
+            r->rx_roff = (int64_t *)calloc((size_t)REACH_K * P, 8); r->rx_rbytes = (int64_t *)calloc((size_t)REACH_K * P, 8);
+            int64_t x_out = 0;
+            r->x_in_bytes = 0;
+            for (int q = 0; q < P; ++q)
+                for (int k = 0; k < REACH_K; ++k) {
+                    int64_t const a = all[(size_t)q * (2 * REACH_K + 1) + 2 * k], b = all[(size_t)q * (2 * REACH_K + 1) + 2 * k + 1];
+                    if (b <= a) continue;
+                    int64_t const *ba = (int64_t const *)bsearch(&a, ends, (size_t)nu, 8, cmp_i64), *bb = (int64_t const *)bsearch(&b, ends, (size_t)nu, 8, cmp_i64);
+                    int64_t const *la = below + (size_t)(ba - ends) * P, *lb = below + (size_t)(bb - ends) * P;
+                    if (q != me) { /* what rank q needs of MY partition */
+                        r->rx_soff[(size_t)k * P + q] = la[me] * r->w;
+                        r->rx_sbytes[(size_t)k * P + q] = (lb[me] - la[me]) * r->w;
+                        x_out += (lb[me] - la[me]) * r->w;
+                    } else
+                        for (int p = 0; p < P; ++p) { /* what I need of partition p: into its place in the gathered buffer */
+                            if (p == me) continue;
+                            r->rx_roff[(size_t)k * P + p] = ((int64_t)p * r->max_count + la[p]) * r->w;
+                            r->rx_rbytes[(size_t)k * P + p] = (lb[p] - la[p]) * r->w;
+                            r->x_in_bytes += (lb[p] - la[p]) * r->w;
+                        }
+                }
+            memcpy(r->reach_iv, iv, sizeof(iv));
+            r->reach_k = REACH_K;
+            /* exchange_bytes counted the whole block to every peer: replace that share */
+            r->exchange_bytes += x_out - (int64_t)(P - 1) * r->counts[me] * r->w;
+        }
+        free(ends); free(below);
+    }
+    free(all);
+    return agree(cm, rc, stream);
 }
 
 int ls_amd_repl_create(ls_amd_repl **out, ls_amd_comm *cm, ls_hs_operator const *op, ls_amd_dtype dtype,
@@ -498,6 +627,15 @@ int ls_amd_repl_create(ls_amd_repl **out, ls_amd_comm *cm, ls_hs_operator const 
         }
     } else if (rc == 0)
         rc = ls_amd_plan_create_replicated(&r->plan, op, dtype, P, me, d_reps_global + r->n0, nb, d_reps_global, count_global, stream);
+    r->x_in_bytes = (r->n - r->counts[me]) * r->w; /* every peer's block, unless the sub-range exchange below applies */
+    if (!indexed && P > 1) {
+        /* (collective; LS_AMD_REPL_REACH=0 keeps the exchange of the whole vector -- the same on every rank, like every switch) */
+        int force = 0;
+        if (reach_setting(&force) != 0 && r->n > 0) {
+            if (rc == 0 && r->d_xglobal && lsk_memset_async(r->d_xglobal, 0, (size_t)(r->n * r->w), stream) != 0) rc = ls_amd_internal_error("%s", lsk_last_error());
+            rc = setup_reach(r, d_masks, rc, stream);
+        }
+    }
     if (agree(cm, rc, stream) != 0) { ls_amd_repl_destroy(r); return -1; } /* buffers and plan exist on every rank, or the object on none */
     *out = r;
     return 0;
@@ -505,6 +643,7 @@ int ls_amd_repl_create(ls_amd_repl **out, ls_amd_comm *cm, ls_hs_operator const 
 
 ls_amd_plan *ls_amd_repl_plan(ls_amd_repl *r) { return r->plan; }
 int64_t ls_amd_repl_exchange_bytes(ls_amd_repl const *r) { return r->exchange_bytes; }
+int64_t ls_amd_repl_x_in_bytes(ls_amd_repl const *r) { return r->x_in_bytes; }
 
 int ls_amd_repl_matvec(ls_amd_repl *r, void const *d_x_local, void *d_y_local, void *stream) {
     int64_t const nb = r->n1 - r->n0, w = r->w;
@@ -538,10 +677,18 @@ int ls_amd_repl_matvec(ls_amd_repl *r, void const *d_x_local, void *d_y_local, v
         /* 1. blocks of x: mine by a device copy, the others straight from their owners */
         int st = ls_amd_internal_stage_begin(r->plan, ST_EXCHANGE, stream);
         DEVC(lsk_d2d_async((char *)r->d_gathered + r->xr_off[r->me], d_x_local, (size_t)(r->counts[r->me] * w), stream));
-        if (r->P > 1) COMM(lsk_comm_alltoallv_on(r->comm->c, stream, d_x_local, r->xs_off, r->xs_bytes, r->d_gathered, r->xr_off, r->xr_bytes));
+        if (r->reach_k > 0) /* only what my rows read: <= REACH_K contiguous pieces of every owner's block, in one group */
+            COMM(lsk_comm_alltoallv_multi_on(r->comm->c, stream, r->reach_k, d_x_local, r->rx_soff, r->rx_sbytes, r->d_gathered, r->rx_roff, r->rx_rbytes));
+        else if (r->P > 1) COMM(lsk_comm_alltoallv_on(r->comm->c, stream, d_x_local, r->xs_off, r->xs_bytes, r->d_gathered, r->xr_off, r->xr_bytes));
         ls_amd_internal_stage_end(r->plan, st, stream);
         st = ls_amd_internal_stage_begin(r->plan, ST_REFRESH, stream);
-        DEVC(lsk_gather_perm(r->n, r->d_perm, r->perm64, (int)w, r->d_gathered, r->d_xglobal, stream));
+        if (r->reach_k > 0) { /* the permutation into global order, on my intervals only */
+            int const ps = r->perm64 ? 8 : 4;
+            for (int k = 0; k < r->reach_k; ++k) {
+                int64_t const a = r->reach_iv[2 * k], b = r->reach_iv[2 * k + 1];
+                if (b > a) DEVC(lsk_gather_perm(b - a, (char const *)r->d_perm + a * ps, r->perm64, (int)w, r->d_gathered, (char *)r->d_xglobal + a * w, stream));
+            }
+        } else DEVC(lsk_gather_perm(r->n, r->d_perm, r->perm64, (int)w, r->d_gathered, r->d_xglobal, stream));
         ls_amd_internal_stage_end(r->plan, st, stream);
         x_rows = r->d_xglobal;
     }

@@ -2503,6 +2503,31 @@ int ls_amd_matvec_replicated(ls_amd_plan *pl, void const *d_x_global, void *d_y_
     }
     return set_error("ls_amd_matvec_replicated: not a replicated-x plan");
 }
+/* Plan time (dist.c, replicated-x exchange of an unprojected basis): the blocks of 2^shift rows of the global vector that this
+ * plan's rows read -- every off-diagonal partner, plus the rows themselves with `halo` rows either side (the LDS windows of the
+ * staged kernels; row0 = global index of the plan's first row).  h_bitmap[nwords] is overwritten.  Returns 0, 1 when the question does not apply (projected bases read x
+ * through the index table; inversion sectors canonicalise the partner first: they keep the whole vector), -1 on a device error. */
+int ls_amd_internal_plan_reach(ls_amd_plan *pl, int shift, int64_t row0, int64_t halo, int64_t nwords, uint32_t *h_bitmap, void *stream) {
+    if (pl->family != FAMILY_REPL_DIRECT || pl->dbs.proj != LSK_PROJ_NONE) return 1;
+    part_state *ps = &pl->parts[0];
+    int64_t const n_global = pl->gindex.count;
+    if (((n_global - 1) >> shift) / 32 >= nwords) return set_error("internal error: reach bitmap too small");
+    memset(h_bitmap, 0, 4 * (size_t)nwords);
+    if (ps->count <= 0) return 0;
+    void *d = NULL;
+    DEV(lsk_malloc(&d, 4 * (size_t)nwords));
+    if (lsk_memset_async(d, 0, 4 * (size_t)nwords, stream) != 0 ||
+        lsk_reach_blocks(pl->dop, pl->gindex, ps->count, ps->d_reps, shift, (uint32_t *)d, stream) != 0 || lsk_sync(stream) != 0 ||
+        lsk_d2h(h_bitmap, d, 4 * (size_t)nwords) != 0) { lsk_free(d); return dev_error(); }
+    lsk_free(d);
+    /* own rows [row0, row0 + count) +- halo */
+    int64_t g0 = row0, g1 = g0 + ps->count;
+    g0 = g0 > halo ? g0 - halo : 0;
+    g1 = g1 + halo < n_global ? g1 + halo : n_global;
+    for (int64_t b = g0 >> shift; b <= (g1 - 1) >> shift; ++b) h_bitmap[b >> 5] |= 1u << (b & 31);
+    return 0;
+}
+
 /* The indexed replicated-x matvec in two steps (dist.c): BEGIN resolves the packets of the first split_rows rows -- stage A,
  * K4 and every slot look-up, nothing of x -- and is enqueued while the blocks of x travel; FINISH gathers them from the
  * received x and runs the fused kernel on whatever rows the packet buffer did not cover. */

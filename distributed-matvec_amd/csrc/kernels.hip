@@ -3427,6 +3427,43 @@ extern "C" int lsk_state_index(lsk_index ix, int64_t n, uint64_t const *spins, i
     LSK_LAUNCH_CHECK();
     return 0;
 }
+// Plan time, replicated-x exchange of unprojected bases: which blocks of 2^shift rows of the GLOBAL vector do the rows
+// alphas[0, n) read?  Every non-zero off-diagonal group of a row -> partner state -> index in the global basis -> one bit.
+// (The rows' own neighbourhood -- the LDS windows of the staged kernels -- is added by the host.)
+__global__ __launch_bounds__(kBlock) void k_reach_blocks(int n_groups, lsk_group const *__restrict__ groups, lsk_term const *__restrict__ off,
+                                                         lsk_index ix, int64_t n, uint64_t const *__restrict__ alphas, int shift,
+                                                         uint32_t *__restrict__ bitmap) {
+    __shared__ uint64_t s_binom[64 * LSK_BINOM_K];
+    if (ix.kind == LSK_INDEX_COMBINADIC) load_binom(s_binom, ix.binom);
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        const uint64_t a = alphas[i];
+        for (int g = 0; g < n_groups; ++g) {
+            lsk_group const G = groups[g];
+            double cr, ci;
+            group_coeff<false>(G, off, a, cr, ci);
+            if (cr == 0.0 && ci == 0.0) continue;
+            const uint64_t s = a ^ G.x;
+            int64_t idx;
+            if (ix.kind == LSK_INDEX_IDENTITY) idx = (int64_t)s < ix.count ? (int64_t)s : -1;
+            else if (ix.kind == LSK_INDEX_COMBINADIC) {
+                idx = rank_combinadic(s, s_binom);
+                if (idx >= ix.count || __popcll(s) != __popcll(ix.reps[0])) idx = -1;
+            } else idx = search_index(ix, s);
+            if (idx < 0) continue; // outside the basis: the matvec reports it (DMV:115-118)
+            const int64_t b = idx >> shift;
+            const uint32_t bit = 1u << (b & 31);
+            if (!(bitmap[b >> 5] & bit)) atomicOr(bitmap + (b >> 5), bit); // plain read first: nearly every block is marked early
+        }
+    }
+}
+extern "C" int lsk_reach_blocks(lsk_operator op, lsk_index ix_global, int64_t n, uint64_t const *alphas, int shift, uint32_t *bitmap,
+                                void *stream) {
+    if (n == 0 || op.n_groups == 0) return 0;
+    hipLaunchKernelGGL(k_reach_blocks, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, op.n_groups, op.groups, op.off, ix_global, n,
+                       alphas, shift, bitmap);
+    LSK_LAUNCH_CHECK();
+    return 0;
+}
 
 __global__ __launch_bounds__(kBlock) void k_offdiag_counts(int n_groups, lsk_group const *__restrict__ groups,
                                                            lsk_term const *__restrict__ off, int64_t n,

@@ -341,6 +341,9 @@ int lsk_hashed_to_block(int64_t n, uint8_t const *masks, int P, int elt_size,
 
 /* out[i] = src[perm[i]], elements of 8 or 16 bytes, perm int32 or int64 */
 int lsk_gather_perm(int64_t n, void const *perm, int perm_is_64, int elt_size, void const *src, void *out, void *stream);
+/* bitmap bit (index of partner >> shift) <- 1 for every off-diagonal partner of the rows alphas[0, n) (u32 words, device): the
+ * blocks of 2^shift rows of the global vector those rows read */
+int lsk_reach_blocks(lsk_operator op, lsk_index ix_global, int64_t n, uint64_t const *alphas, int shift, uint32_t *bitmap, void *stream);
 
 int lsk_iota_i64(int64_t n, int64_t base, int64_t *out, void *stream);
 int lsk_narrow_i32(int64_t n, int64_t const *in, int32_t *out, void *stream);
@@ -366,6 +369,9 @@ int lsk_comm_alltoallv(lsk_comm *c, void const *d_send, int64_t const *send_off,
                        int64_t const *recv_off, int64_t const *recv_bytes);
 int lsk_comm_exchange_end(lsk_comm *c, int slot);
 /* the same grouped send/recv on a stream of the caller's (no second stream, no events) */
+/* K segments per peer in one grouped exchange: entry [k * size + p] = segment k for / from peer p */
+int lsk_comm_alltoallv_multi_on(lsk_comm *c, void *stream, int K, void const *d_send, int64_t const *send_off,
+                                int64_t const *send_bytes, void *d_recv, int64_t const *recv_off, int64_t const *recv_bytes);
 int lsk_comm_alltoallv_on(lsk_comm *c, void *stream, void const *d_send, int64_t const *send_off, int64_t const *send_bytes,
                           void *d_recv, int64_t const *recv_off, int64_t const *recv_bytes);
 int lsk_comm_exchange_wait(lsk_comm *c, int slot, void *compute_stream);

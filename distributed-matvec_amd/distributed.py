@@ -306,6 +306,7 @@ class RcclReplicatedOperator:
         self.rm = ReplMatvec(self.comm, matrix, reps_global, masks, dtype)
         self.engine = RcclDistributedOperator._Engine(self.rm.plan)
         self.exchange_bytes_per_matvec = self.rm.exchange_bytes
+        self.x_bytes_in = self.rm.x_in_bytes  # what this rank receives of x per matvec (sub-range exchange: < N - N/P elements)
 
     def matvec(self, x, y, check: bool = False):
         self.rm.matvec(x, y, check=check)

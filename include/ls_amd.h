@@ -147,6 +147,11 @@ void ls_amd_repl_destroy(ls_amd_repl *repl);
 int ls_amd_repl_matvec(ls_amd_repl *repl, void const *d_x_local, void *d_y_local, void *stream);
 ls_amd_plan *ls_amd_repl_plan(ls_amd_repl *repl);
 int64_t ls_amd_repl_exchange_bytes(ls_amd_repl const *repl);
+/* bytes of x this rank receives per matvec.  Projected bases: every peer's block.  Unprojected bases: the contiguous rows of a
+ * rank read only their own neighbourhood and the partner blocks of the top bonds, kept as <= 16 intervals of global rows; an
+ * owner's elements are ascending in global rank, so each interval is one contiguous piece of every owner's block and is sent
+ * as it lies (chain_32 at 8 ranks: 44 % of the vector; LS_AMD_REPL_REACH=0: the whole vector). */
+int64_t ls_amd_repl_x_in_bytes(ls_amd_repl const *repl);
 
 /* ------------------------------------------------------------------------------------------
  * Plans.  A plan binds an operator to the partition layout and owns every per-basis device table:

@@ -61,7 +61,7 @@ for mode in (["packets", "replicated"] if args.mode == "both" else [args.mode]):
             report = plan.timing_report()
             stages, mv = plan.stage_times()
             out[rank] = (wall_r, report, getattr(op, "exchange_bytes_per_matvec", 0), getattr(op, "num_rounds", 1),
-                         {k: v[0] / max(1, mv) for k, v in stages.items()}, plan.kernel)
+                         {k: v[0] / max(1, mv) for k, v in stages.items()}, plan.kernel, getattr(op, "x_bytes_in", None))
             (op.dm if mode == "packets" else op.rm).destroy()
         except BaseException as e:  # noqa: BLE001
             errors.append(e)
@@ -79,6 +79,11 @@ for mode in (["packets", "replicated"] if args.mode == "both" else [args.mode]):
     xb = sum(v[2] for v in out.values())
     print(f"[{mode}] {P} ranks sharing one GPU: {wall * 1e3:.2f} ms per matvec (all ranks), rounds = {out[0][3]}, "
           f"exchange {xb / 1e9:.2f} GB per matvec over all ranks, max |dy| / max |y| vs one partition = {err:.1e}")
+    if out[0][6] is not None:
+        es = 8
+        full = [(int(masks.numel()) - int(reps[r].numel())) * es for r in range(P)]
+        print("x received per rank [GB]: " + " ".join(f"{out[r][6] / 1e9:.3f}" for r in range(P)) +
+              f"   (whole vector minus own block: {full[0] / 1e9:.3f}; share {sum(out[r][6] for r in range(P)) / max(1, sum(full)):.3f})")
     print("rank 0: " + out[0][1], flush=True)
     # device time of every rank's stages (HIP events; the ranks share ONE device, so stages of different ranks overlap and
     # each is slower than it would be alone): the aggregate is what P GPUs would have to do in total, transport excluded

@@ -90,6 +90,61 @@ def test_ranks_as_threads(name, P, cplx, mode):
         c.destroy()
 
 
+@pytest.mark.parametrize("case", ["heisenberg_chain_20/4/f64/-7", "heisenberg_chain_20/8/c128/-6", "heisenberg_chain_16/3/f64/-5",
+                                  "heisenberg_kagome_16/4/f64/-6", "heisenberg_chain_24/8/f64/-10", "heisenberg_chain_24/8/f64/10",
+                                  "heisenberg_chain_24/2/f64/0"])
+def test_replicated_exchange_sends_only_what_the_rows_reach(monkeypatch, case):
+    """Unprojected bases in the replicated-x exchange: a rank's contiguous rows read their own neighbourhood and the partner
+    blocks of the top bonds, not the whole vector.  The reach is found at plan time (every off-diagonal partner of every row,
+    marked per block of 2^s rows), kept as <= 16 intervals, and each owner sends the contiguous piece of its block that falls into
+    each interval -- one grouped exchange, no packing; the permutation into global order runs on the intervals only.  Result
+    == the oracle; the loop-back transport checks that every sender's byte counts are what the receiver computed; fewer bytes
+    arrive than N - N/P elements.  (-s forces the layout on bases too small for the 80 % rule, s applies the rule, 0 = off.)"""
+    import torch
+
+    import distributed_matvec_amd as D
+    from distributed_matvec_amd.distributed import RcclReplicatedOperator
+    from oracle import c_oracle as CO
+
+    name, P, dt, reach = case.split("/")
+    P = int(P)
+    monkeypatch.setenv("LS_AMD_REPL_REACH", reach)
+    basis, h = D.loadConfigFromDict(model_config(name), hamiltonian=True)
+    reps, masks = D.enumerateStates(basis, P)
+    reps_global = D.arrFromHashedToBlock(reps, masks)
+    dtype = torch.complex128 if dt == "c128" else torch.float64
+    xs = [D.fillRandom(reps[p], 31, dtype) for p in range(P)]
+    others = [D.fillRandom(reps[p], 32, dtype) for p in range(P)]
+    ys = [torch.full_like(x, 4.0) for x in xs]
+    x_in = [None] * P
+
+    def body(rank, comm):
+        op = RcclReplicatedOperator(h, reps_global, masks, dtype, comm=comm)
+        x_in[rank] = op.x_bytes_in
+        op.matvec(others[rank], ys[rank], check=True)  # stale values in the unread parts of the global buffer must not matter
+        op.matvec(xs[rank], ys[rank], check=True)
+        op.rm.destroy()
+
+    comms = _run_ranks(P, body)
+    n = int(masks.numel())
+    es = 16 if dt == "c128" else 8
+    full = [(n - int(reps[p].numel())) * es for p in range(P)]
+    if int(reach) < 0:
+        assert all(a <= b for a, b in zip(x_in, full)) and sum(x_in) < sum(full), (x_in, full)
+    elif int(reach) == 0:
+        assert x_in == full
+    else:  # the 80 % rule decides, for all ranks alike
+        assert x_in == full or all(a < b for a, b in zip(x_in, full)), (x_in, full)
+    want_reps = oracle_reps(name)
+    keys = CO.locale_idx_of(want_reps, P)
+    x = CO.hashed_to_block([v.cpu().numpy() for v in xs], keys)
+    got = CO.hashed_to_block([v.cpu().numpy() for v in ys], keys)
+    want = oracle_for(name).local_matvec(want_reps, x)
+    assert np.abs(got - want).max() <= 1e-12 * max(1.0, np.abs(want).max())
+    for c in comms:
+        c.destroy()
+
+
 @pytest.mark.parametrize("indexed", ["1", "0", "fused", "part", "cached", "cached-part"])
 @pytest.mark.parametrize("case", ["heisenberg_chain_24_symm/4/f64", "heisenberg_chain_24_symm/3/c128", "issue_01/2/f64",
                                   "heisenberg_kagome_12_symm/8/f64", "translation_12_5/3/c128"])
