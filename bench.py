@@ -90,6 +90,14 @@ MODEL_INPUTS_MS = {
 }
 XGMI_IN_GBPS = (7 * 50.0, 7 * 64.0)  # what one GPU receives from its 7 peers at once: 7 links x 50-64 GB/s achievable of 153 nominal
 REACH_SHARE_MAX = 0.56               # 2.358 / 4.208 GB: the rank in the middle of the basis; the average over ranks is 0.44
+
+
+def reach_share(P):
+    """largest share of the other ranks' x a rank receives: at 2 ranks the rows of a rank reach everything, at 4 the middle ranks
+    reach 85 % and the 80 % rule keeps the whole-vector exchange (profiles/r4_loopback_chain28_subrange_share_P2_P4.txt)"""
+    return REACH_SHARE_MAX if P >= 8 else 1.0
+
+
 REPL_OVERHEAD = 1.23                 # per-row cost of a rank's kernels relative to one GPU (x arrives owner-major: the near partners'
                                      # values no longer share lines; measured on eight loop-back ranks, profiles/r3_loopback_*_final.txt)
 
@@ -105,7 +113,7 @@ def scaling_model(model, P, w=8):
     if "resolve" not in m:
         # unprojected bases: the sub-range exchange (dist.c::setup_reach) -- the largest share a rank receives, measured with
         # loop-back ranks on chain_28 / chain_32 at P = 8 (profiles/r4_loopback_chain32_8ranks_subrange_exchange.txt: 2.36 of 4.21 GB)
-        xbytes *= REACH_SHARE_MAX
+        xbytes *= reach_share(P)
     out = {"inputs_ms_one_gpu": m, "assumed_in_GBps": list(XGMI_IN_GBPS), "assumed_kernel_overhead": [1.0, REPL_OVERHEAD], "x_bytes_in_per_rank": xbytes}
     lo_hi = []
     for b in XGMI_IN_GBPS:
@@ -115,7 +123,7 @@ def scaling_model(model, P, w=8):
             if "resolve" in m:
                 t = m["prescale"] / P + max(m["resolve"] / P * f, xch) + m["gather"] / P * f + ret
             else:
-                perm = REACH_SHARE_MAX * m["n"] * 2 * w / 1.0e9 * 1e3 / 2500.0  # the hashed -> block permutation of what arrived: random reads + writes
+                perm = reach_share(P) * m["n"] * 2 * w / 1.0e9 * 1e3 / 2500.0  # the hashed -> block permutation of what arrived: random reads + writes
                 t = xch + perm + m["fused"] / P + ret
             lo_hi.append(t)
     out["predicted_ms_per_matvec"] = [min(lo_hi), max(lo_hi)]
