@@ -2754,6 +2754,23 @@ extern "C" int lsk_test_nw_find(uint64_t const *reps, int n, uint64_t key) {
     return nw_match(tab[2 * (h >> 22)], tab[2 * (h >> 22) + 1], h);
 }
 
+// block -> tile of the pull kernels.  Blocks b = x (mod 8) run on XCD x; a plain grid therefore deals every XCD every eighth
+// tile, and each of the eight L2s fetches its own copy of the partner sectors that neighbouring tiles share.  With a chunk of C
+// tiles per XCD the blocks of one XCD walk C consecutive tiles before they jump by 8 C.  (The last, incomplete round of
+// chunks keeps the identity.)
+__device__ __forceinline__ int64_t pull_tile_of_block(int64_t b, int64_t n_tiles, int C) {
+    if (C <= 1) return b;
+    const int64_t round = 8 * (int64_t)C, full = n_tiles / round * round;
+    if (b >= full) return b;
+    const int64_t x = b & 7, j = b >> 3, q = j / C, r = j - q * C;
+    return (q * 8 + x) * C + r;
+}
+// Measured (profiles/r4_pull_xcd_chunk_ab.txt; C = 0 / 16 / 64 / 256 / 1024 / 4096): chain_36_symm cached gather 4.18 / 3.88 / 3.76 /
+// 3.67 / 3.65 / 3.88 ms, fused 18.08 / 17.58 / 17.24 / 17.38 / 17.28 / 18.08 ms; chain_40_symm cached 65.7 / 63.6 / 59.9 / 60.1 / 60.0 /
+// 61.5 ms, fused 282.5 / 285.0 / 280.9 / 287.3 / 279.5 / 280.1 ms.
+constexpr int kPullXcdChunk = 256;
+static int pull_xcd_chunk() { return kPullXcdChunk; }
+
 template <typename W, int K4M, int COEF, bool CPLX, int SINK>
 __global__ __launch_bounds__(kBlock, (COEF == COEF_CPLX ? 4 : 6)) void k_pull_t(lsk_runs runs, int n_groups, lsk_group const *__restrict__ groups,
                                                    lsk_term const *__restrict__ off, int n_diag,
@@ -2763,7 +2780,7 @@ __global__ __launch_bounds__(kBlock, (COEF == COEF_CPLX ? 4 : 6)) void k_pull_t(
                                                    double const *__restrict__ norms_local, lsk_pullidx ix,
                                                    uint64_t const *__restrict__ greps, int64_t n_global,
                                                    double const *__restrict__ xsrc, int halo, double uni_v,
-                                                   double *__restrict__ y, lsk_pullbuf buf, int *err) {
+                                                   double *__restrict__ y, lsk_pullbuf buf, int *err, int xcd_chunk) {
     typedef typename ChainX<CPLX>::type X;
     constexpr bool REAL = COEF != COEF_CPLX;
     constexpr bool FUSED = SINK == SINK_FUSED;
@@ -2781,7 +2798,9 @@ __global__ __launch_bounds__(kBlock, (COEF == COEF_CPLX ? 4 : 6)) void k_pull_t(
     const int wave = tid >> 6;
     const int rb = wave * kWvRing; // this wave's ring
     uint64_t const *__restrict__ tab = ix.tab.entries;
-    for (int64_t t0 = row0 + (int64_t)blockIdx.x * kBlock; t0 < row1; t0 += (int64_t)gridDim.x * kBlock) {
+    const int64_t n_tiles = (row1 - row0 + kBlock - 1) / kBlock;
+    for (int64_t tb = blockIdx.x; tb < n_tiles; tb += gridDim.x) {
+        const int64_t t0 = row0 + pull_tile_of_block(tb, n_tiles, gridDim.x >= n_tiles ? xcd_chunk : 0) * kBlock;
         const int64_t i = t0 + tid;
         const bool valid = i < row1;
         uint64_t a = 0;
@@ -2994,7 +3013,7 @@ __global__ __launch_bounds__(kBlock) void k_pull_gather(lsk_runs runs, int n_dia
                                                         int64_t row0, int64_t row1, uint64_t const *__restrict__ reps,
                                                         double const *__restrict__ norms_local, lsk_pullidx ix,
                                                         double const *__restrict__ xsrc, double uni_v, double *__restrict__ y,
-                                                        lsk_pullbuf buf) {
+                                                        lsk_pullbuf buf, int xcd_chunk) {
     typedef typename ChainX<CPLX>::type X;
     constexpr bool REAL = COEF != COEF_CPLX;
     constexpr int NC = COEF == COEF_UNI ? 0 : (COEF == COEF_REAL ? 1 : 2);
@@ -3004,7 +3023,9 @@ __global__ __launch_bounds__(kBlock) void k_pull_gather(lsk_runs runs, int n_dia
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    for (int64_t t0 = row0 + (int64_t)blockIdx.x * kBlock; t0 < row1; t0 += (int64_t)gridDim.x * kBlock) {
+    const int64_t n_tiles = (row1 - row0 + kBlock - 1) / kBlock;
+    for (int64_t tb = blockIdx.x; tb < n_tiles; tb += gridDim.x) {
+        const int64_t t0 = row0 + pull_tile_of_block(tb, n_tiles, gridDim.x >= n_tiles ? xcd_chunk : 0) * kBlock;
         if ((t0 + (wave << 6)) >= row1) continue; // wave-uniform
         const int64_t i = t0 + tid;
         const bool valid = i < row1;
@@ -3099,7 +3120,7 @@ static void launch_pull_t(lsk_operator const &op, lsk_basis const &bs, int64_t r
     const size_t dyn = ix.perm ? sizeof(uint32_t) * kNwMaxWin : 0;
     hipLaunchKernelGGL((k_pull_t<W, K4M, COEF, CPLX, SINK>), g, b, dyn, s, op.runs, op.n_groups, op.groups, op.off, op.n_diag, op.diag, bs,
                        bs.elems, row0, row1, reps, norms_local, ix, reps_global, n_global, (double const *)xsrc, halo, op.uni_v,
-                       (double *)y, buf, d_err);
+                       (double *)y, buf, d_err, pull_xcd_chunk());
 }
 template <typename W, bool CPLX, int SINK>
 static int dispatch_pull_t(lsk_operator const &op, lsk_basis const &bs, int64_t row0, int64_t row1, uint64_t const *reps,
@@ -3224,7 +3245,7 @@ extern "C" int lsk_tile_pull_gather(lsk_operator op, lsk_basis bs, int cplx, int
     do {                                                                                                                \
         g.x = (unsigned)tile_grid(k_pull_gather<COEF, CPLX>, work_blocks);                                              \
         hipLaunchKernelGGL((k_pull_gather<COEF, CPLX>), g, b, 0, s, op.runs, op.n_diag, op.diag, bs.k4_mode, row0, row1, reps, \
-                           norms_local, ix, (double const *)xsrc, op.uni_v, (double *)y, buf);                          \
+                           norms_local, ix, (double const *)xsrc, op.uni_v, (double *)y, buf, pull_xcd_chunk());        \
     } while (0)
     if (coef == COEF_CPLX) LSK_PG(COEF_CPLX, true);
     else if (coef == COEF_REAL) { if (cplx) LSK_PG(COEF_REAL, true); else LSK_PG(COEF_REAL, false); }

@@ -20,6 +20,7 @@ ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--dtype", default="f64")
 ap.add_argument("--mode", default="auto")
 ap.add_argument("--tree", action="store_true", help="per-stage timing tree (HIP events around every stage)")
+ap.add_argument("--cache", action="store_true", help="slot cache (ls_amd_plan_cache_slots): time the gather-only matvec")
 args = ap.parse_args()
 
 cfg = config.heisenberg_chain_config(args.L, symm=args.symm)
@@ -37,6 +38,8 @@ t = time.perf_counter()
 pl = D.MatvecPlan(h, reps, td, mode=args.mode)
 torch.cuda.synchronize()
 t_plan = time.perf_counter() - t
+if args.cache:
+    assert pl.cache_slots(0) > 0, "nothing to cache for this plan"
 pl.enable_timing(4096)
 if args.tree:
     pl.enable_stage_timing(65536)

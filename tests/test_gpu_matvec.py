@@ -271,6 +271,19 @@ def test_slot_cache_single_locale(torch, case):
         want = o.local_matvec(want_reps, x)
         assert np.abs(yd.cpu().numpy() - want).max() <= 1e-12 * max(1.0, np.abs(want).max()), (case, trial)
     pl.destroy()
+    # LS_AMD_SLOT_CACHE = bytes: the same for callers that never see the plan (the host-pointer entry points under PRIMME)
+    import os
+
+    os.environ["LS_AMD_SLOT_CACHE"] = str(1 << 30)
+    try:
+        pe = D.MatvecPlan(h, reps, dtype, mode="pull")
+        assert pe.kernel == "tile-pull+indexed+cached" and pe.slot_cache[0] == len(want_reps)
+        for trial in range(2):
+            pe.matvec([xd], [yd])
+            assert np.abs(yd.cpu().numpy() - want).max() <= 1e-12 * max(1.0, np.abs(want).max()), (case, "env", trial)
+        pe.destroy()
+    finally:
+        del os.environ["LS_AMD_SLOT_CACHE"]
     # nothing to cache on an unprojected basis
     D2, b2, h2, reps2, _ = setup_model(torch, model_config("heisenberg_chain_16"), 1)
     p2 = D2.MatvecPlan(h2, reps2, torch.float64, mode="pull")
