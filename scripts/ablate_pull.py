@@ -16,8 +16,13 @@ from distributed_matvec_amd import _lib, config  # noqa: E402
 _lib.LIB_PATH = os.path.join(ROOT, "distributed-matvec_amd", "libls_amd_ablate.so")
 name = sys.argv[1] if len(sys.argv) > 1 else "heisenberg_chain_36_symm"
 masks_ = [int(a) for a in sys.argv[2:]] or [0, 1, 2, 4, 32, 64, 0]
-L = int(name.split("_")[2])
-cfg = config.heisenberg_chain_config(L, symm=name.endswith("_symm"))
+if name.startswith("heisenberg_chain_"):
+    L = int(name.split("_")[2])
+    cfg = config.heisenberg_chain_config(L, symm=name.endswith("_symm"))
+else:  # a lattice model of tests/golden/models.json (heisenberg_square_6x6, ...)
+    import json
+
+    cfg = json.load(open(os.path.join(ROOT, "tests", "golden", "models.json")))["models"][name]["config"]
 for m in masks_:
     os.environ["LS_AMD_ABLATE"] = str(m)
     basis, h = D.loadConfigFromDict(cfg, hamiltonian=True)  # the ablation mask is read when the basis goes to the device

@@ -219,6 +219,19 @@ def test_chain_40_symm_properties_and_ground_state(torch):
     rows = np.unique(np.concatenate([rs.randint(0, n, size=12000), np.arange(256), np.arange(n - 256, n)]))
     rows_t, want = oracle_rows(torch, o, r, rows, u, projected=True)
     assert_rows(a[rows_t].cpu().numpy(), want, "chain_40_symm pull vs oracle rows")
+    # the slot cache at this shape (88.5 GB of packet streams): the gather-only matvec == the matrix-free one on ALL rows, for the
+    # vector that resolved the streams and for another one
+    cached = D.MatvecPlan(h, reps, torch.float64, mode="pull")
+    if cached.cache_slots(120 << 30) == n:
+        assert cached.kernel == "tile-pull+indexed+cached" and cached.slot_cache[1] <= 100e9
+        w = D.fillRandom(r, 5, torch.float64)
+        c = torch.empty_like(u)
+        cached.matvec([w], [c])  # resolves
+        cached.matvec([u], [c])  # gathers only
+        assert float((c - a).abs().max()) <= 1e-12 * float(a.abs().max())
+        del w, c
+    cached.destroy()
+    torch.cuda.empty_cache()
     # Hermiticity <v, H u> == <H v, u>
     v = D.fillRandom(r, 4, torch.float64)
     c = torch.empty_like(u)

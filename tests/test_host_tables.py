@@ -298,7 +298,7 @@ def test_hot_kernel_register_budget():
     # the projected-basis kernels of the BASELINE configs (trivial sector, one amplitude, f64): fused and resolve
     for inst in ("_Z8k_pull_tImLi0ELi0ELb0ELi0E", "_Z8k_pull_tImLi0ELi0ELb0ELi1E", "_Z8k_pull_tIjLi0ELi0ELb0ELi0E"):
         v = stats[[k for k in stats if k.startswith(inst)][0]]
-        assert v["vgpr"] <= 72 and v["lds"] <= 24 * 1024, (inst, v)  # >= 6 blocks per CU by registers and by LDS
+        assert v["vgpr"] <= 80 and v["occ"] >= 6 and v["lds"] <= 24 * 1024, (inst, v)  # >= 6 blocks per CU by registers (granule 8) and by LDS
     pairs = stats[[k for k in stats if k.startswith("_Z9k_pairs_tILb0ELi1024E")][0]]
     assert pairs["vgpr"] <= 84 and pairs["sgpr"] <= 96 and pairs["lds"] <= 27 * 1024, pairs
 
