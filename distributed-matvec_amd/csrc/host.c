@@ -1685,53 +1685,66 @@ int64_t ls_amd_internal_plan_split_rows(ls_amd_plan const *pl) { return pl->spli
  * whatever the device has).  One-partition plans need every row covered (else nothing is cached and 0 is returned: the plan
  * stays matrix-free); plans of the replicated-x exchange cache the rows the buffer covers and run the fused kernel on the
  * rest.  Returns the number of rows whose streams are cached. */
-/* every row, streams laid out back to back at their exact lengths (a count pass of stage A + a scan): about half of what the
- * worst-case stride of the split form reserves.  0 on success; 1 = does not fit `max_bytes` / the device (nothing is left
- * allocated), -1 = device error */
-static int split_enable_exact(ls_amd_plan *pl, int64_t max_bytes) {
+/* Streams laid out back to back at their exact lengths (a count pass of stage A + a scan): about half of what the worst-case
+ * stride of the split form reserves.  Covers every row if `max_bytes` (<= 0: no ceiling) and the device allow, else the longest
+ * prefix of whole 256-row tiles that fits -- the rows behind it keep the fused kernel.  Returns the rows covered (0: none, nothing
+ * is left allocated), -1 on a device error. */
+static int64_t split_enable_exact(ls_amd_plan *pl, int64_t max_bytes) {
     split_free(pl);
     part_state *ps = &pl->parts[0];
-    int64_t const streams = (ps->count + 63) / 64;
+    int64_t const streams_all = (ps->count + 63) / 64;
     int const nc = lsk_pullbuf_coef_doubles(pl->dop, pl->dbs);
-    void *offs = NULL, *a = NULL, *b = NULL, *c = NULL, *d = NULL;
-    if (lsk_malloc(&offs, 8 * (size_t)(streams + 1)) != 0) return 1;
-    int64_t total = 0;
-    if (lsk_tile_pull_stream_offsets(pl->dop, pl->dbs, 0, ps->count, ps->d_reps, (int64_t *)offs, NULL) != 0 ||
-        lsk_d2h(&total, (char *)offs + 8 * (size_t)streams, 8) != 0) { lsk_free(offs); return -1; }
-    int64_t const bytes = total * (4 + 1 + 8 * nc) + 12 * streams + 8;
-    if (total >= ((int64_t)1 << 40) || (max_bytes > 0 && bytes > max_bytes)) { lsk_free(offs); return 1; }
-    if (lsk_malloc(&a, (size_t)(4 * total + 4)) != 0 || lsk_malloc(&b, (size_t)(total + 4)) != 0 ||
-        (nc > 0 && lsk_malloc(&c, (size_t)(8 * nc * total + 8)) != 0) || lsk_malloc(&d, (size_t)(4 * streams)) != 0) {
+    int64_t const per_packet = 4 + 1 + 8 * nc;
+    void *offs = NULL;
+    if (lsk_malloc(&offs, 8 * (size_t)(streams_all + 1)) != 0) return 0;
+    if (lsk_tile_pull_stream_offsets(pl->dop, pl->dbs, 0, ps->count, ps->d_reps, (int64_t *)offs, NULL) != 0) { lsk_free(offs); return -1; }
+    int64_t streams = streams_all;
+    for (;;) {
+        /* largest number of streams (whole tiles, or all of them) whose packets fit the ceiling: offs is ascending */
+        int64_t total = 0;
+        if (lsk_d2h(&total, (char *)offs + 8 * (size_t)streams, 8) != 0) { lsk_free(offs); return -1; }
+        if (max_bytes > 0 && total * per_packet + 12 * streams + 8 > max_bytes) {
+            int64_t lo = 0, hi = streams / 4; /* in tiles: lo fits, hi does not */
+            while (hi - lo > 1) {
+                int64_t const mid = lo + (hi - lo) / 2;
+                int64_t t = 0;
+                if (lsk_d2h(&t, (char *)offs + 8 * (size_t)(4 * mid), 8) != 0) { lsk_free(offs); return -1; }
+                if (t * per_packet + 12 * 4 * mid + 8 <= max_bytes) lo = mid; else hi = mid;
+            }
+            streams = 4 * lo;
+            if (streams <= 0) { lsk_free(offs); return 0; }
+            if (lsk_d2h(&total, (char *)offs + 8 * (size_t)streams, 8) != 0) { lsk_free(offs); return -1; }
+        }
+        if (total >= ((int64_t)1 << 40)) { lsk_free(offs); return 0; }
+        void *a = NULL, *b = NULL, *c = NULL, *d = NULL;
+        if (lsk_malloc(&a, (size_t)(4 * total + 4)) == 0 && lsk_malloc(&b, (size_t)(total + 4)) == 0 &&
+            (nc == 0 || lsk_malloc(&c, (size_t)(8 * nc * total + 8)) == 0) && lsk_malloc(&d, (size_t)(4 * streams)) == 0) {
+            pl->pbuf.slots = (uint32_t *)a; pl->pbuf.rows = (uint8_t *)b; pl->pbuf.coefs = (double *)c; pl->pbuf.counts = (uint32_t *)d;
+            pl->pbuf.offs = (int64_t const *)offs;
+            pl->pbuf.cap = lsk_pullbuf_cap(pl->dop);
+            pl->pbuf.row0 = 0;
+            pl->split_rows = streams * 64 < ps->count ? streams * 64 : ps->count;
+            pl->slot_cache_bytes = total * per_packet + 12 * streams + 8;
+            return pl->split_rows;
+        }
         if (a) lsk_free(a);
         if (b) lsk_free(b);
         if (c) lsk_free(c);
         if (d) lsk_free(d);
-        lsk_free(offs);
-        return 1;
+        /* the device has no room for this many: three quarters of it, in whole tiles */
+        max_bytes = (total * per_packet + 12 * streams + 8) / 4 * 3;
+        if (max_bytes < ((int64_t)1 << 20)) { lsk_free(offs); return 0; }
     }
-    pl->pbuf.slots = (uint32_t *)a; pl->pbuf.rows = (uint8_t *)b; pl->pbuf.coefs = (double *)c; pl->pbuf.counts = (uint32_t *)d;
-    pl->pbuf.offs = (int64_t const *)offs;
-    pl->pbuf.cap = lsk_pullbuf_cap(pl->dop);
-    pl->pbuf.row0 = 0;
-    pl->split_rows = ps->count;
-    pl->slot_cache_bytes = bytes;
-    return 0;
 }
 int64_t ls_amd_plan_cache_slots(ls_amd_plan *pl, int64_t max_bytes) {
     if (!pl || !pl->idx_mode || pl->dbs.proj != LSK_PROJ_FULL || pl->parts[0].count <= 0 ||
         (pl->family != FAMILY_TILE_PULL && pl->family != FAMILY_REPL_TILE)) return 0;
-    int const rc = split_enable_exact(pl, max_bytes);
-    if (rc < 0) return dev_error();
-    if (rc > 0) {
-        /* no room for every row: a replicated-x plan keeps the streams of the rows that do fit (worst-case stride) and runs
-         * the fused kernel on the others; a one-partition plan stays matrix-free */
-        if (pl->family != FAMILY_REPL_TILE || ls_amd_internal_plan_split_enable(pl, max_bytes) <= 0) { split_free(pl); return 0; }
-        int64_t const streams = (pl->split_rows + 63) / 64;
-        pl->slot_cache_bytes = streams * (pl->pbuf.cap * (4 + 1 + 8 * lsk_pullbuf_coef_doubles(pl->dop, pl->dbs)) + 4);
-    }
+    int64_t const rows = split_enable_exact(pl, max_bytes);
+    if (rows < 0) return dev_error();
+    if (rows == 0) return 0;
     pl->slot_cache = 1;
     pl->slot_cache_valid = 0;
-    return pl->split_rows;
+    return rows;
 }
 int ls_amd_plan_slot_cache_rows(ls_amd_plan const *pl, int64_t *rows, int64_t *bytes) {
     if (rows) *rows = pl->slot_cache ? pl->split_rows : 0;
@@ -2689,6 +2702,33 @@ int ls_amd_matvec(ls_amd_plan *pl, void const *const *d_x, void *const *d_y, voi
         ix.tab = pl->gtab->tab;
         ix.perm = NULL;
         ix.row_g0 = 0;
+        if (pl->split_rows > 0 && pl->slot_cache) {
+            /* slot cache: the streams of rows [0, split_rows) are resolved by the first matvec and kept; later matvecs gather.
+             * Rows the cache has no room for take the fused kernel */
+            lsk_pullbuf const pb = pl->pbuf;
+            int st, slot;
+            if (!pl->slot_cache_valid) {
+                st = stage_begin(pl, ST_GENERATE, stream);
+                slot = timing_begin(pl, stream);
+                DEV(lsk_tile_pull_resolve(pl->dop, pl->dbs, 0, pl->split_rows, ps->d_reps, ps->d_norms, ix, ps->d_reps, ps->count, pl->pull_halo, pb,
+                                          pl->d_err, stream));
+                timing_end(pl, slot, stream);
+                stage_end(pl, st, stream);
+                pl->slot_cache_valid = 1;
+            }
+            st = stage_begin(pl, ST_ROWS, stream);
+            slot = timing_begin(pl, stream); /* the gather kernel is the dominant one of a cached plan */
+            DEV(lsk_tile_pull_gather(pl->dop, pl->dbs, pl->cplx, 0, pl->split_rows, ps->d_reps, ps->d_norms, ix, xs, pb, d_y[0], stream));
+            timing_end(pl, slot, stream);
+            if (pl->split_rows < ps->count) {
+                slot = timing_begin(pl, stream);
+                DEV(lsk_tile_pull_idx(pl->dop, pl->dbs, pl->cplx, pl->split_rows, ps->count, ps->d_reps, ps->d_norms, ix, ps->d_reps, ps->count, xs,
+                                      pl->pull_halo, d_y[0], pl->d_err, stream));
+                timing_end(pl, slot, stream);
+            }
+            stage_end(pl, st, stream);
+            return 0;
+        }
         if (pl->split_rows > 0) {
             /* the split form on one device (LS_AMD_PULL_SPLIT: measurement of what the replicated-x exchange runs, dist.c):
              * rounds of resolve | gather over the rows the packet buffer holds */
@@ -2696,20 +2736,14 @@ int ls_amd_matvec(ls_amd_plan *pl, void const *const *d_x, void *const *d_y, voi
                 int64_t const r1 = r0 + pl->split_rows < ps->count ? r0 + pl->split_rows : ps->count;
                 lsk_pullbuf pb = pl->pbuf;
                 pb.row0 = r0;
-                int st, slot;
-                if (!(pl->slot_cache && pl->slot_cache_valid)) { /* (a cached plan covers every row: one round) */
-                    st = stage_begin(pl, ST_GENERATE, stream);
-                    slot = timing_begin(pl, stream);
-                    DEV(lsk_tile_pull_resolve(pl->dop, pl->dbs, r0, r1, ps->d_reps, ps->d_norms, ix, ps->d_reps, ps->count, pl->pull_halo, pb,
-                                              pl->d_err, stream));
-                    timing_end(pl, slot, stream);
-                    stage_end(pl, st, stream);
-                    pl->slot_cache_valid = pl->slot_cache;
-                }
+                int st = stage_begin(pl, ST_GENERATE, stream);
+                int const slot = timing_begin(pl, stream);
+                DEV(lsk_tile_pull_resolve(pl->dop, pl->dbs, r0, r1, ps->d_reps, ps->d_norms, ix, ps->d_reps, ps->count, pl->pull_halo, pb,
+                                          pl->d_err, stream));
+                timing_end(pl, slot, stream);
+                stage_end(pl, st, stream);
                 st = stage_begin(pl, ST_ROWS, stream);
-                slot = pl->slot_cache ? timing_begin(pl, stream) : -1; /* cached: the gather kernel is the dominant (only) one */
                 DEV(lsk_tile_pull_gather(pl->dop, pl->dbs, pl->cplx, r0, r1, ps->d_reps, ps->d_norms, ix, xs, pb, d_y[0], stream));
-                if (slot >= 0) timing_end(pl, slot, stream);
                 stage_end(pl, st, stream);
             }
             return 0;

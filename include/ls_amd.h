@@ -192,8 +192,8 @@ int64_t ls_amd_plan_nnz(ls_amd_plan const *plan);
  * coefficient unless every packet has the same real amplitude).  A plan that is applied many times (Diagonalize / PRIMME)
  * can keep those streams in HBM: the first matvec resolves them, every later one only gathers x[slot] and accumulates.
  * max_bytes = ceiling for the streams (<= 0: whatever the device can allocate).  Returns the number of rows whose streams
- * are kept; 0 = nothing cached, the plan stays matrix-free (unprojected bases, value-table mode, no room).  Plans over one
- * partition cache all rows or none; plans of the replicated-x exchange run the fused kernel on the rows that did not fit. */
+ * are kept -- every row, or the longest prefix of whole 256-row tiles that fits (the rows behind it keep the fused kernel);
+ * 0 = nothing cached, the plan stays matrix-free (unprojected bases, value-table mode, no room). */
 int64_t ls_amd_plan_cache_slots(ls_amd_plan *plan, int64_t max_bytes);
 /* rows covered by the slot cache and the HBM it holds (0 / 0 when off) */
 int ls_amd_plan_slot_cache_rows(ls_amd_plan const *plan, int64_t *rows, int64_t *bytes);

@@ -271,6 +271,16 @@ def test_slot_cache_single_locale(torch, case):
         want = o.local_matvec(want_reps, x)
         assert np.abs(yd.cpu().numpy() - want).max() <= 1e-12 * max(1.0, np.abs(want).max()), (case, trial)
     pl.destroy()
+    # a ceiling that only admits a prefix of the rows: those gather from the cache, the others run the fused kernel
+    if len(want_reps) > 2048:
+        pp = D.MatvecPlan(h, reps, dtype, mode="pull")
+        full_bytes = cbytes
+        prows = pp.cache_slots(max(4096, full_bytes // 7))
+        assert 0 < prows < len(want_reps) and prows % 256 == 0 and pp.slot_cache[1] <= max(4096, full_bytes // 7), (prows, pp.slot_cache)
+        for trial in range(2):
+            pp.matvec([xd], [yd])
+            assert np.abs(yd.cpu().numpy() - want).max() <= 1e-12 * max(1.0, np.abs(want).max()), (case, "prefix", trial)
+        pp.destroy()
     # LS_AMD_SLOT_CACHE = bytes: the same for callers that never see the plan (the host-pointer entry points under PRIMME)
     import os
 

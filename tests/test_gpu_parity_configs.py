@@ -249,7 +249,12 @@ def test_chain_40_symm_properties_and_ground_state(torch):
     torch.cuda.empty_cache()
     # eigensolver: thick-restart Lanczos on the pull kernel; the eigenpair's residual is then measured with the PUSH kernel
     pull.destroy()
-    op = LocalOperator(h, reps, torch.float64, mode="pull")
+    # (what diagonalize() does: whatever HBM is left next to the Krylov basis holds resolved packet streams -- every row of this
+    # basis needs 88.5 GB; a prefix of the rows if less is free, the others stay matrix-free)
+    free_bytes, _ = torch.cuda.mem_get_info()
+    budget = max(0, int(free_bytes) - (12 + 6) * n * 8 - (8 << 30))
+    op = LocalOperator(h, reps, torch.float64, mode="pull", slot_cache_bytes=budget)
+    assert op.cached_rows % 256 == 0 or op.cached_rows == n
     res = lanczos_smallest(op, num_evals=1, eps=1e-6, max_basis=12, max_restarts=60)
     e0 = res.eigenvalues[0]
     vec = res.eigenvectors[0]
