@@ -139,6 +139,25 @@ def scaling_model(model, P, w=8):
     return out
 
 
+def model_config(name):
+    """(config dict, where it came from): the reference's own YAML input as parsed into tests/golden/models.json when the model
+    is one of those (data/heisenberg_chain_{10,...,40_symm}.yaml; /root/reference does not exist on the GPU box), else the same
+    model regenerated (periodic ring, sigma.sigma per bond)"""
+    from distributed_matvec_amd import config
+
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "models.json")
+    try:
+        with open(path) as f:
+            m = json.load(f)["models"].get(name)
+        if m:
+            return m["config"], f"data/{name}.yaml (the reference's input, parsed: tests/golden/models.json)"
+    except (OSError, ValueError, KeyError):
+        pass
+    L, symm = parse_model(name)
+    return (config.heisenberg_chain_config(L, symm=symm, spin_inversion=-1 if (L == 10 and not symm) else None),
+            f"data/{name}.yaml (regenerated: periodic ring, sigma.sigma per bond)")
+
+
 def slot_cache_leg(plan, run, check, kernel_times, time_steps, steps):
     """the same plan with ls_amd_plan_cache_slots: the packet streams (slot of every partner: 5 B per non-zero here) are resolved
     by the first matvec and kept in HBM, later matvecs only gather -- what an eigensolver that applies one plan hundreds of
@@ -162,7 +181,7 @@ def projected_extra(D, torch, dist, name, rank, world, time_steps, allsum, steps
     from distributed_matvec_amd import config
 
     L, symm = parse_model(name)
-    basis, h = D.loadConfigFromDict(config.heisenberg_chain_config(L, symm=symm), hamiltonian=True)
+    basis, h = D.loadConfigFromDict(model_config(name)[0], hamiltonian=True)
     t0 = time.perf_counter()
     parts, masks = D.enumerateStates(basis, world)
     n_total = int(masks.numel())
@@ -447,7 +466,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     L, symm = parse_model(args.model)
-    cfg = config.heisenberg_chain_config(L, symm=symm, spin_inversion=-1 if (L == 10 and not symm) else None)
+    cfg, cfg_source = model_config(args.model)
     basis, h = D.loadConfigFromDict(cfg, hamiltonian=True)
     tdtype = torch.float64 if args.dtype == "f64" else torch.complex128
     w = 8 if args.dtype == "f64" else 16
@@ -710,7 +729,7 @@ def main():
             "config": {
                 "workload": f"{args.model}: y <- H x, {n_total} basis states, {nnz} off-diagonal non-zeros, "
                             f"{args.dtype} vectors, sigma/x/y resident in HBM",
-                "model_yaml": f"data/{args.model}.yaml (regenerated: periodic ring, sigma.sigma per bond)",
+                "model_yaml": cfg_source,
                 "partitions": world, "partitioning": "hash64_01(sigma) % n_gpus" if world > 1 else "single",
                 "exchange": exchange,
                 "kernel": kernel_name, "x": "u(hash(sigma, 42)) - 0.5",

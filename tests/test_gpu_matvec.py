@@ -398,6 +398,23 @@ def test_kernel_table_entry_points(torch):
     assert_close(h2 @ x10, oracle_for("heisenberg_chain_10").local_matvec(r10, x10))
 
 
+def test_slot_cache_through_the_kernel_table_entry(torch, monkeypatch):
+    """LS_AMD_SLOT_CACHE under the reference's own call path: ls_chpl_matrix_vector_product (host f64 arrays, one cached plan
+    per operator) on a projected basis -- the first call resolves the packet streams, the following ones gather; every call
+    == the oracle for its own x."""
+    import distributed_matvec_amd as D
+
+    monkeypatch.setenv("LS_AMD_SLOT_CACHE", str(64 << 20))
+    name = "heisenberg_chain_24_symm"
+    basis, h = D.loadConfigFromDict(model_config(name), hamiltonian=True)
+    basis.build()
+    reps = oracle_reps(name)
+    rs = np.random.RandomState(71)
+    for _ in range(3):
+        x = rs.rand(len(reps)) - 0.5
+        assert_close(h @ x, oracle_for(name).local_matvec(reps, x), name)
+
+
 def test_two_operators_share_one_basis_through_the_kernel_table(torch):
     """ls_chpl_matrix_vector_product caches its device plan per (operator, communicator), not per basis: H and an
     observable built on the SAME ls_hs_basis (the reference loads `observables` next to the Hamiltonian,
