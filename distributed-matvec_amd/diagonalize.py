@@ -16,6 +16,7 @@ local vector length — provided both by a single-process plan (all partitions o
 from __future__ import annotations
 
 import math
+import os
 import time
 from dataclasses import dataclass, field
 
@@ -140,11 +141,28 @@ def lanczos_smallest(op, num_evals: int = 1, eps: float = 1e-6, max_basis: int =
         return op.global_sum(t) if hasattr(op, "global_sum") else t
 
     def norm(u):
-        return math.sqrt(float(gsum((u.abs() ** 2).sum().reshape(1))[0]))
+        # (no full-size temporaries: the vectors of chain_40_symm are 6.9 GB each and the HBM next to them belongs to the slot cache)
+        return math.sqrt(float(gsum((torch.linalg.vector_norm(u) ** 2).reshape(1))[0]))
 
-    V[0] = v / norm(v)
+    torch.div(v, norm(v), out=V[0])
     del v
     w = op.new_vector()
+    # fused orthogonalisation sweeps (real f64 vectors on the device; the partial sums of a rank go through the operator's global sum)
+    fused, fused_rows = None, 0
+    if not cplx and V.is_cuda and V.dtype == torch.float64 and os.environ.get("LS_AMD_FUSED_ORTH", "1") != "0":
+        import ctypes as C
+
+        from . import _lib
+        from .api import _stream_ptr
+
+        lib = _lib.load()
+        fused_rows = int(lib.ls_amd_orth_max_rows())
+        obuf = torch.zeros(fused_rows + 1, dtype=torch.float64, device=V.device)
+
+        def fused(rows, Vb, wv, hin):
+            _lib.check(lib.ls_amd_orth_pass(rows, n, C.c_void_p(Vb.data_ptr()), Vb.stride(0), C.c_void_p(wv.data_ptr()),
+                                            C.c_void_p(hin.data_ptr()) if hin is not None else None, C.c_void_p(obuf.data_ptr()), _stream_ptr()))
+            return gsum(obuf[: rows + 1].clone())
     j0 = 0  # number of locked (restarted) vectors at the front of V
     restarts = 0
     history = []
@@ -152,18 +170,35 @@ def lanczos_smallest(op, num_evals: int = 1, eps: float = 1e-6, max_basis: int =
         for j in range(j0, m):
             op.matvec(V[j], w)
             Vj = V[: j + 1]
-            h = gsum(torch.mv(Vj.conj() if cplx else Vj, w))
-            w -= torch.mv(Vj.t(), h)
-            h2 = gsum(torch.mv(Vj.conj() if cplx else Vj, w))
-            w -= torch.mv(Vj.t(), h2)
-            h = (h + h2).cpu().numpy()
-            beta = norm(w)
+            if fused is not None and j + 1 <= fused_rows:
+                # classical Gram-Schmidt with the fused sweeps of csrc/orth.hip: pass 1 -> h and ||w||^2; pass 2 applies h and returns
+                # the overlaps that are left and the new norm in the same sweep.  A third sweep only when orthogonality was
+                # really lost (the left-over overlaps are not at rounding level relative to what remains of w)
+                out = fused(j + 1, Vj, w, None)
+                h = out[: j + 1].clone()
+                out = fused(j + 1, Vj, w, h)
+                o2 = out.cpu().numpy()
+                h2n, n1 = float(np.sqrt((o2[: j + 1] ** 2).sum())), math.sqrt(max(float(o2[j + 1]), 0.0))
+                if h2n > 1e-11 * n1:
+                    h2 = out[: j + 1].clone()
+                    out = fused(j + 1, Vj, w, h2)
+                    h = h + h2
+                    n1 = math.sqrt(max(float(out[j + 1].item()), 0.0))
+                h = h.cpu().numpy()
+                beta = n1
+            else:
+                h = gsum(torch.mv(Vj.conj() if cplx else Vj, w))
+                w -= torch.mv(Vj.t(), h)
+                h2 = gsum(torch.mv(Vj.conj() if cplx else Vj, w))
+                w -= torch.mv(Vj.t(), h2)
+                h = (h + h2).cpu().numpy()
+                beta = norm(w)
             T[: j + 1, j] = h
             T[j + 1, j] = beta
             if beta < 1e-14 * max(1.0, float(np.abs(h).max())):
                 m_eff = j + 1
                 break
-            V[j + 1] = w / beta
+            torch.div(w, beta, out=V[j + 1])
         else:
             m_eff = m
         Tm = T[:m_eff, :m_eff]
@@ -187,8 +222,11 @@ def lanczos_smallest(op, num_evals: int = 1, eps: float = 1e-6, max_basis: int =
         # thick restart: keep `keep` Ritz vectors, then the next Lanczos vector
         keep = min(m_eff - 2, kk + max(2, (m_eff - kk) // 3))
         St = torch.as_tensor(S[:, :keep], dtype=V.dtype, device=V.device)
-        Y = torch.mm(St.t(), V[:m_eff])
-        V[:keep] = Y
+        # V[:keep] <- S^T V[:m_eff] in column blocks: the product of whole rows would be a temporary of `keep` vectors
+        step = 1 << 24
+        for c0 in range(0, n, step):
+            c1 = min(n, c0 + step)
+            V[:keep, c0:c1] = torch.mm(St.t(), V[:m_eff, c0:c1])
         V[keep] = V[m_eff]
         T[:, :] = 0
         for i in range(keep):

@@ -58,6 +58,14 @@ int ls_amd_stream_copy(void *d_dst, void const *d_src, int64_t bytes, void *stre
 /* the read-only counterpart: every thread reads `per_thread` 16-byte elements and keeps an xor of them (d_sink: 4 bytes of device
  * memory, practically never written): the attainable READ rate of the box, the line the pull kernels' traffic (> 90 % reads)
  * is held against */
+/* Eigensolver callers (Diagonalize.chpl:174-225 hands H to PRIMME; its Lanczos / Davidson steps orthogonalise one vector against
+ * a block of basis vectors).  One sweep over the block V (m <= ls_amd_orth_max_rows() rows of n f64, row stride ldv) and w:
+ *     if d_h_in:  w <- w - sum_k h_in[k] V[k];    out[k] = <V[k], w> (k < m, over the updated w);    out[m] = <w, w>
+ * d_out: device [m + 1].  Pass 1 (h_in NULL) -> coefficients and norm; pass 2 (h_in = them) applies them and returns the remaining
+ * overlaps in the same sweep, so classical Gram-Schmidt "twice" reads V two times instead of four when they are at rounding
+ * level. */
+int ls_amd_orth_max_rows(void);
+int ls_amd_orth_pass(int m, int64_t n, double const *d_V, int64_t ldv, double *d_w, double const *d_h_in, double *d_out, void *stream);
 int ls_amd_stream_read(void const *d_src, int64_t bytes, int per_thread, void *d_sink, void *stream);
 
 /* hash64_01 / localeIdxOf on the host (StatesEnumeration.chpl:122-136) */
