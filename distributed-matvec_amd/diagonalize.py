@@ -166,10 +166,19 @@ def lanczos_smallest(op, num_evals: int = 1, eps: float = 1e-6, max_basis: int =
     j0 = 0  # number of locked (restarted) vectors at the front of V
     restarts = 0
     history = []
+    prof = {"orth": 0.0, "normalise": 0.0, "restart": 0.0} if os.environ.get("LS_AMD_LANCZOS_PROFILE") else None
+
+    def tick():
+        if prof is None:
+            return 0.0
+        torch.cuda.synchronize()
+        return time.perf_counter()
+
     while True:
         for j in range(j0, m):
             op.matvec(V[j], w)
             Vj = V[: j + 1]
+            t_a = tick()
             if fused is not None and j + 1 <= fused_rows:
                 # classical Gram-Schmidt with the fused sweeps of csrc/orth.hip: pass 1 -> h and ||w||^2; pass 2 applies h and returns
                 # the overlaps that are left and the new norm in the same sweep.  A third sweep only when orthogonality was
@@ -193,12 +202,17 @@ def lanczos_smallest(op, num_evals: int = 1, eps: float = 1e-6, max_basis: int =
                 w -= torch.mv(Vj.t(), h2)
                 h = (h + h2).cpu().numpy()
                 beta = norm(w)
+            if prof is not None:
+                prof["orth"] += tick() - t_a
             T[: j + 1, j] = h
             T[j + 1, j] = beta
             if beta < 1e-14 * max(1.0, float(np.abs(h).max())):
                 m_eff = j + 1
                 break
+            t_a = tick()
             torch.div(w, beta, out=V[j + 1])
+            if prof is not None:
+                prof["normalise"] += tick() - t_a
         else:
             m_eff = m
         Tm = T[:m_eff, :m_eff]
@@ -220,6 +234,7 @@ def lanczos_smallest(op, num_evals: int = 1, eps: float = 1e-6, max_basis: int =
             return EigenResult([float(t) for t in theta[:kk]], vecs, [float(r) for r in res], op.matvecs, restarts, bool(done),
                                time.perf_counter() - t0, history)
         # thick restart: keep `keep` Ritz vectors, then the next Lanczos vector
+        t_a = tick()
         keep = min(m_eff - 2, kk + max(2, (m_eff - kk) // 3))
         St = torch.as_tensor(S[:, :keep], dtype=V.dtype, device=V.device)
         # V[:keep] <- S^T V[:m_eff] in column blocks: the product of whole rows would be a temporary of `keep` vectors
@@ -235,6 +250,9 @@ def lanczos_smallest(op, num_evals: int = 1, eps: float = 1e-6, max_basis: int =
             T[i, keep] = np.conj(T[keep, i])
         j0 = keep
         restarts += 1
+        if prof is not None:
+            prof["restart"] += tick() - t_a
+            print(f"[lanczos] profile after restart {restarts}: " + ", ".join(f"{k} {v:.2f} s" for k, v in prof.items()), flush=True)
 
 
 def diagonalize(config, num_evals: int = 1, eps: float = 1e-6, num_partitions: int = 1, dtype=None, output: str | None = None,
