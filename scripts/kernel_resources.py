@@ -9,8 +9,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def resources(extra_flags=()):
-    src = os.path.join(ROOT, "distributed-matvec_amd", "csrc", "kernels.hip")
+def resources(extra_flags=(), source="kernels.hip"):
+    src = os.path.join(ROOT, "distributed-matvec_amd", "csrc", source)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     out = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "--cuda-device-only", "-S", src,
                           "-o", os.devnull, "-Rpass-analysis=kernel-resource-usage", *extra_flags], capture_output=True, text=True,
