@@ -176,6 +176,31 @@ def slot_cache_leg(plan, run, check, kernel_times, time_steps, steps):
             "kernel_ms_avg": sum(ks) / max(1, len(ks)), "matrix_free": False}
 
 
+def eigensolve_extra(D, torch, name, max_basis=12, eps=1e-7):
+    """the caller of the path (BASELINE config 5: Diagonalize): ground state of one of the projected chains with the device-resident
+    thick-restart Lanczos of diagonalize.py -- enumeration, plan, the slot cache in whatever HBM the Krylov basis leaves, fused
+    Gram-Schmidt sweeps; wall seconds from the YAML-equivalent config to the converged eigenpair"""
+    from distributed_matvec_amd.diagonalize import LocalOperator, lanczos_smallest
+
+    t0 = time.perf_counter()
+    basis, h = D.loadConfigFromDict(model_config(name)[0], hamiltonian=True)
+    reps, _masks = D.enumerateStates(basis, 1)
+    n = int(reps[0].numel())
+    free, _total = torch.cuda.mem_get_info()
+    op = LocalOperator(h, reps, torch.float64, slot_cache_bytes=max(0, int(free) - (max_basis + 6) * n * 8 - (8 << 30)))
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    res = lanczos_smallest(op, num_evals=1, eps=eps, max_basis=max_basis, max_restarts=200)
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    out = {"states": n, "E0": res.eigenvalues[0], "E0_per_site": res.eigenvalues[0] / basis.numberSites(), "converged": bool(res.converged),
+           "residual": res.residual_norms[0], "matvecs": res.matvecs, "restarts": res.restarts, "max_basis": max_basis, "eps": eps,
+           "seconds_setup": t1 - t0, "seconds_solve": t2 - t1, "seconds_per_lanczos_step": (t2 - t1) / max(1, res.matvecs),
+           "slot_cache_rows": op.cached_rows, "slot_cache_bytes": op.plan.slot_cache[1], "kernel": op.plan.kernel}
+    op.plan.destroy()
+    return out
+
+
 def projected_extra(D, torch, dist, name, rank, world, time_steps, allsum, steps=3, warmup=2):
     """one of the symmetry-projected BASELINE chains, measured inside the default run (see main)"""
     from distributed_matvec_amd import config
@@ -704,6 +729,16 @@ def main():
             torch.cuda.empty_cache()
         if world > 1:
             extra["model_heisenberg_chain_32"] = scaling_model("heisenberg_chain_32", world)
+        else:
+            for name in ("heisenberg_chain_36_symm", "heisenberg_chain_40_symm"):
+                try:
+                    extra["eigensolve_" + name] = eigensolve_extra(D, torch, name)
+                except Exception as e:  # reported, never hidden
+                    import traceback
+
+                    traceback.print_exc()
+                    extra["eigensolve_" + name] = {"error": repr(e)[:400]}
+                torch.cuda.empty_cache()
 
     cpu = None
     if rank == 0 and not distributed and not args.no_cpu_baseline:

@@ -110,6 +110,7 @@ def load():
         "ls_amd_stream_read": (C.c_int, [vp, C.c_int64, C.c_int, vp, vp]),
         "ls_amd_orth_max_rows": (C.c_int, []),
         "ls_amd_orth_pass": (C.c_int, [C.c_int, C.c_int64, vp, C.c_int64, vp, vp, vp, vp]),
+        "ls_amd_basis_rotate": (C.c_int, [C.c_int, C.c_int, C.c_int64, vp, C.c_int64, vp, vp]),
         "ls_amd_hash64_01": (C.c_uint64, [C.c_uint64]),
         "ls_amd_locale_idx_of": (C.c_int, [C.c_uint64, C.c_int]),
         "ls_amd_plan_create": (C.c_int, [C.POINTER(vp), op, C.c_int, C.c_int, C.c_int, C.POINTER(vp), c_i64p, C.c_int, C.c_int, vp]),

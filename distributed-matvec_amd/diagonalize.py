@@ -237,11 +237,16 @@ def lanczos_smallest(op, num_evals: int = 1, eps: float = 1e-6, max_basis: int =
         t_a = tick()
         keep = min(m_eff - 2, kk + max(2, (m_eff - kk) // 3))
         St = torch.as_tensor(S[:, :keep], dtype=V.dtype, device=V.device)
-        # V[:keep] <- S^T V[:m_eff] in column blocks: the product of whole rows would be a temporary of `keep` vectors
-        step = 1 << 24
-        for c0 in range(0, n, step):
-            c1 = min(n, c0 + step)
-            V[:keep, c0:c1] = torch.mm(St.t(), V[:m_eff, c0:c1])
+        if fused is not None and m_eff <= fused_rows:
+            # V[:keep] <- S^T V[:m_eff] in place, one read of m_eff and one write of keep vectors (csrc/orth.hip)
+            Sc = St.contiguous()
+            _lib.check(lib.ls_amd_basis_rotate(m_eff, keep, n, C.c_void_p(V.data_ptr()), V.stride(0), C.c_void_p(Sc.data_ptr()), _stream_ptr()))
+        else:
+            # ... in column blocks: the product of whole rows would be a temporary of `keep` vectors
+            step = 1 << 24
+            for c0 in range(0, n, step):
+                c1 = min(n, c0 + step)
+                V[:keep, c0:c1] = torch.mm(St.t(), V[:m_eff, c0:c1])
         V[keep] = V[m_eff]
         T[:, :] = 0
         for i in range(keep):

@@ -66,6 +66,8 @@ int ls_amd_stream_copy(void *d_dst, void const *d_src, int64_t bytes, void *stre
  * level. */
 int ls_amd_orth_max_rows(void);
 int ls_amd_orth_pass(int m, int64_t n, double const *d_V, int64_t ldv, double *d_w, double const *d_h_in, double *d_out, void *stream);
+/* thick restart of such a solver: V[:m_out] <- S^T V[:m_in] in place (d_S: m_in x m_out, row-major; m_out <= m_in <= max rows) */
+int ls_amd_basis_rotate(int m_in, int m_out, int64_t n, double *d_V, int64_t ldv, double const *d_S, void *stream);
 int ls_amd_stream_read(void const *d_src, int64_t bytes, int per_thread, void *d_sink, void *stream);
 
 /* hash64_01 / localeIdxOf on the host (StatesEnumeration.chpl:122-136) */

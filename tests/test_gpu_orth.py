@@ -79,3 +79,23 @@ def test_two_sweeps_orthogonalise_to_rounding(torch):
     assert float(left.abs().max()) <= 1e-12 * nrm * 60
     assert abs(nrm - float(torch.linalg.vector_norm(w))) <= 1e-12 * nrm
     assert float(torch.mv(V, w).abs().max()) <= 1e-12 * nrm * 60
+
+
+@pytest.mark.parametrize("m_in,m_out,n,pad", [(12, 8, 100003, 0), (32, 32, 4099, 3), (5, 1, 1 << 18, 2), (2, 2, 3, 0)])
+def test_basis_rotate_matches_torch(torch, m_in, m_out, n, pad):
+    """ls_amd_basis_rotate (thick restart): V[:m_out] <- S^T V[:m_in] in place == torch.mm on a copy; the rows behind m_out stay"""
+    from distributed_matvec_amd import _lib
+
+    lib = _lib.load()
+    g = torch.Generator(device="cuda").manual_seed(7 * m_in + m_out)
+    store = torch.randn((m_in + 1, n + pad), dtype=torch.float64, device="cuda", generator=g)
+    V = store[:, :n]
+    S = torch.randn((m_in, m_out), dtype=torch.float64, device="cuda", generator=g)
+    want = torch.mm(S.t(), V[:m_in])
+    tail = V[m_out:].clone()
+    assert lib.ls_amd_basis_rotate(m_in, m_out, n, C.c_void_p(V.data_ptr()), V.stride(0), C.c_void_p(S.data_ptr()), None) == 0
+    torch.cuda.synchronize()
+    assert float((V[:m_out] - want).abs().max()) <= 1e-12 * float(want.abs().max())
+    assert torch.equal(V[m_out:], tail)
+    assert lib.ls_amd_basis_rotate(m_out, m_in + 1, n, C.c_void_p(V.data_ptr()), V.stride(0), C.c_void_p(S.data_ptr()), None) != 0
+

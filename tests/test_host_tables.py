@@ -304,7 +304,7 @@ def test_hot_kernel_register_budget():
     # the eigensolver's fused Gram-Schmidt sweep (csrc/orth.hip): 33 accumulators per thread that must stay in registers (one
     # run-time index into them sent the array to scratch: 3.9 instead of 5.8 TB/s)
     orth = kernel_resources.resources(source="orth.hip")
-    assert len(orth) == 2 and all(v["scratch"] == 0 and v["occ"] >= 4 for v in orth.values()), orth
+    assert len(orth) == 3 and all(v["scratch"] == 0 and v["occ"] >= 4 for v in orth.values()), orth  # two sweeps + the restart rotation
 
 
 def _fixed_weight_states(L, hw):
