@@ -3262,8 +3262,13 @@ extern "C" int lsk_tile_pull_gather(lsk_operator op, lsk_basis bs, int cplx, int
 template <bool CPLX>
 __global__ __launch_bounds__(kBlock) void k_scatter(lsk_index ix, int64_t n, uint64_t const *__restrict__ betas,
                                                     double const *__restrict__ vals, double *y,
-                                                    double const *__restrict__ norms, int *err) {
-    for (int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x; k < n; k += (int64_t)gridDim.x * kBlock) {
+                                                    double const *__restrict__ norms, int *err, int xcd_chunk) {
+    // XCD-chunked block -> packets map (pull_tile_of_block): the look-ups of neighbouring packet blocks read neighbouring table /
+    // representative lines, which then meet in ONE L2 instead of eight
+    const int64_t n_blocks = (n + kBlock - 1) / kBlock;
+    for (int64_t kb = blockIdx.x; kb < n_blocks; kb += gridDim.x) {
+        const int64_t k = pull_tile_of_block(kb, n_blocks, gridDim.x >= n_blocks ? xcd_chunk : 0) * kBlock + threadIdx.x;
+        if (k >= n) continue;
         double vr, vi = 0.0;
         if (CPLX) { vr = vals[2 * k]; vi = vals[2 * k + 1]; } else vr = vals[k];
         if (vr == 0.0 && vi == 0.0) continue; // DMV:110
@@ -3279,8 +3284,12 @@ extern "C" int lsk_scatter(lsk_index ix, int cplx, int64_t n, uint64_t const *be
     if (n == 0) return 0;
     if (ix.kind == LSK_INDEX_COMBINADIC) { snprintf(g_err, sizeof(g_err), "lsk_scatter: SEARCH/IDENTITY index only"); return -1; }
     dim3 g(grid_for(n)), b(kBlock);
-    if (cplx) hipLaunchKernelGGL(k_scatter<true>, g, b, 0, (hipStream_t)stream, ix, n, betas, (double const *)vals, (double *)y, norms, d_err);
-    else hipLaunchKernelGGL(k_scatter<false>, g, b, 0, (hipStream_t)stream, ix, n, betas, (double const *)vals, (double *)y, norms, d_err);
+    // one block per 256 packets, 64 consecutive blocks per XCD (chain_28 x 8 partitions: consumers 14.85 -> 14.37 ms; chunks of
+    // 1 / 16 / 256 / 1024: 14.65 / 14.42 / 14.36 / 14.39 -- profiles/r4_scatter_xcd_chunk_ab.txt)
+    constexpr int chunk = 64;
+    { const int64_t nb = (n + kBlock - 1) / kBlock; g.x = (unsigned)(nb < ((int64_t)1 << 30) ? nb : ((int64_t)1 << 30)); }
+    if (cplx) hipLaunchKernelGGL(k_scatter<true>, g, b, 0, (hipStream_t)stream, ix, n, betas, (double const *)vals, (double *)y, norms, d_err, chunk);
+    else hipLaunchKernelGGL(k_scatter<false>, g, b, 0, (hipStream_t)stream, ix, n, betas, (double const *)vals, (double *)y, norms, d_err, chunk);
     LSK_LAUNCH_CHECK();
     return 0;
 }
