@@ -398,6 +398,27 @@ def test_kernel_table_entry_points(torch):
     assert_close(h2 @ x10, oracle_for("heisenberg_chain_10").local_matvec(r10, x10))
 
 
+def test_square_5x5_enumeration_and_matvec(torch):
+    """data/heisenberg_square_5x5.yaml of the reference's enumeration matrix (/root/reference/Makefile:112-126): 25 sites at weight 13
+    (5 200 300 states, 50 bonds, not a chain): representatives bit-exact, the staged pair kernel, the generic row kernel and the
+    push formulation == the oracle on every row, and hash-partitioned over three locales"""
+    name = "heisenberg_square_5x5"
+    D, basis, h, reps, masks = setup_model(torch, model_config(name), 1)
+    want_reps = oracle_reps(name)
+    assert len(want_reps) == 5200300
+    assert np.array_equal(reps[0].cpu().numpy().view(np.uint64), want_reps)
+    x = np.random.RandomState(55).rand(len(want_reps)) - 0.5
+    want = oracle_for(name).local_matvec(want_reps, x)
+    got, pl = run_matvec(torch, D, h, reps, masks, x, 1, "pull")
+    assert pl.kernel == "direct-pull+pairs"
+    assert_close(got, want, name + " pairs")
+    got, pl = run_matvec(torch, D, h, reps, masks, x, 1, "push")
+    assert_close(got, want, name + " push")
+    D3, basis3, h3, reps3, masks3 = setup_model(torch, model_config(name), 3)
+    got, _ = run_matvec(torch, D3, h3, reps3, masks3, x, 3)
+    assert_close(got, want, name + " three locales")
+
+
 def test_slot_cache_through_the_kernel_table_entry(torch, monkeypatch):
     """LS_AMD_SLOT_CACHE under the reference's own call path: ls_chpl_matrix_vector_product (host f64 arrays, one cached plan
     per operator) on a projected basis -- the first call resolves the packet streams, the following ones gather; every call
