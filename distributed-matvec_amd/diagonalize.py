@@ -378,6 +378,16 @@ def diagonalize_distributed(config, group=None, num_evals: int = 1, eps: float =
         reps_global = api.arrFromHashedToBlock(parts, masks) if world > 1 else parts[0]
         op = RcclReplicatedOperator(h, reps_global, masks, dtype, group=group)
         del reps_global
+        # one plan, hundreds of matvecs: this rank's rows keep their resolved packet streams in the HBM the Krylov basis leaves
+        # (ls_amd_plan_cache_slots -- a local decision, no collective; rows that do not fit stay matrix-free; LS_AMD_SLOT_CACHE=0: off)
+        plan = getattr(getattr(op, "engine", None), "plan", None)
+        if plan is not None and hasattr(plan, "cache_slots") and my_reps.is_cuda and os.environ.get("LS_AMD_SLOT_CACHE", "1") != "0":
+            free, _total = torch.cuda.mem_get_info()
+            budget = int(free) - (max_basis + 6) * int(my_reps.numel()) * (16 if dtype == torch.complex128 else 8) - (4 << 30)
+            if budget > 0:
+                rows = plan.cache_slots(budget)
+                if verbose and rows:
+                    print(f"[diagonalize_distributed] rank {rank}: slot cache for {rows} rows, {plan.slot_cache[1] / 1e9:.2f} GB", flush=True)
     else:
         op = RcclDistributedOperator(h, my_reps, dtype, group=group)
     del parts
