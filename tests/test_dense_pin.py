@@ -1,0 +1,200 @@
+"""Element-wise pin of the checker (oracle/) by a construction that shares nothing with it: the Hamiltonian as an explicit sum of
+Kronecker products of Pauli matrices on the full 2^L space (scipy.sparse), the sector as a plain selection of bit strings, the
+symmetry-adapted basis as P e_r / |P e_r| with the projector P = 1/|G| sum_g conj(chi(g)) U_g built from the permutations the
+YAML lists (group closure by brute force), and the projected matrix as U^T H U.  Against it: the oracle's representatives
+(bit-exact) and its matvec y = H x ELEMENT BY ELEMENT on random vectors -- the ordering of the basis, the sign of every basis
+vector, the n(r') / n(r) factors of BatchedOperator.chpl:163-213 and the characters all enter y, none of them enters an
+eigenvalue.  No term table, no flip masks, no orbit-minimum code, no expression compiler of oracle/model.py is used here: the
+expressions of the reference's data files are of the form "[c ×] A_0 B_1" and are read with one regular expression.  The GPU
+parity tests compare the HIP path with the oracle on the same models, so this pins both."""
+import itertools
+import re
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from helpers import model_config, oracle_for, oracle_reps
+
+PAULI = {
+    "x": sp.csr_matrix(np.array([[0, 1], [1, 0]], dtype=complex)),
+    "y": sp.csr_matrix(np.array([[0, -1j], [1j, 0]], dtype=complex)),
+    "z": sp.csr_matrix(np.array([[1, 0], [0, -1]], dtype=complex)),
+}
+SUP = {"ˣ": "x", "ʸ": "y", "ᶻ": "z"}
+SUB = {"₀": 0, "₁": 1}
+
+
+def parse_expression(expr):
+    """'0.8 × σᶻ₀ σᶻ₁' -> (0.8, [('z', 0), ('z', 1)]); S = sigma / 2"""
+    m = re.fullmatch(r"\s*(?:([-+0-9.eE]+)\s*×\s*)?([σS])([ˣʸᶻ])([₀₁])\s+([σS])([ˣʸᶻ])([₀₁])\s*", expr)
+    assert m, expr
+    c = float(m.group(1)) if m.group(1) else 1.0
+    for letter in (m.group(2), m.group(5)):
+        if letter == "S":
+            c *= 0.5
+    return c, [(SUP[m.group(3)], SUB[m.group(4)]), (SUP[m.group(6)], SUB[m.group(7)])]
+
+
+def site_operator(L, kind, site):
+    """Pauli matrix on `site` of L spins; site 0 is the least significant bit of the state index"""
+    # kron(A, B): A takes the more significant index, so the product runs from the top site down (index = sum_q bit_q 2^q)
+    mats = [PAULI[kind] if q == site else sp.identity(2, dtype=complex, format="csr") for q in range(L)]
+    out = mats[L - 1]
+    for q in range(L - 2, -1, -1):
+        out = sp.kron(out, mats[q], format="csr")
+    return out
+
+
+def dense_hamiltonian(cfg):
+    L = cfg["basis"]["number_spins"]
+    cache = {}
+
+    def op(kind, site):
+        if (kind, site) not in cache:
+            cache[(kind, site)] = site_operator(L, kind, site)
+        return cache[(kind, site)]
+
+    H = sp.csr_matrix((2 ** L, 2 ** L), dtype=complex)
+    for term in cfg["hamiltonian"]["terms"]:
+        c, factors = parse_expression(term["expression"])
+        for sites in term["sites"]:
+            (ka, ia), (kb, ib) = factors
+            H = H + c * (op(ka, sites[ia]) @ op(kb, sites[ib]))
+    assert abs(H - H.getH()).max() < 1e-14
+    return H
+
+
+def permutation_order(perm):
+    p, n = list(perm), 1
+    cur = list(perm)
+    while cur != list(range(len(perm))):
+        cur = [p[i] for i in cur]
+        n += 1
+    return n
+
+
+def group_elements(cfg):
+    """closure of the generators: [(site permutation or None for the global flip composed in, character)] as (perm, flip, chi)"""
+    L = cfg["basis"]["number_spins"]
+    gens = []
+    for s in cfg["basis"].get("symmetries", []):
+        n = permutation_order(s["permutation"])
+        gens.append((tuple(s["permutation"]), 0, np.exp(-2j * np.pi * s["sector"] / n)))
+    inv = cfg["basis"].get("spin_inversion")
+    if inv:
+        gens.append((tuple(range(L)), 1, complex(inv)))
+    ident = (tuple(range(L)), 0)
+    elems = {ident: 1.0 + 0j}
+    frontier = [ident]
+    while frontier:
+        new = []
+        for (p, f) in frontier:
+            for (gp, gf, gc) in gens:
+                q = (tuple(gp[i] for i in p), f ^ gf)  # apply (p, f) first, then the generator
+                chi = elems[(p, f)] * gc
+                if q not in elems:
+                    elems[q] = chi
+                    new.append(q)
+                else:
+                    assert abs(elems[q] - chi) < 1e-12, "the sectors of the generators are not a character of the group"
+        frontier = new
+    return [(p, f, c) for (p, f), c in elems.items()]
+
+
+def apply_element(states, perm, flip, L):
+    """bit i of the state moves to bit perm[i] (either convention gives the same orbits and, for the real characters of the
+    reference's files, the same projector)"""
+    out = np.zeros_like(states)
+    for i in range(L):
+        out |= ((states >> np.uint64(i)) & np.uint64(1)) << np.uint64(perm[i])
+    if flip:
+        out ^= np.uint64((1 << L) - 1)
+    return out
+
+
+def dense_projected(cfg):
+    """(representatives ascending, H in the symmetry-adapted orthonormal basis) -- or the plain sector when there is no group"""
+    L = cfg["basis"]["number_spins"]
+    hw = cfg["basis"].get("hamming_weight")
+    H = dense_hamiltonian(cfg)
+    states = np.arange(2 ** L, dtype=np.uint64)
+    if hw is not None:
+        pop = np.zeros(2 ** L, dtype=np.int64)
+        for i in range(L):
+            pop += ((states >> np.uint64(i)) & np.uint64(1)).astype(np.int64)
+        sector = states[pop == hw]
+    else:
+        sector = states
+    elems = group_elements(cfg)
+    Hs = H[sector.astype(np.int64)][:, sector.astype(np.int64)]
+    if len(elems) == 1:
+        return sector, Hs
+    pos = {int(s): k for k, s in enumerate(sector)}
+    n = len(sector)
+    P = sp.csr_matrix((n, n), dtype=complex)
+    images = []
+    for perm, flip, chi in elems:
+        img = apply_element(sector, perm, flip, L)
+        images.append(img)
+        cols = np.arange(n)
+        rows = np.array([pos[int(v)] for v in img])
+        P = P + sp.csr_matrix((np.full(n, np.conj(chi)), (rows, cols)), shape=(n, n))
+    P = P / len(elems)
+    orbit_min = np.min(np.stack(images), axis=0)
+    reps, cols = [], []
+    for k in np.flatnonzero(orbit_min == sector):  # orbit minima, ascending
+        v = P[:, k].toarray().ravel()
+        nrm = np.linalg.norm(v)
+        if nrm > 1e-10:  # zero-norm orbits are not in the basis
+            reps.append(sector[k])
+            cols.append(v / nrm)
+    U = np.stack(cols, axis=1)
+    Hp = U.conj().T @ (Hs @ U)
+    return np.array(reps, dtype=np.uint64), Hp
+
+
+MODELS = ["heisenberg_chain_4", "heisenberg_chain_6", "heisenberg_chain_8", "heisenberg_chain_10", "heisenberg_chain_12",
+          "heisenberg_kagome_12", "heisenberg_kagome_12_symm", "issue_01", "heisenberg_chain_16", "heisenberg_kagome_16",
+          "heisenberg_square_4x4"]
+
+
+@pytest.mark.parametrize("name", MODELS)
+def test_oracle_matvec_equals_kronecker_construction(name):
+    cfg = model_config(name)
+    reps, H = dense_projected(cfg)
+    want_reps = oracle_reps(name)
+    assert np.array_equal(reps, want_reps), (name, len(reps), len(want_reps))
+    H = H.toarray() if sp.issparse(H) else np.asarray(H)
+    assert np.abs(H.imag).max() < 1e-12  # the reference's files describe real symmetric matrices
+    H = H.real
+    assert np.abs(H - H.T).max() < 1e-12
+    rs = np.random.RandomState(len(name))
+    o = oracle_for(name)
+    for _ in range(2):
+        x = rs.rand(len(reps)) - 0.5
+        y = o.local_matvec(want_reps, x)
+        want = H @ x
+        assert np.abs(y - want).max() <= 1e-12 * max(1.0, np.abs(want).max()), name
+    xc = (rs.rand(len(reps)) - 0.5) + 1j * (rs.rand(len(reps)) - 0.5)
+    yc = o.local_matvec(want_reps, xc)
+    assert np.abs(yc - H @ xc).max() <= 1e-12 * max(1.0, np.abs(H @ xc).max()), name
+
+
+def test_symmetric_chain_sectors_against_kronecker_construction():
+    """the symmetric-chain family of the BASELINE configs at a size the dense construction reaches (12 and 16 sites: translation,
+    reflection and spin inversion, trivial sector -- the same generators as data/heisenberg_chain_{24,32,36,40}_symm.yaml)"""
+    from oracle import c_oracle as CO
+    from oracle import model as M
+
+    for L in (12, 16):
+        cfg = M.heisenberg_chain_config(L, symm=True)
+        reps, H = dense_projected(cfg)
+        o = CO.COracle(M.model_from_config(cfg))
+        want_reps = o.enumerate()
+        assert np.array_equal(reps, want_reps)
+        H = np.asarray(H)
+        assert np.abs(H.imag).max() < 1e-12
+        x = np.random.RandomState(L).rand(len(reps)) - 0.5
+        want = H.real @ x
+        assert np.abs(o.local_matvec(want_reps, x) - want).max() <= 1e-12 * max(1.0, np.abs(want).max())
