@@ -2758,7 +2758,7 @@ extern "C" int lsk_test_nw_find(uint64_t const *reps, int n, uint64_t key) {
 // tile, and each of the eight L2s fetches its own copy of the partner sectors that neighbouring tiles share.  With a chunk of C
 // tiles per XCD the blocks of one XCD walk C consecutive tiles before they jump by 8 C.  (The last, incomplete round of
 // chunks keeps the identity.)
-__device__ __forceinline__ int64_t pull_tile_of_block(int64_t b, int64_t n_tiles, int C) {
+__host__ __device__ __forceinline__ int64_t pull_tile_of_block(int64_t b, int64_t n_tiles, int C) {
     if (C <= 1) return b;
     const int64_t round = 8 * (int64_t)C, full = n_tiles / round * round;
     if (b >= full) return b;
@@ -2768,6 +2768,7 @@ __device__ __forceinline__ int64_t pull_tile_of_block(int64_t b, int64_t n_tiles
 // Measured (profiles/r4_pull_xcd_chunk_ab.txt; C = 0 / 16 / 64 / 256 / 1024 / 4096): chain_36_symm cached gather 4.18 / 3.88 / 3.76 /
 // 3.67 / 3.65 / 3.88 ms, fused 18.08 / 17.58 / 17.24 / 17.38 / 17.28 / 18.08 ms; chain_40_symm cached 65.7 / 63.6 / 59.9 / 60.1 / 60.0 /
 // 61.5 ms, fused 282.5 / 285.0 / 280.9 / 287.3 / 279.5 / 280.1 ms.
+extern "C" int64_t lsk_test_pull_tile_of_block(int64_t b, int64_t n_tiles, int C) { return pull_tile_of_block(b, n_tiles, C); }
 constexpr int kPullXcdChunk = 256;
 static int pull_xcd_chunk() { return kPullXcdChunk; }
 

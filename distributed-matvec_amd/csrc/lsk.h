@@ -291,6 +291,8 @@ int lsk_test_window_find(uint64_t const *reps, int n, uint64_t key);
 /* ... and of the LDS hash set of the indexed kernels (n <= 1024): position, or -1 when the window does not answer (absent,
  * or dropped from a full set -- such a partner goes through the static index table) */
 int lsk_test_nw_find(uint64_t const *reps, int n, uint64_t key);
+/* block -> tile of the pull kernels and of k_scatter (C consecutive tiles per XCD): host mirror for the tests */
+int64_t lsk_test_pull_tile_of_block(int64_t b, int64_t n_tiles, int C);
 int lsk_test_chain_near_table(int elem, int ldsp, int16_t *out);
 uint64_t lsk_test_rep_trivial_dihedral(uint64_t a, int L, int inv, int reflect);
 /* K4 mode 4: the row table of torus_min (out[2^tw], tw <= 8) and the minimum of v (and, with inv, of its complement) over the

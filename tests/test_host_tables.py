@@ -617,6 +617,23 @@ def test_k4_trivial_sector_orbit_minimum(inv, reflect):
             assert f(a, L, inv, reflect) == _orbit_min(a, L, inv, reflect), (L, hex(a))
 
 
+def test_xcd_chunked_tile_map_is_a_permutation():
+    """pull_tile_of_block (k_pull_t, k_pull_gather, k_scatter): blocks b = x (mod 8) walk C consecutive tiles of XCD x before
+    they jump by 8 C; the last incomplete round keeps the identity.  Every tile must be visited exactly once, and inside a
+    full round the blocks of one XCD must see consecutive tiles."""
+    lib = _lib.load()
+    lib.lsk_test_pull_tile_of_block.restype = C.c_int64
+    lib.lsk_test_pull_tile_of_block.argtypes = [C.c_int64, C.c_int64, C.c_int]
+    for n in (1, 7, 8, 9, 63, 64, 65, 2047, 2048, 2049, 5000, 8 * 256 * 3, 8 * 256 * 3 + 777):
+        for c in (0, 1, 4, 64, 256):
+            seen = sorted(int(lib.lsk_test_pull_tile_of_block(b, n, c)) for b in range(n))
+            assert seen == list(range(n)), (n, c)
+    n, c = 8 * 64 * 2 + 100, 64
+    for x in range(8):
+        tiles = [int(lib.lsk_test_pull_tile_of_block(b, n, c)) for b in range(x, 8 * 64, 8)]  # the first 64 blocks of XCD x
+        assert tiles == list(range(x * 64, x * 64 + 64)), (x, tiles[:4])
+
+
 @pytest.mark.parametrize("inv", [0, 1])
 def test_torus_minimum_by_row_table(inv):
     """torus_min (K4 mode 4 since mid round 4): the minimum over the tw x th translations (and the complement) from one table
