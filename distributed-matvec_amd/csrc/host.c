@@ -1681,10 +1681,6 @@ int64_t ls_amd_internal_plan_split_enable(ls_amd_plan *pl, int64_t max_bytes) {
     return 0;
 }
 int64_t ls_amd_internal_plan_split_rows(ls_amd_plan const *pl) { return pl->split_rows; }
-/* Keep the resolved packet streams across matvecs (see slot_cache above).  max_bytes = ceiling for the packet buffers (<= 0:
- * whatever the device has).  One-partition plans need every row covered (else nothing is cached and 0 is returned: the plan
- * stays matrix-free); plans of the replicated-x exchange cache the rows the buffer covers and run the fused kernel on the
- * rest.  Returns the number of rows whose streams are cached. */
 /* Streams laid out back to back at their exact lengths (a count pass of stage A + a scan): about half of what the worst-case
  * stride of the split form reserves.  Covers every row if `max_bytes` (<= 0: no ceiling) and the device allow, else the longest
  * prefix of whole 256-row tiles that fits -- the rows behind it keep the fused kernel.  Returns the rows covered (0: none, nothing
@@ -1736,6 +1732,8 @@ static int64_t split_enable_exact(ls_amd_plan *pl, int64_t max_bytes) {
         if (max_bytes < ((int64_t)1 << 20)) { lsk_free(offs); return 0; }
     }
 }
+/* Keep the resolved packet streams across matvecs (see slot_cache above; include/ls_amd.h).  Returns the number of rows whose
+ * streams are cached: all of them, or the prefix that fits `max_bytes` / the device -- the rest runs the fused kernel. */
 int64_t ls_amd_plan_cache_slots(ls_amd_plan *pl, int64_t max_bytes) {
     if (!pl || !pl->idx_mode || pl->dbs.proj != LSK_PROJ_FULL || pl->parts[0].count <= 0 ||
         (pl->family != FAMILY_TILE_PULL && pl->family != FAMILY_REPL_TILE)) return 0;
