@@ -260,6 +260,29 @@ __device__ __forceinline__ int64_t search_index(lsk_index const &ix, uint64_t s)
     return (lo < end && ix.reps[lo] == s) ? (int64_t)lo : -1;
 }
 
+// Rank directory (lsk_rankdir, lsk.h): LDS copy of the binomials a rank needs -- C(p, k), p < sites, k <= weight -- and the look-up
+__device__ __forceinline__ int rankdir_lds_entries(lsk_index const &ix) { return ix.dir ? ix.dir_sites * (ix.dir_weight + 1) : 0; }
+__device__ __forceinline__ void rankdir_load(lsk_index const &ix, uint64_t *s_db) { // (the caller synchronises the block)
+    const int kc = ix.dir_weight + 1;
+    for (int i = threadIdx.x; i < ix.dir_sites * kc; i += blockDim.x) s_db[i] = ix.binom[(i / kc) * LSK_BINOM_K + (i % kc)];
+}
+__device__ __forceinline__ int64_t rankdir_index(lsk_index const &ix, uint64_t s, uint64_t const *s_db) {
+    const int kc = ix.dir_weight + 1;
+    if (__popcll(s) != ix.dir_weight || (ix.dir_sites < 64 && (s >> ix.dir_sites) != 0)) return -1;
+    uint64_t g = 0;
+    int k = 1;
+    while (s) {
+        const int p = __ffsll((unsigned long long)s) - 1;
+        g += s_db[p * kc + k];
+        ++k;
+        s &= s - 1;
+    }
+    const ulonglong2 e = *reinterpret_cast<ulonglong2 const *>(ix.dir + (g >> 6));
+    const uint64_t bit = 1ULL << (g & 63);
+    if (!(e.x & bit)) return -1;
+    return (int64_t)(uint32_t)e.y + __popcll(e.x & (bit - 1));
+}
+
 // Open-addressing hash table {representative -> x * norm(rep)} used by the staged pull kernel.  The
 // uncoalesced per-lane loads of a search (table + ~5 probes + value = 8 line requests per packet) were what
 // bounded k_tile_pull (L1/TA issue: one line per lane per cycle); a hit in the home slot costs ONE 16-byte
@@ -2030,6 +2053,8 @@ __global__ __launch_bounds__(kBlock) void k_tile_wv(int n_groups, lsk_group cons
     constexpr int kCap = (kBlock / 64) * kTwRing;
     __shared__ uint64_t s_beta[kCap];
     __shared__ double s_val[COUNT ? 1 : kCap * (CPLX ? 2 : 1)];
+    extern __shared__ uint64_t s_db[]; // rank directory of the own partition: binomials of the closed-form rank (0 bytes without one)
+    if (!COUNT && ix.dir) { rankdir_load(ix, s_db); __syncthreads(); }
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -2090,7 +2115,7 @@ __global__ __launch_bounds__(kBlock) void k_tile_wv(int n_groups, lsk_group cons
             if (!COUNT) {
                 if (live && dest == me) {
                     remote = false;
-                    const int64_t idx = search_index(ix, beta);
+                    const int64_t idx = ix.dir ? rankdir_index(ix, beta, s_db) : search_index(ix, beta);
                     if (idx < 0) atomicExch(err, 1);
                     else {
                         if (bs.proj == LSK_PROJ_FULL && bs.k4_mode != 0) { const double nb = norms[idx]; vr *= nb; vi *= nb; }
@@ -2170,12 +2195,13 @@ extern "C" int lsk_tile_wv(lsk_operator op, lsk_basis bs, lsk_index ix, int cplx
     dim3 g(1), b(kBlock);
     const int64_t work_blocks = (row1 - row0 + kBlock - 1) / kBlock;
     hipStream_t s = (hipStream_t)stream;
+    const size_t dyn_db = ix.dir ? sizeof(uint64_t) * (size_t)ix.dir_sites * (size_t)(ix.dir_weight + 1) : 0;
 #define LSK_TW_ARGS op.n_groups, op.groups, op.off, bs, bs.elems, ix, ow, me, row0, row1, reps, norms, (double const *)x, (double *)y, \
         d_wtab, d_layout, (char *)d_send, d_err
 #define LSK_TW_ONE(W, PM1, CPLX, REAL)                                                                                           \
     do {                                                                                                                         \
         if (count_only) { g.x = tile_grid(k_tile_wv<W, PM1, CPLX, REAL, true>, work_blocks); hipLaunchKernelGGL((k_tile_wv<W, PM1, CPLX, REAL, true>), g, b, 0, s, LSK_TW_ARGS); } \
-        else { g.x = tile_grid(k_tile_wv<W, PM1, CPLX, REAL, false>, work_blocks); hipLaunchKernelGGL((k_tile_wv<W, PM1, CPLX, REAL, false>), g, b, 0, s, LSK_TW_ARGS); } \
+        else { g.x = tile_grid(k_tile_wv<W, PM1, CPLX, REAL, false>, work_blocks); hipLaunchKernelGGL((k_tile_wv<W, PM1, CPLX, REAL, false>), g, b, dyn_db, s, LSK_TW_ARGS); } \
     } while (0)
 #define LSK_TW_LAUNCH(W, PM1)                                                                                  \
     do {                                                                                                       \
@@ -3266,6 +3292,8 @@ __global__ __launch_bounds__(kBlock) void k_scatter(lsk_index ix, int64_t n, uin
                                                     double const *__restrict__ norms, int *err, int xcd_chunk) {
     // XCD-chunked block -> packets map (pull_tile_of_block): the look-ups of neighbouring packet blocks read neighbouring table /
     // representative lines, which then meet in ONE L2 instead of eight
+    extern __shared__ uint64_t s_db[]; // rank directory: the binomials of the closed-form rank (launch-time size, 0 without one)
+    if (ix.dir) { rankdir_load(ix, s_db); __syncthreads(); }
     const int64_t n_blocks = (n + kBlock - 1) / kBlock;
     for (int64_t kb = blockIdx.x; kb < n_blocks; kb += gridDim.x) {
         const int64_t k = pull_tile_of_block(kb, n_blocks, gridDim.x >= n_blocks ? xcd_chunk : 0) * kBlock + threadIdx.x;
@@ -3273,7 +3301,7 @@ __global__ __launch_bounds__(kBlock) void k_scatter(lsk_index ix, int64_t n, uin
         double vr, vi = 0.0;
         if (CPLX) { vr = vals[2 * k]; vi = vals[2 * k + 1]; } else vr = vals[k];
         if (vr == 0.0 && vi == 0.0) continue; // DMV:110
-        int64_t idx = ix.kind == LSK_INDEX_IDENTITY ? (int64_t)betas[k] : search_index(ix, betas[k]);
+        int64_t idx = ix.kind == LSK_INDEX_IDENTITY ? (int64_t)betas[k] : (ix.dir ? rankdir_index(ix, betas[k], s_db) : search_index(ix, betas[k]));
         if (idx < 0) { atomicExch(err, 1); continue; }
         if (norms) { double nb = norms[idx]; vr *= nb; vi *= nb; }
         if (CPLX) { atomic_add_f64(y + 2 * idx, vr); atomic_add_f64(y + 2 * idx + 1, vi); }
@@ -3289,8 +3317,9 @@ extern "C" int lsk_scatter(lsk_index ix, int cplx, int64_t n, uint64_t const *be
     // 1 / 16 / 256 / 1024: 14.65 / 14.42 / 14.36 / 14.39 -- profiles/r4_scatter_xcd_chunk_ab.txt)
     constexpr int chunk = 64;
     { const int64_t nb = (n + kBlock - 1) / kBlock; g.x = (unsigned)(nb < ((int64_t)1 << 30) ? nb : ((int64_t)1 << 30)); }
-    if (cplx) hipLaunchKernelGGL(k_scatter<true>, g, b, 0, (hipStream_t)stream, ix, n, betas, (double const *)vals, (double *)y, norms, d_err, chunk);
-    else hipLaunchKernelGGL(k_scatter<false>, g, b, 0, (hipStream_t)stream, ix, n, betas, (double const *)vals, (double *)y, norms, d_err, chunk);
+    const size_t dyn = ix.dir ? sizeof(uint64_t) * (size_t)ix.dir_sites * (size_t)(ix.dir_weight + 1) : 0;
+    if (cplx) hipLaunchKernelGGL(k_scatter<true>, g, b, dyn, (hipStream_t)stream, ix, n, betas, (double const *)vals, (double *)y, norms, d_err, chunk);
+    else hipLaunchKernelGGL(k_scatter<false>, g, b, dyn, (hipStream_t)stream, ix, n, betas, (double const *)vals, (double *)y, norms, d_err, chunk);
     LSK_LAUNCH_CHECK();
     return 0;
 }
@@ -3391,6 +3420,36 @@ extern "C" int lsk_check_combinadic(lsk_index ix, int hamming_weight, int64_t n,
     hipLaunchKernelGGL(k_check_combinadic, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, ix.binom, n, reps, d_flag);
     LSK_LAUNCH_CHECK();
     return 0;
+}
+
+// ---- rank directory (lsk_rankdir): build + self-check -----------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_rankdir_mark(int64_t n, uint64_t const *__restrict__ reps, int sites, int weight,
+                                                         uint64_t const *__restrict__ g_binom, lsk_rankdir *__restrict__ dir, int *flag) {
+    __shared__ uint64_t s_binom[64 * LSK_BINOM_K];
+    load_binom(s_binom, g_binom);
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        const uint64_t s = reps[i];
+        if (__popcll(s) != weight || (sites < 64 && (s >> sites) != 0)) { atomicExch(flag, 1); continue; }
+        const uint64_t g = (uint64_t)rank_combinadic(s, s_binom);
+        atomicOr((unsigned long long *)&dir[g >> 6].bits, 1ULL << (g & 63));
+    }
+}
+struct ScanDirPopcIn {
+    lsk_rankdir const *dir;
+    __device__ int64_t operator()(int64_t i) const { return (int64_t)__popcll(dir[i].bits); }
+};
+__global__ __launch_bounds__(kBlock) void k_rankdir_prefix(int64_t entries, int64_t const *__restrict__ pre, lsk_rankdir *__restrict__ dir) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < entries; i += (int64_t)gridDim.x * kBlock) {
+        dir[i].prefix = (uint32_t)pre[i];
+        dir[i].pad = 0;
+    }
+}
+__global__ __launch_bounds__(kBlock) void k_rankdir_check(lsk_index ix, int64_t n, uint64_t const *__restrict__ reps, int *flag) {
+    extern __shared__ uint64_t s_db[];
+    rankdir_load(ix, s_db);
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+        if (rankdir_index(ix, reps[i], s_db) != i) atomicExch(flag, 1);
 }
 
 // table[b] = first i with (reps[i] >> shift) >= b.  Element i owns the buckets (bucket(i - 1), bucket(i)]; the representatives of
@@ -3664,6 +3723,38 @@ static int exclusive_scan_i64(int64_t n, int64_t const *in, int64_t *out, hipStr
 }
 extern "C" int lsk_exclusive_scan_i64(int64_t n, int64_t const *in, int64_t *out, void *stream) {
     return exclusive_scan_i64(n, in, out, (hipStream_t)stream);
+}
+extern "C" int lsk_rankdir_build(int64_t n, uint64_t const *reps, int sites, int weight, uint64_t const *d_binom, int64_t entries,
+                                 lsk_rankdir *dir, int *d_flag, void *stream) {
+    if (entries <= 0 || sites < 1 || sites > 64 || weight < 0 || weight >= LSK_BINOM_K) { snprintf(g_err, sizeof(g_err), "lsk_rankdir_build: bad arguments"); return -1; }
+    hipStream_t s = (hipStream_t)stream;
+    LSK_CHECK(hipMemsetAsync(dir, 0, sizeof(lsk_rankdir) * (size_t)entries, s));
+    if (n > 0) {
+        hipLaunchKernelGGL(k_rankdir_mark, dim3(grid_for(n)), dim3(kBlock), 0, s, n, reps, sites, weight, d_binom, dir, d_flag);
+        LSK_LAUNCH_CHECK();
+    }
+    int64_t *pre = nullptr, *scratch = nullptr;
+    LSK_CHECK(hipMalloc((void **)&pre, 8 * (size_t)entries));
+    if (hipMalloc((void **)&scratch, 8 * (size_t)scan_scratch_elems(entries)) != hipSuccess) { (void)hipFree(pre); snprintf(g_err, sizeof(g_err), "lsk_rankdir_build: out of memory"); return -1; }
+    ScanDirPopcIn in{dir};
+    int rc = exclusive_scan<ScanDirPopcIn>(in, entries, pre, scratch, s);
+    if (rc == 0) {
+        hipLaunchKernelGGL(k_rankdir_prefix, dim3(grid_for(entries)), dim3(kBlock), 0, s, entries, pre, dir);
+        if (hipGetLastError() != hipSuccess) rc = -1;
+    }
+    if (rc == 0 && n > 0) {
+        lsk_index ix;
+        memset(&ix, 0, sizeof(ix));
+        ix.kind = LSK_INDEX_SEARCH; ix.count = n; ix.reps = reps; ix.binom = d_binom; ix.dir = dir; ix.dir_sites = sites; ix.dir_weight = weight;
+        hipLaunchKernelGGL(k_rankdir_check, dim3(grid_for(n)), dim3(kBlock), sizeof(uint64_t) * (size_t)sites * (size_t)(weight + 1), s, ix, n, reps, d_flag);
+        if (hipGetLastError() != hipSuccess) rc = -1;
+    }
+    const hipError_t e2 = hipStreamSynchronize(s);
+    (void)hipFree(pre);
+    (void)hipFree(scratch);
+    if (rc != 0) { snprintf(g_err, sizeof(g_err), "lsk_rankdir_build: launch failed"); return -1; }
+    LSK_CHECK(e2);
+    return 0;
 }
 
 // ---------------------------------------------------------------------------------------------

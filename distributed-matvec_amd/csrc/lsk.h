@@ -95,6 +95,16 @@ typedef struct lsk_basis {
 
 enum { LSK_INDEX_IDENTITY = 0, LSK_INDEX_COMBINADIC = 1, LSK_INDEX_SEARCH = 2 };
 
+/* Rank directory of a hash partition of an unprojected fixed-weight basis (optional part of a SEARCH index): the global
+ * (colex) rank g of a state is closed-form, and the local index is the number of this partition's states below it --
+ *     entry = dir[g >> 6];  local = entry.prefix + popcount(entry.bits & below(g));  member <=> bit g of entry.bits
+ * one 16-byte load instead of the prefix-table look-up and the 3-4 dependent probes of the binary search. */
+typedef struct lsk_rankdir {
+    uint64_t bits;   /* bit j: global rank 64 w + j belongs to this partition */
+    uint32_t prefix; /* states of this partition with global rank < 64 w */
+    uint32_t pad;
+} lsk_rankdir;
+
 typedef struct lsk_index {
     int kind;
     int shift;             /* SEARCH: bucket = state >> shift */
@@ -102,7 +112,13 @@ typedef struct lsk_index {
     uint64_t const *reps;  /* device, ascending */
     uint32_t const *table; /* device [(max_state >> shift) + 2] lower bounds */
     uint64_t const *binom; /* device [64 * LSK_BINOM_K] */
+    lsk_rankdir const *dir; /* device [ceil(C(dir_sites, dir_weight) / 64)] or NULL */
+    int dir_sites, dir_weight;
 } lsk_index;
+/* dir[] for the n ascending states `reps` (all of weight `weight` on `sites` sites), entries = ceil(C(sites, weight) / 64); *d_flag is
+ * raised if a state has another weight or the directory does not give reps[i] -> i back */
+int lsk_rankdir_build(int64_t n, uint64_t const *reps, int sites, int weight, uint64_t const *d_binom, int64_t entries, lsk_rankdir *dir,
+                      int *d_flag, void *stream);
 
 /* per-round send layout: byte offsets of the beta / value arrays of every destination segment */
 typedef struct lsk_round_layout {
