@@ -158,13 +158,15 @@ def model_config(name):
             f"data/{name}.yaml (regenerated: periodic ring, sigma.sigma per bond)")
 
 
-def slot_cache_leg(plan, run, check, kernel_times, time_steps, steps):
+def slot_cache_leg(plan, run, check, kernel_times, time_steps, steps, allsum=None, world=1):
     """the same plan with ls_amd_plan_cache_slots: the packet streams (slot of every partner: 5 B per non-zero here) are resolved
     by the first matvec and kept in HBM, later matvecs only gather -- what an eigensolver that applies one plan hundreds of
     times runs.  Opt-in and NOT matrix-free, therefore a separate leg and never the headline."""
     rows = plan.cache_slots(0)
-    if rows <= 0:
-        return {"rows": 0, "note": "not enabled (no room for the packet streams, or nothing to cache)"}
+    # (with more than one rank the matvecs below are collective: every rank takes the leg, or none does)
+    enabled = rows > 0 if allsum is None else allsum(1.0 if rows > 0 else 0.0) >= world
+    if not enabled:
+        return {"rows": 0, "note": "not enabled (no room for the packet streams on some rank, or nothing to cache)"}
     run()  # resolves
     check()
     kernel_times()
@@ -262,7 +264,8 @@ def projected_extra(D, torch, dist, name, rank, world, time_steps, allsum, steps
                 "x_bytes_in_this_rank": op.x_bytes_in,
                 "rank0_stage_ms_per_matvec": {k: v[0] / max(1, mv) for k, v in stages.items()},
                 "model": scaling_model(name, world)})
-    out["slot_cache"] = slot_cache_leg(plan, lambda: op.matvec(x, y, check=False), plan.check, plan.kernel_times_ms, time_steps, steps)
+    out["slot_cache"] = slot_cache_leg(plan, lambda: op.matvec(x, y, check=False), plan.check, plan.kernel_times_ms, time_steps, steps,
+                                       allsum=allsum, world=world)
     op.rm.destroy()
     return out
 
