@@ -203,7 +203,7 @@ def eigensolve_extra(D, torch, name, max_basis=12, eps=1e-7):
     return out
 
 
-def projected_extra(D, torch, dist, name, rank, world, time_steps, allsum, steps=3, warmup=2):
+def projected_extra(D, torch, dist, name, rank, world, time_steps, allsum, steps=3, warmup=2, distributed=False):
     """one of the symmetry-projected BASELINE chains, measured inside the default run (see main)"""
     from distributed_matvec_amd import config
 
@@ -213,7 +213,7 @@ def projected_extra(D, torch, dist, name, rank, world, time_steps, allsum, steps
     parts, masks = D.enumerateStates(basis, world)
     n_total = int(masks.numel())
     out = {"states": n_total, "steps": steps, "warmup": warmup, "dtype": "f64"}
-    if world == 1:
+    if world == 1 and not distributed:
         reps = parts[0]
         x = [D.fillRandom(reps, 42, torch.float64)]
         y = [torch.zeros_like(x[0])]
@@ -445,6 +445,8 @@ def main():
     ap.add_argument("--mode", default=os.environ.get("LS_AMD_MODE", "auto"), choices=["auto", "push", "pull"])
     ap.add_argument("--exchange", default="auto", choices=["auto", "packets", "replicated"],
                     help="N > 1: all-to-all-v of packets (reference formulation), all-gather of x + pull, or (auto) both")
+    ap.add_argument("--distributed-extras", action="store_true",
+                    help="with --force-distributed: also run the projected-chain extras through the N > 1 code path (one rank)")
     ap.add_argument("--force-distributed", action="store_true",
                     help="run the N > 1 code path (process group, exchange) even with one rank (test hook)")
     ap.add_argument("--cpu-sample", type=int, default=0,
@@ -712,7 +714,7 @@ def main():
     # request-rate view of it; an HBM-byte fraction means nothing there), on N > 1 GPUs the replicated-x exchange (slot
     # resolution overlapped with the all-gather of x) next to what the model of DESIGN.md section 4 predicts.  The headline
     # `value` / `config` stay those of --model.
-    if args.model == "heisenberg_chain_32" and not args.no_extra and args.dtype == "f64" and not args.force_distributed:
+    if args.model == "heisenberg_chain_32" and not args.no_extra and args.dtype == "f64" and (not args.force_distributed or args.distributed_extras):
         try:
             del plan, op_obj
         except NameError:
@@ -721,7 +723,7 @@ def main():
         torch.cuda.empty_cache()
         for name in ("heisenberg_chain_36_symm", "heisenberg_chain_40_symm"):
             try:
-                extra[name] = projected_extra(D, torch, dist, name, rank, world, time_steps, allsum)
+                extra[name] = projected_extra(D, torch, dist, name, rank, world, time_steps, allsum, distributed=distributed)
             except Exception as e:  # reported, never hidden
                 import traceback
 
@@ -732,7 +734,7 @@ def main():
             torch.cuda.empty_cache()
         if world > 1:
             extra["model_heisenberg_chain_32"] = scaling_model("heisenberg_chain_32", world)
-        else:
+        elif not distributed:
             for name in ("heisenberg_chain_36_symm", "heisenberg_chain_40_symm"):
                 try:
                     extra["eigensolve_" + name] = eigensolve_extra(D, torch, name)
