@@ -203,7 +203,38 @@ def eigensolve_extra(D, torch, name, max_basis=12, eps=1e-7):
     return out
 
 
-def projected_extra(D, torch, dist, name, rank, world, time_steps, allsum, steps=3, warmup=2, distributed=False):
+def verify_operator(op, x, y, ref, allsum, allmax, inject_fault=False):
+    """the `parity` object of one exchange strategy (distributed-matvec_amd/verify.py): a fresh matvec of the N-rank operator on
+    the benchmark vector against this rank's rows of the one-partition kernel, element by element, plus all-reduced invariants.
+    inject_fault (test hook): misplace one segment of the exchange first -- the object must then say ok = false."""
+    from distributed_matvec_amd import verify
+
+    x_ref, y_ref, ymax, ref_kernel = ref
+    injected = None
+    if inject_fault:
+        injected = allsum(1.0 if op.inject_fault() else 0.0)
+    y.zero_()
+    op.matvec(x, y, check=False)
+    halted = None
+    try:  # the device error flag (a misplaced state outside the basis halts, DMV:115-118) is local: every rank still takes part
+        op.engine.check()  # in the reductions below, and all of them learn about it
+    except Exception as e:
+        halted = str(e)[:300]
+    n_halted = allsum(1.0 if halted else 0.0)
+    out = verify.parity_object(y, x, y_ref, ymax, allsum=allsum, allmax=allmax, reference_kernel=ref_kernel)
+    out["x_equals_reference_x"] = bool(allsum(0.0 if bool((x == x_ref).all()) else 1.0) == 0)
+    out["ok"] = bool(out["ok"] and out["x_equals_reference_x"] and n_halted == 0)
+    if n_halted:
+        out["halted_on_ranks"] = int(n_halted)
+        if halted:
+            out["halt"] = halted
+    if injected is not None:
+        out["fault_injected_on_ranks"] = int(injected)
+    return out
+
+
+def projected_extra(D, torch, dist, name, rank, world, time_steps, allsum, steps=3, warmup=2, distributed=False, allmax=None,
+                    inject_fault=False):
     """one of the symmetry-projected BASELINE chains, measured inside the default run (see main)"""
     from distributed_matvec_amd import config
 
@@ -245,11 +276,18 @@ def projected_extra(D, torch, dist, name, rank, world, time_steps, allsum, steps
     my = parts[rank].clone()
     reps_global = D.arrFromHashedToBlock(parts, masks)
     del parts
+    from distributed_matvec_amd import verify
+
     comm = D.Communicator.from_torch()
     x = D.fillRandom(my, 42, torch.float64)
     y = torch.zeros_like(x)
-    op = RcclReplicatedOperator(h, reps_global, masks, torch.float64, comm=comm)
     out["setup_seconds"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    ref = verify.reference_block(h, reps_global, masks, rank, torch.float64)  # this rank's rows of the one-partition kernel
+    out["reference_seconds"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    op = RcclReplicatedOperator(h, reps_global, masks, torch.float64, comm=comm)
+    out["setup_seconds"] += time.perf_counter() - t0
     plan = op.engine.plan
     plan.enable_stage_timing(4096)
     for _ in range(warmup):
@@ -264,8 +302,13 @@ def projected_extra(D, torch, dist, name, rank, world, time_steps, allsum, steps
                 "x_bytes_in_this_rank": op.x_bytes_in,
                 "rank0_stage_ms_per_matvec": {k: v[0] / max(1, mv) for k, v in stages.items()},
                 "model": scaling_model(name, world)})
+    out["parity"] = verify_operator(op, x, y, ref, allsum, allmax)
     out["slot_cache"] = slot_cache_leg(plan, lambda: op.matvec(x, y, check=False), plan.check, plan.kernel_times_ms, time_steps, steps,
                                        allsum=allsum, world=world)
+    if out["slot_cache"].get("rows"):  # the cached streams serve the same matvec: verified the same way
+        out["slot_cache"]["parity"] = verify_operator(op, x, y, ref, allsum, allmax)
+    if inject_fault:
+        out["parity_after_fault"] = verify_operator(op, x, y, ref, allsum, allmax, inject_fault=True)
     op.rm.destroy()
     return out
 
@@ -449,6 +492,9 @@ def main():
                     help="with --force-distributed: also run the projected-chain extras through the N > 1 code path (one rank)")
     ap.add_argument("--force-distributed", action="store_true",
                     help="run the N > 1 code path (process group, exchange) even with one rank (test hook)")
+    ap.add_argument("--inject-fault", action="store_true",
+                    help="test hook, N > 1 code path: after the timed steps misplace one segment of every exchange strategy's layout "
+                         "(ls_amd_test_corrupt_*); the parity check must catch it and the run must exit non-zero")
     ap.add_argument("--cpu-sample", type=int, default=0,
                     help="chain length of the CPU-baseline sample (0 = the workload itself when the host has >= 64 cores and "
                          "the memory for it, else 28)")
@@ -543,6 +589,13 @@ def main():
         dist.all_reduce(t)
         return float(t.item())
 
+    def allmax(v):
+        if dist is None:
+            return v
+        t = torch.tensor([float(v)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
     nnz = chain_nnz(L, n_total) if not symm else None
     extra = {}
 
@@ -592,7 +645,19 @@ def main():
         #   replicated  Hermitian operators: exchange x itself (N w bytes instead of nnz (8 + w)) and pull locally
         #               (ls_amd_repl_matvec: grouped ncclSend/ncclRecv of the blocks + permutation + pull + all-to-all-v of y)
         # A failure of either is an error of the run, never a footnote.
+        from distributed_matvec_amd import verify
+
         comm = D.Communicator.from_torch()
+        # Evidence of the transport and of the result: the communicator size as RCCL reports it, the ranks an
+        # all-reduce through it counts, and -- per strategy, below -- y against the one-partition kernel on the same vector.
+        one = torch.ones(1, dtype=torch.float64, device="cuda")
+        comm.allreduce_sum(one)
+        torch.cuda.synchronize()
+        rccl_info = {"comm_count": comm.rccl_count(), "ranks_by_allreduce": int(round(float(one.item()))), "world_size": world,
+                     "transport": "rccl (ncclSend/ncclRecv inside the C host)" if comm.rccl_count() > 0 else "loop-back"}
+        t_ref = time.perf_counter()
+        reference = verify.reference_block(h, reps_global, masks, rank, tdtype)
+        rccl_info["reference_seconds"] = time.perf_counter() - t_ref
         makers = {"packets": lambda: RcclDistributedOperator(h, my_reps, tdtype, comm=comm)}
         if h.isHermitian:
             makers["replicated"] = lambda: RcclReplicatedOperator(h, reps_global, masks, tdtype, comm=comm)
@@ -620,11 +685,15 @@ def main():
             results[name] = r
             exchanges[name] = {"matvecs_per_s": args.steps / r[0], "ms_per_step": 1e3 * r[0] / args.steps, "kernel": r[3],
                                "kernel_ms_avg": r[1], "launches_per_step": r[2], "exchange_bytes_per_matvec": r[4]}
+            exchanges[name]["parity"] = verify_operator(r[6], x, y, reference, allsum, allmax)
+            if args.inject_fault:
+                exchanges[name]["parity_after_fault"] = verify_operator(r[6], x, y, reference, allsum, allmax, inject_fault=True)
             if name in x_in_info:
                 exchanges[name]["x_bytes_in"] = x_in_info[name]
             if len(wanted) > 1:  # keep only the numbers; the plans of the other strategy would pin HBM
                 results[name] = r[:5] + (None, None)
                 del r
+        del reference
         if not results:
             raise SystemExit(f"every exchange strategy failed: {failed}")
         # `value` is the faster strategy, named in config.exchange; the times are max-over-ranks (all-reduced in
@@ -723,7 +792,8 @@ def main():
         torch.cuda.empty_cache()
         for name in ("heisenberg_chain_36_symm", "heisenberg_chain_40_symm"):
             try:
-                extra[name] = projected_extra(D, torch, dist, name, rank, world, time_steps, allsum, distributed=distributed)
+                extra[name] = projected_extra(D, torch, dist, name, rank, world, time_steps, allsum, distributed=distributed,
+                                              allmax=allmax, inject_fault=args.inject_fault)
             except Exception as e:  # reported, never hidden
                 import traceback
 
@@ -761,6 +831,28 @@ def main():
             "sample_seconds_per_matvec": s["seconds_per_matvec"],
         }
 
+    # every `parity` object of the run (exchange strategies of --model, the projected extras and their cached legs): one
+    # verdict, and a non-zero exit code when any of them failed (or, with --inject-fault, when a corrupted layout went unnoticed)
+    checks = {f"exchanges.{k}": v["parity"] for k, v in exchanges.items() if isinstance(v, dict) and "parity" in v}
+    faults = {f"exchanges.{k}": v["parity_after_fault"] for k, v in exchanges.items() if isinstance(v, dict) and "parity_after_fault" in v}
+    for k, v in extra.items():
+        if isinstance(v, dict):
+            if "parity" in v:
+                checks[f"extra.{k}"] = v["parity"]
+            if isinstance(v.get("slot_cache"), dict) and "parity" in v["slot_cache"]:
+                checks[f"extra.{k}.slot_cache"] = v["slot_cache"]["parity"]
+            if "parity_after_fault" in v:
+                faults[f"extra.{k}"] = v["parity_after_fault"]
+    parity_failed = sorted(k for k, v in checks.items() if not v.get("ok"))
+    fault_missed = sorted(k for k, v in faults.items() if v.get("ok") and v.get("fault_injected_on_ranks", 0) > 0)
+    parity_summary = None
+    if distributed:
+        parity_summary = {"checked": sorted(checks), "failed": parity_failed,
+                          "max_rel_err": max([v.get("max_rel_err", float("inf")) for v in checks.values()] or [None]),
+                          "ok": not parity_failed and bool(checks)}
+        if args.inject_fault:
+            parity_summary["fault_injection"] = {"detected": sorted(k for k, v in faults.items() if not v.get("ok")), "missed": fault_missed,
+                                                 "nothing_to_corrupt": sorted(k for k, v in faults.items() if v.get("fault_injected_on_ranks", 0) == 0)}
     if rank == 0:
         out = {
             "metric": "matvecs/sec", "value": value, "unit": "matvecs/s", "n_gpus": world, "steps": args.steps,
@@ -779,6 +871,8 @@ def main():
             "value_is": (f"best of {len(exchanges)} exchange strategies ({exchange})" if distributed and len(exchanges) > 1
                          else "the single configuration measured"),
             "failed_exchanges": sorted(failed) if distributed else [],
+            "rccl": rccl_info if distributed else None,
+            "parity": parity_summary,
             "roofline": roofline,
             "cpu_baseline": cpu,
             "setup_seconds": setup_s,
@@ -794,6 +888,10 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if distributed and (parity_failed or not checks or (args.inject_fault and (fault_missed or any(not v.get("ok") for v in faults.values())))):
+        # wrong y on some rank (or a deliberately corrupted exchange, which must end the same way): the number above is not a result
+        print(f"bench.py: PARITY FAILURE: {parity_failed or 'injected fault'}", file=sys.stderr, flush=True)
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -514,6 +514,10 @@ class Communicator:
             dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
         return Communicator(size, rank, box[0])
 
+    def rccl_count(self) -> int:
+        """the communicator size as RCCL reports it (ncclCommCount); 0 for a loop-back group"""
+        return int(_lib.load().ls_amd_comm_rccl_count(self.h))
+
     def set_default(self):
         """the communicator of primmeGlobalSumReal / primmeBroadcastReal / ls_chpl_primme_matvec"""
         _lib.load().ls_amd_set_default_comm(self.h)
@@ -576,6 +580,10 @@ class DistMatvec:
         if check:
             self.plan.check()
 
+    def inject_fault(self) -> bool:
+        """test hook (ls_amd_test_corrupt_dist): misplace one received segment; False when this rank receives none"""
+        return bool(_lib.load().ls_amd_test_corrupt_dist(self.h))
+
     def destroy(self):
         if getattr(self, "h", None):
             self.plan.destroy()
@@ -614,6 +622,10 @@ class ReplMatvec:
         _lib.check(_lib.load().ls_amd_repl_matvec(self.h, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), _stream_ptr()))
         if check:
             self.plan.check()
+
+    def inject_fault(self) -> bool:
+        """test hook (ls_amd_test_corrupt_repl): this rank's own rows come back one element late"""
+        return bool(_lib.load().ls_amd_test_corrupt_repl(self.h))
 
     def destroy(self):
         if getattr(self, "h", None):

@@ -29,6 +29,7 @@ struct Api {
     ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -58,7 +59,8 @@ int load_api() {
         return -1;
     }
     bool ok = sym(g_api.GetUniqueId, "ncclGetUniqueId") && sym(g_api.CommInitRank, "ncclCommInitRank") &&
-              sym(g_api.CommDestroy, "ncclCommDestroy") && sym(g_api.GroupStart, "ncclGroupStart") &&
+              sym(g_api.CommDestroy, "ncclCommDestroy") && sym(g_api.CommCount, "ncclCommCount") &&
+              sym(g_api.GroupStart, "ncclGroupStart") &&
               sym(g_api.GroupEnd, "ncclGroupEnd") && sym(g_api.Send, "ncclSend") && sym(g_api.Recv, "ncclRecv") &&
               sym(g_api.AllReduce, "ncclAllReduce") && sym(g_api.Broadcast, "ncclBroadcast") &&
               sym(g_api.AllGather, "ncclAllGather") && sym(g_api.GetErrorString, "ncclGetErrorString");
@@ -205,6 +207,13 @@ extern "C" void lsk_comm_destroy(lsk_comm *c) {
 }
 extern "C" int lsk_comm_size(lsk_comm const *c) { return c->size; }
 extern "C" int lsk_comm_rank(lsk_comm const *c) { return c->rank; }
+// the communicator size as RCCL itself reports it (ncclCommCount); 0 for a loop-back group, -1 on error
+extern "C" int lsk_comm_rccl_count(lsk_comm const *c) {
+    if (c->local) return 0;
+    int n = -1;
+    if (!g_api.CommCount || g_api.CommCount(c->comm, &n) != ncclSuccess) return -1;
+    return n;
+}
 
 // in-place reductions / broadcast / gather on `stream` (device buffers)
 extern "C" int lsk_comm_allreduce(lsk_comm *c, void *d_buf, int64_t count, int dtype /* 0 f64, 1 f32, 2 i64 */,

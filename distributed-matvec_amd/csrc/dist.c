@@ -99,6 +99,7 @@ void ls_amd_comm_destroy(ls_amd_comm *cm) {
 }
 int ls_amd_comm_size(ls_amd_comm const *cm) { return lsk_comm_size(cm->c); }
 int ls_amd_comm_rank(ls_amd_comm const *cm) { return lsk_comm_rank(cm->c); }
+int ls_amd_comm_rccl_count(ls_amd_comm const *cm) { return lsk_comm_rccl_count(cm->c); }
 int ls_amd_comm_allreduce_sum_f64(ls_amd_comm *cm, double *d_buf, int64_t count, void *stream) {
     COMM(lsk_comm_allreduce(cm->c, d_buf, count, 0, 0, stream));
     return 0;
@@ -295,6 +296,18 @@ int ls_amd_dist_create(ls_amd_dist **out, ls_amd_comm *cm, ls_hs_operator const 
 ls_amd_plan *ls_amd_dist_plan(ls_amd_dist *d) { return d->plan; }
 int64_t ls_amd_dist_exchange_bytes(ls_amd_dist const *d) { return d->exchange_bytes; }
 int ls_amd_dist_num_rounds(ls_amd_dist const *d) { return d->rounds; }
+
+/* test hook (ls_amd.h): the first non-empty remote segment this rank receives loses its first packet's state and its last
+ * packet's value -- the segment is read one state further on, one packet shorter: (beta_{k+1}, value_k) pairs */
+int ls_amd_test_corrupt_dist(ls_amd_dist *d) {
+    for (size_t k = 0; k < (size_t)d->rounds * (size_t)d->P; ++k) {
+        if ((int)(k % (size_t)d->P) == d->me || d->recv_counts[k] < 2) continue;
+        d->recv_off[k] += 8;
+        d->recv_counts[k] -= 1;
+        return 1;
+    }
+    return 0;
+}
 
 static int exchange(ls_amd_dist *d, int r, void *stream) {
     size_t const k = (size_t)r * d->P;
@@ -639,6 +652,14 @@ int ls_amd_repl_create(ls_amd_repl **out, ls_amd_comm *cm, ls_hs_operator const 
     if (agree(cm, rc, stream) != 0) { ls_amd_repl_destroy(r); return -1; } /* buffers and plan exist on every rank, or the object on none */
     *out = r;
     return 0;
+}
+
+/* test hook (ls_amd.h): this rank's own rows come back one element late -- y_local[k] <- row k + 1 of its own piece */
+int ls_amd_test_corrupt_repl(ls_amd_repl *r) {
+    if (r->y_self_bytes < 2 * r->w) return 0;
+    r->ys_off[r->me] += r->w;
+    r->y_self_bytes -= r->w;
+    return 1;
 }
 
 ls_amd_plan *ls_amd_repl_plan(ls_amd_repl *r) { return r->plan; }

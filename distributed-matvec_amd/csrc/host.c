@@ -45,6 +45,8 @@ int ls_amd_internal_error(char const *fmt, ...) {
     return -1;
 }
 #define DEV(expr) do { if ((expr) != 0) return dev_error(); } while (0)
+/* a constructor that succeeded leaves no message behind (a failed attempt before it must not read as this call's error) */
+void ls_amd_internal_clear_error(void) { g_last_error[0] = 0; }
 
 char const *ls_amd_last_error(void) { return g_last_error; }
 void ls_amd_set_error_handler(ls_amd_error_handler handler) { g_handler = handler; }

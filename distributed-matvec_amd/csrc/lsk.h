@@ -377,6 +377,7 @@ int lsk_comm_create_local(lsk_comm **out /* [size] */, int size); /* loop-back g
 void lsk_comm_destroy(lsk_comm *c);
 int lsk_comm_size(lsk_comm const *c);
 int lsk_comm_rank(lsk_comm const *c);
+int lsk_comm_rccl_count(lsk_comm const *c); /* ncclCommCount; 0 = loop-back group, -1 = error */
 int lsk_comm_allreduce(lsk_comm *c, void *d_buf, int64_t count, int dtype /* 0 f64, 1 f32, 2 i64 */, int op /* 0 sum, 1 max */,
                        void *stream);
 int lsk_comm_broadcast(lsk_comm *c, void *d_buf, int64_t bytes, int root, void *stream);

@@ -92,10 +92,14 @@ __global__ __launch_bounds__(kOrthBlock) void k_orth_pass(int m, int64_t n, doub
 }
 
 extern "C" int ls_amd_orth_max_rows(void) { return kOrthMaxRows; }
+extern "C" int ls_amd_internal_error(char const *fmt, ...); // host.c: formats into ls_amd_last_error(), returns -1
+
 extern "C" int ls_amd_orth_pass(int m, int64_t n, double const *d_V, int64_t ldv, double *d_w, double const *d_h_in, double *d_out, void *stream) {
-    if (m < 0 || m > kOrthMaxRows || n < 0 || ldv < n) return -1;
+    if (m < 0 || m > kOrthMaxRows || n < 0 || ldv < n)
+        return ls_amd_internal_error("ls_amd_orth_pass: bad arguments (m = %d of at most %d rows, n = %lld, ldv = %lld)", m, kOrthMaxRows, (long long)n, (long long)ldv);
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(d_out, 0, sizeof(double) * (size_t)(m + 1), s) != hipSuccess) return -1;
+    hipError_t e = hipMemsetAsync(d_out, 0, sizeof(double) * (size_t)(m + 1), s);
+    if (e != hipSuccess) return ls_amd_internal_error("ls_amd_orth_pass: hipMemsetAsync: %s", hipGetErrorString(e));
     if (n == 0) return 0;
     int64_t blocks = ((n >> 1) + kOrthBlock - 1) / kOrthBlock;
     if (blocks < 1) blocks = 1;
@@ -103,7 +107,8 @@ extern "C" int ls_amd_orth_pass(int m, int64_t n, double const *d_V, int64_t ldv
     const bool aligned = ((uintptr_t)d_V % 16 == 0) && ((uintptr_t)d_w % 16 == 0) && (ldv % 2 == 0);
     if (aligned) hipLaunchKernelGGL(k_orth_pass<true>, dim3((unsigned)blocks), dim3(kOrthBlock), 0, s, m, n, d_V, ldv, d_w, d_h_in, d_out);
     else hipLaunchKernelGGL(k_orth_pass<false>, dim3((unsigned)blocks), dim3(kOrthBlock), 0, s, m, n, d_V, ldv, d_w, d_h_in, d_out);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    e = hipGetLastError();
+    return e == hipSuccess ? 0 : ls_amd_internal_error("ls_amd_orth_pass: launch (m = %d, n = %lld, ldv = %lld): %s", m, (long long)n, (long long)ldv, hipGetErrorString(e));
 }
 
 // Thick restart: V[:m_out] <- S^T V[:m_in] in place (S: m_in x m_out, row-major, device), column by column -- a thread holds the
@@ -129,11 +134,14 @@ __global__ __launch_bounds__(kOrthBlock) void k_basis_rotate(int m_in, int m_out
     }
 }
 extern "C" int ls_amd_basis_rotate(int m_in, int m_out, int64_t n, double *d_V, int64_t ldv, double const *d_S, void *stream) {
-    if (m_in < 1 || m_in > kOrthMaxRows || m_out < 1 || m_out > m_in || n < 0 || ldv < n) return -1;
+    // (m_out <= m_in <= kOrthMaxRows also bounds the m_in x m_out coefficients by the kernel's LDS copy, s_S)
+    if (m_in < 1 || m_in > kOrthMaxRows || m_out < 1 || m_out > m_in || m_in * m_out > kOrthMaxRows * kOrthMaxRows || n < 0 || ldv < n)
+        return ls_amd_internal_error("ls_amd_basis_rotate: bad arguments (m_in = %d, m_out = %d, at most %d rows, n = %lld, ldv = %lld)", m_in, m_out, kOrthMaxRows, (long long)n, (long long)ldv);
     if (n == 0) return 0;
     int64_t blocks = (n + kOrthBlock - 1) / kOrthBlock;
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(k_basis_rotate, dim3((unsigned)blocks), dim3(kOrthBlock), 0, (hipStream_t)stream, m_in, m_out, n, d_V, ldv, d_S);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : ls_amd_internal_error("ls_amd_basis_rotate: launch (m_in = %d, m_out = %d, n = %lld): %s", m_in, m_out, (long long)n, hipGetErrorString(e));
 }
 

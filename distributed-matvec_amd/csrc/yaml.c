@@ -28,6 +28,7 @@
 #include "../../include/ls_hs.h"
 
 int ls_amd_internal_error(char const *fmt, ...); /* host.c: formats into ls_amd_last_error(), returns -1 */
+void ls_amd_internal_clear_error(void);
 
 /* ------------------------------------------------------------------------------------------------ */
 /* a small document tree                                                                            */
@@ -667,6 +668,7 @@ ls_hs_yaml_config *ls_amd_load_yaml_config_from_string(char const *text) {
     }
     y_free(doc);
     if (!ok) { ls_hs_destroy_yaml_config(conf); return NULL; }
+    ls_amd_internal_clear_error(); /* success: no stale message of an earlier failed load */
     return conf;
 }
 

@@ -273,6 +273,9 @@ class RcclDistributedOperator:
     def matvec(self, x, y, check: bool = False):
         self.dm.matvec(x, y, check=check)
 
+    def inject_fault(self) -> bool:
+        return self.dm.inject_fault()
+
     def global_sum(self, t):
         """globalSumReal (PRIMME.chpl:267-322) on a device tensor, in place"""
         import torch
@@ -310,6 +313,9 @@ class RcclReplicatedOperator:
 
     def matvec(self, x, y, check: bool = False):
         self.rm.matvec(x, y, check=check)
+
+    def inject_fault(self) -> bool:
+        return self.rm.inject_fault()
 
     global_sum = RcclDistributedOperator.global_sum
     broadcast = RcclDistributedOperator.broadcast

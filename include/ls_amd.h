@@ -58,17 +58,20 @@ int ls_amd_stream_copy(void *d_dst, void const *d_src, int64_t bytes, void *stre
 /* the read-only counterpart: every thread reads `per_thread` 16-byte elements and keeps an xor of them (d_sink: 4 bytes of device
  * memory, practically never written): the attainable READ rate of the box, the line the pull kernels' traffic (> 90 % reads)
  * is held against */
+int ls_amd_stream_read(void const *d_src, int64_t bytes, int per_thread, void *d_sink, void *stream);
+
 /* Eigensolver callers (Diagonalize.chpl:174-225 hands H to PRIMME; its Lanczos / Davidson steps orthogonalise one vector against
  * a block of basis vectors).  One sweep over the block V (m <= ls_amd_orth_max_rows() rows of n f64, row stride ldv) and w:
  *     if d_h_in:  w <- w - sum_k h_in[k] V[k];    out[k] = <V[k], w> (k < m, over the updated w);    out[m] = <w, w>
  * d_out: device [m + 1].  Pass 1 (h_in NULL) -> coefficients and norm; pass 2 (h_in = them) applies them and returns the remaining
  * overlaps in the same sweep, so classical Gram-Schmidt "twice" reads V two times instead of four when they are at rounding
- * level. */
+ * level.
+ * Requirements (not validated beyond the sizes): V and w are f64, each row of V and w contiguous, w does not alias any row of
+ * V, d_out / d_h_in do not alias V or w.  Failures return -1 with a message in ls_amd_last_error(). */
 int ls_amd_orth_max_rows(void);
 int ls_amd_orth_pass(int m, int64_t n, double const *d_V, int64_t ldv, double *d_w, double const *d_h_in, double *d_out, void *stream);
 /* thick restart of such a solver: V[:m_out] <- S^T V[:m_in] in place (d_S: m_in x m_out, row-major; m_out <= m_in <= max rows) */
 int ls_amd_basis_rotate(int m_in, int m_out, int64_t n, double *d_V, int64_t ldv, double const *d_S, void *stream);
-int ls_amd_stream_read(void const *d_src, int64_t bytes, int per_thread, void *d_sink, void *stream);
 
 /* hash64_01 / localeIdxOf on the host (StatesEnumeration.chpl:122-136) */
 uint64_t ls_amd_hash64_01(uint64_t x);
@@ -117,6 +120,9 @@ void ls_amd_comm_destroy(ls_amd_comm *comm);
 int ls_amd_comm_create_local(ls_amd_comm **comms /* [size] */, int size);
 int ls_amd_comm_size(ls_amd_comm const *comm);
 int ls_amd_comm_rank(ls_amd_comm const *comm);
+/* the communicator size as RCCL itself reports it (ncclCommCount): what `bench.py --gpus N` prints as `rccl.comm_count` so that
+ * a multi-GPU number carries evidence of the transport it ran on; 0 = loop-back group (test transport), -1 = error */
+int ls_amd_comm_rccl_count(ls_amd_comm const *comm);
 /* in-place collectives on device buffers (ordered on `stream`) */
 int ls_amd_comm_allreduce_sum_f64(ls_amd_comm *comm, double *d_buf, int64_t count, void *stream);
 int ls_amd_comm_allreduce_max_i64(ls_amd_comm *comm, int64_t *d_buf, int64_t count, void *stream);
@@ -162,6 +168,12 @@ int64_t ls_amd_repl_exchange_bytes(ls_amd_repl const *repl);
  * owner's elements are ascending in global rank, so each interval is one contiguous piece of every owner's block and is sent
  * as it lies (chain_32 at 8 ranks: 44 % of the vector; LS_AMD_REPL_REACH=0: the whole vector). */
 int64_t ls_amd_repl_x_in_bytes(ls_amd_repl const *repl);
+/* Fault injection (test hooks of the self-verification of `bench.py --gpus N`, tests/test_gpu_loopback.py): shift ONE segment
+ * offset of the exchange layout by one element, memory-safely (the segment shrinks by the same element), so that the exchange
+ * still completes but delivers misplaced data.  Return 1 when a segment was corrupted, 0 when the layout has none to corrupt
+ * (e.g. a packet plan with a single rank: nothing leaves the GPU). */
+int ls_amd_test_corrupt_dist(ls_amd_dist *dist);
+int ls_amd_test_corrupt_repl(ls_amd_repl *repl);
 
 /* ------------------------------------------------------------------------------------------
  * Plans.  A plan binds an operator to the partition layout and owns every per-basis device table:

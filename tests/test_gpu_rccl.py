@@ -259,3 +259,42 @@ def test_repl_matvec_multi_gpu_rccl(tmp_path, name, world, cplx):
     got = CO.hashed_to_block(load("y"), keys)
     want = oracle_for(name).local_matvec(reps, x)
     assert np.abs(got - want).max() <= 1e-12 * max(1.0, np.abs(want).max())
+
+
+def _run_bench(*extra):
+    import json
+    import subprocess
+
+    env = dict(os.environ, MASTER_PORT=str(29600 + os.getpid() % 300))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-distributed", "--model", "heisenberg_chain_24",
+                        "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extra", *extra],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert lines, p.stderr[-2000:]
+    return p.returncode, json.loads(lines[-1]), p.stderr
+
+
+def test_bench_distributed_path_is_self_verifying():
+    """`bench.py --gpus N` (here: the same code path with one RCCL rank) reports the communicator size as RCCL gives it and, for
+    EVERY exchange strategy, y against the one-partition kernel; a deliberately misplaced segment makes the run fail.  The
+    driver's multi-GPU run is the only place RCCL's transport runs with > 1 rank: its number must carry this evidence."""
+    rc, out, err = _run_bench()
+    assert rc == 0, err[-2000:]
+    assert out["rccl"]["comm_count"] == 1 and out["rccl"]["ranks_by_allreduce"] == 1 and out["rccl"]["world_size"] == 1
+    assert set(out["exchanges"]) == {"packets", "replicated"} and not out["failed_exchanges"]
+    for name, ex in out["exchanges"].items():
+        par = ex["parity"]
+        assert par["ok"] and par["max_rel_err"] <= 1e-12 and par["rows_off"] == 0, (name, par)
+        for inv in par["invariants"].values():
+            assert inv["rel_err"] <= 1e-12
+    assert out["parity"]["ok"] and out["parity"]["failed"] == [] and len(out["parity"]["checked"]) == 2
+    # one rank: the packet plan has no remote segment to corrupt, the replicated-x layout has (the own rows of y)
+    rc, out, err = _run_bench("--inject-fault")
+    assert rc != 0
+    assert "PARITY FAILURE" in err
+    assert not out["exchanges"]["replicated"]["parity_after_fault"]["ok"]
+    assert "exchanges.replicated" in out["parity"]["fault_injection"]["detected"]
+    assert out["parity"]["fault_injection"]["missed"] == []
+    assert out["exchanges"]["replicated"]["parity"]["ok"]  # the check before the fault was clean
