@@ -145,6 +145,13 @@ class COracle:
         return out
 
     # -- matvecs --------------------------------------------------------------------------
+    @staticmethod
+    def prepare_index(reps):
+        """build the look-up table of `reps` (a C-contiguous uint64 array that is then passed to local_matvec AS IS) ahead of a
+        timed call"""
+        assert reps.dtype == np.uint64 and reps.flags.c_contiguous
+        lib().lso_prepare_index(_p(reps, _u64p), C.c_int64(len(reps)))
+
     def local_matvec(self, reps, x, y=None, num_threads: int = 0):
         reps = np.ascontiguousarray(reps, dtype=np.uint64)
         n = len(reps)

@@ -353,6 +353,9 @@ static inline int64_t indexed_search(const uint64_t *reps, int64_t count, uint64
     }
     return (lo < end && reps[lo] == s) ? lo : -1;
 }
+/* the bucket table of `reps` built ahead of a timed matvec (bench.py's cpu_baseline: the table belongs to the basis, as
+ * ls_hs_basis_build leaves the reference's index structures behind before any matvec is timed) */
+void lso_prepare_index(const uint64_t *reps, int64_t count) { ensure_index(reps, count); }
 void lso_state_index(const uint64_t *reps, int64_t count, int64_t n, const uint64_t *spins,
                      int64_t *indices) {
     for (int64_t i = 0; i < n; ++i) indices[i] = binary_search(reps, count, spins[i]);
