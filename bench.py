@@ -178,6 +178,73 @@ def slot_cache_leg(plan, run, check, kernel_times, time_steps, steps, allsum=Non
             "kernel_ms_avg": sum(ks) / max(1, len(ks)), "matrix_free": False}
 
 
+def boundary_extra(D, torch, h, basis, reps, y_device, x_device, calls=2):
+    """The drop-in entry itself -- `ls_chpl_matrix_vector_product(matrix, 1, double *x, double *y)` (DMV:1095-1110), what Diagonalize /
+    PRIMME call -- timed on the benchmark workload with the caller's vectors in every kind of memory (include/ls_amd.h, "The
+    host-pointer boundary"): pageable host memory (numpy; through the pinned bounce pipeline, and with LS_AMD_STAGE=0 through plain
+    hipMemcpy), registered host memory (ls_amd_host_register), device memory (zero copies).  Wall time per call after one untimed
+    call that builds and caches the plan; GB/s = bytes that crossed PCIe / wall time (kernel included).  Never the headline."""
+    import ctypes as C
+
+    import numpy as np
+
+    from distributed_matvec_amd import _lib
+
+    L = _lib.load()
+    n = int(reps.numel())
+    reps_h = reps.cpu().numpy().view(np.uint64)
+    basis.uncheckedSetRepresentatives(reps_h)  # ls_hs_unchecked_set_representatives: the built basis the reference's callers hold
+    x_h = x_device.cpu().numpy()
+    y_h = np.empty(n)
+    y_h.fill(0.0)
+    f64p = _lib.c_f64p
+    st = _lib.BoundaryStats()
+
+    def call(xp, yp):
+        L.ls_chpl_matrix_vector_product(h.payload, 1, C.cast(xp, f64p), C.cast(yp, f64p))
+        _lib.raise_pending_halt()
+
+    def timed(xp, yp, label):
+        call(xp, yp)  # first call of a variant: plan cached, staging buffers / pool warm
+        L.ls_amd_boundary_stats_get(C.byref(st), 1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(calls):
+            call(xp, yp)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / calls
+        L.ls_amd_boundary_stats_get(C.byref(st), 1)
+        moved = (st.bytes_h2d + st.bytes_d2h) / calls
+        return {"ms_per_call": 1e3 * dt, "pcie_bytes_per_call": moved, "pcie_GBps": moved / dt / 1e9 if moved else None,
+                "x": ("device" if st.device_x else label), "y": ("device" if st.device_y else label)}
+
+    out = {"entry": "ls_chpl_matrix_vector_product (host-pointer ABI of the reference, DMV:1095-1110)", "n": n, "calls_timed": calls}
+    t0 = time.perf_counter()
+    call(x_h.ctypes.data, y_h.ctypes.data)  # uploads the representatives, builds and caches the plan
+    out["first_call_seconds"] = time.perf_counter() - t0
+    out["pageable_staged"] = timed(x_h.ctypes.data, y_h.ctypes.data, "pageable")
+    err = float((torch.from_numpy(y_h).cuda() - y_device).abs().max()) / max(float(y_device.abs().max()), 1e-300)
+    out["max_rel_err_vs_device_plan"] = err
+    os.environ["LS_AMD_STAGE"] = "0"
+    try:
+        out["pageable_plain_hipMemcpy"] = timed(x_h.ctypes.data, y_h.ctypes.data, "pageable")
+    finally:
+        del os.environ["LS_AMD_STAGE"]
+    for a in (x_h, y_h):
+        _lib.check(L.ls_amd_host_register(C.c_void_p(a.ctypes.data), a.nbytes))
+    try:
+        out["registered"] = timed(x_h.ctypes.data, y_h.ctypes.data, "pinned")
+    finally:
+        for a in (x_h, y_h):
+            L.ls_amd_host_unregister(C.c_void_p(a.ctypes.data))
+    y_d = torch.zeros_like(y_device)
+    out["device_pointers"] = timed(x_device.data_ptr(), y_d.data_ptr(), "device")
+    out["device_pointers"]["max_rel_err_vs_device_plan"] = float((y_d - y_device).abs().max()) / max(float(y_device.abs().max()), 1e-300)
+    out["staging_threads"] = int(os.environ.get("LS_AMD_STAGE_THREADS", 0)) or "min(8, cores / 4)"
+    basis.uncheckedSetRepresentatives(np.zeros(0, dtype=np.uint64))  # drops the cached plan, its staging buffers and the device copy
+    return out
+
+
 def eigensolve_extra(D, torch, name, max_basis=12, eps=1e-7):
     """the caller of the path (BASELINE config 5: Diagonalize): ground state of one of the projected chains with the device-resident
     thick-restart Lanczos of diagonalize.py -- enumeration, plan, the slot cache in whatever HBM the Krylov basis leaves, fused
@@ -830,6 +897,16 @@ def main():
     except RuntimeError:
         pass
 
+    if not distributed and not args.no_extra and not symm and args.dtype == "f64" and args.mode == "auto":
+        # the reference's own host-pointer entry on this workload, per kind of caller memory
+        try:
+            plan.matvec([x], [y], check=True)
+            extra["boundary_host_ptr"] = boundary_extra(D, torch, h, basis, my_reps, y, x)
+        except Exception as e:  # reported, never hidden
+            import traceback
+
+            traceback.print_exc()
+            extra["boundary_host_ptr"] = {"error": repr(e)[:400]}
     if not distributed and not args.no_extra and not symm:
         # secondary numbers in the same run: the other scatter/gather mode and the other dtype
         for label, mode2 in (("f64" if args.dtype == "c128" else "c128", args.mode),

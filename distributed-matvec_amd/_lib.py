@@ -68,6 +68,11 @@ class YamlConfig(C.Structure):  # ls_hs_yaml_config (include/ls_hs.h; /root/refe
                 ("observables", C.POINTER(C.POINTER(LsHsOperator)))]
 
 
+class BoundaryStats(C.Structure):  # struct ls_amd_boundary_stats (include/ls_amd.h)
+    _fields_ = [("calls", C.c_int64), ("columns", C.c_int64), ("bytes_h2d", C.c_int64), ("bytes_d2h", C.c_int64),
+                ("device_x", C.c_int64), ("device_y", C.c_int64)]
+
+
 class LsAmdError(RuntimeError):
     pass
 
@@ -111,6 +116,10 @@ def load():
         "ls_amd_orth_max_rows": (C.c_int, []),
         "ls_amd_orth_pass": (C.c_int, [C.c_int, C.c_int64, vp, C.c_int64, vp, vp, vp, vp]),
         "ls_amd_basis_rotate": (C.c_int, [C.c_int, C.c_int, C.c_int64, vp, C.c_int64, vp, vp]),
+        "ls_amd_pointer_kind": (C.c_int, [vp]),
+        "ls_amd_host_register": (C.c_int, [vp, C.c_size_t]),
+        "ls_amd_host_unregister": (C.c_int, [vp]),
+        "ls_amd_boundary_stats_get": (None, [C.POINTER(BoundaryStats), C.c_int]),
         "ls_amd_hash64_01": (C.c_uint64, [C.c_uint64]),
         "ls_amd_locale_idx_of": (C.c_int, [C.c_uint64, C.c_int]),
         "ls_amd_plan_create": (C.c_int, [C.POINTER(vp), op, C.c_int, C.c_int, C.c_int, C.POINTER(vp), c_i64p, C.c_int, C.c_int, vp]),

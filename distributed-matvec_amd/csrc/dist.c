@@ -633,9 +633,16 @@ int ls_amd_repl_create(ls_amd_repl **out, ls_amd_comm *cm, ls_hs_operator const 
              * when they have arrived.  LS_AMD_PULL_SPLIT = bytes of packet buffer per rank (default 32 GB, i.e. every row of
              * chain_40_symm at P >= 2; rows that do not fit take the fused kernel after the exchange), 0 = off. */
             char const *e = getenv("LS_AMD_PULL_SPLIT");
-            int64_t const budget = e ? atoll(e) : (P > 1 ? (int64_t)32 << 30 : 0);
+            int64_t budget = e ? atoll(e) : (P > 1 ? (int64_t)32 << 30 : 0);
+            if (!e && budget > 0) { /* the default never takes more than a third of what is free now: the caller's Krylov basis comes later */
+                size_t fr = 0, tot = 0;
+                if (lsk_mem_info(&fr, &tot) == 0 && (int64_t)(fr / 3) < budget) budget = (int64_t)(fr / 3);
+            }
             if (budget > 0) (void)ls_amd_internal_plan_split_enable(r->plan, budget);
-            e = getenv("LS_AMD_SLOT_CACHE"); /* bytes per rank: keep the resolved streams across matvecs (ls_amd_plan_cache_slots) */
+            /* LS_AMD_SLOT_CACHE: ONE meaning in every layer -- bytes of resolved packet streams to keep across matvecs
+             * (ls_amd_plan_cache_slots); 0 = off; unset = nothing here, and the Python eigensolver drivers size it from what
+             * the Krylov basis leaves free (they skip that when the variable is set: no second cache, no second count) */
+            e = getenv("LS_AMD_SLOT_CACHE");
             if (e && atoll(e) > 0 && ls_amd_plan_cache_slots(r->plan, atoll(e)) < 0) rc = -1;
         }
     } else if (rc == 0)

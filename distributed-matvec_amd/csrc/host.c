@@ -264,6 +264,10 @@ struct ls_amd_basis_ext {
         void *plan;    /* ls_amd_plan* when comm == NULL */
         void *dist;    /* ls_amd_dist* otherwise */
         uint64_t stamp;
+        /* persistent device copies of the caller's host vectors (allocated on first use, kept with the plan; the second pair
+         * only for blocks of columns: the upload of column k + 1 overlaps kernel and download of column k) */
+        void *d_x[2], *d_y[2];
+        int64_t stage_n;
     } host_plans[4];
     uint64_t host_plan_clock;
     uint32_t *d_index_table; /* search table over d_reps_cache (ls_hs_state_index) */
@@ -510,6 +514,7 @@ ls_hs_basis *ls_hs_clone_basis(ls_hs_basis const *basis) {
 static void host_plan_slot_drop(struct host_plan_slot *sl) {
     if (sl->plan) ls_amd_plan_destroy((ls_amd_plan *)sl->plan);
     if (sl->dist) ls_amd_dist_destroy((ls_amd_dist *)sl->dist);
+    for (int i = 0; i < 2; ++i) { if (sl->d_x[i]) lsk_free(sl->d_x[i]); if (sl->d_y[i]) lsk_free(sl->d_y[i]); }
     memset(sl, 0, sizeof(*sl));
 }
 /* Forget the cached plans of one operator (op != NULL), of one communicator (comm != NULL), or all of them.  The slots are
@@ -1695,7 +1700,8 @@ static int64_t split_enable_exact(ls_amd_plan *pl, int64_t max_bytes) {
     int const nc = lsk_pullbuf_coef_doubles(pl->dop, pl->dbs);
     int64_t const per_packet = 4 + 1 + 8 * nc;
     void *offs = NULL;
-    if (lsk_malloc(&offs, 8 * (size_t)(streams_all + 1)) != 0) return 0;
+    /* (offsets and counts for WHOLE tiles of four streams: every wave of the last tile reads its offset and stores its count) */
+    if (lsk_malloc(&offs, 8 * (size_t)(((streams_all + 3) & ~(int64_t)3) + 1)) != 0) return 0;
     if (lsk_tile_pull_stream_offsets(pl->dop, pl->dbs, 0, ps->count, ps->d_reps, (int64_t *)offs, NULL) != 0) { lsk_free(offs); return -1; }
     int64_t streams = streams_all;
     for (;;) {
@@ -1717,7 +1723,7 @@ static int64_t split_enable_exact(ls_amd_plan *pl, int64_t max_bytes) {
         if (total >= ((int64_t)1 << 40)) { lsk_free(offs); return 0; }
         void *a = NULL, *b = NULL, *c = NULL, *d = NULL;
         if (lsk_malloc(&a, (size_t)(4 * total + 4)) == 0 && lsk_malloc(&b, (size_t)(total + 4)) == 0 &&
-            (nc == 0 || lsk_malloc(&c, (size_t)(8 * nc * total + 8)) == 0) && lsk_malloc(&d, (size_t)(4 * streams)) == 0) {
+            (nc == 0 || lsk_malloc(&c, (size_t)(8 * nc * total + 8)) == 0) && lsk_malloc(&d, (size_t)(4 * ((streams + 3) & ~(int64_t)3))) == 0) {
             pl->pbuf.slots = (uint32_t *)a; pl->pbuf.rows = (uint8_t *)b; pl->pbuf.coefs = (double *)c; pl->pbuf.counts = (uint32_t *)d;
             pl->pbuf.offs = (int64_t const *)offs;
             pl->pbuf.cap = lsk_pullbuf_cap(pl->dop);
@@ -2580,11 +2586,11 @@ int ls_amd_internal_repl_split_begin(ls_amd_plan *pl, void *stream) {
     ix.tab = pl->gtab->tab;
     ix.perm = pl->gtab->d_perm;
     ix.row_g0 = pl->row_g0;
-    pl->slot_cache_valid = pl->slot_cache;
     int const st = stage_begin(pl, ST_GENERATE, stream);
     int const slot = timing_begin(pl, stream);
     DEV(lsk_tile_pull_resolve(pl->dop, pl->dbs, 0, pl->split_rows, ps->d_reps, ps->d_norms, ix, pl->gindex.reps, pl->gindex.count,
                               pl->pull_halo, pl->pbuf, pl->d_err, stream));
+    pl->slot_cache_valid = pl->slot_cache; /* only once the resolve launch went through: a failed one leaves nothing to reuse */
     timing_end(pl, slot, stream);
     stage_end(pl, st, stream);
     return 0;
@@ -2935,12 +2941,65 @@ static int ensure_device_reps(ls_hs_basis *b) {
     return 0;
 }
 
-/* localMatrixVector on host vectors (numLocales == 1) */
-static int host_matvec_f64(ls_hs_operator *op, int64_t n, double const *x, double *y, ls_amd_comm *cm) {
+/* ---- the host-pointer boundary (DMV:1095-1110, Diagonalize.chpl:134-162) -------------------------------------------------
+ * The reference's callers hand over `double *`.  What that costs here is decided by where the memory lives (stage.cpp):
+ *   device memory (hipMalloc, torch)      used in place, zero copies
+ *   pinned / registered host memory       one DMA per direction (ls_amd_host_register: once per workspace, PRIMME reuses its)
+ *   pageable host memory                  double-buffered pinned bounce chunks, upload and download at the same time
+ * x and y have persistent device copies in the cached plan slot (no hipMalloc / hipFree per call); y is uploaded only when the
+ * operator has no diagonal terms (else it is assigned, DMV:1062-1063); the columns of a block go through one pipeline.
+ * LS_AMD_STAGE=0 restores plain synchronous hipMemcpy (A/B in bench.py's boundary_host_ptr). */
+static lsk_stager *g_stager = NULL;
+static pthread_mutex_t g_stager_lock = PTHREAD_MUTEX_INITIALIZER;
+static struct ls_amd_boundary_stats g_bstats;
+void ls_amd_boundary_stats_get(struct ls_amd_boundary_stats *out, int reset) {
+    *out = g_bstats;
+    if (reset) memset(&g_bstats, 0, sizeof(g_bstats));
+}
+int ls_amd_host_register(void *p, size_t bytes) {
+    if (lsk_host_register(p, bytes) != 0) return set_error("%s", lsk_stage_last_error());
+    return 0;
+}
+int ls_amd_host_unregister(void *p) {
+    if (lsk_host_unregister(p) != 0) return set_error("%s", lsk_stage_last_error());
+    return 0;
+}
+int ls_amd_pointer_kind(void const *p) { return lsk_pointer_kind(p); }
+static int staging_enabled(void) { char const *e = getenv("LS_AMD_STAGE"); return !(e && atoi(e) == 0); }
+static lsk_stager *stager(void) {
+    pthread_mutex_lock(&g_stager_lock);
+    char const *e = getenv("LS_AMD_STAGE_CHUNK_KB"), *t = getenv("LS_AMD_STAGE_THREADS");
+    size_t const chunk = (e && atoi(e) > 0 ? (size_t)atoi(e) : (size_t)32768) << 10;
+    if (g_stager && lsk_stager_chunk(g_stager) != (chunk < 4096 ? 4096 : chunk & ~(size_t)4095)) { lsk_stager_destroy(g_stager); g_stager = NULL; }
+    if (!g_stager && lsk_stager_create(&g_stager, chunk, t ? atoi(t) : 0) != 0) { g_stager = NULL; set_error("%s", lsk_stage_last_error()); }
+    pthread_mutex_unlock(&g_stager_lock);
+    return g_stager;
+}
+/* up: host -> device, down: device -> host, at the same time; kinds from lsk_pointer_kind (never LSK_PTR_DEVICE here) */
+static int transfer(void *d_up, void const *h_up, size_t up_bytes, int up_kind, void *h_down, void const *d_down, size_t down_bytes,
+                    int down_kind) {
+    if (!up_bytes && !down_bytes) return 0;
+    g_bstats.bytes_h2d += (int64_t)up_bytes;
+    g_bstats.bytes_d2h += (int64_t)down_bytes;
+    if (!staging_enabled()) {
+        if (up_bytes) DEV(lsk_h2d(d_up, h_up, up_bytes));
+        if (down_bytes) DEV(lsk_d2h(h_down, d_down, down_bytes));
+        return 0;
+    }
+    lsk_stager *st = stager();
+    if (!st) return -1;
+    if (lsk_stage_run(st, d_up, h_up, up_bytes, up_kind, h_down, d_down, down_bytes, down_kind) != 0) return set_error("%s", lsk_stage_last_error());
+    return 0;
+}
+
+/* localMatrixVector on `ncols` host (or device) vectors: column k at x + k ldx, y + k ldy */
+static int host_matvec_block(ls_hs_operator *op, int64_t n, int ncols, double const *x, int64_t ldx, double *y, int64_t ldy,
+                             ls_amd_comm *cm) {
     ls_hs_basis *b = op->basis;
     struct ls_amd_basis_ext *e = BEXT(b);
     if (ensure_device_reps(b) != 0) return -1;
     if ((uint64_t)n != e->d_reps_count) return set_error("vector length does not match the number of representatives");
+    if (ncols < 1) return 0;
     if (!cm) cm = ls_amd_default_comm();
     if (cm && ls_amd_comm_size(cm) <= 1) cm = NULL;
     /* the cached plan of THIS operator on THIS communicator (least recently used slot is recycled) */
@@ -2971,34 +3030,48 @@ static int host_matvec_f64(ls_hs_operator *op, int64_t n, double const *x, doubl
         sl = victim;
     }
     sl->stamp = ++e->host_plan_clock;
-    if (cm) {
-        ls_amd_dist *dd = (ls_amd_dist *)sl->dist;
-        void *dx, *dy;
-        DEV(lsk_malloc(&dx, 8 * (size_t)n));
-        DEV(lsk_malloc(&dy, 8 * (size_t)n));
-        int rc = 0;
-        if (lsk_h2d(dx, x, 8 * (size_t)n) != 0 || lsk_h2d(dy, y, 8 * (size_t)n) != 0) rc = dev_error();
-        if (rc == 0) rc = ls_amd_dist_matvec(dd, dx, dy, NULL);
-        if (rc == 0) rc = ls_amd_plan_check(ls_amd_dist_plan(dd), NULL);
-        if (rc == 0 && lsk_d2h(y, dy, 8 * (size_t)n) != 0) rc = dev_error();
-        lsk_free(dx);
-        lsk_free(dy);
-        return rc;
+    ls_amd_plan *plan = cm ? ls_amd_dist_plan((ls_amd_dist *)sl->dist) : (ls_amd_plan *)sl->plan;
+    size_t const bytes = 8 * (size_t)n;
+    int const xk = lsk_pointer_kind(x), yk = lsk_pointer_kind(y);
+    int const upload_y = !op->diag_terms || op->diag_terms->number_terms == 0; /* y += H x: the caller's y matters */
+    int const nbuf = ncols > 1 ? 2 : 1;
+    for (int i = 0; i < nbuf; ++i) {
+        if (xk != LSK_PTR_DEVICE && !sl->d_x[i]) DEV(lsk_malloc(&sl->d_x[i], bytes));
+        if (yk != LSK_PTR_DEVICE && !sl->d_y[i]) DEV(lsk_malloc(&sl->d_y[i], bytes));
     }
-    ls_amd_plan *pl = (ls_amd_plan *)sl->plan;
-    void *dx, *dy;
-    DEV(lsk_malloc(&dx, 8 * (size_t)n));
-    DEV(lsk_malloc(&dy, 8 * (size_t)n));
-    int rc = 0;
-    if (lsk_h2d(dx, x, 8 * (size_t)n) != 0 || lsk_h2d(dy, y, 8 * (size_t)n) != 0) rc = dev_error();
-    void const *xs[1] = {dx};
-    void *ys[1] = {dy};
-    if (rc == 0) rc = ls_amd_matvec(pl, xs, ys, NULL);
-    if (rc == 0) rc = ls_amd_plan_check(pl, NULL);
-    if (rc == 0 && lsk_d2h(y, dy, 8 * (size_t)n) != 0) rc = dev_error();
-    lsk_free(dx);
-    lsk_free(dy);
-    return rc;
+    sl->stage_n = n;
+    g_bstats.calls += 1;
+    g_bstats.columns += ncols;
+    if (xk == LSK_PTR_DEVICE) g_bstats.device_x += ncols;
+    if (yk == LSK_PTR_DEVICE) g_bstats.device_y += ncols;
+    /* pipeline over the columns: [upload x_0 (+ y_0)] ; for k: launch matvec_k | upload x_{k+1} (+ y_{k+1}) and download y_{k-1}
+     * while it runs | check ; [download y_last] */
+#define XDEV(k) (xk == LSK_PTR_DEVICE ? (void *)(x + (int64_t)(k) * ldx) : sl->d_x[(k) & (nbuf - 1)])
+#define YDEV(k) (yk == LSK_PTR_DEVICE ? (void *)(y + (int64_t)(k) * ldy) : sl->d_y[(k) & (nbuf - 1)])
+    if (xk != LSK_PTR_DEVICE && transfer(XDEV(0), x, bytes, xk, NULL, NULL, 0, 0) != 0) return -1;
+    if (yk != LSK_PTR_DEVICE && upload_y && transfer(YDEV(0), y, bytes, yk, NULL, NULL, 0, 0) != 0) return -1;
+    for (int k = 0; k < ncols; ++k) {
+        int rc;
+        if (cm) rc = ls_amd_dist_matvec((ls_amd_dist *)sl->dist, XDEV(k), YDEV(k), NULL);
+        else {
+            void const *xs[1] = {XDEV(k)};
+            void *ys[1] = {YDEV(k)};
+            rc = ls_amd_matvec(plan, xs, ys, NULL);
+        }
+        if (rc != 0) return -1;
+        /* while the kernel runs: the next column goes up, the previous result comes down (different buffers) */
+        int const up = k + 1 < ncols && xk != LSK_PTR_DEVICE, down = k >= 1 && yk != LSK_PTR_DEVICE;
+        if (k + 1 < ncols && yk != LSK_PTR_DEVICE && upload_y &&
+            transfer(YDEV(k + 1), y + (int64_t)(k + 1) * ldy, bytes, yk, NULL, NULL, 0, 0) != 0) return -1;
+        if ((up || down) && transfer(up ? XDEV(k + 1) : NULL, up ? x + (int64_t)(k + 1) * ldx : NULL, up ? bytes : 0, xk,
+                                     down ? y + (int64_t)(k - 1) * ldy : NULL, down ? YDEV(k - 1) : NULL, down ? bytes : 0, yk) != 0) return -1;
+        if (ls_amd_plan_check(plan, NULL) != 0) return -1; /* synchronises the launch stream; halts on an invalid index */
+    }
+    if (yk != LSK_PTR_DEVICE &&
+        transfer(NULL, NULL, 0, 0, y + (int64_t)(ncols - 1) * ldy, YDEV(ncols - 1), bytes, yk) != 0) return -1;
+#undef XDEV
+#undef YDEV
+    return 0;
 }
 
 void ls_chpl_matrix_vector_product(ls_hs_operator *matrixPtr, int numVectors, double *xPtr, double *yPtr) {
@@ -3006,7 +3079,7 @@ void ls_chpl_matrix_vector_product(ls_hs_operator *matrixPtr, int numVectors, do
     if (numVectors != 1) { halt_with("applying the Operator to more than 1 vector is not yet implemented"); return; }
     if (!matrixPtr->basis->representatives.elts) { halt_with("basis is not built"); return; }
     int64_t n = (int64_t)matrixPtr->basis->representatives.num_elts;
-    if (host_matvec_f64(matrixPtr, n, xPtr, yPtr, NULL) != 0) halt_with("%s", g_last_error);
+    if (host_matvec_block(matrixPtr, n, 1, xPtr, n, yPtr, n, NULL) != 0) halt_with("%s", g_last_error);
 }
 
 void ls_chpl_primme_matvec(void *x, int64_t *ldx, void *y, int64_t *ldy, int *blockSize, void *primme,
@@ -3016,12 +3089,11 @@ void ls_chpl_primme_matvec(void *x, int64_t *ldx, void *y, int64_t *ldy, int *bl
     int64_t n = pp->nLocal;
     *ierr = 0;
     if (*ldx < n || *ldy < n) { *ierr = -1; return; }
-    for (int k = 0; k < *blockSize; ++k)
-        if (host_matvec_f64(op, n, (double const *)x + *ldx * k, (double *)y + *ldy * k, (ls_amd_comm *)pp->commInfo) != 0) {
-            halt_with("%s", g_last_error);
-            *ierr = -1;
-            return;
-        }
+    /* all blockSize columns through ONE pipeline (x_{k+1} up and y_{k-1} down while column k computes) */
+    if (host_matvec_block(op, n, *blockSize, (double const *)x, *ldx, (double *)y, *ldy, (ls_amd_comm *)pp->commInfo) != 0) {
+        halt_with("%s", g_last_error);
+        *ierr = -1;
+    }
 }
 /* primmeGlobalSumReal / primmeBroadcastReal: dist.c (collective over the communicator) */
 

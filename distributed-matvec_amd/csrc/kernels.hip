@@ -57,6 +57,7 @@ extern "C" int lsk_malloc(void **p, size_t bytes) {
     return 0;
 }
 extern "C" int lsk_free(void *p) { if (p) LSK_CHECK(hipFree(p)); return 0; }
+extern "C" int lsk_mem_info(size_t *free_bytes, size_t *total_bytes) { LSK_CHECK(hipMemGetInfo(free_bytes, total_bytes)); return 0; }
 extern "C" int lsk_h2d(void *dst, void const *src, size_t bytes) {
     if (bytes) LSK_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
     return 0;
@@ -3221,7 +3222,8 @@ __global__ __launch_bounds__(kBlock) void k_pull_count(int n_groups, lsk_group c
     }
 }
 // out[0, streams] <- exclusive offsets of the packet streams of rows [row0, row1) (streams = ceil(rows / 64); out[streams] =
-// total); synchronises the stream
+// total); `out` has ((streams + 3) & ~3) + 1 entries and the entries behind out[streams] repeat the total: the last 256-row
+// tile of the resolve / gather kernels runs four waves whatever the row count, and each reads its offset.  Synchronises the stream
 extern "C" int lsk_tile_pull_stream_offsets(lsk_operator op, lsk_basis bs, int64_t row0, int64_t row1, uint64_t const *reps,
                                             int64_t *out, void *stream) {
     if (row1 <= row0) return 0;
@@ -3229,13 +3231,14 @@ extern "C" int lsk_tile_pull_stream_offsets(lsk_operator op, lsk_basis bs, int64
     int k4m, coef;
     pull_kinds(op, bs, k4m, coef);
     hipStream_t s = (hipStream_t)stream;
-    LSK_CHECK(hipMemsetAsync(out, 0, 8 * (size_t)(streams + 1), s));
+    const int64_t padded = (streams + 3) & ~(int64_t)3;
+    LSK_CHECK(hipMemsetAsync(out, 0, 8 * (size_t)(padded + 1), s));
     const dim3 g((unsigned)grid_for(row1 - row0)), b(kBlock);
     if (coef == COEF_UNI) hipLaunchKernelGGL(k_pull_count<COEF_UNI>, g, b, 0, s, op.n_groups, op.groups, op.off, row0, row1, reps, out);
     else if (coef == COEF_REAL) hipLaunchKernelGGL(k_pull_count<COEF_REAL>, g, b, 0, s, op.n_groups, op.groups, op.off, row0, row1, reps, out);
     else hipLaunchKernelGGL(k_pull_count<COEF_CPLX>, g, b, 0, s, op.n_groups, op.groups, op.off, row0, row1, reps, out);
     LSK_LAUNCH_CHECK();
-    return exclusive_scan_i64(streams + 1, out, out, s);
+    return exclusive_scan_i64(padded + 1, out, out, s);
 }
 
 // first half of the split matvec: rows [row0, row1) -> packet stream in `buf` (buf.row0 = the row that owns stream 0; a

@@ -141,12 +141,29 @@ int lsk_device_count(void);
 int lsk_set_device(int device);
 int lsk_malloc(void **p, size_t bytes);
 int lsk_free(void *p);
+int lsk_mem_info(size_t *free_bytes, size_t *total_bytes);
 int lsk_h2d(void *dst, void const *src, size_t bytes);
 int lsk_d2h(void *dst, void const *src, size_t bytes);
 int lsk_d2d_async(void *dst, void const *src, size_t bytes, void *stream);
 int lsk_memset_async(void *p, int value, size_t bytes, void *stream);
 int lsk_sync(void *stream);
 int lsk_device_sync(void);
+
+/* host <-> HBM staging of the host-pointer entry points (stage.cpp) ---------------------------- */
+enum { LSK_PTR_PAGEABLE = 0, LSK_PTR_PINNED = 1, LSK_PTR_DEVICE = 2 };
+char const *lsk_stage_last_error(void);
+int lsk_pointer_kind(void const *p); /* hipPointerGetAttributes: device / managed, pinned or registered host, anything else */
+int lsk_host_register(void *p, size_t bytes);
+int lsk_host_unregister(void *p);
+typedef struct lsk_stager lsk_stager;
+int lsk_stager_create(lsk_stager **out, size_t chunk_bytes, int threads /* <= 0: min(8, cores / 4) */);
+void lsk_stager_destroy(lsk_stager *st);
+int lsk_stager_threads(lsk_stager const *st);
+size_t lsk_stager_chunk(lsk_stager const *st);
+/* one upload and one download at the same time (either may have 0 bytes); *_kind = LSK_PTR_PAGEABLE (double-buffered pinned
+ * bounce chunks, host copies by the stager's thread pool) or LSK_PTR_PINNED (one DMA); returns when both are complete */
+int lsk_stage_run(lsk_stager *st, void *d_up, void const *h_up, size_t up_bytes, int up_kind, void *h_down, void const *d_down,
+                  size_t down_bytes, int down_kind);
 
 /* events (kernel timing on the launch stream) */
 int lsk_event_create(void **ev);

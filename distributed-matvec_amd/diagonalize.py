@@ -305,7 +305,8 @@ def diagonalize(config, num_evals: int = 1, eps: float = 1e-6, num_partitions: i
     # one plan, hundreds of matvecs: what is left of HBM after the Krylov basis may hold the resolved packet streams
     # (ls_amd_plan_cache_slots; LS_AMD_SLOT_CACHE=0 keeps the solver matrix-free)
     cache_bytes = 0
-    if num_partitions == 1 and os.environ.get("LS_AMD_SLOT_CACHE", "1") != "0":
+    # (LS_AMD_SLOT_CACHE has one meaning everywhere: bytes; 0 = off; set = the C plan applies it at creation, nothing to add here)
+    if num_partitions == 1 and os.environ.get("LS_AMD_SLOT_CACHE") is None:
         n_states = int(reps[0].numel())
         free, _total = torch.cuda.mem_get_info()
         cache_bytes = max(0, int(free) - (max_basis + 6) * n_states * (16 if dtype == torch.complex128 else 8) - (4 << 30))
@@ -381,7 +382,8 @@ def diagonalize_distributed(config, group=None, num_evals: int = 1, eps: float =
         # one plan, hundreds of matvecs: this rank's rows keep their resolved packet streams in the HBM the Krylov basis leaves
         # (ls_amd_plan_cache_slots -- a local decision, no collective; rows that do not fit stay matrix-free; LS_AMD_SLOT_CACHE=0: off)
         plan = getattr(getattr(op, "engine", None), "plan", None)
-        if plan is not None and hasattr(plan, "cache_slots") and my_reps.is_cuda and os.environ.get("LS_AMD_SLOT_CACHE", "1") != "0":
+        # (LS_AMD_SLOT_CACHE set: bytes, applied by ls_amd_repl_create itself -- 0 = off; unset: sized here)
+        if plan is not None and hasattr(plan, "cache_slots") and my_reps.is_cuda and os.environ.get("LS_AMD_SLOT_CACHE") is None:
             free, _total = torch.cuda.mem_get_info()
             budget = int(free) - (max_basis + 6) * int(my_reps.numel()) * (16 if dtype == torch.complex128 else 8) - (4 << 30)
             if budget > 0:

@@ -73,6 +73,30 @@ int ls_amd_orth_pass(int m, int64_t n, double const *d_V, int64_t ldv, double *d
 /* thick restart of such a solver: V[:m_out] <- S^T V[:m_in] in place (d_S: m_in x m_out, row-major; m_out <= m_in <= max rows) */
 int ls_amd_basis_rotate(int m_in, int m_out, int64_t n, double *d_V, int64_t ldv, double const *d_S, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * The host-pointer boundary: ls_chpl_matrix_vector_product (DMV:1095-1110) and ls_chpl_primme_matvec (Diagonalize.chpl:134-162)
+ * take `double *` as the reference's do.  What a call costs is decided by where that memory lives:
+ *   LS_AMD_PTR_DEVICE    device / managed memory (hipMalloc, a torch CUDA tensor): used in place, ZERO copies -- a GPU-resident
+ *                        eigensolver can call the reference's entry points as they are
+ *   LS_AMD_PTR_PINNED    hipHostMalloc'ed memory, or memory registered with ls_amd_host_register (once per workspace: PRIMME
+ *                        reuses its vectors): one DMA per direction at the PCIe rate
+ *   LS_AMD_PTR_PAGEABLE  anything else: double-buffered pinned bounce chunks filled by a small pool of host threads, upload
+ *                        and download at the same time
+ * The device copies of x / y persist with the cached plan (no hipMalloc / hipFree per call), y is uploaded only when the
+ * operator has no diagonal terms (else it is assigned, DMV:1062-1063), and the columns of a PRIMME block share one pipeline
+ * (column k + 1 goes up and column k - 1 comes down while column k computes).  Knobs: LS_AMD_STAGE=0 (plain synchronous
+ * hipMemcpy), LS_AMD_STAGE_CHUNK_KB (32768), LS_AMD_STAGE_THREADS (min(8, cores / 4)). */
+enum { LS_AMD_PTR_PAGEABLE = 0, LS_AMD_PTR_PINNED = 1, LS_AMD_PTR_DEVICE = 2 };
+int ls_amd_pointer_kind(void const *p);
+int ls_amd_host_register(void *p, size_t bytes);   /* hipHostRegister: the caller keeps the memory alive until ... */
+int ls_amd_host_unregister(void *p);               /* ... this */
+struct ls_amd_boundary_stats {
+    int64_t calls, columns;        /* entries into the boundary, vectors applied */
+    int64_t bytes_h2d, bytes_d2h;  /* bytes that crossed PCIe */
+    int64_t device_x, device_y;    /* columns whose x / y was device memory (used in place) */
+};
+void ls_amd_boundary_stats_get(struct ls_amd_boundary_stats *out, int reset);
+
 /* hash64_01 / localeIdxOf on the host (StatesEnumeration.chpl:122-136) */
 uint64_t ls_amd_hash64_01(uint64_t x);
 int ls_amd_locale_idx_of(uint64_t basis_state, int num_locales);

@@ -1080,3 +1080,113 @@ def test_pairs_kernel_lattices(torch, case):
     gotc, plc = run_matvec(torch, D, h, reps, masks, xc, 1, "pull")
     wantc = o.local_matvec(want_reps, xc)
     assert np.abs(gotc - wantc).max() <= 1e-12 * max(1.0, np.abs(wantc).max()), case
+
+
+def _primme_buffer(n, h):
+    import ctypes as C
+
+    class View(C.Structure):  # the prefix of primme_params this library reads
+        _fields_ = [("n", C.c_int64), ("pad0", C.c_void_p), ("t0", C.c_int), ("pad1", C.c_void_p), ("t1", C.c_int),
+                    ("pad2", C.c_void_p), ("t2", C.c_int), ("numProcs", C.c_int), ("procID", C.c_int), ("nLocal", C.c_int64)]
+
+    from distributed_matvec_amd import _lib
+
+    buf = (C.c_char * 512)()
+    view = View.from_buffer(buf)
+    view.n = n
+    view.nLocal = n
+    C.c_void_p.from_buffer(buf, _lib.load().ls_amd_test_primme_matrix_offset()).value = C.cast(h.payload, C.c_void_p).value
+    return buf
+
+
+@pytest.mark.parametrize("name", ["heisenberg_chain_16", "heisenberg_chain_24_symm", "offdiag_only_chain_16"])
+def test_host_pointer_boundary_memory_kinds(torch, monkeypatch, name):
+    """The reference's host-pointer entries (ls_chpl_matrix_vector_product DMV:1095-1110, ls_chpl_primme_matvec
+    Diagonalize.chpl:134-162) with the caller's vectors in every kind of memory (include/ls_amd.h): device pointers are used in
+    place -- no byte crosses PCIe --, registered host memory takes one DMA per direction, pageable memory the bounce pipeline (tiny
+    chunks here, so that every vector is many chunks and both directions overlap) or, with LS_AMD_STAGE=0, plain hipMemcpy.  All
+    equal the oracle.  y is uploaded only for an operator without diagonal terms (y += H x, DMV:1062-1069)."""
+    import ctypes as C
+
+    import distributed_matvec_amd as D
+    from distributed_matvec_amd import _lib
+    from oracle import c_oracle as CO
+    from oracle import model as M
+
+    monkeypatch.setenv("LS_AMD_STAGE_CHUNK_KB", "16")   # every vector is several chunks
+    monkeypatch.setenv("LS_AMD_STAGE_PAR_MIN_KB", "4")  # ... and every chunk goes through the copy pool
+    L = _lib.load()
+    if name == "offdiag_only_chain_16":
+        cfg = model_config("heisenberg_chain_16")
+        cfg = {"basis": cfg["basis"], "hamiltonian": {"terms": [t for t in cfg["hamiltonian"]["terms"] if "ᶻ" not in t["expression"]]}}
+        o = CO.COracle(M.model_from_config(cfg))
+        reps = o.enumerate()
+    else:
+        cfg = model_config(name)
+        o, reps = oracle_for(name), oracle_reps(name)
+    basis, h = D.loadConfigFromDict(cfg, hamiltonian=True)
+    accumulate = h.numberDiagTerms() == 0
+    h.basis.uncheckedSetRepresentatives(reps)
+    n, bs = len(reps), 4
+    ld = n + 3
+    rng = np.random.RandomState(5)
+    X = np.zeros((bs, ld))
+    X[:, :n] = rng.rand(bs, n) - 0.5
+    Y0 = rng.rand(bs, ld)  # what y holds on entry: garbage with diagonal terms, an addend without
+    want = [o.local_matvec(reps, X[k, :n].copy(), y=(Y0[k, :n].copy() if accumulate else None)) for k in range(bs)]
+    st = _lib.BoundaryStats()
+    f64p = _lib.c_f64p
+
+    def mvp(xp, yp):
+        L.ls_chpl_matrix_vector_product(h.payload, 1, C.cast(xp, f64p), C.cast(yp, f64p))
+        _lib.raise_pending_halt()
+
+    def block(xp, yp):
+        ldx, ldy, blk, ierr = C.c_int64(ld), C.c_int64(ld), C.c_int(bs), C.c_int(-7)
+        L.ls_chpl_primme_matvec(C.c_void_p(xp), C.byref(ldx), C.c_void_p(yp), C.byref(ldy), C.byref(blk), C.cast(_primme_buffer(n, h), C.c_void_p), C.byref(ierr))
+        _lib.raise_pending_halt()
+        assert ierr.value == 0
+
+    # pageable, one vector and the block of columns through one pipeline
+    for stage in ("1", "0"):
+        monkeypatch.setenv("LS_AMD_STAGE", stage)
+        y = Y0[0, :n].copy()
+        L.ls_amd_boundary_stats_get(C.byref(st), 1)
+        mvp(X[0, :n].copy().ctypes.data, y.ctypes.data)
+        assert_close(y, want[0])
+        L.ls_amd_boundary_stats_get(C.byref(st), 1)
+        assert st.calls == 1 and st.bytes_d2h == 8 * n and st.bytes_h2d == (16 * n if accumulate else 8 * n) and st.device_x == 0
+        Y = Y0.copy()
+        block(X.ctypes.data, Y.ctypes.data)
+        for k in range(bs):
+            assert_close(Y[k, :n], want[k])
+            assert np.array_equal(Y[k, n:], Y0[k, n:])  # the padding between the columns is not touched
+    monkeypatch.delenv("LS_AMD_STAGE")
+    # registered (pinned) host memory
+    Xr, Yr = X.copy(), Y0.copy()
+    assert L.ls_amd_pointer_kind(C.c_void_p(Xr.ctypes.data)) == 0
+    for a in (Xr, Yr):
+        _lib.check(L.ls_amd_host_register(C.c_void_p(a.ctypes.data), a.nbytes))
+    try:
+        assert L.ls_amd_pointer_kind(C.c_void_p(Xr.ctypes.data)) == 1
+        block(Xr.ctypes.data, Yr.ctypes.data)
+    finally:
+        for a in (Xr, Yr):
+            _lib.check(L.ls_amd_host_unregister(C.c_void_p(a.ctypes.data)))
+    for k in range(bs):
+        assert_close(Yr[k, :n], want[k])
+    # device pointers: in place, nothing crosses PCIe
+    Xd, Yd = torch.from_numpy(X).cuda(), torch.from_numpy(Y0).cuda()
+    assert L.ls_amd_pointer_kind(C.c_void_p(Xd.data_ptr())) == 2
+    L.ls_amd_boundary_stats_get(C.byref(st), 1)
+    block(Xd.data_ptr(), Yd.data_ptr())
+    L.ls_amd_boundary_stats_get(C.byref(st), 1)
+    assert st.bytes_h2d == 0 and st.bytes_d2h == 0 and st.device_x == bs and st.device_y == bs and st.columns == bs
+    for k in range(bs):
+        assert_close(Yd[k, :n].cpu().numpy(), want[k])
+    # mixed: x on the device, y in pageable host memory
+    y = Y0[1, :n].copy()
+    mvp(Xd[1].data_ptr(), y.ctypes.data)
+    assert_close(y, want[1])
+    L.ls_amd_boundary_stats_get(C.byref(st), 1)
+    assert st.device_x == 1 and st.device_y == 0 and st.bytes_d2h == 8 * n
