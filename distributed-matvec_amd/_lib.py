@@ -145,6 +145,11 @@ def load():
         "ls_amd_diag": (C.c_int, [vp, vp, vp, vp]),
         "ls_amd_generate": (C.c_int, [vp, C.c_int, vp, vp, vp, vp]),
         "ls_amd_scatter": (C.c_int, [vp, C.c_int64, vp, vp, vp, vp]),
+        "ls_amd_plan_key_bytes": (C.c_int, [vp]),
+        "ls_amd_plan_segment_bytes": (C.c_int64, [vp, C.c_int64]),
+        "ls_amd_plan_segment_value_offset": (C.c_int64, [vp, C.c_int64]),
+        "ls_amd_plan_packet_index_bytes": (C.c_int64, [vp]),
+        "ls_amd_scatter_round": (C.c_int, [vp, C.c_int, c_i64p, c_i64p, vp, vp, vp]),
         "ls_amd_adopt_basis": (C.c_int, [bp, C.c_int, c_intp, c_intp]),
         "ls_amd_adopt_operator": (C.c_int, [op]),
         "ls_amd_release": (None, [vp]),

@@ -392,6 +392,19 @@ class MatvecPlan:
     def packet_bytes(self): return int(_lib.load().ls_amd_plan_packet_bytes(self.h))
     @property
     def row_bytes(self): return int(_lib.load().ls_amd_plan_row_bytes(self.h))
+    @property
+    def key_bytes(self):
+        """8: packets carry the state; 4: pre-indexed packets (u32 index at the destination; include/ls_amd.h)"""
+        return int(_lib.load().ls_amd_plan_key_bytes(self.h))
+    @property
+    def packet_index_bytes(self): return int(_lib.load().ls_amd_plan_packet_index_bytes(self.h))
+
+    def segment_bytes(self, count: int) -> int:
+        """bytes of a segment of `count` packets: [key x count, padded to 8 bytes][value x count]"""
+        return int(_lib.load().ls_amd_plan_segment_bytes(self.h, int(count)))
+
+    def segment_value_offset(self, count: int) -> int:
+        return int(_lib.load().ls_amd_plan_segment_value_offset(self.h, int(count)))
 
     def cache_slots(self, max_bytes: int = 0) -> int:
         """keep the resolved packet streams (slot of every partner, 5 B per non-zero on the Heisenberg models) across matvecs:
@@ -460,6 +473,12 @@ class MatvecPlan:
     def scatter(self, n, betas_ptr: int, vals_ptr: int, y):
         _lib.check(_lib.load().ls_amd_scatter(self.h, n, C.c_void_p(betas_ptr), C.c_void_p(vals_ptr),
                                               C.c_void_p(y.data_ptr()), _stream_ptr()))
+
+    def scatter_round(self, counts, offsets, recv_ptr: int, y):
+        """all segments of one round's receive buffer in one launch (ls_amd_scatter_round)"""
+        n = len(counts)
+        _lib.check(_lib.load().ls_amd_scatter_round(self.h, n, (C.c_int64 * n)(*counts), (C.c_int64 * n)(*offsets), C.c_void_p(recv_ptr),
+                                                    C.c_void_p(y.data_ptr()), _stream_ptr()))
 
 
 class _BorrowedPlan(MatvecPlan):

@@ -24,6 +24,7 @@ int ls_amd_internal_error(char const *fmt, ...); /* host.c: formats into ls_amd_
 int ls_amd_internal_stage_begin(ls_amd_plan *pl, int stage, void *stream); /* host.c: stage timers (kDisplayTimings) */
 void ls_amd_internal_stage_end(ls_amd_plan *pl, int slot, void *stream);
 void ls_amd_internal_count_matvec(ls_amd_plan *pl);
+int ls_amd_scatter_round(ls_amd_plan *pl, int num_segments, int64_t const *counts, int64_t const *offsets, void const *d_recv, void *d_y, void *stream);
 enum { ST_REFRESH = 1, ST_EXCHANGE = 4, ST_RETURN = 6 };
 /* host.c: the indexed replicated-x matvec in two kernels -- BEGIN resolves the packets (needs no x), FINISH gathers */
 int64_t ls_amd_internal_plan_split_enable(ls_amd_plan *pl, int64_t max_bytes);
@@ -276,8 +277,9 @@ int ls_amd_dist_create(ls_amd_dist **out, ls_amd_comm *cm, ls_hs_operator const 
         for (int q = 0; q < P; ++q) {
             size_t const k = (size_t)r * P + q;
             d->recv_counts[k] = all[(size_t)q * m + (size_t)r * P + me]; /* what rank q sends to me in round r */
-            d->send_off[k] = so; d->send_bytes[k] = d->send_counts[k] * d->pb; so += d->send_bytes[k];
-            d->recv_off[k] = ro; d->recv_bytes[k] = d->recv_counts[k] * d->pb; ro += d->recv_bytes[k];
+            /* (a segment of c packets: c keys -- u64 states, or u32 indices padded to 8 bytes -- then c values) */
+            d->send_off[k] = so; d->send_bytes[k] = ls_amd_plan_segment_bytes(d->plan, d->send_counts[k]); so += d->send_bytes[k];
+            d->recv_off[k] = ro; d->recv_bytes[k] = ls_amd_plan_segment_bytes(d->plan, d->recv_counts[k]); ro += d->recv_bytes[k];
         }
         if (so > max_send) max_send = so;
         if (ro > max_recv) max_recv = ro;
@@ -300,10 +302,13 @@ int ls_amd_dist_num_rounds(ls_amd_dist const *d) { return d->rounds; }
 /* test hook (ls_amd.h): the first non-empty remote segment this rank receives loses its first packet's state and its last
  * packet's value -- the segment is read one state further on, one packet shorter: (beta_{k+1}, value_k) pairs */
 int ls_amd_test_corrupt_dist(ls_amd_dist *d) {
+    /* 8 bytes further on = one state, or two pre-indexed keys; with the count reduced by as many the values behind the (padded)
+     * key array are still found at their place: (key_{k + drop}, value_k) pairs, every key valid, nothing read out of bounds */
+    int const drop = 8 / ls_amd_plan_key_bytes(d->plan);
     for (size_t k = 0; k < (size_t)d->rounds * (size_t)d->P; ++k) {
-        if ((int)(k % (size_t)d->P) == d->me || d->recv_counts[k] < 2) continue;
+        if ((int)(k % (size_t)d->P) == d->me || d->recv_counts[k] < 2 * drop + 1 || (d->recv_counts[k] & 1)) continue;
         d->recv_off[k] += 8;
-        d->recv_counts[k] -= 1;
+        d->recv_counts[k] -= drop;
         return 1;
     }
     return 0;
@@ -333,13 +338,8 @@ int ls_amd_dist_matvec(ls_amd_dist *d, void const *d_x, void *d_y, void *stream)
         int const st = ls_amd_internal_stage_begin(d->plan, ST_EXCHANGE, stream);
         COMM(lsk_comm_exchange_wait(d->comm->c, r & 1, stream));
         ls_amd_internal_stage_end(d->plan, st, stream);
-        char const *recv = (char const *)d->d_recv[r & 1];
-        for (int s = 0; s < P; ++s) {
-            int64_t const n = d->recv_counts[(size_t)r * P + s];
-            if (n == 0) continue;
-            char const *seg = recv + d->recv_off[(size_t)r * P + s]; /* SoA: n betas, then n values */
-            TRY(ls_amd_scatter(d->plan, n, (uint64_t const *)seg, seg + 8 * n, d_y, stream));
-        }
+        /* every received segment of the round (SoA: keys, then values) in one consumer launch */
+        TRY(ls_amd_scatter_round(d->plan, P, d->recv_counts + (size_t)r * P, d->recv_off + (size_t)r * P, d->d_recv[r & 1], d_y, stream));
     }
     return 0;
 }

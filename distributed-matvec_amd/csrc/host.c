@@ -1347,6 +1347,11 @@ struct ls_amd_plan {
     unsigned long long *d_counts;  /* [P] */
     int *d_err;
     int64_t nnz;
+    /* pre-indexed packets (packet plans over unprojected fixed-weight bases): all-destinations rank directory; the producer
+     * writes (u32 index at the destination, value) and the consumers are search-free (lsk_gdir, lsk.h) */
+    lsk_gdir gd;
+    lsk_rankdir *d_gdir; /* owned */
+    int key_bytes;       /* 4: pre-indexed packets, 8: packets carry the state */
     /* replicated-x mode: index / norms of the GLOBAL basis, global index of every local row */
     lsk_index gindex;
     uint32_t *d_gtable;
@@ -2031,6 +2036,56 @@ static int setup_pairs(ls_amd_plan *pl, int64_t n, uint64_t const *d_reps, void 
     return 0;
 }
 
+/* Pre-indexed packets: for a hash partition of an UNPROJECTED fixed-weight basis every rank can
+ * derive, alone, where any state sits inside its owner's block -- global colex rank (closed form) -> entry [rank / 64][owner] of the
+ * all-destinations directory -> prefix + popcount.  The producer then sends (u32 index, value) = 12 bytes (20 for c128) instead
+ * of (u64 state, value) = 16 (24), the exchange shrinks by a quarter (a sixth), and the consumer is one streaming read + one
+ * atomic per packet.  Costs P / 4 bytes of HBM per basis state on every rank (chain_32 at 8 ranks: 1.2 GB; the per-rank data of the
+ * packet strategy stays O(N / P) otherwise), so it is taken only while it fits LS_AMD_PACKET_INDEX_MAX bytes (default: a quarter
+ * of the free HBM); LS_AMD_PACKET_INDEX=0 keeps the state-carrying packets (also the path of every projected basis, whose
+ * representatives no closed form ranks). */
+static int packets_wave_rings(void);
+/* bytes of the key array (states or indices) of a segment of c packets: the values behind it stay 8-byte aligned */
+static int64_t segment_key_bytes(ls_amd_plan const *pl, int64_t c) { return pl->key_bytes == 4 ? ((4 * c + 7) & ~(int64_t)7) : 8 * c; }
+static int setup_packet_index(ls_amd_plan *pl, uint64_t const *const *d_reps, int64_t const *counts, void *stream) {
+    ls_hs_basis const *b = pl->op->basis;
+    int const L = b->number_sites, h = BEXT(b)->hamming_weight, P = pl->P;
+    char const *e = getenv("LS_AMD_PACKET_INDEX");
+    if (e && atoi(e) == 0) return 0;
+    if (pl->dbs.proj == LSK_PROJ_FULL || h < 0 || h >= LSK_BINOM_K - 1 || L > 64 || P > lsk_tile_wv_max_parts() || P > LSK_MAX_SEGS ||
+        !packets_wave_rings()) return 0;
+    for (int i = 0; i < pl->n_local; ++i) if (counts[i] >= 0xffffffffLL) return 0;
+    int const sites = L - (b->spin_inversion != 0 ? 1 : 0); /* inversion sectors: the canonical states have the top site bit clear */
+    uint64_t const n_ranks = binom(sites, h);
+    if (n_ranks == 0 || n_ranks >= ((uint64_t)1 << 40)) return 0;
+    int64_t const words = (int64_t)((n_ranks + 63) / 64);
+    size_t const bytes = sizeof(lsk_rankdir) * (size_t)words * (size_t)P;
+    size_t fr = 0, tot = 0, ceiling;
+    if (lsk_mem_info(&fr, &tot) != 0) return 0;
+    e = getenv("LS_AMD_PACKET_INDEX_MAX");
+    ceiling = e && atoll(e) > 0 ? (size_t)atoll(e) : fr / 4;
+    if (bytes > ceiling) return 0; /* does not fit: the packets carry the state and the consumers rank it (O(N / P) memory) */
+    uint64_t const *d_binom;
+    if (device_binom(&d_binom) != 0) return -1;
+    void *p = NULL;
+    if (lsk_malloc(&p, bytes) != 0) return 0;
+    lsk_gdir gd;
+    memset(&gd, 0, sizeof(gd));
+    gd.entries = (lsk_rankdir const *)p; gd.P = P; gd.sites = L; gd.weight = h; gd.n_ranks = (int64_t)n_ranks;
+    int zero = 0, flag = 1;
+    int ok = lsk_h2d(pl->d_err, &zero, sizeof(int)) == 0 && lsk_gdir_build(gd, (lsk_rankdir *)p, d_binom, stream) == 0;
+    /* self-check: every state this process owns must come back as (its partition, its position) */
+    for (int i = 0; ok && i < pl->n_local; ++i)
+        ok = lsk_gdir_check(gd, pl->me < 0 ? i : pl->me, counts[i], d_reps[i], d_binom, pl->d_err, stream) == 0;
+    ok = ok && lsk_sync(stream) == 0 && lsk_d2h(&flag, pl->d_err, sizeof(int)) == 0 && flag == 0;
+    (void)lsk_h2d(pl->d_err, &zero, sizeof(int));
+    if (!ok) { lsk_free(p); return 0; } /* not the full fixed-weight basis (or no room for the scans): state-carrying packets */
+    pl->gd = gd;
+    pl->d_gdir = (lsk_rankdir *)p;
+    pl->key_bytes = 4;
+    return 0;
+}
+
 static int plan_setup_part(ls_amd_plan *pl, part_state *ps, int part_id, int num_rounds, void *stream) {
     ls_hs_basis const *b = pl->op->basis;
     int const L = b->number_sites;
@@ -2068,7 +2123,8 @@ static int plan_setup_part(ls_amd_plan *pl, part_state *ps, int part_id, int num
      * fallback (no room, a state of another weight) and for every other caller.  chain_28 x 8 partitions 23.7 -> 22.3 ms, x 2
      * partitions 12.0 -> 10.2 ms, chain_30 x 8 98.0 -> 91.7 ms (profiles/r4_packets_rank_directory_ab.txt).  (Inversion sectors qualify: the canonical
      * state of a pair has the same weight at half filling, which is the only filling they exist at.) */
-    if (pl->family == FAMILY_TILE && pl->dbs.proj != LSK_PROJ_FULL && h >= 0 && h < LSK_BINOM_K - 1 && L <= 64 && ps->count > 0 &&
+    if (pl->family == FAMILY_TILE && !pl->d_gdir /* pre-indexed packets need no per-partition directory */ &&
+        pl->dbs.proj != LSK_PROJ_FULL && h >= 0 && h < LSK_BINOM_K - 1 && L <= 64 && ps->count > 0 &&
         ps->count < 0xffffffffLL && ps->index.kind == LSK_INDEX_SEARCH) {
         uint64_t const n_global = binom(L, h);
         if (n_global > 0 && n_global < ((uint64_t)1 << 40)) {
@@ -2137,7 +2193,7 @@ static int plan_setup_part(ls_amd_plan *pl, part_state *ps, int part_id, int num
         if (lsk_memset_async(pw, 0, bytes, stream) != 0) { free(layouts); return dev_error(); }
         for (int r = 0; r < rounds; ++r) {
             int64_t row0 = ps->count * r / rounds, row1 = ps->count * (r + 1) / rounds;
-            if (lsk_tile_wv(pl->dop, pl->dbs, ps->index, pl->cplx, 1, P, part_id, row0, row1, ps->d_reps, ps->d_norms, NULL, NULL,
+            if (lsk_tile_wv(pl->dop, pl->dbs, ps->index, pl->gd, pl->cplx, 1, P, part_id, row0, row1, ps->d_reps, ps->d_norms, NULL, NULL,
                             ps->d_wtab + (size_t)ps->wtab_first[r] * P, NULL, NULL, pl->d_err, stream) != 0) { free(layouts); return dev_error(); }
         }
         h_wtab = (uint32_t *)malloc(bytes);
@@ -2169,11 +2225,12 @@ static int plan_setup_part(ls_amd_plan *pl, part_state *ps, int part_id, int num
             pl->nnz += (int64_t)hc[d];
             int64_t c = (d == part_id) ? 0 : (int64_t)hc[d];
             ps->send_counts[(size_t)r * P + d] = c;
+            int64_t const keys = segment_key_bytes(pl, c); /* u64 states, or u32 indices padded to 8 bytes */
             layouts[r].beta_off[d] = off;
-            layouts[r].val_off[d] = off + 8 * c;
+            layouts[r].val_off[d] = off + keys;
             ps->h_beta_off[(size_t)r * P + d] = off;
-            ps->h_val_off[(size_t)r * P + d] = off + 8 * c;
-            off += (8 + w) * c;
+            ps->h_val_off[(size_t)r * P + d] = off + keys;
+            off += keys + w * c;
         }
         if (off > ps->max_send_bytes) ps->max_send_bytes = off;
     }
@@ -2264,6 +2321,8 @@ int ls_amd_plan_create(ls_amd_plan **out, ls_hs_operator const *op, ls_amd_dtype
     int zero = 0;
     if (lsk_h2d(pl->d_err, &zero, sizeof(int)) != 0) { ls_amd_plan_destroy(pl); return dev_error(); }
 
+    pl->key_bytes = 8;
+    if (pl->family == FAMILY_TILE && setup_packet_index(pl, d_reps, counts, stream) != 0) { ls_amd_plan_destroy(pl); return -1; }
     pl->parts = (part_state *)calloc(pl->n_local, sizeof(part_state));
     for (int i = 0; i < pl->n_local; ++i) {
         part_state *ps = &pl->parts[i];
@@ -2318,6 +2377,7 @@ int ls_amd_plan_create(ls_amd_plan **out, ls_hs_operator const *op, ls_amd_dtype
 
 void ls_amd_plan_destroy(ls_amd_plan *pl) {
     if (!pl) return;
+    if (pl->d_gdir) lsk_free(pl->d_gdir);
     if (pl->parts) {
         for (int i = 0; i < pl->n_local; ++i) {
             part_state *ps = &pl->parts[i];
@@ -2626,7 +2686,8 @@ char const *ls_amd_plan_kernel_name(ls_amd_plan const *pl) {
     default: return "tile";
     }
 }
-int ls_amd_plan_packet_bytes(ls_amd_plan const *pl) { return pl->cplx ? 24 : 16; }
+/* nominal bytes per packet (a segment of c packets takes ls_amd_plan_segment_bytes(c): pre-indexed keys are padded to 8 bytes) */
+int ls_amd_plan_packet_bytes(ls_amd_plan const *pl) { return pl->key_bytes + (pl->cplx ? 16 : 8); }
 /* bytes of per-row plan / basis data the plan's dominant kernel streams from HBM next to x and y (the roofline's
  * compulsory traffic is rows * (this + 2 w)): the staged row kernel reads the fused 8-byte record, or the low state word(s)
  * plus one cached partner rank per cached pair; the generic row kernels read the 8-byte state; the projected pull kernel
@@ -2689,7 +2750,7 @@ static int generate_round(ls_amd_plan *pl, part_state *ps, int pid, int round, v
     int const st = stage_begin(pl, ST_GENERATE, stream);
     int slot = timing_begin(pl, stream);
     if (ps->d_wtab)
-        DEV(lsk_tile_wv(pl->dop, pl->dbs, ps->index, pl->cplx, 0, pl->P, pid, row0, row1, ps->d_reps, ps->d_norms, d_x, d_y,
+        DEV(lsk_tile_wv(pl->dop, pl->dbs, ps->index, pl->gd, pl->cplx, 0, pl->P, pid, row0, row1, ps->d_reps, ps->d_norms, d_x, d_y,
                         ps->d_wtab + (size_t)ps->wtab_first[round] * pl->P, ps->d_layouts + round, d_send, pl->d_err, stream));
     else
         DEV(lsk_tile(pl->dop, pl->dbs, ps->index, pl->cplx, 0, pl->P, pid, row0, row1, ps->d_reps, ps->d_norms, d_x,
@@ -2712,10 +2773,54 @@ int ls_amd_scatter(ls_amd_plan *pl, int64_t n, uint64_t const *d_betas, void con
     part_state *ps = &pl->parts[0];
     if (ps->index.kind == LSK_INDEX_COMBINADIC) return set_error("ls_amd_scatter: plan has no search index");
     int const st = stage_begin(pl, ST_SCATTER, stream);
-    DEV(lsk_scatter(ps->index, pl->cplx, n, d_betas, d_values, d_y, pl->dbs.k4_mode ? ps->d_norms : NULL, pl->d_err,
-                    stream));
+    if (pl->key_bytes == 4) { /* pre-indexed packets: d_betas is the segment's u32 index array */
+        lsk_segs sg;
+        memset(&sg, 0, sizeof(sg));
+        sg.n = 1; sg.start[0] = 0; sg.start[1] = n; sg.key_off[0] = 0;
+        sg.val_off[0] = (int64_t)((char const *)d_values - (char const *)d_betas);
+        sg.y[0] = d_y;
+        DEV(lsk_scatter_idx(pl->cplx, &sg, d_betas, stream));
+    } else
+        DEV(lsk_scatter(ps->index, pl->cplx, n, d_betas, d_values, d_y, pl->dbs.k4_mode ? ps->d_norms : NULL, pl->d_err,
+                        stream));
     stage_end(pl, st, stream);
     return 0;
+}
+/* All segments of one round's receive buffer in ONE launch (consumer side of a rank): segment s holds counts[s] packets at
+ * d_recv + offsets[s], laid out as ls_amd_plan_segment_bytes describes.  (The per-segment form above cost 56 launches per
+ * matvec on chain_28 x 8.) */
+int ls_amd_scatter_round(ls_amd_plan *pl, int num_segments, int64_t const *counts, int64_t const *offsets, void const *d_recv,
+                         void *d_y, void *stream) {
+    part_state *ps = &pl->parts[0];
+    if (ps->index.kind == LSK_INDEX_COMBINADIC) return set_error("ls_amd_scatter_round: plan has no search index");
+    int const st = stage_begin(pl, ST_SCATTER, stream);
+    int s = 0;
+    while (s < num_segments) {
+        lsk_segs sg;
+        memset(&sg, 0, sizeof(sg));
+        int64_t total = 0;
+        for (; s < num_segments && sg.n < LSK_MAX_SEGS; ++s) {
+            if (counts[s] <= 0) continue;
+            sg.start[sg.n] = total;
+            sg.key_off[sg.n] = offsets[s];
+            sg.val_off[sg.n] = offsets[s] + segment_key_bytes(pl, counts[s]);
+            sg.y[sg.n] = d_y;
+            total += counts[s];
+            ++sg.n;
+        }
+        if (sg.n == 0) break;
+        sg.start[sg.n] = total;
+        if (pl->key_bytes == 4) DEV(lsk_scatter_idx(pl->cplx, &sg, d_recv, stream));
+        else DEV(lsk_scatter_segs(ps->index, pl->cplx, &sg, d_recv, pl->dbs.k4_mode ? ps->d_norms : NULL, pl->d_err, stream));
+    }
+    stage_end(pl, st, stream);
+    return 0;
+}
+int ls_amd_plan_key_bytes(ls_amd_plan const *pl) { return pl->key_bytes; }
+int64_t ls_amd_plan_segment_bytes(ls_amd_plan const *pl, int64_t count) { return segment_key_bytes(pl, count) + (pl->cplx ? 16 : 8) * count; }
+int64_t ls_amd_plan_segment_value_offset(ls_amd_plan const *pl, int64_t count) { return segment_key_bytes(pl, count); }
+int64_t ls_amd_plan_packet_index_bytes(ls_amd_plan const *pl) {
+    return pl->d_gdir ? (int64_t)sizeof(lsk_rankdir) * ((pl->gd.n_ranks + 63) / 64) * pl->gd.P : 0;
 }
 
 int ls_amd_matvec(ls_amd_plan *pl, void const *const *d_x, void *const *d_y, void *stream) {
@@ -2834,6 +2939,29 @@ int ls_amd_matvec(ls_amd_plan *pl, void const *const *d_x, void *const *d_y, voi
         for (int r = 0; r < ps->rounds; ++r) {
             if (generate_round(pl, ps, p, r, d_x[p], d_y[p], pl->d_send, stream) != 0) return -1;
             /* the "exchange": every destination consumes its segment straight from the send buffer */
+            if (pl->key_bytes == 4) { /* pre-indexed packets: all destinations in one launch, each segment with its own y */
+                for (int d0 = 0; d0 < P; d0 += LSK_MAX_SEGS) {
+                    lsk_segs sg;
+                    memset(&sg, 0, sizeof(sg));
+                    int64_t total = 0;
+                    for (int d = d0; d < P && d < d0 + LSK_MAX_SEGS; ++d) {
+                        int64_t const c = ps->send_counts[(size_t)r * P + d];
+                        if (d == p || c == 0) continue;
+                        sg.start[sg.n] = total;
+                        sg.key_off[sg.n] = ps->h_beta_off[(size_t)r * P + d];
+                        sg.val_off[sg.n] = ps->h_val_off[(size_t)r * P + d];
+                        sg.y[sg.n] = d_y[d];
+                        total += c;
+                        ++sg.n;
+                    }
+                    if (sg.n == 0) continue;
+                    sg.start[sg.n] = total;
+                    int const st = stage_begin(pl, ST_SCATTER, stream);
+                    DEV(lsk_scatter_idx(pl->cplx, &sg, pl->d_send, stream));
+                    stage_end(pl, st, stream);
+                }
+                continue;
+            }
             for (int d = 0; d < P; ++d) {
                 int64_t c = ps->send_counts[(size_t)r * P + d];
                 if (d == p || c == 0) continue;

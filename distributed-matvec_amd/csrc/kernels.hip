@@ -284,6 +284,30 @@ __device__ __forceinline__ int64_t rankdir_index(lsk_index const &ix, uint64_t s
     return (int64_t)(uint32_t)e.y + __popcll(e.x & (bit - 1));
 }
 
+// All-destinations directory (lsk_gdir, lsk.h): index of state s inside the block of partition d, or -1 (s_db as above: the
+// binomials C(p, k), p < sites, k <= weight)
+__device__ __forceinline__ int64_t gdir_index(lsk_gdir const &gd, uint64_t s, int d, uint64_t const *s_db) {
+    const int kc = gd.weight + 1;
+    if (__popcll(s) != gd.weight || (gd.sites < 64 && (s >> gd.sites) != 0)) return -1;
+    uint64_t g = 0;
+    int k = 1;
+    while (s) {
+        const int p = __ffsll((unsigned long long)s) - 1;
+        g += s_db[p * kc + k];
+        ++k;
+        s &= s - 1;
+    }
+    if ((int64_t)g >= gd.n_ranks) return -1;
+    const ulonglong2 e = *reinterpret_cast<ulonglong2 const *>(gd.entries + (g >> 6) * (uint64_t)gd.P + (uint64_t)d);
+    const uint64_t bit = 1ULL << (g & 63);
+    if (!(e.x & bit)) return -1;
+    return (int64_t)(uint32_t)e.y + __popcll(e.x & (bit - 1));
+}
+__device__ __forceinline__ void gdir_load(lsk_gdir const &gd, uint64_t const *__restrict__ g_binom, uint64_t *s_db) { // (the caller synchronises)
+    const int kc = gd.weight + 1;
+    for (int i = threadIdx.x; i < gd.sites * kc; i += blockDim.x) s_db[i] = g_binom[(i / kc) * LSK_BINOM_K + (i % kc)];
+}
+
 // Open-addressing hash table {representative -> x * norm(rep)} used by the staged pull kernel.  The
 // uncoalesced per-lane loads of a search (table + ~5 probes + value = 8 line requests per packet) were what
 // bounded k_tile_pull (L1/TA issue: one line per lane per cycle); a hit in the home slot costs ONE 16-byte
@@ -2043,10 +2067,13 @@ constexpr int kTwGroups = 3;
 __device__ __forceinline__ int64_t readlane_i64(int64_t v, int lane) {
     return (int64_t)readlane_t<uint64_t>((uint64_t)v, lane);
 }
-template <typename W, bool PM1, bool CPLX, bool REAL, bool COUNT>
+// PK12 (pre-indexed packets; unprojected fixed-weight bases): the local index of EVERY packet at its destination -- the own
+// partition included -- is read off the all-destinations directory gd (one 16-byte load), remote packets leave as (u32 index,
+// value) and the consumer neither ranks nor searches.
+template <typename W, bool PM1, bool CPLX, bool REAL, bool COUNT, bool PK12>
 __global__ __launch_bounds__(kBlock) void k_tile_wv(int n_groups, lsk_group const *__restrict__ groups,
                                                     lsk_term const *__restrict__ off, lsk_basis bs,
-                                                    lsk_group_elem const *__restrict__ elems, lsk_index ix, Owner owner,
+                                                    lsk_group_elem const *__restrict__ elems, lsk_index ix, lsk_gdir gd, Owner owner,
                                                     int me, int64_t row0, int64_t row1, uint64_t const *__restrict__ reps,
                                                     double const *__restrict__ norms, double const *__restrict__ x, double *y,
                                                     uint32_t *__restrict__ wtab, lsk_round_layout const *__restrict__ layout,
@@ -2055,7 +2082,8 @@ __global__ __launch_bounds__(kBlock) void k_tile_wv(int n_groups, lsk_group cons
     __shared__ uint64_t s_beta[kCap];
     __shared__ double s_val[COUNT ? 1 : kCap * (CPLX ? 2 : 1)];
     extern __shared__ uint64_t s_db[]; // rank directory of the own partition: binomials of the closed-form rank (0 bytes without one)
-    if (!COUNT && ix.dir) { rankdir_load(ix, s_db); __syncthreads(); }
+    if (!COUNT && PK12) { gdir_load(gd, ix.binom, s_db); __syncthreads(); }
+    else if (!COUNT && ix.dir) { rankdir_load(ix, s_db); __syncthreads(); }
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -2113,7 +2141,18 @@ __global__ __launch_bounds__(kBlock) void k_tile_wv(int n_groups, lsk_group cons
             }
             const int dest = live ? owner_of(beta, owner) : -1;
             bool remote = live;
-            if (!COUNT) {
+            uint32_t pidx = 0; // PK12: the packet's index inside its destination's block
+            if (!COUNT && PK12) {
+                if (live) {
+                    const int64_t idx = gdir_index(gd, beta, dest, s_db);
+                    if (idx < 0) { atomicExch(err, 1); remote = false; } // not a basis state (DMV:115-118)
+                    else if (dest == me) {
+                        remote = false;
+                        if (CPLX) { atomic_add_f64(y + 2 * idx, vr); atomic_add_f64(y + 2 * idx + 1, vi); }
+                        else atomic_add_f64(y + idx, vr);
+                    } else pidx = (uint32_t)idx;
+                }
+            } else if (!COUNT) {
                 if (live && dest == me) {
                     remote = false;
                     const int64_t idx = ix.dir ? rankdir_index(ix, beta, s_db) : search_index(ix, beta);
@@ -2137,7 +2176,8 @@ __global__ __launch_bounds__(kBlock) void k_tile_wv(int n_groups, lsk_group cons
                     const int64_t ob = readlane_i64(seg_b, d), ov = readlane_i64(seg_v, d);
                     if (mine) {
                         const size_t pos = (size_t)base + (size_t)__popcll(mm & ((1ULL << lane) - 1));
-                        reinterpret_cast<uint64_t *>(send + ob)[pos] = beta;
+                        if (PK12) reinterpret_cast<uint32_t *>(send + ob)[pos] = pidx;
+                        else reinterpret_cast<uint64_t *>(send + ob)[pos] = beta;
                         double *pv = reinterpret_cast<double *>(send + ov);
                         if (CPLX) { pv[2 * pos] = vr; pv[2 * pos + 1] = vi; } else pv[pos] = vr;
                     }
@@ -2186,29 +2226,40 @@ extern "C" int lsk_tile_wv_max_parts(void) { return 64; }
 // rows [row0, row1) of partition `me` (row0 = first row of the round: wave w of the round owns rows row0 + 64 w ...).
 // count_only: wtab[w][P] <- packets of wave w per destination (the own partition included); otherwise wtab holds the
 // exclusive offsets of every (wave, destination) inside the round's segments and the packets are written to d_send.
-extern "C" int lsk_tile_wv(lsk_operator op, lsk_basis bs, lsk_index ix, int cplx, int count_only, int P, int me,
+extern "C" int lsk_tile_wv(lsk_operator op, lsk_basis bs, lsk_index ix, lsk_gdir gd, int cplx, int count_only, int P, int me,
                            int64_t row0, int64_t row1, uint64_t const *reps, double const *norms, void const *x, void *y,
                            uint32_t *d_wtab, lsk_round_layout const *d_layout, void *d_send, int *d_err, void *stream) {
     if (row1 <= row0 || op.n_groups == 0) return 0;
     if (P > lsk_tile_wv_max_parts() || P < 1 || !d_wtab) { snprintf(g_err, sizeof(g_err), "lsk_tile_wv: bad partition count %d or no wave table", P); return -1; }
-    if (!count_only && ix.kind != LSK_INDEX_SEARCH) { snprintf(g_err, sizeof(g_err), "lsk_tile_wv needs a SEARCH index"); return -1; }
+    const bool pk12 = !count_only && gd.entries != nullptr;
+    if (!count_only && !pk12 && ix.kind != LSK_INDEX_SEARCH) { snprintf(g_err, sizeof(g_err), "lsk_tile_wv needs a SEARCH index"); return -1; }
+    if (pk12 && (bs.proj == LSK_PROJ_FULL || gd.P != P || !ix.binom)) { snprintf(g_err, sizeof(g_err), "lsk_tile_wv: pre-indexed packets need an unprojected basis and a directory over %d partitions", P); return -1; }
     Owner ow = make_owner(P);
     dim3 g(1), b(kBlock);
     const int64_t work_blocks = (row1 - row0 + kBlock - 1) / kBlock;
     hipStream_t s = (hipStream_t)stream;
-    const size_t dyn_db = ix.dir ? sizeof(uint64_t) * (size_t)ix.dir_sites * (size_t)(ix.dir_weight + 1) : 0;
-#define LSK_TW_ARGS op.n_groups, op.groups, op.off, bs, bs.elems, ix, ow, me, row0, row1, reps, norms, (double const *)x, (double *)y, \
+    const size_t dyn_db = pk12 ? sizeof(uint64_t) * (size_t)gd.sites * (size_t)(gd.weight + 1)
+                               : (ix.dir ? sizeof(uint64_t) * (size_t)ix.dir_sites * (size_t)(ix.dir_weight + 1) : 0);
+#define LSK_TW_ARGS op.n_groups, op.groups, op.off, bs, bs.elems, ix, gd, ow, me, row0, row1, reps, norms, (double const *)x, (double *)y, \
         d_wtab, d_layout, (char *)d_send, d_err
 #define LSK_TW_ONE(W, PM1, CPLX, REAL)                                                                                           \
     do {                                                                                                                         \
-        if (count_only) { g.x = tile_grid(k_tile_wv<W, PM1, CPLX, REAL, true>, work_blocks); hipLaunchKernelGGL((k_tile_wv<W, PM1, CPLX, REAL, true>), g, b, 0, s, LSK_TW_ARGS); } \
-        else { g.x = tile_grid(k_tile_wv<W, PM1, CPLX, REAL, false>, work_blocks); hipLaunchKernelGGL((k_tile_wv<W, PM1, CPLX, REAL, false>), g, b, dyn_db, s, LSK_TW_ARGS); } \
+        if (count_only) { g.x = tile_grid(k_tile_wv<W, PM1, CPLX, REAL, true, false>, work_blocks); hipLaunchKernelGGL((k_tile_wv<W, PM1, CPLX, REAL, true, false>), g, b, 0, s, LSK_TW_ARGS); } \
+        else { g.x = tile_grid(k_tile_wv<W, PM1, CPLX, REAL, false, false>, work_blocks); hipLaunchKernelGGL((k_tile_wv<W, PM1, CPLX, REAL, false, false>), g, b, dyn_db, s, LSK_TW_ARGS); } \
     } while (0)
 #define LSK_TW_LAUNCH(W, PM1)                                                                                  \
     do {                                                                                                       \
         if (cplx) { if (op.is_real) LSK_TW_ONE(W, PM1, true, true); else LSK_TW_ONE(W, PM1, true, false); }    \
         else LSK_TW_ONE(W, PM1, false, true); /* f64 vectors: real operators only (the plan refuses the rest) */ \
     } while (0)
+    if (pk12) { // unprojected bases only: W / PM1 are irrelevant
+        if (cplx) {
+            if (op.is_real) { g.x = tile_grid(k_tile_wv<uint64_t, true, true, true, false, true>, work_blocks); hipLaunchKernelGGL((k_tile_wv<uint64_t, true, true, true, false, true>), g, b, dyn_db, s, LSK_TW_ARGS); }
+            else { g.x = tile_grid(k_tile_wv<uint64_t, true, true, false, false, true>, work_blocks); hipLaunchKernelGGL((k_tile_wv<uint64_t, true, true, false, false, true>), g, b, dyn_db, s, LSK_TW_ARGS); }
+        } else { g.x = tile_grid(k_tile_wv<uint64_t, true, false, true, false, true>, work_blocks); hipLaunchKernelGGL((k_tile_wv<uint64_t, true, false, true, false, true>), g, b, dyn_db, s, LSK_TW_ARGS); }
+        LSK_LAUNCH_CHECK();
+        return 0;
+    }
     const bool narrow = bs.number_sites <= 32 && bs.proj == LSK_PROJ_FULL;
     if (narrow) { if (bs.chars_pm1) LSK_TW_LAUNCH(uint32_t, true); else LSK_TW_LAUNCH(uint32_t, false); }
     else if (bs.proj == LSK_PROJ_FULL) { if (bs.chars_pm1) LSK_TW_LAUNCH(uint64_t, true); else LSK_TW_LAUNCH(uint64_t, false); }
@@ -3327,6 +3378,98 @@ extern "C" int lsk_scatter(lsk_index ix, int cplx, int64_t n, uint64_t const *be
     return 0;
 }
 
+// Fused consumers: ONE launch over all segments of a round's receive buffer (chain_28 x 8 partitions ran 56 launches of 0.26 ms
+// per matvec, each with its own ramp and tail).  Block b takes packets [256 b, 256 b + 256) of the concatenated count space;
+// the segment of a packet is found in an LDS copy of the (<= 65) segment starts.
+__device__ __forceinline__ int seg_of(int64_t const *s_start, int n, int64_t k) {
+    int lo = 0, hi = n; // largest s with start[s] <= k
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (s_start[mid] <= k) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+template <bool CPLX>
+__global__ __launch_bounds__(kBlock) void k_scatter_idx(lsk_segs segs, char const *__restrict__ base, int xcd_chunk) {
+    __shared__ int64_t s_start[LSK_MAX_SEGS + 1];
+    for (int i = threadIdx.x; i <= segs.n; i += kBlock) s_start[i] = segs.start[i];
+    __syncthreads();
+    const int64_t n = segs.start[segs.n];
+    const int64_t n_blocks = (n + kBlock - 1) / kBlock;
+    for (int64_t kb = blockIdx.x; kb < n_blocks; kb += gridDim.x) {
+        const int64_t k = pull_tile_of_block(kb, n_blocks, gridDim.x >= n_blocks ? xcd_chunk : 0) * kBlock + threadIdx.x;
+        if (k >= n) continue;
+        const int sg = seg_of(s_start, segs.n, k);
+        const int64_t j = k - s_start[sg];
+        const uint32_t idx = reinterpret_cast<uint32_t const *>(base + segs.key_off[sg])[j];
+        double const *vals = reinterpret_cast<double const *>(base + segs.val_off[sg]);
+        double *y = reinterpret_cast<double *>(segs.y[sg]);
+        if (CPLX) {
+            const double vr = vals[2 * j], vi = vals[2 * j + 1];
+            if (vr == 0.0 && vi == 0.0) continue; // DMV:110
+            atomic_add_f64(y + 2 * (size_t)idx, vr);
+            atomic_add_f64(y + 2 * (size_t)idx + 1, vi);
+        } else {
+            const double vr = vals[j];
+            if (vr == 0.0) continue;
+            atomic_add_f64(y + idx, vr);
+        }
+    }
+}
+extern "C" int lsk_scatter_idx(int cplx, lsk_segs const *segs, void const *base, void *stream) {
+    if (segs->n < 1 || segs->n > LSK_MAX_SEGS) { snprintf(g_err, sizeof(g_err), "lsk_scatter_idx: %d segments", segs->n); return -1; }
+    const int64_t n = segs->start[segs->n];
+    if (n <= 0) return 0;
+    const int64_t nb = (n + kBlock - 1) / kBlock;
+    dim3 g((unsigned)(nb < ((int64_t)1 << 30) ? nb : ((int64_t)1 << 30))), b(kBlock);
+    if (cplx) hipLaunchKernelGGL(k_scatter_idx<true>, g, b, 0, (hipStream_t)stream, *segs, (char const *)base, 64);
+    else hipLaunchKernelGGL(k_scatter_idx<false>, g, b, 0, (hipStream_t)stream, *segs, (char const *)base, 64);
+    LSK_LAUNCH_CHECK();
+    return 0;
+}
+// ... and for packets that carry the state (projected bases, or no room for the all-destinations directory): one index, one y
+template <bool CPLX>
+__global__ __launch_bounds__(kBlock) void k_scatter_segs(lsk_index ix, lsk_segs segs, char const *__restrict__ base,
+                                                         double const *__restrict__ norms, int *err, int xcd_chunk) {
+    __shared__ int64_t s_start[LSK_MAX_SEGS + 1];
+    extern __shared__ uint64_t s_db[];
+    for (int i = threadIdx.x; i <= segs.n; i += kBlock) s_start[i] = segs.start[i];
+    if (ix.dir) rankdir_load(ix, s_db);
+    __syncthreads();
+    const int64_t n = segs.start[segs.n];
+    const int64_t n_blocks = (n + kBlock - 1) / kBlock;
+    double *y = reinterpret_cast<double *>(segs.y[0]);
+    for (int64_t kb = blockIdx.x; kb < n_blocks; kb += gridDim.x) {
+        const int64_t k = pull_tile_of_block(kb, n_blocks, gridDim.x >= n_blocks ? xcd_chunk : 0) * kBlock + threadIdx.x;
+        if (k >= n) continue;
+        const int sg = seg_of(s_start, segs.n, k);
+        const int64_t j = k - s_start[sg];
+        double const *vals = reinterpret_cast<double const *>(base + segs.val_off[sg]);
+        double vr, vi = 0.0;
+        if (CPLX) { vr = vals[2 * j]; vi = vals[2 * j + 1]; } else vr = vals[j];
+        if (vr == 0.0 && vi == 0.0) continue; // DMV:110
+        const uint64_t beta = reinterpret_cast<uint64_t const *>(base + segs.key_off[sg])[j];
+        const int64_t idx = ix.kind == LSK_INDEX_IDENTITY ? (int64_t)beta : (ix.dir ? rankdir_index(ix, beta, s_db) : search_index(ix, beta));
+        if (idx < 0) { atomicExch(err, 1); continue; }
+        if (norms) { const double nb = norms[idx]; vr *= nb; vi *= nb; }
+        if (CPLX) { atomic_add_f64(y + 2 * idx, vr); atomic_add_f64(y + 2 * idx + 1, vi); }
+        else atomic_add_f64(y + idx, vr);
+    }
+}
+extern "C" int lsk_scatter_segs(lsk_index ix, int cplx, lsk_segs const *segs, void const *base, double const *norms, int *d_err, void *stream) {
+    if (segs->n < 1 || segs->n > LSK_MAX_SEGS) { snprintf(g_err, sizeof(g_err), "lsk_scatter_segs: %d segments", segs->n); return -1; }
+    if (ix.kind == LSK_INDEX_COMBINADIC) { snprintf(g_err, sizeof(g_err), "lsk_scatter_segs: SEARCH/IDENTITY index only"); return -1; }
+    const int64_t n = segs->start[segs->n];
+    if (n <= 0) return 0;
+    const int64_t nb = (n + kBlock - 1) / kBlock;
+    dim3 g((unsigned)(nb < ((int64_t)1 << 30) ? nb : ((int64_t)1 << 30))), b(kBlock);
+    const size_t dyn = ix.dir ? sizeof(uint64_t) * (size_t)ix.dir_sites * (size_t)(ix.dir_weight + 1) : 0;
+    if (cplx) hipLaunchKernelGGL(k_scatter_segs<true>, g, b, dyn, (hipStream_t)stream, ix, *segs, (char const *)base, norms, d_err, 64);
+    else hipLaunchKernelGGL(k_scatter_segs<false>, g, b, dyn, (hipStream_t)stream, ix, *segs, (char const *)base, norms, d_err, 64);
+    LSK_LAUNCH_CHECK();
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // out[i] = src[perm[i]]: the hashed -> block permutation of the replicated-x exchange (P ascending streams interleaved).
 // Two outputs per thread so that f64 results leave as 16-byte stores; perm is read with 8- / 16-byte loads.
@@ -3757,6 +3900,78 @@ extern "C" int lsk_rankdir_build(int64_t n, uint64_t const *reps, int sites, int
     (void)hipFree(scratch);
     if (rc != 0) { snprintf(g_err, sizeof(g_err), "lsk_rankdir_build: launch failed"); return -1; }
     LSK_CHECK(e2);
+    return 0;
+}
+
+// ---- all-destinations directory (lsk_gdir): every rank derives it alone -- the owner of a state is a hash of the state ----------
+// thread = one word of 64 consecutive global ranks: unrank the first, Gosper-step through the rest, mark each in its owner's entry
+__global__ __launch_bounds__(kBlock) void k_gdir_mark(lsk_gdir gd, Owner ow, uint64_t const *__restrict__ g_binom, int64_t words,
+                                                      lsk_rankdir *__restrict__ entries) {
+    __shared__ uint64_t s_binom[64 * LSK_BINOM_K];
+    load_binom(s_binom, g_binom);
+    for (int64_t w = (int64_t)blockIdx.x * kBlock + threadIdx.x; w < words; w += (int64_t)gridDim.x * kBlock) {
+        const int64_t g0 = w << 6, g1 = g0 + 64 < gd.n_ranks ? g0 + 64 : gd.n_ranks;
+        uint64_t s = unrank_combinadic(g0, gd.weight, s_binom);
+        lsk_rankdir *row = entries + w * (int64_t)gd.P;
+        for (int64_t g = g0; g < g1; ++g) {
+            row[owner_of(s, ow)].bits |= 1ULL << (g - g0); // (this thread owns the whole row)
+            s = next_fixed_hamming(s);
+        }
+    }
+}
+struct ScanGdirPopcIn {
+    lsk_rankdir const *entries;
+    int64_t P, d;
+    __device__ int64_t operator()(int64_t w) const { return (int64_t)__popcll(entries[w * P + d].bits); }
+};
+__global__ __launch_bounds__(kBlock) void k_gdir_prefix(int64_t words, int64_t P, int64_t d, int64_t const *__restrict__ pre,
+                                                        lsk_rankdir *__restrict__ entries) {
+    for (int64_t w = (int64_t)blockIdx.x * kBlock + threadIdx.x; w < words; w += (int64_t)gridDim.x * kBlock) {
+        entries[w * P + d].prefix = (uint32_t)pre[w];
+        entries[w * P + d].pad = 0;
+    }
+}
+extern "C" int lsk_gdir_build(lsk_gdir gd, lsk_rankdir *entries, uint64_t const *d_binom, void *stream) {
+    if (gd.P < 1 || gd.P > LSK_MAX_PARTS || gd.sites < 1 || gd.sites > 64 || gd.weight < 0 || gd.weight >= LSK_BINOM_K - 1 || gd.n_ranks < 1) {
+        snprintf(g_err, sizeof(g_err), "lsk_gdir_build: bad arguments"); return -1;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t words = (gd.n_ranks + 63) >> 6;
+    LSK_CHECK(hipMemsetAsync(entries, 0, sizeof(lsk_rankdir) * (size_t)words * (size_t)gd.P, s));
+    hipLaunchKernelGGL(k_gdir_mark, dim3(grid_for(words)), dim3(kBlock), 0, s, gd, make_owner(gd.P), d_binom, words, entries);
+    LSK_LAUNCH_CHECK();
+    int64_t *pre = nullptr, *scratch = nullptr;
+    LSK_CHECK(hipMalloc((void **)&pre, 8 * (size_t)words));
+    if (hipMalloc((void **)&scratch, 8 * (size_t)scan_scratch_elems(words)) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(pre); snprintf(g_err, sizeof(g_err), "lsk_gdir_build: out of memory"); return -1; }
+    int rc = 0;
+    for (int d = 0; d < gd.P && rc == 0; ++d) { // one exclusive scan of the popcounts per destination
+        ScanGdirPopcIn in{entries, gd.P, d};
+        rc = exclusive_scan<ScanGdirPopcIn>(in, words, pre, scratch, s);
+        if (rc == 0) {
+            hipLaunchKernelGGL(k_gdir_prefix, dim3(grid_for(words)), dim3(kBlock), 0, s, words, (int64_t)gd.P, (int64_t)d, pre, entries);
+            if (hipGetLastError() != hipSuccess) rc = -1;
+        }
+    }
+    const hipError_t e2 = hipStreamSynchronize(s);
+    (void)hipFree(pre);
+    (void)hipFree(scratch);
+    if (rc != 0) { snprintf(g_err, sizeof(g_err), "lsk_gdir_build: launch failed"); return -1; }
+    LSK_CHECK(e2);
+    return 0;
+}
+__global__ __launch_bounds__(kBlock) void k_gdir_check(lsk_gdir gd, Owner ow, int part, int64_t n, uint64_t const *__restrict__ reps,
+                                                       uint64_t const *__restrict__ g_binom, int *flag) {
+    extern __shared__ uint64_t s_db[];
+    gdir_load(gd, g_binom, s_db);
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+        if (owner_of(reps[i], ow) != part || gdir_index(gd, reps[i], part, s_db) != i) atomicExch(flag, 1);
+}
+extern "C" int lsk_gdir_check(lsk_gdir gd, int part, int64_t n, uint64_t const *reps, uint64_t const *d_binom, int *d_flag, void *stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_gdir_check, dim3(grid_for(n)), dim3(kBlock), sizeof(uint64_t) * (size_t)gd.sites * (size_t)(gd.weight + 1), (hipStream_t)stream,
+                       gd, make_owner(gd.P), part, n, reps, d_binom, d_flag);
+    LSK_LAUNCH_CHECK();
     return 0;
 }
 

@@ -120,6 +120,36 @@ typedef struct lsk_index {
 int lsk_rankdir_build(int64_t n, uint64_t const *reps, int sites, int weight, uint64_t const *d_binom, int64_t entries, lsk_rankdir *dir,
                       int *d_flag, void *stream);
 
+/* All-destinations rank directory of the hash partition of an unprojected fixed-weight basis (pre-indexed packets): entry
+ * [w * P + d] describes what partition d owns of the global (colex) ranks [64 w, 64 w + 64).  The owner of a state is a hash
+ * of the state, so every rank builds the whole table by itself (unrank -> owner, one pass over the basis at plan time).  The
+ * PRODUCER of a packet then knows the index of beta inside its destination's block:
+ *     idx = e.prefix + popcount(e.bits & below(g)),  e = entries[(g >> 6) * P + owner(beta)],  member <=> bit g & 63 of e.bits
+ * and sends (u32 idx, value): 12 instead of 16 bytes per packet, and the consumer is search-free.  P / 4 bytes per basis state. */
+typedef struct lsk_gdir {
+    lsk_rankdir const *entries; /* device [words * P]; NULL = no directory (packets carry the state) */
+    int P, sites, weight;
+    int64_t n_ranks;            /* global ranks [0, n_ranks) are basis states (C(sites, weight), or its lower half under inversion) */
+} lsk_gdir;
+/* entries: ceil(n_ranks / 64) * P, allocated by the caller; synchronises the stream */
+int lsk_gdir_build(lsk_gdir gd, lsk_rankdir *entries, uint64_t const *d_binom, void *stream);
+/* *d_flag is raised unless the directory gives reps[i] -> (part, i) back for the n ascending states of partition `part` */
+int lsk_gdir_check(lsk_gdir gd, int part, int64_t n, uint64_t const *reps, uint64_t const *d_binom, int *d_flag, void *stream);
+
+/* the segments of one fused consumer launch (one round's receive buffer, or the send buffer of a logical partition) */
+#define LSK_MAX_SEGS 64
+typedef struct lsk_segs {
+    int n;
+    int64_t start[LSK_MAX_SEGS + 1]; /* exclusive prefix of the packet counts */
+    int64_t key_off[LSK_MAX_SEGS];   /* byte offset of the segment's u64 states / u32 indices */
+    int64_t val_off[LSK_MAX_SEGS];   /* ... of its values */
+    void *y[LSK_MAX_SEGS];           /* the vector the segment accumulates into (all the same with one partition per process) */
+} lsk_segs;
+/* every packet of every segment: y[seg][idx] += value; pre-indexed packets (u32 idx) */
+int lsk_scatter_idx(int cplx, lsk_segs const *segs, void const *base, void *stream);
+/* the same for packets that carry the state: ONE index (all segments belong to the same destination partition) */
+int lsk_scatter_segs(lsk_index ix, int cplx, lsk_segs const *segs, void const *base, double const *norms, int *d_err, void *stream);
+
 /* per-round send layout: byte offsets of the beta / value arrays of every destination segment */
 typedef struct lsk_round_layout {
     int64_t beta_off[LSK_MAX_PARTS];
@@ -232,7 +262,9 @@ int lsk_tile(lsk_operator op, lsk_basis bs, lsk_index ix, int cplx, int count_on
  * the exclusive offsets of every (wave, destination) inside the round's segments of *d_layout.  No cursors, no atomics on
  * the send side; the packet order does not depend on the block schedule. */
 int lsk_tile_wv_max_parts(void);
-int lsk_tile_wv(lsk_operator op, lsk_basis bs, lsk_index ix, int cplx, int count_only, int P, int me,
+/* gd.entries != NULL: pre-indexed packets -- every packet's local index at its destination comes out of the all-destinations
+ * directory (own-partition packets included: ix is not used), and the send segments hold u32 indices instead of u64 states */
+int lsk_tile_wv(lsk_operator op, lsk_basis bs, lsk_index ix, lsk_gdir gd, int cplx, int count_only, int P, int me,
                 int64_t row0, int64_t row1, uint64_t const *reps, double const *norms, void const *x, void *y,
                 uint32_t *d_wtab, lsk_round_layout const *d_layout, void *d_send, int *d_err, void *stream);
 /* replicated-x pull (Hermitian operators): rows of ONE partition against the whole vector in global

@@ -119,6 +119,13 @@ class HipEngine:
         self.num_rounds = self.plan.num_rounds
         self.packet_bytes = self.plan.packet_bytes
 
+    def segment_bytes(self, count):
+        """bytes of a segment of `count` packets (keys padded to 8 bytes, then values; include/ls_amd.h)"""
+        return self.plan.segment_bytes(count)
+
+    def scatter_round(self, recv, counts, offsets, y):
+        self.plan.scatter_round(counts, offsets, recv.data_ptr(), y)
+
     def send_counts(self, rnd):
         return self.plan.send_counts(rnd)
 
@@ -133,7 +140,7 @@ class HipEngine:
 
     def scatter(self, recv, byte_offset, n, y):
         base = recv.data_ptr() + byte_offset
-        self.plan.scatter(n, base, base + 8 * n, y)
+        self.plan.scatter(n, base, base + self.plan.segment_value_offset(n), y)
 
     def check(self):
         self.plan.check()
@@ -179,12 +186,16 @@ class DistributedOperator:
         self.send_counts = S.t().tolist()             # [round][dest]
         self.recv_counts = R_dev.cpu().t().tolist()   # [round][src]
         self.packet_bytes = pb
-        max_send = max(sum(c) for c in self.send_counts) * pb
-        max_recv = max(sum(c) for c in self.recv_counts) * pb
+        # bytes of a segment of c packets: the engine's layout (pre-indexed packets pad their u32 keys to 8 bytes), else c * pb
+        seg = getattr(self.engine, "segment_bytes", None) or (lambda c: c * pb)
+        self.send_bytes = [[seg(c) for c in row] for row in self.send_counts]
+        self.recv_bytes = [[seg(c) for c in row] for row in self.recv_counts]
+        max_send = max(sum(b) for b in self.send_bytes)
+        max_recv = max(sum(b) for b in self.recv_bytes)
         # double-buffered so that generate(r + 1) can be queued while exchange(r) is in flight
         self.send_bufs = [self.engine.alloc_bytes(max_send) for _ in range(2)]
         self.recv_bufs = [self.engine.alloc_bytes(max_recv) for _ in range(2)]
-        self.exchange_bytes_per_matvec = sum(sum(c) for c in self.send_counts) * pb
+        self.exchange_bytes_per_matvec = sum(sum(b) for b in self.send_bytes)
 
     def matvec(self, x, y, check: bool = False):
         """y <- H x for this rank's blocks of the hashed vectors.
@@ -199,8 +210,7 @@ class DistributedOperator:
 
         def exchange(r):
             send, recv = self.send_bufs[r & 1], self.recv_bufs[r & 1]
-            in_splits = [c * pb for c in self.send_counts[r]]
-            out_splits = [c * pb for c in self.recv_counts[r]]
+            in_splits, out_splits = self.send_bytes[r], self.recv_bytes[r]
             n_in, n_out = sum(in_splits), sum(out_splits)
             return self.transport.all_to_all_single(recv[:max(n_out, 0)], send[:max(n_in, 0)], out_splits, in_splits,
                                                     async_op=True)
@@ -214,12 +224,16 @@ class DistributedOperator:
                 nxt = exchange(r + 1)
             work.wait()
             recv = self.recv_bufs[r & 1]
-            off = 0
+            offs, off = [], 0
             for s in range(self.P):
-                n = self.recv_counts[r][s]
-                if n:
-                    eng.scatter(recv, off, n, y)
-                off += n * pb
+                offs.append(off)
+                off += self.recv_bytes[r][s]
+            if hasattr(eng, "scatter_round"):  # all segments of the round in one consumer launch
+                eng.scatter_round(recv, self.recv_counts[r], offs, y)
+            else:
+                for s in range(self.P):
+                    if self.recv_counts[r][s]:
+                        eng.scatter(recv, offs[s], self.recv_counts[r][s], y)
             work = nxt
         if check:
             eng.check()

@@ -301,6 +301,24 @@ int ls_amd_generate(ls_amd_plan *plan, int round, void const *d_x, void *d_y, vo
                     void *stream);
 int ls_amd_scatter(ls_amd_plan *plan, int64_t n, uint64_t const *d_betas, void const *d_values,
                    void *d_y, void *stream);
+/* Packet layout.  A segment of c packets is [key x c (padded to 8 bytes)][value x c]:
+ *   ls_amd_plan_key_bytes == 8   the key is the state beta (u64) and the consumer ranks / searches it (every projected basis)
+ *   ls_amd_plan_key_bytes == 4   PRE-INDEXED packets (hash partitions of unprojected fixed-weight bases): the key is the u32
+ *                                index of beta inside the destination's block -- the producer reads it off an
+ *                                all-destinations rank directory every rank derives alone (the owner of a state is a hash of
+ *                                the state): 12 instead of 16 bytes per f64 packet on the wire and a search-free consumer, for
+ *                                P / 4 bytes of HBM per basis state (ls_amd_plan_packet_index_bytes); taken while that fits
+ *                                LS_AMD_PACKET_INDEX_MAX (default: a quarter of the free HBM), LS_AMD_PACKET_INDEX=0: never
+ * ls_amd_plan_segment_bytes(c) = bytes of such a segment (what the all-to-all-v moves per (round, peer));
+ * ls_amd_plan_segment_value_offset(c) = where its values start; ls_amd_plan_packet_bytes = key + value bytes (nominal).
+ * ls_amd_scatter takes either kind (d_betas = the segment's key array).  ls_amd_scatter_round consumes ALL segments of a
+ * round's receive buffer in one launch: segment s = counts[s] packets at d_recv + offsets[s]. */
+int ls_amd_plan_key_bytes(ls_amd_plan const *plan);
+int64_t ls_amd_plan_segment_bytes(ls_amd_plan const *plan, int64_t count);
+int64_t ls_amd_plan_segment_value_offset(ls_amd_plan const *plan, int64_t count);
+int64_t ls_amd_plan_packet_index_bytes(ls_amd_plan const *plan);
+int ls_amd_scatter_round(ls_amd_plan *plan, int num_segments, int64_t const *counts, int64_t const *offsets,
+                         void const *d_recv, void *d_y, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Basis construction on the device (enumerateStates, StatesEnumeration.chpl:516-585) and the

@@ -1190,3 +1190,58 @@ def test_host_pointer_boundary_memory_kinds(torch, monkeypatch, name):
     assert_close(y, want[1])
     L.ls_amd_boundary_stats_get(C.byref(st), 1)
     assert st.device_x == 1 and st.device_y == 0 and st.bytes_d2h == 8 * n
+
+
+@pytest.mark.parametrize("case", ["heisenberg_chain_16/3/f64", "heisenberg_chain_16/8/c128", "heisenberg_chain_10/2/f64",
+                                  "heisenberg_kagome_16/4/c128", "heisenberg_chain_20/8/f64", "heisenberg_kagome_12/5/f64"])
+def test_pre_indexed_packets(torch, monkeypatch, case):
+    """Packet plans over hash partitions of an unprojected fixed-weight basis send (u32 index at the destination, value): the
+    producer reads the index off the all-destinations rank directory (include/ls_amd.h, "Packet layout"), the consumers neither
+    rank nor search and run as ONE launch per round.  Equal to the oracle; equal to the state-carrying packets
+    (LS_AMD_PACKET_INDEX=0) that every projected basis keeps; a ceiling the directory does not fit (LS_AMD_PACKET_INDEX_MAX)
+    falls back to them -- the O(N / P)-memory form -- by itself."""
+    name, P, dt = case.split("/")
+    P = int(P)
+    D, basis, h, reps, masks = setup_model(torch, model_config(name), P)
+    want_reps = oracle_reps(name)
+    rng = np.random.RandomState(46)
+    x = rng.rand(len(want_reps)) - 0.5
+    if dt == "c128":
+        x = x + 1j * (rng.rand(len(want_reps)) - 0.5)
+    want = oracle_for(name).local_matvec(want_reps, x)
+    results = {}
+    for label, env in (("indexed", {}), ("states", {"LS_AMD_PACKET_INDEX": "0"}), ("ceiling", {"LS_AMD_PACKET_INDEX_MAX": "64"})):
+        for k in ("LS_AMD_PACKET_INDEX", "LS_AMD_PACKET_INDEX_MAX"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        h.clear_plans()
+        got, pl = run_matvec(torch, D, h, reps, masks, x, P)
+        assert pl.kernel == "tile"
+        assert pl.key_bytes == (4 if label == "indexed" else 8), label
+        w = 16 if dt == "c128" else 8
+        assert pl.packet_bytes == pl.key_bytes + w
+        assert pl.segment_bytes(5) == (24 if label == "indexed" else 40) + 5 * w and pl.segment_value_offset(5) == (24 if label == "indexed" else 40)
+        assert (pl.packet_index_bytes > 0) == (label == "indexed")
+        assert np.abs(got - want).max() <= 1e-12 * max(1.0, np.abs(want).max()), label
+        results[label] = got
+    h.clear_plans()
+
+
+def test_pre_indexed_packets_report_states_outside_the_basis(torch):
+    """DMV:115-118 with pre-indexed packets: a partner that is not a basis state has no entry in the directory -- the producer
+    raises the plan's error flag (the operator below flips ONE spin: its images leave the fixed-weight sector)"""
+    import distributed_matvec_amd as D
+    from distributed_matvec_amd import config
+
+    cfg = config.heisenberg_chain_config(12)
+    cfg["hamiltonian"]["terms"].append({"expression": "σˣ₀", "sites": [[i] for i in range(12)]})
+    basis, h = D.loadConfigFromDict(cfg, hamiltonian=True)
+    reps, masks = D.enumerateStates(basis, 3)
+    pl = D.MatvecPlan(h, reps, torch.float64)
+    assert pl.key_bytes == 4
+    pl.destroy()
+    x = [torch.ones(r.numel(), dtype=torch.float64, device="cuda") for r in reps]
+    y = [torch.zeros_like(v) for v in x]
+    with pytest.raises(D.LsAmdError, match="invalid index"):
+        D.matrixVectorProduct(h, x, y, reps)
