@@ -1,0 +1,48 @@
+#!/bin/bash
+# ONE parametrised runner for every `gpurun` job of the round (replaces the per-job scripts of rounds 3/4):
+#     gpurun --timeout T -- 'bash scripts/gpu_job.sh <tag> <step> [<step> ...]'
+# Steps write under gpurun_out/<tag>/ (merged back by gpurun); what is kept as evidence is copied into profiles/ by hand.
+#   smoke            __graft_entry__.smoke()
+#   tests            the whole -m gpu suite            tests:<expr> = pytest -k <expr>
+#   bench            default bench line                bench1 = --force-distributed --distributed-extras (one RCCL rank)
+#   bench_c128       chain_32 c128 line
+#   packets          packet path A/B: pre-indexed vs state-carrying packets, timing trees (scripts/tile_bench.py)
+#   packets_prof     rocprofv3 kernel trace + SQ counters of chain_28 x 8 partitions
+#   loopback:<L>[s]  scripts/loopback_bench.py, 8 loop-back ranks (s = _symm)
+#   pmc:<model>:<dtype>   kernel trace + FETCH/WRITE/VALU/TCC passes -> pmc_traffic entry (scripts/gpu_pmc_traffic.sh)
+#   prof_bench       rocprofv3 --kernel-trace --stats of the default bench command (no extras)
+#   ab:<ENV>=<a>,<b>:<cmd...>   run <cmd> once per value of ENV (A/B inside one job, one box)
+export TMPDIR=/tmp
+cd "$GRAFT_REPO_ROOT" || exit 1
+TAG=$1; shift
+OUT=gpurun_out/$TAG; mkdir -p "$OUT"
+for step in "$@"; do
+  echo "=== [$TAG] $step ($(date +%T))"
+  case "$step" in
+    smoke) timeout 300 python __graft_entry__.py smoke 2>&1 | tail -3 ;;
+    tests) ( time timeout 1500 python -m pytest tests -m gpu -q --maxfail=15 > "$OUT/pytest_gpu.log" 2>&1 ) 2>&1 | grep real; tail -15 "$OUT/pytest_gpu.log" ;;
+    tests:*) ( time timeout 1200 python -m pytest tests -m gpu -q --maxfail=15 -k "${step#tests:}" > "$OUT/pytest_focus.log" 2>&1 ) 2>&1 | grep real; tail -15 "$OUT/pytest_focus.log" ;;
+    bench) ( time timeout 900 python bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err" ) 2>&1 | grep real; tail -c 6000 "$OUT/bench_default.json"; tail -5 "$OUT/bench_default.err" ;;
+    bench_c128) timeout 300 python bench.py --dtype c128 --steps 10 --warmup 3 --no-cpu-baseline --no-extra > "$OUT/bench_c128.json" 2>/dev/null; cut -c1-400 "$OUT/bench_c128.json" ;;
+    bench1) ( time timeout 900 python bench.py --force-distributed --distributed-extras --no-cpu-baseline --kDisplayTimings > "$OUT/bench_one_rank.json" 2> "$OUT/bench_one_rank.err" ) 2>&1 | grep real; echo "rc=$?"; tail -c 5000 "$OUT/bench_one_rank.json"; grep -v "^$" "$OUT/bench_one_rank.err" | tail -40 ;;
+    packets)
+      for pi in 1 0; do
+        for args in "--L 28 --P 8" "--L 28 --P 8 --dtype c128" "--L 28 --P 2" "--L 30 --P 8"; do
+          echo -n "packet_index=$pi $args: "; LS_AMD_PACKET_INDEX=$pi timeout 300 python scripts/tile_bench.py $args --steps 5 --tree 2>&1 | grep -E "matvec=|producers|consumers" | tr '\n' ' ' | sed 's/  */ /g' | cut -c1-400; echo
+        done
+      done | tee "$OUT/packets_ab.txt" ;;
+    packets_prof)
+      CMD="python $GRAFT_REPO_ROOT/scripts/tile_bench.py --L 28 --P 8 --steps 3" bash scripts/gpu_profile_cmd.sh "${TAG}_packets" > "$OUT/packets_prof.log" 2>&1
+      grep -E "k_tile|k_scatter|k_diag" "gpurun_out/prof_${TAG}_packets/summary.txt" | cut -c1-200 | head -30 ;;
+    loopback:*) a=${step#loopback:}; L=${a%s}; S=""; [ "$a" != "$L" ] && S="--symm"
+      timeout 900 python scripts/loopback_bench.py --L "$L" $S --P 8 --steps 3 > "$OUT/loopback_$a.txt" 2>&1; grep -E "ranks sharing|x received|aggregate" "$OUT/loopback_$a.txt" | cut -c1-300 ;;
+    pmc:*) IFS=: read -r _ model dtype <<< "$step"
+      MODEL=$model DTYPE=$dtype TAG="${TAG}_pmc_${model}_${dtype}" bash scripts/gpu_pmc_traffic.sh 2>&1 | tail -14 ;;
+    prof_bench)
+      cd /tmp && timeout -k 5 300 rocprofv3 --kernel-trace --stats -d "$GRAFT_REPO_ROOT/$OUT/trace" -o trace -- python "$GRAFT_REPO_ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-extra > "$GRAFT_REPO_ROOT/$OUT/prof_bench.log" 2>&1
+      cd "$GRAFT_REPO_ROOT" && python3 scripts/rocpd_summary.py "$OUT" > "$OUT/prof_bench_summary.txt" 2>&1; rm -rf "$OUT"/trace/*.db "$OUT"/trace/*/*.db; head -12 "$OUT/prof_bench_summary.txt" | cut -c1-170 ;;
+    ab:*) spec=${step#ab:}; var=${spec%%=*}; rest=${spec#*=}; vals=${rest%%:*}; cmd=${rest#*:}
+      for v in ${vals//,/ }; do echo "--- $var=$v"; env "$var=$v" timeout 600 bash -c "$cmd" 2>&1 | tail -6 | cut -c1-400; done | tee -a "$OUT/ab_$var.txt" ;;
+    *) echo "unknown step $step" ;;
+  esac
+done
