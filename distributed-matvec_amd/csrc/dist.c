@@ -24,6 +24,7 @@ int ls_amd_internal_error(char const *fmt, ...); /* host.c: formats into ls_amd_
 int ls_amd_internal_stage_begin(ls_amd_plan *pl, int stage, void *stream); /* host.c: stage timers (kDisplayTimings) */
 void ls_amd_internal_stage_end(ls_amd_plan *pl, int slot, void *stream);
 void ls_amd_internal_count_matvec(ls_amd_plan *pl);
+void ls_amd_internal_set_no_packet_index(int v); /* host.c */
 int ls_amd_scatter_round(ls_amd_plan *pl, int num_segments, int64_t const *counts, int64_t const *offsets, void const *d_recv, void *d_y, void *stream);
 enum { ST_REFRESH = 1, ST_EXCHANGE = 4, ST_RETURN = 6 };
 /* host.c: the indexed replicated-x matvec in two kernels -- BEGIN resolves the packets (needs no x), FINISH gathers */
@@ -252,6 +253,21 @@ int ls_amd_dist_create(ls_amd_dist **out, ls_amd_comm *cm, ls_hs_operator const 
     int64_t counts[1] = {count_local};
     size_t const m = (size_t)num_rounds * (size_t)P;
     int rc = ls_amd_plan_create(&d->plan, op, dtype, P, me, reps, counts, num_rounds, LS_AMD_MODE_AUTO, stream);
+    {   /* the packet layout (pre-indexed 4-byte keys or 8-byte states) is ONE decision of all ranks: a rank that had no room
+         * for the all-destinations directory pulls everybody back to the state-carrying packets */
+        int64_t wide = rc != 0 || ls_amd_plan_key_bytes(d->plan) == 8;
+        int const mine = (int)wide;
+        if (!cm->d_status || lsk_h2d(cm->d_status, &wide, sizeof(wide)) != 0 || lsk_comm_allreduce(cm->c, cm->d_status, 1, 2, 1, stream) != 0 ||
+            lsk_sync(stream) != 0 || lsk_d2h(&wide, cm->d_status, sizeof(wide)) != 0) {
+            if (rc == 0) rc = ls_amd_internal_error("packet-layout agreement failed: %s", lsk_comm_last_error());
+        } else if (rc == 0 && wide && !mine) {
+            ls_amd_plan_destroy(d->plan);
+            d->plan = NULL;
+            ls_amd_internal_set_no_packet_index(1);
+            rc = ls_amd_plan_create(&d->plan, op, dtype, P, me, reps, counts, num_rounds, LS_AMD_MODE_AUTO, stream);
+            ls_amd_internal_set_no_packet_index(0);
+        }
+    }
     if (rc == 0 && ls_amd_plan_num_rounds(d->plan) != num_rounds) rc = ls_amd_internal_error("internal error: rounds disagree");
     if (rc == 0) {
         d->pb = ls_amd_plan_packet_bytes(d->plan);

@@ -2045,13 +2045,17 @@ static int setup_pairs(ls_amd_plan *pl, int64_t n, uint64_t const *d_reps, void 
  * of the free HBM); LS_AMD_PACKET_INDEX=0 keeps the state-carrying packets (also the path of every projected basis, whose
  * representatives no closed form ranks). */
 static int packets_wave_rings(void);
+/* dist.c: the packet layout is one decision of all ranks -- a rank whose peers could not build the directory re-creates its plan
+ * with state-carrying packets (thread-local: loop-back ranks are threads) */
+static __thread int g_no_packet_index = 0;
+void ls_amd_internal_set_no_packet_index(int v) { g_no_packet_index = v; }
 /* bytes of the key array (states or indices) of a segment of c packets: the values behind it stay 8-byte aligned */
 static int64_t segment_key_bytes(ls_amd_plan const *pl, int64_t c) { return pl->key_bytes == 4 ? ((4 * c + 7) & ~(int64_t)7) : 8 * c; }
 static int setup_packet_index(ls_amd_plan *pl, uint64_t const *const *d_reps, int64_t const *counts, void *stream) {
     ls_hs_basis const *b = pl->op->basis;
     int const L = b->number_sites, h = BEXT(b)->hamming_weight, P = pl->P;
     char const *e = getenv("LS_AMD_PACKET_INDEX");
-    if (e && atoi(e) == 0) return 0;
+    if ((e && atoi(e) == 0) || g_no_packet_index) return 0;
     if (pl->dbs.proj == LSK_PROJ_FULL || h < 0 || h >= LSK_BINOM_K - 1 || L > 64 || P > lsk_tile_wv_max_parts() || P > LSK_MAX_SEGS ||
         !packets_wave_rings()) return 0;
     for (int i = 0; i < pl->n_local; ++i) if (counts[i] >= 0xffffffffLL) return 0;

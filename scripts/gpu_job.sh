@@ -20,8 +20,10 @@ for step in "$@"; do
   echo "=== [$TAG] $step ($(date +%T))"
   case "$step" in
     smoke) timeout 300 python __graft_entry__.py smoke 2>&1 | tail -3 ;;
-    tests) ( time timeout 1500 python -m pytest tests -m gpu -q --maxfail=15 > "$OUT/pytest_gpu.log" 2>&1 ) 2>&1 | grep real; tail -15 "$OUT/pytest_gpu.log" ;;
-    tests:*) ( time timeout 1200 python -m pytest tests -m gpu -q --maxfail=15 -k "${step#tests:}" > "$OUT/pytest_focus.log" 2>&1 ) 2>&1 | grep real; tail -15 "$OUT/pytest_focus.log" ;;
+    tests) ( time timeout 1500 python -m pytest tests -m gpu -q --maxfail=15 --timeout 420 --timeout-method signal > "$OUT/pytest_gpu.log" 2>&1 ) 2>&1 | grep real; tail -15 "$OUT/pytest_gpu.log" ;;
+    hang:*) # a test suspected of hanging: per-test timeout with a dump of every thread's stack (faulthandler), then exit
+      timeout 400 python -X faulthandler -m pytest tests -m gpu -q -x --timeout 150 --timeout-method thread -k "${step#hang:}" > "$OUT/pytest_hang.log" 2>&1; tail -120 "$OUT/pytest_hang.log" | cut -c1-220 ;;
+    tests:*) ( time timeout 1200 python -m pytest tests -m gpu -q --maxfail=15 --timeout 420 --timeout-method signal -k "${step#tests:}" >> "$OUT/pytest_focus.log" 2>&1 ) 2>&1 | grep real; tail -15 "$OUT/pytest_focus.log" ;;
     bench) ( time timeout 900 python bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err" ) 2>&1 | grep real; tail -c 6000 "$OUT/bench_default.json"; tail -5 "$OUT/bench_default.err" ;;
     bench_c128) timeout 300 python bench.py --dtype c128 --steps 10 --warmup 3 --no-cpu-baseline --no-extra > "$OUT/bench_c128.json" 2>/dev/null; cut -c1-400 "$OUT/bench_c128.json" ;;
     bench1) ( time timeout 900 python bench.py --force-distributed --distributed-extras --no-cpu-baseline --kDisplayTimings > "$OUT/bench_one_rank.json" 2> "$OUT/bench_one_rank.err" ) 2>&1 | grep real; echo "rc=$?"; tail -c 5000 "$OUT/bench_one_rank.json"; grep -v "^$" "$OUT/bench_one_rank.err" | tail -40 ;;

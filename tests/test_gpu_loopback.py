@@ -32,15 +32,19 @@ def _run_ranks(P, body):
         except BaseException as e:  # noqa: BLE001
             errors[r] = e
 
-    threads = [threading.Thread(target=run, args=(r,)) for r in range(P)]
+    import time
+
+    # daemon threads: a rank stuck in a collective must not keep the interpreter alive at exit
+    threads = [threading.Thread(target=run, args=(r,), daemon=True) for r in range(P)]
     for t in threads:
         t.start()
+    deadline = time.monotonic() + 300  # for ALL ranks together: a rank that raised leaves its peers in their next collective
     for t in threads:
-        t.join(timeout=600)
-    assert not any(t.is_alive() for t in threads), "a rank is stuck in a collective"
-    for e in errors:
+        t.join(timeout=max(0.0, deadline - time.monotonic()))
+    for e in errors:  # the rank that failed first explains the others' wait
         if e is not None:
             raise e
+    assert not any(t.is_alive() for t in threads), "a rank is stuck in a collective"
     return comms
 
 

@@ -270,7 +270,7 @@ def _run_bench(*extra):
         env.pop(k, None)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-distributed", "--model", "heisenberg_chain_24",
                         "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extra", *extra],
-                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+                       capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert lines, p.stderr[-2000:]
     return p.returncode, json.loads(lines[-1]), p.stderr
