@@ -2145,8 +2145,11 @@ __global__ __launch_bounds__(kBlock) void k_tile_wv(int n_groups, lsk_group cons
             if (!COUNT && PK12) {
                 if (live) {
                     const int64_t idx = gdir_index(gd, beta, dest, s_db);
-                    if (idx < 0) { atomicExch(err, 1); remote = false; } // not a basis state (DMV:115-118)
-                    else if (dest == me) {
+                    if (idx < 0) { // not a basis state (DMV:115-118): the flag halts the matvec; the slot the count pass reserved for the
+                        atomicExch(err, 1); // packet is still filled -- with (index 0, value 0) -- so that no consumer meets a stale key
+                        if (dest == me) remote = false;
+                        else { vr = 0.0; vi = 0.0; }
+                    } else if (dest == me) {
                         remote = false;
                         if (CPLX) { atomic_add_f64(y + 2 * idx, vr); atomic_add_f64(y + 2 * idx + 1, vi); }
                         else atomic_add_f64(y + idx, vr);

@@ -30,7 +30,12 @@ def _run_ranks(P, body):
             torch.cuda.set_device(0)
             body(r, comms[r])
         except BaseException as e:  # noqa: BLE001
+            import sys
+            import traceback
+
             errors[r] = e
+            print(f"[loop-back rank {r}] raised:", file=sys.stderr, flush=True)
+            traceback.print_exc()
 
     import time
 
@@ -38,9 +43,11 @@ def _run_ranks(P, body):
     threads = [threading.Thread(target=run, args=(r,), daemon=True) for r in range(P)]
     for t in threads:
         t.start()
-    deadline = time.monotonic() + 300  # for ALL ranks together: a rank that raised leaves its peers in their next collective
-    for t in threads:
-        t.join(timeout=max(0.0, deadline - time.monotonic()))
+    deadline = time.monotonic() + 300  # for ALL ranks together
+    while any(t.is_alive() for t in threads) and time.monotonic() < deadline:
+        threads[0].join(timeout=0.2) if threads[0].is_alive() else time.sleep(0.2)
+        if any(e is not None for e in errors):  # a rank that raised leaves its peers in their next collective: no point in waiting
+            deadline = min(deadline, time.monotonic() + 10)
     for e in errors:  # the rank that failed first explains the others' wait
         if e is not None:
             raise e
