@@ -205,6 +205,7 @@ struct ls_amd_dist {
     int64_t *send_counts; /* [rounds][P] packets to every destination */
     int64_t *recv_counts; /* [rounds][P] packets from every source */
     int64_t *send_off, *send_bytes, *recv_off, *recv_bytes; /* [rounds][P] byte layout of the two buffers */
+    int64_t *scat_off, *scat_counts; /* [rounds][P] what the consumer reads: == recv_off / recv_counts (ls_amd_test_corrupt_dist edits these) */
     void *d_send[2], *d_recv[2];
     int64_t exchange_bytes;
 };
@@ -222,6 +223,7 @@ void ls_amd_dist_destroy(ls_amd_dist *d) {
     if (d->plan) ls_amd_plan_destroy(d->plan);
     free(d->send_counts); free(d->recv_counts);
     free(d->send_off); free(d->send_bytes); free(d->recv_off); free(d->recv_bytes);
+    free(d->scat_off); free(d->scat_counts);
     free(d);
 }
 
@@ -275,6 +277,7 @@ int ls_amd_dist_create(ls_amd_dist **out, ls_amd_comm *cm, ls_hs_operator const 
         d->recv_counts = (int64_t *)calloc(m, sizeof(int64_t));
         d->send_off = (int64_t *)calloc(m, sizeof(int64_t)); d->send_bytes = (int64_t *)calloc(m, sizeof(int64_t));
         d->recv_off = (int64_t *)calloc(m, sizeof(int64_t)); d->recv_bytes = (int64_t *)calloc(m, sizeof(int64_t));
+        d->scat_off = (int64_t *)calloc(m, sizeof(int64_t)); d->scat_counts = (int64_t *)calloc(m, sizeof(int64_t));
         for (int r = 0; r < num_rounds && rc == 0; ++r) rc = ls_amd_plan_send_counts(d->plan, r, d->send_counts + (size_t)r * P);
     }
     /* counts matrix, once: everybody learns everybody's [rounds][P] send counts (no per-round size exchange) */
@@ -301,6 +304,7 @@ int ls_amd_dist_create(ls_amd_dist **out, ls_amd_comm *cm, ls_hs_operator const 
         if (ro > max_recv) max_recv = ro;
         d->exchange_bytes += so;
     }
+    if (rc == 0) { memcpy(d->scat_off, d->recv_off, sizeof(int64_t) * m); memcpy(d->scat_counts, d->recv_counts, sizeof(int64_t) * m); }
     free(all);
     for (int i = 0; i < 2 && rc == 0; ++i)
         if (lsk_malloc(&d->d_send[i], (size_t)(max_send > 0 ? max_send : 8)) != 0 ||
@@ -315,16 +319,16 @@ ls_amd_plan *ls_amd_dist_plan(ls_amd_dist *d) { return d->plan; }
 int64_t ls_amd_dist_exchange_bytes(ls_amd_dist const *d) { return d->exchange_bytes; }
 int ls_amd_dist_num_rounds(ls_amd_dist const *d) { return d->rounds; }
 
-/* test hook (ls_amd.h): the first non-empty remote segment this rank receives loses its first packet's state and its last
- * packet's value -- the segment is read one state further on, one packet shorter: (beta_{k+1}, value_k) pairs */
+/* test hook (ls_amd.h) */
 int ls_amd_test_corrupt_dist(ls_amd_dist *d) {
-    /* 8 bytes further on = one state, or two pre-indexed keys; with the count reduced by as many the values behind the (padded)
-     * key array are still found at their place: (key_{k + drop}, value_k) pairs, every key valid, nothing read out of bounds */
+    /* The exchange itself stays as it is; the CONSUMER reads one received segment 8 bytes further on (one state, or two
+     * pre-indexed keys) and that many packets shorter, the values behind the padded key array being found at their place:
+     * (key_{k + drop}, value_k) pairs -- every key valid, nothing read outside the segment. */
     int const drop = 8 / ls_amd_plan_key_bytes(d->plan);
     for (size_t k = 0; k < (size_t)d->rounds * (size_t)d->P; ++k) {
-        if ((int)(k % (size_t)d->P) == d->me || d->recv_counts[k] < 2 * drop + 1 || (d->recv_counts[k] & 1)) continue;
-        d->recv_off[k] += 8;
-        d->recv_counts[k] -= drop;
+        if ((int)(k % (size_t)d->P) == d->me || d->scat_counts[k] < 2 * drop + 1 || (d->scat_counts[k] & 1)) continue;
+        d->scat_off[k] += 8;
+        d->scat_counts[k] -= drop;
         return 1;
     }
     return 0;
@@ -355,7 +359,7 @@ int ls_amd_dist_matvec(ls_amd_dist *d, void const *d_x, void *d_y, void *stream)
         COMM(lsk_comm_exchange_wait(d->comm->c, r & 1, stream));
         ls_amd_internal_stage_end(d->plan, st, stream);
         /* every received segment of the round (SoA: keys, then values) in one consumer launch */
-        TRY(ls_amd_scatter_round(d->plan, P, d->recv_counts + (size_t)r * P, d->recv_off + (size_t)r * P, d->d_recv[r & 1], d_y, stream));
+        TRY(ls_amd_scatter_round(d->plan, P, d->scat_counts + (size_t)r * P, d->scat_off + (size_t)r * P, d->d_recv[r & 1], d_y, stream));
     }
     return 0;
 }

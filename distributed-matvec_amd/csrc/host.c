@@ -3193,10 +3193,11 @@ static int host_matvec_block(ls_hs_operator *op, int64_t n, int ncols, double co
         if (rc != 0) return -1;
         /* while the kernel runs: the next column goes up, the previous result comes down (different buffers) */
         int const up = k + 1 < ncols && xk != LSK_PTR_DEVICE, down = k >= 1 && yk != LSK_PTR_DEVICE;
-        if (k + 1 < ncols && yk != LSK_PTR_DEVICE && upload_y &&
-            transfer(YDEV(k + 1), y + (int64_t)(k + 1) * ldy, bytes, yk, NULL, NULL, 0, 0) != 0) return -1;
         if ((up || down) && transfer(up ? XDEV(k + 1) : NULL, up ? x + (int64_t)(k + 1) * ldx : NULL, up ? bytes : 0, xk,
                                      down ? y + (int64_t)(k - 1) * ldy : NULL, down ? YDEV(k - 1) : NULL, down ? bytes : 0, yk) != 0) return -1;
+        /* (y += H x: the next column's y goes up only now -- its buffer held the result that has just come down) */
+        if (k + 1 < ncols && yk != LSK_PTR_DEVICE && upload_y &&
+            transfer(YDEV(k + 1), y + (int64_t)(k + 1) * ldy, bytes, yk, NULL, NULL, 0, 0) != 0) return -1;
         if (ls_amd_plan_check(plan, NULL) != 0) return -1; /* synchronises the launch stream; halts on an invalid index */
     }
     if (yk != LSK_PTR_DEVICE &&
