@@ -2043,7 +2043,7 @@ static int setup_pairs(ls_amd_plan *pl, int64_t n, uint64_t const *d_reps, void 
  * atomic per packet.  Costs P / 4 bytes of HBM per basis state on every rank (chain_32 at 8 ranks: 1.2 GB; the per-rank data of the
  * packet strategy stays O(N / P) otherwise), so it is taken only while it fits LS_AMD_PACKET_INDEX_MAX bytes (default: a quarter
  * of the free HBM); LS_AMD_PACKET_INDEX=0 keeps the state-carrying packets (also the path of every projected basis, whose
- * representatives no closed form ranks). */
+ * representatives no closed form ranks), =1 takes the indexed ones also for logical partitions inside one process. */
 static int packets_wave_rings(void);
 /* dist.c: the packet layout is one decision of all ranks -- a rank whose peers could not build the directory re-creates its plan
  * with state-carrying packets (thread-local: loop-back ranks are threads) */
@@ -2056,6 +2056,11 @@ static int setup_packet_index(ls_amd_plan *pl, uint64_t const *const *d_reps, in
     int const L = b->number_sites, h = BEXT(b)->hamming_weight, P = pl->P;
     char const *e = getenv("LS_AMD_PACKET_INDEX");
     if ((e && atoi(e) == 0) || g_no_packet_index) return 0;
+    /* Default: only where packets cross a wire (one partition per process).  With all partitions in one process the "exchange" is a
+     * pointer hand-off, and on one device the directory costs the producers more than it saves the consumers (chain_28 x 8: 23.5
+     * against 22.6 ms, chain_30 x 8: 97.7 against 92.2 -- profiles/r5_packets_preindexed_ab.txt: the consumers are bound by their
+     * atomics, not by the rank directory look-up they lose).  LS_AMD_PACKET_INDEX=1 forces it there too (tests, A/B). */
+    if (pl->me < 0 && !(e && atoi(e) == 1)) return 0;
     if (pl->dbs.proj == LSK_PROJ_FULL || h < 0 || h >= LSK_BINOM_K - 1 || L > 64 || P > lsk_tile_wv_max_parts() || P > LSK_MAX_SEGS ||
         !packets_wave_rings()) return 0;
     for (int i = 0; i < pl->n_local; ++i) if (counts[i] >= 0xffffffffLL) return 0;

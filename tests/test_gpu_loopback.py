@@ -401,6 +401,8 @@ def test_self_verification_catches_a_misplaced_segment(name, P, cplx, mode):
 
         op = (RcclDistributedOperator(h, reps[rank], dtype, comm=comm, num_rounds=2) if mode == "packets"
               else RcclReplicatedOperator(h, reps_global, masks, dtype, comm=comm))
+        if mode == "packets":  # one partition per process: pre-indexed packets wherever a closed form ranks the basis
+            assert op.engine.plan.key_bytes == (8 if "symm" in name else 4)
         x = D.fillRandom(reps[rank], 42, dtype)
         y = torch.zeros_like(x)
         xr, yr, ymax, kern = refs[rank]

@@ -1211,7 +1211,10 @@ def test_pre_indexed_packets(torch, monkeypatch, case):
         x = x + 1j * (rng.rand(len(want_reps)) - 0.5)
     want = oracle_for(name).local_matvec(want_reps, x)
     results = {}
-    for label, env in (("indexed", {}), ("states", {"LS_AMD_PACKET_INDEX": "0"}), ("ceiling", {"LS_AMD_PACKET_INDEX_MAX": "8"})):
+    # (logical partitions inside one process default to the state-carrying packets: nothing crosses a wire; one partition per
+    # process -- tests/test_gpu_loopback.py, tests/test_gpu_rccl.py -- defaults to the indexed ones)
+    for label, env in (("indexed", {"LS_AMD_PACKET_INDEX": "1"}), ("states", {"LS_AMD_PACKET_INDEX": "0"}), ("default", {}),
+                       ("ceiling", {"LS_AMD_PACKET_INDEX": "1", "LS_AMD_PACKET_INDEX_MAX": "8"})):
         for k in ("LS_AMD_PACKET_INDEX", "LS_AMD_PACKET_INDEX_MAX"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
@@ -1229,12 +1232,13 @@ def test_pre_indexed_packets(torch, monkeypatch, case):
     h.clear_plans()
 
 
-def test_pre_indexed_packets_report_states_outside_the_basis(torch):
+def test_pre_indexed_packets_report_states_outside_the_basis(torch, monkeypatch):
     """DMV:115-118 with pre-indexed packets: a partner that is not a basis state has no entry in the directory -- the producer
     raises the plan's error flag (the operator below flips ONE spin: its images leave the fixed-weight sector)"""
     import distributed_matvec_amd as D
     from distributed_matvec_amd import config
 
+    monkeypatch.setenv("LS_AMD_PACKET_INDEX", "1")
     cfg = config.heisenberg_chain_config(12)
     cfg["hamiltonian"]["terms"].append({"expression": "σˣ₀", "sites": [[i] for i in range(12)]})
     basis, h = D.loadConfigFromDict(cfg, hamiltonian=True)
