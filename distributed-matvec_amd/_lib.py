@@ -197,6 +197,7 @@ def load():
         "ls_amd_test_free": (None, [vp]),
         "ls_amd_test_translation_cosets": (C.c_int, [bp, C.POINTER(C.c_int)]),
         "ls_amd_test_rep_by_cosets": (C.c_uint64, [bp, C.c_uint64]),
+        "ls_amd_test_d4_mask": (C.c_int, [bp]),
         "ls_amd_test_gtab_bits": (C.c_int, [C.c_int, C.c_int64]),
         "ls_amd_test_gtab_build": (C.c_int, [C.c_int, C.c_int, C.c_int64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.POINTER(C.c_uint64))]),
         "ls_amd_test_gtab_find": (C.c_int64, [C.c_int, C.c_int, C.POINTER(C.c_uint64), C.c_uint64]),

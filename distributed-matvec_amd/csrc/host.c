@@ -252,6 +252,11 @@ struct ls_amd_basis_ext {
     int *coset_ids;
     lsk_group_elem *d_cosets;
     uint32_t *d_trow;    /* mode 4, tw <= 8: the row table of torus_min on the device */
+    int d4_mask;         /* mode 5: which of 1, r, o, r o (bits 0-3) and of their products with the transpose (bits 4-7) the cosets are;
+                          * 0 = not examined, -1 = the cosets are not of that form */
+    lsk_group_elem d4_transpose; /* the transpose network (the only compiled network of mode 5) */
+    lsk_group_elem *d_d4_net;
+    uint64_t *d_trow2;   /* mode 5: row table with the reversed row's fields in the high half */
     int owns_representatives;
     uint64_t *d_reps_cache; /* device copy of `representatives` for the host-pointer entry points */
     uint64_t d_reps_count;
@@ -572,6 +577,8 @@ void ls_hs_destroy_basis(ls_hs_basis *b) {
     if (e->d_elems) lsk_free(e->d_elems);
     if (e->d_cosets) lsk_free(e->d_cosets);
     if (e->d_trow) lsk_free(e->d_trow);
+    if (e->d_d4_net) lsk_free(e->d_d4_net);
+    if (e->d_trow2) lsk_free(e->d_trow2);
     if (e->owns_representatives && b->representatives.elts) free(b->representatives.elts);
     free(e->gen_perms); free(e->gen_sectors); free(e->perms); free(e->elems); free(e->coset_ids);
     reg_del(b);
@@ -693,6 +700,54 @@ static void find_translation_cosets(struct ls_amd_basis_ext *e, int L) {
     free(img); free(table); free(cand); free(trans);
 }
 
+/* K4 mode 5: are the cosets T g found above the point group of the torus itself?  Canonical images of a site (y, x): r = (y, tw-1-x),
+ * o = (th-1-y, x), and on a square torus the transpose (x, y) applied first; a coset matches the canonical element c when
+ * img_g = img_t o img_c for some translation t.  Every coset must match a different c.  Sets e->d4_mask (> 0, or -1). */
+static void classify_d4_cosets(struct ls_amd_basis_ext *e, int L) {
+    e->d4_mask = -1;
+    int const tw = e->tw;
+    if (tw <= 0 || tw > 8 || L % tw || e->n_cosets < 1 || e->n_cosets > 8) return;
+    int const th = L / tw;
+    int mask = 0;
+    for (int r = 0; r < e->n_cosets; ++r) {
+        unsigned char ig[64];
+        for (int s = 0; s < L; ++s) ig[s] = (unsigned char)__builtin_ctzll(host_apply_elem(&e->elems[e->coset_ids[r]], 1ULL << s, L));
+        int found = -1;
+        for (int c = 0; c < 8 && found < 0; ++c) {
+            if ((c & 4) && tw != th) continue;
+            for (int dy = 0; dy < th && found < 0; ++dy)
+                for (int dx = 0; dx < tw && found < 0; ++dx) {
+                    int ok = 1;
+                    for (int s = 0; s < L && ok; ++s) {
+                        int y = s / tw, x = s % tw;
+                        if (c & 4) { int const t = y; y = x; x = t; } /* transpose first */
+                        if (c & 1) x = tw - 1 - x;                     /* r */
+                        if (c & 2) y = th - 1 - y;                     /* o */
+                        ok = ig[s] == ((y + dy) % th) * tw + (x + dx) % tw;
+                    }
+                    if (ok) found = c;
+                }
+        }
+        if (found < 0 || (mask >> found) & 1) return;
+        mask |= 1 << found;
+    }
+    if (!(mask & 1)) return; /* (the coset of the identity is always there) */
+    if (mask >> 4) { /* the transpose as a compiled network: y[i] = x[perm[i]], an involution */
+        int perm[64];
+        for (int s = 0; s < L; ++s) perm[s] = (s % tw) * tw + s / tw;
+        compile_elem(perm, L, 1.0, 0.0, &e->d4_transpose);
+    }
+    e->d4_mask = mask;
+}
+int ls_amd_test_d4_mask(ls_hs_basis const *b) {
+    struct ls_amd_basis_ext *e = BEXT(b);
+    if (ls_amd_test_translation_cosets(b, NULL) <= 0) return 0;
+    pthread_mutex_lock(&g_device_tables_lock);
+    if (e->d4_mask == 0) classify_d4_cosets(e, b->number_sites);
+    pthread_mutex_unlock(&g_device_tables_lock);
+    return e->d4_mask > 0 ? e->d4_mask : 0;
+}
+
 /* host-only test hooks of K4 mode 4: the shape found for a basis (returns tw, or -1), and the orbit minimum of `state` computed
  * the way the kernels do it (coset networks + row / word rotations; the global spin flip folded in by canonicalising to "top
  * site clear" when the basis has one) */
@@ -712,7 +767,16 @@ uint64_t ls_amd_test_rep_by_cosets(ls_hs_basis const *b, uint64_t a) {
     int const tw = e->tw, th = L / tw;
     uint64_t col0 = 0, best = ~0ULL;
     for (int y = 0; y < th; ++y) col0 |= 1ULL << (y * tw);
-    if (tw <= 8) { /* what the kernels run: the row table picks the translations that can be minimal */
+    char const *k4env = getenv("LS_AMD_K4");
+    int const d4 = (k4env && strcmp(k4env, "cosets") == 0) ? 0 : ls_amd_test_d4_mask(b);
+    if (d4 > 0) { /* what the kernels run (mode 5): one transpose network, the rest factorised */
+        uint64_t rowtab2[256];
+        lsk_torus_rowtab2(tw, rowtab2);
+        best = lsk_test_torus_min_d2(a, L, tw, b->spin_inversion != 0, d4 & 15, rowtab2, best);
+        if (d4 >> 4) best = lsk_test_torus_min_d2(host_apply_elem(&e->d4_transpose, a, L), L, tw, b->spin_inversion != 0, d4 >> 4, rowtab2, best);
+        return best;
+    }
+    if (tw <= 8) { /* mode 4: the row table picks the translations that can be minimal */
         uint32_t rowtab[256];
         lsk_torus_rowtab(tw, rowtab);
         for (int r = 0; r < e->n_cosets; ++r)
@@ -763,10 +827,13 @@ static int basis_device_unlocked(ls_hs_basis const *b, lsk_basis *out) {
     out->tcol0 = 0;
     out->cosets = NULL;
     out->trow = NULL;
+    out->d4_mask = 0;
+    out->trow2 = NULL;
     /* LS_AMD_K4 (test hook): general = the element loop with characters and norms even in trivial sectors; brute = trivial
      * sectors by the plain loop over every element (no run pruning, no translation cosets) */
     char const *k4env = getenv("LS_AMD_K4");
     int const k4_general = k4env && strcmp(k4env, "general") == 0, k4_brute = k4env && strcmp(k4env, "brute") == 0;
+    int const k4_cosets = k4env && strcmp(k4env, "cosets") == 0; /* keep mode 4 (one network per coset) where mode 5 applies: A/B */
     if (trivial && e->order > 1 && !k4_general) {
         out->k4_mode = 1;
         /* full cyclic group of the ring (every rotation k = 0..L-1), optionally with all reflections? */
@@ -810,6 +877,27 @@ static int basis_device_unlocked(ls_hs_basis const *b, lsk_basis *out) {
                 out->n_cosets = e->n_cosets;
                 out->cosets = e->d_cosets;
                 for (int y = 0; y < L / e->tw; ++y) out->tcol0 |= 1ULL << (y * e->tw);
+                /* mode 5: the cosets are the point group of the torus -- one network (the transpose) instead of n_cosets */
+                if (e->d4_mask == 0) classify_d4_cosets(e, L);
+                if (e->d4_mask > 0 && !k4_cosets) {
+                    if (!e->d_trow2) {
+                        uint64_t rowtab2[256];
+                        void *p = NULL;
+                        lsk_torus_rowtab2(e->tw, rowtab2);
+                        if (lsk_malloc(&p, sizeof(rowtab2)) != 0 || lsk_h2d(p, rowtab2, sizeof(uint64_t) << e->tw) != 0) { if (p) lsk_free(p); return dev_error(); }
+                        e->d_trow2 = (uint64_t *)p;
+                    }
+                    if ((e->d4_mask >> 4) && !e->d_d4_net) {
+                        void *p = NULL;
+                        if (lsk_malloc(&p, sizeof(lsk_group_elem)) != 0 || lsk_h2d(p, &e->d4_transpose, sizeof(lsk_group_elem)) != 0) { if (p) lsk_free(p); return dev_error(); }
+                        e->d_d4_net = (lsk_group_elem *)p;
+                    }
+                    out->k4_mode = 5;
+                    out->d4_mask = e->d4_mask;
+                    out->trow2 = e->d_trow2;
+                    out->cosets = e->d_d4_net; /* NULL when no image involves the transpose */
+                    out->n_cosets = e->d_d4_net ? 1 : 0;
+                }
             }
         }
     }

@@ -674,6 +674,102 @@ __host__ __device__ __forceinline__ W torus_min(W v, int L, int tw, W mask, W co
     }
     return best;
 }
+// ---- K4 mode 5: the point group of a rectangular / square torus, factorised -------------------------------------
+// The cosets T g of such a lattice group are (modulo translations) the elements of D2 = {1, r, o, r o} -- r reverses every row
+// (x -> tw-1-x), o reverses the order of the rows (y -> th-1-y), r o is the reversal of the whole word -- and, on a square
+// torus, those times the transpose: D4.  Mode 4 sends the word through ONE compiled 11-stage network PER coset (8 x ~110 VALU
+// instructions on 64-bit words) and runs torus_min on each image (8 x ~350).  Here
+//   * only the transpose is a network; r is floor(tw / 2) delta swaps, r o one bit reversal, o = (r o) r;
+//   * the four images of a base word are made of TWO row alphabets: {rows of v} for v and o(v), {reversed rows} for r(v) and
+//     r o (v); rowtab2[row] carries the torus_min fields of the row (low half) AND of the reversed row (high half), so ONE pass
+//     over the rows finds the smallest top row any of the four images can reach (and of their complements under the spin flip);
+//   * only the alphabets that reach it build candidates, for their two words each.
+// `present`: bit 0 = identity, 1 = r, 2 = o, 3 = r o (the images that belong to the group).
+template <typename W>
+__host__ __device__ __forceinline__ W rowrev_w(W v, int tw, W col0) {
+    for (int j = 0; 2 * j + 1 < tw; ++j) { // swap columns j and tw-1-j of every row
+        const int d = tw - 1 - 2 * j;
+        const W t = (W)(((v >> d) ^ v) & (W)(col0 << j));
+        v ^= (W)(t | (W)(t << d));
+    }
+    return v;
+}
+template <typename W>
+__host__ __device__ __forceinline__ W torus_candidate(W word, int i, int kpos, int L, int tw, int th, W mask, W col0) {
+    const W lo = (W)(col0 * (W)((1u << i) - 1u)); // columns 0 .. i-1 of every row
+    const W c = (W)((((W)(word << i)) & (W)~lo & mask) | ((W)(word >> (tw - i)) & lo)); // every row rotated by i
+    return rotl_sites<W>(c, tw * (th - 1 - kpos), L, mask);                              // row kpos to the top
+}
+template <typename W>
+__host__ __device__ __forceinline__ W torus_min_d2(W v, int L, int tw, W mask, W col0, bool inv, int present,
+                                                   uint64_t const *__restrict__ rowtab2, W best) {
+    const int th = L / tw;
+    const uint32_t rmask = (1u << tw) - 1u;
+    const bool needA = present & 5, needB = present & 10;
+    // pass 1: the smallest top row of each alphabet (A: rows as they are, B: rows reversed; 1: of the complemented word)
+    uint32_t mA0 = 0xffffffffu, mA1 = 0xffffffffu, mB0 = 0xffffffffu, mB1 = 0xffffffffu;
+    for (int k = 0; k < th; ++k) {
+        const uint64_t e = rowtab2[(uint32_t)(v >> (k * tw)) & rmask];
+        const uint32_t ea = (uint32_t)e, eb = (uint32_t)(e >> 32);
+        uint32_t m = ea & 0xffu; mA0 = m < mA0 ? m : mA0;
+        m = ~(ea >> 16) & rmask;  mA1 = m < mA1 ? m : mA1;
+        m = eb & 0xffu;           mB0 = m < mB0 ? m : mB0;
+        m = ~(eb >> 16) & rmask;  mB1 = m < mB1 ? m : mB1;
+    }
+    uint32_t mstar = 0xffffffffu;
+    if (needA) { mstar = mA0; if (inv && mA1 < mstar) mstar = mA1; }
+    if (needB) { if (mB0 < mstar) mstar = mB0; if (inv && mB1 < mstar) mstar = mB1; }
+    if ((W)mstar > (W)(best >> (L - tw))) return best;
+    const W rv = rowrev_w<W>(v, tw, col0);
+    const uint32_t inv_tw = 65536u / (uint32_t)tw + 1u; // p / tw for p < 64, tw <= 8
+    // alphabet by alphabet (wave-uniform loop; a lane enters a body only when that alphabet reaches the smallest top row)
+    for (int alph = 0; alph < 4; ++alph) {
+        const bool isB = alph & 2, cpl = alph & 1;
+        const uint32_t mine = isB ? (cpl ? mB1 : mB0) : (cpl ? mA1 : mA0);
+        if ((cpl && !inv) || !(isB ? needB : needA) || mine != mstar) continue;
+        W cand = 0; // bit k tw + i: "rotate the rows by i, then row k (of the base order) to the top"
+        for (int k = 0; k < th; ++k) {
+            const uint64_t e = rowtab2[(uint32_t)(v >> (k * tw)) & rmask];
+            const uint32_t f = isB ? (uint32_t)(e >> 32) : (uint32_t)e;
+            const uint32_t m = cpl ? (~(f >> 16) & rmask) : (f & 0xffu);
+            if (m == mstar) cand |= (W)(cpl ? (f >> 24) : ((f >> 8) & 0xffu)) << (k * tw);
+        }
+        // the two words of this alphabet: rows in the base order (v | r(v)) and in reversed order (o(v) = rev(r(v)) | r o (v) = rev(v))
+        const W w_fwd = isB ? rv : v;
+        const W w_bwd = rev_sites<W>(isB ? v : rv, L);
+        const bool has_fwd = present & (isB ? 2 : 1), has_bwd = present & (isB ? 8 : 4);
+        const W flip = cpl ? mask : (W)0;
+        while (cand) {
+            const int p = sizeof(W) == 4 ? k4_ctz32((uint32_t)cand) : k4_ctz64((uint64_t)cand);
+            cand &= cand - 1;
+            const int k = (int)(((uint32_t)p * inv_tw) >> 16), i = p - k * tw;
+            if (has_fwd) { const W c = torus_candidate<W>((W)(w_fwd ^ flip), i, k, L, tw, th, mask, col0); best = c < best ? c : best; }
+            if (has_bwd) { const W c = torus_candidate<W>((W)(w_bwd ^ flip), i, th - 1 - k, L, tw, th, mask, col0); best = c < best ? c : best; }
+        }
+    }
+    return best;
+}
+// rowtab2[r] = rowtab[r] | rowtab[rev_tw(r)] << 32 (tw <= 8): out[2^tw]
+extern "C" int lsk_torus_rowtab(int tw, uint32_t *out);
+extern "C" int lsk_torus_rowtab2(int tw, uint64_t *out) {
+    if (tw < 1 || tw > 8) return -1;
+    uint32_t t[256];
+    lsk_torus_rowtab(tw, t);
+    for (uint32_t r = 0; r < (1u << tw); ++r) {
+        uint32_t q = 0;
+        for (int i = 0; i < tw; ++i) if (r & (1u << i)) q |= 1u << (tw - 1 - i);
+        out[r] = (uint64_t)t[r] | ((uint64_t)t[q] << 32);
+    }
+    return 0;
+}
+// host test hook: the factorised minimum over the images `present` of one base word (64-bit arithmetic)
+extern "C" uint64_t lsk_test_torus_min_d2(uint64_t v, int L, int tw, int inv, int present, uint64_t const *rowtab2, uint64_t best) {
+    const uint64_t mask = L >= 64 ? ~0ULL : ((1ULL << L) - 1);
+    uint64_t col0 = 0;
+    for (int y = 0; y < L / tw; ++y) col0 |= 1ULL << (y * tw);
+    return torus_min_d2<uint64_t>(v, L, tw, mask, col0, inv != 0, present, rowtab2, best);
+}
+
 // the row table of torus_min for rows of tw <= 8 bits: out[2^tw]
 extern "C" int lsk_torus_rowtab(int tw, uint32_t *out) {
     if (tw < 1 || tw > 8) return -1;
@@ -711,6 +807,12 @@ __device__ __forceinline__ W rep_trivial(lsk_basis const &bs, lsk_group_elem con
     const bool inv = bs.spin_inversion != 0;
     W best = ~(W)0;
     if (bs.k4_mode == 3) return rep_trivial_dihedral<W>(a, L, mask, inv, bs.reflect != 0);
+    if (bs.k4_mode == 5) { // D2 / D4 point group of a torus, factorised: one network (the transpose) instead of one per coset
+        const W col0 = (W)bs.tcol0;
+        best = torus_min_d2<W>(a, L, bs.tw, mask, col0, inv, bs.d4_mask & 15, bs.trow2, best);
+        if (bs.d4_mask >> 4) best = torus_min_d2<W>(apply_elem_w<W>(bs.cosets[0], a, L, mask), L, bs.tw, mask, col0, inv, bs.d4_mask >> 4, bs.trow2, best);
+        return best;
+    }
     if (bs.k4_mode == 4) {
         // translations of a tw x th torus as a subgroup: one compiled network per coset representative (the point group), then
         // tw * th cheap steps -- rotate every row by one site; after tw of them the word is back, rotate it by one row

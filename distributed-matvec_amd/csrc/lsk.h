@@ -81,9 +81,16 @@ typedef struct lsk_basis {
      *  3 as 2, but only the rotations that start at a longest run of zeros are visited;
      *  4 as 1, for a group that contains every translation of a tw x (L / tw) torus (site = y tw + x): G = union of the
      *    right cosets T g_r, so the orbit is { t(g_r(a)) }: n_cosets compiled networks (the point group) and |G| cheap
-     *    translation steps (rotate the rows by one site / the word by one row) instead of |G| networks. */
+     *    translation steps (rotate the rows by one site / the word by one row) instead of |G| networks.
+     *  5 as 4, when those cosets are (modulo translations) the point group D2 = {1, r, o, r o} of the torus -- r reverses every
+     *    row, o the order of the rows -- or, on a square torus, D4 = D2 x {1, transpose}, or a subgroup of it: d4_mask says
+     *    which images belong to the group (bits 0-3: 1, r, o, r o of the word; bits 4-7: of its transpose), cosets[0] is the
+     *    transpose network -- the only compiled network left -- and trow2 the row table with the fields of the reversed row
+     *    in its high half (torus_min_d2, kernels.hip). */
     int k4_mode, reflect;
-    int tw, n_cosets;               /* mode 4 */
+    int d4_mask;                    /* mode 5 */
+    uint64_t const *trow2;          /* mode 5: device [2^tw] */
+    int tw, n_cosets;               /* mode 4 / 5 */
     uint64_t tcol0;                 /* mode 4: the bits of column x = 0 */
     lsk_group_elem const *cosets;   /* mode 4: device [n_cosets] */
     uint32_t const *trow;           /* mode 4, tw <= 8: device [2^tw] row table of torus_min (lsk_torus_rowtab), else NULL */
@@ -363,6 +370,8 @@ uint64_t lsk_test_rep_trivial_dihedral(uint64_t a, int L, int inv, int reflect);
 /* K4 mode 4: the row table of torus_min (out[2^tw], tw <= 8) and the minimum of v (and, with inv, of its complement) over the
  * translations of the tw x (L / tw) torus, starting from `best` (host mirrors of the device code) */
 int lsk_torus_rowtab(int tw, uint32_t *out);
+int lsk_torus_rowtab2(int tw, uint64_t *out); /* mode 5: rowtab[r] | rowtab[reversed r] << 32 */
+uint64_t lsk_test_torus_min_d2(uint64_t v, int L, int tw, int inv, int present, uint64_t const *rowtab2, uint64_t best);
 uint64_t lsk_test_torus_min(uint64_t v, int L, int tw, int inv, uint32_t const *rowtab, uint64_t best);
 int lsk_bench_k4(int L, int inv, int reflect, int variant, int64_t n, uint64_t const *reps, uint64_t *out, void *stream);
 /* n packets -> y[idx(beta)] += value */

@@ -376,6 +376,11 @@ int ls_amd_bench_k4(int L, int inv, int reflect, int variant, int64_t n, uint64_
  * minimum of `state` computed that way (with the global spin flip folded in when the basis has one; ~0 when not applicable) */
 int ls_amd_test_translation_cosets(ls_hs_basis const *basis, int *n_cosets);
 uint64_t ls_amd_test_rep_by_cosets(ls_hs_basis const *basis, uint64_t state);
+/* ... and of its factorised form (K4 mode 5): when the cosets are the point group of the torus itself -- D2 = {1, r, o, r o}
+ * (rows reversed, row order reversed, both) or on a square torus D4 = D2 x {1, transpose}, or a subgroup -- the mask of the
+ * images that belong to the group (bits 0-3 of the word, 4-7 of its transpose; 0: the cosets are not of that form).  Then only
+ * the transpose is a compiled network and ls_amd_test_rep_by_cosets mirrors THAT routine (LS_AMD_K4=cosets: mode 4). */
+int ls_amd_test_d4_mask(ls_hs_basis const *basis);
 /* Host-only test hooks of the static index table {representative -> 32-bit payload} of the indexed pull mode
  * (distributed-matvec_amd/csrc/lsk.h: lsk_gtab): bucket bits for n keys of L bits (-1: no admissible shape), a sequential
  * build with the device kernel's placement rule into a malloc'ed array of 2 << bbits entries (release with

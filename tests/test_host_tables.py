@@ -712,3 +712,69 @@ def test_lattice_group_orbit_minimum_by_translation_cosets(name, tw, cosets):
         if inv != 0:
             imgs = [min(v, v ^ mask) for v in imgs]
         assert int(lib.ls_amd_test_rep_by_cosets(basis.payload, C.c_uint64(a))) == min(imgs), (name, hex(a))
+
+
+def _torus_config(tw, th, weight, gens, inv):
+    """spin basis on a tw x th torus (site = y tw + x) whose symmetry group is generated by the two translations and `gens`
+    (subset of "r" rows reversed, "o" row order reversed, "t" transpose), all in the trivial sector"""
+    L = tw * th
+    site = lambda y, x: (y % th) * tw + x % tw  # noqa: E731
+    perms = {"tx": [site(s // tw, s % tw + 1) for s in range(L)], "ty": [site(s // tw + 1, s % tw) for s in range(L)],
+             "r": [site(s // tw, tw - 1 - s % tw) for s in range(L)], "o": [site(th - 1 - s // tw, s % tw) for s in range(L)],
+             "ro": [site(th - 1 - s // tw, tw - 1 - s % tw) for s in range(L)], "t": [site(s % tw, s // tw) for s in range(L)]}
+    basis = {"number_spins": L, "hamming_weight": weight,
+             "symmetries": [{"permutation": perms[g], "sector": 0} for g in ["tx", "ty"] + list(gens)]}
+    if inv:
+        basis["spin_inversion"] = 1
+    return {"basis": basis}
+
+
+@pytest.mark.parametrize("case", ["6x6/r,o,t/inv/0xff", "4x4/r,o,t/inv/0xff", "6x4/r,o/inv/0x0f", "5x3/r,o//0x0f", "4x4/t//0x11", "6x3/ro//0x09",
+                                  "4x4/r//0x03", "5x5/r,t//0xff", "8x4/o/inv/0x05", "3x3/ro,t//0x99", "7x2/r,o/inv/0x03", "4x6/o//0x05"])
+def test_lattice_group_orbit_minimum_factorised(case, monkeypatch):
+    """K4 mode 5: when the cosets of the translation subgroup are the point group of the torus -- D2 = {1, r, o, r o}, on a square
+    torus D4 = D2 x {1, transpose}, or any subgroup -- only the transpose is a compiled network: r is delta swaps, r o a bit
+    reversal, and ONE pass over the rows prices all four images of a word through a row table that carries the reversed row's
+    fields as well (torus_min_d2).  The mask of images found is the expected one, and the routine (host mirror: same bit
+    operations as the device code) equals the brute-force minimum over the whole group on random states -- and equals mode 4."""
+    shape, gens, inv, want_mask = case.split("/")
+    tw, th = (int(v) for v in shape.split("x"))
+    L = tw * th
+    cfg = _torus_config(tw, th, None if L > 30 and False else L // 2, gens.split(","), bool(inv))
+    lib = _lib.load()
+    basis = D.loadConfigFromDict(cfg)
+    nc = C.c_int(0)
+    w = lib.ls_amd_test_translation_cosets(basis.payload, C.byref(nc))
+    order = basis.groupOrder()
+    assert w > 0 and order == nc.value * L, (w, nc.value, order)
+    mask_found = lib.ls_amd_test_d4_mask(basis.payload)
+    if w == tw:  # (a 4 x 6 torus is found as the 2-wide one first when that qualifies: any factorisation that is found is fine)
+        assert mask_found == int(want_mask, 16), hex(mask_found)
+        assert bin(mask_found).count("1") == nc.value
+    full = (1 << L) - 1
+    rng = np.random.RandomState(11)
+    states = [int(sum(1 << int(b) for b in rng.permutation(L)[: L // 2])) for _ in range(80)]
+    states += [full >> (L // 2), 0x5555555555555555 & full, 1, full ^ 1]
+    for a in states:
+        imgs = [int(lib.ls_amd_basis_apply_group_element(basis.payload, g, C.c_uint64(a))) for g in range(order)]
+        if inv:
+            imgs = [min(v, v ^ full) for v in imgs]
+        got = int(lib.ls_amd_test_rep_by_cosets(basis.payload, C.c_uint64(a)))
+        assert got == min(imgs), (case, hex(a), hex(got), hex(min(imgs)))
+    if mask_found:
+        monkeypatch.setenv("LS_AMD_K4", "cosets")  # mode 4 on the same states
+        for a in states[:20]:
+            imgs = [int(lib.ls_amd_basis_apply_group_element(basis.payload, g, C.c_uint64(a))) for g in range(order)]
+            if inv:
+                imgs = [min(v, v ^ full) for v in imgs]
+            assert int(lib.ls_amd_test_rep_by_cosets(basis.payload, C.c_uint64(a))) == min(imgs)
+
+
+def test_reference_lattice_models_take_the_factorised_form():
+    """heisenberg_square_4x4 / _6x6 (the reference's benchmark model, Makefile:86,109): the 8 cosets are D4 -> mode 5"""
+    lib = _lib.load()
+    for name in ("heisenberg_square_4x4", "heisenberg_square_6x6"):
+        basis = D.loadConfigFromDict(model_config(name))
+        assert lib.ls_amd_test_d4_mask(basis.payload) == 0xff, name
+    basis = D.loadConfigFromDict(model_config("heisenberg_chain_24_symm"))
+    assert lib.ls_amd_test_d4_mask(basis.payload) == 0
