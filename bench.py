@@ -80,14 +80,12 @@ def kernel_instance_sha(instance):
 PULL_KERNELS = ("direct-pull", "tile-pull", "replicated-")
 
 # ---- model of the replicated-x exchange on P GPUs, printed next to every measured N > 1 number -----------
-# One-GPU inputs measured in round 4 (profiles/r4_split_vs_fused_chain{36,40}symm_*.txt, profiles/r4_bench_default.json): the
-# split form of the projected pull kernel (resolve: stage A + K4 + slot look-ups, needs no x; gather: slots -> x -> y), the
-# owner-side prescaling, the staged row kernel of the unprojected chain.
-MODEL_INPUTS_MS = {
-    "heisenberg_chain_40_symm": {"resolve": 240.6, "gather": 65.1, "fused": 282.8, "prescale": 4.65, "n": 861725794},
-    "heisenberg_chain_36_symm": {"resolve": 15.07, "gather": 4.06, "fused": 18.09, "prescale": 0.30, "n": 63068876},
-    "heisenberg_chain_32": {"fused": 7.70, "n": 601080390},
-}
+# The one-GPU time the model starts from is MEASURED IN THE SAME RUN: every rank times the one-partition kernel on the whole
+# basis while it computes the parity reference (verify.reference_block).  What stays fixed are RATIOS of the split form of the
+# projected pull kernel measured on one GPU in round 4 (profiles/r4_split_vs_fused_chain{36,40}symm_*.txt): resolve (stage A +
+# K4 + slot look-ups, needs no x) = 0.85 x fused, gather (slots -> x -> y) = 0.23 x fused, owner-side prescaling = 0.016 x fused.
+MODEL_RATIOS = {"resolve": 0.85, "gather": 0.23, "prescale": 0.0165}
+MODEL_STATES = {"heisenberg_chain_40_symm": 861725794, "heisenberg_chain_36_symm": 63068876, "heisenberg_chain_32": 601080390}
 XGMI_IN_GBPS = (7 * 50.0, 7 * 64.0)  # what one GPU receives from its 7 peers at once: 7 links x 50-64 GB/s achievable of 153 nominal
 REACH_SHARE_MAX = 0.56               # 2.358 / 4.208 GB: the rank in the middle of the basis; the average over ranks is 0.44
 
@@ -102,38 +100,44 @@ REPL_OVERHEAD = 1.23                 # per-row cost of a rank's kernels relative
                                      # values no longer share lines; measured on eight loop-back ranks, profiles/r3_loopback_*_final.txt)
 
 
-def scaling_model(model, P, w=8):
+def scaling_model(model, P, w=8, fused_ms=None):
     """predicted ms per matvec of the replicated-x exchange on P GPUs and the speed-up over one GPU it implies:
     t(P) = prescale / P + max(resolve / P x f, exchange) + gather / P x f + return, exchange = N w (P - 1) / P / B_in; the
-    unprojected chain has no resolve step to hide the exchange behind and pays a permutation pass over all of x."""
-    m = MODEL_INPUTS_MS.get(model)
-    if not m or P < 2:
+    unprojected chain has no resolve step to hide the exchange behind and pays a permutation pass over all of x.
+    fused_ms = the one-GPU matvec of this build measured in this run (None: no model)."""
+    n = MODEL_STATES.get(model)
+    if not n or P < 2 or not fused_ms:
         return None
-    xbytes = m["n"] * w * (P - 1) / P
-    if "resolve" not in m:
+    projected = model.endswith("_symm")
+    m = {"fused": fused_ms, "n": n}
+    if projected:
+        m.update({k: r * fused_ms for k, r in MODEL_RATIOS.items()})
+    xbytes = n * w * (P - 1) / P
+    if not projected:
         # unprojected bases: the sub-range exchange (dist.c::setup_reach) -- the largest share a rank receives, measured with
         # loop-back ranks on chain_28 / chain_32 at P = 8 (profiles/r4_loopback_chain32_8ranks_subrange_exchange.txt: 2.36 of 4.21 GB)
         xbytes *= reach_share(P)
-    out = {"inputs_ms_one_gpu": m, "assumed_in_GBps": list(XGMI_IN_GBPS), "assumed_kernel_overhead": [1.0, REPL_OVERHEAD], "x_bytes_in_per_rank": xbytes}
+    out = {"inputs_ms_one_gpu": m, "inputs_source": "fused: measured in this run (one-partition kernel, this GPU); split ratios: round 4",
+           "assumed_in_GBps": list(XGMI_IN_GBPS), "assumed_kernel_overhead": [1.0, REPL_OVERHEAD], "x_bytes_in_per_rank": xbytes}
     lo_hi = []
     for b in XGMI_IN_GBPS:
-        for f in ((1.0, REPL_OVERHEAD) if "resolve" in m else (1.0,)):  # from "no overhead" to the loop-back figure
+        for f in ((1.0, REPL_OVERHEAD) if projected else (1.0,)):  # from "no overhead" to the loop-back figure
             xch = xbytes / b / 1e6  # ms
-            ret = m["n"] * w / P / 1.0e9 * 1e3 / 3000.0 + (m["n"] * w / P) * (P - 1) / P / b / 1e6  # group rows by owner (~3 TB/s) + send back
-            if "resolve" in m:
+            ret = n * w / P / 1.0e9 * 1e3 / 3000.0 + (n * w / P) * (P - 1) / P / b / 1e6  # group rows by owner (~3 TB/s) + send back
+            if projected:
                 t = m["prescale"] / P + max(m["resolve"] / P * f, xch) + m["gather"] / P * f + ret
             else:
-                perm = reach_share(P) * m["n"] * 2 * w / 1.0e9 * 1e3 / 2500.0  # the hashed -> block permutation of what arrived: random reads + writes
+                perm = reach_share(P) * n * 2 * w / 1.0e9 * 1e3 / 2500.0  # the hashed -> block permutation of what arrived: random reads + writes
                 t = xch + perm + m["fused"] / P + ret
             lo_hi.append(t)
     out["predicted_ms_per_matvec"] = [min(lo_hi), max(lo_hi)]
     out["predicted_speedup_over_one_gpu"] = [m["fused"] / max(lo_hi), m["fused"] / min(lo_hi)]
-    if "resolve" in m:
+    if projected:
         # with the slot cache the resolve step runs once per plan: a matvec is exchange + gather (+ prescale, + return)
         c = []
         for b in XGMI_IN_GBPS:
             for f in (1.0, REPL_OVERHEAD):
-                ret = m["n"] * w / P / 1.0e9 * 1e3 / 3000.0 + (m["n"] * w / P) * (P - 1) / P / b / 1e6
+                ret = n * w / P / 1.0e9 * 1e3 / 3000.0 + (n * w / P) * (P - 1) / P / b / 1e6
                 c.append(m["prescale"] / P + xbytes / b / 1e6 + m["gather"] / P * f + ret)
         out["predicted_ms_per_matvec_slot_cache"] = [min(c), max(c)]
     return out
@@ -364,6 +368,8 @@ def projected_extra(D, torch, dist, name, rank, world, time_steps, allsum, steps
     t0 = time.perf_counter()
     ref = verify.reference_block(h, reps_global, masks, rank, torch.float64)  # this rank's rows of the one-partition kernel
     out["reference_seconds"] = time.perf_counter() - t0
+    one_gpu_ms = verify.LAST_REFERENCE_MS[0]  # the one-partition matvec of this build on this GPU, timed while it made the reference
+    out["one_gpu_ms_per_matvec_this_run"] = one_gpu_ms
     t0 = time.perf_counter()
     op = RcclReplicatedOperator(h, reps_global, masks, torch.float64, comm=comm)
     out["setup_seconds"] += time.perf_counter() - t0
@@ -380,7 +386,9 @@ def projected_extra(D, torch, dist, name, rank, world, time_steps, allsum, steps
                 "n_gpus": world, "exchange_bytes_per_matvec": allsum(getattr(op, "exchange_bytes_per_matvec", 0)),
                 "x_bytes_in_this_rank": op.x_bytes_in,
                 "rank0_stage_ms_per_matvec": {k: v[0] / max(1, mv) for k, v in stages.items()},
-                "model": scaling_model(name, world)})
+                "model": scaling_model(name, world, fused_ms=one_gpu_ms)})
+    if one_gpu_ms:
+        out["speedup_over_one_gpu_this_run"] = one_gpu_ms / out["ms_per_step"]
     out["parity"] = verify_operator(op, x, y, ref, allsum, allmax)
     out["slot_cache"] = slot_cache_leg(plan, lambda: op.matvec(x, y, check=False), plan.check, plan.kernel_times_ms, time_steps, steps,
                                        allsum=allsum, world=world)
@@ -799,10 +807,22 @@ def main():
         t_ref = time.perf_counter()
         reference = verify.reference_block(h, reps_global, masks, rank, tdtype)
         rccl_info["reference_seconds"] = time.perf_counter() - t_ref
+        one_gpu_ms_main = verify.LAST_REFERENCE_MS[0]
+        rccl_info["one_gpu_ms_per_matvec_this_run"] = one_gpu_ms_main  # the one-partition kernel on the whole basis, this GPU
         makers = {"packets": lambda: RcclDistributedOperator(h, my_reps, tdtype, comm=comm)}
         if h.isHermitian:
             makers["replicated"] = lambda: RcclReplicatedOperator(h, reps_global, masks, tdtype, comm=comm)
         wanted = list(makers) if args.exchange == "auto" else [args.exchange]
+        # per-rank HBM of the two strategies: replicated x keeps O(N) tables on EVERY rank, the packets O(N / P);
+        # `auto` measures both while both fit and only the packets when the replicated tables do not (LS_AMD_EXCHANGE_HBM_CEILING)
+        from distributed_matvec_amd.distributed import choose_exchange, exchange_memory_estimate
+
+        free_b, _tot = torch.cuda.mem_get_info()
+        hbm_est = exchange_memory_estimate(n_total, int(my_reps.numel()), world, w, bool(symm), h.numberOffDiagTerms())
+        rccl_info["exchange_hbm_estimate_bytes"] = hbm_est
+        if args.exchange == "auto" and "replicated" in makers and choose_exchange(True, hbm_est, int(free_b)) == "packets":
+            wanted = ["packets"]
+            rccl_info["exchange_auto"] = "packets only: the replicated-x tables do not fit this rank's HBM"
         setup_t0 = time.perf_counter()
         results = {}
         failed = {}
@@ -956,7 +976,7 @@ def main():
                 extra[name] = {"error": "failed on another rank"}
             torch.cuda.empty_cache()
         if world > 1:
-            extra["model_heisenberg_chain_32"] = scaling_model("heisenberg_chain_32", world)
+            extra["model_heisenberg_chain_32"] = scaling_model("heisenberg_chain_32", world, fused_ms=one_gpu_ms_main)
         elif not distributed:
             for name in ("heisenberg_chain_36_symm", "heisenberg_chain_40_symm"):
                 try:

@@ -374,7 +374,17 @@ def diagonalize_distributed(config, group=None, num_evals: int = 1, eps: float =
     parts, masks = api.enumerateStates(basis, world)
     my_reps = parts[rank]
     if exchange == "auto":
-        exchange = "replicated" if h.isHermitian() else "packets"
+        # replicated x is the fast exchange, but its tables are O(N) on EVERY rank; the packets are the O(N / P) strategy and the
+        # fallback when those tables do not fit next to the Krylov basis (exchange_memory_estimate; LS_AMD_EXCHANGE_HBM_CEILING)
+        from .distributed import choose_exchange, exchange_memory_estimate
+
+        free, _total = torch.cuda.mem_get_info() if my_reps.is_cuda else (1 << 62, 0)
+        est = exchange_memory_estimate(int(masks.numel()), int(my_reps.numel()), world, 16 if dtype == torch.complex128 else 8,
+                                       basis.requiresProjection(), h.numberOffDiagTerms(), krylov_vectors=max_basis + 4)
+        exchange = choose_exchange(bool(h.isHermitian), est, int(free))
+        if verbose and rank == 0:
+            print(f"[diagonalize_distributed] exchange = {exchange} (per-rank HBM estimate: replicated {est['replicated'] / 1e9:.2f} GB, "
+                  f"packets {est['packets'] / 1e9:.2f} GB, free {free / 1e9:.1f} GB)", flush=True)
     if exchange == "replicated":
         reps_global = api.arrFromHashedToBlock(parts, masks) if world > 1 else parts[0]
         op = RcclReplicatedOperator(h, reps_global, masks, dtype, group=group)

@@ -336,6 +336,42 @@ class RcclReplicatedOperator:
     dot = RcclDistributedOperator.dot
 
 
+def exchange_memory_estimate(n_global: int, n_local: int, P: int, elem_bytes: int, projected: bool, terms_per_row: int,
+                             rows_per_round: int | None = None, krylov_vectors: int = 0):
+    """Per-rank HBM (bytes) of the two exchange strategies, next to what the solver itself keeps:
+      replicated  O(N): the global representatives (8 B / state), `masks` (1), the gathered x (w), and -- projected bases -- the
+                  static {rep -> slot} table (16-32 B) + the row -> slot permutation (4) + norms, or -- unprojected bases -- x in
+                  global order (w) + the permutation (4) + the staged kernel's records (8 / P); y staging 3 w / P.  Fast (x is
+                  ~30x smaller than the packets) but it only serves a basis whose tables fit EVERY rank.
+      packets     O(N / P): this rank's representatives, index structure and vectors, two send and two receive buffers of one
+                  round (rows_per_round x terms x packet bytes each) -- the reference's formulation (DMV:663-853) and the strategy
+                  that scales in capacity; optionally the all-destinations directory of the pre-indexed packets (P / 4 B per state,
+                  dropped by itself when it does not fit)."""
+    w = elem_bytes
+    rpr = rows_per_round or _rows_per_round()
+    if projected:
+        table = 16 * (1 << max(1, (2 * n_global - 1).bit_length()))  # 2 N entries of 8 B, rounded up to a power of two
+        repl = n_global * (8 + 1 + 4 + w) + table + 8 * n_local + 3 * w * (n_global // P + 1)
+    else:
+        repl = n_global * (8 + 1 + 4 + 2 * w) + (8 + 3 * w) * (n_global // P + 1)
+    rows = min(n_local, rpr)
+    # (about half of the flip-mask groups act on a given state of the Heisenberg models; the buffers are sized from the plan's exact
+    # counts and shrink with LS_AMD_ROWS_PER_ROUND -- they do not grow with N)
+    packets = n_local * (8 + 8 + 4) + 4 * rows * max(1, terms_per_row // 2) * (8 + w) + (8 * n_local if projected else 0)
+    vectors = (2 + krylov_vectors) * w * n_local
+    return {"replicated": int(repl + vectors), "packets": int(packets + vectors), "vectors": int(vectors)}
+
+
+def choose_exchange(hermitian: bool, estimate: dict, free_bytes: int, ceiling: int | None = None):
+    """'replicated' when the operator is Hermitian and its O(N) tables fit the HBM this rank may use, else 'packets' (the O(N / P)
+    strategy).  LS_AMD_EXCHANGE_HBM_CEILING (bytes) stands in for the free memory (tests; capacity planning)."""
+    env = os.environ.get("LS_AMD_EXCHANGE_HBM_CEILING")
+    limit = int(env) if env else (ceiling if ceiling is not None else int(0.9 * free_bytes))
+    if hermitian and estimate["replicated"] <= limit:
+        return "replicated"
+    return "packets"
+
+
 class HipReplicatedEngine:
     """ls_amd replicated-x plan for this rank (include/ls_amd.h)."""
 

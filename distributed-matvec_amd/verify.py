@@ -15,6 +15,7 @@ carry its own correctness evidence.  One-partition kernel and N-rank path share 
 from __future__ import annotations
 
 TOLERANCE = 1e-12  # max |dy| / max |y_ref|: sums of ~20 terms of O(1) in another order differ at 1e-15
+LAST_REFERENCE_MS = [None]  # wall time (HIP events) of the last reference matvec: one partition, whole basis, this GPU
 
 
 def reference_block(matrix, reps_global, masks, part: int, dtype, seed: int = 42):
@@ -31,6 +32,13 @@ def reference_block(matrix, reps_global, masks, part: int, dtype, seed: int = 42
     kernel = plan.kernel
     try:
         plan.matvec([x], [y], check=True)
+        # the same matvec once more, timed: the one-GPU time of THIS build on THIS box, which bench.py's scaling model starts from
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        plan.matvec([x], [y], check=True)
+        e1.record()
+        torch.cuda.synchronize()
+        LAST_REFERENCE_MS[0] = float(e0.elapsed_time(e1))
     finally:
         plan.destroy()
     n = int(masks.numel())

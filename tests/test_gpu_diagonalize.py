@@ -65,8 +65,9 @@ def test_chain_12_symmetric_known_energy(torch):
 
 
 @pytest.mark.parametrize("name,exchange", [("heisenberg_chain_12", "replicated"), ("heisenberg_chain_24_symm", "replicated"),
-                                           ("heisenberg_chain_12", "packets")])
-def test_diagonalize_distributed_one_rank(torch, tmp_path, name, exchange):
+                                           ("heisenberg_chain_12", "packets"), ("heisenberg_chain_24_symm", "auto"),
+                                           ("heisenberg_chain_24_symm", "auto-ceiling")])
+def test_diagonalize_distributed_one_rank(torch, tmp_path, name, exchange, monkeypatch, capfd):
     """Diagonalize.main with one process per GPU (diagonalize_distributed) on the one rank this box has: the C host's
     exchange with a single rank, RCCL reductions, and the block-distributed output file == what the one-process driver
     writes.  (With more ranks the same code runs under torchrun; the layout conversion and the per-rank hyperslab I/O are
@@ -84,11 +85,16 @@ def test_diagonalize_distributed_one_rank(torch, tmp_path, name, exchange):
         pytest.skip("libhdf5 not available")
     port = 29700 + os.getpid() % 200
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    if exchange == "auto-ceiling":  # the O(N) tables of the replicated-x exchange "do not fit": the packets take over by themselves
+        monkeypatch.setenv("LS_AMD_EXCHANGE_HBM_CEILING", "100000")
     try:
         out = str(tmp_path / "distributed.h5")
-        r = diagonalize_distributed(model_config(name), num_evals=1, eps=1e-10, output=out, exchange=exchange)
+        r = diagonalize_distributed(model_config(name), num_evals=1, eps=1e-10, output=out, exchange=exchange.split("-")[0],
+                                    verbose=exchange.startswith("auto"))
     finally:
         dist.destroy_process_group()
+    if exchange.startswith("auto"):
+        assert f"exchange = {'packets' if exchange == 'auto-ceiling' else 'replicated'}" in capfd.readouterr().out
     ref_out = str(tmp_path / "one_process.h5")
     ref = diagonalize(model_config(name), num_evals=1, eps=1e-10, output=ref_out)
     assert r.converged and abs(r.eigenvalues[0] - ref.eigenvalues[0]) < 1e-9

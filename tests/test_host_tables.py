@@ -778,3 +778,26 @@ def test_reference_lattice_models_take_the_factorised_form():
         assert lib.ls_amd_test_d4_mask(basis.payload) == 0xff, name
     basis = D.loadConfigFromDict(model_config("heisenberg_chain_24_symm"))
     assert lib.ls_amd_test_d4_mask(basis.payload) == 0
+
+
+def test_exchange_choice_by_per_rank_memory(monkeypatch):
+    """the replicated-x exchange keeps O(N) tables on EVERY rank, the packets O(N / P); `auto` takes the former
+    while it fits and falls back to the latter -- the strategy that scales in capacity -- when it does not."""
+    from distributed_matvec_amd.distributed import choose_exchange, exchange_memory_estimate
+
+    monkeypatch.delenv("LS_AMD_EXCHANGE_HBM_CEILING", raising=False)
+    n40, n32 = 861725794, 601080390
+    e = exchange_memory_estimate(n40, n40 // 8, 8, 8, True, 40, krylov_vectors=16)
+    assert 50e9 < e["replicated"] < 80e9 and e["packets"] - e["vectors"] < 0.5 * (e["replicated"] - e["vectors"])
+    assert choose_exchange(True, e, 288 << 30) == "replicated"
+    assert choose_exchange(True, e, 64 << 30) == "packets"          # a smaller part: the tables do not fit, the packets do
+    assert choose_exchange(False, e, 288 << 30) == "packets"         # not Hermitian: no pull form at all
+    u = exchange_memory_estimate(n32, n32 // 8, 8, 8, False, 32)
+    assert u["replicated"] > n32 * 29
+    # memory per rank: replicated does not shrink with P; of the packets only the round buffers (LS_AMD_ROWS_PER_ROUND) stay
+    e8, e64 = exchange_memory_estimate(n40, n40 // 8, 8, 8, True, 40), exchange_memory_estimate(n40, n40 // 64, 64, 8, True, 40)
+    assert e64["replicated"] > 0.8 * e8["replicated"]
+    small = exchange_memory_estimate(n40, n40 // 64, 64, 8, True, 40, rows_per_round=1 << 20)
+    assert small["packets"] < 0.05 * small["replicated"]
+    monkeypatch.setenv("LS_AMD_EXCHANGE_HBM_CEILING", str(10 << 30))
+    assert choose_exchange(True, e, 288 << 30) == "packets"
