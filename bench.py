@@ -820,7 +820,8 @@ def main():
         free_b, _tot = torch.cuda.mem_get_info()
         hbm_est = exchange_memory_estimate(n_total, int(my_reps.numel()), world, w, bool(symm), h.numberOffDiagTerms())
         rccl_info["exchange_hbm_estimate_bytes"] = hbm_est
-        if args.exchange == "auto" and "replicated" in makers and choose_exchange(True, hbm_est, int(free_b)) == "packets":
+        # (one decision for all ranks: a rank with less room pulls everybody to the packets)
+        if args.exchange == "auto" and "replicated" in makers and allsum(1.0 if choose_exchange(True, hbm_est, int(free_b)) == "packets" else 0.0) > 0:
             wanted = ["packets"]
             rccl_info["exchange_auto"] = "packets only: the replicated-x tables do not fit this rank's HBM"
         setup_t0 = time.perf_counter()

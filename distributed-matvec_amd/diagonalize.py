@@ -382,6 +382,10 @@ def diagonalize_distributed(config, group=None, num_evals: int = 1, eps: float =
         est = exchange_memory_estimate(int(masks.numel()), int(my_reps.numel()), world, 16 if dtype == torch.complex128 else 8,
                                        basis.requiresProjection(), h.numberOffDiagTerms(), krylov_vectors=max_basis + 4)
         exchange = choose_exchange(bool(h.isHermitian), est, int(free))
+        if world > 1:  # one decision for all ranks: any rank without room for the replicated tables pulls everybody to the packets
+            flag = torch.tensor([1 if exchange == "packets" else 0], dtype=torch.int64, device=my_reps.device if dist.get_backend(group) == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+            exchange = "packets" if int(flag.item()) else "replicated"
         if verbose and rank == 0:
             print(f"[diagonalize_distributed] exchange = {exchange} (per-rank HBM estimate: replicated {est['replicated'] / 1e9:.2f} GB, "
                   f"packets {est['packets'] / 1e9:.2f} GB, free {free / 1e9:.1f} GB)", flush=True)

@@ -8,6 +8,7 @@
 #   bench_c128       chain_32 c128 line
 #   packets          packet path A/B: pre-indexed vs state-carrying packets, timing trees (scripts/tile_bench.py)
 #   packets_prof     rocprofv3 kernel trace + SQ counters of chain_28 x 8 partitions
+#   lattice          heisenberg_square_6x6 / 4x4: K4 mode 5 vs mode 4 (LS_AMD_K4=cosets)      ablate:<model>  scripts/ablate_pull.py
 #   loopback:<L>[s]  scripts/loopback_bench.py, 8 loop-back ranks (s = _symm)
 #   pmc:<model>:<dtype>   kernel trace + FETCH/WRITE/VALU/TCC passes -> pmc_traffic entry (scripts/gpu_pmc_traffic.sh)
 #   prof_bench       rocprofv3 --kernel-trace --stats of the default bench command (no extras)
@@ -20,7 +21,7 @@ for step in "$@"; do
   echo "=== [$TAG] $step ($(date +%T))"
   case "$step" in
     smoke) timeout 300 python __graft_entry__.py smoke 2>&1 | tail -3 ;;
-    tests) ( time timeout 1500 python -m pytest tests -m gpu -q --maxfail=15 --timeout 420 --timeout-method signal > "$OUT/pytest_gpu.log" 2>&1 ) 2>&1 | grep real; tail -15 "$OUT/pytest_gpu.log" ;;
+    tests) ( time timeout 1500 python -m pytest tests -m gpu -q --maxfail=15 --timeout 420 --timeout-method signal --durations=40 > "$OUT/pytest_gpu.log" 2>&1 ) 2>&1 | grep real; grep -A45 "slowest" "$OUT/pytest_gpu.log" | cut -c1-150 | head -48; tail -6 "$OUT/pytest_gpu.log" ;;
     hang:*) # a test suspected of hanging: per-test timeout with a dump of every thread's stack (faulthandler), then exit
       timeout 400 python -X faulthandler -m pytest tests -m gpu -q -x --timeout 150 --timeout-method thread -k "${step#hang:}" > "$OUT/pytest_hang.log" 2>&1; tail -120 "$OUT/pytest_hang.log" | cut -c1-220 ;;
     tests:*) ( time timeout 1200 python -m pytest tests -m gpu -q --maxfail=15 --timeout 420 --timeout-method signal -k "${step#tests:}" >> "$OUT/pytest_focus.log" 2>&1 ) 2>&1 | grep real; tail -15 "$OUT/pytest_focus.log" ;;
@@ -36,6 +37,14 @@ for step in "$@"; do
     packets_prof)
       CMD="python $GRAFT_REPO_ROOT/scripts/tile_bench.py --L 28 --P 8 --steps 3" bash scripts/gpu_profile_cmd.sh "${TAG}_packets" > "$OUT/packets_prof.log" 2>&1
       grep -E "k_tile|k_scatter|k_diag" "gpurun_out/prof_${TAG}_packets/summary.txt" | cut -c1-200 | head -30 ;;
+    lattice) # the reference's benchmark model: K4 mode 5 (factorised point group) against mode 4 (one network per coset), same box
+      for k4 in default cosets; do
+        for m in heisenberg_square_6x6 heisenberg_square_4x4; do
+          echo -n "K4=$k4 $m: "; if [ $k4 = default ]; then timeout 300 python scripts/lattice_bench.py $m 5 2>&1 | tail -1 | cut -c1-600; else LS_AMD_K4=$k4 timeout 300 python scripts/lattice_bench.py $m 5 2>&1 | tail -1 | cut -c1-600; fi
+        done
+      done | tee "$OUT/lattice_k4_ab.txt" ;;
+    ablate:*) # where the time of the projected pull kernel goes (profiling build, results wrong by construction)
+      timeout 600 python scripts/ablate_pull.py "${step#ablate:}" 2>&1 | tee "$OUT/ablate_${step#ablate:}.txt" | tail -12 | cut -c1-300 ;;
     loopback:*) a=${step#loopback:}; L=${a%s}; S=""; [ "$a" != "$L" ] && S="--symm"
       timeout 900 python scripts/loopback_bench.py --L "$L" $S --P 8 --steps 3 > "$OUT/loopback_$a.txt" 2>&1; grep -E "ranks sharing|x received|aggregate" "$OUT/loopback_$a.txt" | cut -c1-300 ;;
     pmc:*) IFS=: read -r _ model dtype <<< "$step"
