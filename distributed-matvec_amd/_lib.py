@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libls_amd.so")
+# LS_AMD_LIB: another build of the same library next to the product (profiling / A/B builds: libls_amd_ablate.so, libls_amd_skew.so)
+LIB_PATH = os.path.join(_HERE, os.environ.get("LS_AMD_LIB", "libls_amd.so"))
 
 c_u64p = C.POINTER(C.c_uint64)
 c_i64p = C.POINTER(C.c_int64)

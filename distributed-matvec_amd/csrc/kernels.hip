@@ -696,7 +696,7 @@ __host__ __device__ __forceinline__ W rowrev_w(W v, int tw, W col0) {
 }
 template <typename W>
 __host__ __device__ __forceinline__ W torus_candidate(W word, int i, int kpos, int L, int tw, int th, W mask, W col0) {
-    const W lo = (W)(col0 * (W)((1u << i) - 1u)); // columns 0 .. i-1 of every row
+    const W lo = (W)((W)(col0 << i) - col0); // columns 0 .. i-1 of every row: 2^i - 1 per row, no borrow between rows (i < tw)
     const W c = (W)((((W)(word << i)) & (W)~lo & mask) | ((W)(word >> (tw - i)) & lo)); // every row rotated by i
     return rotl_sites<W>(c, tw * (th - 1 - kpos), L, mask);                              // row kpos to the top
 }
@@ -716,36 +716,42 @@ __host__ __device__ __forceinline__ W torus_min_d2(W v, int L, int tw, W mask, W
         m = eb & 0xffu;           mB0 = m < mB0 ? m : mB0;
         m = ~(eb >> 16) & rmask;  mB1 = m < mB1 ? m : mB1;
     }
-    uint32_t mstar = 0xffffffffu;
-    if (needA) { mstar = mA0; if (inv && mA1 < mstar) mstar = mA1; }
-    if (needB) { if (mB0 < mstar) mstar = mB0; if (inv && mB1 < mstar) mstar = mB1; }
+    if (!needA) mA0 = mA1 = 0xffffffffu;
+    if (!needB) mB0 = mB1 = 0xffffffffu;
+    if (!inv) mA1 = mB1 = 0xffffffffu;
+    uint32_t mstar = mA0 < mA1 ? mA0 : mA1;
+    mstar = mB0 < mstar ? mB0 : mstar;
+    mstar = mB1 < mstar ? mB1 : mstar;
     if ((W)mstar > (W)(best >> (L - tw))) return best;
+    // pass 2, ONE loop over the rows for all four alphabets (a loop per alphabet made every wave walk the rows four times: some
+    // lane always needs each of them): bit k tw + i of a mask = "rotate the rows by i, then row k (base order) to the top"
+    W cA0 = 0, cA1 = 0, cB0 = 0, cB1 = 0;
+    for (int k = 0; k < th; ++k) {
+        const uint64_t e = rowtab2[(uint32_t)(v >> (k * tw)) & rmask];
+        const uint32_t ea = (uint32_t)e, eb = (uint32_t)(e >> 32);
+        const int sh = k * tw;
+        if ((ea & 0xffu) == mstar && mA0 == mstar) cA0 |= (W)((ea >> 8) & 0xffu) << sh;
+        if ((~(ea >> 16) & rmask) == mstar && mA1 == mstar) cA1 |= (W)(ea >> 24) << sh;
+        if ((eb & 0xffu) == mstar && mB0 == mstar) cB0 |= (W)((eb >> 8) & 0xffu) << sh;
+        if ((~(eb >> 16) & rmask) == mstar && mB1 == mstar) cB1 |= (W)(eb >> 24) << sh;
+    }
+    // the words: rows in the base order (v | r(v)) and in reversed order (o(v) = rev(r(v)) | r o (v) = rev(v))
     const W rv = rowrev_w<W>(v, tw, col0);
+    const W brv = rev_sites<W>(rv, L), bv = rev_sites<W>(v, L);
+    const bool fwdA = present & 1, fwdB = present & 2, bwdA = present & 4, bwdB = present & 8;
     const uint32_t inv_tw = 65536u / (uint32_t)tw + 1u; // p / tw for p < 64, tw <= 8
-    // alphabet by alphabet (wave-uniform loop; a lane enters a body only when that alphabet reaches the smallest top row)
-    for (int alph = 0; alph < 4; ++alph) {
-        const bool isB = alph & 2, cpl = alph & 1;
-        const uint32_t mine = isB ? (cpl ? mB1 : mB0) : (cpl ? mA1 : mA0);
-        if ((cpl && !inv) || !(isB ? needB : needA) || mine != mstar) continue;
-        W cand = 0; // bit k tw + i: "rotate the rows by i, then row k (of the base order) to the top"
-        for (int k = 0; k < th; ++k) {
-            const uint64_t e = rowtab2[(uint32_t)(v >> (k * tw)) & rmask];
-            const uint32_t f = isB ? (uint32_t)(e >> 32) : (uint32_t)e;
-            const uint32_t m = cpl ? (~(f >> 16) & rmask) : (f & 0xffu);
-            if (m == mstar) cand |= (W)(cpl ? (f >> 24) : ((f >> 8) & 0xffu)) << (k * tw);
-        }
-        // the two words of this alphabet: rows in the base order (v | r(v)) and in reversed order (o(v) = rev(r(v)) | r o (v) = rev(v))
-        const W w_fwd = isB ? rv : v;
-        const W w_bwd = rev_sites<W>(isB ? v : rv, L);
-        const bool has_fwd = present & (isB ? 2 : 1), has_bwd = present & (isB ? 8 : 4);
+    // ONE pop loop over the candidates of all alphabets (its trip count is the largest number of candidates a lane of the wave holds)
+    while (cA0 | cA1 | cB0 | cB1) {
+        const bool a0 = cA0 != 0, a1 = !a0 && cA1 != 0, b0 = !a0 && !a1 && cB0 != 0;
+        const bool isB = !a0 && !a1, cpl = a1 || (isB && !b0);
+        const W cm = a0 ? cA0 : (a1 ? cA1 : (b0 ? cB0 : cB1));
+        const int p = sizeof(W) == 4 ? k4_ctz32((uint32_t)cm) : k4_ctz64((uint64_t)cm);
+        const W rest = (W)(cm & (cm - 1));
+        if (a0) cA0 = rest; else if (a1) cA1 = rest; else if (b0) cB0 = rest; else cB1 = rest;
+        const int k = (int)(((uint32_t)p * inv_tw) >> 16), i = p - k * tw;
         const W flip = cpl ? mask : (W)0;
-        while (cand) {
-            const int p = sizeof(W) == 4 ? k4_ctz32((uint32_t)cand) : k4_ctz64((uint64_t)cand);
-            cand &= cand - 1;
-            const int k = (int)(((uint32_t)p * inv_tw) >> 16), i = p - k * tw;
-            if (has_fwd) { const W c = torus_candidate<W>((W)(w_fwd ^ flip), i, k, L, tw, th, mask, col0); best = c < best ? c : best; }
-            if (has_bwd) { const W c = torus_candidate<W>((W)(w_bwd ^ flip), i, th - 1 - k, L, tw, th, mask, col0); best = c < best ? c : best; }
-        }
+        if (isB ? fwdB : fwdA) { const W c = torus_candidate<W>((W)((isB ? rv : v) ^ flip), i, k, L, tw, th, mask, col0); best = c < best ? c : best; }
+        if (isB ? bwdB : bwdA) { const W c = torus_candidate<W>((W)((isB ? bv : brv) ^ flip), i, th - 1 - k, L, tw, th, mask, col0); best = c < best ? c : best; }
     }
     return best;
 }
@@ -3044,9 +3050,9 @@ __global__ __launch_bounds__(kBlock, (COEF == COEF_CPLX ? 4 : 6)) void k_pull_t(
                 if (NC == 2) { hr[k] = s_coef[2 * e]; hi[k] = s_coef[2 * e + 1]; }
                 r[k] = (int)s_row[e];
             }
-#pragma unroll
-            for (int k = 0; k < K; ++k) {
-                if (kAblate && (bs.debug_ablate & 4)) continue; // profiling builds: no K4 (the look-ups then mostly miss)
+            // the three x-independent steps of a chunk: K4, near window (LDS), first-level load (perm entry | home bucket)
+            auto step_k4 = [&](int k) {
+                if (kAblate && (bs.debug_ablate & 4)) return; // profiling builds: no K4 (the look-ups then mostly miss)
                 if (K4M == K4_TRIVIAL) {
                     beta[k] = (uint64_t)rep_trivial<W>(bs, elems, (W)beta[k]); // xsrc is pre-multiplied by norm(rep)
                 } else if (live[k]) {
@@ -3061,9 +3067,8 @@ __global__ __launch_bounds__(kBlock, (COEF == COEF_CPLX ? 4 : 6)) void k_pull_t(
                         hr[k] = tr; hi[k] = ti;
                     }
                 }
-            }
-#pragma unroll
-            for (int k = 0; k < K; ++k) { // near window: LDS only
+            };
+            auto step_window = [&](int k) { // near window: LDS only
                 pos[k] = -1; bkt[k] = 0; tag[k] = 0; slot[k] = kNoSlot;
                 first[k] = make_ulonglong2(0, 0);
                 if (kAblate && (bs.debug_ablate & 2)) { // profiling builds: K4 kept alive, no look-up, no accumulation
@@ -3077,13 +3082,25 @@ __global__ __launch_bounds__(kBlock, (COEF == COEF_CPLX ? 4 : 6)) void k_pull_t(
                     }
                     if (pos[k] < 0) gt_split(ix.tab, beta[k], bkt[k], tag[k]);
                 }
-            }
-#pragma unroll
-            for (int k = 0; k < K; ++k) { // first-level loads: perm entry (near) or home bucket (far)
-                if (!live[k]) continue;
+            };
+            auto step_first = [&](int k) { // first-level loads: perm entry (near) or home bucket (far)
+                if (!live[k]) return;
                 if (pos[k] >= 0) slot[k] = ix.perm ? s_nwslot[pos[k]] : (uint32_t)(gbase + pos[k]);
                 else first[k] = *(ulonglong2 const *)(tab + 2 * bkt[k]);
-            }
+            };
+#ifdef LSK_PULL_SKEW
+            // A/B build: chunk by chunk instead of step by step -- the home-bucket load of chunk k is in flight while
+            // chunk k + 1 runs its K4 (the element / run loops of K4 are basic blocks the scheduler cannot move a load across)
+#pragma unroll
+            for (int k = 0; k < K; ++k) { step_k4(k); step_window(k); step_first(k); }
+#else
+#pragma unroll
+            for (int k = 0; k < K; ++k) step_k4(k);
+#pragma unroll
+            for (int k = 0; k < K; ++k) step_window(k);
+#pragma unroll
+            for (int k = 0; k < K; ++k) step_first(k);
+#endif
 #pragma unroll
             for (int k = 0; k < K; ++k) {
                 if (!live[k] || pos[k] >= 0) continue;
