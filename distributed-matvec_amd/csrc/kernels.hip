@@ -3088,19 +3088,15 @@ __global__ __launch_bounds__(kBlock, (COEF == COEF_CPLX ? 4 : 6)) void k_pull_t(
                 if (pos[k] >= 0) slot[k] = ix.perm ? s_nwslot[pos[k]] : (uint32_t)(gbase + pos[k]);
                 else first[k] = *(ulonglong2 const *)(tab + 2 * bkt[k]);
             };
-#ifdef LSK_PULL_SKEW
-            // A/B build: chunk by chunk instead of step by step -- the home-bucket load of chunk k is in flight while
-            // chunk k + 1 runs its K4 (the element / run loops of K4 are basic blocks the scheduler cannot move a load across)
-#pragma unroll
-            for (int k = 0; k < K; ++k) { step_k4(k); step_window(k); step_first(k); }
-#else
+            // (step by step over the chunks.  Chunk by chunk instead -- the home-bucket load of chunk k in flight while chunk k + 1 runs
+            // its K4 -- measured no different: chain_36_symm 17.61 vs 17.72 ms, chain_40_symm 276.5 vs 277.9 ms,
+            // profiles/r5_pull_skew_ab.txt: the kernel is at the fabric's random-request rate, not at a latency it could hide)
 #pragma unroll
             for (int k = 0; k < K; ++k) step_k4(k);
 #pragma unroll
             for (int k = 0; k < K; ++k) step_window(k);
 #pragma unroll
             for (int k = 0; k < K; ++k) step_first(k);
-#endif
 #pragma unroll
             for (int k = 0; k < K; ++k) {
                 if (!live[k] || pos[k] >= 0) continue;

@@ -8,7 +8,6 @@
 #   bench_c128       chain_32 c128 line
 #   packets          packet path A/B: pre-indexed vs state-carrying packets, timing trees (scripts/tile_bench.py)
 #   packets_prof     rocprofv3 kernel trace + SQ counters of chain_28 x 8 partitions
-#   skew             k_pull_t product build vs the -DLSK_PULL_SKEW build (make -C distributed-matvec_amd/csrc skew)
 #   lattice          heisenberg_square_6x6 / 4x4: K4 mode 5 vs mode 4 (LS_AMD_K4=cosets)      ablate:<model>  scripts/ablate_pull.py
 #   loopback:<L>[s]  scripts/loopback_bench.py, 8 loop-back ranks (s = _symm)
 #   pmc:<model>:<dtype>   kernel trace + FETCH/WRITE/VALU/TCC passes -> pmc_traffic entry (scripts/gpu_pmc_traffic.sh)
@@ -44,12 +43,6 @@ for step in "$@"; do
           echo -n "K4=$k4 $m: "; if [ $k4 = default ]; then timeout 300 python scripts/lattice_bench.py $m 5 2>&1 | tail -1 | cut -c1-600; else LS_AMD_K4=$k4 timeout 300 python scripts/lattice_bench.py $m 5 2>&1 | tail -1 | cut -c1-600; fi
         done
       done | tee "$OUT/lattice_k4_ab.txt" ;;
-    skew) # projected pull kernel, matrix-free: product order (step by step over the chunks) vs the skewed A/B build (chunk by chunk)
-      for lib in libls_amd.so libls_amd_skew.so; do
-        for L in 36 40; do
-          echo -n "LS_AMD_LIB=$lib chain_${L}_symm: "; LS_AMD_LIB=$lib timeout 300 python scripts/tile_bench.py --L $L --symm --mode pull --steps 5 2>&1 | tail -1 | cut -c1-330
-        done
-      done | tee "$OUT/pull_skew_ab.txt" ;;
     ablate:*) # where the time of the projected pull kernel goes (profiling build, results wrong by construction)
       timeout 600 python scripts/ablate_pull.py "${step#ablate:}" 2>&1 | tee "$OUT/ablate_${step#ablate:}.txt" | tail -12 | cut -c1-300 ;;
     loopback:*) a=${step#loopback:}; L=${a%s}; S=""; [ "$a" != "$L" ] && S="--symm"
