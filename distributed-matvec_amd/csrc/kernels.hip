@@ -1358,6 +1358,11 @@ __global__ __launch_bounds__(kBlock, (CPLX || sizeof(R) == 8 ? 5 : (sizeof(W) ==
     constexpr R kNone = ~(R)0;
     X const *__restrict__ x = (X const *)x_v;
     X *__restrict__ y = (X *)y_v;
+    // profiling builds only (make ablate, LS_AMD_ABLATE & 128): ONE MORE 8-byte stream per row, prefetched like the records -- what a
+    // byte per row costs this kernel, i.e. what computing sigma instead of loading it could save at best (scripts/chain_stream_cost.py)
+    const bool extra_stream = kAblate && (n_cached & 0x100);
+    if (kAblate) n_cached &= 0xff;
+    uint64_t ex_next = 0;
     // LDS image made once by the host (chain_lds_image): the binomial table in the rank type, NB rows of kc = weight + 2
     // columns, then the near-pair table (below); copied with 16-byte loads -- one block per tile means once per 1024 rows
     extern __shared__ uint4 s_img[];
@@ -1394,6 +1399,7 @@ __global__ __launch_bounds__(kBlock, (CPLX || sizeof(R) == 8 ? 5 : (sizeof(W) ==
                 if (n_cached > 0) t0_out = __builtin_nontemporal_load(cache + row);
             }
             if (n_cached > 1) t1_out = __builtin_nontemporal_load(cache + (size_t)n + (size_t)row);
+            if (kAblate && extra_stream) ex_next = __builtin_nontemporal_load(reps + (row < (n >> 1) ? row + (n >> 1) : row - (n >> 1)));
         };
         // Lanes past the end of a partial tile stay ACTIVE as ghosts of the tile's last row (they recompute it and
         // store nothing): the far pairs are priced lane-parallel, which needs every lane of a live wave.
@@ -1431,6 +1437,7 @@ __global__ __launch_bounds__(kBlock, (CPLX || sizeof(R) == 8 ? 5 : (sizeof(W) ==
             i_pending = -1;
             const W a = a_next;
             const R t0 = t0_next, t1 = t1_next;
+            const uint64_t ex = ex_next;
             if (sub + 1 < TILE / kBlock && (sub + 1) * kBlock + wave0 < cnt) {
                 const int64_t in = i0 + (r + kBlock < cnt ? r + kBlock : cnt - 1);
                 load_row(in, a_next, t0_next, t1_next);
@@ -1573,6 +1580,7 @@ __global__ __launch_bounds__(kBlock, (CPLX || sizeof(R) == 8 ? 5 : (sizeof(W) ==
             }
             cx_fma(t0 != kNone ? cv0 : 0.0, g0, acc);
             cx_fma(t1 != kNone ? cv1 : 0.0, g1, acc);
+            if (kAblate && extra_stream && ex == 0x0123456789abcdefULL) cx_fma(1.0, xr, acc); // (practically never: keeps the load alive)
             y_pending = acc;
             i_pending = ghost ? -1 : i;
         }
@@ -1728,7 +1736,7 @@ static int launch_chain(lsk_operator op, lsk_basis bs, lsk_index ix, lsk_tilemap
     // some overlap the LDS / ALU phases of others.
     hipLaunchKernelGGL((k_chain_t<W, R, CPLX, TILE, REC>), dim3((unsigned)gb), dim3(kBlock), (size_t)img.bytes, (hipStream_t)stream, op.runs,
                        op.n_diag, op.diag, bs.hamming_weight, img.dev, img.bytes / 16, img.kc, img.near_off, tm.entries, tm.slots_per_xcd, n, reps, x, y,
-                       kChainLdsPairs, n_cached, (R const *)cache, cv0, cv1, row0, n_x);
+                       kChainLdsPairs, n_cached | ((kAblate && (bs.debug_ablate & 128)) ? 0x100 : 0), (R const *)cache, cv0, cv1, row0, n_x);
     LSK_LAUNCH_CHECK();
     return 0;
 }

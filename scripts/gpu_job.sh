@@ -8,6 +8,7 @@
 #   bench_c128       chain_32 c128 line
 #   packets          packet path A/B: pre-indexed vs state-carrying packets, timing trees (scripts/tile_bench.py)
 #   packets_prof     rocprofv3 kernel trace + SQ counters of chain_28 x 8 partitions
+#   stream_cost      k_chain_t with one more 8-byte stream per row (profiling build): what a byte per row costs
 #   lattice          heisenberg_square_6x6 / 4x4: K4 mode 5 vs mode 4 (LS_AMD_K4=cosets)      ablate:<model>  scripts/ablate_pull.py
 #   loopback:<L>[s]  scripts/loopback_bench.py, 8 loop-back ranks (s = _symm)
 #   pmc:<model>:<dtype>   kernel trace + FETCH/WRITE/VALU/TCC passes -> pmc_traffic entry (scripts/gpu_pmc_traffic.sh)
@@ -43,6 +44,7 @@ for step in "$@"; do
           echo -n "K4=$k4 $m: "; if [ $k4 = default ]; then timeout 300 python scripts/lattice_bench.py $m 5 2>&1 | tail -1 | cut -c1-600; else LS_AMD_K4=$k4 timeout 300 python scripts/lattice_bench.py $m 5 2>&1 | tail -1 | cut -c1-600; fi
         done
       done | tee "$OUT/lattice_k4_ab.txt" ;;
+    stream_cost) timeout 400 python scripts/chain_stream_cost.py 32 10 2>&1 | grep -v amdgpu.ids | tee "$OUT/chain_stream_cost.txt" ;;
     ablate:*) # where the time of the projected pull kernel goes (profiling build, results wrong by construction)
       timeout 600 python scripts/ablate_pull.py "${step#ablate:}" 2>&1 | tee "$OUT/ablate_${step#ablate:}.txt" | tail -12 | cut -c1-300 ;;
     loopback:*) a=${step#loopback:}; L=${a%s}; S=""; [ "$a" != "$L" ] && S="--symm"
