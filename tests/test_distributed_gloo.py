@@ -99,7 +99,51 @@ class OracleEngine:
         pass
 
 
-def _worker(rank, world, port, name, cplx, num_rounds, out_dir):
+class OracleEngineIndexed(OracleEngine):
+    """... with the PRE-INDEXED packet layout of the HIP engine (include/ls_amd.h "Packet layout"): a segment of c packets is
+    [u32 index at the destination x c, padded to 8 bytes][value x c], and all segments of a round are consumed by ONE call"""
+
+    all_reps = None  # the whole basis (ascending): the producer ranks a state inside its owner's block, as the rank directory does
+
+    def segment_bytes(self, c):
+        return ((4 * c + 7) & ~7) + (16 if self.cplx else 8) * c
+
+    def generate(self, rnd, x, y, send):
+        betas, vals, keys = self._expand(rnd, x.numpy())
+        self._add(y, betas[keys == self.me], vals[keys == self.me])
+        buf = send.numpy()
+        owners = self.CO.locale_idx_of(self.all_reps, self.P)
+        off = 0
+        for d in range(self.P):
+            if d == self.me:
+                continue
+            sel = keys == d
+            n = int(sel.sum())
+            idx = self.CO.state_index(np.ascontiguousarray(self.all_reps[owners == d]), betas[sel]).astype(np.uint32)
+            kb = (4 * n + 7) & ~7
+            buf[off:off + 4 * n] = idx.view(np.uint8)
+            v = vals[sel] if self.cplx else np.ascontiguousarray(vals[sel].real)
+            w = 16 if self.cplx else 8
+            buf[off + kb:off + kb + w * n] = v.view(np.uint8)
+            off += kb + w * n
+
+    def scatter(self, recv, byte_offset, n, y):
+        raise AssertionError("the operator must consume a round through scatter_round when the engine offers it")
+
+    def scatter_round(self, recv, counts, offsets, y):
+        buf = recv.numpy()
+        w = 16 if self.cplx else 8
+        yn = y.numpy()
+        for n, off in zip(counts, offsets):
+            if n == 0:
+                continue
+            kb = (4 * n + 7) & ~7
+            idx = buf[off:off + 4 * n].view(np.uint32).astype(np.int64)
+            vals = buf[off + kb:off + kb + w * n].view(np.complex128 if self.cplx else np.float64)
+            np.add.at(yn, idx, vals)
+
+
+def _worker(rank, world, port, name, cplx, num_rounds, out_dir, indexed=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from helpers import model_config
@@ -121,8 +165,12 @@ def _worker(rank, world, port, name, cplx, num_rounds, out_dir):
         my_reps = torch.from_numpy(reps[mine].view(np.int64).copy())
         my_x = torch.from_numpy(x[mine].copy())
         my_y = torch.full_like(my_x, 7.0)  # overwritten by the diagonal pass
-        op = DistributedOperator(o, my_reps, my_x.dtype, engine_factory=OracleEngine, num_rounds=num_rounds)
+        OracleEngineIndexed.all_reps = reps
+        op = DistributedOperator(o, my_reps, my_x.dtype, engine_factory=OracleEngineIndexed if indexed else OracleEngine, num_rounds=num_rounds)
         assert op.num_rounds == (num_rounds if num_rounds else 1)
+        if indexed:  # 12 instead of 16 bytes per f64 packet on the wire (keys padded to 8 bytes per segment)
+            packets = sum(sum(c) for c in op.send_counts)
+            assert op.exchange_bytes_per_matvec <= packets * ((20 if cplx else 12)) + 4 * world * op.num_rounds
         # send/recv count matrices are transposes of each other across ranks
         gathered = [None] * world
         dist.all_gather_object(gathered, (op.send_counts, op.recv_counts))
@@ -135,23 +183,49 @@ def _worker(rank, world, port, name, cplx, num_rounds, out_dir):
         nrm2 = op.dot(my_x, my_x)
         assert abs(complex(nrm2) - np.vdot(x, x)) < 1e-9
         np.save(os.path.join(out_dir, f"y{rank}.npy"), my_y.numpy())
+        # the self-verification of `bench.py --gpus N` (distributed-matvec_amd/verify.py) across REAL processes: every rank's block
+        # against its rows of the one-partition result, element-wise + all-reduced invariants; then a fault on ONE rank, which
+        # every rank must learn about
+        from distributed_matvec_amd import verify
+
+        def allsum(v):
+            t = torch.tensor([float(v)], dtype=torch.float64)
+            dist.all_reduce(t)
+            return float(t.item())
+
+        def allmax(v):
+            t = torch.tensor([float(v)], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+
+        y_ref = torch.from_numpy(o.local_matvec(reps, x)[mine].copy())
+        ymax = float(np.abs(o.local_matvec(reps, x)).max())
+        par = verify.parity_object(my_y, my_x, y_ref, ymax, allsum=allsum, allmax=allmax, reference_kernel="oracle")
+        assert par["ok"] and par["max_rel_err"] <= 1e-12 and par["rows_off"] == 0, par
+        bad = my_y.clone()
+        if rank == 0:
+            bad[:-1] = my_y[1:]  # rank 0's rows arrive one element late
+        par = verify.parity_object(bad, my_x, y_ref, ymax, allsum=allsum, allmax=allmax, reference_kernel="oracle")
+        assert not par["ok"] and par["rows_off"] > 0, (rank, par)
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name,world,cplx,rounds", [
-    ("heisenberg_chain_12", 2, False, 1),
-    ("heisenberg_chain_10", 2, False, 3),
-    ("heisenberg_kagome_12_symm", 2, True, 2),
-    ("heisenberg_chain_16", 3, False, 2),
+@pytest.mark.parametrize("name,world,cplx,rounds,indexed", [
+    ("heisenberg_chain_12", 2, False, 1, False),
+    ("heisenberg_chain_10", 2, False, 3, False),
+    ("heisenberg_kagome_12_symm", 2, True, 2, False),
+    ("heisenberg_chain_16", 3, False, 2, False),
+    ("heisenberg_chain_16", 3, False, 2, True),
+    ("heisenberg_kagome_12", 2, True, 3, True),
 ])
-def test_all_to_all_exchange(tmp_path, name, world, cplx, rounds):
+def test_all_to_all_exchange(tmp_path, name, world, cplx, rounds, indexed):
     sys.path.insert(0, ROOT)
     from helpers import oracle_for, oracle_reps
     from oracle import c_oracle as CO
 
     port = 29600 + (os.getpid() % 200) + world * 7 + rounds
-    mp.spawn(_worker, args=(world, port, name, cplx, rounds, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port + (13 if indexed else 0), name, cplx, rounds, str(tmp_path), indexed), nprocs=world, join=True)
     reps = oracle_reps(name)
     rs = np.random.RandomState(5)
     x = rs.rand(len(reps)) - 0.5
