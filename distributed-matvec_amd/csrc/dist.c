@@ -21,6 +21,7 @@
 #include "lsk.h"
 
 int ls_amd_internal_error(char const *fmt, ...); /* host.c: formats into ls_amd_last_error(), returns -1 */
+void ls_amd_internal_clear_error(void);
 int ls_amd_internal_stage_begin(ls_amd_plan *pl, int stage, void *stream); /* host.c: stage timers (kDisplayTimings) */
 void ls_amd_internal_stage_end(ls_amd_plan *pl, int slot, void *stream);
 void ls_amd_internal_count_matvec(ls_amd_plan *pl);
@@ -312,6 +313,7 @@ int ls_amd_dist_create(ls_amd_dist **out, ls_amd_comm *cm, ls_hs_operator const 
             rc = ls_amd_internal_error("%s", lsk_last_error());
     if (agree(cm, rc, stream) != 0) { ls_amd_dist_destroy(d); return -1; } /* nobody enters a matvec some peer cannot serve */
     *out = d;
+    ls_amd_internal_clear_error();
     return 0;
 }
 
@@ -678,6 +680,7 @@ int ls_amd_repl_create(ls_amd_repl **out, ls_amd_comm *cm, ls_hs_operator const 
     }
     if (agree(cm, rc, stream) != 0) { ls_amd_repl_destroy(r); return -1; } /* buffers and plan exist on every rank, or the object on none */
     *out = r;
+    ls_amd_internal_clear_error();
     return 0;
 }
 

@@ -2469,6 +2469,7 @@ int ls_amd_plan_create(ls_amd_plan **out, ls_hs_operator const *op, ls_amd_dtype
     }
     if (lsk_sync(stream) != 0) { ls_amd_plan_destroy(pl); return dev_error(); }
     *out = pl;
+    ls_amd_internal_clear_error(); /* (internal fallbacks -- a table that did not fit, a layout that does not apply -- leave no message) */
     return 0;
 }
 

@@ -210,3 +210,15 @@ hamiltonian:
         assert len(diag) == 4 and sorted(x for v, m, r, x, s in off) == [0b0011, 0b0011, 0b0110, 0b1001, 0b1100]
     finally:
         L.ls_hs_destroy_yaml_config(conf)
+
+
+def test_a_successful_load_leaves_no_stale_error_message():
+    """ls_amd_last_error() after a failed load says why; a later SUCCESSFUL load must not leave that message behind (VERDICT r4:
+    a caller that checks the message instead of the pointer read the old failure as this call's)"""
+    lib = _lib.load()
+    assert not lib.ls_amd_load_yaml_config_from_string(b"hamiltonian:\n  terms: []\n")
+    assert b"basis" in lib.ls_amd_last_error()
+    conf = lib.ls_amd_load_yaml_config_from_string(b"basis:\n  number_spins: 4\n  hamming_weight: 2\n")
+    assert conf
+    assert lib.ls_amd_last_error() == b""
+    lib.ls_hs_destroy_yaml_config(conf)
