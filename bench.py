@@ -241,6 +241,50 @@ def boundary_extra(D, torch, h, basis, reps, y_device, x_device, calls=2):
     finally:
         for a in (x_h, y_h):
             L.ls_amd_host_unregister(C.c_void_p(a.ctypes.data))
+    # the PRIMME callback on a block of 4 columns in pageable memory (Diagonalize.chpl:134-162): one pipeline -- column k + 1 goes up
+    # and column k - 1 comes down while column k computes -- against column-by-column plain copies (LS_AMD_STAGE=0)
+    try:
+        bs = 4
+        Xb = np.empty((bs, n))
+        Yb = np.empty((bs, n))
+        for k in range(bs):
+            Xb[k] = x_h
+        Yb.fill(0.0)
+        pbuf = (C.c_char * 512)()
+        C.c_int64.from_buffer(pbuf, 0).value = n
+        C.c_int64.from_buffer(pbuf, L.ls_amd_test_primme_nlocal_offset()).value = n
+        C.c_void_p.from_buffer(pbuf, L.ls_amd_test_primme_matrix_offset()).value = C.cast(h.payload, C.c_void_p).value
+
+        def block_call():
+            ldx, ldy, blk, ierr = C.c_int64(n), C.c_int64(n), C.c_int(bs), C.c_int(0)
+            L.ls_chpl_primme_matvec(C.c_void_p(Xb.ctypes.data), C.byref(ldx), C.c_void_p(Yb.ctypes.data), C.byref(ldy), C.byref(blk),
+                                    C.cast(pbuf, C.c_void_p), C.byref(ierr))
+            _lib.raise_pending_halt()
+            assert ierr.value == 0
+
+        res = {}
+        for label, env in (("pipelined", "1"), ("plain_duplex_two_threads", "2"), ("plain_hipMemcpy", "0")):
+            if env is not None:
+                os.environ["LS_AMD_STAGE"] = env
+            try:
+                block_call()
+                L.ls_amd_boundary_stats_get(C.byref(st), 1)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                block_call()
+                torch.cuda.synchronize()
+                dtb = time.perf_counter() - t0
+                L.ls_amd_boundary_stats_get(C.byref(st), 1)
+                res[label] = {"ms_per_block": 1e3 * dtb, "ms_per_column": 1e3 * dtb / bs, "pcie_GBps_both_directions": (st.bytes_h2d + st.bytes_d2h) / dtb / 1e9}
+            finally:
+                if env is not None:
+                    del os.environ["LS_AMD_STAGE"]
+        res["max_rel_err_vs_device_plan"] = float((torch.from_numpy(Yb[bs - 1]).cuda() - y_device).abs().max()) / max(float(y_device.abs().max()), 1e-300)
+        res["block_size"] = bs
+        out["primme_block_pageable"] = res
+        del Xb, Yb
+    except Exception as e:  # reported, never hidden
+        out["primme_block_pageable"] = {"error": repr(e)[:300]}
     y_d = torch.zeros_like(y_device)
     out["device_pointers"] = timed(x_device.data_ptr(), y_d.data_ptr(), "device")
     out["device_pointers"]["max_rel_err_vs_device_plan"] = float((y_d - y_device).abs().max()) / max(float(y_device.abs().max()), 1e-300)
