@@ -263,7 +263,7 @@ def boundary_extra(D, torch, h, basis, reps, y_device, x_device, calls=2):
             assert ierr.value == 0
 
         res = {}
-        for label, env in (("pipelined", "1"), ("plain_duplex_two_threads", "2"), ("plain_hipMemcpy", "0")):
+        for label, env in (("pipelined", "1"), ("plain_hipMemcpy", "0")):
             if env is not None:
                 os.environ["LS_AMD_STAGE"] = env
             try:
@@ -288,7 +288,7 @@ def boundary_extra(D, torch, h, basis, reps, y_device, x_device, calls=2):
     y_d = torch.zeros_like(y_device)
     out["device_pointers"] = timed(x_device.data_ptr(), y_d.data_ptr(), "device")
     out["device_pointers"]["max_rel_err_vs_device_plan"] = float((y_d - y_device).abs().max()) / max(float(y_device.abs().max()), 1e-300)
-    out["staging_threads"] = int(os.environ.get("LS_AMD_STAGE_THREADS", 0)) or "min(8, cores / 4)"
+    out["staging_threads"] = int(os.environ.get("LS_AMD_STAGE_THREADS", 0)) or "min(16, cores / 4)"
     basis.uncheckedSetRepresentatives(np.zeros(0, dtype=np.uint64))  # drops the cached plan, its staging buffers and the device copy
     return out
 

@@ -3175,9 +3175,6 @@ static int ensure_device_reps(ls_hs_basis *b) {
  * x and y have persistent device copies in the cached plan slot (no hipMalloc / hipFree per call); y is uploaded only when the
  * operator has no diagonal terms (else it is assigned, DMV:1062-1063); the columns of a block go through one pipeline.
  * LS_AMD_STAGE=0 restores plain synchronous hipMemcpy (A/B in bench.py's boundary_host_ptr). */
-#ifndef LS_AMD_STAGE_DEFAULT
-#define LS_AMD_STAGE_DEFAULT 1
-#endif
 static lsk_stager *g_stager = NULL;
 static pthread_mutex_t g_stager_lock = PTHREAD_MUTEX_INITIALIZER;
 static struct ls_amd_boundary_stats g_bstats;
@@ -3194,9 +3191,9 @@ int ls_amd_host_unregister(void *p) {
     return 0;
 }
 int ls_amd_pointer_kind(void const *p) { return lsk_pointer_kind(p); }
-/* LS_AMD_STAGE: 1 = pinned bounce pipeline (pageable memory; registered memory: one DMA per direction), 2 = the runtime's own copies,
- * the download on a second host thread, 0 = the runtime's own copies one after the other */
-static int staging_mode(void) { char const *e = getenv("LS_AMD_STAGE"); return e ? atoi(e) : LS_AMD_STAGE_DEFAULT; }
+/* LS_AMD_STAGE: 1 (default) = pinned bounce pipeline (pageable memory; registered memory: one DMA per direction), 0 = the runtime's own
+ * copies one after the other (what a single vector costs either way: 179 vs 182 ms on chain_32; a block of four columns: 716 vs 555 ms) */
+static int staging_mode(void) { char const *e = getenv("LS_AMD_STAGE"); return e ? atoi(e) : 1; }
 static lsk_stager *stager(void) {
     pthread_mutex_lock(&g_stager_lock);
     char const *e = getenv("LS_AMD_STAGE_CHUNK_KB"), *t = getenv("LS_AMD_STAGE_THREADS");
@@ -3218,10 +3215,7 @@ static int transfer(void *d_up, void const *h_up, size_t up_bytes, int up_kind, 
         if (down_bytes) DEV(lsk_d2h(h_down, d_down, down_bytes));
         return 0;
     }
-    if (mode == 2 && (up_bytes == 0 || up_kind == LSK_PTR_PAGEABLE) && (down_bytes == 0 || down_kind == LSK_PTR_PAGEABLE)) {
-        if (lsk_stage_plain_duplex(d_up, h_up, up_bytes, h_down, d_down, down_bytes) != 0) return set_error("%s", lsk_stage_last_error());
-        return 0;
-    }
+
     lsk_stager *st = stager();
     if (!st) return -1;
     if (lsk_stage_run(st, d_up, h_up, up_bytes, up_kind, h_down, d_down, down_bytes, down_kind) != 0) return set_error("%s", lsk_stage_last_error());

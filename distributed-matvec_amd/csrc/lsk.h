@@ -199,8 +199,6 @@ int lsk_stager_threads(lsk_stager const *st);
 size_t lsk_stager_chunk(lsk_stager const *st);
 /* one upload and one download at the same time (either may have 0 bytes); *_kind = LSK_PTR_PAGEABLE (double-buffered pinned
  * bounce chunks, host copies by the stager's thread pool) or LSK_PTR_PINNED (one DMA); returns when both are complete */
-/* the same by two plain hipMemcpy calls, the download on a second host thread (no stager, no bounce buffers) */
-int lsk_stage_plain_duplex(void *d_up, void const *h_up, size_t up_bytes, void *h_down, void const *d_down, size_t down_bytes);
 int lsk_stage_run(lsk_stager *st, void *d_up, void const *h_up, size_t up_bytes, int up_kind, void *h_down, void const *d_down,
                   size_t down_bytes, int down_kind);
 

@@ -176,31 +176,8 @@ extern "C" void lsk_stager_destroy(lsk_stager *st) {
 extern "C" int lsk_stager_threads(lsk_stager const *st) { return st->pool->T; }
 extern "C" size_t lsk_stager_chunk(lsk_stager const *st) { return st->chunk; }
 
-// The same pair of transfers by the runtime's own copies, the download on a second host thread: hipMemcpy of pageable memory
-// pins in place and runs at the link rate on this stack (54 GB/s measured), so two of them in opposite directions are the
-// simplest duplex there is -- no bounce buffers, no host copies.
-extern "C" int lsk_stage_plain_duplex(void *d_up, void const *h_up, size_t up_bytes, void *h_down, void const *d_down, size_t down_bytes) {
-    int device = 0;
-    ST_CHECK(hipGetDevice(&device));
-    hipError_t e_down = hipSuccess;
-    std::thread th;
-    if (down_bytes && up_bytes)
-        th = std::thread([&] {
-            e_down = hipSetDevice(device);
-            if (e_down == hipSuccess) e_down = hipMemcpy(h_down, d_down, down_bytes, hipMemcpyDeviceToHost);
-        });
-    hipError_t e_up = hipSuccess;
-    if (up_bytes) e_up = hipMemcpy(d_up, h_up, up_bytes, hipMemcpyHostToDevice);
-    if (th.joinable()) th.join();
-    else if (down_bytes) e_down = hipMemcpy(h_down, d_down, down_bytes, hipMemcpyDeviceToHost);
-    if (e_up != hipSuccess || e_down != hipSuccess) {
-        snprintf(g_serr, sizeof(g_serr), "host <-> device copy failed: %s", hipGetErrorString(e_up != hipSuccess ? e_up : e_down));
-        (void)hipGetLastError();
-        return -1;
-    }
-    return 0;
-}
-
+// (The runtime's own copies from two host threads, one per direction, do NOT overlap on this stack: a block of four chain_32
+// columns took 716 ms either way, against 555 ms through the bounce buffers below -- profiles/r5_bench_default.json.)
 // One upload (host -> device) and one download (device -> host) at the same time; either may be empty (bytes == 0).
 // host_kind: LSK_PTR_PAGEABLE -> bounce buffers, LSK_PTR_PINNED -> one DMA.  Returns when both are complete.
 extern "C" int lsk_stage_run(lsk_stager *st, void *d_up, void const *h_up, size_t up_bytes, int up_kind,

@@ -85,7 +85,7 @@ int ls_amd_basis_rotate(int m_in, int m_out, int64_t n, double *d_V, int64_t ldv
  * The device copies of x / y persist with the cached plan (no hipMalloc / hipFree per call), y is uploaded only when the
  * operator has no diagonal terms (else it is assigned, DMV:1062-1063), and the columns of a PRIMME block share one pipeline
  * (column k + 1 goes up and column k - 1 comes down while column k computes).  Knobs: LS_AMD_STAGE=0 (plain synchronous
- * hipMemcpy), LS_AMD_STAGE_CHUNK_KB (32768), LS_AMD_STAGE_THREADS (min(8, cores / 4)). */
+ * hipMemcpy), LS_AMD_STAGE_CHUNK_KB (32768), LS_AMD_STAGE_THREADS (min(16, cores / 4)). */
 enum { LS_AMD_PTR_PAGEABLE = 0, LS_AMD_PTR_PINNED = 1, LS_AMD_PTR_DEVICE = 2 };
 int ls_amd_pointer_kind(void const *p);
 int ls_amd_host_register(void *p, size_t bytes);   /* hipHostRegister: the caller keeps the memory alive until ... */
