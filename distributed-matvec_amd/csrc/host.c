@@ -1439,6 +1439,8 @@ struct ls_amd_plan {
      * writes (u32 index at the destination, value) and the consumers are search-free (lsk_gdir, lsk.h) */
     lsk_gdir gd;
     lsk_rankdir *d_gdir; /* owned */
+    lsk_part_ctx *d_part_ctx; /* owned: all partitions in this process -- index / norms of every destination for the fused consumer */
+    int part_ctx_any;         /* a partition whose index carries a rank directory (else 0) */
     int key_bytes;       /* 4: pre-indexed packets, 8: packets carry the state */
     /* replicated-x mode: index / norms of the GLOBAL basis, global index of every local row */
     lsk_index gindex;
@@ -2443,6 +2445,20 @@ int ls_amd_plan_create(ls_amd_plan **out, ls_hs_operator const *op, ls_amd_dtype
     if (pl->family == FAMILY_TILE && my_partition < 0 && pl->send_capacity > 0) {
         if (lsk_malloc(&pl->d_send, (size_t)pl->send_capacity) != 0) { ls_amd_plan_destroy(pl); return dev_error(); }
     }
+    if (pl->family == FAMILY_TILE && my_partition < 0 && pl->P > 1 && pl->key_bytes == 8) {
+        /* the destinations' indexes as a device array: all segments a producer's round leaves are consumed by ONE launch */
+        lsk_part_ctx *h = (lsk_part_ctx *)calloc((size_t)pl->P, sizeof(lsk_part_ctx));
+        for (int d = 0; d < pl->P; ++d) {
+            h[d].ix = pl->parts[d].index;
+            h[d].norms = pl->dbs.k4_mode ? pl->parts[d].d_norms : NULL;
+            if (!pl->parts[pl->part_ctx_any].index.dir && pl->parts[d].index.dir) pl->part_ctx_any = d;
+        }
+        void *pc = NULL;
+        int const bad = lsk_malloc(&pc, sizeof(lsk_part_ctx) * (size_t)pl->P) != 0 || lsk_h2d(pc, h, sizeof(lsk_part_ctx) * (size_t)pl->P) != 0;
+        free(h);
+        if (bad) { if (pc) lsk_free(pc); ls_amd_plan_destroy(pl); return dev_error(); }
+        pl->d_part_ctx = (lsk_part_ctx *)pc;
+    }
     if (pl->family == FAMILY_TILE_PULL && pl->idx_mode) {
         /* static index table + room for x * norm(rep), acquired here: a table that cannot be built (no memory, a key that
          * finds no place within 255 buckets) puts the plan on the value-table path instead of failing the first matvec */
@@ -2476,6 +2492,7 @@ int ls_amd_plan_create(ls_amd_plan **out, ls_hs_operator const *op, ls_amd_dtype
 void ls_amd_plan_destroy(ls_amd_plan *pl) {
     if (!pl) return;
     if (pl->d_gdir) lsk_free(pl->d_gdir);
+    if (pl->d_part_ctx) lsk_free(pl->d_part_ctx);
     if (pl->parts) {
         for (int i = 0; i < pl->n_local; ++i) {
             part_state *ps = &pl->parts[i];
@@ -3059,6 +3076,35 @@ int ls_amd_matvec(ls_amd_plan *pl, void const *const *d_x, void *const *d_y, voi
                     stage_end(pl, st, stream);
                 }
                 continue;
+            }
+            if (pl->d_part_ctx) { /* state-carrying packets: one launch too, index and norms of a segment's destination from the context array */
+                /* (a partition whose rank directory is missing while others have one keeps the per-segment form below) */
+                int mixed = 0;
+                for (int d = 0; d < P; ++d) if ((pl->parts[d].index.dir != NULL) != (pl->parts[pl->part_ctx_any].index.dir != NULL) && pl->parts[d].count > 0) mixed = 1;
+                if (!mixed) {
+                    for (int d0 = 0; d0 < P; d0 += LSK_MAX_SEGS) {
+                        lsk_segs sg;
+                        memset(&sg, 0, sizeof(sg));
+                        int64_t total = 0;
+                        for (int d = d0; d < P && d < d0 + LSK_MAX_SEGS; ++d) {
+                            int64_t const c = ps->send_counts[(size_t)r * P + d];
+                            if (d == p || c == 0) continue;
+                            sg.start[sg.n] = total;
+                            sg.key_off[sg.n] = ps->h_beta_off[(size_t)r * P + d];
+                            sg.val_off[sg.n] = ps->h_val_off[(size_t)r * P + d];
+                            sg.y[sg.n] = d_y[d];
+                            sg.part[sg.n] = (uint8_t)d;
+                            total += c;
+                            ++sg.n;
+                        }
+                        if (sg.n == 0) continue;
+                        sg.start[sg.n] = total;
+                        int const st = stage_begin(pl, ST_SCATTER, stream);
+                        DEV(lsk_scatter_parts(pl->d_part_ctx, pl->parts[pl->part_ctx_any].index, pl->cplx, &sg, pl->d_send, pl->d_err, stream));
+                        stage_end(pl, st, stream);
+                    }
+                    continue;
+                }
             }
             for (int d = 0; d < P; ++d) {
                 int64_t c = ps->send_counts[(size_t)r * P + d];

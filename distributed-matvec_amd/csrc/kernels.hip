@@ -3596,6 +3596,54 @@ extern "C" int lsk_scatter_segs(lsk_index ix, int cplx, lsk_segs const *segs, vo
     return 0;
 }
 
+// ... and with the segments of one producer going to DIFFERENT partitions of this process (P logical partitions on one device: the
+// "exchange" is a pointer hand-off): index and norms of a segment come from a device array of per-partition contexts
+template <bool CPLX>
+__global__ __launch_bounds__(kBlock) void k_scatter_parts(lsk_part_ctx const *__restrict__ parts, lsk_index any, lsk_segs segs,
+                                                          char const *__restrict__ base, int *err, int xcd_chunk) {
+    __shared__ int64_t s_start[LSK_MAX_SEGS + 1];
+    extern __shared__ uint64_t s_db[];
+    for (int i = threadIdx.x; i <= segs.n; i += kBlock) s_start[i] = segs.start[i];
+    if (any.dir) rankdir_load(any, s_db); // (sites, weight and the binomials are those of the basis: the same for every partition)
+    __syncthreads();
+    const int64_t n = segs.start[segs.n];
+    const int64_t n_blocks = (n + kBlock - 1) / kBlock;
+    for (int64_t kb = blockIdx.x; kb < n_blocks; kb += gridDim.x) {
+        const int64_t k = pull_tile_of_block(kb, n_blocks, gridDim.x >= n_blocks ? xcd_chunk : 0) * kBlock + threadIdx.x;
+        if (k >= n) continue;
+        const int sg = seg_of(s_start, segs.n, k);
+        const int64_t j = k - s_start[sg];
+        double const *vals = reinterpret_cast<double const *>(base + segs.val_off[sg]);
+        double vr, vi = 0.0;
+        if (CPLX) { vr = vals[2 * j]; vi = vals[2 * j + 1]; } else vr = vals[j];
+        if (vr == 0.0 && vi == 0.0) continue; // DMV:110
+        const uint64_t beta = reinterpret_cast<uint64_t const *>(base + segs.key_off[sg])[j];
+        lsk_part_ctx const *pc = parts + segs.part[sg];
+        lsk_index ix = any; // kind, binom, dir_sites, dir_weight: common; the rest per partition
+        ix.shift = pc->ix.shift; ix.count = pc->ix.count; ix.reps = pc->ix.reps; ix.table = pc->ix.table; ix.dir = pc->ix.dir; ix.kind = pc->ix.kind;
+        const int64_t idx = ix.kind == LSK_INDEX_IDENTITY ? (int64_t)beta : (ix.dir ? rankdir_index(ix, beta, s_db) : search_index(ix, beta));
+        if (idx < 0) { atomicExch(err, 1); continue; }
+        double const *norms = pc->norms;
+        if (norms) { const double nb = norms[idx]; vr *= nb; vi *= nb; }
+        double *y = reinterpret_cast<double *>(segs.y[sg]);
+        if (CPLX) { atomic_add_f64(y + 2 * idx, vr); atomic_add_f64(y + 2 * idx + 1, vi); }
+        else atomic_add_f64(y + idx, vr);
+    }
+}
+extern "C" int lsk_scatter_parts(lsk_part_ctx const *d_parts, lsk_index any, int cplx, lsk_segs const *segs, void const *base, int *d_err, void *stream) {
+    if (segs->n < 1 || segs->n > LSK_MAX_SEGS) { snprintf(g_err, sizeof(g_err), "lsk_scatter_parts: %d segments", segs->n); return -1; }
+    if (any.kind == LSK_INDEX_COMBINADIC) { snprintf(g_err, sizeof(g_err), "lsk_scatter_parts: SEARCH/IDENTITY index only"); return -1; }
+    const int64_t n = segs->start[segs->n];
+    if (n <= 0) return 0;
+    const int64_t nb = (n + kBlock - 1) / kBlock;
+    dim3 g((unsigned)(nb < ((int64_t)1 << 30) ? nb : ((int64_t)1 << 30))), b(kBlock);
+    const size_t dyn = any.dir ? sizeof(uint64_t) * (size_t)any.dir_sites * (size_t)(any.dir_weight + 1) : 0;
+    if (cplx) hipLaunchKernelGGL(k_scatter_parts<true>, g, b, dyn, (hipStream_t)stream, d_parts, any, *segs, (char const *)base, d_err, 64);
+    else hipLaunchKernelGGL(k_scatter_parts<false>, g, b, dyn, (hipStream_t)stream, d_parts, any, *segs, (char const *)base, d_err, 64);
+    LSK_LAUNCH_CHECK();
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // out[i] = src[perm[i]]: the hashed -> block permutation of the replicated-x exchange (P ascending streams interleaved).
 // Two outputs per thread so that f64 results leave as 16-byte stores; perm is read with 8- / 16-byte loads.

@@ -151,9 +151,18 @@ typedef struct lsk_segs {
     int64_t key_off[LSK_MAX_SEGS];   /* byte offset of the segment's u64 states / u32 indices */
     int64_t val_off[LSK_MAX_SEGS];   /* ... of its values */
     void *y[LSK_MAX_SEGS];           /* the vector the segment accumulates into (all the same with one partition per process) */
+    uint8_t part[LSK_MAX_SEGS];      /* lsk_scatter_parts: the partition (entry of the context array) the segment belongs to */
 } lsk_segs;
+/* what a consumer needs to know of a destination partition: all partitions of one process (lsk_scatter_parts) */
+typedef struct lsk_part_ctx {
+    lsk_index ix;
+    double const *norms; /* per-row norms multiplied in (K4 modes that prescale), else NULL */
+} lsk_part_ctx;
 /* every packet of every segment: y[seg][idx] += value; pre-indexed packets (u32 idx) */
 int lsk_scatter_idx(int cplx, lsk_segs const *segs, void const *base, void *stream);
+/* state-carrying packets whose segments belong to DIFFERENT partitions of this process (logical partitions on one device): the
+ * index / norms of segment s are d_parts[segs->part[s]] (device array); all partitions share sites / weight of the rank directory */
+int lsk_scatter_parts(lsk_part_ctx const *d_parts, lsk_index any, int cplx, lsk_segs const *segs, void const *base, int *d_err, void *stream);
 /* the same for packets that carry the state: ONE index (all segments belong to the same destination partition) */
 int lsk_scatter_segs(lsk_index ix, int cplx, lsk_segs const *segs, void const *base, double const *norms, int *d_err, void *stream);
 
