@@ -1417,6 +1417,11 @@ typedef struct part_state {
      * round's send segments, fixed by the plan's count pass -- [sum over rounds of waves][P] u32 */
     uint32_t *d_wtab;     /* owned */
     int64_t *wtab_first;  /* [rounds] first wave of the round in d_wtab */
+    /* sorted packet streams (lsk_tile_st / lsk_window): position of every (tile, destination, stream) inside the destination's
+     * segment -- [sum over rounds of tiles][P * S] u32 -- and the stream starts of every segment, [rounds][P][S + 1] */
+    uint32_t *d_ttab;     /* owned */
+    int64_t *ttab_first;  /* [rounds + 1] first tile of the round in d_ttab */
+    uint32_t *d_soff;     /* owned */
 } part_state;
 
 enum { FAMILY_DIRECT_PUSH = 0, FAMILY_DIRECT_PULL = 1, FAMILY_TILE = 2, FAMILY_TILE_PULL = 3,
@@ -1442,6 +1447,11 @@ struct ls_amd_plan {
     lsk_part_ctx *d_part_ctx; /* owned: all partitions in this process -- index / norms of every destination for the fused consumer */
     int part_ctx_any;         /* a partition whose index carries a rank directory (else 0) */
     int key_bytes;       /* 4: pre-indexed packets, 8: packets carry the state */
+    /* sorted packet streams (all partitions in this process; unprojected fixed-weight bases, exchange operators): every source
+     * partition keeps its round in its own buffer and ONE consumer launch per round adds windows of every y in LDS -- no atomics */
+    int streams, st_S, st_tile_rows, st_wpb, st_rounds;
+    void **d_send_parts;     /* [P] owned */
+    lsk_wsrc *d_wsrcs;       /* owned: device [rounds][P destinations][P sources] */
     /* replicated-x mode: index / norms of the GLOBAL basis, global index of every local row */
     lsk_index gindex;
     uint32_t *d_gtable;
@@ -2141,16 +2151,33 @@ static __thread int g_no_packet_index = 0;
 void ls_amd_internal_set_no_packet_index(int v) { g_no_packet_index = v; }
 /* bytes of the key array (states or indices) of a segment of c packets: the values behind it stay 8-byte aligned */
 static int64_t segment_key_bytes(ls_amd_plan const *pl, int64_t c) { return pl->key_bytes == 4 ? ((4 * c + 7) & ~(int64_t)7) : 8 * c; }
+/* Sorted packet streams (kernels.hip, k_tile_st / k_window) for the partitions of ONE process: every off-diagonal group must be an
+ * exchange pair -- a packet exists iff alpha is anti-aligned on the pair, and beta - alpha is then one of two constants -- on an
+ * unprojected fixed-weight basis (the conditions of the pre-indexed packets, which setup_packet_index checks).
+ * LS_AMD_PACKET_STREAMS=0: the atomics of lsk_scatter_parts / lsk_scatter_idx instead (A/B). */
+static int streams_wanted(ls_amd_plan const *pl) {
+    char const *e = getenv("LS_AMD_PACKET_STREAMS");
+    if (e && atoi(e) == 0) return 0;
+    e = getenv("LS_AMD_PACKET_INDEX"); /* (the streams are made of pre-indexed packets: switched off with them) */
+    if (e && atoi(e) == 0) return 0;
+    if (pl->me >= 0 || pl->family != FAMILY_TILE || pl->dbs.proj != LSK_PROJ_NONE || pl->P > LSK_MAX_SEGS) return 0;
+    struct ls_amd_operator_ext const *oe = OEXT(pl->op);
+    if (oe->n_groups < 1 || oe->n_groups > 128 || pl->P * 2 * oe->n_groups > lsk_tile_st_max_classes()) return 0;
+    for (int g = 0; g < oe->n_groups; ++g)
+        if (oe->groups[g].fast != LSK_GROUP_EXCHANGE || __builtin_popcountll(oe->groups[g].x) != 2) return 0;
+    return 1;
+}
 static int setup_packet_index(ls_amd_plan *pl, uint64_t const *const *d_reps, int64_t const *counts, void *stream) {
     ls_hs_basis const *b = pl->op->basis;
     int const L = b->number_sites, h = BEXT(b)->hamming_weight, P = pl->P;
     char const *e = getenv("LS_AMD_PACKET_INDEX");
+    int const for_streams = streams_wanted(pl); /* the streams need every packet's index at its destination */
     if ((e && atoi(e) == 0) || g_no_packet_index) return 0;
     /* Default: only where packets cross a wire (one partition per process).  With all partitions in one process the "exchange" is a
      * pointer hand-off, and on one device the directory costs the producers more than it saves the consumers (chain_28 x 8: 23.5
      * against 22.6 ms, chain_30 x 8: 97.7 against 92.2 -- profiles/r5_packets_preindexed_ab.txt: the consumers are bound by their
      * atomics, not by the rank directory look-up they lose).  LS_AMD_PACKET_INDEX=1 forces it there too (tests, A/B). */
-    if (pl->me < 0 && !(e && atoi(e) == 1)) return 0;
+    if (pl->me < 0 && !(e && atoi(e) == 1) && !for_streams) return 0;
     if (pl->dbs.proj == LSK_PROJ_FULL || h < 0 || h >= LSK_BINOM_K - 1 || L > 64 || P > lsk_tile_wv_max_parts() || P > LSK_MAX_SEGS ||
         !packets_wave_rings()) return 0;
     for (int i = 0; i < pl->n_local; ++i) if (counts[i] >= 0xffffffffLL) return 0;
@@ -2182,6 +2209,11 @@ static int setup_packet_index(ls_amd_plan *pl, uint64_t const *const *d_reps, in
     pl->gd = gd;
     pl->d_gdir = (lsk_rankdir *)p;
     pl->key_bytes = 4;
+    if (for_streams) {
+        pl->streams = 1;
+        pl->st_S = 2 * OEXT(pl->op)->n_groups;
+        pl->st_tile_rows = 256;
+    }
     return 0;
 }
 
@@ -2274,9 +2306,44 @@ static int plan_setup_part(ls_amd_plan *pl, part_state *ps, int part_id, int num
     int const w = pl->cplx ? 16 : 8;
     unsigned long long hc[LSK_MAX_PARTS];
     /* the per-wave producer (deterministic send layout) whenever lane d of a wave can stand for destination d */
-    int const wave_rings = P <= lsk_tile_wv_max_parts() && packets_wave_rings();
+    int const wave_rings = !pl->streams && P <= lsk_tile_wv_max_parts() && packets_wave_rings();
     uint32_t *h_wtab = NULL;
     int64_t n_waves = 0;
+    /* sorted streams: count pass per (tile, destination, stream); the host turns the counts into positions inside the destination's
+     * segment, streams one after the other, tiles in row order inside a stream */
+    uint32_t *h_ttab = NULL, *h_soff = NULL, *sbase = NULL;
+    uint64_t *running = NULL;
+    int const S = pl->st_S, C = P * S, TR = pl->st_tile_rows;
+    int64_t n_tiles = 0;
+    if (pl->streams) {
+        uint64_t const *d_binom;
+        if (device_binom(&d_binom) != 0) { free(layouts); return -1; }
+        ps->ttab_first = (int64_t *)calloc((size_t)rounds + 1, sizeof(int64_t));
+        for (int r = 0; r < rounds; ++r) {
+            int64_t row0 = ps->count * r / rounds, row1 = ps->count * (r + 1) / rounds;
+            ps->ttab_first[r] = n_tiles;
+            n_tiles += (row1 - row0 + TR - 1) / TR;
+        }
+        ps->ttab_first[rounds] = n_tiles;
+        void *pt;
+        size_t const bytes = sizeof(uint32_t) * (size_t)(n_tiles > 0 ? n_tiles : 1) * (size_t)C;
+        if (lsk_malloc(&pt, bytes) != 0) { free(layouts); return dev_error(); }
+        ps->d_ttab = (uint32_t *)pt;
+        if (lsk_memset_async(pt, 0, bytes, stream) != 0) { free(layouts); return dev_error(); }
+        for (int r = 0; r < rounds; ++r) {
+            int64_t row0 = ps->count * r / rounds, row1 = ps->count * (r + 1) / rounds;
+            if (lsk_tile_st(pl->dop, pl->gd, d_binom, pl->cplx, 1, P, S, TR, row0, row1, ps->d_reps, NULL,
+                            ps->d_ttab + (size_t)ps->ttab_first[r] * C, NULL, NULL, pl->d_err, stream) != 0) { free(layouts); return dev_error(); }
+        }
+        h_ttab = (uint32_t *)malloc(bytes);
+        h_soff = (uint32_t *)calloc((size_t)rounds * P * (S + 1), sizeof(uint32_t));
+        sbase = (uint32_t *)calloc((size_t)C, sizeof(uint32_t));
+        running = (uint64_t *)calloc((size_t)C, sizeof(uint64_t));
+        if (!h_ttab || !h_soff || !sbase || !running || lsk_sync(stream) != 0 || lsk_d2h(h_ttab, pt, bytes) != 0) {
+            free(h_ttab); free(h_soff); free(sbase); free(running); free(layouts);
+            return dev_error();
+        }
+    }
     if (wave_rings) {
         ps->wtab_first = (int64_t *)calloc((size_t)rounds + 1, sizeof(int64_t));
         for (int r = 0; r < rounds; ++r) {
@@ -2300,7 +2367,34 @@ static int plan_setup_part(ls_amd_plan *pl, part_state *ps, int part_id, int num
     }
     for (int r = 0; r < rounds; ++r) {
         int64_t row0 = ps->count * r / rounds, row1 = ps->count * (r + 1) / rounds;
-        if (wave_rings) {
+        if (pl->streams) {
+            memset(running, 0, sizeof(uint64_t) * (size_t)C);
+            for (int64_t t = ps->ttab_first[r]; t < ps->ttab_first[r + 1]; ++t) { /* exclusive prefix over the tiles, class by class */
+                uint32_t *row = h_ttab + (size_t)t * C;
+                for (int c = 0; c < C; ++c) { uint32_t const k = row[c]; row[c] = (uint32_t)running[c]; running[c] += k; }
+            }
+            int too_many = 0;
+            for (int d = 0; d < P; ++d) { /* the streams of a segment one after the other */
+                uint64_t base = 0;
+                uint32_t *so = h_soff + ((size_t)r * P + d) * (S + 1);
+                for (int q = 0; q < S; ++q) {
+                    so[q] = (uint32_t)base;
+                    sbase[d * S + q] = (uint32_t)base;
+                    base += running[d * S + q];
+                    if (base > 0xffffffffULL) too_many = 1;
+                }
+                so[S] = (uint32_t)base;
+                hc[d] = base;
+            }
+            if (too_many) {
+                free(h_ttab); free(h_soff); free(sbase); free(running); free(layouts);
+                return set_error("more than 2^32 packets for one destination in one round: raise the number of rounds");
+            }
+            for (int64_t t = ps->ttab_first[r]; t < ps->ttab_first[r + 1]; ++t) {
+                uint32_t *row = h_ttab + (size_t)t * C;
+                for (int c = 0; c < C; ++c) row[c] += sbase[c];
+            }
+        } else if (wave_rings) {
             /* counts -> exclusive offsets along the waves of the round, destination by destination; the own partition's
              * packets never enter the send buffer */
             for (int d = 0; d < P; ++d) hc[d] = 0;
@@ -2322,7 +2416,7 @@ static int plan_setup_part(ls_amd_plan *pl, part_state *ps, int part_id, int num
         int64_t off = 0;
         for (int d = 0; d < P; ++d) {
             pl->nnz += (int64_t)hc[d];
-            int64_t c = (d == part_id) ? 0 : (int64_t)hc[d];
+            int64_t c = (d == part_id && !pl->streams) ? 0 : (int64_t)hc[d]; /* (sorted streams: the own partition's packets take the buffer too) */
             ps->send_counts[(size_t)r * P + d] = c;
             int64_t const keys = segment_key_bytes(pl, c); /* u64 states, or u32 indices padded to 8 bytes */
             layouts[r].beta_off[d] = off;
@@ -2338,12 +2432,58 @@ static int plan_setup_part(ls_amd_plan *pl, part_state *ps, int part_id, int num
         free(h_wtab);
         if (rcw != 0) { free(layouts); return dev_error(); }
     }
+    if (pl->streams) {
+        void *po = NULL;
+        size_t const sob = sizeof(uint32_t) * (size_t)rounds * (size_t)P * (size_t)(S + 1);
+        int const rcs = lsk_h2d(ps->d_ttab, h_ttab, sizeof(uint32_t) * (size_t)(n_tiles > 0 ? n_tiles : 1) * (size_t)C) != 0 ||
+                        lsk_malloc(&po, sob) != 0 || lsk_h2d(po, h_soff, sob) != 0;
+        ps->d_soff = (uint32_t *)po; /* owned by the plan from here on */
+        free(h_ttab); free(h_soff); free(sbase); free(running);
+        if (rcs != 0) { free(layouts); return dev_error(); }
+    }
     void *p;
     if (lsk_malloc(&p, sizeof(lsk_round_layout) * (size_t)rounds) != 0) { free(layouts); return dev_error(); }
     ps->d_layouts = (lsk_round_layout *)p; /* owned by the plan from here on */
     int const rc = lsk_h2d(p, layouts, sizeof(lsk_round_layout) * (size_t)rounds);
     free(layouts);
     return rc != 0 ? dev_error() : 0;
+}
+
+/* sorted streams, all partitions in this process: one send buffer per source partition (a round of all sources is consumed by
+ * ONE launch, so y is read and written once per round) and the consumer's view of every (round, destination, source) segment */
+static int setup_streams(ls_amd_plan *pl, int rounds) {
+    int const P = pl->P, S = pl->st_S;
+    pl->st_rounds = rounds;
+    pl->d_send_parts = (void **)calloc((size_t)P, sizeof(void *));
+    for (int p = 0; p < P; ++p) {
+        if (pl->parts[p].rounds != rounds) return set_error("internal error: partitions disagree on the number of rounds");
+        if (lsk_malloc(&pl->d_send_parts[p], (size_t)(pl->parts[p].max_send_bytes > 0 ? pl->parts[p].max_send_bytes : 8)) != 0) return dev_error();
+    }
+    size_t const n = (size_t)rounds * (size_t)P * (size_t)P;
+    lsk_wsrc *h = (lsk_wsrc *)calloc(n, sizeof(lsk_wsrc));
+    for (int r = 0; r < rounds; ++r)
+        for (int d = 0; d < P; ++d)
+            for (int q = 0; q < P; ++q) {
+                part_state const *src = &pl->parts[q];
+                lsk_wsrc *w = h + ((size_t)r * P + d) * P + q;
+                w->keys = (uint32_t const *)((char const *)pl->d_send_parts[q] + src->h_beta_off[(size_t)r * P + d]);
+                w->vals = (double const *)((char const *)pl->d_send_parts[q] + src->h_val_off[(size_t)r * P + d]);
+                w->soff = src->d_soff + ((size_t)r * P + d) * (size_t)(S + 1);
+            }
+    void *pw = NULL;
+    int const bad = lsk_malloc(&pw, sizeof(lsk_wsrc) * n) != 0 || lsk_h2d(pw, h, sizeof(lsk_wsrc) * n) != 0;
+    free(h);
+    pl->d_wsrcs = (lsk_wsrc *)pw;
+    if (bad) return dev_error();
+    /* windows per block: the end of one window's run is the start of the next one's (one binary search saved per stream) as long
+     * as the launch still has several blocks per CU */
+    int64_t windows = 0;
+    int const W = lsk_window_rows(pl->cplx);
+    for (int d = 0; d < P; ++d) windows += (pl->parts[d].count + W - 1) / W;
+    pl->st_wpb = windows >= 32768 ? 4 : (windows >= 8192 ? 2 : 1);
+    char const *e = getenv("LS_AMD_STREAM_WPB");
+    if (e && atoi(e) > 0) pl->st_wpb = atoi(e);
+    return 0;
 }
 
 int ls_amd_plan_create(ls_amd_plan **out, ls_hs_operator const *op, ls_amd_dtype dtype,
@@ -2423,6 +2563,12 @@ int ls_amd_plan_create(ls_amd_plan **out, ls_hs_operator const *op, ls_amd_dtype
     pl->key_bytes = 8;
     if (pl->family == FAMILY_TILE && setup_packet_index(pl, d_reps, counts, stream) != 0) { ls_amd_plan_destroy(pl); return -1; }
     pl->parts = (part_state *)calloc(pl->n_local, sizeof(part_state));
+    if (pl->streams && num_rounds <= 0) { /* one consumer launch per round over all sources: every partition runs the same rounds */
+        int64_t mx = 0, rpr = rows_per_round_default();
+        for (int i = 0; i < pl->n_local; ++i) if (counts[i] > mx) mx = counts[i];
+        num_rounds = (int)((mx + rpr - 1) / rpr);
+        if (num_rounds < 1) num_rounds = 1;
+    }
     for (int i = 0; i < pl->n_local; ++i) {
         part_state *ps = &pl->parts[i];
         ps->count = counts[i];
@@ -2431,6 +2577,7 @@ int ls_amd_plan_create(ls_amd_plan **out, ls_hs_operator const *op, ls_amd_dtype
         if (plan_setup_part(pl, ps, pid, num_rounds, stream) != 0) { ls_amd_plan_destroy(pl); return -1; }
         if (ps->max_send_bytes > pl->send_capacity) pl->send_capacity = ps->max_send_bytes;
     }
+    if (pl->streams && setup_streams(pl, num_rounds) != 0) { ls_amd_plan_destroy(pl); return -1; }
     if (pl->family == FAMILY_DIRECT_PULL || pl->family == FAMILY_DIRECT_PUSH) {
         int const combinadic = pl->parts[0].index.kind == LSK_INDEX_COMBINADIC;
         part_state *ps0 = &pl->parts[0];
@@ -2442,7 +2589,7 @@ int ls_amd_plan_create(ls_amd_plan **out, ls_hs_operator const *op, ls_amd_dtype
         }
         if (!pl->has_chain && !pl->has_pairs && build_tilemap(pl, ps0->count, 256) != 0) { ls_amd_plan_destroy(pl); return -1; }
     }
-    if (pl->family == FAMILY_TILE && my_partition < 0 && pl->send_capacity > 0) {
+    if (pl->family == FAMILY_TILE && my_partition < 0 && pl->send_capacity > 0 && !pl->streams) {
         if (lsk_malloc(&pl->d_send, (size_t)pl->send_capacity) != 0) { ls_amd_plan_destroy(pl); return dev_error(); }
     }
     if (pl->family == FAMILY_TILE && my_partition < 0 && pl->P > 1 && pl->key_bytes == 8) {
@@ -2493,6 +2640,11 @@ void ls_amd_plan_destroy(ls_amd_plan *pl) {
     if (!pl) return;
     if (pl->d_gdir) lsk_free(pl->d_gdir);
     if (pl->d_part_ctx) lsk_free(pl->d_part_ctx);
+    if (pl->d_send_parts) {
+        for (int p = 0; p < pl->P; ++p) if (pl->d_send_parts[p]) lsk_free(pl->d_send_parts[p]);
+        free(pl->d_send_parts);
+    }
+    if (pl->d_wsrcs) lsk_free(pl->d_wsrcs);
     if (pl->parts) {
         for (int i = 0; i < pl->n_local; ++i) {
             part_state *ps = &pl->parts[i];
@@ -2502,6 +2654,9 @@ void ls_amd_plan_destroy(ls_amd_plan *pl) {
             if (ps->d_layouts) lsk_free(ps->d_layouts);
             if (ps->d_wtab) lsk_free(ps->d_wtab);
             free(ps->wtab_first);
+            if (ps->d_ttab) lsk_free(ps->d_ttab);
+            if (ps->d_soff) lsk_free(ps->d_soff);
+            free(ps->ttab_first);
             free(ps->send_counts); free(ps->h_beta_off); free(ps->h_val_off);
         }
         free(pl->parts);
@@ -2798,7 +2953,7 @@ char const *ls_amd_plan_kernel_name(ls_amd_plan const *pl) {
     case FAMILY_REPL_DIRECT:
         return pl->has_chain ? "replicated-direct-pull+staged" : "replicated-direct-pull";
     case FAMILY_REPL_TILE: return pl->idx_mode ? (pl->slot_cache ? "replicated-tile-pull+indexed+cached" : "replicated-tile-pull+indexed") : "replicated-tile-pull";
-    default: return "tile";
+    default: return pl->streams ? "tile+streams" : "tile";
     }
 }
 /* nominal bytes per packet (a segment of c packets takes ls_amd_plan_segment_bytes(c): pre-indexed keys are padded to 8 bytes) */
@@ -3049,6 +3204,38 @@ int ls_amd_matvec(ls_amd_plan *pl, void const *const *d_x, void *const *d_y, voi
         return 0;
     }
     int const P = pl->P;
+    if (pl->streams) {
+        /* sorted streams: every source writes its round into its own buffer, then ONE launch adds windows of every y in LDS */
+        uint64_t const *d_binom;
+        if (device_binom(&d_binom) != 0) return -1;
+        int const W = lsk_window_rows(pl->cplx);
+        lsk_wdests wd;
+        memset(&wd, 0, sizeof(wd));
+        wd.n = P;
+        for (int d = 0; d < P; ++d) {
+            int64_t const windows = (pl->parts[d].count + W - 1) / W;
+            wd.count[d] = pl->parts[d].count;
+            wd.y[d] = d_y[d];
+            wd.first_block[d + 1] = wd.first_block[d] + (windows + pl->st_wpb - 1) / pl->st_wpb;
+        }
+        for (int r = 0; r < pl->st_rounds; ++r) {
+            int st = stage_begin(pl, ST_GENERATE, stream);
+            for (int p = 0; p < P; ++p) {
+                part_state *ps = &pl->parts[p];
+                int64_t row0 = ps->count * r / ps->rounds, row1 = ps->count * (r + 1) / ps->rounds;
+                int const slot = timing_begin(pl, stream);
+                DEV(lsk_tile_st(pl->dop, pl->gd, d_binom, pl->cplx, 0, P, pl->st_S, pl->st_tile_rows, row0, row1, ps->d_reps, d_x[p],
+                                ps->d_ttab + (size_t)ps->ttab_first[r] * (size_t)(P * pl->st_S), ps->d_layouts + r, pl->d_send_parts[p],
+                                pl->d_err, stream));
+                timing_end(pl, slot, stream);
+            }
+            stage_end(pl, st, stream);
+            st = stage_begin(pl, ST_SCATTER, stream);
+            DEV(lsk_window(pl->cplx, &wd, pl->d_wsrcs + (size_t)r * P * P, P, pl->st_S, pl->st_wpb, stream));
+            stage_end(pl, st, stream);
+        }
+        return 0;
+    }
     for (int p = 0; p < P; ++p) {
         part_state *ps = &pl->parts[p];
         for (int r = 0; r < ps->rounds; ++r) {

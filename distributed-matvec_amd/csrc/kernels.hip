@@ -3645,6 +3645,293 @@ extern "C" int lsk_scatter_parts(lsk_part_ctx const *d_parts, lsk_index any, int
 }
 
 // ---------------------------------------------------------------------------------------------
+// Packets in SORTED STREAMS: consumers without atomics (unprojected fixed-weight bases, exchange operators).
+//
+// What bounds every consumer above is one fabric atomic per packet (~40 G/s: chain_28 x 8 partitions 13 of 22.6 ms).  But the
+// packets of an exchange pair are not random: for a fixed pair (i, j) and a fixed pattern of alpha on it (01 or 10) the map
+// alpha -> beta = alpha ^ x adds a CONSTANT, so it is monotone; the rows of a producer ascend, the states of a destination
+// ascend, hence the destination indices of the packets of one STREAM = (pair, pattern) ascend along the producer's rows.
+// A producer that writes every (destination, stream) as its own run of the send segment -- in row order -- hands the consumer
+// 2 n_groups SORTED runs per source.  The consumer (k_window) then owns a WINDOW of W consecutive rows of y: it finds the
+// sub-run of every stream that falls into the window by binary search on the keys, streams those packets (coalesced 12-byte
+// reads) into an LDS copy of the window (ds_add_f64) and adds the window to y once: no global atomics, no fabric request per
+// packet, and the packet order inside y's window no longer matters.
+//
+// Producer (k_tile_st): k_tile_wv's wave rings, but a wave walks a TILE of tile_rows rows (64 at a time, the ring carried over)
+// and keeps one cursor per CLASS = (destination, stream) in LDS, initialised from the plan's table ttab[tile][class] = absolute
+// position of the tile's first packet of that class inside the destination's segment (count pass + host scan, like wtab).  The
+// rank of a packet among the packets of its class inside a chunk of 64 comes from one ballot per class BIT (9 ballots for
+// 8 destinations x 56 streams) instead of one pass per destination; ring order = (group, lane) order, so the packets of one
+// class leave in row order: every stream is EXACTLY sorted.  Own-partition packets take the same way (no atomics here either).
+// ---------------------------------------------------------------------------------------------
+constexpr int kStRing = 256;
+constexpr int kStMaxClasses = 1024; // LDS: 4 waves x classes x 4 bytes of cursors
+#define LSK_WAVE_SYNC()                                              \
+    do {                                                             \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       \
+        __builtin_amdgcn_wave_barrier();                             \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");       \
+    } while (0)
+template <bool CPLX, bool REAL, bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_tile_st(int n_groups, lsk_group const *__restrict__ groups,
+                                                    lsk_term const *__restrict__ off, lsk_gdir gd,
+                                                    uint64_t const *__restrict__ g_binom, Owner owner, int S, int cbits,
+                                                    int tile_rows, int64_t row0, int64_t row1, int64_t n_tiles,
+                                                    uint64_t const *__restrict__ reps, double const *__restrict__ x,
+                                                    uint32_t *__restrict__ ttab, lsk_round_layout const *__restrict__ layout,
+                                                    char *send, int *err, int xcd_chunk) {
+    constexpr int kWaves = kBlock / 64;
+    constexpr int kCap = kWaves * kStRing;
+    __shared__ uint64_t s_beta[kCap];
+    __shared__ double s_val[COUNT ? 1 : kCap * (CPLX ? 2 : 1)];
+    __shared__ uint8_t s_sid[kCap];
+    extern __shared__ uint64_t s_dyn[]; // [binomials of the directory][key offsets P][value offsets P][cursors: waves x classes u32]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int rb = wave * kStRing;
+    const int P = (int)owner.P, C = P * S;
+    const int ndb = COUNT ? 0 : gd.sites * (gd.weight + 1);
+    uint64_t *s_db = s_dyn;
+    int64_t *s_koff = reinterpret_cast<int64_t *>(s_dyn + ndb);
+    int64_t *s_voff = s_koff + (COUNT ? 0 : P);
+    uint32_t *s_cur = reinterpret_cast<uint32_t *>(s_voff + (COUNT ? 0 : P)) + wave * C;
+    if (!COUNT) {
+        gdir_load(gd, g_binom, s_db);
+        for (int d = tid; d < P; d += kBlock) { s_koff[d] = layout->beta_off[d]; s_voff[d] = layout->val_off[d]; }
+        __syncthreads();
+    }
+    const int64_t n_work = (n_tiles + kWaves - 1) / kWaves; // a block takes kWaves consecutive tiles, one per wave
+    for (int64_t wb = blockIdx.x; wb < n_work; wb += gridDim.x) {
+        // (consecutive tiles on ONE XCD: they append to the same lines of every stream, which then fill up inside one L2)
+        const int64_t tile = pull_tile_of_block(wb, n_work, gridDim.x >= n_work ? xcd_chunk : 0) * kWaves + wave;
+        if (tile >= n_tiles) continue; // wave-uniform: nothing below synchronises the block
+        const int64_t t0 = row0 + tile * tile_rows;
+        const int64_t t1 = t0 + tile_rows < row1 ? t0 + tile_rows : row1;
+        uint32_t *trow = ttab + (size_t)tile * C;
+        for (int c = lane; c < C; c += 64) s_cur[c] = COUNT ? 0u : trow[c];
+        LSK_WAVE_SYNC();
+        int head = 0, cnt = 0; // wave-uniform: the ring holds [head, head + cnt) mod kStRing
+        auto chunk = [&](int m) {
+            const bool live = lane < m;
+            const int e = rb + ((head + lane) & (kStRing - 1));
+            const uint64_t beta = live ? s_beta[e] : 0;
+            const int dest = live ? owner_of(beta, owner) : 0;
+            const uint32_t cls = (uint32_t)dest * (uint32_t)S + (live ? (uint32_t)s_sid[e] : 0u);
+            // rank among the packets of the same class in this chunk: lanes that agree with me on every class bit
+            unsigned long long same = __ballot(live);
+            for (int b = 0; b < cbits; ++b) {
+                const bool bit = (cls >> b) & 1u;
+                const unsigned long long bb = __ballot(live && bit);
+                same &= bit ? bb : ~bb;
+            }
+            const uint32_t rank = (uint32_t)__popcll(same & ((1ULL << lane) - 1));
+            const uint32_t n_same = (uint32_t)__popcll(same);
+            const uint32_t base = live ? s_cur[cls] : 0u;
+            LSK_WAVE_SYNC(); // every lane has read its cursor before the last lane of a class moves it
+            if (live && rank + 1 == n_same) s_cur[cls] = base + n_same;
+            if (!COUNT && live) {
+                double vr, vi = 0.0;
+                if (CPLX) { vr = s_val[2 * e]; vi = s_val[2 * e + 1]; } else vr = s_val[e];
+                int64_t idx = gdir_index(gd, beta, dest, s_db);
+                if (idx < 0) { // not a basis state (DMV:115-118): the flag halts the matvec; the slot the count pass reserved is still
+                    atomicExch(err, 1); // filled -- (index 0, value 0) -- so that no consumer meets a stale key
+                    idx = 0; vr = 0.0; vi = 0.0;
+                }
+                const size_t pos = (size_t)base + rank;
+                reinterpret_cast<uint32_t *>(send + s_koff[dest])[pos] = (uint32_t)idx;
+                double *pv = reinterpret_cast<double *>(send + s_voff[dest]);
+                if (CPLX) { pv[2 * pos] = vr; pv[2 * pos + 1] = vi; } else pv[pos] = vr;
+            }
+            LSK_WAVE_SYNC();
+        };
+        for (int64_t r0 = t0; r0 < t1; r0 += 64) {
+            const int64_t i = r0 + lane;
+            const bool valid = i < t1;
+            uint64_t a = 0;
+            double xr = 0.0, xi = 0.0;
+            if (valid) {
+                a = reps[i];
+                if (COUNT) xr = 1.0; // the packet set must not depend on x (exact send counts)
+                else if (CPLX) { xr = x[2 * i]; xi = x[2 * i + 1]; }
+                else xr = x[i];
+            }
+            for (int g0 = 0; g0 < n_groups; g0 += kTwGroups) {
+                const int g1 = min(g0 + kTwGroups, n_groups);
+                for (int g = g0; g < g1; ++g) { // stage A: append (beta, value, stream)
+                    lsk_group const G = groups[g];
+                    double cr = 0.0, ci = 0.0;
+                    if (valid) group_coeff<REAL>(G, off, a, cr, ci);
+                    // (every group is an exchange pair: a packet exists iff alpha is anti-aligned on it, whatever its amplitude)
+                    const bool act = valid && __popcll(a & G.x) == 1;
+                    const unsigned long long ball = __ballot(act);
+                    if (act) {
+                        const int slot = rb + ((head + cnt + __popcll(ball & ((1ULL << lane) - 1))) & (kStRing - 1));
+                        s_beta[slot] = a ^ G.x;
+                        s_sid[slot] = (uint8_t)(2 * g + (int)((a >> (__ffsll((unsigned long long)G.x) - 1)) & 1ULL));
+                        if (!COUNT) {
+                            if (CPLX) { s_val[2 * slot] = cr * xr - ci * xi; s_val[2 * slot + 1] = cr * xi + ci * xr; }
+                            else s_val[slot] = cr * xr;
+                        }
+                    }
+                    cnt += __popcll(ball);
+                }
+                LSK_WAVE_SYNC();
+                while (cnt >= 64) {
+                    chunk(64);
+                    head = (head + 64) & (kStRing - 1);
+                    cnt -= 64;
+                }
+            }
+        }
+        if (cnt > 0) chunk(cnt);
+        if (COUNT) for (int c = lane; c < C; c += 64) trow[c] = s_cur[c];
+        LSK_WAVE_SYNC();
+    }
+}
+
+extern "C" int lsk_tile_st_max_classes(void) { return kStMaxClasses; }
+// rows [row0, row1) of one partition, tile t = rows [row0 + t tile_rows, ...).  count_only: d_ttab[tile][P * S] <- packets of every
+// (tile, class = destination * S + stream), stream = 2 * group + (bit of alpha at the pair's lower site); otherwise d_ttab holds
+// the position of the tile's first packet of every class inside the destination's segment of *d_layout, and the packets --
+// (u32 index at the destination, value), the own partition's included -- are written to d_send.
+extern "C" int lsk_tile_st(lsk_operator op, lsk_gdir gd, uint64_t const *d_binom, int cplx, int count_only, int P, int S,
+                           int tile_rows, int64_t row0, int64_t row1, uint64_t const *reps, void const *x, uint32_t *d_ttab,
+                           lsk_round_layout const *d_layout, void *d_send, int *d_err, void *stream) {
+    if (row1 <= row0 || op.n_groups == 0) return 0;
+    if (S != 2 * op.n_groups || S > 256 || P < 1 || P * S > kStMaxClasses || tile_rows < 64 || (tile_rows & 63) || !d_ttab ||
+        (!count_only && (!gd.entries || gd.P != P || !d_binom))) {
+        snprintf(g_err, sizeof(g_err), "lsk_tile_st: bad arguments (P = %d, S = %d, tile_rows = %d)", P, S, tile_rows);
+        return -1;
+    }
+    const int C = P * S;
+    int cbits = 0;
+    while ((1 << cbits) < C) ++cbits;
+    Owner ow = make_owner(P);
+    const int64_t n_tiles = (row1 - row0 + tile_rows - 1) / tile_rows;
+    const int64_t n_work = (n_tiles + kBlock / 64 - 1) / (kBlock / 64);
+    dim3 g(1), b(kBlock);
+    hipStream_t s = (hipStream_t)stream;
+    const size_t dyn = sizeof(uint32_t) * (size_t)(kBlock / 64) * (size_t)C +
+                       (count_only ? 0 : sizeof(uint64_t) * ((size_t)gd.sites * (size_t)(gd.weight + 1) + 2 * (size_t)P));
+#define LSK_ST_ARGS op.n_groups, op.groups, op.off, gd, d_binom, ow, S, cbits, tile_rows, row0, row1, n_tiles, reps, (double const *)x, \
+        d_ttab, d_layout, (char *)d_send, d_err, 64
+#define LSK_ST_ONE(CPLX, REAL)                                                                                                    \
+    do {                                                                                                                          \
+        if (count_only) { g.x = tile_grid(k_tile_st<CPLX, REAL, true>, n_work); hipLaunchKernelGGL((k_tile_st<CPLX, REAL, true>), g, b, dyn, s, LSK_ST_ARGS); } \
+        else { g.x = tile_grid(k_tile_st<CPLX, REAL, false>, n_work); hipLaunchKernelGGL((k_tile_st<CPLX, REAL, false>), g, b, dyn, s, LSK_ST_ARGS); } \
+    } while (0)
+    if (cplx) { if (op.is_real) LSK_ST_ONE(true, true); else LSK_ST_ONE(true, false); }
+    else LSK_ST_ONE(false, true); // f64 vectors: real operators only (the plan refuses the rest)
+#undef LSK_ST_ONE
+#undef LSK_ST_ARGS
+    LSK_LAUNCH_CHECK();
+    return 0;
+}
+
+// Consumer of the sorted streams.  Block -> (destination partition, wpb consecutive windows of W rows of its y).  n_src source
+// segments per destination, S streams each: soff[s] .. soff[s + 1] = packets of stream s inside the segment, keys ascending.
+constexpr int kWinRows = 2048;    // doubles of one window's accumulator (c128: 1024 rows)
+constexpr int kWinStreams = 1024; // run bounds kept in LDS per pass over the streams
+__device__ __forceinline__ uint32_t lower_bound_u32(uint32_t const *__restrict__ k, uint32_t lo, uint32_t hi, uint32_t v) {
+    while (lo < hi) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if (k[mid] < v) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+// first position >= lo whose key is >= v (the window's end is a few dozen packets on: gallop, then search)
+__device__ __forceinline__ uint32_t gallop_u32(uint32_t const *__restrict__ k, uint32_t lo, uint32_t end, uint32_t v) {
+    uint32_t step = 64;
+    while (lo + step <= end && k[lo + step - 1] < v) { lo += step; step <<= 1; }
+    const uint32_t hi = lo + step < end ? lo + step : end;
+    return lower_bound_u32(k, lo, hi, v);
+}
+template <bool CPLX>
+__global__ __launch_bounds__(kBlock) void k_window(lsk_wdests dests, lsk_wsrc const *__restrict__ srcs, int n_src, int S, int wpb) {
+    constexpr int W = CPLX ? kWinRows / 2 : kWinRows;
+    __shared__ double s_acc[kWinRows];
+    __shared__ uint32_t s_lo[kWinStreams], s_hi[kWinStreams];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int d = 0;
+    while (d + 1 < dests.n && (int64_t)blockIdx.x >= dests.first_block[d + 1]) ++d; // block-uniform
+    const int64_t n = dests.count[d];
+    double *__restrict__ y = reinterpret_cast<double *>(dests.y[d]);
+    const int64_t wb = (int64_t)blockIdx.x - dests.first_block[d];
+    const int T = n_src * S;
+    lsk_wsrc const *__restrict__ segs = srcs + (size_t)d * n_src;
+    for (int win = 0; win < wpb; ++win) {
+        const int64_t w0 = (wb * wpb + win) * W;
+        if (w0 >= n) break;
+        const int64_t w1 = w0 + W < n ? w0 + W : n;
+        for (int i = tid; i < kWinRows; i += kBlock) s_acc[i] = 0.0;
+        const bool carry = win > 0 && T <= kWinStreams; // the end of the previous window's run is the start of this one's
+        for (int t0 = 0; t0 < T; t0 += kWinStreams) {
+            const int tn = T - t0 < kWinStreams ? T - t0 : kWinStreams;
+            for (int t = tid; t < tn; t += kBlock) {
+                const int q = (t0 + t) / S, s = (t0 + t) - q * S;
+                uint32_t const *__restrict__ keys = segs[q].keys;
+                uint32_t const *__restrict__ soff = segs[q].soff;
+                const uint32_t a = soff[s], e = soff[s + 1];
+                const uint32_t lo = carry ? s_hi[t] : lower_bound_u32(keys, a, e, (uint32_t)w0);
+                const uint32_t hi = w1 >= n ? e : gallop_u32(keys, lo, e, (uint32_t)w1);
+                s_lo[t] = lo;
+                s_hi[t] = hi;
+            }
+            __syncthreads();
+            // a wave takes the runs t = wave, wave + 4, ..., two at a time (their loads are issued together)
+            for (int t = wave; t < tn; t += 8) {
+                const int tb = t + 4;
+                const bool has_b = tb < tn;
+                const int qa = (t0 + t) / S, qb = has_b ? (t0 + tb) / S : qa;
+                uint32_t const *__restrict__ ka = segs[qa].keys;
+                double const *__restrict__ va = segs[qa].vals;
+                uint32_t const *__restrict__ kb = segs[qb].keys;
+                double const *__restrict__ vb = segs[qb].vals;
+                const uint32_t lo_a = s_lo[t], hi_a = s_hi[t];
+                const uint32_t lo_b = has_b ? s_lo[tb] : 0u, hi_b = has_b ? s_hi[tb] : 0u;
+                const uint32_t len_a = hi_a - lo_a, len_b = hi_b - lo_b;
+                const uint32_t iters = ((len_a > len_b ? len_a : len_b) + 63u) >> 6;
+                for (uint32_t it = 0; it < iters; ++it) {
+                    const uint32_t pa = lo_a + (it << 6) + (uint32_t)lane, pb = lo_b + (it << 6) + (uint32_t)lane;
+                    const bool in_a = pa < hi_a, in_b = pb < hi_b;
+                    uint32_t key_a = 0xffffffffu, key_b = 0xffffffffu;
+                    double ar = 0.0, ai = 0.0, br = 0.0, bi = 0.0;
+                    if (in_a) { key_a = ka[pa]; if (CPLX) { ar = va[2 * (size_t)pa]; ai = va[2 * (size_t)pa + 1]; } else ar = va[pa]; }
+                    if (in_b) { key_b = kb[pb]; if (CPLX) { br = vb[2 * (size_t)pb]; bi = vb[2 * (size_t)pb + 1]; } else br = vb[pb]; }
+                    const uint32_t oa = key_a - (uint32_t)w0, ob = key_b - (uint32_t)w0; // (a key outside the window -- only after a
+                    if (in_a && oa < (uint32_t)W) {                                        //  failed directory look-up -- is dropped)
+                        if (CPLX) { atomicAdd(&s_acc[2 * oa], ar); atomicAdd(&s_acc[2 * oa + 1], ai); } else atomicAdd(&s_acc[oa], ar);
+                    }
+                    if (in_b && ob < (uint32_t)W) {
+                        if (CPLX) { atomicAdd(&s_acc[2 * ob], br); atomicAdd(&s_acc[2 * ob + 1], bi); } else atomicAdd(&s_acc[ob], br);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        const int64_t m = (w1 - w0) * (CPLX ? 2 : 1);
+        double *__restrict__ yw = y + w0 * (CPLX ? 2 : 1);
+        for (int64_t i = tid; i < m; i += kBlock) yw[i] += s_acc[i];
+        __syncthreads();
+    }
+}
+extern "C" int lsk_window_rows(int cplx) { return cplx ? kWinRows / 2 : kWinRows; }
+// y[d][key] += value for every packet of every stream of every source segment: dests (by value) names the destination vectors
+// and the first block of each (ceil(ceil(count / rows) / wpb) blocks per destination); d_srcs is [dests.n][n_src].
+extern "C" int lsk_window(int cplx, lsk_wdests const *dests, lsk_wsrc const *d_srcs, int n_src, int S, int wpb, void *stream) {
+    if (dests->n < 1 || dests->n > LSK_MAX_SEGS || n_src < 1 || S < 1 || wpb < 1) { snprintf(g_err, sizeof(g_err), "lsk_window: bad arguments"); return -1; }
+    const int64_t nb = dests->first_block[dests->n];
+    if (nb <= 0) return 0;
+    if (nb > ((int64_t)1 << 31) - 1) { snprintf(g_err, sizeof(g_err), "lsk_window: too many windows"); return -1; }
+    dim3 g((unsigned)nb), b(kBlock);
+    if (cplx) hipLaunchKernelGGL(k_window<true>, g, b, 0, (hipStream_t)stream, *dests, d_srcs, n_src, S, wpb);
+    else hipLaunchKernelGGL(k_window<false>, g, b, 0, (hipStream_t)stream, *dests, d_srcs, n_src, S, wpb);
+    LSK_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
 // out[i] = src[perm[i]]: the hashed -> block permutation of the replicated-x exchange (P ascending streams interleaved).
 // Two outputs per thread so that f64 results leave as 16-byte stores; perm is read with 8- / 16-byte loads.
 // ---------------------------------------------------------------------------------------------

@@ -283,6 +283,35 @@ int lsk_tile_wv_max_parts(void);
 int lsk_tile_wv(lsk_operator op, lsk_basis bs, lsk_index ix, lsk_gdir gd, int cplx, int count_only, int P, int me,
                 int64_t row0, int64_t row1, uint64_t const *reps, double const *norms, void const *x, void *y,
                 uint32_t *d_wtab, lsk_round_layout const *d_layout, void *d_send, int *d_err, void *stream);
+/* Packets in SORTED STREAMS (kernels.hip, k_tile_st / k_window): unprojected fixed-weight bases, operators whose off-diagonal
+ * groups are all exchange pairs.  stream = 2 * group + (bit of alpha at the pair's lower site); along a stream beta - alpha is a
+ * constant, so the packets of one (destination, stream) -- written in row order -- carry ASCENDING destination indices, and the
+ * consumer adds a window of y at a time in LDS instead of one fabric atomic per packet.
+ * lsk_tile_st: rows [row0, row1) of one partition; tile t = rows [row0 + t tile_rows, ...), walked by one wave.  count_only:
+ * d_ttab[tile][P * S] <- packets of every (tile, class = destination * S + stream); otherwise d_ttab holds the position of the
+ * tile's first packet of every class inside the destination's segment of *d_layout (u32 keys, then values), and every packet --
+ * the own partition's too -- goes to d_send as (u32 index at the destination, value). */
+int lsk_tile_st_max_classes(void);
+int lsk_tile_st(lsk_operator op, lsk_gdir gd, uint64_t const *d_binom, int cplx, int count_only, int P, int S, int tile_rows,
+                int64_t row0, int64_t row1, uint64_t const *reps, void const *x, uint32_t *d_ttab,
+                lsk_round_layout const *d_layout, void *d_send, int *d_err, void *stream);
+/* one (source -> destination) segment as the consumer sees it */
+typedef struct lsk_wsrc {
+    uint32_t const *keys; /* device: indices at the destination, ascending inside every stream */
+    double const *vals;   /* device: the values (re, im interleaved for c128) */
+    uint32_t const *soff; /* device [S + 1]: stream s = packets [soff[s], soff[s + 1]) of the segment */
+} lsk_wsrc;
+/* the destinations of one consumer launch (passed by value): y[d] has count[d] rows and is served by the blocks
+ * [first_block[d], first_block[d + 1]), wpb windows of lsk_window_rows(cplx) rows per block */
+typedef struct lsk_wdests {
+    int n;
+    int64_t count[LSK_MAX_SEGS];
+    int64_t first_block[LSK_MAX_SEGS + 1];
+    void *y[LSK_MAX_SEGS];
+} lsk_wdests;
+int lsk_window_rows(int cplx);
+/* y[d][key] += value over all packets of the n_src source segments of every destination d (d_srcs: device [dests->n][n_src]) */
+int lsk_window(int cplx, lsk_wdests const *dests, lsk_wsrc const *d_srcs, int n_src, int S, int wpb, void *stream);
 /* replicated-x pull (Hermitian operators): rows of ONE partition against the whole vector in global
  * ascending order.  ix_global indexes the global basis; row_gidx[i] = global index of local row i
  * (may be NULL for lsk_direct_gx with closed-form indices, and for lsk_tile_pull when local == global). */

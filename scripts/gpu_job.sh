@@ -6,7 +6,7 @@
 #   tests            the whole -m gpu suite            tests:<expr> = pytest -k <expr>
 #   bench            default bench line                bench1 = --force-distributed --distributed-extras (one RCCL rank)
 #   bench_c128       chain_32 c128 line
-#   packets          packet path A/B: pre-indexed vs state-carrying packets, timing trees (scripts/tile_bench.py)
+#   packets[:v ..]   packet path A/B: sorted streams | pre-indexed + atomics | state-carrying + atomics, timing trees (scripts/tile_bench.py)
 #   packets_prof     rocprofv3 kernel trace + SQ counters of chain_28 x 8 partitions
 #   stream_cost      k_chain_t with one more 8-byte stream per row (profiling build): what a byte per row costs
 #   lattice          heisenberg_square_6x6 / 4x4: K4 mode 5 vs mode 4 (LS_AMD_K4=cosets)      ablate:<model>  scripts/ablate_pull.py
@@ -29,12 +29,14 @@ for step in "$@"; do
     bench) ( time timeout 900 python bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err" ) 2>&1 | grep real; tail -c 6000 "$OUT/bench_default.json"; tail -5 "$OUT/bench_default.err" ;;
     bench_c128) timeout 300 python bench.py --dtype c128 --steps 10 --warmup 3 --no-cpu-baseline --no-extra > "$OUT/bench_c128.json" 2>/dev/null; cut -c1-400 "$OUT/bench_c128.json" ;;
     bench1) ( time timeout 900 python bench.py --force-distributed --distributed-extras --no-cpu-baseline --kDisplayTimings > "$OUT/bench_one_rank.json" 2> "$OUT/bench_one_rank.err" ) 2>&1 | grep real; echo "rc=$?"; tail -c 5000 "$OUT/bench_one_rank.json"; grep -v "^$" "$OUT/bench_one_rank.err" | tail -40 ;;
-    packets)
-      for pi in 1 0; do
+    packets|packets:*) # packet path A/B on one device, P logical partitions: sorted streams (default) | pre-indexed + atomics | state-carrying + atomics
+      variants="${step#packets}"; variants="${variants#:}"; [ -z "$variants" ] && variants="streams indexed states"
+      for v in $variants; do
+        case $v in streams) ENVV="LS_AMD_PACKET_STREAMS=1";; indexed) ENVV="LS_AMD_PACKET_INDEX=1 LS_AMD_PACKET_STREAMS=0";; states) ENVV="LS_AMD_PACKET_INDEX=0";; *) ENVV="$v";; esac
         for args in "--L 28 --P 8" "--L 28 --P 8 --dtype c128" "--L 28 --P 2" "--L 30 --P 8"; do
-          echo -n "packet_index=$pi $args: "; LS_AMD_PACKET_INDEX=$pi timeout 300 python scripts/tile_bench.py $args --steps 5 --tree 2>&1 | grep -E "matvec=|producers|consumers" | tr '\n' ' ' | sed 's/  */ /g' | cut -c1-400; echo
+          echo -n "$v $args: "; env $ENVV timeout 300 python scripts/tile_bench.py $args --steps 5 --tree 2>&1 | grep -E "matvec=|producers|consumers" | tr '\n' ' ' | sed 's/  */ /g' | cut -c1-420; echo
         done
-      done | tee "$OUT/packets_ab.txt" ;;
+      done | tee -a "$OUT/packets_ab.txt" ;;
     packets_prof)
       CMD="python $GRAFT_REPO_ROOT/scripts/tile_bench.py --L 28 --P 8 --steps 3" bash scripts/gpu_profile_cmd.sh "${TAG}_packets" > "$OUT/packets_prof.log" 2>&1
       grep -E "k_tile|k_scatter|k_diag" "gpurun_out/prof_${TAG}_packets/summary.txt" | cut -c1-200 | head -30 ;;

@@ -112,7 +112,7 @@ def test_partitioned_matvec(torch, name, P):
     x = np.random.RandomState(44).rand(len(want_reps)) - 0.5
     want = oracle_for(name).local_matvec(want_reps, x)
     got, pl = run_matvec(torch, D, h, reps, masks, x, P)
-    assert pl.kernel == "tile"
+    assert pl.kernel in ("tile", "tile+streams")
     assert_close(got, want, f"{name} P={P}")
     if P == 4:
         xc = x + 1j * (np.random.RandomState(45).rand(len(want_reps)) - 0.5)
@@ -764,7 +764,7 @@ def test_chain_36_symm_full_size_properties(torch):
     pl = D.matrixVectorProduct(h, [u], [a], reps, mode="pull")
     assert pl.kernel.startswith("tile-pull")
     pl2 = D.matrixVectorProduct(h, [u], [b], reps, mode="push")
-    assert pl2.kernel == "tile"
+    assert pl2.kernel in ("tile", "tile+streams")
     scale = float(a.abs().max())
     assert float((a - b).abs().max()) <= 1e-12 * scale
     D.matrixVectorProduct(h, [v], [c], reps, mode="pull")
@@ -1211,25 +1211,74 @@ def test_pre_indexed_packets(torch, monkeypatch, case):
         x = x + 1j * (rng.rand(len(want_reps)) - 0.5)
     want = oracle_for(name).local_matvec(want_reps, x)
     results = {}
-    # (logical partitions inside one process default to the state-carrying packets: nothing crosses a wire; one partition per
-    # process -- tests/test_gpu_loopback.py, tests/test_gpu_rccl.py -- defaults to the indexed ones)
-    for label, env in (("indexed", {"LS_AMD_PACKET_INDEX": "1"}), ("states", {"LS_AMD_PACKET_INDEX": "0"}), ("default", {}),
+    # (logical partitions inside one process: exchange operators on unprojected fixed-weight bases take the SORTED STREAMS --
+    # pre-indexed packets, window consumers without atomics; everything else defaults to the state-carrying packets: nothing
+    # crosses a wire; one partition per process -- tests/test_gpu_loopback.py, tests/test_gpu_rccl.py -- defaults to the indexed ones)
+    envs = ("LS_AMD_PACKET_INDEX", "LS_AMD_PACKET_INDEX_MAX", "LS_AMD_PACKET_STREAMS", "LS_AMD_STREAM_WPB")
+    streams_ok = not basis.hasSpinInversionSymmetry() and not basis.hasPermutationSymmetries()
+    for label, env in (("indexed", {"LS_AMD_PACKET_INDEX": "1", "LS_AMD_PACKET_STREAMS": "0"}), ("states", {"LS_AMD_PACKET_INDEX": "0"}),
+                       ("default", {}), ("streams-wpb3", {"LS_AMD_STREAM_WPB": "3"}),
                        ("ceiling", {"LS_AMD_PACKET_INDEX": "1", "LS_AMD_PACKET_INDEX_MAX": "8"})):
-        for k in ("LS_AMD_PACKET_INDEX", "LS_AMD_PACKET_INDEX_MAX"):
+        for k in envs:
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         h.clear_plans()
         got, pl = run_matvec(torch, D, h, reps, masks, x, P)
-        assert pl.kernel == "tile"
-        assert pl.key_bytes == (4 if label == "indexed" else 8), label
+        streams = label in ("default", "streams-wpb3") and streams_ok
+        assert pl.kernel == ("tile+streams" if streams else "tile"), label
+        key = 4 if label == "indexed" or streams else 8
+        assert pl.key_bytes == key, label
         w = 16 if dt == "c128" else 8
         assert pl.packet_bytes == pl.key_bytes + w
-        assert pl.segment_bytes(5) == (24 if label == "indexed" else 40) + 5 * w and pl.segment_value_offset(5) == (24 if label == "indexed" else 40)
-        assert (pl.packet_index_bytes > 0) == (label == "indexed")
+        assert pl.segment_bytes(5) == (24 if key == 4 else 40) + 5 * w and pl.segment_value_offset(5) == (24 if key == 4 else 40)
+        assert (pl.packet_index_bytes > 0) == (key == 4)
         assert np.abs(got - want).max() <= 1e-12 * max(1.0, np.abs(want).max()), label
         results[label] = got
     h.clear_plans()
+
+
+@pytest.mark.parametrize("case", ["heisenberg_chain_4/3/f64/0", "heisenberg_chain_8/8/c128/0", "heisenberg_kagome_12/8/f64/0",
+                                  "heisenberg_chain_16/2/f64/3", "heisenberg_chain_16/3/c128/0", "heisenberg_chain_20/8/f64/2",
+                                  "heisenberg_kagome_16/4/c128/5", "heisenberg_chain_20/5/c128/1"])
+def test_sorted_packet_streams(torch, monkeypatch, case):
+    """Sorted streams (csrc/kernels.hip, k_tile_st / k_window): along one (exchange pair, pattern of alpha on it) beta - alpha is a
+    constant, so the packets of a (destination, stream) written in row order carry ascending indices and the consumer adds a
+    window of y at a time in LDS -- no atomics.  Equal to the oracle and to the atomic consumers (LS_AMD_PACKET_STREAMS=0) over
+    partitions smaller than a tile or empty (chain_4 / 3, chain_8 / 8, kagome_12 / 8), several rounds, several windows per block, f64 and c128; y keeps what the
+    diagonal pass assigned (the window pass adds)."""
+    name, P, dt, rounds = case.split("/")
+    P, rounds = int(P), int(rounds)
+    D, basis, h, reps, masks = setup_model(torch, model_config(name), P)
+    want_reps = oracle_reps(name)
+    rng = np.random.RandomState(47)
+    x = rng.rand(len(want_reps)) - 0.5
+    if dt == "c128":
+        x = x + 1j * (rng.rand(len(want_reps)) - 0.5)
+    want = oracle_for(name).local_matvec(want_reps, x)
+    td = torch.complex128 if dt == "c128" else torch.float64
+    xb = torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    xh = D.arrFromBlockToHashed(xb, masks, P)
+    got, nnz = {}, set()
+    for label, env in (("streams", {}), ("streams-wpb2", {"LS_AMD_STREAM_WPB": "2"}), ("atomics", {"LS_AMD_PACKET_STREAMS": "0"})):
+        for k in ("LS_AMD_PACKET_STREAMS", "LS_AMD_STREAM_WPB", "LS_AMD_PACKET_INDEX"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        pl = D.MatvecPlan(h, reps, td, num_rounds=rounds)
+        assert pl.kernel == ("tile" if label == "atomics" else "tile+streams"), label
+        if rounds:
+            assert pl.num_rounds == rounds
+        y = [torch.full_like(v, 3.25) for v in xh]  # localDiagonal ASSIGNS y (DMV:1062-1063): what was there must not survive
+        for _ in range(2):  # a second matvec through the same plan and buffers
+            pl.matvec(xh, y)
+        got[label] = D.arrFromHashedToBlock(y, masks).cpu().numpy()
+        assert np.abs(got[label] - want).max() <= 1e-12 * max(1.0, np.abs(want).max()), label
+        nnz.add(pl.nnz)
+        pl.destroy()
+    assert np.abs(got["streams"] - got["atomics"]).max() <= 1e-13 * max(1.0, np.abs(want).max())
+    assert np.abs(got["streams"] - got["streams-wpb2"]).max() <= 1e-13 * max(1.0, np.abs(want).max())
+    assert len(nnz) == 1  # the count passes of both producers agree on the number of packets
 
 
 def test_pre_indexed_packets_report_states_outside_the_basis(torch, monkeypatch):

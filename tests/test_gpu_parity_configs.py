@@ -176,7 +176,7 @@ def test_chain_36_symm_eight_partitions_packets(torch):
     x8 = D.arrFromBlockToHashed(x_block, masks, P)
     y8 = [torch.full_like(v, 7.0) for v in x8]
     pl = D.matrixVectorProduct(h, x8, y8, reps8)
-    assert pl.kernel == "tile"
+    assert pl.kernel in ("tile", "tile+streams")
     got = D.arrFromHashedToBlock(y8, masks)
     y1 = torch.empty_like(x_block)
     pl1 = D.matrixVectorProduct(h, [x_block], [y1], [r_block], mode="pull")
@@ -242,7 +242,7 @@ def test_chain_40_symm_properties_and_ground_state(torch):
     # push (the reference's formulation: packets + atomics) == pull
     b = torch.zeros_like(u)
     push = D.MatvecPlan(h, reps, torch.float64, mode="push")
-    assert push.kernel == "tile"
+    assert push.kernel in ("tile", "tile+streams")
     push.matvec([u], [b])
     assert float((a - b).abs().max()) <= 1e-12 * float(a.abs().max())
     del a, b, u
