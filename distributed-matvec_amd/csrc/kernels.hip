@@ -3843,8 +3843,8 @@ __device__ __forceinline__ uint32_t lower_bound_u32(uint32_t const *__restrict__
 // first position >= lo whose key is >= v (the window's end is a few dozen packets on: gallop, then search)
 __device__ __forceinline__ uint32_t gallop_u32(uint32_t const *__restrict__ k, uint32_t lo, uint32_t end, uint32_t v) {
     uint32_t step = 64;
-    while (lo + step <= end && k[lo + step - 1] < v) { lo += step; step <<= 1; }
-    const uint32_t hi = lo + step < end ? lo + step : end;
+    while ((uint64_t)lo + step <= (uint64_t)end && k[lo + step - 1] < v) { lo += step; step <<= 1; }
+    const uint32_t hi = (uint64_t)lo + step < (uint64_t)end ? lo + step : end;
     return lower_bound_u32(k, lo, hi, v);
 }
 template <bool CPLX>
