@@ -26,6 +26,12 @@ int ls_amd_internal_stage_begin(ls_amd_plan *pl, int stage, void *stream); /* ho
 void ls_amd_internal_stage_end(ls_amd_plan *pl, int slot, void *stream);
 void ls_amd_internal_count_matvec(ls_amd_plan *pl);
 void ls_amd_internal_set_no_packet_index(int v); /* host.c */
+/* host.c: packets in sorted streams (kernels.hip, k_tile_st / k_window) for a plan that owns one partition */
+void ls_amd_internal_set_want_streams(int v);
+int ls_amd_internal_streams_eligible(ls_hs_operator const *op, int P);
+int ls_amd_internal_plan_streams(ls_amd_plan const *pl);                       /* streams per segment, 0 = none */
+uint32_t const *ls_amd_internal_plan_stream_offsets(ls_amd_plan const *pl);    /* host [rounds][P][S + 1] */
+int ls_amd_internal_window_round(ls_amd_plan *pl, lsk_wsrc const *d_srcs, int n_src, void *d_y, void *stream);
 int ls_amd_scatter_round(ls_amd_plan *pl, int num_segments, int64_t const *counts, int64_t const *offsets, void const *d_recv, void *d_y, void *stream);
 enum { ST_REFRESH = 1, ST_EXCHANGE = 4, ST_RETURN = 6 };
 /* host.c: the indexed replicated-x matvec in two kernels -- BEGIN resolves the packets (needs no x), FINISH gathers */
@@ -209,6 +215,12 @@ struct ls_amd_dist {
     int64_t *scat_off, *scat_counts; /* [rounds][P] what the consumer reads: == recv_off / recv_counts (ls_amd_test_corrupt_dist edits these) */
     void *d_send[2], *d_recv[2];
     int64_t exchange_bytes;
+    /* sorted streams: S streams per segment; the stream offsets of every rank's segments (all-gathered once) and the consumer's
+     * view of every (round, source) segment -- the own one in the send buffer, the others where the exchange puts them */
+    int streams;
+    void *d_soff_all;    /* device [P sources][rounds][P destinations][S + 1] u32 */
+    lsk_wsrc *h_wsrcs;   /* host [rounds][P] */
+    lsk_wsrc *d_wsrcs;   /* device copy */
 };
 
 static int64_t rows_per_round(void) {
@@ -221,11 +233,56 @@ void ls_amd_dist_destroy(ls_amd_dist *d) {
     if (!d) return;
     lsk_device_sync(); /* the exchange stream and the caller's stream may still be using the buffers */
     for (int i = 0; i < 2; ++i) { if (d->d_send[i]) lsk_free(d->d_send[i]); if (d->d_recv[i]) lsk_free(d->d_recv[i]); }
+    if (d->d_soff_all) lsk_free(d->d_soff_all);
+    if (d->d_wsrcs) lsk_free(d->d_wsrcs);
+    free(d->h_wsrcs);
     if (d->plan) ls_amd_plan_destroy(d->plan);
     free(d->send_counts); free(d->recv_counts);
     free(d->send_off); free(d->send_bytes); free(d->recv_off); free(d->recv_bytes);
     free(d->scat_off); free(d->scat_counts);
     free(d);
+}
+
+/* sorted streams: where the streams of every rank's segments start (all-gathered once: [source][round][destination][S + 1]) and
+ * the consumer's view of the P source segments of every round -- the own one lies in the send buffer, the others where the
+ * exchange of that round puts them (slot = round & 1) */
+static void fill_stream_sources(ls_amd_dist *d) {
+    int const P = d->P, me = d->me, R = d->rounds, S = d->streams;
+    for (int r = 0; r < R; ++r)
+        for (int q = 0; q < P; ++q) {
+            size_t const k = (size_t)r * P + q;
+            lsk_wsrc *w = d->h_wsrcs + k;
+            char const *seg = q == me ? (char const *)d->d_send[r & 1] + d->send_off[(size_t)r * P + me]
+                                      : (char const *)d->d_recv[r & 1] + d->scat_off[k];
+            int64_t const c = q == me ? d->send_counts[(size_t)r * P + me] : d->recv_counts[k];
+            w->keys = (uint32_t const *)seg;
+            w->vals = (double const *)(seg + ls_amd_plan_segment_value_offset(d->plan, c) + (q == me ? 0 : d->recv_off[k] - d->scat_off[k]));
+            w->soff = (uint32_t const *)d->d_soff_all + (((size_t)q * R + r) * P + me) * (size_t)(S + 1);
+        }
+}
+static int setup_stream_tables(ls_amd_dist *d, void *stream) {
+    ls_amd_comm *cm = d->comm;
+    int const P = d->P, R = d->rounds, S = d->streams;
+    size_t const bytes = sizeof(uint32_t) * (size_t)R * (size_t)P * (size_t)(S + 1);
+    uint32_t const *mine = ls_amd_internal_plan_stream_offsets(d->plan);
+    void *all = NULL, *one = NULL;
+    int rc = mine ? 0 : ls_amd_internal_error("internal error: a streams plan without stream offsets");
+    if (rc == 0 && (lsk_malloc(&all, bytes * (size_t)P) != 0 || lsk_malloc(&one, bytes) != 0 || lsk_h2d(one, mine, bytes) != 0))
+        rc = ls_amd_internal_error("%s", lsk_last_error());
+    d->d_soff_all = all; /* owned by d from here on */
+    if (agree(cm, rc, stream) != 0) { if (one) lsk_free(one); return -1; }
+    if (lsk_comm_allgather(cm->c, one, all, (int64_t)bytes, stream) != 0) rc = ls_amd_internal_error("%s", lsk_comm_last_error());
+    if (rc == 0 && lsk_sync(stream) != 0) rc = ls_amd_internal_error("%s", lsk_last_error());
+    lsk_free(one);
+    if (rc != 0) return -1;
+    size_t const n = (size_t)R * (size_t)P;
+    d->h_wsrcs = (lsk_wsrc *)calloc(n, sizeof(lsk_wsrc));
+    void *pw = NULL;
+    if (lsk_malloc(&pw, sizeof(lsk_wsrc) * n) != 0) return ls_amd_internal_error("%s", lsk_last_error());
+    d->d_wsrcs = (lsk_wsrc *)pw;
+    fill_stream_sources(d);
+    if (lsk_h2d(pw, d->h_wsrcs, sizeof(lsk_wsrc) * n) != 0) return ls_amd_internal_error("%s", lsk_last_error());
+    return 0;
 }
 
 int ls_amd_dist_create(ls_amd_dist **out, ls_amd_comm *cm, ls_hs_operator const *op, ls_amd_dtype dtype,
@@ -246,7 +303,18 @@ int ls_amd_dist_create(ls_amd_dist **out, ls_amd_comm *cm, ls_hs_operator const 
         if (lsk_comm_allreduce(cm->c, ds, 1, 2, 1, stream) != 0) rc1 = ls_amd_internal_error("%s", lsk_comm_last_error());
         if (rc1 == 0 && (lsk_sync(stream) != 0 || lsk_d2h(&mx, ds, sizeof(mx)) != 0)) rc1 = ls_amd_internal_error("%s", lsk_last_error());
         TRY(agree(cm, rc1, stream));
-        int64_t const rpr = rows_per_round();
+        int64_t rpr = rows_per_round();
+        if (!getenv("LS_AMD_ROWS_PER_ROUND") && ls_amd_internal_streams_eligible(op, P)) {
+            /* sorted streams: every round reads and writes y once and searches every stream once per window, so few LARGE rounds --
+             * send / receive buffers of ~24 GB each (four of them: sized for 288 GB of HBM), and one destination takes < 2^32
+             * packets per round (rows x groups is an upper bound).  Every rank computes the same number: no memory query here */
+            int const ng = ls_hs_operator_max_number_off_diag(op) > 0 ? ls_hs_operator_max_number_off_diag(op) : 1;
+            int64_t const per_row = (int64_t)ng * (dtype == LS_AMD_C128 ? 20 : 12) / 2 + 16; /* half the pairs are anti-aligned */
+            int64_t big = ((int64_t)24 << 30) / per_row;
+            int64_t const cap = ((int64_t)1 << 32) / ng;
+            if (big > cap) big = cap;
+            if (big > rpr) rpr = big;
+        }
         num_rounds = (int)((mx + rpr - 1) / rpr);
         if (num_rounds < 1) num_rounds = 1;
     }
@@ -255,22 +323,26 @@ int ls_amd_dist_create(ls_amd_dist **out, ls_amd_comm *cm, ls_hs_operator const 
     uint64_t const *reps[1] = {d_reps_local};
     int64_t counts[1] = {count_local};
     size_t const m = (size_t)num_rounds * (size_t)P;
+    ls_amd_internal_set_want_streams(1);
     int rc = ls_amd_plan_create(&d->plan, op, dtype, P, me, reps, counts, num_rounds, LS_AMD_MODE_AUTO, stream);
-    {   /* the packet layout (pre-indexed 4-byte keys or 8-byte states) is ONE decision of all ranks: a rank that had no room
-         * for the all-destinations directory pulls everybody back to the state-carrying packets */
-        int64_t wide = rc != 0 || ls_amd_plan_key_bytes(d->plan) == 8;
-        int const mine = (int)wide;
-        if (!cm->d_status || lsk_h2d(cm->d_status, &wide, sizeof(wide)) != 0 || lsk_comm_allreduce(cm->c, cm->d_status, 1, 2, 1, stream) != 0 ||
-            lsk_sync(stream) != 0 || lsk_d2h(&wide, cm->d_status, sizeof(wide)) != 0) {
+    ls_amd_internal_set_want_streams(0);
+    {   /* the packet layout -- sorted streams of pre-indexed packets (0), pre-indexed 4-byte keys (1) or 8-byte states (2) -- is
+         * ONE decision of all ranks: a rank that had no room for the all-destinations directory pulls everybody back to the
+         * state-carrying packets */
+        int64_t level = rc != 0 || ls_amd_plan_key_bytes(d->plan) == 8 ? 2 : (ls_amd_internal_plan_streams(d->plan) ? 0 : 1);
+        int const mine = (int)level;
+        if (!cm->d_status || lsk_h2d(cm->d_status, &level, sizeof(level)) != 0 || lsk_comm_allreduce(cm->c, cm->d_status, 1, 2, 1, stream) != 0 ||
+            lsk_sync(stream) != 0 || lsk_d2h(&level, cm->d_status, sizeof(level)) != 0) {
             if (rc == 0) rc = ls_amd_internal_error("packet-layout agreement failed: %s", lsk_comm_last_error());
-        } else if (rc == 0 && wide && !mine) {
+        } else if (rc == 0 && level > mine) {
             ls_amd_plan_destroy(d->plan);
             d->plan = NULL;
-            ls_amd_internal_set_no_packet_index(1);
-            rc = ls_amd_plan_create(&d->plan, op, dtype, P, me, reps, counts, num_rounds, LS_AMD_MODE_AUTO, stream);
+            ls_amd_internal_set_no_packet_index(level == 2);
+            rc = ls_amd_plan_create(&d->plan, op, dtype, P, me, reps, counts, num_rounds, LS_AMD_MODE_AUTO, stream); /* (no streams) */
             ls_amd_internal_set_no_packet_index(0);
         }
     }
+    d->streams = rc == 0 ? ls_amd_internal_plan_streams(d->plan) : 0;
     if (rc == 0 && ls_amd_plan_num_rounds(d->plan) != num_rounds) rc = ls_amd_internal_error("internal error: rounds disagree");
     if (rc == 0) {
         d->pb = ls_amd_plan_packet_bytes(d->plan);
@@ -297,13 +369,15 @@ int ls_amd_dist_create(ls_amd_dist **out, ls_amd_comm *cm, ls_hs_operator const 
         for (int q = 0; q < P; ++q) {
             size_t const k = (size_t)r * P + q;
             d->recv_counts[k] = all[(size_t)q * m + (size_t)r * P + me]; /* what rank q sends to me in round r */
-            /* (a segment of c packets: c keys -- u64 states, or u32 indices padded to 8 bytes -- then c values) */
+            /* (a segment of c packets: c keys -- u64 states, or u32 indices padded to 8 bytes -- then c values; sorted streams:
+             * the own partition's packets are a segment of the send buffer too and are consumed from there -- the exchange
+             * skips the pair (me, me), and the receive buffer keeps no room for it) */
             d->send_off[k] = so; d->send_bytes[k] = ls_amd_plan_segment_bytes(d->plan, d->send_counts[k]); so += d->send_bytes[k];
-            d->recv_off[k] = ro; d->recv_bytes[k] = ls_amd_plan_segment_bytes(d->plan, d->recv_counts[k]); ro += d->recv_bytes[k];
+            d->recv_off[k] = ro; d->recv_bytes[k] = q == me ? 0 : ls_amd_plan_segment_bytes(d->plan, d->recv_counts[k]); ro += d->recv_bytes[k];
+            if (q != me) d->exchange_bytes += d->send_bytes[k];
         }
         if (so > max_send) max_send = so;
         if (ro > max_recv) max_recv = ro;
-        d->exchange_bytes += so;
     }
     if (rc == 0) { memcpy(d->scat_off, d->recv_off, sizeof(int64_t) * m); memcpy(d->scat_counts, d->recv_counts, sizeof(int64_t) * m); }
     free(all);
@@ -312,6 +386,10 @@ int ls_amd_dist_create(ls_amd_dist **out, ls_amd_comm *cm, ls_hs_operator const 
             lsk_malloc(&d->d_recv[i], (size_t)(max_recv > 0 ? max_recv : 8)) != 0)
             rc = ls_amd_internal_error("%s", lsk_last_error());
     if (agree(cm, rc, stream) != 0) { ls_amd_dist_destroy(d); return -1; } /* nobody enters a matvec some peer cannot serve */
+    if (d->streams) { /* (the same decision on every rank: the layout level was agreed on above) */
+        rc = setup_stream_tables(d, stream);
+        if (agree(cm, rc, stream) != 0) { ls_amd_dist_destroy(d); return -1; }
+    }
     *out = d;
     ls_amd_internal_clear_error();
     return 0;
@@ -331,6 +409,10 @@ int ls_amd_test_corrupt_dist(ls_amd_dist *d) {
         if ((int)(k % (size_t)d->P) == d->me || d->scat_counts[k] < 2 * drop + 1 || (d->scat_counts[k] & 1)) continue;
         d->scat_off[k] += 8;
         d->scat_counts[k] -= drop;
+        if (d->streams) { /* sorted streams: the window consumer's view of that segment -- keys two on, values in place */
+            fill_stream_sources(d);
+            if (lsk_device_sync() != 0 || lsk_h2d(d->d_wsrcs, d->h_wsrcs, sizeof(lsk_wsrc) * (size_t)d->rounds * (size_t)d->P) != 0) return 0;
+        }
         return 1;
     }
     return 0;
@@ -361,7 +443,8 @@ int ls_amd_dist_matvec(ls_amd_dist *d, void const *d_x, void *d_y, void *stream)
         COMM(lsk_comm_exchange_wait(d->comm->c, r & 1, stream));
         ls_amd_internal_stage_end(d->plan, st, stream);
         /* every received segment of the round (SoA: keys, then values) in one consumer launch */
-        TRY(ls_amd_scatter_round(d->plan, P, d->scat_counts + (size_t)r * P, d->scat_off + (size_t)r * P, d->d_recv[r & 1], d_y, stream));
+        if (d->streams) TRY(ls_amd_internal_window_round(d->plan, d->d_wsrcs + (size_t)r * P, P, d_y, stream)); /* + the own segment, no atomics */
+        else TRY(ls_amd_scatter_round(d->plan, P, d->scat_counts + (size_t)r * P, d->scat_off + (size_t)r * P, d->d_recv[r & 1], d_y, stream));
     }
     return 0;
 }

@@ -1422,6 +1422,7 @@ typedef struct part_state {
     uint32_t *d_ttab;     /* owned */
     int64_t *ttab_first;  /* [rounds + 1] first tile of the round in d_ttab */
     uint32_t *d_soff;     /* owned */
+    uint32_t *h_soff;     /* owned: host copy (dist.c exchanges it at set-up) */
 } part_state;
 
 enum { FAMILY_DIRECT_PUSH = 0, FAMILY_DIRECT_PULL = 1, FAMILY_TILE = 2, FAMILY_TILE_PULL = 3,
@@ -2155,17 +2156,29 @@ static int64_t segment_key_bytes(ls_amd_plan const *pl, int64_t c) { return pl->
  * exchange pair -- a packet exists iff alpha is anti-aligned on the pair, and beta - alpha is then one of two constants -- on an
  * unprojected fixed-weight basis (the conditions of the pre-indexed packets, which setup_packet_index checks).
  * LS_AMD_PACKET_STREAMS=0: the atomics of lsk_scatter_parts / lsk_scatter_idx instead (A/B). */
-static int streams_wanted(ls_amd_plan const *pl) {
+/* A plan that owns ONE partition is driven by generate / exchange / scatter: only a driver that knows the streams (dist.c: the
+ * stream offsets of every source are exchanged at set-up, the own segment is consumed out of the send buffer) asks for them */
+static __thread int g_want_streams = 0;
+void ls_amd_internal_set_want_streams(int v) { g_want_streams = v; }
+/* the static part of the conditions (operator and basis): dist.c sizes its rounds by it before the plan exists */
+int ls_amd_internal_streams_eligible(ls_hs_operator const *op, int P) {
     char const *e = getenv("LS_AMD_PACKET_STREAMS");
     if (e && atoi(e) == 0) return 0;
     e = getenv("LS_AMD_PACKET_INDEX"); /* (the streams are made of pre-indexed packets: switched off with them) */
     if (e && atoi(e) == 0) return 0;
-    if (pl->me >= 0 || pl->family != FAMILY_TILE || pl->dbs.proj != LSK_PROJ_NONE || pl->P > LSK_MAX_SEGS) return 0;
-    struct ls_amd_operator_ext const *oe = OEXT(pl->op);
-    if (oe->n_groups < 1 || oe->n_groups > 128 || pl->P * 2 * oe->n_groups > lsk_tile_st_max_classes()) return 0;
+    ls_hs_basis const *b = op->basis;
+    /* (P == 1: every packet is an own-partition packet, whose atomics in the producer meet ~8 packets per line of y -- measured on
+     * chain_32 with one rank: 97 ms with them against 148 ms through 2 x 119 GB of streams) */
+    if (BEXT(b)->order > 1 || b->spin_inversion != 0 || BEXT(b)->hamming_weight < 0 || P < 2 || P > LSK_MAX_SEGS) return 0;
+    struct ls_amd_operator_ext const *oe = OEXT(op);
+    if (oe->n_groups < 1 || oe->n_groups > 128 || P * 2 * oe->n_groups > lsk_tile_st_max_classes()) return 0;
     for (int g = 0; g < oe->n_groups; ++g)
         if (oe->groups[g].fast != LSK_GROUP_EXCHANGE || __builtin_popcountll(oe->groups[g].x) != 2) return 0;
     return 1;
+}
+static int streams_wanted(ls_amd_plan const *pl) {
+    if ((pl->me >= 0 && !g_want_streams) || pl->family != FAMILY_TILE || pl->dbs.proj != LSK_PROJ_NONE) return 0;
+    return ls_amd_internal_streams_eligible(pl->op, pl->P);
 }
 static int setup_packet_index(ls_amd_plan *pl, uint64_t const *const *d_reps, int64_t const *counts, void *stream) {
     ls_hs_basis const *b = pl->op->basis;
@@ -2438,7 +2451,8 @@ static int plan_setup_part(ls_amd_plan *pl, part_state *ps, int part_id, int num
         int const rcs = lsk_h2d(ps->d_ttab, h_ttab, sizeof(uint32_t) * (size_t)(n_tiles > 0 ? n_tiles : 1) * (size_t)C) != 0 ||
                         lsk_malloc(&po, sob) != 0 || lsk_h2d(po, h_soff, sob) != 0;
         ps->d_soff = (uint32_t *)po; /* owned by the plan from here on */
-        free(h_ttab); free(h_soff); free(sbase); free(running);
+        ps->h_soff = h_soff;
+        free(h_ttab); free(sbase); free(running);
         if (rcs != 0) { free(layouts); return dev_error(); }
     }
     void *p;
@@ -2449,6 +2463,12 @@ static int plan_setup_part(ls_amd_plan *pl, part_state *ps, int part_id, int num
     return rc != 0 ? dev_error() : 0;
 }
 
+static int stream_windows_per_block(int64_t windows) {
+    char const *e = getenv("LS_AMD_STREAM_WPB");
+    if (e && atoi(e) > 0) return atoi(e);
+    int64_t const w = windows / 8192; /* (>= 8192 blocks keep 2048 block slots busy without a long tail) */
+    return w < 1 ? 1 : (w > 8 ? 8 : (int)w);
+}
 /* sorted streams, all partitions in this process: one send buffer per source partition (a round of all sources is consumed by
  * ONE launch, so y is read and written once per round) and the consumer's view of every (round, destination, source) segment */
 static int setup_streams(ls_amd_plan *pl, int rounds) {
@@ -2480,9 +2500,7 @@ static int setup_streams(ls_amd_plan *pl, int rounds) {
     int64_t windows = 0;
     int const W = lsk_window_rows(pl->cplx);
     for (int d = 0; d < P; ++d) windows += (pl->parts[d].count + W - 1) / W;
-    pl->st_wpb = windows >= 32768 ? 4 : (windows >= 8192 ? 2 : 1);
-    char const *e = getenv("LS_AMD_STREAM_WPB");
-    if (e && atoi(e) > 0) pl->st_wpb = atoi(e);
+    pl->st_wpb = stream_windows_per_block(windows);
     return 0;
 }
 
@@ -2577,7 +2595,11 @@ int ls_amd_plan_create(ls_amd_plan **out, ls_hs_operator const *op, ls_amd_dtype
         if (plan_setup_part(pl, ps, pid, num_rounds, stream) != 0) { ls_amd_plan_destroy(pl); return -1; }
         if (ps->max_send_bytes > pl->send_capacity) pl->send_capacity = ps->max_send_bytes;
     }
-    if (pl->streams && setup_streams(pl, num_rounds) != 0) { ls_amd_plan_destroy(pl); return -1; }
+    if (pl->streams && my_partition < 0 && setup_streams(pl, num_rounds) != 0) { ls_amd_plan_destroy(pl); return -1; }
+    if (pl->streams && my_partition >= 0) { /* one partition per process: the driver owns the buffers (dist.c) */
+        pl->st_rounds = pl->parts[0].rounds;
+        pl->st_wpb = stream_windows_per_block((pl->parts[0].count + lsk_window_rows(pl->cplx) - 1) / lsk_window_rows(pl->cplx));
+    }
     if (pl->family == FAMILY_DIRECT_PULL || pl->family == FAMILY_DIRECT_PUSH) {
         int const combinadic = pl->parts[0].index.kind == LSK_INDEX_COMBINADIC;
         part_state *ps0 = &pl->parts[0];
@@ -2656,6 +2678,7 @@ void ls_amd_plan_destroy(ls_amd_plan *pl) {
             free(ps->wtab_first);
             if (ps->d_ttab) lsk_free(ps->d_ttab);
             if (ps->d_soff) lsk_free(ps->d_soff);
+            free(ps->h_soff);
             free(ps->ttab_first);
             free(ps->send_counts); free(ps->h_beta_off); free(ps->h_val_off);
         }
@@ -3019,7 +3042,12 @@ static int generate_round(ls_amd_plan *pl, part_state *ps, int pid, int round, v
     if (pl->P > 1 && !ps->d_wtab) DEV(lsk_memset_async(pl->d_cursors, 0, 8 * (size_t)pl->P, stream));
     int const st = stage_begin(pl, ST_GENERATE, stream);
     int slot = timing_begin(pl, stream);
-    if (ps->d_wtab)
+    if (pl->streams) {
+        uint64_t const *d_binom;
+        if (device_binom(&d_binom) != 0) return -1;
+        DEV(lsk_tile_st(pl->dop, pl->gd, d_binom, pl->cplx, 0, pl->P, pl->st_S, pl->st_tile_rows, row0, row1, ps->d_reps, d_x,
+                        ps->d_ttab + (size_t)ps->ttab_first[round] * (size_t)(pl->P * pl->st_S), ps->d_layouts + round, d_send, pl->d_err, stream));
+    } else if (ps->d_wtab)
         DEV(lsk_tile_wv(pl->dop, pl->dbs, ps->index, pl->gd, pl->cplx, 0, pl->P, pid, row0, row1, ps->d_reps, ps->d_norms, d_x, d_y,
                         ps->d_wtab + (size_t)ps->wtab_first[round] * pl->P, ps->d_layouts + round, d_send, pl->d_err, stream));
     else
@@ -3041,6 +3069,7 @@ int ls_amd_generate(ls_amd_plan *pl, int round, void const *d_x, void *d_y, void
 int ls_amd_scatter(ls_amd_plan *pl, int64_t n, uint64_t const *d_betas, void const *d_values, void *d_y,
                    void *stream) {
     part_state *ps = &pl->parts[0];
+    if (pl->streams) return set_error("ls_amd_scatter: the plan writes sorted streams (consumed by windows, dist.c)");
     if (ps->index.kind == LSK_INDEX_COMBINADIC) return set_error("ls_amd_scatter: plan has no search index");
     int const st = stage_begin(pl, ST_SCATTER, stream);
     if (pl->key_bytes == 4) { /* pre-indexed packets: d_betas is the segment's u32 index array */
@@ -3062,6 +3091,7 @@ int ls_amd_scatter(ls_amd_plan *pl, int64_t n, uint64_t const *d_betas, void con
 int ls_amd_scatter_round(ls_amd_plan *pl, int num_segments, int64_t const *counts, int64_t const *offsets, void const *d_recv,
                          void *d_y, void *stream) {
     part_state *ps = &pl->parts[0];
+    if (pl->streams) return set_error("ls_amd_scatter_round: the plan writes sorted streams (consumed by windows, dist.c)");
     if (ps->index.kind == LSK_INDEX_COMBINADIC) return set_error("ls_amd_scatter_round: plan has no search index");
     int const st = stage_begin(pl, ST_SCATTER, stream);
     int s = 0;
@@ -3083,6 +3113,25 @@ int ls_amd_scatter_round(ls_amd_plan *pl, int num_segments, int64_t const *count
         if (pl->key_bytes == 4) DEV(lsk_scatter_idx(pl->cplx, &sg, d_recv, stream));
         else DEV(lsk_scatter_segs(ps->index, pl->cplx, &sg, d_recv, pl->dbs.k4_mode ? ps->d_norms : NULL, pl->d_err, stream));
     }
+    stage_end(pl, st, stream);
+    return 0;
+}
+/* sorted streams of a plan that owns one partition (dist.c): S streams per segment; offsets[rounds][P][S + 1] = where the streams
+ * of the segment for destination d start in round r (packets); the consumer of one round over n_src source segments */
+int ls_amd_internal_plan_streams(ls_amd_plan const *pl) { return pl->streams ? pl->st_S : 0; }
+uint32_t const *ls_amd_internal_plan_stream_offsets(ls_amd_plan const *pl) { return pl->streams ? pl->parts[0].h_soff : NULL; }
+int ls_amd_internal_window_round(ls_amd_plan *pl, lsk_wsrc const *d_srcs, int n_src, void *d_y, void *stream) {
+    if (!pl->streams || pl->me < 0) return set_error("ls_amd_internal_window_round: not a streams plan of one partition");
+    lsk_wdests wd;
+    memset(&wd, 0, sizeof(wd));
+    int const W = lsk_window_rows(pl->cplx);
+    int64_t const windows = (pl->parts[0].count + W - 1) / W;
+    wd.n = 1;
+    wd.count[0] = pl->parts[0].count;
+    wd.y[0] = d_y;
+    wd.first_block[1] = (windows + pl->st_wpb - 1) / pl->st_wpb;
+    int const st = stage_begin(pl, ST_SCATTER, stream);
+    DEV(lsk_window(pl->cplx, &wd, d_srcs, n_src, pl->st_S, pl->st_wpb, stream));
     stage_end(pl, st, stream);
     return 0;
 }

@@ -303,6 +303,15 @@ __device__ __forceinline__ int64_t gdir_index(lsk_gdir const &gd, uint64_t s, in
     if (!(e.x & bit)) return -1;
     return (int64_t)(uint32_t)e.y + __popcll(e.x & (bit - 1));
 }
+// the same look-up for a state whose global rank g is already known
+constexpr uint32_t kNoRank = 0xffffffffu;
+__device__ __forceinline__ int64_t gdir_index_of_rank(lsk_gdir const &gd, uint64_t g, int d) {
+    if ((int64_t)g >= gd.n_ranks) return -1;
+    const ulonglong2 e = *reinterpret_cast<ulonglong2 const *>(gd.entries + (g >> 6) * (uint64_t)gd.P + (uint64_t)d);
+    const uint64_t bit = 1ULL << (g & 63);
+    if (!(e.x & bit)) return -1;
+    return (int64_t)(uint32_t)e.y + __popcll(e.x & (bit - 1));
+}
 __device__ __forceinline__ void gdir_load(lsk_gdir const &gd, uint64_t const *__restrict__ g_binom, uint64_t *s_db) { // (the caller synchronises)
     const int kc = gd.weight + 1;
     for (int i = threadIdx.x; i < gd.sites * kc; i += blockDim.x) s_db[i] = g_binom[(i / kc) * LSK_BINOM_K + (i % kc)];
@@ -3685,6 +3694,11 @@ __global__ __launch_bounds__(kBlock) void k_tile_st(int n_groups, lsk_group cons
     __shared__ uint64_t s_beta[kCap];
     __shared__ double s_val[COUNT ? 1 : kCap * (CPLX ? 2 : 1)];
     __shared__ uint8_t s_sid[kCap];
+    // global (colex) rank of beta when it is one binomial away from alpha's: an exchange on ADJACENT sites (lo, lo + 1) moves the
+    // (k + 1)-th set bit by one place, rank(beta) = rank(alpha) +- C(lo, k), k = set bits of alpha below lo -- the 14-step rank
+    // sum of the directory look-up then runs once per row instead of once per packet (kNoRank: the full sum, e.g. the bond
+    // that closes a ring; bases with >= 2^32 states always take it)
+    __shared__ uint32_t s_rank[COUNT ? 1 : kCap];
     extern __shared__ uint64_t s_dyn[]; // [binomials of the directory][key offsets P][value offsets P][cursors: waves x classes u32]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -3733,7 +3747,8 @@ __global__ __launch_bounds__(kBlock) void k_tile_st(int n_groups, lsk_group cons
             if (!COUNT && live) {
                 double vr, vi = 0.0;
                 if (CPLX) { vr = s_val[2 * e]; vi = s_val[2 * e + 1]; } else vr = s_val[e];
-                int64_t idx = gdir_index(gd, beta, dest, s_db);
+                const uint32_t rk = s_rank[e];
+                int64_t idx = rk != kNoRank ? gdir_index_of_rank(gd, (uint64_t)rk, dest) : gdir_index(gd, beta, dest, s_db);
                 if (idx < 0) { // not a basis state (DMV:115-118): the flag halts the matvec; the slot the count pass reserved is still
                     atomicExch(err, 1); // filled -- (index 0, value 0) -- so that no consumer meets a stale key
                     idx = 0; vr = 0.0; vi = 0.0;
@@ -3756,6 +3771,14 @@ __global__ __launch_bounds__(kBlock) void k_tile_st(int n_groups, lsk_group cons
                 else if (CPLX) { xr = x[2 * i]; xi = x[2 * i + 1]; }
                 else xr = x[i];
             }
+            uint64_t ga = 0; // colex rank of alpha (states of another weight never reach the look-up: their rows have no packets)
+            const bool narrow_ranks = !COUNT && gd.n_ranks <= 0xffffffffLL;
+            if (narrow_ranks && valid) {
+                const int kc = gd.weight + 1;
+                uint64_t t = a;
+                int k = 1;
+                while (t && k < kc) { ga += s_db[(__ffsll((unsigned long long)t) - 1) * kc + k]; ++k; t &= t - 1; }
+            }
             for (int g0 = 0; g0 < n_groups; g0 += kTwGroups) {
                 const int g1 = min(g0 + kTwGroups, n_groups);
                 for (int g = g0; g < g1; ++g) { // stage A: append (beta, value, stream)
@@ -3767,11 +3790,18 @@ __global__ __launch_bounds__(kBlock) void k_tile_st(int n_groups, lsk_group cons
                     const unsigned long long ball = __ballot(act);
                     if (act) {
                         const int slot = rb + ((head + cnt + __popcll(ball & ((1ULL << lane) - 1))) & (kStRing - 1));
+                        const int up = (int)((a >> (__ffsll((unsigned long long)G.x) - 1)) & 1ULL); // the lower site's bit moves up
                         s_beta[slot] = a ^ G.x;
-                        s_sid[slot] = (uint8_t)(2 * g + (int)((a >> (__ffsll((unsigned long long)G.x) - 1)) & 1ULL));
+                        s_sid[slot] = (uint8_t)(2 * g + up);
                         if (!COUNT) {
                             if (CPLX) { s_val[2 * slot] = cr * xr - ci * xi; s_val[2 * slot + 1] = cr * xi + ci * xr; }
                             else s_val[slot] = cr * xr;
+                            uint32_t rk = kNoRank;
+                            if (narrow_ranks && G.adj >= 0) {
+                                const uint64_t c = s_db[G.adj * (gd.weight + 1) + __popcll(a & ((1ULL << G.adj) - 1))];
+                                rk = (uint32_t)(up ? ga + c : ga - c);
+                            }
+                            s_rank[slot] = rk;
                         }
                     }
                     cnt += __popcll(ball);
@@ -3832,7 +3862,8 @@ extern "C" int lsk_tile_st(lsk_operator op, lsk_gdir gd, uint64_t const *d_binom
 // Consumer of the sorted streams.  Block -> (destination partition, wpb consecutive windows of W rows of its y).  n_src source
 // segments per destination, S streams each: soff[s] .. soff[s + 1] = packets of stream s inside the segment, keys ascending.
 constexpr int kWinRows = 2048;    // doubles of one window's accumulator (c128: 1024 rows)
-constexpr int kWinStreams = 1024; // run bounds kept in LDS per pass over the streams
+constexpr int kWinStreams = 512;  // run bounds kept in LDS per pass over the streams
+constexpr int kWinRuns = 4;       // runs a wave has in flight
 __device__ __forceinline__ uint32_t lower_bound_u32(uint32_t const *__restrict__ k, uint32_t lo, uint32_t hi, uint32_t v) {
     while (lo < hi) {
         const uint32_t mid = lo + ((hi - lo) >> 1);
@@ -3851,7 +3882,10 @@ template <bool CPLX>
 __global__ __launch_bounds__(kBlock) void k_window(lsk_wdests dests, lsk_wsrc const *__restrict__ srcs, int n_src, int S, int wpb) {
     constexpr int W = CPLX ? kWinRows / 2 : kWinRows;
     __shared__ double s_acc[kWinRows];
-    __shared__ uint32_t s_lo[kWinStreams], s_hi[kWinStreams];
+    __shared__ uint32_t s_lo[kWinStreams];
+    __shared__ uint16_t s_len[kWinStreams]; // (the keys of a stream are distinct: a window holds <= W of them)
+    __shared__ uint32_t const *s_keys[LSK_MAX_SEGS];
+    __shared__ double const *s_vals[LSK_MAX_SEGS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int d = 0;
     while (d + 1 < dests.n && (int64_t)blockIdx.x >= dests.first_block[d + 1]) ++d; // block-uniform
@@ -3860,6 +3894,7 @@ __global__ __launch_bounds__(kBlock) void k_window(lsk_wdests dests, lsk_wsrc co
     const int64_t wb = (int64_t)blockIdx.x - dests.first_block[d];
     const int T = n_src * S;
     lsk_wsrc const *__restrict__ segs = srcs + (size_t)d * n_src;
+    for (int q = tid; q < n_src; q += kBlock) { s_keys[q] = segs[q].keys; s_vals[q] = segs[q].vals; }
     for (int win = 0; win < wpb; ++win) {
         const int64_t w0 = (wb * wpb + win) * W;
         if (w0 >= n) break;
@@ -3872,39 +3907,47 @@ __global__ __launch_bounds__(kBlock) void k_window(lsk_wdests dests, lsk_wsrc co
                 const int q = (t0 + t) / S, s = (t0 + t) - q * S;
                 uint32_t const *__restrict__ keys = segs[q].keys;
                 uint32_t const *__restrict__ soff = segs[q].soff;
-                const uint32_t a = soff[s], e = soff[s + 1];
-                const uint32_t lo = carry ? s_hi[t] : lower_bound_u32(keys, a, e, (uint32_t)w0);
-                const uint32_t hi = w1 >= n ? e : gallop_u32(keys, lo, e, (uint32_t)w1);
+                const uint32_t e = soff[s + 1];
+                const uint32_t lo = carry ? s_lo[t] + s_len[t] : lower_bound_u32(keys, soff[s], e, (uint32_t)w0);
+                uint32_t hi = w1 >= n ? e : gallop_u32(keys, lo, e, (uint32_t)w1);
+                if (hi - lo > (uint32_t)W) hi = lo + (uint32_t)W; // (only after a failed directory look-up: the flag is up anyway)
                 s_lo[t] = lo;
-                s_hi[t] = hi;
+                s_len[t] = (uint16_t)(hi - lo);
             }
             __syncthreads();
-            // a wave takes the runs t = wave, wave + 4, ..., two at a time (their loads are issued together)
-            for (int t = wave; t < tn; t += 8) {
-                const int tb = t + 4;
-                const bool has_b = tb < tn;
-                const int qa = (t0 + t) / S, qb = has_b ? (t0 + tb) / S : qa;
-                uint32_t const *__restrict__ ka = segs[qa].keys;
-                double const *__restrict__ va = segs[qa].vals;
-                uint32_t const *__restrict__ kb = segs[qb].keys;
-                double const *__restrict__ vb = segs[qb].vals;
-                const uint32_t lo_a = s_lo[t], hi_a = s_hi[t];
-                const uint32_t lo_b = has_b ? s_lo[tb] : 0u, hi_b = has_b ? s_hi[tb] : 0u;
-                const uint32_t len_a = hi_a - lo_a, len_b = hi_b - lo_b;
-                const uint32_t iters = ((len_a > len_b ? len_a : len_b) + 63u) >> 6;
-                for (uint32_t it = 0; it < iters; ++it) {
-                    const uint32_t pa = lo_a + (it << 6) + (uint32_t)lane, pb = lo_b + (it << 6) + (uint32_t)lane;
-                    const bool in_a = pa < hi_a, in_b = pb < hi_b;
-                    uint32_t key_a = 0xffffffffu, key_b = 0xffffffffu;
-                    double ar = 0.0, ai = 0.0, br = 0.0, bi = 0.0;
-                    if (in_a) { key_a = ka[pa]; if (CPLX) { ar = va[2 * (size_t)pa]; ai = va[2 * (size_t)pa + 1]; } else ar = va[pa]; }
-                    if (in_b) { key_b = kb[pb]; if (CPLX) { br = vb[2 * (size_t)pb]; bi = vb[2 * (size_t)pb + 1]; } else br = vb[pb]; }
-                    const uint32_t oa = key_a - (uint32_t)w0, ob = key_b - (uint32_t)w0; // (a key outside the window -- only after a
-                    if (in_a && oa < (uint32_t)W) {                                        //  failed directory look-up -- is dropped)
-                        if (CPLX) { atomicAdd(&s_acc[2 * oa], ar); atomicAdd(&s_acc[2 * oa + 1], ai); } else atomicAdd(&s_acc[oa], ar);
+            // a wave takes the runs t = wave, wave + 4, ..., kWinRuns at a time: all their loads are issued before the first add
+            for (int t = wave; t < tn; t += 4 * kWinRuns) {
+                uint32_t const *kp[kWinRuns];
+                double const *vp[kWinRuns];
+                uint32_t len[kWinRuns], longest = 0;
+#pragma unroll
+                for (int u = 0; u < kWinRuns; ++u) {
+                    const int tu = t + 4 * u;
+                    const bool has = tu < tn;
+                    const int q = has ? (t0 + tu) / S : 0;
+                    const uint32_t lo = has ? s_lo[tu] : 0u;
+                    len[u] = has ? (uint32_t)s_len[tu] : 0u;
+                    kp[u] = s_keys[q] + lo;
+                    vp[u] = s_vals[q] + (size_t)lo * (CPLX ? 2 : 1);
+                    longest = len[u] > longest ? len[u] : longest;
+                }
+                for (uint32_t it = (uint32_t)lane; it < longest + (uint32_t)lane; it += 64) { // (wave-uniform trip count)
+                    uint32_t key[kWinRuns];
+                    double vr[kWinRuns], vi[kWinRuns];
+#pragma unroll
+                    for (int u = 0; u < kWinRuns; ++u) {
+                        key[u] = 0xffffffffu; vr[u] = 0.0; vi[u] = 0.0;
+                        if (it < len[u]) {
+                            key[u] = kp[u][it];
+                            if (CPLX) { vr[u] = vp[u][2 * (size_t)it]; vi[u] = vp[u][2 * (size_t)it + 1]; } else vr[u] = vp[u][it];
+                        }
                     }
-                    if (in_b && ob < (uint32_t)W) {
-                        if (CPLX) { atomicAdd(&s_acc[2 * ob], br); atomicAdd(&s_acc[2 * ob + 1], bi); } else atomicAdd(&s_acc[ob], br);
+#pragma unroll
+                    for (int u = 0; u < kWinRuns; ++u) {
+                        const uint32_t o = key[u] - (uint32_t)w0; // (a key outside the window -- only after a failed look-up -- is dropped)
+                        if (it < len[u] && o < (uint32_t)W) {
+                            if (CPLX) { atomicAdd(&s_acc[2 * o], vr[u]); atomicAdd(&s_acc[2 * o + 1], vi[u]); } else atomicAdd(&s_acc[o], vr[u]);
+                        }
                     }
                 }
             }

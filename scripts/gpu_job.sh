@@ -5,7 +5,7 @@
 #   smoke            __graft_entry__.smoke()
 #   tests            the whole -m gpu suite            tests:<expr> = pytest -k <expr>
 #   bench            default bench line                bench1 = --force-distributed --distributed-extras (one RCCL rank)
-#   bench_c128       chain_32 c128 line
+#   bench_c128       chain_32 c128 line                bench1p = one RCCL rank, packets only
 #   packets[:v ..]   packet path A/B: sorted streams | pre-indexed + atomics | state-carrying + atomics, timing trees (scripts/tile_bench.py)
 #   packets_prof     rocprofv3 kernel trace + SQ counters of chain_28 x 8 partitions
 #   stream_cost      k_chain_t with one more 8-byte stream per row (profiling build): what a byte per row costs
@@ -40,6 +40,8 @@ for step in "$@"; do
     packets_prof)
       CMD="python $GRAFT_REPO_ROOT/scripts/tile_bench.py --L 28 --P 8 --steps 3" bash scripts/gpu_profile_cmd.sh "${TAG}_packets" > "$OUT/packets_prof.log" 2>&1
       grep -E "k_tile|k_scatter|k_diag" "gpurun_out/prof_${TAG}_packets/summary.txt" | cut -c1-200 | head -30 ;;
+    bench1p) # one RCCL rank through the C host's packet path only (chain_32: every packet is an own-partition packet)
+      ( time timeout 600 python bench.py --force-distributed --exchange packets --no-cpu-baseline --no-extra --steps 5 --warmup 2 --kDisplayTimings > "$OUT/bench_one_rank_packets.json" 2> "$OUT/bench_one_rank_packets.err" ) 2>&1 | grep real; echo "rc=$?"; tail -c 3000 "$OUT/bench_one_rank_packets.json"; grep -v "^$" "$OUT/bench_one_rank_packets.err" | tail -25 ;;
     lattice) # the reference's benchmark model: K4 mode 5 (factorised point group) against mode 4 (one network per coset), same box
       for k4 in default cosets; do
         for m in heisenberg_square_6x6 heisenberg_square_4x4; do
