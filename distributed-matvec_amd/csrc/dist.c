@@ -303,20 +303,24 @@ int ls_amd_dist_create(ls_amd_dist **out, ls_amd_comm *cm, ls_hs_operator const 
         if (lsk_comm_allreduce(cm->c, ds, 1, 2, 1, stream) != 0) rc1 = ls_amd_internal_error("%s", lsk_comm_last_error());
         if (rc1 == 0 && (lsk_sync(stream) != 0 || lsk_d2h(&mx, ds, sizeof(mx)) != 0)) rc1 = ls_amd_internal_error("%s", lsk_last_error());
         TRY(agree(cm, rc1, stream));
-        int64_t rpr = rows_per_round();
+        int64_t const rpr = rows_per_round();
+        num_rounds = (int)((mx + rpr - 1) / rpr);
+        if (num_rounds < 1) num_rounds = 1;
         if (!getenv("LS_AMD_ROWS_PER_ROUND") && ls_amd_internal_streams_eligible(op, P)) {
-            /* sorted streams: every round reads and writes y once and searches every stream once per window, so few LARGE rounds --
-             * send / receive buffers of ~24 GB each (four of them: sized for 288 GB of HBM), and one destination takes < 2^32
-             * packets per round (rows x groups is an upper bound).  Every rank computes the same number: no memory query here */
+            /* sorted streams: every round reads and writes y once and searches every stream once per window, and a window's run of
+             * one stream shrinks with the number of rounds -- so FEW rounds: three, which still lets generate(r + 1), the exchange
+             * of round r and the consumer of round r - 1 overlap, unless the buffers ask for more (send / receive buffers of at most
+             * ~24 GB each -- four of them: sized for 288 GB of HBM -- and < 2^32 packets per destination and round: rows x groups
+             * is an upper bound).  Every rank computes the same number: nothing here depends on the local memory state */
             int const ng = ls_hs_operator_max_number_off_diag(op) > 0 ? ls_hs_operator_max_number_off_diag(op) : 1;
             int64_t const per_row = (int64_t)ng * (dtype == LS_AMD_C128 ? 20 : 12) / 2 + 16; /* half the pairs are anti-aligned */
             int64_t big = ((int64_t)24 << 30) / per_row;
             int64_t const cap = ((int64_t)1 << 32) / ng;
             if (big > cap) big = cap;
-            if (big > rpr) rpr = big;
+            int const need = (int)((mx + big - 1) / big);
+            if (num_rounds > 3) num_rounds = 3;
+            if (num_rounds < need) num_rounds = need;
         }
-        num_rounds = (int)((mx + rpr - 1) / rpr);
-        if (num_rounds < 1) num_rounds = 1;
     }
     ls_amd_dist *d = (ls_amd_dist *)calloc(1, sizeof(*d));
     d->comm = cm; d->P = P; d->me = me; d->rounds = num_rounds;

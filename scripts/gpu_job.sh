@@ -51,6 +51,8 @@ for step in "$@"; do
     stream_cost) timeout 400 python scripts/chain_stream_cost.py 32 10 2>&1 | grep -v amdgpu.ids | tee "$OUT/chain_stream_cost.txt" ;;
     ablate:*) # where the time of the projected pull kernel goes (profiling build, results wrong by construction)
       timeout 600 python scripts/ablate_pull.py "${step#ablate:}" 2>&1 | tee "$OUT/ablate_${step#ablate:}.txt" | tail -12 | cut -c1-300 ;;
+    loopbackp:*) a=${step#loopbackp:} # packets only, sorted streams | atomics
+      for st in 1 0; do echo "--- LS_AMD_PACKET_STREAMS=$st"; LS_AMD_PACKET_STREAMS=$st timeout 600 python scripts/loopback_bench.py --L "$a" --P 8 --steps 3 --mode packets 2>&1 | grep -E "ranks sharing|aggregate|rank 0:|producers|localeIdxOf|consumers" | cut -c1-300; done | tee "$OUT/loopback_packets_$a.txt" ;;
     loopback:*) a=${step#loopback:}; L=${a%s}; S=""; [ "$a" != "$L" ] && S="--symm"
       timeout 900 python scripts/loopback_bench.py --L "$L" $S --P 8 --steps 3 > "$OUT/loopback_$a.txt" 2>&1; grep -E "ranks sharing|x received|aggregate" "$OUT/loopback_$a.txt" | cut -c1-300 ;;
     pmc:*) IFS=: read -r _ model dtype <<< "$step"
