@@ -38,8 +38,8 @@ for step in "$@"; do
         done
       done | tee -a "$OUT/packets_ab.txt" ;;
     packets_prof)
-      CMD="python $GRAFT_REPO_ROOT/scripts/tile_bench.py --L 28 --P 8 --steps 3" bash scripts/gpu_profile_cmd.sh "${TAG}_packets" > "$OUT/packets_prof.log" 2>&1
-      grep -E "k_tile|k_scatter|k_diag" "gpurun_out/prof_${TAG}_packets/summary.txt" | cut -c1-200 | head -30 ;;
+      WITH_MEM=1 CMD="python $GRAFT_REPO_ROOT/scripts/tile_bench.py --L 28 --P 8 --steps 3" bash scripts/gpu_profile_cmd.sh "${TAG}_packets" > "$OUT/packets_prof.log" 2>&1
+      grep -E "k_tile|k_scatter|k_window|k_diag" "gpurun_out/prof_${TAG}_packets/summary.txt" | cut -c1-200 | head -30 ;;
     bench1p) # one RCCL rank through the C host's packet path only (chain_32: every packet is an own-partition packet)
       ( time timeout 600 python bench.py --force-distributed --exchange packets --no-cpu-baseline --no-extra --steps 5 --warmup 2 --kDisplayTimings > "$OUT/bench_one_rank_packets.json" 2> "$OUT/bench_one_rank_packets.err" ) 2>&1 | grep real; echo "rc=$?"; tail -c 3000 "$OUT/bench_one_rank_packets.json"; grep -v "^$" "$OUT/bench_one_rank_packets.err" | tail -25 ;;
     lattice) # the reference's benchmark model: K4 mode 5 (factorised point group) against mode 4 (one network per coset), same box

@@ -28,7 +28,7 @@ def main(root):
                 if rows:
                     print(f"{'kernel':60s} {'counter':24s} {'mean/dispatch':>16s} {'n':>5s}")
                 for kn, cn, v, n in rows:
-                    if any(t in kn for t in ("k_direct", "k_diag", "k_tile", "k_scatter", "k_lin", "k_pull", "k_chain", "k_pairs")):
+                    if any(t in kn for t in ("k_direct", "k_diag", "k_tile", "k_scatter", "k_window", "k_lin", "k_pull", "k_chain", "k_pairs")):
                         print(f"{kn[:60]:60s} {cn:24s} {v:16.6g} {n:5d}")
         except sqlite3.Error as e:
             print("  (no counters:", e, ")")
