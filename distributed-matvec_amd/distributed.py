@@ -355,9 +355,18 @@ def exchange_memory_estimate(n_global: int, n_local: int, P: int, elem_bytes: in
     else:
         repl = n_global * (8 + 1 + 4 + 2 * w) + (8 + 3 * w) * (n_global // P + 1)
     rows = min(n_local, rpr)
+    key, tables = 8, 0
+    if not projected and P >= 2 and not os.environ.get("LS_AMD_ROWS_PER_ROUND"):
+        # sorted streams (unprojected fixed-weight bases, exchange operators; csrc/dist.c): at most three rounds unless a buffer
+        # would pass ~24 GB, 12-byte pre-indexed packets, the own partition's packets in the send buffer too, the (tile, destination,
+        # stream) table of the producer (4 B x P x 2 terms per 256 rows) and the all-destinations directory (P / 4 B per state)
+        key = 4
+        rows = max(rows, -(-n_local // 3))
+        rows = min(rows, max(1, (24 << 30) // (max(1, terms_per_row // 2) * (4 + w) + 16)), max(1, (1 << 32) // max(1, terms_per_row)))
+        tables = (n_local // 256 + 1) * P * 2 * terms_per_row * 4 + n_global * P // 4
     # (about half of the flip-mask groups act on a given state of the Heisenberg models; the buffers are sized from the plan's exact
     # counts and shrink with LS_AMD_ROWS_PER_ROUND -- they do not grow with N)
-    packets = n_local * (8 + 8 + 4) + 4 * rows * max(1, terms_per_row // 2) * (8 + w) + (8 * n_local if projected else 0)
+    packets = n_local * (8 + 8 + 4) + 4 * rows * max(1, terms_per_row // 2) * (key + w) + (8 * n_local if projected else 0) + tables
     vectors = (2 + krylov_vectors) * w * n_local
     return {"replicated": int(repl + vectors), "packets": int(packets + vectors), "vectors": int(vectors)}
 
