@@ -2463,10 +2463,14 @@ static int plan_setup_part(ls_amd_plan *pl, part_state *ps, int part_id, int num
     return rc != 0 ? dev_error() : 0;
 }
 
+/* windows of y per consumer block: the end of one window's run is the start of the next one's (one binary search saved per
+ * stream), as long as >= 8192 blocks keep the 2048 block slots busy without a long tail.  (Measured on chain_28 x 8: 1 / 4 / 8
+ * windows per block 2.96 / 2.86 / 3.06 ms -- no knob; the test hook forces the carry path on small bases.) */
+static __thread int g_test_stream_wpb = 0;
+void ls_amd_test_set_stream_windows_per_block(int n) { g_test_stream_wpb = n; }
 static int stream_windows_per_block(int64_t windows) {
-    char const *e = getenv("LS_AMD_STREAM_WPB");
-    if (e && atoi(e) > 0) return atoi(e);
-    int64_t const w = windows / 8192; /* (>= 8192 blocks keep 2048 block slots busy without a long tail) */
+    if (g_test_stream_wpb > 0) return g_test_stream_wpb;
+    int64_t const w = windows / 8192;
     return w < 1 ? 1 : (w > 8 ? 8 : (int)w);
 }
 /* sorted streams, all partitions in this process: one send buffer per source partition (a round of all sources is consumed by

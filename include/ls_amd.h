@@ -197,6 +197,9 @@ int64_t ls_amd_repl_x_in_bytes(ls_amd_repl const *repl);
  * still completes but delivers misplaced data.  Return 1 when a segment was corrupted, 0 when the layout has none to corrupt
  * (e.g. a packet plan with a single rank: nothing leaves the GPU). */
 int ls_amd_test_corrupt_dist(ls_amd_dist *dist);
+/* test hook (thread-local): plans created afterwards consume their sorted packet streams with n windows of y per block (n > 1:
+ * the run of a stream in one window starts where its run in the previous window ended); 0 = the plan decides */
+void ls_amd_test_set_stream_windows_per_block(int n);
 int ls_amd_test_corrupt_repl(ls_amd_repl *repl);
 
 /* ------------------------------------------------------------------------------------------
@@ -312,7 +315,19 @@ int ls_amd_scatter(ls_amd_plan *plan, int64_t n, uint64_t const *d_betas, void c
  * ls_amd_plan_segment_bytes(c) = bytes of such a segment (what the all-to-all-v moves per (round, peer));
  * ls_amd_plan_segment_value_offset(c) = where its values start; ls_amd_plan_packet_bytes = key + value bytes (nominal).
  * ls_amd_scatter takes either kind (d_betas = the segment's key array).  ls_amd_scatter_round consumes ALL segments of a
- * round's receive buffer in one launch: segment s = counts[s] packets at d_recv + offsets[s]. */
+ * round's receive buffer in one launch: segment s = counts[s] packets at d_recv + offsets[s].
+ *
+ * SORTED STREAMS (round 5; drivers that own both ends of the exchange: ls_amd_matvec over the partitions of one process and
+ * ls_amd_dist_matvec with >= 2 ranks; csrc/kernels.hip, k_tile_st / k_window).  When every off-diagonal term of the operator is
+ * an exchange pair and the basis is an unprojected fixed-weight one, the pre-indexed packets of a segment are written as
+ * 2 x (number of pairs) STREAMS, one per (pair, pattern of alpha on the pair): along a stream beta = alpha + constant, so --
+ * the producer's rows and the destination's states both ascending -- the keys of a stream ASCEND.  The consumer then owns a
+ * window of 2048 rows of y, finds every stream's sub-run for the window by binary search, adds those packets into an LDS copy of
+ * the window and writes y once: no atomic, no fabric request per packet (chain_28 over 8 partitions 21.7 -> 10.8 ms, c128 42.8 ->
+ * 14.7 ms; profiles/r5_packets_streams_ab.txt).  The own partition's packets take the same way (a segment of the send buffer).
+ * Layout on the wire is unchanged (12-byte packets, keys then values); the stream starts of every segment are exchanged once at
+ * set-up.  LS_AMD_PACKET_STREAMS=0: the atomic consumers above (A/B).  A plan driven through ls_amd_generate / ls_amd_scatter by a
+ * foreign exchange never writes streams. */
 int ls_amd_plan_key_bytes(ls_amd_plan const *plan);
 int64_t ls_amd_plan_segment_bytes(ls_amd_plan const *plan, int64_t count);
 int64_t ls_amd_plan_segment_value_offset(ls_amd_plan const *plan, int64_t count);

@@ -1203,6 +1203,8 @@ def test_pre_indexed_packets(torch, monkeypatch, case):
     falls back to them -- the O(N / P)-memory form -- by itself."""
     name, P, dt = case.split("/")
     P = int(P)
+    from distributed_matvec_amd import _lib
+
     D, basis, h, reps, masks = setup_model(torch, model_config(name), P)
     want_reps = oracle_reps(name)
     rng = np.random.RandomState(46)
@@ -1214,17 +1216,19 @@ def test_pre_indexed_packets(torch, monkeypatch, case):
     # (logical partitions inside one process: exchange operators on unprojected fixed-weight bases take the SORTED STREAMS --
     # pre-indexed packets, window consumers without atomics; everything else defaults to the state-carrying packets: nothing
     # crosses a wire; one partition per process -- tests/test_gpu_loopback.py, tests/test_gpu_rccl.py -- defaults to the indexed ones)
-    envs = ("LS_AMD_PACKET_INDEX", "LS_AMD_PACKET_INDEX_MAX", "LS_AMD_PACKET_STREAMS", "LS_AMD_STREAM_WPB")
+    envs = ("LS_AMD_PACKET_INDEX", "LS_AMD_PACKET_INDEX_MAX", "LS_AMD_PACKET_STREAMS")
     streams_ok = not basis.hasSpinInversionSymmetry() and not basis.hasPermutationSymmetries()
     for label, env in (("indexed", {"LS_AMD_PACKET_INDEX": "1", "LS_AMD_PACKET_STREAMS": "0"}), ("states", {"LS_AMD_PACKET_INDEX": "0"}),
-                       ("default", {}), ("streams-wpb3", {"LS_AMD_STREAM_WPB": "3"}),
+                       ("default", {}), ("streams-wpb3", {}),
                        ("ceiling", {"LS_AMD_PACKET_INDEX": "1", "LS_AMD_PACKET_INDEX_MAX": "8"})):
         for k in envs:
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         h.clear_plans()
+        _lib.load().ls_amd_test_set_stream_windows_per_block(3 if label == "streams-wpb3" else 0)
         got, pl = run_matvec(torch, D, h, reps, masks, x, P)
+        _lib.load().ls_amd_test_set_stream_windows_per_block(0)
         streams = label in ("default", "streams-wpb3") and streams_ok
         assert pl.kernel == ("tile+streams" if streams else "tile"), label
         key = 4 if label == "indexed" or streams else 8
@@ -1260,12 +1264,16 @@ def test_sorted_packet_streams(torch, monkeypatch, case):
     xb = torch.from_numpy(np.ascontiguousarray(x)).cuda()
     xh = D.arrFromBlockToHashed(xb, masks, P)
     got, nnz = {}, set()
-    for label, env in (("streams", {}), ("streams-wpb2", {"LS_AMD_STREAM_WPB": "2"}), ("atomics", {"LS_AMD_PACKET_STREAMS": "0"})):
-        for k in ("LS_AMD_PACKET_STREAMS", "LS_AMD_STREAM_WPB", "LS_AMD_PACKET_INDEX"):
+    from distributed_matvec_amd import _lib
+
+    for label, env in (("streams", {}), ("streams-wpb2", {}), ("atomics", {"LS_AMD_PACKET_STREAMS": "0"})):
+        for k in ("LS_AMD_PACKET_STREAMS", "LS_AMD_PACKET_INDEX"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
+        _lib.load().ls_amd_test_set_stream_windows_per_block(2 if label == "streams-wpb2" else 0)
         pl = D.MatvecPlan(h, reps, td, num_rounds=rounds)
+        _lib.load().ls_amd_test_set_stream_windows_per_block(0)
         assert pl.kernel == ("tile" if label == "atomics" else "tile+streams"), label
         if rounds:
             assert pl.num_rounds == rounds
