@@ -293,6 +293,54 @@ def boundary_extra(D, torch, h, basis, reps, y_device, x_device, calls=2):
     return out
 
 
+def packet_path_extra(D, torch, time_steps, L=28, P=8, steps=5):
+    """The reference's own formulation -- term expansion, hash -> owner, per-destination buffers, local scatter (DMV:663-853) -- on
+    one device: heisenberg_chain_L over P logical partitions through ls_amd_matvec (the "exchange" is a pointer hand-off), once with
+    the sorted packet streams + window consumers (csrc/kernels.hip, k_tile_st / k_window) and once with the atomic consumers
+    (LS_AMD_PACKET_STREAMS=0), each checked element-wise against the one-partition pull kernel on the same x."""
+    from distributed_matvec_amd import config
+
+    basis, h = D.loadConfigFromDict(config.heisenberg_chain_config(L), hamiltonian=True)
+    reps1, _ = D.enumerateStates(basis, 1)
+    x1 = D.fillRandom(reps1[0], 42, torch.float64)
+    y1 = torch.empty_like(x1)
+    ref = D.MatvecPlan(h, reps1, torch.float64, mode="pull")
+    ref.matvec([x1], [y1], check=True)
+    ref.destroy()
+    reps, masks = D.enumerateStates(basis, P)
+    xs = D.arrFromBlockToHashed(x1, masks, P)
+    out = {"workload": f"heisenberg_chain_{L} over {P} logical partitions on one device (ls_amd_matvec; f64)", "states": int(x1.numel())}
+    scale = float(y1.abs().max())
+    saved = os.environ.get("LS_AMD_PACKET_STREAMS")
+    try:
+        for label, env in (("sorted_streams", None), ("atomic_consumers", "0")):
+            if env is None:
+                os.environ.pop("LS_AMD_PACKET_STREAMS", None)
+            else:
+                os.environ["LS_AMD_PACKET_STREAMS"] = env
+            ys = [torch.full_like(v, 1.5) for v in xs]
+            pl = D.MatvecPlan(h, reps, torch.float64)
+            t = time_steps(lambda: pl.matvec(xs, ys, check=False), steps, 2)
+            pl.check()
+            err = float((D.arrFromHashedToBlock(ys, masks) - y1).abs().max()) / scale
+            out[label] = {"kernel": pl.kernel, "ms_per_matvec": t / steps * 1e3, "matvecs_per_s": steps / t, "nnz": pl.nnz, "rounds": pl.num_rounds,
+                          "packet_bytes": pl.packet_bytes, "max_rel_err_vs_one_partition": err, "ok": err <= 1e-12}
+            pl.destroy()
+            del ys
+    finally:
+        if saved is None:
+            os.environ.pop("LS_AMD_PACKET_STREAMS", None)
+        else:
+            os.environ["LS_AMD_PACKET_STREAMS"] = saved
+    a, b = out["sorted_streams"], out["atomic_consumers"]
+    out["speedup"] = b["ms_per_matvec"] / a["ms_per_matvec"]
+    # SURVEY 8(d) push formula: rows (8 + w) + nnz 2w bytes per matvec, against the HBM line
+    b_alg = int(x1.numel()) * 16 + a["nnz"] * 16
+    out["survey_push_formula"] = {"bytes_per_matvec": b_alg, "GBps": b_alg / (a["ms_per_matvec"] * 1e-3) / 1e9,
+                                  "frac_of_8TBps": b_alg / (a["ms_per_matvec"] * 1e-3) / 8e12}
+    return out
+
+
 def eigensolve_extra(D, torch, name, max_basis=12, eps=1e-7):
     """the caller of the path (BASELINE config 5: Diagonalize): ground state of one of the projected chains with the device-resident
     thick-restart Lanczos of diagonalize.py -- enumeration, plan, the slot cache in whatever HBM the Krylov basis leaves, fused
@@ -972,6 +1020,15 @@ def main():
 
             traceback.print_exc()
             extra["boundary_host_ptr"] = {"error": repr(e)[:400]}
+    if not distributed and not args.no_extra and not symm and args.dtype == "f64" and args.mode == "auto" and args.model == "heisenberg_chain_32":
+        # the packet path (the reference's formulation; the O(N / P)-memory exchange) on one device, self-verified
+        try:
+            extra["packet_path"] = packet_path_extra(D, torch, time_steps)
+        except Exception as e:  # reported, never hidden
+            import traceback
+
+            traceback.print_exc()
+            extra["packet_path"] = {"error": repr(e)[:400]}
     if not distributed and not args.no_extra and not symm:
         # secondary numbers in the same run: the other scatter/gather mode and the other dtype
         for label, mode2 in (("f64" if args.dtype == "c128" else "c128", args.mode),
