@@ -80,6 +80,9 @@ def test_ranks_as_threads(name, P, cplx, mode):
         if mode == "packets":
             op = RcclDistributedOperator(h, reps[rank], dtype, comm=comm, num_rounds=3)
             assert op.num_rounds == 3
+            # exchange operators on unprojected fixed-weight bases leave the producers as sorted streams (window consumers, no atomics)
+            streams = name in ("heisenberg_chain_16", "heisenberg_kagome_16")
+            assert op.engine.plan.kernel == ("tile+streams" if streams else "tile"), (name, op.engine.plan.kernel)
         else:
             op = RcclReplicatedOperator(h, reps_global, masks, dtype, comm=comm)
         op.matvec(xs[rank], ys[rank], check=True)
@@ -99,6 +102,55 @@ def test_ranks_as_threads(name, P, cplx, mode):
         assert abs(d - np.vdot(x, x)) < 1e-9
     for c in comms:
         c.destroy()
+
+
+@pytest.mark.parametrize("case", ["heisenberg_chain_20/4/f64/0", "heisenberg_chain_20/8/c128/2", "heisenberg_kagome_16/3/f64/0", "heisenberg_chain_16/2/c128/5"])
+def test_packet_exchange_sorted_streams_against_atomic_consumers(monkeypatch, case):
+    """ls_amd_dist_matvec with >= 2 ranks: the sorted packet streams (the stream starts of every rank's segments all-gathered once, the
+    own partition's segment consumed out of the send buffer, one window launch per round) against the atomic consumers
+    (LS_AMD_PACKET_STREAMS=0) and the oracle; the default number of rounds (<= 3) and forced ones; the wire carries the same bytes."""
+    import torch
+
+    import distributed_matvec_amd as D
+    from distributed_matvec_amd.distributed import RcclDistributedOperator
+    from oracle import c_oracle as CO
+
+    name, P, dt, rounds = case.split("/")
+    P, rounds = int(P), int(rounds)
+    basis, h = D.loadConfigFromDict(model_config(name), hamiltonian=True)
+    reps, masks = D.enumerateStates(basis, P)
+    dtype = torch.complex128 if dt == "c128" else torch.float64
+    xs = [D.fillRandom(reps[p], 19, dtype) for p in range(P)]
+    want_reps = oracle_reps(name)
+    keys = CO.locale_idx_of(want_reps, P)
+    x = CO.hashed_to_block([v.cpu().numpy() for v in xs], keys)
+    want = oracle_for(name).local_matvec(want_reps, x)
+    results, volumes = {}, {}
+    for label, env in (("streams", None), ("atomics", "0")):
+        if env is None:
+            monkeypatch.delenv("LS_AMD_PACKET_STREAMS", raising=False)
+        else:
+            monkeypatch.setenv("LS_AMD_PACKET_STREAMS", env)
+        ys = [torch.full_like(v, 2.5) for v in xs]
+        info = [None] * P
+
+        def body(rank, comm):
+            op = RcclDistributedOperator(h, reps[rank], dtype, comm=comm, num_rounds=rounds)
+            for _ in range(2):
+                op.matvec(xs[rank], ys[rank], check=True)
+            info[rank] = (op.engine.plan.kernel, op.num_rounds, op.exchange_bytes_per_matvec)
+            op.dm.destroy()
+
+        comms = _run_ranks(P, body)
+        for c in comms:
+            c.destroy()
+        assert all(k == ("tile+streams" if label == "streams" else "tile") for k, _, _ in info), info
+        assert len({r for _, r, _ in info}) == 1 and (info[0][1] == rounds if rounds else info[0][1] <= 3)
+        volumes[label] = sum(b for _, _, b in info)
+        results[label] = CO.hashed_to_block([v.cpu().numpy() for v in ys], keys)
+        assert np.abs(results[label] - want).max() <= 1e-12 * max(1.0, np.abs(want).max()), label
+    assert volumes["streams"] == volumes["atomics"] > 0  # pre-indexed 12 / 20-byte packets either way; the own segment never travels
+    assert np.abs(results["streams"] - results["atomics"]).max() <= 1e-13 * max(1.0, np.abs(want).max())
 
 
 @pytest.mark.parametrize("case", ["heisenberg_chain_20/4/f64/-7", "heisenberg_chain_20/8/c128/-6", "heisenberg_chain_16/3/f64/-5",
