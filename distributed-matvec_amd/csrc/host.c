@@ -2176,8 +2176,9 @@ int ls_amd_internal_streams_eligible(ls_hs_operator const *op, int P) {
         if (oe->groups[g].fast != LSK_GROUP_EXCHANGE || __builtin_popcountll(oe->groups[g].x) != 2) return 0;
     return 1;
 }
+static __thread int g_no_streams = 0; /* set while a plan whose stream buffers did not fit is created again with the atomic consumers */
 static int streams_wanted(ls_amd_plan const *pl) {
-    if ((pl->me >= 0 && !g_want_streams) || pl->family != FAMILY_TILE || pl->dbs.proj != LSK_PROJ_NONE) return 0;
+    if (g_no_streams || (pl->me >= 0 && !g_want_streams) || pl->family != FAMILY_TILE || pl->dbs.proj != LSK_PROJ_NONE) return 0;
     return ls_amd_internal_streams_eligible(pl->op, pl->P);
 }
 static int setup_packet_index(ls_amd_plan *pl, uint64_t const *const *d_reps, int64_t const *counts, void *stream) {
@@ -2475,8 +2476,11 @@ static int stream_windows_per_block(int64_t windows) {
 }
 /* sorted streams, all partitions in this process: one send buffer per source partition (a round of all sources is consumed by
  * ONE launch, so y is read and written once per round) and the consumer's view of every (round, destination, source) segment */
+static __thread int g_test_fail_stream_buffers = 0;
+void ls_amd_test_fail_stream_buffers(int on) { g_test_fail_stream_buffers = on; }
 static int setup_streams(ls_amd_plan *pl, int rounds) {
     int const P = pl->P, S = pl->st_S;
+    if (g_test_fail_stream_buffers) return set_error("test hook: no room for the stream buffers");
     pl->st_rounds = rounds;
     pl->d_send_parts = (void **)calloc((size_t)P, sizeof(void *));
     for (int p = 0; p < P; ++p) {
@@ -2585,6 +2589,7 @@ int ls_amd_plan_create(ls_amd_plan **out, ls_hs_operator const *op, ls_amd_dtype
     pl->key_bytes = 8;
     if (pl->family == FAMILY_TILE && setup_packet_index(pl, d_reps, counts, stream) != 0) { ls_amd_plan_destroy(pl); return -1; }
     pl->parts = (part_state *)calloc(pl->n_local, sizeof(part_state));
+    int const num_rounds_arg = num_rounds;
     if (pl->streams && num_rounds <= 0) { /* one consumer launch per round over all sources: every partition runs the same rounds */
         int64_t mx = 0, rpr = rows_per_round_default();
         for (int i = 0; i < pl->n_local; ++i) if (counts[i] > mx) mx = counts[i];
@@ -2599,7 +2604,16 @@ int ls_amd_plan_create(ls_amd_plan **out, ls_hs_operator const *op, ls_amd_dtype
         if (plan_setup_part(pl, ps, pid, num_rounds, stream) != 0) { ls_amd_plan_destroy(pl); return -1; }
         if (ps->max_send_bytes > pl->send_capacity) pl->send_capacity = ps->max_send_bytes;
     }
-    if (pl->streams && my_partition < 0 && setup_streams(pl, num_rounds) != 0) { ls_amd_plan_destroy(pl); return -1; }
+    if (pl->streams && my_partition < 0 && setup_streams(pl, num_rounds) != 0) {
+        /* one buffer per source partition did not fit (or a table could not be uploaded): the same plan with ONE shared buffer and
+         * the atomic consumers -- the O(N / P) form must not fail where it used to work */
+        ls_amd_plan_destroy(pl);
+        if (g_no_streams) return -1;
+        g_no_streams = 1;
+        int const rc = ls_amd_plan_create(out, op, dtype, num_partitions, my_partition, d_reps, counts, num_rounds_arg, mode, stream);
+        g_no_streams = 0;
+        return rc;
+    }
     if (pl->streams && my_partition >= 0) { /* one partition per process: the driver owns the buffers (dist.c) */
         pl->st_rounds = pl->parts[0].rounds;
         pl->st_wpb = stream_windows_per_block((pl->parts[0].count + lsk_window_rows(pl->cplx) - 1) / lsk_window_rows(pl->cplx));

@@ -200,6 +200,9 @@ int ls_amd_test_corrupt_dist(ls_amd_dist *dist);
 /* test hook (thread-local): plans created afterwards consume their sorted packet streams with n windows of y per block (n > 1:
  * the run of a stream in one window starts where its run in the previous window ended); 0 = the plan decides */
 void ls_amd_test_set_stream_windows_per_block(int n);
+/* test hook (thread-local): the per-source stream buffers of ls_amd_matvec plans "do not fit" -- such a plan must come back with one
+ * shared buffer and the atomic consumers instead of failing */
+void ls_amd_test_fail_stream_buffers(int on);
 int ls_amd_test_corrupt_repl(ls_amd_repl *repl);
 
 /* ------------------------------------------------------------------------------------------

@@ -1290,6 +1290,17 @@ def test_sorted_packet_streams(torch, monkeypatch, case):
     assert np.abs(got["streams"] - got["atomics"]).max() <= 1e-13 * max(1.0, np.abs(want).max())
     assert np.abs(got["streams"] - got["streams-wpb2"]).max() <= 1e-13 * max(1.0, np.abs(want).max())
     assert len(nnz) == 1  # the count passes of both producers agree on the number of packets
+    # no room for one buffer per source partition: the plan comes back with the shared buffer and the atomic consumers
+    _lib.load().ls_amd_test_fail_stream_buffers(1)
+    try:
+        pl = D.MatvecPlan(h, reps, td, num_rounds=rounds)
+    finally:
+        _lib.load().ls_amd_test_fail_stream_buffers(0)
+    assert pl.kernel == "tile"
+    y = [torch.zeros_like(v) for v in xh]
+    pl.matvec(xh, y)
+    assert np.abs(D.arrFromHashedToBlock(y, masks).cpu().numpy() - want).max() <= 1e-12 * max(1.0, np.abs(want).max())
+    pl.destroy()
 
 
 def test_pre_indexed_packets_report_states_outside_the_basis(torch, monkeypatch):
