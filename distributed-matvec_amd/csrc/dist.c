@@ -260,6 +260,8 @@ static void fill_stream_sources(ls_amd_dist *d) {
             w->soff = (uint32_t const *)d->d_soff_all + (((size_t)q * R + r) * P + me) * (size_t)(S + 1);
         }
 }
+static __thread int g_test_fail_dist_streams = 0;
+void ls_amd_test_fail_dist_streams(int on) { g_test_fail_dist_streams = on; }
 static int setup_stream_tables(ls_amd_dist *d, void *stream) {
     ls_amd_comm *cm = d->comm;
     int const P = d->P, R = d->rounds, S = d->streams;
@@ -267,6 +269,7 @@ static int setup_stream_tables(ls_amd_dist *d, void *stream) {
     uint32_t const *mine = ls_amd_internal_plan_stream_offsets(d->plan);
     void *all = NULL, *one = NULL;
     int rc = mine ? 0 : ls_amd_internal_error("internal error: a streams plan without stream offsets");
+    if (rc == 0 && g_test_fail_dist_streams) rc = ls_amd_internal_error("test hook: no room for the stream tables");
     if (rc == 0 && (lsk_malloc(&all, bytes * (size_t)P) != 0 || lsk_malloc(&one, bytes) != 0 || lsk_h2d(one, mine, bytes) != 0))
         rc = ls_amd_internal_error("%s", lsk_last_error());
     d->d_soff_all = all; /* owned by d from here on */
@@ -285,9 +288,24 @@ static int setup_stream_tables(ls_amd_dist *d, void *stream) {
     return 0;
 }
 
+static int dist_create_impl(ls_amd_dist **out, ls_amd_comm *cm, ls_hs_operator const *op, ls_amd_dtype dtype,
+                            uint64_t const *d_reps_local, int64_t count_local, int num_rounds, void *stream, int allow_streams,
+                            int *used_streams);
 int ls_amd_dist_create(ls_amd_dist **out, ls_amd_comm *cm, ls_hs_operator const *op, ls_amd_dtype dtype,
                        uint64_t const *d_reps_local, int64_t count_local, int num_rounds, void *stream) {
+    int used_streams = 0;
+    int rc = dist_create_impl(out, cm, op, dtype, d_reps_local, count_local, num_rounds, stream, 1, &used_streams);
+    /* Every failure of the set-up is a collective verdict (agree()).  If the attempt ran with the sorted streams -- few large rounds,
+     * send / receive buffers of up to ~24 GB each -- all ranks try once more in the form that needs the least memory: the atomic
+     * consumers and the default rows per round */
+    if (rc != 0 && used_streams) rc = dist_create_impl(out, cm, op, dtype, d_reps_local, count_local, num_rounds, stream, 0, &used_streams);
+    return rc;
+}
+static int dist_create_impl(ls_amd_dist **out, ls_amd_comm *cm, ls_hs_operator const *op, ls_amd_dtype dtype,
+                            uint64_t const *d_reps_local, int64_t count_local, int num_rounds, void *stream, int allow_streams,
+                            int *used_streams) {
     *out = NULL;
+    *used_streams = 0;
     if (!cm) return ls_amd_internal_error("ls_amd_dist_create: no communicator");
     int const P = ls_amd_comm_size(cm), me = ls_amd_comm_rank(cm);
     void *ds;
@@ -306,7 +324,7 @@ int ls_amd_dist_create(ls_amd_dist **out, ls_amd_comm *cm, ls_hs_operator const 
         int64_t const rpr = rows_per_round();
         num_rounds = (int)((mx + rpr - 1) / rpr);
         if (num_rounds < 1) num_rounds = 1;
-        if (!getenv("LS_AMD_ROWS_PER_ROUND") && ls_amd_internal_streams_eligible(op, P)) {
+        if (allow_streams && !getenv("LS_AMD_ROWS_PER_ROUND") && ls_amd_internal_streams_eligible(op, P)) {
             /* sorted streams: every round reads and writes y once and searches every stream once per window, and a window's run of
              * one stream shrinks with the number of rounds -- so FEW rounds: three, which still lets generate(r + 1), the exchange
              * of round r and the consumer of round r - 1 overlap, unless the buffers ask for more (send / receive buffers of at most
@@ -327,7 +345,7 @@ int ls_amd_dist_create(ls_amd_dist **out, ls_amd_comm *cm, ls_hs_operator const 
     uint64_t const *reps[1] = {d_reps_local};
     int64_t counts[1] = {count_local};
     size_t const m = (size_t)num_rounds * (size_t)P;
-    ls_amd_internal_set_want_streams(1);
+    ls_amd_internal_set_want_streams(allow_streams);
     int rc = ls_amd_plan_create(&d->plan, op, dtype, P, me, reps, counts, num_rounds, LS_AMD_MODE_AUTO, stream);
     ls_amd_internal_set_want_streams(0);
     {   /* the packet layout -- sorted streams of pre-indexed packets (0), pre-indexed 4-byte keys (1) or 8-byte states (2) -- is
@@ -347,6 +365,14 @@ int ls_amd_dist_create(ls_amd_dist **out, ls_amd_comm *cm, ls_hs_operator const 
         }
     }
     d->streams = rc == 0 ? ls_amd_internal_plan_streams(d->plan) : 0;
+    {   /* (a collective fact: the level was agreed on, so either every healthy rank writes streams or none does -- and a rank
+         * that failed here pulls everybody into the retry through the next agreement) */
+        int64_t any = d->streams != 0;
+        if (cm->d_status && lsk_h2d(cm->d_status, &any, sizeof(any)) == 0 && lsk_comm_allreduce(cm->c, cm->d_status, 1, 2, 1, stream) == 0 &&
+            lsk_sync(stream) == 0 && lsk_d2h(&any, cm->d_status, sizeof(any)) == 0)
+            *used_streams = any != 0;
+        else if (rc == 0) rc = ls_amd_internal_error("packet-layout agreement failed: %s", lsk_comm_last_error());
+    }
     if (rc == 0 && ls_amd_plan_num_rounds(d->plan) != num_rounds) rc = ls_amd_internal_error("internal error: rounds disagree");
     if (rc == 0) {
         d->pb = ls_amd_plan_packet_bytes(d->plan);

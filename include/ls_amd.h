@@ -203,6 +203,9 @@ void ls_amd_test_set_stream_windows_per_block(int n);
 /* test hook (thread-local): the per-source stream buffers of ls_amd_matvec plans "do not fit" -- such a plan must come back with one
  * shared buffer and the atomic consumers instead of failing */
 void ls_amd_test_fail_stream_buffers(int on);
+/* ... and the set-up of the sorted streams fails on the calling rank of ls_amd_dist_create: ALL ranks must come back with the atomic
+ * consumers and the default rows per round (the verdict of every set-up step is collective) */
+void ls_amd_test_fail_dist_streams(int on);
 int ls_amd_test_corrupt_repl(ls_amd_repl *repl);
 
 /* ------------------------------------------------------------------------------------------

@@ -126,7 +126,10 @@ def test_packet_exchange_sorted_streams_against_atomic_consumers(monkeypatch, ca
     x = CO.hashed_to_block([v.cpu().numpy() for v in xs], keys)
     want = oracle_for(name).local_matvec(want_reps, x)
     results, volumes = {}, {}
-    for label, env in (("streams", None), ("atomics", "0")):
+    from distributed_matvec_amd import _lib
+
+    # ("retry": the set-up of the streams fails on ONE rank -- every rank must come back with the atomic consumers)
+    for label, env in (("streams", None), ("atomics", "0"), ("retry", None)):
         if env is None:
             monkeypatch.delenv("LS_AMD_PACKET_STREAMS", raising=False)
         else:
@@ -135,7 +138,11 @@ def test_packet_exchange_sorted_streams_against_atomic_consumers(monkeypatch, ca
         info = [None] * P
 
         def body(rank, comm):
-            op = RcclDistributedOperator(h, reps[rank], dtype, comm=comm, num_rounds=rounds)
+            _lib.load().ls_amd_test_fail_dist_streams(1 if label == "retry" and rank == P - 1 else 0)  # (thread-local: ranks are threads)
+            try:
+                op = RcclDistributedOperator(h, reps[rank], dtype, comm=comm, num_rounds=rounds)
+            finally:
+                _lib.load().ls_amd_test_fail_dist_streams(0)
             for _ in range(2):
                 op.matvec(xs[rank], ys[rank], check=True)
             info[rank] = (op.engine.plan.kernel, op.num_rounds, op.exchange_bytes_per_matvec)
