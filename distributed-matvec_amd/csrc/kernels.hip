@@ -180,6 +180,7 @@ static inline Owner make_owner(int P) {
     return o;
 }
 __device__ __forceinline__ int owner_of(uint64_t s, Owner o) {
+    if (o.P == 1) return 0; // one locale: nothing to hash (wave-uniform)
     uint64_t h = hash64_01(s);
     if (o.pmask != 0xffffffffu) return (int)((uint32_t)h & o.pmask);
     uint32_t hi = (uint32_t)(h >> 32), lo = (uint32_t)h;
@@ -2206,6 +2207,9 @@ __global__ __launch_bounds__(kBlock) void k_tile_wv(int n_groups, lsk_group cons
     constexpr int kCap = (kBlock / 64) * kTwRing;
     __shared__ uint64_t s_beta[kCap];
     __shared__ double s_val[COUNT ? 1 : kCap * (CPLX ? 2 : 1)];
+    // PK12: colex rank of beta when it is one binomial away from alpha's (exchange on adjacent sites: rank(alpha) +- C(lo, k)), so that
+    // the rank sum of the directory look-up runs once per row, not once per packet; kNoRank: the full sum (see k_tile_st)
+    __shared__ uint32_t s_rank[(!COUNT && PK12) ? kCap : 1];
     extern __shared__ uint64_t s_db[]; // rank directory of the own partition: binomials of the closed-form rank (0 bytes without one)
     if (!COUNT && PK12) { gdir_load(gd, ix.binom, s_db); __syncthreads(); }
     else if (!COUNT && ix.dir) { rankdir_load(ix, s_db); __syncthreads(); }
@@ -2235,6 +2239,14 @@ __global__ __launch_bounds__(kBlock) void k_tile_wv(int n_groups, lsk_group cons
                     xi *= s;
                 }
             }
+        }
+        const bool narrow_ranks = !COUNT && PK12 && bs.proj == LSK_PROJ_NONE && gd.n_ranks <= 0xffffffffLL;
+        uint64_t ga = 0; // colex rank of alpha
+        if (narrow_ranks && valid) {
+            const int kc = gd.weight + 1;
+            uint64_t t = a;
+            int k = 1;
+            while (t && k < kc) { ga += s_db[(__ffsll((unsigned long long)t) - 1) * kc + k]; ++k; t &= t - 1; }
         }
         const int64_t wg = ((t0 - row0) >> 6) + wave; // this wave's 64 rows inside the round
         uint32_t cur = 0;                             // lane d: packets so far (COUNT) | next position in segment d
@@ -2269,7 +2281,8 @@ __global__ __launch_bounds__(kBlock) void k_tile_wv(int n_groups, lsk_group cons
             uint32_t pidx = 0; // PK12: the packet's index inside its destination's block
             if (!COUNT && PK12) {
                 if (live) {
-                    const int64_t idx = gdir_index(gd, beta, dest, s_db);
+                    const uint32_t rk = s_rank[e];
+                    const int64_t idx = rk != kNoRank ? gdir_index_of_rank(gd, (uint64_t)rk, dest) : gdir_index(gd, beta, dest, s_db);
                     if (idx < 0) { // not a basis state (DMV:115-118): the flag halts the matvec; the slot the count pass reserved for the
                         atomicExch(err, 1); // packet is still filled -- with (index 0, value 0) -- so that no consumer meets a stale key
                         if (dest == me) remote = false;
@@ -2328,6 +2341,14 @@ __global__ __launch_bounds__(kBlock) void k_tile_wv(int n_groups, lsk_group cons
                     if (!COUNT) {
                         if (CPLX) { s_val[2 * slot] = cr * xr - ci * xi; s_val[2 * slot + 1] = cr * xi + ci * xr; }
                         else s_val[slot] = cr * xr;
+                        if (PK12) {
+                            uint32_t rk = kNoRank;
+                            if (narrow_ranks && G.fast == LSK_GROUP_EXCHANGE && G.adj >= 0) {
+                                const uint64_t c = s_db[G.adj * (gd.weight + 1) + __popcll(a & ((1ULL << G.adj) - 1))];
+                                rk = (uint32_t)(((a >> G.adj) & 1ULL) ? ga + c : ga - c); // the lower site's bit moves up | the upper one's down
+                            }
+                            s_rank[slot] = rk;
+                        }
                     }
                 }
                 cnt += __popcll(ball);
