@@ -391,6 +391,14 @@ static uint64_t host_apply_elem(lsk_group_elem const *e, uint64_t x, int L) {
     return ((x >> e->k) | (x << (L - e->k))) & mask;
 }
 
+/* The kernels loop over the group elements of a projected basis per candidate state; the largest groups of the reference's inputs
+ * have 288 elements (heisenberg_square_6x6), the automorphisms of a 64-site lattice a few thousand */
+enum { LS_AMD_MAX_GROUP_ORDER = 1 << 16 };
+static uint64_t perm_hash(int const *p, int L) {
+    uint64_t h = 0x9e3779b97f4a7c15ULL;
+    for (int i = 0; i < L; ++i) { h ^= (uint64_t)(p[i] + 1); h *= 0xff51afd7ed558ccdULL; h ^= h >> 29; }
+    return h;
+}
 static int close_group(struct ls_amd_basis_ext *ext, int L) {
     int const ng = ext->n_generators;
     int cap = 64, order = 1;
@@ -413,6 +421,13 @@ static int close_group(struct ls_amd_basis_ext *ext, int L) {
         gch[2 * g] = re; gch[2 * g + 1] = im;
     }
     int *cand = (int *)malloc(sizeof(int) * L);
+    /* membership by an open-addressing table of element numbers keyed by a hash of the permutation: the closure is linear in
+     * the group order (a linear scan per candidate made generators of a huge group -- a typo in one permutation of a YAML file
+     * is enough: two random permutations generate S_L -- run ~2^40 comparisons before the size limit below was reached) */
+    size_t tcap = 256;
+    int32_t *table = (int32_t *)malloc(sizeof(int32_t) * tcap);
+    for (size_t i = 0; i < tcap; ++i) table[i] = -1;
+    table[perm_hash(perms, L) & (tcap - 1)] = 0;
     for (int head = 0; head < order; ++head) { /* BFS: `order` grows while we scan */
         for (int g = 0; g < ng; ++g) {
             int const *p = ext->gen_perms + g * L;
@@ -421,14 +436,19 @@ static int close_group(struct ls_amd_basis_ext *ext, int L) {
             double cre = chars[2 * head] * gch[2 * g] - chars[2 * head + 1] * gch[2 * g + 1];
             double cim = chars[2 * head] * gch[2 * g + 1] + chars[2 * head + 1] * gch[2 * g];
             int found = -1;
-            for (int j = 0; j < order; ++j)
-                if (memcmp(perms + (size_t)j * L, cand, sizeof(int) * L) == 0) { found = j; break; }
+            size_t slot = perm_hash(cand, L) & (tcap - 1);
+            for (; table[slot] >= 0; slot = (slot + 1) & (tcap - 1))
+                if (memcmp(perms + (size_t)table[slot] * L, cand, sizeof(int) * L) == 0) { found = table[slot]; break; }
             if (found >= 0) {
                 if (fabs(chars[2 * found] - cre) > 1e-9 || fabs(chars[2 * found + 1] - cim) > 1e-9) {
-                    free(perms); free(chars); free(gch); free(cand);
+                    free(perms); free(chars); free(gch); free(cand); free(table);
                     return set_error("symmetry sectors are incompatible with the group structure");
                 }
                 continue;
+            }
+            if (order >= LS_AMD_MAX_GROUP_ORDER) {
+                free(perms); free(chars); free(gch); free(cand); free(table);
+                return set_error("symmetry group too large (more than %d elements: is every generator the permutation it should be?)", LS_AMD_MAX_GROUP_ORDER);
             }
             if (order == cap) {
                 cap *= 2;
@@ -437,13 +457,21 @@ static int close_group(struct ls_amd_basis_ext *ext, int L) {
             }
             memcpy(perms + (size_t)order * L, cand, sizeof(int) * L);
             chars[2 * order] = cre; chars[2 * order + 1] = cim;
+            table[slot] = order;
             ++order;
-            if (order > (1 << 20)) {
-                free(perms); free(chars); free(gch); free(cand);
-                return set_error("symmetry group too large");
+            if ((size_t)order * 2 > tcap) { /* keep the table at most half full */
+                tcap *= 2;
+                table = (int32_t *)realloc(table, sizeof(int32_t) * tcap);
+                for (size_t i = 0; i < tcap; ++i) table[i] = -1;
+                for (int j = 0; j < order; ++j) {
+                    size_t s2 = perm_hash(perms + (size_t)j * L, L) & (tcap - 1);
+                    while (table[s2] >= 0) s2 = (s2 + 1) & (tcap - 1);
+                    table[s2] = j;
+                }
             }
         }
     }
+    free(table);
     ext->order = order;
     ext->perms = perms;
     ext->elems = (lsk_group_elem *)malloc(sizeof(lsk_group_elem) * order);

@@ -117,6 +117,36 @@ def test_incompatible_sectors_are_rejected():
         M.model_from_config(cfg)
 
 
+def test_generators_of_a_huge_group_are_refused_quickly():
+    """one wrong entry in a permutation of a YAML file is enough to generate (nearly) the symmetric group: the closure must end
+    with an error in milliseconds -- membership is a hash look-up, the order is capped -- not scan ~2^40 pairs (found by
+    mutation-fuzzing the loader: 6 of 6 runs hung on such an input).  A large but legitimate group still closes."""
+    import time
+
+    L = 40
+    cfg = M.heisenberg_chain_config(L)
+    swapped = [L - 1 - i for i in range(L)]
+    swapped[10], swapped[12] = swapped[12], swapped[10]  # the reflection with two entries exchanged
+    cfg["basis"]["symmetries"] = [{"permutation": [(i + 1) % L for i in range(L)], "sector": 0}, {"permutation": swapped, "sector": 0}]
+    t0 = time.perf_counter()
+    with pytest.raises(D.LsAmdError, match="group too large"):
+        D.loadConfigFromDict(cfg)
+    assert time.perf_counter() - t0 < 5.0
+    # 4 x 4 x 4 torus: translations, one axis permutation cycle and one axis swap -> 64 * 6 = 384 elements
+    idx = lambda x, y, z: (x % 4) + 4 * ((y % 4) + 4 * (z % 4))  # noqa: E731
+    sites = [(x, y, z) for z in range(4) for y in range(4) for x in range(4)]
+    cfg = M.heisenberg_chain_config(64)
+    cfg["basis"]["hamming_weight"] = 32
+    cfg["basis"]["symmetries"] = [
+        {"permutation": [idx(x + 1, y, z) for x, y, z in sites], "sector": 0},
+        {"permutation": [idx(y, z, x) for x, y, z in sites], "sector": 0},
+        {"permutation": [idx(y, x, z) for x, y, z in sites], "sector": 0},
+    ]
+    basis = D.loadConfigFromDict(cfg)
+    basis = basis[0] if isinstance(basis, tuple) else basis
+    assert basis.groupOrder() == 384
+
+
 def test_random_permutation_networks():
     """Benes compilation for arbitrary generators (not just rotations / reflections)."""
     rs = np.random.RandomState(123)
