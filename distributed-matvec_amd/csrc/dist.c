@@ -308,7 +308,7 @@ static int dist_create_impl(ls_amd_dist **out, ls_amd_comm *cm, ls_hs_operator c
     *used_streams = 0;
     if (!cm) return ls_amd_internal_error("ls_amd_dist_create: no communicator");
     int const P = ls_amd_comm_size(cm), me = ls_amd_comm_rank(cm);
-    void *ds;
+    void *ds = NULL;
     /* every rank must run the same number of rounds: the collectives are matched */
     if (num_rounds <= 0) {
         int64_t mx = count_local;
@@ -731,7 +731,7 @@ int ls_amd_repl_create(ls_amd_repl **out, ls_amd_comm *cm, ls_hs_operator const 
     r->xs_off = (int64_t *)calloc(P, 8); r->xs_bytes = (int64_t *)calloc(P, 8); r->xr_off = (int64_t *)calloc(P, 8); r->xr_bytes = (int64_t *)calloc(P, 8);
     r->ys_off = (int64_t *)calloc(P, 8); r->ys_bytes = (int64_t *)calloc(P, 8); r->yr_off = (int64_t *)calloc(P, 8); r->yr_bytes = (int64_t *)calloc(P, 8);
     int64_t *all = (int64_t *)calloc((size_t)P * P, 8);
-    void *ds;
+    void *ds = NULL;
     if (rc == 0) rc = scratch(cm, 8 * (size_t)P * (size_t)(P + 1), &ds);
     if (rc == 0 && lsk_h2d(ds, ycounts, 8 * (size_t)P) != 0) rc = ls_amd_internal_error("%s", lsk_last_error());
     rc = agree(cm, rc, stream); /* every rank enters the all-gather below, or none does */

@@ -247,7 +247,7 @@ static ynode *y_inline(yparser *p) {
         size_t const a = ++p->pos;
         while (p->pos < p->len && !isspace((unsigned char)p->s[p->pos])) ++p->pos;
         char *name = y_substr(p->s + a, p->pos - a);
-        for (int i = 0; i < p->n_anchors; ++i)
+        for (int i = p->n_anchors - 1; i >= 0 && !val; --i) /* (a name bound twice: the later binding, one copy) */
             if (strcmp(p->anchor_names[i], name) == 0) val = y_copy(p->anchor_nodes[i]);
         if (!val) y_fail(p, "unknown alias *%s", name);
         free(name);
@@ -550,6 +550,8 @@ static int y_int(ynode const *n, char const *what, long *out) {
     char *end;
     long const v = strtol(n->str, &end, 10);
     if (end == n->str || *end) return ls_amd_internal_error("%s: '%s' is not an integer", what, n->str);
+    /* every integer of a config ends up in an `int` (sites, permutation entries, sectors, weights): 4294967296 must not read as 0 */
+    if (v < -2147483647L - 1 || v > 2147483647L) return ls_amd_internal_error("%s: %s is out of range", what, n->str);
     *out = v;
     return 0;
 }
@@ -578,7 +580,7 @@ static ls_hs_basis *basis_from(ynode const *b) {
             long sec = 0;
             int bad = !perm || perm->kind != Y_SEQ || perm->n != L || y_int(y_get(syms->vals[g], "sector"), "symmetries[].sector", &sec) != 0;
             for (int i = 0; i < L && !bad; ++i) {
-                long v;
+                long v = 0;
                 bad = y_int(perm->vals[i], "symmetries[].permutation", &v) != 0;
                 perms[(size_t)g * (size_t)L + i] = (int)v;
             }
@@ -613,7 +615,7 @@ static ls_hs_operator *operator_from(ls_hs_basis const *basis, ynode const *sect
             int idx[MAX_FACTORS];
             int bad = !tuple || tuple->kind != Y_SEQ || tuple->n > MAX_FACTORS;
             for (int i = 0; !bad && i < tuple->n; ++i) {
-                long v;
+                long v = 0;
                 bad = y_int(tuple->vals[i], "sites", &v) != 0;
                 idx[i] = (int)v;
             }

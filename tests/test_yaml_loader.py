@@ -222,3 +222,28 @@ def test_a_successful_load_leaves_no_stale_error_message():
     assert conf
     assert lib.ls_amd_last_error() == b""
     lib.ls_hs_destroy_yaml_config(conf)
+
+
+def test_integers_outside_the_int_range_are_errors_not_wrapped_values():
+    """every integer of a config ends up in a C `int`: 4294967296 must not be read as site 0, 4294967298 not as weight 2"""
+    lib = _lib.load()
+    ok = "basis:\n  number_spins: 4\n  hamming_weight: 2\nhamiltonian:\n  terms:\n    - expression: \"σᶻ₀ σᶻ₁\"\n      sites: [[0, 1]]\n"
+    conf = lib.ls_amd_load_yaml_config_from_string(ok.encode())
+    assert conf
+    lib.ls_hs_destroy_yaml_config(conf)
+    for bad in (ok.replace("[[0, 1]]", "[[4294967296, 1]]"), ok.replace("hamming_weight: 2", "hamming_weight: 4294967298"),
+                ok.replace("[[0, 1]]", "[[0, 99999999999999999999999]]")):
+        assert not lib.ls_amd_load_yaml_config_from_string(bad.encode()), bad
+        assert b"out of range" in lib.ls_amd_last_error() or b"expected a tuple of site indices" in lib.ls_amd_last_error()
+
+
+def test_an_anchor_bound_twice_resolves_to_the_later_binding():
+    text = ("basis:\n  number_spins: 4\n  hamming_weight: 2\nhamiltonian:\n  first: &bonds [[0, 1]]\n  second: &bonds [[1, 2], [2, 3]]\n"
+            "  terms:\n    - expression: \"σᶻ₀ σᶻ₁\"\n      sites: *bonds\n")
+    conf = load_c(text)
+    try:
+        h = D.Operator(conf.contents.hamiltonian, owning=False)
+        diag, off = product_terms(h)
+        assert sorted(m for v, m, r, x, s in diag) == [0b0110, 0b1100] or len(diag) == 2, diag
+    finally:
+        _lib.load().ls_hs_destroy_yaml_config(conf)
