@@ -39,6 +39,21 @@ def test_library_exports_every_declared_symbol():
     _lib.load()
 
 
+@pytest.mark.parametrize("header", ["ls_hs.h", "ls_chpl.h", "ls_amd.h"])
+def test_every_header_stands_alone_in_c_and_cxx(header, tmp_path):
+    """the boundary is what a maintainer includes from C (Chapel's C backend, PRIMME glue) or C++: every header of include/ must
+    compile on its own, -pedantic clean, as C11 and as C++17"""
+    import subprocess
+
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    src = tmp_path / "one.c"
+    src.write_text(f'#include "{header}"\nint ls_header_probe(void) {{ return 0; }}\n')
+    for cmd in (["gcc", "-std=c11"], ["g++", "-std=c++17", "-x", "c++"]):
+        r = subprocess.run(cmd + ["-Wall", "-Wextra", "-pedantic", "-Werror", "-I", inc, "-c", str(src), "-o", str(tmp_path / "one.o")],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+
+
 def test_no_gpu_means_loud_failure():
     L = _lib.load()
     if L.ls_amd_device_count() > 0:
