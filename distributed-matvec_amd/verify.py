@@ -63,8 +63,11 @@ def parity_object(y_part, x_part, y_ref_part, ymax_ref: float, allsum=None, allm
 
     allsum = allsum or (lambda v: v)
     allmax = allmax or (lambda v: v)
-    if y_part.numel() != y_ref_part.numel():
-        return {"ok": False, "error": f"block sizes differ: {y_part.numel()} vs {y_ref_part.numel()} reference rows"}
+    # (a collective verdict: a rank whose block has the wrong size must not leave while its peers sit in the reductions below)
+    differ = y_part.numel() != y_ref_part.numel()
+    if allsum(1.0 if differ else 0.0) > 0:
+        return {"ok": False, "error": f"block sizes differ: {y_part.numel()} vs {y_ref_part.numel()} reference rows" if differ
+                else "block sizes differ on another rank"}
     d = (y_part - y_ref_part).abs()
     max_abs = allmax(float(d.max()) if d.numel() else 0.0)
     bad = allsum(float((d > TOLERANCE * max(ymax_ref, 1e-300)).sum()) if d.numel() else 0.0)

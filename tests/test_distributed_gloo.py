@@ -207,6 +207,10 @@ def _worker(rank, world, port, name, cplx, num_rounds, out_dir, indexed=False):
             bad[:-1] = my_y[1:]  # rank 0's rows arrive one element late
         par = verify.parity_object(bad, my_x, y_ref, ymax, allsum=allsum, allmax=allmax, reference_kernel="oracle")
         assert not par["ok"] and par["rows_off"] > 0, (rank, par)
+        # a block of the wrong SIZE on one rank: every rank gets the verdict (and none is left waiting in a reduction)
+        short = my_y[:-1] if rank == world - 1 else my_y
+        par = verify.parity_object(short, my_x, y_ref, ymax, allsum=allsum, allmax=allmax, reference_kernel="oracle")
+        assert not par["ok"] and "block sizes differ" in par["error"], (rank, par)
     finally:
         dist.destroy_process_group()
 
