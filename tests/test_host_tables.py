@@ -67,6 +67,25 @@ def test_no_gpu_means_loud_failure():
         h @ np.zeros(126)
 
 
+def test_plain_c_caller_links_and_halts_without_a_gpu(tmp_path):
+    """examples/c_matvec.c needs nothing but include/*.h and libls_amd.so to build (no HIP, no torch on the caller's side); without a
+    device its first call, ls_chpl_init, halts like the reference's `halt` -- a message and a non-zero exit, no CPU fallback"""
+    import subprocess
+
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a HIP device is visible: tests/test_gpu_c_example.py runs the example")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "distributed-matvec_amd")
+    exe = str(tmp_path / "c_matvec")
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "c_matvec.c"),
+                           "-L", libdir, "-lls_amd", f"-Wl,-rpath,{libdir}", "-lm", "-o", exe])
+    out = subprocess.run([exe, "12"], capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0
+    assert "no HIP device" in out.stdout + out.stderr
+
+
 @pytest.mark.parametrize("name", sorted(golden()["models"].keys()))
 def test_basis_flags_and_groups_match_oracle(name):
     cfg = model_config(name)
