@@ -3,7 +3,7 @@
 #     gpurun --timeout T -- 'bash scripts/gpu_job.sh <tag> <step> [<step> ...]'
 # Steps write under gpurun_out/<tag>/ (merged back by gpurun); what is kept as evidence is copied into profiles/ by hand.
 #   smoke            __graft_entry__.smoke()
-#   tests            the whole -m gpu suite            tests:<expr> = pytest -k <expr>
+#   tests            the whole -m gpu suite            tests:<expr> = pytest -k <expr>      tests3 = the suite as three concurrent processes
 #   bench            default bench line                bench1 = --force-distributed --distributed-extras (one RCCL rank)
 #   bench_c128       chain_32 c128 line                bench1p = one RCCL rank, packets only
 #   packets[:v ..]   packet path A/B: sorted streams | pre-indexed + atomics | state-carrying + atomics, timing trees (scripts/tile_bench.py)
@@ -23,6 +23,12 @@ for step in "$@"; do
   case "$step" in
     smoke) timeout 300 python __graft_entry__.py smoke 2>&1 | tail -3 ;;
     tests) ( time timeout 1500 python -m pytest tests -m gpu -q --maxfail=15 --timeout 420 --timeout-method signal --durations=40 > "$OUT/pytest_gpu.log" 2>&1 ) 2>&1 | grep real; grep -A45 "slowest" "$OUT/pytest_gpu.log" | cut -c1-150 | head -48; tail -6 "$OUT/pytest_gpu.log" ;;
+    tests3) # the -m gpu suite as three concurrent pytest processes (partition by file; the ports of the multi-process tests are pid-derived): for a short slot
+      ( timeout 150 python -m pytest tests/test_gpu_parity_configs.py -m gpu -q --timeout 140 --timeout-method signal > "$OUT/pytest_A.log" 2>&1; echo "A rc=$? $(tail -1 "$OUT/pytest_A.log")" ) &
+      ( timeout 150 python -m pytest tests/test_gpu_matvec.py tests/test_gpu_loopback.py -m gpu -q --timeout 140 --timeout-method signal > "$OUT/pytest_B.log" 2>&1; echo "B rc=$? $(tail -1 "$OUT/pytest_B.log")" ) &
+      ( timeout 150 python -m pytest tests -m gpu -q --timeout 140 --timeout-method signal --ignore=tests/test_gpu_parity_configs.py --ignore=tests/test_gpu_matvec.py --ignore=tests/test_gpu_loopback.py > "$OUT/pytest_C.log" 2>&1; echo "C rc=$? $(tail -1 "$OUT/pytest_C.log")" ) &
+      wait
+      grep -h "FAILED\|ERROR" "$OUT"/pytest_[ABC].log | head -20 ;;
     hang:*) # a test suspected of hanging: per-test timeout with a dump of every thread's stack (faulthandler), then exit
       timeout 400 python -X faulthandler -m pytest tests -m gpu -q -x --timeout 150 --timeout-method thread -k "${step#hang:}" > "$OUT/pytest_hang.log" 2>&1; tail -120 "$OUT/pytest_hang.log" | cut -c1-220 ;;
     tests:*) ( time timeout 1200 python -m pytest tests -m gpu -q --maxfail=15 --timeout 420 --timeout-method signal -k "${step#tests:}" >> "$OUT/pytest_focus.log" 2>&1 ) 2>&1 | grep real; tail -15 "$OUT/pytest_focus.log" ;;
