@@ -86,3 +86,37 @@ def test_headline_entries_describe_this_build(key):
     model, dtype, kernel = key.split("/")
     r = _roof(model=model, dtype=dtype, kernel=kernel, ms=8.3 if dtype == "f64" else 14.7, w=8 if dtype == "f64" else 16)
     assert r["traffic"] == ent["traffic_bytes"] and r["frac_traffic"] <= 1.0
+
+
+@pytest.mark.parametrize("model", ["heisenberg_chain_32", "heisenberg_chain_36_symm", "heisenberg_chain_40_symm"])
+@pytest.mark.parametrize("P", [1, 2, 3, 4, 8])
+def test_scaling_model_of_the_multi_gpu_line_is_total_and_serialisable(model, P):
+    """`bench.py --gpus N` attaches scaling_model(...) to its JSON line at every N the driver's SCALE run uses: pure arithmetic that
+    has never executed with N > 1 on hardware -- it must not raise, must serialise, and must order its bounds"""
+    import json
+
+    m = bench.scaling_model(model, P, fused_ms=7.7 if not model.endswith("_symm") else 280.0)
+    if P < 2:
+        assert m is None
+        return
+    json.dumps(m)
+    lo, hi = m["predicted_ms_per_matvec"]
+    assert 0 < lo <= hi
+    s_lo, s_hi = m["predicted_speedup_over_one_gpu"]
+    assert 0 < s_lo <= s_hi
+    assert m["x_bytes_in_per_rank"] <= bench.MODEL_STATES[model] * 8 * (P - 1) / P
+    if model.endswith("_symm"):
+        c_lo, c_hi = m["predicted_ms_per_matvec_slot_cache"]
+        assert 0 < c_lo <= c_hi <= hi
+    assert bench.scaling_model(model, P, fused_ms=None) is None and bench.scaling_model("no_such_model", P, fused_ms=1.0) is None
+
+
+def test_default_cpu_sample_and_model_config_need_no_reference_tree():
+    """what the default run decides before it touches the GPU: the CPU-baseline sample size and the model input (from
+    tests/golden/models.json -- /root/reference does not exist on the GPU box)"""
+    assert bench.default_cpu_sample(20) == 20 and bench.default_cpu_sample(32) in (28, 32)
+    for name in ("heisenberg_chain_32", "heisenberg_chain_36_symm", "heisenberg_chain_40_symm", "heisenberg_chain_28"):
+        cfg, src = bench.model_config(name)
+        L, symm = bench.parse_model(name)
+        assert cfg["basis"]["number_spins"] == L and bool(cfg["basis"].get("symmetries")) == symm
+        assert "/root/reference" not in src
