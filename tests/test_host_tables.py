@@ -54,6 +54,20 @@ def test_every_header_stands_alone_in_c_and_cxx(header, tmp_path):
         assert r.returncode == 0, r.stderr
 
 
+def test_integration_guide_names_only_symbols_the_library_exports():
+    """INTEGRATION.md is the binding a maintainer would write: every ls_* / primme* function it CALLS must be an export of the library"""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md"), encoding="utf-8").read()
+    called = set(re.findall(r"\b((?:ls_amd_|ls_hs_|ls_chpl_)[a-z0-9_]+|primme(?:GlobalSumReal|BroadcastReal))\s*\(", text))
+    quoted = set(re.findall(r'dlsym\(h, "([a-z_0-9]+)"\)', text))
+    nm = subprocess.run(["nm", "-D", "--defined-only", os.path.join(root, "distributed-matvec_amd", "libls_amd.so")], capture_output=True, text=True).stdout
+    exported = {line.split()[-1] for line in nm.splitlines() if line.strip()}
+    assert len(called) >= 10 and quoted
+    assert not sorted((called | quoted) - exported), sorted((called | quoted) - exported)
+
+
 def test_no_gpu_means_loud_failure():
     L = _lib.load()
     if L.ls_amd_device_count() > 0:
