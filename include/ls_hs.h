@@ -96,6 +96,8 @@ void ls_hs_exit(void);  /* FFI.chpl:129 */
  *   hamming_weight < 0  : unrestricted;  spin_inversion in {0, +1, -1};
  *   permutations[g*number_sites + i] = p_i of generator g ("output bit i = input bit p_i");
  *   sectors[g] : character of generator g is exp(-2 pi i sector / order(g)).
+ * The group the generators span is closed here (at most 65536 elements: generators of a larger group -- usually a typo in one
+ * permutation -- are an error, reported in milliseconds); sectors that are no one-dimensional representation of it are an error.
  * Returns NULL on error (message via ls_amd_last_error()). */
 ls_hs_basis *ls_hs_create_spin_basis(int number_sites, int hamming_weight, int spin_inversion,
                                      int number_generators, int const *permutations,
