@@ -600,7 +600,8 @@ void ls_hs_destroy_basis(ls_hs_basis *b) {
     if (!b) return;
     struct ls_amd_basis_ext *e = (struct ls_amd_basis_ext *)reg_get(b);
     if (!e) return; /* not ours (or already gone): leave the struct alone */
-    if (--e->refcount > 0) return; /* operators built on this basis still share it */
+    /* (atomic: threads that clone / destroy operators of one basis -- the reference's tasks do -- must not lose a count) */
+    if (__atomic_sub_fetch(&e->refcount, 1, __ATOMIC_ACQ_REL) > 0) return; /* operators built on this basis still share it */
     basis_drop_device_caches(b);
     if (e->d_elems) lsk_free(e->d_elems);
     if (e->d_cosets) lsk_free(e->d_cosets);
@@ -1218,7 +1219,7 @@ ls_hs_operator *ls_hs_create_operator_from_terms(ls_hs_basis const *basis, int n
     ls_hs_operator *op = (ls_hs_operator *)calloc(1, sizeof(*op));
     reg_put(op, ext, REG_OPERATOR);
     op->basis = (ls_hs_basis *)basis;
-    ++be->refcount;
+    __atomic_add_fetch(&be->refcount, 1, __ATOMIC_RELAXED);
     op->diag_terms = make_nbt(ext->diag, NULL, ext->n_diag, basis->number_sites);
     op->off_diag_terms = make_nbt(ext->off, offx, ext->n_off, basis->number_sites);
     free(offx);
@@ -1277,7 +1278,7 @@ int ls_amd_adopt_operator(ls_hs_operator const *op) {
     if (!ext) return -1;
     ext->adopted = 1;
     reg_put(op, ext, REG_OPERATOR);
-    ++BEXT(op->basis)->refcount;
+    __atomic_add_fetch(&BEXT(op->basis)->refcount, 1, __ATOMIC_RELAXED);
     return 0;
 }
 /* forget an adopted basis / operator (device tables are released; the foreign struct is not touched) */

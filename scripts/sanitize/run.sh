@@ -28,3 +28,11 @@ for f in "$W"/yaml_*.log "$W"/terms_*.log; do echo "$(basename "$f"): $(tail -n 
 echo "== LeakSanitizer: load -> clone -> destroy of the reference inputs"
 gcc -g -fsanitize=address -Iinclude scripts/sanitize/lifecycle_leaks.c -o "$W/leaks" "$W/libls_amd_asan.so" -Wl,-rpath,"$W" || exit 1
 ASAN_OPTIONS=detect_leaks=1 "$W/leaks" /root/reference/data/*.yaml > "$W/leaks.log" 2>&1; echo "rc=$? ($(grep -c 'leak of' "$W/leaks.log") leak reports, $(ls /root/reference/data/*.yaml | wc -l) inputs)"
+echo "== ThreadSanitizer: 8 threads, object lifecycle (own objects; clones of ONE operator / basis)"
+for f in host dist yaml; do gcc -O1 -g -std=gnu11 -fPIC -fsanitize=thread -c $C/$f.c -o "$W/t_$f.o" || exit 1; done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$W/libls_amd_tsan.so" "$W"/t_{host,dist,yaml}.o $C/{kernels,comm,util,orth,stage}.o -lm -ldl -lpthread -L"$GCCLIB" -ltsan || exit 1
+for t in threads_own_objects threads_shared_basis; do
+  gcc -g -fsanitize=thread -Iinclude scripts/sanitize/$t.c -o "$W/$t" "$W/libls_amd_tsan.so" -Wl,-rpath,"$W" -lpthread || exit 1
+  TSAN_OPTIONS=halt_on_error=0 "$W/$t" /root/reference/data/heisenberg_kagome_12_symm.yaml /root/reference/data/heisenberg_chain_1*.yaml /root/reference/data/heisenberg_square_4x4.yaml > "$W/$t.log" 2>&1
+  echo "$t: rc=$? ($(grep -c 'WARNING: ThreadSanitizer' "$W/$t.log") reports)"
+done
