@@ -168,8 +168,7 @@ static uint64_t g_binom[64 * LSK_BINOM_K];
 static int g_binom_ready = 0;
 static uint64_t *g_d_binom = NULL;
 
-static void binom_init(void) {
-    if (g_binom_ready) return;
+static void binom_fill(void) {
     for (int n = 0; n < 64; ++n)
         for (int k = 0; k < LSK_BINOM_K; ++k) {
             uint64_t v;
@@ -180,6 +179,8 @@ static void binom_init(void) {
         }
     g_binom_ready = 1;
 }
+static pthread_once_t g_binom_once = PTHREAD_ONCE_INIT;
+static void binom_init(void) { pthread_once(&g_binom_once, binom_fill); } /* (first use may come from several host threads at once) */
 static uint64_t binom(int n, int k) {
     binom_init();
     if (k < 0 || n < 0 || k > n) return 0;

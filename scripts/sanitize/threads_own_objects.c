@@ -1,5 +1,6 @@
 #include <pthread.h>
 #include <stdio.h>
+#include <stdint.h>
 #include <stdlib.h>
 #include "ls_hs.h"
 #include "ls_amd.h"
@@ -12,6 +13,8 @@ static void *worker(void *arg) {
         ls_hs_operator *o = c->hamiltonian ? ls_hs_clone_operator(c->hamiltonian) : NULL;
         ls_hs_basis *b = ls_hs_clone_basis(c->basis);
         (void)ls_hs_basis_requires_projection(b);
+        (void)ls_hs_max_state_estimate(b); (void)ls_hs_min_state_estimate(b);
+        (void)ls_hs_fixed_hamming_state_to_index(0x0f0fULL + (uint64_t)id); (void)ls_hs_fixed_hamming_index_to_state(it + 1, 6);
         if (o) { (void)ls_hs_operator_max_number_off_diag(o); (void)ls_hs_operator_is_hermitian(o); }
         ls_hs_destroy_yaml_config(c);
         if (o) ls_hs_destroy_operator(o);
