@@ -95,3 +95,71 @@ def test_c_expression_compiler_equals_kronecker_products(seed):
             assert all(x == 0 for _v, _m, _r, x, _s in diag) and all(x != 0 for _v, _m, _r, x, _s in off), text
         finally:
             lib.ls_hs_destroy_yaml_config(conf)
+
+
+def _conserving_term(rs, L):
+    """like random_term, but the product conserves the number of up spins: as many raising as lowering factors, any number of z"""
+    arity = int(rs.randint(2, 5))
+    pairs = int(rs.randint(1, 3))
+    kinds = ["+"] * pairs + ["-"] * pairs + ["z"] * int(rs.randint(0, 3))
+    rs.shuffle(kinds)
+    local = [int(rs.randint(arity)) for _ in kinds]
+    for k in range(arity):  # every local index at least once
+        if k not in local:
+            kinds.append("z")
+            local.append(k)
+    scalar = complex(float(rs.choice([1.0, -0.5, 2.0])), 0.0) * (1j if rs.rand() < 0.3 else 1.0)
+    text = (f"{scalar.imag}j" if scalar.real == 0 else repr(scalar.real)) + " × " + " ".join(
+        ("S" if s else "σ") + KINDS[k][0] + SUB[i] for k, i, s in zip(kinds, local, [rs.rand() < 0.3 for _ in kinds]))
+    # rebuild the factors from the text just written, so that the S / sigma choice is the one in the text
+    factors = []
+    for piece in text.split(" × ")[1].split(" "):
+        mat = KINDS[{v[0]: k for k, v in KINDS.items()}[piece[1]]][1] * (0.5 if piece[0] == "S" else 1.0)
+        factors.append((SUB.index(piece[2]), mat))
+    tuples = [[int(s) for s in rs.choice(L, size=arity, replace=False)] for _ in range(int(rs.randint(1, 4)))]
+    dim = 1 << L
+    H = np.zeros((dim, dim), dtype=complex)
+    for sites in tuples:
+        prod = np.eye(dim, dtype=complex)
+        for idx, mat in factors:
+            full = np.array([[1.0]], dtype=complex)
+            for q in range(L - 1, -1, -1):
+                full = np.kron(full, mat if q == sites[idx] else np.eye(2))
+            prod = prod @ full
+        H += scalar * prod
+    return text, tuples, H
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_oracle_matvec_equals_kronecker_products_on_random_operators(seed):
+    """the CHECKER on operators the reference's inputs never contain (non-Hermitian, complex, non-exchange, up to four sites per
+    term): oracle/ls_oracle.c + oracle/model.py (a third expression compiler) against the same explicit construction, on the full
+    space and -- for operators that conserve the number of up spins -- inside a fixed-weight sector (combinadic ranks, DMV:73-127)"""
+    from oracle import c_oracle as CO
+    from oracle import model as M
+
+    rs = np.random.RandomState(2000 + seed)
+    L = int(rs.randint(4, 8))
+    for _ in range(12):
+        sector = rs.rand() < 0.5
+        terms = [(_conserving_term if sector else random_term)(rs, L) for _ in range(int(rs.randint(1, 4)))]
+        H = sum(t[2] for t in terms)
+        hw = int(rs.randint(1, L)) if sector else None
+        cfg = {"basis": {"number_spins": L, "hamming_weight": hw},
+               "hamiltonian": {"name": "random", "terms": [{"expression": e, "sites": t} for e, t, _ in terms]}}
+        o = CO.COracle(M.model_from_config(cfg))
+        reps = o.enumerate()
+        states = np.arange(1 << L, dtype=np.uint64)
+        want_reps = states if hw is None else states[np.bitwise_count(states) == hw]
+        assert np.array_equal(reps, want_reps)
+        idx = reps.astype(np.int64)
+        Hs = H[np.ix_(idx, idx)]
+        if hw is not None:  # the operator conserves the weight: nothing leaves the sector
+            mask = np.ones(1 << L, dtype=bool)
+            mask[idx] = False
+            assert np.abs(H[np.ix_(mask, ~mask)]).max(initial=0.0) < 1e-14
+        x = (rs.rand(len(reps)) - 0.5) + 1j * (rs.rand(len(reps)) - 0.5)
+        np.testing.assert_allclose(o.local_matvec(reps, x), Hs @ x, rtol=0, atol=1e-12, err_msg=str(cfg))
+        if np.abs(Hs.imag).max() < 1e-14:  # a real operator also takes real vectors (the f64 entry points)
+            xr = rs.rand(len(reps)) - 0.5
+            np.testing.assert_allclose(o.local_matvec(reps, xr), Hs.real @ xr, rtol=0, atol=1e-12, err_msg=str(cfg))
