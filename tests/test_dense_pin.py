@@ -198,3 +198,95 @@ def test_symmetric_chain_sectors_against_kronecker_construction():
         x = np.random.RandomState(L).rand(len(reps)) - 0.5
         want = H.real @ x
         assert np.abs(o.local_matvec(want_reps, x) - want).max() <= 1e-12 * max(1.0, np.abs(want).max())
+
+
+def _dense_from_text(expr, tuples, L):
+    """explicit matrix of a term written by the generators of tests/test_expression_compiler.py (scalars, sigma / S, x y z + -)"""
+    import test_expression_compiler as T
+
+    scalar, factors = 1.0 + 0j, []
+    kind_of = {v[0]: k for k, v in T.KINDS.items()}
+    for piece in expr.split(" "):
+        if piece in ("", "×"):
+            continue
+        if piece[0] in "σS":
+            factors.append((T.SUB.index(piece[2]), T.KINDS[kind_of[piece[1]]][1] * (0.5 if piece[0] == "S" else 1.0)))
+        elif piece.endswith("j"):
+            scalar *= 1j * float(piece[:-1])
+        else:
+            scalar *= float(piece)
+    dim = 1 << L
+    H = np.zeros((dim, dim), dtype=complex)
+    for sites in tuples:
+        prod = np.eye(dim, dtype=complex)
+        for idx, mat in factors:
+            full = np.array([[1.0]], dtype=complex)
+            for q in range(L - 1, -1, -1):
+                full = np.kron(full, mat if q == sites[idx] else np.eye(2))
+            prod = prod @ full
+        H += scalar * prod
+    return H
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_translation_invariant_operators_in_momentum_sectors(seed):
+    """COMPLEX characters and operators the reference's files do not contain: a random term (non-Hermitian, complex, up to four
+    sites) summed over all its translates on a ring commutes with the translation group; in every momentum sector k the oracle's
+    representatives and its y = H x, element by element, must be those of the explicit construction
+        U_g |s>: output bit i = input bit p_i (include/ls_hs.h),   P = 1/|G| sum_g conj(chi(g)) U_g,   chi(T) = exp(-2 pi i k / L),
+    basis vectors P e_r / |P e_r| over the orbit minima r -- the n(r') / n(r) factors and the characters of
+    BatchedOperator.chpl:163-213 all enter y.  (The files of the reference only have real characters, where the direction of the
+    permutation does not matter; here it does, and this fixes the one the oracle -- hence the HIP path held against it -- uses.)"""
+    import test_expression_compiler as T
+    from oracle import c_oracle as CO
+    from oracle import model as M
+
+    rs = np.random.RandomState(3000 + seed)
+    L = int(rs.randint(5, 9))
+    complex_sectors = 0
+    for _ in range(4):
+        conserving = rs.rand() < 0.6
+        terms = []
+        for _t in range(int(rs.randint(1, 3))):
+            expr, tuples, _ = (T._conserving_term if conserving else T.random_term)(rs, L)
+            terms.append((expr, [[(s + t) % L for s in tuples[0]] for t in range(L)]))
+        H = sum(_dense_from_text(e, t, L) for e, t in terms)
+        hw = int(rs.randint(1, L)) if conserving else None
+        k = int(rs.randint(L))
+        perm = [(i + 1) % L for i in range(L)]
+        cfg = {"basis": {"number_spins": L, "hamming_weight": hw, "symmetries": [{"permutation": perm, "sector": k}]},
+               "hamiltonian": {"name": "random", "terms": [{"expression": e, "sites": t} for e, t in terms]}}
+        o = CO.COracle(M.model_from_config(cfg))
+        reps = o.enumerate()
+        states = np.arange(1 << L, dtype=np.uint64)
+        sector = states if hw is None else states[np.bitwise_count(states) == hw]
+        pos = {int(s): j for j, s in enumerate(sector)}
+        n = len(sector)
+        P = np.zeros((n, n), dtype=complex)
+        images, cur = [], list(range(L))
+        for power in range(L):  # g = T^power: p = perm composed `power` times; output bit i = input bit p_i
+            img = np.zeros_like(sector)
+            for i in range(L):
+                img |= ((sector >> np.uint64(cur[i])) & np.uint64(1)) << np.uint64(i)
+            images.append(img)
+            chi = np.exp(-2j * np.pi * k * power / L)
+            P[np.array([pos[int(v)] for v in img]), np.arange(n)] += np.conj(chi)
+            cur = [perm[c] for c in cur]
+        P /= L
+        orbit_min = np.min(np.stack(images), axis=0)
+        want_reps, cols = [], []
+        for j in np.flatnonzero(orbit_min == sector):
+            v = P[:, j]
+            if np.linalg.norm(v) > 1e-10:
+                want_reps.append(sector[j])
+                cols.append(v / np.linalg.norm(v))
+        assert np.array_equal(reps, np.array(want_reps, dtype=np.uint64)), cfg
+        if not want_reps:
+            continue
+        U = np.stack(cols, axis=1)
+        idx = sector.astype(np.int64)
+        Hp = U.conj().T @ (H[np.ix_(idx, idx)] @ U)
+        x = (rs.rand(len(reps)) - 0.5) + 1j * (rs.rand(len(reps)) - 0.5)
+        np.testing.assert_allclose(o.local_matvec(reps, x), Hp @ x, rtol=0, atol=1e-10, err_msg=str(cfg))
+        complex_sectors += (2 * k) % L != 0
+    assert complex_sectors >= 1 or seed not in (0, 1, 2)  # (most seeds meet at least one complex character)
