@@ -290,3 +290,66 @@ def test_random_translation_invariant_operators_in_momentum_sectors(seed):
         np.testing.assert_allclose(o.local_matvec(reps, x), Hp @ x, rtol=0, atol=1e-10, err_msg=str(cfg))
         complex_sectors += (2 * k) % L != 0
     assert complex_sectors >= 1 or seed not in (0, 1, 2)  # (most seeds meet at least one complex character)
+
+
+def _spin_flipped(expr):
+    """X expr X for X = prod_i sigma^x_i, as text: z -> -z, y -> -y, + <-> -"""
+    import test_expression_compiler as T
+
+    out, sign = [], 1
+    for piece in expr.split(" "):
+        if piece and piece[0] in "σS":
+            k = piece[1]
+            if k in (T.KINDS["z"][0], T.KINDS["y"][0]):
+                sign = -sign
+            if k == T.KINDS["+"][0]:
+                piece = piece[0] + T.KINDS["-"][0] + piece[2:]
+            elif k == T.KINDS["-"][0]:
+                piece = piece[0] + T.KINDS["+"][0] + piece[2:]
+        out.append(piece)
+    return ("-1.0 × " if sign < 0 else "1.0 × ") + " ".join(out)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_flip_symmetric_operators_in_inversion_sectors(seed):
+    """the spin-inversion branch of computeOffDiag (BatchedOperator.chpl:124-161) on random operators T + X T X (X = the global
+    spin flip), sectors +1 and -1, with and without a fixed weight: representatives (the smaller of s and its flip; -1 sectors drop
+    nothing here since s != flip(s)) and y element by element against P = (1 +- X) / 2"""
+    import test_expression_compiler as T
+    from oracle import c_oracle as CO
+    from oracle import model as M
+
+    rs = np.random.RandomState(4000 + seed)
+    L = int(rs.choice([4, 6, 8]))
+    for _ in range(4):
+        conserving = rs.rand() < 0.5
+        terms = []
+        for _t in range(int(rs.randint(1, 3))):
+            expr, tuples, _ = (T._conserving_term if conserving else T.random_term)(rs, L)
+            terms += [(expr, tuples), (_spin_flipped(expr), tuples)]
+        H = sum(_dense_from_text(e, t, L) for e, t in terms)
+        hw = L // 2 if conserving else None
+        inv = int(rs.choice([1, -1]))
+        cfg = {"basis": {"number_spins": L, "hamming_weight": hw, "spin_inversion": inv},
+               "hamiltonian": {"name": "random", "terms": [{"expression": e, "sites": t} for e, t in terms]}}
+        o = CO.COracle(M.model_from_config(cfg))
+        reps = o.enumerate()
+        states = np.arange(1 << L, dtype=np.uint64)
+        sector = states if hw is None else states[np.bitwise_count(states) == hw]
+        pos = {int(s): j for j, s in enumerate(sector)}
+        n = len(sector)
+        img = sector ^ np.uint64((1 << L) - 1)
+        P = np.eye(n, dtype=complex) * 0.5
+        P[np.array([pos[int(v)] for v in img]), np.arange(n)] += 0.5 * inv
+        want, cols = [], []
+        for j in np.flatnonzero(np.minimum(sector, img) == sector):
+            v = P[:, j]
+            if np.linalg.norm(v) > 1e-10:
+                want.append(sector[j])
+                cols.append(v / np.linalg.norm(v))
+        assert np.array_equal(reps, np.array(want, dtype=np.uint64)), cfg
+        U = np.stack(cols, axis=1)
+        idx = sector.astype(np.int64)
+        Hp = U.conj().T @ (H[np.ix_(idx, idx)] @ U)
+        x = (rs.rand(len(reps)) - 0.5) + 1j * (rs.rand(len(reps)) - 0.5)
+        np.testing.assert_allclose(o.local_matvec(reps, x), Hp @ x, rtol=0, atol=1e-10, err_msg=str(cfg))
