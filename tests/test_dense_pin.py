@@ -353,3 +353,63 @@ def test_random_flip_symmetric_operators_in_inversion_sectors(seed):
         Hp = U.conj().T @ (H[np.ix_(idx, idx)] @ U)
         x = (rs.rand(len(reps)) - 0.5) + 1j * (rs.rand(len(reps)) - 0.5)
         np.testing.assert_allclose(o.local_matvec(reps, x), Hp @ x, rtol=0, atol=1e-10, err_msg=str(cfg))
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_operators_in_momentum_and_inversion_sectors(seed):
+    """both together -- the group of the BASELINE configs' kind (permutations x global flip) with a COMPLEX momentum character:
+    random operators summed over their translates and their spin-flipped images, sector (k, +-1), against
+    P = 1/(2L) sum_{g, f} conj(chi_k(g) inv^f) X^f U_g"""
+    import test_expression_compiler as T
+    from oracle import c_oracle as CO
+    from oracle import model as M
+
+    rs = np.random.RandomState(5000 + seed)
+    L = int(rs.choice([4, 6, 8]))
+    for _ in range(3):
+        conserving = rs.rand() < 0.5
+        terms = []
+        for _t in range(int(rs.randint(1, 3))):
+            expr, tuples, _ = (T._conserving_term if conserving else T.random_term)(rs, L)
+            translates = [[(s + t) % L for s in tuples[0]] for t in range(L)]
+            terms += [(expr, translates), (_spin_flipped(expr), translates)]
+        H = sum(_dense_from_text(e, t, L) for e, t in terms)
+        hw = L // 2 if conserving else None
+        inv, k = int(rs.choice([1, -1])), int(rs.randint(L))
+        perm = [(i + 1) % L for i in range(L)]
+        cfg = {"basis": {"number_spins": L, "hamming_weight": hw, "spin_inversion": inv, "symmetries": [{"permutation": perm, "sector": k}]},
+               "hamiltonian": {"name": "random", "terms": [{"expression": e, "sites": t} for e, t in terms]}}
+        o = CO.COracle(M.model_from_config(cfg))
+        reps = o.enumerate()
+        states = np.arange(1 << L, dtype=np.uint64)
+        sector = states if hw is None else states[np.bitwise_count(states) == hw]
+        pos = {int(s): j for j, s in enumerate(sector)}
+        n = len(sector)
+        P = np.zeros((n, n), dtype=complex)
+        images, cur = [], list(range(L))
+        for power in range(L):
+            img = np.zeros_like(sector)
+            for i in range(L):  # output bit i = input bit p_i
+                img |= ((sector >> np.uint64(cur[i])) & np.uint64(1)) << np.uint64(i)
+            chi = np.exp(-2j * np.pi * k * power / L)
+            for flip, fc in ((0, 1.0), (1, float(inv))):
+                im2 = img ^ np.uint64((1 << L) - 1) if flip else img
+                images.append(im2)
+                P[np.array([pos[int(v)] for v in im2]), np.arange(n)] += np.conj(chi * fc)
+            cur = [perm[c] for c in cur]
+        P /= 2 * L
+        orbit_min = np.min(np.stack(images), axis=0)
+        want, cols = [], []
+        for j in np.flatnonzero(orbit_min == sector):
+            v = P[:, j]
+            if np.linalg.norm(v) > 1e-10:
+                want.append(sector[j])
+                cols.append(v / np.linalg.norm(v))
+        assert np.array_equal(reps, np.array(want, dtype=np.uint64)), cfg
+        if not want:
+            continue
+        U = np.stack(cols, axis=1)
+        idx = sector.astype(np.int64)
+        Hp = U.conj().T @ (H[np.ix_(idx, idx)] @ U)
+        x = (rs.rand(len(reps)) - 0.5) + 1j * (rs.rand(len(reps)) - 0.5)
+        np.testing.assert_allclose(o.local_matvec(reps, x), Hp @ x, rtol=0, atol=1e-10, err_msg=str(cfg))
