@@ -216,16 +216,22 @@ def _dense_from_text(expr, tuples, L):
         else:
             scalar *= float(piece)
     dim = 1 << L
-    H = np.zeros((dim, dim), dtype=complex)
+    H = sp.csr_matrix((dim, dim), dtype=complex)
     for sites in tuples:
-        prod = np.eye(dim, dtype=complex)
+        prod = sp.identity(dim, dtype=complex, format="csr")
         for idx, mat in factors:
-            full = np.array([[1.0]], dtype=complex)
-            for q in range(L - 1, -1, -1):
-                full = np.kron(full, mat if q == sites[idx] else np.eye(2))
-            prod = prod @ full
-        H += scalar * prod
-    return H
+            key = (L, sites[idx], mat.tobytes())
+            if key not in _SITE_CACHE:
+                full = sp.identity(1, dtype=complex, format="csr")
+                for q in range(L - 1, -1, -1):
+                    full = sp.kron(full, sp.csr_matrix(mat) if q == sites[idx] else sp.identity(2, dtype=complex, format="csr"), format="csr")
+                _SITE_CACHE[key] = full
+            prod = prod @ _SITE_CACHE[key]
+        H = H + scalar * prod
+    return H.toarray()
+
+
+_SITE_CACHE = {}
 
 
 @pytest.mark.parametrize("seed", range(10))
