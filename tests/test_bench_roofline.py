@@ -120,3 +120,25 @@ def test_default_cpu_sample_and_model_config_need_no_reference_tree():
         L, symm = bench.parse_model(name)
         assert cfg["basis"]["number_spins"] == L and bool(cfg["basis"].get("symmetries")) == symm
         assert "/root/reference" not in src
+
+
+def test_cpu_baseline_legs_on_small_samples():
+    """the `cpu_baseline` objects of the default run (the oracle timed on the host cores; the only place outside tests/ and smoke()
+    that may call oracle/): both legs on samples that take a second -- they must produce a positive rate, say what the sample was,
+    and label a scaled figure as scaled"""
+    from oracle import c_oracle as CO
+    from oracle import model as M
+
+    s = bench.cpu_baseline(18, repeats=2)
+    assert s["seconds_per_matvec"] > 0 and s["n"] == 48620 and s["nnz"] == bench.chain_nnz(18, 48620) and s["timed_matvecs"] == 2
+    name = "heisenberg_chain_24_symm"
+    o = CO.COracle(M.model_from_config(bench.model_config(name)[0]))
+    reps = o.enumerate()
+    nnz = bench.chain_nnz(24, len(reps))
+    measured = bench.cpu_baseline_projected(name, reps, nnz, budget_s=60.0)
+    assert measured["value"] > 0 and measured["scaled"] is False and "itself" in measured["sample"] and measured["kind"] == "port"
+    scaled = bench.cpu_baseline_projected(name, None, nnz, probe=measured["probe"])
+    assert scaled["scaled"] is True and scaled["sample"].startswith("SCALED") and scaled["value"] > 0
+    for obj in (measured, scaled):
+        obj.pop("probe", None)
+        json.dumps(obj)
