@@ -277,6 +277,24 @@ def test_host_scalars():
     for i in range(300):
         s = int(lib.ls_hs_fixed_hamming_index_to_state(i, 6))
         assert bin(s).count("1") == 6 and int(lib.ls_hs_fixed_hamming_state_to_index(C.c_uint64(s))) == i
+    # ... and over the whole range the path uses: up to 64 sites, weights up to 33 (ls_hs_fixed_hamming_state_to_index, FFI.chpl:165)
+    import math
+    import random
+
+    rnd = random.Random(5)
+    for _ in range(3000):
+        n = rnd.randint(1, 64)
+        k = rnd.randint(1, min(n, 33))
+        s = sum(1 << b for b in rnd.sample(range(n), k))
+        want, t, j = 0, s, 1
+        while t:
+            want += math.comb((t & -t).bit_length() - 1, j)
+            j += 1
+            t &= t - 1
+        if want >= 2 ** 63:
+            continue
+        assert int(lib.ls_hs_fixed_hamming_state_to_index(C.c_uint64(s))) == want
+        assert int(lib.ls_hs_fixed_hamming_index_to_state(want, k)) & (2 ** 64 - 1) == s
     basis = D.loadConfigFromDict(model_config("heisenberg_chain_10"))
     assert basis.minStateEstimate() == 31 and basis.maxStateEstimate() == 496  # Appendix B
 
