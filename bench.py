@@ -397,6 +397,34 @@ def verify_operator(op, x, y, ref, allsum, allmax, inject_fault=False):
     return out
 
 
+def one_gpu_parity(D, torch, h, reps, tdtype, x, y, plan, projected, make_for_fault=None):
+    """(parity, parity_after_fault) of a one-GPU leg: one more matvec of the measured plan on the benchmark vector, compared element
+    by element with every alternative kernel (verify.alternative_kernels).  make_for_fault (--inject-fault): a second plan of the
+    same kind whose row kernel is made to skip one row (ls_amd_test_corrupt_plan) -- the same check must then fail."""
+    from distributed_matvec_amd import verify
+
+    t0 = time.perf_counter()
+    refs = verify.single_gpu_references(h, reps, tdtype, x, projected)
+    y.zero_()
+    plan.matvec([x], [y], check=True)
+    par = verify.single_gpu_parity(y, x, refs, plan.kernel)
+    par["seconds"] = time.perf_counter() - t0
+    fault = None
+    if make_for_fault is not None:
+        p2 = make_for_fault()
+        injected = p2.inject_fault()
+        y.zero_()
+        p2.matvec([x], [y], check=True)
+        fault = verify.single_gpu_parity(y, x, refs, p2.kernel)
+        fault["fault_injected_on_ranks"] = int(injected)
+        p2.destroy()
+        y.zero_()
+        plan.matvec([x], [y], check=True)
+    del refs
+    torch.cuda.empty_cache()
+    return par, fault
+
+
 def projected_extra(D, torch, dist, name, rank, world, time_steps, allsum, steps=3, warmup=2, distributed=False, allmax=None,
                     inject_fault=False, cpu=None):
     """one of the symmetry-projected BASELINE chains, measured inside the default run (see main)"""
@@ -432,6 +460,10 @@ def projected_extra(D, torch, dist, name, rank, world, time_steps, allsum, steps
             # what bounds this kernel: random 64-byte requests (index-table probes, partner values), not bytes
             out["requests_64B_per_s"] = ent["traffic_bytes"] / 64.0 / (kms * 1e-3)
         out["pmc_note"] = note
+        make2 = (lambda: D.MatvecPlan(h, [reps], torch.float64)) if inject_fault else None
+        out["parity"], fault = one_gpu_parity(D, torch, h, reps, torch.float64, x[0], y[0], pl, True, make2)
+        if fault is not None:
+            out["parity_after_fault"] = fault
         out["slot_cache"] = slot_cache_leg(pl, lambda: pl.matvec(x, y, check=False), pl.check, pl.kernel_times_ms, time_steps, steps)
         pl.destroy()
         if cpu is not None:
@@ -735,8 +767,9 @@ def main():
     ap.add_argument("--force-distributed", action="store_true",
                     help="run the N > 1 code path (process group, exchange) even with one rank (test hook)")
     ap.add_argument("--inject-fault", action="store_true",
-                    help="test hook, N > 1 code path: after the timed steps misplace one segment of every exchange strategy's layout "
-                         "(ls_amd_test_corrupt_*); the parity check must catch it and the run must exit non-zero")
+                    help="test hook: after the timed steps misplace one segment of every exchange strategy's layout (N > 1 code path, "
+                         "ls_amd_test_corrupt_dist / _repl) or make the row kernel skip one row (N = 1, ls_amd_test_corrupt_plan); the parity "
+                         "check must catch it and the run must exit non-zero")
     ap.add_argument("--cpu-sample", type=int, default=0,
                     help="chain length of the CPU-baseline sample (0 = the workload itself when the host has >= 64 cores and "
                          "the memory for it, else 28)")
@@ -877,6 +910,10 @@ def main():
         exchange = "none"
         setup_t0 = time.perf_counter()
         dt, kernel_ms, launches_per_step, kernel_name, exchange_bytes, plan, op_obj = measure(make, args.steps, args.warmup, "main")
+        # the y that was timed, checked in the same run (the reference's single-locale check,
+        # test/TestMatrixVectorProduct.chpl:25-39, with the stored /y replaced by kernels that share no device code with the
+        # measured one): outside the timed region, < 1 s
+        parity_main, parity_main_fault = one_gpu_parity(D, torch, h, my_reps, tdtype, x, y, plan, bool(symm), make if args.inject_fault else None)
     else:
         from distributed_matvec_amd.distributed import RcclDistributedOperator, RcclReplicatedOperator
 
@@ -1047,6 +1084,8 @@ def main():
                     "matvecs_per_s": steps2 / t2,
                     "whole_matvec_GBps": (n_total * (8 + 2 * w2) + nnz * 2 * w2) / (t2 / steps2) / 1e9,
                 }
+                if label != args.dtype:  # the other dtype (c128 on the default run: the north star's): its own parity object
+                    extra[f"{label}/{p2.kernel}"]["parity"], _f = one_gpu_parity(D, torch, h, my_reps, td, x2, y2, p2, False)
                 p2.destroy()
                 del x2, y2
             except D.LsAmdError as e:  # e.g. pull on a non-Hermitian operator
@@ -1120,13 +1159,19 @@ def main():
                 checks[f"extra.{k}.slot_cache"] = v["slot_cache"]["parity"]
             if "parity_after_fault" in v:
                 faults[f"extra.{k}"] = v["parity_after_fault"]
+    if not distributed:  # N = 1: the headline's own object, next to the c128 leg's and the projected extras'
+        checks["main"] = parity_main
+        if parity_main_fault is not None:
+            faults["main"] = parity_main_fault
     parity_failed = sorted(k for k, v in checks.items() if not v.get("ok"))
     fault_missed = sorted(k for k, v in faults.items() if v.get("ok") and v.get("fault_injected_on_ranks", 0) > 0)
     parity_summary = None
-    if distributed:
+    if distributed or checks:
         parity_summary = {"checked": sorted(checks), "failed": parity_failed,
                           "max_rel_err": max([v.get("max_rel_err", float("inf")) for v in checks.values()] or [None]),
                           "ok": not parity_failed and bool(checks)}
+        if not distributed:
+            parity_summary["main"] = parity_main
         if args.inject_fault:
             parity_summary["fault_injection"] = {"detected": sorted(k for k, v in faults.items() if not v.get("ok")), "missed": fault_missed,
                                                  "nothing_to_corrupt": sorted(k for k, v in faults.items() if v.get("fault_injected_on_ranks", 0) == 0)}
@@ -1165,7 +1210,7 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    if distributed and (parity_failed or not checks or (args.inject_fault and (fault_missed or any(not v.get("ok") for v in faults.values())))):
+    if (parity_failed or not checks or (args.inject_fault and (fault_missed or any(not v.get("ok") for v in faults.values())))):
         # wrong y on some rank (or a deliberately corrupted exchange, which must end the same way): the number above is not a result
         print(f"bench.py: PARITY FAILURE: {parity_failed or 'injected fault'}", file=sys.stderr, flush=True)
         sys.exit(3)

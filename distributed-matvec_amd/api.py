@@ -437,6 +437,10 @@ class MatvecPlan:
     def check(self):
         _lib.check(_lib.load().ls_amd_plan_check(self.h, _stream_ptr()))
 
+    def inject_fault(self) -> bool:
+        """test hook (ls_amd_test_corrupt_plan): the row kernel skips one row from now on; False when the plan has no tile map"""
+        return bool(_lib.load().ls_amd_test_corrupt_plan(self.h))
+
     def enable_timing(self, max_samples: int):
         _lib.check(_lib.load().ls_amd_plan_enable_timing(self.h, max_samples))
 

@@ -25,6 +25,7 @@ void ls_amd_internal_clear_error(void);
 int ls_amd_internal_stage_begin(ls_amd_plan *pl, int stage, void *stream); /* host.c: stage timers (kDisplayTimings) */
 void ls_amd_internal_stage_end(ls_amd_plan *pl, int slot, void *stream);
 void ls_amd_internal_count_matvec(ls_amd_plan *pl);
+int ls_amd_internal_check_y(ls_amd_plan *pl, void const *y);
 void ls_amd_internal_set_no_packet_index(int v); /* host.c */
 /* host.c: packets in sorted streams (kernels.hip, k_tile_st / k_window) for a plan that owns one partition */
 void ls_amd_internal_set_want_streams(int v);
@@ -306,6 +307,7 @@ static int dist_create_impl(ls_amd_dist **out, ls_amd_comm *cm, ls_hs_operator c
                             int *used_streams) {
     *out = NULL;
     *used_streams = 0;
+    int rounds_for_streams = 0;
     if (!cm) return ls_amd_internal_error("ls_amd_dist_create: no communicator");
     int const P = ls_amd_comm_size(cm), me = ls_amd_comm_rank(cm);
     void *ds = NULL;
@@ -336,8 +338,14 @@ static int dist_create_impl(ls_amd_dist **out, ls_amd_comm *cm, ls_hs_operator c
             int64_t const cap = ((int64_t)1 << 32) / ng;
             if (big > cap) big = cap;
             int const need = (int)((mx + big - 1) / big);
+            int const dflt = num_rounds;
             if (num_rounds > 3) num_rounds = 3;
             if (num_rounds < need) num_rounds = need;
+            /* (the same on every rank.  If the layout agreement below then falls back to the atomic consumers -- no room for the
+             * directory on some rank, a failed self-check -- these few, very large rounds are the wrong size for them: 16-byte packets
+             * against a 12-byte estimate, buffers several times the default's.  A failure of such a set-up is retried with the default
+             * rows per round even though no rank wrote streams: ADVICE r5) */
+            rounds_for_streams = num_rounds != dflt;
         }
     }
     ls_amd_dist *d = (ls_amd_dist *)calloc(1, sizeof(*d));
@@ -370,7 +378,7 @@ static int dist_create_impl(ls_amd_dist **out, ls_amd_comm *cm, ls_hs_operator c
         int64_t any = d->streams != 0;
         if (cm->d_status && lsk_h2d(cm->d_status, &any, sizeof(any)) == 0 && lsk_comm_allreduce(cm->c, cm->d_status, 1, 2, 1, stream) == 0 &&
             lsk_sync(stream) == 0 && lsk_d2h(&any, cm->d_status, sizeof(any)) == 0)
-            *used_streams = any != 0;
+            *used_streams = any != 0 || rounds_for_streams;
         else if (rc == 0) rc = ls_amd_internal_error("packet-layout agreement failed: %s", lsk_comm_last_error());
     }
     if (rc == 0 && ls_amd_plan_num_rounds(d->plan) != num_rounds) rc = ls_amd_internal_error("internal error: rounds disagree");
@@ -460,6 +468,7 @@ static int exchange(ls_amd_dist *d, int r, void *stream) {
 
 int ls_amd_dist_matvec(ls_amd_dist *d, void const *d_x, void *d_y, void *stream) {
     int const R = d->rounds, P = d->P;
+    TRY(ls_amd_internal_check_y(d->plan, d_y));
     ls_amd_internal_count_matvec(d->plan);
     TRY(ls_amd_diag(d->plan, d_x, d_y, stream)); /* localDiagonal first: y is assigned (DMV:1062-1063) */
     TRY(ls_amd_generate(d->plan, 0, d_x, d_y, d->d_send[0], stream));

@@ -394,7 +394,7 @@ static uint64_t host_apply_elem(lsk_group_elem const *e, uint64_t x, int L) {
 
 /* The kernels loop over the group elements of a projected basis per candidate state; the largest groups of the reference's inputs
  * have 288 elements (heisenberg_square_6x6), the automorphisms of a 64-site lattice a few thousand */
-enum { LS_AMD_MAX_GROUP_ORDER = 1 << 16 };
+enum { LS_AMD_MAX_GROUP_ORDER = 1 << 20 }; /* closure is linear in the order (hash-table membership): a million elements take milliseconds */
 static uint64_t perm_hash(int const *p, int L) {
     uint64_t h = 0x9e3779b97f4a7c15ULL;
     for (int i = 0; i < L; ++i) { h ^= (uint64_t)(p[i] + 1); h *= 0xff51afd7ed558ccdULL; h ^= h >> 29; }
@@ -449,7 +449,7 @@ static int close_group(struct ls_amd_basis_ext *ext, int L) {
             }
             if (order >= LS_AMD_MAX_GROUP_ORDER) {
                 free(perms); free(chars); free(gch); free(cand); free(table);
-                return set_error("symmetry group too large (more than %d elements: is every generator the permutation it should be?)", LS_AMD_MAX_GROUP_ORDER);
+                return set_error("symmetry group too large (more than %d elements; note: one wrong entry in a permutation makes the generators span nearly S_L)", LS_AMD_MAX_GROUP_ORDER);
             }
             if (order == cap) {
                 cap *= 2;
@@ -1521,6 +1521,7 @@ struct ls_amd_plan {
      * HBM for one-amplitude operators, 13 / 21 with real / complex coefficients). */
     int slot_cache, slot_cache_valid;
     int64_t slot_cache_bytes;
+    void const *y_checked[2]; /* y pointers whose memory kind was looked at (push plans: ls_amd_internal_check_y) */
     /* kernel timing ring */
     int t_capacity, t_count;
     void **t_start, **t_stop;
@@ -1683,6 +1684,25 @@ static void stage_end(ls_amd_plan *pl, int slot, void *stream) {
 int ls_amd_internal_stage_begin(ls_amd_plan *pl, int stage, void *stream) { return stage_begin(pl, stage, stream); }
 void ls_amd_internal_stage_end(ls_amd_plan *pl, int slot, void *stream) { stage_end(pl, slot, stream); }
 void ls_amd_internal_count_matvec(ls_amd_plan *pl) { if (pl->st_capacity) ++pl->st_matvecs; }
+/* Plans that accumulate into the caller's y with hardware f64 atomics (push: k_direct, the packet consumers) need y in
+ * coarse-grained memory (hipMalloc): on fine-grained memory -- hipMallocManaged unless advised otherwise -- the unsafe-fp-atomics
+ * `global_atomic_add_f64` may lose updates silently ("Atomics").  A managed y is refused here instead;
+ * the host-pointer boundary (ls_chpl_matrix_vector_product) stages managed memory and never gets here with it.
+ * LS_AMD_ALLOW_MANAGED_Y=1: the caller vouches for hipMemAdvise(..., hipMemAdviseSetCoarseGrain, ...). */
+int ls_amd_internal_check_y(ls_amd_plan *pl, void const *y) {
+    if (pl->family != FAMILY_DIRECT_PUSH && pl->family != FAMILY_TILE) return 0;
+    if (!y || y == pl->y_checked[0] || y == pl->y_checked[1]) return 0;
+    if (lsk_pointer_kind(y) == LSK_PTR_MANAGED) {
+        char const *e = getenv("LS_AMD_ALLOW_MANAGED_Y");
+        if (!e || atoi(e) == 0)
+            return set_error("y is managed (hipMallocManaged) memory: this plan accumulates with hardware f64 atomics, which need "
+                             "coarse-grained memory -- pass hipMalloc memory, go through ls_chpl_matrix_vector_product (which stages it), "
+                             "or advise the range coarse-grained and set LS_AMD_ALLOW_MANAGED_Y=1");
+    }
+    pl->y_checked[1] = pl->y_checked[0];
+    pl->y_checked[0] = y;
+    return 0;
+}
 /* folds the recorded event pairs into the per-stage totals (synchronises on the events) */
 static int stage_collect(ls_amd_plan *pl) {
     for (int i = 0; i < pl->st_count; ++i) {
@@ -1987,6 +2007,19 @@ static int build_tilemap(ls_amd_plan *pl, int64_t n, int TILE) {
     pl->tilemap.entries = (uint64_t const *)pl->d_tilemap;
     pl->tilemap.slots_per_xcd = slots;
     return 0;
+}
+/* test hook (ls_amd.h): the row kernel of a one-process plan skips ONE row -- the first tile of XCD 0's list loses its last row, so
+ * that row's y is never written (pull) or its contributions never leave (push).  Memory-safe: a shorter tile reads nothing new.
+ * Returns 1 when a tile was shortened, 0 when the plan has no tile map (packet plans) or only one-row tiles. */
+int ls_amd_test_corrupt_plan(ls_amd_plan *pl) {
+    if (!pl || !pl->d_tilemap || pl->tilemap.slots_per_xcd <= 0) return 0;
+    uint64_t e = 0;
+    if (lsk_device_sync() != 0 || lsk_d2h(&e, pl->d_tilemap, sizeof(e)) != 0) return 0;
+    uint64_t const rows = e >> 48;
+    if (rows < 2) return 0;
+    e = (e & 0xffffffffffffULL) | ((rows - 1) << 48);
+    if (lsk_h2d(pl->d_tilemap, &e, sizeof(e)) != 0) return 0;
+    return 1;
 }
 /* test hook (host only): the tile map of n rows.  Returns slots per XCD (< 0 on error); *entries is malloc'ed, free
  * with ls_amd_test_free. */
@@ -3192,6 +3225,7 @@ int64_t ls_amd_plan_packet_index_bytes(ls_amd_plan const *pl) {
 
 int ls_amd_matvec(ls_amd_plan *pl, void const *const *d_x, void *const *d_y, void *stream) {
     if (pl->me >= 0) return set_error("ls_amd_matvec: plan owns one partition; drive it with generate/scatter");
+    for (int p = 0; p < pl->n_local; ++p) if (ls_amd_internal_check_y(pl, d_y[p]) != 0) return -1;
     ls_amd_internal_count_matvec(pl);
     if (pl->family == FAMILY_TILE_PULL && pl->idx_mode) {
         /* indexed mode on one device: slot = index; the only per-matvec preparation is x * norm(rep), a streaming pass
@@ -3524,35 +3558,37 @@ int ls_amd_pointer_kind(void const *p) { return lsk_pointer_kind(p); }
 /* LS_AMD_STAGE: 1 (default) = pinned bounce pipeline (pageable memory; registered memory: one DMA per direction), 0 = the runtime's own
  * copies one after the other (what a single vector costs either way: 179 vs 182 ms on chain_32; a block of four columns: 716 vs 555 ms) */
 static int staging_mode(void) { char const *e = getenv("LS_AMD_STAGE"); return e ? atoi(e) : 1; }
-static lsk_stager *stager(void) {
-    pthread_mutex_lock(&g_stager_lock);
+/* (caller holds g_stager_lock -- and keeps it while it uses the stager: a change of the chunk knob destroys and recreates it) */
+static lsk_stager *stager_locked(void) {
     char const *e = getenv("LS_AMD_STAGE_CHUNK_KB"), *t = getenv("LS_AMD_STAGE_THREADS");
     size_t const chunk = (e && atoi(e) > 0 ? (size_t)atoi(e) : (size_t)32768) << 10;
     if (g_stager && lsk_stager_chunk(g_stager) != (chunk < 4096 ? 4096 : chunk & ~(size_t)4095)) { lsk_stager_destroy(g_stager); g_stager = NULL; }
     if (!g_stager && lsk_stager_create(&g_stager, chunk, t ? atoi(t) : 0) != 0) { g_stager = NULL; set_error("%s", lsk_stage_last_error()); }
-    pthread_mutex_unlock(&g_stager_lock);
     return g_stager;
 }
 /* up: host -> device, down: device -> host, at the same time; kinds from lsk_pointer_kind (never LSK_PTR_DEVICE here) */
 static int transfer(void *d_up, void const *h_up, size_t up_bytes, int up_kind, void *h_down, void const *d_down, size_t down_bytes,
                     int down_kind) {
     if (!up_bytes && !down_bytes) return 0;
-    g_bstats.bytes_h2d += (int64_t)up_bytes;
-    g_bstats.bytes_d2h += (int64_t)down_bytes;
+    __atomic_fetch_add(&g_bstats.bytes_h2d, (int64_t)up_bytes, __ATOMIC_RELAXED); /* loop-back ranks call this from several threads */
+    __atomic_fetch_add(&g_bstats.bytes_d2h, (int64_t)down_bytes, __ATOMIC_RELAXED);
     int const mode = staging_mode();
-    if (mode == 0) {
+    if (mode == 0 && up_kind != LSK_PTR_MANAGED && down_kind != LSK_PTR_MANAGED) {
         if (up_bytes) DEV(lsk_h2d(d_up, h_up, up_bytes));
         if (down_bytes) DEV(lsk_d2h(h_down, d_down, down_bytes));
         return 0;
     }
 
-    lsk_stager *st = stager();
-    if (!st) return -1;
-    if (lsk_stage_run(st, d_up, h_up, up_bytes, up_kind, h_down, d_down, down_bytes, down_kind) != 0) return set_error("%s", lsk_stage_last_error());
-    return 0;
+    pthread_mutex_lock(&g_stager_lock);
+    lsk_stager *st = stager_locked();
+    int rc = st ? 0 : -1;
+    if (st && lsk_stage_run(st, d_up, h_up, up_bytes, up_kind, h_down, d_down, down_bytes, down_kind) != 0) rc = set_error("%s", lsk_stage_last_error());
+    pthread_mutex_unlock(&g_stager_lock);
+    return rc;
 }
 
-/* localMatrixVector on `ncols` host (or device) vectors: column k at x + k ldx, y + k ldy */
+/* localMatrixVector on `ncols` host (or device) vectors: column k at x + k ldx, y + k ldy.  The memory kind is looked up ONCE,
+ * at x and at y: all columns of a block must live in one kind of memory (one PRIMME workspace does). */
 static int host_matvec_block(ls_hs_operator *op, int64_t n, int ncols, double const *x, int64_t ldx, double *y, int64_t ldy,
                              ls_amd_comm *cm) {
     ls_hs_basis *b = op->basis;
@@ -3600,10 +3636,10 @@ static int host_matvec_block(ls_hs_operator *op, int64_t n, int ncols, double co
         if (yk != LSK_PTR_DEVICE && !sl->d_y[i]) DEV(lsk_malloc(&sl->d_y[i], bytes));
     }
     sl->stage_n = n;
-    g_bstats.calls += 1;
-    g_bstats.columns += ncols;
-    if (xk == LSK_PTR_DEVICE) g_bstats.device_x += ncols;
-    if (yk == LSK_PTR_DEVICE) g_bstats.device_y += ncols;
+    __atomic_fetch_add(&g_bstats.calls, 1, __ATOMIC_RELAXED);
+    __atomic_fetch_add(&g_bstats.columns, ncols, __ATOMIC_RELAXED);
+    if (xk == LSK_PTR_DEVICE) __atomic_fetch_add(&g_bstats.device_x, ncols, __ATOMIC_RELAXED);
+    if (yk == LSK_PTR_DEVICE) __atomic_fetch_add(&g_bstats.device_y, ncols, __ATOMIC_RELAXED);
     /* pipeline over the columns: [upload x_0 (+ y_0)] ; for k: launch matvec_k | upload x_{k+1} (+ y_{k+1}) and download y_{k-1}
      * while it runs | check ; [download y_last] */
 #define XDEV(k) (xk == LSK_PTR_DEVICE ? (void *)(x + (int64_t)(k) * ldx) : sl->d_x[(k) & (nbuf - 1)])
@@ -3618,15 +3654,19 @@ static int host_matvec_block(ls_hs_operator *op, int64_t n, int ncols, double co
             void *ys[1] = {YDEV(k)};
             rc = ls_amd_matvec(plan, xs, ys, NULL);
         }
-        if (rc != 0) return -1;
+        /* (error exits after a launch wait for the device: the slot's persistent d_x / d_y must not be overwritten by the next call
+         * while a kernel of this one still reads them -- ADVICE r5) */
+#define FAIL_AFTER_LAUNCH do { (void)lsk_device_sync(); return -1; } while (0)
+        if (rc != 0) FAIL_AFTER_LAUNCH;
         /* while the kernel runs: the next column goes up, the previous result comes down (different buffers) */
         int const up = k + 1 < ncols && xk != LSK_PTR_DEVICE, down = k >= 1 && yk != LSK_PTR_DEVICE;
         if ((up || down) && transfer(up ? XDEV(k + 1) : NULL, up ? x + (int64_t)(k + 1) * ldx : NULL, up ? bytes : 0, xk,
-                                     down ? y + (int64_t)(k - 1) * ldy : NULL, down ? YDEV(k - 1) : NULL, down ? bytes : 0, yk) != 0) return -1;
+                                     down ? y + (int64_t)(k - 1) * ldy : NULL, down ? YDEV(k - 1) : NULL, down ? bytes : 0, yk) != 0) FAIL_AFTER_LAUNCH;
         /* (y += H x: the next column's y goes up only now -- its buffer held the result that has just come down) */
         if (k + 1 < ncols && yk != LSK_PTR_DEVICE && upload_y &&
-            transfer(YDEV(k + 1), y + (int64_t)(k + 1) * ldy, bytes, yk, NULL, NULL, 0, 0) != 0) return -1;
-        if (ls_amd_plan_check(plan, NULL) != 0) return -1; /* synchronises the launch stream; halts on an invalid index */
+            transfer(YDEV(k + 1), y + (int64_t)(k + 1) * ldy, bytes, yk, NULL, NULL, 0, 0) != 0) FAIL_AFTER_LAUNCH;
+        if (ls_amd_plan_check(plan, NULL) != 0) FAIL_AFTER_LAUNCH; /* synchronises the launch stream; halts on an invalid index */
+#undef FAIL_AFTER_LAUNCH
     }
     if (yk != LSK_PTR_DEVICE &&
         transfer(NULL, NULL, 0, 0, y + (int64_t)(ncols - 1) * ldy, YDEV(ncols - 1), bytes, yk) != 0) return -1;

@@ -196,9 +196,11 @@ int lsk_sync(void *stream);
 int lsk_device_sync(void);
 
 /* host <-> HBM staging of the host-pointer entry points (stage.cpp) ---------------------------- */
-enum { LSK_PTR_PAGEABLE = 0, LSK_PTR_PINNED = 1, LSK_PTR_DEVICE = 2 };
+enum { LSK_PTR_PAGEABLE = 0, LSK_PTR_PINNED = 1, LSK_PTR_DEVICE = 2,
+       LSK_PTR_MANAGED = 3 /* hipMallocManaged: fine-grained unless advised otherwise -- never used in place (the push kernels'
+                            * global_atomic_add_f64 is specified for coarse-grained memory only); staged by one DMA like pinned memory */ };
 char const *lsk_stage_last_error(void);
-int lsk_pointer_kind(void const *p); /* hipPointerGetAttributes: device / managed, pinned or registered host, anything else */
+int lsk_pointer_kind(void const *p); /* hipPointerGetAttributes: device, managed, pinned or registered host, anything else */
 int lsk_host_register(void *p, size_t bytes);
 int lsk_host_unregister(void *p);
 typedef struct lsk_stager lsk_stager;

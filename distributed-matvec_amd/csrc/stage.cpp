@@ -37,7 +37,11 @@ extern "C" char const *lsk_stage_last_error(void) { return g_serr; }
         }                                                                                                  \
     } while (0)
 
-// 0 = pageable (or unknown) host memory, 1 = pinned / registered host memory, 2 = device (or managed) memory
+// 0 = pageable (or unknown) host memory, 1 = pinned / registered host memory, 2 = device memory (hipMalloc: coarse-grained),
+// 3 = managed memory (hipMallocManaged).  Managed memory is fine-grained unless the caller advised otherwise, and the push
+// kernels' hardware f64 atomics (-munsafe-fp-atomics -> global_atomic_add_f64) are specified for coarse-grained memory only: a
+// managed y used in place could lose updates silently.  It is therefore never used in place: the boundary
+// stages it through the plan's own hipMalloc vectors with one DMA per direction (hipMemcpyDefault), like pinned memory.
 extern "C" int lsk_pointer_kind(void const *p) {
     if (!p) return LSK_PTR_PAGEABLE;
     hipPointerAttribute_t a;
@@ -47,7 +51,8 @@ extern "C" int lsk_pointer_kind(void const *p) {
         (void)hipGetLastError();
         return LSK_PTR_PAGEABLE;
     }
-    if (a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged || a.type == hipMemoryTypeArray) return LSK_PTR_DEVICE;
+    if (a.type == hipMemoryTypeManaged || a.isManaged) return LSK_PTR_MANAGED;
+    if (a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeArray) return LSK_PTR_DEVICE;
     if (a.type == hipMemoryTypeHost) return LSK_PTR_PINNED;
     return LSK_PTR_PAGEABLE; // hipMemoryTypeUnregistered
 }
@@ -179,14 +184,15 @@ extern "C" size_t lsk_stager_chunk(lsk_stager const *st) { return st->chunk; }
 // (The runtime's own copies from two host threads, one per direction, do NOT overlap on this stack: a block of four chain_32
 // columns took 716 ms either way, against 555 ms through the bounce buffers below -- profiles/r5_bench_default.json.)
 // One upload (host -> device) and one download (device -> host) at the same time; either may be empty (bytes == 0).
-// host_kind: LSK_PTR_PAGEABLE -> bounce buffers, LSK_PTR_PINNED -> one DMA.  Returns when both are complete.
+// host_kind: LSK_PTR_PAGEABLE -> bounce buffers, LSK_PTR_PINNED / LSK_PTR_MANAGED -> one DMA.  Returns when both are complete.
 extern "C" int lsk_stage_run(lsk_stager *st, void *d_up, void const *h_up, size_t up_bytes, int up_kind,
                              void *h_down, void const *d_down, size_t down_bytes, int down_kind) {
     std::lock_guard<std::mutex> guard(st->lock);
     const size_t C = st->chunk;
     const bool up_direct = up_kind != LSK_PTR_PAGEABLE, down_direct = down_kind != LSK_PTR_PAGEABLE;
-    if (up_bytes && up_direct) ST_CHECK(hipMemcpyAsync(d_up, h_up, up_bytes, hipMemcpyHostToDevice, st->up.stream));
-    if (down_bytes && down_direct) ST_CHECK(hipMemcpyAsync(h_down, d_down, down_bytes, hipMemcpyDeviceToHost, st->down.stream));
+    // (hipMemcpyDefault: the "host" side may be managed memory, wherever its pages live)
+    if (up_bytes && up_direct) ST_CHECK(hipMemcpyAsync(d_up, h_up, up_bytes, hipMemcpyDefault, st->up.stream));
+    if (down_bytes && down_direct) ST_CHECK(hipMemcpyAsync(h_down, d_down, down_bytes, hipMemcpyDefault, st->down.stream));
     const size_t nu = (up_bytes && !up_direct) ? (up_bytes + C - 1) / C : 0;
     const size_t nd = (down_bytes && !down_direct) ? (down_bytes + C - 1) / C : 0;
     // software pipeline over chunk index i: upload chunk i is copied into its bounce buffer and sent; download chunk i is

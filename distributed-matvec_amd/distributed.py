@@ -107,17 +107,36 @@ class _Transport:
 class HipEngine:
     """ls_amd plan that owns exactly one partition (this rank's)."""
 
-    def __init__(self, matrix, representatives, dtype, num_partitions: int, my_partition: int, num_rounds: int):
+    def __init__(self, matrix, representatives, dtype, num_partitions: int, my_partition: int, num_rounds: int,
+                 state_keys: bool = False):
         import torch
 
+        from . import _lib
         from .api import MatvecPlan
 
         self.torch = torch
-        self.plan = MatvecPlan(matrix, representatives, dtype, my_partition=my_partition,
-                               num_partitions=num_partitions, num_rounds=num_rounds)
+        self._args = (matrix, representatives, dtype, num_partitions, my_partition, num_rounds)
+        if state_keys:  # the ranks agreed on state-carrying packets (DistributedOperator.__init__): no all-destinations directory
+            _lib.load().ls_amd_internal_set_no_packet_index(1)
+        try:
+            self.plan = MatvecPlan(matrix, representatives, dtype, my_partition=my_partition,
+                                   num_partitions=num_partitions, num_rounds=num_rounds)
+        finally:
+            if state_keys:
+                _lib.load().ls_amd_internal_set_no_packet_index(0)
         self.device = representatives.device
         self.num_rounds = self.plan.num_rounds
         self.packet_bytes = self.plan.packet_bytes
+
+    @property
+    def key_bytes(self):
+        """4: pre-indexed packets (u32 index at the destination), 8: the packets carry the state"""
+        return self.plan.key_bytes
+
+    def with_state_keys(self):
+        """the same engine with state-carrying packets (the layout every rank can always produce); this one is destroyed"""
+        self.plan.destroy()
+        return HipEngine(*self._args, state_keys=True)
 
     def segment_bytes(self, count):
         """bytes of a segment of `count` packets (keys padded to 8 bytes, then values; include/ls_amd.h)"""
@@ -176,6 +195,16 @@ class DistributedOperator:
         factory = engine_factory or HipEngine
         self.engine = factory(matrix, representatives, dtype, self.P, self.rank, num_rounds)
         assert self.engine.num_rounds == num_rounds
+        # ONE packet layout for all ranks (csrc/dist.c does the same for the C host's driver): a plan decides alone whether
+        # it writes pre-indexed 12-byte packets (the all-destinations directory must fit a quarter of ITS free HBM and pass its
+        # self-check) or state-carrying 16-byte ones -- ranks that disagreed would read each other's u64 states as u32 indices.
+        # All-reduce the key width with MAX; a rank that is better off than the agreement rebuilds its plan with state keys.
+        kb = torch.tensor([int(getattr(self.engine, "key_bytes", 8))], dtype=torch.int64, device=self.meta_device)
+        dist.all_reduce(kb, op=dist.ReduceOp.MAX, group=group)
+        self.key_bytes = int(kb.item())
+        if int(getattr(self.engine, "key_bytes", 8)) != self.key_bytes:
+            self.engine = self.engine.with_state_keys()
+            assert self.engine.num_rounds == num_rounds and int(getattr(self.engine, "key_bytes", 8)) == self.key_bytes
         pb = self.engine.packet_bytes
         # counts matrix exchange, once: S[d, r] = packets this rank sends to d in round r
         S = torch.tensor([self.engine.send_counts(r) for r in range(num_rounds)], dtype=torch.int64).t().contiguous()

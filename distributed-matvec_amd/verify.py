@@ -93,3 +93,90 @@ def parity_object(y_part, x_part, y_ref_part, ymax_ref: float, allsum=None, allm
     return {"ok": ok, "max_abs_err": max_abs, "max_rel_err": rel, "rows_off": int(bad), "tolerance": TOLERANCE,
             "max_abs_y_reference": ymax_ref, "invariants": inv,
             "reference": f"one-partition kernel ({reference_kernel}) on x = u(hash(sigma, seed)) - 0.5, compared element-wise on every rank's rows"}
+
+
+class _Env:
+    """set / restore environment knobs the C host reads at plan creation"""
+
+    def __init__(self, **kv):
+        self.kv, self.saved = kv, {}
+
+    def __enter__(self):
+        import os
+
+        for k, v in self.kv.items():
+            self.saved[k] = os.environ.get(k)
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+    def __exit__(self, *exc):
+        import os
+
+        for k, v in self.saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def alternative_kernels(matrix, projected: bool):
+    """the independent formulations a one-GPU result is held against, as (label, plan mode, environment) -- none of them shares the
+    measured kernel's device code:
+      unprojected bases   the GENERIC row kernel k_direct in pull form (LS_AMD_ROW_KERNEL=generic: one row per lane, term loop,
+                          index by combinadic rank or prefix table) and in PUSH form (the reference's formulation: atomics);
+      projected bases     PUSH (packets of state-carrying keys -> search -> atomics) and the VALUE-TABLE pull kernel
+                          (LS_AMD_PULL_INDEXED=0: block-wide lists, binary-search window, {rep -> x n(rep)} hash table)."""
+    if projected:
+        out = [("push_atomics", "push", {})]
+        if matrix.isHermitian:
+            out.append(("pull_value_table", "pull", {"LS_AMD_PULL_INDEXED": "0"}))
+        return out
+    out = [("generic_push_atomics", "push", {"LS_AMD_ROW_KERNEL": "generic"})]
+    if matrix.isHermitian:
+        out.insert(0, ("generic_pull", "pull", {"LS_AMD_ROW_KERNEL": "generic"}))
+    return out
+
+
+def single_gpu_references(matrix, reps, dtype, x, projected: bool):
+    """y of every alternative kernel on the same x: {label: (y_ref, kernel name)} -- the reference's single-locale check
+    (/root/reference/test/TestMatrixVectorProduct.chpl:25-39) with the stored `/y` replaced by independent device kernels."""
+    import torch
+
+    from . import api
+
+    refs = {}
+    for label, mode, env in alternative_kernels(matrix, projected):
+        with _Env(**env):
+            plan = api.MatvecPlan(matrix, [reps], dtype, mode=mode)
+        try:
+            y = torch.zeros_like(x)
+            plan.matvec([x], [y], check=True)
+            refs[label] = (y, plan.kernel)
+        finally:
+            plan.destroy()
+    return refs
+
+
+def single_gpu_parity(y, x, refs, measured_kernel: str):
+    """the `parity` object of a one-GPU bench leg: the measured kernel's y against every reference of single_gpu_references,
+    element by element, plus the invariants; ok = all of them agree."""
+    out = {"measured_kernel": measured_kernel, "against": {}}
+    ok = bool(refs)
+    worst = 0.0
+    rows_off = 0
+    for label, (y_ref, kname) in refs.items():
+        ymax = float(y_ref.abs().max()) if y_ref.numel() else 0.0
+        o = parity_object(y, x, y_ref, ymax, reference_kernel=kname)
+        o["reference"] = f"{kname} on the same x, all {y_ref.numel()} rows"
+        o["independent_of_measured_kernel"] = kname != measured_kernel
+        ok = ok and o["ok"] and kname != measured_kernel
+        worst = max(worst, o["max_rel_err"])
+        rows_off = max(rows_off, o["rows_off"])
+        out["against"][label] = o
+    first = next(iter(out["against"].values()), None)
+    out.update({"ok": bool(ok), "max_rel_err": worst, "rows_off": rows_off, "tolerance": TOLERANCE,
+                "sum_y": first["invariants"]["sum_y"]["value"] if first else None,
+                "dot_x_y": first["invariants"]["dot_x_y"]["value"] if first else None})
+    return out

@@ -122,6 +122,19 @@ int main(int argc, char **argv) {
     }
     printf("L = %d, N = %lld, <x|H|x>/<x|x> = %.12f, max|y| = %.6f, |plug-in - partitions| = %.2e, |plug-in - rccl| = %.2e\n",
            L, (long long)n, dot / nrm, scale, e2, e3);
+    if (argc > 2) {
+        /* dump for an external checker (tests/test_gpu_c_example.py compares every element with the oracle): n, then the
+         * representatives, x, and y of the three paths (plug-in | partitions | one-rank RCCL, the last zero-filled without RCCL) */
+        FILE *f = fopen(argv[2], "wb");
+        if (!f) { fprintf(stderr, "cannot write %s\n", argv[2]); return 1; }
+        if (!have_rccl) memset(hy3, 0, 8 * (size_t)n);
+        int64_t hdr[2] = {n, have_rccl};
+        if (fwrite(hdr, 8, 2, f) != 2 || fwrite(reps, 8, (size_t)n, f) != (size_t)n || fwrite(hx, 8, (size_t)n, f) != (size_t)n ||
+            fwrite(hy, 8, (size_t)n, f) != (size_t)n || fwrite(hy2, 8, (size_t)n, f) != (size_t)n || fwrite(hy3, 8, (size_t)n, f) != (size_t)n) {
+            fprintf(stderr, "short write to %s\n", argv[2]); fclose(f); return 1;
+        }
+        fclose(f);
+    }
     ls_hs_destroy_operator(op);
     if (!from_yaml) ls_hs_destroy_basis(basis); /* the creator's reference of the hand-built basis */
     ls_chpl_finalize();

@@ -76,8 +76,12 @@ int ls_amd_basis_rotate(int m_in, int m_out, int64_t n, double *d_V, int64_t ldv
 /* ------------------------------------------------------------------------------------------
  * The host-pointer boundary: ls_chpl_matrix_vector_product (DMV:1095-1110) and ls_chpl_primme_matvec (Diagonalize.chpl:134-162)
  * take `double *` as the reference's do.  What a call costs is decided by where that memory lives:
- *   LS_AMD_PTR_DEVICE    device / managed memory (hipMalloc, a torch CUDA tensor): used in place, ZERO copies -- a GPU-resident
+ *   LS_AMD_PTR_DEVICE    device memory (hipMalloc, a torch CUDA tensor): used in place, ZERO copies -- a GPU-resident
  *                        eigensolver can call the reference's entry points as they are
+ *   LS_AMD_PTR_MANAGED   hipMallocManaged memory: fine-grained unless advised otherwise, and the push kernels' hardware f64 atomics
+ *                        are specified for coarse-grained memory only -- never used in place: staged through the plan's own
+ *                        hipMalloc vectors by one DMA per direction.  (The device-pointer entries -- ls_amd_matvec,
+ *                        ls_amd_dist_matvec -- REFUSE a managed y for plans that accumulate with atomics.)
  *   LS_AMD_PTR_PINNED    hipHostMalloc'ed memory, or memory registered with ls_amd_host_register (once per workspace: PRIMME
  *                        reuses its vectors): one DMA per direction at the PCIe rate
  *   LS_AMD_PTR_PAGEABLE  anything else: double-buffered pinned bounce chunks filled by a small pool of host threads, upload
@@ -86,7 +90,7 @@ int ls_amd_basis_rotate(int m_in, int m_out, int64_t n, double *d_V, int64_t ldv
  * operator has no diagonal terms (else it is assigned, DMV:1062-1063), and the columns of a PRIMME block share one pipeline
  * (column k + 1 goes up and column k - 1 comes down while column k computes).  Knobs: LS_AMD_STAGE=0 (plain synchronous
  * hipMemcpy), LS_AMD_STAGE_CHUNK_KB (32768), LS_AMD_STAGE_THREADS (min(16, cores / 4)). */
-enum { LS_AMD_PTR_PAGEABLE = 0, LS_AMD_PTR_PINNED = 1, LS_AMD_PTR_DEVICE = 2 };
+enum { LS_AMD_PTR_PAGEABLE = 0, LS_AMD_PTR_PINNED = 1, LS_AMD_PTR_DEVICE = 2, LS_AMD_PTR_MANAGED = 3 };
 int ls_amd_pointer_kind(void const *p);
 int ls_amd_host_register(void *p, size_t bytes);   /* hipHostRegister: the caller keeps the memory alive until ... */
 int ls_amd_host_unregister(void *p);               /* ... this */
@@ -207,6 +211,9 @@ void ls_amd_test_fail_stream_buffers(int on);
  * consumers and the default rows per round (the verdict of every set-up step is collective) */
 void ls_amd_test_fail_dist_streams(int on);
 int ls_amd_test_corrupt_repl(ls_amd_repl *repl);
+/* ... and the one-GPU counterpart (`bench.py --inject-fault` at N = 1): the row kernel of a plan whose partitions all live in this
+ * process skips one row of the first tile (memory-safe); 1 when a tile was shortened, 0 when the plan has no tile map. */
+int ls_amd_test_corrupt_plan(ls_amd_plan *plan);
 
 /* ------------------------------------------------------------------------------------------
  * Plans.  A plan binds an operator to the partition layout and owns every per-basis device table:

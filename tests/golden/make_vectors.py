@@ -56,5 +56,33 @@ def main():
     print("wrote vectors.npz")
 
 
+def write_reference_layout(directory, names=None, with_construction=True):
+    """A directory in the layout of the reference's downloaded goldens (/root/reference/Makefile:128-146 unpacks data/matvec,
+    data/construction; /root/reference/input_for_matvec.py:41-46 writes /representatives, /x = x.T and /y = y.T, i.e. shape
+    (batch, N)), filled from vectors.npz: `<dir>/matvec/<name>.h5` for every model that has a dense-oracle y there and
+    `<dir>/construction/<name>.h5` (/representatives only).  SYNTHETIC: these y are this repository's, not the reference's --
+    the directory exists so that the golden harness (distributed_matvec_amd.check.walk_goldens, tests/test_reference_goldens.py)
+    can be exercised end to end without the artefacts.  Returns the model names written."""
+    from distributed_matvec_amd import hdf5
+
+    v = np.load(os.path.join(HERE, "vectors.npz"))
+    have = sorted({k.split("/")[0] for k in v.keys() if k.endswith("/y")})
+    names = [n for n in (names or have) if n in have]
+    os.makedirs(os.path.join(directory, "matvec"), exist_ok=True)
+    if with_construction:
+        os.makedirs(os.path.join(directory, "construction"), exist_ok=True)
+    for n in names:
+        reps = np.ascontiguousarray(v[n + "/representatives"], dtype=np.uint64)
+        x = np.ascontiguousarray(v[n + "/x"], dtype=np.float64)[None, :]
+        y = np.ascontiguousarray(v[n + "/y"], dtype=np.float64)[None, :]
+        hdf5.write_datasets(os.path.join(directory, "matvec", n + ".h5"), {"/representatives": reps, "/x": x, "/y": y})
+        if with_construction:
+            hdf5.write_datasets(os.path.join(directory, "construction", n + ".h5"), {"/representatives": reps})
+    return names
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 2 and sys.argv[1] == "--layout":
+        print("wrote", write_reference_layout(sys.argv[2]))
+    else:
+        main()

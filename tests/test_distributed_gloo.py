@@ -104,6 +104,12 @@ class OracleEngineIndexed(OracleEngine):
     [u32 index at the destination x c, padded to 8 bytes][value x c], and all segments of a round are consumed by ONE call"""
 
     all_reps = None  # the whole basis (ascending): the producer ranks a state inside its owner's block, as the rank directory does
+    key_bytes = 4
+
+    def with_state_keys(self):
+        """what HipEngine.with_state_keys does: the same engine with state-carrying packets"""
+        return OracleEngine(self.o, torch.from_numpy(self.reps.view(np.int64).copy()), torch.complex128 if self.cplx else torch.float64,
+                            self.P, self.me, self.num_rounds)
 
     def segment_bytes(self, c):
         return ((4 * c + 7) & ~7) + (16 if self.cplx else 8) * c
@@ -166,9 +172,16 @@ def _worker(rank, world, port, name, cplx, num_rounds, out_dir, indexed=False):
         my_x = torch.from_numpy(x[mine].copy())
         my_y = torch.full_like(my_x, 7.0)  # overwritten by the diagonal pass
         OracleEngineIndexed.all_reps = reps
-        op = DistributedOperator(o, my_reps, my_x.dtype, engine_factory=OracleEngineIndexed if indexed else OracleEngine, num_rounds=num_rounds)
+        # indexed == "mixed": the ranks DISAGREE -- rank 0's plan comes back with pre-indexed packets, the others' with state-carrying
+        # ones (uneven free HBM, a failed self-check).  The operator must settle on ONE layout: all state-carrying.
+        factory = OracleEngine if not indexed or (indexed == "mixed" and rank != 0) else OracleEngineIndexed
+        op = DistributedOperator(o, my_reps, my_x.dtype, engine_factory=factory, num_rounds=num_rounds)
         assert op.num_rounds == (num_rounds if num_rounds else 1)
-        if indexed:  # 12 instead of 16 bytes per f64 packet on the wire (keys padded to 8 bytes per segment)
+        if indexed == "mixed":
+            assert op.key_bytes == 8 and type(op.engine) is OracleEngine
+        elif indexed:
+            assert op.key_bytes == 4
+        if indexed is True:  # 12 instead of 16 bytes per f64 packet on the wire (keys padded to 8 bytes per segment)
             packets = sum(sum(c) for c in op.send_counts)
             assert op.exchange_bytes_per_matvec <= packets * ((20 if cplx else 12)) + 4 * world * op.num_rounds
         # send/recv count matrices are transposes of each other across ranks
@@ -222,6 +235,8 @@ def _worker(rank, world, port, name, cplx, num_rounds, out_dir, indexed=False):
     ("heisenberg_chain_16", 3, False, 2, False),
     ("heisenberg_chain_16", 3, False, 2, True),
     ("heisenberg_kagome_12", 2, True, 3, True),
+    ("heisenberg_chain_16", 3, False, 2, "mixed"),
+    ("heisenberg_kagome_12", 2, True, 1, "mixed"),
 ])
 def test_all_to_all_exchange(tmp_path, name, world, cplx, rounds, indexed):
     sys.path.insert(0, ROOT)
@@ -229,7 +244,7 @@ def test_all_to_all_exchange(tmp_path, name, world, cplx, rounds, indexed):
     from oracle import c_oracle as CO
 
     port = 29600 + (os.getpid() % 200) + world * 7 + rounds
-    mp.spawn(_worker, args=(world, port + (13 if indexed else 0), name, cplx, rounds, str(tmp_path), indexed), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port + (13 if indexed is True else 29 if indexed else 0), name, cplx, rounds, str(tmp_path), indexed), nprocs=world, join=True)
     reps = oracle_reps(name)
     rs = np.random.RandomState(5)
     x = rs.rand(len(reps)) - 0.5

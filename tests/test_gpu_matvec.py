@@ -1196,6 +1196,68 @@ def test_host_pointer_boundary_memory_kinds(torch, monkeypatch, name):
     assert st.device_x == 1 and st.device_y == 0 and st.bytes_d2h == 8 * n
 
 
+def test_managed_memory_is_never_used_in_place_by_push_plans(torch):
+    """hipMallocManaged memory is fine-grained unless advised otherwise; the push kernels' hardware f64 atomics
+    (global_atomic_add_f64 under -munsafe-fp-atomics) are specified for coarse-grained memory only.  A managed
+    y handed to a NON-HERMITIAN operator (push is its only formulation): the host-pointer boundary classifies it as its own kind,
+    stages it and equals the oracle; the device-pointer entry refuses it instead of risking lost updates."""
+    import ctypes as C
+
+    import distributed_matvec_amd as D
+    from distributed_matvec_amd import _lib
+    from oracle import c_oracle as CO
+    from oracle import model as M
+
+    hip = C.CDLL("libamdhip64.so")
+    L = _lib.load()
+    Ls = 14
+    bonds = [[i, (i + 1) % Ls] for i in range(Ls)]
+    cfg = {"basis": {"number_spins": Ls, "hamming_weight": Ls // 2, "symmetries": []},
+           "hamiltonian": {"terms": [{"expression": "σ⁺₀ σ⁻₁", "sites": bonds}, {"expression": "σᶻ₀ σᶻ₁", "sites": bonds}]}}
+    o = CO.COracle(M.model_from_config(cfg))
+    reps = o.enumerate()
+    n = len(reps)
+    basis, h = D.loadConfigFromDict(cfg, hamiltonian=True)
+    assert not h.isHermitian and h.isReal
+    h.basis.uncheckedSetRepresentatives(reps)
+    x = np.random.RandomState(11).rand(n) - 0.5
+    want = o.local_matvec(reps, x)
+    px, py = C.c_void_p(), C.c_void_p()
+    assert hip.hipMallocManaged(C.byref(px), C.c_size_t(8 * n), C.c_uint(1)) == 0  # hipMemAttachGlobal
+    assert hip.hipMallocManaged(C.byref(py), C.c_size_t(8 * n), C.c_uint(1)) == 0
+    try:
+        assert L.ls_amd_pointer_kind(px) == 3 and L.ls_amd_pointer_kind(py) == 3  # LS_AMD_PTR_MANAGED: its own kind, not "device"
+        xm = np.ctypeslib.as_array(C.cast(px, C.POINTER(C.c_double)), shape=(n,))
+        ym = np.ctypeslib.as_array(C.cast(py, C.POINTER(C.c_double)), shape=(n,))
+        xm[:] = x
+        ym[:] = 7.0  # garbage: the operator has diagonal terms, y is assigned
+        st = _lib.BoundaryStats()
+        L.ls_amd_boundary_stats_get(C.byref(st), 1)
+        L.ls_chpl_matrix_vector_product(h.payload, 1, C.cast(px, _lib.c_f64p), C.cast(py, _lib.c_f64p))
+        _lib.raise_pending_halt()
+        torch.cuda.synchronize()
+        L.ls_amd_boundary_stats_get(C.byref(st), 1)
+        assert st.device_x == 0 and st.device_y == 0 and st.bytes_h2d == 8 * n and st.bytes_d2h == 8 * n  # staged, not in place
+        assert_close(np.array(ym), want)
+        # the device-pointer entry: a push plan refuses a managed y, and takes hipMalloc memory
+        r = torch.from_numpy(reps.view(np.int64)).cuda()
+        pl = D.MatvecPlan(h, [r], torch.float64)
+        assert pl.kernel == "direct-push"
+        xs = (C.c_void_p * 1)(px.value)
+        ys = (C.c_void_p * 1)(py.value)
+        rc = L.ls_amd_matvec(pl.h, xs, ys, None)
+        assert rc != 0 and b"managed" in L.ls_amd_last_error()
+        yd = torch.zeros(n, dtype=torch.float64, device="cuda")
+        pl.matvec([torch.from_numpy(x).cuda()], [yd])
+        assert_close(yd.cpu().numpy(), want)
+        pl.destroy()
+    finally:
+        h.basis.uncheckedSetRepresentatives(np.zeros(0, dtype=np.uint64))
+        torch.cuda.synchronize()
+        hip.hipFree(px)
+        hip.hipFree(py)
+
+
 @pytest.mark.parametrize("case", ["heisenberg_chain_16/3/f64", "heisenberg_chain_16/8/c128", "heisenberg_chain_10/2/f64",
                                   "heisenberg_kagome_16/4/c128", "heisenberg_chain_20/8/f64", "heisenberg_kagome_12/5/f64"])
 def test_pre_indexed_packets(torch, monkeypatch, case):

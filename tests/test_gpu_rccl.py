@@ -298,3 +298,42 @@ def test_bench_distributed_path_is_self_verifying():
     assert "exchanges.replicated" in out["parity"]["fault_injection"]["detected"]
     assert out["parity"]["fault_injection"]["missed"] == []
     assert out["exchanges"]["replicated"]["parity"]["ok"]  # the check before the fault was clean
+
+
+def _run_bench_one_gpu(*extra, model="heisenberg_chain_24"):
+    import json
+    import subprocess
+
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--model", model, "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline", *extra], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert lines, p.stderr[-2000:]
+    return p.returncode, json.loads(lines[-1]), p.stderr
+
+
+@pytest.mark.parametrize("model", ["heisenberg_chain_24", "heisenberg_chain_24_symm"])
+def test_bench_one_gpu_line_carries_its_own_parity(model):
+    """The N = 1 line checks the y it times (the reference's single-locale check, test/TestMatrixVectorProduct.chpl:25-39):
+    the measured kernel against kernels that share no device code with it -- generic pull + push with atomics (unprojected), push +
+    value-table pull (projected) --, element by element; a row kernel that skips ONE row (--inject-fault) ends the run with rc 3."""
+    rc, out, err = _run_bench_one_gpu(model=model)
+    assert rc == 0, err[-2000:]
+    par = out["parity"]
+    assert par["ok"] and par["failed"] == [] and "main" in par["checked"], par
+    main = par["main"]
+    assert main["ok"] and main["rows_off"] == 0 and main["max_rel_err"] <= 1e-12 and len(main["against"]) == 2, main
+    for o in main["against"].values():
+        assert o["ok"] and o["independent_of_measured_kernel"], o
+        for inv in o["invariants"].values():
+            assert inv["rel_err"] <= 1e-12
+    if model == "heisenberg_chain_24":  # the other dtype's leg (c128: the north star's) carries its own object
+        legs = [k for k in par["checked"] if k.startswith("extra.c128/")]
+        assert legs, par["checked"]
+    rc, out, err = _run_bench_one_gpu("--no-extra", "--inject-fault", model=model)
+    assert rc == 3 and "PARITY FAILURE" in err, (rc, err[-1500:])
+    assert out["parity"]["main"]["ok"]  # clean before the fault ...
+    fi = out["parity"]["fault_injection"]
+    assert "main" in fi["detected"] and fi["missed"] == [] and fi["nothing_to_corrupt"] == [], fi
