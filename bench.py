@@ -822,8 +822,23 @@ def main():
     tdtype = torch.float64 if args.dtype == "f64" else torch.complex128
     w = 8 if args.dtype == "f64" else 16
 
-    def barrier():
+    comm_box = []  # the C host's communicator once it exists (distributed runs)
+
+    def drain():
+        """device idle before anything else is issued.  With the C host's communicator: a wait WITH A DEADLINE on its streams first
+        (ls_amd_comm_wait), so that a dead peer or mismatched counts end this rank with a message and a non-zero exit code instead
+        of leaving it in torch.cuda.synchronize() until the driver's timeout; and torch's own collectives (another communicator
+        of the same RCCL) are only ever issued on an idle device -- the two never have operations in flight at the same time."""
+        if comm_box:
+            try:
+                comm_box[0].wait()
+            except D.LsAmdError as e:
+                print(f"bench.py: rank {rank}: EXCHANGE DID NOT COMPLETE: {e}", file=sys.stderr, flush=True)
+                os._exit(4)
         torch.cuda.synchronize()
+
+    def barrier():
+        drain()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
@@ -860,6 +875,7 @@ def main():
     def allsum(v):
         if dist is None:
             return v
+        drain()
         t = torch.tensor([float(v)], dtype=torch.float64, device="cuda")
         dist.all_reduce(t)
         return float(t.item())
@@ -867,6 +883,7 @@ def main():
     def allmax(v):
         if dist is None:
             return v
+        drain()
         t = torch.tensor([float(v)], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
@@ -927,6 +944,7 @@ def main():
         from distributed_matvec_amd import verify
 
         comm = D.Communicator.from_torch()
+        comm_box.append(comm)
         # Evidence of the transport and of the result: the communicator size as RCCL reports it, the ranks an
         # all-reduce through it counts, and -- per strategy, below -- y against the one-partition kernel on the same vector.
         one = torch.ones(1, dtype=torch.float64, device="cuda")

@@ -537,6 +537,11 @@ class Communicator:
             dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
         return Communicator(size, rank, box[0])
 
+    def wait(self, timeout_s: float = 0.0):
+        """ls_amd_comm_wait: until the current stream and the exchange stream have drained; raises after timeout_s (<= 0: the
+        watchdog's deadline, LS_AMD_COMM_WATCHDOG_S) instead of hanging in a synchronisation"""
+        _lib.check(_lib.load().ls_amd_comm_wait(self.h, _stream_ptr(), float(timeout_s)))
+
     def rccl_count(self) -> int:
         """the communicator size as RCCL reports it (ncclCommCount); 0 for a loop-back group"""
         return int(_lib.load().ls_amd_comm_rccl_count(self.h))

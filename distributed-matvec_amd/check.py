@@ -129,7 +129,7 @@ class HipEngine:
     def states(self, cfg):
         basis = self._load(cfg, False)
         basis.build()
-        return np.asarray(basis.representatives()).view(np.uint64)
+        return np.array(basis.representatives(), dtype=np.uint64, copy=True)  # (a view into the basis' own memory otherwise)
 
     def matvec(self, cfg, x_block, numLocales):
         import torch

@@ -153,6 +153,34 @@ static int agree(ls_amd_comm *cm, int rc, void *stream) {
     return flag ? -1 : 0;
 }
 
+/* Set-up cross-check of an exchange layout, collective (comm.cpp, lsk_comm_check_counts): what s sends to d in segment k must be
+ * what d expects -- verified for every pair on every rank, so that a disagreement ends the set-up with a message on ALL ranks
+ * instead of a hang (RCCL) or misplaced data in the first matvec.  A rank whose set-up already failed enters with zeros (its
+ * peers must not wait for it) and keeps its own status. */
+static int check_layout(ls_amd_comm *cm, int K, int64_t const *sb, int64_t const *rb, char const *what, int rc_in, void *stream) {
+    int const P = lsk_comm_size(cm->c);
+    int64_t *z = NULL;
+    if (!sb || !rb || rc_in != 0) { z = (int64_t *)calloc((size_t)(K > 0 ? K : 1) * (size_t)P, 8); sb = rb = z; }
+    int const rc = lsk_comm_check_counts(cm->c, K, sb, rb, what, stream);
+    free(z);
+    if (rc != 0 && rc_in == 0) return ls_amd_internal_error("%s", lsk_comm_last_error());
+    return rc_in;
+}
+/* test hook (ls_amd.h): rank `rank` announces / sends `delta` bytes more (less) to its right neighbour than that one expects.
+ * late == 0: in the layout the set-up check sees (ls_amd_dist_create / ls_amd_repl_create must fail on every rank);
+ * late == 1: after the check, i.e. a run-time fault (the loop-back transport cross-checks every exchange; its ranks then meet a
+ * rendezvous with a deadline instead of waiting for ever).  rank < 0: off. */
+static int g_skew_rank = -1, g_skew_late = 0;
+static int64_t g_skew_delta = 0;
+void ls_amd_test_skew_exchange(int rank, int64_t delta_bytes, int late) { g_skew_rank = rank; g_skew_delta = delta_bytes; g_skew_late = late; }
+static void apply_skew(int me, int P, int late, int64_t *send_bytes) {
+    if (g_skew_rank != me || g_skew_late != late || P < 2) return;
+    int64_t *b = &send_bytes[(me + 1) % P];
+    if (*b + g_skew_delta >= 0) *b += g_skew_delta;
+}
+int ls_amd_comm_wait(ls_amd_comm *cm, void *stream, double timeout_s) { COMM(lsk_comm_wait(cm->c, stream, timeout_s)); return 0; }
+int ls_amd_comm_test_stall(ls_amd_comm *cm, double seconds) { COMM(lsk_comm_test_stall(cm->c, seconds)); return 0; }
+
 /* ============================================================================================ */
 /* PRIMME reductions (host buffers, as PRIMME hands them over)                                  */
 /* ============================================================================================ */
@@ -419,6 +447,9 @@ static int dist_create_impl(ls_amd_dist **out, ls_amd_comm *cm, ls_hs_operator c
     }
     if (rc == 0) { memcpy(d->scat_off, d->recv_off, sizeof(int64_t) * m); memcpy(d->scat_counts, d->recv_counts, sizeof(int64_t) * m); }
     free(all);
+    if (rc == 0) apply_skew(me, P, 0, d->send_bytes);
+    rc = check_layout(cm, num_rounds, d->send_bytes, d->recv_bytes, "ls_amd_dist_create (packets, one segment per round)", rc, stream);
+    if (rc == 0) apply_skew(me, P, 1, d->send_bytes);
     for (int i = 0; i < 2 && rc == 0; ++i)
         if (lsk_malloc(&d->d_send[i], (size_t)(max_send > 0 ? max_send : 8)) != 0 ||
             lsk_malloc(&d->d_recv[i], (size_t)(max_recv > 0 ? max_recv : 8)) != 0)
@@ -459,6 +490,13 @@ int ls_amd_test_corrupt_dist(ls_amd_dist *d) {
 static int exchange(ls_amd_dist *d, int r, void *stream) {
     size_t const k = (size_t)r * d->P;
     int const slot = r & 1;
+    {
+        char tag[160];
+        int64_t out = 0, in = 0;
+        for (int q = 0; q < d->P; ++q) if (q != d->me) { out += d->send_bytes[k + (size_t)q]; in += d->recv_bytes[k + (size_t)q]; }
+        snprintf(tag, sizeof(tag), "packets: round %d of %d, %lld bytes out, %lld bytes in", r, d->rounds, (long long)out, (long long)in);
+        lsk_comm_set_tag(d->comm->c, tag);
+    }
     COMM(lsk_comm_exchange_begin(d->comm->c, slot, stream));
     COMM(lsk_comm_alltoallv(d->comm->c, d->d_send[slot], d->send_off + k, d->send_bytes + k, d->d_recv[slot], d->recv_off + k,
                             d->recv_bytes + k));
@@ -800,6 +838,19 @@ int ls_amd_repl_create(ls_amd_repl **out, ls_amd_comm *cm, ls_hs_operator const 
             rc = setup_reach(r, d_masks, rc, stream);
         }
     }
+    /* every exchange layout of the object, cross-checked between all ranks before the first matvec can use it */
+    if (rc == 0) apply_skew(me, P, 0, r->xs_bytes);
+    rc = check_layout(cm, 1, r->xs_bytes, r->xr_bytes, "ls_amd_repl_create (blocks of x)", rc, stream);
+    rc = check_layout(cm, 1, r->ys_bytes, r->yr_bytes, "ls_amd_repl_create (rows of y back to their owners)", rc, stream);
+    {   /* (the sub-range layout exists on every rank or on none: setup_reach agreed on it -- but a rank that failed since enters too) */
+        int64_t has_reach = r->reach_k > 0;
+        if (cm->d_status && lsk_h2d(cm->d_status, &has_reach, sizeof(has_reach)) == 0 && lsk_comm_allreduce(cm->c, cm->d_status, 1, 2, 1, stream) == 0 &&
+            lsk_sync(stream) == 0 && lsk_d2h(&has_reach, cm->d_status, sizeof(has_reach)) == 0) {
+            if (has_reach) rc = check_layout(cm, REACH_K, r->reach_k > 0 ? r->rx_sbytes : NULL, r->reach_k > 0 ? r->rx_rbytes : NULL,
+                                             "ls_amd_repl_create (sub-range exchange of x)", rc, stream);
+        } else if (rc == 0) rc = ls_amd_internal_error("layout agreement failed: %s", lsk_comm_last_error());
+    }
+    if (rc == 0) apply_skew(me, P, 1, r->xs_bytes);
     if (agree(cm, rc, stream) != 0) { ls_amd_repl_destroy(r); return -1; } /* buffers and plan exist on every rank, or the object on none */
     *out = r;
     ls_amd_internal_clear_error();
@@ -832,6 +883,7 @@ int ls_amd_repl_matvec(ls_amd_repl *r, void const *d_x_local, void *d_y_local, v
         if (r->P > 1 && ls_amd_internal_plan_split_rows(r->plan) > 0) {
             /* compute stream:  x n(rep) | ready |  RESOLVE (no x) ..................... | wait done | GATHER
              * exchange stream:          wait ready | grouped send/recv of the blocks | done                  */
+            lsk_comm_set_tag(r->comm->c, "replicated x: blocks of x n(rep) to every peer, overlapped with slot resolution");
             COMM(lsk_comm_exchange_begin(r->comm->c, 0, stream));
             TRY(ls_amd_internal_repl_split_begin(r->plan, stream));
             COMM(lsk_comm_alltoallv(r->comm->c, r->d_gathered, r->xs_off, r->xs_bytes, r->d_gathered, r->xr_off, r->xr_bytes));
@@ -841,6 +893,7 @@ int ls_amd_repl_matvec(ls_amd_repl *r, void const *d_x_local, void *d_y_local, v
             ls_amd_internal_stage_end(r->plan, st, stream);
         } else {
             st = ls_amd_internal_stage_begin(r->plan, ST_EXCHANGE, stream);
+            lsk_comm_set_tag(r->comm->c, "replicated x: blocks of x to every peer");
             if (r->P > 1) COMM(lsk_comm_alltoallv_on(r->comm->c, stream, r->d_gathered, r->xs_off, r->xs_bytes, r->d_gathered, r->xr_off, r->xr_bytes));
             ls_amd_internal_stage_end(r->plan, st, stream);
             TRY(ls_amd_internal_repl_split_begin(r->plan, stream)); /* (one rank with a forced packet buffer: nothing to hide behind) */
@@ -849,6 +902,7 @@ int ls_amd_repl_matvec(ls_amd_repl *r, void const *d_x_local, void *d_y_local, v
     } else {
         /* 1. blocks of x: mine by a device copy, the others straight from their owners */
         int st = ls_amd_internal_stage_begin(r->plan, ST_EXCHANGE, stream);
+        lsk_comm_set_tag(r->comm->c, r->reach_k > 0 ? "replicated x: sub-range exchange of x" : "replicated x: blocks of x to every peer");
         DEVC(lsk_d2d_async((char *)r->d_gathered + r->xr_off[r->me], d_x_local, (size_t)(r->counts[r->me] * w), stream));
         if (r->reach_k > 0) /* only what my rows read: <= REACH_K contiguous pieces of every owner's block, in one group */
             COMM(lsk_comm_alltoallv_multi_on(r->comm->c, stream, r->reach_k, d_x_local, r->rx_soff, r->rx_sbytes, r->d_gathered, r->rx_roff, r->rx_rbytes));
@@ -874,6 +928,7 @@ int ls_amd_repl_matvec(ls_amd_repl *r, void const *d_x_local, void *d_y_local, v
     /* the pieces land in y itself (y is assigned), or in a staging buffer that is then added to y (no diagonal terms) */
     void *dst = r->accumulate ? r->d_yrecv : d_y_local;
     DEVC(lsk_d2d_async((char *)dst + r->yr_off[r->me], (char *)r->d_ysend + r->ys_off[r->me], (size_t)r->y_self_bytes, stream));
+    lsk_comm_set_tag(r->comm->c, "replicated x: rows of y back to their owners");
     if (r->P > 1) COMM(lsk_comm_alltoallv_on(r->comm->c, stream, r->d_ysend, r->ys_off, r->ys_bytes, dst, r->yr_off, r->yr_bytes));
     if (r->accumulate) DEVC(lsk_add_into(r->cplx, r->counts[r->me], r->d_yrecv, d_y_local, stream));
     ls_amd_internal_stage_end(r->plan, st_ret, stream);

@@ -2010,9 +2010,19 @@ static int build_tilemap(ls_amd_plan *pl, int64_t n, int TILE) {
 }
 /* test hook (ls_amd.h): the row kernel of a one-process plan skips ONE row -- the first tile of XCD 0's list loses its last row, so
  * that row's y is never written (pull) or its contributions never leave (push).  Memory-safe: a shorter tile reads nothing new.
- * Returns 1 when a tile was shortened, 0 when the plan has no tile map (packet plans) or only one-row tiles. */
+ * Returns 1 when plan data was corrupted, 0 when the plan has neither a tile map nor per-row norms (packet plans). */
 int ls_amd_test_corrupt_plan(ls_amd_plan *pl) {
-    if (!pl || !pl->d_tilemap || pl->tilemap.slots_per_xcd <= 0) return 0;
+    if (!pl) return 0;
+    if (pl->family == FAMILY_TILE_PULL && pl->n_local == 1 && pl->parts[0].d_norms && pl->parts[0].count > 0) {
+        /* projected pull plans walk their tiles by arithmetic, not through the map: ONE per-row norm is doubled instead -- that
+         * row's y and the contributions it makes to its partners come out wrong (plan data the kernel reads; memory-safe) */
+        double v = 0;
+        double *p = pl->parts[0].d_norms + pl->parts[0].count / 2;
+        if (lsk_device_sync() != 0 || lsk_d2h(&v, p, sizeof(v)) != 0) return 0;
+        v *= 2.0;
+        return lsk_h2d(p, &v, sizeof(v)) == 0;
+    }
+    if (!pl->d_tilemap || pl->tilemap.slots_per_xcd <= 0) return 0;
     uint64_t e = 0;
     if (lsk_device_sync() != 0 || lsk_d2h(&e, pl->d_tilemap, sizeof(e)) != 0) return 0;
     uint64_t const rows = e >> 48;

@@ -492,6 +492,13 @@ int lsk_comm_alltoallv_multi_on(lsk_comm *c, void *stream, int K, void const *d_
 int lsk_comm_alltoallv_on(lsk_comm *c, void *stream, void const *d_send, int64_t const *send_off, int64_t const *send_bytes,
                           void *d_recv, int64_t const *recv_off, int64_t const *recv_bytes);
 int lsk_comm_exchange_wait(lsk_comm *c, int slot, void *compute_stream);
+/* never hang (comm.cpp): what the next exchange is, for the watchdog's message; a deadline wait on `stream` + the exchange stream
+ * (rc -1 with a message instead of a hung hipStreamSynchronize); the collective set-up cross-check of an exchange layout
+ * ([K][size] byte counts: what s sends to d == what d expects from s, on every rank alike); test hook: stall the exchange stream */
+void lsk_comm_set_tag(lsk_comm *c, char const *what);
+int lsk_comm_wait(lsk_comm *c, void *stream, double timeout_s);
+int lsk_comm_check_counts(lsk_comm *c, int K, int64_t const *send_bytes, int64_t const *recv_bytes, char const *what, void *stream);
+int lsk_comm_test_stall(lsk_comm *c, double seconds);
 
 #ifdef __cplusplus
 }

@@ -211,6 +211,20 @@ void ls_amd_test_fail_stream_buffers(int on);
  * consumers and the default rows per round (the verdict of every set-up step is collective) */
 void ls_amd_test_fail_dist_streams(int on);
 int ls_amd_test_corrupt_repl(ls_amd_repl *repl);
+/* Never hang (csrc/comm.cpp).  Every exchange layout is cross-checked between all ranks at set-up (what s sends to d == what d
+ * expects from s; ls_amd_dist_create / ls_amd_repl_create fail on EVERY rank with the segment, the two ranks and both byte counts).
+ * At run time a watchdog thread per RCCL communicator ends the process (exit code 86, message on stderr: rank, what was in
+ * flight, for how long) when a collective or an exchange has not completed LS_AMD_COMM_WATCHDOG_S seconds (default 300, 0 = off)
+ * after it was issued -- a dead peer or mismatched counts would otherwise leave every rank in a stream synchronisation for ever;
+ * loop-back groups meet at a rendezvous with the same deadline.  ls_amd_comm_wait is the polite form: it waits until `stream` and
+ * the communicator's exchange stream have drained, or returns -1 (message in ls_amd_last_error) after timeout_s (<= 0: the
+ * watchdog's deadline). */
+int ls_amd_comm_wait(ls_amd_comm *comm, void *stream, double timeout_s);
+/* test hooks: rank `rank` sends delta_bytes more (less) to its right neighbour than that one expects -- late == 0: in the layout the
+ * set-up check sees, late == 1: after it (a run-time fault); rank < 0 switches it off.  ls_amd_comm_test_stall: the exchange
+ * stream of an RCCL communicator stalls for `seconds` behind an armed watchdog item. */
+void ls_amd_test_skew_exchange(int rank, int64_t delta_bytes, int late);
+int ls_amd_comm_test_stall(ls_amd_comm *comm, double seconds);
 /* ... and the one-GPU counterpart (`bench.py --inject-fault` at N = 1): the row kernel of a plan whose partitions all live in this
  * process skips one row of the first tile (memory-safe); 1 when a tile was shortened, 0 when the plan has no tile map. */
 int ls_amd_test_corrupt_plan(ls_amd_plan *plan);

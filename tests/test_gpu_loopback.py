@@ -482,3 +482,147 @@ def test_self_verification_catches_a_misplaced_segment(name, P, cplx, mode):
         assert faulty[r]["rows_off"] > 0 and faulty[r]["max_rel_err"] > 1e-6
     for c in comms:
         c.destroy()
+
+
+# ---- never hang (VERDICT r5 #1b): mismatched exchange layouts end with an error on EVERY rank, quickly -------------------------
+
+@pytest.mark.parametrize("mode", ["packets", "replicated"])
+@pytest.mark.parametrize("name,P", [("heisenberg_chain_16", 3), ("heisenberg_chain_24_symm", 2)])
+def test_layout_mismatch_is_caught_at_setup_on_every_rank(name, P, mode):
+    """One rank announces 8 bytes less for its right neighbour than that neighbour expects (ls_amd_test_skew_exchange, late = 0).
+    The set-up cross-check (all-gather of every rank's send AND receive counts, every pair verified on every rank) must fail
+    ls_amd_dist_create / ls_amd_repl_create on ALL ranks, name the two ranks and both byte counts, and start no exchange."""
+    import time
+
+    import torch
+
+    import distributed_matvec_amd as D
+    from distributed_matvec_amd import _lib
+    from distributed_matvec_amd.distributed import RcclDistributedOperator, RcclReplicatedOperator
+
+    basis, h = D.loadConfigFromDict(model_config(name), hamiltonian=True)
+    reps, masks = D.enumerateStates(basis, P)
+    reps_global = D.arrFromHashedToBlock(reps, masks)
+    messages = [None] * P
+    L = _lib.load()
+    L.ls_amd_test_skew_exchange(1, -8, 0)
+    t0 = time.monotonic()
+    try:
+        def body(rank, comm):
+            try:
+                if mode == "packets":
+                    RcclDistributedOperator(h, reps[rank], torch.float64, comm=comm, num_rounds=2)
+                else:
+                    RcclReplicatedOperator(h, reps_global, masks, torch.float64, comm=comm)
+            except D.LsAmdError as e:
+                messages[rank] = str(e)
+
+        comms = _run_ranks(P, body)
+    finally:
+        L.ls_amd_test_skew_exchange(-1, 0, 0)
+    assert time.monotonic() - t0 < 30
+    for r, m in enumerate(messages):
+        assert m is not None, f"rank {r} built its operator on a layout its peers contradict"
+        assert "exchange layouts disagree" in m and f"rank 1 sends" in m and f"to rank {2 % P}" in m and "which expects" in m, m
+    # the same group still works afterwards: nothing was left half-open
+    ys = [None] * P
+
+    def body2(rank, comm):
+        op = RcclDistributedOperator(h, reps[rank], torch.float64, comm=comm, num_rounds=2)
+        x = D.fillRandom(reps[rank], 3, torch.float64)
+        ys[rank] = torch.zeros_like(x)
+        op.matvec(x, ys[rank], check=True)
+        op.dm.destroy()
+
+    for c in comms:
+        c.destroy()
+    comms = _run_ranks(P, body2)
+    for c in comms:
+        c.destroy()
+
+
+def test_run_time_mismatch_ends_with_an_error_not_a_hang(monkeypatch):
+    """A fault AFTER the set-up check (late = 1): one rank's send segment shrinks by 8 bytes.  The loop-back transport cross-checks
+    every exchange (the receiver sees the announced count), the receiver fails, and its peers -- who would wait for it in their
+    next rendezvous for ever -- give up at the deadline (LS_AMD_COMM_WATCHDOG_S): every rank ends with rc != 0 in well under 30 s."""
+    import time
+
+    import torch
+
+    import distributed_matvec_amd as D
+    from distributed_matvec_amd import _lib
+    from distributed_matvec_amd.distributed import RcclDistributedOperator
+
+    monkeypatch.setenv("LS_AMD_COMM_WATCHDOG_S", "3")
+    name, P = "heisenberg_chain_16", 3
+    basis, h = D.loadConfigFromDict(model_config(name), hamiltonian=True)
+    reps, _masks = D.enumerateStates(basis, P)
+    L = _lib.load()
+    outcome = [None] * P
+    L.ls_amd_test_skew_exchange(0, -8, 1)
+    t0 = time.monotonic()
+    try:
+        def body(rank, comm):
+            op = RcclDistributedOperator(h, reps[rank], torch.float64, comm=comm, num_rounds=2)
+            x = D.fillRandom(reps[rank], 3, torch.float64)
+            y = torch.zeros_like(x)
+            try:
+                for _ in range(3):
+                    op.matvec(x, y, check=True)
+                outcome[rank] = "completed"
+            except D.LsAmdError as e:
+                outcome[rank] = str(e)
+
+        _run_ranks(P, body)
+    finally:
+        L.ls_amd_test_skew_exchange(-1, 0, 0)
+    took = time.monotonic() - t0
+    assert took < 30, took
+    assert all(o is not None and o != "completed" for o in outcome), outcome
+    assert any("sends" in o and "which expects" in o for o in outcome), outcome          # the receiver names the mismatch
+    assert any("gave up" in o and "ranks arrived" in o for o in outcome), outcome          # its peers hit the deadline
+    # (the group is broken for good: its communicators are abandoned, not destroyed -- a destroy would synchronise streams)
+
+
+def test_rccl_watchdog_ends_a_stalled_exchange(tmp_path):
+    """The watchdog thread of an RCCL communicator: an exchange-stream event that has not completed by the deadline ends the process
+    with exit code 86 and says which rank, what was in flight and for how long.  (One RCCL rank on this box: the stall is a host
+    callback on the exchange stream, armed exactly like an exchange -- lsk_comm_test_stall.)  ls_amd_comm_wait, the polite form,
+    returns an error for the same stall instead of hanging in a synchronisation."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import os, sys, time
+sys.path.insert(0, %r)
+import torch
+import distributed_matvec_amd as D
+from distributed_matvec_amd import _lib
+torch.cuda.set_device(0)
+mode = sys.argv[1]
+comm = D.Communicator(1, 0, D.Communicator.unique_id())
+L = _lib.load()
+assert L.ls_amd_comm_test_stall(comm.h, 12.0) == 0
+if mode == "polite":
+    t0 = time.monotonic()
+    try:
+        comm.wait(2.0)
+    except D.LsAmdError as e:
+        print("POLITE", round(time.monotonic() - t0, 1), str(e), flush=True)
+        os._exit(0)
+    print("NO ERROR", flush=True)
+    os._exit(1)
+torch.cuda.synchronize()   # what a hung job does: sits in a synchronisation
+print("SURVIVED", flush=True)
+''' % root
+    env = dict(os.environ, LS_AMD_COMM_WATCHDOG_S="3")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, "-c", code, "watchdog"], capture_output=True, text=True, timeout=120, env=env)
+    assert p.returncode == 86, (p.returncode, p.stdout[-500:], p.stderr[-1500:])
+    assert "libls_amd watchdog: rank 0 of 1" in p.stderr and "not complete" in p.stderr and "test stall" in p.stderr, p.stderr[-1500:]
+    assert "SURVIVED" not in p.stdout
+    env["LS_AMD_COMM_WATCHDOG_S"] = "60"
+    p = subprocess.run([sys.executable, "-c", code, "polite"], capture_output=True, text=True, timeout=120, env=env)
+    assert p.returncode == 0 and "POLITE" in p.stdout and "has not drained" in p.stdout, (p.returncode, p.stdout[-800:], p.stderr[-800:])
