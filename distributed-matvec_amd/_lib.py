@@ -168,6 +168,7 @@ def load():
         "ls_amd_test_fail_dist_streams": (None, [C.c_int]),
         "ls_amd_test_corrupt_repl": (C.c_int, [vp]),
         "ls_amd_test_corrupt_plan": (C.c_int, [vp]),
+        "ls_amd_internal_plan_split_active": (C.c_int64, [vp]),
         "ls_amd_comm_wait": (C.c_int, [vp, vp, C.c_double]),
         "ls_amd_test_skew_exchange": (None, [C.c_int, C.c_int64, C.c_int]),
         "ls_amd_comm_test_stall": (C.c_int, [vp, C.c_double]),

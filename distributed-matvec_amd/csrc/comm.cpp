@@ -179,6 +179,8 @@ struct lsk_comm {
     int size, rank;
     hipStream_t xstream;     // exchange stream: the collectives of round r overlap the kernels of round r +- 1
     hipEvent_t ready[2], done[2];
+    hipEvent_t xt0[2], xt1[2]; // timing pair around the exchange of a slot, on the exchange stream (lsk_comm_exchange_ms)
+    bool xt_recorded[2];
     LocalGroup *local;       // non-null: loop-back transport
     Watchdog *wd;            // RCCL communicators with a deadline; else null
     char tag[160];           // what the next exchange is (set by the C host: round, bytes), for the watchdog's message
@@ -296,17 +298,21 @@ extern "C" int lsk_comm_unique_id(void *id128) {
 // stream + event pairs of a communicator; on failure everything created so far is released again
 static int comm_resources(lsk_comm *c) {
     c->xstream = nullptr;
-    for (int i = 0; i < 2; ++i) c->ready[i] = c->done[i] = nullptr;
+    for (int i = 0; i < 2; ++i) { c->ready[i] = c->done[i] = c->xt0[i] = c->xt1[i] = nullptr; c->xt_recorded[i] = false; }
     hipError_t e = hipStreamCreateWithFlags(&c->xstream, hipStreamNonBlocking);
     for (int i = 0; i < 2 && e == hipSuccess; ++i) {
         e = hipEventCreateWithFlags(&c->ready[i], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->done[i], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreate(&c->xt0[i]);
+        if (e == hipSuccess) e = hipEventCreate(&c->xt1[i]);
     }
     if (e == hipSuccess) return 0;
     snprintf(g_cerr, sizeof(g_cerr), "communicator stream / events: %s", hipGetErrorString(e));
     for (int i = 0; i < 2; ++i) {
         if (c->ready[i]) (void)hipEventDestroy(c->ready[i]);
         if (c->done[i]) (void)hipEventDestroy(c->done[i]);
+        if (c->xt0[i]) (void)hipEventDestroy(c->xt0[i]);
+        if (c->xt1[i]) (void)hipEventDestroy(c->xt1[i]);
     }
     if (c->xstream) (void)hipStreamDestroy(c->xstream);
     return -1;
@@ -348,7 +354,7 @@ extern "C" int lsk_comm_create_local(lsk_comm **out, int size) {
         if (comm_resources(c) != 0) { // unwind: the ranks created so far, the barrier, the group
             delete c;
             for (int q = 0; q < r; ++q) {
-                for (int i = 0; i < 2; ++i) { (void)hipEventDestroy(out[q]->ready[i]); (void)hipEventDestroy(out[q]->done[i]); }
+                for (int i = 0; i < 2; ++i) { (void)hipEventDestroy(out[q]->ready[i]); (void)hipEventDestroy(out[q]->done[i]); (void)hipEventDestroy(out[q]->xt0[i]); (void)hipEventDestroy(out[q]->xt1[i]); }
                 (void)hipStreamDestroy(out[q]->xstream);
                 delete out[q];
                 out[q] = nullptr;
@@ -370,14 +376,14 @@ extern "C" void lsk_comm_destroy(lsk_comm *c) {
         const bool last = --c->local->refs == 0;
         pthread_mutex_unlock(&g_local_lock);
         if (last) delete c->local;
-        for (int i = 0; i < 2; ++i) { (void)hipEventDestroy(c->ready[i]); (void)hipEventDestroy(c->done[i]); }
+        for (int i = 0; i < 2; ++i) { (void)hipEventDestroy(c->ready[i]); (void)hipEventDestroy(c->done[i]); (void)hipEventDestroy(c->xt0[i]); (void)hipEventDestroy(c->xt1[i]); }
         (void)hipStreamDestroy(c->xstream);
         delete c;
         return;
     }
     watchdog_stop(c);
     if (g_api.CommDestroy) (void)g_api.CommDestroy(c->comm);
-    for (int i = 0; i < 2; ++i) { (void)hipEventDestroy(c->ready[i]); (void)hipEventDestroy(c->done[i]); }
+    for (int i = 0; i < 2; ++i) { (void)hipEventDestroy(c->ready[i]); (void)hipEventDestroy(c->done[i]); (void)hipEventDestroy(c->xt0[i]); (void)hipEventDestroy(c->xt1[i]); }
     (void)hipStreamDestroy(c->xstream);
     delete c;
 }
@@ -459,6 +465,16 @@ extern "C" int lsk_comm_allgather(lsk_comm *c, void const *d_send, void *d_recv,
 extern "C" int lsk_comm_exchange_begin(lsk_comm *c, int slot, void *compute_stream) {
     HIP_CHECK(hipEventRecord(c->ready[slot], (hipStream_t)compute_stream));
     HIP_CHECK(hipStreamWaitEvent(c->xstream, c->ready[slot], 0));
+    HIP_CHECK(hipEventRecord(c->xt0[slot], c->xstream)); // the exchange could start here: everything behind it is wire (and peers)
+    return 0;
+}
+// how long the last completed exchange of `slot` took on the exchange stream, from "this rank was ready" to "everything arrived":
+// 0 = *ms is valid, 1 = not recorded yet / still running, -1 = error.  Never blocks.
+extern "C" int lsk_comm_exchange_ms(lsk_comm *c, int slot, float *ms) {
+    if (!c->xt_recorded[slot]) return 1;
+    const hipError_t q = hipEventQuery(c->xt1[slot]);
+    if (q == hipErrorNotReady) return 1;
+    if (q != hipSuccess || hipEventElapsedTime(ms, c->xt0[slot], c->xt1[slot]) != hipSuccess) { (void)hipGetLastError(); return -1; }
     return 0;
 }
 // K segments per peer in one call: segment k for / from peer p is entry [k * size + p] of the offset / byte arrays (a
@@ -555,6 +571,8 @@ extern "C" int lsk_comm_exchange_end(lsk_comm *c, int slot) {
         std::lock_guard<std::mutex> lk(c->wd->m);
         HIP_CHECK(hipEventRecord(c->done[slot], c->xstream));
     } else HIP_CHECK(hipEventRecord(c->done[slot], c->xstream));
+    HIP_CHECK(hipEventRecord(c->xt1[slot], c->xstream));
+    c->xt_recorded[slot] = true;
     char what[200];
     snprintf(what, sizeof(what), "grouped ncclSend/ncclRecv on the exchange stream (%s)", c->tag[0] ? c->tag : "all-to-all-v");
     watchdog_arm(c, slot, what);

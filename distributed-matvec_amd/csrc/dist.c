@@ -40,6 +40,10 @@ int64_t ls_amd_internal_plan_split_enable(ls_amd_plan *pl, int64_t max_bytes);
 int64_t ls_amd_internal_plan_split_rows(ls_amd_plan const *pl);
 int ls_amd_internal_repl_split_begin(ls_amd_plan *pl, void *stream);
 int ls_amd_internal_repl_split_finish(ls_amd_plan *pl, void const *d_x_global, void *d_y_local, void *stream);
+int ls_amd_internal_repl_split_rows(ls_amd_plan *pl, void const *d_x_global, void *d_y_local, int64_t row0, int64_t row1, int count, void *stream);
+void ls_amd_internal_plan_split_set_active(ls_amd_plan *pl, int64_t rows);
+int64_t ls_amd_internal_plan_split_active(ls_amd_plan const *pl);
+int ls_amd_internal_plan_slot_cached(ls_amd_plan const *pl);
 /* host.c: static index tables shared per (global basis, partition layout) and the indexed replicated-x plan */
 typedef struct ls_amd_gtab ls_amd_gtab;
 int ls_amd_internal_gtab_acquire(ls_amd_gtab **out, int L, uint64_t const *d_reps, int64_t n, uint8_t const *d_masks, int P, void *stream);
@@ -563,6 +567,21 @@ struct ls_amd_repl {
     int64_t x_in_bytes;              /* bytes of x this rank receives per matvec */
     ls_amd_gtab *gt;                 /* static {rep -> slot} table + global row -> slot permutation (shared, host.c) */
     double *d_norms_own;             /* norm(rep) of the representatives this rank owns (K4 modes that prescale), else NULL */
+    /* Chunked return (indexed mode, P > 1; VERDICT r5 #1a): my rows are computed in yc chunks, and the rows of chunk c travel back
+     * to their owners on the exchange stream while chunk c + 1 is gathered -- the reference's consumers drain while its producers
+     * still compute (DMV:957-1011, :739-853).  Inside an owner's group the rows ascend, so a chunk's rows are ONE contiguous piece of
+     * every group: no second permutation, only the boundaries yc_pos. */
+    int yc;                          /* 0: one return for all rows */
+    int corrupt;                     /* ls_amd_test_corrupt_repl */
+    int64_t yc_row[9];               /* chunk c = rows [yc_row[c], yc_row[c + 1]) of my range; multiples of 256 */
+    int64_t *yc_pos;                 /* [(yc + 1) * P] rows of owner p below boundary c (elements inside p's group) */
+    int64_t *yc_soff, *yc_sbytes, *yc_roff, *yc_rbytes; /* [yc * P] */
+    /* Adaptive split (indexed mode, P > 1): slot resolution hides the exchange of x, but the split form costs ~8 % more device time
+     * than the fused kernel -- so only as many rows are resolved ahead as the exchange takes; the rest runs fused afterwards.
+     * Times of the previous matvec (HIP events, read without blocking): resolve over `adapt_rows` rows, exchange of slot 0. */
+    int adapt;
+    void *ev_res[2];
+    int64_t adapt_rows;              /* rows the pending resolve sample covers; 0 = no sample pending */
 };
 
 void ls_amd_repl_destroy(ls_amd_repl *r) {
@@ -577,6 +596,8 @@ void ls_amd_repl_destroy(ls_amd_repl *r) {
     free(r->xs_off); free(r->xs_bytes); free(r->xr_off); free(r->xr_bytes);
     free(r->ys_off); free(r->ys_bytes); free(r->yr_off); free(r->yr_bytes);
     free(r->rx_soff); free(r->rx_sbytes); free(r->rx_roff); free(r->rx_rbytes);
+    free(r->yc_pos); free(r->yc_soff); free(r->yc_sbytes); free(r->yc_roff); free(r->yc_rbytes);
+    for (int i = 0; i < 2; ++i) if (r->ev_res[i]) lsk_event_destroy(r->ev_res[i]);
     free(r);
 }
 
@@ -704,6 +725,62 @@ static int setup_reach(ls_amd_repl *r, uint8_t const *d_masks, int rc_in, void *
     return agree(cm, rc, stream);
 }
 
+/* Collective.  Lays out the chunked return (see struct ls_amd_repl).  LS_AMD_REPL_RETURN_CHUNKS = 0 (off) .. 8; default 4 when every
+ * rank computes at least 2^16 rows per chunk -- decided from the GLOBAL row count, so every rank decides alike. */
+static int setup_return_chunks(ls_amd_repl *r, uint8_t const *d_masks, int indexed, int rc_in, void *stream) {
+    ls_amd_comm *cm = r->comm;
+    int const P = r->P, me = r->me;
+    int64_t const nb = r->n1 - r->n0, w = r->w;
+    int yc = 0;
+    if (indexed && P > 1 && P <= 64) {
+        char const *e = getenv("LS_AMD_REPL_RETURN_CHUNKS");
+        yc = e ? atoi(e) : 4;
+        if (yc > 8) yc = 8;
+        if (!e) while (yc > 1 && r->n / P / yc < ((int64_t)1 << 16)) yc /= 2;
+        if (yc < 2 || r->n / P < (int64_t)256 * yc) yc = 0;
+    }
+    if (yc == 0) return rc_in;
+    int rc = rc_in;
+    size_t const m = (size_t)yc * (size_t)P;
+    int64_t *cc = (int64_t *)calloc(m, 8), *all = (int64_t *)calloc(m * (size_t)P, 8);
+    r->yc_pos = (int64_t *)calloc((size_t)(yc + 1) * (size_t)P, 8);
+    r->yc_soff = (int64_t *)calloc(m, 8); r->yc_sbytes = (int64_t *)calloc(m, 8);
+    r->yc_roff = (int64_t *)calloc(m, 8); r->yc_rbytes = (int64_t *)calloc(m, 8);
+    for (int c = 0; c <= yc; ++c) r->yc_row[c] = c == yc ? nb : (nb * c / yc) & ~(int64_t)255;
+    for (int c = 0; c < yc && rc == 0; ++c) {
+        int64_t const a = r->yc_row[c], b = r->yc_row[c + 1];
+        if (b > a) rc = ls_amd_mask_counts(b - a, d_masks + r->n0 + a, P, cc + (size_t)c * P, stream);
+        for (int p = 0; p < P; ++p) r->yc_pos[(size_t)(c + 1) * P + p] = r->yc_pos[(size_t)c * P + p] + cc[(size_t)c * P + p];
+    }
+    void *ds = NULL;
+    if (rc == 0) rc = scratch(cm, 8 * m * (size_t)(P + 1), &ds);
+    if (rc == 0 && lsk_h2d(ds, cc, 8 * m) != 0) rc = ls_amd_internal_error("%s", lsk_last_error());
+    rc = agree(cm, rc, stream); /* every rank enters the all-gather below, or none does */
+    if (rc == 0 && lsk_comm_allgather(cm->c, ds, (char *)ds + 8 * m, (int64_t)(8 * m), stream) != 0) rc = ls_amd_internal_error("%s", lsk_comm_last_error());
+    if (rc == 0 && (lsk_sync(stream) != 0 || lsk_d2h(all, (char *)ds + 8 * m, 8 * m * (size_t)P) != 0)) rc = ls_amd_internal_error("%s", lsk_last_error());
+    if (rc == 0) {
+        for (int p = 0; p < P; ++p) {
+            int64_t from_p = 0; /* rows of my partition in rank p's chunks so far */
+            for (int c = 0; c < yc; ++c) {
+                size_t const k = (size_t)c * P + p;
+                r->yc_soff[k] = r->ys_off[p] + r->yc_pos[k] * w;
+                r->yc_sbytes[k] = p == me ? 0 : cc[k] * w;
+                int64_t const cnt = all[(size_t)p * m + (size_t)c * P + me];
+                r->yc_roff[k] = r->yr_off[p] + from_p * w;
+                r->yc_rbytes[k] = p == me ? 0 : cnt * w;
+                from_p += cnt;
+            }
+            if (from_p * w != (p == me ? r->y_self_bytes : r->yr_bytes[p])) rc = ls_amd_internal_error("internal error: chunked return disagrees with the one-piece layout");
+        }
+        if (rc == 0) r->yc = yc;
+    }
+    free(cc); free(all);
+    rc = agree(cm, rc, stream);
+    if (rc == 0) rc = check_layout(cm, yc, r->yc_sbytes, r->yc_rbytes, "ls_amd_repl_create (rows of y back to their owners, per chunk)", rc, stream);
+    else (void)check_layout(cm, yc, NULL, NULL, "ls_amd_repl_create (rows of y back to their owners, per chunk)", rc, stream);
+    return rc;
+}
+
 int ls_amd_repl_create(ls_amd_repl **out, ls_amd_comm *cm, ls_hs_operator const *op, ls_amd_dtype dtype,
                        uint64_t const *d_reps_global, uint8_t const *d_masks, int64_t count_global, void *stream) {
     *out = NULL;
@@ -829,6 +906,12 @@ int ls_amd_repl_create(ls_amd_repl **out, ls_amd_comm *cm, ls_hs_operator const 
         }
     } else if (rc == 0)
         rc = ls_amd_plan_create_replicated(&r->plan, op, dtype, P, me, d_reps_global + r->n0, nb, d_reps_global, count_global, stream);
+    rc = setup_return_chunks(r, d_masks, indexed, rc, stream);
+    if (rc == 0 && indexed && P > 1) {
+        char const *e = getenv("LS_AMD_REPL_ADAPT");
+        r->adapt = !(e && atoi(e) == 0);
+        if (r->adapt && (lsk_event_create(&r->ev_res[0]) != 0 || lsk_event_create(&r->ev_res[1]) != 0)) r->adapt = 0;
+    }
     r->x_in_bytes = (r->n - r->counts[me]) * r->w; /* every peer's block, unless the sub-range exchange below applies */
     if (!indexed && P > 1) {
         /* (collective; LS_AMD_REPL_REACH=0 keeps the exchange of the whole vector -- the same on every rank, like every switch) */
@@ -862,12 +945,69 @@ int ls_amd_test_corrupt_repl(ls_amd_repl *r) {
     if (r->y_self_bytes < 2 * r->w) return 0;
     r->ys_off[r->me] += r->w;
     r->y_self_bytes -= r->w;
+    r->corrupt = 1; /* (chunked return: every own piece starts one row late, the last one is one row shorter) */
     return 1;
 }
 
 ls_amd_plan *ls_amd_repl_plan(ls_amd_repl *r) { return r->plan; }
 int64_t ls_amd_repl_exchange_bytes(ls_amd_repl const *r) { return r->exchange_bytes; }
 int64_t ls_amd_repl_x_in_bytes(ls_amd_repl const *r) { return r->x_in_bytes; }
+
+/* The times of the previous matvec decide how many rows this one resolves ahead: rows = 1.15 x (exchange / resolve rate), moved
+ * half-way from the current value, never below 2^14 rows (the sample must stay measurable) -- or all rows while no sample
+ * exists or the exchange outlasts the resolution of every row. */
+static void adapt_split(ls_amd_repl *r) {
+    float t_res = 0, t_x = 0;
+    if (r->adapt_rows <= 0 || lsk_event_query(r->ev_res[1]) != 0 || lsk_comm_exchange_ms(r->comm->c, 0, &t_x) != 0 ||
+        lsk_event_elapsed_ms(r->ev_res[0], r->ev_res[1], &t_res) != 0 || t_res <= 0) return;
+    int64_t const all = ls_amd_internal_plan_split_rows(r->plan);
+    double const rate = (double)t_res / (double)r->adapt_rows; /* ms per row */
+    double want = (1.15 * (double)t_x + 0.02) / rate;
+    if (want > (double)all) want = (double)all;
+    double next = 0.5 * (double)r->adapt_rows + 0.5 * want;
+    if (next < 16384.0) next = 16384.0;
+    ls_amd_internal_plan_split_set_active(r->plan, next >= (double)all ? 0 : (int64_t)next);
+    r->adapt_rows = 0;
+}
+/* steps 2 + 3 of the indexed matvec with the chunked return: gather chunk c | group its rows by owner | (exchange stream) send
+ * them home while chunk c + 1 is gathered */
+static int repl_rows_chunked(ls_amd_repl *r, void const *x_rows, void *d_y_local, void *stream) {
+    int const P = r->P, me = r->me;
+    int64_t const w = r->w;
+    void *dst = r->accumulate ? r->d_yrecv : d_y_local;
+    for (int c = 0; c < r->yc; ++c) {
+        int64_t const a = r->yc_row[c], b = r->yc_row[c + 1];
+        /* (an empty chunk of mine still takes part in the exchange: my peers' chunk c brings rows of my partition) */
+        TRY(ls_amd_internal_repl_split_rows(r->plan, x_rows, r->d_yblock, a, b, c == 0, stream));
+        int const st_ret = ls_amd_internal_stage_begin(r->plan, ST_RETURN, stream);
+        lsk_ranges R;
+        R.n = P;
+        for (int p = 0; p < P; ++p) {
+            int64_t const g0 = r->ys_off[p] / w - (p == me && r->corrupt ? 1 : 0); /* start of owner p's group in the send buffer (elements) */
+            R.lo[p] = g0 + r->yc_pos[(size_t)c * P + p];
+            R.hi[p] = g0 + r->yc_pos[(size_t)(c + 1) * P + p];
+        }
+        DEVC(lsk_gather_perm_ranges(&R, r->d_yorder, r->yorder64, (int)w, r->d_yblock, r->d_ysend, stream));
+        /* my own piece of the chunk: copied (a corrupted layout -- test hook -- reads it one row late and drops the last row) */
+        int64_t self = (r->yc_pos[(size_t)(c + 1) * P + me] - r->yc_pos[(size_t)c * P + me]) * w;
+        if (r->corrupt && c == r->yc - 1) self -= w;
+        if (self > 0) DEVC(lsk_d2d_async((char *)dst + r->yr_off[me] + r->yc_pos[(size_t)c * P + me] * w,
+                                         (char *)r->d_ysend + r->ys_off[me] + r->yc_pos[(size_t)c * P + me] * w, (size_t)self, stream));
+        char tag[120];
+        snprintf(tag, sizeof(tag), "replicated x: rows of y back to their owners, chunk %d of %d", c + 1, r->yc);
+        lsk_comm_set_tag(r->comm->c, tag);
+        COMM(lsk_comm_exchange_begin(r->comm->c, 1, stream)); /* the exchange stream waits for this chunk's grouping pass */
+        COMM(lsk_comm_alltoallv(r->comm->c, r->d_ysend, r->yc_soff + (size_t)c * P, r->yc_sbytes + (size_t)c * P, dst, r->yc_roff + (size_t)c * P,
+                                r->yc_rbytes + (size_t)c * P));
+        ls_amd_internal_stage_end(r->plan, st_ret, stream);
+    }
+    COMM(lsk_comm_exchange_end(r->comm->c, 1));
+    int const st = ls_amd_internal_stage_begin(r->plan, ST_RETURN, stream); /* what of the return the last chunk's gather did not hide */
+    COMM(lsk_comm_exchange_wait(r->comm->c, 1, stream));
+    if (r->accumulate) DEVC(lsk_add_into(r->cplx, r->counts[me], r->d_yrecv, d_y_local, stream));
+    ls_amd_internal_stage_end(r->plan, st, stream);
+    return 0;
+}
 
 int ls_amd_repl_matvec(ls_amd_repl *r, void const *d_x_local, void *d_y_local, void *stream) {
     int64_t const nb = r->n1 - r->n0, w = r->w;
@@ -884,8 +1024,11 @@ int ls_amd_repl_matvec(ls_amd_repl *r, void const *d_x_local, void *d_y_local, v
             /* compute stream:  x n(rep) | ready |  RESOLVE (no x) ..................... | wait done | GATHER
              * exchange stream:          wait ready | grouped send/recv of the blocks | done                  */
             lsk_comm_set_tag(r->comm->c, "replicated x: blocks of x n(rep) to every peer, overlapped with slot resolution");
+            if (r->adapt) adapt_split(r);
             COMM(lsk_comm_exchange_begin(r->comm->c, 0, stream));
+            if (r->adapt) DEVC(lsk_event_record(r->ev_res[0], stream));
             TRY(ls_amd_internal_repl_split_begin(r->plan, stream));
+            if (r->adapt) { DEVC(lsk_event_record(r->ev_res[1], stream)); r->adapt_rows = ls_amd_internal_plan_slot_cached(r->plan) ? 0 : ls_amd_internal_plan_split_active(r->plan); }
             COMM(lsk_comm_alltoallv(r->comm->c, r->d_gathered, r->xs_off, r->xs_bytes, r->d_gathered, r->xr_off, r->xr_bytes));
             COMM(lsk_comm_exchange_end(r->comm->c, 0));
             st = ls_amd_internal_stage_begin(r->plan, ST_EXCHANGE, stream); /* what of the exchange the resolve kernel did not hide */
@@ -921,6 +1064,7 @@ int ls_amd_repl_matvec(ls_amd_repl *r, void const *d_x_local, void *d_y_local, v
     }
     /* 2. my rows */
     if (r->accumulate) DEVC(lsk_memset_async(r->d_yblock, 0, (size_t)(nb * w), stream));
+    if (r->yc > 0 && ls_amd_internal_plan_split_rows(r->plan) > 0) return repl_rows_chunked(r, x_rows, d_y_local, stream);
     TRY(ls_amd_internal_repl_split_finish(r->plan, x_rows, r->d_yblock, stream)); /* = ls_amd_matvec_replicated when nothing was resolved ahead */
     /* 3. back to the owners: group my rows by owner, keep my own piece, one all-to-all-v for the rest */
     int const st_ret = ls_amd_internal_stage_begin(r->plan, ST_RETURN, stream);

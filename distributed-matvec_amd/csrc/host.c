@@ -1515,6 +1515,8 @@ struct ls_amd_plan {
      * split_rows rows (a multiple of 256, or all of them); 0 = the fused kernel only */
     lsk_pullbuf pbuf;
     int64_t split_rows;
+    int64_t split_active; /* rows [0, split_active) are resolved ahead this matvec (<= split_rows, whole 256-row tiles or all of
+                           * them; 0 = follow split_rows): the replicated-x driver resolves only as many rows as hide its exchange */
     /* slot cache (ls_amd_plan_cache_slots): the packet streams of the split form are plan data -- they depend on the operator,
      * the basis and the partition layout only -- so a plan that is applied many times (an eigensolver) resolves them ONCE and
      * every later matvec is the gather kernel alone.  Opt-in: the path is then no longer matrix-free (5 bytes per non-zero of
@@ -1845,6 +1847,18 @@ int64_t ls_amd_internal_plan_split_enable(ls_amd_plan *pl, int64_t max_bytes) {
     return 0;
 }
 int64_t ls_amd_internal_plan_split_rows(ls_amd_plan const *pl) { return pl->split_rows; }
+/* rows resolved ahead by the NEXT ls_amd_internal_repl_split_begin: a prefix of the rows the packet buffer covers (rounded down
+ * to whole 256-row tiles; <= 0 or >= split_rows: all of them).  A cached plan keeps all its rows. */
+static int64_t split_rows_now(ls_amd_plan const *pl) {
+    if (pl->slot_cache || pl->split_active <= 0 || pl->split_active >= pl->split_rows) return pl->split_rows;
+    return pl->split_active;
+}
+void ls_amd_internal_plan_split_set_active(ls_amd_plan *pl, int64_t rows) {
+    pl->split_active = rows <= 0 ? 0 : (rows & ~(int64_t)255);
+    if (rows > 0 && pl->split_active < 256) pl->split_active = 256;
+}
+int64_t ls_amd_internal_plan_split_active(ls_amd_plan const *pl) { return split_rows_now(pl); }
+int ls_amd_internal_plan_slot_cached(ls_amd_plan const *pl) { return pl->slot_cache != 0; }
 /* Streams laid out back to back at their exact lengths (a count pass of stage A + a scan): about half of what the worst-case
  * stride of the split form reserves.  Covers every row if `max_bytes` (<= 0: no ceiling) and the device allow, else the longest
  * prefix of whole 256-row tiles that fits -- the rows behind it keep the fused kernel.  Returns the rows covered (0: none, nothing
@@ -3032,31 +3046,42 @@ int ls_amd_internal_repl_split_begin(ls_amd_plan *pl, void *stream) {
     ix.row_g0 = pl->row_g0;
     int const st = stage_begin(pl, ST_GENERATE, stream);
     int const slot = timing_begin(pl, stream);
-    DEV(lsk_tile_pull_resolve(pl->dop, pl->dbs, 0, pl->split_rows, ps->d_reps, ps->d_norms, ix, pl->gindex.reps, pl->gindex.count,
+    DEV(lsk_tile_pull_resolve(pl->dop, pl->dbs, 0, split_rows_now(pl), ps->d_reps, ps->d_norms, ix, pl->gindex.reps, pl->gindex.count,
                               pl->pull_halo, pl->pbuf, pl->d_err, stream));
     pl->slot_cache_valid = pl->slot_cache; /* only once the resolve launch went through: a failed one leaves nothing to reuse */
     timing_end(pl, slot, stream);
     stage_end(pl, st, stream);
     return 0;
 }
-int ls_amd_internal_repl_split_finish(ls_amd_plan *pl, void const *d_x_global, void *d_y_local, void *stream) {
-    if (pl->family != FAMILY_REPL_TILE || !pl->idx_mode || pl->split_rows <= 0) return ls_amd_matvec_replicated(pl, d_x_global, d_y_local, stream);
+/* rows [row0, row1) of the split matvec (row0 a multiple of 256): what was resolved ahead is gathered, the rest takes the fused
+ * kernel.  The chunked return of the replicated-x driver calls it once per chunk of rows; count = 1: this call opens the matvec. */
+int ls_amd_internal_repl_split_rows(ls_amd_plan *pl, void const *d_x_global, void *d_y_local, int64_t row0, int64_t row1, int count, void *stream) {
+    if (pl->family != FAMILY_REPL_TILE || !pl->idx_mode || pl->split_rows <= 0) return set_error("internal error: not a split plan");
     part_state *ps = &pl->parts[0];
-    ls_amd_internal_count_matvec(pl);
+    if (row1 > ps->count) row1 = ps->count;
+    if (row0 < 0 || (row0 & 255) != 0 || row0 > row1) return set_error("internal error: bad row range of the split matvec");
+    if (count) ls_amd_internal_count_matvec(pl);
     lsk_pullidx ix;
     ix.tab = pl->gtab->tab;
     ix.perm = pl->gtab->d_perm;
     ix.row_g0 = pl->row_g0;
+    int64_t const S = split_rows_now(pl);
     int const st = stage_begin(pl, ST_ROWS, stream);
-    int const slot = pl->slot_cache ? timing_begin(pl, stream) : -1; /* cached: the gather kernel is the dominant (only) one */
-    DEV(lsk_tile_pull_gather(pl->dop, pl->dbs, pl->cplx, 0, pl->split_rows, ps->d_reps, ps->d_norms, ix, d_x_global, pl->pbuf, d_y_local,
-                             stream));
-    if (slot >= 0) timing_end(pl, slot, stream);
-    if (pl->split_rows < ps->count)
-        DEV(lsk_tile_pull_idx(pl->dop, pl->dbs, pl->cplx, pl->split_rows, ps->count, ps->d_reps, ps->d_norms, ix, pl->gindex.reps,
+    if (row0 < S) {
+        int const slot = pl->slot_cache ? timing_begin(pl, stream) : -1; /* cached: the gather kernel is the dominant (only) one */
+        DEV(lsk_tile_pull_gather(pl->dop, pl->dbs, pl->cplx, row0, row1 < S ? row1 : S, ps->d_reps, ps->d_norms, ix, d_x_global, pl->pbuf, d_y_local,
+                                 stream));
+        if (slot >= 0) timing_end(pl, slot, stream);
+    }
+    if (row1 > S)
+        DEV(lsk_tile_pull_idx(pl->dop, pl->dbs, pl->cplx, row0 > S ? row0 : S, row1, ps->d_reps, ps->d_norms, ix, pl->gindex.reps,
                               pl->gindex.count, d_x_global, pl->pull_halo, d_y_local, pl->d_err, stream));
     stage_end(pl, st, stream);
     return 0;
+}
+int ls_amd_internal_repl_split_finish(ls_amd_plan *pl, void const *d_x_global, void *d_y_local, void *stream) {
+    if (pl->family != FAMILY_REPL_TILE || !pl->idx_mode || pl->split_rows <= 0) return ls_amd_matvec_replicated(pl, d_x_global, d_y_local, stream);
+    return ls_amd_internal_repl_split_rows(pl, d_x_global, d_y_local, 0, pl->parts[0].count, 1, stream);
 }
 char const *ls_amd_plan_kernel_name(ls_amd_plan const *pl) {
     switch (pl->family) {

@@ -38,6 +38,7 @@ static thread_local char g_err[512] = "";
 #define LSK_LAUNCH_CHECK() LSK_CHECK(hipGetLastError())
 
 extern "C" char const *lsk_last_error(void) { return g_err; }
+extern "C" char *lsk_error_buffer(size_t *capacity) { *capacity = sizeof(g_err); return g_err; } // the other translation units report through it
 extern "C" int lsk_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;

@@ -457,6 +457,13 @@ int lsk_hashed_to_block(int64_t n, uint8_t const *masks, int P, int elt_size,
 
 /* out[i] = src[perm[i]], elements of 8 or 16 bytes, perm int32 or int64 */
 int lsk_gather_perm(int64_t n, void const *perm, int perm_is_64, int elt_size, void const *src, void *out, void *stream);
+/* repl.hip: the same over up to 64 index ranges [lo_k, hi_k) of perm / out in ONE launch (the rows of one chunk of y, grouped by
+ * owner: one range per owner), and the event helpers of the chunked return / the adaptive split */
+typedef struct lsk_ranges { int n; int64_t lo[64], hi[64]; } lsk_ranges;
+int lsk_gather_perm_ranges(lsk_ranges const *ranges, void const *perm, int perm_is_64, int elt_size, void const *src, void *out, void *stream);
+int lsk_event_query(void *ev);                      /* 0 complete, 1 not yet, -1 error */
+int lsk_stream_wait_event(void *stream, void *ev);  /* work queued on `stream` after this call waits for `ev` */
+char *lsk_error_buffer(size_t *capacity);           /* kernels.hip: the thread's error message buffer (lsk_last_error) */
 /* bitmap bit (index of partner >> shift) <- 1 for every off-diagonal partner of the rows alphas[0, n) (u32 words, device): the
  * blocks of 2^shift rows of the global vector those rows read */
 int lsk_reach_blocks(lsk_operator op, lsk_index ix_global, int64_t n, uint64_t const *alphas, int shift, uint32_t *bitmap, void *stream);
@@ -495,6 +502,7 @@ int lsk_comm_exchange_wait(lsk_comm *c, int slot, void *compute_stream);
 /* never hang (comm.cpp): what the next exchange is, for the watchdog's message; a deadline wait on `stream` + the exchange stream
  * (rc -1 with a message instead of a hung hipStreamSynchronize); the collective set-up cross-check of an exchange layout
  * ([K][size] byte counts: what s sends to d == what d expects from s, on every rank alike); test hook: stall the exchange stream */
+int lsk_comm_exchange_ms(lsk_comm *c, int slot, float *ms); /* duration of the slot's last completed exchange; 1 = none yet; never blocks */
 void lsk_comm_set_tag(lsk_comm *c, char const *what);
 int lsk_comm_wait(lsk_comm *c, void *stream, double timeout_s);
 int lsk_comm_check_counts(lsk_comm *c, int K, int64_t const *send_bytes, int64_t const *recv_bytes, char const *what, void *stream);

@@ -427,8 +427,8 @@ def test_operator_without_diagonal_accumulates_across_ranks(mode):
 
 @pytest.mark.parametrize("name,P,cplx", [("heisenberg_chain_20", 4, False), ("heisenberg_chain_24_symm", 3, False),
                                          ("heisenberg_chain_16", 2, True)])
-@pytest.mark.parametrize("mode", ["packets", "replicated"])
-def test_self_verification_catches_a_misplaced_segment(name, P, cplx, mode):
+@pytest.mark.parametrize("mode", ["packets", "replicated", "replicated-chunked"])
+def test_self_verification_catches_a_misplaced_segment(monkeypatch, name, P, cplx, mode):
     """The check `bench.py --gpus N` attaches to every exchange strategy (distributed-matvec_amd/verify.py; the reference's
     multi-locale check, test/TestMatrixVectorProduct.chpl:41-59): every rank's block of y against its rows of the ONE-partition
     kernel on x = u(hash(sigma, seed)), element-wise, plus all-reduced invariants.  Clean run: ok, error <= 1e-12.  Then one
@@ -440,6 +440,11 @@ def test_self_verification_catches_a_misplaced_segment(name, P, cplx, mode):
     from distributed_matvec_amd import verify
     from distributed_matvec_amd.distributed import RcclDistributedOperator, RcclReplicatedOperator
 
+    if mode == "replicated-chunked":  # the chunked return of the projected bases' driver (forced: the default chunks >= 2^16 rows)
+        if "symm" not in name:
+            pytest.skip("the chunked return belongs to the indexed (projected) driver")
+        monkeypatch.setenv("LS_AMD_REPL_RETURN_CHUNKS", "3")
+        mode = "replicated"
     basis, h = D.loadConfigFromDict(model_config(name), hamiltonian=True)
     reps, masks = D.enumerateStates(basis, P)
     reps_global = D.arrFromHashedToBlock(reps, masks)
@@ -626,3 +631,59 @@ print("SURVIVED", flush=True)
     env["LS_AMD_COMM_WATCHDOG_S"] = "60"
     p = subprocess.run([sys.executable, "-c", code, "polite"], capture_output=True, text=True, timeout=120, env=env)
     assert p.returncode == 0 and "POLITE" in p.stdout and "has not drained" in p.stdout, (p.returncode, p.stdout[-800:], p.stderr[-800:])
+
+
+# ---- replicated x, projected bases: chunked return of y + adaptive split (VERDICT r5 #1a) ------------------------------------------
+
+@pytest.mark.parametrize("name,P,cplx", [("heisenberg_chain_24_symm", 4, False), ("heisenberg_chain_24_symm", 3, True),
+                                         ("heisenberg_kagome_12_symm", 2, False)])
+@pytest.mark.parametrize("chunks,adapt", [("0", "0"), ("3", "1"), ("8", "1"), ("2", "0")])
+def test_replicated_chunked_return_and_adaptive_split(monkeypatch, name, P, cplx, chunks, adapt):
+    """ls_amd_repl_matvec on a projected basis: the rows of a rank are computed in chunks and every chunk's rows travel back to their
+    owners while the next chunk is gathered (LS_AMD_REPL_RETURN_CHUNKS; forced here -- the default only chunks >= 2^16 rows), and
+    only as many rows are resolved ahead as the exchange of x takes, the rest running fused afterwards (LS_AMD_REPL_ADAPT; the
+    number changes from matvec to matvec: six matvecs in a row must all equal the oracle).  One return for all rows and no
+    adaptation ("0", "0") is the round-5 path."""
+    import torch
+
+    import distributed_matvec_amd as D
+    from distributed_matvec_amd import _lib
+    from distributed_matvec_amd.distributed import RcclReplicatedOperator
+    from oracle import c_oracle as CO
+
+    monkeypatch.setenv("LS_AMD_REPL_RETURN_CHUNKS", chunks)
+    monkeypatch.setenv("LS_AMD_REPL_ADAPT", adapt)
+    basis, h = D.loadConfigFromDict(model_config(name), hamiltonian=True)
+    reps, masks = D.enumerateStates(basis, P)
+    reps_global = D.arrFromHashedToBlock(reps, masks)
+    dtype = torch.complex128 if cplx else torch.float64
+    want_reps = oracle_reps(name)
+    keys = CO.locale_idx_of(want_reps, P)
+    L = _lib.load()
+    active = [[] for _ in range(P)]
+    results = []
+    for it in range(6):
+        xs = [D.fillRandom(reps[p], 100 + it, dtype) for p in range(P)]
+        results.append((xs, [torch.full_like(v, -3.0) for v in xs]))
+
+    def body(rank, comm):
+        op = RcclReplicatedOperator(h, reps_global, masks, dtype, comm=comm)
+        assert op.engine.plan.kernel == "replicated-tile-pull+indexed"
+        for xs, ys in results:
+            op.matvec(xs[rank], ys[rank], check=True)
+            active[rank].append(int(L.ls_amd_internal_plan_split_active(op.engine.plan.h)))
+        op.rm.destroy()
+
+    comms = _run_ranks(P, body)
+    for xs, ys in results:
+        x = CO.hashed_to_block([v.cpu().numpy() for v in xs], keys)
+        got = CO.hashed_to_block([v.cpu().numpy() for v in ys], keys)
+        want = oracle_for(name).local_matvec(want_reps, x)
+        assert np.abs(got - want).max() <= 1e-12 * max(1.0, np.abs(want).max())
+    for r in range(P):  # whole 256-row tiles, or every row of the rank
+        n_r = len(want_reps) * (r + 1) // P - len(want_reps) * r // P
+        assert all(a == n_r or (a % 256 == 0 and 0 < a < n_r) for a in active[r]), (active[r], n_r)
+        if adapt == "0":
+            assert all(a == n_r for a in active[r])
+    for c in comms:
+        c.destroy()
