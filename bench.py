@@ -96,14 +96,21 @@ def reach_share(P):
     return REACH_SHARE_MAX if P >= 8 else 1.0
 
 
-REPL_OVERHEAD = 1.23                 # per-row cost of a rank's kernels relative to one GPU (x arrives owner-major: the near partners'
-                                     # values no longer share lines; measured on eight loop-back ranks, profiles/r3_loopback_*_final.txt)
+REPL_OVERHEAD = 1.27                 # upper bound of the per-row cost of a rank's kernels relative to one GPU: the wall time of EIGHT loop-back
+                                     # ranks sharing one device / the one-partition kernel (profiles/r6_loopback_chain40symm_chunked_return_
+                                     # adaptive_split_ab.txt: 1.26-1.27 whatever the driver does -- eight row kernels at eight places of the basis
+                                     # share one L2 / Infinity Cache there, which eight GPUs would not)
+RETURN_CHUNKS = 4                    # rows of y travel back chunk by chunk while the next chunk is gathered (csrc/dist.c, repl_rows_chunked)
+SPLIT_MARGIN = 1.15                  # adaptive split: rows resolved ahead = 1.15 x what hides the exchange of x (csrc/dist.c, adapt_split)
 
 
 def scaling_model(model, P, w=8, fused_ms=None):
-    """predicted ms per matvec of the replicated-x exchange on P GPUs and the speed-up over one GPU it implies:
-    t(P) = prescale / P + max(resolve / P x f, exchange) + gather / P x f + return, exchange = N w (P - 1) / P / B_in; the
-    unprojected chain has no resolve step to hide the exchange behind and pays a permutation pass over all of x.
+    """predicted ms per matvec of the replicated-x exchange on P GPUs and the speed-up over one GPU it implies.  Projected bases
+    (round 6: adaptive split + chunked return): a share phi = min(1, 1.15 X / R) of the rows is resolved while x travels, the rest
+    runs the fused kernel afterwards, and only the last chunk's rows of y return un-overlapped:
+        t(P) = prescale / P + max(phi R, X) + phi G + (1 - phi) F + return / chunks,
+        R, G, F = resolve, gather, fused per rank (x f), X = N w (P - 1) / P / B_in.
+    The unprojected chain has no resolve step to hide the exchange behind and pays a permutation pass over what it received.
     fused_ms = the one-GPU matvec of this build measured in this run (None: no model)."""
     n = MODEL_STATES.get(model)
     if not n or P < 2 or not fused_ms:
@@ -125,7 +132,9 @@ def scaling_model(model, P, w=8, fused_ms=None):
             xch = xbytes / b / 1e6  # ms
             ret = n * w / P / 1.0e9 * 1e3 / 3000.0 + (n * w / P) * (P - 1) / P / b / 1e6  # group rows by owner (~3 TB/s) + send back
             if projected:
-                t = m["prescale"] / P + max(m["resolve"] / P * f, xch) + m["gather"] / P * f + ret
+                R, G, F = m["resolve"] / P * f, m["gather"] / P * f, m["fused"] / P * f
+                phi = min(1.0, SPLIT_MARGIN * xch / R)
+                t = m["prescale"] / P + max(phi * R, xch) + phi * G + (1.0 - phi) * F + ret / RETURN_CHUNKS
             else:
                 perm = reach_share(P) * n * 2 * w / 1.0e9 * 1e3 / 2500.0  # the hashed -> block permutation of what arrived: random reads + writes
                 t = xch + perm + m["fused"] / P + ret

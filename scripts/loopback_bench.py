@@ -34,9 +34,19 @@ x_block = D.arrFromHashedToBlock(xs, masks)
 y_ref = torch.empty_like(x_block)
 ref = D.MatvecPlan(h, [reps_global], torch.float64, mode="pull")
 ref.matvec([x_block], [y_ref])
+_e0, _e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+_e0.record()
+for _ in range(2):
+    ref.matvec([x_block], [y_ref], check=False)
+_e1.record()
+torch.cuda.synchronize()
+one_gpu_ms = _e0.elapsed_time(_e1) / 2
+ref_kernel = ref.kernel
 ref.destroy()
 del x_block
-print(f"chain_{args.L}{'_symm' if args.symm else ''}: N = {n}, P = {P} loop-back ranks on {torch.cuda.get_device_name(0)}", flush=True)
+print(f"chain_{args.L}{'_symm' if args.symm else ''}: N = {n}, P = {P} loop-back ranks on {torch.cuda.get_device_name(0)}; one-partition kernel "
+      f"({ref_kernel}) {one_gpu_ms:.2f} ms per matvec in this job; LS_AMD_REPL_RETURN_CHUNKS={os.environ.get('LS_AMD_REPL_RETURN_CHUNKS', 'default')} "
+      f"LS_AMD_REPL_ADAPT={os.environ.get('LS_AMD_REPL_ADAPT', 'default')}", flush=True)
 
 for mode in (["packets", "replicated"] if args.mode == "both" else [args.mode]):
     comms = D.Communicator.local_group(P)
@@ -77,8 +87,8 @@ for mode in (["packets", "replicated"] if args.mode == "both" else [args.mode]):
     err = float((got - y_ref).abs().max()) / float(y_ref.abs().max())
     wall = max(v[0] for v in out.values())
     xb = sum(v[2] for v in out.values())
-    print(f"[{mode}] {P} ranks sharing one GPU: {wall * 1e3:.2f} ms per matvec (all ranks), rounds = {out[0][3]}, "
-          f"exchange {xb / 1e9:.2f} GB per matvec over all ranks, max |dy| / max |y| vs one partition = {err:.1e}")
+    print(f"[{mode}] {P} ranks sharing one GPU: {wall * 1e3:.2f} ms per matvec (all ranks) = {wall * 1e3 / one_gpu_ms:.3f} x the one-partition kernel, "
+          f"rounds = {out[0][3]}, exchange {xb / 1e9:.2f} GB per matvec over all ranks, max |dy| / max |y| vs one partition = {err:.1e}")
     if out[0][6] is not None:
         es = 8
         full = [(int(masks.numel()) - int(reps[r].numel())) * es for r in range(P)]
