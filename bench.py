@@ -41,13 +41,17 @@ def chain_nnz(L, n_states):
 
 
 def source_sha():
-    """sha256 of the kernel source the library was built from: ties a PMC measurement to the code it measured"""
+    """sha256 of the kernel sources the library was built from (the k_*.hip translation units + what they share): ties a PMC
+    measurement to the code it measured.  Same recipe as scripts/kernel_isa_sha.py::source_sha."""
     import hashlib
 
     hsh = hashlib.sha256()
-    for f in ("kernels.hip", "lsk.h"):
-        with open(os.path.join(ROOT, "distributed-matvec_amd", "csrc", f), "rb") as fh:
-            hsh.update(fh.read())
+    csrc = os.path.join(ROOT, "distributed-matvec_amd", "csrc")
+    for f in ("k_runtime.hip", "k_rows.hip", "k_packets.hip", "k_pull.hip", "k_plan.hip", "lsk_dev.hpp", "lsk.h"):
+        path = os.path.join(csrc, f)
+        if os.path.exists(path):
+            with open(path, "rb") as fh:
+                hsh.update(fh.read())
     return hsh.hexdigest()[:16]
 
 
@@ -305,7 +309,7 @@ def boundary_extra(D, torch, h, basis, reps, y_device, x_device, calls=2):
 def packet_path_extra(D, torch, time_steps, L=28, P=8, steps=5):
     """The reference's own formulation -- term expansion, hash -> owner, per-destination buffers, local scatter (DMV:663-853) -- on
     one device: heisenberg_chain_L over P logical partitions through ls_amd_matvec (the "exchange" is a pointer hand-off), once with
-    the sorted packet streams + window consumers (csrc/kernels.hip, k_tile_st / k_window) and once with the atomic consumers
+    the sorted packet streams + window consumers (csrc/k_packets.hip, k_tile_st / k_window) and once with the atomic consumers
     (LS_AMD_PACKET_STREAMS=0), each checked element-wise against the one-partition pull kernel on the same x."""
     from distributed_matvec_amd import config
 

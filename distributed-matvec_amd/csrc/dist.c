@@ -27,7 +27,7 @@ void ls_amd_internal_stage_end(ls_amd_plan *pl, int slot, void *stream);
 void ls_amd_internal_count_matvec(ls_amd_plan *pl);
 int ls_amd_internal_check_y(ls_amd_plan *pl, void const *y);
 void ls_amd_internal_set_no_packet_index(int v); /* host.c */
-/* host.c: packets in sorted streams (kernels.hip, k_tile_st / k_window) for a plan that owns one partition */
+/* host.c: packets in sorted streams (k_packets.hip, k_tile_st / k_window) for a plan that owns one partition */
 void ls_amd_internal_set_want_streams(int v);
 int ls_amd_internal_streams_eligible(ls_hs_operator const *op, int P);
 int ls_amd_internal_plan_streams(ls_amd_plan const *pl);                       /* streams per segment, 0 = none */

@@ -1,6 +1,6 @@
 /* host.c -- C host side of the MI355X-native matvec: the ls_hs_* ABI subset, plans, and the
  * ls_chpl_* exports of the reference's shared library.  Plain C11; every device action goes through
- * the extern-"C" shim in kernels.hip (lsk.h).  No compute on the CPU: the functions here build
+ * the extern-"C" shim in the k_*.hip translation units (lsk.h).  No compute on the CPU: the functions here build
  * tables (symmetry-group closure, Benes networks, term grouping), size buffers and launch kernels.
  *
  * Reference behaviour mirrored (see include/ls_chpl.h, include/ls_amd.h for per-symbol citations):
@@ -374,7 +374,7 @@ static uint64_t host_delta_swap(uint64_t x, uint64_t m, int d) {
     uint64_t t = ((x >> d) ^ x) & m;
     return x ^ t ^ (t << d);
 }
-/* CPU mirror of apply_elem in kernels.hip -- used by the test hooks and table checks only */
+/* CPU mirror of apply_elem in lsk_dev.hpp -- used by the test hooks and table checks only */
 static uint64_t host_apply_elem(lsk_group_elem const *e, uint64_t x, int L) {
     static int const dist[LSK_BENES_STAGES] = {32, 16, 8, 4, 2, 1, 2, 4, 8, 16, 32};
     uint64_t const mask = L >= 64 ? ~0ULL : ((1ULL << L) - 1);
@@ -2239,7 +2239,7 @@ static __thread int g_no_packet_index = 0;
 void ls_amd_internal_set_no_packet_index(int v) { g_no_packet_index = v; }
 /* bytes of the key array (states or indices) of a segment of c packets: the values behind it stay 8-byte aligned */
 static int64_t segment_key_bytes(ls_amd_plan const *pl, int64_t c) { return pl->key_bytes == 4 ? ((4 * c + 7) & ~(int64_t)7) : 8 * c; }
-/* Sorted packet streams (kernels.hip, k_tile_st / k_window) for the partitions of ONE process: every off-diagonal group must be an
+/* Sorted packet streams (k_packets.hip, k_tile_st / k_window) for the partitions of ONE process: every off-diagonal group must be an
  * exchange pair -- a packet exists iff alpha is anti-aligned on the pair, and beta - alpha is then one of two constants -- on an
  * unprojected fixed-weight basis (the conditions of the pre-indexed packets, which setup_packet_index checks).
  * LS_AMD_PACKET_STREAMS=0: the atomics of lsk_scatter_parts / lsk_scatter_idx instead (A/B). */

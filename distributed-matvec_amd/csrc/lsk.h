@@ -1,4 +1,4 @@
-/* lsk.h -- internal interface between the C host side (host.c) and the HIP side (kernels.hip).
+/* lsk.h -- internal interface between the C host side (host.c) and the HIP side (k_*.hip: runtime, rows, packets, pull, plan; shared device code in lsk_dev.hpp).
  * "Thin extern-C shim": host.c never includes a HIP header; everything device-related goes through
  * the lsk_* functions declared here.  All structs are plain C PODs passed by value to kernels.
  */
@@ -86,7 +86,7 @@ typedef struct lsk_basis {
      *    row, o the order of the rows -- or, on a square torus, D4 = D2 x {1, transpose}, or a subgroup of it: d4_mask says
      *    which images belong to the group (bits 0-3: 1, r, o, r o of the word; bits 4-7: of its transpose), cosets[0] is the
      *    transpose network -- the only compiled network left -- and trow2 the row table with the fields of the reversed row
-     *    in its high half (torus_min_d2, kernels.hip). */
+     *    in its high half (torus_min_d2, lsk_dev.hpp). */
     int k4_mode, reflect;
     int d4_mask;                    /* mode 5 */
     uint64_t const *trow2;          /* mode 5: device [2^tw] */
@@ -239,7 +239,7 @@ int lsk_chain_tile_rows(int cplx);
 int lsk_chain(lsk_operator op, lsk_basis bs, lsk_index ix, int cplx, int wide_ranks, int fused_records, lsk_tilemap tm,
               int64_t n, uint64_t const *reps, int64_t row0, int64_t n_x, void const *x, void *y, int n_cached,
               void const *cache, double cv0, double cv1, void *stream);
-/* ---- staged row kernel for arbitrary exchange pairs (k_pairs_t, kernels.hip): Heisenberg / XXZ on any lattice -------------
+/* ---- staged row kernel for arbitrary exchange pairs (k_pairs_t, k_rows.hip): Heisenberg / XXZ on any lattice -------------
  * pairs are sorted by class: [0, n_near) both sites below bit 11, [n_near, n_near + n_str) i < 11 <= j, then both >= 11 */
 #define LSK_MAX_PAIRS 128
 #define LSK_PAIR_KC 20 /* columns of the binomial table: weight + 2 <= 20, i.e. hamming weight <= 18 (32 sites: 16) */
@@ -285,7 +285,7 @@ int lsk_tile_wv_max_parts(void);
 int lsk_tile_wv(lsk_operator op, lsk_basis bs, lsk_index ix, lsk_gdir gd, int cplx, int count_only, int P, int me,
                 int64_t row0, int64_t row1, uint64_t const *reps, double const *norms, void const *x, void *y,
                 uint32_t *d_wtab, lsk_round_layout const *d_layout, void *d_send, int *d_err, void *stream);
-/* Packets in SORTED STREAMS (kernels.hip, k_tile_st / k_window): unprojected fixed-weight bases, operators whose off-diagonal
+/* Packets in SORTED STREAMS (k_packets.hip, k_tile_st / k_window): unprojected fixed-weight bases, operators whose off-diagonal
  * groups are all exchange pairs.  stream = 2 * group + (bit of alpha at the pair's lower site); along a stream beta - alpha is a
  * constant, so the packets of one (destination, stream) -- written in row order -- carry ASCENDING destination indices, and the
  * consumer adds a window of y at a time in LDS instead of one fabric atomic per packet.
@@ -463,7 +463,7 @@ typedef struct lsk_ranges { int n; int64_t lo[64], hi[64]; } lsk_ranges;
 int lsk_gather_perm_ranges(lsk_ranges const *ranges, void const *perm, int perm_is_64, int elt_size, void const *src, void *out, void *stream);
 int lsk_event_query(void *ev);                      /* 0 complete, 1 not yet, -1 error */
 int lsk_stream_wait_event(void *stream, void *ev);  /* work queued on `stream` after this call waits for `ev` */
-char *lsk_error_buffer(size_t *capacity);           /* kernels.hip: the thread's error message buffer (lsk_last_error) */
+char *lsk_error_buffer(size_t *capacity);           /* k_runtime.hip: the thread's error message buffer (lsk_last_error) */
 /* bitmap bit (index of partner >> shift) <- 1 for every off-diagonal partner of the rows alphas[0, n) (u32 words, device): the
  * blocks of 2^shift rows of the global vector those rows read */
 int lsk_reach_blocks(lsk_operator op, lsk_index ix_global, int64_t n, uint64_t const *alphas, int shift, uint32_t *bitmap, void *stream);

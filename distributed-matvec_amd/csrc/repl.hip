@@ -1,5 +1,5 @@
 // repl.hip -- helpers of the replicated-x driver (dist.c): the owner-grouping pass of a CHUNK of y and the event plumbing of
-// the chunked return / the adaptive split.  Streaming kernels, nothing of the hot row path (kernels.hip).
+// the chunked return / the adaptive split.  Streaming kernels, nothing of the hot row path (k_rows.hip, k_pull.hip).
 //
 // Reference replaced: /root/reference/src/BlockToHashed.chpl:87-208 restricted to a rank's rows -- "group my results by owner"
 // before they travel back (DistributedMatrixVector.chpl:739-853: consumers drain while producers still compute; here the rows

@@ -345,7 +345,7 @@ int ls_amd_scatter(ls_amd_plan *plan, int64_t n, uint64_t const *d_betas, void c
  * round's receive buffer in one launch: segment s = counts[s] packets at d_recv + offsets[s].
  *
  * SORTED STREAMS (round 5; drivers that own both ends of the exchange: ls_amd_matvec over the partitions of one process and
- * ls_amd_dist_matvec with >= 2 ranks; csrc/kernels.hip, k_tile_st / k_window).  When every off-diagonal term of the operator is
+ * ls_amd_dist_matvec with >= 2 ranks; csrc/k_packets.hip, k_tile_st / k_window).  When every off-diagonal term of the operator is
  * an exchange pair and the basis is an unprojected fixed-weight one, the pre-indexed packets of a segment are written as
  * 2 x (number of pairs) STREAMS, one per (pair, pattern of alpha on the pair): along a stream beta = alpha + constant, so --
  * the producer's rows and the destination's states both ascending -- the keys of a stream ASCEND.  The consumer then owns a
@@ -404,7 +404,7 @@ int ls_amd_test_window_find(uint64_t const *reps, int n, uint64_t key);
  * position of `key`, or -1 when the window does not answer -- the key is absent, or its set was already full when it was
  * staged (the kernel then takes the static index table, which holds every representative); never a wrong position */
 int ls_amd_test_nw_find(uint64_t const *reps, int n, uint64_t key);
-/* Host-only test hook: the near-pair table of the staged row kernel (distributed-matvec_amd/csrc/kernels.hip: chain_lds_image) for
+/* Host-only test hook: the near-pair table of the staged row kernel (distributed-matvec_amd/csrc/k_rows.hip: chain_lds_image) for
  * vectors of `elem` bytes per entry and `ldsp` pairs served from the LDS window: 480 entries of four int16 into `out`. */
 int ls_amd_test_chain_near_table(int elem, int ldsp, int16_t *out);
 /* Host-only test hook: the orbit minimum of `a` under the translations of a ring of L sites (and its reflections / the global

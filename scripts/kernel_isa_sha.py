@@ -1,14 +1,14 @@
 #!/usr/bin/env python3
-"""Per-kernel fingerprints of the gfx950 machine code of csrc/kernels.hip.
+"""Per-kernel fingerprints of the gfx950 machine code of the kernel translation units (csrc/k_*.hip; kernels.hip until round 5).
 
 A PMC measurement (profiles/pmc_traffic.json) belongs to the machine code of ONE kernel family, not to the whole
 source file: editing k_tile_pull must not orphan the traffic measured for k_chain_t, and editing k_chain_t must.  So the
-key is a hash of the kernel's own ISA: kernels.hip is compiled device-only to assembly with the flags of the product
+key is a hash of the kernel's own ISA: every k_*.hip is compiled device-only to assembly with the flags of the product
 build, the body of every kernel (between its label and its .Lfunc_end) is cut out, function-local label numbers and
 comments are normalised away (they depend on the position of the function in the file), and the bodies of all
 instantiations of a family (k_chain_t, k_tile_pull, ...) are hashed together in sorted order.
 
-usage: kernel_isa_sha.py [--source DIR-with-kernels.hip-and-lsk.h] [--out FILE]   (default: the tree, print to stdout)
+usage: kernel_isa_sha.py [--source DIR-with-the-k_*.hip-files] [--out FILE]   (default: the tree, print to stdout)
 Written by __graft_entry__.build() to distributed-matvec_amd/kernel_isa.json; read by bench.py."""
 import hashlib
 import json
@@ -25,13 +25,41 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-
          "-Wno-pass-failed", "-Wno-unused-command-line-argument"]
 
 
+KERNEL_SOURCES = ("k_runtime.hip", "k_rows.hip", "k_packets.hip", "k_pull.hip", "k_plan.hip")
+SHARED_SOURCES = ("lsk_dev.hpp", "lsk.h")
+
+
+def kernel_sources(src_dir):
+    """the kernel translation units of the tree (a pre-split tree: kernels.hip alone)"""
+    have = [f for f in KERNEL_SOURCES if os.path.exists(os.path.join(src_dir, f))]
+    return have or ["kernels.hip"]
+
+
 def device_asm(src_dir):
+    """the device assembly of every kernel translation unit, concatenated (compiled side by side)"""
+    from concurrent.futures import ThreadPoolExecutor
+
     with tempfile.TemporaryDirectory() as tmp:
-        out = os.path.join(tmp, "kernels.s")
-        subprocess.check_call([HIPCC, *FLAGS, "--cuda-device-only", "-S", f"-I{src_dir}",
-                               os.path.join(src_dir, "kernels.hip"), "-o", out], stderr=subprocess.DEVNULL)
-        with open(out) as f:
-            return f.read()
+        def one(f):
+            out = os.path.join(tmp, f + ".s")
+            subprocess.check_call([HIPCC, *FLAGS, "--cuda-device-only", "-S", f"-I{src_dir}", os.path.join(src_dir, f), "-o", out],
+                                  stderr=subprocess.DEVNULL)
+            with open(out) as fh:
+                return fh.read()
+
+        with ThreadPoolExecutor(max_workers=5) as ex:
+            return "\n".join(ex.map(one, kernel_sources(src_dir)))
+
+
+def source_sha(src_dir):
+    """= bench.source_sha(): the source the fingerprints were computed from"""
+    hs = hashlib.sha256()
+    for f in (*kernel_sources(src_dir), *SHARED_SOURCES):
+        path = os.path.join(src_dir, f)
+        if os.path.exists(path):
+            with open(path, "rb") as fh:
+                hs.update(fh.read())
+    return hs.hexdigest()[:16]
 
 
 _LOCAL_LABEL = re.compile(r"\.L(BB|tmp|func_begin|func_end|JTI)(\d+)(_\d+)?")
@@ -81,13 +109,9 @@ def fingerprints(src_dir):
     for mangled in sorted(bodies):
         if family_of(mangled).startswith("k_"):  # this library's kernels; the hipcub/rocprim scans are not fingerprinted
             fam.setdefault(family_of(mangled), []).append(mangled)
-    hs = hashlib.sha256()
-    for f in ("kernels.hip", "lsk.h"):  # = bench.source_sha(): the source these fingerprints were computed from
-        with open(os.path.join(src_dir, f), "rb") as fh:
-            hs.update(fh.read())
-    out = {"_comment": "sha256[:16] of the normalised gfx950 ISA of every kernel family of csrc/kernels.hip "
+    out = {"_comment": "sha256[:16] of the normalised gfx950 ISA of every kernel family of csrc/k_*.hip "
                        "(scripts/kernel_isa_sha.py); bench.py attaches a PMC entry only to the machine code it measured",
-           "source_sha": hs.hexdigest()[:16], "families": {}, "kernels": {}}
+           "source_sha": source_sha(src_dir), "families": {}, "kernels": {}}
     for f, members in sorted(fam.items()):
         h = hashlib.sha256()
         for mangled in members:

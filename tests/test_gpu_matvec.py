@@ -1311,7 +1311,7 @@ def test_pre_indexed_packets(torch, monkeypatch, case):
                                   "heisenberg_chain_16/2/f64/3", "heisenberg_chain_16/3/c128/0", "heisenberg_chain_20/8/f64/2",
                                   "heisenberg_kagome_16/4/c128/5", "heisenberg_chain_20/5/c128/1"])
 def test_sorted_packet_streams(torch, monkeypatch, case):
-    """Sorted streams (csrc/kernels.hip, k_tile_st / k_window): along one (exchange pair, pattern of alpha on it) beta - alpha is a
+    """Sorted streams (csrc/k_packets.hip, k_tile_st / k_window): along one (exchange pair, pattern of alpha on it) beta - alpha is a
     constant, so the packets of a (destination, stream) written in row order carry ascending indices and the consumer adds a
     window of y at a time in LDS -- no atomics.  Equal to the oracle and to the atomic consumers (LS_AMD_PACKET_STREAMS=0) over
     partitions smaller than a tile or empty (chain_4 / 3, chain_8 / 8, kagome_12 / 8), several rounds, several windows per block, f64 and c128; y keeps what the

@@ -535,7 +535,7 @@ def test_operator_shares_its_basis():
 
 def test_near_window_search_of_the_pull_kernel():
     """k_tile_pull resolves partners that lie in the tile's neighbourhood of the sorted representatives with a binary
-    search over saturating 32-bit offsets in LDS (window_find / window_offset in kernels.hip, compiled for the host too):
+    search over saturating 32-bit offsets in LDS (window_find / window_offset in csrc/k_pull.hip, compiled for the host too):
     every member is found at its position, every non-member is a miss, gaps >= 2^32 - 1 fall back to the hash table."""
     lib = _lib.load()
     rng = np.random.RandomState(7)
@@ -565,7 +565,7 @@ def test_near_window_search_of_the_pull_kernel():
 @pytest.mark.parametrize("name", ["heisenberg_chain_24_symm", "heisenberg_chain_16", "heisenberg_square_4x4"])
 def test_near_window_hash_set_of_the_indexed_pull_kernels(name):
     """k_pull_t stages the tile's neighbourhood of the sorted representatives as a two-way hash set in LDS (nw_* in
-    kernels.hip, compiled for the host too).  It may DROP an entry (full set: the partner then goes through the static index
+    csrc/k_pull.hip, compiled for the host too).  It may DROP an entry (full set: the partner then goes through the static index
     table), it must never answer with a wrong position or answer for a state that is not in the window; on real windows of
     768 consecutive representatives it answers for >= 93 % of them."""
     from helpers import oracle_reps

@@ -1,4 +1,4 @@
-"""The property the staged pull kernel for projected bases exploits (k_tile_pull's near window, kernels.hip): in the sorted
+"""The property the staged pull kernel for projected bases exploits (k_tile_pull's near window, csrc/k_pull.hip): in the sorted
 array of representatives the partners rep(beta) of a row cluster around the row itself.  Measured with the oracle (this is
 where the numbers quoted in DESIGN.md section 3 come from; chain_32_symm / chain_36_symm take minutes and are run by hand:
 `python tests/test_partner_locality.py 32`)."""

@@ -1,4 +1,4 @@
-"""The sorted-stream packet formulation (csrc/kernels.hip k_tile_st / k_window) restated in numpy and held
+"""The sorted-stream packet formulation (csrc/k_packets.hip k_tile_st / k_window) restated in numpy and held
 against the oracle on the CPU -- the three facts the HIP kernels rely on, none of which needs a GPU to be checked:
 
   1. ORDER.  On an unprojected fixed-weight basis every off-diagonal group of an exchange operator is a pair (i, j); a packet
