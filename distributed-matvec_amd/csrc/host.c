@@ -1455,6 +1455,9 @@ typedef struct part_state {
     uint32_t *h_soff;     /* owned: host copy (dist.c exchanges it at set-up) */
 } part_state;
 
+#ifndef LS_AMD_PULL_VALUES_DEFAULT
+#define LS_AMD_PULL_VALUES_DEFAULT 0 /* flipped to 1 where the value table measures faster INCLUDING its refresh */
+#endif
 enum { FAMILY_DIRECT_PUSH = 0, FAMILY_DIRECT_PULL = 1, FAMILY_TILE = 2, FAMILY_TILE_PULL = 3,
        FAMILY_REPL_DIRECT = 4, FAMILY_REPL_TILE = 5 };
 
@@ -1510,6 +1513,7 @@ struct ls_amd_plan {
      * same global basis and partition layout; nothing is refreshed per matvec */
     int idx_mode;
     struct ls_amd_gtab *gtab;
+    uint64_t *d_vtab;    /* owned: value table over the same buckets (f64, one partition, matrix-free), else NULL */
     int64_t row_g0;      /* global index of the first local row (replicated-x plans over a contiguous block) */
     /* split matvec of the indexed mode (lsk_tile_pull_resolve | lsk_tile_pull_gather): packet streams of the first
      * split_rows rows (a multiple of 256, or all of them); 0 = the fused kernel only */
@@ -2755,6 +2759,22 @@ int ls_amd_plan_create(ls_amd_plan **out, ls_hs_operator const *op, ls_amd_dtype
              * operator, which then resolves its packet streams on the first matvec only */
             e = getenv("LS_AMD_SLOT_CACHE");
             if (e && atoll(e) > 0 && ls_amd_plan_cache_slots(pl, atoll(e)) < 0) { ls_amd_plan_destroy(pl); return -1; }
+            /* Value table (round 6; k_pull.hip, lsk_vtab_*): f64 vectors of one partition, matrix-free plans --
+             * the far partners' values travel with their table bucket (one fabric request instead of two dependent ones) and
+             * are refreshed once per matvec in table order.  32 bytes per bucket next to the shared index table's 16; taken while
+             * it fits a third of the free HBM.  LS_AMD_PULL_VALUES=0 keeps the index table + x[slot] gather (always the path of
+             * c128 vectors, of the replicated-x exchange -- no rank may do O(N) work per matvec there -- and of the slot cache). */
+            e = getenv("LS_AMD_PULL_VALUES");
+            int const want_values = e ? atoi(e) != 0 : LS_AMD_PULL_VALUES_DEFAULT;
+            if (want_values && !pl->cplx && !pl->slot_cache && pl->split_rows == 0) {
+                size_t fr = 0, tot = 0;
+                size_t const need = (size_t)32 << pl->gtab->tab.bbits;
+                void *vt = NULL;
+                if (lsk_mem_info(&fr, &tot) == 0 && need <= fr / 3 && lsk_malloc(&vt, need) == 0) {
+                    if (lsk_vtab_build(pl->gtab->tab, (uint64_t *)vt, stream) != 0) { lsk_free(vt); ls_amd_plan_destroy(pl); return dev_error(); }
+                    pl->d_vtab = (uint64_t *)vt;
+                }
+            }
         }
     }
     if (lsk_sync(stream) != 0) { ls_amd_plan_destroy(pl); return dev_error(); }
@@ -2765,6 +2785,7 @@ int ls_amd_plan_create(ls_amd_plan **out, ls_hs_operator const *op, ls_amd_dtype
 
 void ls_amd_plan_destroy(ls_amd_plan *pl) {
     if (!pl) return;
+    if (pl->d_vtab) lsk_free(pl->d_vtab);
     if (pl->d_gdir) lsk_free(pl->d_gdir);
     if (pl->d_part_ctx) lsk_free(pl->d_part_ctx);
     if (pl->d_send_parts) {
@@ -2986,6 +3007,7 @@ int ls_amd_matvec_replicated(ls_amd_plan *pl, void const *d_x_global, void *d_y_
         ix.tab = pl->gtab->tab;
         ix.perm = pl->gtab->d_perm;
         ix.row_g0 = pl->row_g0;
+        ix.vtab = NULL;
         int const st = stage_begin(pl, ST_ROWS, stream);
         slot = timing_begin(pl, stream);
         DEV(lsk_tile_pull_idx(pl->dop, pl->dbs, pl->cplx, 0, ps->count, ps->d_reps, ps->d_norms, ix, pl->gindex.reps,
@@ -3044,6 +3066,7 @@ int ls_amd_internal_repl_split_begin(ls_amd_plan *pl, void *stream) {
     ix.tab = pl->gtab->tab;
     ix.perm = pl->gtab->d_perm;
     ix.row_g0 = pl->row_g0;
+    ix.vtab = NULL;
     int const st = stage_begin(pl, ST_GENERATE, stream);
     int const slot = timing_begin(pl, stream);
     DEV(lsk_tile_pull_resolve(pl->dop, pl->dbs, 0, split_rows_now(pl), ps->d_reps, ps->d_norms, ix, pl->gindex.reps, pl->gindex.count,
@@ -3065,6 +3088,7 @@ int ls_amd_internal_repl_split_rows(ls_amd_plan *pl, void const *d_x_global, voi
     ix.tab = pl->gtab->tab;
     ix.perm = pl->gtab->d_perm;
     ix.row_g0 = pl->row_g0;
+    ix.vtab = NULL;
     int64_t const S = split_rows_now(pl);
     int const st = stage_begin(pl, ST_ROWS, stream);
     if (row0 < S) {
@@ -3088,7 +3112,7 @@ char const *ls_amd_plan_kernel_name(ls_amd_plan const *pl) {
     case FAMILY_DIRECT_PUSH: return "direct-push";
     case FAMILY_DIRECT_PULL:
         return pl->has_chain ? "direct-pull+staged" : pl->has_pairs ? "direct-pull+pairs" : "direct-pull";
-    case FAMILY_TILE_PULL: return pl->idx_mode ? (pl->slot_cache ? "tile-pull+indexed+cached" : "tile-pull+indexed") : "tile-pull";
+    case FAMILY_TILE_PULL: return pl->idx_mode ? (pl->slot_cache ? "tile-pull+indexed+cached" : (pl->d_vtab ? "tile-pull+values" : "tile-pull+indexed")) : "tile-pull";
     case FAMILY_REPL_DIRECT:
         return pl->has_chain ? "replicated-direct-pull+staged" : "replicated-direct-pull";
     case FAMILY_REPL_TILE: return pl->idx_mode ? (pl->slot_cache ? "replicated-tile-pull+indexed+cached" : "replicated-tile-pull+indexed") : "replicated-tile-pull";
@@ -3277,6 +3301,8 @@ int ls_amd_matvec(ls_amd_plan *pl, void const *const *d_x, void *const *d_y, voi
         ix.tab = pl->gtab->tab;
         ix.perm = NULL;
         ix.row_g0 = 0;
+        ix.vtab = NULL;
+        if (pl->d_vtab && (pl->slot_cache || pl->split_rows > 0)) { lsk_free(pl->d_vtab); pl->d_vtab = NULL; } /* a cache enabled later takes over */
         if (pl->split_rows > 0 && pl->slot_cache) {
             /* slot cache: the streams of rows [0, split_rows) are resolved by the first matvec and kept; later matvecs gather.
              * Rows the cache has no room for take the fused kernel */
@@ -3322,6 +3348,12 @@ int ls_amd_matvec(ls_amd_plan *pl, void const *const *d_x, void *const *d_y, voi
                 stage_end(pl, st, stream);
             }
             return 0;
+        }
+        if (pl->d_vtab) { /* the values of this matvec's x (x n(rep) in the prescaling K4 modes) into their buckets: table order */
+            int const sr = stage_begin(pl, ST_REFRESH, stream);
+            DEV(lsk_vtab_refresh(pl->gtab->tab, pl->d_vtab, xs, stream));
+            stage_end(pl, sr, stream);
+            ix.vtab = pl->d_vtab;
         }
         int const st = stage_begin(pl, ST_ROWS, stream);
         int slot = timing_begin(pl, stream);

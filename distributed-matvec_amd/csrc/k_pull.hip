@@ -388,6 +388,63 @@ __device__ __forceinline__ uint32_t gt_resolve(lsk_gtab const &t, uint64_t const
         cur = *(ulonglong2 const *)(tab + 2 * b);
     }
 }
+// ---- value table (lsk_vtab): the index table with 32-byte buckets {entry0, entry1, x[slot0], x[slot1]} ------------------------------
+// Same shape, same placement as the index table it is copied from (bucket b of one = bucket b of the other), so the probe
+// sequence is identical; what changes is that the bucket brings the partner's VALUE with it.  Today a far partner of the
+// projected pull kernel costs a bucket probe and then a dependent gather of x[slot] -- two random 64-byte requests where the
+// fabric serves ~56 G/s (chain_40_symm: 1.0 TB of requests per matvec for 27.6 GB of compulsory bytes).  Here it costs one.
+// Price: 32 instead of 16 bytes per bucket (chain_40_symm: 27.6 GB) and a refresh per matvec -- in TABLE order, so the writes
+// stream and only the reads of x are random (N requests; the round-2 value table was refreshed in ROW order: N random 16-byte
+// WRITES, 43 ms on chain_40_symm).  The static half of a bucket is never rewritten.
+__global__ __launch_bounds__(kBlock) void k_vtab_from_gtab(int64_t buckets, uint64_t const *__restrict__ gt, uint64_t *__restrict__ vt) {
+    for (int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x; b < buckets; b += (int64_t)gridDim.x * kBlock) {
+        const ulonglong2 e = *(ulonglong2 const *)(gt + 2 * b);
+        *(ulonglong2 *)(vt + 4 * b) = e;
+        *(ulonglong2 *)(vt + 4 * b + 2) = make_ulonglong2(0, 0);
+    }
+}
+template <typename X8>
+__global__ __launch_bounds__(kBlock) void k_vtab_refresh(int64_t buckets, uint64_t *__restrict__ vt, double const *__restrict__ xsrc) {
+    for (int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x; b < buckets; b += (int64_t)gridDim.x * kBlock) {
+        typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+        const u64x2 raw = __builtin_nontemporal_load((u64x2 const *)(vt + 4 * b));
+        const ulonglong2 e = make_ulonglong2(raw.x, raw.y);
+        double2 v;
+        v.x = e.x != kGtEmpty ? xsrc[(uint32_t)e.x] : 0.0;
+        v.y = e.y != kGtEmpty ? xsrc[(uint32_t)e.y] : 0.0;
+        __builtin_nontemporal_store(v.x, (double *)(vt + 4 * b + 2));
+        __builtin_nontemporal_store(v.y, (double *)(vt + 4 * b + 3));
+    }
+}
+extern "C" int lsk_vtab_build(lsk_gtab t, uint64_t *vt, void *stream) {
+    const int64_t nb = (int64_t)1 << t.bbits;
+    hipLaunchKernelGGL(k_vtab_from_gtab, dim3(grid_for(nb)), dim3(kBlock), 0, (hipStream_t)stream, nb, t.entries, vt);
+    LSK_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int lsk_vtab_refresh(lsk_gtab t, uint64_t *vt, void const *xsrc, void *stream) {
+    const int64_t nb = (int64_t)1 << t.bbits;
+    int64_t blocks = (nb + kBlock - 1) / kBlock;
+    if (blocks > ((int64_t)1 << 30)) blocks = (int64_t)1 << 30; // a plain grid: one bucket per thread streams best
+    hipLaunchKernelGGL(k_vtab_refresh<double>, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, nb, vt, (double const *)xsrc);
+    LSK_LAUNCH_CHECK();
+    return 0;
+}
+// value (and slot) of the key with home bucket b / tag: `cur` / `vals` are the home bucket's two halves, already loaded
+__device__ __forceinline__ double vt_resolve(lsk_gtab const &t, uint64_t const *__restrict__ vt, uint64_t b, uint32_t tag, ulonglong2 cur,
+                                             double2 vals, uint32_t &slot) {
+    const uint64_t bmask = (1ULL << t.bbits) - 1;
+    for (int d = 0;; ++d) {
+        const uint32_t want = gt_hi(tag, d);
+        if ((uint32_t)(cur.x >> 32) == want && cur.x != kGtEmpty) { slot = (uint32_t)cur.x; return vals.x; }
+        if ((uint32_t)(cur.y >> 32) == want && cur.y != kGtEmpty) { slot = (uint32_t)cur.y; return vals.y; }
+        if (cur.x == kGtEmpty || cur.y == kGtEmpty || d == kGtMaxDist) { slot = 0xffffffffu; return 0.0; }
+        b = (b + 1) & bmask;
+        cur = *(ulonglong2 const *)(vt + 4 * b);
+        vals = *(double2 const *)(vt + 4 * b + 2);
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void k_gtab_lookup(lsk_gtab t, int64_t n, uint64_t const *__restrict__ keys,
                                                         uint32_t *__restrict__ out) {
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
@@ -504,7 +561,11 @@ extern "C" int lsk_scatter_owned(int64_t n, uint32_t const *perm, int64_t base, 
 //     (nw_*, below): one ds_read_b64 instead of the 11-step binary search of round 3; global index -> slot (perm[g] or g);
 //   far partners: ONE 16-byte bucket of the static index table (lsk_gtab) -> slot.
 // What happens with the slot is the SINK:
-//   SINK_FUSED   : value = xsrc[slot], ds_add_f64 into the tile's LDS copy of y, y written once (the one-GPU default);
+//   SINK_FUSED   : value = xsrc[slot], ds_add_f64 into the tile's LDS copy of y, y written once;
+//   SINK_VALUE   : (round 6; f64, one partition) as FUSED, but a far partner costs ONE fabric request instead of two dependent
+//                  ones: the table bucket is 32 bytes -- the two index entries AND the values x[slot] of both (lsk_vtab, below) --
+//                  fetched by two 16-byte loads of one 64-byte line; the values are refreshed once per matvec in TABLE order
+//                  (k_vtab_refresh: streaming over the table, one random read of x per representative);
 //   SINK_RESOLVE : the slot (and, unless every packet has the same real amplitude, its coefficient) is written to the
 //                  per-wave packet stream of lsk_pullbuf and NOTHING of x is read -- this half of the matvec runs while the
 //                  blocks of x are still on the wire (ls_amd_repl_matvec, dist.c); k_pull_gather then streams the slots,
@@ -514,7 +575,7 @@ constexpr int kWvRing = 256; // slots per wave: < 64 left over + 3 groups x 64 l
 constexpr int kWvGroups = 3;
 enum { K4_TRIVIAL = 0, K4_PM1 = 1, K4_GENERAL = 2 };     // what K4 has to deliver (lsk_basis.k4_mode != 0 -> TRIVIAL)
 enum { COEF_UNI = 0, COEF_REAL = 1, COEF_CPLX = 2 };      // per-packet coefficient: none (one real amplitude), f64, 2 x f64
-enum { SINK_FUSED = 0, SINK_RESOLVE = 1 };
+enum { SINK_FUSED = 0, SINK_RESOLVE = 1, SINK_VALUE = 2 };
 constexpr uint32_t kNoSlot = 0xffffffffu;
 
 // Near window as a hash set in LDS: kNwSets sets of two 4-byte entries.  h = d * odd constant is a bijection of the 32-bit
@@ -582,7 +643,9 @@ __global__ __launch_bounds__(kBlock, (COEF == COEF_CPLX ? 4 : 6)) void k_pull_t(
                                                    double *__restrict__ y, lsk_pullbuf buf, int *err, int xcd_chunk) {
     typedef typename ChainX<CPLX>::type X;
     constexpr bool REAL = COEF != COEF_CPLX;
-    constexpr bool FUSED = SINK == SINK_FUSED;
+    constexpr bool VALUE = SINK == SINK_VALUE;
+    constexpr bool FUSED = SINK == SINK_FUSED || VALUE;
+    static_assert(!(VALUE && CPLX), "the value table holds f64 values");
     constexpr int NC = COEF == COEF_UNI ? 0 : (COEF == COEF_REAL ? 1 : 2);
     X const *__restrict__ xv = (X const *)xsrc;
     constexpr int kCap = (kBlock / 64) * kWvRing;
@@ -596,7 +659,7 @@ __global__ __launch_bounds__(kBlock, (COEF == COEF_CPLX ? 4 : 6)) void k_pull_t(
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int rb = wave * kWvRing; // this wave's ring
-    uint64_t const *__restrict__ tab = ix.tab.entries;
+    uint64_t const *__restrict__ tab = VALUE ? ix.vtab : ix.tab.entries;
     const int64_t n_tiles = (row1 - row0 + kBlock - 1) / kBlock;
     for (int64_t tb = blockIdx.x; tb < n_tiles; tb += gridDim.x) {
         const int64_t t0 = row0 + pull_tile_of_block(tb, n_tiles, gridDim.x >= n_tiles ? xcd_chunk : 0) * kBlock;
@@ -649,6 +712,7 @@ __global__ __launch_bounds__(kBlock, (COEF == COEF_CPLX ? 4 : 6)) void k_pull_t(
             bool live[K];
             uint32_t tag[K], slot[K];
             ulonglong2 first[K];
+            double2 fval[VALUE ? K : 1]; // SINK_VALUE: the value half of the home bucket
 #pragma unroll
             for (int k = 0; k < K; ++k) {
                 live[k] = k + 1 < K || lane < m;
@@ -695,7 +759,10 @@ __global__ __launch_bounds__(kBlock, (COEF == COEF_CPLX ? 4 : 6)) void k_pull_t(
             auto step_first = [&](int k) { // first-level loads: perm entry (near) or home bucket (far)
                 if (!live[k]) return;
                 if (pos[k] >= 0) slot[k] = ix.perm ? s_nwslot[pos[k]] : (uint32_t)(gbase + pos[k]);
-                else first[k] = *(ulonglong2 const *)(tab + 2 * bkt[k]);
+                else if constexpr (VALUE) { // both halves of the 32-byte bucket at once: one line, one fabric request
+                    first[k] = *(ulonglong2 const *)(tab + 4 * bkt[k]);
+                    fval[k] = *(double2 const *)(tab + 4 * bkt[k] + 2);
+                } else first[k] = *(ulonglong2 const *)(tab + 2 * bkt[k]);
             };
             // (step by step over the chunks.  Chunk by chunk instead -- the home-bucket load of chunk k in flight while chunk k + 1 runs
             // its K4 -- measured no different: chain_36_symm 17.61 vs 17.72 ms, chain_40_symm 276.5 vs 277.9 ms,
@@ -706,16 +773,23 @@ __global__ __launch_bounds__(kBlock, (COEF == COEF_CPLX ? 4 : 6)) void k_pull_t(
             for (int k = 0; k < K; ++k) step_window(k);
 #pragma unroll
             for (int k = 0; k < K; ++k) step_first(k);
+            [[maybe_unused]] double far_val[K];
 #pragma unroll
             for (int k = 0; k < K; ++k) {
+                far_val[k] = 0.0;
                 if (!live[k] || pos[k] >= 0) continue;
-                slot[k] = gt_resolve(ix.tab, tab, bkt[k], tag[k], first[k]);
+                if constexpr (VALUE) far_val[k] = vt_resolve(ix.tab, tab, bkt[k], tag[k], first[k], fval[k], slot[k]);
+                else slot[k] = gt_resolve(ix.tab, tab, bkt[k], tag[k], first[k]);
                 if (slot[k] == kNoSlot) { atomicExch(err, 1); live[k] = false; }
             }
             if constexpr (FUSED) {
                 X val[K];
 #pragma unroll
-                for (int k = 0; k < K; ++k) val[k] = (live[k] && !(kAblate && (bs.debug_ablate & 64))) ? xv[slot[k]] : cx_zero<X>();
+                for (int k = 0; k < K; ++k) {
+                    if constexpr (VALUE) { // far partners brought their value with the bucket; near ones read x next to the tile
+                        val[k] = !live[k] ? 0.0 : (pos[k] >= 0 ? xv[slot[k]] : far_val[k]);
+                    } else val[k] = (live[k] && !(kAblate && (bs.debug_ablate & 64))) ? xv[slot[k]] : cx_zero<X>();
+                }
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
                     if (!live[k]) continue;
@@ -936,7 +1010,7 @@ static int dispatch_pull_t(lsk_operator const &op, lsk_basis const &bs, int64_t 
     pull_kinds(op, bs, k4m, coef);
 #define LSK_PT(K4M, COEF) launch_pull_t<W, K4M, COEF, CPLX, SINK>(op, bs, row0, row1, reps, norms_local, ix, reps_global, n_global, xsrc, halo, y, buf, d_err, s)
     if (coef == COEF_CPLX) {
-        if constexpr (!CPLX && SINK == SINK_FUSED) { snprintf(g_err, sizeof(g_err), "lsk_tile_pull: complex coefficients need c128 vectors"); return -1; }
+        if constexpr (!CPLX && (SINK == SINK_FUSED || SINK == SINK_VALUE)) { snprintf(g_err, sizeof(g_err), "lsk_tile_pull: complex coefficients need c128 vectors"); return -1; }
         else { if (k4m == K4_TRIVIAL) LSK_PT(K4_TRIVIAL, COEF_CPLX); else if (k4m == K4_PM1) LSK_PT(K4_PM1, COEF_CPLX); else LSK_PT(K4_GENERAL, COEF_CPLX); }
     } else if (coef == COEF_REAL) { if (k4m == K4_TRIVIAL) LSK_PT(K4_TRIVIAL, COEF_REAL); else LSK_PT(K4_PM1, COEF_REAL); }
     else LSK_PT(K4_TRIVIAL, COEF_UNI);
@@ -960,7 +1034,10 @@ extern "C" int lsk_tile_pull_idx(lsk_operator op, lsk_basis bs, int cplx, int64_
     hipStream_t s = (hipStream_t)stream;
     int rc;
 #define LSK_PA op, bs, row0, row1, reps, norms_local, ix, reps_global, n_global, xsrc, halo, y, none, d_err, s
-    if (bs.number_sites <= 32) rc = cplx ? dispatch_pull_t<uint32_t, true, SINK_FUSED>(LSK_PA) : dispatch_pull_t<uint32_t, false, SINK_FUSED>(LSK_PA);
+    if (ix.vtab) { // value table (f64, one partition): one fabric request per far partner
+        if (cplx || ix.perm) { snprintf(g_err, sizeof(g_err), "lsk_tile_pull_idx: the value table serves f64 vectors of one partition"); return -1; }
+        rc = bs.number_sites <= 32 ? dispatch_pull_t<uint32_t, false, SINK_VALUE>(LSK_PA) : dispatch_pull_t<uint64_t, false, SINK_VALUE>(LSK_PA);
+    } else if (bs.number_sites <= 32) rc = cplx ? dispatch_pull_t<uint32_t, true, SINK_FUSED>(LSK_PA) : dispatch_pull_t<uint32_t, false, SINK_FUSED>(LSK_PA);
     else rc = cplx ? dispatch_pull_t<uint64_t, true, SINK_FUSED>(LSK_PA) : dispatch_pull_t<uint64_t, false, SINK_FUSED>(LSK_PA);
 #undef LSK_PA
     if (rc != 0) return -1;

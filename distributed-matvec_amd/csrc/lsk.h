@@ -363,7 +363,12 @@ typedef struct lsk_pullidx {
     lsk_gtab tab;
     uint32_t const *perm; /* device [n_global] or NULL */
     int64_t row_g0;
+    uint64_t const *vtab; /* NULL, or the VALUE table of the same shape (k_pull.hip, lsk_vtab_*): 32-byte buckets {entry0, entry1, x[slot0],
+                           * x[slot1]} -- one fabric request per far partner; f64 vectors of one partition, refreshed per matvec */
 } lsk_pullidx;
+/* value table: 32 << bbits bytes (allocated by the caller) copied from the index table `t`; refresh = x[slot] of every entry, in table order */
+int lsk_vtab_build(lsk_gtab t, uint64_t *vtab, void *stream);
+int lsk_vtab_refresh(lsk_gtab t, uint64_t *vtab, void const *xsrc, void *stream);
 int lsk_tile_pull_idx(lsk_operator op, lsk_basis bs, int cplx, int64_t row0, int64_t row1, uint64_t const *reps,
                       double const *norms_local, lsk_pullidx ix, uint64_t const *reps_global, int64_t n_global,
                       void const *xsrc, int halo, void *y, int *d_err, void *stream);

@@ -61,8 +61,8 @@ for step in "$@"; do
       for st in 1 0; do echo "--- LS_AMD_PACKET_STREAMS=$st"; LS_AMD_PACKET_STREAMS=$st timeout 600 python scripts/loopback_bench.py --L "$a" --P 8 --steps 3 --mode packets 2>&1 | grep -E "ranks sharing|aggregate|rank 0:|producers|localeIdxOf|consumers" | cut -c1-300; done | tee "$OUT/loopback_packets_$a.txt" ;;
     loopback:*) a=${step#loopback:}; L=${a%s}; S=""; [ "$a" != "$L" ] && S="--symm"
       timeout 900 python scripts/loopback_bench.py --L "$L" $S --P 8 --steps 3 > "$OUT/loopback_$a.txt" 2>&1; grep -E "ranks sharing|x received|aggregate" "$OUT/loopback_$a.txt" | cut -c1-300 ;;
-    pmc:*) IFS=: read -r _ model dtype <<< "$step"
-      MODEL=$model DTYPE=$dtype TAG="${TAG}_pmc_${model}_${dtype}" bash scripts/gpu_pmc_traffic.sh 2>&1 | tail -14 ;;
+    pmc:*) IFS=: read -r _ model dtype mode <<< "$step"   # pmc:<model>:<dtype>[:push]
+      MODEL=$model DTYPE=$dtype MODE=${mode:-auto} TAG="${TAG}_pmc_${model}_${dtype}${mode:+_$mode}" bash scripts/gpu_pmc_traffic.sh 2>&1 | tail -14 ;;
     prof_bench)
       cd /tmp && timeout -k 5 300 rocprofv3 --kernel-trace --stats -d "$GRAFT_REPO_ROOT/$OUT/trace" -o trace -- python "$GRAFT_REPO_ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-extra > "$GRAFT_REPO_ROOT/$OUT/prof_bench.log" 2>&1
       cd "$GRAFT_REPO_ROOT" && python3 scripts/rocpd_summary.py "$OUT" > "$OUT/prof_bench_summary.txt" 2>&1; rm -rf "$OUT"/trace/*.db "$OUT"/trace/*/*.db; head -12 "$OUT/prof_bench_summary.txt" | cut -c1-170 ;;

@@ -19,17 +19,23 @@ SEEN = []  # kernel names the counters were read from
 
 
 def mean_counter(root, sub, counter, needle):
-    vals = []
+    """mean of `counter` over the dispatches of THE instantiation of `needle` that ran most often (the timed kernel: since round
+    6 the bench line also runs the generic kernels once each for its parity object, and they share a family name)"""
+    by_name = {}
     for db_path in glob.glob(os.path.join(root, sub, "**", "*_results.db"), recursive=True):
         cur = sqlite3.connect(db_path).cursor()
         cols = [c[1] for c in cur.execute("pragma table_info('counters_collection')")]
         name_col = "kernel_name" if "kernel_name" in cols else cols[0]
         for kn, v in cur.execute(f"select {name_col}, value from counters_collection where counter_name = ?", (counter,)):
             if needle in kn:
-                vals.append(v)
-                if kn not in SEEN:
-                    SEEN.append(kn)
-    return (sum(vals) / len(vals), len(vals)) if vals else (None, 0)
+                by_name.setdefault(kn, []).append(v)
+    if not by_name:
+        return None, 0
+    kn = max(by_name, key=lambda k: len(by_name[k]))
+    if kn not in SEEN:
+        SEEN.append(kn)
+    vals = by_name[kn]
+    return sum(vals) / len(vals), len(vals)
 
 
 def main():

@@ -212,6 +212,60 @@ def test_indexed_pull_mode_single_locale(torch, monkeypatch, name, halo, split):
     assert np.abs(gotc - wantc).max() <= 1e-12 * max(1.0, np.abs(wantc).max())
 
 
+@pytest.mark.parametrize("name", PROJECTED_MODELS + ["heisenberg_square_4x4", "heisenberg_chain_32_symm"])
+@pytest.mark.parametrize("halo", ["256", "0", "37"])
+def test_value_table_pull_mode_single_locale(torch, monkeypatch, name, halo):
+    """The VALUE-table form of the projected pull kernel (round 6; k_pull.hip SINK_VALUE, lsk_vtab_*): the index table's buckets
+    widened to 32 bytes {entry0, entry1, x[slot0], x[slot1]} -- one fabric request per far partner --, refreshed per matvec in table
+    order.  f64 vectors of one partition == the oracle with the near window on, off and at an odd size; a second matvec with ANOTHER x
+    (the refresh must replace every value); c128 vectors and a plan that switches the slot cache on fall back to the index table."""
+    monkeypatch.setenv("LS_AMD_PULL_INDEXED", "1")
+    monkeypatch.setenv("LS_AMD_PULL_VALUES", "1")
+    monkeypatch.setenv("LS_AMD_PULL_HALO", halo)
+    if name == "heisenberg_chain_32_symm" and halo != "256":
+        pytest.skip("the large case once")
+    D, basis, h, reps, masks = setup_model(torch, model_config(name), 1)
+    if name == "heisenberg_chain_32_symm":  # 4.7e6 representatives: against the index-table kernel, element by element
+        x = D.fillRandom(reps[0], 7, torch.float64)
+        y = torch.zeros_like(x)
+        pl = D.MatvecPlan(h, reps, torch.float64, mode="pull")
+        assert pl.kernel == "tile-pull+values"
+        pl.matvec([x], [y])
+        monkeypatch.setenv("LS_AMD_PULL_VALUES", "0")
+        y2 = torch.zeros_like(x)
+        pl2 = D.MatvecPlan(h, reps, torch.float64, mode="pull")
+        assert pl2.kernel == "tile-pull+indexed"
+        pl2.matvec([x], [y2])
+        assert float((y - y2).abs().max()) <= 1e-12 * float(y2.abs().max())
+        pl.destroy(); pl2.destroy()
+        return
+    want_reps = oracle_reps(name)
+    rs = np.random.RandomState(152)
+    x = rs.rand(len(want_reps)) - 0.5
+    got, pl = run_matvec(torch, D, h, reps, masks, x, 1, "pull")
+    assert pl.kernel == "tile-pull+values"
+    assert_close(got, oracle_for(name).local_matvec(want_reps, x), name)
+    x2 = rs.rand(len(want_reps)) - 0.5
+    got2, _ = run_matvec(torch, D, h, reps, masks, x2, 1, "pull")  # the same plan (cached per operator): every value is replaced
+    assert_close(got2, oracle_for(name).local_matvec(want_reps, x2), name)
+    xc = x + 1j * (rs.rand(len(want_reps)) - 0.5)
+    gotc, plc = run_matvec(torch, D, h, reps, masks, xc, 1, "pull")
+    assert plc.kernel == "tile-pull+indexed"  # c128: the table holds f64 values
+    wantc = oracle_for(name).local_matvec(want_reps, xc)
+    assert np.abs(gotc - wantc).max() <= 1e-12 * max(1.0, np.abs(wantc).max())
+    # a plan that turns the slot cache on gives its value table up
+    r = reps[0]
+    pl3 = D.MatvecPlan(h, [r], torch.float64, mode="pull")
+    assert pl3.kernel == "tile-pull+values"
+    if pl3.cache_slots(0) > 0:
+        xt = torch.from_numpy(x).cuda()
+        yt = torch.zeros_like(xt)
+        pl3.matvec([xt], [yt])
+        assert pl3.kernel == "tile-pull+indexed+cached"
+        assert_close(yt.cpu().numpy(), oracle_for(name).local_matvec(want_reps, x), name)
+    pl3.destroy()
+
+
 @pytest.mark.parametrize("L,sector", [(8, 1), (12, 5)])
 @pytest.mark.parametrize("split", ["0", "200000"])
 def test_indexed_pull_mode_complex_characters(torch, monkeypatch, L, sector, split):
