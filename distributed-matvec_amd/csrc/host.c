@@ -1528,6 +1528,7 @@ struct ls_amd_plan {
     int slot_cache, slot_cache_valid;
     int64_t slot_cache_bytes;
     void const *y_checked[2]; /* y pointers whose memory kind was looked at (push plans: ls_amd_internal_check_y) */
+    int leaves_basis;         /* pull plan over a non-Hermitian operator whose row expansion leaves the basis (found at plan time) */
     /* kernel timing ring */
     int t_capacity, t_count;
     void **t_start, **t_stop;
@@ -2635,10 +2636,13 @@ int ls_amd_plan_create(ls_amd_plan **out, ls_hs_operator const *op, ls_amd_dtype
             char const *e = getenv("LS_AMD_MODE");
             if (e && strcmp(e, "pull") == 0) m = LS_AMD_MODE_PULL;
             else if (e && strcmp(e, "push") == 0) m = LS_AMD_MODE_PUSH;
-            else m = OEXT(op)->is_hermitian ? LS_AMD_MODE_PULL : LS_AMD_MODE_PUSH; /* measured: pull is 2.6x push on chain_32 */
+            /* measured: pull is 2.6x push on chain_32.  Round 6: on an unprojected basis ANY operator can be pulled -- row i takes
+             * <i|H_g|i ^ x_g> from the partner's row expansion (k_direct, k_rows.hip) -- so non-Hermitian operators leave the
+             * atomics too; only the inversion sectors still pull through the Hermiticity of the projected matrix */
+            else m = (OEXT(op)->is_hermitian || pl->dbs.proj == LSK_PROJ_NONE) ? LS_AMD_MODE_PULL : LS_AMD_MODE_PUSH;
         }
-        if (m == LS_AMD_MODE_PULL && !OEXT(op)->is_hermitian) {
-            if (mode == LS_AMD_MODE_PULL) { free(pl); return set_error("pull mode needs a Hermitian operator"); }
+        if (m == LS_AMD_MODE_PULL && !OEXT(op)->is_hermitian && pl->dbs.proj != LSK_PROJ_NONE) {
+            if (mode == LS_AMD_MODE_PULL) { free(pl); return set_error("pull mode needs a Hermitian operator (or an unprojected basis)"); }
             m = LS_AMD_MODE_PUSH;
         }
         pl->family = m == LS_AMD_MODE_PULL ? FAMILY_DIRECT_PULL : FAMILY_DIRECT_PUSH;
@@ -2719,6 +2723,14 @@ int ls_amd_plan_create(ls_amd_plan **out, ls_hs_operator const *op, ls_amd_dtype
             return -1;
         }
         if (!pl->has_chain && !pl->has_pairs && build_tilemap(pl, ps0->count, 256) != 0) { ls_amd_plan_destroy(pl); return -1; }
+        if (pl->family == FAMILY_DIRECT_PULL && !OEXT(op)->is_hermitian) {
+            /* a gather never sees a state that is mapped OUT of the basis (the reference's halt, DMV:115-118): checked once, here;
+             * ls_amd_plan_check reports it after every matvec like the push kernels' error flag */
+            int flag = 0;
+            if (lsk_direct_validate(pl->dop, pl->dbs, ps0->index, ps0->count, ps0->d_reps, pl->d_err, stream) != 0 || lsk_sync(stream) != 0 ||
+                lsk_d2h(&flag, pl->d_err, sizeof(int)) != 0 || lsk_h2d(pl->d_err, &zero, sizeof(int)) != 0) { ls_amd_plan_destroy(pl); return dev_error(); }
+            pl->leaves_basis = flag != 0;
+        }
     }
     if (pl->family == FAMILY_TILE && my_partition < 0 && pl->send_capacity > 0 && !pl->streams) {
         if (lsk_malloc(&pl->d_send, (size_t)pl->send_capacity) != 0) { ls_amd_plan_destroy(pl); return dev_error(); }
@@ -3395,7 +3407,7 @@ int ls_amd_matvec(ls_amd_plan *pl, void const *const *d_x, void *const *d_y, voi
         else if (pl->has_pairs)
             DEV(lsk_pairs(pl->pairs, pl->dbs.hamming_weight, pl->cplx, pl->tilemap, ps->count, d_x[0], d_y[0], stream));
         else
-            DEV(lsk_direct(pl->dop, pl->dbs, ps->index, pl->cplx, pl->family == FAMILY_DIRECT_PULL, pl->tilemap, ps->d_reps,
+            DEV(lsk_direct(pl->dop, pl->dbs, ps->index, pl->cplx, pl->family == FAMILY_DIRECT_PULL ? (OEXT(pl->op)->is_hermitian ? 1 : 2) : 0, pl->tilemap, ps->d_reps,
                            d_x[0], d_y[0], pl->d_err, stream));
         timing_end(pl, slot, stream);
         stage_end(pl, st, stream);
@@ -3510,7 +3522,7 @@ int ls_amd_plan_check(ls_amd_plan *pl, void *stream) {
     int flag = 0, zero = 0;
     DEV(lsk_sync(stream));
     DEV(lsk_d2h(&flag, pl->d_err, sizeof(int)));
-    if (flag) {
+    if (flag || pl->leaves_basis) {
         DEV(lsk_h2d(pl->d_err, &zero, sizeof(int)));
         return set_error("invalid index: the operator generated a state outside the basis "
                          "(it does not respect the basis symmetries)"); /* DMV:115-118 */

@@ -50,7 +50,10 @@ extern "C" int lsk_diag(lsk_operator op, int cplx, int64_t n, uint64_t const *re
 // over flip-mask groups.  Consecutive lanes hold consecutive basis states, so for a given group
 // the active lanes' targets are (piecewise) consecutive as well: the scatter / gather coalesces.
 //   PUSH: y[idx(beta)] += c x[i]                 (K2 + K3 + K7 + K8 fused; y holds the diagonal part)
-//   PULL: y[i] = d x[i] + sum conj(c) x[idx(beta)]   (Hermitian operators; no atomics, y written once)
+//   PULL: y[i] = d x[i] + sum_g <i|H_g|i ^ x_g> x[idx(i ^ x_g)]   (no atomics, y written once).  The coefficient is the one the
+//         reference's row expansion of the PARTNER state gives to row i -- group g evaluated at i ^ x_g -- so ANY operator on an
+//         unprojected basis can be pulled, Hermitian or not (round 6; for a Hermitian one it equals conj(c)).  Inversion sectors
+//         (INV) keep conj(c) of the row's own expansion: the projected matrix is pulled through its Hermiticity.
 // Exchange runs (adjacent transpositions, e.g. the open bonds of a chain) take a branch-free inner
 // loop: the rank of the target differs from the row's own rank by +-C(lo, k) with k = number of set
 // bits below lo, which is carried incrementally; inactive lanes gather their own x and add 0, so
@@ -168,9 +171,9 @@ __global__ __launch_bounds__(kBlock) void k_direct(lsk_runs runs, int n_groups, 
                             idx = act ? idx : i32;
                             if (CPLX) {
                                 double yr = x[2 * (size_t)idx], yi = x[2 * (size_t)idx + 1];
-                                // conj(v) * x[idx]
-                                accr += act ? (vr * yr + vi * yi) : 0.0;
-                                acci += act ? (vr * yi - vi * yr) : 0.0;
+                                // v * x[idx]: an exchange group has the SAME amplitude for both patterns, so <i|H|j> = v (vi == 0 for a Hermitian H)
+                                accr += act ? (vr * yr - vi * yi) : 0.0;
+                                acci += act ? (vr * yi + vi * yr) : 0.0;
                             } else {
                                 double yv = x[idx];
                                 accr = fma(act ? vr : 0.0, yv, accr);
@@ -187,8 +190,8 @@ __global__ __launch_bounds__(kBlock) void k_direct(lsk_runs runs, int n_groups, 
                             idx = act ? idx : ig;
                             if (CPLX) {
                                 double yr = x[2 * idx], yi = x[2 * idx + 1];
-                                accr += act ? (vr * yr + vi * yi) : 0.0;
-                                acci += act ? (vr * yi - vi * yr) : 0.0;
+                                accr += act ? (vr * yr - vi * yi) : 0.0;
+                                acci += act ? (vr * yi + vi * yr) : 0.0;
                             } else {
                                 double yv = x[idx];
                                 accr = fma(act ? vr : 0.0, yv, accr);
@@ -207,8 +210,11 @@ __global__ __launch_bounds__(kBlock) void k_direct(lsk_runs runs, int n_groups, 
         for (int g = g_begin; g < n_groups; ++g) {
             lsk_group const G = groups[g];
             double cr, ci;
-            group_coeff<REAL>(G, off, (uint64_t)a, cr, ci);
+            // pull on an unprojected basis: <i|H_g|i ^ x_g>, the coefficient of the PARTNER's row expansion (any operator)
+            constexpr bool PARTNER = PULL && !INV;
+            group_coeff<REAL>(G, off, (uint64_t)(PARTNER ? a ^ (W)G.x : a), cr, ci);
             if (cr == 0.0 && (REAL || ci == 0.0)) continue;
+            if (PARTNER) ci = -ci; // (the accumulation below multiplies by conj(c): written for the Hermitian shortcut of the INV sectors)
             W beta = a ^ (W)G.x;
             bool flipped = false;
             if (INV) { // K3
@@ -226,12 +232,15 @@ __global__ __launch_bounds__(kBlock) void k_direct(lsk_runs runs, int n_groups, 
                 } else {
                     // a state of another Hamming weight is outside the basis: ls_hs_state_index would
                     // return a negative index and the reference halts (DMV:115-118)
-                    if (WT::popc(beta) != bs.hamming_weight) { atomicExch(err, 1); continue; }
+                    // (pull over a NON-Hermitian operator, gx bit 1 clear: a partner outside the basis that maps INTO it contributes
+                    // nothing -- x has no such entry; whether the operator maps the basis OUT of itself, the reference's halt, is what
+                    // lsk_direct_validate checks at plan time.  Hermitian operators keep the run-time flag: the two are the same event)
+                    if (WT::popc(beta) != bs.hamming_weight) { if (!PARTNER || (gx & 2)) atomicExch(err, 1); continue; }
                     idx = rank_combinadic_w<W, BT>(beta, s_binom);
                 }
             } else {
                 idx = search_index(ix, (uint64_t)beta);
-                if (idx < 0) { atomicExch(err, 1); continue; } // DMV:115-118
+                if (idx < 0) { if (!PARTNER || (gx & 2)) atomicExch(err, 1); continue; } // DMV:115-118
             }
             if (PULL) {
                 // conj(c) * x[idx]
@@ -269,7 +278,7 @@ static int launch_direct3(lsk_operator op, lsk_basis bs, lsk_index ix, lsk_tilem
     if (cap < 8) cap = 8;
     if (gb > cap) gb = cap; // persistent: one block per 256-row tile costs more than it gains here (13.3 -> 15.5 ms on chain_32)
     dim3 g((unsigned)gb), b(kBlock);
-    gx = (gx & 1) | (kDirectHighPair << 24);
+    gx = (gx & 3) | (kDirectHighPair << 24);
     if (op.is_real || !kCplxOp)
         hipLaunchKernelGGL((k_direct<W, CPLX, INDEX, INV, PULL, true>), g, b, 0, (hipStream_t)stream, op.runs,
                            op.n_groups, op.groups, op.off, op.n_diag, op.diag, bs, ix, tm.entries, tm.slots_per_xcd, reps,
@@ -320,15 +329,48 @@ static int direct_dispatch(lsk_operator op, lsk_basis bs, lsk_index ix, int cplx
                     : launch_direct1<false, LSK_INDEX_SEARCH>(op, bs, ix, pull, n, reps, x, y, d_err, stream, gx, row_gidx);
     }
 }
+// Plan-time check of a pull plan over a NON-Hermitian operator: the reference's row expansion halts when some basis state is
+// mapped out of the basis (negative index, DMV:115-118), and a push matvec reports exactly that.  A gather cannot see it -- it
+// only ever asks which partners map INTO a row -- so the forward expansion is checked once, when the plan is made.
+template <int INDEX>
+__global__ __launch_bounds__(kBlock) void k_direct_validate(int n_groups, lsk_group const *__restrict__ groups, lsk_term const *__restrict__ off,
+                                                            lsk_basis bs, lsk_index ix, int64_t n, uint64_t const *__restrict__ reps, int *err) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        const uint64_t a = reps[i];
+        for (int g = 0; g < n_groups; ++g) {
+            lsk_group const G = groups[g];
+            double cr, ci;
+            group_coeff<false>(G, off, a, cr, ci);
+            if (cr == 0.0 && ci == 0.0) continue;
+            const uint64_t beta = a ^ G.x;
+            bool inside;
+            if (INDEX == LSK_INDEX_IDENTITY) inside = (beta & ~bs.site_mask) == 0;
+            else if (INDEX == LSK_INDEX_COMBINADIC) inside = __popcll(beta) == bs.hamming_weight && (beta & ~bs.site_mask) == 0;
+            else inside = search_index(ix, beta) >= 0;
+            if (!inside) atomicExch(err, 1);
+        }
+    }
+}
+extern "C" int lsk_direct_validate(lsk_operator op, lsk_basis bs, lsk_index ix, int64_t n, uint64_t const *reps, int *d_err, void *stream) {
+    if (n <= 0 || op.n_groups <= 0) return 0;
+    const dim3 g((unsigned)grid_for(n)), b(kBlock);
+    hipStream_t s = (hipStream_t)stream;
+    if (ix.kind == LSK_INDEX_IDENTITY) hipLaunchKernelGGL(k_direct_validate<LSK_INDEX_IDENTITY>, g, b, 0, s, op.n_groups, op.groups, op.off, bs, ix, n, reps, d_err);
+    else if (ix.kind == LSK_INDEX_COMBINADIC) hipLaunchKernelGGL(k_direct_validate<LSK_INDEX_COMBINADIC>, g, b, 0, s, op.n_groups, op.groups, op.off, bs, ix, n, reps, d_err);
+    else hipLaunchKernelGGL(k_direct_validate<LSK_INDEX_SEARCH>, g, b, 0, s, op.n_groups, op.groups, op.off, bs, ix, n, reps, d_err);
+    LSK_LAUNCH_CHECK();
+    return 0;
+}
 extern "C" int lsk_direct(lsk_operator op, lsk_basis bs, lsk_index ix, int cplx, int pull, lsk_tilemap tm,
                           uint64_t const *reps, void const *x, void *y, int *d_err, void *stream) {
-    return direct_dispatch(op, bs, ix, cplx, pull, tm, reps, x, y, d_err, stream, 0, nullptr);
+    // pull: 0 push | 1 pull, partners outside the basis are flagged (Hermitian operators) | 2 pull of a non-Hermitian operator
+    return direct_dispatch(op, bs, ix, cplx, pull != 0, tm, reps, x, y, d_err, stream, pull == 2 ? 0 : 2, nullptr);
 }
 // replicated-x pull: `reps` = the n rows of one partition, `x` = whole vector in global order, `ix` = index
 // of the GLOBAL basis, row_gidx[i] = global index of row i (only read for SEARCH indices)
 extern "C" int lsk_direct_gx(lsk_operator op, lsk_basis bs, lsk_index ix, int cplx, lsk_tilemap tm, uint64_t const *reps,
                              int64_t const *row_gidx, void const *x_global, void *y, int *d_err, void *stream) {
-    return direct_dispatch(op, bs, ix, cplx, 1, tm, reps, x_global, y, d_err, stream, 1, row_gidx);
+    return direct_dispatch(op, bs, ix, cplx, 1, tm, reps, x_global, y, d_err, stream, 1 | 2, row_gidx) // (replicated-x plans are Hermitian: partners outside the basis are flagged);
 }
 
 // ---------------------------------------------------------------------------------------------

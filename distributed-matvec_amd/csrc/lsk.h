@@ -229,6 +229,8 @@ int lsk_diag(lsk_operator op, int cplx, int64_t n, uint64_t const *reps, void co
 /* fused single-partition kernel without permutation symmetries (row per lane).
  * pull == 0: y[idx(beta)] += c x[i] (atomics; y must already hold the diagonal part)
  * pull == 1: y[i] = d x[i] + sum conj(c) x[idx(beta)] */
+/* plan-time check of a pull plan over a non-Hermitian operator: raises *d_err when the row expansion of some basis state leaves the basis */
+int lsk_direct_validate(lsk_operator op, lsk_basis bs, lsk_index ix, int64_t n, uint64_t const *reps, int *d_err, void *stream);
 int lsk_direct(lsk_operator op, lsk_basis bs, lsk_index ix, int cplx, int pull, lsk_tilemap tm,
                uint64_t const *reps, void const *x, void *y, int *d_err, void *stream);
 /* staged row kernel (k_chain_t): pull, real Hermitian operator, the full fixed-Hamming-weight basis without symmetries

@@ -415,6 +415,23 @@ def test_invalid_operator_is_reported(torch):
         y = [torch.zeros_like(v) for v in x]
         with pytest.raises(D.LsAmdError, match="invalid index"):
             D.matrixVectorProduct(h, x, y, reps, mode="push" if P == 1 else "auto")
+    # pull plans report it too: a Hermitian operator through the kernel's own flag, a non-Hermitian one (sigma^+ alone raises the
+    # weight: every row is mapped out of the basis, nothing is mapped in) through the plan-time check of the forward expansion
+    reps, masks = D.enumerateStates(basis, 1)
+    x = [torch.ones(reps[0].numel(), dtype=torch.float64, device="cuda")]
+    y = [torch.zeros_like(x[0])]
+    with pytest.raises(D.LsAmdError, match="invalid index"):
+        D.matrixVectorProduct(h, x, y, reps, mode="pull")
+    cfg2 = config.heisenberg_chain_config(8)
+    cfg2["hamiltonian"]["terms"].append({"expression": "σ⁺₀", "sites": [[3]]})
+    basis2, h2 = D.loadConfigFromDict(cfg2, hamiltonian=True)
+    assert not h2.isHermitian
+    reps2, _ = D.enumerateStates(basis2, 1)
+    x2 = [torch.ones(reps2[0].numel(), dtype=torch.float64, device="cuda")]
+    y2 = [torch.zeros_like(x2[0])]
+    for mode in ("auto", "pull", "push"):
+        with pytest.raises(D.LsAmdError, match="invalid index"):
+            D.matrixVectorProduct(h2, x2, y2, reps2, mode=mode)
 
 
 def test_kernel_table_entry_points(torch):
@@ -853,8 +870,9 @@ def test_replicated_x_block_rows(torch, name):
 
 
 def test_non_hermitian_complex_operator(torch):
-    """push is the only formulation for a non-Hermitian operator: sigma^+ sigma^- hopping plus a term with
-    imaginary matrix elements, c128 vectors, 1 and 3 partitions; pull must refuse."""
+    """A non-Hermitian operator -- sigma^+ sigma^- hopping plus a term with imaginary matrix elements -- on c128 vectors, 1 and 3
+    partitions.  One partition of an unprojected basis: PULLED since round 6 (row i takes <i|H_g|i ^ x_g> from the partner's row
+    expansion: no atomics, no Hermiticity needed), push on request, both == the oracle; several partitions: packets (push)."""
     import distributed_matvec_amd as D
     from oracle import c_oracle as CO
     from oracle import model as M
@@ -882,11 +900,13 @@ def test_non_hermitian_complex_operator(torch):
             D_, basis, h, reps, masks = setup_model(torch, c, P)
             assert not h.isHermitian and h.isReal == want_real
             got, pl = run_matvec(torch, D_, h, reps, masks, x, P)
-            assert pl.kernel in ("direct-push", "tile")
+            assert pl.kernel == ("direct-pull" if P == 1 else "tile")
             assert np.abs(got - want).max() <= 1e-12 * max(1.0, np.abs(want).max())
             if P == 1:
-                with pytest.raises(D.LsAmdError, match="Hermitian"):
-                    run_matvec(torch, D_, h, reps, masks, x, 1, "pull")
+                for mode2, kern in (("pull", "direct-pull"), ("push", "direct-push")):
+                    got2, pl2 = run_matvec(torch, D_, h, reps, masks, x, 1, mode2)
+                    assert pl2.kernel == kern
+                    assert np.abs(got2 - want).max() <= 1e-12 * max(1.0, np.abs(want).max())
         if not want_real:  # complex coefficients cannot act on f64 vectors
             D_, basis, h, reps, masks = setup_model(torch, c, 1)
             with pytest.raises(D.LsAmdError, match="c128"):
@@ -1253,8 +1273,8 @@ def test_host_pointer_boundary_memory_kinds(torch, monkeypatch, name):
 def test_managed_memory_is_never_used_in_place_by_push_plans(torch):
     """hipMallocManaged memory is fine-grained unless advised otherwise; the push kernels' hardware f64 atomics
     (global_atomic_add_f64 under -munsafe-fp-atomics) are specified for coarse-grained memory only.  A managed
-    y handed to a NON-HERMITIAN operator (push is its only formulation): the host-pointer boundary classifies it as its own kind,
-    stages it and equals the oracle; the device-pointer entry refuses it instead of risking lost updates."""
+    y handed to a non-Hermitian operator: the host-pointer boundary classifies it as its own kind, stages it and equals the oracle;
+    the device-pointer entry of a PUSH plan refuses it instead of risking lost updates."""
     import ctypes as C
 
     import distributed_matvec_amd as D
@@ -1295,7 +1315,7 @@ def test_managed_memory_is_never_used_in_place_by_push_plans(torch):
         assert_close(np.array(ym), want)
         # the device-pointer entry: a push plan refuses a managed y, and takes hipMalloc memory
         r = torch.from_numpy(reps.view(np.int64)).cuda()
-        pl = D.MatvecPlan(h, [r], torch.float64)
+        pl = D.MatvecPlan(h, [r], torch.float64, mode="push")  # (the default pulls since round 6: no atomics at all)
         assert pl.kernel == "direct-push"
         xs = (C.c_void_p * 1)(px.value)
         ys = (C.c_void_p * 1)(py.value)
