@@ -370,7 +370,7 @@ extern "C" int lsk_direct(lsk_operator op, lsk_basis bs, lsk_index ix, int cplx,
 // of the GLOBAL basis, row_gidx[i] = global index of row i (only read for SEARCH indices)
 extern "C" int lsk_direct_gx(lsk_operator op, lsk_basis bs, lsk_index ix, int cplx, lsk_tilemap tm, uint64_t const *reps,
                              int64_t const *row_gidx, void const *x_global, void *y, int *d_err, void *stream) {
-    return direct_dispatch(op, bs, ix, cplx, 1, tm, reps, x_global, y, d_err, stream, 1 | 2, row_gidx) // (replicated-x plans are Hermitian: partners outside the basis are flagged);
+    return direct_dispatch(op, bs, ix, cplx, 1, tm, reps, x_global, y, d_err, stream, 1 | 2, row_gidx); // (replicated-x plans are Hermitian: partners outside the basis are flagged)
 }
 
 // ---------------------------------------------------------------------------------------------
