@@ -2090,10 +2090,20 @@ static int chain_eligible(ls_amd_plan const *pl) {
     struct ls_amd_operator_ext const *ext = OEXT(op);
     char const *e = getenv("LS_AMD_ROW_KERNEL"); /* auto (default) | generic: k_direct | pairs: k_pairs_t where it applies */
     if (e && (strcmp(e, "generic") == 0 || strcmp(e, "pairs") == 0)) return 0;
-    if (op->basis->number_sites > 64 || op->basis->spin_inversion != 0 || pl->dbs.proj != LSK_PROJ_NONE ||
+    int const L = op->basis->number_sites;
+    int const inv = op->basis->spin_inversion != 0;
+    /* Inversion sectors WITHOUT permutations (round 6; BASELINE config 1's sector, BatchedOperator.chpl:119-161): at half filling the
+     * canonical state of {sigma, ~sigma} is the one with the top site clear, so the basis is the full set of weight-L/2 words of
+     * L - 1 sites in the same colex order (index kind COMBINADIC with Leff = L - 1), every pair below the top site acts as in the
+     * plain sector, and a pair that touches the top site ALWAYS lands on a flipped state: partner = rank(~beta), amplitude
+     * s v -- a cached pair.  The ring then is a run of L - 2 bonds + two cached pairs, exactly what k_chain_t already takes. */
+    if (inv && (pl->dbs.proj != LSK_PROJ_INVERSION || pl->family != FAMILY_DIRECT_PULL || (L & 1) || BEXT(op->basis)->hamming_weight != L / 2)) return 0;
+    if (L > 64 || (!inv && pl->dbs.proj != LSK_PROJ_NONE) ||
         !ext->is_real || !ext->is_hermitian || ext->runs.n_runs <= 0 || ext->n_diag <= 0)
         return 0;
-    if (ext->n_groups - ext->runs.n_run_groups > 2) return 0;
+    int extra = 0; /* the run bond (L - 2, L - 1) leaves its run and joins the cached pairs */
+    if (inv) for (int q = 0; q < ext->runs.n_runs; ++q) if (ext->runs.lo0[q] + ext->runs.cnt[q] - 1 == L - 2) extra = 1;
+    if (ext->n_groups - ext->runs.n_run_groups + extra > 2) return 0;
     for (int g = ext->runs.n_run_groups; g < ext->n_groups; ++g) {
         lsk_group const *G = &ext->groups[g];
         if (G->fast != LSK_GROUP_EXCHANGE || G->v_im != 0.0 || __builtin_popcountll(G->x) != 2) return 0;
@@ -2106,7 +2116,35 @@ static int chain_eligible(ls_amd_plan const *pl) {
  * as the reference does. */
 static int setup_chain(ls_amd_plan *pl, lsk_index index, int64_t n, uint64_t const *d_reps, void *stream) {
     struct ls_amd_operator_ext const *ext = OEXT(pl->op);
-    int const nc = ext->n_groups - ext->runs.n_run_groups;
+    int nc = ext->n_groups - ext->runs.n_run_groups;
+    /* the cached pairs: flip mask + amplitude.  Inversion sectors (chain_eligible): the run bond that touches the top site becomes
+     * a cached pair, pairs that touch the top site carry the sector's sign, and THIS plan's copy of the run table loses that bond */
+    int const Ls = pl->op->basis->number_sites;
+    int const inv = pl->dbs.proj == LSK_PROJ_INVERSION;
+    uint64_t const top = 1ULL << (Ls - 1);
+    uint64_t cx[3];
+    double cv[3];
+    int k = 0;
+    if (inv)
+        for (int q = 0; q < pl->dop.runs.n_runs; ++q)
+            if (pl->dop.runs.lo0[q] + pl->dop.runs.cnt[q] - 1 == Ls - 2) {
+                cx[k] = 3ULL << (Ls - 2);
+                cv[k++] = pl->dop.runs.v_re[q] * (double)pl->op->basis->spin_inversion;
+                if (--pl->dop.runs.cnt[q] == 0) { /* (a run of that one bond: gone) */
+                    for (int r = q; r + 1 < pl->dop.runs.n_runs; ++r) {
+                        pl->dop.runs.lo0[r] = pl->dop.runs.lo0[r + 1]; pl->dop.runs.cnt[r] = pl->dop.runs.cnt[r + 1];
+                        pl->dop.runs.v_re[r] = pl->dop.runs.v_re[r + 1]; pl->dop.runs.v_im[r] = pl->dop.runs.v_im[r + 1];
+                    }
+                    --pl->dop.runs.n_runs;
+                }
+                break;
+            }
+    for (int g = ext->runs.n_run_groups; g < ext->n_groups && k < 3; ++g) {
+        cx[k] = ext->groups[g].x;
+        cv[k++] = ext->groups[g].v_re * ((inv && (ext->groups[g].x & top)) ? (double)pl->op->basis->spin_inversion : 1.0);
+    }
+    nc = k;
+    if (nc > 2) return 0;
     /* ranks are 32-bit while the whole basis (index.count states: x is indexed by global rank) has < 2^32 - 1 states;
      * LS_AMD_CHAIN_WIDE=1 forces the 64-bit instantiation (test hook: no in-tree config is that large) */
     char const *ew = getenv("LS_AMD_CHAIN_WIDE");
@@ -2119,7 +2157,7 @@ static int setup_chain(ls_amd_plan *pl, lsk_index index, int64_t n, uint64_t con
         int zero = 0, flag = 0;
         DEV(lsk_h2d(pl->d_err, &zero, sizeof(int)));
         for (int c = 0; c < nc; ++c)
-            DEV(lsk_chain_cache(pl->dbs, index, n, d_reps, ext->groups[ext->runs.n_run_groups + c].x,
+            DEV(lsk_chain_cache(pl->dbs, index, n, d_reps, cx[c],
                                 (char *)pl->d_chain_cache + es * (size_t)c * (size_t)n, pl->chain_wide, pl->d_err, stream));
         DEV(lsk_sync(stream));
         DEV(lsk_d2h(&flag, pl->d_err, sizeof(int)));
@@ -2130,8 +2168,8 @@ static int setup_chain(ls_amd_plan *pl, lsk_index index, int64_t n, uint64_t con
             return 0;
         }
         pl->chain_cached = nc;
-        pl->chain_v[0] = ext->groups[ext->runs.n_run_groups].v_re;
-        pl->chain_v[1] = nc > 1 ? ext->groups[ext->runs.n_run_groups + 1].v_re : 0.0;
+        pl->chain_v[0] = cv[0];
+        pl->chain_v[1] = nc > 1 ? cv[1] : 0.0;
     }
     if (build_tilemap(pl, n, lsk_chain_tile_rows(pl->cplx)) != 0) return -1;
     /* 32-bit states and ranks, f64 vectors: state and partner rank of the first cached pair are fused into one 8-byte

@@ -662,7 +662,7 @@ __global__ __launch_bounds__(kBlock, (CPLX || sizeof(R) == 8 ? 5 : (sizeof(W) ==
 // *flag is raised when a partner falls outside the basis (the caller then does not use the cache, and
 // the generic path reports the error at run time as the reference does)
 template <typename W, typename R>
-__global__ __launch_bounds__(kBlock) void k_chain_cache(int64_t n, uint64_t const *__restrict__ reps, uint64_t xmask,
+__global__ __launch_bounds__(kBlock) void k_chain_cache(int64_t n, uint64_t const *__restrict__ reps, uint64_t xmask, uint64_t inv_mask,
                                                         int hamming_weight, uint64_t const *__restrict__ g_binom,
                                                         R *__restrict__ out, int *__restrict__ flag) {
     constexpr int NB = ChainTraits<W, R>::NB;
@@ -673,7 +673,8 @@ __global__ __launch_bounds__(kBlock) void k_chain_cache(int64_t n, uint64_t cons
         const W a = (W)reps[i];
         R t = ~(R)0;
         if (WordTraits<W>::popc(a & (W)xmask) == 1) {
-            const W beta = a ^ (W)xmask;
+            W beta = a ^ (W)xmask;
+            if (inv_mask) { const W f = beta ^ (W)inv_mask; beta = f < beta ? f : beta; } // inversion sector: the canonical state of {beta, ~beta}
             if (WordTraits<W>::popc(beta) != hamming_weight) atomicExch(flag, 1);
             else t = (R)rank_combinadic_w<W, R>(beta, s_binom);
         }
@@ -685,12 +686,13 @@ extern "C" int lsk_chain_cache(lsk_basis bs, lsk_index ix, int64_t n, uint64_t c
     if (n == 0) return 0;
     dim3 g(grid_for(n)), b(kBlock);
     hipStream_t s = (hipStream_t)stream;
+    const uint64_t inv_mask = bs.proj == LSK_PROJ_INVERSION ? bs.site_mask : 0;
     if (bs.number_sites <= 32 && !wide_ranks)
-        hipLaunchKernelGGL((k_chain_cache<uint32_t, uint32_t>), g, b, 0, s, n, reps, xmask, bs.hamming_weight, ix.binom, (uint32_t *)out, d_flag);
+        hipLaunchKernelGGL((k_chain_cache<uint32_t, uint32_t>), g, b, 0, s, n, reps, xmask, inv_mask, bs.hamming_weight, ix.binom, (uint32_t *)out, d_flag);
     else if (!wide_ranks)
-        hipLaunchKernelGGL((k_chain_cache<uint64_t, uint32_t>), g, b, 0, s, n, reps, xmask, bs.hamming_weight, ix.binom, (uint32_t *)out, d_flag);
+        hipLaunchKernelGGL((k_chain_cache<uint64_t, uint32_t>), g, b, 0, s, n, reps, xmask, inv_mask, bs.hamming_weight, ix.binom, (uint32_t *)out, d_flag);
     else
-        hipLaunchKernelGGL((k_chain_cache<uint64_t, uint64_t>), g, b, 0, s, n, reps, xmask, bs.hamming_weight, ix.binom, (uint64_t *)out, d_flag);
+        hipLaunchKernelGGL((k_chain_cache<uint64_t, uint64_t>), g, b, 0, s, n, reps, xmask, inv_mask, bs.hamming_weight, ix.binom, (uint64_t *)out, d_flag);
     LSK_LAUNCH_CHECK();
     return 0;
 }

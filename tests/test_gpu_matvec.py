@@ -930,6 +930,40 @@ def _chain_like_config(L, kind):
     return c
 
 
+@pytest.mark.parametrize("L,sector,kind", [(10, -1, "ring"), (12, 1, "ring"), (16, -1, "ring"), (20, 1, "ring"), (16, 1, "open"), (14, -1, "open")])
+def test_staged_kernel_takes_inversion_sectors(torch, monkeypatch, L, sector, kind):
+    """Spin-inversion sectors without permutations (BASELINE config 1's sector; BatchedOperator.chpl:119-161) on the staged row
+    kernel since round 6: at half filling the canonical states are the weight-L/2 words with the top site clear -- the full
+    fixed-weight set of L - 1 sites in colex order --, bonds below the top site act as in the plain sector, and a bond that touches
+    the top site always lands on a flipped state: a cached pair with amplitude s v.  == the oracle on every row, f64 and c128, and
+    == the generic row kernel."""
+    from oracle import c_oracle as CO
+    from oracle import model as M
+
+    cfg = _chain_like_config(L, kind)
+    cfg["basis"]["spin_inversion"] = sector
+    o = CO.COracle(M.model_from_config(cfg))
+    want_reps = o.enumerate()
+    assert len(want_reps) == __import__("math").comb(L - 1, L // 2)
+    D, basis, h, reps, masks = setup_model(torch, cfg, 1)
+    rs = np.random.RandomState(77)
+    x = rs.rand(len(want_reps)) - 0.5
+    got, pl = run_matvec(torch, D, h, reps, masks, x, 1)
+    assert pl.kernel == "direct-pull+staged", pl.kernel
+    want = o.local_matvec(want_reps, x)
+    assert_close(got, want)
+    xc = x + 1j * (rs.rand(len(want_reps)) - 0.5)
+    gotc, plc = run_matvec(torch, D, h, reps, masks, xc, 1)
+    assert plc.kernel == "direct-pull+staged"
+    wantc = o.local_matvec(want_reps, xc)
+    assert np.abs(gotc - wantc).max() <= 1e-12 * max(1.0, np.abs(wantc).max())
+    monkeypatch.setenv("LS_AMD_ROW_KERNEL", "generic")
+    D2, basis2, h2, reps2, masks2 = setup_model(torch, cfg, 1)
+    got2, pl2 = run_matvec(torch, D2, h2, reps2, masks2, x, 1)
+    assert pl2.kernel == "direct-pull"
+    assert_close(got2, want)
+
+
 ROW_KERNEL_VARIANTS = {
     "default": {},
     "generic-row-kernel": {"LS_AMD_ROW_KERNEL": "generic"},
