@@ -2211,7 +2211,8 @@ static int setup_pairs(ls_amd_plan *pl, int64_t n, uint64_t const *d_reps, void 
     int const L = op->basis->number_sites, hw = BEXT(op->basis)->hamming_weight;
     char const *e = getenv("LS_AMD_ROW_KERNEL");
     if (e && strcmp(e, "generic") == 0) return 0;
-    if (L > 32 || hw < 0 || hw + 2 > LSK_PAIR_KC || op->basis->spin_inversion != 0 || pl->dbs.proj != LSK_PROJ_NONE || !ext->is_real ||
+    int const wide = L > 32; /* 33..64 sites (round 6): the kernel streams the 8-byte representatives themselves */
+    if (L > 64 || hw < 0 || hw + 2 > LSK_PAIR_KC || op->basis->spin_inversion != 0 || pl->dbs.proj != LSK_PROJ_NONE || !ext->is_real ||
         !ext->is_hermitian || ext->n_groups < 1 || ext->n_groups > LSK_MAX_PAIRS || n <= 0 || n >= 0xffffffffLL ||
         ext->n_diag <= 0) /* (no diagonal terms: y is accumulated into, DMV:1062-1063 -- left to the generic kernel) */
         return 0;
@@ -2248,19 +2249,23 @@ static int setup_pairs(ls_amd_plan *pl, int64_t n, uint64_t const *d_reps, void 
         for (int b = 0; b < 11; ++b) if ((w >> b) & 1) r += binom(b, ++k);
         rank_low[w] = (uint16_t)r;
     }
-    uint32_t bin[32 * LSK_PAIR_KC];
-    for (int a = 0; a < 32; ++a) for (int k = 0; k < LSK_PAIR_KC; ++k) bin[a * LSK_PAIR_KC + k] = (uint32_t)binom(a, k);
+    int const nbits = wide ? 64 : 32;
+    uint32_t bin[64 * LSK_PAIR_KC]; /* (entries no valid state of a basis with < 2^32 states can touch are truncated: never read for a live lane) */
+    for (int a = 0; a < nbits; ++a) for (int k = 0; k < LSK_PAIR_KC; ++k) bin[a * LSK_PAIR_KC + k] = (uint32_t)binom(a, k);
     void *q = NULL;
-    if (lsk_malloc(&q, 4 * (size_t)n) != 0) return 0; /* no room for the 4-byte states: the generic kernel */
-    pl->d_states32 = q;
+    if (!wide) {
+        if (lsk_malloc(&q, 4 * (size_t)n) != 0) return 0; /* no room for the 4-byte states: the generic kernel */
+        pl->d_states32 = q;
+    }
     if (upload(&pl->d_pair_recs, recs, sizeof(lsk_pair) * (size_t)ext->n_groups) != 0 || upload(&pl->d_rank_low, rank_low, sizeof(rank_low)) != 0 ||
-        upload(&pl->d_pair_binom, bin, sizeof(bin)) != 0)
+        upload(&pl->d_pair_binom, bin, sizeof(uint32_t) * (size_t)nbits * LSK_PAIR_KC) != 0)
         return -1;
-    DEV(lsk_narrow_states(n, d_reps, (uint32_t *)pl->d_states32, stream));
+    if (!wide) DEV(lsk_narrow_states(n, d_reps, (uint32_t *)pl->d_states32, stream));
     pp.pairs = (lsk_pair const *)pl->d_pair_recs;
     pp.rank_low = (uint16_t const *)pl->d_rank_low;
     pp.binom = (uint32_t const *)pl->d_pair_binom;
-    pp.states = (uint32_t const *)pl->d_states32;
+    pp.states = wide ? (void const *)d_reps : (void const *)pl->d_states32;
+    pp.wide = wide;
     if (build_tilemap(pl, n, lsk_pairs_tile_rows(pl->cplx)) != 0) return -1;
     pl->pairs = pp;
     pl->has_pairs = 1;
@@ -3176,7 +3181,7 @@ int ls_amd_plan_packet_bytes(ls_amd_plan const *pl) { return pl->key_bytes + (pl
  * plus one cached partner rank per cached pair; the generic row kernels read the 8-byte state; the projected pull kernel
  * the state and norm(alpha) */
 int ls_amd_plan_row_bytes(ls_amd_plan const *pl) {
-    if (pl->has_pairs) return 4; /* the plan's 4-byte copy of the states */
+    if (pl->has_pairs) return pl->pairs.wide ? 8 : 4; /* the plan's 4-byte copy of the states, or (33..64 sites) the 8-byte representatives */
     if (pl->has_chain) {
         if (pl->d_chain_rec) return 8;
         int const narrow = pl->op->basis->number_sites <= 32 && !pl->chain_wide;

@@ -862,7 +862,9 @@ constexpr int kPairHalo = 512; // >= C(11, 5)
 constexpr int kPairFar = 8;    // gathers of HIGH pairs in flight per lane
 enum { PAIR_NEAR = 0, PAIR_STRADDLE = 1, PAIR_HIGH = 2 };
 
-template <bool CPLX, int TILE>
+// SW = state word: u32 for <= 32 sites (the plan's 4-byte copy of the states), u64 for 33..64 sites (round 6: the caller's 8-byte
+// representatives as they are; ranks stay 32-bit -- fewer than 2^32 states -- so every binomial a valid state touches fits u32)
+template <typename SW, bool CPLX, int TILE>
 __global__ __launch_bounds__(kBlock, (CPLX ? 4 : 6)) void k_pairs_t(lsk_pairplan pp, int hamming_weight, uint64_t const *__restrict__ tilemap,
                                                               int64_t slots_per_xcd, int64_t n, void const *__restrict__ x_v,
                                                               void *__restrict__ y_v) {
@@ -874,12 +876,17 @@ __global__ __launch_bounds__(kBlock, (CPLX ? 4 : 6)) void k_pairs_t(lsk_pairplan
     X *__restrict__ y = (X *)y_v;
     __shared__ X s_x[WINDOW + 1]; // last slot: 0
     __shared__ uint16_t s_rl[1 << kPairLowBits];
-    __shared__ uint32_t s_binom[32 * LSK_PAIR_KC];
+    constexpr int NBITS = 8 * (int)sizeof(SW);
+    constexpr SW ONE = (SW)1;
+    auto popc = [](SW v) { return sizeof(SW) == 4 ? __popc((uint32_t)v) : __popcll((uint64_t)v); };
+    auto ctz = [](SW v) { return sizeof(SW) == 4 ? __builtin_ctz((uint32_t)v) : __builtin_ctzll((uint64_t)v); };
+    SW const *__restrict__ states = (SW const *)pp.states;
+    __shared__ uint32_t s_binom[NBITS * LSK_PAIR_KC];
     __shared__ lsk_pair s_pairs[LSK_MAX_PAIRS];
     const int n_near = pp.n_near, n_str = pp.n_str, n_high = pp.n_high;
     const int kc = LSK_PAIR_KC;
     for (int k = threadIdx.x; k < (1 << kPairLowBits); k += kBlock) s_rl[k] = pp.rank_low[k];
-    for (int k = threadIdx.x; k < 32 * kc; k += kBlock) s_binom[k] = pp.binom[k];
+    for (int k = threadIdx.x; k < NBITS * kc; k += kBlock) s_binom[k] = pp.binom[k];
     for (int k = threadIdx.x; k < n_near + n_str + n_high; k += kBlock) s_pairs[k] = pp.pairs[k];
     if (threadIdx.x == 0) s_x[WINDOW] = cx_zero<X>();
     const int xcd = blockIdx.x & 7;
@@ -919,9 +926,10 @@ __global__ __launch_bounds__(kBlock, (CPLX ? 4 : 6)) void k_pairs_t(lsk_pairplan
             const int r = sub * kBlock + threadIdx.x;
             const bool ghost = r >= cnt; // lanes past the end stay active as copies of the last row (they store nothing)
             const int64_t i = i0 + (ghost ? cnt - 1 : r);
-            const uint32_t a = __builtin_nontemporal_load(pp.states + i);
+            const SW a = __builtin_nontemporal_load(states + i);
             const uint32_t ig = (uint32_t)i;
-            const uint32_t low = a & LOWMASK, hi = a >> kPairLowBits;
+            const uint32_t low = (uint32_t)a & LOWMASK;
+            const SW hi = a >> kPairLowBits;
             const int jr = own0 + (int)(i - i0);
             const X xr = s_x[jr];
             X acc = cx_zero<X>();
@@ -941,10 +949,10 @@ __global__ __launch_bounds__(kBlock, (CPLX ? 4 : 6)) void k_pairs_t(lsk_pairplan
             unsigned long long pending = __builtin_amdgcn_ballot_w64(true);
             while (pending) {
                 const int l0 = __builtin_ctzll(pending);
-                const uint32_t href = (uint32_t)__builtin_amdgcn_readlane((int)hi, l0);
+                const SW href = readlane_t<SW>(hi, l0);
                 const bool inseg = hi == href;
                 pending &= ~__builtin_amdgcn_ballot_w64(inseg);
-                const int kl = hamming_weight - __popc(href); // set bits of `low`, the same for every lane of the segment
+                const int kl = hamming_weight - popc(href); // set bits of `low`, the same for every lane of the segment
                 double dz_u = 0.0;
                 // ---- HIGH pairs: priced once, lane l <-> pair pass + l -------------------------------------------------------
                 for (int pass = 0; pass < n_high; pass += 64) {
@@ -952,16 +960,16 @@ __global__ __launch_bounds__(kBlock, (CPLX ? 4 : 6)) void k_pairs_t(lsk_pairplan
                     const bool in = q < n_high;
                     lsk_pair const P = s_pairs[n_near + n_str + (in ? q : 0)];
                     const int pi = P.i - kPairLowBits, pj = P.j - kPairLowBits; // positions inside `hi`
-                    const uint32_t bi = (href >> pi) & 1u, bj = (href >> pj) & 1u;
+                    const uint32_t bi = (uint32_t)(href >> pi) & 1u, bj = (uint32_t)(href >> pj) & 1u;
                     const bool act = in && bi != bj;
                     // rank of the configuration "bit at i" minus rank of "bit at j": only the set bits at or above i matter
-                    int k = kl + __popc(href & ((1u << pi) - 1u)); // set bits of the state below site i
-                    uint32_t between = href & ((1u << pj) - 1u) & ~((2u << pi) - 1u);
+                    int k = kl + popc(href & ((ONE << pi) - ONE)); // set bits of the state below site i
+                    SW between = href & ((ONE << pj) - ONE) & ~(((SW)2 << pi) - ONE);
                     int64_t lowcfg = (int64_t)s_binom[P.i * kc + min(k + 1, kc - 1)], highcfg = 0;
                     int tt = 0;
                     while (between) {
-                        const int b = __builtin_ctz(between) + kPairLowBits;
-                        between &= between - 1;
+                        const int b = ctz(between) + kPairLowBits;
+                        between &= between - ONE;
                         ++tt;
                         lowcfg += (int64_t)s_binom[b * kc + min(k + 1 + tt, kc - 1)];
                         highcfg += (int64_t)s_binom[b * kc + min(k + tt, kc - 1)];
@@ -995,16 +1003,16 @@ __global__ __launch_bounds__(kBlock, (CPLX ? 4 : 6)) void k_pairs_t(lsk_pairplan
                     const bool in = q < n_str;
                     lsk_pair const P = s_pairs[n_near + (in ? q : 0)];
                     const int pj = P.j - kPairLowBits;
-                    const uint32_t bj = (href >> pj) & 1u;
-                    const uint32_t h2 = href ^ (1u << pj);
+                    const uint32_t bj = (uint32_t)(href >> pj) & 1u;
+                    const SW h2 = href ^ (ONE << pj);
                     const int kl2 = bj ? kl + 1 : kl - 1; // a bit comes down into `low`, or leaves it
                     uint32_t base = 0;
                     {
-                        uint32_t hb = h2;
+                        SW hb = h2;
                         int idx = kl2;
                         while (hb) {
-                            const int b = __builtin_ctz(hb) + kPairLowBits;
-                            hb &= hb - 1;
+                            const int b = ctz(hb) + kPairLowBits;
+                            hb &= hb - ONE;
                             ++idx;
                             base += s_binom[b * kc + min(max(idx, 0), kc - 1)];
                         }
@@ -1034,8 +1042,11 @@ extern "C" int lsk_pairs(lsk_pairplan pp, int hamming_weight, int cplx, lsk_tile
     if (n == 0 || tm.slots_per_xcd == 0) return 0;
     if (pp.n_near + pp.n_str + pp.n_high > LSK_MAX_PAIRS || hamming_weight + 2 > LSK_PAIR_KC) { snprintf(g_err, sizeof(g_err), "lsk_pairs: plan out of range"); return -1; }
     const int64_t gb = tm.slots_per_xcd * 8; // one block per tile
-    if (cplx) hipLaunchKernelGGL((k_pairs_t<true, 512>), dim3((unsigned)gb), dim3(kBlock), 0, (hipStream_t)stream, pp, hamming_weight, tm.entries, tm.slots_per_xcd, n, x, y);
-    else hipLaunchKernelGGL((k_pairs_t<false, 1024>), dim3((unsigned)gb), dim3(kBlock), 0, (hipStream_t)stream, pp, hamming_weight, tm.entries, tm.slots_per_xcd, n, x, y);
+    if (pp.wide) { // 33..64 sites: 8-byte states
+        if (cplx) hipLaunchKernelGGL((k_pairs_t<uint64_t, true, 512>), dim3((unsigned)gb), dim3(kBlock), 0, (hipStream_t)stream, pp, hamming_weight, tm.entries, tm.slots_per_xcd, n, x, y);
+        else hipLaunchKernelGGL((k_pairs_t<uint64_t, false, 1024>), dim3((unsigned)gb), dim3(kBlock), 0, (hipStream_t)stream, pp, hamming_weight, tm.entries, tm.slots_per_xcd, n, x, y);
+    } else if (cplx) hipLaunchKernelGGL((k_pairs_t<uint32_t, true, 512>), dim3((unsigned)gb), dim3(kBlock), 0, (hipStream_t)stream, pp, hamming_weight, tm.entries, tm.slots_per_xcd, n, x, y);
+    else hipLaunchKernelGGL((k_pairs_t<uint32_t, false, 1024>), dim3((unsigned)gb), dim3(kBlock), 0, (hipStream_t)stream, pp, hamming_weight, tm.entries, tm.slots_per_xcd, n, x, y);
     LSK_LAUNCH_CHECK();
     return 0;
 }

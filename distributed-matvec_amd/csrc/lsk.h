@@ -254,8 +254,9 @@ typedef struct lsk_pairplan {
     int n_near, n_str, n_high;
     lsk_pair const *pairs;     /* device [n_near + n_str + n_high] */
     uint16_t const *rank_low;  /* device [2048]: rank of an 11-bit word among the words of its weight */
-    uint32_t const *binom;     /* device [32][LSK_PAIR_KC] */
-    uint32_t const *states;    /* device [n]: low words of the representatives (the plan's 4-byte copy) */
+    uint32_t const *binom;     /* device [32 | 64][LSK_PAIR_KC] */
+    void const *states;        /* device [n]: u32 low words of the representatives (the plan's 4-byte copy), or, wide, the u64 representatives */
+    int wide;                  /* 33..64 sites: 8-byte states (ranks stay 32-bit) */
     double dsum;               /* sum of vz over all pairs */
 } lsk_pairplan;
 int lsk_pairs_tile_rows(int cplx);

@@ -1160,6 +1160,11 @@ PAIR_KERNEL_CASES = {
     "complete-14": lambda: _lattice_config(14, 7, [(i, j) for i in range(14) for j in range(i + 1, 14)]),   # 91 pairs of every class
     "star-18-w2": lambda: _lattice_config(18, 2, [(0, j) for j in range(1, 18)] + [(17, j) for j in range(1, 17)]),  # tiny blocks: many segments per wave
     "xy-only-16": lambda: {**_lattice_config(16, 8, _square_bonds(4, 4)), "drop_zz": True},                  # no diagonal at all: y is accumulated into
+    # 33..64 sites (round 6): 8-byte states in the same kernel -- pairs of every class with sites above bit 31
+    "square-6x6-w3": lambda: _lattice_config(36, 3, _square_bonds(6, 6)),
+    "square-6x6-w4-xxz": lambda: _lattice_config(36, 4, _square_bonds(6, 6), jz=0.7, jxy=1.3),
+    "ring-40-w3-long": lambda: _lattice_config(40, 3, [(i, (i + 1) % 40) for i in range(40)], extra=([(i, (i + 17) % 40) for i in range(40)], 0.5, 0.25)),
+    "star-64-w2": lambda: _lattice_config(64, 2, [(0, j) for j in range(1, 64)] + [(63, j) for j in range(1, 63)] + [(5, 40), (12, 33), (31, 32)]),
 }
 
 
