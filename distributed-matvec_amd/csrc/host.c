@@ -1031,6 +1031,12 @@ static void classify_groups(struct ls_amd_operator_ext *ext) {
                     G->fast = LSK_GROUP_EXCHANGE;
                     G->v_re = f01r;
                     G->v_im = f01i;
+                } else if (f00r == 0 && f00i == 0 && f11r == 0 && f11i == 0 && ((f01r == 0 && f01i == 0) != (f10r == 0 && f10i == 0))) {
+                    /* a directed pair (sigma^+ sigma^-): one of the two patterns alone is a source */
+                    int const lo_src = !(f01r == 0 && f01i == 0); /* alpha = the pair's lower site alone has a coefficient */
+                    G->fast = lo_src ? LSK_GROUP_HOP_LO : LSK_GROUP_HOP_HI;
+                    G->v_re = lo_src ? f01r : f10r;
+                    G->v_im = lo_src ? f01i : f10i;
                 }
             }
         } else {
@@ -1047,7 +1053,7 @@ static void classify_groups(struct ls_amd_operator_ext *ext) {
     }
 }
 
-typedef struct { int lo; int index; double re, im; } run_item;
+typedef struct { int lo; int index; double re, im; int kind; } run_item;
 static int run_item_cmp(void const *pa, void const *pb) {
     run_item const *a = (run_item const *)pa, *b = (run_item const *)pb;
     return a->lo < b->lo ? -1 : (a->lo > b->lo ? 1 : 0);
@@ -1065,9 +1071,9 @@ static void detect_runs(struct ls_amd_operator_ext *ext, int number_sites, int i
     int ni = 0;
     for (int g = 0; g < ng; ++g) {
         lsk_group const *G = &ext->groups[g];
-        if (G->fast != LSK_GROUP_EXCHANGE || G->adj < 0) continue;
+        if (G->fast == LSK_GROUP_GENERIC || G->adj < 0) continue; /* exchange pairs and directed pairs (HOP_*) on adjacent sites */
         if (inversion && G->adj + 1 >= number_sites - 1) continue;
-        run_item it = {G->adj, g, G->v_re, G->v_im};
+        run_item it = {G->adj, g, G->v_re, G->v_im, G->fast};
         items[ni++] = it;
     }
     qsort(items, ni, sizeof(run_item), run_item_cmp);
@@ -1076,10 +1082,11 @@ static void detect_runs(struct ls_amd_operator_ext *ext, int number_sites, int i
     int w = 0;
     for (int i = 0; i < ni && R->n_runs < LSK_MAX_RUNS;) {
         int j = i + 1;
-        while (j < ni && items[j].lo == items[j - 1].lo + 1 && items[j].re == items[i].re && items[j].im == items[i].im) ++j;
+        while (j < ni && items[j].lo == items[j - 1].lo + 1 && items[j].re == items[i].re && items[j].im == items[i].im && items[j].kind == items[i].kind) ++j;
         if (j - i >= 2) {
             int r = R->n_runs++;
-            R->lo0[r] = items[i].lo; R->cnt[r] = j - i; R->v_re[r] = items[i].re; R->v_im[r] = items[i].im;
+            int const dir = items[i].kind == LSK_GROUP_HOP_LO ? 1 : (items[i].kind == LSK_GROUP_HOP_HI ? 2 : 0);
+            R->lo0[r] = items[i].lo; R->cnt[r] = (j - i) | (dir << 16); R->v_re[r] = items[i].re; R->v_im[r] = items[i].im;
             for (int k = i; k < j; ++k) { reordered[w++] = ext->groups[items[k].index]; taken[items[k].index] = 1; }
         }
         i = j;
@@ -1097,7 +1104,7 @@ static void detect_runs(struct ls_amd_operator_ext *ext, int number_sites, int i
         if (T->m != 0 || T->r != 0 || T->v_im != 0.0 || __builtin_popcountll(T->s) != 2) continue;
         int lo = __builtin_ctzll(T->s);
         if (T->s != (3ULL << lo)) continue;
-        run_item it = {lo, t, T->v_re, 0.0};
+        run_item it = {lo, t, T->v_re, 0.0, 0};
         items[ni++] = it;
     }
     qsort(items, ni, sizeof(run_item), run_item_cmp);
@@ -2216,6 +2223,12 @@ static int setup_pairs(ls_amd_plan *pl, int64_t n, uint64_t const *d_reps, void 
         !ext->is_hermitian || ext->n_groups < 1 || ext->n_groups > LSK_MAX_PAIRS || n <= 0 || n >= 0xffffffffLL ||
         ext->n_diag <= 0) /* (no diagonal terms: y is accumulated into, DMV:1062-1063 -- left to the generic kernel) */
         return 0;
+    /* The kernel walks the basis in blocks "all 11-bit low words of weight kl under one high part": C(11, kl) rows, kl ~ 11 hw / L on
+     * average.  Far from half filling the blocks are a handful of rows, a wave spans many of them and prices its HIGH / STRADDLE pairs
+     * once per block: measured on a 36-site square lattice (profiles/r6_widen_bench.txt) weight 6 -- kl ~ 1.8 -- 1.09 ms against 0.25 ms
+     * of the generic row kernel, weight 9 -- kl ~ 2.75 -- 15.3 against 14.3 ms.  Such bases keep k_direct (LS_AMD_ROW_KERNEL=pairs forces
+     * the staged kernel: tests). */
+    if (!(e && strcmp(e, "pairs") == 0) && (11 * hw < 4 * L || 11 * (L - hw) < 4 * L)) return 0;
     lsk_pair recs[LSK_MAX_PAIRS];
     memset(recs, 0, sizeof(recs));
     for (int g = 0; g < ext->n_groups; ++g) {

@@ -112,7 +112,12 @@ __global__ __launch_bounds__(kBlock) void k_direct(lsk_runs runs, int n_groups, 
             g_begin = runs.n_run_groups;
             const W tdiff = a ^ (a >> 1);
             for (int r = 0; r < runs.n_runs; ++r) {
-                const int lo0 = runs.lo0[r], cnt = runs.cnt[r];
+                const int lo0 = runs.lo0[r], cnt = runs.cnt[r] & 0xffff;
+                // direction of the run's pairs (lsk.h): 0 exchange | 1 the LOWER site alone is the source pattern | 2 the upper one.  A row is
+                // a TARGET of its partner's expansion in pull form, a source in push form: the pattern asked of the row flips with PULL
+                const int dir = runs.cnt[r] >> 16;
+                const W want = (dir == 0) ? (W)0 : (W)(((dir == 1) != PULL) ? ~(W)0 : (W)0); // bit lo of an active row (dir != 0)
+                const W adir = dir == 0 ? (W)~(W)0 : (W)~(a ^ want);                          // bit lo set <=> the row has the asked pattern
                 const double vr = runs.v_re[r], vi = REAL ? 0.0 : runs.v_im[r];
                 int k = WT::popc(a & (W)(((uint64_t)1 << lo0) - 1));
                 int lo_begin = lo0, lo_end = lo0 + cnt;
@@ -129,6 +134,7 @@ __global__ __launch_bounds__(kBlock) void k_direct(lsk_runs runs, int n_groups, 
                                      __builtin_amdgcn_ballot_w64((((uint32_t)a ^ a0) >> split) != 0) == 0;
                     if (uni) {
                         uint32_t m = (a0 ^ (a0 >> 1)) & (uint32_t)((((uint64_t)1 << lo_end) - 1) & ~(((uint64_t)1 << split) - 1));
+                        if (dir != 0) m &= ~(a0 ^ (uint32_t)want); // directed pairs: only rows with the asked pattern take part
                         const uint32_t i32 = (uint32_t)ig;
                         while (m) {
                             double xv[4], xw[4];
@@ -161,7 +167,7 @@ __global__ __launch_bounds__(kBlock) void k_direct(lsk_runs runs, int n_groups, 
 #pragma unroll 4
                 for (int lo = lo_begin; lo < lo_end; ++lo) {
                     const bool bit = (a >> lo) & 1;
-                    const bool act = (tdiff >> lo) & 1;
+                    const bool act = ((tdiff & adir) >> lo) & 1;
                     const BT d = s_binom[lo * LSK_BINOM_K + k];
                     k += bit ? 1 : 0;
                     if (sizeof(W) == 4) {

@@ -22,12 +22,15 @@ typedef struct lsk_term {
 } lsk_term;
 
 /* how the coefficient of a flip-mask group is evaluated */
-enum { LSK_GROUP_GENERIC = 0, LSK_GROUP_EXCHANGE = 1 };
+enum { LSK_GROUP_GENERIC = 0, LSK_GROUP_EXCHANGE = 1,
+       /* round 6: a DIRECTED pair, e.g. sigma^+_i sigma^-_j -- coefficient v iff exactly ONE site of the pair is set in alpha and it is
+        * the pair's lower (HOP_LO) / upper (HOP_HI) site.  Non-Hermitian hopping then takes the same fast paths as an exchange. */
+       LSK_GROUP_HOP_LO = 2, LSK_GROUP_HOP_HI = 3 };
 
 /* one off-diagonal flip-mask group: beta = alpha ^ x, coefficient = sum over terms [begin, end) */
 typedef struct lsk_group {
     uint64_t x;
-    double v_re, v_im; /* EXCHANGE: coefficient when popcount(alpha & x) == 1, else 0 */
+    double v_re, v_im; /* EXCHANGE: coefficient when popcount(alpha & x) == 1, else 0; HOP_*: when alpha & x is the source site alone */
     int32_t begin, end;
     int32_t adj;       /* lo if x == 3 << lo (adjacent pair) else -1 */
     int32_t fast;      /* LSK_GROUP_* */
@@ -41,7 +44,8 @@ typedef struct lsk_group {
 #define LSK_MAX_RUNS 4
 typedef struct lsk_runs {
     int n_runs, n_run_groups;
-    int lo0[LSK_MAX_RUNS], cnt[LSK_MAX_RUNS];
+    int lo0[LSK_MAX_RUNS], cnt[LSK_MAX_RUNS]; /* cnt: pairs in the run | direction << 16 (0: exchange, 1: HOP_LO, 2: HOP_HI groups; k_direct
+                                               * decodes it -- the staged chain kernel only ever sees Hermitian operators, i.e. direction 0) */
     double v_re[LSK_MAX_RUNS], v_im[LSK_MAX_RUNS];
     int n_zz, n_zz_terms;
     int zz_lo0[LSK_MAX_RUNS], zz_cnt[LSK_MAX_RUNS];

@@ -3,6 +3,7 @@
   chain_<L>_inv<s>   heisenberg ring in a spin-inversion sector without permutations (staged chain kernel vs generic row kernel vs push)
   hop_<L>            NON-Hermitian ring: sigma^+_i sigma^-_{i+1} (one direction) + zz (pull of a non-Hermitian operator vs push)
   square_<X>x<Y>_w<k> unsymmetrised periodic square lattice at weight k (> 32 sites: off the 32-bit pairs kernel)
+  j1j2_<L>_w<k>       ring with first and second neighbours at weight k
 Prints one JSON line per (model, variant): kernel, ms per matvec (HIP events inside the library), non-zeros (the push plan's count
 pass), G non-zeros / s, max relative difference against the first variant."""
 import argparse
@@ -31,6 +32,10 @@ def model(name):
         bonds = [[i, (i + 1) % L] for i in range(L)]
         return {"basis": {"number_spins": L, "hamming_weight": L // 2, "symmetries": []},
                 "hamiltonian": {"name": "H", "terms": [{"expression": "σ⁺₀ σ⁻₁", "sites": bonds}, {"expression": "σᶻ₀ σᶻ₁", "sites": bonds}]}}
+    if parts[0] == "j1j2":  # ring with first and second neighbours at weight k
+        L, k = int(parts[1]), int(parts[2][1:])
+        bonds = [[i, (i + 1) % L] for i in range(L)] + [[i, (i + 2) % L] for i in range(L)]
+        return {"basis": {"number_spins": L, "hamming_weight": k, "symmetries": []}, "hamiltonian": heis(bonds)}
     lx, ly = (int(v) for v in parts[1].split("x"))
     k = int(parts[2][1:])
     idx = lambda x, y: (x % lx) + lx * (y % ly)  # noqa: E731

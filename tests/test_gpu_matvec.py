@@ -913,6 +913,40 @@ def test_non_hermitian_complex_operator(torch):
                 run_matvec(torch, D_, h, reps, masks, x.real.copy(), 1)
 
 
+@pytest.mark.parametrize("L,P", [(12, 1), (16, 1), (16, 3), (20, 1)])
+@pytest.mark.parametrize("direction", ["+-", "-+", "mixed"])
+def test_directed_hopping_runs(torch, direction, L, P):
+    """Non-Hermitian hopping sigma^+_i sigma^-_{i+1} (or the other direction, or one direction on the lower half of the ring and the
+    other on the upper half) + zz: the directed pairs are recognised (LSK_GROUP_HOP_*), adjacent ones form runs, and k_direct's
+    branch-free run loop serves them in pull form (one partition) and in push form; several partitions: packets.  == the oracle."""
+    from oracle import c_oracle as CO
+    from oracle import model as M
+
+    bonds = [[i, (i + 1) % L] for i in range(L)]
+    if direction == "mixed":
+        terms = [{"expression": "σ⁺₀ σ⁻₁", "sites": bonds[: L // 2]}, {"expression": "0.5 × σ⁻₀ σ⁺₁", "sites": bonds[L // 2:]}]
+    else:
+        terms = [{"expression": "σ⁺₀ σ⁻₁" if direction == "+-" else "σ⁻₀ σ⁺₁", "sites": bonds}]
+    cfg = {"basis": {"number_spins": L, "hamming_weight": L // 2, "symmetries": []},
+           "hamiltonian": {"terms": terms + [{"expression": "σᶻ₀ σᶻ₁", "sites": bonds}]}}
+    o = CO.COracle(M.model_from_config(cfg))
+    want_reps = o.enumerate()
+    rs = np.random.RandomState(91)
+    x = rs.rand(len(want_reps)) - 0.5
+    want = o.local_matvec(want_reps, x)
+    D, basis, h, reps, masks = setup_model(torch, cfg, P)
+    assert not h.isHermitian and h.isReal
+    for mode in (("auto", "push") if P == 1 else ("auto",)):
+        got, pl = run_matvec(torch, D, h, reps, masks, x, P, mode)
+        if P == 1:
+            assert pl.kernel == ("direct-pull" if mode == "auto" else "direct-push")
+        assert_close(got, want, f"{direction} {mode}")
+    xc = x + 1j * (rs.rand(len(want_reps)) - 0.5)
+    gotc, _ = run_matvec(torch, D, h, reps, masks, xc, P)
+    wantc = o.local_matvec(want_reps, xc)
+    assert np.abs(gotc - wantc).max() <= 1e-12 * max(1.0, np.abs(wantc).max())
+
+
 def _chain_like_config(L, kind):
     """ring / open chain / ring with next-nearest-neighbour bonds (two exchange pairs outside the runs are the
     most the staged kernel caches: J1-J2 has more, so it must fall back to the generic row kernel)."""
@@ -1169,12 +1203,15 @@ PAIR_KERNEL_CASES = {
 
 
 @pytest.mark.parametrize("case", sorted(PAIR_KERNEL_CASES))
-def test_pairs_kernel_lattices(torch, case):
+def test_pairs_kernel_lattices(torch, monkeypatch, case):
     """k_pairs_t (staged row kernel for arbitrary exchange pairs -- what every non-ring lattice runs on one GPU) against the
     oracle: two-dimensional lattices with wrap-around bonds, J1-J2, XXZ amplitudes, all pairs in the low part, the complete
-    graph (near / straddling / high pairs, long spans), tiny blocks (waves of many segments); f64 and c128."""
+    graph (near / straddling / high pairs, long spans), tiny blocks (waves of many segments), 33..64 sites (8-byte states);
+    f64 and c128.  (LS_AMD_ROW_KERNEL=pairs: far from half filling the plan would keep the generic kernel, which is faster there.)"""
     from oracle import c_oracle as CO
     from oracle import model as M
+
+    monkeypatch.setenv("LS_AMD_ROW_KERNEL", "pairs")
 
     cfg = PAIR_KERNEL_CASES[case]()
     if cfg.pop("drop_zz", False):
