@@ -710,7 +710,19 @@ __global__ __launch_bounds__(kBlock) void k_tile_st(int n_groups, lsk_group cons
                 double vr, vi = 0.0;
                 if (CPLX) { vr = s_val[2 * e]; vi = s_val[2 * e + 1]; } else vr = s_val[e];
                 const uint32_t rk = s_rank[e];
-                int64_t idx = rk != kNoRank ? gdir_index_of_rank(gd, (uint64_t)rk, dest) : gdir_index(gd, beta, dest, s_db);
+                int64_t idx;
+                if (gd.entries) idx = rk != kNoRank ? gdir_index_of_rank(gd, (uint64_t)rk, dest) : gdir_index(gd, beta, dest, s_db);
+                else if (rk != kNoRank) idx = (int64_t)rk; // GLOBAL-RANK keys (lsk_wdests): no directory on the producer's side at all
+                else { // (a pair that is not adjacent, e.g. the bond that closes a ring: the full rank sum)
+                    idx = -1;
+                    if (__popcll(beta) == gd.weight && (gd.sites >= 64 || (beta >> gd.sites) == 0)) {
+                        const int kc = gd.weight + 1;
+                        uint64_t t = beta, g = 0;
+                        int k = 1;
+                        while (t) { g += s_db[(__ffsll((unsigned long long)t) - 1) * kc + k]; ++k; t &= t - 1; }
+                        if ((int64_t)g < gd.n_ranks) idx = (int64_t)g;
+                    }
+                }
                 if (idx < 0) { // not a basis state (DMV:115-118): the flag halts the matvec; the slot the count pass reserved is still
                     atomicExch(err, 1); // filled -- (index 0, value 0) -- so that no consumer meets a stale key
                     idx = 0; vr = 0.0; vi = 0.0;
@@ -848,11 +860,14 @@ __global__ __launch_bounds__(kBlock) void k_window(lsk_wdests dests, lsk_wsrc co
     __shared__ uint16_t s_len[kWinStreams]; // (the keys of a stream are distinct: a window holds <= W of them)
     __shared__ uint32_t const *s_keys[LSK_MAX_SEGS];
     __shared__ double const *s_vals[LSK_MAX_SEGS];
+    __shared__ uint32_t s_gb[2]; // global-rank keys: the ranks of the window's first row and of the row behind its last
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int d = 0;
     while (d + 1 < dests.n && (int64_t)blockIdx.x >= dests.first_block[d + 1]) ++d; // block-uniform
     const int64_t n = dests.count[d];
     double *__restrict__ y = reinterpret_cast<double *>(dests.y[d]);
+    lsk_rankdir const *__restrict__ dir = dests.dir[d]; // NULL: the keys are indices at the destination
+    const bool gkeys = dir != nullptr;
     const int64_t wb = (int64_t)blockIdx.x - dests.first_block[d];
     const int T = n_src * S;
     lsk_wsrc const *__restrict__ segs = srcs + (size_t)d * n_src;
@@ -862,6 +877,21 @@ __global__ __launch_bounds__(kBlock) void k_window(lsk_wdests dests, lsk_wsrc co
         if (w0 >= n) break;
         const int64_t w1 = w0 + W < n ? w0 + W : n;
         for (int i = tid; i < kWinRows; i += kBlock) s_acc[i] = 0.0;
+        if (gkeys) { // the window in KEY space: [rank of row w0, rank of row w1) -- rows ascend, so do their ranks
+            if (tid < 2) {
+                const int64_t row = tid == 0 ? w0 : w1;
+                uint64_t g = (uint64_t)dests.n_ranks;
+                if (row < n) {
+                    uint64_t t = dests.reps[d][row];
+                    g = 0;
+                    int k = 1;
+                    while (t) { g += dests.binom[(__ffsll((unsigned long long)t) - 1) * LSK_BINOM_K + k]; ++k; t &= t - 1; }
+                }
+                s_gb[tid] = (uint32_t)(g > 0xffffffffULL ? 0xffffffffULL : g);
+            }
+            __syncthreads();
+        }
+        const uint32_t k0 = gkeys ? s_gb[0] : (uint32_t)w0, k1 = gkeys ? s_gb[1] : (uint32_t)w1;
         const bool carry = win > 0 && T <= kWinStreams; // the end of the previous window's run is the start of this one's
         for (int t0 = 0; t0 < T; t0 += kWinStreams) {
             const int tn = T - t0 < kWinStreams ? T - t0 : kWinStreams;
@@ -870,8 +900,8 @@ __global__ __launch_bounds__(kBlock) void k_window(lsk_wdests dests, lsk_wsrc co
                 uint32_t const *__restrict__ keys = segs[q].keys;
                 uint32_t const *__restrict__ soff = segs[q].soff;
                 const uint32_t e = soff[s + 1];
-                const uint32_t lo = carry ? s_lo[t] + s_len[t] : lower_bound_u32(keys, soff[s], e, (uint32_t)w0);
-                uint32_t hi = w1 >= n ? e : gallop_u32(keys, lo, e, (uint32_t)w1);
+                const uint32_t lo = carry ? s_lo[t] + s_len[t] : lower_bound_u32(keys, soff[s], e, k0);
+                uint32_t hi = w1 >= n ? e : gallop_u32(keys, lo, e, k1);
                 if (hi - lo > (uint32_t)W) hi = lo + (uint32_t)W; // (only after a failed directory look-up: the flag is up anyway)
                 s_lo[t] = lo;
                 s_len[t] = (uint16_t)(hi - lo);
@@ -902,6 +932,19 @@ __global__ __launch_bounds__(kBlock) void k_window(lsk_wdests dests, lsk_wsrc co
                         if (it < len[u]) {
                             key[u] = kp[u][it];
                             if (CPLX) { vr[u] = vp[u][2 * (size_t)it]; vi[u] = vp[u][2 * (size_t)it + 1]; } else vr[u] = vp[u][it];
+                        }
+                    }
+                    if (gkeys) { // rank -> row of y[d]: ONE 16-byte entry of the destination's own directory per key (ascending keys:
+                        ulonglong2 en[kWinRuns]; // neighbouring lanes read the same or the next entry)
+#pragma unroll
+                        for (int u = 0; u < kWinRuns; ++u)
+                            en[u] = it < len[u] ? *reinterpret_cast<ulonglong2 const *>(dir + (key[u] >> 6)) : make_ulonglong2(0, 0);
+#pragma unroll
+                        for (int u = 0; u < kWinRuns; ++u) {
+                            if (it >= len[u]) continue;
+                            const uint64_t bit = 1ULL << (key[u] & 63);
+                            if (!(en[u].x & bit)) { atomicExch(dests.err, 1); key[u] = 0xffffffffu; continue; } // not a state of this partition
+                            key[u] = (uint32_t)en[u].y + (uint32_t)__popcll(en[u].x & (bit - 1));
                         }
                     }
 #pragma unroll

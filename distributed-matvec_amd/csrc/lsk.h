@@ -317,6 +317,16 @@ typedef struct lsk_wdests {
     int64_t count[LSK_MAX_SEGS];
     int64_t first_block[LSK_MAX_SEGS + 1];
     void *y[LSK_MAX_SEGS];
+    /* GLOBAL-RANK keys (round 6; dir[d] != NULL): a key is the colex rank of beta among ALL states of the weight, not its index at
+     * the destination -- the producer needs no all-destinations directory (P / 4 bytes per global state on every rank), the
+     * consumer turns a key into a row of y[d] with destination d's OWN rank directory (lsk_rankdir: 1 / 4 byte per global state,
+     * whatever P) and finds its windows by the ranks of their first rows */
+    lsk_rankdir const *dir[LSK_MAX_SEGS];
+    uint64_t const *reps[LSK_MAX_SEGS]; /* the destination's ascending representatives (window bounds) */
+    uint64_t const *binom;              /* device [64 * LSK_BINOM_K] */
+    int64_t n_ranks;
+    int weight;
+    int *err;                           /* raised when a key is not a state of its destination (DMV:115-118) */
 } lsk_wdests;
 int lsk_window_rows(int cplx);
 /* y[d][key] += value over all packets of the n_src source segments of every destination d (d_srcs: device [dests->n][n_src]) */
