@@ -1491,6 +1491,7 @@ struct ls_amd_plan {
     /* sorted packet streams (all partitions in this process; unprojected fixed-weight bases, exchange operators): every source
      * partition keeps its round in its own buffer and ONE consumer launch per round adds windows of every y in LDS -- no atomics */
     int streams, st_S, st_tile_rows, st_wpb, st_rounds;
+    int stream_gkeys;        /* the keys of the streams are global colex ranks; every partition then carries its own rank directory */
     void **d_send_parts;     /* [P] owned */
     lsk_wsrc *d_wsrcs;       /* owned: device [rounds][P destinations][P sources] */
     /* replicated-x mode: index / norms of the GLOBAL basis, global index of every local row */
@@ -2352,9 +2353,26 @@ static int setup_packet_index(ls_amd_plan *pl, uint64_t const *const *d_reps, in
     if (lsk_mem_info(&fr, &tot) != 0) return 0;
     e = getenv("LS_AMD_PACKET_INDEX_MAX");
     ceiling = e && atoll(e) > 0 ? (size_t)atoll(e) : fr / 4;
-    if (bytes > ceiling) return 0; /* does not fit: the packets carry the state and the consumers rank it (O(N / P) memory) */
     uint64_t const *d_binom;
     if (device_binom(&d_binom) != 0) return -1;
+    /* Sorted streams with GLOBAL-RANK keys (round 6): the key of a packet is the colex rank of beta among all states of
+     * the weight -- the producer needs NO directory (the rank is alpha's +- one binomial on adjacent pairs, a rank sum otherwise) and
+     * the consumer translates rank -> row through its OWN partition's rank directory (lsk_rankdir, built with the partition's index:
+     * 1 / 4 byte per global state whatever P).  The all-destinations directory -- P / 4 bytes per global state on EVERY rank, 1.2 GB
+     * for chain_32 at 8 ranks -- is then not built at all.  Needs < 2^32 global ranks (u32 keys); LS_AMD_STREAM_KEYS=index keeps the
+     * round-5 form (index at the destination out of the all-destinations directory). */
+    e = getenv("LS_AMD_STREAM_KEYS");
+    if (for_streams && n_ranks < 0xffffffffULL && !(e && strcmp(e, "index") == 0)) {
+        memset(&pl->gd, 0, sizeof(pl->gd));
+        pl->gd.entries = NULL; pl->gd.P = P; pl->gd.sites = L; pl->gd.weight = h; pl->gd.n_ranks = (int64_t)n_ranks;
+        pl->key_bytes = 4;
+        pl->stream_gkeys = 1;
+        pl->streams = 1;
+        pl->st_S = 2 * OEXT(pl->op)->n_groups;
+        pl->st_tile_rows = 256;
+        return 0;
+    }
+    if (bytes > ceiling) return 0; /* does not fit: the packets carry the state and the consumers rank it (O(N / P) memory) */
     void *p = NULL;
     if (lsk_malloc(&p, bytes) != 0) return 0;
     lsk_gdir gd;
@@ -2754,6 +2772,18 @@ int ls_amd_plan_create(ls_amd_plan **out, ls_hs_operator const *op, ls_amd_dtype
         int pid = my_partition < 0 ? i : my_partition;
         if (plan_setup_part(pl, ps, pid, num_rounds, stream) != 0) { ls_amd_plan_destroy(pl); return -1; }
         if (ps->max_send_bytes > pl->send_capacity) pl->send_capacity = ps->max_send_bytes;
+    }
+    int gkeys_ok = 1;
+    if (pl->stream_gkeys) for (int i = 0; i < pl->n_local; ++i) if (pl->parts[i].count > 0 && !pl->parts[i].index.dir) gkeys_ok = 0;
+    if (pl->streams && !gkeys_ok) {
+        /* a partition without its rank directory (not the hash partition of the full fixed-weight basis, or no room): the same plan with
+         * the atomic consumers */
+        ls_amd_plan_destroy(pl);
+        if (g_no_streams) return -1;
+        g_no_streams = 1;
+        int const rc = ls_amd_plan_create(out, op, dtype, num_partitions, my_partition, d_reps, counts, num_rounds_arg, mode, stream);
+        g_no_streams = 0;
+        return rc;
     }
     if (pl->streams && my_partition < 0 && setup_streams(pl, num_rounds) != 0) {
         /* one buffer per source partition did not fit (or a table could not be uploaded): the same plan with ONE shared buffer and
@@ -3338,6 +3368,12 @@ int ls_amd_internal_window_round(ls_amd_plan *pl, lsk_wsrc const *d_srcs, int n_
     wd.count[0] = pl->parts[0].count;
     wd.y[0] = d_y;
     wd.first_block[1] = (windows + pl->st_wpb - 1) / pl->st_wpb;
+    if (pl->stream_gkeys) {
+        uint64_t const *d_binom;
+        if (device_binom(&d_binom) != 0) return -1;
+        wd.dir[0] = pl->parts[0].index.dir; wd.reps[0] = pl->parts[0].d_reps;
+        wd.binom = d_binom; wd.n_ranks = pl->gd.n_ranks; wd.weight = pl->gd.weight; wd.err = pl->d_err;
+    }
     int const st = stage_begin(pl, ST_SCATTER, stream);
     DEV(lsk_window(pl->cplx, &wd, d_srcs, n_src, pl->st_S, pl->st_wpb, stream));
     stage_end(pl, st, stream);
@@ -3483,7 +3519,9 @@ int ls_amd_matvec(ls_amd_plan *pl, void const *const *d_x, void *const *d_y, voi
             wd.count[d] = pl->parts[d].count;
             wd.y[d] = d_y[d];
             wd.first_block[d + 1] = wd.first_block[d] + (windows + pl->st_wpb - 1) / pl->st_wpb;
+            if (pl->stream_gkeys) { wd.dir[d] = pl->parts[d].index.dir; wd.reps[d] = pl->parts[d].d_reps; }
         }
+        if (pl->stream_gkeys) { wd.binom = d_binom; wd.n_ranks = pl->gd.n_ranks; wd.weight = pl->gd.weight; wd.err = pl->d_err; }
         for (int r = 0; r < pl->st_rounds; ++r) {
             int st = stage_begin(pl, ST_GENERATE, stream);
             for (int p = 0; p < P; ++p) {

@@ -804,7 +804,7 @@ extern "C" int lsk_tile_st(lsk_operator op, lsk_gdir gd, uint64_t const *d_binom
                            lsk_round_layout const *d_layout, void *d_send, int *d_err, void *stream) {
     if (row1 <= row0 || op.n_groups == 0) return 0;
     if (S != 2 * op.n_groups || S > 256 || P < 1 || P * S > kStMaxClasses || tile_rows < 64 || (tile_rows & 63) || !d_ttab ||
-        (!count_only && (!gd.entries || gd.P != P || !d_binom))) {
+        (!count_only && (gd.P != P || !d_binom || (!gd.entries && gd.n_ranks > 0xffffffffLL) /* global-rank keys are 32-bit */))) {
         snprintf(g_err, sizeof(g_err), "lsk_tile_st: bad arguments (P = %d, S = %d, tile_rows = %d)", P, S, tile_rows);
         return -1;
     }

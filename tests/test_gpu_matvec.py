@@ -1431,11 +1431,15 @@ def test_pre_indexed_packets(torch, monkeypatch, case):
     # (logical partitions inside one process: exchange operators on unprojected fixed-weight bases take the SORTED STREAMS --
     # pre-indexed packets, window consumers without atomics; everything else defaults to the state-carrying packets: nothing
     # crosses a wire; one partition per process -- tests/test_gpu_loopback.py, tests/test_gpu_rccl.py -- defaults to the indexed ones)
-    envs = ("LS_AMD_PACKET_INDEX", "LS_AMD_PACKET_INDEX_MAX", "LS_AMD_PACKET_STREAMS")
+    # Round 6: the streams' keys are GLOBAL colex ranks (the consumer turns them into rows with its own partition's rank directory), so
+    # a streams plan builds no all-destinations directory at all and a ceiling on that directory no longer touches it;
+    # LS_AMD_STREAM_KEYS=index keeps the round-5 keys (index at the destination out of the directory).
+    envs = ("LS_AMD_PACKET_INDEX", "LS_AMD_PACKET_INDEX_MAX", "LS_AMD_PACKET_STREAMS", "LS_AMD_STREAM_KEYS")
     streams_ok = not basis.hasSpinInversionSymmetry() and not basis.hasPermutationSymmetries()
     for label, env in (("indexed", {"LS_AMD_PACKET_INDEX": "1", "LS_AMD_PACKET_STREAMS": "0"}), ("states", {"LS_AMD_PACKET_INDEX": "0"}),
-                       ("default", {}), ("streams-wpb3", {}),
-                       ("ceiling", {"LS_AMD_PACKET_INDEX": "1", "LS_AMD_PACKET_INDEX_MAX": "8"})):
+                       ("default", {}), ("streams-wpb3", {}), ("streams-index-keys", {"LS_AMD_STREAM_KEYS": "index"}),
+                       ("ceiling", {"LS_AMD_PACKET_INDEX": "1", "LS_AMD_PACKET_INDEX_MAX": "8"}),
+                       ("ceiling-index-keys", {"LS_AMD_PACKET_INDEX": "1", "LS_AMD_PACKET_INDEX_MAX": "8", "LS_AMD_STREAM_KEYS": "index"})):
         for k in envs:
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
@@ -1444,14 +1448,15 @@ def test_pre_indexed_packets(torch, monkeypatch, case):
         _lib.load().ls_amd_test_set_stream_windows_per_block(3 if label == "streams-wpb3" else 0)
         got, pl = run_matvec(torch, D, h, reps, masks, x, P)
         _lib.load().ls_amd_test_set_stream_windows_per_block(0)
-        streams = label in ("default", "streams-wpb3") and streams_ok
+        streams = label in ("default", "streams-wpb3", "streams-index-keys", "ceiling") and streams_ok
         assert pl.kernel == ("tile+streams" if streams else "tile"), label
         key = 4 if label == "indexed" or streams else 8
         assert pl.key_bytes == key, label
         w = 16 if dt == "c128" else 8
         assert pl.packet_bytes == pl.key_bytes + w
         assert pl.segment_bytes(5) == (24 if key == 4 else 40) + 5 * w and pl.segment_value_offset(5) == (24 if key == 4 else 40)
-        assert (pl.packet_index_bytes > 0) == (key == 4)
+        # the all-destinations directory: only behind index keys (atomic consumers, or streams with LS_AMD_STREAM_KEYS=index)
+        assert (pl.packet_index_bytes > 0) == (label == "indexed" or (label == "streams-index-keys" and streams)), label
         assert np.abs(got - want).max() <= 1e-12 * max(1.0, np.abs(want).max()), label
         results[label] = got
     h.clear_plans()
@@ -1481,8 +1486,8 @@ def test_sorted_packet_streams(torch, monkeypatch, case):
     got, nnz = {}, set()
     from distributed_matvec_amd import _lib
 
-    for label, env in (("streams", {}), ("streams-wpb2", {}), ("atomics", {"LS_AMD_PACKET_STREAMS": "0"})):
-        for k in ("LS_AMD_PACKET_STREAMS", "LS_AMD_PACKET_INDEX"):
+    for label, env in (("streams", {}), ("streams-wpb2", {}), ("streams-index-keys", {"LS_AMD_STREAM_KEYS": "index"}), ("atomics", {"LS_AMD_PACKET_STREAMS": "0"})):
+        for k in ("LS_AMD_PACKET_STREAMS", "LS_AMD_PACKET_INDEX", "LS_AMD_STREAM_KEYS"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -1501,6 +1506,7 @@ def test_sorted_packet_streams(torch, monkeypatch, case):
         pl.destroy()
     assert np.abs(got["streams"] - got["atomics"]).max() <= 1e-13 * max(1.0, np.abs(want).max())
     assert np.abs(got["streams"] - got["streams-wpb2"]).max() <= 1e-13 * max(1.0, np.abs(want).max())
+    assert np.abs(got["streams"] - got["streams-index-keys"]).max() <= 1e-13 * max(1.0, np.abs(want).max())
     assert len(nnz) == 1  # the count passes of both producers agree on the number of packets
     # no room for one buffer per source partition: the plan comes back with the shared buffer and the atomic consumers
     _lib.load().ls_amd_test_fail_stream_buffers(1)
