@@ -938,7 +938,8 @@ __global__ __launch_bounds__(kBlock) void k_window(lsk_wdests dests, lsk_wsrc co
                         ulonglong2 en[kWinRuns]; // neighbouring lanes read the same or the next entry)
 #pragma unroll
                         for (int u = 0; u < kWinRuns; ++u)
-                            en[u] = it < len[u] ? *reinterpret_cast<ulonglong2 const *>(dir + (key[u] >> 6)) : make_ulonglong2(0, 0);
+                            en[u] = (it < len[u] && (int64_t)key[u] < dests.n_ranks) // (a key that is no rank at all -- a misplaced segment -- reads nothing)
+                                        ? *reinterpret_cast<ulonglong2 const *>(dir + (key[u] >> 6)) : make_ulonglong2(0, 0);
 #pragma unroll
                         for (int u = 0; u < kWinRuns; ++u) {
                             if (it >= len[u]) continue;
