@@ -195,6 +195,9 @@ def slot_cache_leg(plan, run, check, kernel_times, time_steps, steps, allsum=Non
             "kernel_ms_avg": sum(ks) / max(1, len(ks)), "matrix_free": False}
 
 
+_REGISTERED_KEEP_ALIVE = []
+
+
 def boundary_extra(D, torch, h, basis, reps, y_device, x_device, calls=2):
     """The drop-in entry itself -- `ls_chpl_matrix_vector_product(matrix, 1, double *x, double *y)` (DMV:1095-1110), what Diagonalize /
     PRIMME call -- timed on the benchmark workload with the caller's vectors in every kind of memory (include/ls_amd.h, "The
@@ -247,6 +250,7 @@ def boundary_extra(D, torch, h, basis, reps, y_device, x_device, calls=2):
         out["pageable_plain_hipMemcpy"] = timed(x_h.ctypes.data, y_h.ctypes.data, "pageable")
     finally:
         del os.environ["LS_AMD_STAGE"]
+    _REGISTERED_KEEP_ALIVE.extend((x_h, y_h))  # (their addresses are not handed back: the runtime keeps state per registered range)
     for a in (x_h, y_h):
         _lib.check(L.ls_amd_host_register(C.c_void_p(a.ctypes.data), a.nbytes))
     try:

@@ -92,6 +92,9 @@ int ls_amd_basis_rotate(int m_in, int m_out, int64_t n, double *d_V, int64_t ldv
  * hipMemcpy), LS_AMD_STAGE_CHUNK_KB (32768), LS_AMD_STAGE_THREADS (min(16, cores / 4)). */
 enum { LS_AMD_PTR_PAGEABLE = 0, LS_AMD_PTR_PINNED = 1, LS_AMD_PTR_DEVICE = 2, LS_AMD_PTR_MANAGED = 3 };
 int ls_amd_pointer_kind(void const *p);
+/* (Register long-lived, page-aligned workspaces.  On ROCm 7.x without XNACK, registering small malloc'ed heap blocks, unregistering
+ * and freeing them, and letting the allocator reuse those addresses for pageable buffers of later hipMemcpy calls ended in GPU
+ * memory faults of those later copies -- tests/test_gpu_matvec.py::test_host_pointer_boundary_memory_kinds, round 6.) */
 int ls_amd_host_register(void *p, size_t bytes);   /* hipHostRegister: the caller keeps the memory alive until ... */
 int ls_amd_host_unregister(void *p);               /* ... this */
 struct ls_amd_boundary_stats {

@@ -1254,6 +1254,9 @@ def _primme_buffer(n, h):
     return buf
 
 
+_KEEP_ALIVE = []  # registered host mappings of test_host_pointer_boundary_memory_kinds (see there)
+
+
 @pytest.mark.parametrize("name", ["heisenberg_chain_16", "heisenberg_chain_24_symm", "offdiag_only_chain_16"])
 def test_host_pointer_boundary_memory_kinds(torch, monkeypatch, name):
     """The reference's host-pointer entries (ls_chpl_matrix_vector_product DMV:1095-1110, ls_chpl_primme_matvec
@@ -1318,8 +1321,21 @@ def test_host_pointer_boundary_memory_kinds(torch, monkeypatch, name):
             assert_close(Y[k, :n], want[k])
             assert np.array_equal(Y[k, n:], Y0[k, n:])  # the padding between the columns is not touched
     monkeypatch.delenv("LS_AMD_STAGE")
-    # registered (pinned) host memory
-    Xr, Yr = X.copy(), Y0.copy()
+    # registered (pinned) host memory.  The registered arrays live in their OWN anonymous mappings (page-aligned, never handed back to
+    # malloc) and stay alive for the rest of the process: with numpy heap arrays -- registered, unregistered, freed, their addresses
+    # reused by later tensors -- unrelated `.cpu()` / `.cuda()` copies of pageable memory died later in the suite with "Memory access
+    # fault by GPU ... Write access to a read-only page" at those heap addresses (1-2 of 5 runs, bisected in round 6): the runtime
+    # keeps state per registered range.  A caller of ls_amd_host_register (PRIMME's workspace) keeps its vectors alive anyway.
+    import mmap
+
+    def own_mapping(a):
+        buf = mmap.mmap(-1, (a.nbytes + 4095) & ~4095)
+        _KEEP_ALIVE.append(buf)
+        out = np.frombuffer(buf, dtype=a.dtype, count=a.size).reshape(a.shape)
+        out[...] = a
+        return out
+
+    Xr, Yr = own_mapping(X), own_mapping(Y0)
     assert L.ls_amd_pointer_kind(C.c_void_p(Xr.ctypes.data)) == 0
     for a in (Xr, Yr):
         _lib.check(L.ls_amd_host_register(C.c_void_p(a.ctypes.data), a.nbytes))
