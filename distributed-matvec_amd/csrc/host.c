@@ -1072,6 +1072,7 @@ static void detect_runs(struct ls_amd_operator_ext *ext, int number_sites, int i
     for (int g = 0; g < ng; ++g) {
         lsk_group const *G = &ext->groups[g];
         if (G->fast == LSK_GROUP_GENERIC || G->adj < 0) continue; /* exchange pairs and directed pairs (HOP_*) on adjacent sites */
+        if (inversion && G->fast != LSK_GROUP_EXCHANGE) continue;  /* (directed runs: unprojected bases only -- k_direct's DIRECTED instantiation) */
         if (inversion && G->adj + 1 >= number_sites - 1) continue;
         run_item it = {G->adj, g, G->v_re, G->v_im, G->fast};
         items[ni++] = it;
@@ -2750,10 +2751,11 @@ int ls_amd_plan_create(ls_amd_plan **out, ls_hs_operator const *op, ls_amd_dtype
     pl->d_cursors = (unsigned long long *)p;
     if (lsk_malloc(&p, 8 * LSK_MAX_PARTS) != 0) { ls_amd_plan_destroy(pl); return dev_error(); }
     pl->d_counts = (unsigned long long *)p;
-    if (lsk_malloc(&p, sizeof(int)) != 0) { ls_amd_plan_destroy(pl); return dev_error(); }
+    if (lsk_malloc(&p, 2 * sizeof(int)) != 0) { ls_amd_plan_destroy(pl); return dev_error(); } /* [0]: the error flag; [1]: a word nobody reads (lsk_direct) */
     pl->d_err = (int *)p;
     int zero = 0;
-    if (lsk_h2d(pl->d_err, &zero, sizeof(int)) != 0) { ls_amd_plan_destroy(pl); return dev_error(); }
+    int const zero2[2] = {0, 0};
+    if (lsk_h2d(pl->d_err, zero2, sizeof(zero2)) != 0) { ls_amd_plan_destroy(pl); return dev_error(); }
 
     pl->key_bytes = 8;
     if (pl->family == FAMILY_TILE && setup_packet_index(pl, d_reps, counts, stream) != 0) { ls_amd_plan_destroy(pl); return -1; }

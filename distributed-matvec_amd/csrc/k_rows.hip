@@ -62,7 +62,11 @@ extern "C" int lsk_diag(lsk_operator op, int cplx, int64_t n, uint64_t const *re
 // walks that XCD's list of tiles, so the traversal order -- which decides what the XCD's L2 can
 // reuse -- is data, not code.
 // ---------------------------------------------------------------------------------------------
-template <typename W, bool CPLX, int INDEX, bool INV, bool PULL, bool REAL>
+// DIRECTED: some run of the operator consists of directed pairs (lsk.h, LSK_GROUP_HOP_*): an instantiation of its own, so that the
+// run loop of every other operator stays what it was -- at 82 SGPRs instead of <= 80 the occupancy API over-reports the resident
+// blocks of this persistent kernel by one and a straggler round costs a third of its speed (measured in round 6: 14.0 -> 18.2 ms on
+// chain_32; tests/test_host_tables.py::test_hot_kernel_register_budget)
+template <typename W, bool CPLX, int INDEX, bool INV, bool PULL, bool REAL, bool DIRECTED>
 __global__ __launch_bounds__(kBlock) void k_direct(lsk_runs runs, int n_groups, lsk_group const *__restrict__ groups,
                                                    lsk_term const *__restrict__ off, int n_diag,
                                                    lsk_term const *__restrict__ diag, lsk_basis bs,
@@ -112,12 +116,13 @@ __global__ __launch_bounds__(kBlock) void k_direct(lsk_runs runs, int n_groups, 
             g_begin = runs.n_run_groups;
             const W tdiff = a ^ (a >> 1);
             for (int r = 0; r < runs.n_runs; ++r) {
-                const int lo0 = runs.lo0[r], cnt = runs.cnt[r] & 0xffff;
+                const int lo0 = runs.lo0[r], cnt = DIRECTED ? (runs.cnt[r] & 0xffff) : runs.cnt[r];
                 // direction of the run's pairs (lsk.h): 0 exchange | 1 the LOWER site alone is the source pattern | 2 the upper one.  A row is
                 // a TARGET of its partner's expansion in pull form, a source in push form: the pattern asked of the row flips with PULL
-                const int dir = runs.cnt[r] >> 16;
+                const int dir = DIRECTED ? (runs.cnt[r] >> 16) : 0;
                 const W want = (dir == 0) ? (W)0 : (W)(((dir == 1) != PULL) ? ~(W)0 : (W)0); // bit lo of an active row (dir != 0)
                 const W adir = dir == 0 ? (W)~(W)0 : (W)~(a ^ want);                          // bit lo set <=> the row has the asked pattern
+                const W tsel = (!DIRECTED || dir == 0) ? tdiff : (W)(tdiff & adir);           // bit lo set <=> pair lo is active for this row
                 const double vr = runs.v_re[r], vi = REAL ? 0.0 : runs.v_im[r];
                 int k = WT::popc(a & (W)(((uint64_t)1 << lo0) - 1));
                 int lo_begin = lo0, lo_end = lo0 + cnt;
@@ -134,7 +139,7 @@ __global__ __launch_bounds__(kBlock) void k_direct(lsk_runs runs, int n_groups, 
                                      __builtin_amdgcn_ballot_w64((((uint32_t)a ^ a0) >> split) != 0) == 0;
                     if (uni) {
                         uint32_t m = (a0 ^ (a0 >> 1)) & (uint32_t)((((uint64_t)1 << lo_end) - 1) & ~(((uint64_t)1 << split) - 1));
-                        if (dir != 0) m &= ~(a0 ^ (uint32_t)want); // directed pairs: only rows with the asked pattern take part
+                        if (DIRECTED && dir != 0) m &= ~(a0 ^ (uint32_t)want); // directed pairs: only rows with the asked pattern take part
                         const uint32_t i32 = (uint32_t)ig;
                         while (m) {
                             double xv[4], xw[4];
@@ -167,7 +172,7 @@ __global__ __launch_bounds__(kBlock) void k_direct(lsk_runs runs, int n_groups, 
 #pragma unroll 4
                 for (int lo = lo_begin; lo < lo_end; ++lo) {
                     const bool bit = (a >> lo) & 1;
-                    const bool act = ((tdiff & adir) >> lo) & 1;
+                    const bool act = (tsel >> lo) & 1;
                     const BT d = s_binom[lo * LSK_BINOM_K + k];
                     k += bit ? 1 : 0;
                     if (sizeof(W) == 4) {
@@ -238,15 +243,16 @@ __global__ __launch_bounds__(kBlock) void k_direct(lsk_runs runs, int n_groups, 
                 } else {
                     // a state of another Hamming weight is outside the basis: ls_hs_state_index would
                     // return a negative index and the reference halts (DMV:115-118)
-                    // (pull over a NON-Hermitian operator, gx bit 1 clear: a partner outside the basis that maps INTO it contributes
-                    // nothing -- x has no such entry; whether the operator maps the basis OUT of itself, the reference's halt, is what
-                    // lsk_direct_validate checks at plan time.  Hermitian operators keep the run-time flag: the two are the same event)
-                    if (WT::popc(beta) != bs.hamming_weight) { if (!PARTNER || (gx & 2)) atomicExch(err, 1); continue; }
+                    // (pull over a NON-Hermitian operator: a partner outside the basis that maps INTO it contributes nothing -- x has no
+                    // such entry -- and its flag goes to a word nobody reads (lsk_direct, pull == 2); whether the operator maps the basis
+                    // OUT of itself, the reference's halt, is what lsk_direct_validate checks at plan time.  Hermitian operators keep the
+                    // run-time flag: the two are the same event.  No switch in the kernel: it has no scalar register to spare)
+                    if (WT::popc(beta) != bs.hamming_weight) { atomicExch(err, 1); continue; }
                     idx = rank_combinadic_w<W, BT>(beta, s_binom);
                 }
             } else {
                 idx = search_index(ix, (uint64_t)beta);
-                if (idx < 0) { if (!PARTNER || (gx & 2)) atomicExch(err, 1); continue; } // DMV:115-118
+                if (idx < 0) { atomicExch(err, 1); continue; } // DMV:115-118
             }
             if (PULL) {
                 // conj(c) * x[idx]
@@ -271,30 +277,42 @@ __global__ __launch_bounds__(kBlock) void k_direct(lsk_runs runs, int n_groups, 
 // first pair index handled wave-uniformly by the 32-bit pull row kernels.  Measured on chain_32: 14 is best for k_direct,
 // 12 (= every pair outside the LDS window) for k_chain_t.
 constexpr int kDirectHighPair = 14;
-template <typename W, bool CPLX, int INDEX, bool INV, bool PULL>
-static int launch_direct3(lsk_operator op, lsk_basis bs, lsk_index ix, lsk_tilemap tm, uint64_t const *reps,
+template <typename W, bool CPLX, int INDEX, bool INV, bool PULL, bool DIRECTED>
+static int launch_direct4(lsk_operator op, lsk_basis bs, lsk_index ix, lsk_tilemap tm, uint64_t const *reps,
                           void const *x, void *y, int *d_err, void *stream, int gx, int64_t const *row_gidx) {
     int64_t gb = tm.slots_per_xcd * 8;
     // (f64 vectors only ever meet real operators: the plan refuses the other combination, so it is not instantiated)
     constexpr bool kCplxOp = CPLX;
     int64_t cap;
-    if constexpr (kCplxOp) cap = op.is_real ? resident_grid(k_direct<W, CPLX, INDEX, INV, PULL, true>, gb) : resident_grid(k_direct<W, CPLX, INDEX, INV, PULL, false>, gb);
-    else cap = resident_grid(k_direct<W, CPLX, INDEX, INV, PULL, true>, gb);
+    if constexpr (kCplxOp) cap = op.is_real ? resident_grid(k_direct<W, CPLX, INDEX, INV, PULL, true, DIRECTED>, gb) : resident_grid(k_direct<W, CPLX, INDEX, INV, PULL, false, DIRECTED>, gb);
+    else cap = resident_grid(k_direct<W, CPLX, INDEX, INV, PULL, true, DIRECTED>, gb);
     cap &= ~(int64_t)7; // XCD dealing needs a multiple of 8
     if (cap < 8) cap = 8;
     if (gb > cap) gb = cap; // persistent: one block per 256-row tile costs more than it gains here (13.3 -> 15.5 ms on chain_32)
     dim3 g((unsigned)gb), b(kBlock);
-    gx = (gx & 3) | (kDirectHighPair << 24);
+    gx = (gx & 1) | (kDirectHighPair << 24);
     if (op.is_real || !kCplxOp)
-        hipLaunchKernelGGL((k_direct<W, CPLX, INDEX, INV, PULL, true>), g, b, 0, (hipStream_t)stream, op.runs,
+        hipLaunchKernelGGL((k_direct<W, CPLX, INDEX, INV, PULL, true, DIRECTED>), g, b, 0, (hipStream_t)stream, op.runs,
                            op.n_groups, op.groups, op.off, op.n_diag, op.diag, bs, ix, tm.entries, tm.slots_per_xcd, reps,
                            (double const *)x, (double *)y, d_err, gx, row_gidx);
     else if constexpr (kCplxOp)
-        hipLaunchKernelGGL((k_direct<W, CPLX, INDEX, INV, PULL, false>), g, b, 0, (hipStream_t)stream, op.runs,
+        hipLaunchKernelGGL((k_direct<W, CPLX, INDEX, INV, PULL, false, DIRECTED>), g, b, 0, (hipStream_t)stream, op.runs,
                            op.n_groups, op.groups, op.off, op.n_diag, op.diag, bs, ix, tm.entries, tm.slots_per_xcd, reps,
                            (double const *)x, (double *)y, d_err, gx, row_gidx);
     LSK_LAUNCH_CHECK();
     return 0;
+}
+template <typename W, bool CPLX, int INDEX, bool INV, bool PULL>
+static int launch_direct3(lsk_operator op, lsk_basis bs, lsk_index ix, lsk_tilemap tm, uint64_t const *reps,
+                          void const *x, void *y, int *d_err, void *stream, int gx, int64_t const *row_gidx) {
+    bool directed = false; // (the host forms no directed runs on inversion bases: detect_runs)
+    for (int r = 0; r < op.runs.n_runs; ++r) directed = directed || (op.runs.cnt[r] >> 16) != 0;
+    if constexpr (INDEX == LSK_INDEX_COMBINADIC) { // (the run loop only exists for closed-form ranks: elsewhere every group is generic)
+        if constexpr (!INV) {
+            if (directed) return launch_direct4<W, CPLX, INDEX, INV, PULL, true>(op, bs, ix, tm, reps, x, y, d_err, stream, gx, row_gidx);
+        } else if (directed) { snprintf(g_err, sizeof(g_err), "lsk_direct: directed runs on an inversion basis"); return -1; }
+    }
+    return launch_direct4<W, CPLX, INDEX, INV, PULL, false>(op, bs, ix, tm, reps, x, y, d_err, stream, gx, row_gidx);
 }
 template <typename W, bool CPLX, int INDEX>
 static int launch_direct2(lsk_operator op, lsk_basis bs, lsk_index ix, int pull, lsk_tilemap n,
@@ -369,14 +387,15 @@ extern "C" int lsk_direct_validate(lsk_operator op, lsk_basis bs, lsk_index ix, 
 }
 extern "C" int lsk_direct(lsk_operator op, lsk_basis bs, lsk_index ix, int cplx, int pull, lsk_tilemap tm,
                           uint64_t const *reps, void const *x, void *y, int *d_err, void *stream) {
-    // pull: 0 push | 1 pull, partners outside the basis are flagged (Hermitian operators) | 2 pull of a non-Hermitian operator
-    return direct_dispatch(op, bs, ix, cplx, pull != 0, tm, reps, x, y, d_err, stream, pull == 2 ? 0 : 2, nullptr);
+    // pull: 0 push | 1 pull, partners outside the basis are flagged (Hermitian operators) | 2 pull of a non-Hermitian operator: the
+    // flag of a partner outside the basis lands in d_err[1], which nobody reads (d_err points at two ints)
+    return direct_dispatch(op, bs, ix, cplx, pull != 0, tm, reps, x, y, pull == 2 ? d_err + 1 : d_err, stream, 0, nullptr);
 }
 // replicated-x pull: `reps` = the n rows of one partition, `x` = whole vector in global order, `ix` = index
 // of the GLOBAL basis, row_gidx[i] = global index of row i (only read for SEARCH indices)
 extern "C" int lsk_direct_gx(lsk_operator op, lsk_basis bs, lsk_index ix, int cplx, lsk_tilemap tm, uint64_t const *reps,
                              int64_t const *row_gidx, void const *x_global, void *y, int *d_err, void *stream) {
-    return direct_dispatch(op, bs, ix, cplx, 1, tm, reps, x_global, y, d_err, stream, 1 | 2, row_gidx); // (replicated-x plans are Hermitian: partners outside the basis are flagged)
+    return direct_dispatch(op, bs, ix, cplx, 1, tm, reps, x_global, y, d_err, stream, 1, row_gidx);
 }
 
 // ---------------------------------------------------------------------------------------------

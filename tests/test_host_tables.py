@@ -395,8 +395,10 @@ def test_hot_kernel_register_budget():
     for inst in ("_Z8k_pull_tImLi0ELi0ELb0ELi0E", "_Z8k_pull_tImLi0ELi0ELb0ELi1E", "_Z8k_pull_tIjLi0ELi0ELb0ELi0E"):
         v = stats[[k for k in stats if k.startswith(inst)][0]]
         assert v["vgpr"] <= 80 and v["occ"] >= 6 and v["lds"] <= 24 * 1024, (inst, v)  # >= 6 blocks per CU by registers (granule 8) and by LDS
-    pairs = stats[[k for k in stats if k.startswith("_Z9k_pairs_tILb0ELi1024E")][0]]
+    pairs = stats[[k for k in stats if k.startswith("_Z9k_pairs_tIjLb0ELi1024E")][0]]  # 32-bit states (<= 32 sites)
     assert pairs["vgpr"] <= 84 and pairs["sgpr"] <= 96 and pairs["lds"] <= 27 * 1024, pairs
+    wide = stats[[k for k in stats if k.startswith("_Z9k_pairs_tImLb0ELi1024E")][0]]   # 64-bit states (33..64 sites, round 6)
+    assert wide["vgpr"] <= 84 and wide["sgpr"] <= 96 and wide["scratch"] == 0 and wide["lds"] <= 30 * 1024, wide
     # the eigensolver's fused Gram-Schmidt sweep (csrc/orth.hip): 33 accumulators per thread that must stay in registers (one
     # run-time index into them sent the array to scratch: 3.9 instead of 5.8 TB/s)
     orth = kernel_resources.resources(source="orth.hip")
