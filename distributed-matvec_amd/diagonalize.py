@@ -356,14 +356,18 @@ def diagonalize_distributed(config, group=None, num_evals: int = 1, eps: float =
     keeps its hash partition of the states and of the Lanczos vectors, the matvec goes through the C host's exchange
     (replicated-x for Hermitian operators, packets otherwise / on request), the reductions through RCCL, and the output file
     (HDF5, visible to every rank) is written block-distributed: /basis/representatives and /hamiltonian/eigenvectors [k, N]
-    in global ascending order, every rank its own hyperslab (MyHDF5.chpl:303-333), eigenvalues and residuals by rank 0.
+    in global ascending order, every rank its own hyperslab, all ranks writing at once (MyHDF5.chpl:303-333;
+    distributed.write_block_dataset), eigenvalues and residuals by rank 0.  An `output` that already holds
+    /basis/representatives (an earlier run of this driver, or of the reference: makeBasisStates, Diagonalize.chpl:227-246) is
+    extended, not truncated: every rank reads its block of the stored states (readDatasetAsBlocks), they must equal what
+    the configured basis enumerates to, and the dataset is left as it is.
     Must be called by every rank of `group` (torch.distributed, backend "nccl")."""
     import numpy as np
     import torch
     import torch.distributed as dist
 
     from . import api, hdf5
-    from .distributed import RcclDistributedOperator, RcclReplicatedOperator, hashed_to_block, write_hashed_vectors
+    from .distributed import RcclDistributedOperator, RcclReplicatedOperator, hashed_to_block, write_block_dataset, write_hashed_vectors
 
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     if isinstance(config, str):
@@ -371,8 +375,37 @@ def diagonalize_distributed(config, group=None, num_evals: int = 1, eps: float =
     else:
         basis, h = api.loadConfigFromDict(config, hamiltonian=True)
     dtype = dtype or torch.float64
+    if output and not output.endswith((".h5", ".hdf5")):
+        raise ValueError("diagonalize_distributed writes HDF5 (the block-distributed format of the reference)")
     parts, masks = api.enumerateStates(basis, world)
     my_reps = parts[rank]
+    stored_basis = False
+    if output:
+        from .distributed import _broadcast_int
+
+        # rank 0 looks (one decision for all ranks); -1 = no such dataset
+        n_stored = _broadcast_int(hdf5.dataset_shape(output, "/basis/representatives")[-1]
+                                  if rank == 0 and hdf5.has_dataset(output, "/basis/representatives") else None, group)
+        if n_stored is not None:
+            # the reference trusts the stored states to skip an enumeration that costs its CPU path hours; the enumeration
+            # above is seconds of GPU time, so here they are CHECKED instead (like diagonalize()): a stale file -- another
+            # model, sector or Hamming weight, a truncated dataset -- must not be extended silently.  Every rank compares
+            # its own block, read by itself, with its block of the fresh enumeration.
+            n = int(masks.numel())
+            fresh = hashed_to_block(my_reps, masks, group)
+            ok = n_stored == n
+            if ok:
+                mine = hdf5.read_dataset_block(output, "/basis/representatives", world, rank, np.uint64)
+                ok = bool(torch.equal(torch.from_numpy(mine.view(np.int64)), fresh.cpu()))
+            del fresh
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int64, device=my_reps.device if dist.get_backend(group) == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+            if not int(flag.item()):
+                raise api.LsAmdError(f"halt: /basis/representatives of '{output}' does not belong to the configured basis "
+                                     "(stale output file?); remove the dataset or the file")
+            stored_basis = True
+            if verbose and rank == 0:
+                print(f"[diagonalize_distributed] /basis/representatives of '{output}': {n} states, verified, kept", flush=True)
     if exchange == "auto":
         # replicated x is the fast exchange, but its tables are O(N) on EVERY rank; the packets are the O(N / P) strategy and the
         # fallback when those tables do not fit next to the Krylov basis (exchange_memory_estimate; LS_AMD_EXCHANGE_HBM_CEILING)
@@ -409,18 +442,13 @@ def diagonalize_distributed(config, group=None, num_evals: int = 1, eps: float =
     del parts
     r = lanczos_smallest(RankOperator(op, my_reps, dtype), num_evals=num_evals, eps=eps, max_basis=max_basis, verbose=verbose)
     if output:
-        if not output.endswith((".h5", ".hdf5")):
-            raise ValueError("diagonalize_distributed writes HDF5 (the block-distributed format of the reference)")
         if rank == 0:
+            # append: whatever else the file holds stays; hamiltonian/* of an earlier run is replaced (Diagonalize.chpl:248-256)
             hdf5.write_datasets(output, {"/hamiltonian/eigenvalues": np.array(r.eigenvalues),
-                                         "/hamiltonian/residuals": np.array(r.residual_norms)})
-            hdf5.create_dataset(output, "/basis/representatives", (int(masks.numel()),), np.uint64)
+                                         "/hamiltonian/residuals": np.array(r.residual_norms)}, append=os.path.exists(output))
         dist.barrier(group)
-        blk = hashed_to_block(my_reps, masks, group).cpu().numpy().view(np.uint64)
-        lo, _ = hdf5.block_range(int(masks.numel()), world, rank)
-        for w in range(world):  # one writer at a time
-            if w == rank:
-                hdf5.write_dataset_chunk(output, "/basis/representatives", (lo,), blk)
-            dist.barrier(group)
+        if not stored_basis:
+            write_block_dataset(output, "/basis/representatives", (int(masks.numel()),), np.uint64,
+                                (hashed_to_block(my_reps, masks, group).cpu().numpy().view(np.uint64) for _ in range(1)), group)
         write_hashed_vectors(output, "/hamiltonian/eigenvectors", list(r.eigenvectors), masks, group)
     return r

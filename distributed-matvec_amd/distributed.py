@@ -596,29 +596,71 @@ def block_to_hashed(block, masks, group=None):
     return part
 
 
-def write_hashed_vectors(path: str, name: str, parts, masks, group=None):
-    """writeDatasetAsBlocks for hash-partitioned vectors (Diagonalize.chpl:248-256 -> MyHDF5.chpl:303-333): `parts` = this
-    rank's pieces of k vectors; dataset [k, N] in global ascending order, every rank writing its own hyperslab.  The file
-    must be visible to every rank (one node, or a shared file system -- as in the reference)."""
+def _broadcast_int(value, group=None, device=None):
+    """rank 0's integer on every rank (None travels as -1)"""
+    import torch
+    import torch.distributed as dist
+
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else "cpu"
+    t = torch.tensor([-1 if value is None else int(value)], dtype=torch.int64, device=device)
+    dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    v = int(t.item())
+    return None if v < 0 else v
+
+
+def write_block_dataset(path: str, name: str, shape, dtype, rows, group=None):
+    """writeDatasetAsBlocks across processes (MyHDF5.chpl:303-333): rank 0 creates dataset `name` of `shape` with its storage
+    allocated, every rank then writes its own hyperslab of the last dimension -- all ranks AT THE SAME TIME, each straight to
+    the bytes of its hyperslab (hdf5.write_hyperslab_raw: disjoint byte ranges of one contiguous dataset, no HDF5 metadata
+    touched by anyone but rank 0), the `coforall loc in Locales` of the reference.  `rows` yields this rank's block of every
+    leading index in order (rank-1 dataset: exactly one block).  A library that will not give the address of the storage
+    falls back to one H5Dwrite at a time (LS_AMD_HDF5_RAW=0 forces that).  The file must be visible to every rank."""
+    import os
+
     import numpy as np
     import torch.distributed as dist
 
     from . import hdf5
 
     rank, world = dist.get_rank(group), dist.get_world_size(group)
+    shape = tuple(int(v) for v in shape)
+    lo, hi = hdf5.block_range(shape[-1], world, rank)
+    address = None
+    dist.barrier(group)  # nobody still holds the file open (HDF5 locks it: a reader elsewhere makes rank 0's H5Fopen(RDWR) fail)
+    if rank == 0:
+        address = hdf5.create_dataset(path, name, shape, dtype, allocate=os.environ.get("LS_AMD_HDF5_RAW", "1") != "0")
+    address = _broadcast_int(address, group)  # also the barrier the reference needs before the first H5Dopen (MyHDF5.chpl:219-221)
+    lead = shape[:-1]
+    for row, blk in enumerate(rows):
+        blk = np.ascontiguousarray(blk, dtype=dtype)
+        if blk.shape != (hi - lo,):
+            raise ValueError(f"rank {rank}: block of {blk.shape} elements, the Block distribution gives it {hi - lo}")
+        idx = tuple(int(v) for v in np.unravel_index(row, lead)) if lead else ()
+        if address is not None:
+            hdf5.write_hyperslab_raw(path, address, shape, idx + (lo,), blk.reshape((1,) * len(lead) + blk.shape))
+        else:
+            for r in range(world):  # serial HDF5 has no file locking across processes worth trusting: one writer at a time
+                if r == rank:
+                    hdf5.write_dataset_chunk(path, name, idx + (lo,), blk.reshape((1,) * len(lead) + blk.shape))
+                dist.barrier(group)
+    dist.barrier(group)
+    return address is not None
+
+
+def write_hashed_vectors(path: str, name: str, parts, masks, group=None):
+    """writeDatasetAsBlocks for hash-partitioned vectors (Diagonalize.chpl:248-256 -> MyHDF5.chpl:303-333): `parts` = this
+    rank's pieces of k vectors; dataset [k, N] in global ascending order, every rank writing its own hyperslab
+    (write_block_dataset: all ranks at once).  The file must be visible to every rank (one node, or a shared file system --
+    as in the reference)."""
+    import numpy as np
+
     if any(p.is_complex() for p in parts):
         raise NotImplementedError("HDF5 output is implemented for real vectors (the reference's eltType is real(64))")
     n = int(masks.numel())
-    lo, _ = hdf5.block_range(n, world, rank)
-    if rank == 0:
-        hdf5.create_dataset(path, name, (len(parts), n), np.float64)
-    dist.barrier(group)  # "without the barrier, H5Dopen fails when called from multiple locales" (MyHDF5.chpl:219-221)
-    for row, p in enumerate(parts):
-        blk = hashed_to_block(p, masks, group).cpu().numpy()
-        for r in range(world):  # one writer at a time: serial HDF5 has no file locking across processes worth trusting
-            if r == rank:
-                hdf5.write_dataset_chunk(path, name, (row, lo), blk[None, :])
-            dist.barrier(group)
+    # (a generator: the host holds one block at a time -- chain_40_symm vectors are 6.9 GB each)
+    rows = (hashed_to_block(p, masks, group).cpu().numpy() for p in parts)
+    return write_block_dataset(path, name, (len(parts), n), np.float64, rows, group)
 
 
 def read_hashed_vector(path: str, name: str, row: int, masks, group=None, device=None):

@@ -69,6 +69,11 @@ def lib():
         ("H5Tequal", C.c_int, [hid_t, hid_t]),
         ("H5Lexists", C.c_int, [hid_t, C.c_char_p, hid_t]),
         ("H5Ldelete", C.c_int, [hid_t, C.c_char_p, hid_t]),
+        ("H5Dget_offset", C.c_uint64, [hid_t]),
+        ("H5Pcreate", hid_t, [hid_t]),
+        ("H5Pclose", C.c_int, [hid_t]),
+        ("H5Pset_alloc_time", C.c_int, [hid_t, C.c_int]),
+        ("H5Pset_fill_time", C.c_int, [hid_t, C.c_int]),
     ]:
         fn = getattr(L, name)
         fn.restype, fn.argtypes = res, args
@@ -278,10 +283,15 @@ def read_dataset_chunk(path: str, name: str, offset, shape, dtype=np.float64) ->
         L.H5Fclose(f)
 
 
-def create_dataset(path: str, name: str, shape, dtype=np.float64):
+def create_dataset(path: str, name: str, shape, dtype=np.float64, allocate: bool = False):
     """the first half of writeDatasetAsBlocks (MyHDF5.chpl:303-322): an empty dataset of the full shape (an existing one of
-    that name is replaced; the file and the intermediate groups are created when missing)."""
+    that name is replaced; the file and the intermediate groups are created when missing).
+
+    allocate=True: the (contiguous) storage is allocated in the file right away and its byte address is returned
+    (None when the library does not give one), so that the hyperslab writers of all ranks can go to the file side by side
+    with write_hyperslab_raw -- no second process ever touches the HDF5 metadata."""
     L = lib()
+    address = None
     f = L.H5Fopen(path.encode(), H5F_ACC_RDWR, H5P_DEFAULT) if os.path.exists(path) else \
         L.H5Fcreate(path.encode(), H5F_ACC_TRUNC, H5P_DEFAULT, H5P_DEFAULT)
     if f < 0:
@@ -299,13 +309,62 @@ def create_dataset(path: str, name: str, shape, dtype=np.float64):
         shape = tuple(int(v) for v in shape)
         dims = (hsize_t * max(len(shape), 1))(*shape)
         s = L.H5Screate_simple(len(shape), dims, None)
-        d = L.H5Dcreate2(f, full.encode(), _native(dtype), s, H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT)
+        dcpl = H5P_DEFAULT
+        if allocate and all(shape):
+            dcpl = L.H5Pcreate(hid_t.in_dll(L, "H5P_CLS_DATASET_CREATE_ID_g").value)
+            # H5D_ALLOC_TIME_EARLY = 1: space at creation; H5D_FILL_TIME_NEVER = 1: every byte is written by its owner anyway
+            if dcpl < 0 or L.H5Pset_alloc_time(dcpl, 1) < 0 or L.H5Pset_fill_time(dcpl, 1) < 0:
+                raise OSError("cannot set up the dataset creation properties")
+        d = L.H5Dcreate2(f, full.encode(), _native(dtype), s, H5P_DEFAULT, dcpl, H5P_DEFAULT)
         L.H5Sclose(s)
+        if dcpl != H5P_DEFAULT:
+            L.H5Pclose(dcpl)
         if d < 0:
             raise OSError(f"cannot create {name}")
+        if allocate and all(shape):
+            a = int(L.H5Dget_offset(d))
+            address = None if a == 0xFFFFFFFFFFFFFFFF else a  # HADDR_UNDEF: not contiguous / not allocated
         L.H5Dclose(d)
     finally:
-        L.H5Fclose(f)
+        L.H5Fclose(f)  # flushes the metadata and extends the file to the end of the allocation
+    if address is not None and os.path.getsize(path) < address + int(np.prod(shape)) * np.dtype(dtype).itemsize:
+        address = None  # the file does not cover the allocation (a library that defers it after all): stay with H5Dwrite
+    return address
+
+
+def write_hyperslab_raw(path: str, address: int, shape, offset, arr):
+    """the second half of writeDatasetAsBlocks for a dataset made by create_dataset(allocate=True): `arr` goes straight to the
+    bytes of its hyperslab (row-major contiguous storage at `address`; one pwrite per contiguous run), so the writers of all
+    ranks run at the same time on disjoint byte ranges -- what the reference's `coforall loc in Locales` (MyHDF5.chpl:328-332)
+    does through one HDF5 handle per locale.  Native byte order, like H5T_NATIVE_* on this platform."""
+    arr = np.ascontiguousarray(arr)
+    shape, offset = tuple(int(v) for v in shape), tuple(int(v) for v in offset)
+    if len(offset) != arr.ndim or len(shape) != arr.ndim:
+        raise ValueError("offset, dataset and array differ in rank")
+    if any(o < 0 or o + e > n for o, e, n in zip(offset, arr.shape, shape)):
+        raise IndexError(f"hyperslab {offset} + {arr.shape} exceeds the dataset {shape}")
+    if arr.size == 0:
+        return
+    item = arr.dtype.itemsize
+    strides = [item] * arr.ndim
+    for k in range(arr.ndim - 2, -1, -1):
+        strides[k] = strides[k + 1] * shape[k + 1]
+    # the trailing dimensions the hyperslab covers completely are contiguous in the file together with the first partial one
+    run_dim = arr.ndim - 1
+    while run_dim > 0 and arr.shape[run_dim] == shape[run_dim]:
+        run_dim -= 1
+    run_bytes = int(np.prod(arr.shape[run_dim:])) * item
+    flat = arr.reshape(-1).view(np.uint8)
+    fd = os.open(path, os.O_WRONLY)
+    try:
+        for idx, lead in enumerate(np.ndindex(*arr.shape[:run_dim])):
+            pos = address + sum((offset[k] + lead[k]) * strides[k] for k in range(run_dim)) + offset[run_dim] * strides[run_dim]
+            buf = memoryview(flat[idx * run_bytes:(idx + 1) * run_bytes])
+            done = 0
+            while done < run_bytes:
+                done += os.pwrite(fd, buf[done:], pos + done)
+    finally:
+        os.close(fd)
 
 
 def write_dataset_chunk(path: str, name: str, offset, arr):

@@ -364,12 +364,31 @@ def _worker_layouts(rank, world, port, name, out_dir):
         except hdf5.Hdf5Unavailable:
             return
         path = os.path.join(out_dir, "vectors.h5")
-        write_hashed_vectors(path, "/hamiltonian/eigenvectors", parts, masks)
+        # all ranks write at once, straight to the bytes of their hyperslabs (write_block_dataset / hdf5.write_hyperslab_raw) ...
+        assert write_hashed_vectors(path, "/hamiltonian/eigenvectors", parts, masks) is True
         dist.barrier()
         if rank == 0:
             assert np.array_equal(hdf5.read_dataset(path, "/hamiltonian/eigenvectors"), np.stack(xs))
         for row in range(2):
             assert np.array_equal(read_hashed_vector(path, "/hamiltonian/eigenvectors", row, masks).numpy(), xs[row][mine])
+        # ... a rank-1 dataset next to it in the same file (basis/representatives of diagonalize_distributed) leaves it intact ...
+        from distributed_matvec_amd.distributed import write_block_dataset
+
+        assert write_block_dataset(path, "/basis/representatives", (n,), np.uint64, [reps[lo:hi]]) is True
+        assert np.array_equal(hdf5.read_dataset(path, "/basis/representatives"), reps)
+        assert np.array_equal(hdf5.read_dataset_block(path, "/basis/representatives", world, rank, np.uint64), reps[lo:hi])
+        assert np.array_equal(hdf5.read_dataset(path, "/hamiltonian/eigenvectors"), np.stack(xs))
+        with pytest.raises(ValueError):  # a block of the wrong length is refused before anything is written
+            write_block_dataset(path, "/basis/wrong", (n,), np.uint64, [np.zeros(hi - lo + 1, dtype=np.uint64)])
+        dist.barrier()
+        # ... and the one-H5Dwrite-at-a-time fallback (a library that gives no storage address) writes the same file
+        os.environ["LS_AMD_HDF5_RAW"] = "0"
+        try:
+            path2 = os.path.join(out_dir, "vectors_serial.h5")
+            assert write_hashed_vectors(path2, "/hamiltonian/eigenvectors", parts, masks) is False
+            assert np.array_equal(hdf5.read_dataset(path2, "/hamiltonian/eigenvectors"), np.stack(xs))
+        finally:
+            del os.environ["LS_AMD_HDF5_RAW"]
     finally:
         dist.destroy_process_group()
 

@@ -104,6 +104,50 @@ def test_diagonalize_distributed_one_rank(torch, tmp_path, name, exchange, monke
     assert abs(hdf5.read_dataset(out, "/hamiltonian/eigenvalues")[0] - r.eigenvalues[0]) < 1e-12
 
 
+def test_diagonalize_distributed_extends_an_existing_output(torch, tmp_path, capfd):
+    """makeBasisStates (Diagonalize.chpl:227-246) with one process per GPU: an output file that already holds
+    /basis/representatives (and anything else) is extended, not truncated -- the stored states are read block-wise, checked
+    against the configured basis and kept; hamiltonian/* of an earlier run is replaced; a file of another basis is refused"""
+    import os
+
+    import torch.distributed as dist
+
+    from distributed_matvec_amd import api, hdf5
+    from distributed_matvec_amd.diagonalize import diagonalize, diagonalize_distributed
+
+    try:
+        hdf5.lib()
+    except hdf5.Hdf5Unavailable:
+        pytest.skip("libhdf5 not available")
+    out = str(tmp_path / "out.h5")
+    ref = diagonalize(model_config("heisenberg_chain_12"), num_evals=1, eps=1e-10, output=out)  # the earlier run: basis + hamiltonian
+    reps = hdf5.read_dataset(out, "/basis/representatives")
+    hdf5.write_datasets(out, {"/extra/payload": np.arange(7, dtype=np.float64)}, append=True)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{29500 + os.getpid() % 200}", rank=0, world_size=1)
+    try:
+        r = diagonalize_distributed(model_config("heisenberg_chain_12"), num_evals=1, eps=1e-10, output=out, verbose=True)
+        assert "verified, kept" in capfd.readouterr().out
+        assert r.converged and abs(r.eigenvalues[0] - ref.eigenvalues[0]) < 1e-9
+        assert np.array_equal(hdf5.read_dataset(out, "/basis/representatives"), reps)
+        assert np.array_equal(hdf5.read_dataset(out, "/extra/payload"), np.arange(7, dtype=np.float64))
+        assert hdf5.read_dataset(out, "/hamiltonian/eigenvectors").shape == (1, len(reps))
+        assert abs(hdf5.read_dataset(out, "/hamiltonian/eigenvalues")[0] - r.eigenvalues[0]) < 1e-12
+        # the same file handed to another sector / another model: refused, and left as it was
+        for stale in ("heisenberg_kagome_12_symm", "heisenberg_chain_10"):
+            with pytest.raises(api.LsAmdError, match="does not belong to the configured basis"):
+                diagonalize_distributed(model_config(stale), num_evals=1, eps=1e-10, output=out)
+        assert np.array_equal(hdf5.read_dataset(out, "/basis/representatives"), reps)
+        # same count, one state different
+        bad = reps.copy()
+        bad[len(bad) // 2] ^= np.uint64(3)
+        out2 = str(tmp_path / "bad.h5")
+        hdf5.write_datasets(out2, {"/basis/representatives": bad})
+        with pytest.raises(api.LsAmdError, match="stale output file"):
+            diagonalize_distributed(model_config("heisenberg_chain_12"), num_evals=1, eps=1e-10, output=out2)
+    finally:
+        dist.destroy_process_group()
+
+
 def test_square_4x4_published_energy(torch):
     """the 4 x 4 periodic square lattice (data/heisenberg_square_4x4.yaml: 107 symmetry-adapted states, a non-cyclic lattice
     group -- the general K4 path -- with vertical and wrap-around bonds) against the published
