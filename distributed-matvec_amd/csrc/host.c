@@ -1505,7 +1505,7 @@ struct ls_amd_plan {
     void *d_tilemap;
     int has_pairs; /* staged row kernel for arbitrary exchange pairs (lsk_pairs): non-ring lattices */
     lsk_pairplan pairs;
-    void *d_pair_recs, *d_rank_low, *d_pair_binom, *d_states32;
+    void *d_pair_recs, *d_rank_low, *d_pair_binom, *d_states32, *d_pair_rows;
     int has_chain; /* staged row kernel (lsk_chain) */
     int chain_cached;      /* leading non-adjacent exchange groups whose partner ranks are cached */
     void *d_chain_cache;   /* [chain_cached][count] u32, or u64 when chain_wide */
@@ -2097,8 +2097,8 @@ int64_t ls_amd_test_gtab_find(int L, int bbits, uint64_t const *entries, uint64_
 static int chain_eligible(ls_amd_plan const *pl) {
     ls_hs_operator const *op = pl->op;
     struct ls_amd_operator_ext const *ext = OEXT(op);
-    char const *e = getenv("LS_AMD_ROW_KERNEL"); /* auto (default) | generic: k_direct | pairs: k_pairs_t where it applies */
-    if (e && (strcmp(e, "generic") == 0 || strcmp(e, "pairs") == 0)) return 0;
+    char const *e = getenv("LS_AMD_ROW_KERNEL"); /* auto (default) | generic: k_direct | pairs: k_pairs_t where it applies | pairrows: k_pairs_row where it applies */
+    if (e && (strcmp(e, "generic") == 0 || strcmp(e, "pairs") == 0 || strcmp(e, "pairrows") == 0)) return 0;
     int const L = op->basis->number_sites;
     int const inv = op->basis->spin_inversion != 0;
     /* Inversion sectors WITHOUT permutations (round 6; BASELINE config 1's sector, BatchedOperator.chpl:119-161): at half filling the
@@ -2230,7 +2230,9 @@ static int setup_pairs(ls_amd_plan *pl, int64_t n, uint64_t const *d_reps, void 
      * once per block: measured on a 36-site square lattice (profiles/r6_widen_bench.txt) weight 6 -- kl ~ 1.8 -- 1.09 ms against 0.25 ms
      * of the generic row kernel, weight 9 -- kl ~ 2.75 -- 15.3 against 14.3 ms.  Such bases keep k_direct (LS_AMD_ROW_KERNEL=pairs forces
      * the staged kernel: tests). */
-    if (!(e && strcmp(e, "pairs") == 0) && (11 * hw < 4 * L || 11 * (L - hw) < 4 * L)) return 0;
+    /* Round 6: those bases take the one-row-per-lane variant of the same plan instead (k_pairs_row: O(1) rank shifts out of per-row
+     * prefix arrays in LDS), which leaves the generic kernel behind at any filling; LS_AMD_ROW_KERNEL=pairrows forces it everywhere. */
+    int const by_row = (e && strcmp(e, "pairrows") == 0) || (!(e && strcmp(e, "pairs") == 0) && (11 * hw < 4 * L || 11 * (L - hw) < 4 * L));
     lsk_pair recs[LSK_MAX_PAIRS];
     memset(recs, 0, sizeof(recs));
     for (int g = 0; g < ext->n_groups; ++g) {
@@ -2276,12 +2278,26 @@ static int setup_pairs(ls_amd_plan *pl, int64_t n, uint64_t const *d_reps, void 
         upload(&pl->d_pair_binom, bin, sizeof(uint32_t) * (size_t)nbits * LSK_PAIR_KC) != 0)
         return -1;
     if (!wide) DEV(lsk_narrow_states(n, d_reps, (uint32_t *)pl->d_states32, stream));
+    if (by_row) {
+        lsk_pair_row rr[LSK_MAX_PAIRS];
+        memset(rr, 0, sizeof(rr));
+        for (int g = 0; g < ext->n_groups; ++g) {
+            int const i = recs[g].i, j = recs[g].j;
+            rr[g].i = i;
+            rr[g].j = j;
+            rr[g].between = ((1ULL << j) - 1) & ~((2ULL << i) - 1);
+            rr[g].v = recs[g].v;
+            rr[g].vz = recs[g].vz;
+        }
+        if (upload(&pl->d_pair_rows, rr, sizeof(lsk_pair_row) * (size_t)ext->n_groups) != 0) return -1;
+        pp.rows = (lsk_pair_row const *)pl->d_pair_rows;
+    }
     pp.pairs = (lsk_pair const *)pl->d_pair_recs;
     pp.rank_low = (uint16_t const *)pl->d_rank_low;
     pp.binom = (uint32_t const *)pl->d_pair_binom;
     pp.states = wide ? (void const *)d_reps : (void const *)pl->d_states32;
     pp.wide = wide;
-    if (build_tilemap(pl, n, lsk_pairs_tile_rows(pl->cplx)) != 0) return -1;
+    if (build_tilemap(pl, n, by_row ? 256 : lsk_pairs_tile_rows(pl->cplx)) != 0) return -1;
     pl->pairs = pp;
     pl->has_pairs = 1;
     return 0;
@@ -2917,6 +2933,7 @@ void ls_amd_plan_destroy(ls_amd_plan *pl) {
     if (pl->d_chain_cache) lsk_free(pl->d_chain_cache);
     if (pl->d_chain_rec) lsk_free(pl->d_chain_rec);
     if (pl->d_pair_recs) lsk_free(pl->d_pair_recs);
+    if (pl->d_pair_rows) lsk_free(pl->d_pair_rows);
     if (pl->d_rank_low) lsk_free(pl->d_rank_low);
     if (pl->d_pair_binom) lsk_free(pl->d_pair_binom);
     if (pl->d_states32) lsk_free(pl->d_states32);
@@ -3211,7 +3228,7 @@ char const *ls_amd_plan_kernel_name(ls_amd_plan const *pl) {
     switch (pl->family) {
     case FAMILY_DIRECT_PUSH: return "direct-push";
     case FAMILY_DIRECT_PULL:
-        return pl->has_chain ? "direct-pull+staged" : pl->has_pairs ? "direct-pull+pairs" : "direct-pull";
+        return pl->has_chain ? "direct-pull+staged" : pl->has_pairs ? (pl->pairs.rows ? "direct-pull+pairrows" : "direct-pull+pairs") : "direct-pull";
     case FAMILY_TILE_PULL: return pl->idx_mode ? (pl->slot_cache ? "tile-pull+indexed+cached" : (pl->d_vtab ? "tile-pull+values" : "tile-pull+indexed")) : "tile-pull";
     case FAMILY_REPL_DIRECT:
         return pl->has_chain ? "replicated-direct-pull+staged" : "replicated-direct-pull";

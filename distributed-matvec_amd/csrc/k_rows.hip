@@ -1062,10 +1062,104 @@ __global__ __launch_bounds__(kBlock, (CPLX ? 4 : 6)) void k_pairs_t(lsk_pairplan
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same operators FAR FROM HALF FILLING (k_pairs_row; round 6): the blocks k_pairs_t walks shrink to a handful of rows there
+// (C(11, kl), kl ~ 11 w / L) and the generic row kernel, which re-ranks every partner from scratch behind a divergent branch,
+// used to be the faster of the two (6 x 6 square lattice, weight 6: 0.25 against 1.09 ms).  One row per lane, every pair
+// branch-free, the rank of a partner in O(1):
+//   the particles of a row sit at pos_0 < pos_1 < ..., rank = sum_t C(pos_t, t + 1).  A pair (i < j) whose two bits differ moves ONE
+//   particle between i and j past the m particles in between, and each of those changes its index by one:
+//     particle k at i -> j (ends as particle k + m):  d = C(j, k+m+1) - C(i, k+1) - sum_{t = k+1 .. k+m} [C(pos_t, t+1) - C(pos_t, t)]
+//     particle k+m at j -> i (ends as particle k):    d = C(i, k+1) - C(j, k+m+1) - sum_{t = k .. k+m-1} [C(pos_t, t+1) - C(pos_t, t+2)]
+//   with k = particles below i.  The two sums are differences of per-row prefix arrays A[], B[] (weight + 1 entries each) that the
+//   lane writes to LDS once per row (entry u of lane l at [u][l]: conflict-free), so a pair costs three popcounts, two reads of the
+//   binomial table, two of the prefix arrays, one gather of x and an fma -- and nothing depends on the previous pair: the
+//   compiler keeps several gathers in flight.  32-bit arithmetic throughout (fewer than 2^32 states; everything is additive).
+// ---------------------------------------------------------------------------------------------
+template <typename SW, bool CPLX>
+__global__ __launch_bounds__(kBlock) void k_pairs_row(lsk_pairplan pp, int hamming_weight, uint64_t const *__restrict__ tilemap,
+                                                      int64_t slots_per_xcd, void const *__restrict__ x_v, void *__restrict__ y_v) {
+    typedef typename ChainX<CPLX>::type X;
+    constexpr int NBITS = 8 * (int)sizeof(SW);
+    constexpr int kc = LSK_PAIR_KC;
+    X const *__restrict__ x = (X const *)x_v;
+    X *__restrict__ y = (X *)y_v;
+    extern __shared__ uint32_t s_prefix[]; // A: [hamming_weight + 1][kBlock], then B the same
+    __shared__ uint32_t s_binom[NBITS * kc];
+    auto popc = [](SW v) { return sizeof(SW) == 4 ? __popc((uint32_t)v) : __popcll((uint64_t)v); };
+    auto ctz = [](SW v) { return sizeof(SW) == 4 ? __builtin_ctz((uint32_t)v) : __builtin_ctzll((uint64_t)v); };
+    for (int k = threadIdx.x; k < NBITS * kc; k += kBlock) s_binom[k] = pp.binom[k];
+    __syncthreads();
+    uint32_t *const sA = s_prefix + threadIdx.x;
+    uint32_t *const sB = sA + (hamming_weight + 1) * kBlock;
+    SW const *__restrict__ states = (SW const *)pp.states;
+    lsk_pair_row const *__restrict__ rows = pp.rows;
+    const int n_pairs = pp.n_near + pp.n_str + pp.n_high;
+    const int xcd = blockIdx.x & 7;
+    const int64_t blocks_per_xcd = gridDim.x >> 3;
+    tilemap += (int64_t)xcd * slots_per_xcd;
+    for (int64_t t = blockIdx.x >> 3; t < slots_per_xcd; t += blocks_per_xcd) {
+        const uint64_t slot = tilemap[t];
+        if ((uint64_t)threadIdx.x >= (slot >> 48)) continue; // (no block-wide barrier below: every lane owns its LDS column)
+        const int64_t i = (int64_t)(slot & 0xffffffffffffULL) + threadIdx.x;
+        const SW a = __builtin_nontemporal_load(states + i);
+        const uint32_t ig = (uint32_t)i;
+        {
+            uint32_t A = 0, B = 0;
+            SW s = a;
+            sA[0] = 0;
+            sB[0] = 0;
+            for (int u = 0; u < hamming_weight; ++u) { // (the same count for every row of the basis)
+                const int p = ctz(s);
+                s &= s - (SW)1;
+                uint32_t const *c = s_binom + p * kc + u; // C(p, u), C(p, u + 1), C(p, u + 2)
+                A += c[1] - c[0];
+                B += c[1] - c[2];
+                sA[(u + 1) * kBlock] = A;
+                sB[(u + 1) * kBlock] = B;
+            }
+        }
+        const X xr = x[i];
+        X acc = cx_zero<X>();
+        double dsub = 0.0; // sum of vz over this row's anti-aligned pairs
+#pragma unroll 4
+        for (int p = 0; p < n_pairs; ++p) {
+            lsk_pair_row const R = rows[p]; // (wave-uniform: scalar loads)
+            const bool up = ((a >> R.i) & (SW)1) != 0; // the particle sits at i
+            const bool act = up != (((a >> R.j) & (SW)1) != 0);
+            const int k = popc(a & (SW)((((SW)1) << R.i) - (SW)1)), m = popc(a & (SW)R.between);
+            const uint32_t e = s_binom[R.j * kc + k + m + 1] - s_binom[R.i * kc + k + 1];
+            uint32_t const *arr = up ? sA : sB;
+            const int u0 = up ? k + 1 : k;
+            const uint32_t passed = arr[(u0 + m) * kBlock] - arr[u0 * kBlock];
+            const uint32_t d = (up ? e : 0u - e) - passed;
+            const uint32_t idx = act ? ig + d : ig;
+            cx_fma(act ? R.v : 0.0, x[idx], acc);
+            dsub += act ? R.vz : 0.0;
+        }
+        cx_fma(pp.dsum - 2.0 * dsub, xr, acc);
+        cx_store_nt(y + i, acc);
+    }
+}
+template <typename SW, bool CPLX>
+static int launch_pairs_row(lsk_pairplan pp, int hamming_weight, lsk_tilemap tm, void const *x, void *y, void *stream) {
+    const size_t lds = 2 * (size_t)(hamming_weight + 1) * kBlock * sizeof(uint32_t);
+    const int64_t gb = tm.slots_per_xcd * 8;
+    const int cap = resident_grid(k_pairs_row<SW, CPLX>, gb, lds);
+    const unsigned g = (unsigned)(gb < cap ? gb : cap);
+    hipLaunchKernelGGL((k_pairs_row<SW, CPLX>), dim3(g), dim3(kBlock), lds, (hipStream_t)stream, pp, hamming_weight, tm.entries, tm.slots_per_xcd, x, y);
+    LSK_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int lsk_pairs_tile_rows(int cplx) { return cplx ? 512 : 1024; }
 extern "C" int lsk_pairs(lsk_pairplan pp, int hamming_weight, int cplx, lsk_tilemap tm, int64_t n, void const *x, void *y, void *stream) {
     if (n == 0 || tm.slots_per_xcd == 0) return 0;
     if (pp.n_near + pp.n_str + pp.n_high > LSK_MAX_PAIRS || hamming_weight + 2 > LSK_PAIR_KC) { snprintf(g_err, sizeof(g_err), "lsk_pairs: plan out of range"); return -1; }
+    if (pp.rows) { // far from half filling: one row per lane (tiles of kBlock rows)
+        if (pp.wide) return cplx ? launch_pairs_row<uint64_t, true>(pp, hamming_weight, tm, x, y, stream) : launch_pairs_row<uint64_t, false>(pp, hamming_weight, tm, x, y, stream);
+        return cplx ? launch_pairs_row<uint32_t, true>(pp, hamming_weight, tm, x, y, stream) : launch_pairs_row<uint32_t, false>(pp, hamming_weight, tm, x, y, stream);
+    }
     const int64_t gb = tm.slots_per_xcd * 8; // one block per tile
     if (pp.wide) { // 33..64 sites: 8-byte states
         if (cplx) hipLaunchKernelGGL((k_pairs_t<uint64_t, true, 512>), dim3((unsigned)gb), dim3(kBlock), 0, (hipStream_t)stream, pp, hamming_weight, tm.entries, tm.slots_per_xcd, n, x, y);

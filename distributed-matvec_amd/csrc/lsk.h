@@ -254,6 +254,12 @@ typedef struct lsk_pair {
     double v;             /* exchange amplitude: coefficient of |..0_i..1_j..><..1_i..0_j..| + h.c. */
     double vz;            /* diagonal: vz (-1)^{[bits i, j differ]} */
 } lsk_pair;
+/* the same pair as the one-row-per-lane variant reads it (k_pairs_row): the masks its rank shift needs, ready-made */
+typedef struct lsk_pair_row {
+    uint64_t between; /* sites strictly between i and j */
+    double v, vz;
+    int i, j;         /* i < j */
+} lsk_pair_row;
 typedef struct lsk_pairplan {
     int n_near, n_str, n_high;
     lsk_pair const *pairs;     /* device [n_near + n_str + n_high] */
@@ -262,6 +268,7 @@ typedef struct lsk_pairplan {
     void const *states;        /* device [n]: u32 low words of the representatives (the plan's 4-byte copy), or, wide, the u64 representatives */
     int wide;                  /* 33..64 sites: 8-byte states (ranks stay 32-bit) */
     double dsum;               /* sum of vz over all pairs */
+    lsk_pair_row const *rows;  /* device [n_near + n_str + n_high], or NULL: the one-row-per-lane variant (far from half filling) */
 } lsk_pairplan;
 int lsk_pairs_tile_rows(int cplx);
 int lsk_pairs(lsk_pairplan pp, int hamming_weight, int cplx, lsk_tilemap tm, int64_t n, void const *x, void *y, void *stream);

@@ -49,6 +49,7 @@ def model(name):
 ap = argparse.ArgumentParser()
 ap.add_argument("--models", default="chain_32_inv1,hop_30,square_6x6_w6")
 ap.add_argument("--steps", type=int, default=6)
+ap.add_argument("--variants", default="push:auto,auto:auto,pull:generic", help="mode:LS_AMD_ROW_KERNEL, comma-separated")
 args = ap.parse_args()
 for name in args.models.split(","):
     cfg = model(name)
@@ -58,7 +59,7 @@ for name in args.models.split(","):
     x = [D.fillRandom(reps[0], 42, torch.float64)]
     y = [torch.zeros_like(x[0])]
     y_ref, nnz = None, None
-    for mode, rk in (("push", "auto"), ("auto", "auto"), ("pull", "generic")):
+    for mode, rk in (v.split(":") for v in args.variants.split(",")):
         os.environ["LS_AMD_ROW_KERNEL"] = rk
         try:
             pl = D.MatvecPlan(h, reps, torch.float64, mode=mode)

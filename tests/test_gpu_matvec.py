@@ -1008,6 +1008,8 @@ ROW_KERNEL_VARIANTS = {
     # the staged kernel for arbitrary exchange pairs (the default of everything that is not a ring), here on the rings too
     "pairs-kernel": {"LS_AMD_ROW_KERNEL": "pairs"},
     "pairs-kernel-contiguous-tiles": {"LS_AMD_ROW_KERNEL": "pairs", "LS_AMD_TILE_CHUNK": "0"},
+    # its one-row-per-lane variant (round 6: the default far from half filling), here on everything
+    "pairrows-kernel": {"LS_AMD_ROW_KERNEL": "pairrows"},
 }
 
 
@@ -1045,6 +1047,8 @@ def test_row_kernel_variants(torch, monkeypatch, variant):
             assert pl.kernel == ("direct-pull+pairs" if kind == "j1j2" else "direct-pull+staged"), (kind, pl.kernel)
         if variant.startswith("pairs-kernel"):
             assert pl.kernel == "direct-pull+pairs", (kind, pl.kernel)
+        if variant == "pairrows-kernel":
+            assert pl.kernel == "direct-pull+pairrows", (kind, pl.kernel)
         # c128 vectors: the complex instantiation of the same kernel family
         xc = x + 1j * (rs.rand(len(want_reps)) - 0.5)
         gotc, plc = run_matvec(torch, D, h, reps, masks, xc, 1, "pull")
@@ -1201,19 +1205,27 @@ PAIR_KERNEL_CASES = {
     "square-6x6-w4-xxz": lambda: _lattice_config(36, 4, _square_bonds(6, 6), jz=0.7, jxy=1.3),
     "ring-40-w3-long": lambda: _lattice_config(40, 3, [(i, (i + 1) % 40) for i in range(40)], extra=([(i, (i + 17) % 40) for i in range(40)], 0.5, 0.25)),
     "star-64-w2": lambda: _lattice_config(64, 2, [(0, j) for j in range(1, 64)] + [(63, j) for j in range(1, 63)] + [(5, 40), (12, 33), (31, 32)]),
+    # past half filling, and the largest weight the 20-column binomial table takes
+    "square-4x4-w11": lambda: _lattice_config(16, 11, _square_bonds(4, 4)),
+    "ring-20-w18-long": lambda: _lattice_config(20, 18, [(i, (i + 1) % 20) for i in range(20)], extra=([(i, (i + 7) % 20) for i in range(20)], 0.5, 0.25)),
+    "one-particle-24": lambda: _lattice_config(24, 1, [(i, (i + 1) % 24) for i in range(24)] + [(0, 12), (3, 20)]),
 }
 
 
+@pytest.mark.parametrize("kernel", ["pairs", "pairrows", "auto"])
 @pytest.mark.parametrize("case", sorted(PAIR_KERNEL_CASES))
-def test_pairs_kernel_lattices(torch, monkeypatch, case):
+def test_pairs_kernel_lattices(torch, monkeypatch, case, kernel):
     """k_pairs_t (staged row kernel for arbitrary exchange pairs -- what every non-ring lattice runs on one GPU) against the
     oracle: two-dimensional lattices with wrap-around bonds, J1-J2, XXZ amplitudes, all pairs in the low part, the complete
     graph (near / straddling / high pairs, long spans), tiny blocks (waves of many segments), 33..64 sites (8-byte states);
-    f64 and c128.  (LS_AMD_ROW_KERNEL=pairs: far from half filling the plan would keep the generic kernel, which is faster there.)"""
+    f64 and c128.  The same plan has a one-row-per-lane variant (k_pairs_row: O(1) rank shifts from per-row prefix arrays in
+    LDS) that the plan takes by itself far from half filling: every case runs through the staged kernel
+    (LS_AMD_ROW_KERNEL=pairs), through the row variant (=pairrows) and through whichever the plan picks."""
     from oracle import c_oracle as CO
     from oracle import model as M
 
-    monkeypatch.setenv("LS_AMD_ROW_KERNEL", "pairs")
+    if kernel != "auto":
+        monkeypatch.setenv("LS_AMD_ROW_KERNEL", kernel)
 
     cfg = PAIR_KERNEL_CASES[case]()
     if cfg.pop("drop_zz", False):
@@ -1228,8 +1240,12 @@ def test_pairs_kernel_lattices(torch, monkeypatch, case):
     got, pl = run_matvec(torch, D, h, reps, masks, x, 1, "pull")
     if case == "xy-only-16":
         assert pl.kernel == "direct-pull"  # no diagonal terms: y is accumulated into (DMV:1062-1063) -- the generic kernel's job
+    elif kernel == "auto":
+        L, w = cfg["basis"]["number_spins"], cfg["basis"]["hamming_weight"]
+        far = 11 * w < 4 * L or 11 * (L - w) < 4 * L
+        assert pl.kernel == ("direct-pull+pairrows" if far else "direct-pull+pairs"), (pl.kernel, L, w)
     else:
-        assert pl.kernel == "direct-pull+pairs", pl.kernel
+        assert pl.kernel == "direct-pull+" + kernel, pl.kernel
     assert np.abs(got - want).max() <= 1e-12 * max(1.0, np.abs(want).max()), (case, np.abs(got - want).max())
     xc = x + 1j * (rs.rand(len(want_reps)) - 0.5)
     gotc, plc = run_matvec(torch, D, h, reps, masks, xc, 1, "pull")
