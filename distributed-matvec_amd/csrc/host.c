@@ -1505,7 +1505,7 @@ struct ls_amd_plan {
     void *d_tilemap;
     int has_pairs; /* staged row kernel for arbitrary exchange pairs (lsk_pairs): non-ring lattices */
     lsk_pairplan pairs;
-    void *d_pair_recs, *d_rank_low, *d_pair_binom, *d_states32, *d_pair_rows;
+    void *d_pair_recs, *d_rank_low, *d_pair_binom, *d_states32, *d_pair_rows, *d_pair_sites;
     int has_chain; /* staged row kernel (lsk_chain) */
     int chain_cached;      /* leading non-adjacent exchange groups whose partner ranks are cached */
     void *d_chain_cache;   /* [chain_cached][count] u32, or u64 when chain_wide */
@@ -2097,8 +2097,8 @@ int64_t ls_amd_test_gtab_find(int L, int bbits, uint64_t const *entries, uint64_
 static int chain_eligible(ls_amd_plan const *pl) {
     ls_hs_operator const *op = pl->op;
     struct ls_amd_operator_ext const *ext = OEXT(op);
-    char const *e = getenv("LS_AMD_ROW_KERNEL"); /* auto (default) | generic: k_direct | pairs: k_pairs_t where it applies | pairrows: k_pairs_row where it applies */
-    if (e && (strcmp(e, "generic") == 0 || strcmp(e, "pairs") == 0 || strcmp(e, "pairrows") == 0)) return 0;
+    char const *e = getenv("LS_AMD_ROW_KERNEL"); /* auto (default) | generic: k_direct | pairs: k_pairs_t where it applies | pairrows / pairsites: k_pairs_row / k_pairs_site where they apply */
+    if (e && (strcmp(e, "generic") == 0 || strcmp(e, "pairs") == 0 || strcmp(e, "pairrows") == 0 || strcmp(e, "pairsites") == 0)) return 0;
     int const L = op->basis->number_sites;
     int const inv = op->basis->spin_inversion != 0;
     /* Inversion sectors WITHOUT permutations (round 6; BASELINE config 1's sector, BatchedOperator.chpl:119-161): at half filling the
@@ -2232,7 +2232,8 @@ static int setup_pairs(ls_amd_plan *pl, int64_t n, uint64_t const *d_reps, void 
      * the staged kernel: tests). */
     /* Round 6: those bases take the one-row-per-lane variant of the same plan instead (k_pairs_row: O(1) rank shifts out of per-row
      * prefix arrays in LDS), which leaves the generic kernel behind at any filling; LS_AMD_ROW_KERNEL=pairrows forces it everywhere. */
-    int const by_row = (e && strcmp(e, "pairrows") == 0) || (!(e && strcmp(e, "pairs") == 0) && (11 * hw < 4 * L || 11 * (L - hw) < 4 * L));
+    int const force_sites = e && strcmp(e, "pairsites") == 0;
+    int const by_row = force_sites || (e && strcmp(e, "pairrows") == 0) || (!(e && strcmp(e, "pairs") == 0) && (11 * hw < 4 * L || 11 * (L - hw) < 4 * L));
     lsk_pair recs[LSK_MAX_PAIRS];
     memset(recs, 0, sizeof(recs));
     for (int g = 0; g < ext->n_groups; ++g) {
@@ -2291,6 +2292,56 @@ static int setup_pairs(ls_amd_plan *pl, int64_t n, uint64_t const *d_reps, void 
         }
         if (upload(&pl->d_pair_rows, rr, sizeof(lsk_pair_row) * (size_t)ext->n_groups) != 0) return -1;
         pp.rows = (lsk_pair_row const *)pl->d_pair_rows;
+        /* ... or walking the particles of the row: weight x degree candidates instead of all pairs (k_pairs_site is bound by VALU
+         * issue, ~30 instructions per candidate against ~47 per pair of k_pairs_row).  LS_AMD_ROW_KERNEL=pairsites forces it while
+         * the degree fits the table, =pairrows keeps the pair loop. */
+        int deg[64] = {0}, dmax = 0;
+        for (int g = 0; g < ext->n_groups; ++g) { ++deg[recs[g].i]; ++deg[recs[g].j]; }
+        for (int q = 0; q < L; ++q) if (deg[q] > dmax) dmax = deg[q];
+        int const D = dmax <= 4 ? 4 : 8;
+        if (dmax <= LSK_PAIR_SITE_MAX_DEGREE && !(e && strcmp(e, "pairrows") == 0) && (force_sites || 2 * hw * D <= 3 * ext->n_groups)) {
+            /* amplitude classes: distinct (v, vz) */
+            double cv[LSK_PAIR_SITE_MAX_CLASSES], cz[LSK_PAIR_SITE_MAX_CLASSES];
+            uint8_t cls_of[LSK_MAX_PAIRS];
+            int n_cls = 0, ok = 1;
+            for (int g = 0; g < ext->n_groups && ok; ++g) {
+                int c = 0;
+                while (c < n_cls && !(cv[c] == recs[g].v && cz[c] == recs[g].vz)) ++c;
+                if (c == n_cls) {
+                    if (n_cls == LSK_PAIR_SITE_MAX_CLASSES) { ok = 0; break; }
+                    cv[c] = recs[g].v;
+                    cz[c] = recs[g].vz;
+                    ++n_cls;
+                }
+                cls_of[g] = (uint8_t)c;
+            }
+            if (ok) {
+                int const DW = D / 4, amp_at = (2 * L * DW + 3) & ~3, words = amp_at + 4 * n_cls;
+                uint32_t *tab = (uint32_t *)calloc((size_t)words, sizeof(uint32_t));
+                if (!tab) return -1;
+                uint8_t *nb = (uint8_t *)tab, *cl = (uint8_t *)(tab + L * DW);
+                for (int q = 0; q < L; ++q) for (int d = 0; d < D; ++d) nb[q * D + d] = (uint8_t)q; /* padding: the site itself */
+                int fill[64] = {0};
+                for (int g = 0; g < ext->n_groups; ++g) {
+                    int const ends[2] = {recs[g].i, recs[g].j};
+                    for (int side = 0; side < 2; ++side) {
+                        int const p = ends[side], d = fill[p]++;
+                        nb[p * D + d] = (uint8_t)ends[1 - side];
+                        cl[p * D + d] = cls_of[g];
+                    }
+                }
+                double *amp = (double *)(tab + amp_at);
+                for (int c = 0; c < n_cls; ++c) { amp[2 * c] = cv[c]; amp[2 * c + 1] = cz[c]; }
+                int const up = upload(&pl->d_pair_sites, tab, sizeof(uint32_t) * (size_t)words);
+                free(tab);
+                if (up != 0) return -1;
+                pp.sites = (uint32_t const *)pl->d_pair_sites;
+                pp.n_classes = n_cls;
+                pp.site_words = words;
+                pp.n_sites = L;
+                pp.degree = D;
+            }
+        }
     }
     pp.pairs = (lsk_pair const *)pl->d_pair_recs;
     pp.rank_low = (uint16_t const *)pl->d_rank_low;
@@ -2934,6 +2985,7 @@ void ls_amd_plan_destroy(ls_amd_plan *pl) {
     if (pl->d_chain_rec) lsk_free(pl->d_chain_rec);
     if (pl->d_pair_recs) lsk_free(pl->d_pair_recs);
     if (pl->d_pair_rows) lsk_free(pl->d_pair_rows);
+    if (pl->d_pair_sites) lsk_free(pl->d_pair_sites);
     if (pl->d_rank_low) lsk_free(pl->d_rank_low);
     if (pl->d_pair_binom) lsk_free(pl->d_pair_binom);
     if (pl->d_states32) lsk_free(pl->d_states32);
@@ -3228,7 +3280,7 @@ char const *ls_amd_plan_kernel_name(ls_amd_plan const *pl) {
     switch (pl->family) {
     case FAMILY_DIRECT_PUSH: return "direct-push";
     case FAMILY_DIRECT_PULL:
-        return pl->has_chain ? "direct-pull+staged" : pl->has_pairs ? (pl->pairs.rows ? "direct-pull+pairrows" : "direct-pull+pairs") : "direct-pull";
+        return pl->has_chain ? "direct-pull+staged" : pl->has_pairs ? (pl->pairs.sites ? "direct-pull+pairsites" : pl->pairs.rows ? "direct-pull+pairrows" : "direct-pull+pairs") : "direct-pull";
     case FAMILY_TILE_PULL: return pl->idx_mode ? (pl->slot_cache ? "tile-pull+indexed+cached" : (pl->d_vtab ? "tile-pull+values" : "tile-pull+indexed")) : "tile-pull";
     case FAMILY_REPL_DIRECT:
         return pl->has_chain ? "replicated-direct-pull+staged" : "replicated-direct-pull";

@@ -1141,6 +1141,124 @@ __global__ __launch_bounds__(kBlock) void k_pairs_row(lsk_pairplan pp, int hammi
         cx_store_nt(y + i, acc);
     }
 }
+// ---------------------------------------------------------------------------------------------
+// ... and walking the PARTICLES of the row instead of the pairs of the operator (k_pairs_site): a pair is active iff exactly one of
+// its sites is occupied, i.e. iff it is found from an occupied site p looking at an EMPTY neighbour q -- weight x degree candidates
+// per row instead of all pairs (6 x 6 square lattice at weight 6: 24 instead of 72; the kernel is bound by VALU issue, so that is
+// what counts).  The neighbours of a site are a table in LDS (lsk_pair_site, D slots per site); with c = particles below q and the
+// moving particle t at p:  q > p: it ends as particle c - 1, d = C(q, c) - C(p, t+1) - (A[c] - A[t+1]);
+//                           q < p: it ends as particle c,     d = C(q, c+1) - C(p, t+1) - (B[t] - B[c])      (A, B as above).
+// ---------------------------------------------------------------------------------------------
+template <typename SW, bool CPLX, int D, bool UNIFORM>
+__global__ __launch_bounds__(kBlock) void k_pairs_site(lsk_pairplan pp, int hamming_weight, uint64_t const *__restrict__ tilemap,
+                                                       int64_t slots_per_xcd, void const *__restrict__ x_v, void *__restrict__ y_v) {
+    typedef typename ChainX<CPLX>::type X;
+    constexpr int NBITS = 8 * (int)sizeof(SW);
+    constexpr int kc = LSK_PAIR_KC;
+    constexpr int DW = D / 4; // 32-bit words of neighbours per site
+    X const *__restrict__ x = (X const *)x_v;
+    X *__restrict__ y = (X *)y_v;
+    extern __shared__ uint4 s_dyn4[]; // the neighbour table (lsk.h), then the prefix arrays A, B: [hamming_weight + 1][kBlock] each
+    __shared__ uint32_t s_binom[NBITS * kc];
+    auto popc = [](SW v) { return sizeof(SW) == 4 ? __popc((uint32_t)v) : __popcll((uint64_t)v); };
+    auto ctz = [](SW v) { return sizeof(SW) == 4 ? __builtin_ctz((uint32_t)v) : __builtin_ctzll((uint64_t)v); };
+    uint32_t *const s_tab = reinterpret_cast<uint32_t *>(s_dyn4);
+    const int tab_words = (pp.site_words + 3) & ~3;
+    for (int k = threadIdx.x; k < NBITS * kc; k += kBlock) s_binom[k] = pp.binom[k];
+    for (int k = threadIdx.x; k < pp.site_words; k += kBlock) s_tab[k] = pp.sites[k];
+    __syncthreads();
+    uint32_t const *const s_nb = s_tab, *const s_cls = s_tab + pp.n_sites * DW;
+    double2 const *const s_amp = reinterpret_cast<double2 const *>(s_tab + ((2 * pp.n_sites * DW + 3) & ~3));
+    uint32_t *const sA = s_tab + tab_words + threadIdx.x;
+    uint32_t *const sB = sA + (hamming_weight + 1) * kBlock;
+    // one J for all bonds: scalar registers
+    double2 const *g_amp = reinterpret_cast<double2 const *>(pp.sites + ((2 * pp.n_sites * DW + 3) & ~3));
+    const double v0 = g_amp[0].x, vz0 = g_amp[0].y;
+    SW const *__restrict__ states = (SW const *)pp.states;
+    const int xcd = blockIdx.x & 7;
+    const int64_t blocks_per_xcd = gridDim.x >> 3;
+    tilemap += (int64_t)xcd * slots_per_xcd;
+    for (int64_t tl = blockIdx.x >> 3; tl < slots_per_xcd; tl += blocks_per_xcd) {
+        const uint64_t slot = tilemap[tl];
+        if ((uint64_t)threadIdx.x >= (slot >> 48)) continue; // (no block-wide barrier below: every lane owns its LDS column)
+        const int64_t i = (int64_t)(slot & 0xffffffffffffULL) + threadIdx.x;
+        const SW a = __builtin_nontemporal_load(states + i);
+        const uint32_t ig = (uint32_t)i;
+        {
+            uint32_t A = 0, B = 0;
+            SW s = a;
+            sA[0] = 0;
+            sB[0] = 0;
+            for (int u = 0; u < hamming_weight; ++u) {
+                const int p = ctz(s);
+                s &= s - (SW)1;
+                uint32_t const *c = s_binom + p * kc + u;
+                A += c[1] - c[0];
+                B += c[1] - c[2];
+                sA[(u + 1) * kBlock] = A;
+                sB[(u + 1) * kBlock] = B;
+            }
+        }
+        const X xr = x[i];
+        X acc = cx_zero<X>();
+        double dsub = 0.0; // sum of vz over the active pairs (UNIFORM: their number)
+        SW s = a;
+#pragma unroll 2
+        for (int t = 0; t < hamming_weight; ++t) {
+            const int p = ctz(s);
+            s &= s - (SW)1;
+            const uint32_t base = ig - s_binom[p * kc + t + 1]; // the rank without the term of the moving particle
+            const uint32_t At1 = sA[(t + 1) * kBlock], Bt = sB[t * kBlock];
+            uint32_t nbw[DW], clw[DW];
+#pragma unroll
+            for (int j = 0; j < DW; ++j) {
+                nbw[j] = s_nb[p * DW + j];
+                clw[j] = UNIFORM ? 0u : s_cls[p * DW + j];
+            }
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const int q = (int)((nbw[d >> 2] >> (8 * (d & 3))) & 255u);
+                const bool act = ((a >> q) & (SW)1) == 0; // the neighbour is empty (a padding slot holds p itself: occupied)
+                const bool up = q > p;
+                const int c = popc(a & (SW)((((SW)1) << q) - (SW)1)); // particles below q
+                const uint32_t cq = s_binom[q * kc + (up ? c : c + 1)];
+                const uint32_t pr = (up ? sA : sB)[c * kBlock];
+                const uint32_t passed = up ? pr - At1 : Bt - pr;
+                const uint32_t idx = act ? base + cq - passed : ig;
+                if (UNIFORM) {
+                    const double on = act ? 1.0 : 0.0;
+                    cx_fma(on, x[idx], acc);
+                    dsub += on;
+                } else {
+                    const double2 amp = s_amp[(clw[d >> 2] >> (8 * (d & 3))) & 255u];
+                    cx_fma(act ? amp.x : 0.0, x[idx], acc);
+                    dsub += act ? amp.y : 0.0;
+                }
+            }
+        }
+        if (UNIFORM) {
+            acc = cx_scale(v0, acc);
+            dsub *= vz0;
+        }
+        cx_fma(pp.dsum - 2.0 * dsub, xr, acc);
+        cx_store_nt(y + i, acc);
+    }
+}
+template <typename SW, bool CPLX, int D, bool UNIFORM>
+static int launch_pairs_site2(lsk_pairplan pp, int hamming_weight, lsk_tilemap tm, void const *x, void *y, void *stream) {
+    const size_t lds = sizeof(uint32_t) * (size_t)((pp.site_words + 3) & ~3) + 2 * (size_t)(hamming_weight + 1) * kBlock * sizeof(uint32_t);
+    const int64_t gb = tm.slots_per_xcd * 8;
+    const int cap = resident_grid(k_pairs_site<SW, CPLX, D, UNIFORM>, gb, lds);
+    const unsigned g = (unsigned)(gb < cap ? gb : cap);
+    hipLaunchKernelGGL((k_pairs_site<SW, CPLX, D, UNIFORM>), dim3(g), dim3(kBlock), lds, (hipStream_t)stream, pp, hamming_weight, tm.entries, tm.slots_per_xcd, x, y);
+    LSK_LAUNCH_CHECK();
+    return 0;
+}
+template <typename SW, bool CPLX, int D>
+static int launch_pairs_site(lsk_pairplan pp, int hamming_weight, lsk_tilemap tm, void const *x, void *y, void *stream) {
+    return pp.n_classes == 1 ? launch_pairs_site2<SW, CPLX, D, true>(pp, hamming_weight, tm, x, y, stream)
+                             : launch_pairs_site2<SW, CPLX, D, false>(pp, hamming_weight, tm, x, y, stream);
+}
 template <typename SW, bool CPLX>
 static int launch_pairs_row(lsk_pairplan pp, int hamming_weight, lsk_tilemap tm, void const *x, void *y, void *stream) {
     const size_t lds = 2 * (size_t)(hamming_weight + 1) * kBlock * sizeof(uint32_t);
@@ -1156,6 +1274,14 @@ extern "C" int lsk_pairs_tile_rows(int cplx) { return cplx ? 512 : 1024; }
 extern "C" int lsk_pairs(lsk_pairplan pp, int hamming_weight, int cplx, lsk_tilemap tm, int64_t n, void const *x, void *y, void *stream) {
     if (n == 0 || tm.slots_per_xcd == 0) return 0;
     if (pp.n_near + pp.n_str + pp.n_high > LSK_MAX_PAIRS || hamming_weight + 2 > LSK_PAIR_KC) { snprintf(g_err, sizeof(g_err), "lsk_pairs: plan out of range"); return -1; }
+    if (pp.sites) { // one row per lane, walking the particles (tiles of kBlock rows)
+        if (pp.n_sites < 1 || pp.n_sites > (pp.wide ? 64 : 32) || (pp.degree != 4 && pp.degree != 8) || pp.n_classes < 1 ||
+            pp.n_classes > LSK_PAIR_SITE_MAX_CLASSES) { snprintf(g_err, sizeof(g_err), "lsk_pairs: neighbour table out of range"); return -1; }
+#define LSK_SITE(SW, CPLX) (pp.degree == 4 ? launch_pairs_site<SW, CPLX, 4>(pp, hamming_weight, tm, x, y, stream) : launch_pairs_site<SW, CPLX, 8>(pp, hamming_weight, tm, x, y, stream))
+        if (pp.wide) return cplx ? LSK_SITE(uint64_t, true) : LSK_SITE(uint64_t, false);
+        return cplx ? LSK_SITE(uint32_t, true) : LSK_SITE(uint32_t, false);
+#undef LSK_SITE
+    }
     if (pp.rows) { // far from half filling: one row per lane (tiles of kBlock rows)
         if (pp.wide) return cplx ? launch_pairs_row<uint64_t, true>(pp, hamming_weight, tm, x, y, stream) : launch_pairs_row<uint64_t, false>(pp, hamming_weight, tm, x, y, stream);
         return cplx ? launch_pairs_row<uint32_t, true>(pp, hamming_weight, tm, x, y, stream) : launch_pairs_row<uint32_t, false>(pp, hamming_weight, tm, x, y, stream);

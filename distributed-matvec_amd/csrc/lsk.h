@@ -260,6 +260,14 @@ typedef struct lsk_pair_row {
     double v, vz;
     int i, j;         /* i < j */
 } lsk_pair_row;
+/* ... and as the one-row-per-lane variant that walks the PARTICLES of a row reads it (k_pairs_site): one table of 32-bit words,
+ *   [n_sites][degree / 4]  the neighbours of every site, one byte each (slots past the degree of a site hold the site itself:
+ *                          never active, it is occupied)
+ *   [n_sites][degree / 4]  the amplitude class of every slot, one byte each
+ *   [n_classes] x {double v, vz}   (starts on a 16-byte boundary)
+ * n_classes == 1 -- one J for all bonds -- keeps v and vz in scalar registers and never reads the class words. */
+#define LSK_PAIR_SITE_MAX_DEGREE 8
+#define LSK_PAIR_SITE_MAX_CLASSES 64
 typedef struct lsk_pairplan {
     int n_near, n_str, n_high;
     lsk_pair const *pairs;     /* device [n_near + n_str + n_high] */
@@ -269,6 +277,9 @@ typedef struct lsk_pairplan {
     int wide;                  /* 33..64 sites: 8-byte states (ranks stay 32-bit) */
     double dsum;               /* sum of vz over all pairs */
     lsk_pair_row const *rows;  /* device [n_near + n_str + n_high], or NULL: the one-row-per-lane variant (far from half filling) */
+    uint32_t const *sites;     /* device: the neighbour table above, or NULL: ... walking particles instead of pairs (weight x degree < pairs) */
+    int n_sites, degree;       /* degree: slots per site, 4 or 8 */
+    int n_classes, site_words; /* amplitude classes; 32-bit words of the whole table */
 } lsk_pairplan;
 int lsk_pairs_tile_rows(int cplx);
 int lsk_pairs(lsk_pairplan pp, int hamming_weight, int cplx, lsk_tilemap tm, int64_t n, void const *x, void *y, void *stream);

@@ -1010,6 +1010,7 @@ ROW_KERNEL_VARIANTS = {
     "pairs-kernel-contiguous-tiles": {"LS_AMD_ROW_KERNEL": "pairs", "LS_AMD_TILE_CHUNK": "0"},
     # its one-row-per-lane variant (round 6: the default far from half filling), here on everything
     "pairrows-kernel": {"LS_AMD_ROW_KERNEL": "pairrows"},
+    "pairsites-kernel": {"LS_AMD_ROW_KERNEL": "pairsites"},
 }
 
 
@@ -1047,8 +1048,8 @@ def test_row_kernel_variants(torch, monkeypatch, variant):
             assert pl.kernel == ("direct-pull+pairs" if kind == "j1j2" else "direct-pull+staged"), (kind, pl.kernel)
         if variant.startswith("pairs-kernel"):
             assert pl.kernel == "direct-pull+pairs", (kind, pl.kernel)
-        if variant == "pairrows-kernel":
-            assert pl.kernel == "direct-pull+pairrows", (kind, pl.kernel)
+        if variant in ("pairrows-kernel", "pairsites-kernel"):
+            assert pl.kernel == "direct-pull+" + variant.split("-")[0], (kind, pl.kernel)
         # c128 vectors: the complex instantiation of the same kernel family
         xc = x + 1j * (rs.rand(len(want_reps)) - 0.5)
         gotc, plc = run_matvec(torch, D, h, reps, masks, xc, 1, "pull")
@@ -1208,11 +1209,31 @@ PAIR_KERNEL_CASES = {
     # past half filling, and the largest weight the 20-column binomial table takes
     "square-4x4-w11": lambda: _lattice_config(16, 11, _square_bonds(4, 4)),
     "ring-20-w18-long": lambda: _lattice_config(20, 18, [(i, (i + 1) % 20) for i in range(20)], extra=([(i, (i + 7) % 20) for i in range(20)], 0.5, 0.25)),
+    "triangular-5x4-w4": lambda: _lattice_config(20, 4, _square_bonds(5, 4) + [(y * 5 + x, ((y + 1) % 4) * 5 + (x + 1) % 5) for y in range(4) for x in range(5)]),  # degree 6
+    "j1j2j3-40-w5": lambda: _lattice_config(40, 5, [(i, (i + 1) % 40) for i in range(40)], extra=([(i, (i + d) % 40) for d in (2, 19) for i in range(40)], 0.5, 0.25)),  # degree 6, two amplitude classes, 33..64 sites
     "one-particle-24": lambda: _lattice_config(24, 1, [(i, (i + 1) % 24) for i in range(24)] + [(0, 12), (3, 20)]),
 }
 
 
-@pytest.mark.parametrize("kernel", ["pairs", "pairrows", "auto"])
+def _pairs_plan_label(cfg, kernel):
+    """the plan's rule (host.c, setup_pairs): the staged kernel near half filling; far from it one row per lane -- walking the
+    particles of the row when weight x degree is small against the number of pairs and the degree fits the neighbour table,
+    walking the pairs otherwise"""
+    L, w = cfg["basis"]["number_spins"], cfg["basis"]["hamming_weight"]
+    pairs = set()
+    for t in cfg["hamiltonian"]["terms"]:
+        pairs |= {tuple(sorted(b)) for b in t["sites"]}
+    deg = [sum(1 for b in pairs if q in b) for q in range(L)]
+    D = 4 if max(deg) <= 4 else 8
+    far = 11 * w < 4 * L or 11 * (L - w) < 4 * L
+    if kernel == "pairs" or (kernel == "auto" and not far):
+        return "direct-pull+pairs"
+    if kernel != "pairrows" and max(deg) <= 8 and (kernel == "pairsites" or 2 * w * D <= 3 * len(pairs)):
+        return "direct-pull+pairsites"
+    return "direct-pull+pairrows"
+
+
+@pytest.mark.parametrize("kernel", ["pairs", "pairrows", "pairsites", "auto"])
 @pytest.mark.parametrize("case", sorted(PAIR_KERNEL_CASES))
 def test_pairs_kernel_lattices(torch, monkeypatch, case, kernel):
     """k_pairs_t (staged row kernel for arbitrary exchange pairs -- what every non-ring lattice runs on one GPU) against the
@@ -1220,7 +1241,8 @@ def test_pairs_kernel_lattices(torch, monkeypatch, case, kernel):
     graph (near / straddling / high pairs, long spans), tiny blocks (waves of many segments), 33..64 sites (8-byte states);
     f64 and c128.  The same plan has a one-row-per-lane variant (k_pairs_row: O(1) rank shifts from per-row prefix arrays in
     LDS) that the plan takes by itself far from half filling: every case runs through the staged kernel
-    (LS_AMD_ROW_KERNEL=pairs), through the row variant (=pairrows) and through whichever the plan picks."""
+    (LS_AMD_ROW_KERNEL=pairs), through the row variants (=pairrows: a loop over the pairs; =pairsites: over the particles of the
+    row and their neighbours) and through whichever the plan picks."""
     from oracle import c_oracle as CO
     from oracle import model as M
 
@@ -1240,12 +1262,8 @@ def test_pairs_kernel_lattices(torch, monkeypatch, case, kernel):
     got, pl = run_matvec(torch, D, h, reps, masks, x, 1, "pull")
     if case == "xy-only-16":
         assert pl.kernel == "direct-pull"  # no diagonal terms: y is accumulated into (DMV:1062-1063) -- the generic kernel's job
-    elif kernel == "auto":
-        L, w = cfg["basis"]["number_spins"], cfg["basis"]["hamming_weight"]
-        far = 11 * w < 4 * L or 11 * (L - w) < 4 * L
-        assert pl.kernel == ("direct-pull+pairrows" if far else "direct-pull+pairs"), (pl.kernel, L, w)
     else:
-        assert pl.kernel == "direct-pull+" + kernel, pl.kernel
+        assert pl.kernel == _pairs_plan_label(cfg, kernel), (pl.kernel, kernel)
     assert np.abs(got - want).max() <= 1e-12 * max(1.0, np.abs(want).max()), (case, np.abs(got - want).max())
     xc = x + 1j * (rs.rand(len(want_reps)) - 0.5)
     gotc, plc = run_matvec(torch, D, h, reps, masks, xc, 1, "pull")
