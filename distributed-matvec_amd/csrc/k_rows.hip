@@ -1203,7 +1203,10 @@ __global__ __launch_bounds__(kBlock) void k_pairs_site(lsk_pairplan pp, int hamm
         X acc = cx_zero<X>();
         double dsub = 0.0; // sum of vz over the active pairs (UNIFORM: their number)
         SW s = a;
-#pragma unroll 2
+        // (two particles per trip only with one J for all bonds: the amplitude reads of the general form push the kernel past 80 scalar
+        // registers otherwise, where the occupancy API over-reports the resident blocks of a persistent grid -- lsk_dev.hpp)
+        constexpr int kParticlesPerTrip = UNIFORM ? 2 : 1;
+#pragma unroll kParticlesPerTrip
         for (int t = 0; t < hamming_weight; ++t) {
             const int p = ctz(s);
             s &= s - (SW)1;

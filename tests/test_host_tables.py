@@ -374,6 +374,10 @@ def test_hot_kernel_register_budget():
     for name, v in stats.items():  # the generic row kernels run as persistent grids sized by the occupancy API: keep them where it is right
         if name.startswith("_Z8k_directIjLb0ELi1E") or name.startswith("_Z8k_directIjLb1ELi1E"):
             assert v["sgpr"] <= 80 and v["occ"] == 8, (name, v)
+        # ... and so do the one-row-per-lane exchange-pair kernels of round 6 (k_pairs_row, k_pairs_site): no spills, <= 80 SGPRs
+        if name.startswith(("_Z11k_pairs_rowI", "_Z12k_pairs_siteI")):
+            assert v["sgpr"] <= 80 and v["scratch"] == 0, (name, v)
+    assert sum(1 for k in stats if k.startswith("_Z11k_pairs_rowI")) == 4 and sum(1 for k in stats if k.startswith("_Z12k_pairs_siteI")) == 16
     chain = {k: v for k, v in stats.items() if k.startswith("_Z9k_chain_tI")}
     # six instantiations: (u32, u32) f64 on fused records [headline] and c128; (u64, u32) and (u64, u64) f64 / c128
     assert len(chain) == 6, sorted(chain)
