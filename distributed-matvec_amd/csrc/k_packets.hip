@@ -794,6 +794,137 @@ __global__ __launch_bounds__(kBlock) void k_tile_st(int n_groups, lsk_group cons
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same producer WITHOUT the ring (k_tile_sd; round 6, the default -- LS_AMD_STREAM_PRODUCER=ring keeps k_tile_st): a wave takes
+// 64 rows and walks the groups with all of them; the packets of group g belong to the 2 P classes (destination, pattern) of that group only, so their ranks inside
+// the class cost log2(2 P) ballots instead of log2(2 P n_groups), nothing is staged in LDS but the cursors, and the lanes that write
+// one class in one step are neighbours in the stream (the next 64 rows append to the same lines).  Same packets, same order inside
+// every stream, same ttab -- the count pass and the consumers do not know which producer ran.  Lanes whose row is aligned on the
+// pair idle for that step: at half filling half of them.
+// ---------------------------------------------------------------------------------------------
+constexpr int kSdChunks = 4; // 64-row chunks a wave holds in registers while it walks the groups
+template <bool CPLX, bool REAL, bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_tile_sd(int n_groups, lsk_group const *__restrict__ groups,
+                                                    lsk_term const *__restrict__ off, lsk_gdir gd,
+                                                    uint64_t const *__restrict__ g_binom, Owner owner, int S, int sbits,
+                                                    int tile_rows, int64_t row0, int64_t row1, int64_t n_tiles,
+                                                    uint64_t const *__restrict__ reps, double const *__restrict__ x,
+                                                    uint32_t *__restrict__ ttab, lsk_round_layout const *__restrict__ layout,
+                                                    char *send, int *err, int xcd_chunk) {
+    constexpr int kWaves = kBlock / 64;
+    extern __shared__ uint64_t s_dyn[]; // [binomials of the directory][key offsets P][value offsets P][cursors: waves x classes u32]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int P = (int)owner.P, C = P * S;
+    const int ndb = COUNT ? 0 : gd.sites * (gd.weight + 1);
+    uint64_t *s_db = s_dyn;
+    int64_t *s_koff = reinterpret_cast<int64_t *>(s_dyn + ndb);
+    int64_t *s_voff = s_koff + (COUNT ? 0 : P);
+    volatile uint32_t *s_cur = reinterpret_cast<uint32_t *>(s_voff + (COUNT ? 0 : P)) + wave * C; // (a wave's LDS accesses complete in order)
+    if (!COUNT) {
+        gdir_load(gd, g_binom, s_db);
+        for (int d = tid; d < P; d += kBlock) { s_koff[d] = layout->beta_off[d]; s_voff[d] = layout->val_off[d]; }
+        __syncthreads();
+    }
+    const unsigned long long below = (1ULL << lane) - 1;
+    const bool narrow_ranks = !COUNT && gd.n_ranks <= 0xffffffffLL;
+    const int64_t n_work = (n_tiles + kWaves - 1) / kWaves;
+    for (int64_t wb = blockIdx.x; wb < n_work; wb += gridDim.x) {
+        const int64_t tile = pull_tile_of_block(wb, n_work, gridDim.x >= n_work ? xcd_chunk : 0) * kWaves + wave;
+        if (tile >= n_tiles) continue; // wave-uniform: nothing below synchronises the block
+        const int64_t t0 = row0 + tile * tile_rows;
+        const int64_t t1 = t0 + tile_rows < row1 ? t0 + tile_rows : row1;
+        uint32_t *trow = ttab + (size_t)tile * C;
+        for (int c = lane; c < C; c += 64) s_cur[c] = COUNT ? 0u : trow[c];
+        // GROUPS OUTSIDE, rows inside: while a group is walked only its 2 P classes are being appended to, by this wave and by the
+        // waves of the neighbouring tiles -- the open lines of an XCD fit its L2 and leave it complete (with the rows outside every
+        // line of all P S classes stays half-written for the whole tile: measured 2.24 GB written per launch for 0.87 GB of packets)
+        for (int64_t q0 = t0; q0 < t1; q0 += 64 * kSdChunks) {
+            uint64_t a[kSdChunks], ga[kSdChunks];
+            double xr[kSdChunks], xi[kSdChunks];
+            bool valid[kSdChunks];
+#pragma unroll
+            for (int u = 0; u < kSdChunks; ++u) {
+                const int64_t i = q0 + 64 * u + lane;
+                valid[u] = i < t1;
+                a[u] = 0;
+                xr[u] = 0.0;
+                xi[u] = 0.0;
+                if (valid[u]) {
+                    a[u] = reps[i];
+                    if (COUNT) xr[u] = 1.0;
+                    else if (CPLX) { xr[u] = x[2 * i]; xi[u] = x[2 * i + 1]; }
+                    else xr[u] = x[i];
+                }
+                ga[u] = 0; // colex rank of alpha
+                if (narrow_ranks && valid[u]) {
+                    const int kc = gd.weight + 1;
+                    uint64_t t = a[u];
+                    int k = 1;
+                    while (t && k < kc) { ga[u] += s_db[(__ffsll((unsigned long long)t) - 1) * kc + k]; ++k; t &= t - 1; }
+                }
+            }
+            for (int g = 0; g < n_groups; ++g) {
+                lsk_group const G = groups[g];
+#pragma unroll
+                for (int u = 0; u < kSdChunks; ++u) {
+                    // (every group is an exchange pair: a packet exists iff alpha is anti-aligned on it, whatever its amplitude)
+                    const bool act = valid[u] && __popcll(a[u] & G.x) == 1;
+                    unsigned long long same = __ballot(act);
+                    if (same == 0) continue;
+                    const uint64_t beta = a[u] ^ G.x;
+                    const int up = (int)((a[u] >> (__ffsll((unsigned long long)G.x) - 1)) & 1ULL); // the lower site's bit moves up
+                    const int dest = owner_of(beta, owner);
+                    const uint32_t sc = (uint32_t)dest * 2u + (uint32_t)up;
+                    for (int b = 0; b < sbits; ++b) {
+                        const bool bit = (sc >> b) & 1u;
+                        const unsigned long long bb = __ballot(act && bit);
+                        same &= bit ? bb : ~bb;
+                    }
+                    const uint32_t rank = (uint32_t)__popcll(same & below), n_same = (uint32_t)__popcll(same);
+                    const uint32_t cls = (uint32_t)dest * (uint32_t)S + 2u * (uint32_t)g + (uint32_t)up;
+                    if (act) {
+                        const uint32_t base = s_cur[cls];
+                        if (rank + 1 == n_same) s_cur[cls] = base + n_same;
+                        if (!COUNT) {
+                            double cr, ci;
+                            group_coeff<REAL>(G, off, a[u], cr, ci);
+                            double vr = cr * xr[u] - (CPLX ? ci * xi[u] : 0.0), vi = CPLX ? cr * xi[u] + ci * xr[u] : 0.0;
+                            int64_t idx;
+                            if (narrow_ranks && G.adj >= 0) {
+                                // an exchange on ADJACENT sites moves one particle by one place: rank(beta) = rank(alpha) +- C(lo, k)
+                                const uint64_t c = s_db[G.adj * (gd.weight + 1) + __popcll(a[u] & ((1ULL << G.adj) - 1))];
+                                const uint32_t rk = (uint32_t)(up ? ga[u] + c : ga[u] - c);
+                                idx = gd.entries ? gdir_index_of_rank(gd, (uint64_t)rk, dest) : (int64_t)rk;
+                            } else if (gd.entries) idx = gdir_index(gd, beta, dest, s_db);
+                            else { // GLOBAL-RANK keys, a pair that is not adjacent (e.g. the bond that closes a ring): the full rank sum
+                                idx = -1;
+                                if (__popcll(beta) == gd.weight && (gd.sites >= 64 || (beta >> gd.sites) == 0)) {
+                                    const int kc = gd.weight + 1;
+                                    uint64_t t = beta, gsum = 0;
+                                    int k = 1;
+                                    while (t) { gsum += s_db[(__ffsll((unsigned long long)t) - 1) * kc + k]; ++k; t &= t - 1; }
+                                    if ((int64_t)gsum < gd.n_ranks) idx = (int64_t)gsum;
+                                }
+                            }
+                            if (idx < 0) { // not a basis state (DMV:115-118): the flag halts the matvec; the reserved slot is still filled
+                                atomicExch(err, 1);
+                                idx = 0; vr = 0.0; vi = 0.0;
+                            }
+                            const size_t pos = (size_t)base + rank;
+                            reinterpret_cast<uint32_t *>(send + s_koff[dest])[pos] = (uint32_t)idx;
+                            double *pv = reinterpret_cast<double *>(send + s_voff[dest]);
+                            if (CPLX) { pv[2 * pos] = vr; pv[2 * pos + 1] = vi; } else pv[pos] = vr;
+                        }
+                    }
+                }
+            }
+        }
+        if (COUNT) for (int c = lane; c < C; c += 64) trow[c] = s_cur[c];
+    }
+}
+
 extern "C" int lsk_tile_st_max_classes(void) { return kStMaxClasses; }
 // rows [row0, row1) of one partition, tile t = rows [row0 + t tile_rows, ...).  count_only: d_ttab[tile][P * S] <- packets of every
 // (tile, class = destination * S + stream), stream = 2 * group + (bit of alpha at the pair's lower site); otherwise d_ttab holds
@@ -820,6 +951,28 @@ extern "C" int lsk_tile_st(lsk_operator op, lsk_gdir gd, uint64_t const *d_binom
                        (count_only ? 0 : sizeof(uint64_t) * ((size_t)gd.sites * (size_t)(gd.weight + 1) + 2 * (size_t)P));
 #define LSK_ST_ARGS op.n_groups, op.groups, op.off, gd, d_binom, ow, S, cbits, tile_rows, row0, row1, n_tiles, reps, (double const *)x, \
         d_ttab, d_layout, (char *)d_send, d_err, 64
+    // LS_AMD_STREAM_PRODUCER=ring: the round-5 producer (wave rings).  Default since round 6: k_tile_sd.  (The count pass and the
+    // producer agree on nothing but the packet order, which is the same.)
+    char const *prod_env = getenv("LS_AMD_STREAM_PRODUCER");
+    const int direct = (prod_env && strcmp(prod_env, "ring") == 0) ? 0 : 1;
+    if (direct) {
+        int sbits = 0;
+        while ((1 << sbits) < 2 * P) ++sbits;
+        const size_t dyn_d = dyn; // the same image: binomials, offsets, cursors
+#define LSK_SD_ARGS op.n_groups, op.groups, op.off, gd, d_binom, ow, S, sbits, tile_rows, row0, row1, n_tiles, reps, (double const *)x, \
+        d_ttab, d_layout, (char *)d_send, d_err, 64
+#define LSK_SD_ONE(CPLX, REAL)                                                                                                    \
+    do {                                                                                                                          \
+        if (count_only) { g.x = tile_grid(k_tile_sd<CPLX, REAL, true>, n_work); hipLaunchKernelGGL((k_tile_sd<CPLX, REAL, true>), g, b, dyn_d, s, LSK_SD_ARGS); } \
+        else { g.x = tile_grid(k_tile_sd<CPLX, REAL, false>, n_work); hipLaunchKernelGGL((k_tile_sd<CPLX, REAL, false>), g, b, dyn_d, s, LSK_SD_ARGS); } \
+    } while (0)
+        if (cplx) { if (op.is_real) LSK_SD_ONE(true, true); else LSK_SD_ONE(true, false); }
+        else LSK_SD_ONE(false, true);
+#undef LSK_SD_ONE
+#undef LSK_SD_ARGS
+        LSK_LAUNCH_CHECK();
+        return 0;
+    }
 #define LSK_ST_ONE(CPLX, REAL)                                                                                                    \
     do {                                                                                                                          \
         if (count_only) { g.x = tile_grid(k_tile_st<CPLX, REAL, true>, n_work); hipLaunchKernelGGL((k_tile_st<CPLX, REAL, true>), g, b, dyn, s, LSK_ST_ARGS); } \
@@ -837,7 +990,8 @@ extern "C" int lsk_tile_st(lsk_operator op, lsk_gdir gd, uint64_t const *d_binom
 // segments per destination, S streams each: soff[s] .. soff[s + 1] = packets of stream s inside the segment, keys ascending.
 constexpr int kWinRows = 2048;    // doubles of one window's accumulator (c128: 1024 rows)
 constexpr int kWinStreams = 512;  // run bounds kept in LDS per pass over the streams
-constexpr int kWinRuns = 4;       // runs a wave has in flight
+constexpr int kWinRuns = 4;       // runs a wave has in flight (8: the registers cost more occupancy than the loads win -- c128 5.8 -> 7.5 ms)
+constexpr int kWinDir = 512;      // entries of the destination's rank directory a window keeps in LDS (global-rank keys)
 __device__ __forceinline__ uint32_t lower_bound_u32(uint32_t const *__restrict__ k, uint32_t lo, uint32_t hi, uint32_t v) {
     while (lo < hi) {
         const uint32_t mid = lo + ((hi - lo) >> 1);
@@ -861,6 +1015,10 @@ __global__ __launch_bounds__(kBlock) void k_window(lsk_wdests dests, lsk_wsrc co
     __shared__ uint32_t const *s_keys[LSK_MAX_SEGS];
     __shared__ double const *s_vals[LSK_MAX_SEGS];
     __shared__ uint32_t s_gb[2]; // global-rank keys: the ranks of the window's first row and of the row behind its last
+    // ... and the slice of the destination's rank directory those ranks span (round 6): W rows of a hash partition span ~ P W ranks
+    // = P W / 64 entries, read once, coalesced -- the rank -> row translation of a packet is an LDS read instead of a dependent
+    // 16-byte load behind the key's.  A window that spans more (P > 15) keeps the global loads.
+    __shared__ ulonglong2 s_dir[kWinDir];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int d = 0;
     while (d + 1 < dests.n && (int64_t)blockIdx.x >= dests.first_block[d + 1]) ++d; // block-uniform
@@ -892,6 +1050,10 @@ __global__ __launch_bounds__(kBlock) void k_window(lsk_wdests dests, lsk_wsrc co
             __syncthreads();
         }
         const uint32_t k0 = gkeys ? s_gb[0] : (uint32_t)w0, k1 = gkeys ? s_gb[1] : (uint32_t)w1;
+        const uint32_t e0 = k0 >> 6, ne = gkeys ? (uint32_t)(((uint64_t)k1 + 63) >> 6) - e0 : 0u;
+        const bool ldir = gkeys && ne <= (uint32_t)kWinDir;
+        if (ldir) // (visible to everybody after the barrier behind the run searches)
+            for (uint32_t j = tid; j < ne; j += kBlock) s_dir[j] = reinterpret_cast<ulonglong2 const *>(dir)[e0 + j];
         const bool carry = win > 0 && T <= kWinStreams; // the end of the previous window's run is the start of this one's
         for (int t0 = 0; t0 < T; t0 += kWinStreams) {
             const int tn = T - t0 < kWinStreams ? T - t0 : kWinStreams;
@@ -938,8 +1100,12 @@ __global__ __launch_bounds__(kBlock) void k_window(lsk_wdests dests, lsk_wsrc co
                         ulonglong2 en[kWinRuns]; // neighbouring lanes read the same or the next entry)
 #pragma unroll
                         for (int u = 0; u < kWinRuns; ++u)
-                            en[u] = (it < len[u] && (int64_t)key[u] < dests.n_ranks) // (a key that is no rank at all -- a misplaced segment -- reads nothing)
-                                        ? *reinterpret_cast<ulonglong2 const *>(dir + (key[u] >> 6)) : make_ulonglong2(0, 0);
+                            if (ldir) { // (a key outside the window's ranks -- a misplaced segment -- reads nothing and raises the flag below)
+                                const uint32_t j = (key[u] >> 6) - e0;
+                                en[u] = (it < len[u] && j < ne) ? s_dir[j] : make_ulonglong2(0, 0);
+                            } else
+                                en[u] = (it < len[u] && (int64_t)key[u] < dests.n_ranks) // (a key that is no rank at all reads nothing)
+                                            ? *reinterpret_cast<ulonglong2 const *>(dir + (key[u] >> 6)) : make_ulonglong2(0, 0);
 #pragma unroll
                         for (int u = 0; u < kWinRuns; ++u) {
                             if (it >= len[u]) continue;

@@ -1571,8 +1571,10 @@ def test_sorted_packet_streams(torch, monkeypatch, case):
     got, nnz = {}, set()
     from distributed_matvec_amd import _lib
 
-    for label, env in (("streams", {}), ("streams-wpb2", {}), ("streams-index-keys", {"LS_AMD_STREAM_KEYS": "index"}), ("atomics", {"LS_AMD_PACKET_STREAMS": "0"})):
-        for k in ("LS_AMD_PACKET_STREAMS", "LS_AMD_PACKET_INDEX", "LS_AMD_STREAM_KEYS"):
+    for label, env in (("streams", {}), ("streams-wpb2", {}), ("streams-index-keys", {"LS_AMD_STREAM_KEYS": "index"}), ("atomics", {"LS_AMD_PACKET_STREAMS": "0"}),
+                       ("streams-direct-producer", {"LS_AMD_STREAM_PRODUCER": "direct"}), ("streams-ring-producer", {"LS_AMD_STREAM_PRODUCER": "ring"}),
+                       ("streams-direct-producer-index-keys", {"LS_AMD_STREAM_PRODUCER": "direct", "LS_AMD_STREAM_KEYS": "index"})):
+        for k in ("LS_AMD_PACKET_STREAMS", "LS_AMD_PACKET_INDEX", "LS_AMD_STREAM_KEYS", "LS_AMD_STREAM_PRODUCER"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
