@@ -596,8 +596,8 @@ def block_to_hashed(block, masks, group=None):
     return part
 
 
-def _broadcast_int(value, group=None, device=None):
-    """rank 0's integer on every rank (None travels as -1)"""
+def _broadcast_int(value, group=None, device=None, signed=False):
+    """rank 0's integer on every rank (None travels as -1; signed: negative values are returned as they are)"""
     import torch
     import torch.distributed as dist
 
@@ -606,7 +606,7 @@ def _broadcast_int(value, group=None, device=None):
     t = torch.tensor([-1 if value is None else int(value)], dtype=torch.int64, device=device)
     dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
     v = int(t.item())
-    return None if v < 0 else v
+    return v if signed else (None if v < 0 else v)
 
 
 def write_block_dataset(path: str, name: str, shape, dtype, rows, group=None):
@@ -628,9 +628,17 @@ def write_block_dataset(path: str, name: str, shape, dtype, rows, group=None):
     lo, hi = hdf5.block_range(shape[-1], world, rank)
     address = None
     dist.barrier(group)  # nobody still holds the file open (HDF5 locks it: a reader elsewhere makes rank 0's H5Fopen(RDWR) fail)
+    failure = None
     if rank == 0:
-        address = hdf5.create_dataset(path, name, shape, dtype, allocate=os.environ.get("LS_AMD_HDF5_RAW", "1") != "0")
-    address = _broadcast_int(address, group)  # also the barrier the reference needs before the first H5Dopen (MyHDF5.chpl:219-221)
+        try:
+            address = hdf5.create_dataset(path, name, shape, dtype, allocate=os.environ.get("LS_AMD_HDF5_RAW", "1") != "0")
+        except Exception as e:  # noqa: BLE001 -- the peers wait in the broadcast below: they must hear about it
+            failure = e
+    # (also the barrier the reference needs before the first H5Dopen, MyHDF5.chpl:219-221)
+    code = _broadcast_int(-2 if failure is not None else (-1 if address is None else address), group, signed=True)
+    if code == -2:
+        raise OSError(f"rank 0 could not create dataset '{name}' of '{path}'") from failure
+    address = None if code < 0 else code
     lead = shape[:-1]
     for row, blk in enumerate(rows):
         blk = np.ascontiguousarray(blk, dtype=dtype)

@@ -381,6 +381,10 @@ def _worker_layouts(rank, world, port, name, out_dir):
         with pytest.raises(ValueError):  # a block of the wrong length is refused before anything is written
             write_block_dataset(path, "/basis/wrong", (n,), np.uint64, [np.zeros(hi - lo + 1, dtype=np.uint64)])
         dist.barrier()
+        # rank 0 cannot create the dataset (no such directory): EVERY rank raises, nobody is left waiting in the broadcast
+        with pytest.raises(OSError):
+            write_block_dataset(os.path.join(out_dir, "no-such-directory", "v.h5"), "/basis/representatives", (n,), np.uint64, [reps[lo:hi]])
+        dist.barrier()
         # ... and the one-H5Dwrite-at-a-time fallback (a library that gives no storage address) writes the same file
         os.environ["LS_AMD_HDF5_RAW"] = "0"
         try:
