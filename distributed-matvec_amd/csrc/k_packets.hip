@@ -1006,9 +1006,10 @@ __device__ __forceinline__ uint32_t gallop_u32(uint32_t const *__restrict__ k, u
     const uint32_t hi = (uint64_t)lo + step < (uint64_t)end ? lo + step : end;
     return lower_bound_u32(k, lo, hi, v);
 }
-template <bool CPLX>
-__global__ __launch_bounds__(kBlock) void k_window(lsk_wdests dests, lsk_wsrc const *__restrict__ srcs, int n_src, int S, int wpb) {
+template <bool CPLX, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_window(lsk_wdests dests, lsk_wsrc const *__restrict__ srcs, int n_src, int S, int wpb) {
     constexpr int W = CPLX ? kWinRows / 2 : kWinRows;
+    constexpr int WAVES = THREADS / 64;
     __shared__ double s_acc[kWinRows];
     __shared__ uint32_t s_lo[kWinStreams];
     __shared__ uint16_t s_len[kWinStreams]; // (the keys of a stream are distinct: a window holds <= W of them)
@@ -1018,7 +1019,7 @@ __global__ __launch_bounds__(kBlock) void k_window(lsk_wdests dests, lsk_wsrc co
     // ... and the slice of the destination's rank directory those ranks span (round 6): W rows of a hash partition span ~ P W ranks
     // = P W / 64 entries, read once, coalesced -- the rank -> row translation of a packet is an LDS read instead of a dependent
     // 16-byte load behind the key's.  A window that spans more (P > 15) keeps the global loads.
-    __shared__ ulonglong2 s_dir[kWinDir];
+    __shared__ uint2 s_dir[2 * kWinDir]; // as (bits, prefix) of 32 ranks each: the look-up is three 32-bit instructions
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int d = 0;
     while (d + 1 < dests.n && (int64_t)blockIdx.x >= dests.first_block[d + 1]) ++d; // block-uniform
@@ -1029,12 +1030,12 @@ __global__ __launch_bounds__(kBlock) void k_window(lsk_wdests dests, lsk_wsrc co
     const int64_t wb = (int64_t)blockIdx.x - dests.first_block[d];
     const int T = n_src * S;
     lsk_wsrc const *__restrict__ segs = srcs + (size_t)d * n_src;
-    for (int q = tid; q < n_src; q += kBlock) { s_keys[q] = segs[q].keys; s_vals[q] = segs[q].vals; }
+    for (int q = tid; q < n_src; q += THREADS) { s_keys[q] = segs[q].keys; s_vals[q] = segs[q].vals; }
     for (int win = 0; win < wpb; ++win) {
         const int64_t w0 = (wb * wpb + win) * W;
         if (w0 >= n) break;
         const int64_t w1 = w0 + W < n ? w0 + W : n;
-        for (int i = tid; i < kWinRows; i += kBlock) s_acc[i] = 0.0;
+        for (int i = tid; i < kWinRows; i += THREADS) s_acc[i] = 0.0;
         if (gkeys) { // the window in KEY space: [rank of row w0, rank of row w1) -- rows ascend, so do their ranks
             if (tid < 2) {
                 const int64_t row = tid == 0 ? w0 : w1;
@@ -1053,11 +1054,16 @@ __global__ __launch_bounds__(kBlock) void k_window(lsk_wdests dests, lsk_wsrc co
         const uint32_t e0 = k0 >> 6, ne = gkeys ? (uint32_t)(((uint64_t)k1 + 63) >> 6) - e0 : 0u;
         const bool ldir = gkeys && ne <= (uint32_t)kWinDir;
         if (ldir) // (visible to everybody after the barrier behind the run searches)
-            for (uint32_t j = tid; j < ne; j += kBlock) s_dir[j] = reinterpret_cast<ulonglong2 const *>(dir)[e0 + j];
+            for (uint32_t j = tid; j < ne; j += THREADS) {
+                const lsk_rankdir en = dir[e0 + j];
+                const uint32_t lo32 = (uint32_t)en.bits;
+                s_dir[2 * j] = make_uint2(lo32, en.prefix);
+                s_dir[2 * j + 1] = make_uint2((uint32_t)(en.bits >> 32), en.prefix + (uint32_t)__popc(lo32));
+            }
         const bool carry = win > 0 && T <= kWinStreams; // the end of the previous window's run is the start of this one's
         for (int t0 = 0; t0 < T; t0 += kWinStreams) {
             const int tn = T - t0 < kWinStreams ? T - t0 : kWinStreams;
-            for (int t = tid; t < tn; t += kBlock) {
+            for (int t = tid; t < tn; t += THREADS) {
                 const int q = (t0 + t) / S, s = (t0 + t) - q * S;
                 uint32_t const *__restrict__ keys = segs[q].keys;
                 uint32_t const *__restrict__ soff = segs[q].soff;
@@ -1069,14 +1075,14 @@ __global__ __launch_bounds__(kBlock) void k_window(lsk_wdests dests, lsk_wsrc co
                 s_len[t] = (uint16_t)(hi - lo);
             }
             __syncthreads();
-            // a wave takes the runs t = wave, wave + 4, ..., kWinRuns at a time: all their loads are issued before the first add
-            for (int t = wave; t < tn; t += 4 * kWinRuns) {
+            // a wave takes the runs t = wave, wave + WAVES, ..., kWinRuns at a time: all their loads are issued before the first add
+            for (int t = wave; t < tn; t += WAVES * kWinRuns) {
                 uint32_t const *kp[kWinRuns];
                 double const *vp[kWinRuns];
                 uint32_t len[kWinRuns], longest = 0;
 #pragma unroll
                 for (int u = 0; u < kWinRuns; ++u) {
-                    const int tu = t + 4 * u;
+                    const int tu = t + WAVES * u;
                     const bool has = tu < tn;
                     const int q = has ? (t0 + tu) / S : 0;
                     const uint32_t lo = has ? s_lo[tu] : 0u;
@@ -1096,16 +1102,22 @@ __global__ __launch_bounds__(kBlock) void k_window(lsk_wdests dests, lsk_wsrc co
                             if (CPLX) { vr[u] = vp[u][2 * (size_t)it]; vi[u] = vp[u][2 * (size_t)it + 1]; } else vr[u] = vp[u][it];
                         }
                     }
-                    if (gkeys) { // rank -> row of y[d]: ONE 16-byte entry of the destination's own directory per key (ascending keys:
-                        ulonglong2 en[kWinRuns]; // neighbouring lanes read the same or the next entry)
+                    if (gkeys && ldir) { // rank -> row of y[d] out of the window's slice of the directory
+#pragma unroll
+                        for (int u = 0; u < kWinRuns; ++u) {
+                            if (it >= len[u]) continue;
+                            const uint32_t j = (key[u] >> 5) - 2 * e0; // (a key outside the window's ranks -- a misplaced segment -- raises the flag)
+                            const uint2 en = j < 2 * ne ? s_dir[j] : make_uint2(0u, 0u);
+                            const uint32_t b = key[u] & 31u;
+                            if (!((en.x >> b) & 1u)) { atomicExch(dests.err, 1); key[u] = 0xffffffffu; continue; } // not a state of this partition
+                            key[u] = en.y + (uint32_t)__popc(en.x & ((1u << b) - 1u));
+                        }
+                    } else if (gkeys) { // ... or ONE 16-byte entry of the directory per key (ascending keys: neighbouring lanes read the same
+                        ulonglong2 en[kWinRuns]; // or the next entry)
 #pragma unroll
                         for (int u = 0; u < kWinRuns; ++u)
-                            if (ldir) { // (a key outside the window's ranks -- a misplaced segment -- reads nothing and raises the flag below)
-                                const uint32_t j = (key[u] >> 6) - e0;
-                                en[u] = (it < len[u] && j < ne) ? s_dir[j] : make_ulonglong2(0, 0);
-                            } else
-                                en[u] = (it < len[u] && (int64_t)key[u] < dests.n_ranks) // (a key that is no rank at all reads nothing)
-                                            ? *reinterpret_cast<ulonglong2 const *>(dir + (key[u] >> 6)) : make_ulonglong2(0, 0);
+                            en[u] = (it < len[u] && (int64_t)key[u] < dests.n_ranks) // (a key that is no rank at all reads nothing)
+                                        ? *reinterpret_cast<ulonglong2 const *>(dir + (key[u] >> 6)) : make_ulonglong2(0, 0);
 #pragma unroll
                         for (int u = 0; u < kWinRuns; ++u) {
                             if (it >= len[u]) continue;
@@ -1127,7 +1139,7 @@ __global__ __launch_bounds__(kBlock) void k_window(lsk_wdests dests, lsk_wsrc co
         }
         const int64_t m = (w1 - w0) * (CPLX ? 2 : 1);
         double *__restrict__ yw = y + w0 * (CPLX ? 2 : 1);
-        for (int64_t i = tid; i < m; i += kBlock) yw[i] += s_acc[i];
+        for (int64_t i = tid; i < m; i += THREADS) yw[i] += s_acc[i];
         __syncthreads();
     }
 }
@@ -1139,9 +1151,17 @@ extern "C" int lsk_window(int cplx, lsk_wdests const *dests, lsk_wsrc const *d_s
     const int64_t nb = dests->first_block[dests->n];
     if (nb <= 0) return 0;
     if (nb > ((int64_t)1 << 31) - 1) { snprintf(g_err, sizeof(g_err), "lsk_window: too many windows"); return -1; }
-    dim3 g((unsigned)nb), b(kBlock);
-    if (cplx) hipLaunchKernelGGL(k_window<true>, g, b, 0, (hipStream_t)stream, *dests, d_srcs, n_src, S, wpb);
-    else hipLaunchKernelGGL(k_window<false>, g, b, 0, (hipStream_t)stream, *dests, d_srcs, n_src, S, wpb);
+    // threads of a consumer block: 8 waves share a window's LDS where a window has many short runs (f64, >= 256 streams per window:
+    // chain_28 x 8 3.21 -> 2.98 ms, chain_30 x 8 16.2 -> 14.7), 4 otherwise (c128 5.3 vs 6.1 ms, two partitions 3.1 vs 3.3).
+    // LS_AMD_WINDOW_THREADS=256|512 overrides (A/B).
+    char const *te = getenv("LS_AMD_WINDOW_THREADS");
+    const int threads = te ? (atoi(te) >= 512 ? 512 : 256) : ((!cplx && (int64_t)n_src * S >= 256) ? 512 : 256);
+    dim3 g((unsigned)nb), b((unsigned)threads);
+    if (threads == 512) {
+        if (cplx) hipLaunchKernelGGL((k_window<true, 512>), g, b, 0, (hipStream_t)stream, *dests, d_srcs, n_src, S, wpb);
+        else hipLaunchKernelGGL((k_window<false, 512>), g, b, 0, (hipStream_t)stream, *dests, d_srcs, n_src, S, wpb);
+    } else if (cplx) hipLaunchKernelGGL((k_window<true, 256>), g, b, 0, (hipStream_t)stream, *dests, d_srcs, n_src, S, wpb);
+    else hipLaunchKernelGGL((k_window<false, 256>), g, b, 0, (hipStream_t)stream, *dests, d_srcs, n_src, S, wpb);
     LSK_LAUNCH_CHECK();
     return 0;
 }
