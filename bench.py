@@ -313,7 +313,7 @@ def boundary_extra(D, torch, h, basis, reps, y_device, x_device, calls=2):
 def packet_path_extra(D, torch, time_steps, L=28, P=8, steps=5):
     """The reference's own formulation -- term expansion, hash -> owner, per-destination buffers, local scatter (DMV:663-853) -- on
     one device: heisenberg_chain_L over P logical partitions through ls_amd_matvec (the "exchange" is a pointer hand-off), once with
-    the sorted packet streams + window consumers (csrc/k_packets.hip, k_tile_st / k_window) and once with the atomic consumers
+    the sorted packet streams + window consumers (csrc/k_packets.hip, k_tile_sd / k_window) and once with the atomic consumers
     (LS_AMD_PACKET_STREAMS=0), each checked element-wise against the one-partition pull kernel on the same x."""
     from distributed_matvec_amd import config
 
