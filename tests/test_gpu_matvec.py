@@ -1271,6 +1271,71 @@ def test_pairs_kernel_lattices(torch, monkeypatch, case, kernel):
     assert np.abs(gotc - wantc).max() <= 1e-12 * max(1.0, np.abs(wantc).max()), case
 
 
+def _random_pair_case(seed):
+    """a random exchange-pair operator: random graph (degree <= 8 or not), 1-3 amplitude classes, any filling the oracle finishes"""
+    rs = np.random.RandomState(seed)
+    L = int(rs.choice([7, 12, 19, 26, 33, 40, 47, 64]))
+    max_w = {7: 6, 12: 10, 19: 8, 26: 5, 33: 4, 40: 3, 47: 3, 64: 2}[L]
+    w = int(rs.randint(1, max_w + 1))
+    if L <= 12 and rs.rand() < 0.3:
+        w = L - w  # past half filling
+        w = min(max(w, 1), 18, L - 1)
+    all_pairs = [(i, j) for i in range(L) for j in range(i + 1, L)]
+    n_pairs = int(rs.randint(1, min(len(all_pairs), 100) + 1))
+    cap = int(rs.choice([3, 8, 64]))  # degree cap: the 4-slot table, the 8-slot table, no particle walk at all
+    deg = [0] * L
+    pairs = []
+    for k in rs.permutation(len(all_pairs)):
+        i, j = all_pairs[k]
+        if deg[i] < cap and deg[j] < cap:
+            pairs.append((i, j))
+            deg[i] += 1
+            deg[j] += 1
+        if len(pairs) == n_pairs:
+            break
+    n_cls = int(rs.randint(1, 4))
+    amps = [(round(float(rs.uniform(-2, 2)), 3), round(float(rs.uniform(-2, 2)), 3)) for _ in range(n_cls)]
+    cls = rs.randint(0, n_cls, size=len(pairs))
+    cfg = _lattice_config(L, w, [pairs[k] for k in range(len(pairs)) if cls[k] == 0] or [pairs[0]], jz=amps[0][0], jxy=amps[0][1])
+    for c in range(1, n_cls):
+        mine = [list(pairs[k]) for k in range(len(pairs)) if cls[k] == c]
+        if mine:
+            cfg["hamiltonian"]["terms"] += [{"expression": f"{amps[c][1]} × σˣ₀ σˣ₁", "sites": mine}, {"expression": f"{amps[c][1]} × σʸ₀ σʸ₁", "sites": mine},
+                                            {"expression": f"{amps[c][0]} × σᶻ₀ σᶻ₁", "sites": mine}]
+    return cfg
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_pair_kernels_random_graphs(torch, monkeypatch, seed):
+    """the one-row-per-lane exchange-pair kernels (k_pairs_row, k_pairs_site: O(1) rank shifts, particles moving up and down past
+    other particles, 4- and 8-slot neighbour tables, one or several amplitude classes, 4- and 8-byte states) and the staged
+    k_pairs_t on random graphs at random fillings, every row against the oracle, f64 and c128"""
+    from oracle import c_oracle as CO
+    from oracle import model as M
+
+    cfg = _random_pair_case(1000 + seed)
+    o = CO.COracle(M.model_from_config(cfg))
+    want_reps = o.enumerate()
+    rs = np.random.RandomState(seed)
+    x = rs.rand(len(want_reps)) - 0.5
+    xc = x + 1j * (rs.rand(len(want_reps)) - 0.5)
+    want, wantc = o.local_matvec(want_reps, x), o.local_matvec(want_reps, xc)
+    seen = set()
+    for kernel in ("pairs", "pairrows", "pairsites", "auto"):
+        monkeypatch.delenv("LS_AMD_ROW_KERNEL", raising=False)
+        if kernel != "auto":
+            monkeypatch.setenv("LS_AMD_ROW_KERNEL", kernel)
+        D, basis, h, reps, masks = setup_model(torch, cfg, 1)
+        assert np.array_equal(reps[0].cpu().numpy().view(np.uint64), want_reps)
+        got, pl = run_matvec(torch, D, h, reps, masks, x, 1, "pull")
+        seen.add(pl.kernel)
+        L, w = cfg["basis"]["number_spins"], cfg["basis"]["hamming_weight"]
+        assert np.abs(got - want).max() <= 1e-12 * max(1.0, np.abs(want).max()), (kernel, pl.kernel, L, w, np.abs(got - want).max())
+        gotc, plc = run_matvec(torch, D, h, reps, masks, xc, 1, "pull")
+        assert np.abs(gotc - wantc).max() <= 1e-12 * max(1.0, np.abs(wantc).max()), (kernel, plc.kernel, L, w)
+    assert seen & {"direct-pull+pairs", "direct-pull+pairrows", "direct-pull+pairsites", "direct-pull"}, seen
+
+
 def _primme_buffer(n, h):
     import ctypes as C
 
