@@ -1461,6 +1461,7 @@ typedef struct part_state {
     int64_t *ttab_first;  /* [rounds + 1] first tile of the round in d_ttab */
     uint32_t *d_soff;     /* owned */
     uint32_t *h_soff;     /* owned: host copy (dist.c exchanges it at set-up) */
+    struct ls_amd_gtab *scatter_gt; /* shared (refcount): {representative -> index} for the consumers of state-carrying packets, or NULL */
 } part_state;
 
 #ifndef LS_AMD_PULL_VALUES_DEFAULT
@@ -2890,12 +2891,28 @@ int ls_amd_plan_create(ls_amd_plan **out, ls_hs_operator const *op, ls_amd_dtype
     if (pl->family == FAMILY_TILE && my_partition < 0 && pl->send_capacity > 0 && !pl->streams) {
         if (lsk_malloc(&pl->d_send, (size_t)pl->send_capacity) != 0) { ls_amd_plan_destroy(pl); return dev_error(); }
     }
+    if (pl->family == FAMILY_TILE && pl->key_bytes == 8 && pl->P > 1) {
+        /* State-carrying packets into a SEARCHED index (projected bases): the consumer's look-up is one 16-byte probe of a static
+         * {representative -> index} table per partition instead of the prefix table + binary search (4-6 dependent loads per packet;
+         * round 6: chain_36_symm x 8 consumers 40.0 -> see profiles/r6_projected_packets_hash_index_ab.txt).  16-32 bytes per state,
+         * O(N / P); a table that cannot be built leaves the search in place.  LS_AMD_SCATTER_HASH=0: off (A/B). */
+        char const *he = getenv("LS_AMD_SCATTER_HASH");
+        if (!(he && atoi(he) == 0))
+            for (int p = 0; p < pl->n_local; ++p) {
+                part_state *ps = &pl->parts[p];
+                if (ps->index.kind != LSK_INDEX_SEARCH || ps->index.dir || ps->count <= 0 || ps->count >= 0xffffffffLL) continue;
+                if (ls_amd_internal_gtab_acquire(&ps->scatter_gt, op->basis->number_sites, ps->d_reps, ps->count, NULL, 1, stream) != 0) {
+                    ps->scatter_gt = NULL; /* (the error text stays readable through ls_amd_last_error; the plan works without the table) */
+                }
+            }
+    }
     if (pl->family == FAMILY_TILE && my_partition < 0 && pl->P > 1 && pl->key_bytes == 8) {
         /* the destinations' indexes as a device array: all segments a producer's round leaves are consumed by ONE launch */
         lsk_part_ctx *h = (lsk_part_ctx *)calloc((size_t)pl->P, sizeof(lsk_part_ctx));
         for (int d = 0; d < pl->P; ++d) {
             h[d].ix = pl->parts[d].index;
             h[d].norms = pl->dbs.k4_mode ? pl->parts[d].d_norms : NULL;
+            if (pl->parts[d].scatter_gt) h[d].gt = pl->parts[d].scatter_gt->tab;
             if (!pl->parts[pl->part_ctx_any].index.dir && pl->parts[d].index.dir) pl->part_ctx_any = d;
         }
         void *pc = NULL;
@@ -2971,6 +2988,7 @@ void ls_amd_plan_destroy(ls_amd_plan *pl) {
             free(ps->wtab_first);
             if (ps->d_ttab) lsk_free(ps->d_ttab);
             if (ps->d_soff) lsk_free(ps->d_soff);
+            if (ps->scatter_gt) ls_amd_internal_gtab_release(ps->scatter_gt);
             free(ps->h_soff);
             free(ps->ttab_first);
             free(ps->send_counts); free(ps->h_beta_off); free(ps->h_val_off);
@@ -3420,7 +3438,11 @@ int ls_amd_scatter_round(ls_amd_plan *pl, int num_segments, int64_t const *count
         if (sg.n == 0) break;
         sg.start[sg.n] = total;
         if (pl->key_bytes == 4) DEV(lsk_scatter_idx(pl->cplx, &sg, d_recv, stream));
-        else DEV(lsk_scatter_segs(ps->index, pl->cplx, &sg, d_recv, pl->dbs.k4_mode ? ps->d_norms : NULL, pl->d_err, stream));
+        else {
+            lsk_gtab no_gt;
+            memset(&no_gt, 0, sizeof(no_gt));
+            DEV(lsk_scatter_segs(ps->index, ps->scatter_gt ? ps->scatter_gt->tab : no_gt, pl->cplx, &sg, d_recv, pl->dbs.k4_mode ? ps->d_norms : NULL, pl->d_err, stream));
+        }
     }
     stage_end(pl, st, stream);
     return 0;

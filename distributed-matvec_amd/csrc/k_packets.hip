@@ -526,7 +526,7 @@ extern "C" int lsk_scatter_idx(int cplx, lsk_segs const *segs, void const *base,
 }
 // ... and for packets that carry the state (projected bases, or no room for the all-destinations directory): one index, one y
 template <bool CPLX>
-__global__ __launch_bounds__(kBlock) void k_scatter_segs(lsk_index ix, lsk_segs segs, char const *__restrict__ base,
+__global__ __launch_bounds__(kBlock) void k_scatter_segs(lsk_index ix, lsk_gtab gt, lsk_segs segs, char const *__restrict__ base,
                                                          double const *__restrict__ norms, int *err, int xcd_chunk) {
     __shared__ int64_t s_start[LSK_MAX_SEGS + 1];
     extern __shared__ uint64_t s_db[];
@@ -546,14 +546,14 @@ __global__ __launch_bounds__(kBlock) void k_scatter_segs(lsk_index ix, lsk_segs 
         if (CPLX) { vr = vals[2 * j]; vi = vals[2 * j + 1]; } else vr = vals[j];
         if (vr == 0.0 && vi == 0.0) continue; // DMV:110
         const uint64_t beta = reinterpret_cast<uint64_t const *>(base + segs.key_off[sg])[j];
-        const int64_t idx = ix.kind == LSK_INDEX_IDENTITY ? (int64_t)beta : (ix.dir ? rankdir_index(ix, beta, s_db) : search_index(ix, beta));
+        const int64_t idx = ix.kind == LSK_INDEX_IDENTITY ? (int64_t)beta : (ix.dir ? rankdir_index(ix, beta, s_db) : (gt.entries ? gtab_index(gt, beta) : search_index(ix, beta)));
         if (idx < 0) { atomicExch(err, 1); continue; }
         if (norms) { const double nb = norms[idx]; vr *= nb; vi *= nb; }
         if (CPLX) { atomic_add_f64(y + 2 * idx, vr); atomic_add_f64(y + 2 * idx + 1, vi); }
         else atomic_add_f64(y + idx, vr);
     }
 }
-extern "C" int lsk_scatter_segs(lsk_index ix, int cplx, lsk_segs const *segs, void const *base, double const *norms, int *d_err, void *stream) {
+extern "C" int lsk_scatter_segs(lsk_index ix, lsk_gtab gt, int cplx, lsk_segs const *segs, void const *base, double const *norms, int *d_err, void *stream) {
     if (segs->n < 1 || segs->n > LSK_MAX_SEGS) { snprintf(g_err, sizeof(g_err), "lsk_scatter_segs: %d segments", segs->n); return -1; }
     if (ix.kind == LSK_INDEX_COMBINADIC) { snprintf(g_err, sizeof(g_err), "lsk_scatter_segs: SEARCH/IDENTITY index only"); return -1; }
     const int64_t n = segs->start[segs->n];
@@ -561,8 +561,8 @@ extern "C" int lsk_scatter_segs(lsk_index ix, int cplx, lsk_segs const *segs, vo
     const int64_t nb = (n + kBlock - 1) / kBlock;
     dim3 g((unsigned)(nb < ((int64_t)1 << 30) ? nb : ((int64_t)1 << 30))), b(kBlock);
     const size_t dyn = ix.dir ? sizeof(uint64_t) * (size_t)ix.dir_sites * (size_t)(ix.dir_weight + 1) : 0;
-    if (cplx) hipLaunchKernelGGL(k_scatter_segs<true>, g, b, dyn, (hipStream_t)stream, ix, *segs, (char const *)base, norms, d_err, 64);
-    else hipLaunchKernelGGL(k_scatter_segs<false>, g, b, dyn, (hipStream_t)stream, ix, *segs, (char const *)base, norms, d_err, 64);
+    if (cplx) hipLaunchKernelGGL(k_scatter_segs<true>, g, b, dyn, (hipStream_t)stream, ix, gt, *segs, (char const *)base, norms, d_err, 64);
+    else hipLaunchKernelGGL(k_scatter_segs<false>, g, b, dyn, (hipStream_t)stream, ix, gt, *segs, (char const *)base, norms, d_err, 64);
     LSK_LAUNCH_CHECK();
     return 0;
 }
@@ -592,7 +592,7 @@ __global__ __launch_bounds__(kBlock) void k_scatter_parts(lsk_part_ctx const *__
         lsk_part_ctx const *pc = parts + segs.part[sg];
         lsk_index ix = any; // kind, binom, dir_sites, dir_weight: common; the rest per partition
         ix.shift = pc->ix.shift; ix.count = pc->ix.count; ix.reps = pc->ix.reps; ix.table = pc->ix.table; ix.dir = pc->ix.dir; ix.kind = pc->ix.kind;
-        const int64_t idx = ix.kind == LSK_INDEX_IDENTITY ? (int64_t)beta : (ix.dir ? rankdir_index(ix, beta, s_db) : search_index(ix, beta));
+        const int64_t idx = ix.kind == LSK_INDEX_IDENTITY ? (int64_t)beta : (ix.dir ? rankdir_index(ix, beta, s_db) : (pc->gt.entries ? gtab_index(pc->gt, beta) : search_index(ix, beta)));
         if (idx < 0) { atomicExch(err, 1); continue; }
         double const *norms = pc->norms;
         if (norms) { const double nb = norms[idx]; vr *= nb; vi *= nb; }

@@ -334,26 +334,6 @@ extern "C" int lsk_tile_pull(lsk_operator op, lsk_basis bs, lsk_index ix_global,
 // exchange as they arrive from their owners (slot = owner * max_count + local index), which removes the hashed -> block
 // permutation pass as well.  Per-rank work then shrinks with P.
 // ---------------------------------------------------------------------------------------------
-constexpr uint64_t kGtEmpty = ~0ULL;
-constexpr int kGtMaxDist = 255;
-// an L-bit bijection (odd multiplications mod 2^L and xor-shifts): bucket and tag together identify the key
-__host__ __device__ __forceinline__ uint64_t gt_mix(uint64_t k, int L) {
-    const uint64_t m = L >= 64 ? ~0ULL : ((1ULL << L) - 1);
-    const int s = (L + 1) >> 1;
-    k = (k * 0x9E3779B97F4A7C15ULL) & m;
-    k ^= k >> s;
-    k = (k * 0xD6E8FEB86659FD93ULL) & m;
-    k ^= k >> s;
-    return k;
-}
-__host__ __device__ __forceinline__ void gt_split(lsk_gtab const &t, uint64_t key, uint64_t &bucket, uint32_t &tag) {
-    const uint64_t h = gt_mix(key, t.L);
-    bucket = h >> t.tbits;
-    tag = (uint32_t)(h & ((1ULL << t.tbits) - 1));
-}
-// upper word of an entry: tag << 8 | displacement
-__host__ __device__ __forceinline__ uint32_t gt_hi(uint32_t tag, int dist) { return (tag << 8) | (uint32_t)dist; }
-
 __global__ __launch_bounds__(kBlock) void k_gtab_clear(int64_t entries, uint64_t *__restrict__ tab) {
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < entries; i += (int64_t)gridDim.x * kBlock) tab[i] = kGtEmpty;
 }
@@ -373,19 +353,6 @@ __global__ __launch_bounds__(kBlock) void k_gtab_insert(lsk_gtab t, uint64_t *ta
             b = (b + 1) & bmask;
         }
         if (!placed) atomicExch(flag, 1);
-    }
-}
-// payload of `key`, or 0xffffffff; `first` is the home bucket when the caller has already loaded it
-__device__ __forceinline__ uint32_t gt_resolve(lsk_gtab const &t, uint64_t const *__restrict__ tab, uint64_t b, uint32_t tag,
-                                               ulonglong2 cur) {
-    const uint64_t bmask = (1ULL << t.bbits) - 1;
-    for (int d = 0;; ++d) {
-        const uint32_t want = gt_hi(tag, d);
-        if ((uint32_t)(cur.x >> 32) == want && cur.x != kGtEmpty) return (uint32_t)cur.x;
-        if ((uint32_t)(cur.y >> 32) == want && cur.y != kGtEmpty) return (uint32_t)cur.y;
-        if (cur.x == kGtEmpty || cur.y == kGtEmpty || d == kGtMaxDist) return 0xffffffffu; // inserts never skip an empty slot
-        b = (b + 1) & bmask;
-        cur = *(ulonglong2 const *)(tab + 2 * b);
     }
 }
 // ---- value table (lsk_vtab): the index table with 32-byte buckets {entry0, entry1, x[slot0], x[slot1]} ------------------------------

@@ -158,9 +158,16 @@ typedef struct lsk_segs {
     uint8_t part[LSK_MAX_SEGS];      /* lsk_scatter_parts: the partition (entry of the context array) the segment belongs to */
 } lsk_segs;
 /* what a consumer needs to know of a destination partition: all partitions of one process (lsk_scatter_parts) */
+/* static index table {state -> payload} (k_pull.hip; look-up: lsk_dev.hpp) */
+typedef struct lsk_gtab {
+    uint64_t const *entries; /* device [2 << bbits] */
+    int L, bbits, tbits;
+} lsk_gtab;
 typedef struct lsk_part_ctx {
     lsk_index ix;
     double const *norms; /* per-row norms multiplied in (K4 modes that prescale), else NULL */
+    lsk_gtab gt;         /* entries != NULL: {representative -> index} of the partition -- one 16-byte probe instead of the prefix table
+                          * and the binary search (round 6; searched indexes, i.e. projected bases) */
 } lsk_part_ctx;
 /* every packet of every segment: y[seg][idx] += value; pre-indexed packets (u32 idx) */
 int lsk_scatter_idx(int cplx, lsk_segs const *segs, void const *base, void *stream);
@@ -168,7 +175,7 @@ int lsk_scatter_idx(int cplx, lsk_segs const *segs, void const *base, void *stre
  * index / norms of segment s are d_parts[segs->part[s]] (device array); all partitions share sites / weight of the rank directory */
 int lsk_scatter_parts(lsk_part_ctx const *d_parts, lsk_index any, int cplx, lsk_segs const *segs, void const *base, int *d_err, void *stream);
 /* the same for packets that carry the state: ONE index (all segments belong to the same destination partition) */
-int lsk_scatter_segs(lsk_index ix, int cplx, lsk_segs const *segs, void const *base, double const *norms, int *d_err, void *stream);
+int lsk_scatter_segs(lsk_index ix, lsk_gtab gt, int cplx, lsk_segs const *segs, void const *base, double const *norms, int *d_err, void *stream);
 
 /* per-round send layout: byte offsets of the beta / value arrays of every destination segment */
 typedef struct lsk_round_layout {
@@ -374,10 +381,6 @@ int lsk_tile_pull(lsk_operator op, lsk_basis bs, lsk_index ix_global, int cplx, 
  *     entry = tag << 40 | displacement << 32 | payload,   empty = ~0
  * so 2^(bbits + 1) entries of 8 bytes serve n <= 2^bbits keys at load <= 0.5 (half the bytes of a {key, value} table, and
  * nothing to rewrite per matvec).  Needs tbits = L - bbits <= 24 and payloads < 2^32 - 1. */
-typedef struct lsk_gtab {
-    uint64_t const *entries; /* device [2 << bbits] */
-    int L, bbits, tbits;
-} lsk_gtab;
 /* choose bbits for n keys of L bits (returns -1 when no admissible size exists below max_bytes) */
 int lsk_gtab_bits(int L, int64_t n, int64_t max_bytes);
 /* fills entries (device, 16 << bbits bytes, allocated by the caller) with reps[i] -> payload[i] (payload NULL: i);

@@ -206,6 +206,51 @@ __device__ __forceinline__ int64_t search_index(lsk_index const &ix, uint64_t s)
     return (lo < end && ix.reps[lo] == s) ? (int64_t)lo : -1;
 }
 
+// Static index table (lsk_gtab, lsk.h; built by k_pull.hip): {state -> payload} in 16-byte buckets of two entries
+constexpr uint64_t kGtEmpty = ~0ULL;
+constexpr int kGtMaxDist = 255;
+// an L-bit bijection (odd multiplications mod 2^L and xor-shifts): bucket and tag together identify the key
+__host__ __device__ __forceinline__ uint64_t gt_mix(uint64_t k, int L) {
+    const uint64_t m = L >= 64 ? ~0ULL : ((1ULL << L) - 1);
+    const int s = (L + 1) >> 1;
+    k = (k * 0x9E3779B97F4A7C15ULL) & m;
+    k ^= k >> s;
+    k = (k * 0xD6E8FEB86659FD93ULL) & m;
+    k ^= k >> s;
+    return k;
+}
+__host__ __device__ __forceinline__ void gt_split(lsk_gtab const &t, uint64_t key, uint64_t &bucket, uint32_t &tag) {
+    const uint64_t h = gt_mix(key, t.L);
+    bucket = h >> t.tbits;
+    tag = (uint32_t)(h & ((1ULL << t.tbits) - 1));
+}
+// upper word of an entry: tag << 8 | displacement
+__host__ __device__ __forceinline__ uint32_t gt_hi(uint32_t tag, int dist) { return (tag << 8) | (uint32_t)dist; }
+
+// payload of `key`, or 0xffffffff; `first` is the home bucket when the caller has already loaded it
+__device__ __forceinline__ uint32_t gt_resolve(lsk_gtab const &t, uint64_t const *__restrict__ tab, uint64_t b, uint32_t tag,
+                                               ulonglong2 cur) {
+    const uint64_t bmask = (1ULL << t.bbits) - 1;
+    for (int d = 0;; ++d) {
+        const uint32_t want = gt_hi(tag, d);
+        if ((uint32_t)(cur.x >> 32) == want && cur.x != kGtEmpty) return (uint32_t)cur.x;
+        if ((uint32_t)(cur.y >> 32) == want && cur.y != kGtEmpty) return (uint32_t)cur.y;
+        if (cur.x == kGtEmpty || cur.y == kGtEmpty || d == kGtMaxDist) return 0xffffffffu; // inserts never skip an empty slot
+        b = (b + 1) & bmask;
+        cur = *(ulonglong2 const *)(tab + 2 * b);
+    }
+}
+
+// index of state s in the partition the table was built from, or -1 (payload = index)
+__device__ __forceinline__ int64_t gtab_index(lsk_gtab const &t, uint64_t s) {
+    if (t.L < 64 && (s >> t.L) != 0) return -1;
+    uint64_t b;
+    uint32_t tag;
+    gt_split(t, s, b, tag);
+    const uint32_t pay = gt_resolve(t, t.entries, b, tag, *(ulonglong2 const *)(t.entries + 2 * b));
+    return pay == 0xffffffffu ? -1 : (int64_t)pay;
+}
+
 // Rank directory (lsk_rankdir, lsk.h): LDS copy of the binomials a rank needs -- C(p, k), p < sites, k <= weight -- and the look-up
 __device__ __forceinline__ int rankdir_lds_entries(lsk_index const &ix) { return ix.dir ? ix.dir_sites * (ix.dir_weight + 1) : 0; }
 __device__ __forceinline__ void rankdir_load(lsk_index const &ix, uint64_t *s_db) { // (the caller synchronises the block)

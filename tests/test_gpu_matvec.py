@@ -107,8 +107,10 @@ def test_single_locale_matvec_c128(torch, name):
 
 @pytest.mark.parametrize("name", CHECK_MODELS)
 @pytest.mark.parametrize("P", [2, 3, 4, 8])
-def test_partitioned_matvec(torch, name, P):
-    """numLocales = P logical partitions on one device (hash64_01 % P ownership, true modulo)."""
+def test_partitioned_matvec(torch, monkeypatch, name, P):
+    """numLocales = P logical partitions on one device (hash64_01 % P ownership, true modulo).  (P = 3 and 8: once more with the
+    consumers of state-carrying packets searching the sorted representatives instead of probing the partition's hash index,
+    LS_AMD_SCATTER_HASH=0 -- the round-5 form.)"""
     D, basis, h, reps, masks = setup_model(torch, model_config(name), P)
     want_reps = oracle_reps(name)
     x = np.random.RandomState(44).rand(len(want_reps)) - 0.5
@@ -116,6 +118,12 @@ def test_partitioned_matvec(torch, name, P):
     got, pl = run_matvec(torch, D, h, reps, masks, x, P)
     assert pl.kernel in ("tile", "tile+streams")
     assert_close(got, want, f"{name} P={P}")
+    if P in (3, 8):
+        monkeypatch.setenv("LS_AMD_SCATTER_HASH", "0")
+        got0, pl0 = run_matvec(torch, D, h, reps, masks, x, P)
+        monkeypatch.delenv("LS_AMD_SCATTER_HASH")
+        assert pl0.kernel == pl.kernel
+        assert_close(got0, want, f"{name} P={P} (searched index)")
     if P == 4:
         xc = x + 1j * (np.random.RandomState(45).rand(len(want_reps)) - 0.5)
         gotc, _ = run_matvec(torch, D, h, reps, masks, xc, P)
