@@ -1572,6 +1572,7 @@ typedef struct ls_amd_gtab {
     struct ls_amd_gtab *next;
 } ls_amd_gtab;
 static ls_amd_gtab *g_gtabs = NULL;
+static lsk_gtab no_gtab(void) { lsk_gtab t; memset(&t, 0, sizeof(t)); return t; }
 static pthread_mutex_t g_gtab_lock = PTHREAD_MUTEX_INITIALIZER;
 
 static void gtab_free(ls_amd_gtab *t) {
@@ -2609,7 +2610,7 @@ static int plan_setup_part(ls_amd_plan *pl, part_state *ps, int part_id, int num
         for (int r = 0; r < rounds; ++r) {
             int64_t row0 = ps->count * r / rounds, row1 = ps->count * (r + 1) / rounds;
             if (lsk_tile_wv(pl->dop, pl->dbs, ps->index, pl->gd, pl->cplx, 1, P, part_id, row0, row1, ps->d_reps, ps->d_norms, NULL, NULL,
-                            ps->d_wtab + (size_t)ps->wtab_first[r] * P, NULL, NULL, pl->d_err, stream) != 0) { free(layouts); return dev_error(); }
+                            ps->d_wtab + (size_t)ps->wtab_first[r] * P, NULL, NULL, pl->d_err, no_gtab(), stream) != 0) { free(layouts); return dev_error(); }
         }
         h_wtab = (uint32_t *)malloc(bytes);
         if (!h_wtab || lsk_sync(stream) != 0 || lsk_d2h(h_wtab, pw, bytes) != 0) { free(h_wtab); free(layouts); return dev_error(); }
@@ -3376,7 +3377,8 @@ static int generate_round(ls_amd_plan *pl, part_state *ps, int pid, int round, v
                         ps->d_ttab + (size_t)ps->ttab_first[round] * (size_t)(pl->P * pl->st_S), ps->d_layouts + round, d_send, pl->d_err, stream));
     } else if (ps->d_wtab)
         DEV(lsk_tile_wv(pl->dop, pl->dbs, ps->index, pl->gd, pl->cplx, 0, pl->P, pid, row0, row1, ps->d_reps, ps->d_norms, d_x, d_y,
-                        ps->d_wtab + (size_t)ps->wtab_first[round] * pl->P, ps->d_layouts + round, d_send, pl->d_err, stream));
+                        ps->d_wtab + (size_t)ps->wtab_first[round] * pl->P, ps->d_layouts + round, d_send, pl->d_err,
+                        ps->scatter_gt ? ps->scatter_gt->tab : no_gtab(), stream));
     else
         DEV(lsk_tile(pl->dop, pl->dbs, ps->index, pl->cplx, 0, pl->P, pid, row0, row1, ps->d_reps, ps->d_norms, d_x,
                      d_y, pl->d_cursors, ps->d_layouts + round, d_send, pl->d_counts, pl->d_err, stream));
@@ -3439,9 +3441,7 @@ int ls_amd_scatter_round(ls_amd_plan *pl, int num_segments, int64_t const *count
         sg.start[sg.n] = total;
         if (pl->key_bytes == 4) DEV(lsk_scatter_idx(pl->cplx, &sg, d_recv, stream));
         else {
-            lsk_gtab no_gt;
-            memset(&no_gt, 0, sizeof(no_gt));
-            DEV(lsk_scatter_segs(ps->index, ps->scatter_gt ? ps->scatter_gt->tab : no_gt, pl->cplx, &sg, d_recv, pl->dbs.k4_mode ? ps->d_norms : NULL, pl->d_err, stream));
+            DEV(lsk_scatter_segs(ps->index, ps->scatter_gt ? ps->scatter_gt->tab : no_gtab(), pl->cplx, &sg, d_recv, pl->dbs.k4_mode ? ps->d_norms : NULL, pl->d_err, stream));
         }
     }
     stage_end(pl, st, stream);

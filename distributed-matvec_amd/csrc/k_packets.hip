@@ -216,7 +216,7 @@ __global__ __launch_bounds__(kBlock) void k_tile_wv(int n_groups, lsk_group cons
                                                     int me, int64_t row0, int64_t row1, uint64_t const *__restrict__ reps,
                                                     double const *__restrict__ norms, double const *__restrict__ x, double *y,
                                                     uint32_t *__restrict__ wtab, lsk_round_layout const *__restrict__ layout,
-                                                    char *send, int *err) {
+                                                    char *send, int *err, lsk_gtab own_gt) {
     constexpr int kCap = (kBlock / 64) * kTwRing;
     __shared__ uint64_t s_beta[kCap];
     __shared__ double s_val[COUNT ? 1 : kCap * (CPLX ? 2 : 1)];
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(kBlock) void k_tile_wv(int n_groups, lsk_group cons
             } else if (bs.proj == LSK_PROJ_FULL && bs.k4_mode != 0) {
                 beta = (uint64_t)rep_trivial<W>(bs, elems, (W)beta); // norm(rep) applied at index time
             } else if (bs.proj == LSK_PROJ_FULL) {
-                if (live) {
+                if (live && !(kAblate && (bs.debug_ablate & 256))) { // (profiling builds: no K4)
                     W rep; double chr, chi, stab;
                     state_info_w<W, PM1>(bs, elems, (W)beta, rep, chr, chi, stab);
                     const double n2 = stab * bs.inv_order;
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(kBlock) void k_tile_wv(int n_groups, lsk_group cons
                     } else live = false; // zero-norm orbit: c == 0 => skipped (DMV:110)
                 }
             }
-            const int dest = live ? owner_of(beta, owner) : -1;
+            const int dest = live ? ((kAblate && (bs.debug_ablate & 2048)) ? (int)(beta % owner.P) : owner_of(beta, owner)) : -1; // (profiling builds: no hash)
             bool remote = live;
             uint32_t pidx = 0; // PK12: the packet's index inside its destination's block
             if (!COUNT && PK12) {
@@ -307,9 +307,13 @@ __global__ __launch_bounds__(kBlock) void k_tile_wv(int n_groups, lsk_group cons
                     } else pidx = (uint32_t)idx;
                 }
             } else if (!COUNT) {
-                if (live && dest == me) {
+                if (kAblate && (bs.debug_ablate & 1024) && live && dest == me) remote = false; // (profiling builds: own packets dropped)
+                else if (live && dest == me) {
                     remote = false;
-                    const int64_t idx = ix.dir ? rankdir_index(ix, beta, s_db) : search_index(ix, beta);
+                    // (own-partition packets are indexed HERE, by the 1 / P of the lanes they fall on while the rest of the wave waits: the
+                    // dependent loads of a binary search cost the whole wave -- ablation, chain_36_symm x 8: 13 of 62 ms; one probe of
+                    // the partition's hash index when the plan has it)
+                    const int64_t idx = ix.dir ? rankdir_index(ix, beta, s_db) : (own_gt.entries ? gtab_index(own_gt, beta) : search_index(ix, beta));
                     if (idx < 0) atomicExch(err, 1);
                     else {
                         if (bs.proj == LSK_PROJ_FULL && bs.k4_mode != 0) { const double nb = norms[idx]; vr *= nb; vi *= nb; }
@@ -328,7 +332,7 @@ __global__ __launch_bounds__(kBlock) void k_tile_wv(int n_groups, lsk_group cons
                 if (!COUNT) {
                     const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)cur, d);
                     const int64_t ob = readlane_i64(seg_b, d), ov = readlane_i64(seg_v, d);
-                    if (mine) {
+                    if (mine && !(kAblate && (bs.debug_ablate & 512))) { // (profiling builds: nothing stored)
                         const size_t pos = (size_t)base + (size_t)__popcll(mm & ((1ULL << lane) - 1));
                         if (PK12) reinterpret_cast<uint32_t *>(send + ob)[pos] = pidx;
                         else reinterpret_cast<uint64_t *>(send + ob)[pos] = beta;
@@ -390,7 +394,7 @@ extern "C" int lsk_tile_wv_max_parts(void) { return 64; }
 // exclusive offsets of every (wave, destination) inside the round's segments and the packets are written to d_send.
 extern "C" int lsk_tile_wv(lsk_operator op, lsk_basis bs, lsk_index ix, lsk_gdir gd, int cplx, int count_only, int P, int me,
                            int64_t row0, int64_t row1, uint64_t const *reps, double const *norms, void const *x, void *y,
-                           uint32_t *d_wtab, lsk_round_layout const *d_layout, void *d_send, int *d_err, void *stream) {
+                           uint32_t *d_wtab, lsk_round_layout const *d_layout, void *d_send, int *d_err, lsk_gtab own_gt, void *stream) {
     if (row1 <= row0 || op.n_groups == 0) return 0;
     if (P > lsk_tile_wv_max_parts() || P < 1 || !d_wtab) { snprintf(g_err, sizeof(g_err), "lsk_tile_wv: bad partition count %d or no wave table", P); return -1; }
     const bool pk12 = !count_only && gd.entries != nullptr;
@@ -403,7 +407,7 @@ extern "C" int lsk_tile_wv(lsk_operator op, lsk_basis bs, lsk_index ix, lsk_gdir
     const size_t dyn_db = pk12 ? sizeof(uint64_t) * (size_t)gd.sites * (size_t)(gd.weight + 1)
                                : (ix.dir ? sizeof(uint64_t) * (size_t)ix.dir_sites * (size_t)(ix.dir_weight + 1) : 0);
 #define LSK_TW_ARGS op.n_groups, op.groups, op.off, bs, bs.elems, ix, gd, ow, me, row0, row1, reps, norms, (double const *)x, (double *)y, \
-        d_wtab, d_layout, (char *)d_send, d_err
+        d_wtab, d_layout, (char *)d_send, d_err, own_gt
 #define LSK_TW_ONE(W, PM1, CPLX, REAL)                                                                                           \
     do {                                                                                                                         \
         if (count_only) { g.x = tile_grid(k_tile_wv<W, PM1, CPLX, REAL, true, false>, work_blocks); hipLaunchKernelGGL((k_tile_wv<W, PM1, CPLX, REAL, true, false>), g, b, 0, s, LSK_TW_ARGS); } \

@@ -316,7 +316,7 @@ int lsk_tile_wv_max_parts(void);
  * directory (own-partition packets included: ix is not used), and the send segments hold u32 indices instead of u64 states */
 int lsk_tile_wv(lsk_operator op, lsk_basis bs, lsk_index ix, lsk_gdir gd, int cplx, int count_only, int P, int me,
                 int64_t row0, int64_t row1, uint64_t const *reps, double const *norms, void const *x, void *y,
-                uint32_t *d_wtab, lsk_round_layout const *d_layout, void *d_send, int *d_err, void *stream);
+                uint32_t *d_wtab, lsk_round_layout const *d_layout, void *d_send, int *d_err, lsk_gtab own_gt, void *stream);
 /* Packets in SORTED STREAMS (k_packets.hip, k_tile_st / k_window): unprojected fixed-weight bases, operators whose off-diagonal
  * groups are all exchange pairs.  stream = 2 * group + (bit of alpha at the pair's lower site); along a stream beta - alpha is a
  * constant, so the packets of one (destination, stream) -- written in row order -- carry ASCENDING destination indices, and the
