@@ -595,9 +595,11 @@ def roofline_object(args, kernel_name, kernel_ms, launches_per_step, rows_here, 
     if pull:
         alg = rows_here * (row_bytes + 2 * w)
         formulation = f"pull: rows ({row_bytes} B state / plan data + 2w); y written once"
-    elif kernel_name == "direct-push":
-        alg = rows_here * (8 + w) + nnz_here * 2 * w  # the diagonal pass (y write) is a separate, tiny kernel
-        formulation = "push: rows (8 + w) + nnz 2w (SURVEY 8(d))"
+    elif kernel_name.startswith("direct-push"):
+        alg = rows_here * (8 + w) + nnz_here * 2 * w  # (k_direct: the diagonal pass is a separate, tiny kernel; k_push_t adds it itself)
+        formulation = "push: rows (8 + w) + nnz 2w (SURVEY 8(d))" + (
+            "; staged: near targets and the diagonal part meet in an LDS window of y per tile, one atomic per touched row"
+            if kernel_name.endswith("+staged") else "")
     else:  # tile: staged push; remote packets are written (8 + w) and scattered by k_scatter
         alg = rows_here * (8 + w) + nnz_here * 2 * w
         formulation = "push via packets: rows (8 + w) + nnz 2w (SURVEY 8(d)); all launches of one matvec"
@@ -1106,7 +1108,7 @@ def main():
     if not distributed and not args.no_extra and not symm:
         # secondary numbers in the same run: the other scatter/gather mode and the other dtype
         for label, mode2 in (("f64" if args.dtype == "c128" else "c128", args.mode),
-                             (args.dtype, "pull" if kernel_name == "direct-push" else "push")):
+                             (args.dtype, "pull" if kernel_name.startswith("direct-push") else "push")):
             try:
                 td = torch.float64 if label == "f64" else torch.complex128
                 x2 = D.fillRandom(my_reps, 42, td)
@@ -1135,7 +1137,7 @@ def main():
                     ro2["matvecs_per_s"] = steps2 / t2
                     ro2["dtype"] = label
                     extra_rooflines["roofline_c128" if label == "c128" and label != args.dtype else
-                                    ("roofline_push" if p2.kernel == "direct-push" else f"roofline_{label}_{p2.kernel}")] = ro2
+                                    ("roofline_push" if p2.kernel.startswith("direct-push") else f"roofline_{label}_{p2.kernel}")] = ro2
                 if label != args.dtype:  # the other dtype (c128 on the default run: the north star's): its own parity object
                     extra[f"{label}/{p2.kernel}"]["parity"], _f = one_gpu_parity(D, torch, h, my_reps, td, x2, y2, p2, False)
                 p2.destroy()

@@ -1505,6 +1505,7 @@ struct ls_amd_plan {
     lsk_tilemap tilemap;
     void *d_tilemap;
     int has_pairs; /* staged row kernel for arbitrary exchange pairs (lsk_pairs): non-ring lattices */
+    int has_push_staged; /* staged push kernel (lsk_push_staged): LDS window of y per tile; y is cleared, not assigned by k_diag */
     lsk_pairplan pairs;
     void *d_pair_recs, *d_rank_low, *d_pair_binom, *d_states32, *d_pair_rows, *d_pair_sites;
     int has_chain; /* staged row kernel (lsk_chain) */
@@ -2096,6 +2097,19 @@ int64_t ls_amd_test_gtab_find(int L, int bbits, uint64_t const *entries, uint64_
 
 /* Staged row kernel (k_chain_t, lsk.h): pull, f64 or c128 vectors, <= 64 sites, the full fixed-weight basis without
  * symmetries, a real operator made of exchange runs plus at most two other exchange pairs.  LS_AMD_ROW_KERNEL=generic keeps k_direct. */
+/* Staged push (k_push_t, lsk.h): the full fixed-weight basis without symmetries, a real operator with at least one undirected
+ * exchange run (what gives the near targets an LDS window is worth having for).  LS_AMD_ROW_KERNEL=generic keeps k_direct. */
+static int push_staged_eligible(ls_amd_plan const *pl) {
+    ls_hs_operator const *op = pl->op;
+    struct ls_amd_operator_ext const *ext = OEXT(op);
+    char const *e = getenv("LS_AMD_ROW_KERNEL");
+    if (e && strcmp(e, "generic") == 0) return 0;
+    if (op->basis->number_sites > 64 || op->basis->spin_inversion != 0 || pl->dbs.proj != LSK_PROJ_NONE || !ext->is_real ||
+        ext->runs.n_runs <= 0 || BEXT(op->basis)->hamming_weight < 0)
+        return 0;
+    for (int q = 0; q < ext->runs.n_runs; ++q) if (ext->runs.cnt[q] >> 16) return 0; /* directed runs: k_direct's DIRECTED instantiation */
+    return 1;
+}
 static int chain_eligible(ls_amd_plan const *pl) {
     ls_hs_operator const *op = pl->op;
     struct ls_amd_operator_ext const *ext = OEXT(op);
@@ -2879,7 +2893,11 @@ int ls_amd_plan_create(ls_amd_plan **out, ls_hs_operator const *op, ls_amd_dtype
             ls_amd_plan_destroy(pl);
             return -1;
         }
-        if (!pl->has_chain && !pl->has_pairs && build_tilemap(pl, ps0->count, 256) != 0) { ls_amd_plan_destroy(pl); return -1; }
+        if (pl->family == FAMILY_DIRECT_PUSH && combinadic && push_staged_eligible(pl)) {
+            if (build_tilemap(pl, ps0->count, lsk_push_tile_rows(pl->cplx)) != 0) { ls_amd_plan_destroy(pl); return -1; }
+            pl->has_push_staged = 1;
+        }
+        if (!pl->has_chain && !pl->has_pairs && !pl->has_push_staged && build_tilemap(pl, ps0->count, 256) != 0) { ls_amd_plan_destroy(pl); return -1; }
         if (pl->family == FAMILY_DIRECT_PULL && !OEXT(op)->is_hermitian) {
             /* a gather never sees a state that is mapped OUT of the basis (the reference's halt, DMV:115-118): checked once, here;
              * ls_amd_plan_check reports it after every matvec like the push kernels' error flag */
@@ -3297,7 +3315,7 @@ int ls_amd_internal_repl_split_finish(ls_amd_plan *pl, void const *d_x_global, v
 }
 char const *ls_amd_plan_kernel_name(ls_amd_plan const *pl) {
     switch (pl->family) {
-    case FAMILY_DIRECT_PUSH: return "direct-push";
+    case FAMILY_DIRECT_PUSH: return pl->has_push_staged ? "direct-push+staged" : "direct-push";
     case FAMILY_DIRECT_PULL:
         return pl->has_chain ? "direct-pull+staged" : pl->has_pairs ? (pl->pairs.sites ? "direct-pull+pairsites" : pl->pairs.rows ? "direct-pull+pairrows" : "direct-pull+pairs") : "direct-pull";
     case FAMILY_TILE_PULL: return pl->idx_mode ? (pl->slot_cache ? "tile-pull+indexed+cached" : (pl->d_vtab ? "tile-pull+values" : "tile-pull+indexed")) : "tile-pull";
@@ -3574,7 +3592,13 @@ int ls_amd_matvec(ls_amd_plan *pl, void const *const *d_x, void *const *d_y, voi
         return 0;
     }
     /* localDiagonal on every partition first: y is assigned (DMV:1062-1063) */
-    if (pl->family != FAMILY_DIRECT_PULL) {
+    if (pl->has_push_staged) { /* the staged push kernel adds the diagonal part itself: y is cleared (n_diag == 0: accumulated into, DMV:1062-1063) */
+        if (pl->dop.n_diag > 0) {
+            int const st = stage_begin(pl, ST_DIAG, stream);
+            DEV(lsk_memset_async(d_y[0], 0, (size_t)pl->parts[0].count * (pl->cplx ? 16 : 8), stream));
+            stage_end(pl, st, stream);
+        }
+    } else if (pl->family != FAMILY_DIRECT_PULL) {
         int const st = stage_begin(pl, ST_DIAG, stream);
         for (int p = 0; p < pl->n_local; ++p)
             DEV(lsk_diag(pl->dop, pl->cplx, pl->parts[p].count, pl->parts[p].d_reps, d_x[p], d_y[p], stream));
@@ -3591,6 +3615,8 @@ int ls_amd_matvec(ls_amd_plan *pl, void const *const *d_x, void *const *d_y, voi
                           pl->d_chain_cache, pl->chain_v[0], pl->chain_v[1], stream));
         else if (pl->has_pairs)
             DEV(lsk_pairs(pl->pairs, pl->dbs.hamming_weight, pl->cplx, pl->tilemap, ps->count, d_x[0], d_y[0], stream));
+        else if (pl->has_push_staged)
+            DEV(lsk_push_staged(pl->dop, pl->dbs, ps->index, pl->cplx, pl->tilemap, ps->count, ps->d_reps, d_x[0], d_y[0], pl->d_err, stream));
         else
             DEV(lsk_direct(pl->dop, pl->dbs, ps->index, pl->cplx, pl->family == FAMILY_DIRECT_PULL ? (OEXT(pl->op)->is_hermitian ? 1 : 2) : 0, pl->tilemap, ps->d_reps,
                            d_x[0], d_y[0], pl->d_err, stream));

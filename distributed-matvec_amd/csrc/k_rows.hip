@@ -393,6 +393,134 @@ extern "C" int lsk_direct(lsk_operator op, lsk_basis bs, lsk_index ix, int cplx,
 }
 // replicated-x pull: `reps` = the n rows of one partition, `x` = whole vector in global order, `ix` = index
 // of the GLOBAL basis, row_gidx[i] = global index of row i (only read for SEARCH indices)
+// ---------------------------------------------------------------------------------------------
+// Staged PUSH (k_push_t; round 6): the reference's own formulation on one partition -- y[idx(beta)] += c x[i] with f64 atomics -- with
+// the two things the generic row kernel leaves on the table:
+//   * a tile of TILE consecutive rows keeps an LDS copy of y[tile - HALO, tile + TILE + HALO): a contribution whose target lies within
+//     HALO rows of its source (the adjacent pairs at the low sites: |shift| = C(lo, k) <= 462 for lo < 12) is an LDS add, and the window
+//     goes out once, one atomic per touched row, instead of one global atomic per contribution (chain_32: 6 of 16.5 per row);
+//   * the diagonal part goes into the same window (y is cleared by the caller instead of being assigned by k_diag).
+// Everything else is k_direct's push form: exchange runs branch-free with the rank shift C(lo, k) carried along, other groups by a full
+// re-ranking, far targets by global atomics.  Real operators with undirected runs on the full fixed-weight basis (combinadic index),
+// f64 or c128 vectors; LS_AMD_ROW_KERNEL=generic keeps k_direct.
+// ---------------------------------------------------------------------------------------------
+constexpr int kPushHalo = 512;
+template <typename W, bool CPLX, int TILE>
+__global__ __launch_bounds__(kBlock) void k_push_t(lsk_runs runs, int n_groups, lsk_group const *__restrict__ groups,
+                                                   lsk_term const *__restrict__ off, int n_diag, lsk_term const *__restrict__ diag,
+                                                   lsk_basis bs, lsk_index ix, uint64_t const *__restrict__ tilemap, int64_t slots_per_xcd,
+                                                   int64_t n, uint64_t const *__restrict__ reps, double const *__restrict__ x,
+                                                   double *__restrict__ y, int *err) {
+    typedef typename WordTraits<W>::binom_t BT;
+    typedef WordTraits<W> WT;
+    constexpr int HALO = kPushHalo;
+    constexpr int WINDOW = TILE + 2 * HALO;
+    constexpr int NC = CPLX ? 2 : 1;
+    __shared__ BT s_binom[64 * LSK_BINOM_K];
+    __shared__ double s_y[WINDOW * NC];
+    for (int k = threadIdx.x; k < 64 * LSK_BINOM_K; k += kBlock) s_binom[k] = (BT)ix.binom[k];
+    const int xcd = blockIdx.x & 7;
+    const int64_t blocks_per_xcd = gridDim.x >> 3;
+    tilemap += (int64_t)xcd * slots_per_xcd;
+    for (int64_t t = blockIdx.x >> 3; t < slots_per_xcd; t += blocks_per_xcd) {
+        const uint64_t slot = tilemap[t];
+        const int cnt = (int)(slot >> 48);
+        if (cnt == 0) continue; // block-uniform
+        const int64_t i0 = (int64_t)(slot & 0xffffffffffffULL);
+        const int64_t w0 = i0 - HALO;
+        __syncthreads(); // the previous window has gone out (and the binomials are loaded)
+        for (int j = threadIdx.x; j < WINDOW * NC; j += kBlock) s_y[j] = 0.0;
+        __syncthreads();
+#pragma unroll 1
+        for (int sub = 0; sub < TILE / kBlock; ++sub) {
+            const int r = sub * kBlock + threadIdx.x;
+            if (r >= cnt) continue; // (no barrier inside)
+            const int64_t i = i0 + r;
+            const int own = HALO + r;
+            const W a = (W)__builtin_nontemporal_load(reps + i);
+            double xr, xi = 0.0;
+            if (CPLX) { xr = x[2 * i]; xi = x[2 * i + 1]; } else xr = x[i];
+            auto add = [&](int64_t idx, double vr, double vi) { // y[idx] += v: the window when idx lies inside it
+                const int64_t o = idx - w0;
+                if (o >= 0 && o < WINDOW) {
+                    if (CPLX) { atomicAdd(&s_y[2 * o], vr); atomicAdd(&s_y[2 * o + 1], vi); } else atomicAdd(&s_y[o], vr);
+                } else if (CPLX) { atomic_add_f64(y + 2 * idx, vr); atomic_add_f64(y + 2 * idx + 1, vi); }
+                else atomic_add_f64(y + idx, vr);
+            };
+            if (n_diag > 0) {
+                double dr, di;
+                diag_coeff<W, true>(runs, n_diag, diag, a, dr, di);
+                if (CPLX) { atomicAdd(&s_y[2 * own], dr * xr); atomicAdd(&s_y[2 * own + 1], dr * xi); } else atomicAdd(&s_y[own], dr * xr);
+            }
+            // ---- exchange runs: the rank shift C(lo, k) carried along ------------------------------------------------------------
+            const W tdiff = a ^ (a >> 1);
+            for (int q = 0; q < runs.n_runs; ++q) {
+                const int lo0 = runs.lo0[q], rc = runs.cnt[q];
+                const double v = runs.v_re[q];
+                int k = WT::popc(a & (W)(((uint64_t)1 << lo0) - 1));
+#pragma unroll 4
+                for (int lo = lo0; lo < lo0 + rc; ++lo) {
+                    const bool bit = (a >> lo) & 1;
+                    const bool act = (tdiff >> lo) & 1;
+                    const int64_t d = (int64_t)s_binom[lo * LSK_BINOM_K + k];
+                    k += bit ? 1 : 0;
+                    if (act) add(bit ? i + d : i - d, v * xr, v * xi);
+                }
+            }
+            // ---- everything else: generic groups ---------------------------------------------------------------------------------
+            for (int g = runs.n_run_groups; g < n_groups; ++g) {
+                lsk_group const G = groups[g];
+                double cr, ci;
+                group_coeff<true>(G, off, (uint64_t)a, cr, ci);
+                if (cr == 0.0) continue;
+                const W beta = a ^ (W)G.x;
+                int64_t idx;
+                if (G.adj >= 0 && WT::popc(a & (W)G.x) == 1) {
+                    const int k = WT::popc(a & (W)(((uint64_t)1 << G.adj) - 1));
+                    const int64_t d = (int64_t)s_binom[G.adj * LSK_BINOM_K + k];
+                    idx = ((a >> G.adj) & 1) ? i + d : i - d;
+                } else {
+                    if (WT::popc(beta) != bs.hamming_weight) { atomicExch(err, 1); continue; } // DMV:115-118
+                    idx = rank_combinadic_w<W, BT>(beta, s_binom);
+                }
+                add(idx, cr * xr, cr * xi);
+            }
+        }
+        __syncthreads();
+        // the window goes out: one atomic per touched row (the halos overlap the neighbouring tiles' windows and their far targets)
+        for (int j = threadIdx.x; j < WINDOW; j += kBlock) {
+            const int64_t row = w0 + j;
+            if (row < 0 || row >= n) continue;
+            if (CPLX) {
+                const double vr = s_y[2 * j], vi = s_y[2 * j + 1];
+                if (vr != 0.0) atomic_add_f64(y + 2 * row, vr);
+                if (vi != 0.0) atomic_add_f64(y + 2 * row + 1, vi);
+            } else {
+                const double vr = s_y[j];
+                if (vr != 0.0) atomic_add_f64(y + row, vr);
+            }
+        }
+    }
+}
+extern "C" int lsk_push_tile_rows(int cplx) { return cplx ? 512 : 1024; }
+// y must hold zeros (n_diag > 0: the diagonal part is added here) or what the matvec accumulates into (n_diag == 0, DMV:1062-1063)
+extern "C" int lsk_push_staged(lsk_operator op, lsk_basis bs, lsk_index ix, int cplx, lsk_tilemap tm, int64_t n, uint64_t const *reps,
+                               void const *x, void *y, int *d_err, void *stream) {
+    if (n == 0 || tm.slots_per_xcd == 0) return 0;
+    if (!tm.entries || ix.kind != LSK_INDEX_COMBINADIC || bs.proj != LSK_PROJ_NONE || !op.is_real) { snprintf(g_err, sizeof(g_err), "lsk_push_staged: plan out of range"); return -1; }
+    const int64_t gb = tm.slots_per_xcd * 8; // one block per tile
+    dim3 g((unsigned)gb), b(kBlock);
+#define LSK_PT_ARGS op.runs, op.n_groups, op.groups, op.off, op.n_diag, op.diag, bs, ix, tm.entries, tm.slots_per_xcd, n, reps, (double const *)x, (double *)y, d_err
+    if (bs.number_sites <= 32) {
+        if (cplx) hipLaunchKernelGGL((k_push_t<uint32_t, true, 512>), g, b, 0, (hipStream_t)stream, LSK_PT_ARGS);
+        else hipLaunchKernelGGL((k_push_t<uint32_t, false, 1024>), g, b, 0, (hipStream_t)stream, LSK_PT_ARGS);
+    } else if (cplx) hipLaunchKernelGGL((k_push_t<uint64_t, true, 512>), g, b, 0, (hipStream_t)stream, LSK_PT_ARGS);
+    else hipLaunchKernelGGL((k_push_t<uint64_t, false, 1024>), g, b, 0, (hipStream_t)stream, LSK_PT_ARGS);
+#undef LSK_PT_ARGS
+    LSK_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int lsk_direct_gx(lsk_operator op, lsk_basis bs, lsk_index ix, int cplx, lsk_tilemap tm, uint64_t const *reps,
                              int64_t const *row_gidx, void const *x_global, void *y, int *d_err, void *stream) {
     return direct_dispatch(op, bs, ix, cplx, 1, tm, reps, x_global, y, d_err, stream, 1, row_gidx);

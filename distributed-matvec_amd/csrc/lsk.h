@@ -288,6 +288,10 @@ typedef struct lsk_pairplan {
     int n_sites, degree;       /* degree: slots per site, 4 or 8 */
     int n_classes, site_words; /* amplitude classes; 32-bit words of the whole table */
 } lsk_pairplan;
+/* staged push (k_push_t): LDS window of y per tile for near targets + the diagonal part; y cleared by the caller when n_diag > 0 */
+int lsk_push_tile_rows(int cplx);
+int lsk_push_staged(lsk_operator op, lsk_basis bs, lsk_index ix, int cplx, lsk_tilemap tm, int64_t n, uint64_t const *reps,
+                    void const *x, void *y, int *d_err, void *stream);
 int lsk_pairs_tile_rows(int cplx);
 int lsk_pairs(lsk_pairplan pp, int hamming_weight, int cplx, lsk_tilemap tm, int64_t n, void const *x, void *y, void *stream);
 int lsk_narrow_states(int64_t n, uint64_t const *reps, uint32_t *out, void *stream);

@@ -13,7 +13,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-DEVICE_KERNEL = {"staged": "k_chain_t", "indexed": "k_pull_t", "tile-pull": "k_tile_pull<", "direct-push": "k_direct",
+DEVICE_KERNEL = {"push+staged": "k_push_t", "staged": "k_chain_t", "indexed": "k_pull_t", "tile-pull": "k_tile_pull<", "direct-push": "k_direct",
                  "direct-pull": "k_direct", "tile": "k_tile<"}
 SEEN = []  # kernel names the counters were read from
 

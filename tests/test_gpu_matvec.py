@@ -1344,6 +1344,60 @@ def test_pair_kernels_random_graphs(torch, monkeypatch, seed):
     assert seen & {"direct-pull+pairs", "direct-pull+pairrows", "direct-pull+pairsites", "direct-pull"}, seen
 
 
+@pytest.mark.parametrize("case", ["ring-16", "ring-20", "open-18", "j1j2-14", "ring-15-w6", "square-4x4", "ring-40-w3", "xy-only-16", "square-6x6-w3"])
+def test_staged_push_kernel(torch, monkeypatch, case):
+    """k_push_t -- the push form (y[idx(beta)] += c x[i], f64 atomics: the reference's formulation, DMV:73-127) with an LDS window of y
+    per tile for the near targets and the diagonal part -- against the oracle and against the generic push kernel
+    (LS_AMD_ROW_KERNEL=generic); f64 and c128; 4- and 8-byte states; an operator without diagonal terms accumulates into y."""
+    from oracle import c_oracle as CO
+    from oracle import model as M
+
+    if case.startswith(("ring-", "open-", "j1j2-")) and "-w" not in case:
+        kind, L = case.split("-")
+        cfg = _chain_like_config(int(L), kind)
+    elif case == "ring-15-w6":
+        cfg = _ring_config(15, 6)
+    elif case == "ring-40-w3":
+        cfg = _ring_config(40, 3)
+    elif case == "square-4x4":
+        cfg = _lattice_config(16, 8, _square_bonds(4, 4), jz=0.7, jxy=1.3)
+    elif case == "square-6x6-w3":
+        cfg = _lattice_config(36, 3, _square_bonds(6, 6))
+    else:
+        cfg = _lattice_config(16, 8, [(i, (i + 1) % 16) for i in range(16)])
+        cfg["hamiltonian"]["terms"] = [t for t in cfg["hamiltonian"]["terms"] if "ᶻ" not in t["expression"]]
+    o = CO.COracle(M.model_from_config(cfg))
+    want_reps = o.enumerate()
+    rs = np.random.RandomState(11)
+    x = rs.rand(len(want_reps)) - 0.5
+    xc = x + 1j * (rs.rand(len(want_reps)) - 0.5)
+    want, wantc = o.local_matvec(want_reps, x), o.local_matvec(want_reps, xc)
+    results = {}
+    for kernel in ("auto", "generic"):
+        monkeypatch.delenv("LS_AMD_ROW_KERNEL", raising=False)
+        if kernel != "auto":
+            monkeypatch.setenv("LS_AMD_ROW_KERNEL", kernel)
+        D, basis, h, reps, masks = setup_model(torch, cfg, 1)
+        assert np.array_equal(reps[0].cpu().numpy().view(np.uint64), want_reps)
+        got, pl = run_matvec(torch, D, h, reps, masks, x, 1, "push")
+        assert pl.kernel == ("direct-push+staged" if kernel == "auto" else "direct-push"), (case, pl.kernel)
+        assert np.abs(got - want).max() <= 1e-12 * max(1.0, np.abs(want).max()), (case, kernel)
+        gotc, plc = run_matvec(torch, D, h, reps, masks, xc, 1, "push")
+        assert np.abs(gotc - wantc).max() <= 1e-12 * max(1.0, np.abs(wantc).max()), (case, kernel)
+        # the same plan again, into a y that holds something: assigned when the operator has diagonal terms, accumulated into otherwise
+        xd = [torch.from_numpy(x).cuda()]
+        y = [torch.full_like(xd[0], 2.5)]
+        pl2 = D.MatvecPlan(h, reps, torch.float64, mode="push")
+        for _ in range(2):
+            y[0].fill_(2.5)
+            pl2.matvec(xd, y)
+        keep = 2.5 if case == "xy-only-16" else 0.0
+        assert np.abs(y[0].cpu().numpy() - (want + keep)).max() <= 1e-12 * max(1.0, np.abs(want).max()), (case, kernel)
+        pl2.destroy()
+        results[kernel] = got
+    assert np.abs(results["auto"] - results["generic"]).max() <= 1e-13 * max(1.0, np.abs(want).max())
+
+
 def _primme_buffer(n, h):
     import ctypes as C
 
