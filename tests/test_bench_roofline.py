@@ -48,6 +48,15 @@ def test_pull_fractions_cannot_exceed_one_at_the_copy_rate():
     p = _roof(kernel="direct-push", ms=74.0)
     assert p["formulation"].startswith("push") and p["algorithmic_bytes_per_launch"] == N32 * 16 + NNZ32 * 16
     assert 0 < p["frac"] < 1
+    # the staged push kernel (round 6) executes the same formulation: the same bytes, its own PMC entry on its own machine code
+    ps = _roof(kernel="direct-push+staged", ms=41.9)
+    assert ps["formulation"].startswith("push") and "staged" in ps["formulation"] and ps["algorithmic_bytes_per_launch"] == p["algorithmic_bytes_per_launch"]
+    assert 0.49 < ps["frac"] < 0.51
+    with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+        ent = json.load(f)["heisenberg_chain_32/f64/direct-push+staged"]
+    assert ent["device_kernel"] == "k_push_t" and ent["instance"].startswith("k_push_t<")
+    if bench.kernel_instance_sha(ent["instance"]) == ent["instance_isa_sha"]:  # (attached while the kernel is what was measured)
+        assert ps["traffic"] == ent["traffic_bytes"] and ps["wasted_traffic"] < 1.0  # atomics combine: fewer bytes than the formula charges
 
 
 def test_traffic_is_attached_only_to_the_code_it_measured(monkeypatch):
