@@ -358,6 +358,8 @@ static int dist_create_impl(ls_amd_dist **out, ls_amd_comm *cm, ls_hs_operator c
         int64_t const rpr = rows_per_round();
         num_rounds = (int)((mx + rpr - 1) / rpr);
         if (num_rounds < 1) num_rounds = 1;
+        if (P == 1 && !getenv("LS_AMD_ROWS_PER_ROUND")) num_rounds = 1; /* one rank: nothing is sent, nothing to pipeline -- and the one
+                                                                       * round can be the staged push kernel (host.c) */
         if (allow_streams && !getenv("LS_AMD_ROWS_PER_ROUND") && ls_amd_internal_streams_eligible(op, P)) {
             /* sorted streams: every round reads and writes y once and searches every stream once per window, and a window's run of
              * one stream shrinks with the number of rounds -- so FEW rounds: three, which still lets generate(r + 1), the exchange

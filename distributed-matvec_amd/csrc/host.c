@@ -1506,6 +1506,7 @@ struct ls_amd_plan {
     void *d_tilemap;
     int has_pairs; /* staged row kernel for arbitrary exchange pairs (lsk_pairs): non-ring lattices */
     int has_push_staged; /* staged push kernel (lsk_push_staged): LDS window of y per tile; y is cleared, not assigned by k_diag */
+    int one_rank_full_basis; /* FAMILY_TILE with one rank that owns the full fixed-weight basis (plan_setup_part) */
     lsk_pairplan pairs;
     void *d_pair_recs, *d_rank_low, *d_pair_binom, *d_states32, *d_pair_rows, *d_pair_sites;
     int has_chain; /* staged row kernel (lsk_chain) */
@@ -2509,6 +2510,21 @@ static int plan_setup_part(ls_amd_plan *pl, part_state *ps, int part_id, int num
             if (!flag) { ps->index.kind = LSK_INDEX_COMBINADIC; closed_form = 1; }
         }
     }
+    if (pl->P == 1 && pl->family == FAMILY_TILE && pl->dbs.proj == LSK_PROJ_NONE && b->spin_inversion == 0 && h >= 0 &&
+        (uint64_t)ps->count == binom(L, h) && ps->count > 0) {
+        /* ONE rank drives this plan through generate / exchange / scatter (dist.c) and owns the whole basis: every packet is its own.
+         * When the basis is the full fixed-weight set the producer can be the staged push kernel (k_push_t), which scatters them
+         * itself -- verified here, decided at the end of the set-up (ls_amd_plan_create). */
+        int zero = 0, flag = 0;
+        lsk_index cix = ps->index;
+        cix.kind = LSK_INDEX_COMBINADIC;
+        DEV(lsk_h2d(pl->d_err, &zero, sizeof(int)));
+        DEV(lsk_check_combinadic(cix, h, ps->count, ps->d_reps, pl->d_err, stream));
+        DEV(lsk_sync(stream));
+        DEV(lsk_d2h(&flag, pl->d_err, sizeof(int)));
+        DEV(lsk_h2d(pl->d_err, &zero, sizeof(int)));
+        pl->one_rank_full_basis = !flag;
+    }
     if (!closed_form && ps->count > 0) {
         if (build_search_index(ps, L, stream) != 0) return -1;
     }
@@ -2909,6 +2925,13 @@ int ls_amd_plan_create(ls_amd_plan **out, ls_hs_operator const *op, ls_amd_dtype
     }
     if (pl->family == FAMILY_TILE && my_partition < 0 && pl->send_capacity > 0 && !pl->streams) {
         if (lsk_malloc(&pl->d_send, (size_t)pl->send_capacity) != 0) { ls_amd_plan_destroy(pl); return dev_error(); }
+    }
+    if (pl->family == FAMILY_TILE && pl->P == 1 && my_partition >= 0 && pl->one_rank_full_basis && pl->parts[0].rounds == 1 &&
+        push_staged_eligible(pl)) {
+        /* one rank, every packet its own: the producer of the only round is the staged push kernel (round 6: chain_32 through the
+         * C host's packet driver 87.6 -> see profiles/r6_staged_push_ab.txt) */
+        if (build_tilemap(pl, pl->parts[0].count, lsk_push_tile_rows(pl->cplx)) != 0) { ls_amd_plan_destroy(pl); return -1; }
+        pl->has_push_staged = 1;
     }
     if (pl->family == FAMILY_TILE && pl->key_bytes == 8 && pl->P > 1) {
         /* State-carrying packets into a SEARCHED index (projected bases): the consumer's look-up is one 16-byte probe of a static
@@ -3322,7 +3345,7 @@ char const *ls_amd_plan_kernel_name(ls_amd_plan const *pl) {
     case FAMILY_REPL_DIRECT:
         return pl->has_chain ? "replicated-direct-pull+staged" : "replicated-direct-pull";
     case FAMILY_REPL_TILE: return pl->idx_mode ? (pl->slot_cache ? "replicated-tile-pull+indexed+cached" : "replicated-tile-pull+indexed") : "replicated-tile-pull";
-    default: return pl->streams ? "tile+streams" : "tile";
+    default: return pl->streams ? "tile+streams" : (pl->has_push_staged ? "tile(one rank: push+staged)" : "tile");
     }
 }
 /* nominal bytes per packet (a segment of c packets takes ls_amd_plan_segment_bytes(c): pre-indexed keys are padded to 8 bytes) */
@@ -3377,6 +3400,9 @@ static int prescaled_x(ls_amd_plan *pl, int64_t n, uint64_t const *d_reps, void 
 int ls_amd_diag(ls_amd_plan *pl, void const *d_x, void *d_y, void *stream) {
     part_state *ps = &pl->parts[0];
     int const st = stage_begin(pl, ST_DIAG, stream);
+    if (pl->has_push_staged) { /* the staged push kernel adds the diagonal part itself: y is cleared (no diagonal terms: accumulated into) */
+        if (pl->dop.n_diag > 0) DEV(lsk_memset_async(d_y, 0, (size_t)ps->count * (pl->cplx ? 16 : 8), stream));
+    } else
     DEV(lsk_diag(pl->dop, pl->cplx, ps->count, ps->d_reps, d_x, d_y, stream));
     stage_end(pl, st, stream);
     return 0;
@@ -3388,7 +3414,11 @@ static int generate_round(ls_amd_plan *pl, part_state *ps, int pid, int round, v
     if (pl->P > 1 && !ps->d_wtab) DEV(lsk_memset_async(pl->d_cursors, 0, 8 * (size_t)pl->P, stream));
     int const st = stage_begin(pl, ST_GENERATE, stream);
     int slot = timing_begin(pl, stream);
-    if (pl->streams) {
+    if (pl->has_push_staged) { /* (FAMILY_TILE, one rank, one round: every packet is this partition's own) */
+        lsk_index cix = ps->index;
+        cix.kind = LSK_INDEX_COMBINADIC;
+        DEV(lsk_push_staged(pl->dop, pl->dbs, cix, pl->cplx, pl->tilemap, ps->count, ps->d_reps, d_x, d_y, pl->d_err, stream));
+    } else if (pl->streams) {
         uint64_t const *d_binom;
         if (device_binom(&d_binom) != 0) return -1;
         DEV(lsk_tile_st(pl->dop, pl->gd, d_binom, pl->cplx, 0, pl->P, pl->st_S, pl->st_tile_rows, row0, row1, ps->d_reps, d_x,
