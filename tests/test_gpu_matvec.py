@@ -1342,6 +1342,14 @@ def test_pair_kernels_random_graphs(torch, monkeypatch, seed):
         gotc, plc = run_matvec(torch, D, h, reps, masks, xc, 1, "pull")
         assert np.abs(gotc - wantc).max() <= 1e-12 * max(1.0, np.abs(wantc).max()), (kernel, plc.kernel, L, w)
     assert seen & {"direct-pull+pairs", "direct-pull+pairrows", "direct-pull+pairsites", "direct-pull"}, seen
+    # ... and the push form of the same operator: the staged push kernel when the graph has a run of adjacent pairs, k_direct otherwise
+    monkeypatch.delenv("LS_AMD_ROW_KERNEL", raising=False)
+    D, basis, h, reps, masks = setup_model(torch, cfg, 1)
+    gotp, plp = run_matvec(torch, D, h, reps, masks, x, 1, "push")
+    assert plp.kernel in ("direct-push", "direct-push+staged")
+    assert np.abs(gotp - want).max() <= 1e-12 * max(1.0, np.abs(want).max()), (plp.kernel, np.abs(gotp - want).max())
+    gotpc, _ = run_matvec(torch, D, h, reps, masks, xc, 1, "push")
+    assert np.abs(gotpc - wantc).max() <= 1e-12 * max(1.0, np.abs(wantc).max()), plp.kernel
 
 
 @pytest.mark.parametrize("case", ["ring-16", "ring-20", "open-18", "j1j2-14", "ring-15-w6", "square-4x4", "ring-40-w3", "xy-only-16", "square-6x6-w3"])
