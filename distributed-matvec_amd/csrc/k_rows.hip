@@ -549,6 +549,12 @@ constexpr int kChainFar = 12;      // far-pair gathers in flight per row before 
 // W = state word (u32 up to 32 sites, u64 up to 64), R = rank type (u32 while the basis has < 2^32 - 1 states, else u64),
 // CPLX = complex128 vectors (real operator; the window holds double2, gathers are 16 bytes per lane), TILE rows per
 // block iteration (1024 for f64, 512 for c128: 5 blocks per CU).
+__device__ __forceinline__ double cx_load_nt(double const *p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ double2 cx_load_nt(double2 const *p) {
+    typedef double d2v __attribute__((ext_vector_type(2)));
+    const d2v v = __builtin_nontemporal_load(reinterpret_cast<d2v const *>(p));
+    return make_double2(v.x, v.y);
+}
 // Far pairs (>= hb) of a wave-row are priced lane-parallel: lane l looks at pair split + l of the wave-uniform state a0
 // (anti-aligned?, bits below, binomial from LDS, sign), and the loop over the anti-aligned ones only does ballot-mask
 // ctz + v_readlane + add + gather.  (The round-1 kernel did that arithmetic on the scalar unit, ~340 scalar
@@ -584,6 +590,8 @@ __global__ __launch_bounds__(kBlock, (CPLX || sizeof(R) == 8 ? 5 : (sizeof(W) ==
     // profiling builds only (make ablate, LS_AMD_ABLATE & 128): ONE MORE 8-byte stream per row, prefetched like the records -- what a
     // byte per row costs this kernel, i.e. what computing sigma instead of loading it could save at best (scripts/chain_stream_cost.py)
     const bool extra_stream = kAblate && (n_cached & 0x100);
+    // (profiling builds, LS_AMD_ABLATE & 4096 / 8192: the wave-uniform far gathers of pairs >= 20 / of all far pairs as non-temporal loads)
+    const int nt_from = !kAblate ? 99 : ((n_cached & 0x200) ? 20 : ((n_cached & 0x400) ? 0 : 99));
     if (kAblate) n_cached &= 0xff;
     uint64_t ex_next = 0;
     // LDS image made once by the host (chain_lds_image): the binomial table in the rank type, NB rows of kc = weight + 2
@@ -721,7 +729,8 @@ __global__ __launch_bounds__(kBlock, (CPLX || sizeof(R) == 8 ? 5 : (sizeof(W) ==
                         if (m) {
                             const int l = __builtin_ctzll(m);
                             m &= m - 1;
-                            xv[u] = (x + (size_t)(R)(ig0 + readlane_t<R>(off, l)))[dl];
+                            X const *const src = x + (size_t)(R)(ig0 + readlane_t<R>(off, l)) + dl;
+                            if (kAblate && split + l >= nt_from) xv[u] = cx_load_nt(src); else xv[u] = *src;
                         }
                     }
                     lo_end = split;
@@ -961,7 +970,8 @@ static int launch_chain(lsk_operator op, lsk_basis bs, lsk_index ix, lsk_tilemap
     // some overlap the LDS / ALU phases of others.
     hipLaunchKernelGGL((k_chain_t<W, R, CPLX, TILE, REC>), dim3((unsigned)gb), dim3(kBlock), (size_t)img.bytes, (hipStream_t)stream, op.runs,
                        op.n_diag, op.diag, bs.hamming_weight, img.dev, img.bytes / 16, img.kc, img.near_off, tm.entries, tm.slots_per_xcd, n, reps, x, y,
-                       kChainLdsPairs, n_cached | ((kAblate && (bs.debug_ablate & 128)) ? 0x100 : 0), (R const *)cache, cv0, cv1, row0, n_x);
+                       kChainLdsPairs, n_cached | ((kAblate && (bs.debug_ablate & 128)) ? 0x100 : 0) | ((kAblate && (bs.debug_ablate & 4096)) ? 0x200 : 0) |
+                           ((kAblate && (bs.debug_ablate & 8192)) ? 0x400 : 0), (R const *)cache, cv0, cv1, row0, n_x);
     LSK_LAUNCH_CHECK();
     return 0;
 }
